@@ -1,0 +1,200 @@
+/*
+ * emat_backend.h -- C-ABI of the MI355X-native EMAT local-move engine.
+ *
+ * This is the drop-in boundary for Delphy's per-iteration hot path.  The reference has no
+ * FFI for this path; the seam is the C++ class `Subrun` as driven by `Run`
+ * (reference core/subrun.h:16-135, core/run.cpp:110-293,610-693).  Every entry point below
+ * names the reference interaction it replaces.  All functions return an `emat_status`
+ * (0 = OK); nothing throws across the boundary; all pointers are plain host pointers and
+ * the backend copies what it needs (the caller keeps ownership of its buffers).
+ *
+ * Conventions (reference core/tree.h:33-39, core/mutations.h:21-29, core/interval_set.h):
+ *   - nodes are int32 indices local to the subtree, EMAT_NO_NODE = -1;
+ *   - states are 0..3 = A,C,G,T (reference core/sequence.h `Real_seq_letter`);
+ *   - mutations on a branch are sorted by (t, site); the subtree root's "mutations" are
+ *     the deltas ref_sequence -> subroot sequence with t = -DBL_MAX;
+ *   - missation intervals are sorted, disjoint, non-adjacent half-open [start,end).
+ */
+#ifndef EMAT_BACKEND_H_
+#define EMAT_BACKEND_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMAT_NO_NODE (-1)
+
+typedef enum emat_status {
+  EMAT_OK = 0,
+  EMAT_ERR_INVALID_ARGUMENT = 1,
+  EMAT_ERR_NO_DEVICE = 2,        /* HIP device / extension missing: the product path never falls back to CPU */
+  EMAT_ERR_HIP = 3,
+  EMAT_ERR_STATE = 4,            /* call sequence violated (e.g. run before upload) */
+  EMAT_ERR_CAPACITY = 5,         /* a part ran out of slab space; see emat_part_get_status */
+  EMAT_ERR_INTERNAL = 6,
+  EMAT_ERR_BUFFER_TOO_SMALL = 7
+} emat_status;
+
+/* Flat (struct-of-arrays, CSR) image of one `Phylo_tree` (reference core/phylo_tree.h:14-64).
+ * Used in both directions.  For downloads the caller provides the arrays and their capacities. */
+typedef struct emat_flat_tree {
+  int32_t num_nodes;
+  int32_t root;
+  int32_t* parent;       /* [num_nodes] */
+  int32_t* child0;       /* [num_nodes], EMAT_NO_NODE for tips */
+  int32_t* child1;       /* [num_nodes] */
+  double*  t;            /* [num_nodes] */
+  float*   t_min;        /* [num_nodes] tips: date bounds; inner nodes -FLT_MAX */
+  float*   t_max;        /* [num_nodes] tips: date bounds; inner nodes +FLT_MAX */
+  /* mutations, CSR by node */
+  int32_t* mut_offset;   /* [num_nodes+1] */
+  int32_t* mut_site;     /* [num_muts] */
+  uint8_t* mut_from;     /* [num_muts] */
+  uint8_t* mut_to;       /* [num_muts] */
+  double*  mut_t;        /* [num_muts] */
+  /* missation intervals, CSR by node */
+  int32_t* miss_offset;  /* [num_nodes+1] */
+  int32_t* miss_start;   /* [num_intervals] */
+  int32_t* miss_end;     /* [num_intervals] */
+  /* missation from_states (only sites whose state != ref_sequence), CSR by node */
+  int32_t* mfs_offset;   /* [num_nodes+1] */
+  int32_t* mfs_site;     /* [num_from_states] */
+  uint8_t* mfs_state;    /* [num_from_states] */
+  /* capacities of the variable-length arrays (used by downloads only) */
+  int32_t cap_muts;
+  int32_t cap_intervals;
+  int32_t cap_from_states;
+} emat_flat_tree;
+
+/* Population model descriptor (reference core/pop_model.h:12-241). */
+typedef enum emat_pop_model_kind {
+  EMAT_POP_CONST = 0,            /* Const_pop_model{pop}                                  p[0]=pop */
+  EMAT_POP_EXP = 1,              /* Exp_pop_model{t0, pop_at_t0, growth_rate, min_pop}    p[0..3]  */
+  EMAT_POP_SKYGRID = 2           /* Skygrid_pop_model{x[], gamma[], type}                          */
+} emat_pop_model_kind;
+
+typedef struct emat_pop_model {
+  int32_t kind;
+  double  p[4];
+  int32_t skygrid_type;          /* 1 = staircase, 2 = log-linear (reference pop_model.h:149-185) */
+  int32_t skygrid_num_knots;     /* M+1 */
+  const double* skygrid_x;       /* [num_knots] strictly increasing */
+  const double* skygrid_gamma;   /* [num_knots] log N at knots */
+} emat_pop_model;
+
+typedef struct emat_config {
+  int32_t device;                /* HIP device ordinal */
+  int32_t num_sites;             /* L */
+  int32_t max_parts;             /* upper bound on parts resident at once (0 = grow on demand) */
+  double  slab_slack;            /* >=1: per-part working-set capacity as a multiple of its content (0 = default 3.0) */
+  int32_t trace_moves;           /* >0: record the first N moves of every part in a trace ring (tests) */
+  int32_t use_lds;               /* 1 = stage part working sets in LDS when they fit (default), 0 = always HBM */
+} emat_config;
+
+typedef struct emat_backend emat_backend;
+
+/* ---- life cycle ------------------------------------------------------------------------- */
+/* replaces: Subrun construction/destruction as a set (reference run.cpp:131,182-183) */
+emat_status emat_backend_create(const emat_config* cfg, emat_backend** out);
+emat_status emat_backend_destroy(emat_backend* h);
+const char* emat_last_error(const emat_backend* h);   /* human-readable text for the last failure */
+
+/* ---- shared, read-only inputs ----------------------------------------------------------- */
+/* replaces: `subtree.ref_sequence = ref_seq` (reference run.cpp:139-140) */
+emat_status emat_set_ref_sequence(emat_backend* h, const uint8_t* ref_sequence, int32_t num_sites);
+
+/* replaces: Subrun::set_evo (reference subrun.h:29-30; evo_model.h:20-48).  q is row-major
+ * q[beta][a][b] with q[a][a] = -sum_{b!=a} q[a][b].  Invalidates derived quantities. */
+emat_status emat_set_evo(emat_backend* h, int32_t num_partitions, const double* mu /*[P]*/,
+                         const double* pi /*[P][4]*/, const double* q /*[P][4][4]*/,
+                         const double* nu_l /*[L]*/, const int32_t* partition_for_site /*[L]*/);
+
+/* replaces: set_t_max_tip / set_only_displacing_inner_nodes / set_topology_moves_enabled
+ * (reference subrun.h:24-40; pushed in run.cpp:267-275) */
+emat_status emat_set_flags(emat_backend* h, double t_max_tip, int32_t only_displacing_inner_nodes,
+                           int32_t topology_moves_enabled);
+
+/* ---- parts ------------------------------------------------------------------------------ */
+/* replaces: the loop that builds one Subrun per partition part (reference run.cpp:131-184).
+ * Discards all resident parts, then expects exactly `num_parts` emat_part_upload calls
+ * followed by emat_end_upload. */
+emat_status emat_begin_upload(emat_backend* h, int32_t num_parts);
+/* replaces: Subrun(bitgen, tree, includes_run_root, evo) (reference subrun.cpp:10-15).  `seed`
+ * keys the part's counter-based RNG stream (the reference seeds one std::mt19937 per part,
+ * run.cpp:112-114). */
+emat_status emat_part_upload(emat_backend* h, int32_t part_id, const emat_flat_tree* subtree,
+                             int32_t includes_run_root, uint64_t seed);
+emat_status emat_end_upload(emat_backend* h);
+
+/* replaces: Run::reset_very_scalable_coalescent_parts -> make_very_scalable_coalescent_prior_parts
+ * + Subrun::set_coalescent_prior_part (reference run.cpp:277-293; very_scalable_coalescent.cpp:85-232).
+ * Builds every part's k_bar_p / k_twiddle_bar_p and the shared k_twiddle_bar, popsize_bar,
+ * num_active_parts from the resident subtrees.  Invalidates derived quantities. */
+emat_status emat_build_coalescent_parts(emat_backend* h, const emat_pop_model* pop_model,
+                                        int32_t root_part_index, double t_step);
+
+/* ---- the hot path ----------------------------------------------------------------------- */
+/* replaces: Run::run_local_moves(count) (reference run.cpp:682-693): `count / num_parts` calls of
+ * Subrun::mcmc_sub_iteration() on every part, the remainder going to part 0.  Asynchronous with
+ * respect to the host; emat_synchronize (or any getter) waits. */
+emat_status emat_run_local_moves(emat_backend* h, int64_t count);
+/* Same, with an explicit number of moves per part (all parts the same). */
+emat_status emat_run_moves_per_part(emat_backend* h, int64_t moves_per_part);
+emat_status emat_synchronize(emat_backend* h);
+
+/* Forces the from-scratch recomputation that Subrun::validate_derived_quantities() performs
+ * after set_evo / set_coalescent_prior_part (reference subrun.cpp:17-26).  Called implicitly
+ * by the run functions when the derived quantities are stale. */
+emat_status emat_recalc_derived(emat_backend* h);
+
+/* ---- results ---------------------------------------------------------------------------- */
+/* replaces: sum of subrun.log_G() / subrun.log_augmented_coalescent_prior()
+ * (reference run.cpp:340-348) */
+emat_status emat_get_totals(emat_backend* h, double* log_G, double* log_augmented_coalescent_prior);
+
+/* Sizes needed to download a part (so that the caller can size an emat_flat_tree). */
+emat_status emat_part_get_sizes(emat_backend* h, int32_t part_id, int32_t* num_nodes,
+                                int32_t* num_muts, int32_t* num_intervals, int32_t* num_from_states);
+/* replaces: reading subrun.tree() in Run::reassemble (reference run.cpp:200-250) */
+emat_status emat_part_download(emat_backend* h, int32_t part_id, emat_flat_tree* out);
+
+/* replaces: subrun.lambda_i(), num_sites_missing_at_every_node(), log_G(),
+ * log_augmented_coalescent_prior() (reference subrun.h:43-55).  Any pointer may be NULL. */
+emat_status emat_part_get_derived(emat_backend* h, int32_t part_id, double* lambda_i /*[num_nodes]*/,
+                                  int32_t* num_sites_missing /*[num_nodes]*/, double* log_G,
+                                  double* log_augmented_coalescent_prior);
+
+/* Coalescent-part arrays of one part (reference very_scalable_coalescent.h:47-56), for the
+ * cross-part exchange and for tests.  `*num_cells` is in/out (capacity in, length out). */
+emat_status emat_part_get_coalescent(emat_backend* h, int32_t part_id, int32_t* num_cells,
+                                     double* k_bar_p, double* k_twiddle_bar_p, double* k_twiddle_bar,
+                                     double* popsize_bar, int32_t* num_active_parts,
+                                     double* t_ref, double* t_step);
+
+/* Per-part status and move counters. */
+typedef struct emat_part_stats {
+  int32_t status;                /* 0 = OK; otherwise an emat_status raised inside the kernel */
+  int32_t num_nodes;
+  int64_t moves_done;
+  int64_t proposed[5];           /* inner_displace, tip_displace, branch_reform, subtree_slide, spr1 */
+  int64_t accepted[5];
+  int64_t algorithmic_bytes;     /* bytes the moves touched, counted with SURVEY section 8(d)'s per-record sizes */
+  int64_t rng_draws;
+} emat_part_stats;
+emat_status emat_part_get_stats(emat_backend* h, int32_t part_id, emat_part_stats* out);
+
+/* Trace of the first `cfg.trace_moves` moves of a part (tests): 4 doubles per move =
+ * {move kind (0..4, -1 = no-op), node X, accepted (0/1), log_mh (NaN when the move exited early)}. */
+emat_status emat_part_get_trace(emat_backend* h, int32_t part_id, int32_t* num_moves /*in/out*/,
+                                double* trace /*[4*num_moves]*/);
+
+/* Duration of the last emat_run_* launch measured with HIP events on the engine's own stream
+ * (milliseconds), and the kernel's name for cross-checking against rocprofv3. */
+emat_status emat_last_run_ms(emat_backend* h, double* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMAT_BACKEND_H_ */

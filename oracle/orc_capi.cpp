@@ -1,0 +1,260 @@
+// orc_capi.cpp -- CPU ORACLE (test infrastructure, NOT product code).
+// C entry points over the oracle, shaped like include/emat_backend.h (prefix orc_ instead of
+// emat_) so that tests/ can run the same scenario through both and compare.  Also used by
+// bench.py's cpu_baseline leg (kind = "port").
+#include <cstring>
+#include <thread>
+
+#include "../include/emat_backend.h"
+#include "orc_subrun.hpp"
+
+using namespace orc;
+
+namespace {
+
+Phylo_tree tree_from_flat(const emat_flat_tree& v, const std::vector<State>& ref) {
+  Phylo_tree t(v.num_nodes);
+  t.root = v.root;
+  t.ref_sequence = ref;
+  for (int i = 0; i < v.num_nodes; ++i) {
+    auto& nd = t.at(i);
+    nd.parent = v.parent[i]; nd.children[0] = v.child0[i]; nd.children[1] = v.child1[i];
+    nd.t = v.t[i]; nd.t_min = v.t_min[i]; nd.t_max = v.t_max[i];
+    for (int k = v.mut_offset[i]; k < v.mut_offset[i + 1]; ++k) nd.mutations.push_back(Mutation{v.mut_from[k], v.mut_site[k], v.mut_to[k], v.mut_t[k]});
+    for (int k = v.miss_offset[i]; k < v.miss_offset[i + 1]; ++k) nd.missations.intervals.v.push_back({v.miss_start[k], v.miss_end[k]});
+    for (int k = v.mfs_offset[i]; k < v.mfs_offset[i + 1]; ++k) nd.missations.from_states[v.mfs_site[k]] = v.mfs_state[k];
+  }
+  return t;
+}
+
+struct Part {
+  Rng rng;
+  std::unique_ptr<Subrun> subrun;
+};
+
+struct Engine {
+  int L = 0;
+  std::vector<State> ref;
+  Global_evo_model evo;
+  double t_max_tip = 0.0;
+  bool only_displacing_inner_nodes = false, topology_moves_enabled = true;
+  std::vector<std::unique_ptr<Part>> parts;
+  std::vector<Very_scalable_coalescent_prior_part> coal_parts;
+  std::shared_ptr<const Pop_model> pop_model;
+  int trace_moves = 0;
+  std::string last_error;
+};
+
+std::shared_ptr<const Pop_model> make_pop_model(const emat_pop_model& pm) {
+  switch (pm.kind) {
+    case EMAT_POP_CONST: return std::make_shared<Const_pop_model>(pm.p[0]);
+    case EMAT_POP_EXP: return std::make_shared<Exp_pop_model>(pm.p[0], pm.p[1], pm.p[2], pm.p[3]);
+    case EMAT_POP_SKYGRID:
+      return std::make_shared<Skygrid_pop_model>(
+          std::vector<double>(pm.skygrid_x, pm.skygrid_x + pm.skygrid_num_knots),
+          std::vector<double>(pm.skygrid_gamma, pm.skygrid_gamma + pm.skygrid_num_knots),
+          (Skygrid_pop_model::Type)pm.skygrid_type);
+  }
+  throw std::invalid_argument("bad pop model kind");
+}
+
+}  // namespace
+
+#define ORC_TRY try {
+#define ORC_CATCH } catch (const std::exception& ex) { e->last_error = ex.what(); return EMAT_ERR_INTERNAL; } return EMAT_OK;
+
+extern "C" {
+
+typedef struct Engine orc_engine;
+
+int orc_create(int num_sites, int trace_moves, orc_engine** out) {
+  auto* e = new Engine; e->L = num_sites; e->trace_moves = trace_moves; *out = e; return EMAT_OK;
+}
+int orc_destroy(orc_engine* e) { delete e; return EMAT_OK; }
+const char* orc_last_error(orc_engine* e) { return e->last_error.c_str(); }
+
+int orc_set_ref_sequence(orc_engine* e, const uint8_t* ref, int num_sites) {
+  ORC_TRY
+  ORC_CHECK(num_sites == e->L);
+  e->ref.assign(ref, ref + num_sites);
+  ORC_CATCH
+}
+int orc_set_evo(orc_engine* e, int P, const double* mu, const double* pi, const double* q, const double* nu_l, const int* partition_for_site) {
+  ORC_TRY
+  Global_evo_model g;
+  g.partition_for_site.assign(partition_for_site, partition_for_site + e->L);
+  g.nu_l.assign(nu_l, nu_l + e->L);
+  g.partition_evo_model.resize(P);
+  for (int p = 0; p < P; ++p) {
+    g.partition_evo_model[p].mu = mu[p];
+    for (int a = 0; a < 4; ++a) { g.partition_evo_model[p].pi_a[a] = pi[4 * p + a]; for (int b = 0; b < 4; ++b) g.partition_evo_model[p].q_ab[a][b] = q[16 * p + 4 * a + b]; }
+  }
+  e->evo = g;
+  for (auto& pt : e->parts) if (pt && pt->subrun) pt->subrun->set_evo(e->evo);
+  ORC_CATCH
+}
+int orc_set_flags(orc_engine* e, double t_max_tip, int only_displacing_inner_nodes, int topology_moves_enabled) {
+  e->t_max_tip = t_max_tip; e->only_displacing_inner_nodes = only_displacing_inner_nodes != 0; e->topology_moves_enabled = topology_moves_enabled != 0;
+  for (auto& pt : e->parts) if (pt && pt->subrun) {
+    pt->subrun->t_max_tip = t_max_tip; pt->subrun->only_displacing_inner_nodes = e->only_displacing_inner_nodes; pt->subrun->topology_moves_enabled = e->topology_moves_enabled;
+  }
+  return EMAT_OK;
+}
+int orc_begin_upload(orc_engine* e, int num_parts) {
+  e->coal_parts.clear(); e->parts.clear(); e->parts.resize(num_parts); return EMAT_OK;
+}
+int orc_part_upload(orc_engine* e, int part_id, const emat_flat_tree* subtree, int includes_run_root, uint64_t seed) {
+  ORC_TRY
+  auto pt = std::make_unique<Part>();
+  pt->rng.key = seed; pt->rng.counter = 0;
+  pt->subrun = std::make_unique<Subrun>(pt->rng, tree_from_flat(*subtree, e->ref), includes_run_root != 0, e->evo);
+  pt->subrun->t_max_tip = e->t_max_tip;
+  pt->subrun->only_displacing_inner_nodes = e->only_displacing_inner_nodes;
+  pt->subrun->topology_moves_enabled = e->topology_moves_enabled;
+  pt->subrun->trace_capacity = e->trace_moves;
+  e->parts.at(part_id) = std::move(pt);
+  ORC_CATCH
+}
+int orc_end_upload(orc_engine*) { return EMAT_OK; }
+
+int orc_build_coalescent_parts(orc_engine* e, const emat_pop_model* pm, int root_part_index, double t_step) {
+  ORC_TRY
+  e->pop_model = make_pop_model(*pm);
+  std::vector<const Phylo_tree*> subtrees; std::vector<Rng*> prngs;
+  for (auto& pt : e->parts) { subtrees.push_back(&pt->subrun->tree); prngs.push_back(&pt->rng); }
+  e->coal_parts = make_very_scalable_coalescent_prior_parts(subtrees, root_part_index, e->pop_model, prngs, t_step);
+  for (size_t i = 0; i < e->parts.size(); ++i) e->parts[i]->subrun->set_coalescent_prior_part(&e->coal_parts[i]);
+  ORC_CATCH
+}
+
+int orc_recalc_derived(orc_engine* e) {
+  ORC_TRY
+  for (auto& pt : e->parts) { pt->subrun->invalidate_derived_quantities(); pt->subrun->validate_derived_quantities(); }
+  ORC_CATCH
+}
+
+// moves_per_part[i] moves on part i, spread over `num_threads` host threads (parts are independent,
+// reference run.cpp:682-693).  `paranoid` != 0 re-derives everything after every move
+// (Subrun::check_derived_quantities + assert_phylo_tree_integrity, subrun.cpp:28-56,120).
+int orc_run_moves(orc_engine* e, const int64_t* moves_per_part, int num_threads, int paranoid) {
+  ORC_TRY
+  int P = (int)e->parts.size();
+  if (num_threads < 1) num_threads = 1;
+  std::vector<std::string> errors(num_threads);
+  auto work = [&](int tid) {
+    try {
+      for (int p = tid; p < P; p += num_threads) {
+        auto& sr = *e->parts[p]->subrun;
+        for (int64_t i = 0; i < moves_per_part[p]; ++i) {
+          sr.mcmc_sub_iteration();
+          if (paranoid) {
+            auto msg = check_phylo_tree_integrity(sr.tree);
+            if (msg.empty()) msg = sr.check_derived_quantities();
+            if (!msg.empty()) throw std::runtime_error("part " + std::to_string(p) + " move " + std::to_string(i) + ": " + msg);
+          }
+        }
+      }
+    } catch (const std::exception& ex) { errors[tid] = ex.what(); }
+  };
+  if (num_threads == 1) work(0);
+  else { std::vector<std::thread> th; for (int t = 0; t < num_threads; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+  for (auto& s : errors) if (!s.empty()) throw std::runtime_error(s);
+  ORC_CATCH
+}
+
+int orc_get_totals(orc_engine* e, double* log_G, double* log_aug) {
+  ORC_TRY
+  double g = 0.0, a = 0.0;
+  for (auto& pt : e->parts) { pt->subrun->validate_derived_quantities(); g += pt->subrun->log_G; a += pt->subrun->log_augmented_coalescent_prior; }
+  if (log_G) *log_G = g; if (log_aug) *log_aug = a;
+  ORC_CATCH
+}
+
+int orc_part_get_sizes(orc_engine* e, int part_id, int* num_nodes, int* num_muts, int* num_intervals, int* num_from_states) {
+  auto& t = e->parts.at(part_id)->subrun->tree;
+  int nm = 0, ni = 0, nf = 0;
+  for (int i = 0; i < t.size(); ++i) { nm += (int)t.at(i).mutations.size(); ni += t.at(i).missations.num_intervals(); nf += (int)t.at(i).missations.from_states.size(); }
+  *num_nodes = t.size(); *num_muts = nm; *num_intervals = ni; *num_from_states = nf;
+  return EMAT_OK;
+}
+int orc_part_download(orc_engine* e, int part_id, emat_flat_tree* out) {
+  ORC_TRY
+  auto& t = e->parts.at(part_id)->subrun->tree;
+  ORC_CHECK(out->num_nodes == t.size());
+  out->root = t.root;
+  int km = 0, ki = 0, kf = 0;
+  out->mut_offset[0] = out->miss_offset[0] = out->mfs_offset[0] = 0;
+  for (int i = 0; i < t.size(); ++i) {
+    auto& nd = t.at(i);
+    out->parent[i] = nd.parent; out->child0[i] = nd.children[0]; out->child1[i] = nd.children[1];
+    out->t[i] = nd.t; out->t_min[i] = nd.t_min; out->t_max[i] = nd.t_max;
+    for (auto& m : nd.mutations) { ORC_CHECK(km < out->cap_muts); out->mut_site[km] = m.site; out->mut_from[km] = m.from; out->mut_to[km] = m.to; out->mut_t[km] = m.t; ++km; }
+    for (auto& [s, en] : nd.missations.intervals.v) { ORC_CHECK(ki < out->cap_intervals); out->miss_start[ki] = s; out->miss_end[ki] = en; ++ki; }
+    for (auto& [l, s] : nd.missations.from_states) { ORC_CHECK(kf < out->cap_from_states); out->mfs_site[kf] = l; out->mfs_state[kf] = s; ++kf; }
+    out->mut_offset[i + 1] = km; out->miss_offset[i + 1] = ki; out->mfs_offset[i + 1] = kf;
+  }
+  ORC_CATCH
+}
+int orc_part_get_derived(orc_engine* e, int part_id, double* lambda_i, int* num_missing, double* log_G, double* log_aug) {
+  ORC_TRY
+  auto& sr = *e->parts.at(part_id)->subrun;
+  sr.validate_derived_quantities();
+  if (lambda_i) std::copy(sr.lambda_i.begin(), sr.lambda_i.end(), lambda_i);
+  if (num_missing) std::copy(sr.num_sites_missing.begin(), sr.num_sites_missing.end(), num_missing);
+  if (log_G) *log_G = sr.log_G;
+  if (log_aug) *log_aug = sr.log_augmented_coalescent_prior;
+  ORC_CATCH
+}
+int orc_part_get_coalescent(orc_engine* e, int part_id, int* num_cells, double* k_bar_p, double* k_tw_p, double* k_tw,
+                            double* popsize_bar, int* num_active, double* t_ref, double* t_step) {
+  ORC_TRY
+  auto& cp = e->coal_parts.at(part_id);
+  int n = (int)cp.k_bar_p.size();
+  ORC_CHECK(*num_cells >= n);
+  *num_cells = n;
+  for (int i = 0; i < n; ++i) {
+    if (k_bar_p) k_bar_p[i] = cp.k_bar_p[i];
+    if (k_tw_p) k_tw_p[i] = cp.k_twiddle_bar_p[i];
+    if (k_tw) k_tw[i] = cp.k_twiddle_bar[i];
+    if (popsize_bar) popsize_bar[i] = cp.popsize_bar[i];
+    if (num_active) num_active[i] = cp.num_active_parts[i];
+  }
+  if (t_ref) *t_ref = cp.t_ref;
+  if (t_step) *t_step = cp.t_step;
+  ORC_CATCH
+}
+int orc_part_get_stats(orc_engine* e, int part_id, emat_part_stats* out) {
+  auto& pt = *e->parts.at(part_id);
+  std::memset(out, 0, sizeof *out);
+  out->num_nodes = pt.subrun->tree.size();
+  out->moves_done = pt.subrun->moves_done;
+  for (int k = 0; k < 5; ++k) { out->proposed[k] = pt.subrun->proposed[k]; out->accepted[k] = pt.subrun->accepted[k]; }
+  out->rng_draws = (int64_t)pt.rng.counter;
+  return EMAT_OK;
+}
+int orc_part_get_trace(orc_engine* e, int part_id, int* num_moves, double* trace) {
+  auto& tr = e->parts.at(part_id)->subrun->trace;
+  int n = std::min<int>(*num_moves, (int)tr.size());
+  for (int i = 0; i < n; ++i) { trace[4 * i] = tr[i].kind; trace[4 * i + 1] = tr[i].node; trace[4 * i + 2] = tr[i].accepted; trace[4 * i + 3] = tr[i].log_mh; }
+  *num_moves = n;
+  return EMAT_OK;
+}
+// Returns 0 and an empty message when the part passes the reference's debug invariants.
+int orc_part_check(orc_engine* e, int part_id, char* msg, int msg_cap) {
+  auto& sr = *e->parts.at(part_id)->subrun;
+  std::string m;
+  try { m = check_phylo_tree_integrity(sr.tree); if (m.empty()) { sr.validate_derived_quantities(); m = sr.check_derived_quantities(); } }
+  catch (const std::exception& ex) { m = ex.what(); }
+  std::snprintf(msg, msg_cap, "%s", m.c_str());
+  return m.empty() ? 0 : 1;
+}
+
+// scalar helpers exposed for golden-vector tests
+double orc_gamma_q(double a, double x) { return gamma_q(a, x); }
+double orc_gamma_q_inv(double a, double q) { return safe_gamma_q_inv(a, q); }
+double orc_pop_at_time(const emat_pop_model* pm, double t) { return make_pop_model(*pm)->pop_at_time(t); }
+double orc_pop_integral(const emat_pop_model* pm, double a, double b) { return make_pop_model(*pm)->pop_integral(a, b); }
+double orc_intensity_integral(const emat_pop_model* pm, double a, double b) { return make_pop_model(*pm)->intensity_integral(a, b); }
+void orc_rng_block(uint64_t key, uint64_t counter, uint32_t out[4]) { Rng::philox4x32_10(counter, key, out); }
+
+}  // extern "C"
