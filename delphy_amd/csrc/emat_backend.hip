@@ -1,0 +1,711 @@
+// emat_backend.hip -- HIP kernels and the C-ABI of the MI355X-native EMAT local-move engine.
+//
+// Boundary: include/emat_backend.h (each entry point cites the reference call it replaces).
+// Execution model: one 64-lane wavefront (= one workgroup) per partition part.  A part's working set
+// is one slab (emat_slab.hpp); `k_run_moves` streams it into LDS when it fits, runs the requested
+// number of `Subrun::mcmc_sub_iteration` steps (reference core/subrun.cpp:98-121) there, and streams it
+// back.  `k_recalc_derived` is the whole-part recomputation of reference core/subrun.cpp:17-26.
+// There is no CPU fallback: without a HIP device every entry point fails with EMAT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/emat_backend.h"
+#include "emat_device_moves.hpp"
+#include "emat_host_model.hpp"
+#include "flat_tree.hpp"
+
+namespace emat {
+
+// =================================================================================================
+// Kernels
+// =================================================================================================
+struct KernelArgs {
+  uint8_t* slabs;                 // all slabs, back to back
+  const uint64_t* slab_off;       // [num_parts] byte offset of each part's slab
+  const int32_t* order;           // [num_parts] launch order -> part id (largest parts first)
+  const int32_t* ref_freqs;       // [P][4]
+  EvoTable evo;
+  const PopTable* pop;
+  RunFlags flags;
+  int32_t num_parts;
+  uint32_t lds_slab_bytes;        // capacity of the LDS staging area (0 = never stage)
+  int64_t moves_per_part;
+  int64_t extra_moves_part0;      // remainder of Run::run_local_moves goes to part 0 (run.cpp:683-689)
+};
+
+constexpr int k_wave = 64;
+constexpr uint32_t k_lds_tables_bytes = k_max_lds_partitions * (1 + 4 + 16) * 8;   // mu, pi, q per site partition
+
+__device__ inline void wave_copy16(uint8_t* dst, const uint8_t* src, uint32_t bytes, int lane) {
+  const uint4* s = (const uint4*)src; uint4* d = (uint4*)dst;
+  for (uint32_t i = lane; i < bytes / 16; i += k_wave) d[i] = s[i];
+}
+__device__ inline double wave_sum(double x) {
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, k_wave);
+  return __shfl(x, 0, k_wave);
+}
+
+// Fills the model pointers of a context; HKY tables come from LDS when they were staged.
+__device__ inline void init_ctx(dev::Ctx& c, uint8_t* slab, const KernelArgs& a, const double* lds_tables) {
+  c.S = slab; c.H = (SlabHeader*)slab; c.N = (NodeRec*)(slab + c.H->off_nodes);
+  c.L = a.evo.num_sites; c.ref = a.evo.ref_sequence; c.part = a.evo.partition_for_site; c.nu = a.evo.nu_l; c.cumQ = a.evo.cum_Q_l;
+  if (lds_tables) { c.mu = lds_tables; c.pi = lds_tables + k_max_lds_partitions; c.q = lds_tables + k_max_lds_partitions * 5; }
+  else { c.mu = a.evo.mu; c.pi = a.evo.pi; c.q = a.evo.q; }
+  c.pop = a.pop;
+  c.t_max_tip = a.flags.t_max_tip;
+  c.only_displacing_inner_nodes = a.flags.only_displacing_inner_nodes != 0;
+  c.topology_moves_enabled = a.flags.topology_moves_enabled != 0;
+  c.includes_run_root = (c.H->flags & k_flag_includes_run_root) != 0;
+  c.rng_key = c.H->rng_key; c.rng_ctr = c.H->rng_counter;
+  c.mu_prop = 0.0; c.sc_top = c.H->scratch_begin; c.failed = false; c.bytes = 0;
+  c.tr_kind = -1.0; c.tr_node = -1.0; c.tr_acc = 0.0; c.tr_log_mh = 0.0;
+}
+__device__ inline const double* stage_tables(const KernelArgs& a, double* lds_tables, int lane) {
+  if (a.evo.num_partitions > k_max_lds_partitions) return nullptr;
+  const int P = a.evo.num_partitions;
+  for (int i = lane; i < P; i += k_wave) lds_tables[i] = a.evo.mu[i];
+  for (int i = lane; i < P * 4; i += k_wave) lds_tables[k_max_lds_partitions + i] = a.evo.pi[i];
+  for (int i = lane; i < P * 16; i += k_wave) lds_tables[k_max_lds_partitions * 5 + i] = a.evo.q[i];
+  return lds_tables;
+}
+
+// ---- the hot path: `moves` sub-iterations on every part -------------------------------------------------
+__global__ void __launch_bounds__(k_wave) k_run_moves(KernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int lane = threadIdx.x;
+  const int part = a.order[blockIdx.x];
+  uint8_t* gslab = a.slabs + a.slab_off[part];
+  SlabHeader* gh = (SlabHeader*)gslab;
+  double* lds_tables = (double*)lds;
+  uint8_t* lds_slab = lds + k_lds_tables_bytes;
+  const double* tables = stage_tables(a, lds_tables, lane);
+  const uint32_t slab_bytes = gh->slab_bytes;
+  const bool use_lds = a.lds_slab_bytes != 0 && slab_bytes <= a.lds_slab_bytes;
+  uint8_t* slab = gslab;
+  if (use_lds) {
+    wave_copy16(lds_slab, gslab, gh->heap_top, lane);   // header, nodes, cells, trace, live heap; scratch is not copied
+    slab = lds_slab;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    dev::Ctx c;
+    init_ctx(c, slab, a, tables);
+    int64_t moves = a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0);
+    if (c.H->status == 0) {
+      for (int64_t i = 0; i < moves; ++i) if (!dev::mcmc_sub_iteration(c)) break;
+    }
+    c.H->rng_counter = c.rng_ctr;
+    c.H->alg_bytes += c.bytes;
+  }
+  __syncthreads();
+  if (use_lds) wave_copy16(gslab, lds_slab, ((SlabHeader*)lds_slab)->heap_top, lane);
+}
+
+// ---- whole-part derived quantities (Subrun::recalc_derived_quantities, subrun.cpp:17-26) ---------------------
+// Lanes stride over the part's nodes: branch-local work (delta lambda across the branch, missing-site count,
+// branch log-G, log N(t)) is embarrassingly parallel; only the pre-order accumulation of lambda_i /
+// n_missing down the tree is a dependent chain, walked by lane 0 without a stack.
+__global__ void __launch_bounds__(k_wave) k_recalc_derived(KernelArgs a) {
+  __shared__ __attribute__((aligned(16))) double lds_tables[k_lds_tables_bytes / 8];
+  const int lane = threadIdx.x;
+  const int part = a.order[blockIdx.x];
+  uint8_t* slab = a.slabs + a.slab_off[part];
+  const double* tables = stage_tables(a, lds_tables, lane);
+  __syncthreads();
+  dev::Ctx c;
+  init_ctx(c, slab, a, tables);
+  const int n = c.H->n_nodes, root = c.H->root;
+  // phase A: per-branch deltas
+  for (int i = lane; i < n; i += k_wave) {
+    c.N[i].lambda = dev::delta_lambda_across_branch(c, i);
+    c.N[i].n_missing = dev::iv_num_sites(dev::miss_of(c, i), (int)c.N[i].miss.cnt);
+  }
+  __syncthreads();
+  // phase B: pre-order prefix (phylo_tree_calc.cpp:420-436, :67-76)
+  if (lane == 0) {
+    int cur = root;
+    c.N[root].lambda = c.cumQ[c.L] + c.N[root].lambda;
+    while (cur != dev::k_no_node) {
+      if (!dev::is_tip(c, cur)) {
+        for (int k = 0; k < 2; ++k) {
+          int ch = k == 0 ? c.N[cur].child0 : c.N[cur].child1;
+          c.N[ch].lambda = c.N[cur].lambda + c.N[ch].lambda;
+          c.N[ch].n_missing = c.N[cur].n_missing + c.N[ch].n_missing;
+        }
+        cur = c.N[cur].child0;
+      } else {
+        // climb until we arrive from a first child, then step to its sibling
+        int prev = cur; cur = c.N[cur].parent;
+        while (cur != dev::k_no_node && c.N[cur].child1 == prev) { prev = cur; cur = c.N[cur].parent; }
+        if (cur != dev::k_no_node) cur = c.N[cur].child1;
+      }
+    }
+  }
+  __syncthreads();
+  // phase C: log G and the coalescent partial prior
+  double acc_G = 0.0, acc_prior = 0.0;
+  for (int i = lane; i < n; i += k_wave) {
+    if (i != root) acc_G += dev::branch_log_G(c, c.N[c.N[i].parent].t, c.N[i].t, c.N[i].lambda, dev::muts_of(c, i), dev::nmuts(c, i));
+    if (!dev::is_tip(c, i)) acc_prior -= log(dev::pop_at_time(*c.pop, c.N[i].t));
+  }
+  {
+    dev::Cells k = dev::cells_of(c);
+    for (int w = lane; w < c.H->n_cells; w += k_wave) {   // very_scalable_coalescent.cpp:355-386
+      double na = (double)k.nactive[w];
+      acc_prior -= c.H->t_step / k.popsize[w] * (+0.5 * (k.kbar_p[w] * k.kbar_p[w]) * na - (k.ktw_p[w] * na - k.ktw[w] + 0.5) * k.kbar_p[w]);
+    }
+  }
+  acc_G = wave_sum(acc_G); acc_prior = wave_sum(acc_prior);
+  if (lane == 0) {
+    double lg = acc_G;
+    if (c.includes_run_root) lg = dev::calc_log_root_prior(c, a.ref_freqs, a.evo.num_partitions) + acc_G;
+    c.H->log_G = lg;
+    c.H->log_aug_prior = acc_prior;
+  }
+}
+
+// =================================================================================================
+// Host side
+// =================================================================================================
+#define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); return EMAT_ERR_HIP; } } while (0)
+
+template <class T> struct DevBuf {
+  T* p = nullptr; size_t n = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t upload(const T* src, size_t count) {
+    if (count > n) { if (p) (void)hipFree(p); p = nullptr; n = 0; hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); if (e != hipSuccess) return e; n = count; }
+    if (count) return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+    return hipSuccess;
+  }
+};
+
+struct PartHost {
+  FlatTree tree;
+  bool includes_run_root = false;
+  HostRng rng;
+  HostCoalPart coal;
+  bool uploaded = false;
+  // slab geometry
+  uint64_t slab_off = 0;
+  uint32_t slab_bytes = 0;
+  emat_part_stats stats{};
+};
+
+}  // namespace emat
+
+using namespace emat;
+
+struct emat_backend {
+  emat_config cfg{};
+  std::string last_error;
+  int L = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  double last_run_ms = 0.0;
+  // model
+  std::vector<uint8_t> ref, partition_for_site;
+  std::vector<double> nu_l, cumQ, mu, pi, q;
+  std::vector<int32_t> ref_freqs;
+  int num_partitions = 0;
+  RunFlags flags{0.0, 0, 1};
+  bool have_ref = false, have_evo = false, have_pop = false, have_coal = false;
+  HostPopModel pop;
+  DevBuf<uint8_t> d_ref, d_part; DevBuf<double> d_nu, d_cumQ, d_mu, d_pi, d_q, d_sky_x, d_sky_g; DevBuf<int32_t> d_ref_freqs; DevBuf<PopTable> d_pop;
+  bool model_dirty = true;
+  // parts
+  std::vector<PartHost> parts;
+  int uploads_expected = 0;
+  int root_part = -1;
+  std::vector<uint8_t> h_slabs;
+  DevBuf<uint8_t> d_slabs; DevBuf<uint64_t> d_slab_off; DevBuf<int32_t> d_order;
+  bool slabs_on_device = false;     // device slabs are materialised
+  bool host_slabs_current = false;  // h_slabs mirrors the device
+  bool derived_valid = false;
+  uint32_t max_slab_bytes = 0;
+
+  void set_error(const std::string& s) { last_error = s; }
+};
+
+namespace {
+
+uint32_t a16(uint32_t x) { return (x + 15u) & ~15u; }
+
+// Encode one part into its slab (layout: emat_slab.hpp).
+void encode_slab(const emat_backend& B, const PartHost& ph, uint8_t* slab, uint32_t slab_bytes, uint32_t heap_bytes, uint32_t scratch_bytes, int cell_cap, int trace_cap) {
+  std::memset(slab, 0, slab_bytes);
+  const FlatTree& t = ph.tree;
+  const int n = t.num_nodes();
+  SlabHeader* H = (SlabHeader*)slab;
+  H->magic = k_slab_magic; H->slab_bytes = slab_bytes; H->n_nodes = n; H->root = t.root;
+  H->flags = ph.includes_run_root ? k_flag_includes_run_root : 0u;
+  H->status = 0; H->rng_key = ph.rng.key; H->rng_counter = ph.rng.counter;
+  uint32_t off = sizeof(SlabHeader);
+  H->off_nodes = off; off += (uint32_t)n * (uint32_t)sizeof(NodeRec);
+  H->off_cells = off; off += a16((uint32_t)cell_cap * 36u);
+  H->off_trace = off; off += a16((uint32_t)trace_cap * 32u);
+  H->heap_begin = off; H->heap_end = off + heap_bytes;
+  H->scratch_begin = H->heap_end; H->scratch_end = H->scratch_begin + scratch_bytes;
+  H->cell_first = ph.coal.cell_first; H->n_cells = (int)ph.coal.k_bar_p.size(); H->cell_cap = cell_cap; H->n_cells_total = ph.coal.n_cells_total;
+  H->t_ref = ph.coal.t_ref; H->t_step = ph.coal.t_step;
+  H->trace_cap = trace_cap; H->trace_len = 0;
+  NodeRec* N = (NodeRec*)(slab + H->off_nodes);
+  uint32_t top = H->heap_begin;
+  for (int i = 0; i < n; ++i) {
+    NodeRec& r = N[i];
+    r.parent = t.parent[i]; r.child0 = t.child0[i]; r.child1 = t.child1[i];
+    r.t_min = t.t_min[i]; r.t_max = t.t_max[i]; r.t = t.t[i]; r.lambda = 0.0; r.n_missing = 0;
+    int nm = t.mut_offset[i + 1] - t.mut_offset[i], ni = t.miss_offset[i + 1] - t.miss_offset[i], nf = t.mfs_offset[i + 1] - t.mfs_offset[i];
+    r.muts.off = top; r.muts.cnt = (uint16_t)nm; r.muts.cap = (uint16_t)(a16(nm * 16u) / 16u);
+    MutRec* m = (MutRec*)(slab + top);
+    for (int k = 0; k < nm; ++k) { int s = t.mut_offset[i] + k; m[k].t = t.mut_t[s]; m[k].site = t.mut_site[s]; m[k].from = t.mut_from[s]; m[k].to = t.mut_to[s]; m[k].pad = 0; }
+    top += a16(nm * 16u);
+    r.miss.off = top; r.miss.cnt = (uint16_t)ni; r.miss.cap = (uint16_t)(a16(ni * 8u) / 8u);
+    IvRec* iv = (IvRec*)(slab + top);
+    for (int k = 0; k < ni; ++k) { int s = t.miss_offset[i] + k; iv[k].start = t.miss_start[s]; iv[k].end = t.miss_end[s]; }
+    top += a16(ni * 8u);
+    r.mfs.off = top; r.mfs.cnt = (uint16_t)nf; r.mfs.cap = (uint16_t)(a16(nf * 8u) / 8u);
+    FsRec* fs = (FsRec*)(slab + top);
+    for (int k = 0; k < nf; ++k) { int s = t.mfs_offset[i] + k; fs[k].site = t.mfs_site[s]; fs[k].state = t.mfs_state[s]; }
+    top += a16(nf * 8u);
+  }
+  H->heap_top = top;
+  double* cb = (double*)(slab + H->off_cells);
+  const int nc = (int)ph.coal.k_bar_p.size();
+  for (int w = 0; w < nc; ++w) {
+    cb[w] = ph.coal.k_bar_p[w]; cb[cell_cap + w] = ph.coal.k_twiddle_bar_p[w]; cb[2 * cell_cap + w] = ph.coal.k_twiddle_bar[w]; cb[3 * cell_cap + w] = ph.coal.popsize_bar[w];
+    ((int32_t*)(cb + 4 * cell_cap))[w] = ph.coal.num_active_parts[w];
+  }
+  (void)B;
+}
+
+uint32_t heap_content_bytes(const FlatTree& t) {
+  uint32_t b = 0;
+  for (int i = 0; i < t.num_nodes(); ++i)
+    b += a16((t.mut_offset[i + 1] - t.mut_offset[i]) * 16u) + a16((t.miss_offset[i + 1] - t.miss_offset[i]) * 8u) + a16((t.mfs_offset[i + 1] - t.mfs_offset[i]) * 8u);
+  return b;
+}
+
+// Decode the device image of a part back into its host FlatTree + coalescent window + rng + stats.
+void decode_slab(PartHost& ph, const uint8_t* slab) {
+  const SlabHeader* H = (const SlabHeader*)slab;
+  const NodeRec* N = (const NodeRec*)(slab + H->off_nodes);
+  const int n = H->n_nodes;
+  FlatTree& t = ph.tree;
+  int nm = 0, ni = 0, nf = 0;
+  for (int i = 0; i < n; ++i) { nm += N[i].muts.cnt; ni += N[i].miss.cnt; nf += N[i].mfs.cnt; }
+  t.allocate(n, nm, ni, nf);
+  t.root = H->root;
+  int km = 0, ki = 0, kf = 0;
+  for (int i = 0; i < n; ++i) {
+    const NodeRec& r = N[i];
+    t.parent[i] = r.parent; t.child0[i] = r.child0; t.child1[i] = r.child1; t.t[i] = r.t; t.t_min[i] = r.t_min; t.t_max[i] = r.t_max;
+    const MutRec* m = (const MutRec*)(slab + r.muts.off);
+    for (int k = 0; k < r.muts.cnt; ++k) { t.mut_site[km] = m[k].site; t.mut_from[km] = m[k].from; t.mut_to[km] = m[k].to; t.mut_t[km] = m[k].t; ++km; }
+    const IvRec* iv = (const IvRec*)(slab + r.miss.off);
+    for (int k = 0; k < r.miss.cnt; ++k) { t.miss_start[ki] = iv[k].start; t.miss_end[ki] = iv[k].end; ++ki; }
+    const FsRec* fs = (const FsRec*)(slab + r.mfs.off);
+    for (int k = 0; k < r.mfs.cnt; ++k) { t.mfs_site[kf] = fs[k].site; t.mfs_state[kf] = fs[k].state; ++kf; }
+    t.mut_offset[i + 1] = km; t.miss_offset[i + 1] = ki; t.mfs_offset[i + 1] = kf;
+  }
+  ph.rng.counter = H->rng_counter;
+  const int nc = H->n_cells, cap = H->cell_cap;
+  const double* cb = (const double*)(slab + H->off_cells);
+  ph.coal.n_cells_total = H->n_cells_total;
+  ph.coal.k_bar_p.assign(cb, cb + nc); ph.coal.k_twiddle_bar_p.assign(cb + cap, cb + cap + nc); ph.coal.k_twiddle_bar.assign(cb + 2 * cap, cb + 2 * cap + nc);
+  ph.coal.popsize_bar.assign(cb + 3 * cap, cb + 3 * cap + nc);
+  const int32_t* na = (const int32_t*)(cb + 4 * cap); ph.coal.num_active_parts.assign(na, na + nc);
+}
+
+emat_status fail(emat_backend* h, emat_status st, const std::string& msg) { h->set_error(msg); return st; }
+
+emat_status sync_model_to_device(emat_backend* h) {
+  if (!h->model_dirty) return EMAT_OK;
+  auto& B = *h;
+  auto set_error = [&](const std::string& s) { B.set_error(s); };
+  HIP_TRY(B.d_ref.upload(B.ref.data(), B.ref.size()));
+  HIP_TRY(B.d_part.upload(B.partition_for_site.data(), B.partition_for_site.size()));
+  HIP_TRY(B.d_nu.upload(B.nu_l.data(), B.nu_l.size()));
+  HIP_TRY(B.d_cumQ.upload(B.cumQ.data(), B.cumQ.size()));
+  HIP_TRY(B.d_mu.upload(B.mu.data(), B.mu.size()));
+  HIP_TRY(B.d_pi.upload(B.pi.data(), B.pi.size()));
+  HIP_TRY(B.d_q.upload(B.q.data(), B.q.size()));
+  HIP_TRY(B.d_ref_freqs.upload(B.ref_freqs.data(), B.ref_freqs.size()));
+  HIP_TRY(B.d_sky_x.upload(B.pop.x.data(), B.pop.x.size()));
+  HIP_TRY(B.d_sky_g.upload(B.pop.gamma.data(), B.pop.gamma.size()));
+  PopTable pt{};
+  pt.kind = B.pop.kind; pt.skygrid_type = B.pop.skygrid_type; pt.skygrid_num_knots = (int)B.pop.x.size();
+  for (int i = 0; i < 4; ++i) pt.p[i] = B.pop.p[i];
+  pt.t_c = B.pop.t_c; pt.skygrid_x = B.d_sky_x.p; pt.skygrid_gamma = B.d_sky_g.p;
+  HIP_TRY(B.d_pop.upload(&pt, 1));
+  B.model_dirty = false;
+  return EMAT_OK;
+}
+
+// reference_cum_Q and state frequencies of the reference sequence (phylo_tree_calc.cpp:379-388, :95-106)
+void refresh_ref_derived(emat_backend* h) {
+  const int L = h->L;
+  h->cumQ.assign(L + 1, 0.0);
+  double so_far = 0.0;
+  for (int l = 0; l < L; ++l) {
+    const int p = h->partition_for_site[l];
+    so_far += h->mu[p] * h->nu_l[l] * (-h->q[p * 16 + h->ref[l] * 5]);
+    h->cumQ[l + 1] = so_far;
+  }
+  h->ref_freqs.assign((size_t)h->num_partitions * 4, 0);
+  for (int l = 0; l < L; ++l) ++h->ref_freqs[h->partition_for_site[l] * 4 + h->ref[l]];
+  h->model_dirty = true;
+}
+
+KernelArgs make_args(emat_backend* h) {
+  KernelArgs a{};
+  a.slabs = h->d_slabs.p; a.slab_off = h->d_slab_off.p; a.order = h->d_order.p; a.ref_freqs = h->d_ref_freqs.p;
+  a.evo.num_sites = h->L; a.evo.num_partitions = h->num_partitions;
+  a.evo.ref_sequence = h->d_ref.p; a.evo.partition_for_site = h->d_part.p; a.evo.nu_l = h->d_nu.p; a.evo.cum_Q_l = h->d_cumQ.p;
+  a.evo.mu = h->d_mu.p; a.evo.pi = h->d_pi.p; a.evo.q = h->d_q.p;
+  a.pop = h->d_pop.p; a.flags = h->flags; a.num_parts = (int)h->parts.size();
+  a.lds_slab_bytes = 0; a.moves_per_part = 0; a.extra_moves_part0 = 0;
+  return a;
+}
+
+// Bring the host copies of all parts up to date with the device.
+emat_status pull_from_device(emat_backend* h) {
+  if (!h->slabs_on_device || h->host_slabs_current) return EMAT_OK;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(h->h_slabs.data(), h->d_slabs.p, h->h_slabs.size(), hipMemcpyDeviceToHost));
+  for (auto& ph : h->parts) {
+    const uint8_t* slab = h->h_slabs.data() + ph.slab_off;
+    const SlabHeader* H = (const SlabHeader*)slab;
+    decode_slab(ph, slab);
+    ph.stats.status = H->status; ph.stats.num_nodes = H->n_nodes; ph.stats.moves_done = H->moves_done;
+    for (int k = 0; k < 5; ++k) { ph.stats.proposed[k] = H->proposed[k]; ph.stats.accepted[k] = H->accepted[k]; }
+    ph.stats.algorithmic_bytes = H->alg_bytes; ph.stats.rng_draws = (int64_t)H->rng_counter;
+  }
+  h->host_slabs_current = true;
+  return EMAT_OK;
+}
+
+// Encode all parts and push them to the device.
+emat_status materialize(emat_backend* h) {
+  if (h->slabs_on_device) return EMAT_OK;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  if (!h->have_ref || !h->have_evo) return fail(h, EMAT_ERR_STATE, "set_ref_sequence and set_evo must precede running");
+  if (!h->have_coal) return fail(h, EMAT_ERR_STATE, "emat_build_coalescent_parts must precede running");
+  const double slack = h->cfg.slab_slack > 0 ? h->cfg.slab_slack : 3.0;
+  const int trace_cap = h->cfg.trace_moves > 0 ? h->cfg.trace_moves : 0;
+  uint64_t off = 0; h->max_slab_bytes = 0;
+  struct Geo { uint32_t heap, scratch; int cell_cap; };
+  std::vector<Geo> geo(h->parts.size());
+  for (size_t p = 0; p < h->parts.size(); ++p) {
+    PartHost& ph = h->parts[p];
+    const int n = ph.tree.num_nodes();
+    const uint32_t content = heap_content_bytes(ph.tree);
+    Geo g;
+    g.heap = a16((uint32_t)std::max<double>(2048.0, content * slack + 64.0 * n));
+    g.scratch = a16(std::max<uint32_t>(8192u, 4u * content + 256u * (uint32_t)n));
+    int nc = (int)ph.coal.k_bar_p.size();
+    g.cell_cap = ph.includes_run_root ? std::max(nc * 8, nc + 2048) : nc;
+    geo[p] = g;
+    uint32_t bytes = (uint32_t)sizeof(SlabHeader) + (uint32_t)n * (uint32_t)sizeof(NodeRec) + a16((uint32_t)g.cell_cap * 36u) + a16((uint32_t)trace_cap * 32u) + g.heap + g.scratch;
+    ph.slab_off = off; ph.slab_bytes = bytes; off += bytes;
+    h->max_slab_bytes = std::max(h->max_slab_bytes, bytes);
+  }
+  h->h_slabs.assign(off, 0);
+  std::vector<uint64_t> offs(h->parts.size());
+  for (size_t p = 0; p < h->parts.size(); ++p) {
+    PartHost& ph = h->parts[p];
+    offs[p] = ph.slab_off;
+    encode_slab(*h, ph, h->h_slabs.data() + ph.slab_off, ph.slab_bytes, geo[p].heap, geo[p].scratch, geo[p].cell_cap, trace_cap);
+    // carry the statistics over re-materialisations
+    SlabHeader* H = (SlabHeader*)(h->h_slabs.data() + ph.slab_off);
+    H->moves_done = ph.stats.moves_done; for (int k = 0; k < 5; ++k) { H->proposed[k] = ph.stats.proposed[k]; H->accepted[k] = ph.stats.accepted[k]; }
+    H->alg_bytes = ph.stats.algorithmic_bytes;
+  }
+  std::vector<int32_t> order(h->parts.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->parts[a].tree.num_nodes() > h->parts[b].tree.num_nodes(); });
+  HIP_TRY(h->d_slabs.upload(h->h_slabs.data(), h->h_slabs.size()));
+  HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
+  HIP_TRY(h->d_order.upload(order.data(), order.size()));
+  h->slabs_on_device = true; h->host_slabs_current = true; h->derived_valid = false;
+  return EMAT_OK;
+}
+
+uint32_t lds_budget(const emat_backend* h) {
+  if (!h->cfg.use_lds) return 0;
+  // stage when a slab fits in 64 KiB minus the table area (160 KiB per CU => at least two workgroups per CU)
+  return 64u * 1024u - k_lds_tables_bytes;
+}
+
+emat_status launch_recalc(emat_backend* h) {
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  emat_status st = sync_model_to_device(h); if (st) return st;
+  st = materialize(h); if (st) return st;
+  KernelArgs a = make_args(h);
+  hipLaunchKernelGGL(k_recalc_derived, dim3((unsigned)h->parts.size()), dim3(k_wave), 0, h->stream, a);
+  HIP_TRY(hipGetLastError());
+  h->derived_valid = true; h->host_slabs_current = false;
+  return EMAT_OK;
+}
+
+emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0) {
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
+  emat_status st = sync_model_to_device(h); if (st) return st;
+  st = materialize(h); if (st) return st;
+  if (!h->derived_valid) { st = launch_recalc(h); if (st) return st; }
+  KernelArgs a = make_args(h);
+  a.moves_per_part = per_part; a.extra_moves_part0 = extra0;
+  const uint32_t budget = lds_budget(h);
+  uint32_t lds_slab = std::min(budget, (h->max_slab_bytes + 15u) & ~15u);
+  a.lds_slab_bytes = budget == 0 ? 0 : lds_slab;
+  size_t shmem = k_lds_tables_bytes + (budget == 0 ? 0 : lds_slab);
+  if (shmem > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+  hipLaunchKernelGGL(k_run_moves, dim3((unsigned)h->parts.size()), dim3(k_wave), shmem, h->stream, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+  h->host_slabs_current = false;
+  return EMAT_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
+  if (!cfg || !out || cfg->num_sites <= 0) return EMAT_ERR_INVALID_ARGUMENT;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return EMAT_ERR_NO_DEVICE;
+  if (cfg->device < 0 || cfg->device >= ndev) return EMAT_ERR_INVALID_ARGUMENT;
+  if (hipSetDevice(cfg->device) != hipSuccess) return EMAT_ERR_HIP;
+  auto h = std::make_unique<emat_backend>();
+  h->cfg = *cfg; h->L = cfg->num_sites;
+  if (hipStreamCreate(&h->stream) != hipSuccess) return EMAT_ERR_HIP;
+  if (hipEventCreate(&h->ev_start) != hipSuccess || hipEventCreate(&h->ev_stop) != hipSuccess) return EMAT_ERR_HIP;
+  *out = h.release();
+  return EMAT_OK;
+}
+emat_status emat_backend_destroy(emat_backend* h) {
+  if (!h) return EMAT_OK;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+  if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+  if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+  delete h;
+  return EMAT_OK;
+}
+const char* emat_last_error(const emat_backend* h) { return h ? h->last_error.c_str() : "null backend"; }
+
+emat_status emat_set_ref_sequence(emat_backend* h, const uint8_t* ref, int32_t num_sites) {
+  if (!h || !ref || num_sites != h->L) return EMAT_ERR_INVALID_ARGUMENT;
+  for (int l = 0; l < num_sites; ++l) if (ref[l] > 3) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "reference sequence states must be 0..3");
+  h->ref.assign(ref, ref + num_sites); h->have_ref = true;
+  if (h->have_evo) refresh_ref_derived(h);
+  h->derived_valid = false;
+  return EMAT_OK;
+}
+emat_status emat_set_evo(emat_backend* h, int32_t P, const double* mu, const double* pi, const double* q, const double* nu_l, const int32_t* pfs) {
+  if (!h || P <= 0 || P > 255 || !mu || !pi || !q || !nu_l || !pfs) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!h->have_ref) return fail(h, EMAT_ERR_STATE, "emat_set_ref_sequence must precede emat_set_evo");
+  h->partition_for_site.resize(h->L);
+  for (int l = 0; l < h->L; ++l) { if (pfs[l] < 0 || pfs[l] >= P) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "partition_for_site out of range"); h->partition_for_site[l] = (uint8_t)pfs[l]; }
+  h->num_partitions = P;
+  h->mu.assign(mu, mu + P); h->pi.assign(pi, pi + 4 * P); h->q.assign(q, q + 16 * P); h->nu_l.assign(nu_l, nu_l + h->L);
+  h->have_evo = true;
+  refresh_ref_derived(h);
+  h->derived_valid = false;   // Subrun::set_evo invalidates derived quantities (subrun.h:29-30)
+  return EMAT_OK;
+}
+emat_status emat_set_flags(emat_backend* h, double t_max_tip, int32_t only_displacing_inner_nodes, int32_t topology_moves_enabled) {
+  if (!h) return EMAT_ERR_INVALID_ARGUMENT;
+  h->flags.t_max_tip = t_max_tip; h->flags.only_displacing_inner_nodes = only_displacing_inner_nodes; h->flags.topology_moves_enabled = topology_moves_enabled;
+  return EMAT_OK;
+}
+
+emat_status emat_begin_upload(emat_backend* h, int32_t num_parts) {
+  if (!h || num_parts <= 0) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->cfg.max_parts > 0 && num_parts > h->cfg.max_parts) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "more parts than cfg.max_parts");
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  h->parts.clear(); h->parts.resize(num_parts);
+  h->uploads_expected = num_parts; h->root_part = -1;
+  h->slabs_on_device = false; h->host_slabs_current = false; h->have_coal = false; h->derived_valid = false;
+  return EMAT_OK;
+}
+emat_status emat_part_upload(emat_backend* h, int32_t part_id, const emat_flat_tree* subtree, int32_t includes_run_root, uint64_t seed) {
+  if (!h || !subtree || part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->uploads_expected <= 0) return fail(h, EMAT_ERR_STATE, "emat_begin_upload must precede emat_part_upload");
+  std::string msg = validate_flat_tree(*subtree, h->L);
+  if (!msg.empty()) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "part " + std::to_string(part_id) + ": " + msg);
+  for (int i = 0; i < subtree->num_nodes; ++i) {
+    int nm = subtree->mut_offset[i + 1] - subtree->mut_offset[i], ni = subtree->miss_offset[i + 1] - subtree->miss_offset[i], nf = subtree->mfs_offset[i + 1] - subtree->mfs_offset[i];
+    if (nm > 16000 || ni > 16000 || nf > 16000) return fail(h, EMAT_ERR_CAPACITY, "a node list exceeds the 16-bit list capacity");
+  }
+  PartHost& ph = h->parts[part_id];
+  if (ph.uploaded) return fail(h, EMAT_ERR_STATE, "part uploaded twice");
+  ph.tree = FlatTree::from_view(*subtree);
+  ph.includes_run_root = includes_run_root != 0;
+  ph.rng.key = seed; ph.rng.counter = 0;
+  ph.uploaded = true; ph.stats = emat_part_stats{};
+  if (ph.includes_run_root) h->root_part = part_id;
+  return EMAT_OK;
+}
+emat_status emat_end_upload(emat_backend* h) {
+  if (!h) return EMAT_ERR_INVALID_ARGUMENT;
+  for (auto& ph : h->parts) if (!ph.uploaded) return fail(h, EMAT_ERR_STATE, "emat_end_upload before every part was uploaded");
+  h->uploads_expected = 0;
+  return EMAT_OK;
+}
+
+emat_status emat_build_coalescent_parts(emat_backend* h, const emat_pop_model* pm, int32_t root_part_index, double t_step) {
+  if (!h || !pm || !(t_step > 0.0)) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->parts.empty() || h->uploads_expected != 0) return fail(h, EMAT_ERR_STATE, "upload parts first");
+  if (root_part_index < 0 || root_part_index >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  try {
+    emat_status st = pull_from_device(h); if (st) return st;   // the trees (node times) may have moved on the device
+    h->pop = HostPopModel::from_c(*pm);
+    std::vector<const FlatTree*> trees; std::vector<HostRng*> rngs;
+    for (auto& ph : h->parts) { trees.push_back(&ph.tree); rngs.push_back(&ph.rng); }
+    auto cps = make_coalescent_parts(trees, root_part_index, h->pop, rngs, t_step);
+    for (size_t p = 0; p < h->parts.size(); ++p) h->parts[p].coal = std::move(cps[p]);
+  } catch (const std::exception& ex) { return fail(h, EMAT_ERR_INVALID_ARGUMENT, ex.what()); }
+  h->have_pop = true; h->have_coal = true; h->model_dirty = true;
+  h->slabs_on_device = false; h->host_slabs_current = false; h->derived_valid = false;   // re-encode with the new cell tables
+  return EMAT_OK;
+}
+
+emat_status emat_run_local_moves(emat_backend* h, int64_t count) {
+  if (!h || count < 0) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
+  const int64_t P = (int64_t)h->parts.size();
+  const int64_t sub = count / P;   // run.cpp:683-689
+  return launch_moves(h, sub, count - P * sub);
+}
+emat_status emat_run_moves_per_part(emat_backend* h, int64_t moves_per_part) {
+  if (!h || moves_per_part < 0) return EMAT_ERR_INVALID_ARGUMENT;
+  return launch_moves(h, moves_per_part, 0);
+}
+emat_status emat_synchronize(emat_backend* h) {
+  if (!h) return EMAT_ERR_INVALID_ARGUMENT;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return EMAT_OK;
+}
+emat_status emat_recalc_derived(emat_backend* h) {
+  if (!h) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
+  return launch_recalc(h);
+}
+
+emat_status emat_get_totals(emat_backend* h, double* log_G, double* log_aug) {
+  if (!h) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
+  emat_status st;
+  if (!h->slabs_on_device || !h->derived_valid) { st = launch_recalc(h); if (st) return st; }
+  st = pull_from_device(h); if (st) return st;
+  double g = 0.0, a = 0.0;
+  for (auto& ph : h->parts) { const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + ph.slab_off); g += H->log_G; a += H->log_aug_prior; }
+  if (log_G) *log_G = g;
+  if (log_aug) *log_aug = a;
+  return EMAT_OK;
+}
+emat_status emat_part_get_sizes(emat_backend* h, int32_t part_id, int32_t* nn, int32_t* nm, int32_t* ni, int32_t* nf) {
+  if (!h || part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = pull_from_device(h); if (st) return st;
+  const FlatTree& t = h->parts[part_id].tree;
+  if (nn) *nn = t.num_nodes(); if (nm) *nm = t.num_muts(); if (ni) *ni = t.num_intervals(); if (nf) *nf = t.num_from_states();
+  return EMAT_OK;
+}
+emat_status emat_part_download(emat_backend* h, int32_t part_id, emat_flat_tree* out) {
+  if (!h || !out || part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = pull_from_device(h); if (st) return st;
+  const FlatTree& t = h->parts[part_id].tree;
+  const int n = t.num_nodes();
+  if (out->num_nodes < n || out->cap_muts < t.num_muts() || out->cap_intervals < t.num_intervals() || out->cap_from_states < t.num_from_states())
+    return fail(h, EMAT_ERR_BUFFER_TOO_SMALL, "emat_part_download: output arrays too small (see emat_part_get_sizes)");
+  out->num_nodes = n; out->root = t.root;
+  std::copy(t.parent.begin(), t.parent.end(), out->parent); std::copy(t.child0.begin(), t.child0.end(), out->child0); std::copy(t.child1.begin(), t.child1.end(), out->child1);
+  std::copy(t.t.begin(), t.t.end(), out->t); std::copy(t.t_min.begin(), t.t_min.end(), out->t_min); std::copy(t.t_max.begin(), t.t_max.end(), out->t_max);
+  std::copy(t.mut_offset.begin(), t.mut_offset.end(), out->mut_offset); std::copy(t.mut_site.begin(), t.mut_site.end(), out->mut_site);
+  std::copy(t.mut_from.begin(), t.mut_from.end(), out->mut_from); std::copy(t.mut_to.begin(), t.mut_to.end(), out->mut_to); std::copy(t.mut_t.begin(), t.mut_t.end(), out->mut_t);
+  std::copy(t.miss_offset.begin(), t.miss_offset.end(), out->miss_offset); std::copy(t.miss_start.begin(), t.miss_start.end(), out->miss_start); std::copy(t.miss_end.begin(), t.miss_end.end(), out->miss_end);
+  std::copy(t.mfs_offset.begin(), t.mfs_offset.end(), out->mfs_offset); std::copy(t.mfs_site.begin(), t.mfs_site.end(), out->mfs_site); std::copy(t.mfs_state.begin(), t.mfs_state.end(), out->mfs_state);
+  return EMAT_OK;
+}
+emat_status emat_part_get_derived(emat_backend* h, int32_t part_id, double* lambda_i, int32_t* num_missing, double* log_G, double* log_aug) {
+  if (!h || part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st;
+  if (!h->slabs_on_device || !h->derived_valid) { st = launch_recalc(h); if (st) return st; }
+  st = pull_from_device(h); if (st) return st;
+  const uint8_t* slab = h->h_slabs.data() + h->parts[part_id].slab_off;
+  const SlabHeader* H = (const SlabHeader*)slab; const NodeRec* N = (const NodeRec*)(slab + H->off_nodes);
+  for (int i = 0; i < H->n_nodes; ++i) { if (lambda_i) lambda_i[i] = N[i].lambda; if (num_missing) num_missing[i] = N[i].n_missing; }
+  if (log_G) *log_G = H->log_G;
+  if (log_aug) *log_aug = H->log_aug_prior;
+  return EMAT_OK;
+}
+emat_status emat_part_get_coalescent(emat_backend* h, int32_t part_id, int32_t* num_cells, double* k_bar_p, double* k_tw_p, double* k_tw,
+                                     double* popsize_bar, int32_t* num_active, double* t_ref, double* t_step) {
+  if (!h || !num_cells || part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!h->have_coal) return fail(h, EMAT_ERR_STATE, "no coalescent parts built");
+  emat_status st = pull_from_device(h); if (st) return st;
+  const HostCoalPart& cp = h->parts[part_id].coal;
+  const int n = cp.n_cells_total;
+  if (*num_cells < n) { *num_cells = n; return fail(h, EMAT_ERR_BUFFER_TOO_SMALL, "emat_part_get_coalescent: arrays too small"); }
+  *num_cells = n;
+  // expand the window back to the logical vectors of the reference (zeros outside the window; the three
+  // shared vectors are only known inside it)
+  for (int i = 0; i < n; ++i) {
+    int w = i - cp.cell_first; bool in = w >= 0 && w < (int)cp.k_bar_p.size();
+    if (k_bar_p) k_bar_p[i] = in ? cp.k_bar_p[w] : 0.0;
+    if (k_tw_p) k_tw_p[i] = in ? cp.k_twiddle_bar_p[w] : 0.0;
+    if (k_tw) k_tw[i] = in ? cp.k_twiddle_bar[w] : __builtin_nan("");
+    if (popsize_bar) popsize_bar[i] = in ? cp.popsize_bar[w] : __builtin_nan("");
+    if (num_active) num_active[i] = in ? cp.num_active_parts[w] : -1;
+  }
+  if (t_ref) *t_ref = cp.t_ref;
+  if (t_step) *t_step = cp.t_step;
+  return EMAT_OK;
+}
+emat_status emat_part_get_stats(emat_backend* h, int32_t part_id, emat_part_stats* out) {
+  if (!h || !out || part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = pull_from_device(h); if (st) return st;
+  *out = h->parts[part_id].stats;
+  if (h->slabs_on_device) {
+    const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + h->parts[part_id].slab_off);
+    if (H->status != 0) h->set_error("part " + std::to_string(part_id) + " stopped with status " + std::to_string(H->status) + " at device line " + std::to_string(H->fail_line));
+  }
+  return EMAT_OK;
+}
+emat_status emat_part_get_trace(emat_backend* h, int32_t part_id, int32_t* num_moves, double* trace) {
+  if (!h || !num_moves || !trace || part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = pull_from_device(h); if (st) return st;
+  if (!h->slabs_on_device) { *num_moves = 0; return EMAT_OK; }
+  const uint8_t* slab = h->h_slabs.data() + h->parts[part_id].slab_off;
+  const SlabHeader* H = (const SlabHeader*)slab;
+  int n = std::min(*num_moves, H->trace_len);
+  std::memcpy(trace, slab + H->off_trace, (size_t)n * 32);
+  *num_moves = n;
+  return EMAT_OK;
+}
+emat_status emat_last_run_ms(emat_backend* h, double* ms) {
+  if (!h || !ms) return EMAT_ERR_INVALID_ARGUMENT;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  HIP_TRY(hipEventSynchronize(h->ev_stop));
+  float f = 0.f;
+  HIP_TRY(hipEventElapsedTime(&f, h->ev_start, h->ev_stop));
+  h->last_run_ms = f; *ms = f;
+  return EMAT_OK;
+}
+
+}  // extern "C"

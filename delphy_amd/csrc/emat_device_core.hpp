@@ -1,0 +1,651 @@
+// emat_device_core.hpp -- device-side building blocks of the EMAT local-move engine (gfx950).
+//
+// One wavefront owns one partition part and runs its Markov chain on the part's slab
+// (emat_slab.hpp), which lives in LDS when it fits and in HBM otherwise; every function here
+// takes a `Ctx` whose base pointer may be either.  The arithmetic follows the reference
+// expression by expression (file:line cited at each function) so that results stay within 1e-9
+// of the CPU path; integer outputs (sites, states, interval endpoints, region indices) are exact.
+//
+// This header is device code only.  It is NOT shared with oracle/ (which is an independent
+// restatement used to check it).
+#ifndef EMAT_DEVICE_CORE_HPP_
+#define EMAT_DEVICE_CORE_HPP_
+
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+
+#include "emat_slab.hpp"
+
+namespace emat {
+namespace dev {
+
+#define EMAT_D __device__ inline
+#define EMAT_DN __device__ __noinline__
+
+constexpr double k_neg_dbl_max = -1.7976931348623157e308;
+constexpr double k_inf = __builtin_huge_val();
+constexpr int k_no_node = -1;
+
+// ---- per-wave context ----------------------------------------------------------------------------
+struct Ctx {
+  uint8_t* S;                 // slab base (LDS or HBM; generic address space)
+  SlabHeader* H;
+  NodeRec* N;
+  // evolution model: per-site arrays in HBM, per-partition HKY tables in LDS when staged
+  int L;
+  const uint8_t* ref;
+  const uint8_t* part;
+  const double* nu;
+  const double* cumQ;
+  const double* mu;           // [P]
+  const double* pi;           // [P][4]
+  const double* q;            // [P][16]
+  const PopTable* pop;
+  double t_max_tip;
+  bool only_displacing_inner_nodes;
+  bool topology_moves_enabled;
+  bool includes_run_root;
+  // RNG (Philox4x32-10; one 128-bit block per draw)
+  uint64_t rng_key, rng_ctr;
+  double mu_prop;             // effective JC69 rate of the current SPR move (subrun.cpp:502,710)
+  // scratch bump pointer (byte offset from slab base)
+  uint32_t sc_top;
+  bool failed;
+  // statistics
+  int64_t bytes;
+  // trace of the current move
+  double tr_kind, tr_node, tr_acc, tr_log_mh;
+};
+
+EMAT_D void fail_at(Ctx& c, int status, int line) {
+  if (!c.failed) { c.failed = true; if (c.H->status == 0) { c.H->status = status; c.H->fail_line = line; } }
+}
+#define EMAT_FAIL(c, st) ::emat::dev::fail_at((c), (st), __LINE__)
+#define EMAT_CHECK(c, cond) do { if (!(cond)) ::emat::dev::fail_at((c), ::emat::k_part_internal, __LINE__); } while (0)
+
+// ---- RNG: identical stream to the parity oracle (oracle/orc_core.hpp `Rng`) -------------------------
+EMAT_D void philox4x32_10(uint64_t ctr, uint64_t key, uint32_t out[4]) {
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+EMAT_D void rng_next(Ctx& c, uint64_t& a, uint64_t& b) {
+  uint32_t w[4];
+  philox4x32_10(c.rng_ctr++, c.rng_key, w);
+  a = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+  b = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+}
+EMAT_D double to_co(uint64_t a) { return (double)(a >> 11) * 0x1.0p-53; }
+EMAT_D double to_oo(uint64_t a) { return ((double)(a >> 12) + 0.5) * 0x1.0p-52; }
+EMAT_D double to_oc(uint64_t a) { return ((double)(a >> 11) + 1.0) * 0x1.0p-53; }
+EMAT_D double u01_co(Ctx& c) { uint64_t a, b; rng_next(c, a, b); return to_co(a); }
+EMAT_D double u01_oo(Ctx& c) { uint64_t a, b; rng_next(c, a, b); return to_oo(a); }
+EMAT_D double u01_oc(Ctx& c) { uint64_t a, b; rng_next(c, a, b); return to_oc(a); }
+EMAT_D double uniform_co(Ctx& c, double lo, double hi) { return lo + (hi - lo) * u01_co(c); }
+EMAT_D double uniform_oc(Ctx& c, double lo, double hi) { return lo + (hi - lo) * u01_oc(c); }
+EMAT_D int uniform_int(Ctx& c, int n) { uint64_t a, b; rng_next(c, a, b); return (int)__umul64hi(a, (uint64_t)n); }
+EMAT_D double gaussian(Ctx& c, double mean, double sigma) {
+  uint64_t a, b; rng_next(c, a, b);
+  double u1 = to_oc(a), u2 = to_co(b);
+  double r = sqrt(-2.0 * log(u1));
+  return mean + sigma * (r * cos(6.283185307179586476925 * u2));
+}
+EMAT_D double exponential(Ctx& c, double rate) { return -log(u01_oc(c)) / rate; }
+EMAT_D int poisson(Ctx& c, double lambda) {
+  double u = u01_co(c);
+  double p = exp(-lambda), F = p;
+  int k = 0;
+  while (u >= F && k < 100000) { ++k; p *= lambda / k; F += p; }
+  return k;
+}
+
+// ---- scratch arena (temporaries of one move) -----------------------------------------------------------
+template <class T> struct SVec { T* p; int n; int cap; };
+EMAT_D uint8_t* sc_alloc(Ctx& c, uint32_t bytes) {
+  uint32_t b = (bytes + 15u) & ~15u;
+  if (c.sc_top + b > c.H->scratch_end) { EMAT_FAIL(c, k_part_overflow); return c.S + c.H->scratch_begin; }
+  uint8_t* p = c.S + c.sc_top;
+  c.sc_top += b;
+  return p;
+}
+template <class T> EMAT_D SVec<T> sc_vec(Ctx& c, int cap) {
+  SVec<T> v; v.n = 0;
+  uint32_t bytes = (uint32_t)cap * (uint32_t)sizeof(T);
+  uint32_t b = (bytes + 15u) & ~15u;
+  if (cap < 0 || c.sc_top + b > c.H->scratch_end) { EMAT_FAIL(c, k_part_overflow); v.p = (T*)(c.S + c.H->scratch_begin); v.cap = 0; return v; }
+  v.p = (T*)(c.S + c.sc_top); v.cap = cap; c.sc_top += b;
+  return v;
+}
+template <class T> EMAT_D void push(Ctx& c, SVec<T>& v, const T& x) { if (v.n < v.cap) v.p[v.n++] = x; else EMAT_FAIL(c, k_part_overflow); }
+// remaining scratch, expressed in elements of T (for open-ended allocations that are trimmed afterwards)
+template <class T> EMAT_D int sc_room(const Ctx& c) { return (int)((c.H->scratch_end - c.sc_top) / sizeof(T)) - 2; }
+// give back the unused tail of the most recent allocation
+template <class T> EMAT_D void sc_trim(Ctx& c, SVec<T>& v) {
+  uint32_t used = ((uint32_t)v.n * (uint32_t)sizeof(T) + 15u) & ~15u;
+  c.sc_top = (uint32_t)((uint8_t*)v.p - c.S) + used;
+  v.cap = v.n;
+}
+
+// ---- persistent per-node lists in the slab heap ---------------------------------------------------------
+EMAT_D uint32_t heap_alloc(Ctx& c, uint32_t bytes) {
+  uint32_t b = (bytes + 15u) & ~15u;
+  if (c.H->heap_top + b > c.H->heap_end) { EMAT_FAIL(c, k_part_overflow); return c.H->heap_begin; }
+  uint32_t off = c.H->heap_top;
+  c.H->heap_top += b;
+  return off;
+}
+template <class T> EMAT_D T* list_ptr(Ctx& c, const ListRef& r) { return (T*)(c.S + r.off); }
+template <class T> EMAT_D void list_reserve(Ctx& c, ListRef& r, int want) {
+  if (want <= (int)r.cap) return;
+  int nc = (int)r.cap * 2; if (nc < want) nc = want; if (nc < 4) nc = 4;
+  if (nc > 65535) { if (want > 65535) { EMAT_FAIL(c, k_part_overflow); return; } nc = 65535; }
+  uint32_t off = heap_alloc(c, (uint32_t)nc * (uint32_t)sizeof(T));
+  if (c.failed) return;
+  T* dst = (T*)(c.S + off); const T* src = (const T*)(c.S + r.off);
+  for (int i = 0; i < (int)r.cnt; ++i) dst[i] = src[i];
+  r.off = off; r.cap = (uint16_t)nc;
+}
+template <class T> EMAT_D void list_push(Ctx& c, ListRef& r, const T& x) {
+  list_reserve<T>(c, r, (int)r.cnt + 1);
+  if (c.failed) return;
+  list_ptr<T>(c, r)[r.cnt] = x; r.cnt++;
+}
+template <class T> EMAT_D void list_assign(Ctx& c, ListRef& r, const T* src, int n) {
+  list_reserve<T>(c, r, n);
+  if (c.failed) return;
+  T* dst = list_ptr<T>(c, r);
+  for (int i = 0; i < n; ++i) dst[i] = src[i];
+  r.cnt = (uint16_t)n;
+}
+template <class T> EMAT_D void list_erase_prefix(Ctx& c, ListRef& r, int k) {
+  T* p = list_ptr<T>(c, r);
+  for (int i = k; i < (int)r.cnt; ++i) p[i - k] = p[i];
+  r.cnt = (uint16_t)((int)r.cnt - k);
+}
+EMAT_D void swap_lists(ListRef& a, ListRef& b) { ListRef t = a; a = b; b = t; }
+
+EMAT_D MutRec* muts_of(Ctx& c, int n) { return (MutRec*)(c.S + c.N[n].muts.off); }
+EMAT_D IvRec* miss_of(Ctx& c, int n) { return (IvRec*)(c.S + c.N[n].miss.off); }
+EMAT_D FsRec* mfs_of(Ctx& c, int n) { return (FsRec*)(c.S + c.N[n].mfs.off); }
+EMAT_D int nmuts(const Ctx& c, int n) { return (int)c.N[n].muts.cnt; }
+EMAT_D bool is_tip(const Ctx& c, int n) { return c.N[n].child0 == k_no_node; }
+EMAT_D int sibling_of(Ctx& c, int parent, int x) {
+  EMAT_CHECK(c, x == c.N[parent].child0 || x == c.N[parent].child1);
+  return x == c.N[parent].child0 ? c.N[parent].child1 : c.N[parent].child0;
+}
+EMAT_D MutRec make_mut(uint8_t from, int site, uint8_t to, double t) { MutRec m; m.t = t; m.site = site; m.from = from; m.to = to; m.pad = 0; return m; }
+EMAT_D bool mut_less(const MutRec& a, const MutRec& b) { return a.t < b.t || (a.t == b.t && a.site < b.site); }   // mutations.h:41-43
+// stable insertion sort by (t, site): lists are tiny and nearly sorted
+EMAT_D void sort_muts(MutRec* p, int n) {
+  for (int i = 1; i < n; ++i) { MutRec x = p[i]; int j = i - 1; while (j >= 0 && mut_less(x, p[j])) { p[j + 1] = p[j]; --j; } p[j + 1] = x; }
+}
+EMAT_D void clamp_mut_times(MutRec* p, int n, double lo, double hi) {   // mutations.h:55-60
+  for (int i = 0; i < n; ++i) { double t = p[i].t; p[i].t = t < lo ? lo : (hi < t ? hi : t); }
+}
+
+// ---- evolution model accessors (evo_model.h:35-47) ----------------------------------------------------------
+EMAT_D double mu_nu(const Ctx& c, int l) { return c.mu[c.part[l]] * c.nu[l]; }
+EMAT_D double q_a(const Ctx& c, int l, int a) { return -c.q[c.part[l] * 16 + a * 5]; }
+EMAT_D double q_ab(const Ctx& c, int l, int a, int b) { return c.q[c.part[l] * 16 + a * 4 + b]; }
+EMAT_D double pi_a(const Ctx& c, int l, int a) { return c.pi[c.part[l] * 4 + a]; }
+// mu nu (-q_minus + q_plus)
+EMAT_D double dq(const Ctx& c, int l, int minus, int plus) { return c.mu[c.part[l]] * c.nu[l] * (-q_a(c, l, minus) + q_a(c, l, plus)); }
+
+// ---- interval-set algebra on raw sorted arrays (interval_set.h:130-138, 238-500) ---------------------------
+EMAT_D bool iv_contains(const IvRec* v, int n, int l) {
+  int lo = 0, hi = n;   // first interval with start > l
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (l < v[mid].start) hi = mid; else lo = mid + 1; }
+  if (lo == 0) return false;
+  return l < v[lo - 1].end;
+}
+EMAT_D int iv_num_sites(const IvRec* v, int n) { int r = 0; for (int i = 0; i < n; ++i) r += v[i].end - v[i].start; return r; }
+// dst must have room for nA + nB intervals
+EMAT_D int iv_merge(IvRec* dst, const IvRec* A, int nA, const IvRec* B, int nB) {
+  int out = 0, ia = 0, ib = 0; bool inside = false; int cs = 0, ce = 0;
+  while (!(ia == nA && ib == nB)) {
+    bool useA = (ia == nA) ? false : (ib == nB) ? true : (A[ia].start <= B[ib].start);
+    int fs = useA ? A[ia].start : B[ib].start, fe = useA ? A[ia].end : B[ib].end;
+    if (!inside) { cs = fs; ce = fe; if (useA) ++ia; else ++ib; inside = true; }
+    else if (fs <= ce) { ce = ce > fe ? ce : fe; if (useA) ++ia; else ++ib; }
+    else { dst[out].start = cs; dst[out].end = ce; ++out; inside = false; }
+  }
+  if (inside) { dst[out].start = cs; dst[out].end = ce; ++out; }
+  return out;
+}
+// dst must have room for nA + nB intervals
+EMAT_D int iv_intersect(IvRec* dst, const IvRec* A, int nA, const IvRec* B, int nB) {
+  int out = 0, ia = 0, ib = 0;
+  while (ia != nA && ib != nB) {
+    int so = A[ia].start > B[ib].start ? A[ia].start : B[ib].start;
+    int eo = A[ia].end < B[ib].end ? A[ia].end : B[ib].end;
+    if (so < eo) { dst[out].start = so; dst[out].end = eo; ++out; }
+    if (A[ia].end <= B[ib].end) ++ia; else ++ib;
+  }
+  return out;
+}
+EMAT_D bool iv_intersects(const IvRec* A, int nA, const IvRec* B, int nB) {
+  int ia = 0, ib = 0;
+  while (ia != nA && ib != nB) {
+    int so = A[ia].start > B[ib].start ? A[ia].start : B[ib].start;
+    int eo = A[ia].end < B[ib].end ? A[ia].end : B[ib].end;
+    if (so < eo) return true;
+    if (A[ia].end <= B[ib].end) ++ia; else ++ib;
+  }
+  return false;
+}
+// dst = A - B; dst must have room for nA + nB intervals
+EMAT_D int iv_subtract(IvRec* dst, const IvRec* A, int nA, const IvRec* B, int nB) {
+  if (nA == 0) return 0;
+  int out = 0, ia = 0, ib = 0;
+  int cs = A[0].start, ce = A[0].end;
+  while (ia != nA) {
+    bool next = false;
+    if (ib == nB) { dst[out].start = cs; dst[out].end = ce; ++out; next = true; }
+    else {
+      int bs = B[ib].start, be = B[ib].end;
+      if (bs < cs) {
+        if (be <= cs) ++ib;
+        else if (be < ce) { cs = be; ++ib; }
+        else next = true;
+      } else if (bs < ce) {
+        if (cs < bs) { dst[out].start = cs; dst[out].end = bs; ++out; }
+        if (be < ce) { cs = be; ++ib; }
+        else next = true;
+      } else { dst[out].start = cs; dst[out].end = ce; ++out; next = true; }
+    }
+    if (next) { ++ia; if (ia != nA) { cs = A[ia].start; ce = A[ia].end; } }
+  }
+  return out;
+}
+// scratch-allocated results
+EMAT_D SVec<IvRec> iv_subtract_sc(Ctx& c, const IvRec* A, int nA, const IvRec* B, int nB) {
+  SVec<IvRec> r = sc_vec<IvRec>(c, nA + nB + 1);
+  if (!c.failed) r.n = iv_subtract(r.p, A, nA, B, nB);
+  sc_trim(c, r);
+  return r;
+}
+EMAT_D SVec<IvRec> iv_copy_sc(Ctx& c, const IvRec* A, int nA) {
+  SVec<IvRec> r = sc_vec<IvRec>(c, nA);
+  if (!c.failed) { for (int i = 0; i < nA; ++i) r.p[i] = A[i]; r.n = nA; }
+  return r;
+}
+
+// ---- from-state lists (sorted by site) and node missation maps (mutations.h:184-232) ---------------------------
+EMAT_D int fs_lower_bound(const FsRec* v, int n, int l) { int lo = 0, hi = n; while (lo < hi) { int mid = (lo + hi) >> 1; if (v[mid].site < l) lo = mid + 1; else hi = mid; } return lo; }
+EMAT_D bool miss_contains(Ctx& c, int node, int l) { return iv_contains(miss_of(c, node), (int)c.N[node].miss.cnt, l); }
+EMAT_D int miss_get_from_state(Ctx& c, int node, int l) {
+  const FsRec* v = mfs_of(c, node); int n = (int)c.N[node].mfs.cnt;
+  int k = fs_lower_bound(v, n, l);
+  return (k < n && v[k].site == l) ? (int)v[k].state : (int)c.ref[l];
+}
+EMAT_DN void miss_set_from_state(Ctx& c, int node, int l, int from) {
+  ListRef& r = c.N[node].mfs;
+  FsRec* v = mfs_of(c, node); int n = (int)r.cnt;
+  int k = fs_lower_bound(v, n, l);
+  bool present = (k < n && v[k].site == l);
+  if (from != (int)c.ref[l]) {
+    if (present) { v[k].state = (uint8_t)from; return; }
+    list_reserve<FsRec>(c, r, n + 1);
+    if (c.failed) return;
+    v = mfs_of(c, node);
+    for (int i = n; i > k; --i) v[i] = v[i - 1];
+    v[k].site = l; v[k].state = (uint8_t)from; v[k].pad[0] = v[k].pad[1] = v[k].pad[2] = 0;
+    r.cnt = (uint16_t)(n + 1);
+  } else if (present) {
+    for (int i = k; i + 1 < n; ++i) v[i] = v[i + 1];
+    r.cnt = (uint16_t)(n - 1);
+  }
+}
+
+// ---- site deltas: sorted array of {site, from, to} (site_deltas.h:43-154) -----------------------------------------
+struct SdRec { int32_t site; uint8_t from, to; uint16_t pad; };
+EMAT_D int sd_lower_bound(const SdRec* v, int n, int l) { int lo = 0, hi = n; while (lo < hi) { int mid = (lo + hi) >> 1; if (v[mid].site < l) lo = mid + 1; else hi = mid; } return lo; }
+EMAT_D bool sd_contains(const SVec<SdRec>& v, int l) { int k = sd_lower_bound(v.p, v.n, l); return k < v.n && v.p[k].site == l; }
+EMAT_D void sd_insert_at(Ctx& c, SVec<SdRec>& v, int k, int site, int from, int to) {
+  if (v.n >= v.cap) { EMAT_FAIL(c, k_part_overflow); return; }
+  for (int i = v.n; i > k; --i) v.p[i] = v.p[i - 1];
+  v.p[k].site = site; v.p[k].from = (uint8_t)from; v.p[k].to = (uint8_t)to; v.p[k].pad = 0; v.n++;
+}
+EMAT_D void sd_erase_at(SVec<SdRec>& v, int k) { for (int i = k; i + 1 < v.n; ++i) v.p[i] = v.p[i + 1]; v.n--; }
+EMAT_DN void sd_push_front(Ctx& c, SVec<SdRec>& v, int site, int from, int to) {   // site_deltas.h:43-65
+  int k = sd_lower_bound(v.p, v.n, site);
+  if (k < v.n && v.p[k].site == site) {
+    EMAT_CHECK(c, to == (int)v.p[k].from);
+    v.p[k].from = (uint8_t)from;
+    if (v.p[k].from == v.p[k].to) sd_erase_at(v, k);
+  } else sd_insert_at(c, v, k, site, from, to);
+}
+EMAT_D void sd_pop_front(Ctx& c, SVec<SdRec>& v, int site, int from, int to) { sd_push_front(c, v, site, to, from); }
+EMAT_DN void sd_push_back(Ctx& c, SVec<SdRec>& v, int site, int from, int to) {    // site_deltas.h:88-110
+  int k = sd_lower_bound(v.p, v.n, site);
+  if (k < v.n && v.p[k].site == site) {
+    EMAT_CHECK(c, from == (int)v.p[k].to);
+    v.p[k].to = (uint8_t)to;
+    if (v.p[k].from == v.p[k].to) sd_erase_at(v, k);
+  } else sd_insert_at(c, v, k, site, from, to);
+}
+
+// ---- genetic-likelihood calculus (phylo_tree_calc.h:121-206, phylo_tree_calc.cpp:41-118,406-456) ----------------
+EMAT_DN double delta_lambda_across_missations(Ctx& c, const IvRec* iv, int niv, const FsRec* fs, int nfs) {   // h:121-138
+  double r = 0.0;
+  for (int i = 0; i < niv; ++i) r -= c.cumQ[iv[i].end] - c.cumQ[iv[i].start];
+  for (int i = 0; i < nfs; ++i) { int l = fs[i].site; r -= c.mu[c.part[l]] * c.nu[l] * (q_a(c, l, fs[i].state) - q_a(c, l, c.ref[l])); }
+  return r;
+}
+EMAT_D double delta_lambda_across_node_missations(Ctx& c, int node) {
+  return delta_lambda_across_missations(c, miss_of(c, node), (int)c.N[node].miss.cnt, mfs_of(c, node), (int)c.N[node].mfs.cnt);
+}
+EMAT_D double delta_lambda_across_branch(Ctx& c, int node) {   // h:140-155
+  double r = 0.0;
+  const MutRec* m = muts_of(c, node); int nm = nmuts(c, node);
+  for (int i = 0; i < nm; ++i) { int l = m[i].site; r += c.mu[c.part[l]] * c.nu[l] * (q_a(c, l, m[i].to) - q_a(c, l, m[i].from)); }
+  r += delta_lambda_across_node_missations(c, node);
+  return r;
+}
+EMAT_DN double calc_lambda_at_node(Ctx& c, int node) {   // cpp:406-418
+  double r = c.cumQ[c.L];
+  for (int cur = node; cur != k_no_node; cur = c.N[cur].parent) r += delta_lambda_across_branch(c, cur);
+  return r;
+}
+EMAT_DN double branch_log_G(const Ctx& c, double t_P, double t_X, double lambda_X, const MutRec* m, int nm) {   // h:185-206
+  double r = -lambda_X * (t_X - t_P);
+  for (int i = nm - 1; i >= 0; --i) {
+    int l = m[i].site;
+    r -= c.mu[c.part[l]] * c.nu[l] * (q_a(c, l, m[i].from) - q_a(c, l, m[i].to)) * (m[i].t - t_P);
+    r += log(c.mu[c.part[l]] * c.nu[l] * q_ab(c, l, m[i].from, m[i].to));
+  }
+  return r;
+}
+EMAT_DN int calc_site_state_at(Ctx& c, int branch, double t, int l) {   // cpp:108-118
+  for (int cur = branch; cur != k_no_node; cur = c.N[cur].parent) {
+    const MutRec* m = muts_of(c, cur);
+    for (int i = nmuts(c, cur) - 1; i >= 0; --i) { if (m[i].t > t) continue; if (m[i].site == l) return m[i].to; }
+  }
+  return c.ref[l];
+}
+EMAT_D bool is_site_missing_at(Ctx& c, int node, int l) {   // cpp:58-65
+  for (int cur = node; cur != k_no_node; cur = c.N[cur].parent) if (miss_contains(c, cur, l)) return true;
+  return false;
+}
+// cpp:41-56; result in scratch
+EMAT_DN SVec<IvRec> reconstruct_missing_sites_at(Ctx& c, int node) {
+  int total = 0;
+  for (int cur = node; cur != k_no_node; cur = c.N[cur].parent) total += (int)c.N[cur].miss.cnt;
+  SVec<IvRec> a = sc_vec<IvRec>(c, total + 1), b = sc_vec<IvRec>(c, total + 1);
+  if (c.failed) return a;
+  IvRec* so_far = a.p; IvRec* other = b.p; int n = 0;
+  for (int cur = node; cur != k_no_node; cur = c.N[cur].parent) {
+    int k = iv_merge(other, so_far, n, miss_of(c, cur), (int)c.N[cur].miss.cnt);
+    IvRec* t = so_far; so_far = other; other = t; n = k;
+  }
+  SVec<IvRec> r; r.p = so_far; r.n = n; r.cap = total + 1;
+  return r;
+}
+EMAT_D bool descends_from(Ctx& c, int X, int A) {   // phylo_tree.cpp:292-299
+  if (A == k_no_node) return true;
+  for (int cur = X; cur != k_no_node; cur = c.N[cur].parent) {
+    if (cur == A) return true;
+    if (c.N[cur].t < c.N[A].t) return false;
+  }
+  return false;
+}
+EMAT_DN int find_MRCA_of(Ctx& c, int P, int Q) {   // phylo_tree.cpp:204-280
+  if (P == k_no_node) return P;
+  if (Q == k_no_node) return Q;
+  int guard = 0;
+  while (P != Q && guard++ < (1 << 28)) {
+    double tP = c.N[P].t, tQ = c.N[Q].t;
+    if (tP > tQ) { P = c.N[P].parent; EMAT_CHECK(c, P != k_no_node); if (P == k_no_node) return Q; }
+    else if (tP < tQ) { Q = c.N[Q].parent; EMAT_CHECK(c, Q != k_no_node); if (Q == k_no_node) return P; }
+    else if (is_tip(c, P)) { P = c.N[P].parent; if (P == k_no_node) return Q; }
+    else if (is_tip(c, Q)) { Q = c.N[Q].parent; if (Q == k_no_node) return P; }
+    else {
+      // equal times, distinct inner nodes (rare): deepest common node of the two root paths
+      int dP = 0, dQ = 0;
+      for (int x = P; x != k_no_node; x = c.N[x].parent) ++dP;
+      for (int x = Q; x != k_no_node; x = c.N[x].parent) ++dQ;
+      int a = P, b = Q;
+      while (dP > dQ) { a = c.N[a].parent; --dP; }
+      while (dQ > dP) { b = c.N[b].parent; --dQ; }
+      while (a != b) { a = c.N[a].parent; b = c.N[b].parent; }
+      return a;
+    }
+  }
+  return P;
+}
+
+// ---- population models (pop_model.cpp:18-145, 181-204, 247-330, 525-560) ------------------------------------------
+EMAT_D int skygrid_interval(const PopTable& p, double t) {   // lower_bound on knots
+  int lo = 0, hi = p.skygrid_num_knots;
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (p.skygrid_x[mid] < t) lo = mid + 1; else hi = mid; }
+  return lo;   // 0 .. M+1
+}
+EMAT_D double skygrid_log_N(const PopTable& p, double t) {
+  int k = skygrid_interval(p, t), M = p.skygrid_num_knots - 1;
+  if (k == 0) return p.skygrid_gamma[0];
+  if (k > M) return p.skygrid_gamma[M];
+  if (p.skygrid_type == 1) return p.skygrid_gamma[k];
+  double cc = (t - p.skygrid_x[k - 1]) / (p.skygrid_x[k] - p.skygrid_x[k - 1]);
+  return (1 - cc) * p.skygrid_gamma[k - 1] + cc * p.skygrid_gamma[k];
+}
+EMAT_DN double pop_at_time(const PopTable& p, double t) {
+  if (p.kind == 0) return p.p[0];
+  if (p.kind == 1) { double v = p.p[1] * exp((t - p.p[0]) * p.p[2]); return p.p[3] > v ? p.p[3] : v; }
+  return exp(skygrid_log_N(p, t));
+}
+EMAT_D double exp_unclamped_int(const PopTable& p, double a, double b) { double n0 = p.p[1], g = p.p[2], t0 = p.p[0]; return n0 / g * exp(g * (a - t0)) * expm1(g * (b - a)); }
+EMAT_DN double skygrid_log_int_N(const PopTable& p, double a, double b) {   // pop_model.cpp:247-330 with gamma_eff = gamma
+  const double* x = p.skygrid_x; const double* ge = p.skygrid_gamma;
+  int M = p.skygrid_num_knots - 1;
+  int ka = skygrid_interval(p, a), kb = skygrid_interval(p, b);
+  int kka = ka - 1 > 0 ? ka - 1 : 0, kkb = kb < M ? kb : M;
+  double bias = -k_inf;
+  for (int k = kka; k <= kkb; ++k) bias = bias > ge[k] ? bias : ge[k];
+  double result = 0.0;
+  for (int k = ka; k <= kb; ++k) {
+    double lo = k > 0 ? (a > x[k - 1] ? a : x[k - 1]) : a;
+    double hi = k <= M ? (b < x[k] ? b : x[k]) : b;
+    if (k == 0) result += exp(-bias + ge[0]) * (hi - lo);
+    else if (k == M + 1) result += exp(-bias + ge[M]) * (hi - lo);
+    else if (p.skygrid_type == 1) result += exp(-bias + ge[k]) * (hi - lo);
+    else if (ge[k] == ge[k - 1]) result += exp(-bias + ge[k]) * (hi - lo);
+    else {
+      double c_lo = (lo - x[k - 1]) / (x[k] - x[k - 1]), c_hi = (hi - x[k - 1]) / (x[k] - x[k - 1]);
+      double G_lo = (1 - c_lo) * ge[k - 1] + c_lo * ge[k], G_hi = (1 - c_hi) * ge[k - 1] + c_hi * ge[k];
+      double D = G_hi - G_lo;
+      if (D == 0.0) result += exp(-bias + G_lo) * (hi - lo);
+      else result += exp(-bias + G_lo) * (hi - lo) * (expm1(D) / D);
+    }
+  }
+  return log(result) + bias;
+}
+EMAT_DN double pop_integral(const PopTable& p, double a, double b) {
+  if (p.kind == 0) return (b - a) * p.p[0];
+  if (p.kind == 1) {   // pop_model.cpp:43-91
+    double n0 = p.p[1], g = p.p[2], t0 = p.p[0], min_pop = p.p[3], t_c = p.t_c;
+    if (min_pop == 0.0) return g == 0.0 ? (b - a) * n0 : exp_unclamped_int(p, a, b);
+    if (g == 0.0) return (b - a) * (min_pop > n0 ? min_pop : n0);
+    if (g > 0.0) {
+      if (b <= t_c) return (b - a) * min_pop;
+      if (a >= t_c) return exp_unclamped_int(p, a, b);
+      return (t_c - a) * min_pop + n0 / g * exp(g * (t_c - t0)) * expm1(g * (b - t_c));
+    }
+    if (a >= t_c) return (b - a) * min_pop;
+    if (b <= t_c) return exp_unclamped_int(p, a, b);
+    return n0 / g * exp(g * (a - t0)) * expm1(g * (t_c - a)) + (b - t_c) * min_pop;
+  }
+  return exp(skygrid_log_int_N(p, a, b));
+}
+
+// ---- per-part coalescent prior (very_scalable_coalescent.cpp:14-79, 259-459) ----------------------------------------
+// The part stores only its window of cells [cell_first, cell_first + n_cells): outside it k_bar_p is
+// identically zero for the whole residency, so those cells contribute nothing (cpp:355-386).
+struct Cells { double* kbar_p; double* ktw_p; double* ktw; double* popsize; int32_t* nactive; };
+EMAT_D Cells cells_of(Ctx& c) {
+  Cells k; int cap = c.H->cell_cap;
+  double* base = (double*)(c.S + c.H->off_cells);
+  k.kbar_p = base; k.ktw_p = base + cap; k.ktw = base + 2 * cap; k.popsize = base + 3 * cap; k.nactive = (int32_t*)(base + 4 * cap);
+  return k;
+}
+EMAT_D int cell_for(const Ctx& c, double t) { return (int)floor((c.H->t_ref - t) / c.H->t_step); }
+EMAT_D double cell_ubound(const Ctx& c, int cell) { return c.H->t_ref - c.H->t_step * cell; }
+EMAT_D double cell_lbound(const Ctx& c, int cell) { return cell_ubound(c, cell) - c.H->t_step; }
+// cpp:259-299 (only the root part may grow, towards the past)
+EMAT_DN void coal_ensure_space(Ctx& c, double t) {
+  int cell = cell_for(c, t);
+  if (c.includes_run_root) {
+    Cells k = cells_of(c);
+    while (c.H->n_cells_total <= cell) {
+      int i = c.H->n_cells_total, w = i - c.H->cell_first;
+      if (w >= c.H->cell_cap) { EMAT_FAIL(c, k_part_cell_overflow); return; }
+      double popsize_bar_i = pop_integral(*c.pop, cell_lbound(c, i), cell_ubound(c, i)) / c.H->t_step;
+      double sigma = sqrt(popsize_bar_i / c.H->t_step);
+      double ktw = gaussian(c, 0.0, sigma);
+      k.popsize[w] = popsize_bar_i; k.nactive[w] = 1; k.kbar_p[w] = 1.0; k.ktw_p[w] = ktw; k.ktw[w] = ktw;
+      c.H->n_cells_total = i + 1; c.H->n_cells = w + 1;
+    }
+  }
+  if (cell < c.H->cell_first || cell >= c.H->n_cells_total) EMAT_FAIL(c, k_part_internal);
+}
+// cpp:37-79 on k_bar_p
+EMAT_DN void coal_add_interval(Ctx& c, double t_start, double t_end, double delta_k) {
+  if (c.failed) return;
+  if (t_start < t_end) { double t = t_start; t_start = t_end; t_end = t; }
+  Cells k = cells_of(c);
+  const int first = c.H->cell_first;
+  int cell_start = cell_for(c, t_start);
+  int cell_end = c.H->n_cells_total - 1;
+  if (t_end != cell_lbound(c, cell_end)) cell_end = cell_for(c, t_end);
+  if (cell_start < first || cell_end >= c.H->n_cells_total || cell_start > cell_end) { EMAT_FAIL(c, k_part_internal); return; }
+  const double ts = c.H->t_step;
+  if (cell_start == cell_end) k.kbar_p[cell_start - first] += delta_k * (t_start - t_end) / ts;
+  else {
+    k.kbar_p[cell_start - first] += delta_k * (t_start - cell_lbound(c, cell_start)) / ts;
+    k.kbar_p[cell_end - first] += delta_k * (cell_ubound(c, cell_end) - t_end) / ts;
+    for (int i = cell_start + 1; i < cell_end; ++i) k.kbar_p[i - first] += delta_k;
+  }
+  c.bytes += 8 * (int64_t)(cell_end - cell_start + 1);
+}
+EMAT_D double coal_cell_term(const Ctx& c, const Cells& k, int w, double new_k, double old_k) {
+  double na = (double)k.nactive[w];
+  return c.H->t_step / k.popsize[w] * (
+      +0.5 * (new_k * new_k - old_k * old_k) * na
+      - (k.ktw_p[w] * na - k.ktw[w] + 0.5) * (new_k - old_k));
+}
+// cpp:388-459
+EMAT_DN double coal_delta_on_add_interval(Ctx& c, double min_t, double max_t, double delta_k) {
+  { int cm = cell_for(c, max_t); if (cm < c.H->cell_first || cm >= c.H->n_cells_total) { EMAT_FAIL(c, k_part_internal); return 0.0; } }
+  coal_ensure_space(c, min_t);
+  if (c.failed) return 0.0;
+  if (min_t == max_t) return 0.0;
+  Cells k = cells_of(c);
+  const int first = c.H->cell_first; const double ts = c.H->t_step;
+  int cell_start = cell_for(c, max_t), cell_end = cell_for(c, min_t);
+  double d = 0.0;
+  if (cell_start == cell_end) {
+    int w = cell_start - first;
+    double old_k = k.kbar_p[w], new_k = old_k + delta_k * (max_t - min_t) / ts;
+    d -= coal_cell_term(c, k, w, new_k, old_k);
+  } else {
+    int i = cell_start;
+    double dt_start = max_t - cell_lbound(c, cell_start);
+    double dt_end = cell_ubound(c, cell_end) - min_t;
+    double old_k = k.kbar_p[i - first], new_k = old_k + delta_k * dt_start / ts;
+    d -= coal_cell_term(c, k, i - first, new_k, old_k);
+    for (++i; i < cell_end; ++i) { old_k = k.kbar_p[i - first]; new_k = old_k + delta_k; d -= coal_cell_term(c, k, i - first, new_k, old_k); }
+    old_k = k.kbar_p[i - first]; new_k = old_k + delta_k * dt_end / ts;
+    d -= coal_cell_term(c, k, i - first, new_k, old_k);
+  }
+  c.bytes += 36 * (int64_t)(cell_end - cell_start + 1);
+  return d;
+}
+EMAT_D double coal_delta_displace_coalescence(Ctx& c, double old_t, double new_t) {   // cpp:310-326
+  double d = (old_t <= new_t) ? coal_delta_on_add_interval(c, old_t, new_t, -1.0) : coal_delta_on_add_interval(c, new_t, old_t, +1.0);
+  d -= log(pop_at_time(*c.pop, new_t) / pop_at_time(*c.pop, old_t));
+  return d;
+}
+EMAT_D double coal_delta_displace_tip(Ctx& c, double old_t, double new_t) {           // cpp:337-353
+  return (old_t <= new_t) ? coal_delta_on_add_interval(c, old_t, new_t, +1.0) : coal_delta_on_add_interval(c, new_t, old_t, -1.0);
+}
+EMAT_D void coal_coalescence_displaced(Ctx& c, double old_t, double new_t) {           // cpp:301-308
+  coal_ensure_space(c, new_t);
+  coal_add_interval(c, old_t, new_t, old_t <= new_t ? -1.0 : +1.0);
+}
+EMAT_D void coal_tip_displaced(Ctx& c, double old_t, double new_t) {                   // cpp:328-335
+  coal_ensure_space(c, new_t);
+  coal_add_interval(c, old_t, new_t, old_t <= new_t ? +1.0 : -1.0);
+}
+
+// ---- incomplete gamma (replaces Boost gamma_q / gamma_q_inv used at spr_study.cpp:368,463,544;
+//      series / modified-Lentz continued fraction, inverse by Halley steps) --------------------------------------------
+EMAT_DN double gamma_q(double a, double x) {
+  if (x == 0.0) return 1.0;
+  if (isinf(x)) return 0.0;
+  const double lg = lgamma(a);
+  if (x < a + 1.0) {
+    double ap = a, sum = 1.0 / a, del = sum;
+    for (int n = 0; n < 100000; ++n) { ap += 1.0; del *= x / ap; sum += del; if (fabs(del) < fabs(sum) * 1e-17) break; }
+    return 1.0 - sum * exp(-x + a * log(x) - lg);
+  }
+  const double FPMIN = 1e-300;
+  double b = x + 1.0 - a, cc = 1.0 / FPMIN, d = 1.0 / b, h = d;
+  for (int i = 1; i < 100000; ++i) {
+    double an = -i * (i - a);
+    b += 2.0;
+    d = an * d + b; if (fabs(d) < FPMIN) d = FPMIN;
+    cc = b + an / cc; if (fabs(cc) < FPMIN) cc = FPMIN;
+    d = 1.0 / d;
+    double del = d * cc; h *= del;
+    if (fabs(del - 1.0) < 1e-16) break;
+  }
+  return exp(-x + a * log(x) - lg) * h;
+}
+EMAT_DN double gamma_q_inv(double a, double q) {
+  if (q == 0.0) return k_inf;
+  if (q == 1.0) return 0.0;
+  const double lg = lgamma(a);
+  const double p = 1.0 - q;
+  double x;
+  if (a > 1.0) {
+    double pp = (p < 0.5) ? p : q;
+    double t = sqrt(-2.0 * log(pp));
+    double xg = (2.30753 + t * 0.27061) / (1.0 + t * (0.99229 + t * 0.04481)) - t;
+    if (p < 0.5) xg = -xg;
+    double v = a * pow(1.0 - 1.0 / (9.0 * a) - xg / (3.0 * sqrt(a)), 3.0);
+    x = v > 1e-3 ? v : 1e-3;
+  } else {
+    double t = 1.0 - a * (0.253 + a * 0.12);
+    if (p < t) x = pow(p / t, 1.0 / a);
+    else x = 1.0 - log(1.0 - (p - t) / (1.0 - t));
+  }
+  const double a1 = a - 1.0;
+  for (int j = 0; j < 60; ++j) {
+    if (x <= 0.0) x = 1e-300;
+    double err = gamma_q(a, x) - q;
+    double tdens = exp(-x + a1 * log(x) - lg);
+    if (tdens == 0.0) break;
+    double u = -err / tdens;
+    double w = u * (a1 / x - 1.0);
+    double dx = u / (1.0 - 0.5 * (w < 1.0 ? w : 1.0));
+    double xn = x - dx;
+    if (xn <= 0.0) xn = 0.5 * x;
+    double tol = 1e-15 * (xn > 1e-300 ? xn : 1e-300);
+    if (fabs(xn - x) < tol) { x = xn; break; }
+    x = xn;
+  }
+  return x;
+}
+
+}  // namespace dev
+}  // namespace emat
+#endif  // EMAT_DEVICE_CORE_HPP_

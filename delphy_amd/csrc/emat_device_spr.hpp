@@ -1,0 +1,1053 @@
+// emat_device_spr.hpp -- device-side SPR machinery of the EMAT local-move engine (gfx950).
+//
+// Covers SURVEY section 8(a) rows a10-a16: site-delta tracking, the candidate-region scan
+// (reference core/spr_study.cpp:9-549), graft analysis / peel / apply for inner and rooty grafts
+// (core/spr_move.cpp:91-1069), the topological move through elementary tree edits
+// (core/spr_move.cpp:1101-1156, core/tree_editing.cpp:7-302) and JC69 mutational-history sampling
+// (core/spr_move.cpp:1158-1439).  All temporaries live in the part's scratch region; all node lists
+// live in the slab heap.  Unordered maps of the reference become site-sorted arrays (every
+// order-sensitive use in the reference is followed by a (t, site) sort).
+#ifndef EMAT_DEVICE_SPR_HPP_
+#define EMAT_DEVICE_SPR_HPP_
+
+#include "emat_device_core.hpp"
+
+namespace emat {
+namespace dev {
+
+// ---- scratch missation map ("sliding_missations", spr_move.cpp:615-698) ------------------------------------
+EMAT_DN void fsv_set(Ctx& c, SVec<FsRec>& v, int l, int from) {   // Missation_map::set_from_state on a scratch list
+  int k = fs_lower_bound(v.p, v.n, l);
+  bool present = (k < v.n && v.p[k].site == l);
+  if (from != (int)c.ref[l]) {
+    if (present) { v.p[k].state = (uint8_t)from; return; }
+    if (v.n >= v.cap) { EMAT_FAIL(c, k_part_overflow); return; }
+    for (int i = v.n; i > k; --i) v.p[i] = v.p[i - 1];
+    v.p[k].site = l; v.p[k].state = (uint8_t)from; v.p[k].pad[0] = v.p[k].pad[1] = v.p[k].pad[2] = 0; v.n++;
+  } else if (present) { for (int i = k; i + 1 < v.n; ++i) v.p[i] = v.p[i + 1]; v.n--; }
+}
+
+// Rebuild the root's "mutations" (ref -> root deltas, t = -DBL_MAX) from a delta list, in site order.
+EMAT_DN void set_root_muts_from_deltas(Ctx& c, int root, const SVec<SdRec>& d) {
+  ListRef& r = c.N[root].muts;
+  list_reserve<MutRec>(c, r, d.n);
+  if (c.failed) return;
+  MutRec* m = list_ptr<MutRec>(c, r);
+  for (int i = 0; i < d.n; ++i) { EMAT_CHECK(c, c.ref[d.p[i].site] == d.p[i].from); m[i] = make_mut(d.p[i].from, d.p[i].site, d.p[i].to, k_neg_dbl_max); }
+  r.cnt = (uint16_t)d.n;
+}
+EMAT_DN SVec<SdRec> deltas_from_root_muts(Ctx& c, int root, int extra_cap) {
+  SVec<SdRec> d = sc_vec<SdRec>(c, nmuts(c, root) + extra_cap + 1);
+  const MutRec* m = muts_of(c, root);
+  for (int i = 0; i < nmuts(c, root); ++i) sd_push_back(c, d, m[i].site, m[i].from, m[i].to);
+  return d;
+}
+EMAT_D int path_mut_count(Ctx& c, int from_node) { int s = 0; for (int cur = from_node; cur != k_no_node; cur = c.N[cur].parent) s += nmuts(c, cur); return s; }
+
+// =================================================================================================
+// Tree editing (tree_editing.cpp:7-302)
+// =================================================================================================
+struct Edit { int X; SVec<SdRec> deltas; };
+
+// Node missations <- merge(node, other) (mutations.h:315-336)
+EMAT_DN void node_merge_missations_from(Ctx& c, int dst, int other) {
+  uint32_t mark = c.sc_top;
+  int na = (int)c.N[dst].miss.cnt, nb = (int)c.N[other].miss.cnt;
+  SVec<IvRec> iv = sc_vec<IvRec>(c, na + nb + 1);
+  int fa = (int)c.N[dst].mfs.cnt, fb = (int)c.N[other].mfs.cnt;
+  SVec<FsRec> fs = sc_vec<FsRec>(c, fa + fb + 1);
+  if (!c.failed) {
+    iv.n = iv_merge(iv.p, miss_of(c, dst), na, miss_of(c, other), nb);
+    const FsRec* A = mfs_of(c, dst); const FsRec* B = mfs_of(c, other);
+    int i = 0, j = 0;
+    while (i < fa || j < fb) {
+      if (j == fb || (i < fa && A[i].site < B[j].site)) fs.p[fs.n++] = A[i++];
+      else if (i == fa || B[j].site < A[i].site) fs.p[fs.n++] = B[j++];
+      else { fs.p[fs.n++] = A[i++]; ++j; }   // map::insert keeps the first
+    }
+    list_assign<IvRec>(c, c.N[dst].miss, iv.p, iv.n);
+    list_assign<FsRec>(c, c.N[dst].mfs, fs.p, fs.n);
+  }
+  c.sc_top = mark;
+}
+// factor_out_common_missations(A, B, common) (mutations.h:250-312); `common` node's lists are replaced
+EMAT_DN void node_factor_out_common(Ctx& c, int a, int b, int common) {
+  uint32_t mark = c.sc_top;
+  int na = (int)c.N[a].miss.cnt, nb = (int)c.N[b].miss.cnt;
+  SVec<IvRec> ic = sc_vec<IvRec>(c, na + nb + 1), ia = sc_vec<IvRec>(c, 2 * (na + nb) + 2), ib = sc_vec<IvRec>(c, 2 * (na + nb) + 2);
+  int fa = (int)c.N[a].mfs.cnt, fb = (int)c.N[b].mfs.cnt;
+  SVec<FsRec> fca = sc_vec<FsRec>(c, fa + 1), fcb = sc_vec<FsRec>(c, fb + 1), fcc = sc_vec<FsRec>(c, fa + 1);
+  if (!c.failed) {
+    ic.n = iv_intersect(ic.p, miss_of(c, a), na, miss_of(c, b), nb);
+    ia.n = iv_subtract(ia.p, miss_of(c, a), na, ic.p, ic.n);
+    ib.n = iv_subtract(ib.p, miss_of(c, b), nb, ic.p, ic.n);
+    const FsRec* A = mfs_of(c, a); const FsRec* B = mfs_of(c, b);
+    int i = 0, j = 0;
+    while (i < fa && j < fb) {
+      if (A[i].site < B[j].site) fca.p[fca.n++] = A[i++];
+      else if (B[j].site < A[i].site) fcb.p[fcb.n++] = B[j++];
+      else { fcc.p[fcc.n++] = A[i++]; ++j; }
+    }
+    while (i < fa) fca.p[fca.n++] = A[i++];
+    while (j < fb) fcb.p[fcb.n++] = B[j++];
+    list_assign<IvRec>(c, c.N[a].miss, ia.p, ia.n); list_assign<FsRec>(c, c.N[a].mfs, fca.p, fca.n);
+    list_assign<IvRec>(c, c.N[b].miss, ib.p, ib.n); list_assign<FsRec>(c, c.N[b].mfs, fcb.p, fcb.n);
+    list_assign<IvRec>(c, c.N[common].miss, ic.p, ic.n); list_assign<FsRec>(c, c.N[common].mfs, fcc.p, fcc.n);
+  }
+  c.sc_top = mark;
+}
+
+EMAT_DN void edit_slide_root(Ctx& c, Edit& e, double new_t_P) {   // tree_editing.cpp:114-158
+  const int X = e.X, P = c.N[X].parent;
+  EMAT_CHECK(c, P == c.H->root);
+  double old_t_P = c.N[P].t;
+  int S = sibling_of(c, P, X);
+  if (new_t_P > old_t_P) {
+    MutRec* mS = muts_of(c, S); int nS = nmuts(c, S);
+    int last = 0; while (last < nS && !(mS[last].t > new_t_P)) ++last;
+    if (last != 0) {
+      uint32_t mark = c.sc_top;
+      SVec<SdRec> r2r = deltas_from_root_muts(c, P, last);
+      for (int i = 0; i < last && !c.failed; ++i) {
+        MutRec m = mS[i];
+        sd_push_back(c, r2r, m.site, m.from, m.to);
+        if (!miss_contains(c, X, m.site)) sd_push_front(c, e.deltas, m.site, m.to, m.from);
+        else miss_set_from_state(c, X, m.site, m.to);
+        c.N[P].lambda += dq(c, m.site, m.from, m.to);
+      }
+      set_root_muts_from_deltas(c, P, r2r);
+      list_erase_prefix<MutRec>(c, c.N[S].muts, last);
+      c.sc_top = mark;
+    }
+  }
+  c.N[P].t = new_t_P;
+}
+EMAT_DN void edit_slide_P_along_branch(Ctx& c, Edit& e, double new_t_P) {   // tree_editing.cpp:31-112
+  const int X = e.X, P = c.N[X].parent;
+  EMAT_CHECK(c, !is_tip(c, P));
+  if (P == c.H->root) { edit_slide_root(c, e, new_t_P); return; }
+  double old_t_P = c.N[P].t;
+  int S = sibling_of(c, P, X);
+  if (new_t_P < old_t_P) {
+    MutRec* mP = muts_of(c, P); int nP = nmuts(c, P);
+    int first = 0; while (first < nP && !(mP[first].t >= new_t_P)) ++first;
+    if (first != nP) {
+      // the tail of G-P moves (in time order) to the FRONT of P-S
+      int k = nP - first;
+      int kept = 0;
+      for (int i = first; i < nP; ++i) if (!miss_contains(c, S, mP[i].site)) ++kept;
+      int nS = nmuts(c, S);
+      list_reserve<MutRec>(c, c.N[S].muts, nS + kept);
+      if (c.failed) return;
+      MutRec* mS = muts_of(c, S); mP = muts_of(c, P);
+      for (int i = nS - 1; i >= 0; --i) mS[i + kept] = mS[i];
+      int w = kept;
+      for (int i = nP - 1; i >= first && !c.failed; --i) {
+        MutRec m = mP[i];
+        if (!miss_contains(c, S, m.site)) { mS[--w] = m; }
+        else miss_set_from_state(c, S, m.site, m.from);
+        if (!miss_contains(c, X, m.site)) sd_push_front(c, e.deltas, m.site, m.from, m.to);
+        else miss_set_from_state(c, X, m.site, m.from);
+        c.N[P].lambda += dq(c, m.site, m.to, m.from);
+      }
+      c.N[S].muts.cnt = (uint16_t)(nS + kept);
+      c.N[P].muts.cnt = (uint16_t)first;
+      (void)k;
+    }
+  } else {
+    MutRec* mS = muts_of(c, S); int nS = nmuts(c, S);
+    int last = 0; while (last < nS && !(mS[last].t > new_t_P)) ++last;
+    if (last != 0) {
+      list_reserve<MutRec>(c, c.N[P].muts, nmuts(c, P) + last);
+      if (c.failed) return;
+      mS = muts_of(c, S);
+      for (int i = 0; i < last && !c.failed; ++i) {
+        MutRec m = mS[i];
+        MutRec* mP = muts_of(c, P); mP[c.N[P].muts.cnt] = m; c.N[P].muts.cnt++;
+        if (!miss_contains(c, X, m.site)) sd_push_front(c, e.deltas, m.site, m.to, m.from);
+        else miss_set_from_state(c, X, m.site, m.to);
+        c.N[P].lambda += dq(c, m.site, m.from, m.to);
+      }
+      list_erase_prefix<MutRec>(c, c.N[S].muts, last);
+    }
+  }
+  c.N[P].t = new_t_P;
+}
+EMAT_DN void edit_do_hop_up(Ctx& c, int X) {   // tree_editing.cpp:164-231
+  EMAT_CHECK(c, X != c.H->root);
+  const int P = c.N[X].parent;
+  EMAT_CHECK(c, !is_tip(c, P) && P != c.H->root && nmuts(c, P) == 0);
+  const int G = c.N[P].parent;
+  if (c.failed || G == k_no_node) { EMAT_FAIL(c, k_part_internal); return; }
+  EMAT_CHECK(c, c.N[P].t == c.N[G].t);
+  const int U = sibling_of(c, G, P);
+  const int S = sibling_of(c, P, X);
+  if (c.N[P].miss.cnt != 0) {
+    node_merge_missations_from(c, X, P);
+    node_merge_missations_from(c, S, P);
+    c.N[P].miss.cnt = 0; c.N[P].mfs.cnt = 0;
+  }
+  swap_lists(c.N[P].muts, c.N[G].muts);
+  swap_lists(c.N[P].miss, c.N[G].miss);
+  swap_lists(c.N[P].mfs, c.N[G].mfs);
+  EMAT_CHECK(c, c.N[G].miss.cnt == 0);
+  if (iv_intersects(miss_of(c, S), (int)c.N[S].miss.cnt, miss_of(c, U), (int)c.N[U].miss.cnt)) node_factor_out_common(c, S, U, G);
+  if (G == c.H->root) { c.H->root = P; c.N[P].parent = k_no_node; }
+  else {
+    int GG = c.N[G].parent, GU = sibling_of(c, GG, G);
+    c.N[GG].child0 = P; c.N[GG].child1 = GU;
+    c.N[P].parent = GG;
+  }
+  c.N[P].child0 = X; c.N[P].child1 = G;
+  c.N[G].parent = P;
+  c.N[G].child0 = S; c.N[G].child1 = U;
+  c.N[S].parent = G;
+  c.N[P].lambda = c.N[G].lambda;
+  c.N[P].n_missing = c.N[G].n_missing;
+  c.N[G].lambda = c.N[P].lambda + delta_lambda_across_node_missations(c, G);
+  c.N[G].n_missing = c.N[P].n_missing + iv_num_sites(miss_of(c, G), (int)c.N[G].miss.cnt);
+  c.bytes += 5 * 64;
+}
+EMAT_DN void edit_flip(Ctx& c, Edit& e) {   // tree_editing.cpp:233-278
+  const int X = e.X, P = c.N[X].parent;
+  EMAT_CHECK(c, !is_tip(c, P) && P != c.H->root && nmuts(c, P) == 0);
+  const int G = c.N[P].parent;
+  if (c.failed || G == k_no_node) { EMAT_FAIL(c, k_part_internal); return; }
+  EMAT_CHECK(c, c.N[P].t == c.N[G].t);
+  const int U = sibling_of(c, G, P);
+  const int S = sibling_of(c, P, X);
+  if (c.N[P].miss.cnt != 0) {
+    node_merge_missations_from(c, S, P);
+    node_merge_missations_from(c, X, P);
+    c.N[P].miss.cnt = 0; c.N[P].mfs.cnt = 0;
+  }
+  if (iv_intersects(miss_of(c, X), (int)c.N[X].miss.cnt, miss_of(c, U), (int)c.N[U].miss.cnt)) node_factor_out_common(c, X, U, P);
+  c.N[G].child0 = S; c.N[G].child1 = P;
+  c.N[S].parent = G;
+  c.N[P].child0 = X; c.N[P].child1 = U;
+  c.N[U].parent = P;
+  c.N[P].lambda = c.N[G].lambda + delta_lambda_across_node_missations(c, P);
+  c.N[P].n_missing = c.N[G].n_missing + iv_num_sites(miss_of(c, P), (int)c.N[P].miss.cnt);
+  c.bytes += 5 * 64;
+}
+EMAT_D void edit_hop_down(Ctx& c, Edit& e, int SS) {   // tree_editing.cpp:280-292
+  const int P = c.N[e.X].parent;
+  EMAT_CHECK(c, SS != c.H->root);
+  const int U = c.N[SS].parent;
+  EMAT_CHECK(c, c.N[U].parent == P && nmuts(c, U) == 0);
+  if (c.failed) return;
+  edit_do_hop_up(c, sibling_of(c, U, SS));
+}
+// spr_move.cpp:1101-1156
+EMAT_DN void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) {
+  if (c.failed) return;
+  EMAT_CHECK(c, X != c.H->root);
+  const int P = c.N[X].parent, G = c.N[P].parent, S = sibling_of(c, P, X);
+  if (SS == P) SS = S;
+  int GG = c.N[SS].parent;
+  if (GG == P) GG = G;
+  const int A = find_MRCA_of(c, G, GG);
+  uint32_t mark = c.sc_top;
+  Edit e; e.X = X;
+  int cap = nmuts(c, X) + path_mut_count(c, P) + path_mut_count(c, SS) + 8;
+  e.deltas = sc_vec<SdRec>(c, cap);
+  {   // Tree_editing_session ctor (tree_editing.cpp:7-29)
+    const MutRec* m = muts_of(c, X);
+    for (int i = 0; i < nmuts(c, X); ++i) sd_push_back(c, e.deltas, m[i].site, m[i].from, m[i].to);
+    c.N[X].muts.cnt = 0;
+  }
+  int guard = 0;
+  while (!c.failed && c.N[P].parent != A && guard++ < (1 << 24)) {
+    edit_slide_P_along_branch(c, e, c.N[c.N[P].parent].t);
+    if (c.failed) break;
+    edit_do_hop_up(c, X);
+  }
+  if (!c.failed && !(descends_from(c, S, SS) || descends_from(c, SS, S))) {
+    EMAT_CHECK(c, A != k_no_node);
+    if (!c.failed) { edit_slide_P_along_branch(c, e, c.N[A].t); if (!c.failed) edit_flip(c, e); }
+  }
+  if (!c.failed) {
+    // branches from SS up to (excluding) X's current sibling, walked top-down
+    const int Xs_sib = sibling_of(c, P, X);
+    int depth = 0;
+    for (int cur = SS; cur != Xs_sib && cur != k_no_node; cur = c.N[cur].parent) ++depth;
+    for (int d = depth - 1; d >= 0 && !c.failed; --d) {
+      int Y = SS; for (int k = 0; k < d; ++k) Y = c.N[Y].parent;
+      edit_slide_P_along_branch(c, e, c.N[c.N[Y].parent].t);
+      if (c.failed) break;
+      edit_hop_down(c, e, Y);
+    }
+  }
+  if (!c.failed) {
+    EMAT_CHECK(c, sibling_of(c, P, X) == SS);
+    edit_slide_P_along_branch(c, e, new_t_P);
+  }
+  if (!c.failed) {   // Tree_editing_session::end (tree_editing.cpp:294-302)
+    EMAT_CHECK(c, nmuts(c, X) == 0);
+    if (e.deltas.n != 0) {
+      double mut_t = 0.5 * (c.N[X].t + c.N[c.N[X].parent].t);
+      list_reserve<MutRec>(c, c.N[X].muts, e.deltas.n);
+      if (!c.failed) {
+        MutRec* m = muts_of(c, X);
+        for (int i = 0; i < e.deltas.n; ++i) m[i] = make_mut(e.deltas.p[i].from, e.deltas.p[i].site, e.deltas.p[i].to, mut_t);
+        c.N[X].muts.cnt = (uint16_t)e.deltas.n;
+      }
+    }
+  }
+  c.sc_top = mark;
+}
+
+// =================================================================================================
+// Mutational-history sampling (spr_move.cpp:1158-1439)
+// =================================================================================================
+EMAT_D int choose_different_state(Ctx& c, int s) { int delta = 1 + uniform_int(c, 3); return (s + delta) % 4; }
+
+struct KTruncPoisson { double lambda; int min_k; double normalization, term_before_min_k, max_k; };   // distributions.h:77-175
+EMAT_DN KTruncPoisson ktp_make(double lambda, int min_k) {
+  KTruncPoisson d; d.lambda = lambda; d.min_k = min_k; d.normalization = 0.0; d.term_before_min_k = 0.0; d.max_k = 0.0;
+  if ((double)min_k <= lambda) return d;
+  d.max_k = (10.0 * min_k > 10.0 * lambda) ? 10.0 * min_k : 10.0 * lambda;
+  double last_term = 1.0, em1 = expm1(lambda);
+  d.normalization = em1;
+  for (int k = 1; k < min_k; ++k) { last_term *= lambda / k; d.normalization -= last_term; }
+  d.term_before_min_k = last_term;
+  if (d.normalization <= 0.0 || fabs(d.normalization) < 1e-10 * em1) {
+    d.normalization = 0.0;
+    double nlt = last_term;
+    for (int k = min_k; k < d.max_k; ++k) { nlt *= lambda / k; d.normalization += nlt; }
+  }
+  return d;
+}
+EMAT_DN int ktp_sample(Ctx& c, const KTruncPoisson& d) {
+  if (d.normalization == 0.0) { int guard = 0; while (guard++ < (1 << 26)) { int k = poisson(c, d.lambda); if (k >= d.min_k) return k; } return d.min_k; }
+  double u = uniform_co(c, 0.0, d.normalization);
+  double cum = 0.0; int k = d.min_k; double term = d.term_before_min_k;
+  while (k < d.max_k) { term *= d.lambda / k; cum += term; if (cum > u) break; ++k; }
+  return k;
+}
+EMAT_D void sort_doubles(double* p, int n) { for (int i = 1; i < n; ++i) { double x = p[i]; int j = i - 1; while (j >= 0 && p[j] > x) { p[j + 1] = p[j]; --j; } p[j + 1] = x; } }
+
+// Appends to `out` (open-ended scratch vector); returns false on overflow.  States of a trajectory are
+// drawn first (rejection on the end state), then its times, exactly as spr_move.cpp:1181-1227.
+EMAT_DN void sample_site_trajectory(Ctx& c, SVec<MutRec>& out, int l, int from, int to, const KTruncPoisson& dist, double T, bool accept_only_if_match, bool& accepted) {
+  // to_states and times are staged above `out`'s current end, inside its spare capacity
+  int n = 0; int s = from;
+  uint8_t states[64];
+  int guard = 0;
+  while (guard++ < (1 << 26)) {
+    n = ktp_sample(c, dist);
+    s = from;
+    for (int i = 0; i < n; ++i) { s = choose_different_state(c, s); if (i < 64) states[i] = (uint8_t)s; }
+    if (s == to) { accepted = true; break; }
+    if (!accept_only_if_match) { accepted = false; return; }   // caller restarts from scratch on its own terms
+  }
+  if (n > 64) { EMAT_FAIL(c, k_part_overflow); return; }
+  double times[64];
+  for (int i = 0; i < n; ++i) times[i] = uniform_co(c, -T, 0.0);
+  sort_doubles(times, n);
+  int prev = from;
+  for (int i = 0; i < n; ++i) { push(c, out, make_mut((uint8_t)prev, l, states[i], times[i])); prev = states[i]; }
+}
+// spr_move.cpp:1164-1370; result appended into a fresh open-ended scratch vector (caller trims)
+EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double mu, const SVec<SdRec>& deltas) {
+  SVec<MutRec> out = sc_vec<MutRec>(c, sc_room<MutRec>(c) > 4096 ? 4096 : (sc_room<MutRec>(c) > 0 ? sc_room<MutRec>(c) : 0));
+  if (c.failed) return out;
+  if (deltas.n != 0) {
+    KTruncPoisson ge1 = ktp_make(mu * T, 1);
+    for (int i = 0; i < deltas.n && !c.failed; ++i) { bool acc; sample_site_trajectory(c, out, deltas.p[i].site, deltas.p[i].from, deltas.p[i].to, ge1, T, true, acc); }
+  }
+  double muT = mu * T;
+  double p_0 = exp(-muT), p_1 = muT * p_0;
+  double log_one_minus_p_tricky = (muT < 1e-4) ? -0.5 * muT * muT : -muT - log1p(-p_1);
+  int l = 0;
+  if ((double)L * muT * muT < 2e-6) l = L;
+  int guard = 0;
+  while (l < L && !c.failed && guard++ < (1 << 26)) {
+    double u = exponential(c, -log_one_minus_p_tricky);
+    if (!(u >= 0 && u < (double)L)) break;
+    l += (int)floor(u);
+    if (l >= L) break;
+    if (sd_contains(deltas, l)) { ++l; continue; }
+    KTruncPoisson ge2 = ktp_make(mu * T, 2);
+    bool acc = false;
+    sample_site_trajectory(c, out, l, 0, 0, ge2, T, false, acc);
+    if (acc) ++l;
+  }
+  sort_muts(out.p, out.n);
+  sc_trim(c, out);
+  return out;
+}
+// spr_move.cpp:1372-1407
+EMAT_DN SVec<MutRec> sample_unconstrained_mutational_history(Ctx& c, int L, double T, double mu) {
+  SVec<MutRec> out = sc_vec<MutRec>(c, sc_room<MutRec>(c) > 4096 ? 4096 : (sc_room<MutRec>(c) > 0 ? sc_room<MutRec>(c) : 0));
+  if (c.failed) return out;
+  double t = 0.0;
+  int guard = 0;
+  while (!c.failed && guard++ < (1 << 26)) {
+    t -= exponential(c, mu * (double)L);
+    if (t <= -T) break;
+    int l = uniform_int(c, L);
+    // current state of site l going right-to-left = `from` of the most recently generated mutation on l, else A
+    int s = 0;
+    for (int i = out.n - 1; i >= 0; --i) if (out.p[i].site == l) { s = out.p[i].from; break; }
+    int ns = choose_different_state(c, s);
+    push(c, out, make_mut((uint8_t)ns, l, (uint8_t)s, t));
+  }
+  for (int i = 0, j = out.n - 1; i < j; ++i, --j) { MutRec tmp = out.p[i]; out.p[i] = out.p[j]; out.p[j] = tmp; }
+  sc_trim(c, out);
+  return out;
+}
+// spr_move.cpp:1409-1439
+EMAT_DN void adjust_mutational_history(Ctx& c, SVec<MutRec>& h, const SVec<SdRec>& deltas, int end_branch, double end_t) {
+  for (int i = h.n - 1; i >= 0; --i) {
+    MutRec& m = h.p[i];
+    m.t += end_t;
+    if (!sd_contains(deltas, m.site)) {
+      int end_state = calc_site_state_at(c, end_branch, end_t, m.site);   // pure function of (tree, site): memoisation not needed
+      int delta = end_state;
+      m.from = (uint8_t)((m.from + delta) % 4);
+      m.to = (uint8_t)((m.to + delta) % 4);
+    }
+  }
+}
+
+// =================================================================================================
+// Graft analysis (spr_move.h:28-84, spr_move.cpp:91-1099)
+// =================================================================================================
+struct BranchInfo {
+  int A, B; bool is_open; double T_to_X, pl_A, pl_X;
+  SVec<IvRec> warm, hot;
+  SVec<MutRec> hot_muts;
+  SVec<SdRec> hot_deltas;
+};
+struct Graft { int X, S; double t_P; BranchInfo* bi; int nbi; double delta_log_G, log_alpha_mut; bool rooty; };
+enum { k_PX = 0, k_PS = 1, k_SPX = 2 };
+
+EMAT_D void bi_init(BranchInfo& b) { b.A = b.B = k_no_node; b.is_open = false; b.T_to_X = b.pl_A = b.pl_X = 0.0; b.warm.p = nullptr; b.warm.n = b.warm.cap = 0; b.hot = b.warm; b.hot_muts.p = nullptr; b.hot_muts.n = b.hot_muts.cap = 0; b.hot_deltas.p = nullptr; b.hot_deltas.n = b.hot_deltas.cap = 0; }
+EMAT_D double log_alpha_mut_term(double mu_p, int L, double T, int M, bool is_open, int d) {   // spr_move.cpp:296-315, 809-835
+  double r = -mu_p * L * T + M * log(mu_p / 3);
+  if (!is_open) {
+    double P_AC = -0.25 * expm1(-4. / 3. * mu_p * T);
+    r -= (L - d) * log1p(-3 * P_AC) + d * log(P_AC);
+  }
+  return r;
+}
+
+// ---- rooty grafts -----------------------------------------------------------------------------------------
+EMAT_DN Graft start_rooty_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:91-205
+  Graft g; g.X = X; g.rooty = true; g.delta_log_G = g.log_alpha_mut = 0.0;
+  const int P = c.N[X].parent, S = sibling_of(c, P, X);
+  const double t_X = c.N[X].t, t_P = c.N[P].t, t_S = c.N[S].t;
+  g.S = S; g.t_P = t_P;
+  EMAT_CHECK(c, P == c.H->root && c.includes_run_root);
+  g.bi = (BranchInfo*)sc_alloc(c, 3 * sizeof(BranchInfo)); g.nbi = 3;
+  if (c.failed) { g.nbi = 0; return g; }
+  for (int i = 0; i < 3; ++i) bi_init(g.bi[i]);
+  const MutRec* mX = muts_of(c, X); const int nX = nmuts(c, X);
+  const MutRec* mS = muts_of(c, S); const int nS = nmuts(c, S);
+  BranchInfo& PX = g.bi[k_PX];
+  PX.A = P; PX.B = X; PX.is_open = true; PX.T_to_X = t_X - t_P;
+  PX.pl_A = -1 * delta_lambda_across_node_missations(c, S);
+  PX.warm = iv_copy_sc(c, miss_of(c, S), (int)c.N[S].miss.cnt); PX.hot = PX.warm;
+  PX.pl_X = PX.pl_A;
+  PX.hot_muts = sc_vec<MutRec>(c, nX);
+  for (int i = 0; i < nX; ++i) if (iv_contains(PX.hot.p, PX.hot.n, mX[i].site)) { push(c, PX.hot_muts, mX[i]); PX.pl_X += dq(c, mX[i].site, mX[i].from, mX[i].to); }
+  BranchInfo& PS = g.bi[k_PS];
+  PS.A = P; PS.B = S; PS.is_open = true; PS.T_to_X = t_S - t_P;
+  PS.pl_A = -1 * delta_lambda_across_node_missations(c, X);
+  PS.warm = iv_copy_sc(c, miss_of(c, X), (int)c.N[X].miss.cnt); PS.hot = PS.warm;
+  PS.pl_X = PS.pl_A;
+  PS.hot_muts = sc_vec<MutRec>(c, nS);
+  for (int i = 0; i < nS; ++i) if (iv_contains(PS.hot.p, PS.hot.n, mS[i].site)) { push(c, PS.hot_muts, mS[i]); PS.pl_X += dq(c, mS[i].site, mS[i].from, mS[i].to); }
+  BranchInfo& SPX = g.bi[k_SPX];
+  SPX.A = S; SPX.B = P; SPX.is_open = false; SPX.T_to_X = (t_S - t_P) + (t_X - t_P);
+  SPX.pl_X = c.N[X].lambda - PX.pl_X;
+  SPX.pl_A = c.N[S].lambda - PS.pl_X;
+  {
+    IvRec all; all.start = 0; all.end = c.L;
+    SVec<IvRec> s1 = iv_subtract_sc(c, &all, 1, miss_of(c, P), (int)c.N[P].miss.cnt);
+    SVec<IvRec> s2 = iv_subtract_sc(c, s1.p, s1.n, miss_of(c, X), (int)c.N[X].miss.cnt);
+    SVec<IvRec> s3 = iv_subtract_sc(c, s2.p, s2.n, miss_of(c, S), (int)c.N[S].miss.cnt);
+    SPX.warm = s3; SPX.hot = s3;
+  }
+  SPX.hot_muts = sc_vec<MutRec>(c, nS + nX);
+  SPX.hot_deltas = sc_vec<SdRec>(c, nS + nX);
+  for (int i = nS - 1; i >= 0; --i) if (iv_contains(SPX.hot.p, SPX.hot.n, mS[i].site)) {
+    MutRec rm = make_mut(mS[i].to, mS[i].site, mS[i].from, t_P - (mS[i].t - t_P));
+    push(c, SPX.hot_muts, rm); sd_push_back(c, SPX.hot_deltas, rm.site, rm.from, rm.to);
+  }
+  for (int i = 0; i < nX; ++i) if (iv_contains(SPX.hot.p, SPX.hot.n, mX[i].site)) { push(c, SPX.hot_muts, mX[i]); sd_push_back(c, SPX.hot_deltas, mX[i].site, mX[i].from, mX[i].to); }
+  c.bytes += 3 * 64 + 16 * (nX + nS) + 24 * ((int)c.N[X].miss.cnt + (int)c.N[S].miss.cnt + (int)c.N[P].miss.cnt);
+  return g;
+}
+EMAT_D void filter_not_hot(SVec<MutRec>& v, const SVec<IvRec>& hot) { int w = 0; for (int i = 0; i < v.n; ++i) if (iv_contains(hot.p, hot.n, v.p[i].site)) v.p[w++] = v.p[i]; v.n = w; }
+EMAT_D SVec<MutRec> sample_history_for(Ctx& c, const BranchInfo& bi) {
+  return bi.is_open ? sample_unconstrained_mutational_history(c, c.L, bi.T_to_X, c.mu_prop)
+                    : sample_mutational_history(c, c.L, bi.T_to_X, c.mu_prop, bi.hot_deltas);
+}
+EMAT_D void recompute_open_pl_A(Ctx& c, BranchInfo& bi) {   // spr_move.cpp:234-241, 776-783
+  if (!bi.is_open) return;
+  bi.pl_A = bi.pl_X;
+  for (int i = bi.hot_muts.n - 1; i >= 0; --i) bi.pl_A += dq(c, bi.hot_muts.p[i].site, bi.hot_muts.p[i].to, bi.hot_muts.p[i].from);
+}
+EMAT_DN void propose_new_rooty_graft_mutations(Ctx& c, Graft& g) {   // spr_move.cpp:207-244
+  const int X = g.X, P = c.N[X].parent, S = sibling_of(c, P, X);
+  for (int idx = 0; idx < g.nbi && !c.failed; ++idx) {
+    BranchInfo& bi = g.bi[idx];
+    EMAT_CHECK(c, !bi.is_open || bi.hot_deltas.n == 0);
+    if (bi.hot.n != 0) {
+      SVec<MutRec> nm = sample_history_for(c, bi);
+      if (nm.n != 0) {
+        filter_not_hot(nm, bi.hot);
+        int end_branch = (idx == k_PS) ? S : X;
+        adjust_mutational_history(c, nm, bi.hot_deltas, end_branch, c.N[end_branch].t);
+      }
+      bi.hot_muts = nm;
+      recompute_open_pl_A(c, bi);
+    }
+  }
+}
+EMAT_D double log_pi_ratio(const Ctx& c, const MutRec& m) { return log(pi_a(c, m.site, m.from) / pi_a(c, m.site, m.to)); }
+EMAT_DN void finish_rooty_graft_analysis(Ctx& c, Graft& g) {   // spr_move.cpp:246-316
+  if (c.failed) return;
+  const int X = g.X, P = c.N[X].parent, S = sibling_of(c, P, X);
+  const double t_X = c.N[X].t, t_P = c.N[P].t, t_S = c.N[S].t;
+  BranchInfo& PX = g.bi[k_PX]; BranchInfo& PS = g.bi[k_PS]; BranchInfo& SPX = g.bi[k_SPX];
+  g.delta_log_G = 0.0;
+  g.delta_log_G += branch_log_G(c, t_P, t_X, PX.pl_X, PX.hot_muts.p, PX.hot_muts.n);
+  g.delta_log_G += branch_log_G(c, t_P, t_S, PS.pl_X, PS.hot_muts.p, PS.hot_muts.n);
+  uint32_t mark = c.sc_top;
+  SVec<MutRec> on_PS = sc_vec<MutRec>(c, SPX.hot_muts.n), on_PX = sc_vec<MutRec>(c, SPX.hot_muts.n);
+  for (int i = SPX.hot_muts.n - 1; i >= 0; --i) { const MutRec& m = SPX.hot_muts.p[i]; if (m.t < t_P) push(c, on_PS, make_mut(m.to, m.site, m.from, t_P + (t_P - m.t))); }
+  for (int i = 0; i < SPX.hot_muts.n; ++i) if (SPX.hot_muts.p[i].t >= t_P) push(c, on_PX, SPX.hot_muts.p[i]);
+  g.delta_log_G += branch_log_G(c, t_P, t_X, SPX.pl_X, on_PX.p, on_PX.n);
+  g.delta_log_G += branch_log_G(c, t_P, t_S, SPX.pl_A, on_PS.p, on_PS.n);
+  for (int i = 0; i < PX.hot_muts.n; ++i) g.delta_log_G += log_pi_ratio(c, PX.hot_muts.p[i]);
+  for (int i = 0; i < PS.hot_muts.n; ++i) g.delta_log_G += log_pi_ratio(c, PS.hot_muts.p[i]);
+  for (int i = 0; i < on_PS.n; ++i) g.delta_log_G += log_pi_ratio(c, on_PS.p[i]);
+  c.sc_top = mark;
+  g.log_alpha_mut = 0.0;
+  for (int i = 0; i < g.nbi; ++i) {
+    BranchInfo& bi = g.bi[i];
+    g.log_alpha_mut += log_alpha_mut_term(c.mu_prop, iv_num_sites(bi.hot.p, bi.hot.n), bi.T_to_X, bi.hot_muts.n, bi.is_open, bi.hot_deltas.n);
+  }
+}
+EMAT_DN void peel_rooty_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:318-431
+  if (c.failed) return;
+  const int X = g.X, P = c.N[X].parent, S = sibling_of(c, P, X);
+  const double t_X = c.N[X].t, t_P = c.N[P].t;
+  const BranchInfo& PX = g.bi[k_PX]; const BranchInfo& PS = g.bi[k_PS]; const BranchInfo& SPX = g.bi[k_SPX];
+  uint32_t mark = c.sc_top;
+  const int nX = nmuts(c, X), nS = nmuts(c, S);
+  SVec<SdRec> r2r = deltas_from_root_muts(c, P, nX + 2 * nS);
+  const MutRec* mX = muts_of(c, X); const MutRec* mS = muts_of(c, S);
+  for (int i = 0; i < nX && !c.failed; ++i) if (iv_contains(PX.hot.p, PX.hot.n, mX[i].site)) { sd_push_back(c, r2r, mX[i].site, mX[i].from, mX[i].to); miss_set_from_state(c, S, mX[i].site, mX[i].to); }
+  for (int i = 0; i < nS && !c.failed; ++i) if (iv_contains(PS.hot.p, PS.hot.n, mS[i].site)) { sd_push_back(c, r2r, mS[i].site, mS[i].from, mS[i].to); miss_set_from_state(c, X, mS[i].site, mS[i].to); }
+  for (int i = 0; i < nS && !c.failed; ++i) if (iv_contains(SPX.hot.p, SPX.hot.n, mS[i].site)) sd_push_back(c, r2r, mS[i].site, mS[i].from, mS[i].to);
+  c.N[X].muts.cnt = 0; c.N[S].muts.cnt = 0; c.N[P].muts.cnt = 0;
+  const double t_mut_X = 0.5 * (t_P + t_X);
+  list_reserve<MutRec>(c, c.N[X].muts, SPX.hot_deltas.n);
+  if (!c.failed) {
+    MutRec* m = muts_of(c, X);
+    for (int i = 0; i < SPX.hot_deltas.n; ++i) m[i] = make_mut(SPX.hot_deltas.p[i].from, SPX.hot_deltas.p[i].site, SPX.hot_deltas.p[i].to, t_mut_X);
+    c.N[X].muts.cnt = (uint16_t)SPX.hot_deltas.n;
+  }
+  set_root_muts_from_deltas(c, P, r2r);
+  c.N[P].lambda = calc_lambda_at_node(c, P);
+  c.sc_top = mark;
+}
+EMAT_DN void apply_rooty_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:433-547
+  if (c.failed) return;
+  const int X = g.X, P = c.N[X].parent, S = sibling_of(c, P, X);
+  const double t_X = c.N[X].t, t_P = c.N[P].t, t_S = c.N[S].t;
+  const BranchInfo& PX = g.bi[k_PX]; const BranchInfo& PS = g.bi[k_PS]; const BranchInfo& SPX = g.bi[k_SPX];
+  EMAT_CHECK(c, nmuts(c, S) == 0);
+  uint32_t mark = c.sc_top;
+  c.N[X].muts.cnt = 0;
+  SVec<SdRec> r2r = deltas_from_root_muts(c, P, PX.hot_muts.n + PS.hot_muts.n + SPX.hot_muts.n);
+  c.N[P].muts.cnt = 0;
+  for (int i = PX.hot_muts.n - 1; i >= 0 && !c.failed; --i) {
+    const MutRec& m = PX.hot_muts.p[i];
+    list_push<MutRec>(c, c.N[X].muts, m);
+    sd_push_back(c, r2r, m.site, m.to, m.from);
+    miss_set_from_state(c, S, m.site, m.from);
+  }
+  for (int i = PS.hot_muts.n - 1; i >= 0 && !c.failed; --i) {
+    const MutRec& m = PS.hot_muts.p[i];
+    list_push<MutRec>(c, c.N[S].muts, m);
+    sd_push_back(c, r2r, m.site, m.to, m.from);
+    miss_set_from_state(c, X, m.site, m.from);
+  }
+  for (int i = 0; i < SPX.hot_muts.n && !c.failed; ++i) {
+    const MutRec& m = SPX.hot_muts.p[i];
+    if (m.t > t_P) list_push<MutRec>(c, c.N[X].muts, m);
+    else { list_push<MutRec>(c, c.N[S].muts, make_mut(m.to, m.site, m.from, t_P + (t_P - m.t))); sd_push_back(c, r2r, m.site, m.from, m.to); }
+  }
+  sort_muts(muts_of(c, X), nmuts(c, X)); sort_muts(muts_of(c, S), nmuts(c, S));
+  set_root_muts_from_deltas(c, P, r2r);
+  clamp_mut_times(muts_of(c, X), nmuts(c, X), t_P, t_X); clamp_mut_times(muts_of(c, S), nmuts(c, S), t_P, t_S);
+  c.N[P].lambda = c.N[X].lambda - delta_lambda_across_branch(c, X);
+  c.sc_top = mark;
+}
+
+// ---- inner grafts -----------------------------------------------------------------------------------------
+EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:582-738
+  Graft g; g.X = X; g.rooty = false; g.delta_log_G = g.log_alpha_mut = 0.0; g.nbi = 0; g.bi = nullptr;
+  const int P = c.N[X].parent;
+  EMAT_CHECK(c, X != c.H->root && P != c.H->root);
+  if (c.failed) return g;
+  const int S = sibling_of(c, P, X);
+  const double t_X = c.N[X].t, t_P = c.N[P].t;
+  g.S = S; g.t_P = t_P;
+  int depth = 0, path_muts = 0;
+  for (int cur = X; cur != k_no_node; cur = c.N[cur].parent) { ++depth; path_muts += nmuts(c, cur); }
+  g.bi = (BranchInfo*)sc_alloc(c, (uint32_t)(depth + 2) * (uint32_t)sizeof(BranchInfo));
+  if (c.failed) return g;
+  const int bi_cap = depth + 2;
+  {
+    BranchInfo& PX = g.bi[g.nbi++]; bi_init(PX);
+    PX.A = P; PX.B = X; PX.is_open = false; PX.T_to_X = t_X - t_P;
+    PX.warm = sc_vec<IvRec>(c, 1); { IvRec all; all.start = 0; all.end = c.L; push(c, PX.warm, all); }
+    PX.hot = iv_subtract_sc(c, PX.warm.p, PX.warm.n, miss_of(c, S), (int)c.N[S].miss.cnt);
+  }
+  // sliding_missations = copy of S's missations
+  SVec<IvRec> sl_iv = iv_copy_sc(c, miss_of(c, S), (int)c.N[S].miss.cnt);
+  SVec<FsRec> sl_fs = sc_vec<FsRec>(c, (int)c.N[S].mfs.cnt + path_muts + 1);
+  { const FsRec* f = mfs_of(c, S); for (int i = 0; i < (int)c.N[S].mfs.cnt; ++i) push(c, sl_fs, f[i]); }
+  {
+    BranchInfo& PX = g.bi[0];
+    PX.pl_A = c.N[X].lambda;
+    const MutRec* m = muts_of(c, X);
+    for (int i = nmuts(c, X) - 1; i >= 0; --i) PX.pl_A += dq(c, m[i].site, m[i].to, m[i].from);
+  }
+  double next_pl_B = -1 * delta_lambda_across_missations(c, sl_iv.p, sl_iv.n, sl_fs.p, sl_fs.n);
+  g.bi[0].pl_A -= next_pl_B;
+  int cur = P, parent = c.N[cur].parent, sibling = sibling_of(c, parent, cur);
+  double partial_lambda = next_pl_B;
+  while (sl_iv.n != 0 && !c.failed) {
+    if (g.nbi >= bi_cap) { EMAT_FAIL(c, k_part_overflow); break; }
+    BranchInfo& bi = g.bi[g.nbi++]; bi_init(bi);
+    bi.A = parent; bi.B = cur; bi.is_open = false; bi.T_to_X = t_X - c.N[parent].t;
+    bi.warm = sl_iv;
+    const MutRec* mc = muts_of(c, cur);
+    for (int i = nmuts(c, cur) - 1; i >= 0; --i) {
+      if (iv_contains(sl_iv.p, sl_iv.n, mc[i].site)) { partial_lambda += dq(c, mc[i].site, mc[i].to, mc[i].from); fsv_set(c, sl_fs, mc[i].site, mc[i].from); }
+    }
+    bi.hot = iv_subtract_sc(c, bi.warm.p, bi.warm.n, miss_of(c, sibling), (int)c.N[sibling].miss.cnt);
+    SVec<IvRec> new_sl = iv_subtract_sc(c, bi.warm.p, bi.warm.n, bi.hot.p, bi.hot.n);
+    sl_iv = new_sl;
+    { int w = 0; for (int i = 0; i < sl_fs.n; ++i) if (iv_contains(sl_iv.p, sl_iv.n, sl_fs.p[i].site)) sl_fs.p[w++] = sl_fs.p[i]; sl_fs.n = w; }
+    next_pl_B = -1 * delta_lambda_across_missations(c, sl_iv.p, sl_iv.n, sl_fs.p, sl_fs.n);
+    bi.pl_A = partial_lambda - next_pl_B;
+    partial_lambda = next_pl_B;
+    c.bytes += 64 + 16 * nmuts(c, cur) + 24 * ((int)c.N[sibling].miss.cnt + bi.warm.n);
+    if (parent != c.H->root) {
+      cur = parent; parent = c.N[cur].parent; sibling = sibling_of(c, parent, cur);
+    } else {
+      if (!c.includes_run_root) { bi.hot = bi.warm; bi.pl_A += partial_lambda; }
+      else if (sl_iv.n != 0) {
+        if (g.nbi >= bi_cap) { EMAT_FAIL(c, k_part_overflow); break; }
+        BranchInfo& fo = g.bi[g.nbi++]; bi_init(fo);
+        fo.A = k_no_node; fo.B = c.H->root; fo.is_open = true; fo.T_to_X = t_X - c.N[parent].t;
+        fo.warm = sl_iv; fo.hot = sl_iv; fo.pl_A = partial_lambda;
+      }
+      sl_iv.n = 0; sl_fs.n = 0;
+    }
+  }
+  if (c.failed) return g;
+  // distribute hot mutations along the hot path (spr_move.cpp:700-735): gather (mutation, owner), then split by owner
+  struct Owned { MutRec m; int owner; int pad; };
+  SVec<Owned> tmp = sc_vec<Owned>(c, path_muts + 1);
+  for (int i = 0; i < g.nbi; ++i) {
+    BranchInfo& bi_i = g.bi[i];
+    if (bi_i.B == c.H->root) continue;
+    const MutRec* mb = muts_of(c, bi_i.B);
+    for (int k = nmuts(c, bi_i.B) - 1; k >= 0; --k) {
+      if (iv_contains(bi_i.warm.p, bi_i.warm.n, mb[k].site)) {
+        bool found = false;
+        for (int j = i; j < g.nbi; ++j) if (iv_contains(g.bi[j].hot.p, g.bi[j].hot.n, mb[k].site)) { Owned o; o.m = mb[k]; o.owner = j; o.pad = 0; push(c, tmp, o); found = true; }
+        EMAT_CHECK(c, found);
+      }
+    }
+  }
+  for (int j = 0; j < g.nbi && !c.failed; ++j) {
+    BranchInfo& bi = g.bi[j];
+    int cnt = 0; for (int k = 0; k < tmp.n; ++k) if (tmp.p[k].owner == j) ++cnt;
+    bi.hot_muts = sc_vec<MutRec>(c, cnt);
+    bi.hot_deltas = sc_vec<SdRec>(c, cnt);
+    for (int k = tmp.n - 1; k >= 0; --k) if (tmp.p[k].owner == j) push(c, bi.hot_muts, tmp.p[k].m);   // reversed encounter order
+    bi.pl_X = bi.pl_A;
+    for (int k = 0; k < bi.hot_muts.n; ++k) {
+      const MutRec& m = bi.hot_muts.p[k];
+      if (!bi.is_open) sd_push_back(c, bi.hot_deltas, m.site, m.from, m.to);
+      bi.pl_X += dq(c, m.site, m.from, m.to);
+    }
+  }
+  return g;
+}
+EMAT_DN void propose_new_inner_graft_mutations(Ctx& c, Graft& g) {   // spr_move.cpp:740-785
+  const int X = g.X;
+  for (int idx = 0; idx < g.nbi && !c.failed; ++idx) {
+    BranchInfo& bi = g.bi[idx];
+    if (bi.hot.n == 0) { EMAT_CHECK(c, bi.hot_muts.n == 0); continue; }
+    SVec<MutRec> nm = sample_history_for(c, bi);
+    if (nm.n != 0) {
+      filter_not_hot(nm, bi.hot);
+      if (bi.B == X) {
+        int w = 0;
+        for (int i = 0; i < nm.n; ++i) {
+          bool drop = !sd_contains(bi.hot_deltas, nm.p[i].site) && is_site_missing_at(c, X, nm.p[i].site);
+          if (!drop) nm.p[w++] = nm.p[i];
+        }
+        nm.n = w;
+      }
+      adjust_mutational_history(c, nm, bi.hot_deltas, X, c.N[X].t);
+    }
+    bi.hot_muts = nm;
+    recompute_open_pl_A(c, bi);
+  }
+}
+EMAT_DN void finish_inner_graft_analysis(Ctx& c, Graft& g) {   // spr_move.cpp:787-836
+  if (c.failed || g.nbi == 0) return;
+  const int X = g.X; const double t_X = c.N[X].t;
+  g.delta_log_G = 0.0;
+  for (int i = 0; i < g.nbi; ++i) { BranchInfo& bi = g.bi[i]; g.delta_log_G += branch_log_G(c, t_X - bi.T_to_X, t_X, bi.pl_X, bi.hot_muts.p, bi.hot_muts.n); }
+  BranchInfo& last = g.bi[g.nbi - 1];
+  if (last.is_open) for (int i = 0; i < last.hot_muts.n; ++i) g.delta_log_G += log_pi_ratio(c, last.hot_muts.p[i]);
+  g.log_alpha_mut = 0.0;
+  for (int i = 0; i < g.nbi; ++i) {
+    BranchInfo& bi = g.bi[i];
+    int Ls = iv_num_sites(bi.hot.p, bi.hot.n);
+    if (bi.B == X) Ls = (c.L - c.N[X].n_missing) - (iv_num_sites(bi.warm.p, bi.warm.n) - iv_num_sites(bi.hot.p, bi.hot.n));
+    g.log_alpha_mut += log_alpha_mut_term(c.mu_prop, Ls, bi.T_to_X, bi.hot_muts.n, bi.is_open, bi.hot_deltas.n);
+  }
+}
+EMAT_D void recalc_lambda_along_hot_path(Ctx& c, const Graft& g) {   // spr_move.cpp:943-950, 1059-1066
+  for (int i = 0; i + 1 < g.nbi; ++i) { int A = g.bi[i].A, B = g.bi[i].B; c.N[A].lambda = c.N[B].lambda - delta_lambda_across_branch(c, B); }
+}
+EMAT_D void erase_marked_muts(Ctx& c, int node) { MutRec* m = muts_of(c, node); int n = nmuts(c, node), w = 0; for (int i = 0; i < n; ++i) if (m[i].site != -1) m[w++] = m[i]; c.N[node].muts.cnt = (uint16_t)w; }
+EMAT_DN void peel_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:838-953
+  if (c.failed || g.nbi == 0) return;
+  const int X = g.X, P = c.N[X].parent, root = c.H->root;
+  const double t_X = c.N[X].t, t_P = c.N[P].t;
+  const BranchInfo& fin = g.bi[g.nbi - 1];
+  uint32_t mark = c.sc_top;
+  SVec<SdRec> r2r; r2r.p = nullptr; r2r.n = r2r.cap = 0;
+  if (fin.is_open) r2r = deltas_from_root_muts(c, root, path_mut_count(c, X));
+  for (int i = 0; i < g.nbi && !c.failed; ++i) {
+    const BranchInfo& bi = g.bi[i];
+    if (bi.B == root) continue;
+    if (bi.B == X && !fin.is_open) { c.N[X].muts.cnt = 0; continue; }
+    MutRec* mb = muts_of(c, bi.B);
+    for (int k = nmuts(c, bi.B) - 1; k >= 0 && !c.failed; --k) {
+      MutRec& m = mb[k];
+      if (m.site < 0) continue;
+      if (iv_contains(bi.warm.p, bi.warm.n, m.site) && (!fin.is_open || !iv_contains(fin.hot.p, fin.hot.n, m.site))) {
+        for (int cur = X; cur != bi.B; cur = c.N[cur].parent) { int par = c.N[cur].parent; miss_set_from_state(c, sibling_of(c, par, cur), m.site, m.from); }
+        m.site = -1;
+      }
+    }
+  }
+  if (fin.is_open) {
+    for (int i = g.nbi - 1; i >= 0 && !c.failed; --i) {
+      const BranchInfo& bi = g.bi[i];
+      if (bi.B == root) continue;
+      MutRec* mb = muts_of(c, bi.B);
+      for (int k = 0; k < nmuts(c, bi.B) && !c.failed; ++k) {
+        MutRec& m = mb[k];
+        if (m.site < 0) continue;
+        if (iv_contains(fin.hot.p, fin.hot.n, m.site)) {
+          for (int cur = bi.B; cur != root; cur = c.N[cur].parent) { int par = c.N[cur].parent; miss_set_from_state(c, sibling_of(c, par, cur), m.site, m.to); }
+          sd_push_back(c, r2r, m.site, m.from, m.to);
+          m.site = -1;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < g.nbi; ++i) if (g.bi[i].B != root) erase_marked_muts(c, g.bi[i].B);
+  const double t_mut_X = 0.5 * (t_P + t_X);
+  for (int i = 0; i < g.nbi && !c.failed; ++i) {
+    const BranchInfo& bi = g.bi[i];
+    if (bi.B == root) continue;
+    for (int k = 0; k < bi.hot_deltas.n; ++k) list_push<MutRec>(c, c.N[X].muts, make_mut(bi.hot_deltas.p[k].from, bi.hot_deltas.p[k].site, bi.hot_deltas.p[k].to, t_mut_X));
+  }
+  if (fin.is_open) set_root_muts_from_deltas(c, root, r2r);
+  recalc_lambda_along_hot_path(c, g);
+  c.sc_top = mark;
+}
+EMAT_DN void apply_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:955-1069
+  if (c.failed || g.nbi == 0) return;
+  const int X = g.X, root = c.H->root;
+  const BranchInfo& fin = g.bi[g.nbi - 1];
+  uint32_t mark = c.sc_top;
+  c.N[X].muts.cnt = 0;
+  SVec<SdRec> r2r; r2r.p = nullptr; r2r.n = r2r.cap = 0;
+  if (fin.is_open) r2r = deltas_from_root_muts(c, root, fin.hot_muts.n);
+  for (int i = 0; i < g.nbi && !c.failed; ++i) {
+    const BranchInfo& bi = g.bi[i];
+    if (bi.B == X) { list_assign<MutRec>(c, c.N[X].muts, bi.hot_muts.p, bi.hot_muts.n); continue; }
+    if (!bi.is_open) {
+      for (int k = 0; k < bi.hot_muts.n && !c.failed; ++k) {
+        const MutRec m = bi.hot_muts.p[k];
+        for (int cur = X; cur != bi.A; cur = c.N[cur].parent) {
+          int par = c.N[cur].parent;
+          if (c.N[par].t <= m.t && m.t < c.N[cur].t) { list_push<MutRec>(c, c.N[cur].muts, m); break; }
+          miss_set_from_state(c, sibling_of(c, par, cur), m.site, m.to);
+        }
+      }
+    } else {
+      for (int k = bi.hot_muts.n - 1; k >= 0 && !c.failed; --k) {
+        const MutRec m = bi.hot_muts.p[k];
+        for (int cur = X; cur != root; cur = c.N[cur].parent) {
+          int par = c.N[cur].parent;
+          if (c.N[par].t <= m.t && m.t < c.N[cur].t) list_push<MutRec>(c, c.N[cur].muts, m);
+          if (c.N[par].t <= m.t) miss_set_from_state(c, sibling_of(c, par, cur), m.site, m.from);
+        }
+        sd_push_back(c, r2r, m.site, m.to, m.from);
+      }
+    }
+  }
+  for (int i = 0; i < g.nbi; ++i) {
+    const BranchInfo& bi = g.bi[i];
+    if (!bi.is_open) { sort_muts(muts_of(c, bi.B), nmuts(c, bi.B)); clamp_mut_times(muts_of(c, bi.B), nmuts(c, bi.B), c.N[bi.A].t, c.N[bi.B].t); }
+  }
+  if (fin.is_open) set_root_muts_from_deltas(c, root, r2r);
+  recalc_lambda_along_hot_path(c, g);
+  c.sc_top = mark;
+}
+
+// ---- dispatch (spr_move.cpp:9-89, 549-580, 1071-1099) -------------------------------------------------------
+EMAT_D bool is_rooty(const Ctx& c, int X) { return c.N[X].parent == c.H->root; }
+EMAT_D Graft analyze_graft(Ctx& c, int X) {
+  Graft g;
+  if (is_rooty(c, X)) { g = start_rooty_graft_analysis(c, X); finish_rooty_graft_analysis(c, g); }
+  else { g = start_inner_graft_analysis(c, X); finish_inner_graft_analysis(c, g); }
+  return g;
+}
+EMAT_D Graft propose_new_graft(Ctx& c, int X) {
+  Graft g;
+  if (is_rooty(c, X)) { g = start_rooty_graft_analysis(c, X); if (!c.failed) propose_new_rooty_graft_mutations(c, g); finish_rooty_graft_analysis(c, g); }
+  else { g = start_inner_graft_analysis(c, X); if (!c.failed) propose_new_inner_graft_mutations(c, g); finish_inner_graft_analysis(c, g); }
+  return g;
+}
+EMAT_D void peel_graft(Ctx& c, const Graft& g) { if (is_rooty(c, g.X)) peel_rooty_graft(c, g); else peel_inner_graft(c, g); }
+EMAT_D void apply_graft(Ctx& c, const Graft& g) { if (is_rooty(c, g.X)) apply_rooty_graft(c, g); else apply_inner_graft(c, g); }
+EMAT_D int count_min_mutations(const Ctx& c, const Graft& g) {
+  if (g.rooty) return g.bi[k_SPX].hot_deltas.n;
+  int r = 0; for (int i = 0; i < g.nbi; ++i) if (!g.bi[i].is_open) r += g.bi[i].hot_deltas.n; return r;
+}
+// summarize_closed_mutations: fresh scratch delta list with room for `extra` more entries
+EMAT_DN SVec<SdRec> summarize_closed_mutations(Ctx& c, const Graft& g, int extra) {
+  int tot = 0;
+  if (g.rooty) tot = g.bi[k_SPX].hot_deltas.n; else for (int i = 0; i < g.nbi; ++i) if (!g.bi[i].is_open) tot += g.bi[i].hot_deltas.n;
+  SVec<SdRec> r = sc_vec<SdRec>(c, tot + extra + 1);
+  if (g.rooty) { const SVec<SdRec>& d = g.bi[k_SPX].hot_deltas; for (int k = 0; k < d.n; ++k) sd_push_back(c, r, d.p[k].site, d.p[k].from, d.p[k].to); }
+  else for (int i = 0; i < g.nbi; ++i) if (!g.bi[i].is_open) { const SVec<SdRec>& d = g.bi[i].hot_deltas; for (int k = 0; k < d.n; ++k) sd_push_back(c, r, d.p[k].site, d.p[k].from, d.p[k].to); }
+  return r;
+}
+
+// =================================================================================================
+// SPR candidate study (spr_study.h:17-171, spr_study.cpp:9-549)
+// =================================================================================================
+struct Region { int branch, mut_idx; double t_min, t_max; int min_muts; int pad; double logW, W; };   // 48 B
+struct Study {
+  SVec<Region> regions;
+  double lambda_X, mu, f, t_X, t_max_tip, log_Wmax, sum_W;
+};
+struct WorkItem { int branch, mut_idx, backtracking; };
+
+EMAT_D double region_t_min(Ctx& c, int b, int mi) { if (b == c.H->root) return k_neg_dbl_max; if (mi == 0) return c.N[c.N[b].parent].t; return muts_of(c, b)[mi - 1].t; }
+EMAT_D double region_t_max(Ctx& c, int b, int mi) { if (b == c.H->root) return c.N[b].t; if (mi == nmuts(c, b)) return c.N[b].t; return muts_of(c, b)[mi].t; }
+
+// seed_fill_from (spr_study.cpp:9-24).  `deltas` (cur -> X) is consumed; `missing_at_X` must outlive the call.
+// Regions grow upwards from the scratch top while the DFS work stack grows downwards from the scratch end.
+EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec>& missing_at_X, int max_muts_from_start,
+                                    int init_branch, int init_mut_idx, SVec<SdRec>& deltas, bool can_change_root) {
+  SVec<Region> res; res.p = (Region*)(c.S + c.sc_top); res.n = 0; res.cap = 0;
+  if (c.failed) return res;
+  const uint32_t lo0 = (c.sc_top + 15u) & ~15u;
+  res.p = (Region*)(c.S + lo0);
+  WorkItem* stack_base = (WorkItem*)(c.S + (c.H->scratch_end & ~15u));   // items live at stack_base[-1], [-2], ...
+  int sp = 0;
+  auto room = [&](int extra_regions, int extra_items) -> bool {
+    uint64_t lo = (uint64_t)lo0 + (uint64_t)(res.n + extra_regions) * sizeof(Region);
+    uint64_t hi = (uint64_t)(c.H->scratch_end & ~15u) - (uint64_t)(sp + extra_items) * sizeof(WorkItem);
+    return lo + 16 <= hi;
+  };
+  int cur_branch = k_no_node, cur_mut_idx = -1, cur_from_start = 0;
+  auto add_forward = [&](int tb, int tmi) {
+    if (!room(0, 2)) { EMAT_FAIL(c, k_part_overflow); return; }
+    ++sp; stack_base[-sp].branch = cur_branch; stack_base[-sp].mut_idx = cur_mut_idx; stack_base[-sp].backtracking = 1;
+    ++sp; stack_base[-sp].branch = tb; stack_base[-sp].mut_idx = tmi; stack_base[-sp].backtracking = 0;
+  };
+  add_forward(init_branch, init_mut_idx);
+  const int root = c.H->root;
+  while (sp > 0 && !c.failed) {
+    WorkItem w = stack_base[-sp]; --sp;
+    const int ob = cur_branch, omi = cur_mut_idx;
+    // move_to_neighbor (spr_study.cpp:43-91)
+    if (cur_branch != k_no_node && w.branch == cur_branch) {
+      const MutRec* m = muts_of(c, cur_branch);
+      if (w.mut_idx == cur_mut_idx + 1) {
+        const MutRec& mm = m[cur_mut_idx];
+        if (!iv_contains(missing_at_X.p, missing_at_X.n, mm.site)) { sd_pop_front(c, deltas, mm.site, mm.from, mm.to); cur_from_start += w.backtracking ? -1 : +1; }
+      } else if (w.mut_idx == cur_mut_idx - 1) {
+        const MutRec& mm = m[w.mut_idx];
+        if (!iv_contains(missing_at_X.p, missing_at_X.n, mm.site)) { sd_push_front(c, deltas, mm.site, mm.from, mm.to); cur_from_start += w.backtracking ? -1 : +1; }
+      } else EMAT_FAIL(c, k_part_internal);
+    }
+    cur_branch = w.branch; cur_mut_idx = w.mut_idx;
+    if (!w.backtracking && cur_branch != X && cur_from_start <= max_muts_from_start) {
+      // visit_cur_region (spr_study.cpp:93-101)
+      if (!room(1, 0)) { EMAT_FAIL(c, k_part_overflow); break; }
+      Region& r = res.p[res.n++];
+      r.branch = cur_branch; r.mut_idx = cur_mut_idx; r.t_min = region_t_min(c, cur_branch, cur_mut_idx); r.t_max = region_t_max(c, cur_branch, cur_mut_idx);
+      r.min_muts = deltas.n; r.pad = 0; r.logW = 0.0; r.W = 0.0;
+      c.bytes += 64 + 16;
+      // seed_neighbors_except (spr_study.cpp:103-128)
+      if (cur_branch != root) {
+        if (cur_mut_idx > 0) { if (!(cur_branch == ob && cur_mut_idx - 1 == omi)) add_forward(cur_branch, cur_mut_idx - 1); }
+        else { int pb = c.N[cur_branch].parent, pmi = nmuts(c, pb); if (!(pb == ob && pmi == omi)) add_forward(pb, pmi); }
+      }
+      if (cur_mut_idx < nmuts(c, cur_branch)) { if (!(cur_branch == ob && cur_mut_idx + 1 == omi)) add_forward(cur_branch, cur_mut_idx + 1); }
+      else if (!is_tip(c, cur_branch)) {
+        int c0 = c.N[cur_branch].child0, c1 = c.N[cur_branch].child1;
+        if (!(c0 == ob && 0 == omi)) add_forward(c0, 0);
+        if (!(c1 == ob && 0 == omi)) add_forward(c1, 0);
+      }
+    }
+  }
+  // account_for_Xs_detachment (spr_study.cpp:130-209)
+  if (X == k_no_node) { if (!can_change_root) for (int i = 0; i < res.n; ++i) if (res.p[i].branch == root) res.p[i].branch = -1; }
+  else {
+    const int P = c.N[X].parent, S = sibling_of(c, P, X);
+    const int nGP = nmuts(c, P);
+    for (int i = 0; i < res.n; ++i) {
+      Region& region = res.p[i];
+      if (!can_change_root) { if (region.branch == root) { region.branch = -1; continue; } }
+      if (region.branch != S && region.branch != P) continue;
+      if (P != root) {
+        if (region.branch == S) { if (region.mut_idx == 0) region.t_min = region_t_min(c, P, nGP); region.mut_idx += nGP; }
+        else { if (region.mut_idx == nGP) region.branch = -1; else region.branch = S; }
+      } else {
+        if (!can_change_root) { if (region.branch == P) region.branch = -1; }
+        else {
+          if (region.branch == S && region.mut_idx == nmuts(c, S)) { region.mut_idx += nGP; region.t_min = k_neg_dbl_max; }
+          else region.branch = -1;
+        }
+      }
+    }
+  }
+  // remove_regions_in_Xs_future (spr_study.cpp:211-224), fused with the compaction of marked regions
+  int w = 0;
+  for (int i = 0; i < res.n; ++i) {
+    Region r = res.p[i];
+    if (r.branch == -1) continue;
+    if (r.t_min >= t_X) continue;
+    if (r.t_max > t_X) r.t_max = t_X;
+    res.p[w++] = r;
+  }
+  res.n = w; res.cap = w;
+  c.sc_top = lo0 + (((uint32_t)w * (uint32_t)sizeof(Region) + 15u) & ~15u);
+  return res;
+}
+struct RootRegionParams { double f, t_S, s_min, s_max, x_min, x_max; int m; };
+EMAT_D RootRegionParams root_region_params(Ctx& c, const Study& st, const Region& r) {
+  RootRegionParams p; p.f = st.f; p.m = r.min_muts; p.t_S = c.N[r.branch].t;
+  p.s_min = fabs(st.t_X - p.t_S);
+  double t_early = st.t_X < p.t_S ? st.t_X : p.t_S;
+  double tree_span = st.t_max_tip - t_early;
+  EMAT_CHECK(c, tree_span >= 0.0);
+  p.s_max = p.s_min + 20.0 * tree_span;
+  p.x_min = st.lambda_X * p.f * p.s_min; p.x_max = st.lambda_X * p.f * p.s_max;
+  return p;
+}
+EMAT_D double safe_log_gamma_integral(Ctx& c, double a, double x_min, double x_max) {   // safe_gamma_math.h:82-90
+  EMAT_CHECK(c, x_min < x_max);
+  double Q_hi = gamma_q(a, x_min), Q_lo = gamma_q(a, x_max);
+  return log(Q_hi - Q_lo);
+}
+constexpr double k_ln2 = 0.693147180559945309417232121458176568;
+EMAT_DN Study make_study(Ctx& c, SVec<Region> regions, int num_missing_at_X, double lambda_X, double f, double t_X, double t_max_tip) {   // spr_study.cpp:226-385
+  Study st; st.regions = regions; st.lambda_X = lambda_X; st.f = f; st.t_X = t_X; st.t_max_tip = t_max_tip; st.log_Wmax = 0.0; st.sum_W = 0.0;
+  st.mu = lambda_X / (c.L - num_missing_at_X);
+  if (c.failed) return st;
+  EMAT_CHECK(c, regions.n > 0);
+  for (int i = 0; i < regions.n; ++i) {
+    Region& r = regions.p[i];
+    const int m = r.min_muts;
+    if (r.t_min != k_neg_dbl_max) {
+      double t_prime = 0.5 * (r.t_min + r.t_max);
+      r.logW = log(f * lambda_X * (r.t_max - r.t_min)) + f * (-lambda_X * (t_X - t_prime) + m * log(st.mu * (t_X - t_prime) / 3));
+    } else {
+      RootRegionParams p = root_region_params(c, st, r);
+      if (p.x_max < 0.01) {
+        double alpha = f * m + 1;
+        r.logW = -k_ln2 + log(f * lambda_X) + f * m * log(st.mu / 3) + alpha * log(p.s_max) + log1p(-pow(p.s_min / p.s_max, alpha)) - log(alpha);
+      } else {
+        r.logW = -k_ln2 + f * m * log(st.mu / (3 * lambda_X * f)) + lgamma(f * m + 1) + safe_log_gamma_integral(c, f * m + 1, p.x_min, p.x_max);
+      }
+    }
+  }
+  if (regions.n > 0) {
+    st.log_Wmax = regions.p[0].logW;
+    for (int i = 0; i < regions.n; ++i) st.log_Wmax = st.log_Wmax > regions.p[i].logW ? st.log_Wmax : regions.p[i].logW;
+    // NaN-aware max as std::max(a, b) = (a < b) ? b : a
+    st.log_Wmax = regions.p[0].logW;
+    for (int i = 0; i < regions.n; ++i) if (st.log_Wmax < regions.p[i].logW) st.log_Wmax = regions.p[i].logW;
+    for (int i = 0; i < regions.n; ++i) { Region& r = regions.p[i]; r.logW -= st.log_Wmax; r.W = exp(r.logW); st.sum_W += r.W; }
+  }
+  c.bytes += 2 * 48 * (int64_t)regions.n;
+  return st;
+}
+EMAT_D int study_pick_nexus_region(Ctx& c, const Study& st) {   // spr_study.cpp:404-422
+  double r = uniform_co(c, 0.0, st.sum_W);
+  for (int i = 0; i < st.regions.n; ++i) { if (st.regions.p[i].W >= r) return i; r -= st.regions.p[i].W; }
+  return 0;
+}
+EMAT_DN double study_pick_time_in_region(Ctx& c, const Study& st, int idx) {   // spr_study.cpp:424-471
+  const Region& r = st.regions.p[idx];
+  if (r.t_min != k_neg_dbl_max) return uniform_oc(c, r.t_min, r.t_max);
+  RootRegionParams p = root_region_params(c, st, r);
+  double rand_s;
+  if (p.x_max < 0.01) {
+    double alpha = p.f * p.m + 1;
+    double U = u01_oo(c);
+    double smin_a = pow(p.s_min, alpha), smax_a = pow(p.s_max, alpha);
+    rand_s = pow(smin_a + U * (smax_a - smin_a), 1.0 / alpha);
+  } else {   // safe_sample_truncated_gamma (safe_gamma_math.h:112-139)
+    double alpha = p.f * p.m + 1, beta = st.lambda_X * p.f;
+    double y_lo = beta * p.s_min, y_hi = beta * p.s_max;
+    double Q_hi = gamma_q(alpha, y_lo), Q_lo = gamma_q(alpha, y_hi);
+    EMAT_CHECK(c, Q_lo < Q_hi);
+    double rand_Q = uniform_oc(c, Q_lo, Q_hi);
+    double y = gamma_q_inv(alpha, rand_Q);
+    double x = y / beta;
+    rand_s = x < p.s_min ? p.s_min : (p.s_max < x ? p.s_max : x);
+  }
+  double rand_t = 0.5 * (st.t_X + p.t_S - rand_s);
+  double lo = r.t_max < rand_t ? r.t_max : rand_t;
+  return r.t_min > lo ? r.t_min : lo;
+}
+EMAT_D int study_find_region(const Study& st, int branch, double t) {   // spr_study.cpp:474-484
+  for (int i = 0; i < st.regions.n; ++i) { const Region& r = st.regions.p[i]; if (r.branch == branch && r.t_min < t && t <= r.t_max) return i; }
+  return -1;
+}
+EMAT_DN double study_log_alpha_in_region(Ctx& c, const Study& st, int idx, double t) {   // spr_study.cpp:486-549
+  const Region& r = st.regions.p[idx];
+  double log_p_region = r.logW - log(st.sum_W);
+  if (r.t_min != k_neg_dbl_max) return log_p_region - log(r.t_max - r.t_min);
+  RootRegionParams p = root_region_params(c, st, r);
+  double s = st.t_X - t + p.t_S - t;
+  if (s > p.s_max + 1e-6) return -k_inf;
+  if (p.x_max < 0.01) {
+    double alpha = p.f * p.m + 1;
+    return log_p_region + k_ln2 + log(alpha) + (alpha - 1) * log(s) + -alpha * log(p.s_max) + -log1p(-pow(p.s_min / p.s_max, alpha));
+  }
+  return log_p_region + k_ln2 + log(st.lambda_X * p.f) + p.f * p.m * log(st.lambda_X * p.f * s) + -st.lambda_X * p.f * s
+      + -lgamma(p.f * p.m + 1) - safe_log_gamma_integral(c, p.f * p.m + 1, p.x_min, p.x_max);
+}
+
+}  // namespace dev
+}  // namespace emat
+#endif  // EMAT_DEVICE_SPR_HPP_

@@ -1,0 +1,196 @@
+// emat_host_model.hpp -- host-side pieces of the engine that the reference also keeps on the host:
+//   * the counter-based RNG shared with the kernels (one Philox4x32-10 block per draw);
+//   * population models (reference core/pop_model.cpp:18-145, 181-204, 247-330, 525-560);
+//   * make_very_scalable_coalescent_prior_parts (reference core/very_scalable_coalescent.cpp:85-232),
+//     which Run::reset_very_scalable_coalescent_parts (core/run.cpp:277-293) executes on the host at every
+//     push of global parameters.
+// Product code (NOT the test oracle): it feeds the HIP engine's slabs.
+#ifndef EMAT_HOST_MODEL_HPP_
+#define EMAT_HOST_MODEL_HPP_
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <vector>
+
+#include "flat_tree.hpp"
+
+namespace emat {
+
+struct HostRng {
+  uint64_t key = 0, counter = 0;
+  static void philox(uint64_t ctr, uint64_t key, uint32_t out[4]) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0, k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+    for (int r = 0; r < 10; ++r) {
+      uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+      uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+      c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+  }
+  double gaussian(double mean, double sigma) {
+    uint32_t w[4]; philox(counter++, key, w);
+    uint64_t a = (uint64_t)w[0] | ((uint64_t)w[1] << 32), b = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+    double u1 = ((double)(a >> 11) + 1.0) * 0x1.0p-53, u2 = (double)(b >> 11) * 0x1.0p-53;
+    return mean + sigma * (std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586476925 * u2));
+  }
+};
+
+struct HostPopModel {
+  int kind = EMAT_POP_CONST;
+  double p[4] = {1, 0, 0, 0};
+  double t_c = std::numeric_limits<double>::quiet_NaN();
+  int skygrid_type = 1;
+  std::vector<double> x, gamma;
+
+  static HostPopModel from_c(const emat_pop_model& m) {
+    HostPopModel h; h.kind = m.kind;
+    for (int i = 0; i < 4; ++i) h.p[i] = m.p[i];
+    if (m.kind == EMAT_POP_CONST) { if (!(m.p[0] > 0.0)) throw std::invalid_argument("Population size should be positive"); }
+    else if (m.kind == EMAT_POP_EXP) {
+      if (!(m.p[1] > 0.0)) throw std::invalid_argument("Initial effective population size should be positive");
+      if (m.p[3] < 0.0) throw std::invalid_argument("Minimum effective population size should be non-negative");
+      if (m.p[3] > 0.0 && m.p[2] != 0.0) h.t_c = m.p[0] + std::log(m.p[3] / m.p[1]) / m.p[2];
+    } else if (m.kind == EMAT_POP_SKYGRID) {
+      if (m.skygrid_num_knots < 2) throw std::invalid_argument("Skygrid_pop_model needs at least two knots");
+      h.skygrid_type = m.skygrid_type;
+      h.x.assign(m.skygrid_x, m.skygrid_x + m.skygrid_num_knots);
+      h.gamma.assign(m.skygrid_gamma, m.skygrid_gamma + m.skygrid_num_knots);
+      for (size_t i = 0; i + 1 < h.x.size(); ++i) if (!(h.x[i] < h.x[i + 1])) throw std::invalid_argument("Skygrid_pop_model needs strictly increasing knot times");
+    } else throw std::invalid_argument("unknown population model kind");
+    return h;
+  }
+  int interval(double t) const { return (int)(std::lower_bound(x.begin(), x.end(), t) - x.begin()); }
+  double exp_int(double a, double b) const { return p[1] / p[2] * std::exp(p[2] * (a - p[0])) * std::expm1(p[2] * (b - a)); }
+  double pop_integral(double a, double b) const {
+    if (kind == EMAT_POP_CONST) return (b - a) * p[0];
+    if (kind == EMAT_POP_EXP) {
+      const double t0 = p[0], n0 = p[1], g = p[2], mp = p[3];
+      if (mp == 0.0) return g == 0.0 ? (b - a) * n0 : exp_int(a, b);
+      if (g == 0.0) return (b - a) * std::max(mp, n0);
+      if (g > 0.0) {
+        if (b <= t_c) return (b - a) * mp;
+        if (a >= t_c) return exp_int(a, b);
+        return (t_c - a) * mp + n0 / g * std::exp(g * (t_c - t0)) * std::expm1(g * (b - t_c));
+      }
+      if (a >= t_c) return (b - a) * mp;
+      if (b <= t_c) return exp_int(a, b);
+      return n0 / g * std::exp(g * (a - t0)) * std::expm1(g * (t_c - a)) + (b - t_c) * mp;
+    }
+    const int M = (int)x.size() - 1;
+    int ka = interval(a), kb = interval(b);
+    int kka = std::max(ka - 1, 0), kkb = std::min(kb, M);
+    double bias = -std::numeric_limits<double>::infinity();
+    for (int k = kka; k <= kkb; ++k) bias = std::max(bias, gamma[k]);
+    double result = 0.0;
+    for (int k = ka; k <= kb; ++k) {
+      double lo = k > 0 ? std::max(a, x[k - 1]) : a, hi = k <= M ? std::min(b, x[k]) : b;
+      if (k == 0) result += std::exp(-bias + gamma[0]) * (hi - lo);
+      else if (k == M + 1) result += std::exp(-bias + gamma[M]) * (hi - lo);
+      else if (skygrid_type == 1) result += std::exp(-bias + gamma[k]) * (hi - lo);
+      else if (gamma[k] == gamma[k - 1]) result += std::exp(-bias + gamma[k]) * (hi - lo);
+      else {
+        double c_lo = (lo - x[k - 1]) / (x[k] - x[k - 1]), c_hi = (hi - x[k - 1]) / (x[k] - x[k - 1]);
+        double G_lo = (1 - c_lo) * gamma[k - 1] + c_lo * gamma[k], G_hi = (1 - c_hi) * gamma[k - 1] + c_hi * gamma[k];
+        double D = G_hi - G_lo;
+        result += (D == 0.0) ? std::exp(-bias + G_lo) * (hi - lo) : std::exp(-bias + G_lo) * (hi - lo) * (std::expm1(D) / D);
+      }
+    }
+    return std::exp(std::log(result) + bias);
+  }
+};
+
+// One part's share of the augmented coalescent prior, restricted to the window of cells it can touch.
+struct HostCoalPart {
+  int cell_first = 0;                 // first stored cell
+  int n_cells_total = 0;              // length of the logical k_bar_p vector (last_cell + 1)
+  std::vector<double> k_bar_p, k_twiddle_bar_p, k_twiddle_bar, popsize_bar;   // window [cell_first, n_cells_total)
+  std::vector<int32_t> num_active_parts;
+  double t_ref = 0.0, t_step = 1.0;
+};
+
+namespace coal_detail {
+inline int cell_for(double t, double t_ref, double t_step) { return (int)std::floor((t_ref - t) / t_step); }
+inline double cell_ubound(int c, double t_ref, double t_step) { return t_ref - t_step * c; }
+inline double cell_lbound(int c, double t_ref, double t_step) { return cell_ubound(c, t_ref, t_step) - t_step; }
+inline void add_interval(double ts, double te, double dk, std::vector<double>& k, double t_ref, double t_step) {   // cpp:37-79
+  if (ts < te) std::swap(ts, te);
+  int cs = cell_for(ts, t_ref, t_step);
+  int ce = (int)k.size() - 1;
+  if (te != cell_lbound(ce, t_ref, t_step)) ce = cell_for(te, t_ref, t_step);
+  if (cs < 0 || ce >= (int)k.size() || cs > ce) throw std::runtime_error("coalescent grid: interval outside the part's cells");
+  if (cs == ce) k[cs] += dk * (ts - te) / t_step;
+  else {
+    k[cs] += dk * (ts - cell_lbound(cs, t_ref, t_step)) / t_step;
+    k[ce] += dk * (cell_ubound(ce, t_ref, t_step) - te) / t_step;
+    for (int i = cs + 1; i < ce; ++i) k[i] += dk;
+  }
+}
+}  // namespace coal_detail
+
+// very_scalable_coalescent.cpp:85-232.  `rngs[p]` is part p's own stream (the reference draws from the
+// part's std::mt19937).  Returns one windowed part per subtree.
+inline std::vector<HostCoalPart> make_coalescent_parts(const std::vector<const FlatTree*>& subtrees, int root_part,
+                                                       const HostPopModel& pop, std::vector<HostRng*>& rngs, double t_step) {
+  using namespace coal_detail;
+  const int P = (int)subtrees.size();
+  std::vector<HostCoalPart> out(P);
+  if (P == 0) return out;
+  std::vector<double> tmin(P, std::numeric_limits<double>::max()), tmax(P, -std::numeric_limits<double>::max());
+  for (int p = 0; p < P; ++p) {
+    const FlatTree& st = *subtrees[p];
+    for (int n = 0; n < st.num_nodes(); ++n) {
+      bool tip = st.is_tip(n);
+      tmin[p] = std::min(tmin[p], tip ? (double)st.t_min[n] : st.t[n]);
+      tmax[p] = std::max(tmax[p], tip ? (double)st.t_max[n] : st.t[n]);
+    }
+  }
+  double all_min = *std::min_element(tmin.begin(), tmin.end()), all_max = *std::max_element(tmax.begin(), tmax.end());
+  tmin[root_part] = all_min;
+  const double t_ref = all_max;
+  const int num_cells = cell_for(all_min, t_ref, t_step) + 1;
+  std::vector<int32_t> num_active(num_cells, 0);
+  std::vector<int> fc(P), lc(P);
+  std::vector<std::vector<double>> kbar_p(P), ktw_p(P);
+  for (int p = 0; p < P; ++p) {
+    fc[p] = cell_for(tmax[p], t_ref, t_step); lc[p] = cell_for(tmin[p], t_ref, t_step);
+    if (!(0 <= fc[p] && fc[p] <= lc[p] && lc[p] < num_cells)) throw std::runtime_error("coalescent grid: bad cell range");
+    for (int c = fc[p]; c <= lc[p]; ++c) num_active[c] += 1;
+    kbar_p[p].assign(lc[p] + 1, 0.0); ktw_p[p].assign(lc[p] + 1, 0.0);
+  }
+  if (num_active.back() == 0) throw std::runtime_error("coalescent grid: inactive final cell");
+  for (int p = 0; p < P; ++p) {
+    const FlatTree& st = *subtrees[p];
+    for (int n = 0; n < st.num_nodes(); ++n) if (n != st.root) add_interval(st.t[st.parent[n]], st.t[n], +1.0, kbar_p[p], t_ref, t_step);
+  }
+  add_interval(cell_lbound(num_cells - 1, t_ref, t_step), subtrees[root_part]->t[subtrees[root_part]->root], +1.0, kbar_p[root_part], t_ref, t_step);
+  std::vector<double> k_bar(num_cells, 0.0), popsize(num_cells, 0.0), k_tw(num_cells, 0.0);
+  for (int p = 0; p < P; ++p) for (size_t i = 0; i < kbar_p[p].size(); ++i) k_bar[i] += kbar_p[p][i];
+  for (int i = 0; i < num_cells; ++i) popsize[i] = pop.pop_integral(cell_lbound(i, t_ref, t_step), cell_ubound(i, t_ref, t_step)) / t_step;
+  for (int p = 0; p < P; ++p)
+    for (int i = 0; i < (int)ktw_p[p].size(); ++i) {
+      if (fc[p] <= i && i <= lc[p]) {
+        double mu = kbar_p[p][i] - k_bar[i] / num_active[i];
+        double sigma = std::sqrt(popsize[i] / (num_active[i] * t_step));
+        ktw_p[p][i] = rngs[p]->gaussian(mu, sigma);
+      } else ktw_p[p][i] = 0.0;
+    }
+  for (int p = 0; p < P; ++p) for (size_t i = 0; i < ktw_p[p].size(); ++i) k_tw[i] += ktw_p[p][i];
+  for (int p = 0; p < P; ++p) {
+    HostCoalPart& cp = out[p];
+    cp.cell_first = fc[p]; cp.n_cells_total = lc[p] + 1; cp.t_ref = t_ref; cp.t_step = t_step;
+    cp.k_bar_p.assign(kbar_p[p].begin() + fc[p], kbar_p[p].end());
+    cp.k_twiddle_bar_p.assign(ktw_p[p].begin() + fc[p], ktw_p[p].end());
+    cp.k_twiddle_bar.assign(k_tw.begin() + fc[p], k_tw.begin() + lc[p] + 1);
+    cp.popsize_bar.assign(popsize.begin() + fc[p], popsize.begin() + lc[p] + 1);
+    cp.num_active_parts.assign(num_active.begin() + fc[p], num_active.begin() + lc[p] + 1);
+    // outside the window k_bar_p must be identically zero (it is: no branch of the part reaches there)
+    for (int i = 0; i < fc[p]; ++i) if (kbar_p[p][i] != 0.0) throw std::runtime_error("coalescent grid: lineage outside the part's window");
+  }
+  return out;
+}
+
+}  // namespace emat
+#endif  // EMAT_HOST_MODEL_HPP_

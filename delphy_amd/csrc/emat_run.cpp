@@ -1,0 +1,492 @@
+// emat_run.cpp -- host-side driver above the engine boundary (include/emat_host.h).
+//
+// Restates, on the host and in plain C++, the part of reference `Run` that orchestrates the local-move
+// hot path: random partition stencils (core/tree_partitioning.h:139-194), partition_tree (:196-239),
+// Run::repartition (core/run.cpp:110-193), Run::normalize_root (:258-265), Run::push_global_params_to_subruns
+// (:267-275), Run::run_local_moves (:682-693) and Run::reassemble (:195-256).  Global moves
+// (run.cpp:695-1235) are out of scope and are not here.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/emat_host.h"
+#include "flat_tree.hpp"
+#include "synth.hpp"
+
+namespace emat {
+
+struct HMut { double t; int32_t site; uint8_t from, to; };
+struct HIv { int32_t start, end; };
+struct HFs { int32_t site; uint8_t state; };
+struct HNode {
+  int32_t parent = EMAT_NO_NODE, c0 = EMAT_NO_NODE, c1 = EMAT_NO_NODE;
+  float t_min = -FLT_MAX, t_max = FLT_MAX;
+  double t = 0.0;
+  std::vector<HMut> muts; std::vector<HIv> miss; std::vector<HFs> mfs;
+  bool is_tip() const { return c0 == EMAT_NO_NODE; }
+};
+struct HTree {
+  int32_t root = EMAT_NO_NODE;
+  std::vector<HNode> nodes;
+  static HTree from_view(const emat_flat_tree& v) {
+    HTree t; t.root = v.root; t.nodes.resize(v.num_nodes);
+    for (int i = 0; i < v.num_nodes; ++i) {
+      HNode& n = t.nodes[i];
+      n.parent = v.parent[i]; n.c0 = v.child0[i]; n.c1 = v.child1[i]; n.t_min = v.t_min[i]; n.t_max = v.t_max[i]; n.t = v.t[i];
+      for (int k = v.mut_offset[i]; k < v.mut_offset[i + 1]; ++k) n.muts.push_back({v.mut_t[k], v.mut_site[k], v.mut_from[k], v.mut_to[k]});
+      for (int k = v.miss_offset[i]; k < v.miss_offset[i + 1]; ++k) n.miss.push_back({v.miss_start[k], v.miss_end[k]});
+      for (int k = v.mfs_offset[i]; k < v.mfs_offset[i + 1]; ++k) n.mfs.push_back({v.mfs_site[k], v.mfs_state[k]});
+    }
+    return t;
+  }
+  FlatTree to_flat() const {
+    FlatTree f; const int n = (int)nodes.size();
+    f.resize_nodes(n); f.root = root;
+    for (int i = 0; i < n; ++i) {
+      const HNode& nd = nodes[i];
+      f.parent[i] = nd.parent; f.child0[i] = nd.c0; f.child1[i] = nd.c1; f.t[i] = nd.t; f.t_min[i] = nd.t_min; f.t_max[i] = nd.t_max;
+      for (auto& m : nd.muts) { f.mut_site.push_back(m.site); f.mut_from.push_back(m.from); f.mut_to.push_back(m.to); f.mut_t.push_back(m.t); }
+      for (auto& iv : nd.miss) { f.miss_start.push_back(iv.start); f.miss_end.push_back(iv.end); }
+      for (auto& fs : nd.mfs) { f.mfs_site.push_back(fs.site); f.mfs_state.push_back(fs.state); }
+      f.mut_offset[i + 1] = (int32_t)f.mut_site.size(); f.miss_offset[i + 1] = (int32_t)f.miss_start.size(); f.mfs_offset[i + 1] = (int32_t)f.mfs_site.size();
+    }
+    return f;
+  }
+};
+
+static bool iv_contains(const std::vector<HIv>& v, int l) {
+  auto it = std::upper_bound(v.begin(), v.end(), l, [](int x, const HIv& iv) { return x < iv.start; });
+  if (it == v.begin()) return false;
+  --it; return l < it->end;
+}
+static std::vector<HIv> iv_merge(const std::vector<HIv>& A, const std::vector<HIv>& B) {   // interval_set.h:238-288
+  std::vector<HIv> out; size_t ia = 0, ib = 0; bool inside = false; int cs = 0, ce = 0;
+  while (!(ia == A.size() && ib == B.size())) {
+    bool useA = (ia == A.size()) ? false : (ib == B.size()) ? true : (A[ia].start <= B[ib].start);
+    HIv f = useA ? A[ia] : B[ib];
+    if (!inside) { cs = f.start; ce = f.end; (useA ? ia : ib)++; inside = true; }
+    else if (f.start <= ce) { ce = std::max(ce, f.end); (useA ? ia : ib)++; }
+    else { out.push_back({cs, ce}); inside = false; }
+  }
+  if (inside) out.push_back({cs, ce});
+  return out;
+}
+
+// A part of the partition: subtree <-> whole-tree node maps (tree_partitioning.h:31-54).
+struct PartMap {
+  int32_t cut_point = EMAT_NO_NODE;
+  std::vector<int32_t> orig;      // subtree node -> whole-tree node
+};
+
+struct RunDriver {
+  emat_backend* backend = nullptr;
+  std::string last_error;
+  HTree tree;
+  std::vector<uint8_t> ref;
+  int L = 0;
+  uint64_t seed = 0;
+  SplitMix64 bitgen{0};
+  int num_parts = 1;
+  // model
+  bool have_hky = false; double hky_mu = 0, hky_kappa = 1, hky_pi[4] = {0.25, 0.25, 0.25, 0.25};
+  std::vector<double> nu_l;
+  bool have_pop = false; emat_pop_model pop{}; std::vector<double> sky_x, sky_g;
+  double t_step = 1.0; bool t_step_set = false;
+  int only_displacing_inner_nodes = 0, topology_moves_enabled = 1;
+  // partition state
+  std::vector<std::vector<int32_t>> stencils; int64_t stencil_refresh_countdown = 0;
+  std::vector<PartMap> parts; std::vector<HTree> subtrees; std::vector<uint64_t> part_seeds;
+  int root_part = -1;
+  uint64_t epoch = 0;
+  bool parts_uploaded = false, model_pushed = false, coal_built = false;
+
+  double t_max_tip() const { double t = -INFINITY; for (auto& n : tree.nodes) if (n.is_tip() && n.t_max > t) t = n.t_max; return t; }   // phylo_tree_calc.cpp:636-644
+
+  // tree_partitioning.h:139-194
+  std::vector<int32_t> generate_random_partition_stencil() {
+    std::vector<int32_t> cuts;
+    const int N = (int)tree.nodes.size();
+    std::vector<int> descendants(N, 0);
+    long num_branches_left = N; int num_parts_left = num_parts;
+    struct Item { int32_t node; int csf; };
+    std::vector<Item> stack; stack.push_back({tree.root, -1});
+    bool done = false;
+    while (!stack.empty() && !done) {
+      Item it = stack.back(); stack.pop_back();
+      const HNode& nd = tree.nodes[it.node];
+      const int nch = nd.is_tip() ? 0 : 2;
+      if (it.csf == -1) {
+        stack.push_back({it.node, nch});
+        if (nch == 2) {
+          if (bitgen.next() >> 63) { stack.push_back({nd.c0, -1}); stack.push_back({it.node, 1}); stack.push_back({nd.c1, -1}); stack.push_back({it.node, 0}); }
+          else { stack.push_back({nd.c1, -1}); stack.push_back({it.node, 1}); stack.push_back({nd.c0, -1}); stack.push_back({it.node, 0}); }
+        }
+        continue;
+      }
+      if (it.csf != nch) continue;   // only post-order visits matter
+      const int node = it.node;
+      if (node == tree.root) break;
+      if ((int)cuts.size() == num_parts - 1) break;
+      descendants[node] = 1;
+      if (nch == 2) descendants[node] += descendants[nd.c0] + descendants[nd.c1];
+      long min_subtree_size = std::max(10L, num_branches_left / (num_parts_left + 1));
+      if (descendants[node] >= min_subtree_size) {
+        bool allowed = true;
+        if (allowed && (num_branches_left - (descendants[node] - 1)) < min_subtree_size) allowed = false;
+        if (allowed && (bitgen.next() >> 63)) allowed = false;
+        if (allowed) {
+          num_branches_left -= descendants[node] - 1;
+          cuts.push_back(node);
+          descendants[node] = 1;
+          --num_parts_left;
+        }
+      }
+    }
+    return cuts;
+  }
+
+  // tree_partitioning.h:88-135 and :196-239
+  void partition_tree(const std::vector<int32_t>& stencil) {
+    int root_idx = (int)stencil.size(); bool root_in = false;
+    for (size_t i = 0; i < stencil.size(); ++i) if (stencil[i] == tree.root) { root_in = true; root_idx = (int)i; break; }
+    const int P = (int)stencil.size() + (root_in ? 0 : 1);
+    std::unordered_set<int32_t> cut_points(stencil.begin(), stencil.end());
+    if (!root_in) { cut_points.insert(tree.root); root_idx = P - 1; }
+    root_part = root_idx;
+    parts.assign(P, PartMap{});
+    for (int i = 0; i < P; ++i) {
+      PartMap& pm = parts[i];
+      pm.cut_point = (i == root_part) ? tree.root : stencil[i];
+      struct W { int32_t src, dst; };
+      std::vector<W> work; pm.orig.clear(); pm.orig.push_back(pm.cut_point);
+      work.push_back({pm.cut_point, 0});
+      // children get consecutive indices when their parent is expanded; right child expanded first (LIFO)
+      std::vector<std::pair<int32_t, int32_t>> kids(1, {EMAT_NO_NODE, EMAT_NO_NODE});
+      while (!work.empty()) {
+        W w = work.back(); work.pop_back();
+        const HNode& sn = tree.nodes[w.src];
+        bool is_cut = cut_points.count(w.src) != 0;
+        if (sn.is_tip() || (is_cut && w.src != pm.cut_point)) continue;
+        int32_t dl = (int32_t)pm.orig.size(); pm.orig.push_back(sn.c0);
+        int32_t dr = (int32_t)pm.orig.size(); pm.orig.push_back(sn.c1);
+        kids.resize(pm.orig.size(), {EMAT_NO_NODE, EMAT_NO_NODE});
+        kids[w.dst] = {dl, dr};
+        work.push_back({sn.c0, dl}); work.push_back({sn.c1, dr});
+      }
+      part_kids.push_back(std::move(kids));
+    }
+  }
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> part_kids;
+
+  // Run::normalize_root + rereference_to_root_sequence (run.cpp:258-265, phylo_tree.cpp:309-322)
+  void normalize_root() {
+    HNode& r = tree.nodes[tree.root];
+    if (r.muts.empty()) return;
+    for (auto& m : r.muts) ref[m.site] = m.to;
+    for (auto& nd : tree.nodes) {
+      if (nd.miss.empty()) continue;
+      for (auto& m : r.muts) {
+        if (!iv_contains(nd.miss, m.site)) continue;
+        auto it = std::lower_bound(nd.mfs.begin(), nd.mfs.end(), m.site, [](const HFs& f, int l) { return f.site < l; });
+        if (it != nd.mfs.end() && it->site == m.site) { if (it->state == m.to) nd.mfs.erase(it); }
+        else if (m.from != m.to) nd.mfs.insert(it, HFs{m.site, m.from});
+      }
+    }
+    r.muts.clear();
+    model_pushed = false;   // the reference sequence (hence cum_Q) changed
+  }
+
+  void build_subtrees() {   // run.cpp:131-184
+    subtrees.clear(); part_seeds.clear();
+    const int P = (int)parts.size();
+    for (int p = 0; p < P; ++p) {
+      const PartMap& pm = parts[p];
+      const int n = (int)pm.orig.size();
+      HTree st; st.nodes.resize(n); st.root = 0;
+      const int32_t subroot = pm.cut_point;
+      // sites missing at the subroot and deltas ref -> subroot sequence (view_of_sequence_at, phylo_tree_calc.cpp:19-35)
+      std::vector<HIv> root_miss;
+      for (int cur = subroot; cur != EMAT_NO_NODE; cur = tree.nodes[cur].parent) root_miss = iv_merge(root_miss, tree.nodes[cur].miss);
+      std::map<int32_t, std::pair<uint8_t, uint8_t>> deltas;   // push_front_site_deltas walking up
+      for (int cur = subroot; cur != EMAT_NO_NODE; cur = tree.nodes[cur].parent) {
+        const auto& ms = tree.nodes[cur].muts;
+        for (auto it = ms.rbegin(); it != ms.rend(); ++it) {
+          auto f = deltas.find(it->site);
+          if (f == deltas.end()) deltas[it->site] = {it->from, it->to};
+          else { if (f->second.first != it->to) throw std::runtime_error("inconsistent mutation chain above a subroot"); f->second.first = it->from; if (f->second.first == f->second.second) deltas.erase(f); }
+        }
+      }
+      for (int s = 0; s < n; ++s) {
+        const int32_t o = pm.orig[s];
+        const HNode& on = tree.nodes[o];
+        HNode& sn = st.nodes[s];
+        sn.c0 = part_kids[p][s].first; sn.c1 = part_kids[p][s].second;
+        if (sn.c0 != EMAT_NO_NODE) { st.nodes[sn.c0].parent = s; st.nodes[sn.c1].parent = s; }
+        sn.t = on.t;
+        if (sn.is_tip() && !on.is_tip()) { sn.t_min = (float)on.t; sn.t_max = (float)on.t; }   // frozen boundary node (run.cpp:165-168)
+        else { sn.t_min = on.t_min; sn.t_max = on.t_max; }
+        if (o == subroot) {
+          sn.miss = root_miss;
+          for (auto& [l, d] : deltas) if (!iv_contains(root_miss, l)) sn.muts.push_back(HMut{-std::numeric_limits<double>::max(), l, ref[l], d.second});
+        } else { sn.muts = on.muts; sn.miss = on.miss; sn.mfs = on.mfs; }
+      }
+      st.nodes[0].parent = EMAT_NO_NODE;
+      // A frozen boundary "tip" whose float-rounded bounds do not bracket t would fail the t_min <= t <= t_max
+      // convention by an ulp of float; the reference tolerates 1e-2 (phylo_tree.cpp:117-121).  Keep t exact.
+      subtrees.push_back(std::move(st));
+      uint64_t z = seed ^ (0x9E3779B97F4A7C15ull * (epoch + 1)) ^ ((uint64_t)p << 32 | (uint64_t)p);
+      SplitMix64 sm(z);
+      part_seeds.push_back(sm.next());
+    }
+  }
+
+  emat_status fail(emat_status st, const std::string& m) { last_error = m; return st; }
+  emat_status bk(emat_status st) { if (st != EMAT_OK) last_error = std::string("backend: ") + emat_last_error(backend); return st; }
+
+  emat_status push_model() {
+    if (!backend) return EMAT_OK;
+    if (!have_hky) return fail(EMAT_ERR_STATE, "emat_run_set_hky must be called first");
+    emat_status st = bk(emat_set_ref_sequence(backend, ref.data(), L)); if (st) return st;
+    // Hky_model::derive_site_evo_model (evo_hky.cpp:7-50)
+    const double k = hky_kappa; const double* pi = hky_pi;
+    double r[4][4] = {{0, 1, k, 1}, {1, 0, 1, k}, {k, 1, 0, 1}, {1, k, 1, 0}};
+    double rowv[4]; for (int b = 0; b < 4; ++b) { rowv[b] = 0.0; for (int a = 0; a < 4; ++a) rowv[b] += pi[a] * r[a][b]; }
+    double R = 0.0; for (int b = 0; b < 4; ++b) R += rowv[b] * pi[b];
+    double q[16];
+    for (int a = 0; a < 4; ++a) { q[a * 4 + a] = 0.0; for (int b = 0; b < 4; ++b) if (a != b) { q[a * 4 + b] = r[a][b] / R * pi[b]; q[a * 4 + a] -= q[a * 4 + b]; } }
+    std::vector<int32_t> pfs(L, 0);
+    std::vector<double> nu = nu_l.empty() ? std::vector<double>(L, 1.0) : nu_l;
+    st = bk(emat_set_evo(backend, 1, &hky_mu, pi, q, nu.data(), pfs.data())); if (st) return st;
+    st = bk(emat_set_flags(backend, t_max_tip(), only_displacing_inner_nodes, topology_moves_enabled)); if (st) return st;
+    model_pushed = true;
+    return EMAT_OK;
+  }
+  double default_t_step() const {   // Run keeps ~400 cells over the tree span (run.cpp:20, :734-747)
+    double lo = tree.nodes[tree.root].t, hi = t_max_tip();
+    double span = hi - lo; if (!(span > 0)) span = 1.0;
+    return std::max(span / 400.0, 1.0 / 400.0);
+  }
+  emat_status build_coalescent() {   // Run::reset_very_scalable_coalescent_parts (run.cpp:277-293)
+    if (!backend) return EMAT_OK;
+    if (!have_pop) return fail(EMAT_ERR_STATE, "emat_run_set_pop_model must be called first");
+    emat_pop_model pm = pop; pm.skygrid_x = sky_x.data(); pm.skygrid_gamma = sky_g.data();
+    emat_status st = bk(emat_build_coalescent_parts(backend, &pm, root_part, t_step_set ? t_step : default_t_step())); if (st) return st;
+    coal_built = true;
+    return EMAT_OK;
+  }
+  emat_status upload_parts() {
+    if (!backend) return EMAT_OK;
+    emat_status st = bk(emat_begin_upload(backend, (int)subtrees.size())); if (st) return st;
+    for (size_t p = 0; p < subtrees.size(); ++p) {
+      FlatTree f = subtrees[p].to_flat();
+      emat_flat_tree v = f.view();
+      st = bk(emat_part_upload(backend, (int)p, &v, (int)p == root_part ? 1 : 0, part_seeds[p])); if (st) return st;
+    }
+    st = bk(emat_end_upload(backend)); if (st) return st;
+    parts_uploaded = true;
+    return EMAT_OK;
+  }
+
+  emat_status repartition() {   // run.cpp:110-193 (+ refresh_partition_stencils :87-108)
+    try {
+      if (stencils.empty() || stencil_refresh_countdown <= 0) {
+        stencils.clear();
+        for (int i = 0; i < 10; ++i) stencils.push_back(generate_random_partition_stencil());
+        stencil_refresh_countdown = 200;
+      }
+      --stencil_refresh_countdown;
+      const auto& stencil = stencils[bitgen.below((int)stencils.size())];
+      part_kids.clear();
+      partition_tree(stencil);
+      if (!tree.nodes[tree.root].mfs.empty()) return fail(EMAT_ERR_INTERNAL, "root missations carry from_states");
+      normalize_root();
+      ++epoch;
+      build_subtrees();
+    } catch (const std::exception& ex) { return fail(EMAT_ERR_INTERNAL, ex.what()); }
+    parts_uploaded = false; coal_built = false;
+    if (backend) {
+      emat_status st;
+      if (!model_pushed) { st = push_model(); if (st) return st; }
+      st = upload_parts(); if (st) return st;
+      st = build_coalescent(); if (st) return st;
+    }
+    return EMAT_OK;
+  }
+
+  emat_status reassemble() {   // run.cpp:195-256
+    try {
+      if (backend && parts_uploaded) {
+        for (size_t p = 0; p < subtrees.size(); ++p) {
+          int32_t nn, nm, ni, nf;
+          emat_status st = bk(emat_part_get_sizes(backend, (int)p, &nn, &nm, &ni, &nf)); if (st) return st;
+          FlatTree f; f.allocate(nn, nm, ni, nf);
+          emat_flat_tree v = f.view();
+          st = bk(emat_part_download(backend, (int)p, &v)); if (st) return st;
+          f.root = v.root;
+          emat_flat_tree v2 = f.view();
+          subtrees[p] = HTree::from_view(v2);
+        }
+      }
+      for (size_t p = 0; p < subtrees.size(); ++p) {
+        const PartMap& pm = parts[p]; const HTree& st = subtrees[p];
+        if ((int)st.nodes.size() != (int)pm.orig.size()) return fail(EMAT_ERR_INTERNAL, "subtree size changed");
+        for (int s = 0; s < (int)st.nodes.size(); ++s) {
+          const int32_t o = pm.orig[s]; const HNode& sn = st.nodes[s]; HNode& on = tree.nodes[o];
+          on.t = sn.t;
+          if (s != st.root) { on.muts = sn.muts; on.miss = sn.miss; on.mfs = sn.mfs; }
+          if (!sn.is_tip()) {
+            int32_t l = pm.orig[sn.c0], r = pm.orig[sn.c1];
+            on.c0 = l; on.c1 = r; tree.nodes[l].parent = o; tree.nodes[r].parent = o;
+          }
+        }
+        if ((int)p == root_part) {
+          const int32_t nr = pm.orig[st.root];
+          tree.root = nr; tree.nodes[nr].parent = EMAT_NO_NODE;
+          tree.nodes[nr].muts = st.nodes[st.root].muts; tree.nodes[nr].miss = st.nodes[st.root].miss; tree.nodes[nr].mfs = st.nodes[st.root].mfs;
+        }
+      }
+    } catch (const std::exception& ex) { return fail(EMAT_ERR_INTERNAL, ex.what()); }
+    return EMAT_OK;
+  }
+};
+
+}  // namespace emat
+
+using namespace emat;
+
+struct emat_synth { SynthResult res; };
+struct emat_run { RunDriver d; };
+
+extern "C" {
+
+emat_status emat_synth_create(const emat_synth_params* p, emat_synth** out) {
+  if (!p || !out || p->num_tips < 2 || p->num_sites < 1) return EMAT_ERR_INVALID_ARGUMENT;
+  SynthParams sp;
+  sp.num_tips = p->num_tips; sp.num_sites = p->num_sites; sp.tip_span = p->tip_span; sp.tip_date_uncertainty = p->tip_date_uncertainty;
+  sp.frac_uncertain_tips = p->frac_uncertain_tips; sp.pop_n0 = p->pop_n0; sp.pop_growth = p->pop_growth; sp.mu = p->mu; sp.kappa = p->kappa;
+  for (int a = 0; a < 4; ++a) sp.pi[a] = p->pi[a];
+  sp.gaps_per_tip = p->gaps_per_tip; sp.mean_gap_len = p->mean_gap_len; sp.seed = p->seed;
+  auto* s = new emat_synth;
+  try { s->res = make_synthetic_emat(sp); } catch (...) { delete s; return EMAT_ERR_INTERNAL; }
+  *out = s;
+  return EMAT_OK;
+}
+void emat_synth_destroy(emat_synth* s) { delete s; }
+emat_status emat_synth_get(emat_synth* s, emat_flat_tree* tree_view, const uint8_t** ref, double* t_max_tip) {
+  if (!s) return EMAT_ERR_INVALID_ARGUMENT;
+  if (tree_view) *tree_view = s->res.tree.view();
+  if (ref) *ref = s->res.ref_sequence.data();
+  if (t_max_tip) *t_max_tip = s->res.t_max_tip;
+  return EMAT_OK;
+}
+
+emat_status emat_run_create(emat_backend* backend, const emat_flat_tree* tree, const uint8_t* ref, int32_t L, uint64_t seed, emat_run** out) {
+  if (!tree || !ref || !out || L <= 0) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!validate_flat_tree(*tree, L).empty()) return EMAT_ERR_INVALID_ARGUMENT;
+  auto* r = new emat_run;
+  r->d.backend = backend; r->d.tree = HTree::from_view(*tree); r->d.ref.assign(ref, ref + L); r->d.L = L; r->d.seed = seed; r->d.bitgen = SplitMix64(seed ^ 0xD1B54A32D192ED03ull);
+  *out = r;
+  return EMAT_OK;
+}
+emat_status emat_run_destroy(emat_run* r) { delete r; return EMAT_OK; }
+const char* emat_run_last_error(const emat_run* r) { return r ? r->d.last_error.c_str() : "null run"; }
+
+emat_status emat_run_set_num_parts(emat_run* r, int32_t n) { if (!r || n < 1) return EMAT_ERR_INVALID_ARGUMENT; r->d.num_parts = n; r->d.stencils.clear(); return EMAT_OK; }
+emat_status emat_run_set_hky(emat_run* r, double mu, double kappa, const double pi[4], const double* nu_l) {
+  if (!r || !pi || !(mu >= 0) || !(kappa > 0)) return EMAT_ERR_INVALID_ARGUMENT;
+  r->d.hky_mu = mu; r->d.hky_kappa = kappa; for (int a = 0; a < 4; ++a) r->d.hky_pi[a] = pi[a];
+  if (nu_l) r->d.nu_l.assign(nu_l, nu_l + r->d.L); else r->d.nu_l.clear();
+  r->d.have_hky = true; r->d.model_pushed = false;
+  return EMAT_OK;
+}
+emat_status emat_run_set_pop_model(emat_run* r, const emat_pop_model* pm) {
+  if (!r || !pm) return EMAT_ERR_INVALID_ARGUMENT;
+  r->d.pop = *pm;
+  if (pm->kind == EMAT_POP_SKYGRID) { r->d.sky_x.assign(pm->skygrid_x, pm->skygrid_x + pm->skygrid_num_knots); r->d.sky_g.assign(pm->skygrid_gamma, pm->skygrid_gamma + pm->skygrid_num_knots); }
+  r->d.have_pop = true; r->d.coal_built = false;
+  return EMAT_OK;
+}
+emat_status emat_run_set_coalescent_t_step(emat_run* r, double t_step) { if (!r || !(t_step > 0)) return EMAT_ERR_INVALID_ARGUMENT; r->d.t_step = t_step; r->d.t_step_set = true; return EMAT_OK; }
+emat_status emat_run_set_flags(emat_run* r, int32_t odin, int32_t topo) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; r->d.only_displacing_inner_nodes = odin; r->d.topology_moves_enabled = topo; r->d.model_pushed = false; return EMAT_OK; }
+
+emat_status emat_run_repartition(emat_run* r) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; return r->d.repartition(); }
+emat_status emat_run_num_parts(emat_run* r, int32_t* n, int32_t* root_part) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; if (n) *n = (int)r->d.parts.size(); if (root_part) *root_part = r->d.root_part; return EMAT_OK; }
+emat_status emat_run_part_sizes(emat_run* r, int32_t p, int32_t* nn, int32_t* nm, int32_t* ni, int32_t* nf) {
+  if (!r || p < 0 || p >= (int)r->d.subtrees.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  int m = 0, i = 0, f = 0; for (auto& nd : r->d.subtrees[p].nodes) { m += (int)nd.muts.size(); i += (int)nd.miss.size(); f += (int)nd.mfs.size(); }
+  if (nn) *nn = (int)r->d.subtrees[p].nodes.size(); if (nm) *nm = m; if (ni) *ni = i; if (nf) *nf = f;
+  return EMAT_OK;
+}
+static emat_status copy_out(const FlatTree& t, emat_flat_tree* out) {
+  const int n = t.num_nodes();
+  if (out->num_nodes < n || out->cap_muts < t.num_muts() || out->cap_intervals < t.num_intervals() || out->cap_from_states < t.num_from_states()) return EMAT_ERR_BUFFER_TOO_SMALL;
+  out->num_nodes = n; out->root = t.root;
+  std::copy(t.parent.begin(), t.parent.end(), out->parent); std::copy(t.child0.begin(), t.child0.end(), out->child0); std::copy(t.child1.begin(), t.child1.end(), out->child1);
+  std::copy(t.t.begin(), t.t.end(), out->t); std::copy(t.t_min.begin(), t.t_min.end(), out->t_min); std::copy(t.t_max.begin(), t.t_max.end(), out->t_max);
+  std::copy(t.mut_offset.begin(), t.mut_offset.end(), out->mut_offset); std::copy(t.mut_site.begin(), t.mut_site.end(), out->mut_site);
+  std::copy(t.mut_from.begin(), t.mut_from.end(), out->mut_from); std::copy(t.mut_to.begin(), t.mut_to.end(), out->mut_to); std::copy(t.mut_t.begin(), t.mut_t.end(), out->mut_t);
+  std::copy(t.miss_offset.begin(), t.miss_offset.end(), out->miss_offset); std::copy(t.miss_start.begin(), t.miss_start.end(), out->miss_start); std::copy(t.miss_end.begin(), t.miss_end.end(), out->miss_end);
+  std::copy(t.mfs_offset.begin(), t.mfs_offset.end(), out->mfs_offset); std::copy(t.mfs_site.begin(), t.mfs_site.end(), out->mfs_site); std::copy(t.mfs_state.begin(), t.mfs_state.end(), out->mfs_state);
+  return EMAT_OK;
+}
+emat_status emat_run_part_get(emat_run* r, int32_t p, emat_flat_tree* out, int32_t* incl_root, uint64_t* seed) {
+  if (!r || !out || p < 0 || p >= (int)r->d.subtrees.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  if (incl_root) *incl_root = p == r->d.root_part ? 1 : 0;
+  if (seed) *seed = r->d.part_seeds[p];
+  return copy_out(r->d.subtrees[p].to_flat(), out);
+}
+emat_status emat_run_part_put(emat_run* r, int32_t p, const emat_flat_tree* st) {
+  if (!r || !st || p < 0 || p >= (int)r->d.subtrees.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!validate_flat_tree(*st, r->d.L).empty() || st->num_nodes != (int)r->d.parts[p].orig.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  r->d.subtrees[p] = HTree::from_view(*st);
+  return EMAT_OK;
+}
+emat_status emat_run_push_params(emat_run* r) {
+  if (!r) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!r->d.backend) return EMAT_OK;
+  emat_status st = r->d.push_model(); if (st) return st;
+  if (!r->d.parts_uploaded) return r->d.fail(EMAT_ERR_STATE, "repartition first");
+  return r->d.build_coalescent();   // run.cpp:267-275 rebuilds the coalescent parts at every push
+}
+emat_status emat_run_moves(emat_run* r, int64_t count) {
+  if (!r || count < 0) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!r->d.backend) return r->d.fail(EMAT_ERR_NO_DEVICE, "no backend attached: the host driver never runs moves itself");
+  if (!r->d.parts_uploaded) return r->d.fail(EMAT_ERR_STATE, "repartition first");
+  return r->d.bk(emat_run_local_moves(r->d.backend, count));
+}
+emat_status emat_run_reassemble(emat_run* r) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; return r->d.reassemble(); }
+emat_status emat_run_do_mcmc_steps(emat_run* r, int64_t steps, int64_t per_cycle) {   // run.cpp:622-657 minus global moves
+  if (!r || steps < 0) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!r->d.backend) return r->d.fail(EMAT_ERR_NO_DEVICE, "no backend attached");
+  if (per_cycle <= 0) per_cycle = 50 * (int64_t)r->d.tree.nodes.size();
+  int64_t done = 0;
+  while (done < steps) {
+    emat_status st = r->d.repartition(); if (st) return st;
+    int64_t k = std::min(per_cycle, steps - done);
+    st = r->d.bk(emat_run_local_moves(r->d.backend, k)); if (st) return st;
+    st = r->d.reassemble(); if (st) return st;
+    done += k;
+  }
+  r->d.normalize_root();
+  return EMAT_OK;
+}
+emat_status emat_run_tree_sizes(emat_run* r, int32_t* nn, int32_t* nm, int32_t* ni, int32_t* nf) {
+  if (!r) return EMAT_ERR_INVALID_ARGUMENT;
+  int m = 0, i = 0, f = 0; for (auto& nd : r->d.tree.nodes) { m += (int)nd.muts.size(); i += (int)nd.miss.size(); f += (int)nd.mfs.size(); }
+  if (nn) *nn = (int)r->d.tree.nodes.size(); if (nm) *nm = m; if (ni) *ni = i; if (nf) *nf = f;
+  return EMAT_OK;
+}
+emat_status emat_run_tree_get(emat_run* r, emat_flat_tree* out, uint8_t* ref) {
+  if (!r || !out) return EMAT_ERR_INVALID_ARGUMENT;
+  if (ref) std::copy(r->d.ref.begin(), r->d.ref.end(), ref);
+  return copy_out(r->d.tree.to_flat(), out);
+}
+emat_status emat_run_t_max_tip(emat_run* r, double* t) { if (!r || !t) return EMAT_ERR_INVALID_ARGUMENT; *t = r->d.t_max_tip(); return EMAT_OK; }
+
+}  // extern "C"

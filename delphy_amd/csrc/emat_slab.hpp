@@ -1,0 +1,140 @@
+// emat_slab.hpp -- layout of one partition part's working set ("slab") in HBM / LDS.
+//
+// Reference data model being flattened: Phylo_node{parent, children[2], t_min, t_max, t,
+// vector<Mutation>, Missation_map} (core/phylo_tree.h:14-23), plus the Subrun's derived per-node
+// arrays lambda_i_ and num_sites_missing_at_every_node_ (core/subrun.h:100-107) and the part's
+// Very_scalable_coalescent_prior_part vectors (core/very_scalable_coalescent.h:47-56).
+//
+// A slab is ONE relocatable byte blob per part (all internal references are byte offsets), so that a
+// workgroup can stream it into LDS with one coalesced copy, run its chain there, and stream it back:
+//
+//   [SlabHeader 512 B][NodeRec x n_nodes (64 B each)][cell table (5 arrays x cell_cap)]
+//   [trace ring][list heap: 16-B mutation / 8-B interval / 8-B from-state records][scratch]
+//
+// Plain C++ (no HIP types) because the host encoder and the kernels share it.
+#ifndef EMAT_SLAB_HPP_
+#define EMAT_SLAB_HPP_
+
+#include <cstdint>
+
+namespace emat {
+
+constexpr uint32_t k_slab_magic = 0x454D4154u;  // "EMAT"
+
+enum PartStatus : int32_t {
+  k_part_ok = 0,
+  k_part_need_space = 101,     // stopped BEFORE a move: heap reserve or scratch too small (state is consistent)
+  k_part_overflow = 102,       // a container overflowed INSIDE a move (state is not trustworthy)
+  k_part_cell_overflow = 103,  // root part needed more coalescent cells than its capacity
+  k_part_internal = 104        // an invariant that the reference CHECKs failed
+};
+
+enum SlabFlags : uint32_t { k_flag_includes_run_root = 1u };
+
+// A list living in the slab heap.  `off` is a byte offset from the slab base.
+struct ListRef {
+  uint32_t off;
+  uint16_t cnt;
+  uint16_t cap;
+};
+
+struct MutRec {     // 16 B   (reference Mutation{from, site, to, t}, core/mutations.h:21-29)
+  double t;
+  int32_t site;
+  uint8_t from;
+  uint8_t to;
+  uint16_t pad;
+};
+struct IvRec { int32_t start, end; };          // 8 B, half-open [start,end)  (core/interval_set.h:26)
+struct FsRec { int32_t site; uint8_t state; uint8_t pad[3]; };   // 8 B, Missation_map::from_states entry
+
+struct NodeRec {    // 64 B = one cache line per node
+  int32_t parent;
+  int32_t child0;
+  int32_t child1;
+  float t_min;
+  float t_max;
+  ListRef muts;       // MutRec[]
+  ListRef miss;       // IvRec[]
+  ListRef mfs;        // FsRec[]
+  int32_t n_missing;  // num_sites_missing_at_every_node_[node]
+  double t;
+  double lambda;      // lambda_i_[node]
+};
+static_assert(sizeof(ListRef) == 8, "ListRef must be 8 bytes");
+static_assert(sizeof(MutRec) == 16, "MutRec must be 16 bytes");
+static_assert(sizeof(NodeRec) == 64, "NodeRec must be 64 bytes");
+
+struct SlabHeader {
+  uint32_t magic;
+  uint32_t slab_bytes;         // total capacity of this slab
+  int32_t n_nodes;
+  int32_t root;
+  uint32_t flags;
+  int32_t status;              // PartStatus
+  uint64_t rng_key;
+  uint64_t rng_counter;
+  double log_G;
+  double log_aug_prior;
+  // regions (byte offsets from slab base)
+  uint32_t off_nodes;
+  uint32_t off_cells;          // 4 double arrays [cell_cap] then 1 int32 array [cell_cap]
+  uint32_t off_trace;
+  uint32_t heap_begin, heap_top, heap_end;
+  uint32_t scratch_begin, scratch_end;
+  // coalescent window: stored cells are [cell_first, cell_first + n_cells)
+  int32_t cell_first;
+  int32_t n_cells;
+  int32_t cell_cap;
+  int32_t n_cells_total;       // length of the part's logical k_bar_p vector (= cell_first + n_cells)
+  double t_ref;
+  double t_step;
+  // trace ring (tests)
+  int32_t trace_cap;
+  int32_t trace_len;
+  // statistics
+  int64_t moves_done;
+  int64_t proposed[5];
+  int64_t accepted[5];
+  int64_t alg_bytes;
+  int32_t fail_line;           // source line of the first failed device check (debugging aid)
+  int32_t compactions;
+  uint8_t reserved[280];
+};
+static_assert(sizeof(SlabHeader) == 512, "SlabHeader must be 512 bytes");
+
+// Shared, read-only model data in HBM (one copy per device).
+struct EvoTable {               // reference Global_evo_model (core/evo_model.h:20-48)
+  int32_t num_sites;
+  int32_t num_partitions;
+  const uint8_t* ref_sequence;        // [L]
+  const uint8_t* partition_for_site;  // [L]
+  const double* nu_l;                 // [L]
+  const double* cum_Q_l;              // [L+1]   ref_cum_Q_l_ (core/phylo_tree_calc.cpp:379-388)
+  const double* mu;                   // [P]
+  const double* pi;                   // [P][4]
+  const double* q;                    // [P][4][4]
+};
+constexpr int k_max_lds_partitions = 4;   // HKY tables of up to this many site partitions are staged in LDS
+
+struct PopTable {               // reference Pop_model family (core/pop_model.h)
+  int32_t kind;                 // emat_pop_model_kind
+  int32_t skygrid_type;
+  int32_t skygrid_num_knots;
+  int32_t pad;
+  double p[4];
+  double t_c;                   // Exp_pop_model::t_c_
+  const double* skygrid_x;
+  const double* skygrid_gamma;
+};
+
+struct RunFlags {
+  double t_max_tip;
+  int32_t only_displacing_inner_nodes;
+  int32_t topology_moves_enabled;
+};
+
+inline uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace emat
+#endif  // EMAT_SLAB_HPP_

@@ -1,0 +1,530 @@
+"""ctypes mirror of include/emat_backend.h and include/emat_host.h.
+
+Names and argument meaning follow the reference interface each call replaces (`Subrun` as driven by
+`Run`, /root/reference core/subrun.h:16-135 and core/run.cpp:110-293,610-693); see the headers for the
+file:line of every entry point.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_LIB_NAME = "libemat_hip.so"
+
+
+class EmatError(RuntimeError):
+    pass
+
+
+STATUS_NAMES = {
+    0: "EMAT_OK", 1: "EMAT_ERR_INVALID_ARGUMENT", 2: "EMAT_ERR_NO_DEVICE", 3: "EMAT_ERR_HIP", 4: "EMAT_ERR_STATE",
+    5: "EMAT_ERR_CAPACITY", 6: "EMAT_ERR_INTERNAL", 7: "EMAT_ERR_BUFFER_TOO_SMALL",
+}
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+def build_library(force: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    path = library_path()
+    if force and os.path.exists(path):
+        os.remove(path)
+    subprocess.run(["make", "-C", _CSRC], check=True, capture_output=not bool(os.environ.get("EMAT_VERBOSE_BUILD")))
+    if not os.path.exists(path):
+        raise EmatError("building %s failed" % _LIB_NAME)
+    return path
+
+
+class _FlatTreeC(C.Structure):
+    _fields_ = [
+        ("num_nodes", C.c_int32), ("root", C.c_int32),
+        ("parent", C.POINTER(C.c_int32)), ("child0", C.POINTER(C.c_int32)), ("child1", C.POINTER(C.c_int32)),
+        ("t", C.POINTER(C.c_double)), ("t_min", C.POINTER(C.c_float)), ("t_max", C.POINTER(C.c_float)),
+        ("mut_offset", C.POINTER(C.c_int32)), ("mut_site", C.POINTER(C.c_int32)), ("mut_from", C.POINTER(C.c_uint8)),
+        ("mut_to", C.POINTER(C.c_uint8)), ("mut_t", C.POINTER(C.c_double)),
+        ("miss_offset", C.POINTER(C.c_int32)), ("miss_start", C.POINTER(C.c_int32)), ("miss_end", C.POINTER(C.c_int32)),
+        ("mfs_offset", C.POINTER(C.c_int32)), ("mfs_site", C.POINTER(C.c_int32)), ("mfs_state", C.POINTER(C.c_uint8)),
+        ("cap_muts", C.c_int32), ("cap_intervals", C.c_int32), ("cap_from_states", C.c_int32),
+    ]
+
+
+class _PopModelC(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("p", C.c_double * 4), ("skygrid_type", C.c_int32), ("skygrid_num_knots", C.c_int32),
+                ("skygrid_x", C.POINTER(C.c_double)), ("skygrid_gamma", C.POINTER(C.c_double))]
+
+
+class _ConfigC(C.Structure):
+    _fields_ = [("device", C.c_int32), ("num_sites", C.c_int32), ("max_parts", C.c_int32), ("slab_slack", C.c_double),
+                ("trace_moves", C.c_int32), ("use_lds", C.c_int32)]
+
+
+class _PartStatsC(C.Structure):
+    _fields_ = [("status", C.c_int32), ("num_nodes", C.c_int32), ("moves_done", C.c_int64), ("proposed", C.c_int64 * 5),
+                ("accepted", C.c_int64 * 5), ("algorithmic_bytes", C.c_int64), ("rng_draws", C.c_int64)]
+
+
+class _SynthParamsC(C.Structure):
+    _fields_ = [("num_tips", C.c_int32), ("num_sites", C.c_int32), ("tip_span", C.c_double), ("tip_date_uncertainty", C.c_double),
+                ("frac_uncertain_tips", C.c_double), ("pop_n0", C.c_double), ("pop_growth", C.c_double), ("mu", C.c_double),
+                ("kappa", C.c_double), ("pi", C.c_double * 4), ("gaps_per_tip", C.c_int32), ("mean_gap_len", C.c_double), ("seed", C.c_uint64)]
+
+
+def _ptr(a: np.ndarray, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+@dataclass
+class FlatTree:
+    """numpy owner of an `emat_flat_tree` (struct-of-arrays + CSR lists; include/emat_backend.h)."""
+    root: int
+    parent: np.ndarray
+    child0: np.ndarray
+    child1: np.ndarray
+    t: np.ndarray
+    t_min: np.ndarray
+    t_max: np.ndarray
+    mut_offset: np.ndarray
+    mut_site: np.ndarray
+    mut_from: np.ndarray
+    mut_to: np.ndarray
+    mut_t: np.ndarray
+    miss_offset: np.ndarray
+    miss_start: np.ndarray
+    miss_end: np.ndarray
+    mfs_offset: np.ndarray
+    mfs_site: np.ndarray
+    mfs_state: np.ndarray
+
+    @property
+    def num_nodes(self) -> int:
+        return int(self.parent.shape[0])
+
+    @staticmethod
+    def empty(n: int, nm: int, ni: int, nf: int) -> "FlatTree":
+        i32, f64, f32, u8 = np.int32, np.float64, np.float32, np.uint8
+        return FlatTree(-1, np.full(n, -1, i32), np.full(n, -1, i32), np.full(n, -1, i32), np.zeros(n, f64), np.zeros(n, f32), np.zeros(n, f32),
+                        np.zeros(n + 1, i32), np.zeros(max(nm, 1), i32), np.zeros(max(nm, 1), u8), np.zeros(max(nm, 1), u8), np.zeros(max(nm, 1), f64),
+                        np.zeros(n + 1, i32), np.zeros(max(ni, 1), i32), np.zeros(max(ni, 1), i32),
+                        np.zeros(n + 1, i32), np.zeros(max(nf, 1), i32), np.zeros(max(nf, 1), u8))
+
+    def c_view(self) -> _FlatTreeC:
+        v = _FlatTreeC()
+        v.num_nodes = self.num_nodes
+        v.root = self.root
+        v.parent, v.child0, v.child1 = _ptr(self.parent, C.c_int32), _ptr(self.child0, C.c_int32), _ptr(self.child1, C.c_int32)
+        v.t, v.t_min, v.t_max = _ptr(self.t, C.c_double), _ptr(self.t_min, C.c_float), _ptr(self.t_max, C.c_float)
+        v.mut_offset, v.mut_site = _ptr(self.mut_offset, C.c_int32), _ptr(self.mut_site, C.c_int32)
+        v.mut_from, v.mut_to, v.mut_t = _ptr(self.mut_from, C.c_uint8), _ptr(self.mut_to, C.c_uint8), _ptr(self.mut_t, C.c_double)
+        v.miss_offset, v.miss_start, v.miss_end = _ptr(self.miss_offset, C.c_int32), _ptr(self.miss_start, C.c_int32), _ptr(self.miss_end, C.c_int32)
+        v.mfs_offset, v.mfs_site, v.mfs_state = _ptr(self.mfs_offset, C.c_int32), _ptr(self.mfs_site, C.c_int32), _ptr(self.mfs_state, C.c_uint8)
+        v.cap_muts, v.cap_intervals, v.cap_from_states = self.mut_site.shape[0], self.miss_start.shape[0], self.mfs_site.shape[0]
+        return v
+
+    def trimmed(self) -> "FlatTree":
+        """Drop the padding of the variable-length arrays (after a download)."""
+        n = self.num_nodes
+        nm, ni, nf = int(self.mut_offset[n]), int(self.miss_offset[n]), int(self.mfs_offset[n])
+        return FlatTree(self.root, self.parent, self.child0, self.child1, self.t, self.t_min, self.t_max,
+                        self.mut_offset, self.mut_site[:nm].copy(), self.mut_from[:nm].copy(), self.mut_to[:nm].copy(), self.mut_t[:nm].copy(),
+                        self.miss_offset, self.miss_start[:ni].copy(), self.miss_end[:ni].copy(),
+                        self.mfs_offset, self.mfs_site[:nf].copy(), self.mfs_state[:nf].copy())
+
+    @staticmethod
+    def from_c_view(v: _FlatTreeC) -> "FlatTree":
+        n = v.num_nodes
+        def arr(p, cnt, dt):
+            return np.ctypeslib.as_array(p, shape=(max(cnt, 1),)).astype(dt, copy=True)[:cnt] if cnt > 0 else np.zeros(0, dt)
+        mo = arr(v.mut_offset, n + 1, np.int32)
+        io = arr(v.miss_offset, n + 1, np.int32)
+        fo = arr(v.mfs_offset, n + 1, np.int32)
+        nm, ni, nf = int(mo[n]), int(io[n]), int(fo[n])
+        def padded(a, dt):
+            return a if a.shape[0] > 0 else np.zeros(1, dt)
+        return FlatTree(v.root, arr(v.parent, n, np.int32), arr(v.child0, n, np.int32), arr(v.child1, n, np.int32),
+                        arr(v.t, n, np.float64), arr(v.t_min, n, np.float32), arr(v.t_max, n, np.float32),
+                        mo, padded(arr(v.mut_site, nm, np.int32), np.int32), padded(arr(v.mut_from, nm, np.uint8), np.uint8),
+                        padded(arr(v.mut_to, nm, np.uint8), np.uint8), padded(arr(v.mut_t, nm, np.float64), np.float64),
+                        io, padded(arr(v.miss_start, ni, np.int32), np.int32), padded(arr(v.miss_end, ni, np.int32), np.int32),
+                        fo, padded(arr(v.mfs_site, nf, np.int32), np.int32), padded(arr(v.mfs_state, nf, np.uint8), np.uint8))
+
+
+@dataclass
+class PopModel:
+    """Population model descriptor (reference core/pop_model.h): kind 0 const{pop}, 1 exp{t0,n0,g,min_pop}, 2 skygrid."""
+    kind: int = 0
+    p: Sequence[float] = (1.0, 0.0, 0.0, 0.0)
+    skygrid_type: int = 1
+    skygrid_x: Optional[np.ndarray] = None
+    skygrid_gamma: Optional[np.ndarray] = None
+    _keep: list = field(default_factory=list, repr=False)
+
+    @staticmethod
+    def const(pop: float) -> "PopModel":
+        return PopModel(0, (pop, 0.0, 0.0, 0.0))
+
+    @staticmethod
+    def exp(t0: float, n0: float, g: float, min_pop: float = 0.0) -> "PopModel":
+        return PopModel(1, (t0, n0, g, min_pop))
+
+    @staticmethod
+    def skygrid(x, gamma, log_linear: bool = False) -> "PopModel":
+        return PopModel(2, (0.0, 0.0, 0.0, 0.0), 2 if log_linear else 1, np.ascontiguousarray(x, np.float64), np.ascontiguousarray(gamma, np.float64))
+
+    def c_struct(self) -> _PopModelC:
+        m = _PopModelC()
+        m.kind = self.kind
+        for i in range(4):
+            m.p[i] = float(self.p[i])
+        m.skygrid_type = self.skygrid_type
+        if self.kind == 2:
+            m.skygrid_num_knots = int(self.skygrid_x.shape[0])
+            m.skygrid_x = _ptr(self.skygrid_x, C.c_double)
+            m.skygrid_gamma = _ptr(self.skygrid_gamma, C.c_double)
+        return m
+
+
+@dataclass
+class SynthParams:
+    num_tips: int = 100
+    num_sites: int = 30000
+    tip_span: float = 365.0
+    tip_date_uncertainty: float = 0.0
+    frac_uncertain_tips: float = 0.0
+    pop_n0: float = 365.0
+    pop_growth: float = 0.0
+    mu: float = 1e-3 / 365.0
+    kappa: float = 5.0
+    pi: Sequence[float] = (0.3, 0.2, 0.2, 0.3)
+    gaps_per_tip: int = 2
+    mean_gap_len: float = 150.0
+    seed: int = 20261001
+
+
+_lib = None
+
+
+def load_library():
+    """Load libemat_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise EmatError("%s is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    B, R, S = C.c_void_p, C.c_void_p, C.c_void_p
+    i32, i64, u64, dbl = C.c_int32, C.c_int64, C.c_uint64, C.c_double
+    P = C.POINTER
+    sigs = {
+        "emat_backend_create": [P(_ConfigC), P(B)], "emat_backend_destroy": [B],
+        "emat_set_ref_sequence": [B, P(C.c_uint8), i32],
+        "emat_set_evo": [B, i32, P(dbl), P(dbl), P(dbl), P(dbl), P(i32)],
+        "emat_set_flags": [B, dbl, i32, i32],
+        "emat_begin_upload": [B, i32], "emat_part_upload": [B, i32, P(_FlatTreeC), i32, u64], "emat_end_upload": [B],
+        "emat_build_coalescent_parts": [B, P(_PopModelC), i32, dbl],
+        "emat_run_local_moves": [B, i64], "emat_run_moves_per_part": [B, i64], "emat_synchronize": [B], "emat_recalc_derived": [B],
+        "emat_get_totals": [B, P(dbl), P(dbl)],
+        "emat_part_get_sizes": [B, i32, P(i32), P(i32), P(i32), P(i32)], "emat_part_download": [B, i32, P(_FlatTreeC)],
+        "emat_part_get_derived": [B, i32, P(dbl), P(i32), P(dbl), P(dbl)],
+        "emat_part_get_coalescent": [B, i32, P(i32), P(dbl), P(dbl), P(dbl), P(dbl), P(i32), P(dbl), P(dbl)],
+        "emat_part_get_stats": [B, i32, P(_PartStatsC)], "emat_part_get_trace": [B, i32, P(i32), P(dbl)],
+        "emat_last_run_ms": [B, P(dbl)],
+        "emat_synth_create": [P(_SynthParamsC), P(S)], "emat_synth_get": [S, P(_FlatTreeC), P(P(C.c_uint8)), P(dbl)],
+        "emat_run_create": [B, P(_FlatTreeC), P(C.c_uint8), i32, u64, P(R)], "emat_run_destroy": [R],
+        "emat_run_set_num_parts": [R, i32], "emat_run_set_hky": [R, dbl, dbl, P(dbl), P(dbl)], "emat_run_set_pop_model": [R, P(_PopModelC)],
+        "emat_run_set_coalescent_t_step": [R, dbl], "emat_run_set_flags": [R, i32, i32],
+        "emat_run_repartition": [R], "emat_run_num_parts": [R, P(i32), P(i32)],
+        "emat_run_part_sizes": [R, i32, P(i32), P(i32), P(i32), P(i32)], "emat_run_part_get": [R, i32, P(_FlatTreeC), P(i32), P(u64)],
+        "emat_run_part_put": [R, i32, P(_FlatTreeC)], "emat_run_push_params": [R], "emat_run_moves": [R, i64], "emat_run_reassemble": [R],
+        "emat_run_do_mcmc_steps": [R, i64, i64], "emat_run_tree_sizes": [R, P(i32), P(i32), P(i32), P(i32)],
+        "emat_run_tree_get": [R, P(_FlatTreeC), P(C.c_uint8)], "emat_run_t_max_tip": [R, P(dbl)],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.emat_last_error.argtypes = [B]
+    lib.emat_last_error.restype = C.c_char_p
+    lib.emat_run_last_error.argtypes = [R]
+    lib.emat_run_last_error.restype = C.c_char_p
+    lib.emat_synth_destroy.argtypes = [S]
+    lib.emat_synth_destroy.restype = None
+    _lib = lib
+    return lib
+
+
+def hky_q_matrix(kappa: float, pi: Sequence[float]) -> np.ndarray:
+    """Normalised HKY rate matrix, q_ab = r_ab pi_b / (pi^T r pi) (reference core/evo_hky.cpp:7-50)."""
+    pi = np.asarray(pi, np.float64)
+    r = np.array([[0, 1, kappa, 1], [1, 0, 1, kappa], [kappa, 1, 0, 1], [1, kappa, 1, 0]], np.float64)
+    rowv = np.array([sum(pi[a] * r[a][b] for a in range(4)) for b in range(4)])
+    R = 0.0
+    for b in range(4):
+        R += rowv[b] * pi[b]
+    q = np.zeros((4, 4))
+    for a in range(4):
+        for b in range(4):
+            if a != b:
+                q[a, b] = r[a, b] / R * pi[b]
+                q[a, a] -= q[a, b]
+    return q
+
+
+def make_synthetic_emat(p: SynthParams):
+    """Seeded synthetic EMAT.  Returns (FlatTree, ref_sequence uint8[L], t_max_tip)."""
+    lib = load_library()
+    sp = _SynthParamsC()
+    for f in ("num_tips", "num_sites", "tip_span", "tip_date_uncertainty", "frac_uncertain_tips", "pop_n0", "pop_growth", "mu", "kappa",
+              "gaps_per_tip", "mean_gap_len", "seed"):
+        setattr(sp, f, getattr(p, f))
+    for a in range(4):
+        sp.pi[a] = float(p.pi[a])
+    h = C.c_void_p()
+    st = lib.emat_synth_create(C.byref(sp), C.byref(h))
+    if st != 0:
+        raise EmatError("emat_synth_create failed: %s" % STATUS_NAMES.get(st, st))
+    try:
+        v = _FlatTreeC()
+        ref = C.POINTER(C.c_uint8)()
+        tmax = C.c_double()
+        lib.emat_synth_get(h, C.byref(v), C.byref(ref), C.byref(tmax))
+        tree = FlatTree.from_c_view(v)
+        refseq = np.ctypeslib.as_array(ref, shape=(p.num_sites,)).copy()
+        return tree, refseq, float(tmax.value)
+    finally:
+        lib.emat_synth_destroy(h)
+
+
+class EmatBackend:
+    """The engine behind include/emat_backend.h: one resident `Subrun` per partition part, on the GPU."""
+
+    def __init__(self, num_sites: int, device: int = 0, trace_moves: int = 0, use_lds: bool = True, slab_slack: float = 0.0, max_parts: int = 0):
+        self._lib = load_library()
+        cfg = _ConfigC(device, num_sites, max_parts, slab_slack, trace_moves, 1 if use_lds else 0)
+        self._h = C.c_void_p()
+        st = self._lib.emat_backend_create(C.byref(cfg), C.byref(self._h))
+        if st != 0:
+            raise EmatError("emat_backend_create failed: %s (the engine needs a HIP device; there is no CPU fallback)" % STATUS_NAMES.get(st, st))
+        self.num_sites = num_sites
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.emat_backend_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _ck(self, st: int, what: str):
+        if st != 0:
+            msg = self._lib.emat_last_error(self._h)
+            raise EmatError("%s: %s (%s)" % (what, STATUS_NAMES.get(st, st), msg.decode() if msg else ""))
+
+    def set_ref_sequence(self, ref: np.ndarray):
+        ref = np.ascontiguousarray(ref, np.uint8)
+        self._ck(self._lib.emat_set_ref_sequence(self._h, _ptr(ref, C.c_uint8), ref.shape[0]), "emat_set_ref_sequence")
+
+    def set_evo(self, mu, pi, q, nu_l, partition_for_site):
+        mu = np.ascontiguousarray(mu, np.float64).reshape(-1)
+        P = mu.shape[0]
+        pi = np.ascontiguousarray(pi, np.float64).reshape(P * 4)
+        q = np.ascontiguousarray(q, np.float64).reshape(P * 16)
+        nu_l = np.ascontiguousarray(nu_l, np.float64)
+        pfs = np.ascontiguousarray(partition_for_site, np.int32)
+        self._ck(self._lib.emat_set_evo(self._h, P, _ptr(mu, C.c_double), _ptr(pi, C.c_double), _ptr(q, C.c_double), _ptr(nu_l, C.c_double), _ptr(pfs, C.c_int32)), "emat_set_evo")
+
+    def set_hky(self, mu: float, kappa: float, pi, nu_l=None):
+        nu = np.ones(self.num_sites) if nu_l is None else nu_l
+        self.set_evo([mu], [pi], [hky_q_matrix(kappa, pi)], nu, np.zeros(self.num_sites, np.int32))
+
+    def set_flags(self, t_max_tip: float, only_displacing_inner_nodes: bool = False, topology_moves_enabled: bool = True):
+        self._ck(self._lib.emat_set_flags(self._h, t_max_tip, int(only_displacing_inner_nodes), int(topology_moves_enabled)), "emat_set_flags")
+
+    def upload_parts(self, parts: Sequence[FlatTree], includes_run_root: Sequence[bool], seeds: Sequence[int]):
+        self._ck(self._lib.emat_begin_upload(self._h, len(parts)), "emat_begin_upload")
+        for i, (t, r, s) in enumerate(zip(parts, includes_run_root, seeds)):
+            v = t.c_view()
+            self._ck(self._lib.emat_part_upload(self._h, i, C.byref(v), int(r), int(s)), "emat_part_upload")
+        self._ck(self._lib.emat_end_upload(self._h), "emat_end_upload")
+
+    def build_coalescent_parts(self, pop: PopModel, root_part_index: int, t_step: float):
+        m = pop.c_struct()
+        self._ck(self._lib.emat_build_coalescent_parts(self._h, C.byref(m), root_part_index, t_step), "emat_build_coalescent_parts")
+
+    def run_local_moves(self, count: int):
+        self._ck(self._lib.emat_run_local_moves(self._h, count), "emat_run_local_moves")
+
+    def run_moves_per_part(self, moves: int):
+        self._ck(self._lib.emat_run_moves_per_part(self._h, moves), "emat_run_moves_per_part")
+
+    def synchronize(self):
+        self._ck(self._lib.emat_synchronize(self._h), "emat_synchronize")
+
+    def recalc_derived(self):
+        self._ck(self._lib.emat_recalc_derived(self._h), "emat_recalc_derived")
+
+    def last_run_ms(self) -> float:
+        ms = C.c_double()
+        self._ck(self._lib.emat_last_run_ms(self._h, C.byref(ms)), "emat_last_run_ms")
+        return float(ms.value)
+
+    def totals(self):
+        g, a = C.c_double(), C.c_double()
+        self._ck(self._lib.emat_get_totals(self._h, C.byref(g), C.byref(a)), "emat_get_totals")
+        return float(g.value), float(a.value)
+
+    def part_download(self, part: int) -> FlatTree:
+        n, nm, ni, nf = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._lib.emat_part_get_sizes(self._h, part, C.byref(n), C.byref(nm), C.byref(ni), C.byref(nf)), "emat_part_get_sizes")
+        t = FlatTree.empty(n.value, nm.value, ni.value, nf.value)
+        v = t.c_view()
+        self._ck(self._lib.emat_part_download(self._h, part, C.byref(v)), "emat_part_download")
+        t.root = v.root
+        return t.trimmed()
+
+    def part_derived(self, part: int, num_nodes: int):
+        lam = np.zeros(num_nodes)
+        nmiss = np.zeros(num_nodes, np.int32)
+        g, a = C.c_double(), C.c_double()
+        self._ck(self._lib.emat_part_get_derived(self._h, part, _ptr(lam, C.c_double), _ptr(nmiss, C.c_int32), C.byref(g), C.byref(a)), "emat_part_get_derived")
+        return lam, nmiss, float(g.value), float(a.value)
+
+    def part_coalescent(self, part: int, cap: int = 1 << 16):
+        n = C.c_int32(cap)
+        kb, kt, k, ps = np.zeros(cap), np.zeros(cap), np.zeros(cap), np.zeros(cap)
+        na = np.zeros(cap, np.int32)
+        tr, ts = C.c_double(), C.c_double()
+        self._ck(self._lib.emat_part_get_coalescent(self._h, part, C.byref(n), _ptr(kb, C.c_double), _ptr(kt, C.c_double), _ptr(k, C.c_double),
+                                                    _ptr(ps, C.c_double), _ptr(na, C.c_int32), C.byref(tr), C.byref(ts)), "emat_part_get_coalescent")
+        m = n.value
+        return dict(k_bar_p=kb[:m], k_twiddle_bar_p=kt[:m], k_twiddle_bar=k[:m], popsize_bar=ps[:m], num_active_parts=na[:m], t_ref=tr.value, t_step=ts.value)
+
+    def part_stats(self, part: int) -> dict:
+        s = _PartStatsC()
+        self._ck(self._lib.emat_part_get_stats(self._h, part, C.byref(s)), "emat_part_get_stats")
+        return dict(status=s.status, num_nodes=s.num_nodes, moves_done=s.moves_done, proposed=list(s.proposed), accepted=list(s.accepted),
+                    algorithmic_bytes=s.algorithmic_bytes, rng_draws=s.rng_draws)
+
+    def part_trace(self, part: int, cap: int) -> np.ndarray:
+        n = C.c_int32(cap)
+        tr = np.zeros((max(cap, 1), 4))
+        self._ck(self._lib.emat_part_get_trace(self._h, part, C.byref(n), _ptr(tr, C.c_double)), "emat_part_get_trace")
+        return tr[: n.value]
+
+    def last_error(self) -> str:
+        return self._lib.emat_last_error(self._h).decode()
+
+
+class EmatRun:
+    """Host-side driver above the boundary (include/emat_host.h): partitioning, repartition, reassemble."""
+
+    def __init__(self, backend: Optional[EmatBackend], tree: FlatTree, ref_sequence: np.ndarray, seed: int):
+        self._lib = load_library()
+        self.backend = backend
+        self._ref = np.ascontiguousarray(ref_sequence, np.uint8)
+        self.num_sites = int(self._ref.shape[0])
+        self._h = C.c_void_p()
+        v = tree.c_view()
+        st = self._lib.emat_run_create(backend.handle if backend is not None else None, C.byref(v), _ptr(self._ref, C.c_uint8), self.num_sites, int(seed), C.byref(self._h))
+        if st != 0:
+            raise EmatError("emat_run_create failed: %s" % STATUS_NAMES.get(st, st))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.emat_run_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st: int, what: str):
+        if st != 0:
+            msg = self._lib.emat_run_last_error(self._h)
+            raise EmatError("%s: %s (%s)" % (what, STATUS_NAMES.get(st, st), msg.decode() if msg else ""))
+
+    def set_num_parts(self, n: int):
+        self._ck(self._lib.emat_run_set_num_parts(self._h, n), "emat_run_set_num_parts")
+
+    def set_hky(self, mu: float, kappa: float, pi, nu_l=None):
+        pi = np.ascontiguousarray(pi, np.float64)
+        nu = None if nu_l is None else np.ascontiguousarray(nu_l, np.float64)
+        self._ck(self._lib.emat_run_set_hky(self._h, mu, kappa, _ptr(pi, C.c_double), None if nu is None else _ptr(nu, C.c_double)), "emat_run_set_hky")
+
+    def set_pop_model(self, pop: PopModel):
+        m = pop.c_struct()
+        self._ck(self._lib.emat_run_set_pop_model(self._h, C.byref(m)), "emat_run_set_pop_model")
+
+    def set_coalescent_t_step(self, t_step: float):
+        self._ck(self._lib.emat_run_set_coalescent_t_step(self._h, t_step), "emat_run_set_coalescent_t_step")
+
+    def set_flags(self, only_displacing_inner_nodes: bool = False, topology_moves_enabled: bool = True):
+        self._ck(self._lib.emat_run_set_flags(self._h, int(only_displacing_inner_nodes), int(topology_moves_enabled)), "emat_run_set_flags")
+
+    def repartition(self):
+        self._ck(self._lib.emat_run_repartition(self._h), "emat_run_repartition")
+
+    def num_parts(self):
+        n, r = C.c_int32(), C.c_int32()
+        self._ck(self._lib.emat_run_num_parts(self._h, C.byref(n), C.byref(r)), "emat_run_num_parts")
+        return n.value, r.value
+
+    def part(self, i: int):
+        n, nm, ni, nf = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._lib.emat_run_part_sizes(self._h, i, C.byref(n), C.byref(nm), C.byref(ni), C.byref(nf)), "emat_run_part_sizes")
+        t = FlatTree.empty(n.value, nm.value, ni.value, nf.value)
+        v = t.c_view()
+        incl, seed = C.c_int32(), C.c_uint64()
+        self._ck(self._lib.emat_run_part_get(self._h, i, C.byref(v), C.byref(incl), C.byref(seed)), "emat_run_part_get")
+        t.root = v.root
+        return t.trimmed(), bool(incl.value), int(seed.value)
+
+    def part_put(self, i: int, subtree: FlatTree):
+        v = subtree.c_view()
+        self._ck(self._lib.emat_run_part_put(self._h, i, C.byref(v)), "emat_run_part_put")
+
+    def push_params(self):
+        self._ck(self._lib.emat_run_push_params(self._h), "emat_run_push_params")
+
+    def run_moves(self, count: int):
+        self._ck(self._lib.emat_run_moves(self._h, count), "emat_run_moves")
+
+    def reassemble(self):
+        self._ck(self._lib.emat_run_reassemble(self._h), "emat_run_reassemble")
+
+    def do_mcmc_steps(self, steps: int, local_moves_per_cycle: int = -1):
+        self._ck(self._lib.emat_run_do_mcmc_steps(self._h, steps, local_moves_per_cycle), "emat_run_do_mcmc_steps")
+
+    def tree(self):
+        n, nm, ni, nf = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._lib.emat_run_tree_sizes(self._h, C.byref(n), C.byref(nm), C.byref(ni), C.byref(nf)), "emat_run_tree_sizes")
+        t = FlatTree.empty(n.value, nm.value, ni.value, nf.value)
+        v = t.c_view()
+        ref = np.zeros(self.num_sites, np.uint8)
+        self._ck(self._lib.emat_run_tree_get(self._h, C.byref(v), _ptr(ref, C.c_uint8)), "emat_run_tree_get")
+        t.root = v.root
+        return t.trimmed(), ref
+
+    def t_max_tip(self) -> float:
+        t = C.c_double()
+        self._ck(self._lib.emat_run_t_max_tip(self._h, C.byref(t)), "emat_run_t_max_tip")
+        return float(t.value)

@@ -1,0 +1,96 @@
+/*
+ * emat_host.h -- C-ABI of the host-side driver that sits ABOVE the engine boundary
+ * (include/emat_backend.h): the part of Delphy's `Run` that the north star keeps on the host.
+ *
+ *   reference                                              here
+ *   ---------                                              ----
+ *   generate_random_partition_stencil, partition_tree      emat_run_repartition
+ *     (core/tree_partitioning.h:139-239)
+ *   Run::repartition (core/run.cpp:110-193)                emat_run_repartition
+ *   Run::push_global_params_to_subruns (run.cpp:267-275)   emat_run_push_params
+ *   Run::run_local_moves (run.cpp:682-693)                 emat_run_moves        -> emat_run_local_moves of the backend
+ *   Run::reassemble (run.cpp:195-256)                      emat_run_reassemble
+ *   Run::do_mcmc_steps without the global moves            emat_run_do_mcmc_steps
+ *     (run.cpp:622-657; global moves are out of scope)
+ *
+ * Also exports the seeded synthetic-EMAT generator used by the bench and the tests
+ * (SURVEY section 8(d) configs C1..C5).
+ */
+#ifndef EMAT_HOST_H_
+#define EMAT_HOST_H_
+
+#include "emat_backend.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- synthetic EMATs ------------------------------------------------------------------------ */
+typedef struct emat_synth_params {
+  int32_t num_tips;
+  int32_t num_sites;
+  double tip_span;              /* tip dates ~ U[0, tip_span) days */
+  double tip_date_uncertainty;  /* half-width of [t_min, t_max] for the uncertain tips */
+  double frac_uncertain_tips;
+  double pop_n0;                /* N(t0) * generation time at the latest tip, days */
+  double pop_growth;            /* per day */
+  double mu;                    /* substitutions / site / day */
+  double kappa;
+  double pi[4];
+  int32_t gaps_per_tip;
+  double mean_gap_len;
+  uint64_t seed;
+} emat_synth_params;
+
+typedef struct emat_synth emat_synth;
+emat_status emat_synth_create(const emat_synth_params* p, emat_synth** out);
+void emat_synth_destroy(emat_synth* s);
+/* Pointers stay valid until emat_synth_destroy. */
+emat_status emat_synth_get(emat_synth* s, emat_flat_tree* tree_view, const uint8_t** ref_sequence, double* t_max_tip);
+
+/* ---- host tree container + partitioning (usable without any GPU) -------------------------------- */
+typedef struct emat_run emat_run;
+
+/* `backend` may be NULL: the driver then only partitions / reassembles (CPU tests, and feeding the
+ * parity oracle with exactly the same subtrees as the HIP engine). */
+emat_status emat_run_create(emat_backend* backend, const emat_flat_tree* tree, const uint8_t* ref_sequence,
+                            int32_t num_sites, uint64_t seed, emat_run** out);
+emat_status emat_run_destroy(emat_run* r);
+const char* emat_run_last_error(const emat_run* r);
+
+/* reference Run::set_num_parts (run.h:46-47) */
+emat_status emat_run_set_num_parts(emat_run* r, int32_t num_parts);
+/* HKY substitution model with per-site relative rates nu_l (NULL = all 1): reference Hky_model +
+ * Run::derive_evo (evo_hky.cpp:7-50).  One site partition. */
+emat_status emat_run_set_hky(emat_run* r, double mu, double kappa, const double pi[4], const double* nu_l);
+emat_status emat_run_set_pop_model(emat_run* r, const emat_pop_model* pm);
+emat_status emat_run_set_coalescent_t_step(emat_run* r, double t_step);
+emat_status emat_run_set_flags(emat_run* r, int32_t only_displacing_inner_nodes, int32_t topology_moves_enabled);
+
+/* Cut the tree into parts and (when a backend is attached) upload them and build their coalescent parts. */
+emat_status emat_run_repartition(emat_run* r);
+emat_status emat_run_num_parts(emat_run* r, int32_t* num_parts, int32_t* root_part_index);
+/* Sizes / contents of part i as built by the last repartition (to feed another engine, e.g. the oracle). */
+emat_status emat_run_part_sizes(emat_run* r, int32_t part, int32_t* num_nodes, int32_t* num_muts, int32_t* num_intervals, int32_t* num_from_states);
+emat_status emat_run_part_get(emat_run* r, int32_t part, emat_flat_tree* out, int32_t* includes_run_root, uint64_t* seed);
+/* Replace part i's subtree (e.g. with what another engine computed) before emat_run_reassemble. */
+emat_status emat_run_part_put(emat_run* r, int32_t part, const emat_flat_tree* subtree);
+
+emat_status emat_run_push_params(emat_run* r);
+emat_status emat_run_moves(emat_run* r, int64_t count);
+/* Gather the parts back into the whole tree; with a backend attached the parts are downloaded first. */
+emat_status emat_run_reassemble(emat_run* r);
+/* repartition -> [push params, local moves, reassemble] per cycle of `local_moves_per_cycle` moves
+ * (<= 0: 50 x nodes, the reference default run.cpp:669-672), repartitioning at every cycle boundary. */
+emat_status emat_run_do_mcmc_steps(emat_run* r, int64_t steps, int64_t local_moves_per_cycle);
+
+/* Whole tree out (sizes first). The reference sequence may have been re-referenced to the root
+ * sequence (Run::normalize_root, run.cpp:258-265). */
+emat_status emat_run_tree_sizes(emat_run* r, int32_t* num_nodes, int32_t* num_muts, int32_t* num_intervals, int32_t* num_from_states);
+emat_status emat_run_tree_get(emat_run* r, emat_flat_tree* out, uint8_t* ref_sequence /*[L]*/);
+emat_status emat_run_t_max_tip(emat_run* r, double* t_max_tip);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMAT_HOST_H_ */

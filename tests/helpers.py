@@ -1,0 +1,104 @@
+"""Shared helpers for the parity tests (HIP engine vs CPU oracle)."""
+import numpy as np
+
+import delphy_amd as d
+from oracle_ffi import OracleEngine
+
+
+def split_parts(sc, num_parts, seed):
+    """Partition the scenario's tree with the product's host driver (no GPU needed)."""
+    run = d.EmatRun(None, sc.tree, sc.ref, seed)
+    run.set_num_parts(num_parts)
+    run.repartition()
+    n, root_part = run.num_parts()
+    parts, incl, seeds = [], [], []
+    for i in range(n):
+        t, r, s = run.part(i)
+        parts.append(t); incl.append(r); seeds.append(s)
+    _, ref = run.tree()
+    run.close()
+    return parts, incl, seeds, root_part, ref
+
+
+def configure(engine, sc, ref, parts, incl, seeds, root_part, t_step=None, topology=True, only_displace=False, nu_l=None):
+    engine.set_ref_sequence(ref)
+    engine.set_hky(sc.mu, sc.kappa, sc.pi, nu_l)
+    engine.set_flags(sc.t_max_tip, only_displace, topology)
+    engine.upload_parts(parts, incl, seeds)
+    engine.build_coalescent_parts(sc.pop, root_part, t_step if t_step is not None else sc.default_t_step())
+
+
+def rel_close(a, b, tol):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.all(np.abs(a - b) <= tol * np.maximum(1.0, np.maximum(np.abs(a), np.abs(b))))
+
+
+def assert_trees_match(tg: d.FlatTree, to: d.FlatTree, tol=1e-9, what=""):
+    """Topology, sites, states, interval endpoints bit-exact; times within `tol` relative."""
+    assert tg.root == to.root, what
+    for f in ("parent", "child0", "child1", "mut_offset", "mut_site", "mut_from", "mut_to", "miss_offset", "miss_start", "miss_end",
+              "mfs_offset", "mfs_site", "mfs_state"):
+        a, b = getattr(tg, f), getattr(to, f)
+        assert a.shape == b.shape and np.array_equal(a, b), "%s: %s differs" % (what, f)
+    assert np.array_equal(tg.t_min, to.t_min) and np.array_equal(tg.t_max, to.t_max), what
+    assert rel_close(tg.t, to.t, tol), "%s: node times differ: max %g" % (what, np.max(np.abs(tg.t - to.t)))
+    finite = np.abs(to.mut_t) < 1e300
+    assert np.array_equal(finite, np.abs(tg.mut_t) < 1e300), what
+    assert rel_close(tg.mut_t[finite], to.mut_t[finite], tol), "%s: mutation times differ" % what
+
+
+def assert_traces_match(trg, tro, tol=1e-9, what=""):
+    assert trg.shape == tro.shape, "%s: trace length %s vs %s" % (what, trg.shape, tro.shape)
+    for i in range(trg.shape[0]):
+        kg, ko = trg[i], tro[i]
+        assert kg[0] == ko[0] and kg[1] == ko[1] and kg[2] == ko[2], "%s: move %d differs: gpu %s oracle %s" % (what, i, kg, ko)
+        if np.isnan(ko[3]) or np.isnan(kg[3]):
+            assert np.isnan(ko[3]) and np.isnan(kg[3]), "%s: move %d log_mh nan mismatch: %s %s" % (what, i, kg, ko)
+        elif np.isinf(ko[3]):
+            assert kg[3] == ko[3], "%s: move %d" % (what, i)
+        else:
+            assert abs(kg[3] - ko[3]) <= tol * max(1.0, abs(ko[3])), "%s: move %d log_mh %r vs %r" % (what, i, kg[3], ko[3])
+
+
+def run_parity(sc, num_parts, moves_per_part, seed=11, topology=True, only_displace=False, trace=200, use_lds=True, t_step=None, nu_l=None, tol=1e-9):
+    """Run the same seeded scenario through the HIP engine and the oracle and compare everything."""
+    parts, incl, seeds, root_part, ref = split_parts(sc, num_parts, seed)
+    gpu = d.EmatBackend(sc.num_sites, trace_moves=trace, use_lds=use_lds)
+    orc = OracleEngine(sc.num_sites, trace_moves=trace)
+    try:
+        configure(gpu, sc, ref, parts, incl, seeds, root_part, t_step, topology, only_displace, nu_l)
+        configure(orc, sc, ref, parts, incl, seeds, root_part, t_step, topology, only_displace, nu_l)
+        # derived quantities from scratch
+        for p in range(len(parts)):
+            n = parts[p].num_nodes
+            lg, ng, Gg, Ag = gpu.part_derived(p, n)
+            lo, no, Go, Ao = orc.part_derived(p, n)
+            assert np.array_equal(ng, no), "part %d num_sites_missing" % p
+            assert rel_close(lg, lo, 1e-11), "part %d lambda_i max diff %g" % (p, np.max(np.abs(lg - lo)))
+            assert rel_close(Gg, Go, tol) and rel_close(Ag, Ao, tol), "part %d log_G %r/%r prior %r/%r" % (p, Gg, Go, Ag, Ao)
+        if moves_per_part > 0:
+            gpu.run_moves_per_part(moves_per_part)
+            gpu.synchronize()
+            orc.run_moves_per_part(moves_per_part, threads=4)
+            for p in range(len(parts)):
+                sg, so = gpu.part_stats(p), orc.part_stats(p)
+                assert sg["status"] == 0, "part %d device status %d: %s" % (p, sg["status"], gpu.last_error())
+                assert_traces_match(gpu.part_trace(p, trace), orc.part_trace(p, trace), tol, "part %d" % p)
+                assert sg["moves_done"] == so["moves_done"] == moves_per_part
+                assert sg["proposed"] == so["proposed"] and sg["accepted"] == so["accepted"], "part %d counters %s vs %s" % (p, sg, so)
+                assert sg["rng_draws"] == so["rng_draws"], "part %d rng draws %d vs %d" % (p, sg["rng_draws"], so["rng_draws"])
+                assert_trees_match(gpu.part_download(p), orc.part_download(p), tol, "part %d" % p)
+                n = parts[p].num_nodes
+                lg, ng, Gg, Ag = gpu.part_derived(p, n)
+                lo, no, Go, Ao = orc.part_derived(p, n)
+                assert np.array_equal(ng, no)
+                assert rel_close(lg, lo, 1e-9), "part %d lambda_i after moves" % p
+                assert rel_close(Gg, Go, tol) and rel_close(Ag, Ao, tol), "part %d totals after moves: %r/%r %r/%r" % (p, Gg, Go, Ag, Ao)
+                cg, co = gpu.part_coalescent(p), orc.part_coalescent(p)
+                assert cg["k_bar_p"].shape == co["k_bar_p"].shape
+                assert rel_close(cg["k_bar_p"], co["k_bar_p"], 1e-9) and rel_close(cg["k_twiddle_bar_p"], co["k_twiddle_bar_p"], 1e-9)
+            Gg, Ag = gpu.totals(); Go, Ao = orc.totals()
+            assert rel_close(Gg, Go, tol) and rel_close(Ag, Ao, tol)
+        return gpu.part_stats(0)
+    finally:
+        gpu.close(); orc.close()

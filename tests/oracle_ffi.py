@@ -1,0 +1,145 @@
+"""ctypes binding of the CPU oracle (oracle/orc_capi.cpp).  TEST INFRASTRUCTURE ONLY: nothing under
+delphy_amd/ imports this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from delphy_amd.engine import FlatTree, PopModel, _FlatTreeC, _PartStatsC, _PopModelC, _ptr, hky_q_matrix
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ROOT, "oracle", "_build", "libemat_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle library missing: run `make -C oracle`")
+        L = C.CDLL(path)
+        E = C.c_void_p
+        i32, i64, u64, dbl = C.c_int32, C.c_int64, C.c_uint64, C.c_double
+        P = C.POINTER
+        sigs = {
+            "orc_create": [C.c_int, C.c_int, P(E)], "orc_destroy": [E],
+            "orc_set_ref_sequence": [E, P(C.c_uint8), C.c_int], "orc_set_evo": [E, C.c_int, P(dbl), P(dbl), P(dbl), P(dbl), P(C.c_int)],
+            "orc_set_flags": [E, dbl, C.c_int, C.c_int], "orc_begin_upload": [E, C.c_int],
+            "orc_part_upload": [E, C.c_int, P(_FlatTreeC), C.c_int, u64], "orc_end_upload": [E],
+            "orc_build_coalescent_parts": [E, P(_PopModelC), C.c_int, dbl], "orc_recalc_derived": [E],
+            "orc_run_moves": [E, P(i64), C.c_int, C.c_int], "orc_get_totals": [E, P(dbl), P(dbl)],
+            "orc_part_get_sizes": [E, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)], "orc_part_download": [E, C.c_int, P(_FlatTreeC)],
+            "orc_part_get_derived": [E, C.c_int, P(dbl), P(C.c_int), P(dbl), P(dbl)],
+            "orc_part_get_coalescent": [E, C.c_int, P(C.c_int), P(dbl), P(dbl), P(dbl), P(dbl), P(C.c_int), P(dbl), P(dbl)],
+            "orc_part_get_stats": [E, C.c_int, P(_PartStatsC)], "orc_part_get_trace": [E, C.c_int, P(C.c_int), P(dbl)],
+            "orc_part_check": [E, C.c_int, C.c_char_p, C.c_int],
+        }
+        for n, a in sigs.items():
+            f = getattr(L, n); f.argtypes = a; f.restype = C.c_int
+        L.orc_last_error.argtypes = [E]; L.orc_last_error.restype = C.c_char_p
+        L.orc_gamma_q.argtypes = [dbl, dbl]; L.orc_gamma_q.restype = dbl
+        L.orc_gamma_q_inv.argtypes = [dbl, dbl]; L.orc_gamma_q_inv.restype = dbl
+        for n in ("orc_pop_at_time",):
+            getattr(L, n).argtypes = [P(_PopModelC), dbl]; getattr(L, n).restype = dbl
+        for n in ("orc_pop_integral", "orc_intensity_integral"):
+            getattr(L, n).argtypes = [P(_PopModelC), dbl, dbl]; getattr(L, n).restype = dbl
+        L.orc_rng_block.argtypes = [u64, u64, P(C.c_uint32)]; L.orc_rng_block.restype = None
+        _lib = L
+    return _lib
+
+
+class OracleEngine:
+    """Same call sequence as delphy_amd.EmatBackend, executed by the CPU oracle."""
+
+    def __init__(self, num_sites, trace_moves=0):
+        self.L = lib()
+        self.num_sites = num_sites
+        self.h = C.c_void_p()
+        assert self.L.orc_create(num_sites, trace_moves, C.byref(self.h)) == 0
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h); self.h = None
+
+    def _ck(self, st, what):
+        if st != 0:
+            raise RuntimeError("%s failed: %s" % (what, self.L.orc_last_error(self.h).decode()))
+
+    def set_ref_sequence(self, ref):
+        ref = np.ascontiguousarray(ref, np.uint8)
+        self._ck(self.L.orc_set_ref_sequence(self.h, _ptr(ref, C.c_uint8), ref.shape[0]), "set_ref_sequence")
+
+    def set_evo(self, mu, pi, q, nu_l, pfs):
+        mu = np.ascontiguousarray(mu, np.float64).reshape(-1); P = mu.shape[0]
+        pi = np.ascontiguousarray(pi, np.float64).reshape(P * 4); q = np.ascontiguousarray(q, np.float64).reshape(P * 16)
+        nu_l = np.ascontiguousarray(nu_l, np.float64); pfs = np.ascontiguousarray(pfs, np.int32)
+        self._ck(self.L.orc_set_evo(self.h, P, _ptr(mu, C.c_double), _ptr(pi, C.c_double), _ptr(q, C.c_double), _ptr(nu_l, C.c_double), _ptr(pfs, C.c_int)), "set_evo")
+
+    def set_hky(self, mu, kappa, pi, nu_l=None):
+        nu = np.ones(self.num_sites) if nu_l is None else nu_l
+        self.set_evo([mu], [pi], [hky_q_matrix(kappa, pi)], nu, np.zeros(self.num_sites, np.int32))
+
+    def set_flags(self, t_max_tip, only_displacing_inner_nodes=False, topology_moves_enabled=True):
+        self._ck(self.L.orc_set_flags(self.h, t_max_tip, int(only_displacing_inner_nodes), int(topology_moves_enabled)), "set_flags")
+
+    def upload_parts(self, parts, includes_run_root, seeds):
+        self._ck(self.L.orc_begin_upload(self.h, len(parts)), "begin_upload")
+        for i, (t, r, s) in enumerate(zip(parts, includes_run_root, seeds)):
+            v = t.c_view()
+            self._ck(self.L.orc_part_upload(self.h, i, C.byref(v), int(r), int(s)), "part_upload")
+        self.num_parts = len(parts)
+
+    def build_coalescent_parts(self, pop: PopModel, root_part_index, t_step):
+        m = pop.c_struct()
+        self._ck(self.L.orc_build_coalescent_parts(self.h, C.byref(m), root_part_index, t_step), "build_coalescent_parts")
+
+    def recalc_derived(self):
+        self._ck(self.L.orc_recalc_derived(self.h), "recalc_derived")
+
+    def run_moves_per_part(self, moves, threads=1, paranoid=False):
+        m = np.full(self.num_parts, moves, np.int64)
+        self._ck(self.L.orc_run_moves(self.h, _ptr(m, C.c_int64), threads, int(paranoid)), "run_moves")
+
+    def run_local_moves(self, count, threads=1, paranoid=False):
+        sub = count // self.num_parts
+        m = np.full(self.num_parts, sub, np.int64); m[0] = count - (self.num_parts - 1) * sub
+        self._ck(self.L.orc_run_moves(self.h, _ptr(m, C.c_int64), threads, int(paranoid)), "run_moves")
+
+    def totals(self):
+        g, a = C.c_double(), C.c_double()
+        self._ck(self.L.orc_get_totals(self.h, C.byref(g), C.byref(a)), "get_totals")
+        return g.value, a.value
+
+    def part_download(self, part):
+        n, nm, ni, nf = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.L.orc_part_get_sizes(self.h, part, C.byref(n), C.byref(nm), C.byref(ni), C.byref(nf))
+        t = FlatTree.empty(n.value, nm.value, ni.value, nf.value)
+        v = t.c_view()
+        self._ck(self.L.orc_part_download(self.h, part, C.byref(v)), "part_download")
+        t.root = v.root
+        return t.trimmed()
+
+    def part_derived(self, part, num_nodes):
+        lam = np.zeros(num_nodes); nm = np.zeros(num_nodes, np.int32); g, a = C.c_double(), C.c_double()
+        self._ck(self.L.orc_part_get_derived(self.h, part, _ptr(lam, C.c_double), _ptr(nm, C.c_int), C.byref(g), C.byref(a)), "part_get_derived")
+        return lam, nm, g.value, a.value
+
+    def part_coalescent(self, part, cap=1 << 16):
+        n = C.c_int(cap); kb, kt, k, ps = np.zeros(cap), np.zeros(cap), np.zeros(cap), np.zeros(cap); na = np.zeros(cap, np.int32); tr, ts = C.c_double(), C.c_double()
+        self._ck(self.L.orc_part_get_coalescent(self.h, part, C.byref(n), _ptr(kb, C.c_double), _ptr(kt, C.c_double), _ptr(k, C.c_double), _ptr(ps, C.c_double), _ptr(na, C.c_int), C.byref(tr), C.byref(ts)), "part_get_coalescent")
+        m = n.value
+        return dict(k_bar_p=kb[:m], k_twiddle_bar_p=kt[:m], k_twiddle_bar=k[:m], popsize_bar=ps[:m], num_active_parts=na[:m], t_ref=tr.value, t_step=ts.value)
+
+    def part_stats(self, part):
+        s = _PartStatsC(); self.L.orc_part_get_stats(self.h, part, C.byref(s))
+        return dict(status=s.status, num_nodes=s.num_nodes, moves_done=s.moves_done, proposed=list(s.proposed), accepted=list(s.accepted), rng_draws=s.rng_draws)
+
+    def part_trace(self, part, cap):
+        n = C.c_int(cap); tr = np.zeros((max(cap, 1), 4))
+        self.L.orc_part_get_trace(self.h, part, C.byref(n), _ptr(tr, C.c_double))
+        return tr[: n.value]
+
+    def part_check(self, part):
+        buf = C.create_string_buffer(512)
+        rc = self.L.orc_part_check(self.h, part, buf, 512)
+        return rc, buf.value.decode()
