@@ -229,6 +229,8 @@ struct emat_backend {
   bool host_slabs_current = false;  // h_slabs mirrors the device
   bool derived_valid = false;
   uint32_t max_slab_bytes = 0;
+  bool host_only = false;           // cfg.device == -1: uploads / coalescent staging only, every launch fails with EMAT_ERR_NO_DEVICE
+  std::unique_ptr<CoalBuilder> coal_builder;
 
   void set_error(const std::string& s) { last_error = s; }
 };
@@ -326,6 +328,7 @@ void decode_slab(PartHost& ph, const uint8_t* slab) {
 emat_status fail(emat_backend* h, emat_status st, const std::string& msg) { h->set_error(msg); return st; }
 
 emat_status sync_model_to_device(emat_backend* h) {
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
   if (!h->model_dirty) return EMAT_OK;
   auto& B = *h;
   auto set_error = [&](const std::string& s) { B.set_error(s); };
@@ -376,7 +379,7 @@ KernelArgs make_args(emat_backend* h) {
 
 // Bring the host copies of all parts up to date with the device.
 emat_status pull_from_device(emat_backend* h) {
-  if (!h->slabs_on_device || h->host_slabs_current) return EMAT_OK;
+  if (h->host_only || !h->slabs_on_device || h->host_slabs_current) return EMAT_OK;
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(h->h_slabs.data(), h->d_slabs.p, h->h_slabs.size(), hipMemcpyDeviceToHost));
@@ -394,6 +397,7 @@ emat_status pull_from_device(emat_backend* h) {
 
 // Encode all parts and push them to the device.
 emat_status materialize(emat_backend* h) {
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
   if (h->slabs_on_device) return EMAT_OK;
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   if (!h->have_ref || !h->have_evo) return fail(h, EMAT_ERR_STATE, "set_ref_sequence and set_evo must precede running");
@@ -485,6 +489,12 @@ extern "C" {
 
 emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   if (!cfg || !out || cfg->num_sites <= 0) return EMAT_ERR_INVALID_ARGUMENT;
+  if (cfg->device == -1) {   // host-only handle: can stage data and build coalescent parts, can never run a move
+    auto h = std::make_unique<emat_backend>();
+    h->cfg = *cfg; h->L = cfg->num_sites; h->host_only = true;
+    *out = h.release();
+    return EMAT_OK;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return EMAT_ERR_NO_DEVICE;
   if (cfg->device < 0 || cfg->device >= ndev) return EMAT_ERR_INVALID_ARGUMENT;
@@ -498,6 +508,7 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
 }
 emat_status emat_backend_destroy(emat_backend* h) {
   if (!h) return EMAT_OK;
+  if (h->host_only) { delete h; return EMAT_OK; }
   (void)hipSetDevice(h->cfg.device);
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
@@ -537,6 +548,7 @@ emat_status emat_begin_upload(emat_backend* h, int32_t num_parts) {
   if (!h || num_parts <= 0) return EMAT_ERR_INVALID_ARGUMENT;
   if (h->cfg.max_parts > 0 && num_parts > h->cfg.max_parts) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "more parts than cfg.max_parts");
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  h->coal_builder.reset();
   h->parts.clear(); h->parts.resize(num_parts);
   h->uploads_expected = num_parts; h->root_part = -1;
   h->slabs_on_device = false; h->host_slabs_current = false; h->have_coal = false; h->derived_valid = false;
@@ -584,6 +596,62 @@ emat_status emat_build_coalescent_parts(emat_backend* h, const emat_pop_model* p
   return EMAT_OK;
 }
 
+// ---- staged form of emat_build_coalescent_parts for runs sharded over several GPUs ---------------
+emat_status emat_coalescent_begin(emat_backend* h, const emat_pop_model* pm, int32_t root_part_index, double t_step, double* local_t_min, double* local_t_max) {
+  if (!h || !pm || !(t_step > 0.0) || !local_t_min || !local_t_max) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->parts.empty() || h->uploads_expected != 0) return fail(h, EMAT_ERR_STATE, "upload parts first");
+  if (root_part_index < -1 || root_part_index >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  try {
+    emat_status st = pull_from_device(h); if (st) return st;
+    h->pop = HostPopModel::from_c(*pm);
+    h->coal_builder = std::make_unique<CoalBuilder>();
+    h->coal_builder->pop = h->pop; h->coal_builder->t_step = t_step;
+    for (size_t p = 0; p < h->parts.size(); ++p) h->coal_builder->add_part(&h->parts[p].tree, &h->parts[p].rng, (int)p == root_part_index);
+    h->coal_builder->local_range(*local_t_min, *local_t_max);
+  } catch (const std::exception& ex) { return fail(h, EMAT_ERR_INVALID_ARGUMENT, ex.what()); }
+  return EMAT_OK;
+}
+emat_status emat_coalescent_set_range(emat_backend* h, double all_t_min, double all_t_max, int32_t* num_cells) {
+  if (!h || !num_cells) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!h->coal_builder) return fail(h, EMAT_ERR_STATE, "emat_coalescent_begin first");
+  *num_cells = h->coal_builder->set_range(all_t_min, all_t_max);
+  return EMAT_OK;
+}
+emat_status emat_coalescent_local_grid(emat_backend* h, double* k_bar, int32_t* num_active) {
+  if (!h || !k_bar || !num_active) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!h->coal_builder) return fail(h, EMAT_ERR_STATE, "emat_coalescent_begin first");
+  try {
+    std::vector<double> kb; std::vector<int32_t> na;
+    h->coal_builder->local_grid(kb, na);
+    std::copy(kb.begin(), kb.end(), k_bar); std::copy(na.begin(), na.end(), num_active);
+  } catch (const std::exception& ex) { return fail(h, EMAT_ERR_INVALID_ARGUMENT, ex.what()); }
+  return EMAT_OK;
+}
+emat_status emat_coalescent_sample(emat_backend* h, const double* k_bar, const int32_t* num_active, double* k_twiddle_bar_local) {
+  if (!h || !k_bar || !num_active || !k_twiddle_bar_local) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!h->coal_builder) return fail(h, EMAT_ERR_STATE, "emat_coalescent_begin first");
+  try {
+    const int n = h->coal_builder->num_cells;
+    std::vector<double> kt;
+    h->coal_builder->sample(std::vector<double>(k_bar, k_bar + n), std::vector<int32_t>(num_active, num_active + n), kt);
+    std::copy(kt.begin(), kt.end(), k_twiddle_bar_local);
+  } catch (const std::exception& ex) { return fail(h, EMAT_ERR_INVALID_ARGUMENT, ex.what()); }
+  return EMAT_OK;
+}
+emat_status emat_coalescent_finish(emat_backend* h, const double* k_twiddle_bar) {
+  if (!h || !k_twiddle_bar) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!h->coal_builder) return fail(h, EMAT_ERR_STATE, "emat_coalescent_begin first");
+  try {
+    const int n = h->coal_builder->num_cells;
+    auto cps = h->coal_builder->finish(std::vector<double>(k_twiddle_bar, k_twiddle_bar + n));
+    for (size_t p = 0; p < h->parts.size(); ++p) h->parts[p].coal = std::move(cps[p]);
+  } catch (const std::exception& ex) { return fail(h, EMAT_ERR_INVALID_ARGUMENT, ex.what()); }
+  h->coal_builder.reset();
+  h->have_pop = true; h->have_coal = true; h->model_dirty = true;
+  h->slabs_on_device = false; h->host_slabs_current = false; h->derived_valid = false;
+  return EMAT_OK;
+}
+
 emat_status emat_run_local_moves(emat_backend* h, int64_t count) {
   if (!h || count < 0) return EMAT_ERR_INVALID_ARGUMENT;
   if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
@@ -597,6 +665,7 @@ emat_status emat_run_moves_per_part(emat_backend* h, int64_t moves_per_part) {
 }
 emat_status emat_synchronize(emat_backend* h) {
   if (!h) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return EMAT_OK;
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipStreamSynchronize(h->stream));
   return EMAT_OK;
@@ -700,6 +769,7 @@ emat_status emat_part_get_trace(emat_backend* h, int32_t part_id, int32_t* num_m
 }
 emat_status emat_last_run_ms(emat_backend* h, double* ms) {
   if (!h || !ms) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle");
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipEventSynchronize(h->ev_stop));
   float f = 0.f;

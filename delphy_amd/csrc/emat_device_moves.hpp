@@ -292,7 +292,7 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   if (c.failed) return;
   const int old_min_muts = count_min_mutations(c, old_graft);
   int extra = 4;
-  if (limit != 1) { extra = 8; for (int n = 0; n < c.H->n_nodes; ++n) extra += nmuts(c, n); }
+  if (limit != 1) { extra = 8; for (int n = 0; n < c.H->n_nodes; ++n) if (c.includes_run_root || n != c.H->root) extra += nmuts(c, n); }
   SVec<SdRec> old_deltas = summarize_closed_mutations(c, old_graft, extra);
   SVec<IvRec> missing_at_X = reconstruct_missing_sites_at(c, X);
   const int n_missing_at_X = iv_num_sites(missing_at_X.p, missing_at_X.n);

@@ -42,7 +42,14 @@ EMAT_DN SVec<SdRec> deltas_from_root_muts(Ctx& c, int root, int extra_cap) {
   for (int i = 0; i < nmuts(c, root); ++i) sd_push_back(c, d, m[i].site, m[i].from, m[i].to);
   return d;
 }
-EMAT_D int path_mut_count(Ctx& c, int from_node) { int s = 0; for (int cur = from_node; cur != k_no_node; cur = c.N[cur].parent) s += nmuts(c, cur); return s; }
+// Upper bound on the mutations met on the way from `from_node` to the root.  In a part that does not hold
+// the run's root, the subroot's list (ref -> subroot deltas, possibly hundreds of entries) is frozen and never
+// crossed by a move, so it is not counted.
+EMAT_D int path_mut_count(Ctx& c, int from_node) {
+  int s = 0;
+  for (int cur = from_node; cur != k_no_node; cur = c.N[cur].parent) if (c.includes_run_root || c.N[cur].parent != k_no_node) s += nmuts(c, cur);
+  return s;
+}
 
 // =================================================================================================
 // Tree editing (tree_editing.cpp:7-302)
@@ -600,7 +607,7 @@ EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:582-
   const double t_X = c.N[X].t, t_P = c.N[P].t;
   g.S = S; g.t_P = t_P;
   int depth = 0, path_muts = 0;
-  for (int cur = X; cur != k_no_node; cur = c.N[cur].parent) { ++depth; path_muts += nmuts(c, cur); }
+  for (int cur = X; cur != k_no_node; cur = c.N[cur].parent) { ++depth; if (c.includes_run_root || c.N[cur].parent != k_no_node) path_muts += nmuts(c, cur); }
   g.bi = (BranchInfo*)sc_alloc(c, (uint32_t)(depth + 2) * (uint32_t)sizeof(BranchInfo));
   if (c.failed) return g;
   const int bi_cap = depth + 2;

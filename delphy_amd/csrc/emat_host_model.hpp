@@ -130,66 +130,118 @@ inline void add_interval(double ts, double te, double dk, std::vector<double>& k
 }
 }  // namespace coal_detail
 
-// very_scalable_coalescent.cpp:85-232.  `rngs[p]` is part p's own stream (the reference draws from the
-// part's std::mt19937).  Returns one windowed part per subtree.
+// very_scalable_coalescent.cpp:85-232, split into the stages between which a multi-GPU run exchanges data
+// (SURVEY 8e): (1) local time range -> all-reduce min/max; (2) local k_bar / num_active_parts contributions ->
+// all-reduce sum; (3) Gaussian k_twiddle_bar_p draws from each part's own stream -> all-reduce sum of
+// k_twiddle_bar; (4) window extraction.  A single process simply runs the four stages back to back.
+struct CoalBuilder {
+  HostPopModel pop;
+  double t_step = 1.0;
+  std::vector<const FlatTree*> trees;
+  std::vector<HostRng*> rngs;
+  int root_local = -1;               // index (in `trees`) of the part holding the run's root, or -1 if it lives on another rank
+  std::vector<double> tmin, tmax;
+  double t_ref = 0.0, all_min = 0.0;
+  int num_cells = 0;
+  std::vector<int> fc, lc;
+  std::vector<std::vector<double>> kbar_p, ktw_p;
+  std::vector<double> popsize, k_bar, k_tw;
+  std::vector<int32_t> num_active;
+
+  void add_part(const FlatTree* t, HostRng* rng, bool is_root) { if (is_root) root_local = (int)trees.size(); trees.push_back(t); rngs.push_back(rng); }
+  // stage 1
+  void local_range(double& lo, double& hi) {
+    using namespace coal_detail;
+    const int P = (int)trees.size();
+    tmin.assign(P, std::numeric_limits<double>::max()); tmax.assign(P, -std::numeric_limits<double>::max());
+    for (int p = 0; p < P; ++p) {
+      const FlatTree& st = *trees[p];
+      for (int n = 0; n < st.num_nodes(); ++n) {
+        bool tip = st.is_tip(n);
+        tmin[p] = std::min(tmin[p], tip ? (double)st.t_min[n] : st.t[n]);
+        tmax[p] = std::max(tmax[p], tip ? (double)st.t_max[n] : st.t[n]);
+      }
+    }
+    lo = std::numeric_limits<double>::max(); hi = -std::numeric_limits<double>::max();
+    for (int p = 0; p < P; ++p) { lo = std::min(lo, tmin[p]); hi = std::max(hi, tmax[p]); }
+  }
+  // stage 2: with the global range known, this rank's contributions to k_bar and num_active_parts
+  int set_range(double all_t_min, double all_t_max) {
+    using namespace coal_detail;
+    all_min = all_t_min; t_ref = all_t_max;
+    if (root_local >= 0) tmin[root_local] = all_t_min;
+    num_cells = cell_for(all_t_min, t_ref, t_step) + 1;
+    return num_cells;
+  }
+  void local_grid(std::vector<double>& k_bar_local, std::vector<int32_t>& num_active_local) {
+    using namespace coal_detail;
+    const int P = (int)trees.size();
+    k_bar_local.assign(num_cells, 0.0); num_active_local.assign(num_cells, 0);
+    fc.assign(P, 0); lc.assign(P, 0); kbar_p.assign(P, {}); ktw_p.assign(P, {});
+    for (int p = 0; p < P; ++p) {
+      fc[p] = cell_for(tmax[p], t_ref, t_step); lc[p] = cell_for(tmin[p], t_ref, t_step);
+      if (!(0 <= fc[p] && fc[p] <= lc[p] && lc[p] < num_cells)) throw std::runtime_error("coalescent grid: bad cell range");
+      for (int c = fc[p]; c <= lc[p]; ++c) num_active_local[c] += 1;
+      kbar_p[p].assign(lc[p] + 1, 0.0); ktw_p[p].assign(lc[p] + 1, 0.0);
+      const FlatTree& st = *trees[p];
+      for (int n = 0; n < st.num_nodes(); ++n) if (n != st.root) add_interval(st.t[st.parent[n]], st.t[n], +1.0, kbar_p[p], t_ref, t_step);
+    }
+    if (root_local >= 0) {
+      const FlatTree& rt = *trees[root_local];
+      add_interval(cell_lbound(num_cells - 1, t_ref, t_step), rt.t[rt.root], +1.0, kbar_p[root_local], t_ref, t_step);
+    }
+    for (int p = 0; p < P; ++p) for (size_t i = 0; i < kbar_p[p].size(); ++i) k_bar_local[i] += kbar_p[p][i];
+  }
+  // stage 3: draws, given the GLOBAL k_bar and num_active_parts; returns this rank's contribution to k_twiddle_bar
+  void sample(const std::vector<double>& k_bar_global, const std::vector<int32_t>& num_active_global, std::vector<double>& k_tw_local) {
+    using namespace coal_detail;
+    const int P = (int)trees.size();
+    k_bar = k_bar_global; num_active = num_active_global;
+    if (num_active.back() == 0) throw std::runtime_error("coalescent grid: inactive final cell");
+    popsize.assign(num_cells, 0.0);
+    for (int i = 0; i < num_cells; ++i) popsize[i] = pop.pop_integral(cell_lbound(i, t_ref, t_step), cell_ubound(i, t_ref, t_step)) / t_step;
+    k_tw_local.assign(num_cells, 0.0);
+    for (int p = 0; p < P; ++p)
+      for (int i = 0; i < (int)ktw_p[p].size(); ++i) {
+        if (fc[p] <= i && i <= lc[p]) {
+          double mu = kbar_p[p][i] - k_bar[i] / num_active[i];
+          double sigma = std::sqrt(popsize[i] / (num_active[i] * t_step));
+          ktw_p[p][i] = rngs[p]->gaussian(mu, sigma);
+        } else ktw_p[p][i] = 0.0;
+        k_tw_local[i] += ktw_p[p][i];
+      }
+  }
+  // stage 4
+  std::vector<HostCoalPart> finish(const std::vector<double>& k_tw_global) {
+    const int P = (int)trees.size();
+    k_tw = k_tw_global;
+    std::vector<HostCoalPart> out(P);
+    for (int p = 0; p < P; ++p) {
+      HostCoalPart& cp = out[p];
+      cp.cell_first = fc[p]; cp.n_cells_total = lc[p] + 1; cp.t_ref = t_ref; cp.t_step = t_step;
+      cp.k_bar_p.assign(kbar_p[p].begin() + fc[p], kbar_p[p].end());
+      cp.k_twiddle_bar_p.assign(ktw_p[p].begin() + fc[p], ktw_p[p].end());
+      cp.k_twiddle_bar.assign(k_tw.begin() + fc[p], k_tw.begin() + lc[p] + 1);
+      cp.popsize_bar.assign(popsize.begin() + fc[p], popsize.begin() + lc[p] + 1);
+      cp.num_active_parts.assign(num_active.begin() + fc[p], num_active.begin() + lc[p] + 1);
+      for (int i = 0; i < fc[p]; ++i) if (kbar_p[p][i] != 0.0) throw std::runtime_error("coalescent grid: lineage outside the part's window");
+    }
+    return out;
+  }
+};
+
+// Single-process form (what Run::reset_very_scalable_coalescent_parts does, run.cpp:277-293).
 inline std::vector<HostCoalPart> make_coalescent_parts(const std::vector<const FlatTree*>& subtrees, int root_part,
                                                        const HostPopModel& pop, std::vector<HostRng*>& rngs, double t_step) {
-  using namespace coal_detail;
-  const int P = (int)subtrees.size();
-  std::vector<HostCoalPart> out(P);
-  if (P == 0) return out;
-  std::vector<double> tmin(P, std::numeric_limits<double>::max()), tmax(P, -std::numeric_limits<double>::max());
-  for (int p = 0; p < P; ++p) {
-    const FlatTree& st = *subtrees[p];
-    for (int n = 0; n < st.num_nodes(); ++n) {
-      bool tip = st.is_tip(n);
-      tmin[p] = std::min(tmin[p], tip ? (double)st.t_min[n] : st.t[n]);
-      tmax[p] = std::max(tmax[p], tip ? (double)st.t_max[n] : st.t[n]);
-    }
-  }
-  double all_min = *std::min_element(tmin.begin(), tmin.end()), all_max = *std::max_element(tmax.begin(), tmax.end());
-  tmin[root_part] = all_min;
-  const double t_ref = all_max;
-  const int num_cells = cell_for(all_min, t_ref, t_step) + 1;
-  std::vector<int32_t> num_active(num_cells, 0);
-  std::vector<int> fc(P), lc(P);
-  std::vector<std::vector<double>> kbar_p(P), ktw_p(P);
-  for (int p = 0; p < P; ++p) {
-    fc[p] = cell_for(tmax[p], t_ref, t_step); lc[p] = cell_for(tmin[p], t_ref, t_step);
-    if (!(0 <= fc[p] && fc[p] <= lc[p] && lc[p] < num_cells)) throw std::runtime_error("coalescent grid: bad cell range");
-    for (int c = fc[p]; c <= lc[p]; ++c) num_active[c] += 1;
-    kbar_p[p].assign(lc[p] + 1, 0.0); ktw_p[p].assign(lc[p] + 1, 0.0);
-  }
-  if (num_active.back() == 0) throw std::runtime_error("coalescent grid: inactive final cell");
-  for (int p = 0; p < P; ++p) {
-    const FlatTree& st = *subtrees[p];
-    for (int n = 0; n < st.num_nodes(); ++n) if (n != st.root) add_interval(st.t[st.parent[n]], st.t[n], +1.0, kbar_p[p], t_ref, t_step);
-  }
-  add_interval(cell_lbound(num_cells - 1, t_ref, t_step), subtrees[root_part]->t[subtrees[root_part]->root], +1.0, kbar_p[root_part], t_ref, t_step);
-  std::vector<double> k_bar(num_cells, 0.0), popsize(num_cells, 0.0), k_tw(num_cells, 0.0);
-  for (int p = 0; p < P; ++p) for (size_t i = 0; i < kbar_p[p].size(); ++i) k_bar[i] += kbar_p[p][i];
-  for (int i = 0; i < num_cells; ++i) popsize[i] = pop.pop_integral(cell_lbound(i, t_ref, t_step), cell_ubound(i, t_ref, t_step)) / t_step;
-  for (int p = 0; p < P; ++p)
-    for (int i = 0; i < (int)ktw_p[p].size(); ++i) {
-      if (fc[p] <= i && i <= lc[p]) {
-        double mu = kbar_p[p][i] - k_bar[i] / num_active[i];
-        double sigma = std::sqrt(popsize[i] / (num_active[i] * t_step));
-        ktw_p[p][i] = rngs[p]->gaussian(mu, sigma);
-      } else ktw_p[p][i] = 0.0;
-    }
-  for (int p = 0; p < P; ++p) for (size_t i = 0; i < ktw_p[p].size(); ++i) k_tw[i] += ktw_p[p][i];
-  for (int p = 0; p < P; ++p) {
-    HostCoalPart& cp = out[p];
-    cp.cell_first = fc[p]; cp.n_cells_total = lc[p] + 1; cp.t_ref = t_ref; cp.t_step = t_step;
-    cp.k_bar_p.assign(kbar_p[p].begin() + fc[p], kbar_p[p].end());
-    cp.k_twiddle_bar_p.assign(ktw_p[p].begin() + fc[p], ktw_p[p].end());
-    cp.k_twiddle_bar.assign(k_tw.begin() + fc[p], k_tw.begin() + lc[p] + 1);
-    cp.popsize_bar.assign(popsize.begin() + fc[p], popsize.begin() + lc[p] + 1);
-    cp.num_active_parts.assign(num_active.begin() + fc[p], num_active.begin() + lc[p] + 1);
-    // outside the window k_bar_p must be identically zero (it is: no branch of the part reaches there)
-    for (int i = 0; i < fc[p]; ++i) if (kbar_p[p][i] != 0.0) throw std::runtime_error("coalescent grid: lineage outside the part's window");
-  }
-  return out;
+  CoalBuilder b; b.pop = pop; b.t_step = t_step;
+  for (size_t p = 0; p < subtrees.size(); ++p) b.add_part(subtrees[p], rngs[p], (int)p == root_part);
+  if (subtrees.empty()) return {};
+  double lo, hi; b.local_range(lo, hi);
+  b.set_range(lo, hi);
+  std::vector<double> kb, kt; std::vector<int32_t> na;
+  b.local_grid(kb, na);
+  b.sample(kb, na, kt);
+  return b.finish(kt);
 }
 
 }  // namespace emat

@@ -231,6 +231,8 @@ def load_library():
         "emat_set_flags": [B, dbl, i32, i32],
         "emat_begin_upload": [B, i32], "emat_part_upload": [B, i32, P(_FlatTreeC), i32, u64], "emat_end_upload": [B],
         "emat_build_coalescent_parts": [B, P(_PopModelC), i32, dbl],
+        "emat_coalescent_begin": [B, P(_PopModelC), i32, dbl, P(dbl), P(dbl)], "emat_coalescent_set_range": [B, dbl, dbl, P(i32)],
+        "emat_coalescent_local_grid": [B, P(dbl), P(i32)], "emat_coalescent_sample": [B, P(dbl), P(i32), P(dbl)], "emat_coalescent_finish": [B, P(dbl)],
         "emat_run_local_moves": [B, i64], "emat_run_moves_per_part": [B, i64], "emat_synchronize": [B], "emat_recalc_derived": [B],
         "emat_get_totals": [B, P(dbl), P(dbl)],
         "emat_part_get_sizes": [B, i32, P(i32), P(i32), P(i32), P(i32)], "emat_part_download": [B, i32, P(_FlatTreeC)],
@@ -367,6 +369,36 @@ class EmatBackend:
     def build_coalescent_parts(self, pop: PopModel, root_part_index: int, t_step: float):
         m = pop.c_struct()
         self._ck(self._lib.emat_build_coalescent_parts(self._h, C.byref(m), root_part_index, t_step), "emat_build_coalescent_parts")
+
+    # staged form for parts sharded over several processes / GPUs
+    def coalescent_begin(self, pop: PopModel, root_part_index: int, t_step: float):
+        m = pop.c_struct()
+        lo, hi = C.c_double(), C.c_double()
+        self._ck(self._lib.emat_coalescent_begin(self._h, C.byref(m), root_part_index, t_step, C.byref(lo), C.byref(hi)), "emat_coalescent_begin")
+        return float(lo.value), float(hi.value)
+
+    def coalescent_set_range(self, all_t_min: float, all_t_max: float) -> int:
+        n = C.c_int32()
+        self._ck(self._lib.emat_coalescent_set_range(self._h, all_t_min, all_t_max, C.byref(n)), "emat_coalescent_set_range")
+        self._coal_cells = n.value
+        return n.value
+
+    def coalescent_local_grid(self):
+        kb = np.zeros(self._coal_cells)
+        na = np.zeros(self._coal_cells, np.int32)
+        self._ck(self._lib.emat_coalescent_local_grid(self._h, _ptr(kb, C.c_double), _ptr(na, C.c_int32)), "emat_coalescent_local_grid")
+        return kb, na
+
+    def coalescent_sample(self, k_bar: np.ndarray, num_active: np.ndarray) -> np.ndarray:
+        k_bar = np.ascontiguousarray(k_bar, np.float64)
+        num_active = np.ascontiguousarray(num_active, np.int32)
+        kt = np.zeros(self._coal_cells)
+        self._ck(self._lib.emat_coalescent_sample(self._h, _ptr(k_bar, C.c_double), _ptr(num_active, C.c_int32), _ptr(kt, C.c_double)), "emat_coalescent_sample")
+        return kt
+
+    def coalescent_finish(self, k_twiddle_bar: np.ndarray):
+        k = np.ascontiguousarray(k_twiddle_bar, np.float64)
+        self._ck(self._lib.emat_coalescent_finish(self._h, _ptr(k, C.c_double)), "emat_coalescent_finish")
 
     def run_local_moves(self, count: int):
         self._ck(self._lib.emat_run_local_moves(self._h, count), "emat_run_local_moves")

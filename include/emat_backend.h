@@ -85,7 +85,8 @@ typedef struct emat_pop_model {
 } emat_pop_model;
 
 typedef struct emat_config {
-  int32_t device;                /* HIP device ordinal */
+  int32_t device;                /* HIP device ordinal; -1 = host-only handle (uploads and coalescent staging work,
+                                    every launch returns EMAT_ERR_NO_DEVICE: there is no CPU fallback) */
   int32_t num_sites;             /* L */
   int32_t max_parts;             /* upper bound on parts resident at once (0 = grow on demand) */
   double  slab_slack;            /* >=1: per-part working-set capacity as a multiple of its content (0 = default 3.0) */
@@ -134,6 +135,21 @@ emat_status emat_end_upload(emat_backend* h);
  * num_active_parts from the resident subtrees.  Invalidates derived quantities. */
 emat_status emat_build_coalescent_parts(emat_backend* h, const emat_pop_model* pop_model,
                                         int32_t root_part_index, double t_step);
+
+/* Staged form of emat_build_coalescent_parts for a run whose parts are sharded over several GPUs (one
+ * process per GPU).  Between the stages the caller all-reduces tiny vectors over RCCL:
+ *   begin       -> this rank's [t_min, t_max]                       -> all-reduce MIN / MAX
+ *   set_range   -> number of grid cells
+ *   local_grid  -> this rank's k_bar / num_active_parts             -> all-reduce SUM   (very_scalable_coalescent.cpp:153-188)
+ *   sample      -> this rank's share of k_twiddle_bar (Gaussian draws from each part's stream, :198-219) -> all-reduce SUM
+ *   finish      -> every resident part gets its Very_scalable_coalescent_prior_part
+ * `root_part_index` is -1 on ranks that do not hold the run's root part. */
+emat_status emat_coalescent_begin(emat_backend* h, const emat_pop_model* pop_model, int32_t root_part_index, double t_step,
+                                  double* local_t_min, double* local_t_max);
+emat_status emat_coalescent_set_range(emat_backend* h, double all_t_min, double all_t_max, int32_t* num_cells);
+emat_status emat_coalescent_local_grid(emat_backend* h, double* k_bar /*[num_cells]*/, int32_t* num_active_parts /*[num_cells]*/);
+emat_status emat_coalescent_sample(emat_backend* h, const double* k_bar, const int32_t* num_active_parts, double* k_twiddle_bar_local /*[num_cells]*/);
+emat_status emat_coalescent_finish(emat_backend* h, const double* k_twiddle_bar /*[num_cells]*/);
 
 /* ---- the hot path ----------------------------------------------------------------------- */
 /* replaces: Run::run_local_moves(count) (reference run.cpp:682-693): `count / num_parts` calls of
