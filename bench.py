@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--parts", type=int, default=8192, help="number of partition parts requested from the partitioner")
     ap.add_argument("--moves-per-part", type=int, default=1000)
     ap.add_argument("--no-lds", action="store_true")
+    ap.add_argument("--no-topology", action="store_true", help="diagnostic: disable subtree-slide and SPR moves")
+    ap.add_argument("--only-displace", action="store_true", help="diagnostic: only inner-node displacement moves")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-moves", type=int, default=2500)
     return ap.parse_args()
@@ -82,6 +84,8 @@ def main():
 
     sc = make_scenario(args.workload, num_tips=args.tips)
     eng = ShardedEngine(sc, num_parts=args.parts, seed=20261001, rank=rank, world=world, device=local_rank, use_lds=not args.no_lds)
+    eng.topology = not args.no_topology
+    eng.only_displace = args.only_displace
     eng.setup()   # partition, upload this rank's parts, exchange the coalescent grid, recalc derived quantities
 
     def barrier():

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -36,6 +37,8 @@ struct KernelArgs {
   RunFlags flags;
   int32_t num_parts;
   uint32_t lds_slab_bytes;        // capacity of the LDS staging area (0 = never stage)
+  uint32_t lds_scratch_bytes;     // size of the per-part LDS scratch arena
+  int32_t parts_per_wave;         // P: independent parts per wavefront, one lane each
   int64_t moves_per_part;
   int64_t extra_moves_part0;      // remainder of Run::run_local_moves goes to part 0 (run.cpp:683-689)
 };
@@ -53,8 +56,8 @@ __device__ inline double wave_sum(double x) {
 }
 
 // Fills the model pointers of a context; HKY tables come from LDS when they were staged.
-__device__ inline void init_ctx(dev::Ctx& c, uint8_t* slab, const KernelArgs& a, const double* lds_tables) {
-  c.S = slab; c.H = (SlabHeader*)slab; c.N = (NodeRec*)(slab + c.H->off_nodes);
+__device__ inline void init_ctx(dev::Ctx& c, uint8_t* slab, uint8_t* gslab, const KernelArgs& a, const double* lds_tables) {
+  c.S = slab; c.G = gslab; c.H = (SlabHeader*)slab; c.N = (NodeRec*)(slab + c.H->off_nodes);
   c.L = a.evo.num_sites; c.ref = a.evo.ref_sequence; c.part = a.evo.partition_for_site; c.nu = a.evo.nu_l; c.cumQ = a.evo.cum_Q_l;
   if (lds_tables) { c.mu = lds_tables; c.pi = lds_tables + k_max_lds_partitions; c.q = lds_tables + k_max_lds_partitions * 5; }
   else { c.mu = a.evo.mu; c.pi = a.evo.pi; c.q = a.evo.q; }
@@ -63,8 +66,8 @@ __device__ inline void init_ctx(dev::Ctx& c, uint8_t* slab, const KernelArgs& a,
   c.only_displacing_inner_nodes = a.flags.only_displacing_inner_nodes != 0;
   c.topology_moves_enabled = a.flags.topology_moves_enabled != 0;
   c.includes_run_root = (c.H->flags & k_flag_includes_run_root) != 0;
-  c.rng_key = c.H->rng_key; c.rng_ctr = c.H->rng_counter;
-  c.mu_prop = 0.0; c.sc_top = c.H->scratch_begin; c.failed = false; c.bytes = 0;
+  c.rng_key = c.H->rng_key; c.rng_ctr = c.H->rng_counter; c.rng_spare = c.H->rng_spare; c.rng_has_spare = c.H->rng_has_spare != 0;
+  c.mu_prop = 0.0; c.sc_top = c.H->scratch_begin; c.A = nullptr; c.a_top = 0; c.a_end = 0; c.failed = false; c.bytes = 0;
   c.tr_kind = -1.0; c.tr_node = -1.0; c.tr_acc = 0.0; c.tr_log_mh = 0.0;
 }
 __device__ inline const double* stage_tables(const KernelArgs& a, double* lds_tables, int lane) {
@@ -77,35 +80,72 @@ __device__ inline const double* stage_tables(const KernelArgs& a, double* lds_ta
 }
 
 // ---- the hot path: `moves` sub-iterations on every part -------------------------------------------------
-__global__ void __launch_bounds__(k_wave) k_run_moves(KernelArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+// One wavefront runs `parts_per_wave` (P) independent parts, one per lane (lanes 0..P-1), in SIMT lock-step:
+// every part is its own Markov chain with its own RNG stream, so the schedule does not change any result.
+// P = 1 keeps a whole wavefront per part; larger P trades occupancy for SIMD utilisation (lanes that take
+// the same path share its instruction issue).
+// LDS layout per workgroup: [HKY tables][P x context][P x staged slab][P x scratch arena].
+#ifndef EMAT_WAVES_PER_EU
+#define EMAT_WAVES_PER_EU 4
+#endif
+__device__ __forceinline__ void run_moves_body(const KernelArgs& a, uint8_t* lds) {
   const int lane = threadIdx.x;
-  const int part = a.order[blockIdx.x];
-  uint8_t* gslab = a.slabs + a.slab_off[part];
-  SlabHeader* gh = (SlabHeader*)gslab;
+  const int P = a.parts_per_wave;
   double* lds_tables = (double*)lds;
-  uint8_t* lds_slab = lds + k_lds_tables_bytes;
+  const uint32_t ctx_bytes = (uint32_t)((sizeof(dev::Ctx) + 15) & ~15u);
+  uint8_t* lds_ctx = lds + k_lds_tables_bytes;
+  uint8_t* lds_slabs = lds_ctx + (uint32_t)P * ctx_bytes;
+  uint8_t* lds_scratch = lds_slabs + (uint32_t)P * a.lds_slab_bytes;
   const double* tables = stage_tables(a, lds_tables, lane);
-  const uint32_t slab_bytes = gh->slab_bytes;
-  const bool use_lds = a.lds_slab_bytes != 0 && slab_bytes <= a.lds_slab_bytes;
-  uint8_t* slab = gslab;
-  if (use_lds) {
-    wave_copy16(lds_slab, gslab, gh->heap_top, lane);   // header, nodes, cells, trace, live heap; scratch is not copied
-    slab = lds_slab;
+  // stage the persistent state of the wave's parts (header, nodes, cells, trace, list heap); scratch stays in HBM
+  for (int q = 0; q < P; ++q) {
+    const int idx = blockIdx.x * P + q;
+    if (idx >= a.num_parts) break;
+    uint8_t* gslab = a.slabs + a.slab_off[a.order[idx]];
+    const SlabHeader* gh = (const SlabHeader*)gslab;
+    if (a.lds_slab_bytes != 0 && gh->heap_end <= a.lds_slab_bytes) wave_copy16(lds_slabs + (uint32_t)q * a.lds_slab_bytes, gslab, gh->heap_top, lane);
   }
   __syncthreads();
-  if (lane == 0) {
-    dev::Ctx c;
-    init_ctx(c, slab, a, tables);
+  const int my_idx = blockIdx.x * P + lane;
+  if (lane < P && my_idx < a.num_parts) {
+    const int part = a.order[my_idx];
+    uint8_t* gslab = a.slabs + a.slab_off[part];
+    const bool staged = a.lds_slab_bytes != 0 && ((const SlabHeader*)gslab)->heap_end <= a.lds_slab_bytes;
+    uint8_t* slab = staged ? lds_slabs + (uint32_t)lane * a.lds_slab_bytes : gslab;
+    // The per-part context lives in LDS, not in private memory: it is touched by almost every instruction.
+    dev::Ctx& c = *(dev::Ctx*)(lds_ctx + (uint32_t)lane * ctx_bytes);
+    init_ctx(c, slab, gslab, a, tables);
+    if (a.lds_scratch_bytes) { c.A = lds_scratch + (uint32_t)lane * a.lds_scratch_bytes; c.a_end = a.lds_scratch_bytes; }
     int64_t moves = a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0);
+    const uint64_t tick0 = wall_clock64();
     if (c.H->status == 0) {
       for (int64_t i = 0; i < moves; ++i) if (!dev::mcmc_sub_iteration(c)) break;
     }
-    c.H->rng_counter = c.rng_ctr;
+    c.H->rng_counter = c.rng_ctr; c.H->rng_spare = c.rng_spare; c.H->rng_has_spare = c.rng_has_spare ? 1u : 0u;
     c.H->alg_bytes += c.bytes;
+    c.H->device_ticks += (int64_t)(wall_clock64() - tick0);
   }
   __syncthreads();
-  if (use_lds) wave_copy16(gslab, lds_slab, ((SlabHeader*)lds_slab)->heap_top, lane);
+  for (int q = 0; q < P; ++q) {
+    const int idx = blockIdx.x * P + q;
+    if (idx >= a.num_parts) break;
+    uint8_t* gslab = a.slabs + a.slab_off[a.order[idx]];
+    if (a.lds_slab_bytes != 0 && ((const SlabHeader*)gslab)->heap_end <= a.lds_slab_bytes) {
+      const uint8_t* src = lds_slabs + (uint32_t)q * a.lds_slab_bytes;
+      wave_copy16(gslab, src, ((const SlabHeader*)src)->heap_top, lane);
+    }
+  }
+}
+// Two entry points over the same body: the bulk of the parts (small LDS staging area, high occupancy) and the
+// few large parts (large staging area), launched concurrently on two streams so that the large parts, which
+// set the duration of a pass, also run out of LDS.
+__global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves(KernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  run_moves_body(a, lds);
+}
+__global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves_large(KernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  run_moves_body(a, lds);
 }
 
 // ---- whole-part derived quantities (Subrun::recalc_derived_quantities, subrun.cpp:17-26) ---------------------
@@ -120,7 +160,7 @@ __global__ void __launch_bounds__(k_wave) k_recalc_derived(KernelArgs a) {
   const double* tables = stage_tables(a, lds_tables, lane);
   __syncthreads();
   dev::Ctx c;
-  init_ctx(c, slab, a, tables);
+  init_ctx(c, slab, slab, a, tables);
   const int n = c.H->n_nodes, root = c.H->root;
   // phase A: per-branch deltas
   for (int i = lane; i < n; i += k_wave) {
@@ -206,8 +246,10 @@ struct emat_backend {
   emat_config cfg{};
   std::string last_error;
   int L = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  hipStream_t stream = nullptr, stream_large = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_pass0 = nullptr, ev_pass1 = nullptr;
+  int num_large = 0;                // the first `num_large` entries of the launch order form the large class
+  uint32_t lds_small = 0, lds_large = 0;
   double last_run_ms = 0.0;
   // model
   std::vector<uint8_t> ref, partition_for_site;
@@ -229,6 +271,13 @@ struct emat_backend {
   bool host_slabs_current = false;  // h_slabs mirrors the device
   bool derived_valid = false;
   uint32_t max_slab_bytes = 0;
+  std::vector<uint32_t> persistent_bytes;   // per part: slab size without scratch
+  double cfg_heap_per_node = 64.0;  // EMAT_HEAP_PER_NODE: heap bytes per node on top of slack x content
+  int cfg_parts_per_wave = 1;       // EMAT_PARTS_PER_WAVE (tuning knob)
+  uint32_t cfg_lds_scratch = 4096;  // EMAT_LDS_SCRATCH (tuning knob)
+  int cfg_lds_pct = 90;             // EMAT_LDS_PCT (tuning knob): percentile of persistent sizes that sets the staging area
+  uint32_t cfg_lds_cap = 16 * 1024; // EMAT_LDS_CAP (tuning knob): largest staging area of the bulk class
+  uint32_t cfg_lds_cap_large = 48 * 1024; // EMAT_LDS_CAP_LARGE: largest staging area of the large class
   bool host_only = false;           // cfg.device == -1: uploads / coalescent staging only, every launch fails with EMAT_ERR_NO_DEVICE
   std::unique_ptr<CoalBuilder> coal_builder;
 
@@ -247,7 +296,7 @@ void encode_slab(const emat_backend& B, const PartHost& ph, uint8_t* slab, uint3
   SlabHeader* H = (SlabHeader*)slab;
   H->magic = k_slab_magic; H->slab_bytes = slab_bytes; H->n_nodes = n; H->root = t.root;
   H->flags = ph.includes_run_root ? k_flag_includes_run_root : 0u;
-  H->status = 0; H->rng_key = ph.rng.key; H->rng_counter = ph.rng.counter;
+  H->status = 0; H->rng_key = ph.rng.key; H->rng_counter = ph.rng.counter; H->rng_spare = ph.rng.spare; H->rng_has_spare = ph.rng.has_spare ? 1u : 0u;
   uint32_t off = sizeof(SlabHeader);
   H->off_nodes = off; off += (uint32_t)n * (uint32_t)sizeof(NodeRec);
   H->off_cells = off; off += a16((uint32_t)cell_cap * 36u);
@@ -316,7 +365,7 @@ void decode_slab(PartHost& ph, const uint8_t* slab) {
     for (int k = 0; k < r.mfs.cnt; ++k) { t.mfs_site[kf] = fs[k].site; t.mfs_state[kf] = fs[k].state; ++kf; }
     t.mut_offset[i + 1] = km; t.miss_offset[i + 1] = ki; t.mfs_offset[i + 1] = kf;
   }
-  ph.rng.counter = H->rng_counter;
+  ph.rng.counter = H->rng_counter; ph.rng.spare = H->rng_spare; ph.rng.has_spare = H->rng_has_spare != 0;
   const int nc = H->n_cells, cap = H->cell_cap;
   const double* cb = (const double*)(slab + H->off_cells);
   ph.coal.n_cells_total = H->n_cells_total;
@@ -373,7 +422,7 @@ KernelArgs make_args(emat_backend* h) {
   a.evo.ref_sequence = h->d_ref.p; a.evo.partition_for_site = h->d_part.p; a.evo.nu_l = h->d_nu.p; a.evo.cum_Q_l = h->d_cumQ.p;
   a.evo.mu = h->d_mu.p; a.evo.pi = h->d_pi.p; a.evo.q = h->d_q.p;
   a.pop = h->d_pop.p; a.flags = h->flags; a.num_parts = (int)h->parts.size();
-  a.lds_slab_bytes = 0; a.moves_per_part = 0; a.extra_moves_part0 = 0;
+  a.lds_slab_bytes = 0; a.lds_scratch_bytes = 0; a.parts_per_wave = 1; a.moves_per_part = 0; a.extra_moves_part0 = 0;
   return a;
 }
 
@@ -389,7 +438,7 @@ emat_status pull_from_device(emat_backend* h) {
     decode_slab(ph, slab);
     ph.stats.status = H->status; ph.stats.num_nodes = H->n_nodes; ph.stats.moves_done = H->moves_done;
     for (int k = 0; k < 5; ++k) { ph.stats.proposed[k] = H->proposed[k]; ph.stats.accepted[k] = H->accepted[k]; }
-    ph.stats.algorithmic_bytes = H->alg_bytes; ph.stats.rng_draws = (int64_t)H->rng_counter;
+    ph.stats.algorithmic_bytes = H->alg_bytes; ph.stats.rng_draws = (int64_t)H->rng_counter; ph.stats.device_ticks = H->device_ticks;
   }
   h->host_slabs_current = true;
   return EMAT_OK;
@@ -404,7 +453,7 @@ emat_status materialize(emat_backend* h) {
   if (!h->have_coal) return fail(h, EMAT_ERR_STATE, "emat_build_coalescent_parts must precede running");
   const double slack = h->cfg.slab_slack > 0 ? h->cfg.slab_slack : 3.0;
   const int trace_cap = h->cfg.trace_moves > 0 ? h->cfg.trace_moves : 0;
-  uint64_t off = 0; h->max_slab_bytes = 0;
+  uint64_t off = 0; h->max_slab_bytes = 0; h->persistent_bytes.assign(h->parts.size(), 0);
   struct Geo { uint32_t heap, scratch; int cell_cap; };
   std::vector<Geo> geo(h->parts.size());
   for (size_t p = 0; p < h->parts.size(); ++p) {
@@ -412,13 +461,17 @@ emat_status materialize(emat_backend* h) {
     const int n = ph.tree.num_nodes();
     const uint32_t content = heap_content_bytes(ph.tree);
     Geo g;
-    g.heap = a16((uint32_t)std::max<double>(2048.0, content * slack + 64.0 * n));
-    g.scratch = a16(std::max<uint32_t>(8192u, 4u * content + 256u * (uint32_t)n));
+    g.heap = a16((uint32_t)std::max<double>(2048.0, content * slack + h->cfg_heap_per_node * n));
+    // worst case of one move: an unlimited SPR scan visits every (branch, inter-mutation segment) region of the
+    // part (48 B each) with a DFS stack of up to 4 items per region (12 B each), next to two graft analyses
+    const uint32_t regions_max = (uint32_t)n + (uint32_t)ph.tree.num_muts();
+    g.scratch = a16(std::max<uint32_t>(8192u, 128u * regions_max + 4u * content + 256u * (uint32_t)n));
     int nc = (int)ph.coal.k_bar_p.size();
     g.cell_cap = ph.includes_run_root ? std::max(nc * 8, nc + 2048) : nc;
     geo[p] = g;
     uint32_t bytes = (uint32_t)sizeof(SlabHeader) + (uint32_t)n * (uint32_t)sizeof(NodeRec) + a16((uint32_t)g.cell_cap * 36u) + a16((uint32_t)trace_cap * 32u) + g.heap + g.scratch;
     ph.slab_off = off; ph.slab_bytes = bytes; off += bytes;
+    h->persistent_bytes[p] = bytes - g.scratch;
     h->max_slab_bytes = std::max(h->max_slab_bytes, bytes);
   }
   h->h_slabs.assign(off, 0);
@@ -430,22 +483,29 @@ emat_status materialize(emat_backend* h) {
     // carry the statistics over re-materialisations
     SlabHeader* H = (SlabHeader*)(h->h_slabs.data() + ph.slab_off);
     H->moves_done = ph.stats.moves_done; for (int k = 0; k < 5; ++k) { H->proposed[k] = ph.stats.proposed[k]; H->accepted[k] = ph.stats.accepted[k]; }
-    H->alg_bytes = ph.stats.algorithmic_bytes;
+    H->alg_bytes = ph.stats.algorithmic_bytes; H->device_ticks = ph.stats.device_ticks;
   }
   std::vector<int32_t> order(h->parts.size());
   std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->parts[a].tree.num_nodes() > h->parts[b].tree.num_nodes(); });
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->persistent_bytes[a] > h->persistent_bytes[b]; });
+  {   // size classes: the bulk stages up to the `lds_pct` percentile; the rest forms the large class
+    std::vector<uint32_t> v = h->persistent_bytes;
+    std::sort(v.begin(), v.end());
+    uint32_t small = v[std::min(v.size() - 1, (size_t)(v.size() * (size_t)h->cfg_lds_pct / 100))];
+    small = std::min<uint32_t>((small + 1023u) & ~1023u, h->cfg_lds_cap);
+    uint32_t large = std::min<uint32_t>((v.back() + 1023u) & ~1023u, h->cfg_lds_cap_large);
+    int nl = 0;
+    while (nl < (int)order.size() && h->persistent_bytes[order[nl]] > small) ++nl;
+    if (!h->cfg.use_lds) { small = large = 0; nl = 0; }
+    if (large <= small) nl = 0;
+    h->num_large = nl; h->lds_small = small; h->lds_large = large;
+    if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] parts %zu persistent bytes p50 %u p90 %u p99 %u max %u | bulk LDS %u (%d parts) large LDS %u (%d parts)\n", v.size(), v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 99 / 100], v.back(), small, (int)order.size() - nl, large, nl);
+  }
   HIP_TRY(h->d_slabs.upload(h->h_slabs.data(), h->h_slabs.size()));
   HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
   HIP_TRY(h->d_order.upload(order.data(), order.size()));
   h->slabs_on_device = true; h->host_slabs_current = true; h->derived_valid = false;
   return EMAT_OK;
-}
-
-uint32_t lds_budget(const emat_backend* h) {
-  if (!h->cfg.use_lds) return 0;
-  // stage when a slab fits in 64 KiB minus the table area (160 KiB per CU => at least two workgroups per CU)
-  return 64u * 1024u - k_lds_tables_bytes;
 }
 
 emat_status launch_recalc(emat_backend* h) {
@@ -467,14 +527,36 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0) {
   if (!h->derived_valid) { st = launch_recalc(h); if (st) return st; }
   KernelArgs a = make_args(h);
   a.moves_per_part = per_part; a.extra_moves_part0 = extra0;
-  const uint32_t budget = lds_budget(h);
-  uint32_t lds_slab = std::min(budget, (h->max_slab_bytes + 15u) & ~15u);
-  a.lds_slab_bytes = budget == 0 ? 0 : lds_slab;
-  size_t shmem = k_lds_tables_bytes + (budget == 0 ? 0 : lds_slab);
-  if (shmem > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  int P = h->cfg_parts_per_wave > 0 ? h->cfg_parts_per_wave : 1;
+  if (P > k_wave) P = k_wave;
+  a.parts_per_wave = P;
+  a.lds_scratch_bytes = h->cfg.use_lds ? h->cfg_lds_scratch : 0u;
+  const uint32_t ctx_bytes = (uint32_t)((sizeof(dev::Ctx) + 15) & ~15u);
+  const int n_all = (int)h->parts.size(), n_large = h->num_large, n_small = n_all - n_large;
+  auto shmem_for = [&](uint32_t slab_area) { return (size_t)k_lds_tables_bytes + (size_t)P * (ctx_bytes + slab_area + a.lds_scratch_bytes); };
+  const size_t sh_small = shmem_for(h->lds_small), sh_large = shmem_for(h->lds_large);
+  if (std::max(sh_small, sh_large) > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower parts_per_wave or disable use_lds");
+  if (sh_small > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_small));
+  if (n_large > 0 && sh_large > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves_large, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_large));
   HIP_TRY(hipEventRecord(h->ev_start, h->stream));
-  hipLaunchKernelGGL(k_run_moves, dim3((unsigned)h->parts.size()), dim3(k_wave), shmem, h->stream, a);
-  HIP_TRY(hipGetLastError());
+  if (n_large > 0) {   // fork: the large class runs on its own stream, concurrently with the bulk
+    HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->stream_large, h->ev_fork, 0));
+    KernelArgs b = a;
+    b.num_parts = n_large; b.lds_slab_bytes = h->lds_large;
+    hipLaunchKernelGGL(k_run_moves_large, dim3((unsigned)((n_large + P - 1) / P)), dim3(k_wave), sh_large, h->stream_large, b);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_join, h->stream_large));
+  }
+  if (n_small > 0) {
+    KernelArgs b = a;
+    b.order = a.order + n_large; b.num_parts = n_small; b.lds_slab_bytes = h->lds_small;
+    HIP_TRY(hipEventRecord(h->ev_pass0, h->stream));
+    hipLaunchKernelGGL(k_run_moves, dim3((unsigned)((n_small + P - 1) / P)), dim3(k_wave), sh_small, h->stream, b);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_pass1, h->stream));
+  }
+  if (n_large > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
   h->host_slabs_current = false;
   return EMAT_OK;
@@ -501,8 +583,17 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   if (hipSetDevice(cfg->device) != hipSuccess) return EMAT_ERR_HIP;
   auto h = std::make_unique<emat_backend>();
   h->cfg = *cfg; h->L = cfg->num_sites;
+  if (const char* e = getenv("EMAT_SLACK")) h->cfg.slab_slack = atof(e);
+  if (const char* e = getenv("EMAT_HEAP_PER_NODE")) h->cfg_heap_per_node = atof(e);
+  if (const char* e = getenv("EMAT_PARTS_PER_WAVE")) h->cfg_parts_per_wave = atoi(e);
+  if (const char* e = getenv("EMAT_LDS_SCRATCH")) h->cfg_lds_scratch = (uint32_t)atoi(e) & ~15u;
+  if (const char* e = getenv("EMAT_LDS_PCT")) h->cfg_lds_pct = std::max(1, std::min(100, atoi(e)));
+  if (const char* e = getenv("EMAT_LDS_CAP_LARGE")) h->cfg_lds_cap_large = (uint32_t)atoi(e) & ~1023u;
+  if (const char* e = getenv("EMAT_LDS_CAP")) h->cfg_lds_cap = (uint32_t)atoi(e) & ~1023u;
   if (hipStreamCreate(&h->stream) != hipSuccess) return EMAT_ERR_HIP;
-  if (hipEventCreate(&h->ev_start) != hipSuccess || hipEventCreate(&h->ev_stop) != hipSuccess) return EMAT_ERR_HIP;
+  if (hipStreamCreate(&h->stream_large) != hipSuccess) return EMAT_ERR_HIP;
+  for (hipEvent_t* e : {&h->ev_start, &h->ev_stop, &h->ev_pass0, &h->ev_pass1}) if (hipEventCreate(e) != hipSuccess) return EMAT_ERR_HIP;
+  for (hipEvent_t* e : {&h->ev_fork, &h->ev_join}) if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return EMAT_ERR_HIP;
   *out = h.release();
   return EMAT_OK;
 }
@@ -511,8 +602,8 @@ emat_status emat_backend_destroy(emat_backend* h) {
   if (h->host_only) { delete h; return EMAT_OK; }
   (void)hipSetDevice(h->cfg.device);
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-  if (h->ev_start) (void)hipEventDestroy(h->ev_start);
-  if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+  if (h->stream_large) { (void)hipStreamSynchronize(h->stream_large); (void)hipStreamDestroy(h->stream_large); }
+  for (hipEvent_t e : {h->ev_start, h->ev_stop, h->ev_fork, h->ev_join, h->ev_pass0, h->ev_pass1}) if (e) (void)hipEventDestroy(e);
   delete h;
   return EMAT_OK;
 }
@@ -567,7 +658,7 @@ emat_status emat_part_upload(emat_backend* h, int32_t part_id, const emat_flat_t
   if (ph.uploaded) return fail(h, EMAT_ERR_STATE, "part uploaded twice");
   ph.tree = FlatTree::from_view(*subtree);
   ph.includes_run_root = includes_run_root != 0;
-  ph.rng.key = seed; ph.rng.counter = 0;
+  ph.rng.key = seed; ph.rng.counter = 0; ph.rng.spare = 0; ph.rng.has_spare = false;
   ph.uploaded = true; ph.stats = emat_part_stats{};
   if (ph.includes_run_root) h->root_part = part_id;
   return EMAT_OK;
@@ -765,6 +856,26 @@ emat_status emat_part_get_trace(emat_backend* h, int32_t part_id, int32_t* num_m
   int n = std::min(*num_moves, H->trace_len);
   std::memcpy(trace, slab + H->off_trace, (size_t)n * 32);
   *num_moves = n;
+  return EMAT_OK;
+}
+/* debugging aid (not part of the boundary): phase profile of a part, see EMAT_PROFILE_PHASES */
+emat_status emat_debug_phase_ticks(emat_backend* h, int32_t part_id, int64_t* out16) {
+  if (!h || !out16 || part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = pull_from_device(h); if (st) return st;
+  const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + h->parts[part_id].slab_off);
+  for (int i = 0; i < 16; ++i) out16[i] = H->phase_ticks[i];
+  return EMAT_OK;
+}
+/* Duration of the bulk-class kernel (k_run_moves) of the last pass, from HIP events around that launch on its stream. */
+emat_status emat_last_kernel_ms(emat_backend* h, double* ms, int32_t* num_parts_in_kernel) {
+  if (!h || !ms) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle");
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  HIP_TRY(hipEventSynchronize(h->ev_pass1));
+  float f = 0.f;
+  HIP_TRY(hipEventElapsedTime(&f, h->ev_pass0, h->ev_pass1));
+  *ms = f;
+  if (num_parts_in_kernel) *num_parts_in_kernel = (int)h->parts.size() - h->num_large;
   return EMAT_OK;
 }
 emat_status emat_last_run_ms(emat_backend* h, double* ms) {

@@ -22,6 +22,7 @@ namespace dev {
 
 #define EMAT_D __device__ inline
 #define EMAT_DN __device__ __noinline__
+#define EMAT_DF __device__ __forceinline__
 
 constexpr double k_neg_dbl_max = -1.7976931348623157e308;
 constexpr double k_inf = __builtin_huge_val();
@@ -30,6 +31,7 @@ constexpr int k_no_node = -1;
 // ---- per-wave context ----------------------------------------------------------------------------
 struct Ctx {
   uint8_t* S;                 // slab base (LDS or HBM; generic address space)
+  uint8_t* G;                 // base for scratch offsets: always the HBM copy of the slab (scratch is never staged in LDS)
   SlabHeader* H;
   NodeRec* N;
   // evolution model: per-site arrays in HBM, per-partition HKY tables in LDS when staged
@@ -48,9 +50,12 @@ struct Ctx {
   bool includes_run_root;
   // RNG (Philox4x32-10; one 128-bit block per draw)
   uint64_t rng_key, rng_ctr;
+  uint64_t rng_spare; bool rng_has_spare;   // second 64-bit half of the last Philox block, not yet consumed
   double mu_prop;             // effective JC69 rate of the current SPR move (subrun.cpp:502,710)
-  // scratch bump pointer (byte offset from slab base)
-  uint32_t sc_top;
+  // scratch: a small LDS arena first (A), the part's HBM scratch region as overflow (offsets from G)
+  uint8_t* A;                 // LDS arena base (may be null)
+  uint32_t a_top, a_end;      // byte offsets from A
+  uint32_t sc_top;            // HBM arena bump pointer (byte offset from G)
   bool failed;
   // statistics
   int64_t bytes;
@@ -63,6 +68,14 @@ EMAT_D void fail_at(Ctx& c, int status, int line) {
 }
 #define EMAT_FAIL(c, st) ::emat::dev::fail_at((c), (st), __LINE__)
 #define EMAT_CHECK(c, cond) do { if (!(cond)) ::emat::dev::fail_at((c), ::emat::k_part_internal, __LINE__); } while (0)
+
+#ifdef EMAT_PROFILE_PHASES
+#define EMAT_PHASE_BEGIN() long long _ph_t0 = clock64()
+#define EMAT_PHASE(c, k) do { long long _t = clock64(); (c).H->phase_ticks[k] += _t - _ph_t0; _ph_t0 = _t; } while (0)
+#else
+#define EMAT_PHASE_BEGIN() do {} while (0)
+#define EMAT_PHASE(c, k) do {} while (0)
+#endif
 
 // ---- RNG: identical stream to the parity oracle (oracle/orc_core.hpp `Rng`) -------------------------
 EMAT_D void philox4x32_10(uint64_t ctr, uint64_t key, uint32_t out[4]) {
@@ -79,23 +92,24 @@ EMAT_D void philox4x32_10(uint64_t ctr, uint64_t key, uint32_t out[4]) {
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-EMAT_D void rng_next(Ctx& c, uint64_t& a, uint64_t& b) {
+EMAT_D uint64_t rng_next64(Ctx& c) {
+  if (c.rng_has_spare) { c.rng_has_spare = false; return c.rng_spare; }
   uint32_t w[4];
   philox4x32_10(c.rng_ctr++, c.rng_key, w);
-  a = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-  b = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+  c.rng_spare = (uint64_t)w[2] | ((uint64_t)w[3] << 32); c.rng_has_spare = true;
+  return (uint64_t)w[0] | ((uint64_t)w[1] << 32);
 }
 EMAT_D double to_co(uint64_t a) { return (double)(a >> 11) * 0x1.0p-53; }
 EMAT_D double to_oo(uint64_t a) { return ((double)(a >> 12) + 0.5) * 0x1.0p-52; }
 EMAT_D double to_oc(uint64_t a) { return ((double)(a >> 11) + 1.0) * 0x1.0p-53; }
-EMAT_D double u01_co(Ctx& c) { uint64_t a, b; rng_next(c, a, b); return to_co(a); }
-EMAT_D double u01_oo(Ctx& c) { uint64_t a, b; rng_next(c, a, b); return to_oo(a); }
-EMAT_D double u01_oc(Ctx& c) { uint64_t a, b; rng_next(c, a, b); return to_oc(a); }
+EMAT_D double u01_co(Ctx& c) { return to_co(rng_next64(c)); }
+EMAT_D double u01_oo(Ctx& c) { return to_oo(rng_next64(c)); }
+EMAT_D double u01_oc(Ctx& c) { return to_oc(rng_next64(c)); }
 EMAT_D double uniform_co(Ctx& c, double lo, double hi) { return lo + (hi - lo) * u01_co(c); }
 EMAT_D double uniform_oc(Ctx& c, double lo, double hi) { return lo + (hi - lo) * u01_oc(c); }
-EMAT_D int uniform_int(Ctx& c, int n) { uint64_t a, b; rng_next(c, a, b); return (int)__umul64hi(a, (uint64_t)n); }
+EMAT_D int uniform_int(Ctx& c, int n) { return (int)__umul64hi(rng_next64(c), (uint64_t)n); }
 EMAT_D double gaussian(Ctx& c, double mean, double sigma) {
-  uint64_t a, b; rng_next(c, a, b);
+  uint64_t a = rng_next64(c), b = rng_next64(c);
   double u1 = to_oc(a), u2 = to_co(b);
   double r = sqrt(-2.0 * log(u1));
   return mean + sigma * (r * cos(6.283185307179586476925 * u2));
@@ -109,12 +123,18 @@ EMAT_D int poisson(Ctx& c, double lambda) {
   return k;
 }
 
-// ---- scratch arena (temporaries of one move) -----------------------------------------------------------
+// ---- scratch arenas (temporaries of one move) -----------------------------------------------------------
 template <class T> struct SVec { T* p; int n; int cap; };
+struct ScMark { uint32_t a, g; };
+EMAT_D ScMark sc_mark(const Ctx& c) { ScMark m; m.a = c.a_top; m.g = c.sc_top; return m; }
+EMAT_D void sc_release(Ctx& c, ScMark m) { c.a_top = m.a; c.sc_top = m.g; }
+EMAT_D void sc_reset(Ctx& c) { c.a_top = 0; c.sc_top = c.H->scratch_begin; }
+EMAT_D bool sc_in_lds(const Ctx& c, const void* p) { return c.A != nullptr && (const uint8_t*)p >= c.A && (const uint8_t*)p < c.A + c.a_end; }
 EMAT_D uint8_t* sc_alloc(Ctx& c, uint32_t bytes) {
   uint32_t b = (bytes + 15u) & ~15u;
-  if (c.sc_top + b > c.H->scratch_end) { EMAT_FAIL(c, k_part_overflow); return c.S + c.H->scratch_begin; }
-  uint8_t* p = c.S + c.sc_top;
+  if (c.a_top + b <= c.a_end) { uint8_t* p = c.A + c.a_top; c.a_top += b; return p; }
+  if (c.sc_top + b > c.H->scratch_end) { EMAT_FAIL(c, k_part_overflow); return c.G + c.H->scratch_begin; }
+  uint8_t* p = c.G + c.sc_top;
   c.sc_top += b;
   return p;
 }
@@ -122,18 +142,53 @@ template <class T> EMAT_D SVec<T> sc_vec(Ctx& c, int cap) {
   SVec<T> v; v.n = 0;
   uint32_t bytes = (uint32_t)cap * (uint32_t)sizeof(T);
   uint32_t b = (bytes + 15u) & ~15u;
-  if (cap < 0 || c.sc_top + b > c.H->scratch_end) { EMAT_FAIL(c, k_part_overflow); v.p = (T*)(c.S + c.H->scratch_begin); v.cap = 0; return v; }
-  v.p = (T*)(c.S + c.sc_top); v.cap = cap; c.sc_top += b;
+  if (cap >= 0 && c.a_top + b <= c.a_end) { v.p = (T*)(c.A + c.a_top); v.cap = cap; c.a_top += b; return v; }
+  if (cap < 0 || c.sc_top + b > c.H->scratch_end) { EMAT_FAIL(c, k_part_overflow); v.p = (T*)(c.G + c.H->scratch_begin); v.cap = 0; return v; }
+  v.p = (T*)(c.G + c.sc_top); v.cap = cap; c.sc_top += b;
   return v;
 }
 template <class T> EMAT_D void push(Ctx& c, SVec<T>& v, const T& x) { if (v.n < v.cap) v.p[v.n++] = x; else EMAT_FAIL(c, k_part_overflow); }
-// remaining scratch, expressed in elements of T (for open-ended allocations that are trimmed afterwards)
-template <class T> EMAT_D int sc_room(const Ctx& c) { return (int)((c.H->scratch_end - c.sc_top) / sizeof(T)) - 2; }
-// give back the unused tail of the most recent allocation
+// An open-ended vector: takes (up to `max_elems` of) the free space of one arena -- the LDS arena when it still
+// has at least `min_lds_elems` elements of room, else the HBM arena -- and must be trimmed with sc_trim.
+template <class T> EMAT_D SVec<T> sc_open(Ctx& c, int max_elems, int min_lds_elems) {
+  SVec<T> v; v.n = 0;
+  uint32_t a0 = (c.a_top + 15u) & ~15u;
+  int room_a = c.a_end > a0 ? (int)((c.a_end - a0) / sizeof(T)) : 0;
+  if (room_a >= min_lds_elems) { v.p = (T*)(c.A + a0); v.cap = room_a < max_elems ? room_a : max_elems; c.a_top = c.a_end; return v; }
+  uint32_t g0 = (c.sc_top + 15u) & ~15u;
+  int room_g = c.H->scratch_end > g0 ? (int)((c.H->scratch_end - g0) / sizeof(T)) : 0;
+  v.p = (T*)(c.G + g0); v.cap = room_g < max_elems ? room_g : max_elems; c.sc_top = c.H->scratch_end;
+  if (v.cap <= 0) { v.cap = 0; EMAT_FAIL(c, k_part_overflow); }
+  return v;
+}
+// give back the unused tail of the most recent allocation in its arena
 template <class T> EMAT_D void sc_trim(Ctx& c, SVec<T>& v) {
   uint32_t used = ((uint32_t)v.n * (uint32_t)sizeof(T) + 15u) & ~15u;
-  c.sc_top = (uint32_t)((uint8_t*)v.p - c.S) + used;
+  if (sc_in_lds(c, v.p)) c.a_top = (uint32_t)((uint8_t*)v.p - c.A) + used;
+  else c.sc_top = (uint32_t)((uint8_t*)v.p - c.G) + used;
   v.cap = v.n;
+}
+// Two containers growing towards each other inside one arena (results upwards from `lo`, a work stack downwards
+// from `hi`); picks the LDS arena when it has at least `min_lds_bytes` free.
+struct ScSpan { uint8_t* lo; uint8_t* hi; bool lds; };
+EMAT_D ScSpan sc_span(Ctx& c, uint32_t min_lds_bytes) {
+  ScSpan s;
+  uint32_t a0 = (c.a_top + 15u) & ~15u;
+  if (c.a_end > a0 && c.a_end - a0 >= min_lds_bytes) { s.lo = c.A + a0; s.hi = c.A + (c.a_end & ~15u); s.lds = true; return s; }
+  uint32_t g0 = (c.sc_top + 15u) & ~15u;
+  s.lo = c.G + g0; s.hi = c.G + (c.H->scratch_end & ~15u); s.lds = false;
+  if (s.hi < s.lo) s.hi = s.lo;
+  return s;
+}
+EMAT_D ScSpan sc_span_hbm(Ctx& c) {
+  ScSpan s; uint32_t g0 = (c.sc_top + 15u) & ~15u;
+  s.lo = c.G + g0; s.hi = c.G + (c.H->scratch_end & ~15u); s.lds = false;
+  if (s.hi < s.lo) s.hi = s.lo;
+  return s;
+}
+EMAT_D void sc_span_commit(Ctx& c, const ScSpan& s, uint32_t used_bytes) {
+  uint32_t u = (used_bytes + 15u) & ~15u;
+  if (s.lds) c.a_top = (uint32_t)(s.lo - c.A) + u; else c.sc_top = (uint32_t)(s.lo - c.G) + u;
 }
 
 // ---- persistent per-node lists in the slab heap ---------------------------------------------------------
@@ -336,7 +391,7 @@ EMAT_DN void sd_push_back(Ctx& c, SVec<SdRec>& v, int site, int from, int to) { 
 }
 
 // ---- genetic-likelihood calculus (phylo_tree_calc.h:121-206, phylo_tree_calc.cpp:41-118,406-456) ----------------
-EMAT_DN double delta_lambda_across_missations(Ctx& c, const IvRec* iv, int niv, const FsRec* fs, int nfs) {   // h:121-138
+EMAT_D double delta_lambda_across_missations(Ctx& c, const IvRec* iv, int niv, const FsRec* fs, int nfs) {   // h:121-138
   double r = 0.0;
   for (int i = 0; i < niv; ++i) r -= c.cumQ[iv[i].end] - c.cumQ[iv[i].start];
   for (int i = 0; i < nfs; ++i) { int l = fs[i].site; r -= c.mu[c.part[l]] * c.nu[l] * (q_a(c, l, fs[i].state) - q_a(c, l, c.ref[l])); }
@@ -357,7 +412,7 @@ EMAT_DN double calc_lambda_at_node(Ctx& c, int node) {   // cpp:406-418
   for (int cur = node; cur != k_no_node; cur = c.N[cur].parent) r += delta_lambda_across_branch(c, cur);
   return r;
 }
-EMAT_DN double branch_log_G(const Ctx& c, double t_P, double t_X, double lambda_X, const MutRec* m, int nm) {   // h:185-206
+EMAT_D double branch_log_G(const Ctx& c, double t_P, double t_X, double lambda_X, const MutRec* m, int nm) {   // h:185-206
   double r = -lambda_X * (t_X - t_P);
   for (int i = nm - 1; i >= 0; --i) {
     int l = m[i].site;
@@ -425,12 +480,12 @@ EMAT_DN int find_MRCA_of(Ctx& c, int P, int Q) {   // phylo_tree.cpp:204-280
 }
 
 // ---- population models (pop_model.cpp:18-145, 181-204, 247-330, 525-560) ------------------------------------------
-EMAT_D int skygrid_interval(const PopTable& p, double t) {   // lower_bound on knots
+EMAT_DF int skygrid_interval(const PopTable& p, double t) {   // lower_bound on knots
   int lo = 0, hi = p.skygrid_num_knots;
   while (lo < hi) { int mid = (lo + hi) >> 1; if (p.skygrid_x[mid] < t) lo = mid + 1; else hi = mid; }
   return lo;   // 0 .. M+1
 }
-EMAT_D double skygrid_log_N(const PopTable& p, double t) {
+EMAT_DF double skygrid_log_N(const PopTable& p, double t) {
   int k = skygrid_interval(p, t), M = p.skygrid_num_knots - 1;
   if (k == 0) return p.skygrid_gamma[0];
   if (k > M) return p.skygrid_gamma[M];
@@ -438,10 +493,17 @@ EMAT_D double skygrid_log_N(const PopTable& p, double t) {
   double cc = (t - p.skygrid_x[k - 1]) / (p.skygrid_x[k] - p.skygrid_x[k - 1]);
   return (1 - cc) * p.skygrid_gamma[k - 1] + cc * p.skygrid_gamma[k];
 }
-EMAT_DN double pop_at_time(const PopTable& p, double t) {
+EMAT_DF double pop_at_time(const PopTable& p, double t) {
   if (p.kind == 0) return p.p[0];
   if (p.kind == 1) { double v = p.p[1] * exp((t - p.p[0]) * p.p[2]); return p.p[3] > v ? p.p[3] : v; }
   return exp(skygrid_log_N(p, t));
+}
+// log(N(t_new) / N(t_old)) (very_scalable_coalescent.cpp:323).  For the skygrid N = exp(log_N), so the ratio is
+// formed in log space directly; the other models go through pop_at_time as the reference does.
+EMAT_DF double log_pop_ratio(const PopTable& p, double t_new, double t_old) {
+  if (p.kind == 0) return 0.0;
+  if (p.kind == 2) return skygrid_log_N(p, t_new) - skygrid_log_N(p, t_old);
+  return log(pop_at_time(p, t_new) / pop_at_time(p, t_old));
 }
 EMAT_D double exp_unclamped_int(const PopTable& p, double a, double b) { double n0 = p.p[1], g = p.p[2], t0 = p.p[0]; return n0 / g * exp(g * (a - t0)) * expm1(g * (b - a)); }
 EMAT_DN double skygrid_log_int_N(const PopTable& p, double a, double b) {   // pop_model.cpp:247-330 with gamma_eff = gamma
@@ -501,9 +563,14 @@ EMAT_D int cell_for(const Ctx& c, double t) { return (int)floor((c.H->t_ref - t)
 EMAT_D double cell_ubound(const Ctx& c, int cell) { return c.H->t_ref - c.H->t_step * cell; }
 EMAT_D double cell_lbound(const Ctx& c, int cell) { return cell_ubound(c, cell) - c.H->t_step; }
 // cpp:259-299 (only the root part may grow, towards the past)
-EMAT_DN void coal_ensure_space(Ctx& c, double t) {
+EMAT_DN void coal_grow(Ctx& c, int cell);
+EMAT_DF void coal_ensure_space(Ctx& c, double t) {
   int cell = cell_for(c, t);
-  if (c.includes_run_root) {
+  if (cell >= c.H->n_cells_total && c.includes_run_root) coal_grow(c, cell);   // rare: the root moved past the grid
+  if (cell < c.H->cell_first || cell >= c.H->n_cells_total) EMAT_FAIL(c, k_part_internal);
+}
+EMAT_DN void coal_grow(Ctx& c, int cell) {
+  {
     Cells k = cells_of(c);
     while (c.H->n_cells_total <= cell) {
       int i = c.H->n_cells_total, w = i - c.H->cell_first;
@@ -515,10 +582,9 @@ EMAT_DN void coal_ensure_space(Ctx& c, double t) {
       c.H->n_cells_total = i + 1; c.H->n_cells = w + 1;
     }
   }
-  if (cell < c.H->cell_first || cell >= c.H->n_cells_total) EMAT_FAIL(c, k_part_internal);
 }
 // cpp:37-79 on k_bar_p
-EMAT_DN void coal_add_interval(Ctx& c, double t_start, double t_end, double delta_k) {
+EMAT_DF void coal_add_interval(Ctx& c, double t_start, double t_end, double delta_k) {
   if (c.failed) return;
   if (t_start < t_end) { double t = t_start; t_start = t_end; t_end = t; }
   Cells k = cells_of(c);
@@ -536,14 +602,14 @@ EMAT_DN void coal_add_interval(Ctx& c, double t_start, double t_end, double delt
   }
   c.bytes += 8 * (int64_t)(cell_end - cell_start + 1);
 }
-EMAT_D double coal_cell_term(const Ctx& c, const Cells& k, int w, double new_k, double old_k) {
+EMAT_DF double coal_cell_term(const Ctx& c, const Cells& k, int w, double new_k, double old_k) {
   double na = (double)k.nactive[w];
   return c.H->t_step / k.popsize[w] * (
       +0.5 * (new_k * new_k - old_k * old_k) * na
       - (k.ktw_p[w] * na - k.ktw[w] + 0.5) * (new_k - old_k));
 }
 // cpp:388-459
-EMAT_DN double coal_delta_on_add_interval(Ctx& c, double min_t, double max_t, double delta_k) {
+EMAT_DF double coal_delta_on_add_interval(Ctx& c, double min_t, double max_t, double delta_k) {
   { int cm = cell_for(c, max_t); if (cm < c.H->cell_first || cm >= c.H->n_cells_total) { EMAT_FAIL(c, k_part_internal); return 0.0; } }
   coal_ensure_space(c, min_t);
   if (c.failed) return 0.0;
@@ -569,19 +635,19 @@ EMAT_DN double coal_delta_on_add_interval(Ctx& c, double min_t, double max_t, do
   c.bytes += 36 * (int64_t)(cell_end - cell_start + 1);
   return d;
 }
-EMAT_D double coal_delta_displace_coalescence(Ctx& c, double old_t, double new_t) {   // cpp:310-326
+EMAT_DF double coal_delta_displace_coalescence(Ctx& c, double old_t, double new_t) {   // cpp:310-326
   double d = (old_t <= new_t) ? coal_delta_on_add_interval(c, old_t, new_t, -1.0) : coal_delta_on_add_interval(c, new_t, old_t, +1.0);
-  d -= log(pop_at_time(*c.pop, new_t) / pop_at_time(*c.pop, old_t));
+  d -= log_pop_ratio(*c.pop, new_t, old_t);
   return d;
 }
-EMAT_D double coal_delta_displace_tip(Ctx& c, double old_t, double new_t) {           // cpp:337-353
+EMAT_DF double coal_delta_displace_tip(Ctx& c, double old_t, double new_t) {           // cpp:337-353
   return (old_t <= new_t) ? coal_delta_on_add_interval(c, old_t, new_t, +1.0) : coal_delta_on_add_interval(c, new_t, old_t, -1.0);
 }
-EMAT_D void coal_coalescence_displaced(Ctx& c, double old_t, double new_t) {           // cpp:301-308
+EMAT_DF void coal_coalescence_displaced(Ctx& c, double old_t, double new_t) {           // cpp:301-308
   coal_ensure_space(c, new_t);
   coal_add_interval(c, old_t, new_t, old_t <= new_t ? -1.0 : +1.0);
 }
-EMAT_D void coal_tip_displaced(Ctx& c, double old_t, double new_t) {                   // cpp:328-335
+EMAT_DF void coal_tip_displaced(Ctx& c, double old_t, double new_t) {                   // cpp:328-335
   coal_ensure_space(c, new_t);
   coal_add_interval(c, old_t, new_t, old_t <= new_t ? +1.0 : -1.0);
 }

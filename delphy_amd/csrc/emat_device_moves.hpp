@@ -14,7 +14,7 @@ EMAT_D void note_move(Ctx& c, int node, double log_mh, bool acc, int kind) { c.t
 EMAT_D bool mh_accept(Ctx& c, double log_mh) { return log_mh >= 0.0 || uniform_co(c, 0.0, 1.0) < exp(log_mh); }
 
 // distributions.h:38-69
-EMAT_DN double bounded_exponential(Ctx& c, double lambda, double a, double b) {
+EMAT_D double bounded_exponential(Ctx& c, double lambda, double a, double b) {
   double u = u01_oo(c);
   double ltr = lambda * (b - a);
   double x;
@@ -37,10 +37,14 @@ EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new_t, double a
   const double new_t_P = new_t;
   if (new_t_P == t_X || new_t_P == c.N[new_branch].t || (P != c.H->root && new_t_P == c.N[c.N[P].parent].t)) return;
   c.mu_prop = c.N[c.H->root].lambda / (c.L - c.N[c.H->root].n_missing);
+  EMAT_PHASE_BEGIN();
   Graft old_graft = analyze_graft(c, X);
   peel_graft(c, old_graft);
+  EMAT_PHASE(c, 0);
   spr_move_topology(c, X, new_branch, new_t);
+  EMAT_PHASE(c, 1);
   Graft new_graft = propose_new_graft(c, X);
+  EMAT_PHASE(c, 2);
   if (c.failed) return;
   double d_prior = coal_delta_displace_coalescence(c, old_t_P, new_t);
   double log_mh = (new_graft.delta_log_G - new_graft.log_alpha_mut) - (old_graft.delta_log_G - old_graft.log_alpha_mut) + log(alpha_ratio) + d_prior;
@@ -56,9 +60,10 @@ EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new_t, double a
     spr_move_topology(c, X, old_S, old_t_P);
     apply_graft(c, old_graft);
   }
+  EMAT_PHASE(c, 4);
 }
 
-EMAT_DN void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
+EMAT_D void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
   begin_move(c, k_inner_node_displace);
   int node;
   { int guard = 0; do { node = pick_random_node(c); } while (is_tip(c, node) && guard++ < (1 << 26)); }
@@ -120,7 +125,7 @@ EMAT_DN void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
   }
 }
 
-EMAT_DN void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
+EMAT_D void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
   begin_move(c, k_tip_displace);
   int node;
   { int guard = 0; do { node = pick_random_node(c); } while (!is_tip(c, node) && guard++ < (1 << 26)); }
@@ -153,7 +158,7 @@ EMAT_DN void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
 }
 
 // phylo_tree.cpp:579-644; result in scratch
-EMAT_DN SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) {
+EMAT_D SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) {
   const int n = nmuts(c, X);
   SVec<MutRec> out = sc_vec<MutRec>(c, n);
   if (c.failed) return out;
@@ -182,7 +187,7 @@ EMAT_DN SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) {
   return out;
 }
 
-EMAT_DN void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
+EMAT_D void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
   begin_move(c, k_branch_reform);
   if (c.H->n_nodes < 3) return;
   const int X = pick_random_node(c);
@@ -206,12 +211,22 @@ EMAT_DN void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
 // subrun.cpp:325-350, iterative with an explicit stack in scratch
 EMAT_DN SVec<int> enumerate_descendant_branches_straddling(Ctx& c, int P, double t, int X) {
   SVec<int> out; out.n = 0;
-  // results grow up from the scratch top, the DFS stack grows down from the scratch end
-  const uint32_t lo0 = (c.sc_top + 15u) & ~15u;
-  out.p = (int*)(c.S + lo0); out.cap = 0;
-  int* stack_base = (int*)(c.S + (c.H->scratch_end & ~15u));
+  // results grow up from the bottom of a scratch span, the DFS stack grows down from its top
+  ScSpan span = sc_span(c, 512);
+  out.p = (int*)span.lo; out.cap = 0;
+  int* stack_base = (int*)span.hi;
   int sp = 0;
-  auto room = [&](int er, int es) { return (uint64_t)lo0 + (uint64_t)(out.n + er) * 4 + 16 <= (uint64_t)(c.H->scratch_end & ~15u) - (uint64_t)(sp + es) * 4; };
+  auto room = [&](int er, int es) -> bool {
+    if (span.lo + (size_t)(out.n + er) * 4 + 16 <= span.hi - (size_t)(sp + es) * 4) return true;
+    if (!span.lds) return false;
+    ScSpan big = sc_span_hbm(c);   // outgrew the LDS arena: migrate
+    if (big.lo + (size_t)(out.n + er) * 4 + 16 > big.hi - (size_t)(sp + es) * 4) return false;
+    int* no = (int*)big.lo; int* nb = (int*)big.hi;
+    for (int i = 0; i < out.n; ++i) no[i] = out.p[i];
+    for (int i = 1; i <= sp; ++i) nb[-i] = stack_base[-i];
+    span = big; out.p = no; stack_base = nb;
+    return true;
+  };
   if (!room(0, 1)) { EMAT_FAIL(c, k_part_overflow); return out; }
   stack_base[-(++sp)] = P;
   while (sp > 0 && !c.failed) {
@@ -225,7 +240,7 @@ EMAT_DN SVec<int> enumerate_descendant_branches_straddling(Ctx& c, int P, double
     }
   }
   out.cap = out.n;
-  c.sc_top = lo0 + (((uint32_t)out.n * 4u + 15u) & ~15u);
+  sc_span_commit(c, span, (uint32_t)out.n * 4u);
   return out;
 }
 
@@ -287,8 +302,10 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   const int old_G = c.N[P].parent;
   const bool pruning_changes_root = P == c.H->root;
   if (pruning_changes_root && !c.includes_run_root) return;
+  EMAT_PHASE_BEGIN();
   Graft old_graft = analyze_graft(c, X);
   peel_graft(c, old_graft);
+  EMAT_PHASE(c, 5);
   if (c.failed) return;
   const int old_min_muts = count_min_mutations(c, old_graft);
   int extra = 4;
@@ -298,6 +315,8 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   const int n_missing_at_X = iv_num_sites(missing_at_X.p, missing_at_X.n);
   const double lambda_X = c.N[X].lambda;
   SVec<Region> pre_regions = study_seed_fill(c, X, t_X, missing_at_X, limit, old_S, 0, old_deltas, c.includes_run_root);
+  EMAT_PHASE(c, 6);
+  c.H->phase_ticks[13] += pre_regions.n;
   Study pre = make_study(c, pre_regions, n_missing_at_X, lambda_X, annealing_factor, t_X, c.t_max_tip);
   if (c.failed) return;
   const int new_region = study_pick_nexus_region(c, pre);
@@ -310,14 +329,19 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   if (new_G == P) new_G = old_G;
   const double t_new_G = (new_G == k_no_node) ? k_neg_dbl_max : c.N[new_G].t;
   if (c.failed) return;
+  EMAT_PHASE(c, 7);
   if (new_t_P == t_X || new_t_P == t_new_S || new_t_P == t_new_G) { apply_graft(c, old_graft); return; }
   spr_move_topology(c, X, new_S, new_t_P);
+  EMAT_PHASE(c, 8);
   Graft new_graft = propose_new_graft(c, X);
+  EMAT_PHASE(c, 9);
   if (c.failed) return;
   EMAT_CHECK(c, c.N[X].parent == P);
   const int new_min_muts = count_min_mutations(c, new_graft);
   SVec<SdRec> new_deltas = summarize_closed_mutations(c, new_graft, extra);
   SVec<Region> post_regions = study_seed_fill(c, X, t_X, missing_at_X, limit, new_S, 0, new_deltas, c.includes_run_root);
+  EMAT_PHASE(c, 10);
+  c.H->phase_ticks[13] += post_regions.n;
   Study post = make_study(c, post_regions, n_missing_at_X, lambda_X, annealing_factor, t_X, c.t_max_tip);
   if (c.failed) return;
   const int old_region = study_find_region(post, old_S, old_t_P);
@@ -326,6 +350,7 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   const double log_alpha_n2o = study_log_alpha_in_region(c, post, old_region, old_t_P);
   EMAT_CHECK(c, new_min_muts == pre.regions.p[new_region].min_muts);
   EMAT_CHECK(c, old_min_muts == post.regions.p[old_region].min_muts);
+  EMAT_PHASE(c, 11);
   const double d_prior = coal_delta_displace_coalescence(c, old_t_P, new_t_P);
   if (c.failed) return;
   const double log_mh = (new_graft.delta_log_G - new_graft.log_alpha_mut) - (old_graft.delta_log_G - old_graft.log_alpha_mut)
@@ -341,6 +366,7 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
     spr_move_topology(c, X, old_S, old_t_P);
     apply_graft(c, old_graft);
   }
+  EMAT_PHASE(c, 12);
 }
 
 // ---- slab housekeeping ----------------------------------------------------------------------------------
@@ -354,7 +380,7 @@ EMAT_DN bool compact_heap(Ctx& c) {
     live += (((uint32_t)c.N[i].mfs.cnt * 8u) + 15u) & ~15u;
   }
   if (live > c.H->scratch_end - c.H->scratch_begin) return false;
-  uint8_t* stage = c.S + c.H->scratch_begin;
+  uint8_t* stage = c.G + c.H->scratch_begin;
   uint32_t w = 0;
   for (int i = 0; i < n; ++i) {
     ListRef* refs[3] = {&c.N[i].muts, &c.N[i].miss, &c.N[i].mfs};
@@ -394,8 +420,11 @@ EMAT_D bool mcmc_sub_iteration(Ctx& c) {
       if (!compact_heap(c) || c.H->heap_end - c.H->heap_top < reserve) { if (c.H->status == 0) c.H->status = k_part_need_space; return false; }
     }
   }
-  c.sc_top = c.H->scratch_begin;
+  sc_reset(c);
   c.tr_kind = -1.0; c.tr_node = -1.0; c.tr_acc = 0.0; c.tr_log_mh = __builtin_nan("");
+#ifdef EMAT_PROFILE_PHASES
+  long long _mv0 = clock64();
+#endif
   if (c.only_displacing_inner_nodes) inner_node_displace_move(c);
   else {
     double total_weight = 15.0 + 15.0;
@@ -406,6 +435,9 @@ EMAT_D bool mcmc_sub_iteration(Ctx& c) {
     else if (r < 30.0) branch_reform_move(c);
     else if (c.topology_moves_enabled) { if (r < 31.0) subtree_slide_move(c); else spr1_move(c); }
   }
+#ifdef EMAT_PROFILE_PHASES
+  c.H->phase_ticks[(c.tr_kind >= 3.0) ? 15 : 14] += clock64() - _mv0;
+#endif
   if (c.H->trace_len < c.H->trace_cap) {
     double* tr = (double*)(c.S + c.H->off_trace) + 4 * c.H->trace_len;
     tr[0] = c.tr_kind; tr[1] = c.tr_node; tr[2] = c.tr_acc; tr[3] = c.tr_log_mh;

@@ -58,7 +58,7 @@ struct Edit { int X; SVec<SdRec> deltas; };
 
 // Node missations <- merge(node, other) (mutations.h:315-336)
 EMAT_DN void node_merge_missations_from(Ctx& c, int dst, int other) {
-  uint32_t mark = c.sc_top;
+  ScMark mark = sc_mark(c);
   int na = (int)c.N[dst].miss.cnt, nb = (int)c.N[other].miss.cnt;
   SVec<IvRec> iv = sc_vec<IvRec>(c, na + nb + 1);
   int fa = (int)c.N[dst].mfs.cnt, fb = (int)c.N[other].mfs.cnt;
@@ -75,11 +75,11 @@ EMAT_DN void node_merge_missations_from(Ctx& c, int dst, int other) {
     list_assign<IvRec>(c, c.N[dst].miss, iv.p, iv.n);
     list_assign<FsRec>(c, c.N[dst].mfs, fs.p, fs.n);
   }
-  c.sc_top = mark;
+  sc_release(c, mark);
 }
 // factor_out_common_missations(A, B, common) (mutations.h:250-312); `common` node's lists are replaced
 EMAT_DN void node_factor_out_common(Ctx& c, int a, int b, int common) {
-  uint32_t mark = c.sc_top;
+  ScMark mark = sc_mark(c);
   int na = (int)c.N[a].miss.cnt, nb = (int)c.N[b].miss.cnt;
   SVec<IvRec> ic = sc_vec<IvRec>(c, na + nb + 1), ia = sc_vec<IvRec>(c, 2 * (na + nb) + 2), ib = sc_vec<IvRec>(c, 2 * (na + nb) + 2);
   int fa = (int)c.N[a].mfs.cnt, fb = (int)c.N[b].mfs.cnt;
@@ -101,7 +101,7 @@ EMAT_DN void node_factor_out_common(Ctx& c, int a, int b, int common) {
     list_assign<IvRec>(c, c.N[b].miss, ib.p, ib.n); list_assign<FsRec>(c, c.N[b].mfs, fcb.p, fcb.n);
     list_assign<IvRec>(c, c.N[common].miss, ic.p, ic.n); list_assign<FsRec>(c, c.N[common].mfs, fcc.p, fcc.n);
   }
-  c.sc_top = mark;
+  sc_release(c, mark);
 }
 
 EMAT_DN void edit_slide_root(Ctx& c, Edit& e, double new_t_P) {   // tree_editing.cpp:114-158
@@ -113,7 +113,7 @@ EMAT_DN void edit_slide_root(Ctx& c, Edit& e, double new_t_P) {   // tree_editin
     MutRec* mS = muts_of(c, S); int nS = nmuts(c, S);
     int last = 0; while (last < nS && !(mS[last].t > new_t_P)) ++last;
     if (last != 0) {
-      uint32_t mark = c.sc_top;
+      ScMark mark = sc_mark(c);
       SVec<SdRec> r2r = deltas_from_root_muts(c, P, last);
       for (int i = 0; i < last && !c.failed; ++i) {
         MutRec m = mS[i];
@@ -124,7 +124,7 @@ EMAT_DN void edit_slide_root(Ctx& c, Edit& e, double new_t_P) {   // tree_editin
       }
       set_root_muts_from_deltas(c, P, r2r);
       list_erase_prefix<MutRec>(c, c.N[S].muts, last);
-      c.sc_top = mark;
+      sc_release(c, mark);
     }
   }
   c.N[P].t = new_t_P;
@@ -254,7 +254,7 @@ EMAT_DN void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) {
   int GG = c.N[SS].parent;
   if (GG == P) GG = G;
   const int A = find_MRCA_of(c, G, GG);
-  uint32_t mark = c.sc_top;
+  ScMark mark = sc_mark(c);
   Edit e; e.X = X;
   int cap = nmuts(c, X) + path_mut_count(c, P) + path_mut_count(c, SS) + 8;
   e.deltas = sc_vec<SdRec>(c, cap);
@@ -301,7 +301,7 @@ EMAT_DN void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) {
       }
     }
   }
-  c.sc_top = mark;
+  sc_release(c, mark);
 }
 
 // =================================================================================================
@@ -357,7 +357,7 @@ EMAT_DN void sample_site_trajectory(Ctx& c, SVec<MutRec>& out, int l, int from, 
 }
 // spr_move.cpp:1164-1370; result appended into a fresh open-ended scratch vector (caller trims)
 EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double mu, const SVec<SdRec>& deltas) {
-  SVec<MutRec> out = sc_vec<MutRec>(c, sc_room<MutRec>(c) > 4096 ? 4096 : (sc_room<MutRec>(c) > 0 ? sc_room<MutRec>(c) : 0));
+  SVec<MutRec> out = sc_open<MutRec>(c, 4096, 4 * deltas.n + 48);
   if (c.failed) return out;
   if (deltas.n != 0) {
     KTruncPoisson ge1 = ktp_make(mu * T, 1);
@@ -386,7 +386,7 @@ EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double m
 }
 // spr_move.cpp:1372-1407
 EMAT_DN SVec<MutRec> sample_unconstrained_mutational_history(Ctx& c, int L, double T, double mu) {
-  SVec<MutRec> out = sc_vec<MutRec>(c, sc_room<MutRec>(c) > 4096 ? 4096 : (sc_room<MutRec>(c) > 0 ? sc_room<MutRec>(c) : 0));
+  SVec<MutRec> out = sc_open<MutRec>(c, 4096, 96);
   if (c.failed) return out;
   double t = 0.0;
   int guard = 0;
@@ -523,7 +523,7 @@ EMAT_DN void finish_rooty_graft_analysis(Ctx& c, Graft& g) {   // spr_move.cpp:2
   g.delta_log_G = 0.0;
   g.delta_log_G += branch_log_G(c, t_P, t_X, PX.pl_X, PX.hot_muts.p, PX.hot_muts.n);
   g.delta_log_G += branch_log_G(c, t_P, t_S, PS.pl_X, PS.hot_muts.p, PS.hot_muts.n);
-  uint32_t mark = c.sc_top;
+  ScMark mark = sc_mark(c);
   SVec<MutRec> on_PS = sc_vec<MutRec>(c, SPX.hot_muts.n), on_PX = sc_vec<MutRec>(c, SPX.hot_muts.n);
   for (int i = SPX.hot_muts.n - 1; i >= 0; --i) { const MutRec& m = SPX.hot_muts.p[i]; if (m.t < t_P) push(c, on_PS, make_mut(m.to, m.site, m.from, t_P + (t_P - m.t))); }
   for (int i = 0; i < SPX.hot_muts.n; ++i) if (SPX.hot_muts.p[i].t >= t_P) push(c, on_PX, SPX.hot_muts.p[i]);
@@ -532,7 +532,7 @@ EMAT_DN void finish_rooty_graft_analysis(Ctx& c, Graft& g) {   // spr_move.cpp:2
   for (int i = 0; i < PX.hot_muts.n; ++i) g.delta_log_G += log_pi_ratio(c, PX.hot_muts.p[i]);
   for (int i = 0; i < PS.hot_muts.n; ++i) g.delta_log_G += log_pi_ratio(c, PS.hot_muts.p[i]);
   for (int i = 0; i < on_PS.n; ++i) g.delta_log_G += log_pi_ratio(c, on_PS.p[i]);
-  c.sc_top = mark;
+  sc_release(c, mark);
   g.log_alpha_mut = 0.0;
   for (int i = 0; i < g.nbi; ++i) {
     BranchInfo& bi = g.bi[i];
@@ -544,7 +544,7 @@ EMAT_DN void peel_rooty_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:318-43
   const int X = g.X, P = c.N[X].parent, S = sibling_of(c, P, X);
   const double t_X = c.N[X].t, t_P = c.N[P].t;
   const BranchInfo& PX = g.bi[k_PX]; const BranchInfo& PS = g.bi[k_PS]; const BranchInfo& SPX = g.bi[k_SPX];
-  uint32_t mark = c.sc_top;
+  ScMark mark = sc_mark(c);
   const int nX = nmuts(c, X), nS = nmuts(c, S);
   SVec<SdRec> r2r = deltas_from_root_muts(c, P, nX + 2 * nS);
   const MutRec* mX = muts_of(c, X); const MutRec* mS = muts_of(c, S);
@@ -561,7 +561,7 @@ EMAT_DN void peel_rooty_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:318-43
   }
   set_root_muts_from_deltas(c, P, r2r);
   c.N[P].lambda = calc_lambda_at_node(c, P);
-  c.sc_top = mark;
+  sc_release(c, mark);
 }
 EMAT_DN void apply_rooty_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:433-547
   if (c.failed) return;
@@ -569,7 +569,7 @@ EMAT_DN void apply_rooty_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:433-5
   const double t_X = c.N[X].t, t_P = c.N[P].t, t_S = c.N[S].t;
   const BranchInfo& PX = g.bi[k_PX]; const BranchInfo& PS = g.bi[k_PS]; const BranchInfo& SPX = g.bi[k_SPX];
   EMAT_CHECK(c, nmuts(c, S) == 0);
-  uint32_t mark = c.sc_top;
+  ScMark mark = sc_mark(c);
   c.N[X].muts.cnt = 0;
   SVec<SdRec> r2r = deltas_from_root_muts(c, P, PX.hot_muts.n + PS.hot_muts.n + SPX.hot_muts.n);
   c.N[P].muts.cnt = 0;
@@ -594,7 +594,7 @@ EMAT_DN void apply_rooty_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:433-5
   set_root_muts_from_deltas(c, P, r2r);
   clamp_mut_times(muts_of(c, X), nmuts(c, X), t_P, t_X); clamp_mut_times(muts_of(c, S), nmuts(c, S), t_P, t_S);
   c.N[P].lambda = c.N[X].lambda - delta_lambda_across_branch(c, X);
-  c.sc_top = mark;
+  sc_release(c, mark);
 }
 
 // ---- inner grafts -----------------------------------------------------------------------------------------
@@ -738,7 +738,7 @@ EMAT_DN void peel_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:838-95
   const int X = g.X, P = c.N[X].parent, root = c.H->root;
   const double t_X = c.N[X].t, t_P = c.N[P].t;
   const BranchInfo& fin = g.bi[g.nbi - 1];
-  uint32_t mark = c.sc_top;
+  ScMark mark = sc_mark(c);
   SVec<SdRec> r2r; r2r.p = nullptr; r2r.n = r2r.cap = 0;
   if (fin.is_open) r2r = deltas_from_root_muts(c, root, path_mut_count(c, X));
   for (int i = 0; i < g.nbi && !c.failed; ++i) {
@@ -780,13 +780,13 @@ EMAT_DN void peel_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:838-95
   }
   if (fin.is_open) set_root_muts_from_deltas(c, root, r2r);
   recalc_lambda_along_hot_path(c, g);
-  c.sc_top = mark;
+  sc_release(c, mark);
 }
 EMAT_DN void apply_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:955-1069
   if (c.failed || g.nbi == 0) return;
   const int X = g.X, root = c.H->root;
   const BranchInfo& fin = g.bi[g.nbi - 1];
-  uint32_t mark = c.sc_top;
+  ScMark mark = sc_mark(c);
   c.N[X].muts.cnt = 0;
   SVec<SdRec> r2r; r2r.p = nullptr; r2r.n = r2r.cap = 0;
   if (fin.is_open) r2r = deltas_from_root_muts(c, root, fin.hot_muts.n);
@@ -820,7 +820,7 @@ EMAT_DN void apply_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:955-1
   }
   if (fin.is_open) set_root_muts_from_deltas(c, root, r2r);
   recalc_lambda_along_hot_path(c, g);
-  c.sc_top = mark;
+  sc_release(c, mark);
 }
 
 // ---- dispatch (spr_move.cpp:9-89, 549-580, 1071-1099) -------------------------------------------------------
@@ -870,18 +870,29 @@ EMAT_D double region_t_max(Ctx& c, int b, int mi) { if (b == c.H->root) return c
 // Regions grow upwards from the scratch top while the DFS work stack grows downwards from the scratch end.
 EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec>& missing_at_X, int max_muts_from_start,
                                     int init_branch, int init_mut_idx, SVec<SdRec>& deltas, bool can_change_root) {
-  SVec<Region> res; res.p = (Region*)(c.S + c.sc_top); res.n = 0; res.cap = 0;
+  SVec<Region> res; res.p = nullptr; res.n = 0; res.cap = 0;
   if (c.failed) return res;
-  const uint32_t lo0 = (c.sc_top + 15u) & ~15u;
-  res.p = (Region*)(c.S + lo0);
-  WorkItem* stack_base = (WorkItem*)(c.S + (c.H->scratch_end & ~15u));   // items live at stack_base[-1], [-2], ...
+  // local scans (the 99% case) start in the LDS arena and migrate to the HBM arena if they outgrow it
+  ScSpan span = (max_muts_from_start == 1) ? sc_span(c, 1024) : sc_span_hbm(c);
+  res.p = (Region*)span.lo;
+  WorkItem* stack_base = (WorkItem*)span.hi;   // items live at stack_base[-1], [-2], ...
   int sp = 0;
   auto room = [&](int extra_regions, int extra_items) -> bool {
-    uint64_t lo = (uint64_t)lo0 + (uint64_t)(res.n + extra_regions) * sizeof(Region);
-    uint64_t hi = (uint64_t)(c.H->scratch_end & ~15u) - (uint64_t)(sp + extra_items) * sizeof(WorkItem);
-    return lo + 16 <= hi;
+    const uint8_t* lo = span.lo + (size_t)(res.n + extra_regions) * sizeof(Region);
+    const uint8_t* hi = span.hi - (size_t)(sp + extra_items) * sizeof(WorkItem);
+    if (lo + 16 <= hi) return true;
+    if (!span.lds) return false;
+    ScSpan big = sc_span_hbm(c);
+    if (big.lo + (size_t)(res.n + extra_regions) * sizeof(Region) + 16 > big.hi - (size_t)(sp + extra_items) * sizeof(WorkItem)) return false;
+    Region* nr = (Region*)big.lo; WorkItem* nb = (WorkItem*)big.hi;
+    for (int i = 0; i < res.n; ++i) nr[i] = res.p[i];
+    for (int i = 1; i <= sp; ++i) nb[-i] = stack_base[-i];
+    span = big; res.p = nr; stack_base = nb;
+    return true;
   };
   int cur_branch = k_no_node, cur_mut_idx = -1, cur_from_start = 0;
+  int cur_size = deltas.n;
+  const bool fast = (max_muts_from_start == 1);
   auto add_forward = [&](int tb, int tmi) {
     if (!room(0, 2)) { EMAT_FAIL(c, k_part_overflow); return; }
     ++sp; stack_base[-sp].branch = cur_branch; stack_base[-sp].mut_idx = cur_mut_idx; stack_base[-sp].backtracking = 1;
@@ -895,13 +906,32 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
     // move_to_neighbor (spr_study.cpp:43-91)
     if (cur_branch != k_no_node && w.branch == cur_branch) {
       const MutRec* m = muts_of(c, cur_branch);
-      if (w.mut_idx == cur_mut_idx + 1) {
-        const MutRec& mm = m[cur_mut_idx];
-        if (!iv_contains(missing_at_X.p, missing_at_X.n, mm.site)) { sd_pop_front(c, deltas, mm.site, mm.from, mm.to); cur_from_start += w.backtracking ? -1 : +1; }
-      } else if (w.mut_idx == cur_mut_idx - 1) {
-        const MutRec& mm = m[w.mut_idx];
-        if (!iv_contains(missing_at_X.p, missing_at_X.n, mm.site)) { sd_push_front(c, deltas, mm.site, mm.from, mm.to); cur_from_start += w.backtracking ? -1 : +1; }
-      } else EMAT_FAIL(c, k_part_internal);
+      const bool down = (w.mut_idx == cur_mut_idx + 1);
+      if (!down && w.mut_idx != cur_mut_idx - 1) EMAT_FAIL(c, k_part_internal);
+      const MutRec mm = m[down ? cur_mut_idx : w.mut_idx];
+      if (!iv_contains(missing_at_X.p, missing_at_X.n, mm.site)) {
+        if (fast) {
+          // Local scan: at most one counted mutation is ever crossed inside the scope, so the size of the
+          // cur->X delta set follows from the INITIAL set: +1 if the site is new, -1 if the crossing cancels
+          // the entry, 0 if it only rewrites it (site_deltas.h:43-83).  The set itself is never modified.
+          if (!w.backtracking) {
+            if (cur_from_start == 0) {
+              const int new_from = down ? (int)mm.to : (int)mm.from;
+              const int k = sd_lower_bound(deltas.p, deltas.n, mm.site);
+              const bool present = k < deltas.n && deltas.p[k].site == mm.site;
+              cur_size = deltas.n + (present ? (new_from == (int)deltas.p[k].to ? -1 : 0) : +1);
+            }
+            cur_from_start += 1;
+          } else {
+            cur_from_start -= 1;
+            if (cur_from_start == 0) cur_size = deltas.n;
+          }
+        } else {
+          if (down) sd_pop_front(c, deltas, mm.site, mm.from, mm.to); else sd_push_front(c, deltas, mm.site, mm.from, mm.to);
+          cur_from_start += w.backtracking ? -1 : +1;
+          cur_size = deltas.n;
+        }
+      }
     }
     cur_branch = w.branch; cur_mut_idx = w.mut_idx;
     if (!w.backtracking && cur_branch != X && cur_from_start <= max_muts_from_start) {
@@ -909,7 +939,7 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
       if (!room(1, 0)) { EMAT_FAIL(c, k_part_overflow); break; }
       Region& r = res.p[res.n++];
       r.branch = cur_branch; r.mut_idx = cur_mut_idx; r.t_min = region_t_min(c, cur_branch, cur_mut_idx); r.t_max = region_t_max(c, cur_branch, cur_mut_idx);
-      r.min_muts = deltas.n; r.pad = 0; r.logW = 0.0; r.W = 0.0;
+      r.min_muts = cur_size; r.pad = 0; r.logW = 0.0; r.W = 0.0;
       c.bytes += 64 + 16;
       // seed_neighbors_except (spr_study.cpp:103-128)
       if (cur_branch != root) {
@@ -955,7 +985,7 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
     res.p[w++] = r;
   }
   res.n = w; res.cap = w;
-  c.sc_top = lo0 + (((uint32_t)w * (uint32_t)sizeof(Region) + 15u) & ~15u);
+  sc_span_commit(c, span, (uint32_t)w * (uint32_t)sizeof(Region));
   return res;
 }
 struct RootRegionParams { double f, t_S, s_min, s_max, x_min, x_max; int m; };

@@ -30,9 +30,15 @@ struct HostRng {
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
   }
-  double gaussian(double mean, double sigma) {
+  uint64_t spare = 0; bool has_spare = false;   // second 64-bit half of the last block, not yet consumed
+  uint64_t next64() {
+    if (has_spare) { has_spare = false; return spare; }
     uint32_t w[4]; philox(counter++, key, w);
-    uint64_t a = (uint64_t)w[0] | ((uint64_t)w[1] << 32), b = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+    spare = (uint64_t)w[2] | ((uint64_t)w[3] << 32); has_spare = true;
+    return (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+  }
+  double gaussian(double mean, double sigma) {
+    uint64_t a = next64(), b = next64();
     double u1 = ((double)(a >> 11) + 1.0) * 0x1.0p-53, u2 = (double)(b >> 11) * 0x1.0p-53;
     return mean + sigma * (std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586476925 * u2));
   }

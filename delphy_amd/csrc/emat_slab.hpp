@@ -99,7 +99,12 @@ struct SlabHeader {
   int64_t alg_bytes;
   int32_t fail_line;           // source line of the first failed device check (debugging aid)
   int32_t compactions;
-  uint8_t reserved[280];
+  int64_t device_ticks;        // wall_clock64() ticks (100 MHz) spent in the serial section of k_run_moves, cumulative
+  uint64_t rng_spare;          // unconsumed second half of the last Philox block
+  uint32_t rng_has_spare;
+  uint32_t pad0;
+  int64_t phase_ticks[16];     // optional phase profile (builds with -DEMAT_PROFILE_PHASES), s_memtime ticks
+  uint8_t reserved[128];
 };
 static_assert(sizeof(SlabHeader) == 512, "SlabHeader must be 512 bytes");
 

@@ -30,7 +30,7 @@ STATUS_NAMES = {
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, _LIB_NAME)
+    return os.environ.get("EMAT_LIB_PATH") or os.path.join(_HERE, _LIB_NAME)
 
 
 def build_library(force: bool = False) -> str:
@@ -69,7 +69,7 @@ class _ConfigC(C.Structure):
 
 class _PartStatsC(C.Structure):
     _fields_ = [("status", C.c_int32), ("num_nodes", C.c_int32), ("moves_done", C.c_int64), ("proposed", C.c_int64 * 5),
-                ("accepted", C.c_int64 * 5), ("algorithmic_bytes", C.c_int64), ("rng_draws", C.c_int64)]
+                ("accepted", C.c_int64 * 5), ("algorithmic_bytes", C.c_int64), ("rng_draws", C.c_int64), ("device_ticks", C.c_int64)]
 
 
 class _SynthParamsC(C.Structure):
@@ -239,7 +239,7 @@ def load_library():
         "emat_part_get_derived": [B, i32, P(dbl), P(i32), P(dbl), P(dbl)],
         "emat_part_get_coalescent": [B, i32, P(i32), P(dbl), P(dbl), P(dbl), P(dbl), P(i32), P(dbl), P(dbl)],
         "emat_part_get_stats": [B, i32, P(_PartStatsC)], "emat_part_get_trace": [B, i32, P(i32), P(dbl)],
-        "emat_last_run_ms": [B, P(dbl)],
+        "emat_last_run_ms": [B, P(dbl)], "emat_last_kernel_ms": [B, P(dbl), P(i32)],
         "emat_synth_create": [P(_SynthParamsC), P(S)], "emat_synth_get": [S, P(_FlatTreeC), P(P(C.c_uint8)), P(dbl)],
         "emat_run_create": [B, P(_FlatTreeC), P(C.c_uint8), i32, u64, P(R)], "emat_run_destroy": [R],
         "emat_run_set_num_parts": [R, i32], "emat_run_set_hky": [R, dbl, dbl, P(dbl), P(dbl)], "emat_run_set_pop_model": [R, P(_PopModelC)],
@@ -417,6 +417,11 @@ class EmatBackend:
         self._ck(self._lib.emat_last_run_ms(self._h, C.byref(ms)), "emat_last_run_ms")
         return float(ms.value)
 
+    def last_kernel_ms(self):
+        ms, n = C.c_double(), C.c_int32()
+        self._ck(self._lib.emat_last_kernel_ms(self._h, C.byref(ms), C.byref(n)), "emat_last_kernel_ms")
+        return float(ms.value), int(n.value)
+
     def totals(self):
         g, a = C.c_double(), C.c_double()
         self._ck(self._lib.emat_get_totals(self._h, C.byref(g), C.byref(a)), "emat_get_totals")
@@ -452,7 +457,7 @@ class EmatBackend:
         s = _PartStatsC()
         self._ck(self._lib.emat_part_get_stats(self._h, part, C.byref(s)), "emat_part_get_stats")
         return dict(status=s.status, num_nodes=s.num_nodes, moves_done=s.moves_done, proposed=list(s.proposed), accepted=list(s.accepted),
-                    algorithmic_bytes=s.algorithmic_bytes, rng_draws=s.rng_draws)
+                    algorithmic_bytes=s.algorithmic_bytes, rng_draws=s.rng_draws, device_ticks=s.device_ticks)
 
     def part_trace(self, part: int, cap: int) -> np.ndarray:
         n = C.c_int32(cap)

@@ -49,6 +49,8 @@ class ShardedEngine:
         self.num_local_parts = 0
         self.part_lo = self.part_hi = 0
         self.root_part = -1
+        self.topology = True
+        self.only_displace = False
 
     def close(self):
         self.backend.close()
@@ -72,7 +74,7 @@ class ShardedEngine:
         b = self.backend
         b.set_ref_sequence(ref)
         b.set_hky(sc.mu, sc.kappa, sc.pi, sc.nu_l)
-        b.set_flags(sc.t_max_tip, False, True)
+        b.set_flags(sc.t_max_tip, self.only_displace, self.topology)
         b.upload_parts(parts, incl, seeds)
         self.build_coalescent()
 

@@ -198,6 +198,7 @@ typedef struct emat_part_stats {
   int64_t accepted[5];
   int64_t algorithmic_bytes;     /* bytes the moves touched, counted with SURVEY section 8(d)'s per-record sizes */
   int64_t rng_draws;
+  int64_t device_ticks;          /* 100 MHz wall-clock ticks this part's wavefront spent running moves (cumulative) */
 } emat_part_stats;
 emat_status emat_part_get_stats(emat_backend* h, int32_t part_id, emat_part_stats* out);
 
@@ -209,6 +210,8 @@ emat_status emat_part_get_trace(emat_backend* h, int32_t part_id, int32_t* num_m
 /* Duration of the last emat_run_* launch measured with HIP events on the engine's own stream
  * (milliseconds), and the kernel's name for cross-checking against rocprofv3. */
 emat_status emat_last_run_ms(emat_backend* h, double* ms);
+/* Duration of the dominant kernel (k_run_moves, the bulk size class) inside the last pass, and how many parts it ran. */
+emat_status emat_last_kernel_ms(emat_backend* h, double* ms, int32_t* num_parts_in_kernel);
 
 #ifdef __cplusplus
 }

@@ -106,7 +106,7 @@ int orc_begin_upload(orc_engine* e, int num_parts) {
 int orc_part_upload(orc_engine* e, int part_id, const emat_flat_tree* subtree, int includes_run_root, uint64_t seed) {
   ORC_TRY
   auto pt = std::make_unique<Part>();
-  pt->rng.key = seed; pt->rng.counter = 0;
+  pt->rng.key = seed; pt->rng.counter = 0; pt->rng.spare = 0; pt->rng.has_spare = false;
   pt->subrun = std::make_unique<Subrun>(pt->rng, tree_from_flat(*subtree, e->ref), includes_run_root != 0, e->evo);
   pt->subrun->t_max_tip = e->t_max_tip;
   pt->subrun->only_displacing_inner_nodes = e->only_displacing_inner_nodes;

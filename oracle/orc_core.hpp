@@ -49,7 +49,7 @@ constexpr double k_neg_dbl_max = -std::numeric_limits<double>::max();
 // ---- counter-based RNG ------------------------------------------------------------------------
 // The reference draws from std::mt19937 through Abseil distributions (subrun.cpp:110,125,200-205;
 // spr_move.cpp:1160-1388), which cannot be reproduced on a GPU.  Oracle and HIP engine share this
-// Philox4x32-10 stream instead: one 128-bit block per draw, keyed per part, indexed by a draw
+// Philox4x32-10 stream instead: two 64-bit draws per 128-bit block, keyed per part, indexed by a block
 // counter.  Parity is therefore exact on every discrete decision given the same seed.
 struct Rng {
   uint64_t key = 0;
@@ -69,28 +69,28 @@ struct Rng {
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
   }
-  void next(uint64_t& a, uint64_t& b) {
+  // Each Philox block yields two 64-bit draws; the second half is kept for the next draw.
+  uint64_t spare = 0; bool has_spare = false;
+  uint64_t next64() {
+    if (has_spare) { has_spare = false; return spare; }
     uint32_t w[4];
     philox4x32_10(counter++, key, w);
-    a = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-    b = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+    spare = (uint64_t)w[2] | ((uint64_t)w[3] << 32); has_spare = true;
+    return (uint64_t)w[0] | ((uint64_t)w[1] << 32);
   }
   static double to_co(uint64_t a) { return (double)(a >> 11) * 0x1.0p-53; }                 // [0,1)
   static double to_oo(uint64_t a) { return ((double)(a >> 12) + 0.5) * 0x1.0p-52; }         // (0,1)
   static double to_oc(uint64_t a) { return ((double)(a >> 11) + 1.0) * 0x1.0p-53; }         // (0,1]
-  double u01_co() { uint64_t a, b; next(a, b); return to_co(a); }
-  double u01_oo() { uint64_t a, b; next(a, b); return to_oo(a); }
-  double u01_oc() { uint64_t a, b; next(a, b); return to_oc(a); }
+  double u01_co() { return to_co(next64()); }
+  double u01_oo() { return to_oo(next64()); }
+  double u01_oc() { return to_oc(next64()); }
   double uniform_co(double lo, double hi) { return lo + (hi - lo) * u01_co(); }   // absl::Uniform(lo, hi)
   double uniform_oc(double lo, double hi) { return lo + (hi - lo) * u01_oc(); }   // IntervalOpenClosed
   double uniform_oo(double lo, double hi) { return lo + (hi - lo) * u01_oo(); }   // IntervalOpenOpen
-  int uniform_int(int n) {  // [0, n)
-    uint64_t a, b; next(a, b);
-    return (int)(((unsigned __int128)a * (uint64_t)n) >> 64);
-  }
-  bool coin() { uint64_t a, b; next(a, b); return (a >> 63) != 0; }
-  double gaussian(double mean, double sigma) {  // Box-Muller on one 128-bit block
-    uint64_t a, b; next(a, b);
+  int uniform_int(int n) { return (int)(((unsigned __int128)next64() * (uint64_t)n) >> 64); }   // [0, n)
+  bool coin() { return (next64() >> 63) != 0; }
+  double gaussian(double mean, double sigma) {  // Box-Muller on two 64-bit draws
+    uint64_t a = next64(), b = next64();
     double u1 = to_oc(a), u2 = to_co(b);
     double r = std::sqrt(-2.0 * std::log(u1));
     return mean + sigma * (r * std::cos(6.283185307179586476925 * u2));

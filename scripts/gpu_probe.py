@@ -47,3 +47,94 @@ if __name__ == "__main__":
         timing("C4", 100000, 29903, 4096, 1000)
         timing("C4", 100000, 29903, 8192, 1000)
         timing("C4", 100000, 29903, 8192, 1000, use_lds=False)
+
+
+def tail_probe(nparts=8192, moves=1000):
+    """Per-part device time distribution: which waves set the kernel's duration?"""
+    from delphy_amd.sharding import ShardedEngine
+    sc = make_scenario("C4")
+    eng = ShardedEngine(sc, num_parts=nparts, seed=20261001)
+    eng.setup()
+    eng.backend.run_moves_per_part(moves); eng.backend.synchronize()
+    t0 = [eng.backend.part_stats(p)["device_ticks"] for p in range(eng.num_local_parts)]
+    eng.backend.run_moves_per_part(moves); eng.backend.synchronize(); ms = eng.backend.last_run_ms()
+    st = [eng.backend.part_stats(p) for p in range(eng.num_local_parts)]
+    ticks = np.array([s["device_ticks"] for s in st]) - np.array(t0)
+    us = ticks / 100.0
+    sizes = np.array(eng.local_sizes)
+    print("kernel %.2f ms; per-part serial time (ms): min %.2f med %.2f p90 %.2f p99 %.2f max %.2f" % (ms, us.min() / 1e3, np.median(us) / 1e3, np.percentile(us, 90) / 1e3, np.percentile(us, 99) / 1e3, us.max() / 1e3))
+    order = np.argsort(-us)[:12]
+    for i in order:
+        print("   part %5d nodes %4d root %s time %.2f ms" % (i, sizes[i], i == eng.root_part - eng.part_lo, us[i] / 1e3))
+    print("   sum of per-part times %.1f ms-waves => avg concurrency %.0f waves" % (us.sum() / 1e3, us.sum() / 1e3 / ms))
+    print("   part sizes (nodes): p50 %d p90 %d p95 %d p99 %d max %d" % tuple(np.percentile(sizes, [50, 90, 95, 99, 100])))
+    c = np.corrcoef(sizes, us)[0, 1]
+    print("   corr(size, time) = %.2f" % c)
+    eng.close()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tail":
+    tail_probe()
+
+
+def phase_probe(nparts=8192, moves=1000):
+    """Needs a library built with -DEMAT_PROFILE_PHASES; reads the phase ticks straight out of the slab headers."""
+    import ctypes as C
+    from delphy_amd.sharding import ShardedEngine
+    sc = make_scenario("C4")
+    eng = ShardedEngine(sc, num_parts=nparts, seed=20261001)
+    eng.setup()
+    eng.backend.run_moves_per_part(moves); eng.backend.synchronize()
+    lib = d.load_library()
+    buf = (C.c_int64 * 16)()
+    tot = np.zeros(16)
+    lib.emat_debug_phase_ticks.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    for p in range(eng.num_local_parts):
+        lib.emat_debug_phase_ticks(eng.backend.handle, p, buf)
+        tot += np.array(list(buf), dtype=np.float64)
+    names = ["core:analyze+peel", "core:topology", "core:propose", "(unused)", "core:coal+accept+apply", "spr1:analyze+peel", "spr1:missing+seed_fill pre", "spr1:study pre+pick",
+             "spr1:topology", "spr1:propose", "spr1:seed_fill post", "spr1:study post+alpha", "spr1:accept+apply", "regions (count)", "ALL simple moves", "ALL topology moves"]
+    total = tot[14] + tot[15]
+    for i, nme in enumerate(names):
+        print("%-28s %14.0f  %5.1f%%" % (nme, tot[i], 100 * tot[i] / total if i != 13 else 0))
+    st = eng.local_stats()
+    print("proposed", st["proposed"], "regions per study %.1f" % (tot[13] / max(1, 2 * st["proposed"][4])))
+    eng.close()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "phase":
+    phase_probe()
+
+
+def size_probe(nparts=8192, moves=1000):
+    """Phase ticks per part-size bucket (needs the -DEMAT_PROFILE_PHASES library)."""
+    import ctypes as C
+    from delphy_amd.sharding import ShardedEngine
+    sc = make_scenario("C4")
+    eng = ShardedEngine(sc, num_parts=nparts, seed=20261001)
+    eng.setup()
+    eng.backend.run_moves_per_part(moves); eng.backend.synchronize()
+    lib = d.load_library()
+    lib.emat_debug_phase_ticks.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    buf = (C.c_int64 * 16)()
+    rows = []
+    for p in range(eng.num_local_parts):
+        lib.emat_debug_phase_ticks(eng.backend.handle, p, buf)
+        st = eng.backend.part_stats(p)
+        rows.append([eng.local_sizes[p]] + list(buf) + st["proposed"] + [st["device_ticks"]])
+    a = np.array(rows, dtype=np.float64)
+    edges = [0, 15, 20, 25, 30, 40, 50, 70, 1000]
+    print("size-bucket  parts  simple_ticks/move  topo_ticks/topo_move  spr1_seedfill/spr1  regions/study  wall_ms")
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        m = (a[:, 0] >= lo) & (a[:, 0] < hi)
+        if not m.any():
+            continue
+        b = a[m]
+        nsimple = b[:, 17:20].sum(); ntopo = b[:, 20:22].sum(); nspr1 = b[:, 21].sum()
+        print("%4d-%-4d   %6d   %12.0f   %14.0f   %14.0f   %8.1f   %8.2f" % (lo, hi, m.sum(), b[:, 15].sum() / nsimple, b[:, 16].sum() / max(1, ntopo),
+              (b[:, 7].sum() + b[:, 11].sum()) / max(1, nspr1), b[:, 14].sum() / max(1, 2 * nspr1), b[:, 22].mean() / 1e5))
+    eng.close()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "size":
+    size_probe()
