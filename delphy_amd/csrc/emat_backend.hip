@@ -15,6 +15,7 @@
 #include <memory>
 #include <numeric>
 #include <string>
+#include <queue>
 #include <vector>
 
 #include "../../include/emat_backend.h"
@@ -30,7 +31,9 @@ namespace emat {
 struct KernelArgs {
   uint8_t* slabs;                 // all slabs, back to back
   const uint64_t* slab_off;       // [num_parts] byte offset of each part's slab
-  const int32_t* order;           // [num_parts] launch order -> part id (largest parts first)
+  const int32_t* order;           // [num_parts] part ids grouped by workgroup (see block_begin)
+  const int32_t* block_begin;     // [num_blocks + 1] workgroup b runs parts order[block_begin[b] .. block_begin[b+1]) one after the other
+  int64_t* part_ticks;            // [num_parts] wall-clock ticks of each part's last run (feeds the host's load balancer)
   const int32_t* ref_freqs;       // [P][4]
   EvoTable evo;
   const PopTable* pop;
@@ -97,53 +100,50 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a, uint8_t* lds
   uint8_t* lds_slabs = lds_ctx + (uint32_t)P * ctx_bytes;
   uint8_t* lds_scratch = lds_slabs + (uint32_t)P * a.lds_slab_bytes;
   const double* tables = stage_tables(a, lds_tables, lane);
-  // stage the persistent state of the wave's parts (header, nodes, cells, trace, list heap); scratch stays in HBM
-  for (int q = 0; q < P; ++q) {
-    const int idx = blockIdx.x * P + q;
-    if (idx >= a.num_parts) break;
-    uint8_t* gslab = a.slabs + a.slab_off[a.order[idx]];
-    const SlabHeader* gh = (const SlabHeader*)gslab;
-    if (a.lds_slab_bytes != 0 && gh->heap_end <= a.lds_slab_bytes) wave_copy16(lds_slabs + (uint32_t)q * a.lds_slab_bytes, gslab, gh->heap_top, lane);
-  }
-  __syncthreads();
-  const int my_idx = blockIdx.x * P + lane;
-  if (lane < P && my_idx < a.num_parts) {
-    const int part = a.order[my_idx];
-    uint8_t* gslab = a.slabs + a.slab_off[part];
-    const bool staged = a.lds_slab_bytes != 0 && ((const SlabHeader*)gslab)->heap_end <= a.lds_slab_bytes;
-    uint8_t* slab = staged ? lds_slabs + (uint32_t)lane * a.lds_slab_bytes : gslab;
-    // The per-part context lives in LDS, not in private memory: it is touched by almost every instruction.
-    dev::Ctx& c = *(dev::Ctx*)(lds_ctx + (uint32_t)lane * ctx_bytes);
-    init_ctx(c, slab, gslab, a, tables);
-    if (a.lds_scratch_bytes) { c.A = lds_scratch + (uint32_t)lane * a.lds_scratch_bytes; c.a_end = a.lds_scratch_bytes; }
-    int64_t moves = a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0);
-    const uint64_t tick0 = wall_clock64();
-    if (c.H->status == 0) {
-      for (int64_t i = 0; i < moves; ++i) if (!dev::mcmc_sub_iteration(c)) break;
+  // The workgroup walks its list of parts P at a time (P parts side by side in SIMT lanes; P = 1 by default).
+  const int list_lo = a.block_begin[blockIdx.x], list_hi = a.block_begin[blockIdx.x + 1];
+  for (int base = list_lo; base < list_hi; base += P) {
+    __syncthreads();
+    // stage the persistent state of this group's parts (header, nodes, cells, trace, list heap); scratch stays in HBM
+    for (int q = 0; q < P && base + q < list_hi; ++q) {
+      uint8_t* gslab = a.slabs + a.slab_off[a.order[base + q]];
+      const SlabHeader* gh = (const SlabHeader*)gslab;
+      if (a.lds_slab_bytes != 0 && gh->heap_end <= a.lds_slab_bytes) wave_copy16(lds_slabs + (uint32_t)q * a.lds_slab_bytes, gslab, gh->heap_top, lane);
     }
-    c.H->rng_counter = c.rng_ctr; c.H->rng_spare = c.rng_spare; c.H->rng_has_spare = c.rng_has_spare ? 1u : 0u;
-    c.H->alg_bytes += c.bytes;
-    c.H->device_ticks += (int64_t)(wall_clock64() - tick0);
-  }
-  __syncthreads();
-  for (int q = 0; q < P; ++q) {
-    const int idx = blockIdx.x * P + q;
-    if (idx >= a.num_parts) break;
-    uint8_t* gslab = a.slabs + a.slab_off[a.order[idx]];
-    if (a.lds_slab_bytes != 0 && ((const SlabHeader*)gslab)->heap_end <= a.lds_slab_bytes) {
-      const uint8_t* src = lds_slabs + (uint32_t)q * a.lds_slab_bytes;
-      wave_copy16(gslab, src, ((const SlabHeader*)src)->heap_top, lane);
+    __syncthreads();
+    if (lane < P && base + lane < list_hi) {
+      const int part = a.order[base + lane];
+      uint8_t* gslab = a.slabs + a.slab_off[part];
+      const bool staged = a.lds_slab_bytes != 0 && ((const SlabHeader*)gslab)->heap_end <= a.lds_slab_bytes;
+      uint8_t* slab = staged ? lds_slabs + (uint32_t)lane * a.lds_slab_bytes : gslab;
+      // The per-part context lives in LDS, not in private memory: it is touched by almost every instruction.
+      dev::Ctx& c = *(dev::Ctx*)(lds_ctx + (uint32_t)lane * ctx_bytes);
+      init_ctx(c, slab, gslab, a, tables);
+      if (a.lds_scratch_bytes) { c.A = lds_scratch + (uint32_t)lane * a.lds_scratch_bytes; c.a_end = a.lds_scratch_bytes; }
+      int64_t moves = a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0);
+      const uint64_t tick0 = wall_clock64();
+      if (c.H->status == 0) {
+        for (int64_t i = 0; i < moves; ++i) if (!dev::mcmc_sub_iteration(c)) break;
+      }
+      c.H->rng_counter = c.rng_ctr; c.H->rng_spare = c.rng_spare; c.H->rng_has_spare = c.rng_has_spare ? 1u : 0u;
+      c.H->alg_bytes += c.bytes;
+      const int64_t dt = (int64_t)(wall_clock64() - tick0);
+      c.H->device_ticks += dt;
+      a.part_ticks[part] = dt;
+    }
+    __syncthreads();
+    for (int q = 0; q < P && base + q < list_hi; ++q) {
+      uint8_t* gslab = a.slabs + a.slab_off[a.order[base + q]];
+      if (a.lds_slab_bytes != 0 && ((const SlabHeader*)gslab)->heap_end <= a.lds_slab_bytes) {
+        const uint8_t* src = lds_slabs + (uint32_t)q * a.lds_slab_bytes;
+        wave_copy16(gslab, src, ((const SlabHeader*)src)->heap_top, lane);
+      }
     }
   }
 }
-// Two entry points over the same body: the bulk of the parts (small LDS staging area, high occupancy) and the
-// few large parts (large staging area), launched concurrently on two streams so that the large parts, which
-// set the duration of a pass, also run out of LDS.
+// The grid is sized to what the chip holds at once (one wavefront per workgroup); every workgroup runs a
+// host-built list of parts back to back, so no wave slot idles while the longest parts finish.
 __global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves(KernelArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  run_moves_body(a, lds);
-}
-__global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves_large(KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   run_moves_body(a, lds);
 }
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves_large(K
 __global__ void __launch_bounds__(k_wave) k_recalc_derived(KernelArgs a) {
   __shared__ __attribute__((aligned(16))) double lds_tables[k_lds_tables_bytes / 8];
   const int lane = threadIdx.x;
-  const int part = a.order[blockIdx.x];
+  const int part = blockIdx.x;
   uint8_t* slab = a.slabs + a.slab_off[part];
   const double* tables = stage_tables(a, lds_tables, lane);
   __syncthreads();
@@ -246,10 +246,11 @@ struct emat_backend {
   emat_config cfg{};
   std::string last_error;
   int L = 0;
-  hipStream_t stream = nullptr, stream_large = nullptr;
-  hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_pass0 = nullptr, ev_pass1 = nullptr;
-  int num_large = 0;                // the first `num_large` entries of the launch order form the large class
-  uint32_t lds_small = 0, lds_large = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  int num_cus = 0;
+  uint32_t lds_small = 0;           // LDS staging area per part (bytes)
+  bool schedule_valid = false; int launches_since_balance = 0; int sched_blocks = 0;
   double last_run_ms = 0.0;
   // model
   std::vector<uint8_t> ref, partition_for_site;
@@ -266,7 +267,9 @@ struct emat_backend {
   int uploads_expected = 0;
   int root_part = -1;
   std::vector<uint8_t> h_slabs;
-  DevBuf<uint8_t> d_slabs; DevBuf<uint64_t> d_slab_off; DevBuf<int32_t> d_order;
+  DevBuf<uint8_t> d_slabs; DevBuf<uint64_t> d_slab_off; DevBuf<int32_t> d_order, d_block_begin; DevBuf<int64_t> d_part_ticks;
+  std::vector<double> part_cost;      // load-balancing cost of each part (measured ticks of its last run, or a size proxy)
+  bool have_measured_cost = false;
   bool slabs_on_device = false;     // device slabs are materialised
   bool host_slabs_current = false;  // h_slabs mirrors the device
   bool derived_valid = false;
@@ -274,10 +277,12 @@ struct emat_backend {
   std::vector<uint32_t> persistent_bytes;   // per part: slab size without scratch
   double cfg_heap_per_node = 64.0;  // EMAT_HEAP_PER_NODE: heap bytes per node on top of slack x content
   int cfg_parts_per_wave = 1;       // EMAT_PARTS_PER_WAVE (tuning knob)
-  uint32_t cfg_lds_scratch = 4096;  // EMAT_LDS_SCRATCH (tuning knob)
+  uint32_t cfg_lds_scratch = 0;     // EMAT_LDS_SCRATCH (tuning knob): per-part LDS scratch arena; 0 = all scratch in HBM (measured best at C4)
   int cfg_lds_pct = 90;             // EMAT_LDS_PCT (tuning knob): percentile of persistent sizes that sets the staging area
   uint32_t cfg_lds_cap = 16 * 1024; // EMAT_LDS_CAP (tuning knob): largest staging area of the bulk class
-  uint32_t cfg_lds_cap_large = 48 * 1024; // EMAT_LDS_CAP_LARGE: largest staging area of the large class
+  bool cfg_balance = true;          // EMAT_BALANCE (tuning knob): 0 = one workgroup per part, no lists
+  int cfg_sched_blocks = 0;         // EMAT_SCHED_BLOCKS (tuning knob): grid size of the balanced launch; 0 = what the chip holds at once
+  int cfg_rebalance_every = 8;      // EMAT_REBALANCE_EVERY (tuning knob): launches between schedule rebuilds from measured ticks
   bool host_only = false;           // cfg.device == -1: uploads / coalescent staging only, every launch fails with EMAT_ERR_NO_DEVICE
   std::unique_ptr<CoalBuilder> coal_builder;
 
@@ -417,7 +422,7 @@ void refresh_ref_derived(emat_backend* h) {
 
 KernelArgs make_args(emat_backend* h) {
   KernelArgs a{};
-  a.slabs = h->d_slabs.p; a.slab_off = h->d_slab_off.p; a.order = h->d_order.p; a.ref_freqs = h->d_ref_freqs.p;
+  a.slabs = h->d_slabs.p; a.slab_off = h->d_slab_off.p; a.order = h->d_order.p; a.block_begin = h->d_block_begin.p; a.part_ticks = h->d_part_ticks.p; a.ref_freqs = h->d_ref_freqs.p;
   a.evo.num_sites = h->L; a.evo.num_partitions = h->num_partitions;
   a.evo.ref_sequence = h->d_ref.p; a.evo.partition_for_site = h->d_part.p; a.evo.nu_l = h->d_nu.p; a.evo.cum_Q_l = h->d_cumQ.p;
   a.evo.mu = h->d_mu.p; a.evo.pi = h->d_pi.p; a.evo.q = h->d_q.p;
@@ -485,25 +490,22 @@ emat_status materialize(emat_backend* h) {
     H->moves_done = ph.stats.moves_done; for (int k = 0; k < 5; ++k) { H->proposed[k] = ph.stats.proposed[k]; H->accepted[k] = ph.stats.accepted[k]; }
     H->alg_bytes = ph.stats.algorithmic_bytes; H->device_ticks = ph.stats.device_ticks;
   }
-  std::vector<int32_t> order(h->parts.size());
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->persistent_bytes[a] > h->persistent_bytes[b]; });
-  {   // size classes: the bulk stages up to the `lds_pct` percentile; the rest forms the large class
+  {   // LDS staging budget: the `lds_pct` percentile of the parts' persistent sizes (larger parts run out of HBM)
     std::vector<uint32_t> v = h->persistent_bytes;
     std::sort(v.begin(), v.end());
     uint32_t small = v[std::min(v.size() - 1, (size_t)(v.size() * (size_t)h->cfg_lds_pct / 100))];
     small = std::min<uint32_t>((small + 1023u) & ~1023u, h->cfg_lds_cap);
-    uint32_t large = std::min<uint32_t>((v.back() + 1023u) & ~1023u, h->cfg_lds_cap_large);
-    int nl = 0;
-    while (nl < (int)order.size() && h->persistent_bytes[order[nl]] > small) ++nl;
-    if (!h->cfg.use_lds) { small = large = 0; nl = 0; }
-    if (large <= small) nl = 0;
-    h->num_large = nl; h->lds_small = small; h->lds_large = large;
-    if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] parts %zu persistent bytes p50 %u p90 %u p99 %u max %u | bulk LDS %u (%d parts) large LDS %u (%d parts)\n", v.size(), v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 99 / 100], v.back(), small, (int)order.size() - nl, large, nl);
+    if (!h->cfg.use_lds) small = 0;
+    h->lds_small = small;
+    if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] parts %zu persistent bytes p50 %u p90 %u p99 %u max %u | LDS staging area %u\n", v.size(), v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 99 / 100], v.back(), small);
   }
+  // first guess at each part's cost: affine in its persistent size (replaced by measured ticks after a pass)
+  h->part_cost.assign(h->parts.size(), 0.0);
+  for (size_t i = 0; i < h->parts.size(); ++i) h->part_cost[i] = 4096.0 + (double)h->persistent_bytes[i];
+  h->have_measured_cost = false; h->schedule_valid = false; h->launches_since_balance = 0;
   HIP_TRY(h->d_slabs.upload(h->h_slabs.data(), h->h_slabs.size()));
   HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
-  HIP_TRY(h->d_order.upload(order.data(), order.size()));
+  { std::vector<int64_t> z(h->parts.size(), 0); HIP_TRY(h->d_part_ticks.upload(z.data(), z.size())); }
   h->slabs_on_device = true; h->host_slabs_current = true; h->derived_valid = false;
   return EMAT_OK;
 }
@@ -519,45 +521,87 @@ emat_status launch_recalc(emat_backend* h) {
   return EMAT_OK;
 }
 
+// Deal the parts to `nblocks` workgroups: longest-processing-time-first onto the least-loaded workgroup.
+// The schedule only decides WHERE and WHEN a part's chain runs; every chain is independent (own RNG stream, own
+// slab), so results do not depend on it.
+emat_status build_schedule(emat_backend* h, int nblocks, int P) {
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  const int n = (int)h->parts.size();
+  std::vector<int32_t> order; order.reserve(n);
+  std::vector<int32_t> begin;
+  if (nblocks >= (n + P - 1) / P || P > 1 || !h->cfg_balance) {   // everything fits at once (or balancing is off): P parts per workgroup
+    std::vector<int32_t> by_cost(n);
+    std::iota(by_cost.begin(), by_cost.end(), 0);
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return h->part_cost[a] > h->part_cost[b]; });
+    order = by_cost;
+    for (int i = 0; i < n; i += P) begin.push_back(i);
+    begin.push_back(n);
+  } else {
+    std::vector<int32_t> by_cost(n);
+    std::iota(by_cost.begin(), by_cost.end(), 0);
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return h->part_cost[a] > h->part_cost[b]; });
+    std::vector<std::vector<int32_t>> lists(nblocks);
+    typedef std::pair<double, int> Load;
+    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+    for (int b = 0; b < nblocks; ++b) heap.push({0.0, b});
+    for (int part : by_cost) {
+      Load l = heap.top(); heap.pop();
+      lists[l.second].push_back(part);
+      heap.push({l.first + h->part_cost[part], l.second});
+    }
+    for (int b = 0; b < nblocks; ++b) { begin.push_back((int32_t)order.size()); order.insert(order.end(), lists[b].begin(), lists[b].end()); }
+    begin.push_back((int32_t)order.size());
+  }
+  h->sched_blocks = (int)begin.size() - 1;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(h->d_order.upload(order.data(), order.size()));
+  HIP_TRY(h->d_block_begin.upload(begin.data(), begin.size()));
+  h->schedule_valid = true; h->launches_since_balance = 0;
+  return EMAT_OK;
+}
+
 emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
   emat_status st = sync_model_to_device(h); if (st) return st;
   st = materialize(h); if (st) return st;
   if (!h->derived_valid) { st = launch_recalc(h); if (st) return st; }
-  KernelArgs a = make_args(h);
-  a.moves_per_part = per_part; a.extra_moves_part0 = extra0;
   int P = h->cfg_parts_per_wave > 0 ? h->cfg_parts_per_wave : 1;
   if (P > k_wave) P = k_wave;
-  a.parts_per_wave = P;
-  a.lds_scratch_bytes = h->cfg.use_lds ? h->cfg_lds_scratch : 0u;
+  const uint32_t lds_scratch = h->cfg.use_lds ? h->cfg_lds_scratch : 0u;
   const uint32_t ctx_bytes = (uint32_t)((sizeof(dev::Ctx) + 15) & ~15u);
-  const int n_all = (int)h->parts.size(), n_large = h->num_large, n_small = n_all - n_large;
-  auto shmem_for = [&](uint32_t slab_area) { return (size_t)k_lds_tables_bytes + (size_t)P * (ctx_bytes + slab_area + a.lds_scratch_bytes); };
-  const size_t sh_small = shmem_for(h->lds_small), sh_large = shmem_for(h->lds_large);
-  if (std::max(sh_small, sh_large) > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower parts_per_wave or disable use_lds");
-  if (sh_small > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_small));
-  if (n_large > 0 && sh_large > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves_large, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_large));
+  const size_t shmem = (size_t)k_lds_tables_bytes + (size_t)P * (ctx_bytes + h->lds_small + lds_scratch);
+  if (shmem > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower parts_per_wave or disable use_lds");
+  if (shmem > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  // (re)build the schedule: at the first launch from the size proxy, at the second from measured ticks, then every
+  // few launches as the trees drift
+  const int n = (int)h->parts.size();
+  const bool want_rebalance = h->cfg_balance && P == 1 && h->schedule_valid && h->sched_blocks < n &&
+                              (!h->have_measured_cost || h->launches_since_balance >= h->cfg_rebalance_every);
+  if (!h->schedule_valid || want_rebalance) {
+    if (h->schedule_valid) {   // previous launch's per-part ticks (waits for that launch)
+      std::vector<int64_t> ticks(n);
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(hipMemcpy(ticks.data(), h->d_part_ticks.p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost));
+      bool any = false;
+      for (int i = 0; i < n; ++i) if (ticks[i] > 0) { h->part_cost[i] = (double)ticks[i]; any = true; }
+      h->have_measured_cost = any;
+    }
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_run_moves, k_wave, shmem));
+    int nblocks = std::max(1, per_cu) * std::max(1, h->num_cus);
+    if (h->cfg_sched_blocks > 0) nblocks = h->cfg_sched_blocks;
+    st = build_schedule(h, nblocks, P); if (st) return st;
+    if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] schedule: %d parts on %d workgroups (%d per CU x %d CUs), costs %s\n", n, h->sched_blocks, per_cu, h->num_cus, h->have_measured_cost ? "measured" : "size proxy");
+  }
+  KernelArgs a = make_args(h);
+  a.moves_per_part = per_part; a.extra_moves_part0 = extra0;
+  a.parts_per_wave = P; a.lds_scratch_bytes = lds_scratch; a.lds_slab_bytes = h->lds_small;
   HIP_TRY(hipEventRecord(h->ev_start, h->stream));
-  if (n_large > 0) {   // fork: the large class runs on its own stream, concurrently with the bulk
-    HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
-    HIP_TRY(hipStreamWaitEvent(h->stream_large, h->ev_fork, 0));
-    KernelArgs b = a;
-    b.num_parts = n_large; b.lds_slab_bytes = h->lds_large;
-    hipLaunchKernelGGL(k_run_moves_large, dim3((unsigned)((n_large + P - 1) / P)), dim3(k_wave), sh_large, h->stream_large, b);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(h->ev_join, h->stream_large));
-  }
-  if (n_small > 0) {
-    KernelArgs b = a;
-    b.order = a.order + n_large; b.num_parts = n_small; b.lds_slab_bytes = h->lds_small;
-    HIP_TRY(hipEventRecord(h->ev_pass0, h->stream));
-    hipLaunchKernelGGL(k_run_moves, dim3((unsigned)((n_small + P - 1) / P)), dim3(k_wave), sh_small, h->stream, b);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(h->ev_pass1, h->stream));
-  }
-  if (n_large > 0) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  hipLaunchKernelGGL(k_run_moves, dim3((unsigned)h->sched_blocks), dim3(k_wave), shmem, h->stream, a);
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+  ++h->launches_since_balance;
   h->host_slabs_current = false;
   return EMAT_OK;
 }
@@ -588,12 +632,13 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   if (const char* e = getenv("EMAT_PARTS_PER_WAVE")) h->cfg_parts_per_wave = atoi(e);
   if (const char* e = getenv("EMAT_LDS_SCRATCH")) h->cfg_lds_scratch = (uint32_t)atoi(e) & ~15u;
   if (const char* e = getenv("EMAT_LDS_PCT")) h->cfg_lds_pct = std::max(1, std::min(100, atoi(e)));
-  if (const char* e = getenv("EMAT_LDS_CAP_LARGE")) h->cfg_lds_cap_large = (uint32_t)atoi(e) & ~1023u;
+  if (const char* e = getenv("EMAT_BALANCE")) h->cfg_balance = atoi(e) != 0;
+  if (const char* e = getenv("EMAT_SCHED_BLOCKS")) h->cfg_sched_blocks = atoi(e);
+  if (const char* e = getenv("EMAT_REBALANCE_EVERY")) h->cfg_rebalance_every = std::max(1, atoi(e));
+  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return EMAT_ERR_HIP; h->num_cus = prop.multiProcessorCount; }
   if (const char* e = getenv("EMAT_LDS_CAP")) h->cfg_lds_cap = (uint32_t)atoi(e) & ~1023u;
   if (hipStreamCreate(&h->stream) != hipSuccess) return EMAT_ERR_HIP;
-  if (hipStreamCreate(&h->stream_large) != hipSuccess) return EMAT_ERR_HIP;
-  for (hipEvent_t* e : {&h->ev_start, &h->ev_stop, &h->ev_pass0, &h->ev_pass1}) if (hipEventCreate(e) != hipSuccess) return EMAT_ERR_HIP;
-  for (hipEvent_t* e : {&h->ev_fork, &h->ev_join}) if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return EMAT_ERR_HIP;
+  for (hipEvent_t* e : {&h->ev_start, &h->ev_stop}) if (hipEventCreate(e) != hipSuccess) return EMAT_ERR_HIP;
   *out = h.release();
   return EMAT_OK;
 }
@@ -602,8 +647,7 @@ emat_status emat_backend_destroy(emat_backend* h) {
   if (h->host_only) { delete h; return EMAT_OK; }
   (void)hipSetDevice(h->cfg.device);
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-  if (h->stream_large) { (void)hipStreamSynchronize(h->stream_large); (void)hipStreamDestroy(h->stream_large); }
-  for (hipEvent_t e : {h->ev_start, h->ev_stop, h->ev_fork, h->ev_join, h->ev_pass0, h->ev_pass1}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {h->ev_start, h->ev_stop}) if (e) (void)hipEventDestroy(e);
   delete h;
   return EMAT_OK;
 }
@@ -866,16 +910,16 @@ emat_status emat_debug_phase_ticks(emat_backend* h, int32_t part_id, int64_t* ou
   for (int i = 0; i < 16; ++i) out16[i] = H->phase_ticks[i];
   return EMAT_OK;
 }
-/* Duration of the bulk-class kernel (k_run_moves) of the last pass, from HIP events around that launch on its stream. */
+/* Duration of the k_run_moves launch of the last pass, from HIP events around that launch on its stream. */
 emat_status emat_last_kernel_ms(emat_backend* h, double* ms, int32_t* num_parts_in_kernel) {
   if (!h || !ms) return EMAT_ERR_INVALID_ARGUMENT;
   if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle");
   auto set_error = [&](const std::string& s) { h->set_error(s); };
-  HIP_TRY(hipEventSynchronize(h->ev_pass1));
+  HIP_TRY(hipEventSynchronize(h->ev_stop));
   float f = 0.f;
-  HIP_TRY(hipEventElapsedTime(&f, h->ev_pass0, h->ev_pass1));
+  HIP_TRY(hipEventElapsedTime(&f, h->ev_start, h->ev_stop));
   *ms = f;
-  if (num_parts_in_kernel) *num_parts_in_kernel = (int)h->parts.size() - h->num_large;
+  if (num_parts_in_kernel) *num_parts_in_kernel = (int)h->parts.size();
   return EMAT_OK;
 }
 emat_status emat_last_run_ms(emat_backend* h, double* ms) {

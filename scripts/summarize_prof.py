@@ -1,42 +1,38 @@
-"""Summarise rocprofv3 (rocpd sqlite) outputs of scripts/profile.sh into JSON: per-kernel durations and
-per-launch PMC sums for k_run_moves.  Usage: summarize_prof.py <dir> [--launch-moves N]"""
-import glob, json, os, sqlite3, sys
+"""Summarise the rocprofv3 CSV outputs of scripts/profile.sh: per-kernel durations (kernel trace) and per-launch
+PMC sums for k_run_moves.  Writes <dir>/summary.json and <dir>/kernel_stats.csv (copy of rocprofv3's own --stats table).
+Usage: summarize_prof.py <dir>"""
+import csv, glob, json, os, shutil, sys
 out = sys.argv[1]
-res = {"kernel_ms": {}, "pmc_k_run_moves_per_launch": {}}
-
-
-def tables(con):
-    t = [r[0] for r in con.execute("select name from sqlite_master where type='table' and name like 'rocpd_kernel_dispatch%'")]
-    return t[0].replace("rocpd_kernel_dispatch", "") if t else None
-
-
-for f in sorted(glob.glob(os.path.join(out, "*", "*.db"))):
-    con = sqlite3.connect(f)
-    sfx = tables(con)
-    if sfx is None:
-        continue
-    names = {r[0]: r[1] for r in con.execute(f"select id, kernel_name from rocpd_info_kernel_symbol{sfx}")}
-    disp = list(con.execute(f"select kernel_id, start, end, event_id, private_segment_size, group_segment_size, grid_size_x, workgroup_size_x from rocpd_kernel_dispatch{sfx}"))
-    tag = os.path.basename(os.path.dirname(f))
-    if tag == "trace":
-        ks = {}
-        for kid, s, e, ev, priv, grp, gx, wx in disp:
-            n = names.get(kid, "?")
-            short = n.split("(")[0]
-            ks.setdefault(short, []).append((e - s) / 1e6)
-            res.setdefault("kernel_launch_info", {})[short] = {"scratch_bytes_per_lane": priv, "lds_bytes": grp, "grid": gx, "workgroup": wx}
-        tot = sum(sum(v) for v in ks.values())
-        res["kernel_ms"] = {k: {"calls": len(v), "total_ms": sum(v), "avg_ms": sum(v) / len(v), "min_ms": min(v), "max_ms": max(v), "pct": 100 * sum(v) / tot} for k, v in ks.items()}
-    else:
-        pmc_names = {r[0]: r[1] for r in con.execute(f"select id, name from rocpd_info_pmc{sfx}")}
-        ev_kernel = {ev: names.get(kid, "?") for kid, s, e, ev, *_ in disp}
-        acc = {}
-        for ev, pid, val in con.execute(f"select event_id, pmc_id, value from rocpd_pmc_event{sfx}"):
-            if "k_run_moves" not in ev_kernel.get(ev, ""):
-                continue
-            acc.setdefault(pmc_names.get(pid, str(pid)), {}).setdefault(ev, 0.0)
-            acc[pmc_names.get(pid, str(pid))][ev] += val
-        for name, per_ev in acc.items():
-            res["pmc_k_run_moves_per_launch"][name] = sum(per_ev.values()) / max(1, len(per_ev))
+res = {"kernel_ms": {}, "pmc_k_run_moves_per_launch": {}, "bench_line": None}
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(out, "kernel_stats.csv"))
+    res["rocprofv3_kernel_stats"] = list(csv.DictReader(open(f)))
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    ks = {}
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0]
+        ks.setdefault(name, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+        res.setdefault("kernel_launch_info", {})[name] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
+    tot = sum(sum(v) for v in ks.values())
+    res["kernel_ms"] = {k: {"calls": len(v), "total_ms": sum(v), "avg_ms": sum(v) / len(v), "min_ms": min(v), "max_ms": max(v), "pct": 100 * sum(v) / tot} for k, v in ks.items()}
+acc = {}
+for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"].split("(")[0].endswith("k_run_moves") or "k_run_movesE" in r["Kernel_Name"]:
+            acc.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+            acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+res["pmc_k_run_moves_per_launch"] = {k: sum(v.values()) / max(1, len(v)) for k, v in acc.items()}
+log = os.path.join(out, "bench_trace.log")
+if os.path.exists(log):
+    for line in open(log):
+        if line.startswith("{") and '"metric"' in line:
+            res["bench_line"] = json.loads(line)
+p = res["pmc_k_run_moves_per_launch"]
+if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide
+    # coalesced streaming reads by 2x; this kernel's reads are narrow single-lane accesses, for which no calibration
+    # exists, so the uncorrected figure is recorded and flagged as such.
+    res["hbm_bytes_per_launch"] = (p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0
+    res["hbm_bytes_note"] = "uncorrected (FETCH_SIZE + WRITE_SIZE) * 1024; narrow single-lane access pattern, gfx950 2x streaming correction not applied"
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
-print(json.dumps(res, indent=1))
+print(json.dumps({k: v for k, v in res.items() if k != "rocprofv3_kernel_stats"}, indent=1))

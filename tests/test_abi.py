@@ -1,0 +1,50 @@
+"""The C-ABI library loads and exports every symbol include/*.h declares; no compute without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import delphy_amd as d
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = []
+    for hdr in ("emat_backend.h", "emat_host.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(?:emat_status|const char\*|void)\s+(emat_\w+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(d.library_path())
+    syms = declared_symbols()
+    assert len(syms) >= 45
+    for s in syms:
+        assert hasattr(lib, s), "missing export: " + s
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(d.EmatError, match="NO_DEVICE"):
+        d.EmatBackend(1000)                      # a real handle needs a HIP device
+    b = d.EmatBackend(1000, device=-1)           # host-only handle: staging works, launches do not
+    with pytest.raises(d.EmatError):
+        b.run_moves_per_part(1)
+    b.close()
+
+
+def test_product_never_references_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "delphy_amd")):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"oracle_ffi|orc_capi|libemat_oracle|#include\s+\"[^\"]*orc_", txt):
+                    bad.append(f)
+    assert not bad, bad

@@ -1,0 +1,101 @@
+"""BASELINE.json-size runs (config C4: 100k tips) checked through size-independent properties:
+  * the incrementally maintained log-G / log-prior of every part equal a from-scratch recomputation on the device
+    (the reference's own debug invariant, Subrun::check_derived_quantities, subrun.cpp:28-56) AND the oracle's
+    from-scratch values on the downloaded trees;
+  * every sampled downloaded part passes the reference's tree-integrity asserts (phylo_tree.cpp:18-136) in the oracle;
+  * the same seed gives bit-identical results twice, and the LDS-staged and HBM-resident paths agree bit for bit;
+  * the whole cycle repartition -> moves -> reassemble through the host driver keeps the full tree valid.
+"""
+import numpy as np
+import pytest
+
+import delphy_amd as d
+from delphy_amd.scenarios import make_scenario
+from delphy_amd.sharding import ShardedEngine
+from helpers import configure, rel_close
+from oracle_ffi import OracleEngine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c4():
+    return make_scenario("C4")
+
+
+def _run(sc, use_lds, moves=300):
+    eng = ShardedEngine(sc, num_parts=8192, seed=20261001, use_lds=use_lds)
+    eng.setup()
+    eng.backend.run_moves_per_part(moves)
+    eng.backend.synchronize()
+    return eng
+
+
+def test_c4_incremental_totals_match_recomputation_and_oracle(c4):
+    eng = _run(c4, True)
+    b = eng.backend
+    st = eng.local_stats()
+    assert st["bad_parts"] == 0 and st["moves_done"] == eng.total_parts * 300
+    assert sum(st["accepted"]) > 0.05 * st["moves_done"] and st["accepted"][3] + st["accepted"][4] > 0
+    sample = list(range(0, eng.total_parts, 97)) + [eng.root_part]
+    inc = {p: b.part_derived(p, eng.local_sizes[p]) for p in sample}
+    G_inc, A_inc = b.totals()
+    b.recalc_derived()
+    G_re, A_re = b.totals()
+    assert rel_close(G_inc, G_re, 1e-9) and rel_close(A_inc, A_re, 1e-9), (G_inc, G_re, A_inc, A_re)
+    # oracle: integrity + from-scratch derived quantities of the downloaded parts
+    trees = [b.part_download(p) for p in sample]
+    orc = OracleEngine(c4.num_sites)
+    orc.set_ref_sequence(eng_ref(eng)); orc.set_hky(c4.mu, c4.kappa, c4.pi); orc.set_flags(c4.t_max_tip)
+    orc.upload_parts(trees, [p == eng.root_part for p in sample], [1] * len(sample))
+    for i, p in enumerate(sample):
+        rc, msg = orc.part_check(i)
+        assert rc == 0, "part %d: %s" % (p, msg)
+        lam_o, nm_o, G_o, _ = orc.part_derived(i, trees[i].num_nodes)
+        lam_g, nm_g, G_g, _ = inc[p]
+        assert np.array_equal(nm_o, nm_g)
+        assert rel_close(lam_g, lam_o, 1e-9) and rel_close(G_g, G_o, 1e-9), (p, G_g, G_o)
+    orc.close(); eng.close()
+
+
+def eng_ref(eng):
+    run = d.EmatRun(None, eng.sc.tree, eng.sc.ref, eng.seed)
+    run.set_num_parts(eng.num_parts_requested)
+    run.repartition()
+    _, ref = run.tree()
+    run.close()
+    return ref
+
+
+def test_c4_deterministic_and_lds_equals_hbm(c4):
+    a = _run(c4, True, 200)
+    b = _run(c4, False, 200)
+    c = _run(c4, True, 200)
+    for p in list(range(0, a.total_parts, 211)) + [a.root_part]:
+        ta, tb, tc = a.backend.part_download(p), b.backend.part_download(p), c.backend.part_download(p)
+        for f in ("parent", "child0", "child1", "t", "mut_offset", "mut_site", "mut_from", "mut_to", "mut_t", "miss_offset", "miss_start", "miss_end", "mfs_offset", "mfs_site", "mfs_state"):
+            assert np.array_equal(getattr(ta, f), getattr(tb, f)), (p, f)
+            assert np.array_equal(getattr(ta, f), getattr(tc, f)), (p, f)
+    assert a.backend.totals() == b.backend.totals() == c.backend.totals()
+    a.close(); b.close(); c.close()
+
+
+def test_run_driver_cycles_on_device():
+    sc = make_scenario("C3", num_tips=3000, num_sites=29903, uncertain_tips=0.1)
+    b = d.EmatBackend(sc.num_sites)
+    run = d.EmatRun(b, sc.tree, sc.ref, 5)
+    run.set_num_parts(128)
+    run.set_hky(sc.mu, sc.kappa, sc.pi)
+    run.set_pop_model(sc.pop)
+    run.do_mcmc_steps(3 * 128 * 500, 128 * 500)          # three repartition -> moves -> reassemble cycles
+    tree, ref = run.tree()
+    assert tree.num_nodes == sc.tree.num_nodes
+    chk = OracleEngine(sc.num_sites)
+    sc.tree, sc.ref = tree, ref
+    configure(chk, sc, ref, [tree], [True], [1], 0)
+    rc, msg = chk.part_check(0)
+    assert rc == 0, msg
+    # tips keep their dates' bounds and the tree still has the same tips
+    tips = tree.child0 == -1
+    assert np.all(tree.t[tips] >= tree.t_min[tips] - 1e-2) and np.all(tree.t[tips] <= tree.t_max[tips] + 1e-2)
+    chk.close(); run.close(); b.close()

