@@ -37,15 +37,15 @@ def parse():
     ap.add_argument("--no-topology", action="store_true", help="diagnostic: disable subtree-slide and SPR moves")
     ap.add_argument("--only-displace", action="store_true", help="diagnostic: only inner-node displacement moves")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-moves", type=int, default=2500)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the CPU baseline sample")
     return ap.parse_args()
 
 
-def cpu_baseline(sc, num_parts, seed, sample_moves, t_step):
+def cpu_baseline(sc, num_parts, seed, target_seconds, t_step):
     """The CPU restatement of Delphy's algorithm (oracle/, kind = "port") timed on this box's host cores on a
-    bounded sample of the same workload: the same parts, `sample_moves` moves per part, one thread per core
-    with the parts dealt round-robin to the threads (the reference's policy is one part per thread,
-    tools/delphy.cpp:130-132)."""
+    bounded sample of the same workload: the same parts, the same number of moves on every part, one thread per
+    core with the parts dealt round-robin to the threads (the reference's policy is one part per thread,
+    tools/delphy.cpp:130-132).  A short pilot sizes the sample to about `target_seconds` of wall time."""
     from helpers import configure, split_parts
     from oracle_ffi import OracleEngine
     cores = max(1, min(os.cpu_count() or 1, 64))
@@ -53,13 +53,20 @@ def cpu_baseline(sc, num_parts, seed, sample_moves, t_step):
     orc = OracleEngine(sc.num_sites)
     configure(orc, sc, ref, parts, incl, seeds, root_part, t_step)
     orc.recalc_derived()
+    pilot = 2000
+    t0 = time.perf_counter()
+    orc.run_moves_per_part(pilot, threads=cores)
+    rate = len(parts) * pilot / max(1e-6, time.perf_counter() - t0)
+    # the pilot runs hot in cache and over-estimates the sustained rate by about 2x: size the sample for 0.45 x target
+    sample_moves = int(min(400000, max(1000, 0.45 * target_seconds * rate / len(parts))))
     t0 = time.perf_counter()
     orc.run_moves_per_part(sample_moves, threads=cores)
     dt = time.perf_counter() - t0
     orc.close()
     return {"value": len(parts) * sample_moves / dt, "unit": "moves/s", "cores": cores, "kind": "port",
-            "sample": "same %d parts, %d moves per part (%.1f s wall on %d host threads); CPU restatement of Delphy's algorithm, not Delphy"
-                      % (len(parts), sample_moves, dt, cores)}
+            "sample": "same %d parts, %d moves per part = %.3g moves (%.1f s wall on %d host threads, after a %d-move pilot); "
+                      "CPU restatement of Delphy's algorithm (oracle/), not Delphy itself"
+                      % (len(parts), sample_moves, len(parts) * sample_moves, dt, cores, pilot)}
 
 
 def main():
@@ -139,7 +146,7 @@ def main():
 
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_base = cpu_baseline(sc, args.parts, 20261001, args.cpu_sample_moves, eng.t_step)
+        cpu_base = cpu_baseline(sc, args.parts, 20261001, args.cpu_seconds, eng.t_step)
 
     if rank == 0:
         out = {

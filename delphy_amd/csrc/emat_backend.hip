@@ -249,7 +249,14 @@ struct emat_backend {
   hipStream_t stream = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int num_cus = 0;
-  uint32_t lds_small = 0;           // LDS staging area per part (bytes)
+  // size classes: parts sorted by persistent size; class c stages up to class_lds[c] bytes per part and runs on its own stream
+  static constexpr int k_max_classes = 4;
+  hipStream_t class_stream[k_max_classes] = {nullptr, nullptr, nullptr, nullptr};   // class 0 runs on `stream`
+  hipEvent_t ev_fork = nullptr, ev_join[k_max_classes] = {nullptr, nullptr, nullptr, nullptr};
+  int num_classes = 1; int class_begin[k_max_classes + 1] = {0, 0, 0, 0, 0}; uint32_t class_lds[k_max_classes] = {0, 0, 0, 0};
+  std::vector<int> cfg_class_pct{90};                // EMAT_LDS_CLASSES (tuning knob): percentiles of persistent size that close each class; the last
+                                                     // class always extends to the largest part (its staging area is still that percentile's size)
+  uint32_t cfg_lds_max = 96 * 1024;                  // EMAT_LDS_MAX (tuning knob): largest staging area; larger parts run out of HBM
   bool schedule_valid = false; int launches_since_balance = 0; int sched_blocks = 0;
   double last_run_ms = 0.0;
   // model
@@ -278,9 +285,7 @@ struct emat_backend {
   double cfg_heap_per_node = 64.0;  // EMAT_HEAP_PER_NODE: heap bytes per node on top of slack x content
   int cfg_parts_per_wave = 1;       // EMAT_PARTS_PER_WAVE (tuning knob)
   uint32_t cfg_lds_scratch = 0;     // EMAT_LDS_SCRATCH (tuning knob): per-part LDS scratch arena; 0 = all scratch in HBM (measured best at C4)
-  int cfg_lds_pct = 90;             // EMAT_LDS_PCT (tuning knob): percentile of persistent sizes that sets the staging area
-  uint32_t cfg_lds_cap = 16 * 1024; // EMAT_LDS_CAP (tuning knob): largest staging area of the bulk class
-  bool cfg_balance = true;          // EMAT_BALANCE (tuning knob): 0 = one workgroup per part, no lists
+  bool cfg_balance = false;         // EMAT_BALANCE (tuning knob): 0 = one workgroup per part, no lists
   int cfg_sched_blocks = 0;         // EMAT_SCHED_BLOCKS (tuning knob): grid size of the balanced launch; 0 = what the chip holds at once
   int cfg_rebalance_every = 8;      // EMAT_REBALANCE_EVERY (tuning knob): launches between schedule rebuilds from measured ticks
   bool host_only = false;           // cfg.device == -1: uploads / coalescent staging only, every launch fails with EMAT_ERR_NO_DEVICE
@@ -490,14 +495,44 @@ emat_status materialize(emat_backend* h) {
     H->moves_done = ph.stats.moves_done; for (int k = 0; k < 5; ++k) { H->proposed[k] = ph.stats.proposed[k]; H->accepted[k] = ph.stats.accepted[k]; }
     H->alg_bytes = ph.stats.algorithmic_bytes; H->device_ticks = ph.stats.device_ticks;
   }
-  {   // LDS staging budget: the `lds_pct` percentile of the parts' persistent sizes (larger parts run out of HBM)
+  {   // size classes over the parts sorted by persistent size (descending): class c closes at percentile cfg_class_pct[c]
     std::vector<uint32_t> v = h->persistent_bytes;
     std::sort(v.begin(), v.end());
-    uint32_t small = v[std::min(v.size() - 1, (size_t)(v.size() * (size_t)h->cfg_lds_pct / 100))];
-    small = std::min<uint32_t>((small + 1023u) & ~1023u, h->cfg_lds_cap);
-    if (!h->cfg.use_lds) small = 0;
-    h->lds_small = small;
-    if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] parts %zu persistent bytes p50 %u p90 %u p99 %u max %u | LDS staging area %u\n", v.size(), v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 99 / 100], v.back(), small);
+    const size_t n = v.size();
+    h->num_classes = 0;
+    size_t lo = 0;   // ascending rank where the current class starts
+    std::vector<std::pair<size_t, uint32_t>> asc;   // (end rank, staging bytes), ascending sizes
+    for (size_t ci = 0; ci < h->cfg_class_pct.size(); ++ci) {
+      const int pct = h->cfg_class_pct[ci];
+      const bool last = ci + 1 == h->cfg_class_pct.size() || (int)asc.size() + 1 == emat_backend::k_max_classes;
+      size_t hi = std::min(n, (n * (size_t)pct + 99) / 100);
+      if (pct >= 100) hi = n;
+      if (hi <= lo) { if (last) break; continue; }
+      uint32_t need = (v[hi - 1] + 511u) & ~511u;
+      if (need > h->cfg_lds_max) {   // the staging area covers what fits; the rest of the class runs out of HBM
+        size_t fit = lo; while (fit < hi && v[fit] <= h->cfg_lds_max) ++fit;
+        need = fit > lo ? (v[fit - 1] + 511u) & ~511u : 0u;
+      }
+      asc.push_back({last ? n : hi, need});
+      lo = hi;
+      if (last) break;
+    }
+    if (asc.empty()) asc.push_back({n, 0u});
+    asc.back().first = n;
+    if (!h->cfg.use_lds) { asc.clear(); asc.push_back({n, 0u}); }
+    // launch order is descending size: class 0 = the largest parts
+    h->num_classes = (int)asc.size();
+    for (int c = 0; c < h->num_classes; ++c) {
+      const auto& a = asc[h->num_classes - 1 - c];
+      h->class_lds[c] = a.second;
+      h->class_begin[c + 1] = (int)(n - (h->num_classes - 1 - c > 0 ? asc[h->num_classes - 2 - c].first : 0));
+    }
+    h->class_begin[0] = 0;
+    if (getenv("EMAT_VERBOSE")) {
+      fprintf(stderr, "[emat] parts %zu persistent bytes p50 %u p90 %u p99 %u max %u | classes:", n, v[n / 2], v[n * 9 / 10], v[n * 99 / 100], v.back());
+      for (int c = 0; c < h->num_classes; ++c) fprintf(stderr, " [%d parts, LDS %u]", h->class_begin[c + 1] - h->class_begin[c], h->class_lds[c]);
+      fprintf(stderr, "\n");
+    }
   }
   // first guess at each part's cost: affine in its persistent size (replaced by measured ticks after a pass)
   h->part_cost.assign(h->parts.size(), 0.0);
@@ -529,13 +564,13 @@ emat_status build_schedule(emat_backend* h, int nblocks, int P) {
   const int n = (int)h->parts.size();
   std::vector<int32_t> order; order.reserve(n);
   std::vector<int32_t> begin;
-  if (nblocks >= (n + P - 1) / P || P > 1 || !h->cfg_balance) {   // everything fits at once (or balancing is off): P parts per workgroup
+  if (!h->cfg_balance) {   // one part per workgroup, largest first: the hardware dispatcher is the list scheduler
     std::vector<int32_t> by_cost(n);
     std::iota(by_cost.begin(), by_cost.end(), 0);
-    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return h->part_cost[a] > h->part_cost[b]; });
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return h->persistent_bytes[a] > h->persistent_bytes[b]; });
     order = by_cost;
-    for (int i = 0; i < n; i += P) begin.push_back(i);
-    begin.push_back(n);
+    if (P == 1) { for (int i = 0; i <= n; ++i) begin.push_back(i); }   // identity: list b = {order[b]}; a class launch offsets `order`
+    else { for (int i = 0; i < n; i += P) begin.push_back(i); begin.push_back(n); }
   } else {
     std::vector<int32_t> by_cost(n);
     std::iota(by_cost.begin(), by_cost.end(), 0);
@@ -568,16 +603,18 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0) {
   if (!h->derived_valid) { st = launch_recalc(h); if (st) return st; }
   int P = h->cfg_parts_per_wave > 0 ? h->cfg_parts_per_wave : 1;
   if (P > k_wave) P = k_wave;
+  const int n = (int)h->parts.size();
+  const bool lists = h->cfg_balance && P == 1;   // experimental: one launch, workgroups walk LPT-packed lists
+  const bool single = lists || P > 1;            // both experimental modes use one class: the second-largest staging area
   const uint32_t lds_scratch = h->cfg.use_lds ? h->cfg_lds_scratch : 0u;
   const uint32_t ctx_bytes = (uint32_t)((sizeof(dev::Ctx) + 15) & ~15u);
-  const size_t shmem = (size_t)k_lds_tables_bytes + (size_t)P * (ctx_bytes + h->lds_small + lds_scratch);
-  if (shmem > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower parts_per_wave or disable use_lds");
-  if (shmem > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  // (re)build the schedule: at the first launch from the size proxy, at the second from measured ticks, then every
-  // few launches as the trees drift
-  const int n = (int)h->parts.size();
-  const bool want_rebalance = h->cfg_balance && P == 1 && h->schedule_valid && h->sched_blocks < n &&
-                              (!h->have_measured_cost || h->launches_since_balance >= h->cfg_rebalance_every);
+  auto shmem_for = [&](uint32_t slab_area) { return (size_t)k_lds_tables_bytes + (size_t)P * (ctx_bytes + slab_area + lds_scratch); };
+  const uint32_t single_lds = h->class_lds[std::min(1, h->num_classes - 1)];
+  for (int c = 0; c < (single ? 1 : h->num_classes); ++c)
+    if (shmem_for(single ? single_lds : h->class_lds[c]) > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower parts_per_wave or disable use_lds");
+  // (re)build the schedule; with lists: at the first launch from the size proxy, at the second from measured ticks,
+  // then every few launches as the trees drift
+  const bool want_rebalance = lists && h->schedule_valid && (!h->have_measured_cost || h->launches_since_balance >= h->cfg_rebalance_every);
   if (!h->schedule_valid || want_rebalance) {
     if (h->schedule_valid) {   // previous launch's per-part ticks (waits for that launch)
       std::vector<int64_t> ticks(n);
@@ -587,19 +624,43 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0) {
       for (int i = 0; i < n; ++i) if (ticks[i] > 0) { h->part_cost[i] = (double)ticks[i]; any = true; }
       h->have_measured_cost = any;
     }
-    int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_run_moves, k_wave, shmem));
-    int nblocks = std::max(1, per_cu) * std::max(1, h->num_cus);
-    if (h->cfg_sched_blocks > 0) nblocks = h->cfg_sched_blocks;
+    int nblocks = n;
+    if (lists) {
+      int per_cu = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_run_moves, k_wave, shmem_for(single_lds)));
+      nblocks = std::max(1, per_cu) * std::max(1, h->num_cus);
+      if (h->cfg_sched_blocks > 0) nblocks = h->cfg_sched_blocks;
+    }
     st = build_schedule(h, nblocks, P); if (st) return st;
-    if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] schedule: %d parts on %d workgroups (%d per CU x %d CUs), costs %s\n", n, h->sched_blocks, per_cu, h->num_cus, h->have_measured_cost ? "measured" : "size proxy");
+    if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] schedule: %d parts on %d workgroups, %s\n", n, h->sched_blocks, lists ? (h->have_measured_cost ? "lists from measured costs" : "lists from size proxy") : "largest first");
   }
   KernelArgs a = make_args(h);
   a.moves_per_part = per_part; a.extra_moves_part0 = extra0;
-  a.parts_per_wave = P; a.lds_scratch_bytes = lds_scratch; a.lds_slab_bytes = h->lds_small;
+  a.parts_per_wave = P; a.lds_scratch_bytes = lds_scratch;
   HIP_TRY(hipEventRecord(h->ev_start, h->stream));
-  hipLaunchKernelGGL(k_run_moves, dim3((unsigned)h->sched_blocks), dim3(k_wave), shmem, h->stream, a);
-  HIP_TRY(hipGetLastError());
+  if (single) {
+    const size_t sh = shmem_for(single_lds);
+    if (sh > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    a.lds_slab_bytes = single_lds;
+    hipLaunchKernelGGL(k_run_moves, dim3((unsigned)h->sched_blocks), dim3(k_wave), sh, h->stream, a);
+    HIP_TRY(hipGetLastError());
+  } else {
+    // fork: every class runs on its own stream so that the classes share the chip; class 0 (largest parts) first
+    const size_t sh_max = shmem_for(*std::max_element(h->class_lds, h->class_lds + h->num_classes));
+    if (sh_max > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_max));
+    if (h->num_classes > 1) HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+    for (int c = 0; c < h->num_classes; ++c) {
+      const int lo = h->class_begin[c], cnt = h->class_begin[c + 1] - lo;
+      if (cnt <= 0) continue;
+      hipStream_t sm = c == 0 ? h->stream : h->class_stream[c];
+      if (c > 0) HIP_TRY(hipStreamWaitEvent(sm, h->ev_fork, 0));
+      KernelArgs b = a;
+      b.order = a.order + lo; b.lds_slab_bytes = h->class_lds[c];
+      hipLaunchKernelGGL(k_run_moves, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
+      HIP_TRY(hipGetLastError());
+      if (c > 0) { HIP_TRY(hipEventRecord(h->ev_join[c], sm)); HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[c], 0)); }
+    }
+  }
   HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
   ++h->launches_since_balance;
   h->host_slabs_current = false;
@@ -631,14 +692,22 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   if (const char* e = getenv("EMAT_HEAP_PER_NODE")) h->cfg_heap_per_node = atof(e);
   if (const char* e = getenv("EMAT_PARTS_PER_WAVE")) h->cfg_parts_per_wave = atoi(e);
   if (const char* e = getenv("EMAT_LDS_SCRATCH")) h->cfg_lds_scratch = (uint32_t)atoi(e) & ~15u;
-  if (const char* e = getenv("EMAT_LDS_PCT")) h->cfg_lds_pct = std::max(1, std::min(100, atoi(e)));
+  if (const char* e = getenv("EMAT_LDS_CLASSES")) {   // e.g. "60,90,99,100"
+    h->cfg_class_pct.clear();
+    for (const char* q = e; *q;) { h->cfg_class_pct.push_back(std::max(1, std::min(100, atoi(q)))); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+  }
+  if (const char* e = getenv("EMAT_LDS_MAX")) h->cfg_lds_max = (uint32_t)atoi(e) & ~511u;
   if (const char* e = getenv("EMAT_BALANCE")) h->cfg_balance = atoi(e) != 0;
   if (const char* e = getenv("EMAT_SCHED_BLOCKS")) h->cfg_sched_blocks = atoi(e);
   if (const char* e = getenv("EMAT_REBALANCE_EVERY")) h->cfg_rebalance_every = std::max(1, atoi(e));
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return EMAT_ERR_HIP; h->num_cus = prop.multiProcessorCount; }
-  if (const char* e = getenv("EMAT_LDS_CAP")) h->cfg_lds_cap = (uint32_t)atoi(e) & ~1023u;
   if (hipStreamCreate(&h->stream) != hipSuccess) return EMAT_ERR_HIP;
   for (hipEvent_t* e : {&h->ev_start, &h->ev_stop}) if (hipEventCreate(e) != hipSuccess) return EMAT_ERR_HIP;
+  if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return EMAT_ERR_HIP;
+  for (int c = 1; c < emat_backend::k_max_classes; ++c) {
+    if (hipStreamCreate(&h->class_stream[c]) != hipSuccess) return EMAT_ERR_HIP;
+    if (hipEventCreateWithFlags(&h->ev_join[c], hipEventDisableTiming) != hipSuccess) return EMAT_ERR_HIP;
+  }
   *out = h.release();
   return EMAT_OK;
 }
@@ -647,7 +716,11 @@ emat_status emat_backend_destroy(emat_backend* h) {
   if (h->host_only) { delete h; return EMAT_OK; }
   (void)hipSetDevice(h->cfg.device);
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-  for (hipEvent_t e : {h->ev_start, h->ev_stop}) if (e) (void)hipEventDestroy(e);
+  for (int c = 1; c < emat_backend::k_max_classes; ++c) {
+    if (h->class_stream[c]) { (void)hipStreamSynchronize(h->class_stream[c]); (void)hipStreamDestroy(h->class_stream[c]); }
+    if (h->ev_join[c]) (void)hipEventDestroy(h->ev_join[c]);
+  }
+  for (hipEvent_t e : {h->ev_start, h->ev_stop, h->ev_fork}) if (e) (void)hipEventDestroy(e);
   delete h;
   return EMAT_OK;
 }

@@ -20,8 +20,8 @@
 namespace emat {
 namespace dev {
 
-#define EMAT_D __device__ inline
-#define EMAT_DN __device__ __noinline__
+#define EMAT_D static __device__ inline
+#define EMAT_DN static __device__ __noinline__
 #define EMAT_DF __device__ __forceinline__
 
 constexpr double k_neg_dbl_max = -1.7976931348623157e308;

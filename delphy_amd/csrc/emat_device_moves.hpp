@@ -63,7 +63,7 @@ EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new_t, double a
   EMAT_PHASE(c, 4);
 }
 
-EMAT_D void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
+EMAT_DN void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
   begin_move(c, k_inner_node_displace);
   int node;
   { int guard = 0; do { node = pick_random_node(c); } while (is_tip(c, node) && guard++ < (1 << 26)); }
@@ -125,7 +125,7 @@ EMAT_D void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
   }
 }
 
-EMAT_D void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
+EMAT_DN void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
   begin_move(c, k_tip_displace);
   int node;
   { int guard = 0; do { node = pick_random_node(c); } while (!is_tip(c, node) && guard++ < (1 << 26)); }
@@ -187,7 +187,7 @@ EMAT_D SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) {
   return out;
 }
 
-EMAT_D void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
+EMAT_DN void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
   begin_move(c, k_branch_reform);
   if (c.H->n_nodes < 3) return;
   const int X = pick_random_node(c);

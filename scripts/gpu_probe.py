@@ -138,3 +138,28 @@ def size_probe(nparts=8192, moves=1000):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "size":
     size_probe()
+
+
+def cycle_probe(nparts=8192, moves=1000):
+    """One whole host cycle through the C++ run driver at C4: repartition (host partitioning + slab encode + H2D),
+    local moves, reassemble (D2H + decode + host gather).  Gives the PCIe- and host-inclusive rate quoted in DESIGN.md."""
+    import time
+    sc = make_scenario("C4")
+    b = d.EmatBackend(sc.num_sites)
+    run = d.EmatRun(b, sc.tree, sc.ref, 20261001)
+    run.set_num_parts(nparts)
+    run.set_hky(sc.mu, sc.kappa, sc.pi)
+    run.set_pop_model(sc.pop)
+    for cyc in range(3):
+        t0 = time.perf_counter(); run.repartition(); n, _ = run.num_parts(); run.push_params(); t1 = time.perf_counter()
+        run.run_moves(n * moves); b.synchronize(); t2 = time.perf_counter()
+        ms = b.last_run_ms()
+        run.reassemble(); t3 = time.perf_counter()
+        print("cycle %d: %d parts | repartition+upload %.1f ms | moves %.1f ms (kernel %.1f ms; first call includes slab build + H2D + recalc) | reassemble (D2H + gather) %.1f ms | "
+              "whole cycle %.1f ms => %.1f M moves/s inclusive vs %.1f M moves/s resident" % (cyc, n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, ms, (t3 - t2) * 1e3, (t3 - t0) * 1e3,
+              n * moves / (t3 - t0) / 1e6, n * moves / (ms * 1e-3) / 1e6))
+    run.close(); b.close()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "cycle":
+    cycle_probe()
