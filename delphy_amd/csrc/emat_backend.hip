@@ -22,6 +22,7 @@
 #include "emat_device_moves.hpp"
 #include "emat_host_model.hpp"
 #include "flat_tree.hpp"
+#include "host_parallel.hpp"
 
 namespace emat {
 
@@ -442,14 +443,15 @@ emat_status pull_from_device(emat_backend* h) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(h->h_slabs.data(), h->d_slabs.p, h->h_slabs.size(), hipMemcpyDeviceToHost));
-  for (auto& ph : h->parts) {
+  parallel_for((int)h->parts.size(), [&](int p) {
+    PartHost& ph = h->parts[p];
     const uint8_t* slab = h->h_slabs.data() + ph.slab_off;
     const SlabHeader* H = (const SlabHeader*)slab;
     decode_slab(ph, slab);
     ph.stats.status = H->status; ph.stats.num_nodes = H->n_nodes; ph.stats.moves_done = H->moves_done;
     for (int k = 0; k < 5; ++k) { ph.stats.proposed[k] = H->proposed[k]; ph.stats.accepted[k] = H->accepted[k]; }
     ph.stats.algorithmic_bytes = H->alg_bytes; ph.stats.rng_draws = (int64_t)H->rng_counter; ph.stats.device_ticks = H->device_ticks;
-  }
+  });
   h->host_slabs_current = true;
   return EMAT_OK;
 }
@@ -486,7 +488,7 @@ emat_status materialize(emat_backend* h) {
   }
   h->h_slabs.assign(off, 0);
   std::vector<uint64_t> offs(h->parts.size());
-  for (size_t p = 0; p < h->parts.size(); ++p) {
+  parallel_for((int)h->parts.size(), [&](int p) {
     PartHost& ph = h->parts[p];
     offs[p] = ph.slab_off;
     encode_slab(*h, ph, h->h_slabs.data() + ph.slab_off, ph.slab_bytes, geo[p].heap, geo[p].scratch, geo[p].cell_cap, trace_cap);
@@ -494,7 +496,7 @@ emat_status materialize(emat_backend* h) {
     SlabHeader* H = (SlabHeader*)(h->h_slabs.data() + ph.slab_off);
     H->moves_done = ph.stats.moves_done; for (int k = 0; k < 5; ++k) { H->proposed[k] = ph.stats.proposed[k]; H->accepted[k] = ph.stats.accepted[k]; }
     H->alg_bytes = ph.stats.algorithmic_bytes; H->device_ticks = ph.stats.device_ticks;
-  }
+  });
   {   // size classes over the parts sorted by persistent size (descending): class c closes at percentile cfg_class_pct[c]
     std::vector<uint32_t> v = h->persistent_bytes;
     std::sort(v.begin(), v.end());

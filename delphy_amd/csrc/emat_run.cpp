@@ -6,9 +6,16 @@
 // (:267-275), Run::run_local_moves (:682-693) and Run::reassemble (:195-256).  Global moves
 // (run.cpp:695-1235) are out of scope and are not here.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -17,6 +24,7 @@
 
 #include "../../include/emat_host.h"
 #include "flat_tree.hpp"
+#include "host_parallel.hpp"
 #include "synth.hpp"
 
 namespace emat {
@@ -202,26 +210,74 @@ struct RunDriver {
     model_pushed = false;   // the reference sequence (hence cum_Q) changed
   }
 
-  void build_subtrees() {   // run.cpp:131-184
-    subtrees.clear(); part_seeds.clear();
+  // State at a cut point c: the sites missing at c (union of the missations from c up to the root) and the deltas
+  // reference sequence -> sequence at c (reconstruct_missing_sites_at phylo_tree_calc.cpp:41-56, view_of_sequence_at
+  // :19-35).  The reference recomputes both by walking from every subroot to the root; here they are carried down the
+  // tree of cut points instead -- state(c) = state(nearest cut point above c) extended by the path between the two --
+  // which gives the same sets at a cost proportional to the part depth rather than the tree depth.
+  struct HFsPair { int32_t site; uint8_t from, to; };
+  struct CutState { std::vector<HIv> miss; std::vector<HFsPair> deltas; };
+  void cut_point_states(std::vector<CutState>& out) {
     const int P = (int)parts.size();
+    out.assign(P, CutState{});
+    std::unordered_map<int32_t, int> part_of_cut; part_of_cut.reserve(P * 2);
+    for (int p = 0; p < P; ++p) part_of_cut[parts[p].cut_point] = p;
+    // depth of every cut point = number of cut points strictly above it; process shallow ones first
+    std::vector<int> above(P, -1);   // part whose cut point is the nearest one above this part's cut point
+    std::vector<std::vector<int32_t>> path(P);   // nodes strictly below `above`'s cut point down to this cut point, top-down
     for (int p = 0; p < P; ++p) {
+      std::vector<int32_t> up;
+      int32_t cur = parts[p].cut_point;
+      up.push_back(cur);
+      for (cur = tree.nodes[cur].parent; cur != EMAT_NO_NODE; cur = tree.nodes[cur].parent) {
+        auto it = part_of_cut.find(cur);
+        if (it != part_of_cut.end()) { above[p] = it->second; break; }
+        up.push_back(cur);
+      }
+      path[p].assign(up.rbegin(), up.rend());
+    }
+    std::vector<int> order; order.reserve(P);
+    {   // topological order over the `above` forest
+      std::vector<std::vector<int>> below(P); std::vector<int> roots;
+      for (int p = 0; p < P; ++p) if (above[p] >= 0) below[above[p]].push_back(p); else roots.push_back(p);
+      std::vector<int> stack(roots.begin(), roots.end());
+      while (!stack.empty()) { int p = stack.back(); stack.pop_back(); order.push_back(p); for (int q : below[p]) stack.push_back(q); }
+    }
+    for (int p : order) {
+      CutState& st = out[p];
+      std::map<int32_t, std::pair<uint8_t, uint8_t>> deltas;
+      if (above[p] >= 0) {
+        const CutState& a = out[above[p]];
+        st.miss = a.miss;
+        for (const auto& d : a.deltas) deltas.emplace_hint(deltas.end(), d.site, std::make_pair(d.from, d.to));
+      }
+      for (int32_t node : path[p]) {
+        const HNode& nd = tree.nodes[node];
+        if (!nd.miss.empty()) st.miss = iv_merge(st.miss, nd.miss);
+        for (const auto& m : nd.muts) {   // forward in time: push_back_site_deltas
+          auto f = deltas.find(m.site);
+          if (f == deltas.end()) deltas[m.site] = {m.from, m.to};
+          else { if (f->second.second != m.from) throw std::runtime_error("inconsistent mutation chain above a subroot"); f->second.second = m.to; if (f->second.first == f->second.second) deltas.erase(f); }
+        }
+      }
+      st.deltas.reserve(deltas.size());
+      for (const auto& [l, d] : deltas) st.deltas.push_back(HFsPair{l, d.first, d.second});
+    }
+  }
+
+  void build_subtrees() {   // run.cpp:131-184
+    const int P = (int)parts.size();
+    subtrees.clear(); subtrees.resize(P); part_seeds.assign(P, 0);
+    std::vector<CutState> states;
+    auto tc0 = std::chrono::steady_clock::now();
+    cut_point_states(states);
+    if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat_run] cut_point_states %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
+    auto build_one = [&](int p) {
       const PartMap& pm = parts[p];
       const int n = (int)pm.orig.size();
       HTree st; st.nodes.resize(n); st.root = 0;
       const int32_t subroot = pm.cut_point;
-      // sites missing at the subroot and deltas ref -> subroot sequence (view_of_sequence_at, phylo_tree_calc.cpp:19-35)
-      std::vector<HIv> root_miss;
-      for (int cur = subroot; cur != EMAT_NO_NODE; cur = tree.nodes[cur].parent) root_miss = iv_merge(root_miss, tree.nodes[cur].miss);
-      std::map<int32_t, std::pair<uint8_t, uint8_t>> deltas;   // push_front_site_deltas walking up
-      for (int cur = subroot; cur != EMAT_NO_NODE; cur = tree.nodes[cur].parent) {
-        const auto& ms = tree.nodes[cur].muts;
-        for (auto it = ms.rbegin(); it != ms.rend(); ++it) {
-          auto f = deltas.find(it->site);
-          if (f == deltas.end()) deltas[it->site] = {it->from, it->to};
-          else { if (f->second.first != it->to) throw std::runtime_error("inconsistent mutation chain above a subroot"); f->second.first = it->from; if (f->second.first == f->second.second) deltas.erase(f); }
-        }
-      }
+      const std::vector<HIv>& root_miss = states[p].miss;
       for (int s = 0; s < n; ++s) {
         const int32_t o = pm.orig[s];
         const HNode& on = tree.nodes[o];
@@ -233,17 +289,18 @@ struct RunDriver {
         else { sn.t_min = on.t_min; sn.t_max = on.t_max; }
         if (o == subroot) {
           sn.miss = root_miss;
-          for (auto& [l, d] : deltas) if (!iv_contains(root_miss, l)) sn.muts.push_back(HMut{-std::numeric_limits<double>::max(), l, ref[l], d.second});
+          for (const auto& d : states[p].deltas) if (!iv_contains(root_miss, d.site)) sn.muts.push_back(HMut{-std::numeric_limits<double>::max(), d.site, ref[d.site], d.to});
         } else { sn.muts = on.muts; sn.miss = on.miss; sn.mfs = on.mfs; }
       }
       st.nodes[0].parent = EMAT_NO_NODE;
       // A frozen boundary "tip" whose float-rounded bounds do not bracket t would fail the t_min <= t <= t_max
       // convention by an ulp of float; the reference tolerates 1e-2 (phylo_tree.cpp:117-121).  Keep t exact.
-      subtrees.push_back(std::move(st));
+      subtrees[p] = std::move(st);
       uint64_t z = seed ^ (0x9E3779B97F4A7C15ull * (epoch + 1)) ^ ((uint64_t)p << 32 | (uint64_t)p);
       SplitMix64 sm(z);
-      part_seeds.push_back(sm.next());
-    }
+      part_seeds[p] = sm.next();
+    };
+    parallel_for(P, build_one);
   }
 
   emat_status fail(emat_status st, const std::string& m) { last_error = m; return st; }
@@ -283,17 +340,24 @@ struct RunDriver {
   emat_status upload_parts() {
     if (!backend) return EMAT_OK;
     emat_status st = bk(emat_begin_upload(backend, (int)subtrees.size())); if (st) return st;
-    for (size_t p = 0; p < subtrees.size(); ++p) {
+    std::atomic<int> bad{EMAT_OK};
+    parallel_for((int)subtrees.size(), [&](int p) {   // emat_part_upload is safe to call concurrently for distinct parts
       FlatTree f = subtrees[p].to_flat();
       emat_flat_tree v = f.view();
-      st = bk(emat_part_upload(backend, (int)p, &v, (int)p == root_part ? 1 : 0, part_seeds[p])); if (st) return st;
-    }
+      emat_status s1 = emat_part_upload(backend, p, &v, p == root_part ? 1 : 0, part_seeds[p]);
+      if (s1 != EMAT_OK) bad.store(s1);
+    });
+    if (bad.load() != EMAT_OK) return bk((emat_status)bad.load());
     st = bk(emat_end_upload(backend)); if (st) return st;
     parts_uploaded = true;
     return EMAT_OK;
   }
 
   emat_status repartition() {   // run.cpp:110-193 (+ refresh_partition_stencils :87-108)
+    const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto t0 = now(), t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0;
     try {
       if (stencils.empty() || stencil_refresh_countdown <= 0) {
         stencils.clear();
@@ -303,35 +367,46 @@ struct RunDriver {
       --stencil_refresh_countdown;
       const auto& stencil = stencils[bitgen.below((int)stencils.size())];
       part_kids.clear();
+      t1 = now();
       partition_tree(stencil);
       if (!tree.nodes[tree.root].mfs.empty()) return fail(EMAT_ERR_INTERNAL, "root missations carry from_states");
       normalize_root();
       ++epoch;
+      t2 = now();
       build_subtrees();
+      t3 = now();
     } catch (const std::exception& ex) { return fail(EMAT_ERR_INTERNAL, ex.what()); }
     parts_uploaded = false; coal_built = false;
     if (backend) {
       emat_status st;
       if (!model_pushed) { st = push_model(); if (st) return st; }
+      t4 = now();
       st = upload_parts(); if (st) return st;
+      t5 = now();
       st = build_coalescent(); if (st) return st;
     }
+    if (verbose) fprintf(stderr, "[emat_run] repartition: stencils %.1f ms | partition_tree + normalize_root %.1f ms | build_subtrees %.1f ms | push_model %.1f ms | upload_parts %.1f ms | build_coalescent %.1f ms\n",
+                         ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, now()));
     return EMAT_OK;
   }
 
   emat_status reassemble() {   // run.cpp:195-256
     try {
       if (backend && parts_uploaded) {
-        for (size_t p = 0; p < subtrees.size(); ++p) {
+        int32_t nn0, nm0, ni0, nf0;
+        emat_status st0 = bk(emat_part_get_sizes(backend, 0, &nn0, &nm0, &ni0, &nf0)); if (st0) return st0;   // one D2H of all slabs, before the threads start
+        std::atomic<int> bad{EMAT_OK};
+        parallel_for((int)subtrees.size(), [&](int p) {
           int32_t nn, nm, ni, nf;
-          emat_status st = bk(emat_part_get_sizes(backend, (int)p, &nn, &nm, &ni, &nf)); if (st) return st;
+          emat_status st = emat_part_get_sizes(backend, p, &nn, &nm, &ni, &nf); if (st) { bad.store(st); return; }
           FlatTree f; f.allocate(nn, nm, ni, nf);
           emat_flat_tree v = f.view();
-          st = bk(emat_part_download(backend, (int)p, &v)); if (st) return st;
+          st = emat_part_download(backend, p, &v); if (st) { bad.store(st); return; }
           f.root = v.root;
           emat_flat_tree v2 = f.view();
           subtrees[p] = HTree::from_view(v2);
-        }
+        });
+        if (bad.load() != EMAT_OK) return bk((emat_status)bad.load());
       }
       for (size_t p = 0; p < subtrees.size(); ++p) {
         const PartMap& pm = parts[p]; const HTree& st = subtrees[p];

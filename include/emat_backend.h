@@ -125,6 +125,8 @@ emat_status emat_begin_upload(emat_backend* h, int32_t num_parts);
 /* replaces: Subrun(bitgen, tree, includes_run_root, evo) (reference subrun.cpp:10-15).  `seed`
  * keys the part's counter-based RNG stream (the reference seeds one std::mt19937 per part,
  * run.cpp:112-114). */
+/* Thread-safety: between emat_begin_upload and emat_end_upload, emat_part_upload may be called concurrently for
+ * DISTINCT part ids; every other entry point expects one caller at a time per handle. */
 emat_status emat_part_upload(emat_backend* h, int32_t part_id, const emat_flat_tree* subtree,
                              int32_t includes_run_root, uint64_t seed);
 emat_status emat_end_upload(emat_backend* h);
