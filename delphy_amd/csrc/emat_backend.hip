@@ -19,6 +19,15 @@
 #include <vector>
 
 #include "../../include/emat_backend.h"
+// The device code is compiled twice (see emat_device_core.hpp): `dev_lds` for parts whose slab is staged in LDS,
+// `dev` for parts that run on their HBM slab (and for k_recalc_derived).
+#define EMAT_DEV_NS dev_lds
+#define EMAT_VARIANT_LDS 1
+#include "emat_device_moves.hpp"
+#undef EMAT_DEV_NS
+#undef EMAT_VARIANT_LDS
+#define EMAT_DEV_NS dev
+#define EMAT_VARIANT_LDS 0
 #include "emat_device_moves.hpp"
 #include "emat_host_model.hpp"
 #include "flat_tree.hpp"
@@ -42,13 +51,11 @@ struct KernelArgs {
   int32_t num_parts;
   uint32_t lds_slab_bytes;        // capacity of the LDS staging area (0 = never stage)
   uint32_t lds_scratch_bytes;     // size of the per-part LDS scratch arena
-  int32_t parts_per_wave;         // P: independent parts per wavefront, one lane each
   int64_t moves_per_part;
   int64_t extra_moves_part0;      // remainder of Run::run_local_moves goes to part 0 (run.cpp:683-689)
 };
 
 constexpr int k_wave = 64;
-constexpr uint32_t k_lds_tables_bytes = k_max_lds_partitions * (1 + 4 + 16) * 8;   // mu, pi, q per site partition
 
 __device__ inline void wave_copy16(uint8_t* dst, const uint8_t* src, uint32_t bytes, int lane) {
   const uint4* s = (const uint4*)src; uint4* d = (uint4*)dst;
@@ -60,7 +67,7 @@ __device__ inline double wave_sum(double x) {
 }
 
 // Fills the model pointers of a context; HKY tables come from LDS when they were staged.
-__device__ inline void init_ctx(dev::Ctx& c, uint8_t* slab, uint8_t* gslab, const KernelArgs& a, const double* lds_tables) {
+template <class CtxT> __device__ inline void init_ctx(CtxT& c, uint8_t* slab, uint8_t* gslab, const KernelArgs& a, const double* lds_tables) {
   c.S = slab; c.G = gslab; c.H = (SlabHeader*)slab; c.N = (NodeRec*)(slab + c.H->off_nodes);
   c.L = a.evo.num_sites; c.ref = a.evo.ref_sequence; c.part = a.evo.partition_for_site; c.nu = a.evo.nu_l; c.cumQ = a.evo.cum_Q_l;
   if (lds_tables) { c.mu = lds_tables; c.pi = lds_tables + k_max_lds_partitions; c.q = lds_tables + k_max_lds_partitions * 5; }
@@ -84,70 +91,60 @@ __device__ inline const double* stage_tables(const KernelArgs& a, double* lds_ta
 }
 
 // ---- the hot path: `moves` sub-iterations on every part -------------------------------------------------
-// One wavefront runs `parts_per_wave` (P) independent parts, one per lane (lanes 0..P-1), in SIMT lock-step:
-// every part is its own Markov chain with its own RNG stream, so the schedule does not change any result.
-// P = 1 keeps a whole wavefront per part; larger P trades occupancy for SIMD utilisation (lanes that take
-// the same path share its instruction issue).
-// LDS layout per workgroup: [HKY tables][P x context][P x staged slab][P x scratch arena].
+// One wavefront (= one workgroup) per part.  Every part is its own Markov chain with its own RNG stream, so the
+// launch schedule does not change any result.  The chain itself is serial and runs on lane 0; all 64 lanes move the
+// slab between HBM and LDS.  Dynamic LDS layout: [HKY tables][context][staged slab][optional scratch arena]; the
+// first three sit at compile-time offsets, which is what lets the `dev_lds` variant address them with DS instructions.
 #ifndef EMAT_WAVES_PER_EU
 #define EMAT_WAVES_PER_EU 4
 #endif
-__device__ __forceinline__ void run_moves_body(const KernelArgs& a, uint8_t* lds) {
+template <class CtxT, class Step> __device__ __forceinline__ void run_chain(CtxT& c, const KernelArgs& a, int part, SlabHeader* H, Step step) {
+  const int64_t moves = a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0);
+  const uint64_t tick0 = wall_clock64();
+  if (H->status == 0) {
+    for (int64_t i = 0; i < moves; ++i) if (!step(c)) break;
+  }
+  H->rng_counter = c.rng_ctr; H->rng_spare = c.rng_spare; H->rng_has_spare = c.rng_has_spare ? 1u : 0u;
+  H->alg_bytes += c.bytes;
+  const int64_t dt = (int64_t)(wall_clock64() - tick0);
+  H->device_ticks += dt;
+  a.part_ticks[part] = dt;
+}
+
+__device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
   const int lane = threadIdx.x;
-  const int P = a.parts_per_wave;
-  double* lds_tables = (double*)lds;
-  const uint32_t ctx_bytes = (uint32_t)((sizeof(dev::Ctx) + 15) & ~15u);
-  uint8_t* lds_ctx = lds + k_lds_tables_bytes;
-  uint8_t* lds_slabs = lds_ctx + (uint32_t)P * ctx_bytes;
-  uint8_t* lds_scratch = lds_slabs + (uint32_t)P * a.lds_slab_bytes;
-  const double* tables = stage_tables(a, lds_tables, lane);
-  // The workgroup walks its list of parts P at a time (P parts side by side in SIMT lanes; P = 1 by default).
+  double* lds_tables = (double*)emat_lds;
+  const bool tables_staged = stage_tables(a, lds_tables, lane) != nullptr;
+  uint8_t* lds_slab = emat_lds + k_lds_slab_off;
+  // the workgroup walks its list of parts (one part per workgroup unless the host packed lists)
   const int list_lo = a.block_begin[blockIdx.x], list_hi = a.block_begin[blockIdx.x + 1];
-  for (int base = list_lo; base < list_hi; base += P) {
+  for (int idx = list_lo; idx < list_hi; ++idx) {
+    const int part = a.order[idx];
+    uint8_t* gslab = a.slabs + a.slab_off[part];
+    const SlabHeader* gh = (const SlabHeader*)gslab;
     __syncthreads();
-    // stage the persistent state of this group's parts (header, nodes, cells, trace, list heap); scratch stays in HBM
-    for (int q = 0; q < P && base + q < list_hi; ++q) {
-      uint8_t* gslab = a.slabs + a.slab_off[a.order[base + q]];
-      const SlabHeader* gh = (const SlabHeader*)gslab;
-      if (a.lds_slab_bytes != 0 && gh->heap_end <= a.lds_slab_bytes) wave_copy16(lds_slabs + (uint32_t)q * a.lds_slab_bytes, gslab, gh->heap_top, lane);
-    }
+    // stage the persistent state (header, nodes, cells, trace, list heap); scratch stays in HBM
+    const bool staged = tables_staged && a.lds_slab_bytes != 0 && gh->heap_end <= a.lds_slab_bytes && gh->off_nodes == (uint32_t)sizeof(SlabHeader);
+    if (staged) wave_copy16(lds_slab, gslab, gh->heap_top, lane);
     __syncthreads();
-    if (lane < P && base + lane < list_hi) {
-      const int part = a.order[base + lane];
-      uint8_t* gslab = a.slabs + a.slab_off[part];
-      const bool staged = a.lds_slab_bytes != 0 && ((const SlabHeader*)gslab)->heap_end <= a.lds_slab_bytes;
-      uint8_t* slab = staged ? lds_slabs + (uint32_t)lane * a.lds_slab_bytes : gslab;
-      // The per-part context lives in LDS, not in private memory: it is touched by almost every instruction.
-      dev::Ctx& c = *(dev::Ctx*)(lds_ctx + (uint32_t)lane * ctx_bytes);
-      init_ctx(c, slab, gslab, a, tables);
-      if (a.lds_scratch_bytes) { c.A = lds_scratch + (uint32_t)lane * a.lds_scratch_bytes; c.a_end = a.lds_scratch_bytes; }
-      int64_t moves = a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0);
-      const uint64_t tick0 = wall_clock64();
-      if (c.H->status == 0) {
-        for (int64_t i = 0; i < moves; ++i) if (!dev::mcmc_sub_iteration(c)) break;
-      }
-      c.H->rng_counter = c.rng_ctr; c.H->rng_spare = c.rng_spare; c.H->rng_has_spare = c.rng_has_spare ? 1u : 0u;
-      c.H->alg_bytes += c.bytes;
-      const int64_t dt = (int64_t)(wall_clock64() - tick0);
-      c.H->device_ticks += dt;
-      a.part_ticks[part] = dt;
-    }
-    __syncthreads();
-    for (int q = 0; q < P && base + q < list_hi; ++q) {
-      uint8_t* gslab = a.slabs + a.slab_off[a.order[base + q]];
-      if (a.lds_slab_bytes != 0 && ((const SlabHeader*)gslab)->heap_end <= a.lds_slab_bytes) {
-        const uint8_t* src = lds_slabs + (uint32_t)q * a.lds_slab_bytes;
-        wave_copy16(gslab, src, ((const SlabHeader*)src)->heap_top, lane);
+    if (lane == 0) {
+      // The context lives in LDS, not in private memory: it is touched by almost every instruction.
+      if (staged) {
+        dev_lds::Ctx& c = *(dev_lds::Ctx*)(emat_lds + k_lds_ctx_off);
+        init_ctx(c, lds_slab, gslab, a, lds_tables);
+        if (a.lds_scratch_bytes) { c.A = lds_slab + a.lds_slab_bytes; c.a_end = a.lds_scratch_bytes; }
+        run_chain(c, a, part, (SlabHeader*)lds_slab, [](dev_lds::Ctx& cc) { return dev_lds::mcmc_sub_iteration(cc); });
+      } else {
+        dev::Ctx& c = *(dev::Ctx*)(emat_lds + k_lds_ctx_off);
+        init_ctx(c, gslab, gslab, a, tables_staged ? lds_tables : nullptr);
+        run_chain(c, a, part, (SlabHeader*)gslab, [](dev::Ctx& cc) { return dev::mcmc_sub_iteration(cc); });
       }
     }
+    __syncthreads();
+    if (staged) wave_copy16(gslab, lds_slab, ((const SlabHeader*)lds_slab)->heap_top, lane);
   }
 }
-// The grid is sized to what the chip holds at once (one wavefront per workgroup); every workgroup runs a
-// host-built list of parts back to back, so no wave slot idles while the longest parts finish.
-__global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves(KernelArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  run_moves_body(a, lds);
-}
+__global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves(KernelArgs a) { run_moves_body(a); }
 
 // ---- whole-part derived quantities (Subrun::recalc_derived_quantities, subrun.cpp:17-26) ---------------------
 // Lanes stride over the part's nodes: branch-local work (delta lambda across the branch, missing-site count,
@@ -284,7 +281,6 @@ struct emat_backend {
   uint32_t max_slab_bytes = 0;
   std::vector<uint32_t> persistent_bytes;   // per part: slab size without scratch
   double cfg_heap_per_node = 64.0;  // EMAT_HEAP_PER_NODE: heap bytes per node on top of slack x content
-  int cfg_parts_per_wave = 1;       // EMAT_PARTS_PER_WAVE (tuning knob)
   uint32_t cfg_lds_scratch = 0;     // EMAT_LDS_SCRATCH (tuning knob): per-part LDS scratch arena; 0 = all scratch in HBM (measured best at C4)
   bool cfg_balance = false;         // EMAT_BALANCE (tuning knob): 0 = one workgroup per part, no lists
   int cfg_sched_blocks = 0;         // EMAT_SCHED_BLOCKS (tuning knob): grid size of the balanced launch; 0 = what the chip holds at once
@@ -433,7 +429,7 @@ KernelArgs make_args(emat_backend* h) {
   a.evo.ref_sequence = h->d_ref.p; a.evo.partition_for_site = h->d_part.p; a.evo.nu_l = h->d_nu.p; a.evo.cum_Q_l = h->d_cumQ.p;
   a.evo.mu = h->d_mu.p; a.evo.pi = h->d_pi.p; a.evo.q = h->d_q.p;
   a.pop = h->d_pop.p; a.flags = h->flags; a.num_parts = (int)h->parts.size();
-  a.lds_slab_bytes = 0; a.lds_scratch_bytes = 0; a.parts_per_wave = 1; a.moves_per_part = 0; a.extra_moves_part0 = 0;
+  a.lds_slab_bytes = 0; a.lds_scratch_bytes = 0; a.moves_per_part = 0; a.extra_moves_part0 = 0;
   return a;
 }
 
@@ -561,7 +557,7 @@ emat_status launch_recalc(emat_backend* h) {
 // Deal the parts to `nblocks` workgroups: longest-processing-time-first onto the least-loaded workgroup.
 // The schedule only decides WHERE and WHEN a part's chain runs; every chain is independent (own RNG stream, own
 // slab), so results do not depend on it.
-emat_status build_schedule(emat_backend* h, int nblocks, int P) {
+emat_status build_schedule(emat_backend* h, int nblocks) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   const int n = (int)h->parts.size();
   std::vector<int32_t> order; order.reserve(n);
@@ -571,8 +567,7 @@ emat_status build_schedule(emat_backend* h, int nblocks, int P) {
     std::iota(by_cost.begin(), by_cost.end(), 0);
     std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return h->persistent_bytes[a] > h->persistent_bytes[b]; });
     order = by_cost;
-    if (P == 1) { for (int i = 0; i <= n; ++i) begin.push_back(i); }   // identity: list b = {order[b]}; a class launch offsets `order`
-    else { for (int i = 0; i < n; i += P) begin.push_back(i); begin.push_back(n); }
+    for (int i = 0; i <= n; ++i) begin.push_back(i);   // identity: list b = {order[b]}; a class launch offsets `order`
   } else {
     std::vector<int32_t> by_cost(n);
     std::iota(by_cost.begin(), by_cost.end(), 0);
@@ -603,17 +598,14 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0) {
   emat_status st = sync_model_to_device(h); if (st) return st;
   st = materialize(h); if (st) return st;
   if (!h->derived_valid) { st = launch_recalc(h); if (st) return st; }
-  int P = h->cfg_parts_per_wave > 0 ? h->cfg_parts_per_wave : 1;
-  if (P > k_wave) P = k_wave;
   const int n = (int)h->parts.size();
-  const bool lists = h->cfg_balance && P == 1;   // experimental: one launch, workgroups walk LPT-packed lists
-  const bool single = lists || P > 1;            // both experimental modes use one class: the second-largest staging area
+  const bool lists = h->cfg_balance;   // experimental: one launch, workgroups walk LPT-packed lists
+  const bool single = lists;           // ... with one class: the second-largest staging area
   const uint32_t lds_scratch = h->cfg.use_lds ? h->cfg_lds_scratch : 0u;
-  const uint32_t ctx_bytes = (uint32_t)((sizeof(dev::Ctx) + 15) & ~15u);
-  auto shmem_for = [&](uint32_t slab_area) { return (size_t)k_lds_tables_bytes + (size_t)P * (ctx_bytes + slab_area + lds_scratch); };
+  auto shmem_for = [&](uint32_t slab_area) { return (size_t)k_lds_slab_off + slab_area + lds_scratch; };
   const uint32_t single_lds = h->class_lds[std::min(1, h->num_classes - 1)];
   for (int c = 0; c < (single ? 1 : h->num_classes); ++c)
-    if (shmem_for(single ? single_lds : h->class_lds[c]) > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower parts_per_wave or disable use_lds");
+    if (shmem_for(single ? single_lds : h->class_lds[c]) > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower EMAT_LDS_MAX or disable use_lds");
   // (re)build the schedule; with lists: at the first launch from the size proxy, at the second from measured ticks,
   // then every few launches as the trees drift
   const bool want_rebalance = lists && h->schedule_valid && (!h->have_measured_cost || h->launches_since_balance >= h->cfg_rebalance_every);
@@ -633,12 +625,12 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0) {
       nblocks = std::max(1, per_cu) * std::max(1, h->num_cus);
       if (h->cfg_sched_blocks > 0) nblocks = h->cfg_sched_blocks;
     }
-    st = build_schedule(h, nblocks, P); if (st) return st;
+    st = build_schedule(h, nblocks); if (st) return st;
     if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] schedule: %d parts on %d workgroups, %s\n", n, h->sched_blocks, lists ? (h->have_measured_cost ? "lists from measured costs" : "lists from size proxy") : "largest first");
   }
   KernelArgs a = make_args(h);
   a.moves_per_part = per_part; a.extra_moves_part0 = extra0;
-  a.parts_per_wave = P; a.lds_scratch_bytes = lds_scratch;
+  a.lds_scratch_bytes = lds_scratch;
   HIP_TRY(hipEventRecord(h->ev_start, h->stream));
   if (single) {
     const size_t sh = shmem_for(single_lds);
@@ -692,7 +684,6 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   h->cfg = *cfg; h->L = cfg->num_sites;
   if (const char* e = getenv("EMAT_SLACK")) h->cfg.slab_slack = atof(e);
   if (const char* e = getenv("EMAT_HEAP_PER_NODE")) h->cfg_heap_per_node = atof(e);
-  if (const char* e = getenv("EMAT_PARTS_PER_WAVE")) h->cfg_parts_per_wave = atoi(e);
   if (const char* e = getenv("EMAT_LDS_SCRATCH")) h->cfg_lds_scratch = (uint32_t)atoi(e) & ~15u;
   if (const char* e = getenv("EMAT_LDS_CLASSES")) {   // e.g. "60,90,99,100"
     h->cfg_class_pct.clear();

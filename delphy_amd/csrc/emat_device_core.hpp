@@ -8,8 +8,15 @@
 //
 // This header is device code only.  It is NOT shared with oracle/ (which is an independent
 // restatement used to check it).
-#ifndef EMAT_DEVICE_CORE_HPP_
-#define EMAT_DEVICE_CORE_HPP_
+// NO include guard: this header (through emat_device_moves.hpp) is included once per code variant by
+// emat_backend.hip, with EMAT_DEV_NS naming the variant's namespace and EMAT_VARIANT_LDS selecting it:
+//   EMAT_VARIANT_LDS = 1  the part's persistent slab is staged in LDS at a fixed offset of the workgroup's dynamic LDS
+//                         block, so the slab base, header, node array and HKY tables are compile-time LDS addresses
+//                         (ds_read / ds_write with immediate offsets, 32-bit address arithmetic);
+//   EMAT_VARIANT_LDS = 0  the slab stays in HBM; base pointers are loaded from the context (generic addressing).
+#ifndef EMAT_DEV_NS
+#error "define EMAT_DEV_NS and EMAT_VARIANT_LDS before including the device headers"
+#endif
 
 #include <hip/hip_runtime.h>
 #include <cfloat>
@@ -17,12 +24,23 @@
 
 #include "emat_slab.hpp"
 
+#ifndef EMAT_DEVICE_COMMON_ONCE_
+#define EMAT_DEVICE_COMMON_ONCE_
 namespace emat {
-namespace dev {
-
+// The workgroup's dynamic LDS block: [HKY tables][context][staged slab ...][optional scratch arena]
+extern __shared__ __attribute__((aligned(16))) uint8_t emat_lds[];
+constexpr uint32_t k_lds_tables_bytes = k_max_lds_partitions * (1 + 4 + 16) * 8;   // mu, pi, q per site partition
+constexpr uint32_t k_lds_ctx_off = k_lds_tables_bytes;
+constexpr uint32_t k_lds_ctx_bytes = 384;
+constexpr uint32_t k_lds_slab_off = k_lds_ctx_off + k_lds_ctx_bytes;
+}  // namespace emat
 #define EMAT_D static __device__ inline
 #define EMAT_DN static __device__ __noinline__
-#define EMAT_DF __device__ __forceinline__
+#define EMAT_DF static __device__ __forceinline__
+#endif  // EMAT_DEVICE_COMMON_ONCE_
+
+namespace emat {
+namespace EMAT_DEV_NS {
 
 constexpr double k_neg_dbl_max = -1.7976931348623157e308;
 constexpr double k_inf = __builtin_huge_val();
@@ -63,18 +81,37 @@ struct Ctx {
   double tr_kind, tr_node, tr_acc, tr_log_mh;
 };
 
-EMAT_D void fail_at(Ctx& c, int status, int line) {
-  if (!c.failed) { c.failed = true; if (c.H->status == 0) { c.H->status = status; c.H->fail_line = line; } }
-}
-#define EMAT_FAIL(c, st) ::emat::dev::fail_at((c), (st), __LINE__)
-#define EMAT_CHECK(c, cond) do { if (!(cond)) ::emat::dev::fail_at((c), ::emat::k_part_internal, __LINE__); } while (0)
+static_assert(sizeof(Ctx) <= k_lds_ctx_bytes, "context outgrew its LDS slot");
+// Base pointers of the part's persistent state.
+#if EMAT_VARIANT_LDS
+EMAT_DF uint8_t* slab_of(const Ctx&) { return emat_lds + k_lds_slab_off; }
+EMAT_DF SlabHeader* hdr_of(const Ctx&) { return (SlabHeader*)(emat_lds + k_lds_slab_off); }
+EMAT_DF NodeRec* nodes_of(const Ctx&) { return (NodeRec*)(emat_lds + k_lds_slab_off + sizeof(SlabHeader)); }   // off_nodes == sizeof(SlabHeader), checked at launch
+EMAT_DF const double* mu_of(const Ctx&) { return (const double*)emat_lds; }
+EMAT_DF const double* pi_of(const Ctx&) { return (const double*)emat_lds + k_max_lds_partitions; }
+EMAT_DF const double* q_of(const Ctx&) { return (const double*)emat_lds + k_max_lds_partitions * 5; }
+#else
+EMAT_DF uint8_t* slab_of(const Ctx& c) { return c.S; }
+EMAT_DF SlabHeader* hdr_of(const Ctx& c) { return c.H; }
+EMAT_DF NodeRec* nodes_of(const Ctx& c) { return c.N; }
+EMAT_DF const double* mu_of(const Ctx& c) { return c.mu; }
+EMAT_DF const double* pi_of(const Ctx& c) { return c.pi; }
+EMAT_DF const double* q_of(const Ctx& c) { return c.q; }
+#endif
 
+EMAT_D void fail_at(Ctx& c, int status, int line) {
+  if (!c.failed) { c.failed = true; if (hdr_of(c)->status == 0) { hdr_of(c)->status = status; hdr_of(c)->fail_line = line; } }
+}
+#ifndef EMAT_FAIL
+#define EMAT_FAIL(c, st) fail_at((c), (st), __LINE__)
+#define EMAT_CHECK(c, cond) do { if (!(cond)) fail_at((c), ::emat::k_part_internal, __LINE__); } while (0)
 #ifdef EMAT_PROFILE_PHASES
 #define EMAT_PHASE_BEGIN() long long _ph_t0 = clock64()
-#define EMAT_PHASE(c, k) do { long long _t = clock64(); (c).H->phase_ticks[k] += _t - _ph_t0; _ph_t0 = _t; } while (0)
+#define EMAT_PHASE(c, k) do { long long _t = clock64(); hdr_of(c)->phase_ticks[k] += _t - _ph_t0; _ph_t0 = _t; } while (0)
 #else
 #define EMAT_PHASE_BEGIN() do {} while (0)
 #define EMAT_PHASE(c, k) do {} while (0)
+#endif
 #endif
 
 // ---- RNG: identical stream to the parity oracle (oracle/orc_core.hpp `Rng`) -------------------------
@@ -128,12 +165,12 @@ template <class T> struct SVec { T* p; int n; int cap; };
 struct ScMark { uint32_t a, g; };
 EMAT_D ScMark sc_mark(const Ctx& c) { ScMark m; m.a = c.a_top; m.g = c.sc_top; return m; }
 EMAT_D void sc_release(Ctx& c, ScMark m) { c.a_top = m.a; c.sc_top = m.g; }
-EMAT_D void sc_reset(Ctx& c) { c.a_top = 0; c.sc_top = c.H->scratch_begin; }
+EMAT_D void sc_reset(Ctx& c) { c.a_top = 0; c.sc_top = hdr_of(c)->scratch_begin; }
 EMAT_D bool sc_in_lds(const Ctx& c, const void* p) { return c.A != nullptr && (const uint8_t*)p >= c.A && (const uint8_t*)p < c.A + c.a_end; }
 EMAT_D uint8_t* sc_alloc(Ctx& c, uint32_t bytes) {
   uint32_t b = (bytes + 15u) & ~15u;
   if (c.a_top + b <= c.a_end) { uint8_t* p = c.A + c.a_top; c.a_top += b; return p; }
-  if (c.sc_top + b > c.H->scratch_end) { EMAT_FAIL(c, k_part_overflow); return c.G + c.H->scratch_begin; }
+  if (c.sc_top + b > hdr_of(c)->scratch_end) { EMAT_FAIL(c, k_part_overflow); return c.G + hdr_of(c)->scratch_begin; }
   uint8_t* p = c.G + c.sc_top;
   c.sc_top += b;
   return p;
@@ -143,7 +180,7 @@ template <class T> EMAT_D SVec<T> sc_vec(Ctx& c, int cap) {
   uint32_t bytes = (uint32_t)cap * (uint32_t)sizeof(T);
   uint32_t b = (bytes + 15u) & ~15u;
   if (cap >= 0 && c.a_top + b <= c.a_end) { v.p = (T*)(c.A + c.a_top); v.cap = cap; c.a_top += b; return v; }
-  if (cap < 0 || c.sc_top + b > c.H->scratch_end) { EMAT_FAIL(c, k_part_overflow); v.p = (T*)(c.G + c.H->scratch_begin); v.cap = 0; return v; }
+  if (cap < 0 || c.sc_top + b > hdr_of(c)->scratch_end) { EMAT_FAIL(c, k_part_overflow); v.p = (T*)(c.G + hdr_of(c)->scratch_begin); v.cap = 0; return v; }
   v.p = (T*)(c.G + c.sc_top); v.cap = cap; c.sc_top += b;
   return v;
 }
@@ -156,8 +193,8 @@ template <class T> EMAT_D SVec<T> sc_open(Ctx& c, int max_elems, int min_lds_ele
   int room_a = c.a_end > a0 ? (int)((c.a_end - a0) / sizeof(T)) : 0;
   if (room_a >= min_lds_elems) { v.p = (T*)(c.A + a0); v.cap = room_a < max_elems ? room_a : max_elems; c.a_top = c.a_end; return v; }
   uint32_t g0 = (c.sc_top + 15u) & ~15u;
-  int room_g = c.H->scratch_end > g0 ? (int)((c.H->scratch_end - g0) / sizeof(T)) : 0;
-  v.p = (T*)(c.G + g0); v.cap = room_g < max_elems ? room_g : max_elems; c.sc_top = c.H->scratch_end;
+  int room_g = hdr_of(c)->scratch_end > g0 ? (int)((hdr_of(c)->scratch_end - g0) / sizeof(T)) : 0;
+  v.p = (T*)(c.G + g0); v.cap = room_g < max_elems ? room_g : max_elems; c.sc_top = hdr_of(c)->scratch_end;
   if (v.cap <= 0) { v.cap = 0; EMAT_FAIL(c, k_part_overflow); }
   return v;
 }
@@ -176,13 +213,13 @@ EMAT_D ScSpan sc_span(Ctx& c, uint32_t min_lds_bytes) {
   uint32_t a0 = (c.a_top + 15u) & ~15u;
   if (c.a_end > a0 && c.a_end - a0 >= min_lds_bytes) { s.lo = c.A + a0; s.hi = c.A + (c.a_end & ~15u); s.lds = true; return s; }
   uint32_t g0 = (c.sc_top + 15u) & ~15u;
-  s.lo = c.G + g0; s.hi = c.G + (c.H->scratch_end & ~15u); s.lds = false;
+  s.lo = c.G + g0; s.hi = c.G + (hdr_of(c)->scratch_end & ~15u); s.lds = false;
   if (s.hi < s.lo) s.hi = s.lo;
   return s;
 }
 EMAT_D ScSpan sc_span_hbm(Ctx& c) {
   ScSpan s; uint32_t g0 = (c.sc_top + 15u) & ~15u;
-  s.lo = c.G + g0; s.hi = c.G + (c.H->scratch_end & ~15u); s.lds = false;
+  s.lo = c.G + g0; s.hi = c.G + (hdr_of(c)->scratch_end & ~15u); s.lds = false;
   if (s.hi < s.lo) s.hi = s.lo;
   return s;
 }
@@ -194,19 +231,19 @@ EMAT_D void sc_span_commit(Ctx& c, const ScSpan& s, uint32_t used_bytes) {
 // ---- persistent per-node lists in the slab heap ---------------------------------------------------------
 EMAT_D uint32_t heap_alloc(Ctx& c, uint32_t bytes) {
   uint32_t b = (bytes + 15u) & ~15u;
-  if (c.H->heap_top + b > c.H->heap_end) { EMAT_FAIL(c, k_part_overflow); return c.H->heap_begin; }
-  uint32_t off = c.H->heap_top;
-  c.H->heap_top += b;
+  if (hdr_of(c)->heap_top + b > hdr_of(c)->heap_end) { EMAT_FAIL(c, k_part_overflow); return hdr_of(c)->heap_begin; }
+  uint32_t off = hdr_of(c)->heap_top;
+  hdr_of(c)->heap_top += b;
   return off;
 }
-template <class T> EMAT_D T* list_ptr(Ctx& c, const ListRef& r) { return (T*)(c.S + r.off); }
+template <class T> EMAT_D T* list_ptr(Ctx& c, const ListRef& r) { return (T*)(slab_of(c) + r.off); }
 template <class T> EMAT_D void list_reserve(Ctx& c, ListRef& r, int want) {
   if (want <= (int)r.cap) return;
   int nc = (int)r.cap * 2; if (nc < want) nc = want; if (nc < 4) nc = 4;
   if (nc > 65535) { if (want > 65535) { EMAT_FAIL(c, k_part_overflow); return; } nc = 65535; }
   uint32_t off = heap_alloc(c, (uint32_t)nc * (uint32_t)sizeof(T));
   if (c.failed) return;
-  T* dst = (T*)(c.S + off); const T* src = (const T*)(c.S + r.off);
+  T* dst = (T*)(slab_of(c) + off); const T* src = (const T*)(slab_of(c) + r.off);
   for (int i = 0; i < (int)r.cnt; ++i) dst[i] = src[i];
   r.off = off; r.cap = (uint16_t)nc;
 }
@@ -229,14 +266,14 @@ template <class T> EMAT_D void list_erase_prefix(Ctx& c, ListRef& r, int k) {
 }
 EMAT_D void swap_lists(ListRef& a, ListRef& b) { ListRef t = a; a = b; b = t; }
 
-EMAT_D MutRec* muts_of(Ctx& c, int n) { return (MutRec*)(c.S + c.N[n].muts.off); }
-EMAT_D IvRec* miss_of(Ctx& c, int n) { return (IvRec*)(c.S + c.N[n].miss.off); }
-EMAT_D FsRec* mfs_of(Ctx& c, int n) { return (FsRec*)(c.S + c.N[n].mfs.off); }
-EMAT_D int nmuts(const Ctx& c, int n) { return (int)c.N[n].muts.cnt; }
-EMAT_D bool is_tip(const Ctx& c, int n) { return c.N[n].child0 == k_no_node; }
+EMAT_D MutRec* muts_of(Ctx& c, int n) { return (MutRec*)(slab_of(c) + nodes_of(c)[n].muts.off); }
+EMAT_D IvRec* miss_of(Ctx& c, int n) { return (IvRec*)(slab_of(c) + nodes_of(c)[n].miss.off); }
+EMAT_D FsRec* mfs_of(Ctx& c, int n) { return (FsRec*)(slab_of(c) + nodes_of(c)[n].mfs.off); }
+EMAT_D int nmuts(const Ctx& c, int n) { return (int)nodes_of(c)[n].muts.cnt; }
+EMAT_D bool is_tip(const Ctx& c, int n) { return nodes_of(c)[n].child0 == k_no_node; }
 EMAT_D int sibling_of(Ctx& c, int parent, int x) {
-  EMAT_CHECK(c, x == c.N[parent].child0 || x == c.N[parent].child1);
-  return x == c.N[parent].child0 ? c.N[parent].child1 : c.N[parent].child0;
+  EMAT_CHECK(c, x == nodes_of(c)[parent].child0 || x == nodes_of(c)[parent].child1);
+  return x == nodes_of(c)[parent].child0 ? nodes_of(c)[parent].child1 : nodes_of(c)[parent].child0;
 }
 EMAT_D MutRec make_mut(uint8_t from, int site, uint8_t to, double t) { MutRec m; m.t = t; m.site = site; m.from = from; m.to = to; m.pad = 0; return m; }
 EMAT_D bool mut_less(const MutRec& a, const MutRec& b) { return a.t < b.t || (a.t == b.t && a.site < b.site); }   // mutations.h:41-43
@@ -249,12 +286,12 @@ EMAT_D void clamp_mut_times(MutRec* p, int n, double lo, double hi) {   // mutat
 }
 
 // ---- evolution model accessors (evo_model.h:35-47) ----------------------------------------------------------
-EMAT_D double mu_nu(const Ctx& c, int l) { return c.mu[c.part[l]] * c.nu[l]; }
-EMAT_D double q_a(const Ctx& c, int l, int a) { return -c.q[c.part[l] * 16 + a * 5]; }
-EMAT_D double q_ab(const Ctx& c, int l, int a, int b) { return c.q[c.part[l] * 16 + a * 4 + b]; }
-EMAT_D double pi_a(const Ctx& c, int l, int a) { return c.pi[c.part[l] * 4 + a]; }
+EMAT_D double mu_nu(const Ctx& c, int l) { return mu_of(c)[c.part[l]] * c.nu[l]; }
+EMAT_D double q_a(const Ctx& c, int l, int a) { return -q_of(c)[c.part[l] * 16 + a * 5]; }
+EMAT_D double q_ab(const Ctx& c, int l, int a, int b) { return q_of(c)[c.part[l] * 16 + a * 4 + b]; }
+EMAT_D double pi_a(const Ctx& c, int l, int a) { return pi_of(c)[c.part[l] * 4 + a]; }
 // mu nu (-q_minus + q_plus)
-EMAT_D double dq(const Ctx& c, int l, int minus, int plus) { return c.mu[c.part[l]] * c.nu[l] * (-q_a(c, l, minus) + q_a(c, l, plus)); }
+EMAT_D double dq(const Ctx& c, int l, int minus, int plus) { return mu_of(c)[c.part[l]] * c.nu[l] * (-q_a(c, l, minus) + q_a(c, l, plus)); }
 
 // ---- interval-set algebra on raw sorted arrays (interval_set.h:130-138, 238-500) ---------------------------
 EMAT_D bool iv_contains(const IvRec* v, int n, int l) {
@@ -337,14 +374,14 @@ EMAT_D SVec<IvRec> iv_copy_sc(Ctx& c, const IvRec* A, int nA) {
 
 // ---- from-state lists (sorted by site) and node missation maps (mutations.h:184-232) ---------------------------
 EMAT_D int fs_lower_bound(const FsRec* v, int n, int l) { int lo = 0, hi = n; while (lo < hi) { int mid = (lo + hi) >> 1; if (v[mid].site < l) lo = mid + 1; else hi = mid; } return lo; }
-EMAT_D bool miss_contains(Ctx& c, int node, int l) { return iv_contains(miss_of(c, node), (int)c.N[node].miss.cnt, l); }
+EMAT_D bool miss_contains(Ctx& c, int node, int l) { return iv_contains(miss_of(c, node), (int)nodes_of(c)[node].miss.cnt, l); }
 EMAT_D int miss_get_from_state(Ctx& c, int node, int l) {
-  const FsRec* v = mfs_of(c, node); int n = (int)c.N[node].mfs.cnt;
+  const FsRec* v = mfs_of(c, node); int n = (int)nodes_of(c)[node].mfs.cnt;
   int k = fs_lower_bound(v, n, l);
   return (k < n && v[k].site == l) ? (int)v[k].state : (int)c.ref[l];
 }
 EMAT_DN void miss_set_from_state(Ctx& c, int node, int l, int from) {
-  ListRef& r = c.N[node].mfs;
+  ListRef& r = nodes_of(c)[node].mfs;
   FsRec* v = mfs_of(c, node); int n = (int)r.cnt;
   int k = fs_lower_bound(v, n, l);
   bool present = (k < n && v[k].site == l);
@@ -394,53 +431,53 @@ EMAT_DN void sd_push_back(Ctx& c, SVec<SdRec>& v, int site, int from, int to) { 
 EMAT_D double delta_lambda_across_missations(Ctx& c, const IvRec* iv, int niv, const FsRec* fs, int nfs) {   // h:121-138
   double r = 0.0;
   for (int i = 0; i < niv; ++i) r -= c.cumQ[iv[i].end] - c.cumQ[iv[i].start];
-  for (int i = 0; i < nfs; ++i) { int l = fs[i].site; r -= c.mu[c.part[l]] * c.nu[l] * (q_a(c, l, fs[i].state) - q_a(c, l, c.ref[l])); }
+  for (int i = 0; i < nfs; ++i) { int l = fs[i].site; r -= mu_of(c)[c.part[l]] * c.nu[l] * (q_a(c, l, fs[i].state) - q_a(c, l, c.ref[l])); }
   return r;
 }
 EMAT_D double delta_lambda_across_node_missations(Ctx& c, int node) {
-  return delta_lambda_across_missations(c, miss_of(c, node), (int)c.N[node].miss.cnt, mfs_of(c, node), (int)c.N[node].mfs.cnt);
+  return delta_lambda_across_missations(c, miss_of(c, node), (int)nodes_of(c)[node].miss.cnt, mfs_of(c, node), (int)nodes_of(c)[node].mfs.cnt);
 }
 EMAT_D double delta_lambda_across_branch(Ctx& c, int node) {   // h:140-155
   double r = 0.0;
   const MutRec* m = muts_of(c, node); int nm = nmuts(c, node);
-  for (int i = 0; i < nm; ++i) { int l = m[i].site; r += c.mu[c.part[l]] * c.nu[l] * (q_a(c, l, m[i].to) - q_a(c, l, m[i].from)); }
+  for (int i = 0; i < nm; ++i) { int l = m[i].site; r += mu_of(c)[c.part[l]] * c.nu[l] * (q_a(c, l, m[i].to) - q_a(c, l, m[i].from)); }
   r += delta_lambda_across_node_missations(c, node);
   return r;
 }
 EMAT_DN double calc_lambda_at_node(Ctx& c, int node) {   // cpp:406-418
   double r = c.cumQ[c.L];
-  for (int cur = node; cur != k_no_node; cur = c.N[cur].parent) r += delta_lambda_across_branch(c, cur);
+  for (int cur = node; cur != k_no_node; cur = nodes_of(c)[cur].parent) r += delta_lambda_across_branch(c, cur);
   return r;
 }
 EMAT_D double branch_log_G(const Ctx& c, double t_P, double t_X, double lambda_X, const MutRec* m, int nm) {   // h:185-206
   double r = -lambda_X * (t_X - t_P);
   for (int i = nm - 1; i >= 0; --i) {
     int l = m[i].site;
-    r -= c.mu[c.part[l]] * c.nu[l] * (q_a(c, l, m[i].from) - q_a(c, l, m[i].to)) * (m[i].t - t_P);
-    r += log(c.mu[c.part[l]] * c.nu[l] * q_ab(c, l, m[i].from, m[i].to));
+    r -= mu_of(c)[c.part[l]] * c.nu[l] * (q_a(c, l, m[i].from) - q_a(c, l, m[i].to)) * (m[i].t - t_P);
+    r += log(mu_of(c)[c.part[l]] * c.nu[l] * q_ab(c, l, m[i].from, m[i].to));
   }
   return r;
 }
 EMAT_DN int calc_site_state_at(Ctx& c, int branch, double t, int l) {   // cpp:108-118
-  for (int cur = branch; cur != k_no_node; cur = c.N[cur].parent) {
+  for (int cur = branch; cur != k_no_node; cur = nodes_of(c)[cur].parent) {
     const MutRec* m = muts_of(c, cur);
     for (int i = nmuts(c, cur) - 1; i >= 0; --i) { if (m[i].t > t) continue; if (m[i].site == l) return m[i].to; }
   }
   return c.ref[l];
 }
 EMAT_D bool is_site_missing_at(Ctx& c, int node, int l) {   // cpp:58-65
-  for (int cur = node; cur != k_no_node; cur = c.N[cur].parent) if (miss_contains(c, cur, l)) return true;
+  for (int cur = node; cur != k_no_node; cur = nodes_of(c)[cur].parent) if (miss_contains(c, cur, l)) return true;
   return false;
 }
 // cpp:41-56; result in scratch
 EMAT_DN SVec<IvRec> reconstruct_missing_sites_at(Ctx& c, int node) {
   int total = 0;
-  for (int cur = node; cur != k_no_node; cur = c.N[cur].parent) total += (int)c.N[cur].miss.cnt;
+  for (int cur = node; cur != k_no_node; cur = nodes_of(c)[cur].parent) total += (int)nodes_of(c)[cur].miss.cnt;
   SVec<IvRec> a = sc_vec<IvRec>(c, total + 1), b = sc_vec<IvRec>(c, total + 1);
   if (c.failed) return a;
   IvRec* so_far = a.p; IvRec* other = b.p; int n = 0;
-  for (int cur = node; cur != k_no_node; cur = c.N[cur].parent) {
-    int k = iv_merge(other, so_far, n, miss_of(c, cur), (int)c.N[cur].miss.cnt);
+  for (int cur = node; cur != k_no_node; cur = nodes_of(c)[cur].parent) {
+    int k = iv_merge(other, so_far, n, miss_of(c, cur), (int)nodes_of(c)[cur].miss.cnt);
     IvRec* t = so_far; so_far = other; other = t; n = k;
   }
   SVec<IvRec> r; r.p = so_far; r.n = n; r.cap = total + 1;
@@ -448,9 +485,9 @@ EMAT_DN SVec<IvRec> reconstruct_missing_sites_at(Ctx& c, int node) {
 }
 EMAT_D bool descends_from(Ctx& c, int X, int A) {   // phylo_tree.cpp:292-299
   if (A == k_no_node) return true;
-  for (int cur = X; cur != k_no_node; cur = c.N[cur].parent) {
+  for (int cur = X; cur != k_no_node; cur = nodes_of(c)[cur].parent) {
     if (cur == A) return true;
-    if (c.N[cur].t < c.N[A].t) return false;
+    if (nodes_of(c)[cur].t < nodes_of(c)[A].t) return false;
   }
   return false;
 }
@@ -459,20 +496,20 @@ EMAT_DN int find_MRCA_of(Ctx& c, int P, int Q) {   // phylo_tree.cpp:204-280
   if (Q == k_no_node) return Q;
   int guard = 0;
   while (P != Q && guard++ < (1 << 28)) {
-    double tP = c.N[P].t, tQ = c.N[Q].t;
-    if (tP > tQ) { P = c.N[P].parent; EMAT_CHECK(c, P != k_no_node); if (P == k_no_node) return Q; }
-    else if (tP < tQ) { Q = c.N[Q].parent; EMAT_CHECK(c, Q != k_no_node); if (Q == k_no_node) return P; }
-    else if (is_tip(c, P)) { P = c.N[P].parent; if (P == k_no_node) return Q; }
-    else if (is_tip(c, Q)) { Q = c.N[Q].parent; if (Q == k_no_node) return P; }
+    double tP = nodes_of(c)[P].t, tQ = nodes_of(c)[Q].t;
+    if (tP > tQ) { P = nodes_of(c)[P].parent; EMAT_CHECK(c, P != k_no_node); if (P == k_no_node) return Q; }
+    else if (tP < tQ) { Q = nodes_of(c)[Q].parent; EMAT_CHECK(c, Q != k_no_node); if (Q == k_no_node) return P; }
+    else if (is_tip(c, P)) { P = nodes_of(c)[P].parent; if (P == k_no_node) return Q; }
+    else if (is_tip(c, Q)) { Q = nodes_of(c)[Q].parent; if (Q == k_no_node) return P; }
     else {
       // equal times, distinct inner nodes (rare): deepest common node of the two root paths
       int dP = 0, dQ = 0;
-      for (int x = P; x != k_no_node; x = c.N[x].parent) ++dP;
-      for (int x = Q; x != k_no_node; x = c.N[x].parent) ++dQ;
+      for (int x = P; x != k_no_node; x = nodes_of(c)[x].parent) ++dP;
+      for (int x = Q; x != k_no_node; x = nodes_of(c)[x].parent) ++dQ;
       int a = P, b = Q;
-      while (dP > dQ) { a = c.N[a].parent; --dP; }
-      while (dQ > dP) { b = c.N[b].parent; --dQ; }
-      while (a != b) { a = c.N[a].parent; b = c.N[b].parent; }
+      while (dP > dQ) { a = nodes_of(c)[a].parent; --dP; }
+      while (dQ > dP) { b = nodes_of(c)[b].parent; --dQ; }
+      while (a != b) { a = nodes_of(c)[a].parent; b = nodes_of(c)[b].parent; }
       return a;
     }
   }
@@ -554,32 +591,32 @@ EMAT_DN double pop_integral(const PopTable& p, double a, double b) {
 // identically zero for the whole residency, so those cells contribute nothing (cpp:355-386).
 struct Cells { double* kbar_p; double* ktw_p; double* ktw; double* popsize; int32_t* nactive; };
 EMAT_D Cells cells_of(Ctx& c) {
-  Cells k; int cap = c.H->cell_cap;
-  double* base = (double*)(c.S + c.H->off_cells);
+  Cells k; int cap = hdr_of(c)->cell_cap;
+  double* base = (double*)(slab_of(c) + hdr_of(c)->off_cells);
   k.kbar_p = base; k.ktw_p = base + cap; k.ktw = base + 2 * cap; k.popsize = base + 3 * cap; k.nactive = (int32_t*)(base + 4 * cap);
   return k;
 }
-EMAT_D int cell_for(const Ctx& c, double t) { return (int)floor((c.H->t_ref - t) / c.H->t_step); }
-EMAT_D double cell_ubound(const Ctx& c, int cell) { return c.H->t_ref - c.H->t_step * cell; }
-EMAT_D double cell_lbound(const Ctx& c, int cell) { return cell_ubound(c, cell) - c.H->t_step; }
+EMAT_D int cell_for(const Ctx& c, double t) { return (int)floor((hdr_of(c)->t_ref - t) / hdr_of(c)->t_step); }
+EMAT_D double cell_ubound(const Ctx& c, int cell) { return hdr_of(c)->t_ref - hdr_of(c)->t_step * cell; }
+EMAT_D double cell_lbound(const Ctx& c, int cell) { return cell_ubound(c, cell) - hdr_of(c)->t_step; }
 // cpp:259-299 (only the root part may grow, towards the past)
 EMAT_DN void coal_grow(Ctx& c, int cell);
 EMAT_DF void coal_ensure_space(Ctx& c, double t) {
   int cell = cell_for(c, t);
-  if (cell >= c.H->n_cells_total && c.includes_run_root) coal_grow(c, cell);   // rare: the root moved past the grid
-  if (cell < c.H->cell_first || cell >= c.H->n_cells_total) EMAT_FAIL(c, k_part_internal);
+  if (cell >= hdr_of(c)->n_cells_total && c.includes_run_root) coal_grow(c, cell);   // rare: the root moved past the grid
+  if (cell < hdr_of(c)->cell_first || cell >= hdr_of(c)->n_cells_total) EMAT_FAIL(c, k_part_internal);
 }
 EMAT_DN void coal_grow(Ctx& c, int cell) {
   {
     Cells k = cells_of(c);
-    while (c.H->n_cells_total <= cell) {
-      int i = c.H->n_cells_total, w = i - c.H->cell_first;
-      if (w >= c.H->cell_cap) { EMAT_FAIL(c, k_part_cell_overflow); return; }
-      double popsize_bar_i = pop_integral(*c.pop, cell_lbound(c, i), cell_ubound(c, i)) / c.H->t_step;
-      double sigma = sqrt(popsize_bar_i / c.H->t_step);
+    while (hdr_of(c)->n_cells_total <= cell) {
+      int i = hdr_of(c)->n_cells_total, w = i - hdr_of(c)->cell_first;
+      if (w >= hdr_of(c)->cell_cap) { EMAT_FAIL(c, k_part_cell_overflow); return; }
+      double popsize_bar_i = pop_integral(*c.pop, cell_lbound(c, i), cell_ubound(c, i)) / hdr_of(c)->t_step;
+      double sigma = sqrt(popsize_bar_i / hdr_of(c)->t_step);
       double ktw = gaussian(c, 0.0, sigma);
       k.popsize[w] = popsize_bar_i; k.nactive[w] = 1; k.kbar_p[w] = 1.0; k.ktw_p[w] = ktw; k.ktw[w] = ktw;
-      c.H->n_cells_total = i + 1; c.H->n_cells = w + 1;
+      hdr_of(c)->n_cells_total = i + 1; hdr_of(c)->n_cells = w + 1;
     }
   }
 }
@@ -588,12 +625,12 @@ EMAT_DF void coal_add_interval(Ctx& c, double t_start, double t_end, double delt
   if (c.failed) return;
   if (t_start < t_end) { double t = t_start; t_start = t_end; t_end = t; }
   Cells k = cells_of(c);
-  const int first = c.H->cell_first;
+  const int first = hdr_of(c)->cell_first;
   int cell_start = cell_for(c, t_start);
-  int cell_end = c.H->n_cells_total - 1;
+  int cell_end = hdr_of(c)->n_cells_total - 1;
   if (t_end != cell_lbound(c, cell_end)) cell_end = cell_for(c, t_end);
-  if (cell_start < first || cell_end >= c.H->n_cells_total || cell_start > cell_end) { EMAT_FAIL(c, k_part_internal); return; }
-  const double ts = c.H->t_step;
+  if (cell_start < first || cell_end >= hdr_of(c)->n_cells_total || cell_start > cell_end) { EMAT_FAIL(c, k_part_internal); return; }
+  const double ts = hdr_of(c)->t_step;
   if (cell_start == cell_end) k.kbar_p[cell_start - first] += delta_k * (t_start - t_end) / ts;
   else {
     k.kbar_p[cell_start - first] += delta_k * (t_start - cell_lbound(c, cell_start)) / ts;
@@ -604,18 +641,18 @@ EMAT_DF void coal_add_interval(Ctx& c, double t_start, double t_end, double delt
 }
 EMAT_DF double coal_cell_term(const Ctx& c, const Cells& k, int w, double new_k, double old_k) {
   double na = (double)k.nactive[w];
-  return c.H->t_step / k.popsize[w] * (
+  return hdr_of(c)->t_step / k.popsize[w] * (
       +0.5 * (new_k * new_k - old_k * old_k) * na
       - (k.ktw_p[w] * na - k.ktw[w] + 0.5) * (new_k - old_k));
 }
 // cpp:388-459
 EMAT_DF double coal_delta_on_add_interval(Ctx& c, double min_t, double max_t, double delta_k) {
-  { int cm = cell_for(c, max_t); if (cm < c.H->cell_first || cm >= c.H->n_cells_total) { EMAT_FAIL(c, k_part_internal); return 0.0; } }
+  { int cm = cell_for(c, max_t); if (cm < hdr_of(c)->cell_first || cm >= hdr_of(c)->n_cells_total) { EMAT_FAIL(c, k_part_internal); return 0.0; } }
   coal_ensure_space(c, min_t);
   if (c.failed) return 0.0;
   if (min_t == max_t) return 0.0;
   Cells k = cells_of(c);
-  const int first = c.H->cell_first; const double ts = c.H->t_step;
+  const int first = hdr_of(c)->cell_first; const double ts = hdr_of(c)->t_step;
   int cell_start = cell_for(c, max_t), cell_end = cell_for(c, min_t);
   double d = 0.0;
   if (cell_start == cell_end) {
@@ -712,6 +749,5 @@ EMAT_DN double gamma_q_inv(double a, double q) {
   return x;
 }
 
-}  // namespace dev
+}  // namespace EMAT_DEV_NS
 }  // namespace emat
-#endif  // EMAT_DEVICE_CORE_HPP_

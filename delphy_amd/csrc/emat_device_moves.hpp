@@ -1,16 +1,15 @@
 // emat_device_moves.hpp -- the five local moves of reference core/subrun.cpp:98-742 on a part slab.
-#ifndef EMAT_DEVICE_MOVES_HPP_
-#define EMAT_DEVICE_MOVES_HPP_
+// NO include guard (see emat_device_core.hpp).
 
 #include "emat_device_spr.hpp"
 
 namespace emat {
-namespace dev {
+namespace EMAT_DEV_NS {
 
 enum { k_inner_node_displace = 0, k_tip_displace = 1, k_branch_reform = 2, k_subtree_slide = 3, k_spr1 = 4 };
 
-EMAT_D void begin_move(Ctx& c, int kind) { c.H->proposed[kind]++; c.tr_kind = (double)kind; c.tr_node = -1.0; c.tr_acc = 0.0; c.tr_log_mh = __builtin_nan(""); }
-EMAT_D void note_move(Ctx& c, int node, double log_mh, bool acc, int kind) { c.tr_node = (double)node; c.tr_log_mh = log_mh; c.tr_acc = acc ? 1.0 : 0.0; if (acc) c.H->accepted[kind]++; }
+EMAT_D void begin_move(Ctx& c, int kind) { hdr_of(c)->proposed[kind]++; c.tr_kind = (double)kind; c.tr_node = -1.0; c.tr_acc = 0.0; c.tr_log_mh = __builtin_nan(""); }
+EMAT_D void note_move(Ctx& c, int node, double log_mh, bool acc, int kind) { c.tr_node = (double)node; c.tr_log_mh = log_mh; c.tr_acc = acc ? 1.0 : 0.0; if (acc) hdr_of(c)->accepted[kind]++; }
 EMAT_D bool mh_accept(Ctx& c, double log_mh) { return log_mh >= 0.0 || uniform_co(c, 0.0, 1.0) < exp(log_mh); }
 
 // distributions.h:38-69
@@ -24,19 +23,19 @@ EMAT_D double bounded_exponential(Ctx& c, double lambda, double a, double b) {
   else x = a + log1p(u * (exp(ltr) - 1)) / lambda;
   return x < a ? a : (b < x ? b : x);
 }
-EMAT_D int pick_random_node(Ctx& c) { return uniform_int(c, c.H->n_nodes); }
+EMAT_D int pick_random_node(Ctx& c) { return uniform_int(c, hdr_of(c)->n_nodes); }
 
 // subrun.cpp:683-742
 EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new_t, double alpha_ratio) {
-  if (X == c.H->root) return;
-  if (!c.includes_run_root) if (c.N[X].parent == c.H->root || new_branch == c.H->root) return;
-  const double t_X = c.N[X].t;
-  const int P = c.N[X].parent;
-  const double old_t_P = c.N[P].t;
+  if (X == hdr_of(c)->root) return;
+  if (!c.includes_run_root) if (nodes_of(c)[X].parent == hdr_of(c)->root || new_branch == hdr_of(c)->root) return;
+  const double t_X = nodes_of(c)[X].t;
+  const int P = nodes_of(c)[X].parent;
+  const double old_t_P = nodes_of(c)[P].t;
   const int old_S = sibling_of(c, P, X);
   const double new_t_P = new_t;
-  if (new_t_P == t_X || new_t_P == c.N[new_branch].t || (P != c.H->root && new_t_P == c.N[c.N[P].parent].t)) return;
-  c.mu_prop = c.N[c.H->root].lambda / (c.L - c.N[c.H->root].n_missing);
+  if (new_t_P == t_X || new_t_P == nodes_of(c)[new_branch].t || (P != hdr_of(c)->root && new_t_P == nodes_of(c)[nodes_of(c)[P].parent].t)) return;
+  c.mu_prop = nodes_of(c)[hdr_of(c)->root].lambda / (c.L - nodes_of(c)[hdr_of(c)->root].n_missing);
   EMAT_PHASE_BEGIN();
   Graft old_graft = analyze_graft(c, X);
   peel_graft(c, old_graft);
@@ -53,8 +52,8 @@ EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new_t, double a
   if (c.tr_kind == (double)k_subtree_slide) note_move(c, X, log_mh, acc, k_subtree_slide);
   if (acc) {
     apply_graft(c, new_graft);
-    c.H->log_G -= old_graft.delta_log_G; c.H->log_G += new_graft.delta_log_G;
-    c.H->log_aug_prior += d_prior;
+    hdr_of(c)->log_G -= old_graft.delta_log_G; hdr_of(c)->log_G += new_graft.delta_log_G;
+    hdr_of(c)->log_aug_prior += d_prior;
     coal_coalescence_displaced(c, old_t_P, new_t);
   } else {
     spr_move_topology(c, X, old_S, old_t_P);
@@ -68,12 +67,12 @@ EMAT_DN void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
   int node;
   { int guard = 0; do { node = pick_random_node(c); } while (is_tip(c, node) && guard++ < (1 << 26)); }
   c.tr_node = (double)node;
-  const int root = c.H->root;
+  const int root = hdr_of(c)->root;
   if (node == root && !c.includes_run_root) return;
-  const NodeRec nd = c.N[node];
+  const NodeRec nd = nodes_of(c)[node];
   double t_min = -k_inf;
   if (node != root) {
-    t_min = c.N[nd.parent].t;
+    t_min = nodes_of(c)[nd.parent].t;
     const MutRec* m = muts_of(c, node);
     for (int i = 0; i < (int)nd.muts.cnt; ++i) t_min = t_min > m[i].t ? t_min : m[i].t;
   }
@@ -84,11 +83,11 @@ EMAT_DN void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
   if (node != root) d_logG_dt += -lambda_at_node;
   for (int k = 0; k < 2; ++k) {
     const int cc = ch[k];
-    t_max = t_max < c.N[cc].t ? t_max : c.N[cc].t;
+    t_max = t_max < nodes_of(c)[cc].t ? t_max : nodes_of(c)[cc].t;
     const MutRec* m = muts_of(c, cc);
     const int nm = nmuts(c, cc);
     for (int i = 0; i < nm; ++i) t_max = t_max < m[i].t ? t_max : m[i].t;
-    c.bytes += 64 + 16 * nm + 24 * (int)c.N[cc].miss.cnt;
+    c.bytes += 64 + 16 * nm + 24 * (int)nodes_of(c)[cc].miss.cnt;
   }
   for (int k = 0; k < 2; ++k) {
     double lambda_just_below = lambda_at_node + delta_lambda_across_node_missations(c, ch[k]);
@@ -119,9 +118,9 @@ EMAT_DN void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
   note_move(c, node, log_mh, acc, k_inner_node_displace);
   if (acc) {
     coal_coalescence_displaced(c, old_t, new_t);
-    c.N[node].t = new_t;
-    c.H->log_G += d_logG_dt * (new_t - old_t);
-    c.H->log_aug_prior += delta_log_prior;
+    nodes_of(c)[node].t = new_t;
+    hdr_of(c)->log_G += d_logG_dt * (new_t - old_t);
+    hdr_of(c)->log_aug_prior += delta_log_prior;
   }
 }
 
@@ -130,10 +129,10 @@ EMAT_DN void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
   int node;
   { int guard = 0; do { node = pick_random_node(c); } while (!is_tip(c, node) && guard++ < (1 << 26)); }
   c.tr_node = (double)node;
-  const NodeRec nd = c.N[node];
+  const NodeRec nd = nodes_of(c)[node];
   if (nd.t_min == nd.t_max) return;
-  double t_min = (double)nd.t_min > c.N[nd.parent].t ? (double)nd.t_min : c.N[nd.parent].t;   // std::max(a, b) = a < b ? b : a
-  if ((double)nd.t_min < c.N[nd.parent].t) t_min = c.N[nd.parent].t; else t_min = (double)nd.t_min;
+  double t_min = (double)nd.t_min > nodes_of(c)[nd.parent].t ? (double)nd.t_min : nodes_of(c)[nd.parent].t;   // std::max(a, b) = a < b ? b : a
+  if ((double)nd.t_min < nodes_of(c)[nd.parent].t) t_min = nodes_of(c)[nd.parent].t; else t_min = (double)nd.t_min;
   const MutRec* m = muts_of(c, node);
   for (int i = 0; i < (int)nd.muts.cnt; ++i) t_min = t_min > m[i].t ? t_min : m[i].t;
   const double t_max = (double)nd.t_max;
@@ -151,9 +150,9 @@ EMAT_DN void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
   note_move(c, node, log_mh, acc, k_tip_displace);
   if (acc) {
     coal_tip_displaced(c, old_t, new_t);
-    c.N[node].t = new_t;
-    c.H->log_G += d_logG_dt * (new_t - old_t);
-    c.H->log_aug_prior += delta_log_prior;
+    nodes_of(c)[node].t = new_t;
+    hdr_of(c)->log_G += d_logG_dt * (new_t - old_t);
+    hdr_of(c)->log_aug_prior += delta_log_prior;
   }
 }
 
@@ -163,8 +162,8 @@ EMAT_D SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) {
   SVec<MutRec> out = sc_vec<MutRec>(c, n);
   if (c.failed) return out;
   const MutRec* old = muts_of(c, X);
-  if (X == c.H->root) { for (int i = 0; i < n; ++i) push(c, out, old[i]); return out; }
-  const double t_X = c.N[X].t, t_P = c.N[c.N[X].parent].t;
+  if (X == hdr_of(c)->root) { for (int i = 0; i < n; ++i) push(c, out, old[i]); return out; }
+  const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[nodes_of(c)[X].parent].t;
   bool complicated = false;
   for (int i = 0; i < n && !complicated; ++i) for (int j = i + 1; j < n; ++j) if (old[i].site == old[j].site) { complicated = true; break; }
   if (!complicated) {
@@ -189,23 +188,23 @@ EMAT_D SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) {
 
 EMAT_DN void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
   begin_move(c, k_branch_reform);
-  if (c.H->n_nodes < 3) return;
+  if (hdr_of(c)->n_nodes < 3) return;
   const int X = pick_random_node(c);
   c.tr_node = (double)X;
-  if (X == c.H->root) return;
-  const int P = c.N[X].parent;
+  if (X == hdr_of(c)->root) return;
+  const int P = nodes_of(c)[X].parent;
   const int S = sibling_of(c, P, X);
-  const double t_X = c.N[X].t, t_P = c.N[P].t;
-  if (P == c.H->root) { spr_move_core(c, X, S, t_P, 1.0); if (c.failed) return; }
+  const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t;
+  if (P == hdr_of(c)->root) { spr_move_core(c, X, S, t_P, 1.0); if (c.failed) return; }
   SVec<MutRec> nm = randomize_branch_mutation_times(c, X);
   if (c.failed) return;
-  const double lam = c.N[X].lambda;
+  const double lam = nodes_of(c)[X].lambda;
   double delta_log_G = branch_log_G(c, t_P, t_X, lam, nm.p, nm.n) - branch_log_G(c, t_P, t_X, lam, muts_of(c, X), nmuts(c, X));
   c.bytes += 2 * 64 + 2 * 16 * nm.n;
   double log_mh = delta_log_G;
   bool acc = mh_accept(c, log_mh);
   note_move(c, X, log_mh, acc, k_branch_reform);
-  if (acc) { list_assign<MutRec>(c, c.N[X].muts, nm.p, nm.n); c.H->log_G += delta_log_G; c.bytes += 16 * nm.n; }
+  if (acc) { list_assign<MutRec>(c, nodes_of(c)[X].muts, nm.p, nm.n); hdr_of(c)->log_G += delta_log_G; c.bytes += 16 * nm.n; }
 }
 
 // subrun.cpp:325-350, iterative with an explicit stack in scratch
@@ -232,11 +231,11 @@ EMAT_DN SVec<int> enumerate_descendant_branches_straddling(Ctx& c, int P, double
   while (sp > 0 && !c.failed) {
     int n = stack_base[-sp]; --sp;
     if (n == X) continue;
-    if (t <= c.N[n].t) { if (!room(1, 0)) { EMAT_FAIL(c, k_part_overflow); break; } out.p[out.n++] = n; }
+    if (t <= nodes_of(c)[n].t) { if (!room(1, 0)) { EMAT_FAIL(c, k_part_overflow); break; } out.p[out.n++] = n; }
     else if (!is_tip(c, n)) {
       if (!room(0, 2)) { EMAT_FAIL(c, k_part_overflow); break; }
-      stack_base[-(++sp)] = c.N[n].child1;   // child0 is processed first, as in the recursive original
-      stack_base[-(++sp)] = c.N[n].child0;
+      stack_base[-(++sp)] = nodes_of(c)[n].child1;   // child0 is processed first, as in the recursive original
+      stack_base[-(++sp)] = nodes_of(c)[n].child0;
     }
   }
   out.cap = out.n;
@@ -246,32 +245,32 @@ EMAT_DN SVec<int> enumerate_descendant_branches_straddling(Ctx& c, int P, double
 
 EMAT_DN void subtree_slide_move(Ctx& c) {   // subrun.cpp:352-448
   begin_move(c, k_subtree_slide);
-  if (c.H->n_nodes < 2) return;
+  if (hdr_of(c)->n_nodes < 2) return;
   const int X = pick_random_node(c);
   c.tr_node = (double)X;
-  const int root = c.H->root;
+  const int root = hdr_of(c)->root;
   if (X == root) return;
-  const int P = c.N[X].parent, S = sibling_of(c, P, X);
-  double t_early = (P == root) ? (c.N[X].t < c.N[S].t ? c.N[X].t : c.N[S].t) : c.N[root].t;
-  if (P == root) { if (c.N[S].t < c.N[X].t) t_early = c.N[S].t; else t_early = c.N[X].t; }   // std::min(tX, tS)
+  const int P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
+  double t_early = (P == root) ? (nodes_of(c)[X].t < nodes_of(c)[S].t ? nodes_of(c)[X].t : nodes_of(c)[S].t) : nodes_of(c)[root].t;
+  if (P == root) { if (nodes_of(c)[S].t < nodes_of(c)[X].t) t_early = nodes_of(c)[S].t; else t_early = nodes_of(c)[X].t; }   // std::min(tX, tS)
   double tree_span = c.t_max_tip - t_early;
   EMAT_CHECK(c, tree_span >= 0.0);
-  double ds = (1 / c.N[X].lambda) / 2;
+  double ds = (1 / nodes_of(c)[X].lambda) / 2;
   double delta_scale = tree_span < ds ? tree_span : ds;
   double delta_t = gaussian(c, 0.0, delta_scale);
-  const double old_P_t = c.N[P].t, new_P_t = old_P_t + delta_t;
+  const double old_P_t = nodes_of(c)[P].t, new_P_t = old_P_t + delta_t;
   if (delta_t < 0.0) {
-    if (P != root && new_P_t < c.N[c.N[P].parent].t) {
-      int GG = c.N[P].parent, SS = P;
-      while (new_P_t < c.N[GG].t) { SS = GG; GG = c.N[GG].parent; if (GG == k_no_node) break; }
+    if (P != root && new_P_t < nodes_of(c)[nodes_of(c)[P].parent].t) {
+      int GG = nodes_of(c)[P].parent, SS = P;
+      while (new_P_t < nodes_of(c)[GG].t) { SS = GG; GG = nodes_of(c)[GG].parent; if (GG == k_no_node) break; }
       SVec<int> branches = enumerate_descendant_branches_straddling(c, SS, old_P_t, X);
       if (c.failed) return;
       double a_o2n = 1.0, a_n2o = 1.0 / (double)branches.n;
       spr_move_core(c, X, SS, new_P_t, a_n2o / a_o2n);
     } else spr_move_core(c, X, S, new_P_t, 1.0);
   } else {
-    if (new_P_t > c.N[X].t) return;
-    if (new_P_t > c.N[S].t) {
+    if (new_P_t > nodes_of(c)[X].t) return;
+    if (new_P_t > nodes_of(c)[S].t) {
       SVec<int> branches = enumerate_descendant_branches_straddling(c, P, new_P_t, X);
       if (c.failed) return;
       if (branches.n == 0) return;
@@ -285,22 +284,22 @@ EMAT_DN void subtree_slide_move(Ctx& c) {   // subrun.cpp:352-448
 
 EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   begin_move(c, k_spr1);
-  if (c.H->n_nodes < 2) return;
+  if (hdr_of(c)->n_nodes < 2) return;
   const double chooser = uniform_co(c, 0.0, 1.0);
   const int limit = chooser < 0.01 ? 0x7fffffff : 1;
-  const int root0 = c.H->root;
-  c.mu_prop = c.N[root0].lambda / (c.L - c.N[root0].n_missing);
+  const int root0 = hdr_of(c)->root;
+  c.mu_prop = nodes_of(c)[root0].lambda / (c.L - nodes_of(c)[root0].n_missing);
   const double annealing_factor = 0.8;
   int X;
-  { int guard = 0; do { X = pick_random_node(c); } while (c.H->root == X && guard++ < (1 << 26)); }
+  { int guard = 0; do { X = pick_random_node(c); } while (hdr_of(c)->root == X && guard++ < (1 << 26)); }
   c.tr_node = (double)X;
-  if (c.N[X].lambda == 0.0) return;
-  const double t_X = c.N[X].t;
-  const int P = c.N[X].parent;
-  const double old_t_P = c.N[P].t;
+  if (nodes_of(c)[X].lambda == 0.0) return;
+  const double t_X = nodes_of(c)[X].t;
+  const int P = nodes_of(c)[X].parent;
+  const double old_t_P = nodes_of(c)[P].t;
   const int old_S = sibling_of(c, P, X);
-  const int old_G = c.N[P].parent;
-  const bool pruning_changes_root = P == c.H->root;
+  const int old_G = nodes_of(c)[P].parent;
+  const bool pruning_changes_root = P == hdr_of(c)->root;
   if (pruning_changes_root && !c.includes_run_root) return;
   EMAT_PHASE_BEGIN();
   Graft old_graft = analyze_graft(c, X);
@@ -309,14 +308,14 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   if (c.failed) return;
   const int old_min_muts = count_min_mutations(c, old_graft);
   int extra = 4;
-  if (limit != 1) { extra = 8; for (int n = 0; n < c.H->n_nodes; ++n) if (c.includes_run_root || n != c.H->root) extra += nmuts(c, n); }
+  if (limit != 1) { extra = 8; for (int n = 0; n < hdr_of(c)->n_nodes; ++n) if (c.includes_run_root || n != hdr_of(c)->root) extra += nmuts(c, n); }
   SVec<SdRec> old_deltas = summarize_closed_mutations(c, old_graft, extra);
   SVec<IvRec> missing_at_X = reconstruct_missing_sites_at(c, X);
   const int n_missing_at_X = iv_num_sites(missing_at_X.p, missing_at_X.n);
-  const double lambda_X = c.N[X].lambda;
+  const double lambda_X = nodes_of(c)[X].lambda;
   SVec<Region> pre_regions = study_seed_fill(c, X, t_X, missing_at_X, limit, old_S, 0, old_deltas, c.includes_run_root);
   EMAT_PHASE(c, 6);
-  c.H->phase_ticks[13] += pre_regions.n;
+  hdr_of(c)->phase_ticks[13] += pre_regions.n;
   Study pre = make_study(c, pre_regions, n_missing_at_X, lambda_X, annealing_factor, t_X, c.t_max_tip);
   if (c.failed) return;
   const int new_region = study_pick_nexus_region(c, pre);
@@ -324,10 +323,10 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   EMAT_CHECK(c, new_S != P);
   const double new_t_P = study_pick_time_in_region(c, pre, new_region);
   const double log_alpha_o2n = study_log_alpha_in_region(c, pre, new_region, new_t_P);
-  const double t_new_S = c.N[new_S].t;
-  int new_G = c.N[new_S].parent;
+  const double t_new_S = nodes_of(c)[new_S].t;
+  int new_G = nodes_of(c)[new_S].parent;
   if (new_G == P) new_G = old_G;
-  const double t_new_G = (new_G == k_no_node) ? k_neg_dbl_max : c.N[new_G].t;
+  const double t_new_G = (new_G == k_no_node) ? k_neg_dbl_max : nodes_of(c)[new_G].t;
   if (c.failed) return;
   EMAT_PHASE(c, 7);
   if (new_t_P == t_X || new_t_P == t_new_S || new_t_P == t_new_G) { apply_graft(c, old_graft); return; }
@@ -336,12 +335,12 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   Graft new_graft = propose_new_graft(c, X);
   EMAT_PHASE(c, 9);
   if (c.failed) return;
-  EMAT_CHECK(c, c.N[X].parent == P);
+  EMAT_CHECK(c, nodes_of(c)[X].parent == P);
   const int new_min_muts = count_min_mutations(c, new_graft);
   SVec<SdRec> new_deltas = summarize_closed_mutations(c, new_graft, extra);
   SVec<Region> post_regions = study_seed_fill(c, X, t_X, missing_at_X, limit, new_S, 0, new_deltas, c.includes_run_root);
   EMAT_PHASE(c, 10);
-  c.H->phase_ticks[13] += post_regions.n;
+  hdr_of(c)->phase_ticks[13] += post_regions.n;
   Study post = make_study(c, post_regions, n_missing_at_X, lambda_X, annealing_factor, t_X, c.t_max_tip);
   if (c.failed) return;
   const int old_region = study_find_region(post, old_S, old_t_P);
@@ -359,8 +358,8 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   note_move(c, X, log_mh, acc, k_spr1);
   if (acc) {
     apply_graft(c, new_graft);
-    c.H->log_G -= old_graft.delta_log_G; c.H->log_G += new_graft.delta_log_G;
-    c.H->log_aug_prior += d_prior;
+    hdr_of(c)->log_G -= old_graft.delta_log_G; hdr_of(c)->log_G += new_graft.delta_log_G;
+    hdr_of(c)->log_aug_prior += d_prior;
     coal_coalescence_displaced(c, old_t_P, new_t_P);
   } else {
     spr_move_topology(c, X, old_S, old_t_P);
@@ -373,39 +372,39 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
 // Squeeze the garbage out of the list heap by staging all live lists in the (idle) scratch region.
 EMAT_DN bool compact_heap(Ctx& c) {
   uint32_t live = 0;
-  const int n = c.H->n_nodes;
+  const int n = hdr_of(c)->n_nodes;
   for (int i = 0; i < n; ++i) {
-    live += (((uint32_t)c.N[i].muts.cnt * 16u) + 15u) & ~15u;
-    live += (((uint32_t)c.N[i].miss.cnt * 8u) + 15u) & ~15u;
-    live += (((uint32_t)c.N[i].mfs.cnt * 8u) + 15u) & ~15u;
+    live += (((uint32_t)nodes_of(c)[i].muts.cnt * 16u) + 15u) & ~15u;
+    live += (((uint32_t)nodes_of(c)[i].miss.cnt * 8u) + 15u) & ~15u;
+    live += (((uint32_t)nodes_of(c)[i].mfs.cnt * 8u) + 15u) & ~15u;
   }
-  if (live > c.H->scratch_end - c.H->scratch_begin) return false;
-  uint8_t* stage = c.G + c.H->scratch_begin;
+  if (live > hdr_of(c)->scratch_end - hdr_of(c)->scratch_begin) return false;
+  uint8_t* stage = c.G + hdr_of(c)->scratch_begin;
   uint32_t w = 0;
   for (int i = 0; i < n; ++i) {
-    ListRef* refs[3] = {&c.N[i].muts, &c.N[i].miss, &c.N[i].mfs};
+    ListRef* refs[3] = {&nodes_of(c)[i].muts, &nodes_of(c)[i].miss, &nodes_of(c)[i].mfs};
     const uint32_t es[3] = {16u, 8u, 8u};
     for (int k = 0; k < 3; ++k) {
       uint32_t bytes = (uint32_t)refs[k]->cnt * es[k];
-      const uint64_t* src = (const uint64_t*)(c.S + refs[k]->off); uint64_t* dst = (uint64_t*)(stage + w);
+      const uint64_t* src = (const uint64_t*)(slab_of(c) + refs[k]->off); uint64_t* dst = (uint64_t*)(stage + w);
       for (uint32_t q = 0; q < bytes / 8; ++q) dst[q] = src[q];
       w += (bytes + 15u) & ~15u;
     }
   }
-  uint32_t top = c.H->heap_begin, r = 0;
+  uint32_t top = hdr_of(c)->heap_begin, r = 0;
   for (int i = 0; i < n; ++i) {
-    ListRef* refs[3] = {&c.N[i].muts, &c.N[i].miss, &c.N[i].mfs};
+    ListRef* refs[3] = {&nodes_of(c)[i].muts, &nodes_of(c)[i].miss, &nodes_of(c)[i].mfs};
     const uint32_t es[3] = {16u, 8u, 8u};
     for (int k = 0; k < 3; ++k) {
       uint32_t bytes = (uint32_t)refs[k]->cnt * es[k], padded = (bytes + 15u) & ~15u;
-      const uint64_t* src = (const uint64_t*)(stage + r); uint64_t* dst = (uint64_t*)(c.S + top);
+      const uint64_t* src = (const uint64_t*)(stage + r); uint64_t* dst = (uint64_t*)(slab_of(c) + top);
       for (uint32_t q = 0; q < bytes / 8; ++q) dst[q] = src[q];
       refs[k]->off = top; refs[k]->cap = (uint16_t)(padded / es[k]);
       top += padded; r += padded;
     }
   }
-  c.H->heap_top = top;
-  c.H->compactions++;
+  hdr_of(c)->heap_top = top;
+  hdr_of(c)->compactions++;
   return true;
 }
 
@@ -413,11 +412,11 @@ EMAT_DN bool compact_heap(Ctx& c) {
 EMAT_D bool mcmc_sub_iteration(Ctx& c) {
   // space check BEFORE the move, so that a stop leaves a consistent state
   {
-    uint32_t heap_size = c.H->heap_end - c.H->heap_begin, free_b = c.H->heap_end - c.H->heap_top;
+    uint32_t heap_size = hdr_of(c)->heap_end - hdr_of(c)->heap_begin, free_b = hdr_of(c)->heap_end - hdr_of(c)->heap_top;
     uint32_t reserve = heap_size / 4 > 1024u ? heap_size / 4 : 1024u;
     if (reserve > heap_size / 2) reserve = heap_size / 2;
     if (free_b < reserve) {
-      if (!compact_heap(c) || c.H->heap_end - c.H->heap_top < reserve) { if (c.H->status == 0) c.H->status = k_part_need_space; return false; }
+      if (!compact_heap(c) || hdr_of(c)->heap_end - hdr_of(c)->heap_top < reserve) { if (hdr_of(c)->status == 0) hdr_of(c)->status = k_part_need_space; return false; }
     }
   }
   sc_reset(c);
@@ -436,14 +435,14 @@ EMAT_D bool mcmc_sub_iteration(Ctx& c) {
     else if (c.topology_moves_enabled) { if (r < 31.0) subtree_slide_move(c); else spr1_move(c); }
   }
 #ifdef EMAT_PROFILE_PHASES
-  c.H->phase_ticks[(c.tr_kind >= 3.0) ? 15 : 14] += clock64() - _mv0;
+  hdr_of(c)->phase_ticks[(c.tr_kind >= 3.0) ? 15 : 14] += clock64() - _mv0;
 #endif
-  if (c.H->trace_len < c.H->trace_cap) {
-    double* tr = (double*)(c.S + c.H->off_trace) + 4 * c.H->trace_len;
+  if (hdr_of(c)->trace_len < hdr_of(c)->trace_cap) {
+    double* tr = (double*)(slab_of(c) + hdr_of(c)->off_trace) + 4 * hdr_of(c)->trace_len;
     tr[0] = c.tr_kind; tr[1] = c.tr_node; tr[2] = c.tr_acc; tr[3] = c.tr_log_mh;
-    c.H->trace_len++;
+    hdr_of(c)->trace_len++;
   }
-  c.H->moves_done++;
+  hdr_of(c)->moves_done++;
   return !c.failed;
 }
 
@@ -454,7 +453,7 @@ EMAT_D bool mcmc_sub_iteration(Ctx& c) {
 //      partition [P][4] (Subrun::state_frequencies_of_ref_sequence_per_partition_).  Executed by ONE lane;
 //      the wave-parallel version lives in emat_kernels.hip. --------------------------------------------------
 EMAT_DN double calc_log_root_prior(Ctx& c, const int32_t* ref_freqs, int P) {
-  const int root = c.H->root;
+  const int root = hdr_of(c)->root;
   // counts are adjusted on the fly instead of copying the table
   double result = 0.0;
   for (int p = 0; p < P; ++p) {
@@ -463,10 +462,10 @@ EMAT_DN double calc_log_root_prior(Ctx& c, const int32_t* ref_freqs, int P) {
       const MutRec* m = muts_of(c, root);
       for (int i = 0; i < nmuts(c, root); ++i) if ((int)c.part[m[i].site] == p) { if (m[i].from == a) --f; if (m[i].to == a) ++f; }
       const IvRec* iv = miss_of(c, root);
-      for (int i = 0; i < (int)c.N[root].miss.cnt; ++i) for (int l = iv[i].start; l < iv[i].end; ++l) if ((int)c.part[l] == p && (int)c.ref[l] == a) --f;
+      for (int i = 0; i < (int)nodes_of(c)[root].miss.cnt; ++i) for (int l = iv[i].start; l < iv[i].end; ++l) if ((int)c.part[l] == p && (int)c.ref[l] == a) --f;
       const FsRec* fs = mfs_of(c, root);
-      for (int i = 0; i < (int)c.N[root].mfs.cnt; ++i) if ((int)c.part[fs[i].site] == p) { if ((int)c.ref[fs[i].site] == a) ++f; if ((int)fs[i].state == a) --f; }
-      double pa = c.pi[p * 4 + a];
+      for (int i = 0; i < (int)nodes_of(c)[root].mfs.cnt; ++i) if ((int)c.part[fs[i].site] == p) { if ((int)c.ref[fs[i].site] == a) ++f; if ((int)fs[i].state == a) --f; }
+      double pa = pi_of(c)[p * 4 + a];
       if (pa != 0.0) result += f * log(pa);
       else if (f != 0) return -k_inf;
     }
@@ -474,6 +473,5 @@ EMAT_DN double calc_log_root_prior(Ctx& c, const int32_t* ref_freqs, int P) {
   return result;
 }
 
-}  // namespace dev
+}  // namespace EMAT_DEV_NS
 }  // namespace emat
-#endif  // EMAT_DEVICE_MOVES_HPP_

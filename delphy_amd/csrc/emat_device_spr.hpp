@@ -7,13 +7,12 @@
 // (core/spr_move.cpp:1158-1439).  All temporaries live in the part's scratch region; all node lists
 // live in the slab heap.  Unordered maps of the reference become site-sorted arrays (every
 // order-sensitive use in the reference is followed by a (t, site) sort).
-#ifndef EMAT_DEVICE_SPR_HPP_
-#define EMAT_DEVICE_SPR_HPP_
+// NO include guard (see emat_device_core.hpp).
 
 #include "emat_device_core.hpp"
 
 namespace emat {
-namespace dev {
+namespace EMAT_DEV_NS {
 
 // ---- scratch missation map ("sliding_missations", spr_move.cpp:615-698) ------------------------------------
 EMAT_DN void fsv_set(Ctx& c, SVec<FsRec>& v, int l, int from) {   // Missation_map::set_from_state on a scratch list
@@ -29,7 +28,7 @@ EMAT_DN void fsv_set(Ctx& c, SVec<FsRec>& v, int l, int from) {   // Missation_m
 
 // Rebuild the root's "mutations" (ref -> root deltas, t = -DBL_MAX) from a delta list, in site order.
 EMAT_DN void set_root_muts_from_deltas(Ctx& c, int root, const SVec<SdRec>& d) {
-  ListRef& r = c.N[root].muts;
+  ListRef& r = nodes_of(c)[root].muts;
   list_reserve<MutRec>(c, r, d.n);
   if (c.failed) return;
   MutRec* m = list_ptr<MutRec>(c, r);
@@ -47,7 +46,7 @@ EMAT_DN SVec<SdRec> deltas_from_root_muts(Ctx& c, int root, int extra_cap) {
 // crossed by a move, so it is not counted.
 EMAT_D int path_mut_count(Ctx& c, int from_node) {
   int s = 0;
-  for (int cur = from_node; cur != k_no_node; cur = c.N[cur].parent) if (c.includes_run_root || c.N[cur].parent != k_no_node) s += nmuts(c, cur);
+  for (int cur = from_node; cur != k_no_node; cur = nodes_of(c)[cur].parent) if (c.includes_run_root || nodes_of(c)[cur].parent != k_no_node) s += nmuts(c, cur);
   return s;
 }
 
@@ -59,9 +58,9 @@ struct Edit { int X; SVec<SdRec> deltas; };
 // Node missations <- merge(node, other) (mutations.h:315-336)
 EMAT_DN void node_merge_missations_from(Ctx& c, int dst, int other) {
   ScMark mark = sc_mark(c);
-  int na = (int)c.N[dst].miss.cnt, nb = (int)c.N[other].miss.cnt;
+  int na = (int)nodes_of(c)[dst].miss.cnt, nb = (int)nodes_of(c)[other].miss.cnt;
   SVec<IvRec> iv = sc_vec<IvRec>(c, na + nb + 1);
-  int fa = (int)c.N[dst].mfs.cnt, fb = (int)c.N[other].mfs.cnt;
+  int fa = (int)nodes_of(c)[dst].mfs.cnt, fb = (int)nodes_of(c)[other].mfs.cnt;
   SVec<FsRec> fs = sc_vec<FsRec>(c, fa + fb + 1);
   if (!c.failed) {
     iv.n = iv_merge(iv.p, miss_of(c, dst), na, miss_of(c, other), nb);
@@ -72,17 +71,17 @@ EMAT_DN void node_merge_missations_from(Ctx& c, int dst, int other) {
       else if (i == fa || B[j].site < A[i].site) fs.p[fs.n++] = B[j++];
       else { fs.p[fs.n++] = A[i++]; ++j; }   // map::insert keeps the first
     }
-    list_assign<IvRec>(c, c.N[dst].miss, iv.p, iv.n);
-    list_assign<FsRec>(c, c.N[dst].mfs, fs.p, fs.n);
+    list_assign<IvRec>(c, nodes_of(c)[dst].miss, iv.p, iv.n);
+    list_assign<FsRec>(c, nodes_of(c)[dst].mfs, fs.p, fs.n);
   }
   sc_release(c, mark);
 }
 // factor_out_common_missations(A, B, common) (mutations.h:250-312); `common` node's lists are replaced
 EMAT_DN void node_factor_out_common(Ctx& c, int a, int b, int common) {
   ScMark mark = sc_mark(c);
-  int na = (int)c.N[a].miss.cnt, nb = (int)c.N[b].miss.cnt;
+  int na = (int)nodes_of(c)[a].miss.cnt, nb = (int)nodes_of(c)[b].miss.cnt;
   SVec<IvRec> ic = sc_vec<IvRec>(c, na + nb + 1), ia = sc_vec<IvRec>(c, 2 * (na + nb) + 2), ib = sc_vec<IvRec>(c, 2 * (na + nb) + 2);
-  int fa = (int)c.N[a].mfs.cnt, fb = (int)c.N[b].mfs.cnt;
+  int fa = (int)nodes_of(c)[a].mfs.cnt, fb = (int)nodes_of(c)[b].mfs.cnt;
   SVec<FsRec> fca = sc_vec<FsRec>(c, fa + 1), fcb = sc_vec<FsRec>(c, fb + 1), fcc = sc_vec<FsRec>(c, fa + 1);
   if (!c.failed) {
     ic.n = iv_intersect(ic.p, miss_of(c, a), na, miss_of(c, b), nb);
@@ -97,17 +96,17 @@ EMAT_DN void node_factor_out_common(Ctx& c, int a, int b, int common) {
     }
     while (i < fa) fca.p[fca.n++] = A[i++];
     while (j < fb) fcb.p[fcb.n++] = B[j++];
-    list_assign<IvRec>(c, c.N[a].miss, ia.p, ia.n); list_assign<FsRec>(c, c.N[a].mfs, fca.p, fca.n);
-    list_assign<IvRec>(c, c.N[b].miss, ib.p, ib.n); list_assign<FsRec>(c, c.N[b].mfs, fcb.p, fcb.n);
-    list_assign<IvRec>(c, c.N[common].miss, ic.p, ic.n); list_assign<FsRec>(c, c.N[common].mfs, fcc.p, fcc.n);
+    list_assign<IvRec>(c, nodes_of(c)[a].miss, ia.p, ia.n); list_assign<FsRec>(c, nodes_of(c)[a].mfs, fca.p, fca.n);
+    list_assign<IvRec>(c, nodes_of(c)[b].miss, ib.p, ib.n); list_assign<FsRec>(c, nodes_of(c)[b].mfs, fcb.p, fcb.n);
+    list_assign<IvRec>(c, nodes_of(c)[common].miss, ic.p, ic.n); list_assign<FsRec>(c, nodes_of(c)[common].mfs, fcc.p, fcc.n);
   }
   sc_release(c, mark);
 }
 
 EMAT_DN void edit_slide_root(Ctx& c, Edit& e, double new_t_P) {   // tree_editing.cpp:114-158
-  const int X = e.X, P = c.N[X].parent;
-  EMAT_CHECK(c, P == c.H->root);
-  double old_t_P = c.N[P].t;
+  const int X = e.X, P = nodes_of(c)[X].parent;
+  EMAT_CHECK(c, P == hdr_of(c)->root);
+  double old_t_P = nodes_of(c)[P].t;
   int S = sibling_of(c, P, X);
   if (new_t_P > old_t_P) {
     MutRec* mS = muts_of(c, S); int nS = nmuts(c, S);
@@ -120,20 +119,20 @@ EMAT_DN void edit_slide_root(Ctx& c, Edit& e, double new_t_P) {   // tree_editin
         sd_push_back(c, r2r, m.site, m.from, m.to);
         if (!miss_contains(c, X, m.site)) sd_push_front(c, e.deltas, m.site, m.to, m.from);
         else miss_set_from_state(c, X, m.site, m.to);
-        c.N[P].lambda += dq(c, m.site, m.from, m.to);
+        nodes_of(c)[P].lambda += dq(c, m.site, m.from, m.to);
       }
       set_root_muts_from_deltas(c, P, r2r);
-      list_erase_prefix<MutRec>(c, c.N[S].muts, last);
+      list_erase_prefix<MutRec>(c, nodes_of(c)[S].muts, last);
       sc_release(c, mark);
     }
   }
-  c.N[P].t = new_t_P;
+  nodes_of(c)[P].t = new_t_P;
 }
 EMAT_DN void edit_slide_P_along_branch(Ctx& c, Edit& e, double new_t_P) {   // tree_editing.cpp:31-112
-  const int X = e.X, P = c.N[X].parent;
+  const int X = e.X, P = nodes_of(c)[X].parent;
   EMAT_CHECK(c, !is_tip(c, P));
-  if (P == c.H->root) { edit_slide_root(c, e, new_t_P); return; }
-  double old_t_P = c.N[P].t;
+  if (P == hdr_of(c)->root) { edit_slide_root(c, e, new_t_P); return; }
+  double old_t_P = nodes_of(c)[P].t;
   int S = sibling_of(c, P, X);
   if (new_t_P < old_t_P) {
     MutRec* mP = muts_of(c, P); int nP = nmuts(c, P);
@@ -144,7 +143,7 @@ EMAT_DN void edit_slide_P_along_branch(Ctx& c, Edit& e, double new_t_P) {   // t
       int kept = 0;
       for (int i = first; i < nP; ++i) if (!miss_contains(c, S, mP[i].site)) ++kept;
       int nS = nmuts(c, S);
-      list_reserve<MutRec>(c, c.N[S].muts, nS + kept);
+      list_reserve<MutRec>(c, nodes_of(c)[S].muts, nS + kept);
       if (c.failed) return;
       MutRec* mS = muts_of(c, S); mP = muts_of(c, P);
       for (int i = nS - 1; i >= 0; --i) mS[i + kept] = mS[i];
@@ -155,103 +154,103 @@ EMAT_DN void edit_slide_P_along_branch(Ctx& c, Edit& e, double new_t_P) {   // t
         else miss_set_from_state(c, S, m.site, m.from);
         if (!miss_contains(c, X, m.site)) sd_push_front(c, e.deltas, m.site, m.from, m.to);
         else miss_set_from_state(c, X, m.site, m.from);
-        c.N[P].lambda += dq(c, m.site, m.to, m.from);
+        nodes_of(c)[P].lambda += dq(c, m.site, m.to, m.from);
       }
-      c.N[S].muts.cnt = (uint16_t)(nS + kept);
-      c.N[P].muts.cnt = (uint16_t)first;
+      nodes_of(c)[S].muts.cnt = (uint16_t)(nS + kept);
+      nodes_of(c)[P].muts.cnt = (uint16_t)first;
       (void)k;
     }
   } else {
     MutRec* mS = muts_of(c, S); int nS = nmuts(c, S);
     int last = 0; while (last < nS && !(mS[last].t > new_t_P)) ++last;
     if (last != 0) {
-      list_reserve<MutRec>(c, c.N[P].muts, nmuts(c, P) + last);
+      list_reserve<MutRec>(c, nodes_of(c)[P].muts, nmuts(c, P) + last);
       if (c.failed) return;
       mS = muts_of(c, S);
       for (int i = 0; i < last && !c.failed; ++i) {
         MutRec m = mS[i];
-        MutRec* mP = muts_of(c, P); mP[c.N[P].muts.cnt] = m; c.N[P].muts.cnt++;
+        MutRec* mP = muts_of(c, P); mP[nodes_of(c)[P].muts.cnt] = m; nodes_of(c)[P].muts.cnt++;
         if (!miss_contains(c, X, m.site)) sd_push_front(c, e.deltas, m.site, m.to, m.from);
         else miss_set_from_state(c, X, m.site, m.to);
-        c.N[P].lambda += dq(c, m.site, m.from, m.to);
+        nodes_of(c)[P].lambda += dq(c, m.site, m.from, m.to);
       }
-      list_erase_prefix<MutRec>(c, c.N[S].muts, last);
+      list_erase_prefix<MutRec>(c, nodes_of(c)[S].muts, last);
     }
   }
-  c.N[P].t = new_t_P;
+  nodes_of(c)[P].t = new_t_P;
 }
 EMAT_DN void edit_do_hop_up(Ctx& c, int X) {   // tree_editing.cpp:164-231
-  EMAT_CHECK(c, X != c.H->root);
-  const int P = c.N[X].parent;
-  EMAT_CHECK(c, !is_tip(c, P) && P != c.H->root && nmuts(c, P) == 0);
-  const int G = c.N[P].parent;
+  EMAT_CHECK(c, X != hdr_of(c)->root);
+  const int P = nodes_of(c)[X].parent;
+  EMAT_CHECK(c, !is_tip(c, P) && P != hdr_of(c)->root && nmuts(c, P) == 0);
+  const int G = nodes_of(c)[P].parent;
   if (c.failed || G == k_no_node) { EMAT_FAIL(c, k_part_internal); return; }
-  EMAT_CHECK(c, c.N[P].t == c.N[G].t);
+  EMAT_CHECK(c, nodes_of(c)[P].t == nodes_of(c)[G].t);
   const int U = sibling_of(c, G, P);
   const int S = sibling_of(c, P, X);
-  if (c.N[P].miss.cnt != 0) {
+  if (nodes_of(c)[P].miss.cnt != 0) {
     node_merge_missations_from(c, X, P);
     node_merge_missations_from(c, S, P);
-    c.N[P].miss.cnt = 0; c.N[P].mfs.cnt = 0;
+    nodes_of(c)[P].miss.cnt = 0; nodes_of(c)[P].mfs.cnt = 0;
   }
-  swap_lists(c.N[P].muts, c.N[G].muts);
-  swap_lists(c.N[P].miss, c.N[G].miss);
-  swap_lists(c.N[P].mfs, c.N[G].mfs);
-  EMAT_CHECK(c, c.N[G].miss.cnt == 0);
-  if (iv_intersects(miss_of(c, S), (int)c.N[S].miss.cnt, miss_of(c, U), (int)c.N[U].miss.cnt)) node_factor_out_common(c, S, U, G);
-  if (G == c.H->root) { c.H->root = P; c.N[P].parent = k_no_node; }
+  swap_lists(nodes_of(c)[P].muts, nodes_of(c)[G].muts);
+  swap_lists(nodes_of(c)[P].miss, nodes_of(c)[G].miss);
+  swap_lists(nodes_of(c)[P].mfs, nodes_of(c)[G].mfs);
+  EMAT_CHECK(c, nodes_of(c)[G].miss.cnt == 0);
+  if (iv_intersects(miss_of(c, S), (int)nodes_of(c)[S].miss.cnt, miss_of(c, U), (int)nodes_of(c)[U].miss.cnt)) node_factor_out_common(c, S, U, G);
+  if (G == hdr_of(c)->root) { hdr_of(c)->root = P; nodes_of(c)[P].parent = k_no_node; }
   else {
-    int GG = c.N[G].parent, GU = sibling_of(c, GG, G);
-    c.N[GG].child0 = P; c.N[GG].child1 = GU;
-    c.N[P].parent = GG;
+    int GG = nodes_of(c)[G].parent, GU = sibling_of(c, GG, G);
+    nodes_of(c)[GG].child0 = P; nodes_of(c)[GG].child1 = GU;
+    nodes_of(c)[P].parent = GG;
   }
-  c.N[P].child0 = X; c.N[P].child1 = G;
-  c.N[G].parent = P;
-  c.N[G].child0 = S; c.N[G].child1 = U;
-  c.N[S].parent = G;
-  c.N[P].lambda = c.N[G].lambda;
-  c.N[P].n_missing = c.N[G].n_missing;
-  c.N[G].lambda = c.N[P].lambda + delta_lambda_across_node_missations(c, G);
-  c.N[G].n_missing = c.N[P].n_missing + iv_num_sites(miss_of(c, G), (int)c.N[G].miss.cnt);
+  nodes_of(c)[P].child0 = X; nodes_of(c)[P].child1 = G;
+  nodes_of(c)[G].parent = P;
+  nodes_of(c)[G].child0 = S; nodes_of(c)[G].child1 = U;
+  nodes_of(c)[S].parent = G;
+  nodes_of(c)[P].lambda = nodes_of(c)[G].lambda;
+  nodes_of(c)[P].n_missing = nodes_of(c)[G].n_missing;
+  nodes_of(c)[G].lambda = nodes_of(c)[P].lambda + delta_lambda_across_node_missations(c, G);
+  nodes_of(c)[G].n_missing = nodes_of(c)[P].n_missing + iv_num_sites(miss_of(c, G), (int)nodes_of(c)[G].miss.cnt);
   c.bytes += 5 * 64;
 }
 EMAT_DN void edit_flip(Ctx& c, Edit& e) {   // tree_editing.cpp:233-278
-  const int X = e.X, P = c.N[X].parent;
-  EMAT_CHECK(c, !is_tip(c, P) && P != c.H->root && nmuts(c, P) == 0);
-  const int G = c.N[P].parent;
+  const int X = e.X, P = nodes_of(c)[X].parent;
+  EMAT_CHECK(c, !is_tip(c, P) && P != hdr_of(c)->root && nmuts(c, P) == 0);
+  const int G = nodes_of(c)[P].parent;
   if (c.failed || G == k_no_node) { EMAT_FAIL(c, k_part_internal); return; }
-  EMAT_CHECK(c, c.N[P].t == c.N[G].t);
+  EMAT_CHECK(c, nodes_of(c)[P].t == nodes_of(c)[G].t);
   const int U = sibling_of(c, G, P);
   const int S = sibling_of(c, P, X);
-  if (c.N[P].miss.cnt != 0) {
+  if (nodes_of(c)[P].miss.cnt != 0) {
     node_merge_missations_from(c, S, P);
     node_merge_missations_from(c, X, P);
-    c.N[P].miss.cnt = 0; c.N[P].mfs.cnt = 0;
+    nodes_of(c)[P].miss.cnt = 0; nodes_of(c)[P].mfs.cnt = 0;
   }
-  if (iv_intersects(miss_of(c, X), (int)c.N[X].miss.cnt, miss_of(c, U), (int)c.N[U].miss.cnt)) node_factor_out_common(c, X, U, P);
-  c.N[G].child0 = S; c.N[G].child1 = P;
-  c.N[S].parent = G;
-  c.N[P].child0 = X; c.N[P].child1 = U;
-  c.N[U].parent = P;
-  c.N[P].lambda = c.N[G].lambda + delta_lambda_across_node_missations(c, P);
-  c.N[P].n_missing = c.N[G].n_missing + iv_num_sites(miss_of(c, P), (int)c.N[P].miss.cnt);
+  if (iv_intersects(miss_of(c, X), (int)nodes_of(c)[X].miss.cnt, miss_of(c, U), (int)nodes_of(c)[U].miss.cnt)) node_factor_out_common(c, X, U, P);
+  nodes_of(c)[G].child0 = S; nodes_of(c)[G].child1 = P;
+  nodes_of(c)[S].parent = G;
+  nodes_of(c)[P].child0 = X; nodes_of(c)[P].child1 = U;
+  nodes_of(c)[U].parent = P;
+  nodes_of(c)[P].lambda = nodes_of(c)[G].lambda + delta_lambda_across_node_missations(c, P);
+  nodes_of(c)[P].n_missing = nodes_of(c)[G].n_missing + iv_num_sites(miss_of(c, P), (int)nodes_of(c)[P].miss.cnt);
   c.bytes += 5 * 64;
 }
 EMAT_D void edit_hop_down(Ctx& c, Edit& e, int SS) {   // tree_editing.cpp:280-292
-  const int P = c.N[e.X].parent;
-  EMAT_CHECK(c, SS != c.H->root);
-  const int U = c.N[SS].parent;
-  EMAT_CHECK(c, c.N[U].parent == P && nmuts(c, U) == 0);
+  const int P = nodes_of(c)[e.X].parent;
+  EMAT_CHECK(c, SS != hdr_of(c)->root);
+  const int U = nodes_of(c)[SS].parent;
+  EMAT_CHECK(c, nodes_of(c)[U].parent == P && nmuts(c, U) == 0);
   if (c.failed) return;
   edit_do_hop_up(c, sibling_of(c, U, SS));
 }
 // spr_move.cpp:1101-1156
 EMAT_DN void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) {
   if (c.failed) return;
-  EMAT_CHECK(c, X != c.H->root);
-  const int P = c.N[X].parent, G = c.N[P].parent, S = sibling_of(c, P, X);
+  EMAT_CHECK(c, X != hdr_of(c)->root);
+  const int P = nodes_of(c)[X].parent, G = nodes_of(c)[P].parent, S = sibling_of(c, P, X);
   if (SS == P) SS = S;
-  int GG = c.N[SS].parent;
+  int GG = nodes_of(c)[SS].parent;
   if (GG == P) GG = G;
   const int A = find_MRCA_of(c, G, GG);
   ScMark mark = sc_mark(c);
@@ -261,26 +260,26 @@ EMAT_DN void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) {
   {   // Tree_editing_session ctor (tree_editing.cpp:7-29)
     const MutRec* m = muts_of(c, X);
     for (int i = 0; i < nmuts(c, X); ++i) sd_push_back(c, e.deltas, m[i].site, m[i].from, m[i].to);
-    c.N[X].muts.cnt = 0;
+    nodes_of(c)[X].muts.cnt = 0;
   }
   int guard = 0;
-  while (!c.failed && c.N[P].parent != A && guard++ < (1 << 24)) {
-    edit_slide_P_along_branch(c, e, c.N[c.N[P].parent].t);
+  while (!c.failed && nodes_of(c)[P].parent != A && guard++ < (1 << 24)) {
+    edit_slide_P_along_branch(c, e, nodes_of(c)[nodes_of(c)[P].parent].t);
     if (c.failed) break;
     edit_do_hop_up(c, X);
   }
   if (!c.failed && !(descends_from(c, S, SS) || descends_from(c, SS, S))) {
     EMAT_CHECK(c, A != k_no_node);
-    if (!c.failed) { edit_slide_P_along_branch(c, e, c.N[A].t); if (!c.failed) edit_flip(c, e); }
+    if (!c.failed) { edit_slide_P_along_branch(c, e, nodes_of(c)[A].t); if (!c.failed) edit_flip(c, e); }
   }
   if (!c.failed) {
     // branches from SS up to (excluding) X's current sibling, walked top-down
     const int Xs_sib = sibling_of(c, P, X);
     int depth = 0;
-    for (int cur = SS; cur != Xs_sib && cur != k_no_node; cur = c.N[cur].parent) ++depth;
+    for (int cur = SS; cur != Xs_sib && cur != k_no_node; cur = nodes_of(c)[cur].parent) ++depth;
     for (int d = depth - 1; d >= 0 && !c.failed; --d) {
-      int Y = SS; for (int k = 0; k < d; ++k) Y = c.N[Y].parent;
-      edit_slide_P_along_branch(c, e, c.N[c.N[Y].parent].t);
+      int Y = SS; for (int k = 0; k < d; ++k) Y = nodes_of(c)[Y].parent;
+      edit_slide_P_along_branch(c, e, nodes_of(c)[nodes_of(c)[Y].parent].t);
       if (c.failed) break;
       edit_hop_down(c, e, Y);
     }
@@ -292,12 +291,12 @@ EMAT_DN void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) {
   if (!c.failed) {   // Tree_editing_session::end (tree_editing.cpp:294-302)
     EMAT_CHECK(c, nmuts(c, X) == 0);
     if (e.deltas.n != 0) {
-      double mut_t = 0.5 * (c.N[X].t + c.N[c.N[X].parent].t);
-      list_reserve<MutRec>(c, c.N[X].muts, e.deltas.n);
+      double mut_t = 0.5 * (nodes_of(c)[X].t + nodes_of(c)[nodes_of(c)[X].parent].t);
+      list_reserve<MutRec>(c, nodes_of(c)[X].muts, e.deltas.n);
       if (!c.failed) {
         MutRec* m = muts_of(c, X);
         for (int i = 0; i < e.deltas.n; ++i) m[i] = make_mut(e.deltas.p[i].from, e.deltas.p[i].site, e.deltas.p[i].to, mut_t);
-        c.N[X].muts.cnt = (uint16_t)e.deltas.n;
+        nodes_of(c)[X].muts.cnt = (uint16_t)e.deltas.n;
       }
     }
   }
@@ -443,10 +442,10 @@ EMAT_D double log_alpha_mut_term(double mu_p, int L, double T, int M, bool is_op
 // ---- rooty grafts -----------------------------------------------------------------------------------------
 EMAT_DN Graft start_rooty_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:91-205
   Graft g; g.X = X; g.rooty = true; g.delta_log_G = g.log_alpha_mut = 0.0;
-  const int P = c.N[X].parent, S = sibling_of(c, P, X);
-  const double t_X = c.N[X].t, t_P = c.N[P].t, t_S = c.N[S].t;
+  const int P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
+  const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t, t_S = nodes_of(c)[S].t;
   g.S = S; g.t_P = t_P;
-  EMAT_CHECK(c, P == c.H->root && c.includes_run_root);
+  EMAT_CHECK(c, P == hdr_of(c)->root && c.includes_run_root);
   g.bi = (BranchInfo*)sc_alloc(c, 3 * sizeof(BranchInfo)); g.nbi = 3;
   if (c.failed) { g.nbi = 0; return g; }
   for (int i = 0; i < 3; ++i) bi_init(g.bi[i]);
@@ -455,26 +454,26 @@ EMAT_DN Graft start_rooty_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:91-2
   BranchInfo& PX = g.bi[k_PX];
   PX.A = P; PX.B = X; PX.is_open = true; PX.T_to_X = t_X - t_P;
   PX.pl_A = -1 * delta_lambda_across_node_missations(c, S);
-  PX.warm = iv_copy_sc(c, miss_of(c, S), (int)c.N[S].miss.cnt); PX.hot = PX.warm;
+  PX.warm = iv_copy_sc(c, miss_of(c, S), (int)nodes_of(c)[S].miss.cnt); PX.hot = PX.warm;
   PX.pl_X = PX.pl_A;
   PX.hot_muts = sc_vec<MutRec>(c, nX);
   for (int i = 0; i < nX; ++i) if (iv_contains(PX.hot.p, PX.hot.n, mX[i].site)) { push(c, PX.hot_muts, mX[i]); PX.pl_X += dq(c, mX[i].site, mX[i].from, mX[i].to); }
   BranchInfo& PS = g.bi[k_PS];
   PS.A = P; PS.B = S; PS.is_open = true; PS.T_to_X = t_S - t_P;
   PS.pl_A = -1 * delta_lambda_across_node_missations(c, X);
-  PS.warm = iv_copy_sc(c, miss_of(c, X), (int)c.N[X].miss.cnt); PS.hot = PS.warm;
+  PS.warm = iv_copy_sc(c, miss_of(c, X), (int)nodes_of(c)[X].miss.cnt); PS.hot = PS.warm;
   PS.pl_X = PS.pl_A;
   PS.hot_muts = sc_vec<MutRec>(c, nS);
   for (int i = 0; i < nS; ++i) if (iv_contains(PS.hot.p, PS.hot.n, mS[i].site)) { push(c, PS.hot_muts, mS[i]); PS.pl_X += dq(c, mS[i].site, mS[i].from, mS[i].to); }
   BranchInfo& SPX = g.bi[k_SPX];
   SPX.A = S; SPX.B = P; SPX.is_open = false; SPX.T_to_X = (t_S - t_P) + (t_X - t_P);
-  SPX.pl_X = c.N[X].lambda - PX.pl_X;
-  SPX.pl_A = c.N[S].lambda - PS.pl_X;
+  SPX.pl_X = nodes_of(c)[X].lambda - PX.pl_X;
+  SPX.pl_A = nodes_of(c)[S].lambda - PS.pl_X;
   {
     IvRec all; all.start = 0; all.end = c.L;
-    SVec<IvRec> s1 = iv_subtract_sc(c, &all, 1, miss_of(c, P), (int)c.N[P].miss.cnt);
-    SVec<IvRec> s2 = iv_subtract_sc(c, s1.p, s1.n, miss_of(c, X), (int)c.N[X].miss.cnt);
-    SVec<IvRec> s3 = iv_subtract_sc(c, s2.p, s2.n, miss_of(c, S), (int)c.N[S].miss.cnt);
+    SVec<IvRec> s1 = iv_subtract_sc(c, &all, 1, miss_of(c, P), (int)nodes_of(c)[P].miss.cnt);
+    SVec<IvRec> s2 = iv_subtract_sc(c, s1.p, s1.n, miss_of(c, X), (int)nodes_of(c)[X].miss.cnt);
+    SVec<IvRec> s3 = iv_subtract_sc(c, s2.p, s2.n, miss_of(c, S), (int)nodes_of(c)[S].miss.cnt);
     SPX.warm = s3; SPX.hot = s3;
   }
   SPX.hot_muts = sc_vec<MutRec>(c, nS + nX);
@@ -484,7 +483,7 @@ EMAT_DN Graft start_rooty_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:91-2
     push(c, SPX.hot_muts, rm); sd_push_back(c, SPX.hot_deltas, rm.site, rm.from, rm.to);
   }
   for (int i = 0; i < nX; ++i) if (iv_contains(SPX.hot.p, SPX.hot.n, mX[i].site)) { push(c, SPX.hot_muts, mX[i]); sd_push_back(c, SPX.hot_deltas, mX[i].site, mX[i].from, mX[i].to); }
-  c.bytes += 3 * 64 + 16 * (nX + nS) + 24 * ((int)c.N[X].miss.cnt + (int)c.N[S].miss.cnt + (int)c.N[P].miss.cnt);
+  c.bytes += 3 * 64 + 16 * (nX + nS) + 24 * ((int)nodes_of(c)[X].miss.cnt + (int)nodes_of(c)[S].miss.cnt + (int)nodes_of(c)[P].miss.cnt);
   return g;
 }
 EMAT_D void filter_not_hot(SVec<MutRec>& v, const SVec<IvRec>& hot) { int w = 0; for (int i = 0; i < v.n; ++i) if (iv_contains(hot.p, hot.n, v.p[i].site)) v.p[w++] = v.p[i]; v.n = w; }
@@ -498,7 +497,7 @@ EMAT_D void recompute_open_pl_A(Ctx& c, BranchInfo& bi) {   // spr_move.cpp:234-
   for (int i = bi.hot_muts.n - 1; i >= 0; --i) bi.pl_A += dq(c, bi.hot_muts.p[i].site, bi.hot_muts.p[i].to, bi.hot_muts.p[i].from);
 }
 EMAT_DN void propose_new_rooty_graft_mutations(Ctx& c, Graft& g) {   // spr_move.cpp:207-244
-  const int X = g.X, P = c.N[X].parent, S = sibling_of(c, P, X);
+  const int X = g.X, P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
   for (int idx = 0; idx < g.nbi && !c.failed; ++idx) {
     BranchInfo& bi = g.bi[idx];
     EMAT_CHECK(c, !bi.is_open || bi.hot_deltas.n == 0);
@@ -507,7 +506,7 @@ EMAT_DN void propose_new_rooty_graft_mutations(Ctx& c, Graft& g) {   // spr_move
       if (nm.n != 0) {
         filter_not_hot(nm, bi.hot);
         int end_branch = (idx == k_PS) ? S : X;
-        adjust_mutational_history(c, nm, bi.hot_deltas, end_branch, c.N[end_branch].t);
+        adjust_mutational_history(c, nm, bi.hot_deltas, end_branch, nodes_of(c)[end_branch].t);
       }
       bi.hot_muts = nm;
       recompute_open_pl_A(c, bi);
@@ -517,8 +516,8 @@ EMAT_DN void propose_new_rooty_graft_mutations(Ctx& c, Graft& g) {   // spr_move
 EMAT_D double log_pi_ratio(const Ctx& c, const MutRec& m) { return log(pi_a(c, m.site, m.from) / pi_a(c, m.site, m.to)); }
 EMAT_DN void finish_rooty_graft_analysis(Ctx& c, Graft& g) {   // spr_move.cpp:246-316
   if (c.failed) return;
-  const int X = g.X, P = c.N[X].parent, S = sibling_of(c, P, X);
-  const double t_X = c.N[X].t, t_P = c.N[P].t, t_S = c.N[S].t;
+  const int X = g.X, P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
+  const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t, t_S = nodes_of(c)[S].t;
   BranchInfo& PX = g.bi[k_PX]; BranchInfo& PS = g.bi[k_PS]; BranchInfo& SPX = g.bi[k_SPX];
   g.delta_log_G = 0.0;
   g.delta_log_G += branch_log_G(c, t_P, t_X, PX.pl_X, PX.hot_muts.p, PX.hot_muts.n);
@@ -541,8 +540,8 @@ EMAT_DN void finish_rooty_graft_analysis(Ctx& c, Graft& g) {   // spr_move.cpp:2
 }
 EMAT_DN void peel_rooty_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:318-431
   if (c.failed) return;
-  const int X = g.X, P = c.N[X].parent, S = sibling_of(c, P, X);
-  const double t_X = c.N[X].t, t_P = c.N[P].t;
+  const int X = g.X, P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
+  const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t;
   const BranchInfo& PX = g.bi[k_PX]; const BranchInfo& PS = g.bi[k_PS]; const BranchInfo& SPX = g.bi[k_SPX];
   ScMark mark = sc_mark(c);
   const int nX = nmuts(c, X), nS = nmuts(c, S);
@@ -551,63 +550,63 @@ EMAT_DN void peel_rooty_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:318-43
   for (int i = 0; i < nX && !c.failed; ++i) if (iv_contains(PX.hot.p, PX.hot.n, mX[i].site)) { sd_push_back(c, r2r, mX[i].site, mX[i].from, mX[i].to); miss_set_from_state(c, S, mX[i].site, mX[i].to); }
   for (int i = 0; i < nS && !c.failed; ++i) if (iv_contains(PS.hot.p, PS.hot.n, mS[i].site)) { sd_push_back(c, r2r, mS[i].site, mS[i].from, mS[i].to); miss_set_from_state(c, X, mS[i].site, mS[i].to); }
   for (int i = 0; i < nS && !c.failed; ++i) if (iv_contains(SPX.hot.p, SPX.hot.n, mS[i].site)) sd_push_back(c, r2r, mS[i].site, mS[i].from, mS[i].to);
-  c.N[X].muts.cnt = 0; c.N[S].muts.cnt = 0; c.N[P].muts.cnt = 0;
+  nodes_of(c)[X].muts.cnt = 0; nodes_of(c)[S].muts.cnt = 0; nodes_of(c)[P].muts.cnt = 0;
   const double t_mut_X = 0.5 * (t_P + t_X);
-  list_reserve<MutRec>(c, c.N[X].muts, SPX.hot_deltas.n);
+  list_reserve<MutRec>(c, nodes_of(c)[X].muts, SPX.hot_deltas.n);
   if (!c.failed) {
     MutRec* m = muts_of(c, X);
     for (int i = 0; i < SPX.hot_deltas.n; ++i) m[i] = make_mut(SPX.hot_deltas.p[i].from, SPX.hot_deltas.p[i].site, SPX.hot_deltas.p[i].to, t_mut_X);
-    c.N[X].muts.cnt = (uint16_t)SPX.hot_deltas.n;
+    nodes_of(c)[X].muts.cnt = (uint16_t)SPX.hot_deltas.n;
   }
   set_root_muts_from_deltas(c, P, r2r);
-  c.N[P].lambda = calc_lambda_at_node(c, P);
+  nodes_of(c)[P].lambda = calc_lambda_at_node(c, P);
   sc_release(c, mark);
 }
 EMAT_DN void apply_rooty_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:433-547
   if (c.failed) return;
-  const int X = g.X, P = c.N[X].parent, S = sibling_of(c, P, X);
-  const double t_X = c.N[X].t, t_P = c.N[P].t, t_S = c.N[S].t;
+  const int X = g.X, P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
+  const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t, t_S = nodes_of(c)[S].t;
   const BranchInfo& PX = g.bi[k_PX]; const BranchInfo& PS = g.bi[k_PS]; const BranchInfo& SPX = g.bi[k_SPX];
   EMAT_CHECK(c, nmuts(c, S) == 0);
   ScMark mark = sc_mark(c);
-  c.N[X].muts.cnt = 0;
+  nodes_of(c)[X].muts.cnt = 0;
   SVec<SdRec> r2r = deltas_from_root_muts(c, P, PX.hot_muts.n + PS.hot_muts.n + SPX.hot_muts.n);
-  c.N[P].muts.cnt = 0;
+  nodes_of(c)[P].muts.cnt = 0;
   for (int i = PX.hot_muts.n - 1; i >= 0 && !c.failed; --i) {
     const MutRec& m = PX.hot_muts.p[i];
-    list_push<MutRec>(c, c.N[X].muts, m);
+    list_push<MutRec>(c, nodes_of(c)[X].muts, m);
     sd_push_back(c, r2r, m.site, m.to, m.from);
     miss_set_from_state(c, S, m.site, m.from);
   }
   for (int i = PS.hot_muts.n - 1; i >= 0 && !c.failed; --i) {
     const MutRec& m = PS.hot_muts.p[i];
-    list_push<MutRec>(c, c.N[S].muts, m);
+    list_push<MutRec>(c, nodes_of(c)[S].muts, m);
     sd_push_back(c, r2r, m.site, m.to, m.from);
     miss_set_from_state(c, X, m.site, m.from);
   }
   for (int i = 0; i < SPX.hot_muts.n && !c.failed; ++i) {
     const MutRec& m = SPX.hot_muts.p[i];
-    if (m.t > t_P) list_push<MutRec>(c, c.N[X].muts, m);
-    else { list_push<MutRec>(c, c.N[S].muts, make_mut(m.to, m.site, m.from, t_P + (t_P - m.t))); sd_push_back(c, r2r, m.site, m.from, m.to); }
+    if (m.t > t_P) list_push<MutRec>(c, nodes_of(c)[X].muts, m);
+    else { list_push<MutRec>(c, nodes_of(c)[S].muts, make_mut(m.to, m.site, m.from, t_P + (t_P - m.t))); sd_push_back(c, r2r, m.site, m.from, m.to); }
   }
   sort_muts(muts_of(c, X), nmuts(c, X)); sort_muts(muts_of(c, S), nmuts(c, S));
   set_root_muts_from_deltas(c, P, r2r);
   clamp_mut_times(muts_of(c, X), nmuts(c, X), t_P, t_X); clamp_mut_times(muts_of(c, S), nmuts(c, S), t_P, t_S);
-  c.N[P].lambda = c.N[X].lambda - delta_lambda_across_branch(c, X);
+  nodes_of(c)[P].lambda = nodes_of(c)[X].lambda - delta_lambda_across_branch(c, X);
   sc_release(c, mark);
 }
 
 // ---- inner grafts -----------------------------------------------------------------------------------------
 EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:582-738
   Graft g; g.X = X; g.rooty = false; g.delta_log_G = g.log_alpha_mut = 0.0; g.nbi = 0; g.bi = nullptr;
-  const int P = c.N[X].parent;
-  EMAT_CHECK(c, X != c.H->root && P != c.H->root);
+  const int P = nodes_of(c)[X].parent;
+  EMAT_CHECK(c, X != hdr_of(c)->root && P != hdr_of(c)->root);
   if (c.failed) return g;
   const int S = sibling_of(c, P, X);
-  const double t_X = c.N[X].t, t_P = c.N[P].t;
+  const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t;
   g.S = S; g.t_P = t_P;
   int depth = 0, path_muts = 0;
-  for (int cur = X; cur != k_no_node; cur = c.N[cur].parent) { ++depth; if (c.includes_run_root || c.N[cur].parent != k_no_node) path_muts += nmuts(c, cur); }
+  for (int cur = X; cur != k_no_node; cur = nodes_of(c)[cur].parent) { ++depth; if (c.includes_run_root || nodes_of(c)[cur].parent != k_no_node) path_muts += nmuts(c, cur); }
   g.bi = (BranchInfo*)sc_alloc(c, (uint32_t)(depth + 2) * (uint32_t)sizeof(BranchInfo));
   if (c.failed) return g;
   const int bi_cap = depth + 2;
@@ -615,47 +614,47 @@ EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:582-
     BranchInfo& PX = g.bi[g.nbi++]; bi_init(PX);
     PX.A = P; PX.B = X; PX.is_open = false; PX.T_to_X = t_X - t_P;
     PX.warm = sc_vec<IvRec>(c, 1); { IvRec all; all.start = 0; all.end = c.L; push(c, PX.warm, all); }
-    PX.hot = iv_subtract_sc(c, PX.warm.p, PX.warm.n, miss_of(c, S), (int)c.N[S].miss.cnt);
+    PX.hot = iv_subtract_sc(c, PX.warm.p, PX.warm.n, miss_of(c, S), (int)nodes_of(c)[S].miss.cnt);
   }
   // sliding_missations = copy of S's missations
-  SVec<IvRec> sl_iv = iv_copy_sc(c, miss_of(c, S), (int)c.N[S].miss.cnt);
-  SVec<FsRec> sl_fs = sc_vec<FsRec>(c, (int)c.N[S].mfs.cnt + path_muts + 1);
-  { const FsRec* f = mfs_of(c, S); for (int i = 0; i < (int)c.N[S].mfs.cnt; ++i) push(c, sl_fs, f[i]); }
+  SVec<IvRec> sl_iv = iv_copy_sc(c, miss_of(c, S), (int)nodes_of(c)[S].miss.cnt);
+  SVec<FsRec> sl_fs = sc_vec<FsRec>(c, (int)nodes_of(c)[S].mfs.cnt + path_muts + 1);
+  { const FsRec* f = mfs_of(c, S); for (int i = 0; i < (int)nodes_of(c)[S].mfs.cnt; ++i) push(c, sl_fs, f[i]); }
   {
     BranchInfo& PX = g.bi[0];
-    PX.pl_A = c.N[X].lambda;
+    PX.pl_A = nodes_of(c)[X].lambda;
     const MutRec* m = muts_of(c, X);
     for (int i = nmuts(c, X) - 1; i >= 0; --i) PX.pl_A += dq(c, m[i].site, m[i].to, m[i].from);
   }
   double next_pl_B = -1 * delta_lambda_across_missations(c, sl_iv.p, sl_iv.n, sl_fs.p, sl_fs.n);
   g.bi[0].pl_A -= next_pl_B;
-  int cur = P, parent = c.N[cur].parent, sibling = sibling_of(c, parent, cur);
+  int cur = P, parent = nodes_of(c)[cur].parent, sibling = sibling_of(c, parent, cur);
   double partial_lambda = next_pl_B;
   while (sl_iv.n != 0 && !c.failed) {
     if (g.nbi >= bi_cap) { EMAT_FAIL(c, k_part_overflow); break; }
     BranchInfo& bi = g.bi[g.nbi++]; bi_init(bi);
-    bi.A = parent; bi.B = cur; bi.is_open = false; bi.T_to_X = t_X - c.N[parent].t;
+    bi.A = parent; bi.B = cur; bi.is_open = false; bi.T_to_X = t_X - nodes_of(c)[parent].t;
     bi.warm = sl_iv;
     const MutRec* mc = muts_of(c, cur);
     for (int i = nmuts(c, cur) - 1; i >= 0; --i) {
       if (iv_contains(sl_iv.p, sl_iv.n, mc[i].site)) { partial_lambda += dq(c, mc[i].site, mc[i].to, mc[i].from); fsv_set(c, sl_fs, mc[i].site, mc[i].from); }
     }
-    bi.hot = iv_subtract_sc(c, bi.warm.p, bi.warm.n, miss_of(c, sibling), (int)c.N[sibling].miss.cnt);
+    bi.hot = iv_subtract_sc(c, bi.warm.p, bi.warm.n, miss_of(c, sibling), (int)nodes_of(c)[sibling].miss.cnt);
     SVec<IvRec> new_sl = iv_subtract_sc(c, bi.warm.p, bi.warm.n, bi.hot.p, bi.hot.n);
     sl_iv = new_sl;
     { int w = 0; for (int i = 0; i < sl_fs.n; ++i) if (iv_contains(sl_iv.p, sl_iv.n, sl_fs.p[i].site)) sl_fs.p[w++] = sl_fs.p[i]; sl_fs.n = w; }
     next_pl_B = -1 * delta_lambda_across_missations(c, sl_iv.p, sl_iv.n, sl_fs.p, sl_fs.n);
     bi.pl_A = partial_lambda - next_pl_B;
     partial_lambda = next_pl_B;
-    c.bytes += 64 + 16 * nmuts(c, cur) + 24 * ((int)c.N[sibling].miss.cnt + bi.warm.n);
-    if (parent != c.H->root) {
-      cur = parent; parent = c.N[cur].parent; sibling = sibling_of(c, parent, cur);
+    c.bytes += 64 + 16 * nmuts(c, cur) + 24 * ((int)nodes_of(c)[sibling].miss.cnt + bi.warm.n);
+    if (parent != hdr_of(c)->root) {
+      cur = parent; parent = nodes_of(c)[cur].parent; sibling = sibling_of(c, parent, cur);
     } else {
       if (!c.includes_run_root) { bi.hot = bi.warm; bi.pl_A += partial_lambda; }
       else if (sl_iv.n != 0) {
         if (g.nbi >= bi_cap) { EMAT_FAIL(c, k_part_overflow); break; }
         BranchInfo& fo = g.bi[g.nbi++]; bi_init(fo);
-        fo.A = k_no_node; fo.B = c.H->root; fo.is_open = true; fo.T_to_X = t_X - c.N[parent].t;
+        fo.A = k_no_node; fo.B = hdr_of(c)->root; fo.is_open = true; fo.T_to_X = t_X - nodes_of(c)[parent].t;
         fo.warm = sl_iv; fo.hot = sl_iv; fo.pl_A = partial_lambda;
       }
       sl_iv.n = 0; sl_fs.n = 0;
@@ -667,7 +666,7 @@ EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:582-
   SVec<Owned> tmp = sc_vec<Owned>(c, path_muts + 1);
   for (int i = 0; i < g.nbi; ++i) {
     BranchInfo& bi_i = g.bi[i];
-    if (bi_i.B == c.H->root) continue;
+    if (bi_i.B == hdr_of(c)->root) continue;
     const MutRec* mb = muts_of(c, bi_i.B);
     for (int k = nmuts(c, bi_i.B) - 1; k >= 0; --k) {
       if (iv_contains(bi_i.warm.p, bi_i.warm.n, mb[k].site)) {
@@ -708,7 +707,7 @@ EMAT_DN void propose_new_inner_graft_mutations(Ctx& c, Graft& g) {   // spr_move
         }
         nm.n = w;
       }
-      adjust_mutational_history(c, nm, bi.hot_deltas, X, c.N[X].t);
+      adjust_mutational_history(c, nm, bi.hot_deltas, X, nodes_of(c)[X].t);
     }
     bi.hot_muts = nm;
     recompute_open_pl_A(c, bi);
@@ -716,7 +715,7 @@ EMAT_DN void propose_new_inner_graft_mutations(Ctx& c, Graft& g) {   // spr_move
 }
 EMAT_DN void finish_inner_graft_analysis(Ctx& c, Graft& g) {   // spr_move.cpp:787-836
   if (c.failed || g.nbi == 0) return;
-  const int X = g.X; const double t_X = c.N[X].t;
+  const int X = g.X; const double t_X = nodes_of(c)[X].t;
   g.delta_log_G = 0.0;
   for (int i = 0; i < g.nbi; ++i) { BranchInfo& bi = g.bi[i]; g.delta_log_G += branch_log_G(c, t_X - bi.T_to_X, t_X, bi.pl_X, bi.hot_muts.p, bi.hot_muts.n); }
   BranchInfo& last = g.bi[g.nbi - 1];
@@ -725,18 +724,18 @@ EMAT_DN void finish_inner_graft_analysis(Ctx& c, Graft& g) {   // spr_move.cpp:7
   for (int i = 0; i < g.nbi; ++i) {
     BranchInfo& bi = g.bi[i];
     int Ls = iv_num_sites(bi.hot.p, bi.hot.n);
-    if (bi.B == X) Ls = (c.L - c.N[X].n_missing) - (iv_num_sites(bi.warm.p, bi.warm.n) - iv_num_sites(bi.hot.p, bi.hot.n));
+    if (bi.B == X) Ls = (c.L - nodes_of(c)[X].n_missing) - (iv_num_sites(bi.warm.p, bi.warm.n) - iv_num_sites(bi.hot.p, bi.hot.n));
     g.log_alpha_mut += log_alpha_mut_term(c.mu_prop, Ls, bi.T_to_X, bi.hot_muts.n, bi.is_open, bi.hot_deltas.n);
   }
 }
 EMAT_D void recalc_lambda_along_hot_path(Ctx& c, const Graft& g) {   // spr_move.cpp:943-950, 1059-1066
-  for (int i = 0; i + 1 < g.nbi; ++i) { int A = g.bi[i].A, B = g.bi[i].B; c.N[A].lambda = c.N[B].lambda - delta_lambda_across_branch(c, B); }
+  for (int i = 0; i + 1 < g.nbi; ++i) { int A = g.bi[i].A, B = g.bi[i].B; nodes_of(c)[A].lambda = nodes_of(c)[B].lambda - delta_lambda_across_branch(c, B); }
 }
-EMAT_D void erase_marked_muts(Ctx& c, int node) { MutRec* m = muts_of(c, node); int n = nmuts(c, node), w = 0; for (int i = 0; i < n; ++i) if (m[i].site != -1) m[w++] = m[i]; c.N[node].muts.cnt = (uint16_t)w; }
+EMAT_D void erase_marked_muts(Ctx& c, int node) { MutRec* m = muts_of(c, node); int n = nmuts(c, node), w = 0; for (int i = 0; i < n; ++i) if (m[i].site != -1) m[w++] = m[i]; nodes_of(c)[node].muts.cnt = (uint16_t)w; }
 EMAT_DN void peel_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:838-953
   if (c.failed || g.nbi == 0) return;
-  const int X = g.X, P = c.N[X].parent, root = c.H->root;
-  const double t_X = c.N[X].t, t_P = c.N[P].t;
+  const int X = g.X, P = nodes_of(c)[X].parent, root = hdr_of(c)->root;
+  const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t;
   const BranchInfo& fin = g.bi[g.nbi - 1];
   ScMark mark = sc_mark(c);
   SVec<SdRec> r2r; r2r.p = nullptr; r2r.n = r2r.cap = 0;
@@ -744,13 +743,13 @@ EMAT_DN void peel_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:838-95
   for (int i = 0; i < g.nbi && !c.failed; ++i) {
     const BranchInfo& bi = g.bi[i];
     if (bi.B == root) continue;
-    if (bi.B == X && !fin.is_open) { c.N[X].muts.cnt = 0; continue; }
+    if (bi.B == X && !fin.is_open) { nodes_of(c)[X].muts.cnt = 0; continue; }
     MutRec* mb = muts_of(c, bi.B);
     for (int k = nmuts(c, bi.B) - 1; k >= 0 && !c.failed; --k) {
       MutRec& m = mb[k];
       if (m.site < 0) continue;
       if (iv_contains(bi.warm.p, bi.warm.n, m.site) && (!fin.is_open || !iv_contains(fin.hot.p, fin.hot.n, m.site))) {
-        for (int cur = X; cur != bi.B; cur = c.N[cur].parent) { int par = c.N[cur].parent; miss_set_from_state(c, sibling_of(c, par, cur), m.site, m.from); }
+        for (int cur = X; cur != bi.B; cur = nodes_of(c)[cur].parent) { int par = nodes_of(c)[cur].parent; miss_set_from_state(c, sibling_of(c, par, cur), m.site, m.from); }
         m.site = -1;
       }
     }
@@ -764,7 +763,7 @@ EMAT_DN void peel_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:838-95
         MutRec& m = mb[k];
         if (m.site < 0) continue;
         if (iv_contains(fin.hot.p, fin.hot.n, m.site)) {
-          for (int cur = bi.B; cur != root; cur = c.N[cur].parent) { int par = c.N[cur].parent; miss_set_from_state(c, sibling_of(c, par, cur), m.site, m.to); }
+          for (int cur = bi.B; cur != root; cur = nodes_of(c)[cur].parent) { int par = nodes_of(c)[cur].parent; miss_set_from_state(c, sibling_of(c, par, cur), m.site, m.to); }
           sd_push_back(c, r2r, m.site, m.from, m.to);
           m.site = -1;
         }
@@ -776,7 +775,7 @@ EMAT_DN void peel_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:838-95
   for (int i = 0; i < g.nbi && !c.failed; ++i) {
     const BranchInfo& bi = g.bi[i];
     if (bi.B == root) continue;
-    for (int k = 0; k < bi.hot_deltas.n; ++k) list_push<MutRec>(c, c.N[X].muts, make_mut(bi.hot_deltas.p[k].from, bi.hot_deltas.p[k].site, bi.hot_deltas.p[k].to, t_mut_X));
+    for (int k = 0; k < bi.hot_deltas.n; ++k) list_push<MutRec>(c, nodes_of(c)[X].muts, make_mut(bi.hot_deltas.p[k].from, bi.hot_deltas.p[k].site, bi.hot_deltas.p[k].to, t_mut_X));
   }
   if (fin.is_open) set_root_muts_from_deltas(c, root, r2r);
   recalc_lambda_along_hot_path(c, g);
@@ -784,31 +783,31 @@ EMAT_DN void peel_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:838-95
 }
 EMAT_DN void apply_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:955-1069
   if (c.failed || g.nbi == 0) return;
-  const int X = g.X, root = c.H->root;
+  const int X = g.X, root = hdr_of(c)->root;
   const BranchInfo& fin = g.bi[g.nbi - 1];
   ScMark mark = sc_mark(c);
-  c.N[X].muts.cnt = 0;
+  nodes_of(c)[X].muts.cnt = 0;
   SVec<SdRec> r2r; r2r.p = nullptr; r2r.n = r2r.cap = 0;
   if (fin.is_open) r2r = deltas_from_root_muts(c, root, fin.hot_muts.n);
   for (int i = 0; i < g.nbi && !c.failed; ++i) {
     const BranchInfo& bi = g.bi[i];
-    if (bi.B == X) { list_assign<MutRec>(c, c.N[X].muts, bi.hot_muts.p, bi.hot_muts.n); continue; }
+    if (bi.B == X) { list_assign<MutRec>(c, nodes_of(c)[X].muts, bi.hot_muts.p, bi.hot_muts.n); continue; }
     if (!bi.is_open) {
       for (int k = 0; k < bi.hot_muts.n && !c.failed; ++k) {
         const MutRec m = bi.hot_muts.p[k];
-        for (int cur = X; cur != bi.A; cur = c.N[cur].parent) {
-          int par = c.N[cur].parent;
-          if (c.N[par].t <= m.t && m.t < c.N[cur].t) { list_push<MutRec>(c, c.N[cur].muts, m); break; }
+        for (int cur = X; cur != bi.A; cur = nodes_of(c)[cur].parent) {
+          int par = nodes_of(c)[cur].parent;
+          if (nodes_of(c)[par].t <= m.t && m.t < nodes_of(c)[cur].t) { list_push<MutRec>(c, nodes_of(c)[cur].muts, m); break; }
           miss_set_from_state(c, sibling_of(c, par, cur), m.site, m.to);
         }
       }
     } else {
       for (int k = bi.hot_muts.n - 1; k >= 0 && !c.failed; --k) {
         const MutRec m = bi.hot_muts.p[k];
-        for (int cur = X; cur != root; cur = c.N[cur].parent) {
-          int par = c.N[cur].parent;
-          if (c.N[par].t <= m.t && m.t < c.N[cur].t) list_push<MutRec>(c, c.N[cur].muts, m);
-          if (c.N[par].t <= m.t) miss_set_from_state(c, sibling_of(c, par, cur), m.site, m.from);
+        for (int cur = X; cur != root; cur = nodes_of(c)[cur].parent) {
+          int par = nodes_of(c)[cur].parent;
+          if (nodes_of(c)[par].t <= m.t && m.t < nodes_of(c)[cur].t) list_push<MutRec>(c, nodes_of(c)[cur].muts, m);
+          if (nodes_of(c)[par].t <= m.t) miss_set_from_state(c, sibling_of(c, par, cur), m.site, m.from);
         }
         sd_push_back(c, r2r, m.site, m.to, m.from);
       }
@@ -816,7 +815,7 @@ EMAT_DN void apply_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:955-1
   }
   for (int i = 0; i < g.nbi; ++i) {
     const BranchInfo& bi = g.bi[i];
-    if (!bi.is_open) { sort_muts(muts_of(c, bi.B), nmuts(c, bi.B)); clamp_mut_times(muts_of(c, bi.B), nmuts(c, bi.B), c.N[bi.A].t, c.N[bi.B].t); }
+    if (!bi.is_open) { sort_muts(muts_of(c, bi.B), nmuts(c, bi.B)); clamp_mut_times(muts_of(c, bi.B), nmuts(c, bi.B), nodes_of(c)[bi.A].t, nodes_of(c)[bi.B].t); }
   }
   if (fin.is_open) set_root_muts_from_deltas(c, root, r2r);
   recalc_lambda_along_hot_path(c, g);
@@ -824,7 +823,7 @@ EMAT_DN void apply_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:955-1
 }
 
 // ---- dispatch (spr_move.cpp:9-89, 549-580, 1071-1099) -------------------------------------------------------
-EMAT_D bool is_rooty(const Ctx& c, int X) { return c.N[X].parent == c.H->root; }
+EMAT_D bool is_rooty(const Ctx& c, int X) { return nodes_of(c)[X].parent == hdr_of(c)->root; }
 EMAT_D Graft analyze_graft(Ctx& c, int X) {
   Graft g;
   if (is_rooty(c, X)) { g = start_rooty_graft_analysis(c, X); finish_rooty_graft_analysis(c, g); }
@@ -863,8 +862,8 @@ struct Study {
 };
 struct WorkItem { int branch, mut_idx, backtracking; };
 
-EMAT_D double region_t_min(Ctx& c, int b, int mi) { if (b == c.H->root) return k_neg_dbl_max; if (mi == 0) return c.N[c.N[b].parent].t; return muts_of(c, b)[mi - 1].t; }
-EMAT_D double region_t_max(Ctx& c, int b, int mi) { if (b == c.H->root) return c.N[b].t; if (mi == nmuts(c, b)) return c.N[b].t; return muts_of(c, b)[mi].t; }
+EMAT_D double region_t_min(Ctx& c, int b, int mi) { if (b == hdr_of(c)->root) return k_neg_dbl_max; if (mi == 0) return nodes_of(c)[nodes_of(c)[b].parent].t; return muts_of(c, b)[mi - 1].t; }
+EMAT_D double region_t_max(Ctx& c, int b, int mi) { if (b == hdr_of(c)->root) return nodes_of(c)[b].t; if (mi == nmuts(c, b)) return nodes_of(c)[b].t; return muts_of(c, b)[mi].t; }
 
 // seed_fill_from (spr_study.cpp:9-24).  `deltas` (cur -> X) is consumed; `missing_at_X` must outlive the call.
 // Regions grow upwards from the scratch top while the DFS work stack grows downwards from the scratch end.
@@ -899,7 +898,7 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
     ++sp; stack_base[-sp].branch = tb; stack_base[-sp].mut_idx = tmi; stack_base[-sp].backtracking = 0;
   };
   add_forward(init_branch, init_mut_idx);
-  const int root = c.H->root;
+  const int root = hdr_of(c)->root;
   while (sp > 0 && !c.failed) {
     WorkItem w = stack_base[-sp]; --sp;
     const int ob = cur_branch, omi = cur_mut_idx;
@@ -944,11 +943,11 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
       // seed_neighbors_except (spr_study.cpp:103-128)
       if (cur_branch != root) {
         if (cur_mut_idx > 0) { if (!(cur_branch == ob && cur_mut_idx - 1 == omi)) add_forward(cur_branch, cur_mut_idx - 1); }
-        else { int pb = c.N[cur_branch].parent, pmi = nmuts(c, pb); if (!(pb == ob && pmi == omi)) add_forward(pb, pmi); }
+        else { int pb = nodes_of(c)[cur_branch].parent, pmi = nmuts(c, pb); if (!(pb == ob && pmi == omi)) add_forward(pb, pmi); }
       }
       if (cur_mut_idx < nmuts(c, cur_branch)) { if (!(cur_branch == ob && cur_mut_idx + 1 == omi)) add_forward(cur_branch, cur_mut_idx + 1); }
       else if (!is_tip(c, cur_branch)) {
-        int c0 = c.N[cur_branch].child0, c1 = c.N[cur_branch].child1;
+        int c0 = nodes_of(c)[cur_branch].child0, c1 = nodes_of(c)[cur_branch].child1;
         if (!(c0 == ob && 0 == omi)) add_forward(c0, 0);
         if (!(c1 == ob && 0 == omi)) add_forward(c1, 0);
       }
@@ -957,7 +956,7 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
   // account_for_Xs_detachment (spr_study.cpp:130-209)
   if (X == k_no_node) { if (!can_change_root) for (int i = 0; i < res.n; ++i) if (res.p[i].branch == root) res.p[i].branch = -1; }
   else {
-    const int P = c.N[X].parent, S = sibling_of(c, P, X);
+    const int P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
     const int nGP = nmuts(c, P);
     for (int i = 0; i < res.n; ++i) {
       Region& region = res.p[i];
@@ -990,7 +989,7 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
 }
 struct RootRegionParams { double f, t_S, s_min, s_max, x_min, x_max; int m; };
 EMAT_D RootRegionParams root_region_params(Ctx& c, const Study& st, const Region& r) {
-  RootRegionParams p; p.f = st.f; p.m = r.min_muts; p.t_S = c.N[r.branch].t;
+  RootRegionParams p; p.f = st.f; p.m = r.min_muts; p.t_S = nodes_of(c)[r.branch].t;
   p.s_min = fabs(st.t_X - p.t_S);
   double t_early = st.t_X < p.t_S ? st.t_X : p.t_S;
   double tree_span = st.t_max_tip - t_early;
@@ -1085,6 +1084,5 @@ EMAT_DN double study_log_alpha_in_region(Ctx& c, const Study& st, int idx, doubl
       + -lgamma(p.f * p.m + 1) - safe_log_gamma_integral(c, p.f * p.m + 1, p.x_min, p.x_max);
 }
 
-}  // namespace dev
+}  // namespace EMAT_DEV_NS
 }  // namespace emat
-#endif  // EMAT_DEVICE_SPR_HPP_

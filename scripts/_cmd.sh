@@ -1,2 +1,3 @@
-for t in 1 4 16 64; do echo "== host threads $t"; EMAT_HOST_THREADS=$t EMAT_VERBOSE=1 python scripts/gpu_probe.py cycle 2>&1 | grep -E "^cycle [12]|emat_run\] repart" | tail -3; done
-python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | grep -o '"value": [0-9.]*\|"kernel_ms": [0-9.]*'
+python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-topology 2>&1 | tail -1 | grep -o '"value": [0-9.]*'
