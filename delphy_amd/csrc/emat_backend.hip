@@ -109,6 +109,7 @@ template <class CtxT, class Step> __device__ __forceinline__ void run_chain(CtxT
   const int64_t dt = (int64_t)(wall_clock64() - tick0);
   H->device_ticks += dt;
   a.part_ticks[part] = dt;
+  a.part_ticks[a.num_parts + part] = (int64_t)tick0;   // start time, for occupancy timelines (emat_debug_part_ticks)
 }
 
 __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
@@ -538,7 +539,7 @@ emat_status materialize(emat_backend* h) {
   h->have_measured_cost = false; h->schedule_valid = false; h->launches_since_balance = 0;
   HIP_TRY(h->d_slabs.upload(h->h_slabs.data(), h->h_slabs.size()));
   HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
-  { std::vector<int64_t> z(h->parts.size(), 0); HIP_TRY(h->d_part_ticks.upload(z.data(), z.size())); }
+  { std::vector<int64_t> z(2 * h->parts.size(), 0); HIP_TRY(h->d_part_ticks.upload(z.data(), z.size())); }
   h->slabs_on_device = true; h->host_slabs_current = true; h->derived_valid = false;
   return EMAT_OK;
 }
@@ -966,6 +967,14 @@ emat_status emat_part_get_trace(emat_backend* h, int32_t part_id, int32_t* num_m
   int n = std::min(*num_moves, H->trace_len);
   std::memcpy(trace, slab + H->off_trace, (size_t)n * 32);
   *num_moves = n;
+  return EMAT_OK;
+}
+/* debugging aid (not part of the boundary): duration and start tick (100 MHz wall clock) of every part in the last pass */
+emat_status emat_debug_part_ticks(emat_backend* h, int64_t* out_2n) {
+  if (!h || !out_2n || h->host_only || !h->slabs_on_device) return EMAT_ERR_INVALID_ARGUMENT;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out_2n, h->d_part_ticks.p, sizeof(int64_t) * 2 * h->parts.size(), hipMemcpyDeviceToHost));
   return EMAT_OK;
 }
 /* debugging aid (not part of the boundary): phase profile of a part, see EMAT_PROFILE_PHASES */

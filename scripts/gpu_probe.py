@@ -163,3 +163,37 @@ def cycle_probe(nparts=8192, moves=1000):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "cycle":
     cycle_probe()
+
+
+def timeline_probe(nparts=8192, moves=1000):
+    """Occupancy timeline of one pass: how many parts are running at each instant (from per-part start ticks and durations)."""
+    import ctypes as C
+    from delphy_amd.sharding import ShardedEngine
+    sc = make_scenario("C4")
+    eng = ShardedEngine(sc, num_parts=nparts, seed=20261001)
+    eng.setup()
+    for _ in range(2):
+        eng.backend.run_moves_per_part(moves); eng.backend.synchronize()
+    ms = eng.backend.last_run_ms()
+    n = eng.num_local_parts
+    buf = (C.c_int64 * (2 * n))()
+    lib = d.load_library()
+    lib.emat_debug_part_ticks.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    assert lib.emat_debug_part_ticks(eng.backend.handle, buf) == 0
+    a = np.array(list(buf), dtype=np.float64)
+    dur, start = a[:n] / 1e5, a[n:] / 1e5   # ms
+    start -= start.min(); end = start + dur
+    print("kernel %.2f ms; parts %d; last end %.2f ms; sum %.0f ms-waves" % (ms, n, end.max(), dur.sum()))
+    edges = np.linspace(0, end.max(), 25)
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        mid = 0.5 * (lo + hi)
+        running = int(((start <= mid) & (end > mid)).sum()); started = int(((start >= lo) & (start < hi)).sum())
+        print("  t=%5.1f ms  running %5d  started in bin %5d" % (mid, running, started))
+    sizes = np.array(eng.local_sizes)
+    late = np.argsort(-end)[:8]
+    for i in late: print("   part %5d nodes %4d start %.1f dur %.1f end %.1f" % (i, sizes[i], start[i], dur[i], end[i]))
+    eng.close()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "timeline":
+    timeline_probe()
