@@ -69,7 +69,9 @@ __device__ inline double wave_sum(double x) {
 // Fills the model pointers of a context; HKY tables come from LDS when they were staged.
 template <class CtxT> __device__ inline void init_ctx(CtxT& c, uint8_t* slab, uint8_t* gslab, const KernelArgs& a, const double* lds_tables) {
   c.S = slab; c.G = gslab; c.H = (SlabHeader*)slab; c.N = (NodeRec*)(slab + c.H->off_nodes);
-  c.L = a.evo.num_sites; c.ref = a.evo.ref_sequence; c.part = a.evo.partition_for_site; c.nu = a.evo.nu_l; c.cumQ = a.evo.cum_Q_l;
+  c.L = a.evo.num_sites;
+  c.ref = (const __attribute__((address_space(1))) uint8_t*)a.evo.ref_sequence; c.part = (const __attribute__((address_space(1))) uint8_t*)a.evo.partition_for_site;
+  c.nu = (const __attribute__((address_space(1))) double*)a.evo.nu_l; c.cumQ = (const __attribute__((address_space(1))) double*)a.evo.cum_Q_l;
   if (lds_tables) { c.mu = lds_tables; c.pi = lds_tables + k_max_lds_partitions; c.q = lds_tables + k_max_lds_partitions * 5; }
   else { c.mu = a.evo.mu; c.pi = a.evo.pi; c.q = a.evo.q; }
   c.pop = a.pop;
@@ -403,6 +405,7 @@ emat_status sync_model_to_device(emat_backend* h) {
   pt.kind = B.pop.kind; pt.skygrid_type = B.pop.skygrid_type; pt.skygrid_num_knots = (int)B.pop.x.size();
   for (int i = 0; i < 4; ++i) pt.p[i] = B.pop.p[i];
   pt.t_c = B.pop.t_c; pt.skygrid_x = B.d_sky_x.p; pt.skygrid_gamma = B.d_sky_g.p;
+  pt.skygrid_inv_dx = (B.pop.x.size() >= 2 && B.pop.x.back() > B.pop.x.front()) ? (double)(B.pop.x.size() - 1) / (B.pop.x.back() - B.pop.x.front()) : 0.0;
   HIP_TRY(B.d_pop.upload(&pt, 1));
   B.model_dirty = false;
   return EMAT_OK;

@@ -54,10 +54,12 @@ struct Ctx {
   NodeRec* N;
   // evolution model: per-site arrays in HBM, per-partition HKY tables in LDS when staged
   int L;
-  const uint8_t* ref;
-  const uint8_t* part;
-  const double* nu;
-  const double* cumQ;
+  // per-site model arrays: always in HBM, typed as global pointers so that they are read with global_load (own
+  // counter, no LDS-aperture check) instead of generic flat_load
+  const __attribute__((address_space(1))) uint8_t* ref;
+  const __attribute__((address_space(1))) uint8_t* part;
+  const __attribute__((address_space(1))) double* nu;
+  const __attribute__((address_space(1))) double* cumQ;
   const double* mu;           // [P]
   const double* pi;           // [P][4]
   const double* q;            // [P][16]
@@ -517,10 +519,17 @@ EMAT_DN int find_MRCA_of(Ctx& c, int P, int Q) {   // phylo_tree.cpp:204-280
 }
 
 // ---- population models (pop_model.cpp:18-145, 181-204, 247-330, 525-560) ------------------------------------------
-EMAT_DF int skygrid_interval(const PopTable& p, double t) {   // lower_bound on knots
-  int lo = 0, hi = p.skygrid_num_knots;
-  while (lo < hi) { int mid = (lo + hi) >> 1; if (p.skygrid_x[mid] < t) lo = mid + 1; else hi = mid; }
-  return lo;   // 0 .. M+1
+// lower_bound on the knots: the first k with x[k] >= t, 0 .. M+1 (pop_model.cpp: std::ranges::lower_bound).  Instead of
+// a binary search (a chain of dependent loads) the index is guessed from the mean knot spacing and then corrected by
+// comparing with the neighbouring knots, which yields exactly the lower_bound result for any knot placement and
+// costs two independent loads when the knots are evenly spaced (the usual Skygrid set-up).
+EMAT_DF int skygrid_interval(const PopTable& p, double t) {
+  const int n = p.skygrid_num_knots;
+  double g = (t - p.skygrid_x[0]) * p.skygrid_inv_dx;
+  int k = g > 0.0 ? (g < (double)n ? (int)g : n) : 0;   // NaN -> 0
+  while (k > 0 && !(p.skygrid_x[k - 1] < t)) --k;
+  while (k < n && p.skygrid_x[k] < t) ++k;
+  return k;
 }
 EMAT_DF double skygrid_log_N(const PopTable& p, double t) {
   int k = skygrid_interval(p, t), M = p.skygrid_num_knots - 1;

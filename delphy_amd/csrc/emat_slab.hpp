@@ -129,6 +129,7 @@ struct PopTable {               // reference Pop_model family (core/pop_model.h)
   int32_t pad;
   double p[4];
   double t_c;                   // Exp_pop_model::t_c_
+  double skygrid_inv_dx;        // (knots - 1) / (x_last - x_first): first guess of the knot interval of a time (0 if degenerate)
   const double* skygrid_x;
   const double* skygrid_gamma;
 };
