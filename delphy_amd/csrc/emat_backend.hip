@@ -19,10 +19,16 @@
 #include <vector>
 
 #include "../../include/emat_backend.h"
-// The device code is compiled twice (see emat_device_core.hpp): `dev_lds` for parts whose slab is staged in LDS,
-// `dev` for parts that run on their HBM slab (and for k_recalc_derived).
+// The device code is compiled three times (see emat_device_core.hpp): `dev_lds` for parts whose whole persistent slab
+// is staged in LDS, `dev_mix` for larger parts of which only header + nodes + cells are staged, and `dev` for parts
+// that run entirely on their HBM slab (and for k_recalc_derived).
 #define EMAT_DEV_NS dev_lds
 #define EMAT_VARIANT_LDS 1
+#include "emat_device_moves.hpp"
+#undef EMAT_DEV_NS
+#undef EMAT_VARIANT_LDS
+#define EMAT_DEV_NS dev_mix
+#define EMAT_VARIANT_LDS 2
 #include "emat_device_moves.hpp"
 #undef EMAT_DEV_NS
 #undef EMAT_VARIANT_LDS
@@ -126,9 +132,13 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
     uint8_t* gslab = a.slabs + a.slab_off[part];
     const SlabHeader* gh = (const SlabHeader*)gslab;
     __syncthreads();
-    // stage the persistent state (header, nodes, cells, trace, list heap); scratch stays in HBM
-    const bool staged = tables_staged && a.lds_slab_bytes != 0 && gh->heap_end <= a.lds_slab_bytes && gh->off_nodes == (uint32_t)sizeof(SlabHeader);
-    if (staged) wave_copy16(lds_slab, gslab, gh->heap_top, lane);
+    // stage the persistent state (header, nodes, cells, trace, list heap) -- or, for a part too large for that, its
+    // fixed-size prefix up to the list heap; scratch always stays in HBM
+    const bool can_stage = tables_staged && a.lds_slab_bytes != 0 && gh->off_nodes == (uint32_t)sizeof(SlabHeader);
+    const bool staged = can_stage && gh->heap_end <= a.lds_slab_bytes;
+    const bool prefix = can_stage && !staged && gh->heap_begin <= a.lds_slab_bytes;
+    const uint32_t staged_bytes = staged ? gh->heap_top : (prefix ? gh->heap_begin : 0u);
+    if (staged_bytes) wave_copy16(lds_slab, gslab, staged_bytes, lane);
     __syncthreads();
     if (lane == 0) {
       // The context lives in LDS, not in private memory: it is touched by almost every instruction.
@@ -137,6 +147,10 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
         init_ctx(c, lds_slab, gslab, a, lds_tables);
         if (a.lds_scratch_bytes) { c.A = lds_slab + a.lds_slab_bytes; c.a_end = a.lds_scratch_bytes; }
         run_chain(c, a, part, (SlabHeader*)lds_slab, [](dev_lds::Ctx& cc) { return dev_lds::mcmc_sub_iteration(cc); });
+      } else if (prefix) {
+        dev_mix::Ctx& c = *(dev_mix::Ctx*)(emat_lds + k_lds_ctx_off);
+        init_ctx(c, lds_slab, gslab, a, lds_tables);
+        run_chain(c, a, part, (SlabHeader*)lds_slab, [](dev_mix::Ctx& cc) { return dev_mix::mcmc_sub_iteration(cc); });
       } else {
         dev::Ctx& c = *(dev::Ctx*)(emat_lds + k_lds_ctx_off);
         init_ctx(c, gslab, gslab, a, tables_staged ? lds_tables : nullptr);
@@ -145,6 +159,7 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
     }
     __syncthreads();
     if (staged) wave_copy16(gslab, lds_slab, ((const SlabHeader*)lds_slab)->heap_top, lane);
+    else if (prefix) wave_copy16(gslab, lds_slab, staged_bytes, lane);
   }
 }
 __global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves(KernelArgs a) { run_moves_body(a); }
@@ -511,10 +526,7 @@ emat_status materialize(emat_backend* h) {
       if (pct >= 100) hi = n;
       if (hi <= lo) { if (last) break; continue; }
       uint32_t need = (v[hi - 1] + 511u) & ~511u;
-      if (need > h->cfg_lds_max) {   // the staging area covers what fits; the rest of the class runs out of HBM
-        size_t fit = lo; while (fit < hi && v[fit] <= h->cfg_lds_max) ++fit;
-        need = fit > lo ? (v[fit - 1] + 511u) & ~511u : 0u;
-      }
+      if (need > h->cfg_lds_max) need = h->cfg_lds_max & ~511u;   // larger parts: prefix-staged or HBM only
       asc.push_back({last ? n : hi, need});
       lo = hi;
       if (last) break;
@@ -970,6 +982,23 @@ emat_status emat_part_get_trace(emat_backend* h, int32_t part_id, int32_t* num_m
   int n = std::min(*num_moves, H->trace_len);
   std::memcpy(trace, slab + H->off_trace, (size_t)n * 32);
   *num_moves = n;
+  return EMAT_OK;
+}
+/* debugging aid (not part of the boundary): how many parts the next launch runs with each code variant
+ * (out3 = {whole slab staged in LDS, prefix staged, HBM only}); mirrors the kernel's per-part decision (single class). */
+emat_status emat_debug_variant_counts(emat_backend* h, int32_t* out3) {
+  if (!h || !out3 || h->host_only) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = sync_model_to_device(h); if (st) return st;
+  st = materialize(h); if (st) return st;
+  st = pull_from_device(h); if (st) return st;
+  out3[0] = out3[1] = out3[2] = 0;
+  const uint32_t area = h->class_lds[std::min(1, h->num_classes - 1)];
+  const bool tables = h->num_partitions <= k_max_lds_partitions;
+  for (auto& ph : h->parts) {
+    const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + ph.slab_off);
+    const bool can = tables && area != 0 && H->off_nodes == (uint32_t)sizeof(SlabHeader);
+    if (can && H->heap_end <= area) ++out3[0]; else if (can && H->heap_begin <= area) ++out3[1]; else ++out3[2];
+  }
   return EMAT_OK;
 }
 /* debugging aid (not part of the boundary): duration and start tick (100 MHz wall clock) of every part in the last pass */

@@ -13,6 +13,8 @@
 //   EMAT_VARIANT_LDS = 1  the part's persistent slab is staged in LDS at a fixed offset of the workgroup's dynamic LDS
 //                         block, so the slab base, header, node array and HKY tables are compile-time LDS addresses
 //                         (ds_read / ds_write with immediate offsets, 32-bit address arithmetic);
+//   EMAT_VARIANT_LDS = 2  only the slab's fixed-size prefix (header, nodes, coalescent cells, trace) is staged, at the
+//                         same LDS offsets; the list heap stays in HBM (parts too large to stage whole);
 //   EMAT_VARIANT_LDS = 0  the slab stays in HBM; base pointers are loaded from the context (generic addressing).
 #ifndef EMAT_DEV_NS
 #error "define EMAT_DEV_NS and EMAT_VARIANT_LDS before including the device headers"
@@ -92,7 +94,13 @@ EMAT_DF NodeRec* nodes_of(const Ctx&) { return (NodeRec*)(emat_lds + k_lds_slab_
 EMAT_DF const double* mu_of(const Ctx&) { return (const double*)emat_lds; }
 EMAT_DF const double* pi_of(const Ctx&) { return (const double*)emat_lds + k_max_lds_partitions; }
 EMAT_DF const double* q_of(const Ctx&) { return (const double*)emat_lds + k_max_lds_partitions * 5; }
+#if EMAT_VARIANT_LDS == 2
+EMAT_DF uint8_t* heap_base_of(const Ctx& c) { return c.G; }   // list offsets are slab-relative: same numbers, HBM base
 #else
+EMAT_DF uint8_t* heap_base_of(const Ctx&) { return emat_lds + k_lds_slab_off; }
+#endif
+#else
+EMAT_DF uint8_t* heap_base_of(const Ctx& c) { return c.S; }
 EMAT_DF uint8_t* slab_of(const Ctx& c) { return c.S; }
 EMAT_DF SlabHeader* hdr_of(const Ctx& c) { return c.H; }
 EMAT_DF NodeRec* nodes_of(const Ctx& c) { return c.N; }
@@ -238,14 +246,14 @@ EMAT_D uint32_t heap_alloc(Ctx& c, uint32_t bytes) {
   hdr_of(c)->heap_top += b;
   return off;
 }
-template <class T> EMAT_D T* list_ptr(Ctx& c, const ListRef& r) { return (T*)(slab_of(c) + r.off); }
+template <class T> EMAT_D T* list_ptr(Ctx& c, const ListRef& r) { return (T*)(heap_base_of(c) + r.off); }
 template <class T> EMAT_D void list_reserve(Ctx& c, ListRef& r, int want) {
   if (want <= (int)r.cap) return;
   int nc = (int)r.cap * 2; if (nc < want) nc = want; if (nc < 4) nc = 4;
   if (nc > 65535) { if (want > 65535) { EMAT_FAIL(c, k_part_overflow); return; } nc = 65535; }
   uint32_t off = heap_alloc(c, (uint32_t)nc * (uint32_t)sizeof(T));
   if (c.failed) return;
-  T* dst = (T*)(slab_of(c) + off); const T* src = (const T*)(slab_of(c) + r.off);
+  T* dst = (T*)(heap_base_of(c) + off); const T* src = (const T*)(heap_base_of(c) + r.off);
   for (int i = 0; i < (int)r.cnt; ++i) dst[i] = src[i];
   r.off = off; r.cap = (uint16_t)nc;
 }
@@ -268,9 +276,9 @@ template <class T> EMAT_D void list_erase_prefix(Ctx& c, ListRef& r, int k) {
 }
 EMAT_D void swap_lists(ListRef& a, ListRef& b) { ListRef t = a; a = b; b = t; }
 
-EMAT_D MutRec* muts_of(Ctx& c, int n) { return (MutRec*)(slab_of(c) + nodes_of(c)[n].muts.off); }
-EMAT_D IvRec* miss_of(Ctx& c, int n) { return (IvRec*)(slab_of(c) + nodes_of(c)[n].miss.off); }
-EMAT_D FsRec* mfs_of(Ctx& c, int n) { return (FsRec*)(slab_of(c) + nodes_of(c)[n].mfs.off); }
+EMAT_D MutRec* muts_of(Ctx& c, int n) { return (MutRec*)(heap_base_of(c) + nodes_of(c)[n].muts.off); }
+EMAT_D IvRec* miss_of(Ctx& c, int n) { return (IvRec*)(heap_base_of(c) + nodes_of(c)[n].miss.off); }
+EMAT_D FsRec* mfs_of(Ctx& c, int n) { return (FsRec*)(heap_base_of(c) + nodes_of(c)[n].mfs.off); }
 EMAT_D int nmuts(const Ctx& c, int n) { return (int)nodes_of(c)[n].muts.cnt; }
 EMAT_D bool is_tip(const Ctx& c, int n) { return nodes_of(c)[n].child0 == k_no_node; }
 EMAT_D int sibling_of(Ctx& c, int parent, int x) {

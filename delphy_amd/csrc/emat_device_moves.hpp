@@ -386,7 +386,7 @@ EMAT_DN bool compact_heap(Ctx& c) {
     const uint32_t es[3] = {16u, 8u, 8u};
     for (int k = 0; k < 3; ++k) {
       uint32_t bytes = (uint32_t)refs[k]->cnt * es[k];
-      const uint64_t* src = (const uint64_t*)(slab_of(c) + refs[k]->off); uint64_t* dst = (uint64_t*)(stage + w);
+      const uint64_t* src = (const uint64_t*)(heap_base_of(c) + refs[k]->off); uint64_t* dst = (uint64_t*)(stage + w);
       for (uint32_t q = 0; q < bytes / 8; ++q) dst[q] = src[q];
       w += (bytes + 15u) & ~15u;
     }
@@ -397,7 +397,7 @@ EMAT_DN bool compact_heap(Ctx& c) {
     const uint32_t es[3] = {16u, 8u, 8u};
     for (int k = 0; k < 3; ++k) {
       uint32_t bytes = (uint32_t)refs[k]->cnt * es[k], padded = (bytes + 15u) & ~15u;
-      const uint64_t* src = (const uint64_t*)(stage + r); uint64_t* dst = (uint64_t*)(slab_of(c) + top);
+      const uint64_t* src = (const uint64_t*)(stage + r); uint64_t* dst = (uint64_t*)(heap_base_of(c) + top);
       for (uint32_t q = 0; q < bytes / 8; ++q) dst[q] = src[q];
       refs[k]->off = top; refs[k]->cap = (uint16_t)(padded / es[k]);
       top += padded; r += padded;

@@ -8,7 +8,7 @@ import pytest
 
 import delphy_amd as d
 from delphy_amd.scenarios import make_scenario
-from helpers import run_parity
+from helpers import configure, run_parity, split_parts
 
 pytestmark = pytest.mark.gpu
 
@@ -64,3 +64,39 @@ def test_site_rate_heterogeneity():
     sc = make_scenario("C1", num_tips=100, num_sites=2000, uncertain_tips=0.2)
     nu = 0.25 + 1.5 * np.random.default_rng(5).random(2000)
     run_parity(sc, 4, 2000, trace=2000, nu_l=nu)
+
+
+def _variant_counts(sc, lds_max, monkeypatch):
+    import ctypes as C
+    if lds_max is None:
+        monkeypatch.delenv("EMAT_LDS_MAX", raising=False)
+    else:
+        monkeypatch.setenv("EMAT_LDS_MAX", str(lds_max))
+    parts, incl, seeds, root_part, ref = split_parts(sc, 4, 23)
+    b = d.EmatBackend(sc.num_sites, trace_moves=200)
+    configure(b, sc, ref, parts, incl, seeds, root_part, None)
+    lib = d.load_library()
+    lib.emat_debug_variant_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    out = (C.c_int32 * 3)()
+    assert lib.emat_debug_variant_counts(b.handle, out) == 0
+    b.close()
+    return list(out)
+
+
+def test_code_variants_whole_prefix_hbm(monkeypatch):
+    """The engine compiles its device code three times (whole slab in LDS / fixed-size prefix in LDS / HBM only) and
+    picks per part; capping the staging area forces each variant in turn, and each must match the oracle."""
+    sc = make_scenario("C1", num_tips=120, num_sites=4000)
+    seen = {}
+    for cap in (None, 32768, 16384, 12288, 10240, 8192, 6144, 4096, 2048, 512):
+        counts = _variant_counts(sc, cap, monkeypatch)   # same decision as the kernel's, evaluated on the host
+        for v in range(3):
+            if counts[v] > 0 and v not in seen:
+                seen[v] = cap
+    assert sorted(seen) == [0, 1, 2], "staging caps tried do not exercise every variant: %s" % seen
+    for v, cap in seen.items():
+        if cap is None:
+            monkeypatch.delenv("EMAT_LDS_MAX", raising=False)
+        else:
+            monkeypatch.setenv("EMAT_LDS_MAX", str(cap))
+        run_parity(sc, 4, 3000, seed=23)
