@@ -145,7 +145,10 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
       if (staged) {
         dev_lds::Ctx& c = *(dev_lds::Ctx*)(emat_lds + k_lds_ctx_off);
         init_ctx(c, lds_slab, gslab, a, lds_tables);
-        if (a.lds_scratch_bytes) { c.A = lds_slab + a.lds_slab_bytes; c.a_end = a.lds_scratch_bytes; }
+        // whatever the part leaves unused of the staging area (plus the optional extra arena) serves as the first-level
+        // scratch arena of its moves; scratch that does not fit goes to the part's HBM scratch region as before
+        const uint32_t used = (gh->heap_end + 15u) & ~15u;
+        c.A = lds_slab + used; c.a_end = a.lds_slab_bytes + a.lds_scratch_bytes - used;
         run_chain(c, a, part, (SlabHeader*)lds_slab, [](dev_lds::Ctx& cc) { return dev_lds::mcmc_sub_iteration(cc); });
       } else if (prefix) {
         dev_mix::Ctx& c = *(dev_mix::Ctx*)(emat_lds + k_lds_ctx_off);
@@ -270,7 +273,7 @@ struct emat_backend {
   hipStream_t class_stream[k_max_classes] = {nullptr, nullptr, nullptr, nullptr};   // class 0 runs on `stream`
   hipEvent_t ev_fork = nullptr, ev_join[k_max_classes] = {nullptr, nullptr, nullptr, nullptr};
   int num_classes = 1; int class_begin[k_max_classes + 1] = {0, 0, 0, 0, 0}; uint32_t class_lds[k_max_classes] = {0, 0, 0, 0};
-  std::vector<int> cfg_class_pct{90};                // EMAT_LDS_CLASSES (tuning knob): percentiles of persistent size that close each class; the last
+  std::vector<int> cfg_class_pct{75};                // EMAT_LDS_CLASSES (tuning knob): percentiles of persistent size that close each class; the last
                                                      // class always extends to the largest part (its staging area is still that percentile's size)
   uint32_t cfg_lds_max = 96 * 1024;                  // EMAT_LDS_MAX (tuning knob): largest staging area; larger parts run out of HBM
   bool schedule_valid = false; int launches_since_balance = 0; int sched_blocks = 0;
@@ -533,6 +536,20 @@ emat_status materialize(emat_backend* h) {
     }
     if (asc.empty()) asc.push_back({n, 0u});
     asc.back().first = n;
+    if (asc.size() == 1 && asc[0].second != 0) {
+      // One class (the default): the percentile only says which parts MUST fit whole.  LDS is the resource that limits
+      // residency, so take the most workgroups per CU (up to the 16 the VGPR budget allows) whose share of the 160 KiB
+      // still holds that percentile, and give every workgroup its whole share: larger parts than asked for get staged
+      // whole at no cost in occupancy, the rest stage their prefix.
+      const uint32_t lds_cu = 160u * 1024u, prefix = k_lds_slab_off + (h->cfg.use_lds ? h->cfg_lds_scratch : 0u);
+      const uint32_t need = asc[0].second;
+      for (uint32_t k = 16; k >= 1; --k) {
+        const uint32_t share = (lds_cu / k) & ~511u;   // LDS is allocated in 512-byte granules
+        if (share <= prefix) continue;
+        const uint32_t area = std::min<uint32_t>((share - prefix) & ~15u, h->cfg_lds_max & ~15u);
+        if (area >= need || k == 1) { asc[0].second = area; break; }
+      }
+    }
     if (!h->cfg.use_lds) { asc.clear(); asc.push_back({n, 0u}); }
     // launch order is descending size: class 0 = the largest parts
     h->num_classes = (int)asc.size();
