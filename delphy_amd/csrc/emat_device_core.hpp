@@ -217,10 +217,21 @@ template <class T> EMAT_D void sc_trim(Ctx& c, SVec<T>& v) {
 }
 // Two containers growing towards each other inside one arena (results upwards from `lo`, a work stack downwards
 // from `hi`); picks the LDS arena when it has at least `min_lds_bytes` free.
-struct ScSpan { uint8_t* lo; uint8_t* hi; bool lds; };
+struct ScSpan { uint8_t* lo; uint8_t* hi; bool lds; bool reserved; };
+// A block of the LDS arena set aside at the start of a topology move for its hottest temporaries (candidate-scan
+// regions and DFS stack, the sets the scan searches per region), before the bulkier and colder graft analysis
+// claims the arena.  Lives until the move's sc_reset; reused by consecutive scans of the move.
+struct HotBlock { uint8_t* p; uint32_t bytes; };
+EMAT_D HotBlock sc_reserve_hot(Ctx& c, uint32_t bytes) {
+  HotBlock h; h.p = nullptr; h.bytes = 0;
+  uint32_t a0 = (c.a_top + 15u) & ~15u;
+  if (c.A != nullptr && c.a_end > a0 && c.a_end - a0 >= bytes) { h.p = c.A + a0; h.bytes = bytes; c.a_top = a0 + bytes; }
+  return h;
+}
 EMAT_D ScSpan sc_span(Ctx& c, uint32_t min_lds_bytes) {
   ScSpan s;
   uint32_t a0 = (c.a_top + 15u) & ~15u;
+  s.reserved = false;
   if (c.a_end > a0 && c.a_end - a0 >= min_lds_bytes) { s.lo = c.A + a0; s.hi = c.A + (c.a_end & ~15u); s.lds = true; return s; }
   uint32_t g0 = (c.sc_top + 15u) & ~15u;
   s.lo = c.G + g0; s.hi = c.G + (hdr_of(c)->scratch_end & ~15u); s.lds = false;
@@ -229,12 +240,14 @@ EMAT_D ScSpan sc_span(Ctx& c, uint32_t min_lds_bytes) {
 }
 EMAT_D ScSpan sc_span_hbm(Ctx& c) {
   ScSpan s; uint32_t g0 = (c.sc_top + 15u) & ~15u;
+  s.reserved = false;
   s.lo = c.G + g0; s.hi = c.G + (hdr_of(c)->scratch_end & ~15u); s.lds = false;
   if (s.hi < s.lo) s.hi = s.lo;
   return s;
 }
 EMAT_D void sc_span_commit(Ctx& c, const ScSpan& s, uint32_t used_bytes) {
   uint32_t u = (used_bytes + 15u) & ~15u;
+  if (s.reserved) return;   // the block stays reserved
   if (s.lds) c.a_top = (uint32_t)(s.lo - c.A) + u; else c.sc_top = (uint32_t)(s.lo - c.G) + u;
 }
 

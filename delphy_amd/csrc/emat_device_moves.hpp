@@ -302,6 +302,7 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   const bool pruning_changes_root = P == hdr_of(c)->root;
   if (pruning_changes_root && !c.includes_run_root) return;
   EMAT_PHASE_BEGIN();
+  const HotBlock hot = (limit == 1) ? sc_reserve_hot(c, 1536) : HotBlock{nullptr, 0};
   Graft old_graft = analyze_graft(c, X);
   peel_graft(c, old_graft);
   EMAT_PHASE(c, 5);
@@ -313,7 +314,7 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   SVec<IvRec> missing_at_X = reconstruct_missing_sites_at(c, X);
   const int n_missing_at_X = iv_num_sites(missing_at_X.p, missing_at_X.n);
   const double lambda_X = nodes_of(c)[X].lambda;
-  SVec<Region> pre_regions = study_seed_fill(c, X, t_X, missing_at_X, limit, old_S, 0, old_deltas, c.includes_run_root);
+  SVec<Region> pre_regions = study_seed_fill(c, X, t_X, missing_at_X, limit, old_S, 0, old_deltas, c.includes_run_root, hot);
   EMAT_PHASE(c, 6);
   hdr_of(c)->phase_ticks[13] += pre_regions.n;
   Study pre = make_study(c, pre_regions, n_missing_at_X, lambda_X, annealing_factor, t_X, c.t_max_tip);
@@ -323,6 +324,7 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   EMAT_CHECK(c, new_S != P);
   const double new_t_P = study_pick_time_in_region(c, pre, new_region);
   const double log_alpha_o2n = study_log_alpha_in_region(c, pre, new_region, new_t_P);
+  const int pre_new_region_min_muts = pre.regions.p[new_region].min_muts;   // the second scan reuses the regions' storage
   const double t_new_S = nodes_of(c)[new_S].t;
   int new_G = nodes_of(c)[new_S].parent;
   if (new_G == P) new_G = old_G;
@@ -338,7 +340,7 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   EMAT_CHECK(c, nodes_of(c)[X].parent == P);
   const int new_min_muts = count_min_mutations(c, new_graft);
   SVec<SdRec> new_deltas = summarize_closed_mutations(c, new_graft, extra);
-  SVec<Region> post_regions = study_seed_fill(c, X, t_X, missing_at_X, limit, new_S, 0, new_deltas, c.includes_run_root);
+  SVec<Region> post_regions = study_seed_fill(c, X, t_X, missing_at_X, limit, new_S, 0, new_deltas, c.includes_run_root, hot);
   EMAT_PHASE(c, 10);
   hdr_of(c)->phase_ticks[13] += post_regions.n;
   Study post = make_study(c, post_regions, n_missing_at_X, lambda_X, annealing_factor, t_X, c.t_max_tip);
@@ -347,7 +349,7 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   EMAT_CHECK(c, old_region != -1);
   if (c.failed) return;
   const double log_alpha_n2o = study_log_alpha_in_region(c, post, old_region, old_t_P);
-  EMAT_CHECK(c, new_min_muts == pre.regions.p[new_region].min_muts);
+  EMAT_CHECK(c, new_min_muts == pre_new_region_min_muts);
   EMAT_CHECK(c, old_min_muts == post.regions.p[old_region].min_muts);
   EMAT_PHASE(c, 11);
   const double d_prior = coal_delta_displace_coalescence(c, old_t_P, new_t_P);

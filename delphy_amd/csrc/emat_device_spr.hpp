@@ -855,24 +855,54 @@ EMAT_DN SVec<SdRec> summarize_closed_mutations(Ctx& c, const Graft& g, int extra
 // =================================================================================================
 // SPR candidate study (spr_study.h:17-171, spr_study.cpp:9-549)
 // =================================================================================================
-struct Region { int branch, mut_idx; double t_min, t_max; int min_muts; int pad; double logW, W; };   // 48 B
+// 48 B, three 16-byte groups: the scan writes the first two with one wide store each, the study fills the third.
+struct alignas(16) Region { int branch, mut_idx, min_muts, pad; double t_min, t_max; double logW, W; };
 struct Study {
   SVec<Region> regions;
   double lambda_X, mu, f, t_X, t_max_tip, log_Wmax, sum_W;
 };
-struct WorkItem { int branch, mut_idx, backtracking; };
+// DFS work item in one 64-bit word (one load / one store per pop / push): branch in the high half, then
+// mut_idx (list sizes are < 2^16) and the backtracking flag in bit 0.
+typedef uint64_t WorkItem;
+EMAT_DF WorkItem wi_make(int branch, int mut_idx, int backtracking) { return ((uint64_t)(uint32_t)branch << 32) | ((uint64_t)(uint32_t)mut_idx << 1) | (uint64_t)(backtracking & 1); }
+EMAT_DF int wi_branch(WorkItem w) { return (int)(uint32_t)(w >> 32); }
+EMAT_DF int wi_mut_idx(WorkItem w) { return (int)((uint32_t)w >> 1); }
+EMAT_DF int wi_backtracking(WorkItem w) { return (int)(w & 1u); }
 
 EMAT_D double region_t_min(Ctx& c, int b, int mi) { if (b == hdr_of(c)->root) return k_neg_dbl_max; if (mi == 0) return nodes_of(c)[nodes_of(c)[b].parent].t; return muts_of(c, b)[mi - 1].t; }
 EMAT_D double region_t_max(Ctx& c, int b, int mi) { if (b == hdr_of(c)->root) return nodes_of(c)[b].t; if (mi == nmuts(c, b)) return nodes_of(c)[b].t; return muts_of(c, b)[mi].t; }
 
 // seed_fill_from (spr_study.cpp:9-24).  `deltas` (cur -> X) is consumed; `missing_at_X` must outlive the call.
 // Regions grow upwards from the scratch top while the DFS work stack grows downwards from the scratch end.
-EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec>& missing_at_X, int max_muts_from_start,
-                                    int init_branch, int init_mut_idx, SVec<SdRec>& deltas, bool can_change_root) {
+EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec>& missing_at_X_in, int max_muts_from_start,
+                                    int init_branch, int init_mut_idx, SVec<SdRec>& deltas_in, bool can_change_root, HotBlock hot) {
   SVec<Region> res; res.p = nullptr; res.n = 0; res.cap = 0;
   if (c.failed) return res;
-  // local scans (the 99% case) start in the LDS arena and migrate to the HBM arena if they outgrow it
-  ScSpan span = (max_muts_from_start == 1) ? sc_span(c, 1024) : sc_span_hbm(c);
+  // Local scans (the 99% case) work out of the move's reserved LDS block when there is one: the two sets that are
+  // searched for every region are copied to its front (a local scan never modifies them), regions and DFS stack
+  // share the rest and migrate to the HBM arena if they outgrow it.  Without a block they start in what is left of
+  // the LDS arena, or in HBM.
+  SVec<IvRec> missing_at_X = missing_at_X_in;
+  SVec<SdRec> deltas_local = deltas_in;
+  const bool local_scan = (max_muts_from_start == 1);
+  ScSpan span;
+  uint32_t front = 0;
+  if (local_scan && hot.p != nullptr) {
+    const uint32_t need = (((uint32_t)missing_at_X_in.n * (uint32_t)sizeof(IvRec) + 15u) & ~15u) + (((uint32_t)deltas_in.n * (uint32_t)sizeof(SdRec) + 15u) & ~15u);
+    if (need + 512u <= hot.bytes) {
+      IvRec* mi = (IvRec*)hot.p; for (int i = 0; i < missing_at_X_in.n; ++i) mi[i] = missing_at_X_in.p[i];
+      front = ((uint32_t)missing_at_X_in.n * (uint32_t)sizeof(IvRec) + 15u) & ~15u;
+      SdRec* di = (SdRec*)(hot.p + front); for (int i = 0; i < deltas_in.n; ++i) di[i] = deltas_in.p[i];
+      missing_at_X.p = mi; deltas_local.p = di; deltas_local.cap = deltas_in.n;
+      front = need;
+    }
+  }
+  SVec<SdRec>& deltas = (front != 0) ? deltas_local : deltas_in;
+  if (front != 0) { span.lo = hot.p + front; span.hi = hot.p + (hot.bytes & ~15u); span.lds = true; span.reserved = true; }
+  else span = local_scan ? sc_span(c, 1024) : sc_span_hbm(c);
+#ifdef EMAT_PROFILE_PHASES
+  if (span.lds) hdr_of(c)->phase_ticks[3] += 1;   // scans that start in the LDS arena
+#endif
   res.p = (Region*)span.lo;
   WorkItem* stack_base = (WorkItem*)span.hi;   // items live at stack_base[-1], [-2], ...
   int sp = 0;
@@ -889,18 +919,27 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
     span = big; res.p = nr; stack_base = nb;
     return true;
   };
+#ifdef EMAT_PROFILE_SEEDFILL
+  long long _sf_t = clock64();
+#define SF_TICK(k) do { long long _n = clock64(); hdr_of(c)->phase_ticks[k] += _n - _sf_t; _sf_t = _n; } while (0)
+#else
+#define SF_TICK(k) do {} while (0)
+#endif
   int cur_branch = k_no_node, cur_mut_idx = -1, cur_from_start = 0;
   int cur_size = deltas.n;
   const bool fast = (max_muts_from_start == 1);
   auto add_forward = [&](int tb, int tmi) {
     if (!room(0, 2)) { EMAT_FAIL(c, k_part_overflow); return; }
-    ++sp; stack_base[-sp].branch = cur_branch; stack_base[-sp].mut_idx = cur_mut_idx; stack_base[-sp].backtracking = 1;
-    ++sp; stack_base[-sp].branch = tb; stack_base[-sp].mut_idx = tmi; stack_base[-sp].backtracking = 0;
+    stack_base[-(sp + 1)] = wi_make(cur_branch, cur_mut_idx, 1);
+    stack_base[-(sp + 2)] = wi_make(tb, tmi, 0);
+    sp += 2;
   };
   add_forward(init_branch, init_mut_idx);
   const int root = hdr_of(c)->root;
   while (sp > 0 && !c.failed) {
-    WorkItem w = stack_base[-sp]; --sp;
+    SF_TICK(4);
+    const WorkItem wi = stack_base[-sp]; --sp;
+    struct { int branch, mut_idx, backtracking; } w = {wi_branch(wi), wi_mut_idx(wi), wi_backtracking(wi)};
     const int ob = cur_branch, omi = cur_mut_idx;
     // move_to_neighbor (spr_study.cpp:43-91)
     if (cur_branch != k_no_node && w.branch == cur_branch) {
@@ -933,13 +972,18 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
       }
     }
     cur_branch = w.branch; cur_mut_idx = w.mut_idx;
+    SF_TICK(0);
     if (!w.backtracking && cur_branch != X && cur_from_start <= max_muts_from_start) {
       // visit_cur_region (spr_study.cpp:93-101)
       if (!room(1, 0)) { EMAT_FAIL(c, k_part_overflow); break; }
-      Region& r = res.p[res.n++];
-      r.branch = cur_branch; r.mut_idx = cur_mut_idx; r.t_min = region_t_min(c, cur_branch, cur_mut_idx); r.t_max = region_t_max(c, cur_branch, cur_mut_idx);
-      r.min_muts = cur_size; r.pad = 0; r.logW = 0.0; r.W = 0.0;
+      {   // logW / W are the study's to fill (make_study); only the two leading 16-byte groups are written here
+        Region* r = &res.p[res.n++];
+        const int4 head = make_int4(cur_branch, cur_mut_idx, cur_size, 0);
+        const double2 times = make_double2(region_t_min(c, cur_branch, cur_mut_idx), region_t_max(c, cur_branch, cur_mut_idx));
+        *(int4*)r = head; *(double2*)&r->t_min = times;
+      }
       c.bytes += 64 + 16;
+      SF_TICK(1);
       // seed_neighbors_except (spr_study.cpp:103-128)
       if (cur_branch != root) {
         if (cur_mut_idx > 0) { if (!(cur_branch == ob && cur_mut_idx - 1 == omi)) add_forward(cur_branch, cur_mut_idx - 1); }
@@ -951,37 +995,42 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
         if (!(c0 == ob && 0 == omi)) add_forward(c0, 0);
         if (!(c1 == ob && 0 == omi)) add_forward(c1, 0);
       }
+      SF_TICK(2);
     }
   }
-  // account_for_Xs_detachment (spr_study.cpp:130-209)
-  if (X == k_no_node) { if (!can_change_root) for (int i = 0; i < res.n; ++i) if (res.p[i].branch == root) res.p[i].branch = -1; }
-  else {
-    const int P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
-    const int nGP = nmuts(c, P);
+  SF_TICK(4);
+  // account_for_Xs_detachment (spr_study.cpp:130-209) and remove_regions_in_Xs_future (:211-224), fused into one
+  // read-modify-compact pass over the regions (each is loaded and stored once, as whole 16-byte groups)
+  int w = 0;
+  {
+    const bool have_X = X != k_no_node;
+    const int P = have_X ? nodes_of(c)[X].parent : k_no_node, S = have_X ? sibling_of(c, P, X) : k_no_node;
+    const int nGP = have_X ? nmuts(c, P) : 0;
+    const int nS = (have_X && P == root) ? nmuts(c, S) : 0;
+    const double t_min_P_end = (have_X && P != root) ? region_t_min(c, P, nGP) : 0.0;
     for (int i = 0; i < res.n; ++i) {
-      Region& region = res.p[i];
-      if (!can_change_root) { if (region.branch == root) { region.branch = -1; continue; } }
-      if (region.branch != S && region.branch != P) continue;
-      if (P != root) {
-        if (region.branch == S) { if (region.mut_idx == 0) region.t_min = region_t_min(c, P, nGP); region.mut_idx += nGP; }
-        else { if (region.mut_idx == nGP) region.branch = -1; else region.branch = S; }
-      } else {
-        if (!can_change_root) { if (region.branch == P) region.branch = -1; }
-        else {
-          if (region.branch == S && region.mut_idx == nmuts(c, S)) { region.mut_idx += nGP; region.t_min = k_neg_dbl_max; }
-          else region.branch = -1;
+      int4 head = *(const int4*)&res.p[i];
+      double2 times = *(const double2*)&res.p[i].t_min;
+      int branch = head.x, mut_idx = head.y;
+      if (!can_change_root && branch == root) continue;
+      if (have_X && (branch == S || branch == P)) {
+        if (P != root) {
+          if (branch == S) { if (mut_idx == 0) times.x = t_min_P_end; mut_idx += nGP; }
+          else { if (mut_idx == nGP) continue; branch = S; }
+        } else {
+          if (!can_change_root) { if (branch == P) continue; }
+          else {
+            if (branch == S && mut_idx == nS) { mut_idx += nGP; times.x = k_neg_dbl_max; }
+            else continue;
+          }
         }
       }
+      if (times.x >= t_X) continue;
+      if (times.y > t_X) times.y = t_X;
+      head.x = branch; head.y = mut_idx;
+      *(int4*)&res.p[w] = head; *(double2*)&res.p[w].t_min = times;
+      ++w;
     }
-  }
-  // remove_regions_in_Xs_future (spr_study.cpp:211-224), fused with the compaction of marked regions
-  int w = 0;
-  for (int i = 0; i < res.n; ++i) {
-    Region r = res.p[i];
-    if (r.branch == -1) continue;
-    if (r.t_min >= t_X) continue;
-    if (r.t_max > t_X) r.t_max = t_X;
-    res.p[w++] = r;
   }
   res.n = w; res.cap = w;
   sc_span_commit(c, span, (uint32_t)w * (uint32_t)sizeof(Region));
