@@ -6,7 +6,8 @@ A "step" is one `emat_run_local_moves` pass (reference Run::run_local_moves, cor
 slabs already resident in HBM.  Default workload = config C4 of SURVEY section 8(d): a seeded synthetic
 100k-tip SARS-CoV-2-like EMAT (29 903 sites, HKY + skygrid) cut by the reference's tree-partitioning rule.
 
-N > 1 (launched by torchrun, one rank per GPU): the parts are sharded across ranks in contiguous blocks;
+N > 1 (launched by torchrun, one rank per GPU): 8192 parts are requested per GPU (the partitioner's minimum part
+size caps what the tree yields) and sharded across ranks in contiguous blocks;
 the only cross-rank exchange is the per-cycle coalescent-grid all-reduce (<= a few KB) done
 before the timed region and a 2-double all-reduce of the log-posterior totals after it.  The tree is fixed
 as N grows => "scaling": "strong".
@@ -31,7 +32,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C4", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--tips", type=int, default=None, help="override the number of tips (debug)")
-    ap.add_argument("--parts", type=int, default=8192, help="number of partition parts requested from the partitioner")
+    ap.add_argument("--parts", type=int, default=None, help="number of partition parts requested from the partitioner (default 8192 per GPU)")
     ap.add_argument("--moves-per-part", type=int, default=1000)
     ap.add_argument("--no-lds", action="store_true")
     ap.add_argument("--no-topology", action="store_true", help="diagnostic: disable subtree-slide and SPR moves")
@@ -90,6 +91,11 @@ def main():
     from delphy_amd.sharding import ShardedEngine
 
     sc = make_scenario(args.workload, num_tips=args.tips)
+    # The reference cuts the tree into as many parts as it has workers (tools/delphy.cpp:130-132); here a worker is a
+    # wavefront slot, ~4 000 per GPU, so the request grows with the number of GPUs.  The tree is the same at every N
+    # ("strong" scaling); the partitioner's minimum part size (10 branches) caps what a 100k-tip tree can yield.
+    if args.parts is None:
+        args.parts = min(8192 * world, 16384)   # this tree yields ~13 000 parts at most; asking for more only unbalances them
     eng = ShardedEngine(sc, num_parts=args.parts, seed=20261001, rank=rank, world=world, device=local_rank, use_lds=not args.no_lds)
     eng.topology = not args.no_topology
     eng.only_displace = args.only_displace

@@ -301,6 +301,8 @@ struct emat_backend {
   bool derived_valid = false;
   uint32_t max_slab_bytes = 0;
   std::vector<uint32_t> persistent_bytes;   // per part: slab size without scratch
+  std::vector<uint32_t> prefix_bytes;       // per part: header + nodes + cells + trace (what the prefix-staged variant keeps in LDS)
+  bool cfg_giants = true;                   // EMAT_GIANTS (tuning knob): parts that cannot even stage their prefix get a class of their own
   double cfg_heap_per_node = 64.0;  // EMAT_HEAP_PER_NODE: heap bytes per node on top of slack x content
   uint32_t cfg_lds_scratch = 0;     // EMAT_LDS_SCRATCH (tuning knob): per-part LDS scratch arena; 0 = all scratch in HBM (measured best at C4)
   bool cfg_balance = false;         // EMAT_BALANCE (tuning knob): 0 = one workgroup per part, no lists
@@ -483,7 +485,7 @@ emat_status materialize(emat_backend* h) {
   if (!h->have_coal) return fail(h, EMAT_ERR_STATE, "emat_build_coalescent_parts must precede running");
   const double slack = h->cfg.slab_slack > 0 ? h->cfg.slab_slack : 3.0;
   const int trace_cap = h->cfg.trace_moves > 0 ? h->cfg.trace_moves : 0;
-  uint64_t off = 0; h->max_slab_bytes = 0; h->persistent_bytes.assign(h->parts.size(), 0);
+  uint64_t off = 0; h->max_slab_bytes = 0; h->persistent_bytes.assign(h->parts.size(), 0); h->prefix_bytes.assign(h->parts.size(), 0);
   struct Geo { uint32_t heap, scratch; int cell_cap; };
   std::vector<Geo> geo(h->parts.size());
   for (size_t p = 0; p < h->parts.size(); ++p) {
@@ -497,11 +499,12 @@ emat_status materialize(emat_backend* h) {
     const uint32_t regions_max = (uint32_t)n + (uint32_t)ph.tree.num_muts();
     g.scratch = a16(std::max<uint32_t>(8192u, 128u * regions_max + 4u * content + 256u * (uint32_t)n));
     int nc = (int)ph.coal.k_bar_p.size();
-    g.cell_cap = ph.includes_run_root ? std::max(nc * 8, nc + 2048) : nc;
+    g.cell_cap = ph.includes_run_root ? nc + std::max(512, nc) : nc;   // room for the root part's grid to grow into the past (a part that outgrows it stops with status 103)
     geo[p] = g;
     uint32_t bytes = (uint32_t)sizeof(SlabHeader) + (uint32_t)n * (uint32_t)sizeof(NodeRec) + a16((uint32_t)g.cell_cap * 36u) + a16((uint32_t)trace_cap * 32u) + g.heap + g.scratch;
     ph.slab_off = off; ph.slab_bytes = bytes; off += bytes;
     h->persistent_bytes[p] = bytes - g.scratch;
+    h->prefix_bytes[p] = bytes - g.scratch - g.heap;
     h->max_slab_bytes = std::max(h->max_slab_bytes, bytes);
   }
   h->h_slabs.assign(off, 0);
@@ -548,6 +551,24 @@ emat_status materialize(emat_backend* h) {
         if (share <= prefix) continue;
         const uint32_t area = std::min<uint32_t>((share - prefix) & ~15u, h->cfg_lds_max & ~15u);
         if (area >= need || k == 1) { asc[0].second = area; break; }
+      }
+      // Giants: a part whose fixed-size prefix does not fit the area would run entirely out of HBM, at less than half
+      // the speed, and -- every part doing the same number of moves -- hold up the whole pass.  Such parts (a handful
+      // per partition) form a class of their own with an area sized for the largest of them.
+      if (h->cfg_giants) {
+        uint32_t smallest_giant = 0xffffffffu, largest = 0;
+        for (size_t p = 0; p < n; ++p) if (h->prefix_bytes[p] > asc[0].second) smallest_giant = std::min(smallest_giant, h->persistent_bytes[p]);
+        if (smallest_giant != 0xffffffffu) {
+          size_t first = std::lower_bound(v.begin(), v.end(), smallest_giant) - v.begin();   // ascending rank where the class starts
+          if (first > 0 && first < n) {
+            for (size_t i = first; i < n; ++i) largest = std::max(largest, v[i]);
+            const uint32_t giant_area = std::min<uint32_t>((largest + 511u) & ~511u, h->cfg_lds_max & ~511u);
+            const uint32_t main_area = asc[0].second;
+            asc.clear();
+            asc.push_back({first, main_area});
+            asc.push_back({n, giant_area});
+          }
+        }
       }
     }
     if (!h->cfg.use_lds) { asc.clear(); asc.push_back({n, 0u}); }
@@ -723,6 +744,7 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
     for (const char* q = e; *q;) { h->cfg_class_pct.push_back(std::max(1, std::min(100, atoi(q)))); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
   }
   if (const char* e = getenv("EMAT_LDS_MAX")) h->cfg_lds_max = (uint32_t)atoi(e) & ~511u;
+  if (const char* e = getenv("EMAT_GIANTS")) h->cfg_giants = atoi(e) != 0;
   if (const char* e = getenv("EMAT_BALANCE")) h->cfg_balance = atoi(e) != 0;
   if (const char* e = getenv("EMAT_SCHED_BLOCKS")) h->cfg_sched_blocks = atoi(e);
   if (const char* e = getenv("EMAT_REBALANCE_EVERY")) h->cfg_rebalance_every = std::max(1, atoi(e));
