@@ -33,7 +33,7 @@ namespace emat {
 extern __shared__ __attribute__((aligned(16))) uint8_t emat_lds[];
 constexpr uint32_t k_lds_tables_bytes = k_max_lds_partitions * (1 + 4 + 16) * 8;   // mu, pi, q per site partition
 constexpr uint32_t k_lds_ctx_off = k_lds_tables_bytes;
-constexpr uint32_t k_lds_ctx_bytes = 384;
+constexpr uint32_t k_lds_ctx_bytes = 256;
 constexpr uint32_t k_lds_slab_off = k_lds_ctx_off + k_lds_ctx_bytes;
 }  // namespace emat
 #define EMAT_D static __device__ inline

@@ -1058,29 +1058,35 @@ EMAT_DN Study make_study(Ctx& c, SVec<Region> regions, int num_missing_at_X, dou
   st.mu = lambda_X / (c.L - num_missing_at_X);
   if (c.failed) return st;
   EMAT_CHECK(c, regions.n > 0);
+  // pass 1: log-weights, with the running maximum (NaN-aware, as std::max(a, b) = (a < b) ? b : a seeded with the first)
+  double log_Wmax = 0.0;
   for (int i = 0; i < regions.n; ++i) {
-    Region& r = regions.p[i];
+    const Region r = regions.p[i];   // head + times: two 16-byte loads
     const int m = r.min_muts;
+    double logW;
     if (r.t_min != k_neg_dbl_max) {
       double t_prime = 0.5 * (r.t_min + r.t_max);
-      r.logW = log(f * lambda_X * (r.t_max - r.t_min)) + f * (-lambda_X * (t_X - t_prime) + m * log(st.mu * (t_X - t_prime) / 3));
+      logW = log(f * lambda_X * (r.t_max - r.t_min)) + f * (-lambda_X * (t_X - t_prime) + m * log(st.mu * (t_X - t_prime) / 3));
     } else {
       RootRegionParams p = root_region_params(c, st, r);
       if (p.x_max < 0.01) {
         double alpha = f * m + 1;
-        r.logW = -k_ln2 + log(f * lambda_X) + f * m * log(st.mu / 3) + alpha * log(p.s_max) + log1p(-pow(p.s_min / p.s_max, alpha)) - log(alpha);
+        logW = -k_ln2 + log(f * lambda_X) + f * m * log(st.mu / 3) + alpha * log(p.s_max) + log1p(-pow(p.s_min / p.s_max, alpha)) - log(alpha);
       } else {
-        r.logW = -k_ln2 + f * m * log(st.mu / (3 * lambda_X * f)) + lgamma(f * m + 1) + safe_log_gamma_integral(c, f * m + 1, p.x_min, p.x_max);
+        logW = -k_ln2 + f * m * log(st.mu / (3 * lambda_X * f)) + lgamma(f * m + 1) + safe_log_gamma_integral(c, f * m + 1, p.x_min, p.x_max);
       }
     }
+    regions.p[i].logW = logW;
+    if (i == 0) log_Wmax = logW; else if (log_Wmax < logW) log_Wmax = logW;
   }
+  // pass 2: normalise by the maximum, weights and their sum (one 16-byte store per region)
   if (regions.n > 0) {
-    st.log_Wmax = regions.p[0].logW;
-    for (int i = 0; i < regions.n; ++i) st.log_Wmax = st.log_Wmax > regions.p[i].logW ? st.log_Wmax : regions.p[i].logW;
-    // NaN-aware max as std::max(a, b) = (a < b) ? b : a
-    st.log_Wmax = regions.p[0].logW;
-    for (int i = 0; i < regions.n; ++i) if (st.log_Wmax < regions.p[i].logW) st.log_Wmax = regions.p[i].logW;
-    for (int i = 0; i < regions.n; ++i) { Region& r = regions.p[i]; r.logW -= st.log_Wmax; r.W = exp(r.logW); st.sum_W += r.W; }
+    st.log_Wmax = log_Wmax;
+    for (int i = 0; i < regions.n; ++i) {
+      const double lw = regions.p[i].logW - log_Wmax, W = exp(lw);
+      *(double2*)&regions.p[i].logW = make_double2(lw, W);
+      st.sum_W += W;
+    }
   }
   c.bytes += 2 * 48 * (int64_t)regions.n;
   return st;

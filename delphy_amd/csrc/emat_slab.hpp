@@ -120,7 +120,7 @@ struct EvoTable {               // reference Global_evo_model (core/evo_model.h:
   const double* pi;                   // [P][4]
   const double* q;                    // [P][4][4]
 };
-constexpr int k_max_lds_partitions = 4;   // HKY tables of up to this many site partitions are staged in LDS
+constexpr int k_max_lds_partitions = 2;   // HKY tables of up to this many site partitions are staged in LDS
 
 struct PopTable {               // reference Pop_model family (core/pop_model.h)
   int32_t kind;                 // emat_pop_model_kind

@@ -1,2 +1,2 @@
 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | grep -o '"value": [0-9.]*\|"kernel_ms": [0-9.]*' | tr '\n' ' '; echo
+EMAT_VERBOSE=1 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | grep -E "classes|value" | sed -E 's/.*classes: (.*)/\1/; s/.*"value": ([0-9.]+).*"ms_per_step": ([0-9.]+).*/value \1 ms \2/'
