@@ -166,6 +166,9 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
   }
 }
 __global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves(KernelArgs a) { run_moves_body(a); }
+// Same body under another name for the side launches of the size classes (the "giants", §4 of DESIGN.md), so that
+// profiles keep the statistics of the main launch -- the one bench.py's roofline is about -- apart.
+__global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves_side(KernelArgs a) { run_moves_body(a); }
 
 // ---- whole-part derived quantities (Subrun::recalc_derived_quantities, subrun.cpp:17-26) ---------------------
 // Lanes stride over the part's nodes: branch-local work (delta lambda across the branch, missing-site count,
@@ -302,6 +305,7 @@ struct emat_backend {
   uint32_t max_slab_bytes = 0;
   std::vector<uint32_t> persistent_bytes;   // per part: slab size without scratch
   std::vector<uint32_t> prefix_bytes;       // per part: header + nodes + cells + trace (what the prefix-staged variant keeps in LDS)
+  int cfg_giant_pct = 0;                    // EMAT_GIANT_PCT (tuning knob): also move the largest N % of the parts into the giants' class
   bool cfg_giants = true;                   // EMAT_GIANTS (tuning knob): parts that cannot even stage their prefix get a class of their own
   double cfg_heap_per_node = 64.0;  // EMAT_HEAP_PER_NODE: heap bytes per node on top of slack x content
   uint32_t cfg_lds_scratch = 0;     // EMAT_LDS_SCRATCH (tuning knob): per-part LDS scratch arena; 0 = all scratch in HBM (measured best at C4)
@@ -558,6 +562,12 @@ emat_status materialize(emat_backend* h) {
       if (h->cfg_giants) {
         uint32_t smallest_giant = 0xffffffffu, largest = 0;
         for (size_t p = 0; p < n; ++p) if (h->prefix_bytes[p] > asc[0].second) smallest_giant = std::min(smallest_giant, h->persistent_bytes[p]);
+        // ... and so do the largest few percent of the parts that only stage their prefix: they are the slowest of the
+        // main launch (their lists live in HBM) and there are too few of them to cost the main launch any occupancy
+        if (h->cfg_giant_pct > 0) {
+          const size_t k = std::min(n - 1, n - std::max<size_t>(1, n * (size_t)h->cfg_giant_pct / 100));
+          if (v[k] > asc[0].second) smallest_giant = std::min(smallest_giant, v[k]);
+        }
         if (smallest_giant != 0xffffffffu) {
           size_t first = std::lower_bound(v.begin(), v.end(), smallest_giant) - v.begin();   // ascending rank where the class starts
           if (first > 0 && first < n) {
@@ -695,19 +705,35 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0) {
   } else {
     // fork: every class runs on its own stream so that the classes share the chip; class 0 (largest parts) first
     const size_t sh_max = shmem_for(*std::max_element(h->class_lds, h->class_lds + h->num_classes));
-    if (sh_max > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_max));
-    if (h->num_classes > 1) HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
-    for (int c = 0; c < h->num_classes; ++c) {
-      const int lo = h->class_begin[c], cnt = h->class_begin[c + 1] - lo;
-      if (cnt <= 0) continue;
-      hipStream_t sm = c == 0 ? h->stream : h->class_stream[c];
-      if (c > 0) HIP_TRY(hipStreamWaitEvent(sm, h->ev_fork, 0));
-      KernelArgs b = a;
-      b.order = a.order + lo; b.lds_slab_bytes = h->class_lds[c];
-      hipLaunchKernelGGL(k_run_moves, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
-      HIP_TRY(hipGetLastError());
-      if (c > 0) { HIP_TRY(hipEventRecord(h->ev_join[c], sm)); HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[c], 0)); }
+    if (sh_max > 48 * 1024) {
+      HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_max));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves_side, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_max));
     }
+    const int main_class = h->num_classes - 1;   // the last class holds the bulk of the parts
+    // The bulk of the parts runs on the engine's own stream (the one the timing events are recorded on); the side
+    // classes fork onto their own streams first, so that their (largest, slowest) parts start at once, and join back.
+    if (h->num_classes > 1) HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int c = 0; c < h->num_classes; ++c) {
+        const bool is_main = c == main_class;
+        if ((pass == 0) == is_main) continue;   // pass 0: side classes, pass 1: the main class
+        const int lo = h->class_begin[c], cnt = h->class_begin[c + 1] - lo;
+        if (cnt <= 0) continue;
+        KernelArgs b = a;
+        b.order = a.order + lo; b.lds_slab_bytes = h->class_lds[c];
+        if (is_main) {
+          hipLaunchKernelGGL(k_run_moves, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), h->stream, b);
+          HIP_TRY(hipGetLastError());
+        } else {
+          hipStream_t sm = h->class_stream[c + 1];
+          HIP_TRY(hipStreamWaitEvent(sm, h->ev_fork, 0));
+          hipLaunchKernelGGL(k_run_moves_side, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
+          HIP_TRY(hipGetLastError());
+          HIP_TRY(hipEventRecord(h->ev_join[c + 1], sm));
+        }
+      }
+    }
+    for (int c = 0; c < h->num_classes - 1; ++c) if (h->class_begin[c + 1] > h->class_begin[c]) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[c + 1], 0));
   }
   HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
   ++h->launches_since_balance;
@@ -745,6 +771,7 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   }
   if (const char* e = getenv("EMAT_LDS_MAX")) h->cfg_lds_max = (uint32_t)atoi(e) & ~511u;
   if (const char* e = getenv("EMAT_GIANTS")) h->cfg_giants = atoi(e) != 0;
+  if (const char* e = getenv("EMAT_GIANT_PCT")) h->cfg_giant_pct = std::max(0, std::min(50, atoi(e)));
   if (const char* e = getenv("EMAT_BALANCE")) h->cfg_balance = atoi(e) != 0;
   if (const char* e = getenv("EMAT_SCHED_BLOCKS")) h->cfg_sched_blocks = atoi(e);
   if (const char* e = getenv("EMAT_REBALANCE_EVERY")) h->cfg_rebalance_every = std::max(1, atoi(e));

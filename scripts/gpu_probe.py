@@ -89,9 +89,13 @@ def phase_probe(nparts=8192, moves=1000):
     buf = (C.c_int64 * 16)()
     tot = np.zeros(16)
     lib.emat_debug_phase_ticks.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    root_local = eng.root_part - eng.part_lo
     for p in range(eng.num_local_parts):
         lib.emat_debug_phase_ticks(eng.backend.handle, p, buf)
         tot += np.array(list(buf), dtype=np.float64)
+        if p == root_local:
+            rp = np.array(list(buf), dtype=np.float64); st = eng.backend.part_stats(p)
+            print("root part %d (%d nodes): simple-move ticks %.3g, topology-move ticks %.3g, proposed %s, device ms %.1f" % (p, st["num_nodes"], rp[14], rp[15], st["proposed"], st["device_ticks"] / 1e5))
     names = ["core:analyze+peel", "core:topology", "core:propose", "(unused)", "core:coal+accept+apply", "spr1:analyze+peel", "spr1:missing+seed_fill pre", "spr1:study pre+pick",
              "spr1:topology", "spr1:propose", "spr1:seed_fill post", "spr1:study post+alpha", "spr1:accept+apply", "regions (count)", "ALL simple moves", "ALL topology moves"]
     total = tot[14] + tot[15]
