@@ -1,1 +1,2 @@
-EMAT_LIB_PATH=$PWD/delphy_amd/libemat_hip_prof.so python scripts/gpu_probe.py phase 2>&1 | grep -E "root part|ALL"
+python bench.py 2>&1 | tail -1 > gpurun_out/bench_r01.json; cut -c1-330 gpurun_out/bench_r01.json
+bash scripts/profile.sh r01 > gpurun_out/profile_r01.log 2>&1; tail -4 gpurun_out/profile_r01.log
