@@ -904,6 +904,79 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
   if (span.lds) hdr_of(c)->phase_ticks[3] += 1;   // scans that start in the LDS arena
 #endif
   res.p = (Region*)span.lo;
+  const int root = hdr_of(c)->root;
+  if (local_scan && deltas.n < 8000) {
+    // ---- local scan (99 % of the scans): at most one counted mutation is crossed inside the scope, so the cur->X delta
+    // set is never modified and its size follows from the INITIAL set (+1 if the crossed site is new, -1 if the
+    // crossing cancels the entry, 0 if it only rewrites it; site_deltas.h:43-83).  That removes the need to undo
+    // anything on the way back: a work item carries the state of the region that pushed it -- {branch, mut_idx,
+    // pusher branch, pusher mut_idx | counted crossings so far << 16 | delta-set size << 18}, one 16-byte load or
+    // store -- and the DFS visits the regions in exactly the order of the general algorithm below.
+    int4* stack_top = (int4*)span.hi;   // items live at stack_top[-1], [-2], ...
+    int sp = 0;
+    auto room = [&](int extra_regions, int extra_items) -> bool {
+      const uint8_t* lo = span.lo + (size_t)(res.n + extra_regions) * sizeof(Region);
+      const uint8_t* hi = span.hi - (size_t)(sp + extra_items) * sizeof(int4);
+      if (lo + 16 <= hi) return true;
+      if (!span.lds) return false;
+      ScSpan big = sc_span_hbm(c);
+      if (big.lo + (size_t)(res.n + extra_regions) * sizeof(Region) + 16 > big.hi - (size_t)(sp + extra_items) * sizeof(int4)) return false;
+      Region* nr = (Region*)big.lo; int4* nb = (int4*)big.hi;
+      for (int i = 0; i < res.n; ++i) nr[i] = res.p[i];
+      for (int i = 1; i <= sp; ++i) nb[-i] = stack_top[-i];
+      span = big; res.p = nr; stack_top = nb;
+      return true;
+    };
+    auto push_item = [&](int tb, int tmi, int pb, int pmi, int fs, int size) {
+      if (!room(0, 1)) { EMAT_FAIL(c, k_part_overflow); return; }
+      ++sp; stack_top[-sp] = make_int4(tb, tmi, pb, (pmi & 0xffff) | (fs << 16) | (size << 18));
+    };
+    push_item(init_branch, init_mut_idx, k_no_node, -1, 0, deltas.n);
+    while (sp > 0 && !c.failed) {
+      const int4 it = stack_top[-sp]; --sp;
+      const int branch = it.x, mut_idx = it.y, pb = it.z, pmi = (int)(int16_t)(it.w & 0xffff);
+      int fs = (it.w >> 16) & 3, size = (int)((uint32_t)it.w >> 18);
+      // move_to_neighbor (spr_study.cpp:43-91)
+      if (pb != k_no_node && branch == pb) {
+        const MutRec* m = muts_of(c, branch);
+        const bool down = (mut_idx == pmi + 1);
+        if (!down && mut_idx != pmi - 1) EMAT_FAIL(c, k_part_internal);
+        const MutRec mm = m[down ? pmi : mut_idx];
+        if (!iv_contains(missing_at_X.p, missing_at_X.n, mm.site)) {
+          if (fs == 0) {
+            const int new_from = down ? (int)mm.to : (int)mm.from;
+            const int kk = sd_lower_bound(deltas.p, deltas.n, mm.site);
+            const bool present = kk < deltas.n && deltas.p[kk].site == mm.site;
+            size = deltas.n + (present ? (new_from == (int)deltas.p[kk].to ? -1 : 0) : +1);
+          }
+          fs += 1;
+        }
+      }
+      if (branch == X || fs > 1) continue;
+      // visit_cur_region (spr_study.cpp:93-101): logW / W are the study's to fill; two 16-byte stores here
+      if (!room(1, 0)) { EMAT_FAIL(c, k_part_overflow); break; }
+      {
+        Region* r = &res.p[res.n++];
+        const int4 head = make_int4(branch, mut_idx, size, 0);
+        const double2 times = make_double2(region_t_min(c, branch, mut_idx), region_t_max(c, branch, mut_idx));
+        *(int4*)r = head; *(double2*)&r->t_min = times;
+      }
+      c.bytes += 64 + 16;
+      // seed_neighbors_except (spr_study.cpp:103-128)
+      const int nm = nmuts(c, branch);
+      if (branch != root) {
+        if (mut_idx > 0) { if (!(branch == pb && mut_idx - 1 == pmi)) push_item(branch, mut_idx - 1, branch, mut_idx, fs, size); }
+        else { const int ub = nodes_of(c)[branch].parent, umi = nmuts(c, ub); if (!(ub == pb && umi == pmi)) push_item(ub, umi, branch, mut_idx, fs, size); }
+      }
+      if (mut_idx < nm) { if (!(branch == pb && mut_idx + 1 == pmi)) push_item(branch, mut_idx + 1, branch, mut_idx, fs, size); }
+      else if (!is_tip(c, branch)) {
+        const int c0 = nodes_of(c)[branch].child0, c1 = nodes_of(c)[branch].child1;
+        if (!(c0 == pb && 0 == pmi)) push_item(c0, 0, branch, mut_idx, fs, size);
+        if (!(c1 == pb && 0 == pmi)) push_item(c1, 0, branch, mut_idx, fs, size);
+      }
+    }
+  } else {
+  // ---- general scan (spr_study.cpp:9-128): the delta set is updated while walking and restored by "backtracking" items
   WorkItem* stack_base = (WorkItem*)span.hi;   // items live at stack_base[-1], [-2], ...
   int sp = 0;
   auto room = [&](int extra_regions, int extra_items) -> bool {
@@ -919,15 +992,8 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
     span = big; res.p = nr; stack_base = nb;
     return true;
   };
-#ifdef EMAT_PROFILE_SEEDFILL
-  long long _sf_t = clock64();
-#define SF_TICK(k) do { long long _n = clock64(); hdr_of(c)->phase_ticks[k] += _n - _sf_t; _sf_t = _n; } while (0)
-#else
-#define SF_TICK(k) do {} while (0)
-#endif
   int cur_branch = k_no_node, cur_mut_idx = -1, cur_from_start = 0;
   int cur_size = deltas.n;
-  const bool fast = (max_muts_from_start == 1);
   auto add_forward = [&](int tb, int tmi) {
     if (!room(0, 2)) { EMAT_FAIL(c, k_part_overflow); return; }
     stack_base[-(sp + 1)] = wi_make(cur_branch, cur_mut_idx, 1);
@@ -935,9 +1001,7 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
     sp += 2;
   };
   add_forward(init_branch, init_mut_idx);
-  const int root = hdr_of(c)->root;
   while (sp > 0 && !c.failed) {
-    SF_TICK(4);
     const WorkItem wi = stack_base[-sp]; --sp;
     struct { int branch, mut_idx, backtracking; } w = {wi_branch(wi), wi_mut_idx(wi), wi_backtracking(wi)};
     const int ob = cur_branch, omi = cur_mut_idx;
@@ -948,31 +1012,12 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
       if (!down && w.mut_idx != cur_mut_idx - 1) EMAT_FAIL(c, k_part_internal);
       const MutRec mm = m[down ? cur_mut_idx : w.mut_idx];
       if (!iv_contains(missing_at_X.p, missing_at_X.n, mm.site)) {
-        if (fast) {
-          // Local scan: at most one counted mutation is ever crossed inside the scope, so the size of the
-          // cur->X delta set follows from the INITIAL set: +1 if the site is new, -1 if the crossing cancels
-          // the entry, 0 if it only rewrites it (site_deltas.h:43-83).  The set itself is never modified.
-          if (!w.backtracking) {
-            if (cur_from_start == 0) {
-              const int new_from = down ? (int)mm.to : (int)mm.from;
-              const int k = sd_lower_bound(deltas.p, deltas.n, mm.site);
-              const bool present = k < deltas.n && deltas.p[k].site == mm.site;
-              cur_size = deltas.n + (present ? (new_from == (int)deltas.p[k].to ? -1 : 0) : +1);
-            }
-            cur_from_start += 1;
-          } else {
-            cur_from_start -= 1;
-            if (cur_from_start == 0) cur_size = deltas.n;
-          }
-        } else {
-          if (down) sd_pop_front(c, deltas, mm.site, mm.from, mm.to); else sd_push_front(c, deltas, mm.site, mm.from, mm.to);
-          cur_from_start += w.backtracking ? -1 : +1;
-          cur_size = deltas.n;
-        }
+        if (down) sd_pop_front(c, deltas, mm.site, mm.from, mm.to); else sd_push_front(c, deltas, mm.site, mm.from, mm.to);
+        cur_from_start += w.backtracking ? -1 : +1;
+        cur_size = deltas.n;
       }
     }
     cur_branch = w.branch; cur_mut_idx = w.mut_idx;
-    SF_TICK(0);
     if (!w.backtracking && cur_branch != X && cur_from_start <= max_muts_from_start) {
       // visit_cur_region (spr_study.cpp:93-101)
       if (!room(1, 0)) { EMAT_FAIL(c, k_part_overflow); break; }
@@ -983,7 +1028,6 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
         *(int4*)r = head; *(double2*)&r->t_min = times;
       }
       c.bytes += 64 + 16;
-      SF_TICK(1);
       // seed_neighbors_except (spr_study.cpp:103-128)
       if (cur_branch != root) {
         if (cur_mut_idx > 0) { if (!(cur_branch == ob && cur_mut_idx - 1 == omi)) add_forward(cur_branch, cur_mut_idx - 1); }
@@ -995,10 +1039,9 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
         if (!(c0 == ob && 0 == omi)) add_forward(c0, 0);
         if (!(c1 == ob && 0 == omi)) add_forward(c1, 0);
       }
-      SF_TICK(2);
     }
   }
-  SF_TICK(4);
+  }
   // account_for_Xs_detachment (spr_study.cpp:130-209) and remove_regions_in_Xs_future (:211-224), fused into one
   // read-modify-compact pass over the regions (each is loaded and stored once, as whole 16-byte groups)
   int w = 0;

@@ -1,2 +1,3 @@
-python bench.py 2>&1 | tail -1 > gpurun_out/bench_r01.json; cut -c1-330 gpurun_out/bench_r01.json
-bash scripts/profile.sh r01 > gpurun_out/profile_r01.log 2>&1; tail -4 gpurun_out/profile_r01.log
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+for i in 1 2; do python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | grep -o '"value": [0-9.]*\|"kernel_ms": [0-9.]*' | tr '\n' ' '; echo; done
+python scripts/gpu_probe.py tail 2>&1 | grep -E "kernel|sum of"
