@@ -149,7 +149,13 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
         // scratch arena of its moves; scratch that does not fit goes to the part's HBM scratch region as before
         const uint32_t used = (gh->heap_end + 15u) & ~15u;
         c.A = lds_slab + used; c.a_end = a.lds_slab_bytes + a.lds_scratch_bytes - used;
+        // The root part is one chain like any other, but its moves walk long runs of coalescent cells (deep branches span
+        // hundreds of cells): compute-bound, the longest chain of the pass and alone in its launch.  Let its wave win
+        // instruction-issue arbitration on its SIMD.
+        const bool is_root_part = (gh->flags & k_flag_includes_run_root) != 0;
+        if (is_root_part) __builtin_amdgcn_s_setprio(3);
         run_chain(c, a, part, (SlabHeader*)lds_slab, [](dev_lds::Ctx& cc) { return dev_lds::mcmc_sub_iteration(cc); });
+        if (is_root_part) __builtin_amdgcn_s_setprio(0);
       } else if (prefix) {
         dev_mix::Ctx& c = *(dev_mix::Ctx*)(emat_lds + k_lds_ctx_off);
         init_ctx(c, lds_slab, gslab, a, lds_tables);
@@ -221,7 +227,7 @@ __global__ void __launch_bounds__(k_wave) k_recalc_derived(KernelArgs a) {
     dev::Cells k = dev::cells_of(c);
     for (int w = lane; w < c.H->n_cells; w += k_wave) {   // very_scalable_coalescent.cpp:355-386
       double na = (double)k.nactive[w];
-      acc_prior -= c.H->t_step / k.popsize[w] * (+0.5 * (k.kbar_p[w] * k.kbar_p[w]) * na - (k.ktw_p[w] * na - k.ktw[w] + 0.5) * k.kbar_p[w]);
+      acc_prior -= k.ts_over_pop[w] * (+0.5 * (k.kbar_p[w] * k.kbar_p[w]) * na - (k.ktw_p[w] * na - k.ktw[w] + 0.5) * k.kbar_p[w]);
     }
   }
   acc_G = wave_sum(acc_G); acc_prior = wave_sum(acc_prior);
@@ -333,7 +339,7 @@ void encode_slab(const emat_backend& B, const PartHost& ph, uint8_t* slab, uint3
   H->status = 0; H->rng_key = ph.rng.key; H->rng_counter = ph.rng.counter; H->rng_spare = ph.rng.spare; H->rng_has_spare = ph.rng.has_spare ? 1u : 0u;
   uint32_t off = sizeof(SlabHeader);
   H->off_nodes = off; off += (uint32_t)n * (uint32_t)sizeof(NodeRec);
-  H->off_cells = off; off += a16((uint32_t)cell_cap * 36u);
+  H->off_cells = off; off += a16((uint32_t)cell_cap * k_cell_bytes);
   H->off_trace = off; off += a16((uint32_t)trace_cap * 32u);
   H->heap_begin = off; H->heap_end = off + heap_bytes;
   H->scratch_begin = H->heap_end; H->scratch_end = H->scratch_begin + scratch_bytes;
@@ -365,7 +371,8 @@ void encode_slab(const emat_backend& B, const PartHost& ph, uint8_t* slab, uint3
   const int nc = (int)ph.coal.k_bar_p.size();
   for (int w = 0; w < nc; ++w) {
     cb[w] = ph.coal.k_bar_p[w]; cb[cell_cap + w] = ph.coal.k_twiddle_bar_p[w]; cb[2 * cell_cap + w] = ph.coal.k_twiddle_bar[w]; cb[3 * cell_cap + w] = ph.coal.popsize_bar[w];
-    ((int32_t*)(cb + 4 * cell_cap))[w] = ph.coal.num_active_parts[w];
+    cb[4 * cell_cap + w] = ph.coal.t_step / ph.coal.popsize_bar[w];   // the factor every cell term starts with, divided once
+    ((int32_t*)(cb + 5 * cell_cap))[w] = ph.coal.num_active_parts[w];
   }
   (void)B;
 }
@@ -405,7 +412,7 @@ void decode_slab(PartHost& ph, const uint8_t* slab) {
   ph.coal.n_cells_total = H->n_cells_total;
   ph.coal.k_bar_p.assign(cb, cb + nc); ph.coal.k_twiddle_bar_p.assign(cb + cap, cb + cap + nc); ph.coal.k_twiddle_bar.assign(cb + 2 * cap, cb + 2 * cap + nc);
   ph.coal.popsize_bar.assign(cb + 3 * cap, cb + 3 * cap + nc);
-  const int32_t* na = (const int32_t*)(cb + 4 * cap); ph.coal.num_active_parts.assign(na, na + nc);
+  const int32_t* na = (const int32_t*)(cb + 5 * cap); ph.coal.num_active_parts.assign(na, na + nc);
 }
 
 emat_status fail(emat_backend* h, emat_status st, const std::string& msg) { h->set_error(msg); return st; }
@@ -505,7 +512,7 @@ emat_status materialize(emat_backend* h) {
     int nc = (int)ph.coal.k_bar_p.size();
     g.cell_cap = ph.includes_run_root ? nc + std::max(512, nc) : nc;   // room for the root part's grid to grow into the past (a part that outgrows it stops with status 103)
     geo[p] = g;
-    uint32_t bytes = (uint32_t)sizeof(SlabHeader) + (uint32_t)n * (uint32_t)sizeof(NodeRec) + a16((uint32_t)g.cell_cap * 36u) + a16((uint32_t)trace_cap * 32u) + g.heap + g.scratch;
+    uint32_t bytes = (uint32_t)sizeof(SlabHeader) + (uint32_t)n * (uint32_t)sizeof(NodeRec) + a16((uint32_t)g.cell_cap * k_cell_bytes) + a16((uint32_t)trace_cap * 32u) + g.heap + g.scratch;
     ph.slab_off = off; ph.slab_bytes = bytes; off += bytes;
     h->persistent_bytes[p] = bytes - g.scratch;
     h->prefix_bytes[p] = bytes - g.scratch - g.heap;
@@ -710,30 +717,35 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0) {
       HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves_side, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_max));
     }
     const int main_class = h->num_classes - 1;   // the last class holds the bulk of the parts
-    // The bulk of the parts runs on the engine's own stream (the one the timing events are recorded on); the side
-    // classes fork onto their own streams first, so that their (largest, slowest) parts start at once, and join back.
-    if (h->num_classes > 1) HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
-    for (int pass = 0; pass < 2; ++pass) {
-      for (int c = 0; c < h->num_classes; ++c) {
-        const bool is_main = c == main_class;
-        if ((pass == 0) == is_main) continue;   // pass 0: side classes, pass 1: the main class
-        const int lo = h->class_begin[c], cnt = h->class_begin[c + 1] - lo;
-        if (cnt <= 0) continue;
-        KernelArgs b = a;
-        b.order = a.order + lo; b.lds_slab_bytes = h->class_lds[c];
-        if (is_main) {
-          hipLaunchKernelGGL(k_run_moves, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), h->stream, b);
-          HIP_TRY(hipGetLastError());
-        } else {
-          hipStream_t sm = h->class_stream[c + 1];
-          HIP_TRY(hipStreamWaitEvent(sm, h->ev_fork, 0));
-          hipLaunchKernelGGL(k_run_moves_side, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
-          HIP_TRY(hipGetLastError());
-          HIP_TRY(hipEventRecord(h->ev_join[c + 1], sm));
-        }
+    // Order matters: a side class holds few, large workgroups (tens of KB of LDS each), which can only be placed while
+    // the CUs are not yet packed with the 10 KB workgroups of the main class -- arriving second they would wait for
+    // several neighbours to finish (measured: the root part started 10-15 ms into the pass).  So the side classes are
+    // launched first, on the engine's own stream, and the main class forks onto a second stream; the timing events on
+    // the engine's stream bracket the fork and the join.
+    HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+    bool forked = false;
+    for (int c = 0; c < h->num_classes; ++c) {
+      const bool is_main = c == main_class;
+      const int lo = h->class_begin[c], cnt = h->class_begin[c + 1] - lo;
+      if (cnt <= 0) continue;
+      KernelArgs b = a;
+      b.order = a.order + lo; b.lds_slab_bytes = h->class_lds[c];
+      if (is_main && h->num_classes > 1) {
+        hipStream_t sm = h->class_stream[1];
+        HIP_TRY(hipStreamWaitEvent(sm, h->ev_fork, 0));
+        hipLaunchKernelGGL(k_run_moves, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(h->ev_join[1], sm));
+        forked = true;
+      } else if (is_main) {
+        hipLaunchKernelGGL(k_run_moves, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), h->stream, b);
+        HIP_TRY(hipGetLastError());
+      } else {   // side classes share the engine's stream: they are few and short-listed, and run back to back
+        hipLaunchKernelGGL(k_run_moves_side, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), h->stream, b);
+        HIP_TRY(hipGetLastError());
       }
     }
-    for (int c = 0; c < h->num_classes - 1; ++c) if (h->class_begin[c + 1] > h->class_begin[c]) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[c + 1], 0));
+    if (forked) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[1], 0));
   }
   HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
   ++h->launches_since_balance;

@@ -619,11 +619,11 @@ EMAT_DN double pop_integral(const PopTable& p, double a, double b) {
 // ---- per-part coalescent prior (very_scalable_coalescent.cpp:14-79, 259-459) ----------------------------------------
 // The part stores only its window of cells [cell_first, cell_first + n_cells): outside it k_bar_p is
 // identically zero for the whole residency, so those cells contribute nothing (cpp:355-386).
-struct Cells { double* kbar_p; double* ktw_p; double* ktw; double* popsize; int32_t* nactive; };
+struct Cells { double* kbar_p; double* ktw_p; double* ktw; double* popsize; double* ts_over_pop; int32_t* nactive; };
 EMAT_D Cells cells_of(Ctx& c) {
   Cells k; int cap = hdr_of(c)->cell_cap;
   double* base = (double*)(slab_of(c) + hdr_of(c)->off_cells);
-  k.kbar_p = base; k.ktw_p = base + cap; k.ktw = base + 2 * cap; k.popsize = base + 3 * cap; k.nactive = (int32_t*)(base + 4 * cap);
+  k.kbar_p = base; k.ktw_p = base + cap; k.ktw = base + 2 * cap; k.popsize = base + 3 * cap; k.ts_over_pop = base + 4 * cap; k.nactive = (int32_t*)(base + 5 * cap);
   return k;
 }
 EMAT_D int cell_for(const Ctx& c, double t) { return (int)floor((hdr_of(c)->t_ref - t) / hdr_of(c)->t_step); }
@@ -645,7 +645,7 @@ EMAT_DN void coal_grow(Ctx& c, int cell) {
       double popsize_bar_i = pop_integral(*c.pop, cell_lbound(c, i), cell_ubound(c, i)) / hdr_of(c)->t_step;
       double sigma = sqrt(popsize_bar_i / hdr_of(c)->t_step);
       double ktw = gaussian(c, 0.0, sigma);
-      k.popsize[w] = popsize_bar_i; k.nactive[w] = 1; k.kbar_p[w] = 1.0; k.ktw_p[w] = ktw; k.ktw[w] = ktw;
+      k.popsize[w] = popsize_bar_i; k.ts_over_pop[w] = hdr_of(c)->t_step / popsize_bar_i; k.nactive[w] = 1; k.kbar_p[w] = 1.0; k.ktw_p[w] = ktw; k.ktw[w] = ktw;
       hdr_of(c)->n_cells_total = i + 1; hdr_of(c)->n_cells = w + 1;
     }
   }
@@ -671,7 +671,7 @@ EMAT_DF void coal_add_interval(Ctx& c, double t_start, double t_end, double delt
 }
 EMAT_DF double coal_cell_term(const Ctx& c, const Cells& k, int w, double new_k, double old_k) {
   double na = (double)k.nactive[w];
-  return hdr_of(c)->t_step / k.popsize[w] * (
+  return k.ts_over_pop[w] * (   // == t_step / popsize_bar[w], the same double, divided when the cell was made
       +0.5 * (new_k * new_k - old_k * old_k) * na
       - (k.ktw_p[w] * na - k.ktw[w] + 0.5) * (new_k - old_k));
 }

@@ -120,6 +120,9 @@ struct EvoTable {               // reference Global_evo_model (core/evo_model.h:
   const double* pi;                   // [P][4]
   const double* q;                    // [P][4][4]
 };
+// coalescent cell table of a part: 5 double arrays (k_bar_p, k_twiddle_bar_p, k_twiddle_bar, popsize_bar, t_step / popsize_bar)
+// + 1 int32 array (num_active_parts), each `cell_cap` long
+constexpr uint32_t k_cell_bytes = 5 * 8 + 4;
 constexpr int k_max_lds_partitions = 2;   // HKY tables of up to this many site partitions are staged in LDS
 
 struct PopTable {               // reference Pop_model family (core/pop_model.h)
