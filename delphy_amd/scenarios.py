@@ -43,7 +43,7 @@ def _skygrid(t_max_tip: float, span: float, n0: float, knots: int = 50, log_line
 
 
 def make_scenario(name: str, num_tips: Optional[int] = None, num_sites: Optional[int] = None, seed: Optional[int] = None,
-                  uncertain_tips: float = 0.0) -> Scenario:
+                  uncertain_tips: float = 0.0, skygrid_log_linear: bool = False) -> Scenario:
     """name in {"C1","C2","C3","C4","C5"}; num_tips / num_sites override the config's size (tests use small ones)."""
     base = 20261001
     if name == "C1":
@@ -76,5 +76,5 @@ def make_scenario(name: str, num_tips: Optional[int] = None, num_sites: Optional
     elif name == "C2":
         pop = PopModel.exp(tmax, 3 * 365.0, 2.0 / 365.0, 1.0)
     else:
-        pop = _skygrid(tmax, p.tip_span * 1.2, 5.0 * 365.0)
+        pop = _skygrid(tmax, p.tip_span * 1.2, 5.0 * 365.0, log_linear=skygrid_log_linear)
     return Scenario(name, tree, ref, tmax, p.mu, p.kappa, PI, pop, p.num_sites)

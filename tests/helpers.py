@@ -20,9 +20,14 @@ def split_parts(sc, num_parts, seed):
     return parts, incl, seeds, root_part, ref
 
 
-def configure(engine, sc, ref, parts, incl, seeds, root_part, t_step=None, topology=True, only_displace=False, nu_l=None):
+def configure(engine, sc, ref, parts, incl, seeds, root_part, t_step=None, topology=True, only_displace=False, nu_l=None, evo=None):
+    """`evo` = (mu[P], pi[P][4], q[P][4][4], partition_for_site[L]) replaces the scenario's single HKY partition."""
     engine.set_ref_sequence(ref)
-    engine.set_hky(sc.mu, sc.kappa, sc.pi, nu_l)
+    if evo is not None:
+        mu, pi, q, pfs = evo
+        engine.set_evo(mu, pi, q, nu_l if nu_l is not None else np.ones(sc.num_sites), pfs)
+    else:
+        engine.set_hky(sc.mu, sc.kappa, sc.pi, nu_l)
     engine.set_flags(sc.t_max_tip, only_displace, topology)
     engine.upload_parts(parts, incl, seeds)
     engine.build_coalescent_parts(sc.pop, root_part, t_step if t_step is not None else sc.default_t_step())
@@ -60,14 +65,17 @@ def assert_traces_match(trg, tro, tol=1e-9, what=""):
             assert abs(kg[3] - ko[3]) <= tol * max(1.0, abs(ko[3])), "%s: move %d log_mh %r vs %r" % (what, i, kg[3], ko[3])
 
 
-def run_parity(sc, num_parts, moves_per_part, seed=11, topology=True, only_displace=False, trace=200, use_lds=True, t_step=None, nu_l=None, tol=1e-9):
+def run_parity(sc, num_parts, moves_per_part, seed=11, topology=True, only_displace=False, trace=200, use_lds=True, t_step=None, nu_l=None, tol=1e-9,
+               evo=None, total_moves=None):
+    """`total_moves`: drive both engines through run_local_moves(total) (reference Run::run_local_moves: count / parts each,
+    remainder to part 0) instead of the same count on every part."""
     """Run the same seeded scenario through the HIP engine and the oracle and compare everything."""
     parts, incl, seeds, root_part, ref = split_parts(sc, num_parts, seed)
     gpu = d.EmatBackend(sc.num_sites, trace_moves=trace, use_lds=use_lds)
     orc = OracleEngine(sc.num_sites, trace_moves=trace)
     try:
-        configure(gpu, sc, ref, parts, incl, seeds, root_part, t_step, topology, only_displace, nu_l)
-        configure(orc, sc, ref, parts, incl, seeds, root_part, t_step, topology, only_displace, nu_l)
+        configure(gpu, sc, ref, parts, incl, seeds, root_part, t_step, topology, only_displace, nu_l, evo)
+        configure(orc, sc, ref, parts, incl, seeds, root_part, t_step, topology, only_displace, nu_l, evo)
         # derived quantities from scratch
         for p in range(len(parts)):
             n = parts[p].num_nodes
@@ -77,14 +85,20 @@ def run_parity(sc, num_parts, moves_per_part, seed=11, topology=True, only_displ
             assert rel_close(lg, lo, 1e-11), "part %d lambda_i max diff %g" % (p, np.max(np.abs(lg - lo)))
             assert rel_close(Gg, Go, tol) and rel_close(Ag, Ao, tol), "part %d log_G %r/%r prior %r/%r" % (p, Gg, Go, Ag, Ao)
         if moves_per_part > 0:
-            gpu.run_moves_per_part(moves_per_part)
-            gpu.synchronize()
-            orc.run_moves_per_part(moves_per_part, threads=4)
+            if total_moves is not None:
+                gpu.run_local_moves(total_moves)
+                gpu.synchronize()
+                orc.run_local_moves(total_moves, threads=4)
+            else:
+                gpu.run_moves_per_part(moves_per_part)
+                gpu.synchronize()
+                orc.run_moves_per_part(moves_per_part, threads=4)
             for p in range(len(parts)):
+                expected_moves = moves_per_part if total_moves is None else total_moves // len(parts) + (total_moves - len(parts) * (total_moves // len(parts)) if p == 0 else 0)
                 sg, so = gpu.part_stats(p), orc.part_stats(p)
                 assert sg["status"] == 0, "part %d device status %d: %s" % (p, sg["status"], gpu.last_error())
                 assert_traces_match(gpu.part_trace(p, trace), orc.part_trace(p, trace), tol, "part %d" % p)
-                assert sg["moves_done"] == so["moves_done"] == moves_per_part
+                assert sg["moves_done"] == so["moves_done"] == expected_moves
                 assert sg["proposed"] == so["proposed"] and sg["accepted"] == so["accepted"], "part %d counters %s vs %s" % (p, sg, so)
                 assert sg["rng_draws"] == so["rng_draws"], "part %d rng draws %d vs %d" % (p, sg["rng_draws"], so["rng_draws"])
                 assert_trees_match(gpu.part_download(p), orc.part_download(p), tol, "part %d" % p)

@@ -100,3 +100,26 @@ def test_code_variants_whole_prefix_hbm(monkeypatch):
         else:
             monkeypatch.setenv("EMAT_LDS_MAX", str(cap))
         run_parity(sc, 4, 3000, seed=23)
+
+
+def test_two_site_partitions():
+    """Two site partitions with their own mu / HKY tables (the reference's mpox set-up, run.cpp:400-435): per-partition
+    tables are staged in LDS, the partition map is read per site."""
+    sc = make_scenario("C1", num_tips=90, num_sites=6000)
+    pi2 = np.array([0.1, 0.4, 0.3, 0.2])
+    mu = np.array([sc.mu, 3.0 * sc.mu])
+    pi = np.stack([np.asarray(sc.pi, np.float64), pi2])
+    q = np.stack([d.hky_q_matrix(sc.kappa, sc.pi), d.hky_q_matrix(2.0, pi2)])
+    pfs = (np.arange(sc.num_sites) // 500 % 2).astype(np.int32)
+    run_parity(sc, 3, 4000, seed=31, evo=(mu, pi, q, pfs))
+
+
+def test_skygrid_log_linear():
+    sc = make_scenario("C3", num_tips=150, num_sites=5000, skygrid_log_linear=True)
+    run_parity(sc, 4, 3000, seed=37)
+
+
+def test_run_local_moves_remainder_goes_to_part_zero():
+    """Run::run_local_moves (run.cpp:682-693): count / parts moves on every part, the remainder on part 0."""
+    sc = make_scenario("C1", num_tips=80, num_sites=3000)
+    run_parity(sc, 3, 1, seed=41, total_moves=3 * 1500 + 2, trace=0)
