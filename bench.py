@@ -79,10 +79,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # EMAT_BENCH_SHARED_GPU=1 is a plumbing check for boxes with ONE GPU: every rank uses cuda:0 and the collectives go
+    # over gloo (RCCL refuses two ranks on one device).  It exercises the multi-rank control flow, not RCCL, and its
+    # numbers mean nothing; the driver never sets it.
+    shared_gpu = world > 1 and os.environ.get("EMAT_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the EMAT engine has no CPU fallback")
 
@@ -96,7 +105,13 @@ def main():
     # ("strong" scaling); the partitioner's minimum part size (10 branches) caps what a 100k-tip tree can yield.
     if args.parts is None:
         args.parts = min(8192 * world, 16384)   # this tree yields ~13 000 parts at most; asking for more only unbalances them
-    eng = ShardedEngine(sc, num_parts=args.parts, seed=20261001, rank=rank, world=world, device=local_rank, use_lds=not args.no_lds)
+    allreduce = None
+    if shared_gpu:
+        def allreduce(arr, op):
+            t = torch.from_numpy(np.ascontiguousarray(arr))
+            dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op])
+            return t.numpy()
+    eng = ShardedEngine(sc, num_parts=args.parts, seed=20261001, rank=rank, world=world, device=local_rank, use_lds=not args.no_lds, allreduce=allreduce)
     eng.topology = not args.no_topology
     eng.only_displace = args.only_displace
     eng.setup()   # partition, upload this rank's parts, exchange the coalescent grid, recalc derived quantities
@@ -127,7 +142,7 @@ def main():
         ev_ms.append(eng.backend.last_run_ms())
     stats1 = eng.local_stats()
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     total_parts = eng.total_parts
@@ -143,7 +158,8 @@ def main():
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc_path):
+    # the committed PMC figure was collected on the default single-GPU workload: only quote it for that one
+    if os.path.exists(pmc_path) and world == 1 and args.workload == "C4" and args.tips is None and args.parts == 8192 and args.moves_per_part == 1000 and not (args.no_topology or args.only_displace or args.no_lds):
         try:
             traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
         except Exception:
