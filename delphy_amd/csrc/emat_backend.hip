@@ -51,6 +51,8 @@ struct KernelArgs {
   const int32_t* block_begin;     // [num_blocks + 1] workgroup b runs parts order[block_begin[b] .. block_begin[b+1]) one after the other
   int64_t* part_ticks;            // [num_parts] wall-clock ticks of each part's last run (feeds the host's load balancer)
   const int32_t* ref_freqs;       // [P][4]
+  const double* cum_nu;           // [L + 1][P][4]: nu-weighted counts of reference states per site partition over sites < k (k_global_stats)
+  double* stats_out;              // [num_parts][k_stats_row]: per-part output of k_global_stats
   EvoTable evo;
   const PopTable* pop;
   RunFlags flags;
@@ -176,6 +178,88 @@ __global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves(KernelA
 // profiles keep the statistics of the main launch -- the one bench.py's roofline is about -- apart.
 __global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves_side(KernelArgs a) { run_moves_body(a); }
 
+// ---- sufficient statistics of the global moves (calc_Ttwiddle_beta_a phylo_tree_calc.cpp:288-369, calc_num_muts_beta_ab
+//      :599-610, calc_num_muts :577-585), one part per workgroup ---------------------------------------------------------
+// n^beta_a(node) = nu-weighted number of sites of partition beta present in state a at the node.  Its change across a
+// branch comes from the branch's missation intervals (two gathers into a prefix table over the reference sequence
+// instead of the reference's site-by-site loop), from_states and mutations: lane-parallel over the nodes.  The
+// values themselves follow from a pre-order accumulation (lane 0), and the statistics are sums over the non-root
+// branches, again lane-parallel, reduced across lanes in a fixed order so that the result is reproducible.
+constexpr int k_max_stats_partitions = 4;
+constexpr int k_stats_row = k_max_stats_partitions * (4 + 16) + 1;   // Ttwiddle[P][4], num_muts[P][4][4], num_muts
+__global__ void __launch_bounds__(k_wave) k_global_stats(KernelArgs a) {
+  __shared__ double sh_T[k_wave][k_max_stats_partitions * 4];
+  __shared__ int sh_M[k_wave][k_max_stats_partitions * 16];
+  const int lane = threadIdx.x;
+  const int part = blockIdx.x;
+  uint8_t* slab = a.slabs + a.slab_off[part];
+  dev::Ctx c;
+  init_ctx(c, slab, slab, a, nullptr);
+  const int P = a.evo.num_partitions, W = 4 * P;
+  const int n = c.H->n_nodes, root = c.H->root;
+  double* D = (double*)(slab + c.H->scratch_begin);   // [n][W]: per-branch change, then the value at the node
+  // phase A: change of n^beta_a across every branch
+  for (int i = lane; i < n; i += k_wave) {
+    double* d = D + (size_t)i * W;
+    for (int k = 0; k < W; ++k) d[k] = 0.0;
+    const IvRec* iv = dev::miss_of(c, i);
+    for (int j = 0; j < (int)c.N[i].miss.cnt; ++j) {
+      const double* hi = a.cum_nu + (size_t)iv[j].end * W; const double* lo = a.cum_nu + (size_t)iv[j].start * W;
+      for (int k = 0; k < W; ++k) d[k] -= hi[k] - lo[k];
+    }
+    const FsRec* fs = dev::mfs_of(c, i);
+    for (int j = 0; j < (int)c.N[i].mfs.cnt; ++j) { const int l = fs[j].site, b = c.part[l]; d[4 * b + c.ref[l]] += c.nu[l]; d[4 * b + fs[j].state] -= c.nu[l]; }
+    const MutRec* m = dev::muts_of(c, i);
+    for (int j = 0; j < dev::nmuts(c, i); ++j) { const int l = m[j].site, b = c.part[l]; d[4 * b + m[j].from] -= c.nu[l]; d[4 * b + m[j].to] += c.nu[l]; }
+  }
+  __syncthreads();
+  // phase B: pre-order accumulation from the reference sequence's counts (the last row of the prefix table)
+  if (lane == 0) {
+    const double* ref_row = a.cum_nu + (size_t)c.L * W;
+    for (int k = 0; k < W; ++k) D[(size_t)root * W + k] += ref_row[k];
+    int cur = root;
+    while (cur != dev::k_no_node) {
+      if (!dev::is_tip(c, cur)) {
+        for (int kk = 0; kk < 2; ++kk) {
+          const int ch = kk == 0 ? c.N[cur].child0 : c.N[cur].child1;
+          for (int k = 0; k < W; ++k) D[(size_t)ch * W + k] += D[(size_t)cur * W + k];
+        }
+        cur = c.N[cur].child0;
+      } else {
+        int prev = cur; cur = c.N[cur].parent;
+        while (cur != dev::k_no_node && c.N[cur].child1 == prev) { prev = cur; cur = c.N[cur].parent; }
+        if (cur != dev::k_no_node) cur = c.N[cur].child1;
+      }
+    }
+  }
+  __syncthreads();
+  // phase C: sums over the non-root branches
+  for (int k = 0; k < W; ++k) sh_T[lane][k] = 0.0;
+  for (int k = 0; k < 4 * W; ++k) sh_M[lane][k] = 0;
+  for (int i = lane; i < n; i += k_wave) {
+    if (i == root) continue;   // "mutations" above the root are deltas from the reference sequence
+    const double t_P = c.N[c.N[i].parent].t, len = c.N[i].t - t_P;
+    const double* d = D + (size_t)i * W;
+    for (int k = 0; k < W; ++k) sh_T[lane][k] += d[k] * len;
+    const MutRec* m = dev::muts_of(c, i);
+    for (int j = dev::nmuts(c, i) - 1; j >= 0; --j) {
+      const int l = m[j].site, b = c.part[l];
+      sh_T[lane][4 * b + m[j].to] -= c.nu[l] * (m[j].t - t_P);
+      sh_T[lane][4 * b + m[j].from] += c.nu[l] * (m[j].t - t_P);
+      sh_M[lane][16 * b + 4 * m[j].from + m[j].to] += 1;
+    }
+  }
+  __syncthreads();
+  double* out = a.stats_out + (size_t)part * k_stats_row;
+  for (int k = lane; k < W; k += k_wave) { double sum = 0.0; for (int r = 0; r < k_wave; ++r) sum += sh_T[r][k]; out[k] = sum; }
+  for (int k = lane; k < 4 * W; k += k_wave) { long long sum = 0; for (int r = 0; r < k_wave; ++r) sum += sh_M[r][k]; out[k_max_stats_partitions * 4 + k] = (double)sum; }
+  if (lane == 0) {
+    long long nm = 0;
+    for (int k = 0; k < 4 * W; ++k) for (int r = 0; r < k_wave; ++r) nm += sh_M[r][k];
+    out[k_stats_row - 1] = (double)nm;
+  }
+}
+
 // ---- whole-part derived quantities (Subrun::recalc_derived_quantities, subrun.cpp:17-26) ---------------------
 // Lanes stride over the part's nodes: branch-local work (delta lambda across the branch, missing-site count,
 // branch log-G, log N(t)) is embarrassingly parallel; only the pre-order accumulation of lambda_i /
@@ -289,13 +373,13 @@ struct emat_backend {
   double last_run_ms = 0.0;
   // model
   std::vector<uint8_t> ref, partition_for_site;
-  std::vector<double> nu_l, cumQ, mu, pi, q;
+  std::vector<double> nu_l, cumQ, cum_nu, mu, pi, q;
   std::vector<int32_t> ref_freqs;
   int num_partitions = 0;
   RunFlags flags{0.0, 0, 1};
   bool have_ref = false, have_evo = false, have_pop = false, have_coal = false;
   HostPopModel pop;
-  DevBuf<uint8_t> d_ref, d_part; DevBuf<double> d_nu, d_cumQ, d_mu, d_pi, d_q, d_sky_x, d_sky_g; DevBuf<int32_t> d_ref_freqs; DevBuf<PopTable> d_pop;
+  DevBuf<uint8_t> d_ref, d_part; DevBuf<double> d_nu, d_cumQ, d_cum_nu, d_stats, d_mu, d_pi, d_q, d_sky_x, d_sky_g; DevBuf<int32_t> d_ref_freqs; DevBuf<PopTable> d_pop;
   bool model_dirty = true;
   // parts
   std::vector<PartHost> parts;
@@ -426,6 +510,7 @@ emat_status sync_model_to_device(emat_backend* h) {
   HIP_TRY(B.d_part.upload(B.partition_for_site.data(), B.partition_for_site.size()));
   HIP_TRY(B.d_nu.upload(B.nu_l.data(), B.nu_l.size()));
   HIP_TRY(B.d_cumQ.upload(B.cumQ.data(), B.cumQ.size()));
+  HIP_TRY(B.d_cum_nu.upload(B.cum_nu.data(), B.cum_nu.size()));
   HIP_TRY(B.d_mu.upload(B.mu.data(), B.mu.size()));
   HIP_TRY(B.d_pi.upload(B.pi.data(), B.pi.size()));
   HIP_TRY(B.d_q.upload(B.q.data(), B.q.size()));
@@ -452,6 +537,15 @@ void refresh_ref_derived(emat_backend* h) {
     so_far += h->mu[p] * h->nu_l[l] * (-h->q[p * 16 + h->ref[l] * 5]);
     h->cumQ[l + 1] = so_far;
   }
+  {   // prefix table for k_global_stats: cum_nu[k][beta][a] = sum over sites l < k of partition beta with reference state a of nu_l
+    const int W = 4 * h->num_partitions;
+    h->cum_nu.assign((size_t)(L + 1) * W, 0.0);
+    for (int l = 0; l < L; ++l) {
+      const double* prev = &h->cum_nu[(size_t)l * W]; double* next = &h->cum_nu[(size_t)(l + 1) * W];
+      for (int k = 0; k < W; ++k) next[k] = prev[k];
+      next[4 * h->partition_for_site[l] + h->ref[l]] += h->nu_l[l];
+    }
+  }
   h->ref_freqs.assign((size_t)h->num_partitions * 4, 0);
   for (int l = 0; l < L; ++l) ++h->ref_freqs[h->partition_for_site[l] * 4 + h->ref[l]];
   h->model_dirty = true;
@@ -459,7 +553,7 @@ void refresh_ref_derived(emat_backend* h) {
 
 KernelArgs make_args(emat_backend* h) {
   KernelArgs a{};
-  a.slabs = h->d_slabs.p; a.slab_off = h->d_slab_off.p; a.order = h->d_order.p; a.block_begin = h->d_block_begin.p; a.part_ticks = h->d_part_ticks.p; a.ref_freqs = h->d_ref_freqs.p;
+  a.slabs = h->d_slabs.p; a.slab_off = h->d_slab_off.p; a.order = h->d_order.p; a.block_begin = h->d_block_begin.p; a.part_ticks = h->d_part_ticks.p; a.ref_freqs = h->d_ref_freqs.p; a.cum_nu = h->d_cum_nu.p; a.stats_out = h->d_stats.p;
   a.evo.num_sites = h->L; a.evo.num_partitions = h->num_partitions;
   a.evo.ref_sequence = h->d_ref.p; a.evo.partition_for_site = h->d_part.p; a.evo.nu_l = h->d_nu.p; a.evo.cum_Q_l = h->d_cumQ.p;
   a.evo.mu = h->d_mu.p; a.evo.pi = h->d_pi.p; a.evo.q = h->d_q.p;
@@ -1060,6 +1154,41 @@ emat_status emat_part_get_trace(emat_backend* h, int32_t part_id, int32_t* num_m
   int n = std::min(*num_moves, H->trace_len);
   std::memcpy(trace, slab + H->off_trace, (size_t)n * 32);
   *num_moves = n;
+  return EMAT_OK;
+}
+/* Sufficient statistics of the global moves over the parts of this handle (header: emat_get_global_stats). */
+emat_status emat_get_global_stats(emat_backend* h, int32_t num_partitions, double* Ttwiddle_beta_a, int64_t* num_muts_beta_ab, int64_t* num_muts) {
+  if (!h || !Ttwiddle_beta_a || !num_muts_beta_ab) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  emat_status st = sync_model_to_device(h); if (st) return st;
+  if (num_partitions != h->num_partitions) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "num_partitions does not match emat_set_evo");
+  if (num_partitions > k_max_stats_partitions) return fail(h, EMAT_ERR_CAPACITY, "emat_get_global_stats supports at most 4 site partitions");
+  st = materialize(h); if (st) return st;
+  const int W = 4 * num_partitions;
+  for (auto& ph : h->parts) {   // the per-node table lives in the part's scratch region
+    const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + ph.slab_off);
+    if ((uint64_t)ph.tree.num_nodes() * W * 8u > (uint64_t)ph.slab_bytes - H->scratch_begin) return fail(h, EMAT_ERR_CAPACITY, "scratch region too small for the statistics table");
+  }
+  const size_t n = h->parts.size();
+  if (h->d_stats.n < n * k_stats_row) { std::vector<double> z(n * k_stats_row, 0.0); HIP_TRY(h->d_stats.upload(z.data(), z.size())); }
+  KernelArgs a = make_args(h);
+  hipLaunchKernelGGL(k_global_stats, dim3((unsigned)n), dim3(k_wave), 0, h->stream, a);
+  HIP_TRY(hipGetLastError());
+  std::vector<double> rows(n * k_stats_row);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(rows.data(), h->d_stats.p, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int k = 0; k < W; ++k) Ttwiddle_beta_a[k] = 0.0;
+  for (int k = 0; k < 4 * W; ++k) num_muts_beta_ab[k] = 0;
+  int64_t nm = 0;
+  for (size_t p = 0; p < n; ++p) {   // fixed order: reproducible sums
+    const double* r = rows.data() + p * k_stats_row;
+    for (int k = 0; k < W; ++k) Ttwiddle_beta_a[k] += r[k];
+    for (int k = 0; k < 4 * W; ++k) num_muts_beta_ab[k] += (int64_t)r[k_max_stats_partitions * 4 + k];
+    nm += (int64_t)r[k_stats_row - 1];
+  }
+  if (num_muts) *num_muts = nm;
   return EMAT_OK;
 }
 /* debugging aid (not part of the boundary): how many parts the next launch runs with each code variant

@@ -234,7 +234,7 @@ def load_library():
         "emat_coalescent_begin": [B, P(_PopModelC), i32, dbl, P(dbl), P(dbl)], "emat_coalescent_set_range": [B, dbl, dbl, P(i32)],
         "emat_coalescent_local_grid": [B, P(dbl), P(i32)], "emat_coalescent_sample": [B, P(dbl), P(i32), P(dbl)], "emat_coalescent_finish": [B, P(dbl)],
         "emat_run_local_moves": [B, i64], "emat_run_moves_per_part": [B, i64], "emat_synchronize": [B], "emat_recalc_derived": [B],
-        "emat_get_totals": [B, P(dbl), P(dbl)],
+        "emat_get_totals": [B, P(dbl), P(dbl)], "emat_get_global_stats": [B, i32, P(dbl), P(i64), P(i64)],
         "emat_part_get_sizes": [B, i32, P(i32), P(i32), P(i32), P(i32)], "emat_part_download": [B, i32, P(_FlatTreeC)],
         "emat_part_get_derived": [B, i32, P(dbl), P(i32), P(dbl), P(dbl)],
         "emat_part_get_coalescent": [B, i32, P(i32), P(dbl), P(dbl), P(dbl), P(dbl), P(i32), P(dbl), P(dbl)],
@@ -426,6 +426,13 @@ class EmatBackend:
         g, a = C.c_double(), C.c_double()
         self._ck(self._lib.emat_get_totals(self._h, C.byref(g), C.byref(a)), "emat_get_totals")
         return float(g.value), float(a.value)
+
+    def global_stats(self, num_partitions: int = 1):
+        """(Ttwiddle_beta_a [P][4], num_muts_beta_ab [P][4][4], num_muts) over the parts of this handle."""
+        T = np.zeros((num_partitions, 4)); M = np.zeros((num_partitions, 4, 4), np.int64); nm = C.c_int64()
+        self._ck(self._lib.emat_get_global_stats(self._h, num_partitions, T.ctypes.data_as(C.POINTER(C.c_double)), M.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nm)),
+                 "emat_get_global_stats")
+        return T, M, int(nm.value)
 
     def part_download(self, part: int) -> FlatTree:
         n, nm, ni, nf = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()

@@ -105,6 +105,14 @@ class ShardedEngine:
                 tot["accepted"][k] += s["accepted"][k]
         return tot
 
+    def global_stats(self, num_partitions: int = 1):
+        """Sufficient statistics of the global moves over ALL parts: per-GPU sums, then one all-reduce each."""
+        T, M, nm = self.backend.global_stats(num_partitions)
+        T = self.allreduce(T.reshape(-1), "sum").reshape(num_partitions, 4)
+        M = self.allreduce(M.reshape(-1).astype(np.int64), "sum").reshape(num_partitions, 4, 4)
+        nm = int(self.allreduce(np.array([nm], np.int64), "sum")[0])
+        return T, M, nm
+
     def global_totals(self):
         g, a = self.backend.totals()
         v = self.allreduce(np.array([g, a]), "sum")

@@ -172,6 +172,18 @@ emat_status emat_recalc_derived(emat_backend* h);
  * (reference run.cpp:340-348) */
 emat_status emat_get_totals(emat_backend* h, double* log_G, double* log_augmented_coalescent_prior);
 
+/* ---- sufficient statistics of the global moves ---------------------------- */
+/* replaces: Run::calc_cur_Ttwiddle_beta_a / calc_cur_num_muts / calc_cur_num_muts_ab (reference run.cpp:445-453), i.e.
+ * calc_Ttwiddle_beta_a (phylo_tree_calc.cpp:288-369), calc_num_muts_beta_ab (:599-610), calc_num_muts (:577-585), which
+ * the host-side global moves (mu, HKY kappa / pi; run.cpp:781-1010) consume.  Computed on the device over the parts of
+ * this handle and summed in part order, so that the trees need not be downloaded for them: every branch of the whole
+ * tree is a non-root branch of exactly one part.  With parts spread over several handles (GPUs) the caller adds the
+ * per-handle results.  Ttwiddle_beta_a[beta][a] = sum over sites l of partition beta of nu_l x (time site l spends in
+ * state a over all branches, missing stretches excluded); num_muts_beta_ab[beta][a][b] counts mutations a -> b.
+ * num_partitions must equal the value given to emat_set_evo and be <= 4 (EMAT_ERR_CAPACITY otherwise). */
+emat_status emat_get_global_stats(emat_backend* h, int32_t num_partitions, double* Ttwiddle_beta_a /*[P][4]*/,
+                                  int64_t* num_muts_beta_ab /*[P][4][4]*/, int64_t* num_muts /* may be NULL */);
+
 /* Sizes needed to download a part (so that the caller can size an emat_flat_tree). */
 emat_status emat_part_get_sizes(emat_backend* h, int32_t part_id, int32_t* num_nodes,
                                 int32_t* num_muts, int32_t* num_intervals, int32_t* num_from_states);

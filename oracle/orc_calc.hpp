@@ -267,6 +267,53 @@ inline int calc_num_muts(const Phylo_tree& tree) {   // :577-585
   for (int i = 0; i < tree.size(); ++i) if (i != tree.root) n += (int)tree.at(i).mutations.size();
   return n;
 }
+// ---- sufficient statistics of the global moves (phylo_tree_calc.cpp:288-369, 577-610) ----------------------------
+// Ttwiddle^beta_a = sum_{l in beta} nu_l T^(l)_a: the nu-weighted time every site of partition beta spends in state a
+// over all branches below the root, sites missing on a branch excluded.  Follows the reference's enter / exit traversal.
+typedef std::vector<std::array<double, 4>> Partition_state_times;
+inline Partition_state_times calc_Ttwiddle_beta_a(const Phylo_tree& tree, const Global_evo_model& evo) {
+  const int P = (int)evo.partition_evo_model.size();
+  Partition_state_times T(P, std::array<double, 4>{0, 0, 0, 0}), n(P, std::array<double, 4>{0, 0, 0, 0});
+  for (int l = 0; l < (int)tree.ref_sequence.size(); ++l) n[evo.partition_for_site[l]][tree.ref_sequence[l]] += evo.nu_l[l];
+  auto enter = [&](Node_index node) {   // n: state at parent -> state at node
+    const auto& nd = tree.at(node);
+    for (const auto& iv : nd.missations.intervals.v) for (int l = iv.first; l != iv.second; ++l) n[evo.partition_for_site[l]][tree.ref_sequence[l]] -= evo.nu_l[l];
+    for (const auto& [l, from] : nd.missations.from_states) { int b = evo.partition_for_site[l]; n[b][tree.ref_sequence[l]] += evo.nu_l[l]; n[b][from] -= evo.nu_l[l]; }
+    for (const auto& m : nd.mutations) { int b = evo.partition_for_site[m.site]; n[b][m.from] -= evo.nu_l[m.site]; n[b][m.to] += evo.nu_l[m.site]; }
+    if (node != tree.root) {
+      const double t_P = tree.at(nd.parent).t, len = nd.t - t_P;
+      for (int b = 0; b < P; ++b) for (int a = 0; a < 4; ++a) T[b][a] += n[b][a] * len;
+      for (auto it = nd.mutations.rbegin(); it != nd.mutations.rend(); ++it) {
+        int b = evo.partition_for_site[it->site];
+        T[b][it->to] -= evo.nu_l[it->site] * (it->t - t_P);
+        T[b][it->from] += evo.nu_l[it->site] * (it->t - t_P);
+      }
+    }
+  };
+  auto leave = [&](Node_index node) {   // n: state at node -> state at parent
+    const auto& nd = tree.at(node);
+    for (const auto& m : nd.mutations) { int b = evo.partition_for_site[m.site]; n[b][m.to] -= evo.nu_l[m.site]; n[b][m.from] += evo.nu_l[m.site]; }
+    for (const auto& iv : nd.missations.intervals.v) for (int l = iv.first; l != iv.second; ++l) n[evo.partition_for_site[l]][tree.ref_sequence[l]] += evo.nu_l[l];
+    for (const auto& [l, from] : nd.missations.from_states) { int b = evo.partition_for_site[l]; n[b][tree.ref_sequence[l]] -= evo.nu_l[l]; n[b][from] += evo.nu_l[l]; }
+  };
+  if (tree.size() == 0) return T;
+  std::vector<std::pair<Node_index, int>> stack;   // traversal(tree): (node, children visited so far)
+  stack.push_back({tree.root, 0});
+  enter(tree.root);
+  while (!stack.empty()) {
+    auto& [node, k] = stack.back();
+    if (tree.at(node).is_tip() || k == 2) { leave(node); stack.pop_back(); }
+    else { Node_index ch = tree.at(node).children[k]; ++k; stack.push_back({ch, 0}); enter(ch); }
+  }
+  return T;
+}
+typedef std::vector<std::array<std::array<long long, 4>, 4>> Partition_mut_counts;
+inline Partition_mut_counts calc_num_muts_beta_ab(const Phylo_tree& tree, const Global_evo_model& evo) {   // :599-610
+  Partition_mut_counts r(evo.partition_evo_model.size());
+  for (auto& x : r) for (auto& y : x) y = {0, 0, 0, 0};
+  for (int i = 0; i < tree.size(); ++i) if (i != tree.root) for (const auto& m : tree.at(i).mutations) ++r[evo.partition_for_site[m.site]][m.from][m.to];
+  return r;
+}
 inline double calc_max_tip_time(const Phylo_tree& tree) {   // :636-644
   double t = -std::numeric_limits<double>::infinity();
   for (int i = 0; i < tree.size(); ++i) if (tree.at(i).is_tip() && tree.at(i).t_max > t) t = tree.at(i).t_max;

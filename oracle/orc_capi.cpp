@@ -162,6 +162,27 @@ int orc_run_moves(orc_engine* e, const int64_t* moves_per_part, int num_threads,
   ORC_CATCH
 }
 
+/* Sufficient statistics of the global moves summed over the parts: every branch of the whole tree is a non-root branch
+ * of exactly one part (a cut node is a tip of the part above it and the root of the part below), and a part's root
+ * lists carry the state at the cut node, so the sums equal the whole-tree values (Run::calc_cur_Ttwiddle_beta_a,
+ * calc_cur_num_muts_ab, run.cpp:445-453). */
+int orc_global_stats(orc_engine* e, int P, double* Ttwiddle_beta_a /*[P][4]*/, int64_t* num_muts_beta_ab /*[P][4][4]*/, int64_t* num_muts) {
+  ORC_TRY
+  ORC_CHECK(P == (int)e->evo.partition_evo_model.size());
+  for (int i = 0; i < 4 * P; ++i) Ttwiddle_beta_a[i] = 0.0;
+  for (int i = 0; i < 16 * P; ++i) num_muts_beta_ab[i] = 0;
+  int64_t nm = 0;
+  for (auto& pt : e->parts) {
+    const Phylo_tree& tree = pt->subrun->tree;
+    auto T = calc_Ttwiddle_beta_a(tree, e->evo);
+    auto M = calc_num_muts_beta_ab(tree, e->evo);
+    for (int b = 0; b < P; ++b) for (int a = 0; a < 4; ++a) { Ttwiddle_beta_a[4 * b + a] += T[b][a]; for (int c = 0; c < 4; ++c) num_muts_beta_ab[16 * b + 4 * a + c] += M[b][a][c]; }
+    nm += calc_num_muts(tree);
+  }
+  if (num_muts) *num_muts = nm;
+  ORC_CATCH
+}
+
 int orc_get_totals(orc_engine* e, double* log_G, double* log_aug) {
   ORC_TRY
   double g = 0.0, a = 0.0;

@@ -209,6 +209,31 @@ TEST(calc_fixture_sequences_and_missing) {
   EXPECT_NEAR(calc_T(t), 8.0, 1e-12);
   EXPECT(calc_num_muts(t) == 5);
 }
+// phylo_tree_calc_tests.cpp:248-284 (calc_Ttwiddle_beta_a), :441-469 (calc_num_muts, _ab, _beta_ab)
+TEST(calc_fixture_global_move_statistics) {
+  auto t = complex_tree(false);
+  auto evo = fixture_evo();
+  auto nu = [&](int l) { return evo.nu_l[l]; };
+  double expected[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  // site 0, partition 0
+  expected[0][sA] += 0.5 * nu(0); expected[0][sT] += 0.5 * nu(0);   // r->x branch up to / from A0T
+  expected[0][sT] += 0.5 * nu(0); expected[0][sC] += 0.5 * nu(0);   // x->a branch to / from T0C
+  expected[0][sT] += 2.0 * nu(0);                                   // x->b branch
+  expected[0][sA] += 1.0 * nu(0); expected[0][sT] += 1.0 * nu(0); expected[0][sG] += 2.0 * nu(0);   // r->c branch: A0T, T0G
+  // site 1, partition 1 (missing on r->c)
+  expected[1][sA] += 1.0 * nu(1); expected[1][sA] += 1.0 * nu(1); expected[1][sA] += 1.0 * nu(1); expected[1][sG] += 1.0 * nu(1);
+  // site 2, partition 0 (missing below r->x); site 3 missing everywhere
+  expected[0][sA] += 4.0 * nu(2);
+  auto T = calc_Ttwiddle_beta_a(t, evo);
+  EXPECT(T.size() == 2);
+  for (int b = 0; b < 2; ++b) for (int a = 0; a < 4; ++a) EXPECT_NEAR(T[b][a], expected[b][a], 1e-12);
+  auto M = calc_num_muts_beta_ab(t, evo);
+  long long em[2][4][4] = {};
+  ++em[0][sA][sT]; ++em[0][sT][sC]; ++em[1][sA][sG]; ++em[0][sA][sT]; ++em[0][sT][sG];
+  long long total = 0;
+  for (int b = 0; b < 2; ++b) for (int a = 0; a < 4; ++a) for (int c2 = 0; c2 < 4; ++c2) { EXPECT(M[b][a][c2] == em[b][a][c2]); total += M[b][a][c2]; }
+  EXPECT(total == calc_num_muts(t));
+}
 TEST(calc_fixture_log_G_and_lambda) {
   auto t = complex_tree(false);
   auto evo = fixture_evo();

@@ -27,7 +27,7 @@ def lib():
             "orc_set_flags": [E, dbl, C.c_int, C.c_int], "orc_begin_upload": [E, C.c_int],
             "orc_part_upload": [E, C.c_int, P(_FlatTreeC), C.c_int, u64], "orc_end_upload": [E],
             "orc_build_coalescent_parts": [E, P(_PopModelC), C.c_int, dbl], "orc_recalc_derived": [E],
-            "orc_run_moves": [E, P(i64), C.c_int, C.c_int], "orc_get_totals": [E, P(dbl), P(dbl)],
+            "orc_run_moves": [E, P(i64), C.c_int, C.c_int], "orc_get_totals": [E, P(dbl), P(dbl)], "orc_global_stats": [E, C.c_int, P(dbl), P(i64), P(i64)],
             "orc_part_get_sizes": [E, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)], "orc_part_download": [E, C.c_int, P(_FlatTreeC)],
             "orc_part_get_derived": [E, C.c_int, P(dbl), P(C.c_int), P(dbl), P(dbl)],
             "orc_part_get_coalescent": [E, C.c_int, P(C.c_int), P(dbl), P(dbl), P(dbl), P(dbl), P(C.c_int), P(dbl), P(dbl)],
@@ -109,6 +109,11 @@ class OracleEngine:
         g, a = C.c_double(), C.c_double()
         self._ck(self.L.orc_get_totals(self.h, C.byref(g), C.byref(a)), "get_totals")
         return g.value, a.value
+
+    def global_stats(self, num_partitions=1):
+        T = np.zeros((num_partitions, 4)); M = np.zeros((num_partitions, 4, 4), np.int64); nm = C.c_int64()
+        self._ck(self.L.orc_global_stats(self.h, num_partitions, _ptr(T, C.c_double), _ptr(M, C.c_int64), C.byref(nm)), "global_stats")
+        return T, M, int(nm.value)
 
     def part_download(self, part):
         n, nm, ni, nf = C.c_int(), C.c_int(), C.c_int(), C.c_int()

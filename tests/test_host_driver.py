@@ -127,3 +127,23 @@ def test_bad_inputs_are_rejected():
     with pytest.raises(d.EmatError):
         b.upload_parts([t], [True], [1])
     b.close()
+
+
+def test_global_statistics_decompose_over_parts():
+    """The sufficient statistics of the global moves are sums over the non-root branches, and every branch of the whole
+    tree is a non-root branch of exactly one part: the oracle's sum over the parts of a partition must equal its value
+    on the whole tree (this is what lets the engine compute them per part, emat_get_global_stats)."""
+    from oracle_ffi import OracleEngine
+    from helpers import configure, split_parts
+    sc = make_scenario("C2", num_tips=300, num_sites=5000)
+    whole = OracleEngine(sc.num_sites)
+    configure(whole, sc, sc.ref, [sc.tree], [True], [1], 0)
+    Tw, Mw, nw = whole.global_stats(1)
+    whole.close()
+    parts, incl, seeds, root_part, ref = split_parts(sc, 7, 5)
+    split = OracleEngine(sc.num_sites)
+    configure(split, sc, ref, parts, incl, seeds, root_part)
+    Ts, Ms, ns = split.global_stats(1)
+    split.close()
+    assert ns == nw and np.array_equal(Ms, Mw)
+    assert np.allclose(Ts, Tw, rtol=1e-10, atol=0)

@@ -8,7 +8,8 @@ import pytest
 
 import delphy_amd as d
 from delphy_amd.scenarios import make_scenario
-from helpers import configure, run_parity, split_parts
+from helpers import configure, rel_close, run_parity, split_parts
+from oracle_ffi import OracleEngine
 
 pytestmark = pytest.mark.gpu
 
@@ -123,3 +124,32 @@ def test_run_local_moves_remainder_goes_to_part_zero():
     """Run::run_local_moves (run.cpp:682-693): count / parts moves on every part, the remainder on part 0."""
     sc = make_scenario("C1", num_tips=80, num_sites=3000)
     run_parity(sc, 3, 1, seed=41, total_moves=3 * 1500 + 2, trace=0)
+
+
+def _stats_parity(sc, num_parts, moves, seed, evo=None, P=1):
+    parts, incl, seeds, root_part, ref = split_parts(sc, num_parts, seed)
+    gpu = d.EmatBackend(sc.num_sites)
+    orc = OracleEngine(sc.num_sites)
+    try:
+        configure(gpu, sc, ref, parts, incl, seeds, root_part, None, evo=evo)
+        configure(orc, sc, ref, parts, incl, seeds, root_part, None, evo=evo)
+        for rounds in range(2):
+            Tg, Mg, ng = gpu.global_stats(P)
+            To, Mo, no = orc.global_stats(P)
+            assert ng == no and np.array_equal(Mg, Mo), "mutation counts differ: %s vs %s" % (Mg.tolist(), Mo.tolist())
+            assert rel_close(Tg, To, 1e-9), "Ttwiddle differs: %s vs %s" % (Tg.tolist(), To.tolist())
+            assert Mg.sum() == ng and ng > 0 and np.all(Tg > 0)
+            gpu.run_moves_per_part(moves); gpu.synchronize(); orc.run_moves_per_part(moves, threads=4)
+    finally:
+        gpu.close(); orc.close()
+
+
+def test_global_move_statistics():
+    """emat_get_global_stats (calc_Ttwiddle_beta_a, calc_num_muts_beta_ab, calc_num_muts on the device) against the oracle,
+    before and after moves, with one and with two site partitions and per-site rates."""
+    sc = make_scenario("C3", num_tips=400, num_sites=8000)
+    _stats_parity(sc, 6, 1500, seed=43)
+    pi2 = np.array([0.1, 0.4, 0.3, 0.2])
+    evo = (np.array([sc.mu, 2.0 * sc.mu]), np.stack([np.asarray(sc.pi, np.float64), pi2]), np.stack([d.hky_q_matrix(sc.kappa, sc.pi), d.hky_q_matrix(2.0, pi2)]),
+           (np.arange(sc.num_sites) // 700 % 2).astype(np.int32))
+    _stats_parity(sc, 5, 1000, seed=47, evo=evo, P=2)
