@@ -366,7 +366,7 @@ struct emat_backend {
   hipStream_t class_stream[k_max_classes] = {nullptr, nullptr, nullptr, nullptr};   // class 0 runs on `stream`
   hipEvent_t ev_fork = nullptr, ev_join[k_max_classes] = {nullptr, nullptr, nullptr, nullptr};
   int num_classes = 1; int class_begin[k_max_classes + 1] = {0, 0, 0, 0, 0}; uint32_t class_lds[k_max_classes] = {0, 0, 0, 0};
-  std::vector<int> cfg_class_pct{75};                // EMAT_LDS_CLASSES (tuning knob): percentiles of persistent size that close each class; the last
+  std::vector<int> cfg_class_pct{60};                // EMAT_LDS_CLASSES (tuning knob): percentiles of persistent size that close each class; the last
                                                      // class always extends to the largest part (its staging area is still that percentile's size)
   uint32_t cfg_lds_max = 96 * 1024;                  // EMAT_LDS_MAX (tuning knob): largest staging area; larger parts run out of HBM
   bool schedule_valid = false; int launches_since_balance = 0; int sched_blocks = 0;

@@ -53,8 +53,10 @@ def make_scenario(name: str, num_tips: Optional[int] = None, num_sites: Optional
     elif name in ("C3", "C4", "C5"):
         tips = {"C3": 10000, "C4": 100000, "C5": 1000000}[name]
         span = {"C3": 365.0, "C4": 730.0, "C5": 730.0}[name]
-        # exponential growth keeps the synthetic genealogy star-like, as pandemic-scale SARS-CoV-2 trees are
-        p = SynthParams(num_tips=tips, num_sites=29903, tip_span=span, pop_n0=20.0 * 365.0, pop_growth=6.0 / 365.0, mu=1e-3 / 365.0, gaps_per_tip=2, mean_gap_len=270.0,
+        # exponential growth keeps the synthetic genealogy star-like, as pandemic-scale SARS-CoV-2 trees are; the scale of
+        # N(t) is set so that the tree carries about one mutation per tip ("M ~ tips ... 3 tips"; C4: 95 748
+        # mutations on 100 000 tips, mean branch 5.9 days at 30 substitutions per genome per year)
+        p = SynthParams(num_tips=tips, num_sites=29903, tip_span=span, pop_n0=1500.0 * 365.0, pop_growth=6.0 / 365.0, mu=1e-3 / 365.0, gaps_per_tip=2, mean_gap_len=270.0,
                         seed=base + {"C3": 2, "C4": 3, "C5": 4}[name])
     else:
         raise ValueError(name)
@@ -76,5 +78,5 @@ def make_scenario(name: str, num_tips: Optional[int] = None, num_sites: Optional
     elif name == "C2":
         pop = PopModel.exp(tmax, 3 * 365.0, 2.0 / 365.0, 1.0)
     else:
-        pop = _skygrid(tmax, p.tip_span * 1.2, 5.0 * 365.0, log_linear=skygrid_log_linear)
+        pop = _skygrid(tmax, p.tip_span * 1.2, 200.0 * 365.0, log_linear=skygrid_log_linear)   # N of the order of the generating model's over the sampled period
     return Scenario(name, tree, ref, tmax, p.mu, p.kappa, PI, pop, p.num_sites)

@@ -1,13 +1,6 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -6
-python - <<'PY'
-import sys, time; sys.path.insert(0, "."); sys.path.insert(0, "tests")
-import delphy_amd as d
-from delphy_amd.scenarios import make_scenario
-from delphy_amd.sharding import ShardedEngine
-sc = make_scenario("C4"); eng = ShardedEngine(sc, num_parts=8192, seed=20261001); eng.setup()
-eng.backend.run_moves_per_part(100); eng.backend.synchronize()
-for i in range(3):
-    t0 = time.perf_counter(); T, M, nm = eng.global_stats(1); dt = time.perf_counter() - t0
-print("C4 global stats in %.2f ms: num_muts %d, Ttwiddle %s" % (dt * 1e3, nm, T.tolist()))
-eng.close()
-PY
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+python bench.py 2>&1 | tail -1 > gpurun_out/bench_r01.json; cut -c1-330 gpurun_out/bench_r01.json
+bash scripts/profile.sh r01 > gpurun_out/profile_r01.log 2>&1; tail -4 gpurun_out/profile_r01.log
+bash scripts/pmc_mix.sh full
+python scripts/gpu_probe.py cycle 2>&1 | grep -E "^cycle" | cut -c1-330
+python bench.py --steps 6 --warmup 2 --no-cpu-baseline --parts 16384 2>&1 | tail -1 | grep -o '"value": [0-9.]*\|[0-9]* partition parts'
