@@ -15,7 +15,6 @@
 #include <memory>
 #include <numeric>
 #include <string>
-#include <queue>
 #include <vector>
 
 #include "../../include/emat_backend.h"
@@ -47,9 +46,8 @@ namespace emat {
 struct KernelArgs {
   uint8_t* slabs;                 // all slabs, back to back
   const uint64_t* slab_off;       // [num_parts] byte offset of each part's slab
-  const int32_t* order;           // [num_parts] part ids grouped by workgroup (see block_begin)
-  const int32_t* block_begin;     // [num_blocks + 1] workgroup b runs parts order[block_begin[b] .. block_begin[b+1]) one after the other
-  int64_t* part_ticks;            // [num_parts] wall-clock ticks of each part's last run (feeds the host's load balancer)
+  const int32_t* order;           // [parts of this launch] part ids, largest first: workgroup b runs part order[b]
+  int64_t* part_ticks;            // [2][num_parts] wall-clock ticks and start tick of each part's last run (occupancy timelines)
   const int32_t* ref_freqs;       // [P][4]
   const double* cum_nu;           // [L + 1][P][4]: nu-weighted counts of reference states per site partition over sites < k (k_global_stats)
   double* stats_out;              // [num_parts][k_stats_row]: per-part output of k_global_stats
@@ -127,10 +125,8 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
   double* lds_tables = (double*)emat_lds;
   const bool tables_staged = stage_tables(a, lds_tables, lane) != nullptr;
   uint8_t* lds_slab = emat_lds + k_lds_slab_off;
-  // the workgroup walks its list of parts (one part per workgroup unless the host packed lists)
-  const int list_lo = a.block_begin[blockIdx.x], list_hi = a.block_begin[blockIdx.x + 1];
-  for (int idx = list_lo; idx < list_hi; ++idx) {
-    const int part = a.order[idx];
+  {
+    const int part = a.order[blockIdx.x];
     uint8_t* gslab = a.slabs + a.slab_off[part];
     const SlabHeader* gh = (const SlabHeader*)gslab;
     __syncthreads();
@@ -369,7 +365,7 @@ struct emat_backend {
   std::vector<int> cfg_class_pct{60};                // EMAT_LDS_CLASSES (tuning knob): percentiles of persistent size that close each class; the last
                                                      // class always extends to the largest part (its staging area is still that percentile's size)
   uint32_t cfg_lds_max = 96 * 1024;                  // EMAT_LDS_MAX (tuning knob): largest staging area; larger parts run out of HBM
-  bool schedule_valid = false; int launches_since_balance = 0; int sched_blocks = 0;
+  bool order_valid = false;         // d_order holds the current parts, largest first
   double last_run_ms = 0.0;
   // model
   std::vector<uint8_t> ref, partition_for_site;
@@ -386,22 +382,16 @@ struct emat_backend {
   int uploads_expected = 0;
   int root_part = -1;
   std::vector<uint8_t> h_slabs;
-  DevBuf<uint8_t> d_slabs; DevBuf<uint64_t> d_slab_off; DevBuf<int32_t> d_order, d_block_begin; DevBuf<int64_t> d_part_ticks;
-  std::vector<double> part_cost;      // load-balancing cost of each part (measured ticks of its last run, or a size proxy)
-  bool have_measured_cost = false;
+  DevBuf<uint8_t> d_slabs; DevBuf<uint64_t> d_slab_off; DevBuf<int32_t> d_order; DevBuf<int64_t> d_part_ticks;
   bool slabs_on_device = false;     // device slabs are materialised
   bool host_slabs_current = false;  // h_slabs mirrors the device
   bool derived_valid = false;
   uint32_t max_slab_bytes = 0;
   std::vector<uint32_t> persistent_bytes;   // per part: slab size without scratch
   std::vector<uint32_t> prefix_bytes;       // per part: header + nodes + cells + trace (what the prefix-staged variant keeps in LDS)
-  int cfg_giant_pct = 0;                    // EMAT_GIANT_PCT (tuning knob): also move the largest N % of the parts into the giants' class
   bool cfg_giants = true;                   // EMAT_GIANTS (tuning knob): parts that cannot even stage their prefix get a class of their own
   double cfg_heap_per_node = 64.0;  // EMAT_HEAP_PER_NODE: heap bytes per node on top of slack x content
   uint32_t cfg_lds_scratch = 0;     // EMAT_LDS_SCRATCH (tuning knob): per-part LDS scratch arena; 0 = all scratch in HBM (measured best at C4)
-  bool cfg_balance = false;         // EMAT_BALANCE (tuning knob): 0 = one workgroup per part, no lists
-  int cfg_sched_blocks = 0;         // EMAT_SCHED_BLOCKS (tuning knob): grid size of the balanced launch; 0 = what the chip holds at once
-  int cfg_rebalance_every = 8;      // EMAT_REBALANCE_EVERY (tuning knob): launches between schedule rebuilds from measured ticks
   bool host_only = false;           // cfg.device == -1: uploads / coalescent staging only, every launch fails with EMAT_ERR_NO_DEVICE
   std::unique_ptr<CoalBuilder> coal_builder;
 
@@ -553,7 +543,7 @@ void refresh_ref_derived(emat_backend* h) {
 
 KernelArgs make_args(emat_backend* h) {
   KernelArgs a{};
-  a.slabs = h->d_slabs.p; a.slab_off = h->d_slab_off.p; a.order = h->d_order.p; a.block_begin = h->d_block_begin.p; a.part_ticks = h->d_part_ticks.p; a.ref_freqs = h->d_ref_freqs.p; a.cum_nu = h->d_cum_nu.p; a.stats_out = h->d_stats.p;
+  a.slabs = h->d_slabs.p; a.slab_off = h->d_slab_off.p; a.order = h->d_order.p; a.part_ticks = h->d_part_ticks.p; a.ref_freqs = h->d_ref_freqs.p; a.cum_nu = h->d_cum_nu.p; a.stats_out = h->d_stats.p;
   a.evo.num_sites = h->L; a.evo.num_partitions = h->num_partitions;
   a.evo.ref_sequence = h->d_ref.p; a.evo.partition_for_site = h->d_part.p; a.evo.nu_l = h->d_nu.p; a.evo.cum_Q_l = h->d_cumQ.p;
   a.evo.mu = h->d_mu.p; a.evo.pi = h->d_pi.p; a.evo.q = h->d_q.p;
@@ -663,12 +653,6 @@ emat_status materialize(emat_backend* h) {
       if (h->cfg_giants) {
         uint32_t smallest_giant = 0xffffffffu, largest = 0;
         for (size_t p = 0; p < n; ++p) if (h->prefix_bytes[p] > asc[0].second) smallest_giant = std::min(smallest_giant, h->persistent_bytes[p]);
-        // ... and so do the largest few percent of the parts that only stage their prefix: they are the slowest of the
-        // main launch (their lists live in HBM) and there are too few of them to cost the main launch any occupancy
-        if (h->cfg_giant_pct > 0) {
-          const size_t k = std::min(n - 1, n - std::max<size_t>(1, n * (size_t)h->cfg_giant_pct / 100));
-          if (v[k] > asc[0].second) smallest_giant = std::min(smallest_giant, v[k]);
-        }
         if (smallest_giant != 0xffffffffu) {
           size_t first = std::lower_bound(v.begin(), v.end(), smallest_giant) - v.begin();   // ascending rank where the class starts
           if (first > 0 && first < n) {
@@ -697,10 +681,7 @@ emat_status materialize(emat_backend* h) {
       fprintf(stderr, "\n");
     }
   }
-  // first guess at each part's cost: affine in its persistent size (replaced by measured ticks after a pass)
-  h->part_cost.assign(h->parts.size(), 0.0);
-  for (size_t i = 0; i < h->parts.size(); ++i) h->part_cost[i] = 4096.0 + (double)h->persistent_bytes[i];
-  h->have_measured_cost = false; h->schedule_valid = false; h->launches_since_balance = 0;
+  h->order_valid = false;
   HIP_TRY(h->d_slabs.upload(h->h_slabs.data(), h->h_slabs.size()));
   HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
   { std::vector<int64_t> z(2 * h->parts.size(), 0); HIP_TRY(h->d_part_ticks.upload(z.data(), z.size())); }
@@ -719,41 +700,19 @@ emat_status launch_recalc(emat_backend* h) {
   return EMAT_OK;
 }
 
-// Deal the parts to `nblocks` workgroups: longest-processing-time-first onto the least-loaded workgroup.
-// The schedule only decides WHERE and WHEN a part's chain runs; every chain is independent (own RNG stream, own
-// slab), so results do not depend on it.
-emat_status build_schedule(emat_backend* h, int nblocks) {
+// Launch order: one workgroup per part, largest persistent state first.  The hardware dispatcher hands workgroups to
+// free slots in index order, which makes it a longest-processing-time-first list scheduler (size and duration of a
+// part correlate at 0.85); packing lists of parts per workgroup on the host was measured slower twice.  The order only
+// decides WHEN a part's chain runs; every chain is independent (own RNG stream, own slab).
+emat_status build_order(emat_backend* h) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   const int n = (int)h->parts.size();
-  std::vector<int32_t> order; order.reserve(n);
-  std::vector<int32_t> begin;
-  if (!h->cfg_balance) {   // one part per workgroup, largest first: the hardware dispatcher is the list scheduler
-    std::vector<int32_t> by_cost(n);
-    std::iota(by_cost.begin(), by_cost.end(), 0);
-    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return h->persistent_bytes[a] > h->persistent_bytes[b]; });
-    order = by_cost;
-    for (int i = 0; i <= n; ++i) begin.push_back(i);   // identity: list b = {order[b]}; a class launch offsets `order`
-  } else {
-    std::vector<int32_t> by_cost(n);
-    std::iota(by_cost.begin(), by_cost.end(), 0);
-    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return h->part_cost[a] > h->part_cost[b]; });
-    std::vector<std::vector<int32_t>> lists(nblocks);
-    typedef std::pair<double, int> Load;
-    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
-    for (int b = 0; b < nblocks; ++b) heap.push({0.0, b});
-    for (int part : by_cost) {
-      Load l = heap.top(); heap.pop();
-      lists[l.second].push_back(part);
-      heap.push({l.first + h->part_cost[part], l.second});
-    }
-    for (int b = 0; b < nblocks; ++b) { begin.push_back((int32_t)order.size()); order.insert(order.end(), lists[b].begin(), lists[b].end()); }
-    begin.push_back((int32_t)order.size());
-  }
-  h->sched_blocks = (int)begin.size() - 1;
+  std::vector<int32_t> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->persistent_bytes[a] > h->persistent_bytes[b]; });
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(h->d_order.upload(order.data(), order.size()));
-  HIP_TRY(h->d_block_begin.upload(begin.data(), begin.size()));
-  h->schedule_valid = true; h->launches_since_balance = 0;
+  h->order_valid = true;
   return EMAT_OK;
 }
 
@@ -763,48 +722,16 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0) {
   emat_status st = sync_model_to_device(h); if (st) return st;
   st = materialize(h); if (st) return st;
   if (!h->derived_valid) { st = launch_recalc(h); if (st) return st; }
-  const int n = (int)h->parts.size();
-  const bool lists = h->cfg_balance;   // experimental: one launch, workgroups walk LPT-packed lists
-  const bool single = lists;           // ... with one class: the second-largest staging area
   const uint32_t lds_scratch = h->cfg.use_lds ? h->cfg_lds_scratch : 0u;
   auto shmem_for = [&](uint32_t slab_area) { return (size_t)k_lds_slab_off + slab_area + lds_scratch; };
-  const uint32_t single_lds = h->class_lds[std::min(1, h->num_classes - 1)];
-  for (int c = 0; c < (single ? 1 : h->num_classes); ++c)
-    if (shmem_for(single ? single_lds : h->class_lds[c]) > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower EMAT_LDS_MAX or disable use_lds");
-  // (re)build the schedule; with lists: at the first launch from the size proxy, at the second from measured ticks,
-  // then every few launches as the trees drift
-  const bool want_rebalance = lists && h->schedule_valid && (!h->have_measured_cost || h->launches_since_balance >= h->cfg_rebalance_every);
-  if (!h->schedule_valid || want_rebalance) {
-    if (h->schedule_valid) {   // previous launch's per-part ticks (waits for that launch)
-      std::vector<int64_t> ticks(n);
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      HIP_TRY(hipMemcpy(ticks.data(), h->d_part_ticks.p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost));
-      bool any = false;
-      for (int i = 0; i < n; ++i) if (ticks[i] > 0) { h->part_cost[i] = (double)ticks[i]; any = true; }
-      h->have_measured_cost = any;
-    }
-    int nblocks = n;
-    if (lists) {
-      int per_cu = 0;
-      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_run_moves, k_wave, shmem_for(single_lds)));
-      nblocks = std::max(1, per_cu) * std::max(1, h->num_cus);
-      if (h->cfg_sched_blocks > 0) nblocks = h->cfg_sched_blocks;
-    }
-    st = build_schedule(h, nblocks); if (st) return st;
-    if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] schedule: %d parts on %d workgroups, %s\n", n, h->sched_blocks, lists ? (h->have_measured_cost ? "lists from measured costs" : "lists from size proxy") : "largest first");
-  }
+  for (int c = 0; c < h->num_classes; ++c)
+    if (shmem_for(h->class_lds[c]) > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower EMAT_LDS_MAX or disable use_lds");
+  if (!h->order_valid) { st = build_order(h); if (st) return st; }
   KernelArgs a = make_args(h);
   a.moves_per_part = per_part; a.extra_moves_part0 = extra0;
   a.lds_scratch_bytes = lds_scratch;
   HIP_TRY(hipEventRecord(h->ev_start, h->stream));
-  if (single) {
-    const size_t sh = shmem_for(single_lds);
-    if (sh > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    a.lds_slab_bytes = single_lds;
-    hipLaunchKernelGGL(k_run_moves, dim3((unsigned)h->sched_blocks), dim3(k_wave), sh, h->stream, a);
-    HIP_TRY(hipGetLastError());
-  } else {
-    // fork: every class runs on its own stream so that the classes share the chip; class 0 (largest parts) first
+  {
     const size_t sh_max = shmem_for(*std::max_element(h->class_lds, h->class_lds + h->num_classes));
     if (sh_max > 48 * 1024) {
       HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_max));
@@ -842,7 +769,6 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0) {
     if (forked) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[1], 0));
   }
   HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
-  ++h->launches_since_balance;
   h->host_slabs_current = false;
   return EMAT_OK;
 }
@@ -877,10 +803,6 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   }
   if (const char* e = getenv("EMAT_LDS_MAX")) h->cfg_lds_max = (uint32_t)atoi(e) & ~511u;
   if (const char* e = getenv("EMAT_GIANTS")) h->cfg_giants = atoi(e) != 0;
-  if (const char* e = getenv("EMAT_GIANT_PCT")) h->cfg_giant_pct = std::max(0, std::min(50, atoi(e)));
-  if (const char* e = getenv("EMAT_BALANCE")) h->cfg_balance = atoi(e) != 0;
-  if (const char* e = getenv("EMAT_SCHED_BLOCKS")) h->cfg_sched_blocks = atoi(e);
-  if (const char* e = getenv("EMAT_REBALANCE_EVERY")) h->cfg_rebalance_every = std::max(1, atoi(e));
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return EMAT_ERR_HIP; h->num_cus = prop.multiProcessorCount; }
   if (hipStreamCreate(&h->stream) != hipSuccess) return EMAT_ERR_HIP;
   for (hipEvent_t* e : {&h->ev_start, &h->ev_stop}) if (hipEventCreate(e) != hipSuccess) return EMAT_ERR_HIP;
