@@ -58,6 +58,8 @@ struct KernelArgs {
   uint32_t lds_slab_bytes;        // capacity of the LDS staging area (0 = never stage)
   uint32_t lds_scratch_bytes;     // size of the per-part LDS scratch arena
   int64_t moves_per_part;
+  const int64_t* moves_for_part;  // [num_parts] or null: per-part counts of a recovery launch (overrides moves_per_part / extra_moves_part0)
+  int32_t* part_status;           // [num_parts] status every part ended its chain with (0 = ran to completion)
   int64_t extra_moves_part0;      // remainder of Run::run_local_moves goes to part 0 (run.cpp:683-689)
 };
 
@@ -107,7 +109,7 @@ __device__ inline const double* stage_tables(const KernelArgs& a, double* lds_ta
 #define EMAT_WAVES_PER_EU 4
 #endif
 template <class CtxT, class Step> __device__ __forceinline__ void run_chain(CtxT& c, const KernelArgs& a, int part, SlabHeader* H, Step step) {
-  const int64_t moves = a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0);
+  const int64_t moves = a.moves_for_part ? a.moves_for_part[part] : a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0);
   const uint64_t tick0 = wall_clock64();
   if (H->status == 0) {
     for (int64_t i = 0; i < moves; ++i) if (!step(c)) break;
@@ -118,6 +120,7 @@ template <class CtxT, class Step> __device__ __forceinline__ void run_chain(CtxT
   H->device_ticks += dt;
   a.part_ticks[part] = dt;
   a.part_ticks[a.num_parts + part] = (int64_t)tick0;   // start time, for occupancy timelines (emat_debug_part_ticks)
+  a.part_status[part] = H->status;
 }
 
 __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
@@ -344,6 +347,8 @@ struct PartHost {
   uint64_t slab_off = 0;
   uint32_t slab_bytes = 0;
   emat_part_stats stats{};
+  int64_t expected_moves = 0;      // moves requested of this part since its upload
+  double space_boost = 1.0;        // multiplier of the heap and scratch capacities; doubled when the part ran out of space
 };
 
 }  // namespace emat
@@ -366,6 +371,7 @@ struct emat_backend {
                                                      // class always extends to the largest part (its staging area is still that percentile's size)
   uint32_t cfg_lds_max = 96 * 1024;                  // EMAT_LDS_MAX (tuning knob): largest staging area; larger parts run out of HBM
   bool order_valid = false;         // d_order holds the current parts, largest first
+  bool pass_pending = false;        // a launch has not been checked for stopped parts yet (finish_pass)
   double last_run_ms = 0.0;
   // model
   std::vector<uint8_t> ref, partition_for_site;
@@ -382,7 +388,7 @@ struct emat_backend {
   int uploads_expected = 0;
   int root_part = -1;
   std::vector<uint8_t> h_slabs;
-  DevBuf<uint8_t> d_slabs; DevBuf<uint64_t> d_slab_off; DevBuf<int32_t> d_order; DevBuf<int64_t> d_part_ticks;
+  DevBuf<uint8_t> d_slabs; DevBuf<uint64_t> d_slab_off; DevBuf<int32_t> d_order, d_part_status; DevBuf<int64_t> d_part_ticks, d_moves_for_part;
   bool slabs_on_device = false;     // device slabs are materialised
   bool host_slabs_current = false;  // h_slabs mirrors the device
   bool derived_valid = false;
@@ -543,7 +549,7 @@ void refresh_ref_derived(emat_backend* h) {
 
 KernelArgs make_args(emat_backend* h) {
   KernelArgs a{};
-  a.slabs = h->d_slabs.p; a.slab_off = h->d_slab_off.p; a.order = h->d_order.p; a.part_ticks = h->d_part_ticks.p; a.ref_freqs = h->d_ref_freqs.p; a.cum_nu = h->d_cum_nu.p; a.stats_out = h->d_stats.p;
+  a.slabs = h->d_slabs.p; a.slab_off = h->d_slab_off.p; a.order = h->d_order.p; a.part_status = h->d_part_status.p; a.moves_for_part = nullptr; a.part_ticks = h->d_part_ticks.p; a.ref_freqs = h->d_ref_freqs.p; a.cum_nu = h->d_cum_nu.p; a.stats_out = h->d_stats.p;
   a.evo.num_sites = h->L; a.evo.num_partitions = h->num_partitions;
   a.evo.ref_sequence = h->d_ref.p; a.evo.partition_for_site = h->d_part.p; a.evo.nu_l = h->d_nu.p; a.evo.cum_Q_l = h->d_cumQ.p;
   a.evo.mu = h->d_mu.p; a.evo.pi = h->d_pi.p; a.evo.q = h->d_q.p;
@@ -553,7 +559,56 @@ KernelArgs make_args(emat_backend* h) {
 }
 
 // Bring the host copies of all parts up to date with the device.
+emat_status pull_from_device(emat_backend* h);
+emat_status materialize(emat_backend* h);
+emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, const std::vector<int64_t>* counts);
+
+// After a launch: did every part run its chain to completion?  A part that ran out of list-heap or scratch space
+// stops BEFORE a move with its state intact (status 101): it is given twice the room and the rest of its moves, up
+// to four times.  Any other status means an invariant broke inside a move; that is reported, loudly, and the caller
+// must not use the part's tree.
+emat_status finish_pass(emat_backend* h) {
+  if (h->host_only || !h->pass_pending || !h->slabs_on_device) return EMAT_OK;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  const size_t n = h->parts.size();
+  std::vector<int32_t> status(n);
+  for (int round = 0; round < 5; ++round) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(status.data(), h->d_part_status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    h->pass_pending = false;
+    size_t stopped = 0, fatal = n;
+    for (size_t p = 0; p < n; ++p) if (status[p] != 0) { ++stopped; if (status[p] != k_part_need_space && fatal == n) fatal = p; }
+    if (stopped == 0) return EMAT_OK;
+    h->host_slabs_current = false;
+    emat_status st = pull_from_device(h); if (st) return st;
+    if (fatal != n) {
+      const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + h->parts[fatal].slab_off);
+      return fail(h, status[fatal] == k_part_cell_overflow ? EMAT_ERR_CAPACITY : EMAT_ERR_INTERNAL,
+                  "part " + std::to_string(fatal) + " stopped inside a move with status " + std::to_string(status[fatal]) + " (device source line " + std::to_string(H->fail_line) +
+                  "); " + std::to_string(stopped) + " part(s) stopped in all");
+    }
+    if (round == 4) return fail(h, EMAT_ERR_CAPACITY, std::to_string(stopped) + " part(s) still out of slab space after four doublings");
+    std::vector<int64_t> counts(n, 0);
+    for (size_t p = 0; p < n; ++p) if (status[p] != 0) {
+      PartHost& ph = h->parts[p];
+      ph.space_boost *= 2.0;
+      counts[p] = ph.expected_moves - ph.stats.moves_done;
+      ph.stats.status = 0;
+    }
+    if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] %zu part(s) ran out of slab space: re-materialising with more room and running the rest of their moves\n", stopped);
+    h->slabs_on_device = false; h->host_slabs_current = false;   // every part is re-encoded from its decoded state (tree, RNG, cells, statistics)
+    st = launch_moves(h, 0, 0, &counts); if (st) return st;
+  }
+  return EMAT_OK;
+}
+
+emat_status pull_from_device_impl(emat_backend* h);
 emat_status pull_from_device(emat_backend* h) {
+  if (h->host_only || !h->slabs_on_device) return EMAT_OK;
+  if (h->pass_pending) { emat_status st = finish_pass(h); if (st) return st; }
+  return pull_from_device_impl(h);
+}
+emat_status pull_from_device_impl(emat_backend* h) {
   if (h->host_only || !h->slabs_on_device || h->host_slabs_current) return EMAT_OK;
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -588,11 +643,11 @@ emat_status materialize(emat_backend* h) {
     const int n = ph.tree.num_nodes();
     const uint32_t content = heap_content_bytes(ph.tree);
     Geo g;
-    g.heap = a16((uint32_t)std::max<double>(2048.0, content * slack + h->cfg_heap_per_node * n));
+    g.heap = a16((uint32_t)(ph.space_boost * std::max<double>(2048.0, content * slack + h->cfg_heap_per_node * n)));
     // worst case of one move: an unlimited SPR scan visits every (branch, inter-mutation segment) region of the
     // part (48 B each) with a DFS stack of up to 4 items per region (12 B each), next to two graft analyses
     const uint32_t regions_max = (uint32_t)n + (uint32_t)ph.tree.num_muts();
-    g.scratch = a16(std::max<uint32_t>(8192u, 128u * regions_max + 4u * content + 256u * (uint32_t)n));
+    g.scratch = a16((uint32_t)(ph.space_boost * std::max<uint32_t>(8192u, 128u * regions_max + 4u * content + 256u * (uint32_t)n)));
     int nc = (int)ph.coal.k_bar_p.size();
     g.cell_cap = ph.includes_run_root ? nc + std::max(512, nc) : nc;   // room for the root part's grid to grow into the past (a part that outgrows it stops with status 103)
     geo[p] = g;
@@ -685,6 +740,7 @@ emat_status materialize(emat_backend* h) {
   HIP_TRY(h->d_slabs.upload(h->h_slabs.data(), h->h_slabs.size()));
   HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
   { std::vector<int64_t> z(2 * h->parts.size(), 0); HIP_TRY(h->d_part_ticks.upload(z.data(), z.size())); }
+  { std::vector<int32_t> z(h->parts.size(), 0); HIP_TRY(h->d_part_status.upload(z.data(), z.size())); }
   h->slabs_on_device = true; h->host_slabs_current = true; h->derived_valid = false;
   return EMAT_OK;
 }
@@ -716,7 +772,7 @@ emat_status build_order(emat_backend* h) {
   return EMAT_OK;
 }
 
-emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0) {
+emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, const std::vector<int64_t>* counts = nullptr) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
   emat_status st = sync_model_to_device(h); if (st) return st;
@@ -730,6 +786,9 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0) {
   KernelArgs a = make_args(h);
   a.moves_per_part = per_part; a.extra_moves_part0 = extra0;
   a.lds_scratch_bytes = lds_scratch;
+  if (counts) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(h->d_moves_for_part.upload(counts->data(), counts->size())); a.moves_for_part = h->d_moves_for_part.p; }
+  else for (size_t p = 0; p < h->parts.size(); ++p) h->parts[p].expected_moves += per_part + (p == 0 ? extra0 : 0);
+  h->pass_pending = true;
   HIP_TRY(hipEventRecord(h->ev_start, h->stream));
   {
     const size_t sh_max = shmem_for(*std::max_element(h->class_lds, h->class_lds + h->num_classes));
@@ -879,7 +938,7 @@ emat_status emat_part_upload(emat_backend* h, int32_t part_id, const emat_flat_t
   ph.tree = FlatTree::from_view(*subtree);
   ph.includes_run_root = includes_run_root != 0;
   ph.rng.key = seed; ph.rng.counter = 0; ph.rng.spare = 0; ph.rng.has_spare = false;
-  ph.uploaded = true; ph.stats = emat_part_stats{};
+  ph.uploaded = true; ph.stats = emat_part_stats{}; ph.expected_moves = 0; ph.space_boost = 1.0;
   if (ph.includes_run_root) h->root_part = part_id;
   return EMAT_OK;
 }
@@ -979,7 +1038,7 @@ emat_status emat_synchronize(emat_backend* h) {
   if (h->host_only) return EMAT_OK;
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipStreamSynchronize(h->stream));
-  return EMAT_OK;
+  return finish_pass(h);
 }
 emat_status emat_recalc_derived(emat_backend* h) {
   if (!h) return EMAT_ERR_INVALID_ARGUMENT;

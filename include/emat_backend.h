@@ -160,6 +160,12 @@ emat_status emat_coalescent_finish(emat_backend* h, const double* k_twiddle_bar 
 emat_status emat_run_local_moves(emat_backend* h, int64_t count);
 /* Same, with an explicit number of moves per part (all parts the same). */
 emat_status emat_run_moves_per_part(emat_backend* h, int64_t moves_per_part);
+/* Waits for the launches issued so far and checks that every part ran its chain to completion.  A part that ran out of
+ * list-heap or scratch space stops BEFORE a move with its state intact; it is re-materialised with twice the room and
+ * the rest of its moves run, transparently (up to four doublings, then EMAT_ERR_CAPACITY).  A part that stopped INSIDE
+ * a move (an invariant the reference CHECKs, or the root part's cell table overflowing) makes this -- and every getter,
+ * all of which synchronise first -- fail with EMAT_ERR_INTERNAL / EMAT_ERR_CAPACITY naming the part; the reference
+ * aborts in that situation. */
 emat_status emat_synchronize(emat_backend* h);
 
 /* Forces the from-scratch recomputation that Subrun::validate_derived_quantities() performs

@@ -153,3 +153,18 @@ def test_global_move_statistics():
     evo = (np.array([sc.mu, 2.0 * sc.mu]), np.stack([np.asarray(sc.pi, np.float64), pi2]), np.stack([d.hky_q_matrix(sc.kappa, sc.pi), d.hky_q_matrix(2.0, pi2)]),
            (np.arange(sc.num_sites) // 700 % 2).astype(np.int32))
     _stats_parity(sc, 5, 1000, seed=47, evo=evo, P=2)
+
+
+def test_parts_that_run_out_of_slab_space_are_regrown_and_finish(monkeypatch):
+    """A part whose list heap is too small stops BEFORE a move (status 101, state intact); the engine must notice at the
+    next synchronisation, give it more room and run the rest of its moves -- the caller sees a complete pass whose
+    results still match the oracle move for move.  Forced here by uploading with no heap slack at all."""
+    import delphy_amd.engine as e
+    monkeypatch.setenv("EMAT_SLACK", "1.0")
+    monkeypatch.setenv("EMAT_HEAP_PER_NODE", "0")
+    sc = make_scenario("C1", num_tips=80, num_sites=400, seed=77)
+    sc.mu = 3e-4
+    tree, ref, tmax = e.make_synthetic_emat(e.SynthParams(num_tips=80, num_sites=400, mu=3e-4, gaps_per_tip=3, mean_gap_len=25, seed=77))
+    sc.tree, sc.ref, sc.t_max_tip = tree, ref, tmax
+    sc.pop = d.PopModel.exp(tmax, 365.0, 0.0, 0.0)
+    run_parity(sc, 2, 4000, trace=0)   # the trace ring restarts when a part is re-materialised, so traces are not compared
