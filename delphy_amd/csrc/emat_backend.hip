@@ -108,8 +108,7 @@ __device__ inline const double* stage_tables(const KernelArgs& a, double* lds_ta
 #ifndef EMAT_WAVES_PER_EU
 #define EMAT_WAVES_PER_EU 4
 #endif
-template <class CtxT, class Step> __device__ __forceinline__ void run_chain(CtxT& c, const KernelArgs& a, int part, SlabHeader* H, Step step) {
-  const int64_t moves = a.moves_for_part ? a.moves_for_part[part] : a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0);
+template <class CtxT, class Step> __device__ __forceinline__ void run_chain(CtxT& c, const KernelArgs& a, int part, SlabHeader* H, int64_t moves, Step step) {
   const uint64_t tick0 = wall_clock64();
   if (H->status == 0) {
     for (int64_t i = 0; i < moves; ++i) if (!step(c)) break;
@@ -118,58 +117,83 @@ template <class CtxT, class Step> __device__ __forceinline__ void run_chain(CtxT
   H->alg_bytes += c.bytes;
   const int64_t dt = (int64_t)(wall_clock64() - tick0);
   H->device_ticks += dt;
-  a.part_ticks[part] = dt;
-  a.part_ticks[a.num_parts + part] = (int64_t)tick0;   // start time, for occupancy timelines (emat_debug_part_ticks)
+  a.part_ticks[part] += dt;
   a.part_status[part] = H->status;
 }
+
+// Room a part staged with an LDS-local heap limit (below) must have above its used heap to be worth staging whole.
+constexpr uint32_t k_lds_heap_room = 2048;
 
 __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
   const int lane = threadIdx.x;
   double* lds_tables = (double*)emat_lds;
   const bool tables_staged = stage_tables(a, lds_tables, lane) != nullptr;
   uint8_t* lds_slab = emat_lds + k_lds_slab_off;
-  {
-    const int part = a.order[blockIdx.x];
-    uint8_t* gslab = a.slabs + a.slab_off[part];
-    const SlabHeader* gh = (const SlabHeader*)gslab;
+  int* lds_flag = (int*)(emat_lds + k_lds_ctx_off + k_lds_ctx_bytes - 16);   // spare tail of the context slot: lane 0 -> all lanes
+  const int part = a.order[blockIdx.x];
+  uint8_t* gslab = a.slabs + a.slab_off[part];
+  SlabHeader* gh = (SlabHeader*)gslab;
+  const int64_t target = a.moves_for_part ? a.moves_for_part[part] : a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0);
+  const int64_t done_at_start = gh->moves_done;
+  const uint32_t area = a.lds_slab_bytes;
+  const bool can_stage = tables_staged && area != 0 && gh->off_nodes == (uint32_t)sizeof(SlabHeader);
+  if (lane == 0) { a.part_ticks[part] = 0; a.part_ticks[a.num_parts + part] = (int64_t)wall_clock64(); }   // duration, start (emat_debug_part_ticks)
+  // Up to two legs: a part whose USED state fits the staging area but whose heap capacity does not is staged whole with
+  // an LDS-local heap limit; should its lists outgrow that, it is written back and finishes with its heap in HBM.
+  bool allow_whole = true;
+  for (int leg = 0; leg < 2; ++leg) {
     __syncthreads();
+    const uint32_t hbm_heap_end = gh->heap_end;
+    uint32_t lds_heap_end = 0;
+    if (can_stage && allow_whole) {
+      if (hbm_heap_end <= area) lds_heap_end = hbm_heap_end;
+      else if (gh->heap_top + k_lds_heap_room <= area) lds_heap_end = area & ~15u;
+    }
+    const bool staged = lds_heap_end != 0;
+    const bool prefix = can_stage && !staged && gh->heap_begin <= area;
     // stage the persistent state (header, nodes, cells, trace, list heap) -- or, for a part too large for that, its
     // fixed-size prefix up to the list heap; scratch always stays in HBM
-    const bool can_stage = tables_staged && a.lds_slab_bytes != 0 && gh->off_nodes == (uint32_t)sizeof(SlabHeader);
-    const bool staged = can_stage && gh->heap_end <= a.lds_slab_bytes;
-    const bool prefix = can_stage && !staged && gh->heap_begin <= a.lds_slab_bytes;
     const uint32_t staged_bytes = staged ? gh->heap_top : (prefix ? gh->heap_begin : 0u);
     if (staged_bytes) wave_copy16(lds_slab, gslab, staged_bytes, lane);
     __syncthreads();
     if (lane == 0) {
+      SlabHeader* H = (staged || prefix) ? (SlabHeader*)lds_slab : gh;
+      const int64_t moves = target - (H->moves_done - done_at_start);
+      int again = 0;
       // The context lives in LDS, not in private memory: it is touched by almost every instruction.
       if (staged) {
         dev_lds::Ctx& c = *(dev_lds::Ctx*)(emat_lds + k_lds_ctx_off);
         init_ctx(c, lds_slab, gslab, a, lds_tables);
+        H->heap_end = lds_heap_end;
         // whatever the part leaves unused of the staging area (plus the optional extra arena) serves as the first-level
         // scratch arena of its moves; scratch that does not fit goes to the part's HBM scratch region as before
-        const uint32_t used = (gh->heap_end + 15u) & ~15u;
-        c.A = lds_slab + used; c.a_end = a.lds_slab_bytes + a.lds_scratch_bytes - used;
+        const uint32_t used = (lds_heap_end + 15u) & ~15u;
+        c.A = lds_slab + used; c.a_end = area + a.lds_scratch_bytes - used;
         // The root part is one chain like any other, but its moves walk long runs of coalescent cells (deep branches span
         // hundreds of cells): compute-bound, the longest chain of the pass and alone in its launch.  Let its wave win
         // instruction-issue arbitration on its SIMD.
         const bool is_root_part = (gh->flags & k_flag_includes_run_root) != 0;
         if (is_root_part) __builtin_amdgcn_s_setprio(3);
-        run_chain(c, a, part, (SlabHeader*)lds_slab, [](dev_lds::Ctx& cc) { return dev_lds::mcmc_sub_iteration(cc); });
+        run_chain(c, a, part, H, moves, [](dev_lds::Ctx& cc) { return dev_lds::mcmc_sub_iteration(cc); });
         if (is_root_part) __builtin_amdgcn_s_setprio(0);
+        H->heap_end = hbm_heap_end;
+        if (H->status == k_part_need_space && lds_heap_end < hbm_heap_end && H->heap_top <= hbm_heap_end) { H->status = 0; a.part_status[part] = 0; again = 1; }
       } else if (prefix) {
         dev_mix::Ctx& c = *(dev_mix::Ctx*)(emat_lds + k_lds_ctx_off);
         init_ctx(c, lds_slab, gslab, a, lds_tables);
-        run_chain(c, a, part, (SlabHeader*)lds_slab, [](dev_mix::Ctx& cc) { return dev_mix::mcmc_sub_iteration(cc); });
+        run_chain(c, a, part, H, moves, [](dev_mix::Ctx& cc) { return dev_mix::mcmc_sub_iteration(cc); });
       } else {
         dev::Ctx& c = *(dev::Ctx*)(emat_lds + k_lds_ctx_off);
         init_ctx(c, gslab, gslab, a, tables_staged ? lds_tables : nullptr);
-        run_chain(c, a, part, (SlabHeader*)gslab, [](dev::Ctx& cc) { return dev::mcmc_sub_iteration(cc); });
+        run_chain(c, a, part, H, moves, [](dev::Ctx& cc) { return dev::mcmc_sub_iteration(cc); });
       }
+      *lds_flag = again;
     }
     __syncthreads();
     if (staged) wave_copy16(gslab, lds_slab, ((const SlabHeader*)lds_slab)->heap_top, lane);
     else if (prefix) wave_copy16(gslab, lds_slab, staged_bytes, lane);
+    if (*lds_flag == 0) break;
+    allow_whole = false;
   }
 }
 __global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves(KernelArgs a) { run_moves_body(a); }
@@ -1185,7 +1209,7 @@ emat_status emat_debug_variant_counts(emat_backend* h, int32_t* out3) {
   for (auto& ph : h->parts) {
     const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + ph.slab_off);
     const bool can = tables && area != 0 && H->off_nodes == (uint32_t)sizeof(SlabHeader);
-    if (can && H->heap_end <= area) ++out3[0]; else if (can && H->heap_begin <= area) ++out3[1]; else ++out3[2];
+    if (can && (H->heap_end <= area || H->heap_top + k_lds_heap_room <= area)) ++out3[0]; else if (can && H->heap_begin <= area) ++out3[1]; else ++out3[2];
   }
   return EMAT_OK;
 }

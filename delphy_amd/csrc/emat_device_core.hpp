@@ -85,7 +85,7 @@ struct Ctx {
   double tr_kind, tr_node, tr_acc, tr_log_mh;
 };
 
-static_assert(sizeof(Ctx) <= k_lds_ctx_bytes, "context outgrew its LDS slot");
+static_assert(sizeof(Ctx) + 16 <= k_lds_ctx_bytes, "context outgrew its LDS slot (the last 16 bytes are the kernel's flag word)");
 // Base pointers of the part's persistent state.
 #if EMAT_VARIANT_LDS
 EMAT_DF uint8_t* slab_of(const Ctx&) { return emat_lds + k_lds_slab_off; }
