@@ -361,6 +361,28 @@ template <class T> struct DevBuf {
   }
 };
 
+// Host mirror of the device slabs in page-locked memory (grow-only): the per-cycle 64 MB H2D / D2H of C4 run at PCIe
+// speed instead of being staged through a bounce buffer.  Not zero-filled: encode_slab initialises what it owns.
+struct PinnedBytes {
+  uint8_t* p = nullptr; size_t n = 0, cap = 0;
+  ~PinnedBytes() { if (p) (void)hipHostFree(p); }
+  uint8_t* data() { return p; }
+  const uint8_t* data() const { return p; }
+  size_t size() const { return n; }
+  hipError_t resize(size_t bytes) {
+    if (bytes > cap) {
+      if (p) (void)hipHostFree(p);
+      p = nullptr; cap = 0;
+      const size_t want = bytes + bytes / 8;
+      hipError_t e = hipHostMalloc((void**)&p, want, hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+      cap = want;
+    }
+    n = bytes;
+    return hipSuccess;
+  }
+};
+
 struct PartHost {
   FlatTree tree;
   bool includes_run_root = false;
@@ -411,7 +433,7 @@ struct emat_backend {
   std::vector<PartHost> parts;
   int uploads_expected = 0;
   int root_part = -1;
-  std::vector<uint8_t> h_slabs;
+  PinnedBytes h_slabs;
   DevBuf<uint8_t> d_slabs; DevBuf<uint64_t> d_slab_off; DevBuf<int32_t> d_order, d_part_status; DevBuf<int64_t> d_part_ticks, d_moves_for_part;
   bool slabs_on_device = false;     // device slabs are materialised
   bool host_slabs_current = false;  // h_slabs mirrors the device
@@ -434,7 +456,7 @@ uint32_t a16(uint32_t x) { return (x + 15u) & ~15u; }
 
 // Encode one part into its slab (layout: emat_slab.hpp).
 void encode_slab(const emat_backend& B, const PartHost& ph, uint8_t* slab, uint32_t slab_bytes, uint32_t heap_bytes, uint32_t scratch_bytes, int cell_cap, int trace_cap) {
-  std::memset(slab, 0, slab_bytes);
+  std::memset(slab, 0, slab_bytes - scratch_bytes);   // scratch (the slab's tail) is transient: never read before written
   const FlatTree& t = ph.tree;
   const int n = t.num_nodes();
   SlabHeader* H = (SlabHeader*)slab;
@@ -681,7 +703,7 @@ emat_status materialize(emat_backend* h) {
     h->prefix_bytes[p] = bytes - g.scratch - g.heap;
     h->max_slab_bytes = std::max(h->max_slab_bytes, bytes);
   }
-  h->h_slabs.assign(off, 0);
+  HIP_TRY(h->h_slabs.resize(off));
   std::vector<uint64_t> offs(h->parts.size());
   parallel_for((int)h->parts.size(), [&](int p) {
     PartHost& ph = h->parts[p];

@@ -1,1 +1,2 @@
-EMAT_LIB_PATH=$PWD/delphy_amd/libemat_hip_prof.so python scripts/gpu_probe.py phase 2>&1 | tail -19
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+python scripts/gpu_probe.py cycle 2>&1 | grep -E "^cycle" | cut -c1-330
