@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--tips", type=int, default=None, help="override the number of tips (debug)")
     ap.add_argument("--parts", type=int, default=None, help="number of partition parts requested from the partitioner (default 8192 per GPU)")
     ap.add_argument("--moves-per-part", type=int, default=1000)
+    ap.add_argument("--max-part-nodes", type=int, default=0, help="not in the reference: cut parts larger than this further (0 = the reference's partitioning rule)")
     ap.add_argument("--no-lds", action="store_true")
     ap.add_argument("--no-topology", action="store_true", help="diagnostic: disable subtree-slide and SPR moves")
     ap.add_argument("--only-displace", action="store_true", help="diagnostic: only inner-node displacement moves")
@@ -111,7 +112,7 @@ def main():
             t = torch.from_numpy(np.ascontiguousarray(arr))
             dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op])
             return t.numpy()
-    eng = ShardedEngine(sc, num_parts=args.parts, seed=20261001, rank=rank, world=world, device=local_rank, use_lds=not args.no_lds, allreduce=allreduce)
+    eng = ShardedEngine(sc, num_parts=args.parts, seed=20261001, rank=rank, world=world, device=local_rank, use_lds=not args.no_lds, allreduce=allreduce, max_part_nodes=args.max_part_nodes)
     eng.topology = not args.no_topology
     eng.only_displace = args.only_displace
     eng.setup()   # partition, upload this rank's parts, exchange the coalescent grid, recalc derived quantities
@@ -159,7 +160,7 @@ def main():
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     # the committed PMC figure was collected on the default single-GPU workload: only quote it for that one
-    if os.path.exists(pmc_path) and world == 1 and args.workload == "C4" and args.tips is None and args.parts == 8192 and args.moves_per_part == 1000 and not (args.no_topology or args.only_displace or args.no_lds):
+    if os.path.exists(pmc_path) and world == 1 and args.workload == "C4" and args.tips is None and args.parts == 8192 and args.moves_per_part == 1000 and args.max_part_nodes == 0 and not (args.no_topology or args.only_displace or args.no_lds):
         try:
             traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
         except Exception:
@@ -188,7 +189,7 @@ def main():
                 "workload": "%s: synthetic %d-tip EMAT, %d sites, HKY(kappa=5) + %s, %d partition parts (%d nodes), %d moves/part/step, move mix 7.5/7.5/15/1/1"
                             % (sc.name, sc.num_tips, sc.num_sites, {0: "constant pop", 1: "exponential-growth coalescent", 2: "skygrid"}[sc.pop.kind],
                                total_parts, sc.tree.num_nodes, args.moves_per_part),
-                "parts_per_gpu": local_parts,
+                "parts_per_gpu": local_parts, "max_part_nodes": args.max_part_nodes,
                 "lds_staging": not args.no_lds,
                 "parallelism": "parts sharded over %d GPU(s), one wavefront per part" % world,
             },

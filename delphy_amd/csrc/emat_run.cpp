@@ -101,6 +101,7 @@ struct RunDriver {
   uint64_t seed = 0;
   SplitMix64 bitgen{0};
   int num_parts = 1;
+  int max_part_nodes = 0;   // > 0: parts larger than this are cut further at every repartition (not in the reference; see refine_stencil)
   // model
   bool have_hky = false; double hky_mu = 0, hky_kappa = 1, hky_pi[4] = {0.25, 0.25, 0.25, 0.25};
   std::vector<double> nu_l;
@@ -155,6 +156,55 @@ struct RunDriver {
           --num_parts_left;
         }
       }
+    }
+    return cuts;
+  }
+
+  // NOT in the reference: cut oversized parts further.  The reference sizes its parts for a handful of CPU threads and
+  // lets them vary freely (a stencil drawn for 8 000 parts routinely contains a few parts of 300+ nodes next to a
+  // median of 25); every part performs the same number of moves per pass and the GPU runs all parts at once, so the pass
+  // lasts as long as the largest part.  Any set of cut nodes is a valid partition for the sampler (it only decides
+  // which nodes are frozen during a pass), so parts above `max_part_nodes` are split at the node that halves them
+  // best, with the reference's floor of 10 nodes per part.  Applied to the stencil in use at every repartition, since
+  // part sizes drift as the tree is re-hung.
+  std::vector<int32_t> refine_stencil(std::vector<int32_t> cuts) const {
+    if (max_part_nodes <= 0) return cuts;
+    const int N = (int)tree.nodes.size();
+    const int limit = std::max(max_part_nodes, 21);
+    std::vector<char> is_cut(N, 0);
+    for (int32_t c : cuts) is_cut[c] = 1;
+    is_cut[tree.root] = 1;
+    // size[v]: nodes of v's part that lie in v's subtree (a cut child counts as one: it is a tip of this part)
+    std::vector<int32_t> size(N, 1), order; order.reserve(N);
+    { std::vector<int32_t> st; st.push_back(tree.root);
+      while (!st.empty()) { int32_t v = st.back(); st.pop_back(); order.push_back(v); if (!tree.nodes[v].is_tip()) { st.push_back(tree.nodes[v].c0); st.push_back(tree.nodes[v].c1); } } }
+    for (auto it = order.rbegin(); it != order.rend(); ++it) {
+      const HNode& nd = tree.nodes[*it];
+      if (!nd.is_tip()) size[*it] = 1 + (is_cut[nd.c0] ? 1 : size[nd.c0]) + (is_cut[nd.c1] ? 1 : size[nd.c1]);
+    }
+    std::vector<int32_t> work;
+    for (int v = 0; v < N; ++v) if (is_cut[v] && size[v] > limit) work.push_back(v);
+    while (!work.empty()) {
+      const int32_t c = work.back(); work.pop_back();
+      if (size[c] <= limit) continue;
+      // walk down the heavier side until the subtree holds at most half of the part
+      int32_t v = c, best = -1; int best_score = -1;
+      while (!tree.nodes[v].is_tip()) {
+        const int32_t a = tree.nodes[v].c0, b = tree.nodes[v].c1;
+        const int sa = is_cut[a] ? 1 : size[a], sb = is_cut[b] ? 1 : size[b];
+        const int32_t h = sa >= sb ? a : b; const int sh = std::max(sa, sb);
+        if (is_cut[h] || sh < 10) break;
+        const int rest = size[c] - sh + 1;   // the part keeps a frozen tip where the subtree was
+        const int score = std::min(sh, rest);
+        if (rest >= 10 && score > best_score) { best_score = score; best = h; }
+        if (sh * 2 <= size[c]) break;
+        v = h;
+      }
+      if (best < 0) continue;   // cannot be split within the size floor
+      is_cut[best] = 1; cuts.push_back(best);
+      for (int32_t u = tree.nodes[best].parent; ; u = tree.nodes[u].parent) { size[u] -= size[best] - 1; if (u == c) break; }
+      if (size[best] > limit) work.push_back(best);
+      if (size[c] > limit) work.push_back(c);
     }
     return cuts;
   }
@@ -365,7 +415,7 @@ struct RunDriver {
         stencil_refresh_countdown = 200;
       }
       --stencil_refresh_countdown;
-      const auto& stencil = stencils[bitgen.below((int)stencils.size())];
+      const std::vector<int32_t> stencil = refine_stencil(stencils[bitgen.below((int)stencils.size())]);
       part_kids.clear();
       t1 = now();
       partition_tree(stencil);
@@ -472,6 +522,7 @@ emat_status emat_run_create(emat_backend* backend, const emat_flat_tree* tree, c
 emat_status emat_run_destroy(emat_run* r) { delete r; return EMAT_OK; }
 const char* emat_run_last_error(const emat_run* r) { return r ? r->d.last_error.c_str() : "null run"; }
 
+emat_status emat_run_set_max_part_nodes(emat_run* r, int32_t n) { if (!r || n < 0) return EMAT_ERR_INVALID_ARGUMENT; r->d.max_part_nodes = n; return EMAT_OK; }
 emat_status emat_run_set_num_parts(emat_run* r, int32_t n) { if (!r || n < 1) return EMAT_ERR_INVALID_ARGUMENT; r->d.num_parts = n; r->d.stencils.clear(); return EMAT_OK; }
 emat_status emat_run_set_hky(emat_run* r, double mu, double kappa, const double pi[4], const double* nu_l) {
   if (!r || !pi || !(mu >= 0) || !(kappa > 0)) return EMAT_ERR_INVALID_ARGUMENT;

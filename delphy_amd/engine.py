@@ -242,7 +242,7 @@ def load_library():
         "emat_last_run_ms": [B, P(dbl)], "emat_last_kernel_ms": [B, P(dbl), P(i32)],
         "emat_synth_create": [P(_SynthParamsC), P(S)], "emat_synth_get": [S, P(_FlatTreeC), P(P(C.c_uint8)), P(dbl)],
         "emat_run_create": [B, P(_FlatTreeC), P(C.c_uint8), i32, u64, P(R)], "emat_run_destroy": [R],
-        "emat_run_set_num_parts": [R, i32], "emat_run_set_hky": [R, dbl, dbl, P(dbl), P(dbl)], "emat_run_set_pop_model": [R, P(_PopModelC)],
+        "emat_run_set_num_parts": [R, i32], "emat_run_set_max_part_nodes": [R, i32], "emat_run_set_hky": [R, dbl, dbl, P(dbl), P(dbl)], "emat_run_set_pop_model": [R, P(_PopModelC)],
         "emat_run_set_coalescent_t_step": [R, dbl], "emat_run_set_flags": [R, i32, i32],
         "emat_run_repartition": [R], "emat_run_num_parts": [R, P(i32), P(i32)],
         "emat_run_part_sizes": [R, i32, P(i32), P(i32), P(i32), P(i32)], "emat_run_part_get": [R, i32, P(_FlatTreeC), P(i32), P(u64)],
@@ -508,6 +508,10 @@ class EmatRun:
 
     def set_num_parts(self, n: int):
         self._ck(self._lib.emat_run_set_num_parts(self._h, n), "emat_run_set_num_parts")
+
+    def set_max_part_nodes(self, n: int):
+        """Not in the reference: cut parts larger than n nodes further at every repartition (0 = off)."""
+        self._ck(self._lib.emat_run_set_max_part_nodes(self._h, n), "emat_run_set_max_part_nodes")
 
     def set_hky(self, mu: float, kappa: float, pi, nu_l=None):
         pi = np.ascontiguousarray(pi, np.float64)

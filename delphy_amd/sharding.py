@@ -38,7 +38,8 @@ def _torch_allreduce(device: str):
 
 class ShardedEngine:
     def __init__(self, sc: Scenario, num_parts: int, seed: int, rank: int = 0, world: int = 1, device: int = 0, use_lds: bool = True,
-                 allreduce: Optional[Callable[[np.ndarray, str], np.ndarray]] = None, trace_moves: int = 0, t_step: Optional[float] = None):
+                 allreduce: Optional[Callable[[np.ndarray, str], np.ndarray]] = None, trace_moves: int = 0, t_step: Optional[float] = None,
+                 max_part_nodes: int = 0):
         self.sc, self.num_parts_requested, self.seed, self.rank, self.world = sc, num_parts, seed, rank, world
         self.t_step = t_step if t_step is not None else sc.default_t_step()
         if allreduce is None:
@@ -51,6 +52,7 @@ class ShardedEngine:
         self.root_part = -1
         self.topology = True
         self.only_displace = False
+        self.max_part_nodes = max_part_nodes   # not in the reference: cut larger parts further (0 = the reference's rule)
 
     def close(self):
         self.backend.close()
@@ -59,6 +61,7 @@ class ShardedEngine:
         sc = self.sc
         run = EmatRun(None, sc.tree, sc.ref, self.seed)   # host-only driver: same partition on every rank
         run.set_num_parts(self.num_parts_requested)
+        run.set_max_part_nodes(self.max_part_nodes)
         run.repartition()
         n, root_part = run.num_parts()
         self.total_parts, self.root_part = n, root_part

@@ -60,6 +60,9 @@ const char* emat_run_last_error(const emat_run* r);
 
 /* reference Run::set_num_parts (run.h:46-47) */
 emat_status emat_run_set_num_parts(emat_run* r, int32_t num_parts);
+/* NOT in the reference (0 = off, the reference's rule): at every repartition, parts of more than `max_nodes` nodes are cut
+ * further, because on the GPU a pass lasts as long as its largest part.  Any set of cut nodes is a valid partition. */
+emat_status emat_run_set_max_part_nodes(emat_run* r, int32_t max_nodes);
 /* HKY substitution model with per-site relative rates nu_l (NULL = all 1): reference Hky_model +
  * Run::derive_evo (evo_hky.cpp:7-50).  One site partition. */
 emat_status emat_run_set_hky(emat_run* r, double mu, double kappa, const double pi[4], const double* nu_l);

@@ -144,7 +144,7 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "size":
     size_probe()
 
 
-def cycle_probe(nparts=8192, moves=1000):
+def cycle_probe(nparts=8192, moves=1000, max_part_nodes=0):
     """One whole host cycle through the C++ run driver at C4: repartition (host partitioning + slab encode + H2D),
     local moves, reassemble (D2H + decode + host gather).  Gives the PCIe- and host-inclusive rate quoted in DESIGN.md."""
     import time
@@ -152,9 +152,10 @@ def cycle_probe(nparts=8192, moves=1000):
     b = d.EmatBackend(sc.num_sites)
     run = d.EmatRun(b, sc.tree, sc.ref, 20261001)
     run.set_num_parts(nparts)
+    run.set_max_part_nodes(max_part_nodes)
     run.set_hky(sc.mu, sc.kappa, sc.pi)
     run.set_pop_model(sc.pop)
-    for cyc in range(3):
+    for cyc in range(4):
         t0 = time.perf_counter(); run.repartition(); n, _ = run.num_parts(); run.push_params(); t1 = time.perf_counter()
         run.run_moves(n * moves); b.synchronize(); t2 = time.perf_counter()
         ms = b.last_run_ms()
@@ -163,7 +164,9 @@ def cycle_probe(nparts=8192, moves=1000):
         if cyc == 0: prev = np.zeros(0)
         d_t = ticks - (prev if len(prev) == n else 0) if False else ticks   # parts are re-uploaded every cycle: ticks restart
         top = np.argsort(-d_t)[:4]
-        print("   slowest parts:", ", ".join("part %d nodes %d %.1f ms" % (i, st[i]["num_nodes"], d_t[i] / 1e5) for i in top))
+        _, rp = run.num_parts()
+        print("   slowest parts:", ", ".join("part %d nodes %d %.1f ms" % (i, st[i]["num_nodes"], d_t[i] / 1e5) for i in top),
+              "| root part %d: %.1f ms, %d cells" % (rp, d_t[rp] / 1e5, len(b.part_coalescent(rp)["k_bar_p"])))
         run.reassemble(); t3 = time.perf_counter()
         print("cycle %d: %d parts | repartition+upload %.1f ms | moves %.1f ms (kernel %.1f ms; first call includes slab build + H2D + recalc) | reassemble (D2H + gather) %.1f ms | "
               "whole cycle %.1f ms => %.1f M moves/s inclusive vs %.1f M moves/s resident" % (cyc, n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, ms, (t3 - t2) * 1e3, (t3 - t0) * 1e3,
@@ -172,7 +175,7 @@ def cycle_probe(nparts=8192, moves=1000):
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "cycle":
-    cycle_probe()
+    cycle_probe(max_part_nodes=int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 
 
 def timeline_probe(nparts=8192, moves=1000):

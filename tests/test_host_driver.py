@@ -147,3 +147,36 @@ def test_global_statistics_decompose_over_parts():
     split.close()
     assert ns == nw and np.array_equal(Ms, Mw)
     assert np.allclose(Ts, Tw, rtol=1e-10, atol=0)
+
+
+def test_oversized_parts_can_be_cut_further(sc):
+    """emat_run_set_max_part_nodes (not in the reference): with a limit, no part exceeds it (parts cannot shrink below the
+    reference's floor of 10), the partition still covers the tree, the parts still pass the reference's tree invariants,
+    and reassembling reproduces the tree exactly."""
+    from oracle_ffi import OracleEngine
+    from helpers import configure
+    sizes = {}
+    for limit in (0, 40):
+        run = d.EmatRun(None, sc.tree, sc.ref, 3)
+        run.set_num_parts(8)
+        run.set_max_part_nodes(limit)
+        run.repartition()
+        n, root_part = run.num_parts()
+        parts = [run.part(i) for i in range(n)]
+        sizes[limit] = [t.num_nodes for t, _, _ in parts]
+        assert sum(sizes[limit]) == sc.tree.num_nodes + (n - 1)
+        if limit:
+            assert max(sizes[limit]) <= limit and min(sizes[limit]) >= 3
+            _, ref = run.tree()
+            chk = OracleEngine(sc.num_sites)
+            configure(chk, sc, ref, [t for t, _, _ in parts], [r for _, r, _ in parts], [s for _, _, s in parts], root_part)
+            for p in range(n):
+                rc, msg = chk.part_check(p)
+                assert rc == 0, "part %d: %s" % (p, msg)
+            chk.close()
+        run.reassemble()
+        t2, ref2 = run.tree()
+        assert_trees_match(t2, sc.tree, 0.0, "reassembled with limit %d" % limit)
+        run.close()
+    assert max(sizes[0]) > 40, "the unrefined partition should contain a part above the limit for this test to bite"
+    assert len(sizes[40]) > len(sizes[0])
