@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "flat_tree.hpp"
+#include "host_parallel.hpp"
 
 namespace emat {
 
@@ -184,19 +185,20 @@ struct CoalBuilder {
     const int P = (int)trees.size();
     k_bar_local.assign(num_cells, 0.0); num_active_local.assign(num_cells, 0);
     fc.assign(P, 0); lc.assign(P, 0); kbar_p.assign(P, {}); ktw_p.assign(P, {});
-    for (int p = 0; p < P; ++p) {
+    parallel_for(P, [&](int p) {   // per-part lineage counts: independent
       fc[p] = cell_for(tmax[p], t_ref, t_step); lc[p] = cell_for(tmin[p], t_ref, t_step);
       if (!(0 <= fc[p] && fc[p] <= lc[p] && lc[p] < num_cells)) throw std::runtime_error("coalescent grid: bad cell range");
-      for (int c = fc[p]; c <= lc[p]; ++c) num_active_local[c] += 1;
       kbar_p[p].assign(lc[p] + 1, 0.0); ktw_p[p].assign(lc[p] + 1, 0.0);
       const FlatTree& st = *trees[p];
       for (int n = 0; n < st.num_nodes(); ++n) if (n != st.root) add_interval(st.t[st.parent[n]], st.t[n], +1.0, kbar_p[p], t_ref, t_step);
+      if (p == root_local) add_interval(cell_lbound(num_cells - 1, t_ref, t_step), st.t[st.root], +1.0, kbar_p[p], t_ref, t_step);
+    });
+    // reductions in part order (outside a part's window its counts are exactly zero: skipping them changes nothing)
+    for (int p = 0; p < P; ++p) {
+      for (int c = fc[p]; c <= lc[p]; ++c) num_active_local[c] += 1;
+      for (int i = fc[p]; i <= lc[p]; ++i) k_bar_local[i] += kbar_p[p][i];
+      for (int i = 0; i < fc[p]; ++i) if (kbar_p[p][i] != 0.0) throw std::runtime_error("coalescent grid: lineage outside the part's window");
     }
-    if (root_local >= 0) {
-      const FlatTree& rt = *trees[root_local];
-      add_interval(cell_lbound(num_cells - 1, t_ref, t_step), rt.t[rt.root], +1.0, kbar_p[root_local], t_ref, t_step);
-    }
-    for (int p = 0; p < P; ++p) for (size_t i = 0; i < kbar_p[p].size(); ++i) k_bar_local[i] += kbar_p[p][i];
   }
   // stage 3: draws, given the GLOBAL k_bar and num_active_parts; returns this rank's contribution to k_twiddle_bar
   void sample(const std::vector<double>& k_bar_global, const std::vector<int32_t>& num_active_global, std::vector<double>& k_tw_local) {
@@ -205,24 +207,23 @@ struct CoalBuilder {
     k_bar = k_bar_global; num_active = num_active_global;
     if (num_active.back() == 0) throw std::runtime_error("coalescent grid: inactive final cell");
     popsize.assign(num_cells, 0.0);
-    for (int i = 0; i < num_cells; ++i) popsize[i] = pop.pop_integral(cell_lbound(i, t_ref, t_step), cell_ubound(i, t_ref, t_step)) / t_step;
+    parallel_for(num_cells, [&](int i) { popsize[i] = pop.pop_integral(cell_lbound(i, t_ref, t_step), cell_ubound(i, t_ref, t_step)) / t_step; }, 16);
     k_tw_local.assign(num_cells, 0.0);
-    for (int p = 0; p < P; ++p)
-      for (int i = 0; i < (int)ktw_p[p].size(); ++i) {
-        if (fc[p] <= i && i <= lc[p]) {
-          double mu = kbar_p[p][i] - k_bar[i] / num_active[i];
-          double sigma = std::sqrt(popsize[i] / (num_active[i] * t_step));
-          ktw_p[p][i] = rngs[p]->gaussian(mu, sigma);
-        } else ktw_p[p][i] = 0.0;
-        k_tw_local[i] += ktw_p[p][i];
+    parallel_for(P, [&](int p) {   // every part draws from its own stream
+      for (int i = fc[p]; i <= lc[p]; ++i) {
+        double mu = kbar_p[p][i] - k_bar[i] / num_active[i];
+        double sigma = std::sqrt(popsize[i] / (num_active[i] * t_step));
+        ktw_p[p][i] = rngs[p]->gaussian(mu, sigma);
       }
+    });
+    for (int p = 0; p < P; ++p) for (int i = fc[p]; i <= lc[p]; ++i) k_tw_local[i] += ktw_p[p][i];   // part order: reproducible sums
   }
   // stage 4
   std::vector<HostCoalPart> finish(const std::vector<double>& k_tw_global) {
     const int P = (int)trees.size();
     k_tw = k_tw_global;
     std::vector<HostCoalPart> out(P);
-    for (int p = 0; p < P; ++p) {
+    parallel_for(P, [&](int p) {
       HostCoalPart& cp = out[p];
       cp.cell_first = fc[p]; cp.n_cells_total = lc[p] + 1; cp.t_ref = t_ref; cp.t_step = t_step;
       cp.k_bar_p.assign(kbar_p[p].begin() + fc[p], kbar_p[p].end());
@@ -230,8 +231,7 @@ struct CoalBuilder {
       cp.k_twiddle_bar.assign(k_tw.begin() + fc[p], k_tw.begin() + lc[p] + 1);
       cp.popsize_bar.assign(popsize.begin() + fc[p], popsize.begin() + lc[p] + 1);
       cp.num_active_parts.assign(num_active.begin() + fc[p], num_active.begin() + lc[p] + 1);
-      for (int i = 0; i < fc[p]; ++i) if (kbar_p[p][i] != 0.0) throw std::runtime_error("coalescent grid: lineage outside the part's window");
-    }
+    });
     return out;
   }
 };

@@ -214,11 +214,13 @@ struct RunDriver {
     int root_idx = (int)stencil.size(); bool root_in = false;
     for (size_t i = 0; i < stencil.size(); ++i) if (stencil[i] == tree.root) { root_in = true; root_idx = (int)i; break; }
     const int P = (int)stencil.size() + (root_in ? 0 : 1);
-    std::unordered_set<int32_t> cut_points(stencil.begin(), stencil.end());
-    if (!root_in) { cut_points.insert(tree.root); root_idx = P - 1; }
+    std::vector<char> is_cut(tree.nodes.size(), 0);
+    for (int32_t c : stencil) is_cut[c] = 1;
+    if (!root_in) { is_cut[tree.root] = 1; root_idx = P - 1; }
     root_part = root_idx;
     parts.assign(P, PartMap{});
-    for (int i = 0; i < P; ++i) {
+    part_kids.assign(P, {});
+    parallel_for(P, [&](int i) {   // every part walks down from its own cut point: independent
       PartMap& pm = parts[i];
       pm.cut_point = (i == root_part) ? tree.root : stencil[i];
       struct W { int32_t src, dst; };
@@ -229,16 +231,15 @@ struct RunDriver {
       while (!work.empty()) {
         W w = work.back(); work.pop_back();
         const HNode& sn = tree.nodes[w.src];
-        bool is_cut = cut_points.count(w.src) != 0;
-        if (sn.is_tip() || (is_cut && w.src != pm.cut_point)) continue;
+        if (sn.is_tip() || (is_cut[w.src] && w.src != pm.cut_point)) continue;
         int32_t dl = (int32_t)pm.orig.size(); pm.orig.push_back(sn.c0);
         int32_t dr = (int32_t)pm.orig.size(); pm.orig.push_back(sn.c1);
         kids.resize(pm.orig.size(), {EMAT_NO_NODE, EMAT_NO_NODE});
         kids[w.dst] = {dl, dr};
         work.push_back({sn.c0, dl}); work.push_back({sn.c1, dr});
       }
-      part_kids.push_back(std::move(kids));
-    }
+      part_kids[i] = std::move(kids);
+    });
   }
   std::vector<std::vector<std::pair<int32_t, int32_t>>> part_kids;
 
@@ -458,24 +459,23 @@ struct RunDriver {
         });
         if (bad.load() != EMAT_OK) return bk((emat_status)bad.load());
       }
-      for (size_t p = 0; p < subtrees.size(); ++p) {
+      for (size_t p = 0; p < subtrees.size(); ++p) if (subtrees[p].nodes.size() != parts[p].orig.size()) return fail(EMAT_ERR_INTERNAL, "subtree size changed");
+      // Every node of the whole tree is a non-root node of exactly one part (the run's root: the root of the root part),
+      // and that part alone writes its time, lists and child links; a cut node's parent link is written by the part
+      // above it, as the parent of one of its children.  The parts therefore gather independently.
+      parallel_for((int)subtrees.size(), [&](int p) {
         const PartMap& pm = parts[p]; const HTree& st = subtrees[p];
-        if ((int)st.nodes.size() != (int)pm.orig.size()) return fail(EMAT_ERR_INTERNAL, "subtree size changed");
         for (int s = 0; s < (int)st.nodes.size(); ++s) {
           const int32_t o = pm.orig[s]; const HNode& sn = st.nodes[s]; HNode& on = tree.nodes[o];
-          on.t = sn.t;
-          if (s != st.root) { on.muts = sn.muts; on.miss = sn.miss; on.mfs = sn.mfs; }
+          const bool owns = s != st.root || p == root_part;
+          if (owns) { on.t = sn.t; on.muts = sn.muts; on.miss = sn.miss; on.mfs = sn.mfs; }
           if (!sn.is_tip()) {
             int32_t l = pm.orig[sn.c0], r = pm.orig[sn.c1];
             on.c0 = l; on.c1 = r; tree.nodes[l].parent = o; tree.nodes[r].parent = o;
           }
         }
-        if ((int)p == root_part) {
-          const int32_t nr = pm.orig[st.root];
-          tree.root = nr; tree.nodes[nr].parent = EMAT_NO_NODE;
-          tree.nodes[nr].muts = st.nodes[st.root].muts; tree.nodes[nr].miss = st.nodes[st.root].miss; tree.nodes[nr].mfs = st.nodes[st.root].mfs;
-        }
-      }
+        if (p == root_part) { const int32_t nr = pm.orig[st.root]; tree.root = nr; tree.nodes[nr].parent = EMAT_NO_NODE; }
+      });
     } catch (const std::exception& ex) { return fail(EMAT_ERR_INTERNAL, ex.what()); }
     return EMAT_OK;
   }

@@ -1,1 +1,2 @@
-for lim in 0 100 70 50; do echo "== max part nodes $lim"; python bench.py --steps 6 --warmup 2 --no-cpu-baseline --max-part-nodes $lim 2>&1 | tail -1 | grep -o '"value": [0-9.]*\|"kernel_ms": [0-9.]*\|[0-9]* partition parts' | tr '\n' ' '; echo; done
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+EMAT_VERBOSE=1 python scripts/gpu_probe.py cycle 100 2>&1 | grep -E "^cycle [123]|emat_run\] repart" | cut -c1-260 | tail -5
