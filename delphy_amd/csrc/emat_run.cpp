@@ -47,6 +47,7 @@ struct HTree {
     for (int i = 0; i < v.num_nodes; ++i) {
       HNode& n = t.nodes[i];
       n.parent = v.parent[i]; n.c0 = v.child0[i]; n.c1 = v.child1[i]; n.t_min = v.t_min[i]; n.t_max = v.t_max[i]; n.t = v.t[i];
+      n.muts.reserve(v.mut_offset[i + 1] - v.mut_offset[i]); n.miss.reserve(v.miss_offset[i + 1] - v.miss_offset[i]); n.mfs.reserve(v.mfs_offset[i + 1] - v.mfs_offset[i]);
       for (int k = v.mut_offset[i]; k < v.mut_offset[i + 1]; ++k) n.muts.push_back({v.mut_t[k], v.mut_site[k], v.mut_from[k], v.mut_to[k]});
       for (int k = v.miss_offset[i]; k < v.miss_offset[i + 1]; ++k) n.miss.push_back({v.miss_start[k], v.miss_end[k]});
       for (int k = v.mfs_offset[i]; k < v.mfs_offset[i + 1]; ++k) n.mfs.push_back({v.mfs_site[k], v.mfs_state[k]});
@@ -56,6 +57,8 @@ struct HTree {
   FlatTree to_flat() const {
     FlatTree f; const int n = (int)nodes.size();
     f.resize_nodes(n); f.root = root;
+    { size_t nm = 0, ni = 0, nf = 0; for (const HNode& nd : nodes) { nm += nd.muts.size(); ni += nd.miss.size(); nf += nd.mfs.size(); }
+      f.mut_site.reserve(nm); f.mut_from.reserve(nm); f.mut_to.reserve(nm); f.mut_t.reserve(nm); f.miss_start.reserve(ni); f.miss_end.reserve(ni); f.mfs_site.reserve(nf); f.mfs_state.reserve(nf); }
     for (int i = 0; i < n; ++i) {
       const HNode& nd = nodes[i];
       f.parent[i] = nd.parent; f.child0[i] = nd.c0; f.child1[i] = nd.c1; f.t[i] = nd.t; f.t_min[i] = nd.t_min; f.t_max[i] = nd.t_max;
@@ -167,7 +170,7 @@ struct RunDriver {
   // which nodes are frozen during a pass), so parts above `max_part_nodes` are split at the node that halves them
   // best, with the reference's floor of 10 nodes per part.  Applied to the stencil in use at every repartition, since
   // part sizes drift as the tree is re-hung.
-  std::vector<int32_t> refine_stencil(std::vector<int32_t> cuts) const {
+  std::vector<int32_t> refine_stencil(std::vector<int32_t> cuts) const {   // needs sync_topology()
     if (max_part_nodes <= 0) return cuts;
     const int N = (int)tree.nodes.size();
     const int limit = std::max(max_part_nodes, 21);
@@ -177,10 +180,10 @@ struct RunDriver {
     // size[v]: nodes of v's part that lie in v's subtree (a cut child counts as one: it is a tip of this part)
     std::vector<int32_t> size(N, 1), order; order.reserve(N);
     { std::vector<int32_t> st; st.push_back(tree.root);
-      while (!st.empty()) { int32_t v = st.back(); st.pop_back(); order.push_back(v); if (!tree.nodes[v].is_tip()) { st.push_back(tree.nodes[v].c0); st.push_back(tree.nodes[v].c1); } } }
+      while (!st.empty()) { int32_t v = st.back(); st.pop_back(); order.push_back(v); if (tp_c0[v] != EMAT_NO_NODE) { st.push_back(tp_c0[v]); st.push_back(tp_c1[v]); } } }
     for (auto it = order.rbegin(); it != order.rend(); ++it) {
-      const HNode& nd = tree.nodes[*it];
-      if (!nd.is_tip()) size[*it] = 1 + (is_cut[nd.c0] ? 1 : size[nd.c0]) + (is_cut[nd.c1] ? 1 : size[nd.c1]);
+      const int32_t k0 = tp_c0[*it], k1 = tp_c1[*it];
+      if (k0 != EMAT_NO_NODE) size[*it] = 1 + (is_cut[k0] ? 1 : size[k0]) + (is_cut[k1] ? 1 : size[k1]);
     }
     std::vector<int32_t> work;
     for (int v = 0; v < N; ++v) if (is_cut[v] && size[v] > limit) work.push_back(v);
@@ -189,8 +192,8 @@ struct RunDriver {
       if (size[c] <= limit) continue;
       // walk down the heavier side until the subtree holds at most half of the part
       int32_t v = c, best = -1; int best_score = -1;
-      while (!tree.nodes[v].is_tip()) {
-        const int32_t a = tree.nodes[v].c0, b = tree.nodes[v].c1;
+      while (tp_c0[v] != EMAT_NO_NODE) {
+        const int32_t a = tp_c0[v], b = tp_c1[v];
         const int sa = is_cut[a] ? 1 : size[a], sb = is_cut[b] ? 1 : size[b];
         const int32_t h = sa >= sb ? a : b; const int sh = std::max(sa, sb);
         if (is_cut[h] || sh < 10) break;
@@ -202,7 +205,7 @@ struct RunDriver {
       }
       if (best < 0) continue;   // cannot be split within the size floor
       is_cut[best] = 1; cuts.push_back(best);
-      for (int32_t u = tree.nodes[best].parent; ; u = tree.nodes[u].parent) { size[u] -= size[best] - 1; if (u == c) break; }
+      for (int32_t u = tp_parent[best]; ; u = tp_parent[u]) { size[u] -= size[best] - 1; if (u == c) break; }
       if (size[best] > limit) work.push_back(best);
       if (size[c] > limit) work.push_back(c);
     }
@@ -230,18 +233,26 @@ struct RunDriver {
       std::vector<std::pair<int32_t, int32_t>> kids(1, {EMAT_NO_NODE, EMAT_NO_NODE});
       while (!work.empty()) {
         W w = work.back(); work.pop_back();
-        const HNode& sn = tree.nodes[w.src];
-        if (sn.is_tip() || (is_cut[w.src] && w.src != pm.cut_point)) continue;
-        int32_t dl = (int32_t)pm.orig.size(); pm.orig.push_back(sn.c0);
-        int32_t dr = (int32_t)pm.orig.size(); pm.orig.push_back(sn.c1);
+        const int32_t k0 = tp_c0[w.src], k1 = tp_c1[w.src];
+        if (k0 == EMAT_NO_NODE || (is_cut[w.src] && w.src != pm.cut_point)) continue;
+        int32_t dl = (int32_t)pm.orig.size(); pm.orig.push_back(k0);
+        int32_t dr = (int32_t)pm.orig.size(); pm.orig.push_back(k1);
         kids.resize(pm.orig.size(), {EMAT_NO_NODE, EMAT_NO_NODE});
         kids[w.dst] = {dl, dr};
-        work.push_back({sn.c0, dl}); work.push_back({sn.c1, dr});
+        work.push_back({k0, dl}); work.push_back({k1, dr});
       }
       part_kids[i] = std::move(kids);
     });
   }
   std::vector<std::vector<std::pair<int32_t, int32_t>>> part_kids;
+  // Compact copy of the whole tree's topology (the node records carry three vectors each and are 100+ bytes apart:
+  // walking them misses the cache at every step).  Rebuilt at the start of every repartition.
+  std::vector<int32_t> tp_parent, tp_c0, tp_c1;
+  void sync_topology() {
+    const int N = (int)tree.nodes.size();
+    tp_parent.resize(N); tp_c0.resize(N); tp_c1.resize(N);
+    parallel_for(N, [&](int v) { const HNode& nd = tree.nodes[v]; tp_parent[v] = nd.parent; tp_c0[v] = nd.c0; tp_c1[v] = nd.c1; }, 4096);
+  }
 
   // Run::normalize_root + rereference_to_root_sequence (run.cpp:258-265, phylo_tree.cpp:309-322)
   void normalize_root() {
@@ -271,30 +282,35 @@ struct RunDriver {
   void cut_point_states(std::vector<CutState>& out) {
     const int P = (int)parts.size();
     out.assign(P, CutState{});
-    std::unordered_map<int32_t, int> part_of_cut; part_of_cut.reserve(P * 2);
-    for (int p = 0; p < P; ++p) part_of_cut[parts[p].cut_point] = p;
-    // depth of every cut point = number of cut points strictly above it; process shallow ones first
+    std::vector<int32_t> part_of_node(tree.nodes.size(), -1);
+    for (int p = 0; p < P; ++p) part_of_node[parts[p].cut_point] = p;
     std::vector<int> above(P, -1);   // part whose cut point is the nearest one above this part's cut point
     std::vector<std::vector<int32_t>> path(P);   // nodes strictly below `above`'s cut point down to this cut point, top-down
-    for (int p = 0; p < P; ++p) {
+    parallel_for(P, [&](int p) {
       std::vector<int32_t> up;
       int32_t cur = parts[p].cut_point;
       up.push_back(cur);
-      for (cur = tree.nodes[cur].parent; cur != EMAT_NO_NODE; cur = tree.nodes[cur].parent) {
-        auto it = part_of_cut.find(cur);
-        if (it != part_of_cut.end()) { above[p] = it->second; break; }
+      for (cur = tp_parent[cur]; cur != EMAT_NO_NODE; cur = tp_parent[cur]) {
+        if (part_of_node[cur] >= 0) { above[p] = part_of_node[cur]; break; }
         up.push_back(cur);
       }
       path[p].assign(up.rbegin(), up.rend());
+    });
+    // levels of the forest of cut points: a part's state needs only the state of the part above it, so the parts of
+    // one level are independent
+    std::vector<std::vector<int>> levels;
+    {
+      std::vector<std::vector<int>> below(P); std::vector<int> frontier;
+      for (int p = 0; p < P; ++p) if (above[p] >= 0) below[above[p]].push_back(p); else frontier.push_back(p);
+      while (!frontier.empty()) {
+        std::vector<int> next;
+        for (int p : frontier) for (int q : below[p]) next.push_back(q);
+        levels.push_back(std::move(frontier));
+        frontier = std::move(next);
+      }
     }
-    std::vector<int> order; order.reserve(P);
-    {   // topological order over the `above` forest
-      std::vector<std::vector<int>> below(P); std::vector<int> roots;
-      for (int p = 0; p < P; ++p) if (above[p] >= 0) below[above[p]].push_back(p); else roots.push_back(p);
-      std::vector<int> stack(roots.begin(), roots.end());
-      while (!stack.empty()) { int p = stack.back(); stack.pop_back(); order.push_back(p); for (int q : below[p]) stack.push_back(q); }
-    }
-    for (int p : order) {
+    for (const auto& level : levels) parallel_for((int)level.size(), [&](int li) {
+      const int p = level[li];
       CutState& st = out[p];
       std::map<int32_t, std::pair<uint8_t, uint8_t>> deltas;
       if (above[p] >= 0) {
@@ -313,7 +329,7 @@ struct RunDriver {
       }
       st.deltas.reserve(deltas.size());
       for (const auto& [l, d] : deltas) st.deltas.push_back(HFsPair{l, d.first, d.second});
-    }
+    }, 8);
   }
 
   void build_subtrees() {   // run.cpp:131-184
@@ -416,6 +432,7 @@ struct RunDriver {
         stencil_refresh_countdown = 200;
       }
       --stencil_refresh_countdown;
+      sync_topology();
       const std::vector<int32_t> stencil = refine_stencil(stencils[bitgen.below((int)stencils.size())]);
       part_kids.clear();
       t1 = now();
@@ -442,10 +459,15 @@ struct RunDriver {
   }
 
   emat_status reassemble() {   // run.cpp:195-256
+    const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto t0 = now(), t1 = t0, t2 = t0;
     try {
       if (backend && parts_uploaded) {
         int32_t nn0, nm0, ni0, nf0;
         emat_status st0 = bk(emat_part_get_sizes(backend, 0, &nn0, &nm0, &ni0, &nf0)); if (st0) return st0;   // one D2H of all slabs, before the threads start
+        t1 = now();
         std::atomic<int> bad{EMAT_OK};
         parallel_for((int)subtrees.size(), [&](int p) {
           int32_t nn, nm, ni, nf;
@@ -459,6 +481,7 @@ struct RunDriver {
         });
         if (bad.load() != EMAT_OK) return bk((emat_status)bad.load());
       }
+      t2 = now();
       for (size_t p = 0; p < subtrees.size(); ++p) if (subtrees[p].nodes.size() != parts[p].orig.size()) return fail(EMAT_ERR_INTERNAL, "subtree size changed");
       // Every node of the whole tree is a non-root node of exactly one part (the run's root: the root of the root part),
       // and that part alone writes its time, lists and child links; a cut node's parent link is written by the part
@@ -477,6 +500,7 @@ struct RunDriver {
         if (p == root_part) { const int32_t nr = pm.orig[st.root]; tree.root = nr; tree.nodes[nr].parent = EMAT_NO_NODE; }
       });
     } catch (const std::exception& ex) { return fail(EMAT_ERR_INTERNAL, ex.what()); }
+    if (verbose) fprintf(stderr, "[emat_run] reassemble: D2H + decode %.1f ms | per-part download %.1f ms | gather %.1f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, now()));
     return EMAT_OK;
   }
 };

@@ -3,8 +3,10 @@
 #define EMAT_HOST_PARALLEL_HPP_
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <exception>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -18,22 +20,76 @@ inline int host_threads() {
   return (int)std::min(hw, 16u);   // the per-part work is allocation-bound: measured flat beyond ~16 threads
 }
 
-// Calls f(i) for i in [0, n) in chunks of `grain` dealt dynamically to the threads; rethrows the first exception.
-template <class F> void parallel_for(int n, F&& f, int grain = 32) {
-  const int T = std::min(host_threads(), std::max(1, n / std::max(1, grain)));
-  if (T <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
-  std::atomic<int> next{0};
-  std::exception_ptr err; std::mutex err_mu;
-  auto worker = [&] {
+// A small pool of persistent workers: a host cycle issues a few dozen short parallel loops, and starting threads for
+// each of them costs more than some of the loops.  One loop runs at a time (callers are serialised by `submit_mu`);
+// the calling thread takes part in the work.
+class HostPool {
+ public:
+  static HostPool& instance() { static HostPool p; return p; }
+  // Calls f(i) for i in [0, n) in chunks of `grain` dealt dynamically to the threads; rethrows the first exception.
+  void run(int n, int grain, const std::function<void(int)>& f) {
+    const int want = std::min(host_threads(), std::max(1, n / std::max(1, grain)));
+    if (want <= 1 || in_worker()) { for (int i = 0; i < n; ++i) f(i); return; }
+    std::lock_guard<std::mutex> submit(submit_mu_);
+    ensure_workers(want - 1);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      job_ = &f; n_ = n; grain_ = std::max(1, grain); next_.store(0); err_ = nullptr;
+      helpers_wanted_ = want - 1; running_ = 0; ++epoch_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> g(mu_);
+    helpers_wanted_ = 0;                       // late wakers must not join a finished job
+    done_cv_.wait(g, [&] { return running_ == 0; });
+    job_ = nullptr;
+    if (err_) std::rethrow_exception(err_);
+  }
+
+ private:
+  HostPool() = default;
+  ~HostPool() {
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  static bool& in_worker() { static thread_local bool w = false; return w; }
+  void ensure_workers(int k) {
+    while ((int)workers_.size() < k) workers_.emplace_back([this] { in_worker() = true; loop(); });
+  }
+  void work() {
     try {
-      for (;;) { const int i0 = next.fetch_add(grain); if (i0 >= n) break; for (int i = i0; i < std::min(n, i0 + grain); ++i) f(i); }
-    } catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
-  };
-  std::vector<std::thread> th; th.reserve(T - 1);
-  for (int t = 1; t < T; ++t) th.emplace_back(worker);
-  worker();
-  for (auto& t : th) t.join();
-  if (err) std::rethrow_exception(err);
+      for (;;) { const int i0 = next_.fetch_add(grain_); if (i0 >= n_) break; for (int i = i0; i < std::min(n_, i0 + grain_); ++i) (*job_)(i); }
+    } catch (...) { std::lock_guard<std::mutex> g(mu_); if (!err_) err_ = std::current_exception(); next_.store(n_); }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> g(mu_);
+    for (;;) {
+      cv_.wait(g, [&] { return stop_ || (epoch_ != seen && helpers_wanted_ > 0); });
+      if (stop_) return;
+      seen = epoch_; --helpers_wanted_; ++running_;
+      g.unlock();
+      work();
+      g.lock();
+      if (--running_ == 0) done_cv_.notify_all();
+    }
+  }
+  std::mutex submit_mu_, mu_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> workers_;
+  const std::function<void(int)>* job_ = nullptr;
+  int n_ = 0, grain_ = 1, helpers_wanted_ = 0, running_ = 0;
+  std::atomic<int> next_{0};
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+  std::exception_ptr err_;
+};
+
+template <class F> void parallel_for(int n, F&& f, int grain = 32) {
+  if (n <= 0) return;
+  const std::function<void(int)> fn = [&f](int i) { f(i); };
+  HostPool::instance().run(n, grain, fn);
 }
 
 }  // namespace emat

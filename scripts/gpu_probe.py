@@ -156,21 +156,19 @@ def cycle_probe(nparts=8192, moves=1000, max_part_nodes=0):
     run.set_hky(sc.mu, sc.kappa, sc.pi)
     run.set_pop_model(sc.pop)
     for cyc in range(4):
-        t0 = time.perf_counter(); run.repartition(); n, _ = run.num_parts(); run.push_params(); t1 = time.perf_counter()
+        t0 = time.perf_counter(); run.repartition(); n, _ = run.num_parts(); t1 = time.perf_counter()   # repartition pushes the model and builds the coalescent parts
         run.run_moves(n * moves); b.synchronize(); t2 = time.perf_counter()
         ms = b.last_run_ms()
+        run.reassemble(); t3 = time.perf_counter()
         st = [b.part_stats(p) for p in range(n)]
-        ticks = np.array([x["device_ticks"] for x in st], dtype=np.float64)
-        if cyc == 0: prev = np.zeros(0)
-        d_t = ticks - (prev if len(prev) == n else 0) if False else ticks   # parts are re-uploaded every cycle: ticks restart
+        d_t = np.array([x["device_ticks"] for x in st], dtype=np.float64)   # parts are re-uploaded every cycle: ticks restart
         top = np.argsort(-d_t)[:4]
         _, rp = run.num_parts()
-        print("   slowest parts:", ", ".join("part %d nodes %d %.1f ms" % (i, st[i]["num_nodes"], d_t[i] / 1e5) for i in top),
-              "| root part %d: %.1f ms, %d cells" % (rp, d_t[rp] / 1e5, len(b.part_coalescent(rp)["k_bar_p"])))
-        run.reassemble(); t3 = time.perf_counter()
+        slowest = "   slowest parts: " + ", ".join("part %d nodes %d %.1f ms" % (i, st[i]["num_nodes"], d_t[i] / 1e5) for i in top) + " | root part %d: %.1f ms" % (rp, d_t[rp] / 1e5)
         print("cycle %d: %d parts | repartition+upload %.1f ms | moves %.1f ms (kernel %.1f ms; first call includes slab build + H2D + recalc) | reassemble (D2H + gather) %.1f ms | "
               "whole cycle %.1f ms => %.1f M moves/s inclusive vs %.1f M moves/s resident" % (cyc, n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, ms, (t3 - t2) * 1e3, (t3 - t0) * 1e3,
               n * moves / (t3 - t0) / 1e6, n * moves / (ms * 1e-3) / 1e6))
+        print(slowest)
     run.close(); b.close()
 
 
