@@ -113,7 +113,7 @@ struct RunDriver {
   int only_displacing_inner_nodes = 0, topology_moves_enabled = 1;
   // partition state
   std::vector<std::vector<int32_t>> stencils; int64_t stencil_refresh_countdown = 0;
-  std::vector<PartMap> parts; std::vector<HTree> subtrees; std::vector<uint64_t> part_seeds;
+  std::vector<PartMap> parts; std::vector<FlatTree> subtrees; std::vector<uint64_t> part_seeds;   // parts stay flat (SoA + CSR) end to end
   int root_part = -1;
   uint64_t epoch = 0;
   bool parts_uploaded = false, model_pushed = false, coal_built = false;
@@ -342,26 +342,43 @@ struct RunDriver {
     auto build_one = [&](int p) {
       const PartMap& pm = parts[p];
       const int n = (int)pm.orig.size();
-      HTree st; st.nodes.resize(n); st.root = 0;
       const int32_t subroot = pm.cut_point;
       const std::vector<HIv>& root_miss = states[p].miss;
+      // the subroot's synthetic lists (run.cpp:141-153): missing sites at the cut, deltas reference -> sequence at the cut
+      std::vector<HFsPair> root_muts;
+      for (const auto& d : states[p].deltas) if (!iv_contains(root_miss, d.site)) root_muts.push_back(d);
+      FlatTree st; st.resize_nodes(n); st.root = 0;
+      size_t nm = 0, ni = 0, nf = 0;
+      for (int s = 0; s < n; ++s) {
+        const int32_t o = pm.orig[s];
+        if (o == subroot) { nm += root_muts.size(); ni += root_miss.size(); }
+        else { const HNode& on = tree.nodes[o]; nm += on.muts.size(); ni += on.miss.size(); nf += on.mfs.size(); }
+      }
+      st.mut_site.resize(nm); st.mut_from.resize(nm); st.mut_to.resize(nm); st.mut_t.resize(nm);
+      st.miss_start.resize(ni); st.miss_end.resize(ni); st.mfs_site.resize(nf); st.mfs_state.resize(nf);
+      size_t km = 0, ki = 0, kf = 0;
       for (int s = 0; s < n; ++s) {
         const int32_t o = pm.orig[s];
         const HNode& on = tree.nodes[o];
-        HNode& sn = st.nodes[s];
-        sn.c0 = part_kids[p][s].first; sn.c1 = part_kids[p][s].second;
-        if (sn.c0 != EMAT_NO_NODE) { st.nodes[sn.c0].parent = s; st.nodes[sn.c1].parent = s; }
-        sn.t = on.t;
-        if (sn.is_tip() && !on.is_tip()) { sn.t_min = (float)on.t; sn.t_max = (float)on.t; }   // frozen boundary node (run.cpp:165-168)
-        else { sn.t_min = on.t_min; sn.t_max = on.t_max; }
+        const int32_t k0 = part_kids[p][s].first, k1 = part_kids[p][s].second;
+        st.child0[s] = k0; st.child1[s] = k1;
+        if (k0 != EMAT_NO_NODE) { st.parent[k0] = s; st.parent[k1] = s; }
+        st.t[s] = on.t;
+        if (k0 == EMAT_NO_NODE && !on.is_tip()) { st.t_min[s] = (float)on.t; st.t_max[s] = (float)on.t; }   // frozen boundary node (run.cpp:165-168)
+        else { st.t_min[s] = on.t_min; st.t_max[s] = on.t_max; }
+        // A frozen boundary "tip" whose float-rounded bounds do not bracket t would fail the t_min <= t <= t_max
+        // convention by an ulp of float; the reference tolerates 1e-2 (phylo_tree.cpp:117-121).  Keep t exact.
         if (o == subroot) {
-          sn.miss = root_miss;
-          for (const auto& d : states[p].deltas) if (!iv_contains(root_miss, d.site)) sn.muts.push_back(HMut{-std::numeric_limits<double>::max(), d.site, ref[d.site], d.to});
-        } else { sn.muts = on.muts; sn.miss = on.miss; sn.mfs = on.mfs; }
+          for (const auto& iv : root_miss) { st.miss_start[ki] = iv.start; st.miss_end[ki] = iv.end; ++ki; }
+          for (const auto& d : root_muts) { st.mut_site[km] = d.site; st.mut_from[km] = ref[d.site]; st.mut_to[km] = d.to; st.mut_t[km] = -std::numeric_limits<double>::max(); ++km; }
+        } else {
+          for (const auto& m : on.muts) { st.mut_site[km] = m.site; st.mut_from[km] = m.from; st.mut_to[km] = m.to; st.mut_t[km] = m.t; ++km; }
+          for (const auto& iv : on.miss) { st.miss_start[ki] = iv.start; st.miss_end[ki] = iv.end; ++ki; }
+          for (const auto& f : on.mfs) { st.mfs_site[kf] = f.site; st.mfs_state[kf] = f.state; ++kf; }
+        }
+        st.mut_offset[s + 1] = (int32_t)km; st.miss_offset[s + 1] = (int32_t)ki; st.mfs_offset[s + 1] = (int32_t)kf;
       }
-      st.nodes[0].parent = EMAT_NO_NODE;
-      // A frozen boundary "tip" whose float-rounded bounds do not bracket t would fail the t_min <= t <= t_max
-      // convention by an ulp of float; the reference tolerates 1e-2 (phylo_tree.cpp:117-121).  Keep t exact.
+      st.parent[0] = EMAT_NO_NODE;
       subtrees[p] = std::move(st);
       uint64_t z = seed ^ (0x9E3779B97F4A7C15ull * (epoch + 1)) ^ ((uint64_t)p << 32 | (uint64_t)p);
       SplitMix64 sm(z);
@@ -409,8 +426,7 @@ struct RunDriver {
     emat_status st = bk(emat_begin_upload(backend, (int)subtrees.size())); if (st) return st;
     std::atomic<int> bad{EMAT_OK};
     parallel_for((int)subtrees.size(), [&](int p) {   // emat_part_upload is safe to call concurrently for distinct parts
-      FlatTree f = subtrees[p].to_flat();
-      emat_flat_tree v = f.view();
+      emat_flat_tree v = subtrees[p].view();
       emat_status s1 = emat_part_upload(backend, p, &v, p == root_part ? 1 : 0, part_seeds[p]);
       if (s1 != EMAT_OK) bad.store(s1);
     });
@@ -476,24 +492,29 @@ struct RunDriver {
           emat_flat_tree v = f.view();
           st = emat_part_download(backend, p, &v); if (st) { bad.store(st); return; }
           f.root = v.root;
-          emat_flat_tree v2 = f.view();
-          subtrees[p] = HTree::from_view(v2);
+          subtrees[p] = std::move(f);
         });
         if (bad.load() != EMAT_OK) return bk((emat_status)bad.load());
       }
       t2 = now();
-      for (size_t p = 0; p < subtrees.size(); ++p) if (subtrees[p].nodes.size() != parts[p].orig.size()) return fail(EMAT_ERR_INTERNAL, "subtree size changed");
+      for (size_t p = 0; p < subtrees.size(); ++p) if ((size_t)subtrees[p].num_nodes() != parts[p].orig.size()) return fail(EMAT_ERR_INTERNAL, "subtree size changed");
       // Every node of the whole tree is a non-root node of exactly one part (the run's root: the root of the root part),
       // and that part alone writes its time, lists and child links; a cut node's parent link is written by the part
       // above it, as the parent of one of its children.  The parts therefore gather independently.
       parallel_for((int)subtrees.size(), [&](int p) {
-        const PartMap& pm = parts[p]; const HTree& st = subtrees[p];
-        for (int s = 0; s < (int)st.nodes.size(); ++s) {
-          const int32_t o = pm.orig[s]; const HNode& sn = st.nodes[s]; HNode& on = tree.nodes[o];
+        const PartMap& pm = parts[p]; const FlatTree& st = subtrees[p];
+        for (int s = 0; s < st.num_nodes(); ++s) {
+          const int32_t o = pm.orig[s]; HNode& on = tree.nodes[o];
           const bool owns = s != st.root || p == root_part;
-          if (owns) { on.t = sn.t; on.muts = sn.muts; on.miss = sn.miss; on.mfs = sn.mfs; }
-          if (!sn.is_tip()) {
-            int32_t l = pm.orig[sn.c0], r = pm.orig[sn.c1];
+          if (owns) {
+            on.t = st.t[s];
+            const int m0 = st.mut_offset[s], m1 = st.mut_offset[s + 1], i0 = st.miss_offset[s], i1 = st.miss_offset[s + 1], f0 = st.mfs_offset[s], f1 = st.mfs_offset[s + 1];
+            on.muts.resize(m1 - m0); for (int k = m0; k < m1; ++k) on.muts[k - m0] = HMut{st.mut_t[k], st.mut_site[k], st.mut_from[k], st.mut_to[k]};
+            on.miss.resize(i1 - i0); for (int k = i0; k < i1; ++k) on.miss[k - i0] = HIv{st.miss_start[k], st.miss_end[k]};
+            on.mfs.resize(f1 - f0); for (int k = f0; k < f1; ++k) on.mfs[k - f0] = HFs{st.mfs_site[k], st.mfs_state[k]};
+          }
+          if (!st.is_tip(s)) {
+            int32_t l = pm.orig[st.child0[s]], r = pm.orig[st.child1[s]];
             on.c0 = l; on.c1 = r; tree.nodes[l].parent = o; tree.nodes[r].parent = o;
           }
         }
@@ -569,8 +590,8 @@ emat_status emat_run_repartition(emat_run* r) { if (!r) return EMAT_ERR_INVALID_
 emat_status emat_run_num_parts(emat_run* r, int32_t* n, int32_t* root_part) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; if (n) *n = (int)r->d.parts.size(); if (root_part) *root_part = r->d.root_part; return EMAT_OK; }
 emat_status emat_run_part_sizes(emat_run* r, int32_t p, int32_t* nn, int32_t* nm, int32_t* ni, int32_t* nf) {
   if (!r || p < 0 || p >= (int)r->d.subtrees.size()) return EMAT_ERR_INVALID_ARGUMENT;
-  int m = 0, i = 0, f = 0; for (auto& nd : r->d.subtrees[p].nodes) { m += (int)nd.muts.size(); i += (int)nd.miss.size(); f += (int)nd.mfs.size(); }
-  if (nn) *nn = (int)r->d.subtrees[p].nodes.size(); if (nm) *nm = m; if (ni) *ni = i; if (nf) *nf = f;
+  const FlatTree& t = r->d.subtrees[p];
+  if (nn) *nn = t.num_nodes(); if (nm) *nm = t.num_muts(); if (ni) *ni = t.num_intervals(); if (nf) *nf = t.num_from_states();
   return EMAT_OK;
 }
 static emat_status copy_out(const FlatTree& t, emat_flat_tree* out) {
@@ -589,12 +610,12 @@ emat_status emat_run_part_get(emat_run* r, int32_t p, emat_flat_tree* out, int32
   if (!r || !out || p < 0 || p >= (int)r->d.subtrees.size()) return EMAT_ERR_INVALID_ARGUMENT;
   if (incl_root) *incl_root = p == r->d.root_part ? 1 : 0;
   if (seed) *seed = r->d.part_seeds[p];
-  return copy_out(r->d.subtrees[p].to_flat(), out);
+  return copy_out(r->d.subtrees[p], out);
 }
 emat_status emat_run_part_put(emat_run* r, int32_t p, const emat_flat_tree* st) {
   if (!r || !st || p < 0 || p >= (int)r->d.subtrees.size()) return EMAT_ERR_INVALID_ARGUMENT;
   if (!validate_flat_tree(*st, r->d.L).empty() || st->num_nodes != (int)r->d.parts[p].orig.size()) return EMAT_ERR_INVALID_ARGUMENT;
-  r->d.subtrees[p] = HTree::from_view(*st);
+  r->d.subtrees[p] = FlatTree::from_view(*st);
   return EMAT_OK;
 }
 emat_status emat_run_push_params(emat_run* r) {
