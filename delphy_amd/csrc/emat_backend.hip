@@ -742,7 +742,7 @@ emat_status materialize(emat_backend* h) {
       // whole at no cost in occupancy, the rest stage their prefix.
       const uint32_t lds_cu = 160u * 1024u, prefix = k_lds_slab_off + (h->cfg.use_lds ? h->cfg_lds_scratch : 0u);
       const uint32_t need = asc[0].second;
-      for (uint32_t k = 16; k >= 1; --k) {
+      for (uint32_t k = 4u * EMAT_WAVES_PER_EU; k >= 1; --k) {   // 4 SIMDs x waves per SIMD allowed by the VGPR budget (one wave per workgroup)
         const uint32_t share = (lds_cu / k) & ~511u;   // LDS is allocated in 512-byte granules
         if (share <= prefix) continue;
         const uint32_t area = std::min<uint32_t>((share - prefix) & ~15u, h->cfg_lds_max & ~15u);
