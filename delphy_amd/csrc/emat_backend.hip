@@ -543,7 +543,11 @@ void decode_slab(PartHost& ph, const uint8_t* slab) {
 
 emat_status fail(emat_backend* h, emat_status st, const std::string& msg) { h->set_error(msg); return st; }
 
+// Several handles may live in one process, one per GPU: every entry point that talks to the device selects its own first.
+inline bool bind_device(emat_backend* h) { return h->host_only || hipSetDevice(h->cfg.device) == hipSuccess; }
+
 emat_status sync_model_to_device(emat_backend* h) {
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
   if (!h->model_dirty) return EMAT_OK;
   auto& B = *h;
@@ -614,6 +618,7 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
 // to four times.  Any other status means an invariant broke inside a move; that is reported, loudly, and the caller
 // must not use the part's tree.
 emat_status finish_pass(emat_backend* h) {
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   if (h->host_only || !h->pass_pending || !h->slabs_on_device) return EMAT_OK;
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   const size_t n = h->parts.size();
@@ -650,6 +655,7 @@ emat_status finish_pass(emat_backend* h) {
 
 emat_status pull_from_device_impl(emat_backend* h);
 emat_status pull_from_device(emat_backend* h) {
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   if (h->host_only || !h->slabs_on_device) return EMAT_OK;
   if (h->pass_pending) { emat_status st = finish_pass(h); if (st) return st; }
   return pull_from_device_impl(h);
@@ -674,6 +680,7 @@ emat_status pull_from_device_impl(emat_backend* h) {
 
 // Encode all parts and push them to the device.
 emat_status materialize(emat_backend* h) {
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
   if (h->slabs_on_device) return EMAT_OK;
   auto set_error = [&](const std::string& s) { h->set_error(s); };
@@ -792,6 +799,7 @@ emat_status materialize(emat_backend* h) {
 }
 
 emat_status launch_recalc(emat_backend* h) {
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   emat_status st = sync_model_to_device(h); if (st) return st;
   st = materialize(h); if (st) return st;
@@ -1081,6 +1089,7 @@ emat_status emat_run_moves_per_part(emat_backend* h, int64_t moves_per_part) {
 }
 emat_status emat_synchronize(emat_backend* h) {
   if (!h) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   if (h->host_only) return EMAT_OK;
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1238,6 +1247,7 @@ emat_status emat_debug_variant_counts(emat_backend* h, int32_t* out3) {
 /* debugging aid (not part of the boundary): duration and start tick (100 MHz wall clock) of every part in the last pass */
 emat_status emat_debug_part_ticks(emat_backend* h, int64_t* out_2n) {
   if (!h || !out_2n || h->host_only || !h->slabs_on_device) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out_2n, h->d_part_ticks.p, sizeof(int64_t) * 2 * h->parts.size(), hipMemcpyDeviceToHost));
@@ -1254,6 +1264,7 @@ emat_status emat_debug_phase_ticks(emat_backend* h, int32_t part_id, int64_t* ou
 /* Duration of the k_run_moves launch of the last pass, from HIP events around that launch on its stream. */
 emat_status emat_last_kernel_ms(emat_backend* h, double* ms, int32_t* num_parts_in_kernel) {
   if (!h || !ms) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle");
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipEventSynchronize(h->ev_stop));
@@ -1265,6 +1276,7 @@ emat_status emat_last_kernel_ms(emat_backend* h, double* ms, int32_t* num_parts_
 }
 emat_status emat_last_run_ms(emat_backend* h, double* ms) {
   if (!h || !ms) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle");
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipEventSynchronize(h->ev_stop));
