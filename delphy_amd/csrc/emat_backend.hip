@@ -393,6 +393,7 @@ struct PartHost {
   uint64_t slab_off = 0;
   uint32_t slab_bytes = 0;
   emat_part_stats stats{};
+  std::vector<double> trace;       // the part's move trace so far (4 doubles per move), carried over re-materialisations
   int64_t expected_moves = 0;      // moves requested of this part since its upload
   double space_boost = 1.0;        // multiplier of the heap and scratch capacities; doubled when the part ran out of space
 };
@@ -471,7 +472,8 @@ void encode_slab(const emat_backend& B, const PartHost& ph, uint8_t* slab, uint3
   H->scratch_begin = H->heap_end; H->scratch_end = H->scratch_begin + scratch_bytes;
   H->cell_first = ph.coal.cell_first; H->n_cells = (int)ph.coal.k_bar_p.size(); H->cell_cap = cell_cap; H->n_cells_total = ph.coal.n_cells_total;
   H->t_ref = ph.coal.t_ref; H->t_step = ph.coal.t_step;
-  H->trace_cap = trace_cap; H->trace_len = 0;
+  H->trace_cap = trace_cap; H->trace_len = std::min<int>(trace_cap, (int)(ph.trace.size() / 4));
+  if (H->trace_len > 0) std::memcpy(slab + H->off_trace, ph.trace.data(), (size_t)H->trace_len * 32);
   NodeRec* N = (NodeRec*)(slab + H->off_nodes);
   uint32_t top = H->heap_begin;
   for (int i = 0; i < n; ++i) {
@@ -533,6 +535,7 @@ void decode_slab(PartHost& ph, const uint8_t* slab) {
     t.mut_offset[i + 1] = km; t.miss_offset[i + 1] = ki; t.mfs_offset[i + 1] = kf;
   }
   ph.rng.counter = H->rng_counter; ph.rng.spare = H->rng_spare; ph.rng.has_spare = H->rng_has_spare != 0;
+  { const double* tr = (const double*)(slab + H->off_trace); ph.trace.assign(tr, tr + (size_t)4 * H->trace_len); }
   const int nc = H->n_cells, cap = H->cell_cap;
   const double* cb = (const double*)(slab + H->off_cells);
   ph.coal.n_cells_total = H->n_cells_total;
@@ -992,7 +995,7 @@ emat_status emat_part_upload(emat_backend* h, int32_t part_id, const emat_flat_t
   ph.tree = FlatTree::from_view(*subtree);
   ph.includes_run_root = includes_run_root != 0;
   ph.rng.key = seed; ph.rng.counter = 0; ph.rng.spare = 0; ph.rng.has_spare = false;
-  ph.uploaded = true; ph.stats = emat_part_stats{}; ph.expected_moves = 0; ph.space_boost = 1.0;
+  ph.uploaded = true; ph.stats = emat_part_stats{}; ph.expected_moves = 0; ph.space_boost = 1.0; ph.trace.clear();
   if (ph.includes_run_root) h->root_part = part_id;
   return EMAT_OK;
 }

@@ -167,4 +167,4 @@ def test_parts_that_run_out_of_slab_space_are_regrown_and_finish(monkeypatch):
     tree, ref, tmax = e.make_synthetic_emat(e.SynthParams(num_tips=80, num_sites=400, mu=3e-4, gaps_per_tip=3, mean_gap_len=25, seed=77))
     sc.tree, sc.ref, sc.t_max_tip = tree, ref, tmax
     sc.pop = d.PopModel.exp(tmax, 365.0, 0.0, 0.0)
-    run_parity(sc, 2, 4000, trace=0)   # the trace ring restarts when a part is re-materialised, so traces are not compared
+    run_parity(sc, 2, 4000, trace=4000)   # the trace survives the re-materialisation too
