@@ -46,7 +46,7 @@ struct SynthParams {
   double pop_growth = 0.0;          // per day
   double mu = 1e-3 / 365.0;         // substitutions / site / day
   double kappa = 5.0;
-  double pi[4] = {0.3, 0.2, 0.2, 0.3};
+  double pi[4] = {0.31, 0.19, 0.21, 0.29};
   int32_t gaps_per_tip = 2;
   double mean_gap_len = 150.0;
   uint64_t seed = 20261001;

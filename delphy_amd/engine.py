@@ -203,7 +203,7 @@ class SynthParams:
     pop_growth: float = 0.0
     mu: float = 1e-3 / 365.0
     kappa: float = 5.0
-    pi: Sequence[float] = (0.3, 0.2, 0.2, 0.3)
+    pi: Sequence[float] = (0.31, 0.19, 0.21, 0.29)
     gaps_per_tip: int = 2
     mean_gap_len: float = 150.0
     seed: int = 20261001

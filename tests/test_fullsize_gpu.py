@@ -99,3 +99,11 @@ def test_run_driver_cycles_on_device():
     tips = tree.child0 == -1
     assert np.all(tree.t[tips] >= tree.t_min[tips] - 1e-2) and np.all(tree.t[tips] <= tree.t_max[tips] + 1e-2)
     chk.close(); run.close(); b.close()
+
+
+def test_trajectory_parity_at_c3_full_size():
+    """Config C3 as a whole (10 000 tips, 29 903 sites, skygrid): 400 parts x 3000 moves, every move of every part compared
+    with the oracle (kind, node, accept flag exact; log-MH within 1e-9), then trees, counters and RNG consumption."""
+    from helpers import run_parity
+    sc = make_scenario("C3")
+    run_parity(sc, 400, 3000, seed=101, trace=3000)
