@@ -107,3 +107,11 @@ def test_trajectory_parity_at_c3_full_size():
     from helpers import run_parity
     sc = make_scenario("C3")
     run_parity(sc, 400, 3000, seed=101, trace=3000)
+
+
+def test_trajectory_parity_on_the_benchmark_workload():
+    """The benchmark itself, checked move for move: config C4 (100 000 tips) cut exactly as bench.py cuts it, one pass of
+    1 000 moves on every one of the ~7 955 parts, each part's trace, tree, counters and RNG consumption against the oracle."""
+    from helpers import run_parity
+    sc = make_scenario("C4")
+    run_parity(sc, 8192, 1000, seed=20261001, trace=1000)
