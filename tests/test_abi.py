@@ -36,6 +36,10 @@ def test_no_cpu_fallback():
     b = d.EmatBackend(1000, device=-1)           # host-only handle: staging works, launches do not
     with pytest.raises(d.EmatError):
         b.run_moves_per_part(1)
+    with pytest.raises(d.EmatError, match="NO_DEVICE"):
+        b.global_stats(1)                        # device-side reductions have no host stand-in either
+    with pytest.raises(d.EmatError):
+        b.recalc_derived()
     b.close()
 
 
