@@ -108,11 +108,9 @@ __device__ inline const double* stage_tables(const KernelArgs& a, double* lds_ta
 #ifndef EMAT_WAVES_PER_EU
 #define EMAT_WAVES_PER_EU 4
 #endif
-template <class CtxT, class Step> __device__ __forceinline__ void run_chain(CtxT& c, const KernelArgs& a, int part, SlabHeader* H, int64_t moves, Step step) {
+template <class CtxT, class Loop> __device__ __forceinline__ void run_chain(CtxT& c, const KernelArgs& a, int part, SlabHeader* H, int64_t moves, Loop loop) {
   const uint64_t tick0 = wall_clock64();
-  if (H->status == 0) {
-    for (int64_t i = 0; i < moves; ++i) if (!step(c)) break;
-  }
+  if (H->status == 0) { c.moves_left = moves; loop(c); }
   H->rng_counter = c.rng_ctr; H->rng_spare = c.rng_spare; H->rng_has_spare = c.rng_has_spare ? 1u : 0u;
   H->alg_bytes += c.bytes;
   const int64_t dt = (int64_t)(wall_clock64() - tick0);
@@ -174,18 +172,18 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
         // instruction-issue arbitration on its SIMD.
         const bool is_root_part = (gh->flags & k_flag_includes_run_root) != 0;
         if (is_root_part) __builtin_amdgcn_s_setprio(3);
-        run_chain(c, a, part, H, moves, [](dev_lds::Ctx& cc) { return dev_lds::mcmc_sub_iteration(cc); });
+        run_chain(c, a, part, H, moves, [](dev_lds::Ctx& cc) { dev_lds::run_chain_loop(cc); });
         if (is_root_part) __builtin_amdgcn_s_setprio(0);
         H->heap_end = hbm_heap_end;
         if (H->status == k_part_need_space && lds_heap_end < hbm_heap_end && H->heap_top <= hbm_heap_end) { H->status = 0; a.part_status[part] = 0; again = 1; }
       } else if (prefix) {
         dev_mix::Ctx& c = *(dev_mix::Ctx*)(emat_lds + k_lds_ctx_off);
         init_ctx(c, lds_slab, gslab, a, lds_tables);
-        run_chain(c, a, part, H, moves, [](dev_mix::Ctx& cc) { return dev_mix::mcmc_sub_iteration(cc); });
+        run_chain(c, a, part, H, moves, [](dev_mix::Ctx& cc) { dev_mix::run_chain_loop(cc); });
       } else {
         dev::Ctx& c = *(dev::Ctx*)(emat_lds + k_lds_ctx_off);
         init_ctx(c, gslab, gslab, a, tables_staged ? lds_tables : nullptr);
-        run_chain(c, a, part, H, moves, [](dev::Ctx& cc) { return dev::mcmc_sub_iteration(cc); });
+        run_chain(c, a, part, H, moves, [](dev::Ctx& cc) { dev::run_chain_loop(cc); });
       }
       *lds_flag = again;
     }
@@ -344,6 +342,12 @@ __global__ void __launch_bounds__(k_wave) k_recalc_derived(KernelArgs a) {
     c.H->log_G = lg;
     c.H->log_aug_prior = acc_prior;
   }
+}
+
+// ---- test hook: the device's incomplete-gamma routines evaluated point by point (emat_debug_gamma) ----------------------
+__global__ void k_debug_gamma(const double* a, const double* x, double* out, int n, int mode) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = mode == 0 ? dev::gamma_q(a[i], x[i]) : dev::gamma_q_inv(a[i], x[i]);
 }
 
 // =================================================================================================
@@ -1228,6 +1232,21 @@ emat_status emat_get_global_stats(emat_backend* h, int32_t num_partitions, doubl
     nm += (int64_t)r[k_stats_row - 1];
   }
   if (num_muts) *num_muts = nm;
+  return EMAT_OK;
+}
+/* test hook (header: emat_debug_gamma) */
+emat_status emat_debug_gamma(emat_backend* h, int32_t mode, int32_t n, const double* a, const double* x_or_q, double* out) {
+  if (!h || n < 0 || (mode != 0 && mode != 1) || (n > 0 && (!a || !x_or_q || !out))) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
+  if (n == 0) return EMAT_OK;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  DevBuf<double> da, dx, dout;
+  HIP_TRY(da.upload(a, (size_t)n)); HIP_TRY(dx.upload(x_or_q, (size_t)n)); HIP_TRY(dout.upload(x_or_q, (size_t)n));
+  hipLaunchKernelGGL(k_debug_gamma, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, da.p, dx.p, dout.p, n, mode);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   return EMAT_OK;
 }
 /* debugging aid (not part of the boundary): how many parts the next launch runs with each code variant

@@ -83,6 +83,7 @@ struct Ctx {
   int64_t bytes;
   // trace of the current move
   double tr_kind, tr_node, tr_acc, tr_log_mh;
+  int64_t moves_left;         // moves of the current launch still to do (run_chain_loop keeps nothing in registers across a move)
 };
 
 static_assert(sizeof(Ctx) + 16 <= k_lds_ctx_bytes, "context outgrew its LDS slot (the last 16 bytes are the kernel's flag word)");
@@ -618,7 +619,9 @@ EMAT_DN double pop_integral(const PopTable& p, double a, double b) {
 
 // ---- per-part coalescent prior (very_scalable_coalescent.cpp:14-79, 259-459) ----------------------------------------
 // The part stores only its window of cells [cell_first, cell_first + n_cells): outside it k_bar_p is
-// identically zero for the whole residency, so those cells contribute nothing (cpp:355-386).
+// identically zero for the whole residency, so those cells contribute nothing (cpp:355-386).  The window starts at the
+// cell of the part's latest node time in full precision or at the reference's first_cell, whichever comes first
+// (emat_host_model.hpp, CoalBuilder::local_grid).
 struct Cells { double* kbar_p; double* ktw_p; double* ktw; double* popsize; double* ts_over_pop; int32_t* nactive; };
 EMAT_D Cells cells_of(Ctx& c) {
   Cells k; int cap = hdr_of(c)->cell_cap;
@@ -630,10 +633,13 @@ EMAT_D int cell_for(const Ctx& c, double t) { return (int)floor((hdr_of(c)->t_re
 EMAT_D double cell_ubound(const Ctx& c, int cell) { return hdr_of(c)->t_ref - hdr_of(c)->t_step * cell; }
 EMAT_D double cell_lbound(const Ctx& c, int cell) { return cell_ubound(c, cell) - hdr_of(c)->t_step; }
 // cpp:259-299 (only the root part may grow, towards the past)
+// `kGrow` = the caller may be running the part that holds the run's root.  Parts that do not can never append cells, and
+// their simple moves are compiled with kGrow = false so that they contain no call at all (leaf functions: no return
+// address or frame pointer to save).
 EMAT_DN void coal_grow(Ctx& c, int cell);
-EMAT_DF void coal_ensure_space(Ctx& c, double t) {
+template <bool kGrow = true> EMAT_DF void coal_ensure_space(Ctx& c, double t) {
   int cell = cell_for(c, t);
-  if (cell >= hdr_of(c)->n_cells_total && c.includes_run_root) coal_grow(c, cell);   // rare: the root moved past the grid
+  if (kGrow) { if (cell >= hdr_of(c)->n_cells_total && c.includes_run_root) coal_grow(c, cell); }   // rare: the root moved past the grid
   if (cell < hdr_of(c)->cell_first || cell >= hdr_of(c)->n_cells_total) EMAT_FAIL(c, k_part_internal);
 }
 EMAT_DN void coal_grow(Ctx& c, int cell) {
@@ -676,9 +682,9 @@ EMAT_DF double coal_cell_term(const Ctx& c, const Cells& k, int w, double new_k,
       - (k.ktw_p[w] * na - k.ktw[w] + 0.5) * (new_k - old_k));
 }
 // cpp:388-459
-EMAT_DF double coal_delta_on_add_interval(Ctx& c, double min_t, double max_t, double delta_k) {
+template <bool kGrow = true> EMAT_DF double coal_delta_on_add_interval(Ctx& c, double min_t, double max_t, double delta_k) {
   { int cm = cell_for(c, max_t); if (cm < hdr_of(c)->cell_first || cm >= hdr_of(c)->n_cells_total) { EMAT_FAIL(c, k_part_internal); return 0.0; } }
-  coal_ensure_space(c, min_t);
+  coal_ensure_space<kGrow>(c, min_t);
   if (c.failed) return 0.0;
   if (min_t == max_t) return 0.0;
   Cells k = cells_of(c);
@@ -702,20 +708,20 @@ EMAT_DF double coal_delta_on_add_interval(Ctx& c, double min_t, double max_t, do
   c.bytes += 36 * (int64_t)(cell_end - cell_start + 1);
   return d;
 }
-EMAT_DF double coal_delta_displace_coalescence(Ctx& c, double old_t, double new_t) {   // cpp:310-326
-  double d = (old_t <= new_t) ? coal_delta_on_add_interval(c, old_t, new_t, -1.0) : coal_delta_on_add_interval(c, new_t, old_t, +1.0);
+template <bool kGrow = true> EMAT_DF double coal_delta_displace_coalescence(Ctx& c, double old_t, double new_t) {   // cpp:310-326
+  double d = (old_t <= new_t) ? coal_delta_on_add_interval<kGrow>(c, old_t, new_t, -1.0) : coal_delta_on_add_interval<kGrow>(c, new_t, old_t, +1.0);
   d -= log_pop_ratio(*c.pop, new_t, old_t);
   return d;
 }
-EMAT_DF double coal_delta_displace_tip(Ctx& c, double old_t, double new_t) {           // cpp:337-353
-  return (old_t <= new_t) ? coal_delta_on_add_interval(c, old_t, new_t, +1.0) : coal_delta_on_add_interval(c, new_t, old_t, -1.0);
+template <bool kGrow = true> EMAT_DF double coal_delta_displace_tip(Ctx& c, double old_t, double new_t) {           // cpp:337-353
+  return (old_t <= new_t) ? coal_delta_on_add_interval<kGrow>(c, old_t, new_t, +1.0) : coal_delta_on_add_interval<kGrow>(c, new_t, old_t, -1.0);
 }
-EMAT_DF void coal_coalescence_displaced(Ctx& c, double old_t, double new_t) {           // cpp:301-308
-  coal_ensure_space(c, new_t);
+template <bool kGrow = true> EMAT_DF void coal_coalescence_displaced(Ctx& c, double old_t, double new_t) {           // cpp:301-308
+  coal_ensure_space<kGrow>(c, new_t);
   coal_add_interval(c, old_t, new_t, old_t <= new_t ? -1.0 : +1.0);
 }
-EMAT_DF void coal_tip_displaced(Ctx& c, double old_t, double new_t) {                   // cpp:328-335
-  coal_ensure_space(c, new_t);
+template <bool kGrow = true> EMAT_DF void coal_tip_displaced(Ctx& c, double old_t, double new_t) {                   // cpp:328-335
+  coal_ensure_space<kGrow>(c, new_t);
   coal_add_interval(c, old_t, new_t, old_t <= new_t ? +1.0 : -1.0);
 }
 

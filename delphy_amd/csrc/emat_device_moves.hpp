@@ -62,16 +62,20 @@ EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new_t, double a
   EMAT_PHASE(c, 4);
 }
 
-EMAT_DN void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
+// The three simple moves are compiled twice: kRoot = true for the part that holds the run's root (its root node may be
+// displaced, its coalescent grid may grow, branch reforms next to the root go through spr_move_core) and kRoot = false for
+// every other part, where none of that can happen: those versions contain no call and no root-only code, so they are
+// leaf functions without a stack frame.
+template <bool kRoot> EMAT_DN void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
   begin_move(c, k_inner_node_displace);
   int node;
   { int guard = 0; do { node = pick_random_node(c); } while (is_tip(c, node) && guard++ < (1 << 26)); }
   c.tr_node = (double)node;
   const int root = hdr_of(c)->root;
-  if (node == root && !c.includes_run_root) return;
+  if (!kRoot && node == root) return;   // node == root && !includes_run_root
   const NodeRec nd = nodes_of(c)[node];
   double t_min = -k_inf;
-  if (node != root) {
+  if (!kRoot || node != root) {
     t_min = nodes_of(c)[nd.parent].t;
     const MutRec* m = muts_of(c, node);
     for (int i = 0; i < (int)nd.muts.cnt; ++i) t_min = t_min > m[i].t ? t_min : m[i].t;
@@ -80,7 +84,7 @@ EMAT_DN void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
   const int ch[2] = {nd.child0, nd.child1};
   const double lambda_at_node = nd.lambda;
   double d_logG_dt = 0.0;
-  if (node != root) d_logG_dt += -lambda_at_node;
+  if (!kRoot || node != root) d_logG_dt += -lambda_at_node;
   for (int k = 0; k < 2; ++k) {
     const int cc = ch[k];
     t_max = t_max < nodes_of(c)[cc].t ? t_max : nodes_of(c)[cc].t;
@@ -96,11 +100,11 @@ EMAT_DN void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
   c.bytes += 2 * 64 + 16 * (int)nd.muts.cnt;
   const double old_t = nd.t;
   double log_alpha_ratio = 0.0, new_t = old_t;
-  if (node == root) {
+  if (kRoot && node == root) {
     double tree_span = c.t_max_tip - t_max;
     EMAT_CHECK(c, tree_span >= 0.0);
     double ds = (1 / nd.lambda) / 2;
-    double delta_scale = ds < tree_span ? ds : tree_span;   // std::min(ds, tree_span)
+    double delta_scale;   // std::min(ds, tree_span)
     if (tree_span < ds) delta_scale = tree_span; else delta_scale = ds;
     new_t = old_t + gaussian(c, 0.0, delta_scale);
     if (new_t < t_min || new_t > t_max) return;
@@ -111,27 +115,27 @@ EMAT_DN void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
   }
   if (new_t == t_min || new_t == t_max) return;
   double delta_log_G = d_logG_dt * (new_t - old_t);
-  double delta_log_prior = coal_delta_displace_coalescence(c, old_t, new_t);
+  double delta_log_prior = coal_delta_displace_coalescence<kRoot>(c, old_t, new_t);
   if (c.failed) return;
   double log_mh = delta_log_G + delta_log_prior - log_alpha_ratio;
   bool acc = mh_accept(c, log_mh);
   note_move(c, node, log_mh, acc, k_inner_node_displace);
   if (acc) {
-    coal_coalescence_displaced(c, old_t, new_t);
+    coal_coalescence_displaced<kRoot>(c, old_t, new_t);
     nodes_of(c)[node].t = new_t;
     hdr_of(c)->log_G += d_logG_dt * (new_t - old_t);
     hdr_of(c)->log_aug_prior += delta_log_prior;
   }
 }
 
-EMAT_DN void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
+template <bool kRoot> EMAT_DN void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
   begin_move(c, k_tip_displace);
   int node;
   { int guard = 0; do { node = pick_random_node(c); } while (!is_tip(c, node) && guard++ < (1 << 26)); }
   c.tr_node = (double)node;
   const NodeRec nd = nodes_of(c)[node];
   if (nd.t_min == nd.t_max) return;
-  double t_min = (double)nd.t_min > nodes_of(c)[nd.parent].t ? (double)nd.t_min : nodes_of(c)[nd.parent].t;   // std::max(a, b) = a < b ? b : a
+  double t_min;   // std::max(a, b) = a < b ? b : a
   if ((double)nd.t_min < nodes_of(c)[nd.parent].t) t_min = nodes_of(c)[nd.parent].t; else t_min = (double)nd.t_min;
   const MutRec* m = muts_of(c, node);
   for (int i = 0; i < (int)nd.muts.cnt; ++i) t_min = t_min > m[i].t ? t_min : m[i].t;
@@ -143,13 +147,13 @@ EMAT_DN void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
   double log_alpha_ratio = d_logG_dt * (new_t - old_t);
   if (new_t == t_min || new_t == t_max) return;
   double delta_log_G = d_logG_dt * (new_t - old_t);
-  double delta_log_prior = coal_delta_displace_tip(c, old_t, new_t);
+  double delta_log_prior = coal_delta_displace_tip<kRoot>(c, old_t, new_t);
   if (c.failed) return;
   double log_mh = delta_log_G + delta_log_prior - log_alpha_ratio;
   bool acc = mh_accept(c, log_mh);
   note_move(c, node, log_mh, acc, k_tip_displace);
   if (acc) {
-    coal_tip_displaced(c, old_t, new_t);
+    coal_tip_displaced<kRoot>(c, old_t, new_t);
     nodes_of(c)[node].t = new_t;
     hdr_of(c)->log_G += d_logG_dt * (new_t - old_t);
     hdr_of(c)->log_aug_prior += delta_log_prior;
@@ -186,7 +190,7 @@ EMAT_D SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) {
   return out;
 }
 
-EMAT_DN void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
+template <bool kRoot> EMAT_DN void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
   begin_move(c, k_branch_reform);
   if (hdr_of(c)->n_nodes < 3) return;
   const int X = pick_random_node(c);
@@ -195,7 +199,8 @@ EMAT_DN void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
   const int P = nodes_of(c)[X].parent;
   const int S = sibling_of(c, P, X);
   const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t;
-  if (P == hdr_of(c)->root) { spr_move_core(c, X, S, t_P, 1.0); if (c.failed) return; }
+  // in a part without the run's root, spr_move_core returns at once for a branch next to the subroot (subrun.cpp:689-697)
+  if (kRoot) { if (P == hdr_of(c)->root) { spr_move_core(c, X, S, t_P, 1.0); if (c.failed) return; } }
   SVec<MutRec> nm = randomize_branch_mutation_times(c, X);
   if (c.failed) return;
   const double lam = nodes_of(c)[X].lambda;
@@ -426,14 +431,14 @@ EMAT_D bool mcmc_sub_iteration(Ctx& c) {
 #ifdef EMAT_PROFILE_PHASES
   long long _mv0 = clock64();
 #endif
-  if (c.only_displacing_inner_nodes) inner_node_displace_move(c);
+  if (c.only_displacing_inner_nodes) { if (c.includes_run_root) inner_node_displace_move<true>(c); else inner_node_displace_move<false>(c); }
   else {
     double total_weight = 15.0 + 15.0;
     if (c.topology_moves_enabled) total_weight += 1.0 + 1.0;
     double r = uniform_co(c, 0.0, total_weight);
-    if (r < 7.5) inner_node_displace_move(c);
-    else if (r < 15.0) tip_displace_move(c);
-    else if (r < 30.0) branch_reform_move(c);
+    if (r < 7.5) { if (c.includes_run_root) inner_node_displace_move<true>(c); else inner_node_displace_move<false>(c); }
+    else if (r < 15.0) { if (c.includes_run_root) tip_displace_move<true>(c); else tip_displace_move<false>(c); }
+    else if (r < 30.0) { if (c.includes_run_root) branch_reform_move<true>(c); else branch_reform_move<false>(c); }
     else if (c.topology_moves_enabled) { if (r < 31.0) subtree_slide_move(c); else spr1_move(c); }
   }
 #ifdef EMAT_PROFILE_PHASES
@@ -446,6 +451,13 @@ EMAT_D bool mcmc_sub_iteration(Ctx& c) {
   }
   hdr_of(c)->moves_done++;
   return !c.failed;
+}
+
+// The chain itself: `c.moves_left` sub-iterations.  Its own function, and its counter in the context, so that nothing is
+// live in registers across a move: the moves clobber every register (no callee-saved saves, see the Makefile), and
+// whatever their caller kept in registers would be spilled and reloaded around each of them.
+EMAT_DN void run_chain_loop(Ctx& c) {
+  while (c.moves_left > 0) { c.moves_left -= 1; if (!mcmc_sub_iteration(c)) break; }
 }
 
 // ---- derived quantities of one part from scratch (Subrun::recalc_derived_quantities, subrun.cpp:17-26;

@@ -336,9 +336,12 @@ EMAT_D void sort_doubles(double* p, int n) { for (int i = 1; i < n; ++i) { doubl
 // Appends to `out` (open-ended scratch vector); returns false on overflow.  States of a trajectory are
 // drawn first (rejection on the end state), then its times, exactly as spr_move.cpp:1181-1227.
 EMAT_DN void sample_site_trajectory(Ctx& c, SVec<MutRec>& out, int l, int from, int to, const KTruncPoisson& dist, double T, bool accept_only_if_match, bool& accepted) {
-  // to_states and times are staged above `out`'s current end, inside its spare capacity
+  // to_states and times are staged at the far end of `out`'s spare capacity (576 bytes = 36 records), not on the stack
+  constexpr int k_stage_recs = (64 * 8 + 64) / (int)sizeof(MutRec);
+  if (out.cap - out.n < k_stage_recs + 1) { EMAT_FAIL(c, k_part_overflow); accepted = false; return; }
+  double* times = (double*)(out.p + (out.cap - k_stage_recs));
+  uint8_t* states = (uint8_t*)(times + 64);
   int n = 0; int s = from;
-  uint8_t states[64];
   int guard = 0;
   while (guard++ < (1 << 26)) {
     n = ktp_sample(c, dist);
@@ -347,8 +350,7 @@ EMAT_DN void sample_site_trajectory(Ctx& c, SVec<MutRec>& out, int l, int from, 
     if (s == to) { accepted = true; break; }
     if (!accept_only_if_match) { accepted = false; return; }   // caller restarts from scratch on its own terms
   }
-  if (n > 64) { EMAT_FAIL(c, k_part_overflow); return; }
-  double times[64];
+  if (n > 64 || out.cap - out.n < k_stage_recs + n) { EMAT_FAIL(c, k_part_overflow); return; }
   for (int i = 0; i < n; ++i) times[i] = uniform_co(c, -T, 0.0);
   sort_doubles(times, n);
   int prev = from;
@@ -356,7 +358,7 @@ EMAT_DN void sample_site_trajectory(Ctx& c, SVec<MutRec>& out, int l, int from, 
 }
 // spr_move.cpp:1164-1370; result appended into a fresh open-ended scratch vector (caller trims)
 EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double mu, const SVec<SdRec>& deltas) {
-  SVec<MutRec> out = sc_open<MutRec>(c, 4096, 4 * deltas.n + 48);
+  SVec<MutRec> out = sc_open<MutRec>(c, 4096, 4 * deltas.n + 48 + 36);   // + the staging area of sample_site_trajectory
   if (c.failed) return out;
   if (deltas.n != 0) {
     KTruncPoisson ge1 = ktp_make(mu * T, 1);

@@ -148,9 +148,11 @@ struct CoalBuilder {
   std::vector<HostRng*> rngs;
   int root_local = -1;               // index (in `trees`) of the part holding the run's root, or -1 if it lives on another rank
   std::vector<double> tmin, tmax;
+  std::vector<double> tmax_exact;    // latest node time of each part in full precision (tips' t_min / t_max are floats)
   double t_ref = 0.0, all_min = 0.0;
   int num_cells = 0;
-  std::vector<int> fc, lc;
+  std::vector<int> fc, lc;           // the reference's [first_cell, last_cell] of each part: where it is "active" and draws k_twiddle_bar_p
+  std::vector<int> wf;               // first cell each part STORES: <= fc (see local_grid)
   std::vector<std::vector<double>> kbar_p, ktw_p;
   std::vector<double> popsize, k_bar, k_tw;
   std::vector<int32_t> num_active;
@@ -161,12 +163,14 @@ struct CoalBuilder {
     using namespace coal_detail;
     const int P = (int)trees.size();
     tmin.assign(P, std::numeric_limits<double>::max()); tmax.assign(P, -std::numeric_limits<double>::max());
+    tmax_exact.assign(P, -std::numeric_limits<double>::max());
     for (int p = 0; p < P; ++p) {
       const FlatTree& st = *trees[p];
       for (int n = 0; n < st.num_nodes(); ++n) {
         bool tip = st.is_tip(n);
         tmin[p] = std::min(tmin[p], tip ? (double)st.t_min[n] : st.t[n]);
         tmax[p] = std::max(tmax[p], tip ? (double)st.t_max[n] : st.t[n]);
+        tmax_exact[p] = std::max(tmax_exact[p], st.t[n]);
       }
     }
     lo = std::numeric_limits<double>::max(); hi = -std::numeric_limits<double>::max();
@@ -184,10 +188,16 @@ struct CoalBuilder {
     using namespace coal_detail;
     const int P = (int)trees.size();
     k_bar_local.assign(num_cells, 0.0); num_active_local.assign(num_cells, 0);
-    fc.assign(P, 0); lc.assign(P, 0); kbar_p.assign(P, {}); ktw_p.assign(P, {});
+    fc.assign(P, 0); lc.assign(P, 0); wf.assign(P, 0); kbar_p.assign(P, {}); ktw_p.assign(P, {});
     parallel_for(P, [&](int p) {   // per-part lineage counts: independent
       fc[p] = cell_for(tmax[p], t_ref, t_step); lc[p] = cell_for(tmin[p], t_ref, t_step);
       if (!(0 <= fc[p] && fc[p] <= lc[p] && lc[p] < num_cells)) throw std::runtime_error("coalescent grid: bad cell range");
+      // The reference keeps every part's vectors from cell 0, so nothing stops a lineage from ending LATER than the
+      // part's float-derived t_max: a frozen cut-point tip has t_max = (float)t, which may lie below its exact time t,
+      // and when a cell boundary falls in between, the branch above it (and a displaced parent) reaches cell
+      // first_cell - 1.  The stored window therefore starts at the cell of the part's latest EXACT node time when
+      // that is earlier in the grid; activity counts and draws stay on the reference's [first_cell, last_cell].
+      wf[p] = std::min(fc[p], std::max(0, cell_for(tmax_exact[p], t_ref, t_step)));
       kbar_p[p].assign(lc[p] + 1, 0.0); ktw_p[p].assign(lc[p] + 1, 0.0);
       const FlatTree& st = *trees[p];
       for (int n = 0; n < st.num_nodes(); ++n) if (n != st.root) add_interval(st.t[st.parent[n]], st.t[n], +1.0, kbar_p[p], t_ref, t_step);
@@ -196,8 +206,8 @@ struct CoalBuilder {
     // reductions in part order (outside a part's window its counts are exactly zero: skipping them changes nothing)
     for (int p = 0; p < P; ++p) {
       for (int c = fc[p]; c <= lc[p]; ++c) num_active_local[c] += 1;
-      for (int i = fc[p]; i <= lc[p]; ++i) k_bar_local[i] += kbar_p[p][i];
-      for (int i = 0; i < fc[p]; ++i) if (kbar_p[p][i] != 0.0) throw std::runtime_error("coalescent grid: lineage outside the part's window");
+      for (int i = wf[p]; i <= lc[p]; ++i) k_bar_local[i] += kbar_p[p][i];   // the reference adds every stored cell (cpp:183-188)
+      for (int i = 0; i < wf[p]; ++i) if (kbar_p[p][i] != 0.0) throw std::runtime_error("coalescent grid: lineage outside the part's window");
     }
   }
   // stage 3: draws, given the GLOBAL k_bar and num_active_parts; returns this rank's contribution to k_twiddle_bar
@@ -225,12 +235,12 @@ struct CoalBuilder {
     std::vector<HostCoalPart> out(P);
     parallel_for(P, [&](int p) {
       HostCoalPart& cp = out[p];
-      cp.cell_first = fc[p]; cp.n_cells_total = lc[p] + 1; cp.t_ref = t_ref; cp.t_step = t_step;
-      cp.k_bar_p.assign(kbar_p[p].begin() + fc[p], kbar_p[p].end());
-      cp.k_twiddle_bar_p.assign(ktw_p[p].begin() + fc[p], ktw_p[p].end());
-      cp.k_twiddle_bar.assign(k_tw.begin() + fc[p], k_tw.begin() + lc[p] + 1);
-      cp.popsize_bar.assign(popsize.begin() + fc[p], popsize.begin() + lc[p] + 1);
-      cp.num_active_parts.assign(num_active.begin() + fc[p], num_active.begin() + lc[p] + 1);
+      cp.cell_first = wf[p]; cp.n_cells_total = lc[p] + 1; cp.t_ref = t_ref; cp.t_step = t_step;
+      cp.k_bar_p.assign(kbar_p[p].begin() + wf[p], kbar_p[p].end());
+      cp.k_twiddle_bar_p.assign(ktw_p[p].begin() + wf[p], ktw_p[p].end());   // zero outside [first_cell, last_cell], as in the reference
+      cp.k_twiddle_bar.assign(k_tw.begin() + wf[p], k_tw.begin() + lc[p] + 1);
+      cp.popsize_bar.assign(popsize.begin() + wf[p], popsize.begin() + lc[p] + 1);
+      cp.num_active_parts.assign(num_active.begin() + wf[p], num_active.begin() + lc[p] + 1);
     });
     return out;
   }

@@ -240,6 +240,7 @@ def load_library():
         "emat_part_get_coalescent": [B, i32, P(i32), P(dbl), P(dbl), P(dbl), P(dbl), P(i32), P(dbl), P(dbl)],
         "emat_part_get_stats": [B, i32, P(_PartStatsC)], "emat_part_get_trace": [B, i32, P(i32), P(dbl)],
         "emat_last_run_ms": [B, P(dbl)], "emat_last_kernel_ms": [B, P(dbl), P(i32)],
+        "emat_debug_gamma": [B, i32, i32, P(dbl), P(dbl), P(dbl)],
         "emat_synth_create": [P(_SynthParamsC), P(S)], "emat_synth_get": [S, P(_FlatTreeC), P(P(C.c_uint8)), P(dbl)],
         "emat_run_create": [B, P(_FlatTreeC), P(C.c_uint8), i32, u64, P(R)], "emat_run_destroy": [R],
         "emat_run_set_num_parts": [R, i32], "emat_run_set_max_part_nodes": [R, i32], "emat_run_set_hky": [R, dbl, dbl, P(dbl), P(dbl)], "emat_run_set_pop_model": [R, P(_PopModelC)],
@@ -433,6 +434,13 @@ class EmatBackend:
         self._ck(self._lib.emat_get_global_stats(self._h, num_partitions, T.ctypes.data_as(C.POINTER(C.c_double)), M.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nm)),
                  "emat_get_global_stats")
         return T, M, int(nm.value)
+
+    def debug_gamma(self, mode: int, a, x_or_q) -> np.ndarray:
+        """Test hook: the device's gamma_q (mode 0) / gamma_q_inv (mode 1), point by point."""
+        a = np.ascontiguousarray(a, np.float64); x = np.ascontiguousarray(x_or_q, np.float64); out = np.zeros_like(a)
+        dp = C.POINTER(C.c_double)
+        self._ck(self._lib.emat_debug_gamma(self._h, mode, a.shape[0], a.ctypes.data_as(dp), x.ctypes.data_as(dp), out.ctypes.data_as(dp)), "emat_debug_gamma")
+        return out
 
     def part_download(self, part: int) -> FlatTree:
         n, nm, ni, nf = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()

@@ -233,6 +233,13 @@ emat_status emat_last_run_ms(emat_backend* h, double* ms);
 /* Duration of the dominant kernel (k_run_moves, the bulk size class) inside the last pass, and how many parts it ran. */
 emat_status emat_last_kernel_ms(emat_backend* h, double* ms, int32_t* num_parts_in_kernel);
 
+/* ---- test hooks (not part of the boundary) ------------------------------------------------- */
+/* Evaluates, on the device and point by point, the engine's own implementations of the regularised upper incomplete gamma
+ * function: mode 0: out[i] = Q(a[i], x_or_q[i]); mode 1: out[i] = the x with Q(a[i], x) = x_or_q[i].  They stand in for
+ * boost::math::gamma_q / gamma_q_inv (Boost 1.84, reference safe_gamma_math.h:46,68; reached from spr_study.cpp:368,463,544),
+ * whose source is not part of the reference tree; tests/test_parity_gpu.py sweeps them over tests/golden/gamma_q.json. */
+emat_status emat_debug_gamma(emat_backend* h, int32_t mode, int32_t n, const double* a, const double* x_or_q, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,26 @@ def assert_traces_match(trg, tro, tol=1e-9, what=""):
             assert abs(kg[3] - ko[3]) <= tol * max(1.0, abs(ko[3])), "%s: move %d log_mh %r vs %r" % (what, i, kg[3], ko[3])
 
 
+def compare_part(gpu, orc, p, num_nodes, trace, tol, expected_moves):
+    """Everything one part's chain leaves behind, HIP engine vs oracle: move trace, counters, RNG consumption, tree, derived
+    quantities and coalescent cells."""
+    sg, so = gpu.part_stats(p), orc.part_stats(p)
+    assert sg["status"] == 0, "part %d device status %d: %s" % (p, sg["status"], gpu.last_error())
+    assert_traces_match(gpu.part_trace(p, trace), orc.part_trace(p, trace), tol, "part %d" % p)
+    assert sg["moves_done"] == so["moves_done"] == expected_moves
+    assert sg["proposed"] == so["proposed"] and sg["accepted"] == so["accepted"], "part %d counters %s vs %s" % (p, sg, so)
+    assert sg["rng_draws"] == so["rng_draws"], "part %d rng draws %d vs %d" % (p, sg["rng_draws"], so["rng_draws"])
+    assert_trees_match(gpu.part_download(p), orc.part_download(p), tol, "part %d" % p)
+    lg, ng, Gg, Ag = gpu.part_derived(p, num_nodes)
+    lo, no, Go, Ao = orc.part_derived(p, num_nodes)
+    assert np.array_equal(ng, no)
+    assert rel_close(lg, lo, 1e-9), "part %d lambda_i after moves" % p
+    assert rel_close(Gg, Go, tol) and rel_close(Ag, Ao, tol), "part %d totals after moves: %r/%r %r/%r" % (p, Gg, Go, Ag, Ao)
+    cg, co = gpu.part_coalescent(p), orc.part_coalescent(p)
+    assert cg["k_bar_p"].shape == co["k_bar_p"].shape
+    assert rel_close(cg["k_bar_p"], co["k_bar_p"], 1e-9) and rel_close(cg["k_twiddle_bar_p"], co["k_twiddle_bar_p"], 1e-9)
+
+
 def run_parity(sc, num_parts, moves_per_part, seed=11, topology=True, only_displace=False, trace=200, use_lds=True, t_step=None, nu_l=None, tol=1e-9,
                evo=None, total_moves=None):
     """`total_moves`: drive both engines through run_local_moves(total) (reference Run::run_local_moves: count / parts each,
@@ -95,22 +115,7 @@ def run_parity(sc, num_parts, moves_per_part, seed=11, topology=True, only_displ
                 orc.run_moves_per_part(moves_per_part, threads=4)
             for p in range(len(parts)):
                 expected_moves = moves_per_part if total_moves is None else total_moves // len(parts) + (total_moves - len(parts) * (total_moves // len(parts)) if p == 0 else 0)
-                sg, so = gpu.part_stats(p), orc.part_stats(p)
-                assert sg["status"] == 0, "part %d device status %d: %s" % (p, sg["status"], gpu.last_error())
-                assert_traces_match(gpu.part_trace(p, trace), orc.part_trace(p, trace), tol, "part %d" % p)
-                assert sg["moves_done"] == so["moves_done"] == expected_moves
-                assert sg["proposed"] == so["proposed"] and sg["accepted"] == so["accepted"], "part %d counters %s vs %s" % (p, sg, so)
-                assert sg["rng_draws"] == so["rng_draws"], "part %d rng draws %d vs %d" % (p, sg["rng_draws"], so["rng_draws"])
-                assert_trees_match(gpu.part_download(p), orc.part_download(p), tol, "part %d" % p)
-                n = parts[p].num_nodes
-                lg, ng, Gg, Ag = gpu.part_derived(p, n)
-                lo, no, Go, Ao = orc.part_derived(p, n)
-                assert np.array_equal(ng, no)
-                assert rel_close(lg, lo, 1e-9), "part %d lambda_i after moves" % p
-                assert rel_close(Gg, Go, tol) and rel_close(Ag, Ao, tol), "part %d totals after moves: %r/%r %r/%r" % (p, Gg, Go, Ag, Ao)
-                cg, co = gpu.part_coalescent(p), orc.part_coalescent(p)
-                assert cg["k_bar_p"].shape == co["k_bar_p"].shape
-                assert rel_close(cg["k_bar_p"], co["k_bar_p"], 1e-9) and rel_close(cg["k_twiddle_bar_p"], co["k_twiddle_bar_p"], 1e-9)
+                compare_part(gpu, orc, p, parts[p].num_nodes, trace, tol, expected_moves)
             Gg, Ag = gpu.totals(); Go, Ao = orc.totals()
             assert rel_close(Gg, Go, tol) and rel_close(Ag, Ao, tol)
         return gpu.part_stats(0)

@@ -100,6 +100,12 @@ class OracleEngine:
         m = np.full(self.num_parts, moves, np.int64)
         self._ck(self.L.orc_run_moves(self.h, _ptr(m, C.c_int64), threads, int(paranoid)), "run_moves")
 
+    def run_moves_counts(self, counts, threads=1, paranoid=False):
+        """An explicit number of moves for every part (0 = leave the part alone)."""
+        m = np.ascontiguousarray(counts, np.int64)
+        assert m.shape[0] == self.num_parts
+        self._ck(self.L.orc_run_moves(self.h, _ptr(m, C.c_int64), threads, int(paranoid)), "run_moves")
+
     def run_local_moves(self, count, threads=1, paranoid=False):
         sub = count // self.num_parts
         m = np.full(self.num_parts, sub, np.int64); m[0] = count - (self.num_parts - 1) * sub

@@ -115,3 +115,49 @@ def test_trajectory_parity_on_the_benchmark_workload():
     from helpers import run_parity
     sc = make_scenario("C4")
     run_parity(sc, 8192, 1000, seed=20261001, trace=1000)
+
+
+def test_trajectory_parity_at_c2_full_size():
+    """Config C2 exactly as SURVEY 8(d) states it (1 610 tips, 18 959 sites, exponential growth with a minimum population):
+    64 parts x 20 000 moves, every move of every part against the oracle."""
+    from helpers import run_parity
+    sc = make_scenario("C2")
+    assert sc.num_tips == 1610 and sc.num_sites == 18959
+    st = run_parity(sc, 64, 20000, seed=103, trace=20000)
+    assert st["moves_done"] == 20000
+
+
+def test_c5_one_gpu_sampled_trajectories_and_whole_run_properties():
+    """Config C5 (1 000 000 tips) on one GPU.  All ~80 000 parts run 300 moves; every 41st part (and the root part) is
+    replayed by the oracle from the same coalescent tables and compared move for move; over ALL parts: every chain ran
+    to completion, and the incrementally maintained totals equal a from-scratch recomputation on the device."""
+    from helpers import compare_part, split_parts
+    moves = 300
+    sc = make_scenario("C5")
+    assert sc.num_tips == 1000000
+    parts, incl, seeds, root_part, ref = split_parts(sc, 81920, 20261005)
+    assert len(parts) > 60000
+    gpu = d.EmatBackend(sc.num_sites, trace_moves=moves)
+    orc = OracleEngine(sc.num_sites, trace_moves=moves)
+    try:
+        configure(gpu, sc, ref, parts, incl, seeds, root_part)
+        configure(orc, sc, ref, parts, incl, seeds, root_part)
+        gpu.run_moves_per_part(moves)
+        gpu.synchronize()
+        sample = sorted(set(list(range(0, len(parts), 41)) + [root_part]))
+        counts = np.zeros(len(parts), np.int64); counts[sample] = moves
+        orc.run_moves_counts(counts, threads=8)
+        for p in sample:
+            compare_part(gpu, orc, p, parts[p].num_nodes, moves, 1e-9, moves)
+        acc = np.zeros(5, np.int64)
+        for p in range(len(parts)):
+            st = gpu.part_stats(p)
+            assert st["status"] == 0 and st["moves_done"] == moves, (p, st)
+            acc += np.array(st["accepted"])
+        assert acc.sum() > 0.05 * moves * len(parts) and acc[3] + acc[4] > 0
+        G_inc, A_inc = gpu.totals()
+        gpu.recalc_derived()
+        G_re, A_re = gpu.totals()
+        assert rel_close(G_inc, G_re, 1e-9) and rel_close(A_inc, A_re, 1e-9), (G_inc, G_re, A_inc, A_re)
+    finally:
+        gpu.close(); orc.close()

@@ -180,3 +180,42 @@ def test_oversized_parts_can_be_cut_further(sc):
         run.close()
     assert max(sizes[0]) > 40, "the unrefined partition should contain a part above the limit for this test to bite"
     assert len(sizes[40]) > len(sizes[0])
+
+
+def test_coalescent_window_covers_lineages_past_a_frozen_tips_float_bound():
+    """A frozen cut-point tip carries t_min = t_max = (float)t, which can lie below its exact double time t.  When that tip
+    is the latest node of its part and a cell boundary falls between (float)t and t, the branch above it reaches the
+    cell BEFORE the part's float-derived first cell.  The reference keeps every part's vectors from cell 0 and carries
+    on (very_scalable_coalescent.cpp:141-170); the engine's stored window must cover that cell too instead of
+    rejecting the tree.  t_step is chosen here to put a boundary into such a gap."""
+    sc3 = make_scenario("C3", num_tips=3000, num_sites=2000)
+    parts, incl, seeds, root_part, ref = split_parts(sc3, 256, 9)
+    t_ref = max(float(np.max(np.where(p.child0 == -1, p.t_max.astype(np.float64), p.t))) for p in parts)
+    # find a part whose latest node is a frozen tip with (float)t < t, and a t_step with a boundary inside the gap
+    t_step = None
+    for p in parts:
+        tips = p.child0 == -1
+        k = int(np.argmax(p.t))
+        if tips[k] and p.t_min[k] == p.t_max[k] and float(p.t_max[k]) < p.t[k] and float(np.max(np.where(tips, p.t_max.astype(np.float64), p.t))) == float(p.t_max[k]):
+            lo, hi = t_ref - p.t[k], t_ref - float(p.t_max[k])   # distances from t_ref: a boundary c * t_step must fall in (lo, hi]
+            for c in range(200, 400):
+                ts = 0.5 * (lo + hi) / c
+                if np.floor(lo / ts) != np.floor(hi / ts):
+                    t_step = ts
+                    break
+        if t_step is not None:
+            break
+    assert t_step is not None, "scenario has no frozen tip with a float bound below its exact time"
+    eng = d.EmatBackend(sc3.num_sites, device=-1)
+    orc = OracleEngine(sc3.num_sites)
+    configure(eng, sc3, ref, parts, incl, seeds, root_part, t_step)     # raised EMAT_ERR_INVALID_ARGUMENT before the fix
+    configure(orc, sc3, ref, parts, incl, seeds, root_part, t_step)
+    outside = 0
+    for p in range(len(parts)):
+        cg, co = eng.part_coalescent(p), orc.part_coalescent(p)
+        assert cg["k_bar_p"].shape == co["k_bar_p"].shape
+        assert rel_close(cg["k_bar_p"], co["k_bar_p"], 1e-12) and rel_close(cg["k_twiddle_bar_p"], co["k_twiddle_bar_p"], 1e-12), p
+        first_active = int(np.argmax(co["k_twiddle_bar_p"] != 0.0))
+        outside += int(np.any(co["k_bar_p"][:first_active] != 0.0))
+    assert outside >= 1, "the chosen t_step did not put a lineage before any part's first active cell"
+    eng.close(); orc.close()

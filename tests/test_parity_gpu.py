@@ -168,3 +168,29 @@ def test_parts_that_run_out_of_slab_space_are_regrown_and_finish(monkeypatch):
     sc.tree, sc.ref, sc.t_max_tip = tree, ref, tmax
     sc.pop = d.PopModel.exp(tmax, 365.0, 0.0, 0.0)
     run_parity(sc, 2, 4000, trace=4000)   # the trace survives the re-materialisation too
+
+
+def test_device_gamma_q_against_scipy_golden_vectors():
+    """The device's own gamma_q / gamma_q_inv (they replace Boost's, whose source is not in the reference tree) swept over
+    the same scipy vectors and tolerances the oracle's are pinned to (tests/test_oracle_pinning.py; the reference compares
+    at 1e-12 absolute, safe_gamma_math_tests.cpp:35-56)."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gamma_q.json")))
+    b = d.EmatBackend(100)
+    try:
+        rows = g["q"]
+        got = b.debug_gamma(0, [r["a"] for r in rows], [r["x"] for r in rows])
+        for r, v in zip(rows, got):
+            assert abs(v - r["q"]) <= 1e-12 + 1e-10 * r["q"], (r, v)
+        rows = g["q_inv"]
+        a = np.array([r["a"] for r in rows])
+        got = b.debug_gamma(1, a, [r["q"] for r in rows])
+        back = b.debug_gamma(0, a, got)
+        for r, v, q in zip(rows, got, back):
+            assert abs(v - r["x"]) <= 1e-9 * max(1.0, r["x"]), (r, v)
+            assert abs(q - r["q"]) <= 1e-11 * r["q"] + 1e-14, (r, v, q)
+        # limits the reference tests (safe_gamma_math_tests.cpp:65-106): Q(a, 0) = 1, Q(a, inf) = 0, inverse of 1 and 0
+        assert list(b.debug_gamma(0, [0.5, 3.0], [0.0, np.inf])) == [1.0, 0.0]
+        assert list(b.debug_gamma(1, [0.5, 3.0], [1.0, 0.0])) == [0.0, np.inf]
+    finally:
+        b.close()
