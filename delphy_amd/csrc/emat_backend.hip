@@ -1280,7 +1280,11 @@ emat_status emat_debug_phase_ticks(emat_backend* h, int32_t part_id, int64_t* ou
   if (!h || !out16 || part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
   emat_status st = pull_from_device(h); if (st) return st;
   const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + h->parts[part_id].slab_off);
+#ifdef EMAT_PROFILE_PHASES
   for (int i = 0; i < 16; ++i) out16[i] = H->phase_ticks[i];
+#else
+  (void)H; for (int i = 0; i < 16; ++i) out16[i] = 0;   // phase counters exist only in -DEMAT_PROFILE_PHASES builds
+#endif
   return EMAT_OK;
 }
 /* Duration of the k_run_moves launch of the last pass, from HIP events around that launch on its stream. */

@@ -321,7 +321,9 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   const double lambda_X = nodes_of(c)[X].lambda;
   SVec<Region> pre_regions = study_seed_fill(c, X, t_X, missing_at_X, limit, old_S, 0, old_deltas, c.includes_run_root, hot);
   EMAT_PHASE(c, 6);
+#ifdef EMAT_PROFILE_PHASES
   hdr_of(c)->phase_ticks[13] += pre_regions.n;
+#endif
   Study pre = make_study(c, pre_regions, n_missing_at_X, lambda_X, annealing_factor, t_X, c.t_max_tip);
   if (c.failed) return;
   const int new_region = study_pick_nexus_region(c, pre);
@@ -347,7 +349,9 @@ EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
   SVec<SdRec> new_deltas = summarize_closed_mutations(c, new_graft, extra);
   SVec<Region> post_regions = study_seed_fill(c, X, t_X, missing_at_X, limit, new_S, 0, new_deltas, c.includes_run_root, hot);
   EMAT_PHASE(c, 10);
+#ifdef EMAT_PROFILE_PHASES
   hdr_of(c)->phase_ticks[13] += post_regions.n;
+#endif
   Study post = make_study(c, post_regions, n_missing_at_X, lambda_X, annealing_factor, t_X, c.t_max_tip);
   if (c.failed) return;
   const int old_region = study_find_region(post, old_S, old_t_P);

@@ -8,7 +8,7 @@
 // A slab is ONE relocatable byte blob per part (all internal references are byte offsets), so that a
 // workgroup can stream it into LDS with one coalesced copy, run its chain there, and stream it back:
 //
-//   [SlabHeader 512 B][NodeRec x n_nodes (64 B each)][cell table (5 arrays x cell_cap)]
+//   [SlabHeader 256 B][NodeRec x n_nodes (64 B each)][cell table (5 arrays x cell_cap)]
 //   [trace ring][list heap: 16-B mutation / 8-B interval / 8-B from-state records][scratch]
 //
 // Plain C++ (no HIP types) because the host encoder and the kernels share it.
@@ -103,10 +103,16 @@ struct SlabHeader {
   uint64_t rng_spare;          // unconsumed second half of the last Philox block
   uint32_t rng_has_spare;
   uint32_t pad0;
+#ifdef EMAT_PROFILE_PHASES
   int64_t phase_ticks[16];     // optional phase profile (builds with -DEMAT_PROFILE_PHASES), s_memtime ticks
   uint8_t reserved[128];
 };
-static_assert(sizeof(SlabHeader) == 512, "SlabHeader must be 512 bytes");
+static_assert(sizeof(SlabHeader) == 512, "SlabHeader must be 512 bytes in profiling builds");
+#else
+};
+// Every byte of the header is staged in LDS with the part, and LDS is what limits how many parts a CU holds.
+static_assert(sizeof(SlabHeader) == 256, "SlabHeader must be 256 bytes");
+#endif
 
 // Shared, read-only model data in HBM (one copy per device).
 struct EvoTable {               // reference Global_evo_model (core/evo_model.h:20-48)

@@ -208,3 +208,85 @@ def timeline_probe(nparts=8192, moves=1000):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "timeline":
     timeline_probe()
+
+
+def parts_probe(nparts=8192, moves=1000, out_csv="gpurun_out/parts_probe.csv"):
+    """Per-part features next to the part's duration in one pass: what makes a chain slow?"""
+    import ctypes as C
+    sc = make_scenario("C4")
+    parts, incl, seeds, root_part, ref = split_parts(sc, nparts, 20261001)
+    gpu = d.EmatBackend(sc.num_sites)
+    configure(gpu, sc, ref, parts, incl, seeds, root_part)
+    gpu.run_moves_per_part(moves); gpu.synchronize()
+    t0 = np.array([gpu.part_stats(p)["device_ticks"] for p in range(len(parts))], dtype=np.float64)
+    p0 = np.array([gpu.part_stats(p)["proposed"] for p in range(len(parts))], dtype=np.float64)
+    gpu.run_moves_per_part(moves); gpu.synchronize(); ms = gpu.last_run_ms()
+    st = [gpu.part_stats(p) for p in range(len(parts))]
+    dur = (np.array([s["device_ticks"] for s in st], dtype=np.float64) - t0) / 1e5
+    prop = np.array([s["proposed"] for s in st], dtype=np.float64) - p0
+    acc = np.array([s["accepted"] for s in st], dtype=np.float64)
+    n = len(parts)
+    buf = (C.c_int64 * (2 * n))()
+    lib = d.load_library()
+    lib.emat_debug_part_ticks.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    assert lib.emat_debug_part_ticks(gpu.handle, buf) == 0
+    a = np.array(list(buf), dtype=np.float64); start = a[n:] / 1e5; start -= start.min()
+    feats = np.array([[p.num_nodes, p.mut_site.shape[0], p.miss_start.shape[0], p.mfs_site.shape[0], int(p.mut_offset[1] - p.mut_offset[0]),
+                       16 * p.mut_site.shape[0] + 8 * p.miss_start.shape[0] + 8 * p.mfs_site.shape[0] + 64 * p.num_nodes] for p in parts], dtype=np.float64)
+    # depth statistics
+    depth = []
+    for p in parts:
+        dp = np.zeros(p.num_nodes, np.int32)
+        order = np.argsort(p.t, kind="stable")
+        for i in order:
+            if p.parent[i] >= 0: dp[i] = dp[p.parent[i]] + 1
+        depth.append([dp.mean(), dp.max()])
+    depth = np.array(depth)
+    M = np.column_stack([feats, depth, dur, start, prop, acc[:, 3:5]])
+    hdr = "nodes,muts,ivs,fss,root_muts,bytes,depth_mean,depth_max,dur_ms,start_ms,p_inner,p_tip,p_reform,p_slide,p_spr1,a_slide,a_spr1"
+    np.savetxt(os.path.join(ROOT, out_csv), M, delimiter=",", header=hdr, fmt="%.4g")
+    print("kernel %.2f ms, parts %d" % (ms, n))
+    names = hdr.split(",")
+    for j, nm in enumerate(names):
+        if nm != "dur_ms": print("  corr(dur, %-10s) = %+.2f" % (nm, np.corrcoef(M[:, j], dur)[0, 1]))
+    # linear fit
+    X = np.column_stack([np.ones(n), feats[:, 0], feats[:, 1], feats[:, 2], feats[:, 4], depth[:, 0]])
+    coef, *_ = np.linalg.lstsq(X, dur, rcond=None)
+    print("  dur ~ %.2f + %.3f nodes + %.4f muts + %.4f ivs + %.4f root_muts + %.3f depth_mean; resid std %.2f ms" % (*coef, np.std(dur - X @ coef)))
+    for lo, hi in [(0, 9000), (9000, 9700), (9700, 12000), (12000, 16000), (16000, 10**9)]:
+        m = (feats[:, 5] >= lo) & (feats[:, 5] < hi)
+        if m.any(): print("  content bytes %6d-%-8d parts %5d dur mean %.2f p90 %.2f max %.2f ms" % (lo, hi, m.sum(), dur[m].mean(), np.percentile(dur[m], 90), dur[m].max()))
+    gpu.close()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "parts":
+    parts_probe()
+
+
+def slow_phase_probe(nparts=8192, moves=1000, top=6):
+    """Phase breakdown (needs the -DEMAT_PROFILE_PHASES library, EMAT_LIB_PATH) of the slowest parts of a pass."""
+    import ctypes as C
+    from delphy_amd.sharding import ShardedEngine
+    sc = make_scenario("C4")
+    eng = ShardedEngine(sc, num_parts=nparts, seed=20261001)
+    eng.setup()
+    eng.backend.run_moves_per_part(moves); eng.backend.synchronize()
+    lib = d.load_library()
+    lib.emat_debug_phase_ticks.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    buf = (C.c_int64 * 16)()
+    st = [eng.backend.part_stats(p) for p in range(eng.num_local_parts)]
+    dur = np.array([s["device_ticks"] for s in st], dtype=np.float64) / 1e5
+    names = ["core:analyze+peel", "core:topology", "core:propose", "scans in LDS", "core:coal+accept+apply", "spr1:analyze+peel", "spr1:missing+seed_fill pre", "spr1:study pre+pick",
+             "spr1:topology", "spr1:propose", "spr1:seed_fill post", "spr1:study post+alpha", "spr1:accept+apply", "regions (count)", "ALL simple moves", "ALL topology moves"]
+    sel = list(np.argsort(-dur)[:top]) + list(np.argsort(dur)[len(dur) // 2: len(dur) // 2 + 2])
+    for p in sel:
+        lib.emat_debug_phase_ticks(eng.backend.handle, int(p), buf)
+        v = np.array(list(buf), dtype=np.float64)
+        tot = v[14] + v[15]
+        print("part %d nodes %d dur %.2f ms proposed %s | regions/study %.1f" % (p, eng.local_sizes[p], dur[p], st[p]["proposed"], v[13] / max(1, 2 * st[p]["proposed"][4])))
+        print("    " + " | ".join("%s %.1f%%" % (names[i], 100 * v[i] / tot) for i in list(range(0, 3)) + list(range(4, 13)) + [14, 15]))
+    eng.close()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "slowphase":
+    slow_phase_probe()
