@@ -344,6 +344,82 @@ __global__ void __launch_bounds__(k_wave) k_recalc_derived(KernelArgs a) {
   }
 }
 
+// ---- compact copies of what the host reads most often, so that it does not have to download the slabs for them ----------
+// Every part's 256-byte header (status, counters, log_G, log prior, RNG position) into one dense array.
+__global__ void __launch_bounds__(k_wave) k_gather_headers(KernelArgs a, uint8_t* out) {
+  const int part = blockIdx.x, lane = threadIdx.x;
+  const uint4* src = (const uint4*)(a.slabs + a.slab_off[part]);
+  uint4* dst = (uint4*)(out + (size_t)part * sizeof(SlabHeader));
+  for (int i = lane; i < (int)(sizeof(SlabHeader) / 16); i += k_wave) dst[i] = src[i];
+}
+
+// calc_num_muts_l (phylo_tree_calc.cpp:612-622): mutations per site over the non-root branches of every part (integer
+// atomics: the result does not depend on the order).
+__global__ void __launch_bounds__(k_wave) k_num_muts_l(KernelArgs a, int32_t* out) {
+  const int part = blockIdx.x, lane = threadIdx.x;
+  uint8_t* slab = a.slabs + a.slab_off[part];
+  dev::Ctx c;
+  init_ctx(c, slab, slab, a, nullptr);
+  const int n = c.H->n_nodes, root = c.H->root;
+  for (int i = lane; i < n; i += k_wave) {
+    if (i == root) continue;   // "mutations" above a part's root are deltas from the reference sequence
+    const MutRec* m = dev::muts_of(c, i);
+    for (int j = 0; j < dev::nmuts(c, i); ++j) atomicAdd(&out[m[j].site], 1);
+  }
+}
+
+// ---- Scalable_coalescent_prior (scalable_coalescent.cpp:88-138, 163-187), one part per workgroup ----------------------
+// The whole-tree grid prior is -sum_cells dt kbar (kbar - 1) / (2 Nbar) - sum_inner log N(t), where kbar_j, the mean number
+// of lineages in cell j = [t_ref + j dt, t_ref + (j + 1) dt), j < 0, is 1 (the lineage above the root) plus, for every
+// coalescence at t_i, the overlap of [t_i, t_ref] with the cell, minus the same for every tip.  That sum is additive over
+// nodes, hence over parts: a cut node is the root of the part below it (counted there, as the coalescence it is) and a
+// frozen tip of the part above it (which cannot tell it from a real tip and subtracts it), so the part below adds it once
+// more.  With that, a part without the run's root contributes exactly nothing outside the cells its own nodes span, and
+// the root part a constant -1 after them.  Lanes take cells; every lane walks the part's nodes in index order, so the
+// partial sums are reproducible.  meta[part] = {first cell, number of cells, sum over inner nodes of -log N(t), status}.
+__global__ void __launch_bounds__(k_wave) k_scalable_prior(KernelArgs a, double t_ref, double t_step, const uint64_t* out_off, const uint32_t* out_cap, double* out, double* meta) {
+  __shared__ __attribute__((aligned(16))) double lds_tables[k_lds_tables_bytes / 8];
+  const int part = blockIdx.x, lane = threadIdx.x;
+  uint8_t* slab = a.slabs + a.slab_off[part];
+  const double* tables = stage_tables(a, lds_tables, lane);
+  __syncthreads();
+  dev::Ctx c;
+  init_ctx(c, slab, slab, a, tables);
+  const int n = c.H->n_nodes, root = c.H->root;
+  const bool root_part = c.includes_run_root;
+  double tmin = dev::k_inf, tmax = -dev::k_inf, acc = 0.0;
+  for (int i = lane; i < n; i += k_wave) {
+    const double t = c.N[i].t;
+    tmin = tmin < t ? tmin : t; tmax = tmax > t ? tmax : t;
+    if (!dev::is_tip(c, i)) acc -= log(dev::pop_at_time(*c.pop, t));
+  }
+  for (int off = 32; off > 0; off >>= 1) { double o = __shfl_down(tmin, off, k_wave); tmin = tmin < o ? tmin : o; o = __shfl_down(tmax, off, k_wave); tmax = tmax > o ? tmax : o; }
+  tmin = __shfl(tmin, 0, k_wave); tmax = __shfl(tmax, 0, k_wave);
+  acc = wave_sum(acc);
+  auto cell_of = [&](double t) { return (int)floor((t - t_ref) / t_step); };
+  const int jlo = cell_of(tmin);
+  int jhi = cell_of(tmax); if (jhi > -1) jhi = -1;   // cell 0 and later: no lineage of the tree lives after t_ref
+  const int cnt = jhi >= jlo ? jhi - jlo + 1 : 0;
+  double* row = out + out_off[part];
+  const bool fits = (uint32_t)cnt <= out_cap[part];
+  if (fits) {
+    for (int j = jlo + lane; j <= jhi; j += k_wave) {
+      const double ub_j = t_ref + (double)(j + 1) * t_step;
+      double sum = 0.0;
+      for (int i = 0; i < n; ++i) {
+        const double t = c.N[i].t;
+        const int cs = cell_of(t);
+        if (j < cs) continue;
+        double w = dev::is_tip(c, i) ? -1.0 : +1.0;
+        if (i == root && !root_part) w += 1.0;
+        sum += (j == cs) ? w * (ub_j - t) / t_step : w;   // add_interval: partial first cell, whole cells after it (:100-115)
+      }
+      row[j - jlo] = sum;
+    }
+  }
+  if (lane == 0) { double* m = meta + (size_t)part * 4; m[0] = (double)jlo; m[1] = (double)cnt; m[2] = acc; m[3] = fits ? 0.0 : 1.0; }
+}
+
 // ---- test hook: the device's incomplete-gamma routines evaluated point by point (emat_debug_gamma) ----------------------
 __global__ void k_debug_gamma(const double* a, const double* x, double* out, int n, int mode) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -358,6 +434,10 @@ __global__ void k_debug_gamma(const double* a, const double* x, double* out, int
 template <class T> struct DevBuf {
   T* p = nullptr; size_t n = 0;
   ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t count) {   // room for `count` elements, contents undefined
+    if (count > n) { if (p) (void)hipFree(p); p = nullptr; n = 0; hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); if (e != hipSuccess) return e; n = count; }
+    return hipSuccess;
+  }
   hipError_t upload(const T* src, size_t count) {
     if (count > n) { if (p) (void)hipFree(p); p = nullptr; n = 0; hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); if (e != hipSuccess) return e; n = count; }
     if (count) return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
@@ -423,6 +503,8 @@ struct emat_backend {
   uint32_t cfg_lds_max = 96 * 1024;                  // EMAT_LDS_MAX (tuning knob): largest staging area; larger parts run out of HBM
   bool order_valid = false;         // d_order holds the current parts, largest first
   bool pass_pending = false;        // a launch has not been checked for stopped parts yet (finish_pass)
+  emat_status fatal_status = EMAT_OK;   // a part stopped INSIDE a move: its tree is untrustworthy, and every run / getter keeps
+  std::string fatal_message;            // failing with this until the parts are uploaded afresh (emat_begin_upload)
   double last_run_ms = 0.0;
   // model
   std::vector<uint8_t> ref, partition_for_site;
@@ -451,6 +533,8 @@ struct emat_backend {
   uint32_t cfg_lds_scratch = 0;     // EMAT_LDS_SCRATCH (tuning knob): per-part LDS scratch arena; 0 = all scratch in HBM (measured best at C4)
   bool host_only = false;           // cfg.device == -1: uploads / coalescent staging only, every launch fails with EMAT_ERR_NO_DEVICE
   std::unique_ptr<CoalBuilder> coal_builder;
+  // dense copy of every part's slab header (k_gather_headers): what the scalar getters read instead of the slabs
+  DevBuf<uint8_t> d_headers; std::vector<uint8_t> h_headers; bool headers_current = false;
 
   void set_error(const std::string& s) { last_error = s; }
 };
@@ -617,6 +701,7 @@ KernelArgs make_args(emat_backend* h) {
 
 // Bring the host copies of all parts up to date with the device.
 emat_status pull_from_device(emat_backend* h);
+emat_status pull_headers(emat_backend* h);
 emat_status materialize(emat_backend* h);
 emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, const std::vector<int64_t>* counts);
 
@@ -626,6 +711,7 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
 // must not use the part's tree.
 emat_status finish_pass(emat_backend* h) {
   if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
+  if (h->fatal_status != EMAT_OK) return fail(h, h->fatal_status, h->fatal_message);
   if (h->host_only || !h->pass_pending || !h->slabs_on_device) return EMAT_OK;
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   const size_t n = h->parts.size();
@@ -637,13 +723,14 @@ emat_status finish_pass(emat_backend* h) {
     size_t stopped = 0, fatal = n;
     for (size_t p = 0; p < n; ++p) if (status[p] != 0) { ++stopped; if (status[p] != k_part_need_space && fatal == n) fatal = p; }
     if (stopped == 0) return EMAT_OK;
-    h->host_slabs_current = false;
+    h->host_slabs_current = false; h->headers_current = false;
     emat_status st = pull_from_device(h); if (st) return st;
     if (fatal != n) {
       const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + h->parts[fatal].slab_off);
-      return fail(h, status[fatal] == k_part_cell_overflow ? EMAT_ERR_CAPACITY : EMAT_ERR_INTERNAL,
-                  "part " + std::to_string(fatal) + " stopped inside a move with status " + std::to_string(status[fatal]) + " (device source line " + std::to_string(H->fail_line) +
-                  "); " + std::to_string(stopped) + " part(s) stopped in all");
+      h->fatal_status = status[fatal] == k_part_cell_overflow ? EMAT_ERR_CAPACITY : EMAT_ERR_INTERNAL;
+      h->fatal_message = "part " + std::to_string(fatal) + " stopped inside a move with status " + std::to_string(status[fatal]) + " (device source line " + std::to_string(H->fail_line) +
+                         "); " + std::to_string(stopped) + " part(s) stopped in all";
+      return fail(h, h->fatal_status, h->fatal_message);
     }
     if (round == 4) return fail(h, EMAT_ERR_CAPACITY, std::to_string(stopped) + " part(s) still out of slab space after four doublings");
     std::vector<int64_t> counts(n, 0);
@@ -654,7 +741,7 @@ emat_status finish_pass(emat_backend* h) {
       ph.stats.status = 0;
     }
     if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] %zu part(s) ran out of slab space: re-materialising with more room and running the rest of their moves\n", stopped);
-    h->slabs_on_device = false; h->host_slabs_current = false;   // every part is re-encoded from its decoded state (tree, RNG, cells, statistics)
+    h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false;   // every part is re-encoded from its decoded state (tree, RNG, cells, statistics)
     st = launch_moves(h, 0, 0, &counts); if (st) return st;
   }
   return EMAT_OK;
@@ -663,6 +750,7 @@ emat_status finish_pass(emat_backend* h) {
 emat_status pull_from_device_impl(emat_backend* h);
 emat_status pull_from_device(emat_backend* h) {
   if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
+  if (h->fatal_status != EMAT_OK) return fail(h, h->fatal_status, h->fatal_message);
   if (h->host_only || !h->slabs_on_device) return EMAT_OK;
   if (h->pass_pending) { emat_status st = finish_pass(h); if (st) return st; }
   return pull_from_device_impl(h);
@@ -684,6 +772,31 @@ emat_status pull_from_device_impl(emat_backend* h) {
   h->host_slabs_current = true;
   return EMAT_OK;
 }
+
+// Dense copy of the parts' headers: what emat_get_totals / emat_part_get_stats need is 256 bytes per part, not the slabs.
+emat_status pull_headers(emat_backend* h) {
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
+  if (h->fatal_status != EMAT_OK) return fail(h, h->fatal_status, h->fatal_message);
+  if (h->host_only || !h->slabs_on_device) return EMAT_OK;
+  if (h->pass_pending) { emat_status st = finish_pass(h); if (st) return st; }
+  if (h->headers_current) return EMAT_OK;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  const size_t n = h->parts.size();
+  h->h_headers.resize(n * sizeof(SlabHeader));
+  if (h->host_slabs_current) {
+    for (size_t p = 0; p < n; ++p) std::memcpy(h->h_headers.data() + p * sizeof(SlabHeader), h->h_slabs.data() + h->parts[p].slab_off, sizeof(SlabHeader));
+  } else {
+    HIP_TRY(h->d_headers.alloc(n * sizeof(SlabHeader)));
+    KernelArgs a = make_args(h);
+    hipLaunchKernelGGL(k_gather_headers, dim3((unsigned)n), dim3(k_wave), 0, h->stream, a, h->d_headers.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->h_headers.data(), h->d_headers.p, n * sizeof(SlabHeader), hipMemcpyDeviceToHost));
+  }
+  h->headers_current = true;
+  return EMAT_OK;
+}
+inline const SlabHeader* header_of(const emat_backend* h, size_t part) { return (const SlabHeader*)(h->h_headers.data() + part * sizeof(SlabHeader)); }
 
 // Encode all parts and push them to the device.
 emat_status materialize(emat_backend* h) {
@@ -813,7 +926,7 @@ emat_status launch_recalc(emat_backend* h) {
   KernelArgs a = make_args(h);
   hipLaunchKernelGGL(k_recalc_derived, dim3((unsigned)h->parts.size()), dim3(k_wave), 0, h->stream, a);
   HIP_TRY(hipGetLastError());
-  h->derived_valid = true; h->host_slabs_current = false;
+  h->derived_valid = true; h->host_slabs_current = false; h->headers_current = false;
   return EMAT_OK;
 }
 
@@ -836,6 +949,7 @@ emat_status build_order(emat_backend* h) {
 emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, const std::vector<int64_t>* counts = nullptr) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
+  if (h->fatal_status != EMAT_OK) return fail(h, h->fatal_status, h->fatal_message);
   emat_status st = sync_model_to_device(h); if (st) return st;
   st = materialize(h); if (st) return st;
   if (!h->derived_valid) { st = launch_recalc(h); if (st) return st; }
@@ -889,7 +1003,7 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
     if (forked) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[1], 0));
   }
   HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
-  h->host_slabs_current = false;
+  h->host_slabs_current = false; h->headers_current = false;
   return EMAT_OK;
 }
 
@@ -980,9 +1094,10 @@ emat_status emat_begin_upload(emat_backend* h, int32_t num_parts) {
   if (h->cfg.max_parts > 0 && num_parts > h->cfg.max_parts) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "more parts than cfg.max_parts");
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->coal_builder.reset();
+  h->fatal_status = EMAT_OK; h->fatal_message.clear(); h->pass_pending = false;
   h->parts.clear(); h->parts.resize(num_parts);
   h->uploads_expected = num_parts; h->root_part = -1;
-  h->slabs_on_device = false; h->host_slabs_current = false; h->have_coal = false; h->derived_valid = false;
+  h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false; h->have_coal = false; h->derived_valid = false;
   return EMAT_OK;
 }
 emat_status emat_part_upload(emat_backend* h, int32_t part_id, const emat_flat_tree* subtree, int32_t includes_run_root, uint64_t seed) {
@@ -1023,7 +1138,7 @@ emat_status emat_build_coalescent_parts(emat_backend* h, const emat_pop_model* p
     for (size_t p = 0; p < h->parts.size(); ++p) h->parts[p].coal = std::move(cps[p]);
   } catch (const std::exception& ex) { return fail(h, EMAT_ERR_INVALID_ARGUMENT, ex.what()); }
   h->have_pop = true; h->have_coal = true; h->model_dirty = true;
-  h->slabs_on_device = false; h->host_slabs_current = false; h->derived_valid = false;   // re-encode with the new cell tables
+  h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false; h->derived_valid = false;   // re-encode with the new cell tables
   return EMAT_OK;
 }
 
@@ -1079,7 +1194,7 @@ emat_status emat_coalescent_finish(emat_backend* h, const double* k_twiddle_bar)
   } catch (const std::exception& ex) { return fail(h, EMAT_ERR_INVALID_ARGUMENT, ex.what()); }
   h->coal_builder.reset();
   h->have_pop = true; h->have_coal = true; h->model_dirty = true;
-  h->slabs_on_device = false; h->host_slabs_current = false; h->derived_valid = false;
+  h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false; h->derived_valid = false;
   return EMAT_OK;
 }
 
@@ -1113,9 +1228,9 @@ emat_status emat_get_totals(emat_backend* h, double* log_G, double* log_aug) {
   if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
   emat_status st;
   if (!h->slabs_on_device || !h->derived_valid) { st = launch_recalc(h); if (st) return st; }
-  st = pull_from_device(h); if (st) return st;
+  st = pull_headers(h); if (st) return st;   // 256 bytes per part through a gather kernel; the slabs stay where they are
   double g = 0.0, a = 0.0;
-  for (auto& ph : h->parts) { const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + ph.slab_off); g += H->log_G; a += H->log_aug_prior; }
+  for (size_t p = 0; p < h->parts.size(); ++p) { const SlabHeader* H = header_of(h, p); g += H->log_G; a += H->log_aug_prior; }   // part order: reproducible
   if (log_G) *log_G = g;
   if (log_aug) *log_aug = a;
   return EMAT_OK;
@@ -1180,10 +1295,13 @@ emat_status emat_part_get_coalescent(emat_backend* h, int32_t part_id, int32_t* 
 }
 emat_status emat_part_get_stats(emat_backend* h, int32_t part_id, emat_part_stats* out) {
   if (!h || !out || part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
-  emat_status st = pull_from_device(h); if (st) return st;
+  emat_status st = pull_headers(h); if (st) return st;
   *out = h->parts[part_id].stats;
-  if (h->slabs_on_device) {
-    const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + h->parts[part_id].slab_off);
+  if (h->slabs_on_device && !h->host_only) {
+    const SlabHeader* H = header_of(h, (size_t)part_id);
+    out->status = H->status; out->num_nodes = H->n_nodes; out->moves_done = H->moves_done;
+    for (int k = 0; k < 5; ++k) { out->proposed[k] = H->proposed[k]; out->accepted[k] = H->accepted[k]; }
+    out->algorithmic_bytes = H->alg_bytes; out->rng_draws = (int64_t)H->rng_counter; out->device_ticks = H->device_ticks;
     if (H->status != 0) h->set_error("part " + std::to_string(part_id) + " stopped with status " + std::to_string(H->status) + " at device line " + std::to_string(H->fail_line));
   }
   return EMAT_OK;
@@ -1209,6 +1327,7 @@ emat_status emat_get_global_stats(emat_backend* h, int32_t num_partitions, doubl
   if (num_partitions != h->num_partitions) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "num_partitions does not match emat_set_evo");
   if (num_partitions > k_max_stats_partitions) return fail(h, EMAT_ERR_CAPACITY, "emat_get_global_stats supports at most 4 site partitions");
   st = materialize(h); if (st) return st;
+  if (h->pass_pending) { st = finish_pass(h); if (st) return st; }   // statistics of chains that finished their moves, or a loud failure
   const int W = 4 * num_partitions;
   for (auto& ph : h->parts) {   // the per-node table lives in the part's scratch region
     const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + ph.slab_off);
@@ -1234,6 +1353,102 @@ emat_status emat_get_global_stats(emat_backend* h, int32_t num_partitions, doubl
   if (num_muts) *num_muts = nm;
   return EMAT_OK;
 }
+/* calc_num_muts_l on the device (header: emat_get_num_muts_l) */
+emat_status emat_get_num_muts_l(emat_backend* h, int32_t* num_muts_l) {
+  if (!h || !num_muts_l) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  emat_status st = sync_model_to_device(h); if (st) return st;
+  st = materialize(h); if (st) return st;
+  if (h->pass_pending) { st = finish_pass(h); if (st) return st; }
+  DevBuf<int32_t> d_out;
+  HIP_TRY(d_out.alloc((size_t)h->L));
+  HIP_TRY(hipMemsetAsync(d_out.p, 0, (size_t)h->L * sizeof(int32_t), h->stream));
+  KernelArgs a = make_args(h);
+  hipLaunchKernelGGL(k_num_muts_l, dim3((unsigned)h->parts.size()), dim3(k_wave), 0, h->stream, a, d_out.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(num_muts_l, d_out.p, (size_t)h->L * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return EMAT_OK;
+}
+
+/* Scalable_coalescent_prior on the device (header: emat_scalable_coalescent_partial / _log_prior / emat_get_scalable_coalescent_log_prior) */
+emat_status emat_scalable_coalescent_partial(emat_backend* h, double t_ref, double t_step, int32_t first_cell, int32_t num_cells,
+                                             double* k_bar_partial, double* sum_neg_log_pop, int32_t* first_cell_needed) {
+  if (!h || !(t_step > 0.0) || num_cells < 0 || (num_cells > 0 && !k_bar_partial)) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
+  if (!h->have_pop) return fail(h, EMAT_ERR_STATE, "no population model: emat_build_coalescent_parts (or the staged form) first");
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  emat_status st = sync_model_to_device(h); if (st) return st;
+  st = materialize(h); if (st) return st;
+  if (h->pass_pending) { st = finish_pass(h); if (st) return st; }
+  const size_t n = h->parts.size();
+  // a part's nodes span about as many cells of this grid as of its very-scalable window (same cell width, other origin)
+  std::vector<uint64_t> off(n); std::vector<uint32_t> cap(n); uint64_t tot = 0;
+  const double ratio = h->parts[0].coal.t_step > 0.0 ? h->parts[0].coal.t_step / t_step : 1.0;
+  for (size_t p = 0; p < n; ++p) {
+    const PartHost& ph = h->parts[p];
+    const double cells_vs = (double)(ph.includes_run_root ? 2 * ph.coal.k_bar_p.size() + 512 : ph.coal.k_bar_p.size());
+    cap[p] = (uint32_t)std::min<double>(1e7, std::ceil(cells_vs * ratio) + 4.0);
+    off[p] = tot; tot += cap[p];
+  }
+  DevBuf<uint64_t> d_off; DevBuf<uint32_t> d_cap; DevBuf<double> d_out, d_meta;
+  HIP_TRY(d_off.upload(off.data(), n)); HIP_TRY(d_cap.upload(cap.data(), n)); HIP_TRY(d_out.alloc((size_t)tot)); HIP_TRY(d_meta.alloc(n * 4));
+  KernelArgs a = make_args(h);
+  hipLaunchKernelGGL(k_scalable_prior, dim3((unsigned)n), dim3(k_wave), 0, h->stream, a, t_ref, t_step, d_off.p, d_cap.p, d_out.p, d_meta.p);
+  HIP_TRY(hipGetLastError());
+  std::vector<double> rows((size_t)tot), meta(n * 4);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(rows.data(), d_out.p, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(meta.data(), d_meta.p, meta.size() * sizeof(double), hipMemcpyDeviceToHost));
+  int first_needed = 0;
+  for (size_t p = 0; p < n; ++p) {
+    if (meta[4 * p + 3] != 0.0) return fail(h, EMAT_ERR_CAPACITY, "part " + std::to_string(p) + " spans more grid cells than expected");
+    if (meta[4 * p + 1] > 0.0) first_needed = std::min(first_needed, (int)meta[4 * p]);
+  }
+  if (first_cell_needed) *first_cell_needed = first_needed;
+  for (int j = 0; j < num_cells; ++j) k_bar_partial[j] = 0.0;
+  double logs = 0.0;
+  for (size_t p = 0; p < n; ++p) {   // part order: reproducible sums
+    const int jlo = (int)meta[4 * p], cnt = (int)meta[4 * p + 1];
+    logs += meta[4 * p + 2];
+    if (num_cells == 0) continue;
+    if (cnt > 0 && (jlo < first_cell || jlo + cnt > first_cell + num_cells)) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "the cell range given does not cover every node (ask with num_cells = 0 for first_cell_needed)");
+    const double* row = rows.data() + off[p];
+    for (int k = 0; k < cnt; ++k) k_bar_partial[jlo - first_cell + k] += row[k];
+    if (h->parts[p].includes_run_root) for (int j = jlo + cnt; j < first_cell + num_cells && j < 0; ++j) k_bar_partial[j - first_cell] -= 1.0;   // the root part's constant tail
+  }
+  if (sum_neg_log_pop) *sum_neg_log_pop = logs;
+  return EMAT_OK;
+}
+emat_status emat_scalable_coalescent_log_prior(emat_backend* h, double t_ref, double t_step, int32_t first_cell, int32_t num_cells,
+                                               const double* k_bar_partial_sum, double sum_neg_log_pop, double* log_prior) {
+  if (!h || !(t_step > 0.0) || num_cells < 0 || (num_cells > 0 && !k_bar_partial_sum) || !log_prior) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!h->have_pop) return fail(h, EMAT_ERR_STATE, "no population model: emat_build_coalescent_parts (or the staged form) first");
+  double r = 0.0;
+  for (int k = 0; k < num_cells; ++k) {   // scalable_coalescent.cpp:163-187, cells in increasing time
+    const int j = first_cell + k;
+    if (j >= 0) break;
+    const double lb = t_ref + (double)j * t_step, ub = lb + t_step;
+    double popsize_bar = h->pop.pop_integral(lb, ub) / t_step;
+    if (popsize_bar == 0.0) popsize_bar = 1e-100;   // the reference's stopgap (:62-64)
+    const double kbar = 1.0 + k_bar_partial_sum[k];   // cells before t_ref start at one lineage (:56)
+    r -= t_step * kbar * (kbar - 1) / (2.0 * popsize_bar);
+  }
+  *log_prior = r + sum_neg_log_pop;
+  return EMAT_OK;
+}
+emat_status emat_get_scalable_coalescent_log_prior(emat_backend* h, double t_ref, double t_step, double* log_prior) {
+  if (!h || !log_prior) return EMAT_ERR_INVALID_ARGUMENT;
+  int32_t first = 0;
+  emat_status st = emat_scalable_coalescent_partial(h, t_ref, t_step, 0, 0, nullptr, nullptr, &first); if (st) return st;
+  std::vector<double> kb((size_t)(-first)); double logs = 0.0;
+  st = emat_scalable_coalescent_partial(h, t_ref, t_step, first, -first, kb.data(), &logs, nullptr); if (st) return st;
+  return emat_scalable_coalescent_log_prior(h, t_ref, t_step, first, -first, kb.data(), logs, log_prior);
+}
+
 /* test hook (header: emat_debug_gamma) */
 emat_status emat_debug_gamma(emat_backend* h, int32_t mode, int32_t n, const double* a, const double* x_or_q, double* out) {
   if (!h || n < 0 || (mode != 0 && mode != 1) || (n > 0 && (!a || !x_or_q || !out))) return EMAT_ERR_INVALID_ARGUMENT;

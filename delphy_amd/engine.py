@@ -241,6 +241,9 @@ def load_library():
         "emat_part_get_stats": [B, i32, P(_PartStatsC)], "emat_part_get_trace": [B, i32, P(i32), P(dbl)],
         "emat_last_run_ms": [B, P(dbl)], "emat_last_kernel_ms": [B, P(dbl), P(i32)],
         "emat_debug_gamma": [B, i32, i32, P(dbl), P(dbl), P(dbl)],
+        "emat_get_num_muts_l": [B, P(i32)], "emat_get_scalable_coalescent_log_prior": [B, dbl, dbl, P(dbl)],
+        "emat_scalable_coalescent_partial": [B, dbl, dbl, i32, i32, P(dbl), P(dbl), P(i32)],
+        "emat_scalable_coalescent_log_prior": [B, dbl, dbl, i32, i32, P(dbl), dbl, P(dbl)],
         "emat_synth_create": [P(_SynthParamsC), P(S)], "emat_synth_get": [S, P(_FlatTreeC), P(P(C.c_uint8)), P(dbl)],
         "emat_run_create": [B, P(_FlatTreeC), P(C.c_uint8), i32, u64, P(R)], "emat_run_destroy": [R],
         "emat_run_set_num_parts": [R, i32], "emat_run_set_max_part_nodes": [R, i32], "emat_run_set_hky": [R, dbl, dbl, P(dbl), P(dbl)], "emat_run_set_pop_model": [R, P(_PopModelC)],
@@ -434,6 +437,31 @@ class EmatBackend:
         self._ck(self._lib.emat_get_global_stats(self._h, num_partitions, T.ctypes.data_as(C.POINTER(C.c_double)), M.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nm)),
                  "emat_get_global_stats")
         return T, M, int(nm.value)
+
+    def num_muts_l(self) -> np.ndarray:
+        """calc_num_muts_l over the parts of this handle (mutations per site)."""
+        out = np.zeros(self.num_sites, np.int32)
+        self._ck(self._lib.emat_get_num_muts_l(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))), "emat_get_num_muts_l")
+        return out
+
+    def scalable_coalescent_log_prior(self, t_ref: float, t_step: float) -> float:
+        """Scalable_coalescent_prior::calc_log_prior of the whole tree, from the parts of this handle."""
+        v = C.c_double()
+        self._ck(self._lib.emat_get_scalable_coalescent_log_prior(self._h, t_ref, t_step, C.byref(v)), "emat_get_scalable_coalescent_log_prior")
+        return float(v.value)
+
+    def scalable_coalescent_partial(self, t_ref: float, t_step: float, first_cell: int, num_cells: int):
+        """(partial k_bar grid over [first_cell, first_cell + num_cells), sum of -log N(t) over inner nodes, first cell needed)."""
+        kb = np.zeros(max(num_cells, 1)); logs = C.c_double(); need = C.c_int32()
+        self._ck(self._lib.emat_scalable_coalescent_partial(self._h, t_ref, t_step, first_cell, num_cells, kb.ctypes.data_as(C.POINTER(C.c_double)), C.byref(logs), C.byref(need)),
+                 "emat_scalable_coalescent_partial")
+        return kb[:num_cells], float(logs.value), int(need.value)
+
+    def scalable_coalescent_log_prior_from_grid(self, t_ref: float, t_step: float, first_cell: int, k_bar_sum: np.ndarray, sum_neg_log_pop: float) -> float:
+        kb = np.ascontiguousarray(k_bar_sum, np.float64); v = C.c_double()
+        self._ck(self._lib.emat_scalable_coalescent_log_prior(self._h, t_ref, t_step, first_cell, kb.shape[0], kb.ctypes.data_as(C.POINTER(C.c_double)), sum_neg_log_pop, C.byref(v)),
+                 "emat_scalable_coalescent_log_prior")
+        return float(v.value)
 
     def debug_gamma(self, mode: int, a, x_or_q) -> np.ndarray:
         """Test hook: the device's gamma_q (mode 0) / gamma_q_inv (mode 1), point by point."""

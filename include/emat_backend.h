@@ -190,6 +190,28 @@ emat_status emat_get_totals(emat_backend* h, double* log_G, double* log_augmente
 emat_status emat_get_global_stats(emat_backend* h, int32_t num_partitions, double* Ttwiddle_beta_a /*[P][4]*/,
                                   int64_t* num_muts_beta_ab /*[P][4][4]*/, int64_t* num_muts /* may be NULL */);
 
+/* replaces: calc_num_muts_l (reference phylo_tree_calc.cpp:612-622), consumed with calc_Ttwiddle_l by the site-rate
+ * (alpha / nu_l) moves (run.cpp:1109-1110, 1184-1185): mutations per site over all branches of all parts of this handle
+ * (the deltas above a part's root are not mutations).  With parts on several handles the caller adds the vectors. */
+emat_status emat_get_num_muts_l(emat_backend* h, int32_t* num_muts_l /*[num_sites]*/);
+
+/* replaces: Run::calc_cur_log_coalescent_prior (reference run.cpp:455-465), i.e. Scalable_coalescent_prior::calc_log_prior
+ * (scalable_coalescent.cpp:163-187) with every node displaced to its current time (:88-138): the whole-tree grid prior
+ *   - sum_cells t_step kbar (kbar - 1) / (2 Nbar)  -  sum over inner nodes of log N(t),
+ * under the population model last given to emat_build_coalescent_parts / emat_coalescent_begin.  `t_ref` is the time of
+ * the latest tip (calc_max_tip_time, run.cpp:40) and cell j is [t_ref + j t_step, t_ref + (j + 1) t_step), j < 0.
+ * The grid is additive over nodes and therefore over parts (a cut node counts once, as the coalescence it is), the prior
+ * is not linear in it: with parts on several GPUs each rank asks for its partial grid over a common cell range
+ * (`first_cell_needed`, all-reduce MIN, tells how far back that must reach; call with num_cells = 0 to get it), the
+ * partial grids and log sums are all-reduced (SUM) and any rank evaluates the formula.  A single handle uses the
+ * one-call form. */
+emat_status emat_scalable_coalescent_partial(emat_backend* h, double t_ref, double t_step, int32_t first_cell, int32_t num_cells,
+                                             double* k_bar_partial /*[num_cells], overwritten*/, double* sum_neg_log_pop /* may be NULL */,
+                                             int32_t* first_cell_needed /* may be NULL */);
+emat_status emat_scalable_coalescent_log_prior(emat_backend* h, double t_ref, double t_step, int32_t first_cell, int32_t num_cells,
+                                               const double* k_bar_partial_sum /*[num_cells]*/, double sum_neg_log_pop, double* log_prior);
+emat_status emat_get_scalable_coalescent_log_prior(emat_backend* h, double t_ref, double t_step, double* log_prior);
+
 /* Sizes needed to download a part (so that the caller can size an emat_flat_tree). */
 emat_status emat_part_get_sizes(emat_backend* h, int32_t part_id, int32_t* num_nodes,
                                 int32_t* num_muts, int32_t* num_intervals, int32_t* num_from_states);

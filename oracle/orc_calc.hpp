@@ -267,6 +267,11 @@ inline int calc_num_muts(const Phylo_tree& tree) {   // :577-585
   for (int i = 0; i < tree.size(); ++i) if (i != tree.root) n += (int)tree.at(i).mutations.size();
   return n;
 }
+inline std::vector<int> calc_num_muts_l(const Phylo_tree& tree) {   // :612-622
+  std::vector<int> r(tree.num_sites(), 0);
+  for (int i = 0; i < tree.size(); ++i) if (i != tree.root) for (const auto& m : tree.at(i).mutations) ++r[m.site];   // "mutations" above the root are deltas from the reference sequence
+  return r;
+}
 // ---- sufficient statistics of the global moves (phylo_tree_calc.cpp:288-369, 577-610) ----------------------------
 // Ttwiddle^beta_a = sum_{l in beta} nu_l T^(l)_a: the nu-weighted time every site of partition beta spends in state a
 // over all branches below the root, sites missing on a branch excluded.  Follows the reference's enter / exit traversal.

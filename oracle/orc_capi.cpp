@@ -183,6 +183,26 @@ int orc_global_stats(orc_engine* e, int P, double* Ttwiddle_beta_a /*[P][4]*/, i
   ORC_CATCH
 }
 
+/* calc_num_muts_l summed over the parts (the deltas above a part's root are not mutations). */
+int orc_num_muts_l(orc_engine* e, int* out /*[L]*/) {
+  ORC_TRY
+  for (int l = 0; l < e->L; ++l) out[l] = 0;
+  for (auto& pt : e->parts) { auto v = calc_num_muts_l(pt->subrun->tree); for (int l = 0; l < e->L; ++l) out[l] += v[l]; }
+  ORC_CATCH
+}
+/* Run::calc_cur_log_coalescent_prior (run.cpp:455-465) on the tree of ONE part (upload the whole tree as a single part):
+ * a Scalable_coalescent_prior built as Run builds it (run.cpp:40, 52-58), every node displaced to its time in index order. */
+int orc_scalable_log_prior(orc_engine* e, int part_id, double t_ref, double t_step, double* out) {
+  ORC_TRY
+  const Phylo_tree& tree = e->parts.at(part_id)->subrun->tree;
+  ORC_CHECK(e->pop_model != nullptr);
+  Scalable_coalescent_prior prior(e->pop_model, tree.size(), t_ref, t_step);
+  for (int n = 0; n < tree.size(); ++n) { if (tree.at(n).is_tip()) prior.mark_as_tip(n); else prior.mark_as_coalescence(n); }
+  for (int n = 0; n < tree.size(); ++n) { if (tree.at(n).is_tip()) prior.displace_tip(n, tree.at(n).t); else prior.displace_coalescence(n, tree.at(n).t); }
+  *out = prior.calc_log_prior();
+  ORC_CATCH
+}
+
 int orc_get_totals(orc_engine* e, double* log_G, double* log_aug) {
   ORC_TRY
   double g = 0.0, a = 0.0;

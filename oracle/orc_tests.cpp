@@ -233,6 +233,8 @@ TEST(calc_fixture_global_move_statistics) {
   long long total = 0;
   for (int b = 0; b < 2; ++b) for (int a = 0; a < 4; ++a) for (int c2 = 0; c2 < 4; ++c2) { EXPECT(M[b][a][c2] == em[b][a][c2]); total += M[b][a][c2]; }
   EXPECT(total == calc_num_muts(t));
+  // phylo_tree_calc_tests.cpp:471-482: A0T on r->x, T0C on x->a, A0T and T0G on r->c; A1G on x->b; C2A above the root is not a mutation
+  EXPECT(calc_num_muts_l(t) == (std::vector<int>{4, 1, 0, 0}));
 }
 TEST(calc_fixture_log_G_and_lambda) {
   auto t = complex_tree(false);
@@ -699,6 +701,61 @@ TEST(scalable_coalescent_matches_exact_kingman_for_fine_grid) {   // scalable_co
   double delta = prior.calc_delta_log_prior_after_displace_coalescence(node, new_t);
   prior.displace_coalescence(node, new_t);
   EXPECT_NEAR(prior.calc_log_prior() - before, delta, 1e-8);
+}
+// scalable_coalescent_tests.cpp:10-58 `log_prior`, the reference's own case with its own numbers: 10 tips, 9 coalescences,
+// constant population 20, t_ref = 0, one-day cells
+TEST(scalable_coalescent_reference_log_prior_case) {
+  const double pop = 20.0; const int num_tips = 10, num_nodes = 2 * num_tips - 1;
+  auto pm = std::make_shared<Const_pop_model>(pop);
+  Scalable_coalescent_prior prior(pm, num_nodes, 0.0, 1.0);
+  for (int i = 0; i != num_tips - 1; ++i) prior.mark_as_coalescence(i);
+  for (int i = num_tips - 1; i != num_nodes; ++i) prior.mark_as_tip(i);
+  EXPECT_NEAR(prior.calc_log_prior(), -(num_tips - 1) * std::log(pop), 1e-8);
+  const double tc[9] = {-50, -40, -40, -30, -30, -30, -30, -20, -10};
+  for (int i = 0; i < 9; ++i) prior.displace_coalescence(i, tc[i]);
+  double expected = 0.0 - (-40.0 - (-50.0)) * (2 * 1) / 2 / pop - (-30.0 - (-40.0)) * (4 * 3) / 2 / pop - (-20.0 - (-30.0)) * (8 * 7) / 2 / pop
+      - (-10.0 - (-20.0)) * (9 * 8) / 2 / pop - (-00.0 - (-10.0)) * (10 * 9) / 2 / pop - (num_tips - 1) * std::log(pop);
+  EXPECT_NEAR(prior.calc_log_prior(), expected, 1e-8);
+  const double tt[5] = {-45.0, -35.0, -30.0, -30.0, -25.0};
+  for (int k = 0; k < 5; ++k) prior.displace_tip(num_tips - 1 + k, tt[k]);
+  expected = 0.0 - (-45.0 - (-50.0)) * (2 * 1) / 2 / pop - (-40.0 - (-45.0)) * (1 * 0) / 2 / pop - (-35.0 - (-40.0)) * (3 * 2) / 2 / pop
+      - (-30.0 - (-35.0)) * (2 * 1) / 2 / pop - (-25.0 - (-30.0)) * (4 * 3) / 2 / pop - (-20.0 - (-25.0)) * (3 * 2) / 2 / pop
+      - (-10.0 - (-20.0)) * (4 * 3) / 2 / pop - (-00.0 - (-10.0)) * (5 * 4) / 2 / pop - (num_tips - 1) * std::log(pop);
+  EXPECT_NEAR(prior.calc_log_prior(), expected, 1e-8);
+}
+// scalable_coalescent_tests.cpp:60-110 `delta_log_prior`: exponential growth, t_step 0.17841, coalescence times applied in a
+// shuffled order (the reference shuffles with std::random_device; every order must satisfy the same identity, three are tried)
+TEST(scalable_coalescent_reference_delta_log_prior_case) {
+  for (int perm = 0; perm < 3; ++perm) {
+    auto pm = std::make_shared<Exp_pop_model>(0.0, 20.0, 0.1, 0.0);
+    const int num_tips = 10, num_nodes = 2 * num_tips - 1;
+    Scalable_coalescent_prior prior(pm, num_nodes, 0.0, 0.17841);
+    for (int i = 0; i != num_tips - 1; ++i) prior.mark_as_coalescence(i);
+    for (int i = num_tips - 1; i != num_nodes; ++i) prior.mark_as_tip(i);
+    std::vector<double> ts{-50.0, -40.0, -40.0, -30.0, -30.0, -30.0, -30.0, -20.0, -10.0};
+    Rng rng; rng.key = 900 + perm;
+    for (int i = (int)ts.size() - 1; i > 0; --i) std::swap(ts[i], ts[rng.uniform_int(i + 1)]);
+    double now = prior.calc_log_prior();
+    for (int i = 0; i != num_tips - 1; ++i) {
+      double delta = prior.calc_delta_log_prior_after_displace_coalescence(i, ts[i]);
+      prior.displace_coalescence(i, ts[i]);
+      double after = prior.calc_log_prior();
+      EXPECT_NEAR(delta, after - now, 1e-8);
+      now = after;
+    }
+    for (int i = 0; i != num_tips - 1; ++i) prior.displace_coalescence(i, 0.0);
+    for (int i = 0; i != num_tips - 1; ++i) prior.displace_coalescence(i, -60.0);
+    const double tt[5] = {-45.0, -35.0, -30.0, -30.0, -25.0};
+    for (int k = 0; k < 5; ++k) prior.displace_tip(num_tips - 1 + k, tt[k]);
+    now = prior.calc_log_prior();
+    for (int i = 0; i != num_tips - 1; ++i) {
+      double delta = prior.calc_delta_log_prior_after_displace_coalescence(i, ts[i]);
+      prior.displace_coalescence(i, ts[i]);
+      double after = prior.calc_log_prior();
+      EXPECT_NEAR(delta, after - now, 1e-8);
+      now = after;
+    }
+  }
 }
 TEST(vsc_parts_sum_to_whole_and_delta_consistency) {   // very_scalable_coalescent_tests.cpp:99-182
   emat::SynthParams p; p.num_tips = 60; p.num_sites = 50; p.seed = 31; p.tip_date_uncertainty = 5.0; p.frac_uncertain_tips = 0.3;

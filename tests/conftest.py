@@ -13,6 +13,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _gpu_count():
+    """Number of HIP devices, asked of a child process so that collecting tests never initialises the GPU here."""
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def pytest_collection_modifyitems(config, items):
+    gpu_items = [it for it in items if "gpu" in it.keywords]
+    if gpu_items and _gpu_count() == 0:
+        skip = pytest.mark.skip(reason="no HIP device: the engine has no CPU fallback (run with -m gpu on an MI355X)")
+        for it in gpu_items:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """Build the oracle (test infrastructure) and, when missing, the HIP library (hipcc cross-compiles on CPU)."""

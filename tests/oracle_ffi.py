@@ -33,6 +33,7 @@ def lib():
             "orc_part_get_coalescent": [E, C.c_int, P(C.c_int), P(dbl), P(dbl), P(dbl), P(dbl), P(C.c_int), P(dbl), P(dbl)],
             "orc_part_get_stats": [E, C.c_int, P(_PartStatsC)], "orc_part_get_trace": [E, C.c_int, P(C.c_int), P(dbl)],
             "orc_part_check": [E, C.c_int, C.c_char_p, C.c_int],
+            "orc_num_muts_l": [E, P(C.c_int)], "orc_scalable_log_prior": [E, C.c_int, dbl, dbl, P(dbl)],
         }
         for n, a in sigs.items():
             f = getattr(L, n); f.argtypes = a; f.restype = C.c_int
@@ -120,6 +121,16 @@ class OracleEngine:
         T = np.zeros((num_partitions, 4)); M = np.zeros((num_partitions, 4, 4), np.int64); nm = C.c_int64()
         self._ck(self.L.orc_global_stats(self.h, num_partitions, _ptr(T, C.c_double), _ptr(M, C.c_int64), C.byref(nm)), "global_stats")
         return T, M, int(nm.value)
+
+    def num_muts_l(self):
+        out = np.zeros(self.num_sites, np.int32)
+        self._ck(self.L.orc_num_muts_l(self.h, _ptr(out, C.c_int)), "num_muts_l")
+        return out
+
+    def scalable_log_prior(self, part, t_ref, t_step):
+        v = C.c_double()
+        self._ck(self.L.orc_scalable_log_prior(self.h, part, t_ref, t_step, C.byref(v)), "scalable_log_prior")
+        return v.value
 
     def part_download(self, part):
         n, nm, ni, nf = C.c_int(), C.c_int(), C.c_int(), C.c_int()

@@ -29,17 +29,22 @@ def test_library_exports_every_declared_symbol():
 
 def test_no_cpu_fallback():
     import torch
-    if torch.cuda.is_available():
-        pytest.skip("GPU present")
-    with pytest.raises(d.EmatError, match="NO_DEVICE"):
-        d.EmatBackend(1000)                      # a real handle needs a HIP device
-    b = d.EmatBackend(1000, device=-1)           # host-only handle: staging works, launches do not
+    if torch.cuda.device_count() == 0:
+        with pytest.raises(d.EmatError, match="NO_DEVICE"):
+            d.EmatBackend(1000)                  # a real handle needs a HIP device
+    b = d.EmatBackend(1000, device=-1)           # host-only handle (also on a GPU box): staging works, launches do not
     with pytest.raises(d.EmatError):
         b.run_moves_per_part(1)
     with pytest.raises(d.EmatError, match="NO_DEVICE"):
         b.global_stats(1)                        # device-side reductions have no host stand-in either
     with pytest.raises(d.EmatError):
         b.recalc_derived()
+    with pytest.raises(d.EmatError, match="NO_DEVICE"):
+        b.num_muts_l()
+    with pytest.raises(d.EmatError, match="NO_DEVICE"):
+        b.scalable_coalescent_log_prior(0.0, 1.0)
+    with pytest.raises(d.EmatError, match="NO_DEVICE"):
+        b.debug_gamma(0, [1.0], [1.0])
     b.close()
 
 

@@ -194,3 +194,68 @@ def test_device_gamma_q_against_scipy_golden_vectors():
         assert list(b.debug_gamma(1, [0.5, 3.0], [1.0, 0.0])) == [0.0, np.inf]
     finally:
         b.close()
+
+
+def test_whole_tree_coalescent_prior_and_per_site_mutation_counts_from_the_parts():
+    """SURVEY 8 rows a20 and (f).1: Scalable_coalescent_prior::calc_log_prior (the whole-tree grid prior Run keeps beside the
+    per-part ones, run.cpp:455-465) and calc_num_muts_l, computed on the device from the PARTS, against the oracle's
+    restatement on the WHOLE tree -- before and after moves, for the three population models."""
+    for name, kw, nparts in (("C1", dict(num_tips=150, num_sites=3000), 5), ("C2", dict(num_tips=400, num_sites=4000, uncertain_tips=0.2), 12),
+                             ("C3", dict(num_tips=700, num_sites=5000), 24)):
+        sc = make_scenario(name, **kw)
+        parts, incl, seeds, root_part, ref = split_parts(sc, nparts, 53)
+        gpu = d.EmatBackend(sc.num_sites)
+        configure(gpu, sc, ref, parts, incl, seeds, root_part)
+        try:
+            for rounds in range(2):
+                # reassemble what the device holds into one tree, through the product's own host driver
+                run = d.EmatRun(None, sc.tree, sc.ref, 53)
+                run.set_num_parts(nparts); run.repartition()
+                for p in range(len(parts)):
+                    run.part_put(p, gpu.part_download(p))
+                run.reassemble()
+                whole, ref2 = run.tree(); run.close()
+                tips = whole.child0 == -1
+                t_ref = float(np.max(whole.t[tips]))                     # calc_max_tip_time
+                t_step = sc.default_t_step()
+                orc = OracleEngine(sc.num_sites)
+                sc2 = make_scenario(name, **kw); sc2.tree, sc2.ref = whole, ref2
+                configure(orc, sc2, ref2, [whole], [True], [1], 0)
+                want = orc.scalable_log_prior(0, t_ref, t_step)
+                got = gpu.scalable_coalescent_log_prior(t_ref, t_step)
+                assert abs(got - want) <= 1e-9 * max(1.0, abs(want)), (name, rounds, got, want)
+                # the staged (multi-GPU) form gives the same number
+                _, _, first = gpu.scalable_coalescent_partial(t_ref, t_step, 0, 0)
+                kb, logs, _ = gpu.scalable_coalescent_partial(t_ref, t_step, first - 3, 3 - first)
+                assert gpu.scalable_coalescent_log_prior_from_grid(t_ref, t_step, first - 3, kb, logs) == pytest.approx(got, rel=1e-13)
+                assert np.array_equal(gpu.num_muts_l(), orc.num_muts_l())
+                assert gpu.num_muts_l().sum() == gpu.global_stats(1)[2]
+                orc.close()
+                gpu.run_moves_per_part(1500); gpu.synchronize()
+        finally:
+            gpu.close()
+
+
+def test_global_stats_wait_for_regrown_parts(monkeypatch):
+    """emat_get_global_stats right after emat_run_* (no emat_synchronize in between) with parts that run out of heap space
+    mid-pass: the statistics must describe chains that finished ALL their moves (the getter finishes the pass first)."""
+    import delphy_amd.engine as e
+    monkeypatch.setenv("EMAT_SLACK", "1.0")
+    monkeypatch.setenv("EMAT_HEAP_PER_NODE", "0")
+    sc = make_scenario("C1", num_tips=80, num_sites=400, seed=77)
+    sc.mu = 3e-4
+    tree, ref, tmax = e.make_synthetic_emat(e.SynthParams(num_tips=80, num_sites=400, mu=3e-4, gaps_per_tip=3, mean_gap_len=25, seed=77))
+    sc.tree, sc.ref, sc.t_max_tip = tree, ref, tmax
+    sc.pop = d.PopModel.exp(tmax, 365.0, 0.0, 0.0)
+    parts, incl, seeds, root_part, ref = split_parts(sc, 2, 11)
+    gpu = d.EmatBackend(sc.num_sites); orc = OracleEngine(sc.num_sites)
+    try:
+        configure(gpu, sc, ref, parts, incl, seeds, root_part); configure(orc, sc, ref, parts, incl, seeds, root_part)
+        gpu.run_moves_per_part(4000)
+        Tg, Mg, ng = gpu.global_stats(1)            # no synchronize() before it
+        orc.run_moves_per_part(4000, threads=2)
+        To, Mo, no = orc.global_stats(1)
+        assert ng == no and np.array_equal(Mg, Mo) and rel_close(Tg, To, 1e-9)
+        assert all(gpu.part_stats(p)["moves_done"] == 4000 for p in range(len(parts)))
+    finally:
+        gpu.close(); orc.close()
