@@ -87,7 +87,7 @@ template <class CtxT> __device__ inline void init_ctx(CtxT& c, uint8_t* slab, ui
   c.only_displacing_inner_nodes = a.flags.only_displacing_inner_nodes != 0;
   c.topology_moves_enabled = a.flags.topology_moves_enabled != 0;
   c.includes_run_root = (c.H->flags & k_flag_includes_run_root) != 0;
-  c.rng_key = c.H->rng_key; c.rng_ctr = c.H->rng_counter; c.rng_spare = c.H->rng_spare; c.rng_has_spare = c.H->rng_has_spare != 0;
+  c.rng_key = c.H->rng_key; c.rng_ctr = c.H->rng_counter; c.rng_spare = c.H->rng_spare; c.rng_has_spare = c.H->rng_has_spare != 0; c.phase = 0; c.svc = 0; c.frame = nullptr;
   c.mu_prop = 0.0; c.sc_top = c.H->scratch_begin; c.A = nullptr; c.a_top = 0; c.a_end = 0; c.failed = false; c.bytes = 0;
   c.tr_kind = -1.0; c.tr_node = -1.0; c.tr_acc = 0.0; c.tr_log_mh = 0.0;
 }
@@ -108,17 +108,6 @@ __device__ inline const double* stage_tables(const KernelArgs& a, double* lds_ta
 #ifndef EMAT_WAVES_PER_EU
 #define EMAT_WAVES_PER_EU 4
 #endif
-template <class CtxT, class Loop> __device__ __forceinline__ void run_chain(CtxT& c, const KernelArgs& a, int part, SlabHeader* H, int64_t moves, Loop loop) {
-  const uint64_t tick0 = wall_clock64();
-  if (H->status == 0) { c.moves_left = moves; loop(c); }
-  H->rng_counter = c.rng_ctr; H->rng_spare = c.rng_spare; H->rng_has_spare = c.rng_has_spare ? 1u : 0u;
-  H->alg_bytes += c.bytes;
-  const int64_t dt = (int64_t)(wall_clock64() - tick0);
-  H->device_ticks += dt;
-  a.part_ticks[part] += dt;
-  a.part_status[part] = H->status;
-}
-
 // Room a part staged with an LDS-local heap limit (below) must have above its used heap to be worth staging whole.
 constexpr uint32_t k_lds_heap_room = 2048;
 
@@ -154,10 +143,12 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
     const uint32_t staged_bytes = staged ? gh->heap_top : (prefix ? gh->heap_begin : 0u);
     if (staged_bytes) wave_copy16(lds_slab, gslab, staged_bytes, lane);
     __syncthreads();
+    SlabHeader* H = (staged || prefix) ? (SlabHeader*)lds_slab : gh;
+    // The root part is one chain like any other, but its moves walk long runs of coalescent cells (deep branches span
+    // hundreds of cells): compute-bound, the longest chain of its launch.  Let its wave win issue arbitration on its SIMD.
+    const bool is_root_part = (gh->flags & k_flag_includes_run_root) != 0;
+    uint64_t tick0 = 0;
     if (lane == 0) {
-      SlabHeader* H = (staged || prefix) ? (SlabHeader*)lds_slab : gh;
-      const int64_t moves = target - (H->moves_done - done_at_start);
-      int again = 0;
       // The context lives in LDS, not in private memory: it is touched by almost every instruction.
       if (staged) {
         dev_lds::Ctx& c = *(dev_lds::Ctx*)(emat_lds + k_lds_ctx_off);
@@ -167,23 +158,41 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
         // scratch arena of its moves; scratch that does not fit goes to the part's HBM scratch region as before
         const uint32_t used = (lds_heap_end + 15u) & ~15u;
         c.A = lds_slab + used; c.a_end = area + a.lds_scratch_bytes - used;
-        // The root part is one chain like any other, but its moves walk long runs of coalescent cells (deep branches span
-        // hundreds of cells): compute-bound, the longest chain of the pass and alone in its launch.  Let its wave win
-        // instruction-issue arbitration on its SIMD.
-        const bool is_root_part = (gh->flags & k_flag_includes_run_root) != 0;
-        if (is_root_part) __builtin_amdgcn_s_setprio(3);
-        run_chain(c, a, part, H, moves, [](dev_lds::Ctx& cc) { dev_lds::run_chain_loop(cc); });
-        if (is_root_part) __builtin_amdgcn_s_setprio(0);
+      } else if (prefix) init_ctx(*(dev_mix::Ctx*)(emat_lds + k_lds_ctx_off), lds_slab, gslab, a, lds_tables);
+      else init_ctx(*(dev::Ctx*)(emat_lds + k_lds_ctx_off), gslab, gslab, a, tables_staged ? lds_tables : nullptr);
+      ((dev::Ctx*)(emat_lds + k_lds_ctx_off))->moves_left = H->status == 0 ? target - (H->moves_done - done_at_start) : 0;   // the three Ctx types share one layout
+      tick0 = wall_clock64();
+      if (is_root_part) __builtin_amdgcn_s_setprio(3);
+    }
+    __syncthreads();
+    // The chain: stretches of moves on lane 0; whenever a move parks itself for work the whole wave shares (the candidate
+    // scan and study of an SPR move), all 64 lanes do that work and lane 0 picks the move up again.
+    for (;;) {
+      if (lane == 0) {
+        if (staged) dev_lds::run_chain_loop(*(dev_lds::Ctx*)(emat_lds + k_lds_ctx_off));
+        else if (prefix) dev_mix::run_chain_loop(*(dev_mix::Ctx*)(emat_lds + k_lds_ctx_off));
+        else dev::run_chain_loop(*(dev::Ctx*)(emat_lds + k_lds_ctx_off));
+      }
+      __syncthreads();
+      if (((const dev::Ctx*)(emat_lds + k_lds_ctx_off))->svc == 0) break;
+      if (staged) dev_lds::wave_scan_and_study(*(dev_lds::Ctx*)(emat_lds + k_lds_ctx_off));
+      else if (prefix) dev_mix::wave_scan_and_study(*(dev_mix::Ctx*)(emat_lds + k_lds_ctx_off));
+      else dev::wave_scan_and_study(*(dev::Ctx*)(emat_lds + k_lds_ctx_off));
+      __syncthreads();
+    }
+    if (lane == 0) {
+      if (is_root_part) __builtin_amdgcn_s_setprio(0);
+      const dev::Ctx& c = *(const dev::Ctx*)(emat_lds + k_lds_ctx_off);
+      H->rng_counter = c.rng_ctr; H->rng_spare = c.rng_spare; H->rng_has_spare = c.rng_has_spare ? 1u : 0u;
+      H->alg_bytes += c.bytes;
+      const int64_t dt = (int64_t)(wall_clock64() - tick0);
+      H->device_ticks += dt;
+      a.part_ticks[part] += dt;
+      a.part_status[part] = H->status;
+      int again = 0;
+      if (staged) {
         H->heap_end = hbm_heap_end;
         if (H->status == k_part_need_space && lds_heap_end < hbm_heap_end && H->heap_top <= hbm_heap_end) { H->status = 0; a.part_status[part] = 0; again = 1; }
-      } else if (prefix) {
-        dev_mix::Ctx& c = *(dev_mix::Ctx*)(emat_lds + k_lds_ctx_off);
-        init_ctx(c, lds_slab, gslab, a, lds_tables);
-        run_chain(c, a, part, H, moves, [](dev_mix::Ctx& cc) { dev_mix::run_chain_loop(cc); });
-      } else {
-        dev::Ctx& c = *(dev::Ctx*)(emat_lds + k_lds_ctx_off);
-        init_ctx(c, gslab, gslab, a, tables_staged ? lds_tables : nullptr);
-        run_chain(c, a, part, H, moves, [](dev::Ctx& cc) { dev::run_chain_loop(cc); });
       }
       *lds_flag = again;
     }

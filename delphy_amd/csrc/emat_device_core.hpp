@@ -70,9 +70,14 @@ struct Ctx {
   bool only_displacing_inner_nodes;
   bool topology_moves_enabled;
   bool includes_run_root;
+  bool rng_has_spare;         // rng_spare holds the second 64-bit half of the last Philox block, not yet consumed
+  // A move that wants work done by the whole wave (candidate scan and study of an SPR move) parks itself: `phase` says
+  // where it resumes, `svc` what the wave is to do meanwhile, `frame` points at the move's state in the scratch arena.
+  uint8_t phase, svc;
   // RNG (Philox4x32-10; one 128-bit block per draw)
   uint64_t rng_key, rng_ctr;
-  uint64_t rng_spare; bool rng_has_spare;   // second 64-bit half of the last Philox block, not yet consumed
+  uint64_t rng_spare;
+  uint8_t* frame;
   double mu_prop;             // effective JC69 rate of the current SPR move (subrun.cpp:502,710)
   // scratch: a small LDS arena first (A), the part's HBM scratch region as overflow (offsets from G)
   uint8_t* A;                 // LDS arena base (may be null)

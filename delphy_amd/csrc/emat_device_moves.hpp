@@ -287,94 +287,109 @@ EMAT_DN void subtree_slide_move(Ctx& c) {   // subrun.cpp:352-448
   }
 }
 
-EMAT_DN void spr1_move(Ctx& c) {   // subrun.cpp:492-675
+// subrun.cpp:492-675 in three stretches on lane 0; between them the whole wave scans for candidate regions and weighs them
+// (wave_scan_and_study).  A stretch that ends the move clears c.phase; one that parks it sets c.phase and c.svc.
+EMAT_D void spr1_park(Ctx& c, int phase) { c.phase = (uint8_t)phase; c.svc = 1; }
+EMAT_DN void spr1_move_begin(Ctx& c) {
   begin_move(c, k_spr1);
+  c.phase = 0;
   if (hdr_of(c)->n_nodes < 2) return;
   const double chooser = uniform_co(c, 0.0, 1.0);
   const int limit = chooser < 0.01 ? 0x7fffffff : 1;
   const int root0 = hdr_of(c)->root;
   c.mu_prop = nodes_of(c)[root0].lambda / (c.L - nodes_of(c)[root0].n_missing);
-  const double annealing_factor = 0.8;
   int X;
   { int guard = 0; do { X = pick_random_node(c); } while (hdr_of(c)->root == X && guard++ < (1 << 26)); }
   c.tr_node = (double)X;
   if (nodes_of(c)[X].lambda == 0.0) return;
-  const double t_X = nodes_of(c)[X].t;
   const int P = nodes_of(c)[X].parent;
-  const double old_t_P = nodes_of(c)[P].t;
-  const int old_S = sibling_of(c, P, X);
-  const int old_G = nodes_of(c)[P].parent;
   const bool pruning_changes_root = P == hdr_of(c)->root;
   if (pruning_changes_root && !c.includes_run_root) return;
   EMAT_PHASE_BEGIN();
-  const HotBlock hot = (limit == 1) ? sc_reserve_hot(c, 1536) : HotBlock{nullptr, 0};
-  Graft old_graft = analyze_graft(c, X);
-  peel_graft(c, old_graft);
+  Spr1Frame* frp = (Spr1Frame*)sc_alloc(c, (uint32_t)sizeof(Spr1Frame));
+  if (c.failed) return;
+  Spr1Frame& fr = *frp;
+  c.frame = (uint8_t*)frp;
+  fr.X = X; fr.t_X = nodes_of(c)[X].t; fr.P = P; fr.old_t_P = nodes_of(c)[P].t; fr.old_S = sibling_of(c, P, X); fr.old_G = nodes_of(c)[P].parent;
+  fr.limit = limit; fr.f = 0.8 /* annealing factor */; fr.t_max_tip = c.t_max_tip; fr.can_change_root = c.includes_run_root;
+  fr.hot = (limit == 1) ? sc_reserve_hot(c, 1536) : HotBlock{nullptr, 0};
+  fr.old_graft = analyze_graft(c, X);
+  peel_graft(c, fr.old_graft);
   EMAT_PHASE(c, 5);
   if (c.failed) return;
-  const int old_min_muts = count_min_mutations(c, old_graft);
+  fr.old_min_muts = count_min_mutations(c, fr.old_graft);
   int extra = 4;
   if (limit != 1) { extra = 8; for (int n = 0; n < hdr_of(c)->n_nodes; ++n) if (c.includes_run_root || n != hdr_of(c)->root) extra += nmuts(c, n); }
-  SVec<SdRec> old_deltas = summarize_closed_mutations(c, old_graft, extra);
-  SVec<IvRec> missing_at_X = reconstruct_missing_sites_at(c, X);
-  const int n_missing_at_X = iv_num_sites(missing_at_X.p, missing_at_X.n);
-  const double lambda_X = nodes_of(c)[X].lambda;
-  SVec<Region> pre_regions = study_seed_fill(c, X, t_X, missing_at_X, limit, old_S, 0, old_deltas, c.includes_run_root, hot);
-  EMAT_PHASE(c, 6);
-#ifdef EMAT_PROFILE_PHASES
-  hdr_of(c)->phase_ticks[13] += pre_regions.n;
-#endif
-  Study pre = make_study(c, pre_regions, n_missing_at_X, lambda_X, annealing_factor, t_X, c.t_max_tip);
+  fr.extra = extra;
+  fr.deltas = summarize_closed_mutations(c, fr.old_graft, extra);
+  fr.missing_at_X = reconstruct_missing_sites_at(c, X);
+  fr.n_missing_at_X = iv_num_sites(fr.missing_at_X.p, fr.missing_at_X.n);
+  fr.lambda_X = nodes_of(c)[X].lambda;
+  fr.init_branch = fr.old_S;
   if (c.failed) return;
+  spr1_park(c, 1);   // -> scan from the old sibling, study; resumes in spr1_move_propose
+}
+EMAT_DN void spr1_move_propose(Ctx& c) {
+  Spr1Frame& fr = *(Spr1Frame*)c.frame;
+  c.phase = 0;
+  if (c.failed) return;
+  EMAT_PHASE_BEGIN();
+  const Study& pre = fr.study;
+  const int X = fr.X, P = fr.P;
   const int new_region = study_pick_nexus_region(c, pre);
   const int new_S = pre.regions.p[new_region].branch;
   EMAT_CHECK(c, new_S != P);
   const double new_t_P = study_pick_time_in_region(c, pre, new_region);
-  const double log_alpha_o2n = study_log_alpha_in_region(c, pre, new_region, new_t_P);
-  const int pre_new_region_min_muts = pre.regions.p[new_region].min_muts;   // the second scan reuses the regions' storage
+  fr.log_alpha_o2n = study_log_alpha_in_region(c, pre, new_region, new_t_P);
+  fr.pre_new_region_min_muts = pre.regions.p[new_region].min_muts;   // the second scan reuses the regions' storage
+  fr.new_S = new_S; fr.new_t_P = new_t_P;
   const double t_new_S = nodes_of(c)[new_S].t;
   int new_G = nodes_of(c)[new_S].parent;
-  if (new_G == P) new_G = old_G;
+  if (new_G == P) new_G = fr.old_G;
   const double t_new_G = (new_G == k_no_node) ? k_neg_dbl_max : nodes_of(c)[new_G].t;
   if (c.failed) return;
   EMAT_PHASE(c, 7);
-  if (new_t_P == t_X || new_t_P == t_new_S || new_t_P == t_new_G) { apply_graft(c, old_graft); return; }
+  if (new_t_P == fr.t_X || new_t_P == t_new_S || new_t_P == t_new_G) { apply_graft(c, fr.old_graft); return; }
   spr_move_topology(c, X, new_S, new_t_P);
   EMAT_PHASE(c, 8);
-  Graft new_graft = propose_new_graft(c, X);
+  fr.new_graft = propose_new_graft(c, X);
   EMAT_PHASE(c, 9);
   if (c.failed) return;
   EMAT_CHECK(c, nodes_of(c)[X].parent == P);
-  const int new_min_muts = count_min_mutations(c, new_graft);
-  SVec<SdRec> new_deltas = summarize_closed_mutations(c, new_graft, extra);
-  SVec<Region> post_regions = study_seed_fill(c, X, t_X, missing_at_X, limit, new_S, 0, new_deltas, c.includes_run_root, hot);
-  EMAT_PHASE(c, 10);
-#ifdef EMAT_PROFILE_PHASES
-  hdr_of(c)->phase_ticks[13] += post_regions.n;
-#endif
-  Study post = make_study(c, post_regions, n_missing_at_X, lambda_X, annealing_factor, t_X, c.t_max_tip);
+  fr.new_min_muts = count_min_mutations(c, fr.new_graft);
+  fr.deltas = summarize_closed_mutations(c, fr.new_graft, fr.extra);
+  fr.init_branch = new_S;
   if (c.failed) return;
-  const int old_region = study_find_region(post, old_S, old_t_P);
+  spr1_park(c, 2);   // -> scan from the new sibling, study; resumes in spr1_move_finish
+}
+EMAT_DN void spr1_move_finish(Ctx& c) {
+  Spr1Frame& fr = *(Spr1Frame*)c.frame;
+  c.phase = 0;
+  if (c.failed) return;
+  EMAT_PHASE_BEGIN();
+  const Study& post = fr.study;
+  const int X = fr.X;
+  const int old_region = study_find_region(post, fr.old_S, fr.old_t_P);
   EMAT_CHECK(c, old_region != -1);
   if (c.failed) return;
-  const double log_alpha_n2o = study_log_alpha_in_region(c, post, old_region, old_t_P);
-  EMAT_CHECK(c, new_min_muts == pre_new_region_min_muts);
-  EMAT_CHECK(c, old_min_muts == post.regions.p[old_region].min_muts);
+  const double log_alpha_n2o = study_log_alpha_in_region(c, post, old_region, fr.old_t_P);
+  EMAT_CHECK(c, fr.new_min_muts == fr.pre_new_region_min_muts);
+  EMAT_CHECK(c, fr.old_min_muts == post.regions.p[old_region].min_muts);
   EMAT_PHASE(c, 11);
-  const double d_prior = coal_delta_displace_coalescence(c, old_t_P, new_t_P);
+  const double d_prior = coal_delta_displace_coalescence(c, fr.old_t_P, fr.new_t_P);
   if (c.failed) return;
-  const double log_mh = (new_graft.delta_log_G - new_graft.log_alpha_mut) - (old_graft.delta_log_G - old_graft.log_alpha_mut)
-      + log_alpha_n2o - log_alpha_o2n + d_prior;
+  const double log_mh = (fr.new_graft.delta_log_G - fr.new_graft.log_alpha_mut) - (fr.old_graft.delta_log_G - fr.old_graft.log_alpha_mut)
+      + log_alpha_n2o - fr.log_alpha_o2n + d_prior;
   const bool acc = mh_accept(c, log_mh);
   note_move(c, X, log_mh, acc, k_spr1);
   if (acc) {
-    apply_graft(c, new_graft);
-    hdr_of(c)->log_G -= old_graft.delta_log_G; hdr_of(c)->log_G += new_graft.delta_log_G;
+    apply_graft(c, fr.new_graft);
+    hdr_of(c)->log_G -= fr.old_graft.delta_log_G; hdr_of(c)->log_G += fr.new_graft.delta_log_G;
     hdr_of(c)->log_aug_prior += d_prior;
-    coal_coalescence_displaced(c, old_t_P, new_t_P);
+    coal_coalescence_displaced(c, fr.old_t_P, fr.new_t_P);
   } else {
-    spr_move_topology(c, X, old_S, old_t_P);
-    apply_graft(c, old_graft);
+    spr_move_topology(c, X, fr.old_S, fr.old_t_P);
+    apply_graft(c, fr.old_graft);
   }
   EMAT_PHASE(c, 12);
 }
@@ -419,8 +434,15 @@ EMAT_DN bool compact_heap(Ctx& c) {
   return true;
 }
 
-// Subrun::mcmc_sub_iteration (subrun.cpp:98-121).  Returns false when the part must stop.
+// Subrun::mcmc_sub_iteration (subrun.cpp:98-121).  Returns false when the part must stop.  An SPR1 move parks itself
+// twice for the wave's scan + study (c.svc != 0 on return): the next call resumes it.
 EMAT_D bool mcmc_sub_iteration(Ctx& c) {
+#ifdef EMAT_PROFILE_PHASES
+  const long long _mv0 = clock64();
+#endif
+  if (c.phase == 1) spr1_move_propose(c);
+  else if (c.phase == 2) spr1_move_finish(c);
+  else {
   // space check BEFORE the move, so that a stop leaves a consistent state
   {
     uint32_t heap_size = hdr_of(c)->heap_end - hdr_of(c)->heap_begin, free_b = hdr_of(c)->heap_end - hdr_of(c)->heap_top;
@@ -432,9 +454,6 @@ EMAT_D bool mcmc_sub_iteration(Ctx& c) {
   }
   sc_reset(c);
   c.tr_kind = -1.0; c.tr_node = -1.0; c.tr_acc = 0.0; c.tr_log_mh = __builtin_nan("");
-#ifdef EMAT_PROFILE_PHASES
-  long long _mv0 = clock64();
-#endif
   if (c.only_displacing_inner_nodes) { if (c.includes_run_root) inner_node_displace_move<true>(c); else inner_node_displace_move<false>(c); }
   else {
     double total_weight = 15.0 + 15.0;
@@ -443,11 +462,14 @@ EMAT_D bool mcmc_sub_iteration(Ctx& c) {
     if (r < 7.5) { if (c.includes_run_root) inner_node_displace_move<true>(c); else inner_node_displace_move<false>(c); }
     else if (r < 15.0) { if (c.includes_run_root) tip_displace_move<true>(c); else tip_displace_move<false>(c); }
     else if (r < 30.0) { if (c.includes_run_root) branch_reform_move<true>(c); else branch_reform_move<false>(c); }
-    else if (c.topology_moves_enabled) { if (r < 31.0) subtree_slide_move(c); else spr1_move(c); }
+    else if (c.topology_moves_enabled) { if (r < 31.0) subtree_slide_move(c); else spr1_move_begin(c); }
+  }
   }
 #ifdef EMAT_PROFILE_PHASES
   hdr_of(c)->phase_ticks[(c.tr_kind >= 3.0) ? 15 : 14] += clock64() - _mv0;
 #endif
+  if (c.svc != 0 && !c.failed) return true;   // parked: the move is not over
+  c.phase = 0; c.svc = 0;
   if (hdr_of(c)->trace_len < hdr_of(c)->trace_cap) {
     double* tr = (double*)(slab_of(c) + hdr_of(c)->off_trace) + 4 * hdr_of(c)->trace_len;
     tr[0] = c.tr_kind; tr[1] = c.tr_node; tr[2] = c.tr_acc; tr[3] = c.tr_log_mh;
@@ -460,8 +482,15 @@ EMAT_D bool mcmc_sub_iteration(Ctx& c) {
 // The chain itself: `c.moves_left` sub-iterations.  Its own function, and its counter in the context, so that nothing is
 // live in registers across a move: the moves clobber every register (no callee-saved saves, see the Makefile), and
 // whatever their caller kept in registers would be spilled and reloaded around each of them.
+// Returns with c.svc != 0 when the current move waits for the wave (the kernel serves it and calls again), else when the
+// moves are done or the part had to stop.
 EMAT_DN void run_chain_loop(Ctx& c) {
-  while (c.moves_left > 0) { c.moves_left -= 1; if (!mcmc_sub_iteration(c)) break; }
+  c.svc = 0;
+  for (;;) {
+    if (c.phase == 0) { if (c.moves_left <= 0) return; c.moves_left -= 1; }
+    if (!mcmc_sub_iteration(c)) { c.moves_left = 0; c.phase = 0; c.svc = 0; return; }
+    if (c.svc != 0) return;
+  }
 }
 
 // ---- derived quantities of one part from scratch (Subrun::recalc_derived_quantities, subrun.cpp:17-26;

@@ -1184,5 +1184,100 @@ EMAT_DN double study_log_alpha_in_region(Ctx& c, const Study& st, int idx, doubl
       + -lgamma(p.f * p.m + 1) - safe_log_gamma_integral(c, p.f * p.m + 1, p.x_min, p.x_max);
 }
 
+// =================================================================================================
+// Wave-cooperative candidate ranking (all 64 lanes; the rest of a move runs on lane 0)
+// =================================================================================================
+// State of an SPR1 move across its stretches on lane 0 and the wave-wide work in between.  Lives in the scratch arena.
+struct Spr1Frame {
+  // what the scan + study service reads ...
+  int X, init_branch, limit, n_missing_at_X;
+  double t_X, lambda_X, f, t_max_tip;
+  SVec<IvRec> missing_at_X;
+  SVec<SdRec> deltas;
+  HotBlock hot;
+  bool can_change_root;
+  // ... and what it leaves behind
+  Study study;
+  // the move's own variables that outlive a stretch
+  int P, old_S, old_G, extra, old_min_muts, new_min_muts, new_S, pre_new_region_min_muts;
+  double old_t_P, new_t_P, log_alpha_o2n;
+  Graft old_graft, new_graft;
+};
+EMAT_DF int wave_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+EMAT_DF double wave_bcast(double x, int src) { return __shfl(x, src, 64); }
+
+// Spr_study's constructor (spr_study.cpp:226-385) with one region per lane: the log-weights (two logarithms each, an
+// incomplete gamma function above the root) and the weights exp(logW - max) are evaluated side by side, with exactly the
+// arithmetic of make_study; the maximum is order-independent, and the sum of the weights -- which is not -- is taken by
+// lane 0 in region order, so every number equals the serial one bit for bit.
+EMAT_D void wave_make_study(Ctx& c, Spr1Frame& fr, SVec<Region> regions) {
+  const int lane = wave_lane();
+  Study& st = fr.study;
+  if (lane == 0) {
+    st.regions = regions; st.lambda_X = fr.lambda_X; st.f = fr.f; st.t_X = fr.t_X; st.t_max_tip = fr.t_max_tip; st.log_Wmax = 0.0; st.sum_W = 0.0;
+    st.mu = fr.lambda_X / (c.L - fr.n_missing_at_X);
+    EMAT_CHECK(c, regions.n > 0);
+  }
+  __syncthreads();
+  if (c.failed || regions.n <= 0) return;
+  const double f = fr.f, lambda_X = fr.lambda_X, t_X = fr.t_X, mu = st.mu;
+  // pass 1: log-weights; running maximum as std::max(a, b) = (a < b) ? b : a seeded with the first (NaN-aware)
+  double my_max = -k_inf; bool any = false;
+  for (int i = lane; i < regions.n; i += 64) {
+    const Region r = regions.p[i];
+    const int m = r.min_muts;
+    double logW;
+    if (r.t_min != k_neg_dbl_max) {
+      double t_prime = 0.5 * (r.t_min + r.t_max);
+      logW = log(f * lambda_X * (r.t_max - r.t_min)) + f * (-lambda_X * (t_X - t_prime) + m * log(mu * (t_X - t_prime) / 3));
+    } else {
+      RootRegionParams p = root_region_params(c, st, r);
+      if (p.x_max < 0.01) {
+        double alpha = f * m + 1;
+        logW = -k_ln2 + log(f * lambda_X) + f * m * log(mu / 3) + alpha * log(p.s_max) + log1p(-pow(p.s_min / p.s_max, alpha)) - log(alpha);
+      } else {
+        logW = -k_ln2 + f * m * log(mu / (3 * lambda_X * f)) + lgamma(f * m + 1) + safe_log_gamma_integral(c, f * m + 1, p.x_min, p.x_max);
+      }
+    }
+    regions.p[i].logW = logW;
+    if (logW == logW) { if (!any || my_max < logW) my_max = logW; any = true; }   // NaNs never replace the running maximum
+  }
+  for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(my_max, off, 64); if (my_max < o) my_max = o; }
+  __syncthreads();
+  double log_Wmax = wave_bcast(my_max, 0);
+  { const double first = regions.p[0].logW; if (first != first) log_Wmax = first; }   // a NaN in front stays (every later comparison is false)
+  // pass 2: normalise by the maximum, weights
+  for (int i = lane; i < regions.n; i += 64) {
+    const double lw = regions.p[i].logW - log_Wmax, W = exp(lw);
+    *(double2*)&regions.p[i].logW = make_double2(lw, W);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    double sum_W = 0.0;
+    for (int i = 0; i < regions.n; ++i) sum_W += regions.p[i].W;
+    st.log_Wmax = log_Wmax; st.sum_W = sum_W;
+    c.bytes += 2 * 48 * (int64_t)regions.n;
+  }
+  __syncthreads();
+}
+
+// The wave-wide part of an SPR1 move: candidate scan (study_seed_fill) and study of the regions it found.
+EMAT_DN void wave_scan_and_study(Ctx& c) {
+  Spr1Frame& fr = *(Spr1Frame*)c.frame;
+  const int lane = wave_lane();
+  SVec<Region>* shared = &fr.study.regions;
+  if (lane == 0) {
+    EMAT_PHASE_BEGIN();
+    *shared = study_seed_fill(c, fr.X, fr.t_X, fr.missing_at_X, fr.limit, fr.init_branch, 0, fr.deltas, fr.can_change_root, fr.hot);
+    EMAT_PHASE(c, 6);
+#ifdef EMAT_PROFILE_PHASES
+    hdr_of(c)->phase_ticks[13] += shared->n;
+#endif
+  }
+  __syncthreads();
+  const SVec<Region> regions = *shared;
+  wave_make_study(c, fr, regions);
+}
+
 }  // namespace EMAT_DEV_NS
 }  // namespace emat
