@@ -6,11 +6,10 @@ A "step" is one `emat_run_local_moves` pass (reference Run::run_local_moves, cor
 slabs already resident in HBM.  Default workload = config C4 of SURVEY section 8(d): a seeded synthetic
 100k-tip SARS-CoV-2-like EMAT (29 903 sites, HKY + skygrid) cut by the reference's tree-partitioning rule.
 
-N > 1 (launched by torchrun, one rank per GPU): 8192 parts are requested per GPU (the partitioner's minimum part
-size caps what the tree yields) and sharded across ranks in contiguous blocks;
-the only cross-rank exchange is the per-cycle coalescent-grid all-reduce (<= a few KB) done
-before the timed region and a 2-double all-reduce of the log-posterior totals after it.  The tree is fixed
-as N grows => "scaling": "strong".
+N > 1 (launched by torchrun, one rank per GPU): the SAME partition at every N (8192 parts requested, 7 955 obtained),
+sharded across ranks in contiguous blocks; the only cross-rank exchange is the per-cycle coalescent-grid all-reduce
+(<= a few KB) done before the timed region and a 2-double all-reduce of the log-posterior totals after it.
+Tree and partition are fixed as N grows => "scaling": "strong".
 """
 import argparse
 import json
@@ -25,6 +24,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def device_code_sha16():
+    """Identifies the device code a PMC profile belongs to: sha256 over the HIP sources the kernels are built from."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "delphy_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".hip", ".hpp")) or f == "Makefile":
+            h.update(open(os.path.join(src, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -32,43 +42,81 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C4", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--tips", type=int, default=None, help="override the number of tips (debug)")
-    ap.add_argument("--parts", type=int, default=None, help="number of partition parts requested from the partitioner (default 8192 per GPU)")
+    ap.add_argument("--parts", type=int, default=8192, help="number of partition parts requested from the partitioner (the same at every N: strong scaling of one decomposition)")
     ap.add_argument("--moves-per-part", type=int, default=1000)
     ap.add_argument("--max-part-nodes", type=int, default=0, help="not in the reference: cut parts larger than this further (0 = the reference's partitioning rule)")
     ap.add_argument("--no-lds", action="store_true")
     ap.add_argument("--no-topology", action="store_true", help="diagnostic: disable subtree-slide and SPR moves")
     ap.add_argument("--only-displace", action="store_true", help="diagnostic: only inner-node displacement moves")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-time budget of each CPU baseline sample")
+    ap.add_argument("--no-inclusive", action="store_true", help="skip the host-cycle-inclusive figure (repartition + moves + reassemble through the run driver)")
     return ap.parse_args()
 
 
-def cpu_baseline(sc, num_parts, seed, target_seconds, t_step):
-    """The CPU restatement of Delphy's algorithm (oracle/, kind = "port") timed on this box's host cores on a
-    bounded sample of the same workload: the same parts, the same number of moves on every part, one thread per
-    core with the parts dealt round-robin to the threads (the reference's policy is one part per thread,
-    tools/delphy.cpp:130-132).  A short pilot sizes the sample to about `target_seconds` of wall time."""
+def _time_oracle(sc, num_parts, seed, target_seconds, t_step, threads, pilot):
+    """Oracle (CPU restatement) on `num_parts` parts of `sc`: the same number of moves on every part, parts dealt round-robin
+    to `threads` host threads; a short pilot sizes the sample to about `target_seconds` of wall time."""
     from helpers import configure, split_parts
     from oracle_ffi import OracleEngine
-    cores = max(1, min(os.cpu_count() or 1, 64))
     parts, incl, seeds, root_part, ref = split_parts(sc, num_parts, seed)
     orc = OracleEngine(sc.num_sites)
     configure(orc, sc, ref, parts, incl, seeds, root_part, t_step)
     orc.recalc_derived()
-    pilot = 2000
     t0 = time.perf_counter()
-    orc.run_moves_per_part(pilot, threads=cores)
+    orc.run_moves_per_part(pilot, threads=threads)
     rate = len(parts) * pilot / max(1e-6, time.perf_counter() - t0)
     # the pilot runs hot in cache and over-estimates the sustained rate by about 2x: size the sample for 0.45 x target
-    sample_moves = int(min(400000, max(1000, 0.45 * target_seconds * rate / len(parts))))
+    sample_moves = int(min(50_000_000, max(pilot, 0.45 * target_seconds * rate / len(parts))))
     t0 = time.perf_counter()
-    orc.run_moves_per_part(sample_moves, threads=cores)
+    orc.run_moves_per_part(sample_moves, threads=threads)
     dt = time.perf_counter() - t0
     orc.close()
-    return {"value": len(parts) * sample_moves / dt, "unit": "moves/s", "cores": cores, "kind": "port",
-            "sample": "same %d parts, %d moves per part = %.3g moves (%.1f s wall on %d host threads, after a %d-move pilot); "
-                      "CPU restatement of Delphy's algorithm (oracle/), not Delphy itself"
-                      % (len(parts), sample_moves, len(parts) * sample_moves, dt, cores, pilot)}
+    return len(parts), sample_moves, dt
+
+
+def cpu_baseline(sc, num_parts, seed, target_seconds, t_step):
+    """The CPU restatement of Delphy's algorithm (oracle/, kind = "port") timed on this box's host cores on bounded
+    samples of the same workload.  `value` = the GPU's own partition replayed on the CPU (the same ~7 955 small parts,
+    dealt round-robin to one thread per core).  `policies` adds the two figures SURVEY 8(d) asks for: the reference's own
+    policy of as many parts as cores (tools/delphy.cpp:130-132) on the same tree, and config C1 on a single thread."""
+    from delphy_amd.scenarios import make_scenario
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    n, moves, dt = _time_oracle(sc, num_parts, seed, target_seconds, t_step, cores, 2000)
+    out = {"value": n * moves / dt, "unit": "moves/s", "cores": cores, "kind": "port",
+           "sample": "GPU partition replayed on the CPU: same %d parts, %d moves per part = %.3g moves (%.1f s wall on %d host threads, after a 2000-move pilot); "
+                     "CPU restatement of Delphy's algorithm (oracle/), not Delphy itself" % (n, moves, n * moves, dt, cores)}
+    n2, moves2, dt2 = _time_oracle(sc, cores, seed, target_seconds, t_step, cores, 20000)
+    c1 = make_scenario("C1")
+    n3, moves3, dt3 = _time_oracle(c1, 1, seed, min(target_seconds, 5.0), c1.default_t_step(), 1, 20000)
+    out["policies"] = {
+        "parts_equal_cores": {"value": n2 * moves2 / dt2, "unit": "moves/s", "cores": cores,
+                              "sample": "reference policy num_parts = cores: same tree in %d parts, %d moves per part (%.1f s wall)" % (n2, moves2, dt2)},
+        "c1_single_thread": {"value": n3 * moves3 / dt3, "unit": "moves/s", "cores": 1,
+                             "sample": "config C1 (100 tips, 30 000 sites, one part), %d moves on one thread (%.1f s wall)" % (moves3, dt3)},
+    }
+    return out
+
+
+def inclusive_cycles(sc, args, cycles=3):
+    """Whole cycles through the host run driver (emat_run_do_mcmc_steps: repartition -> subtree build -> slab encode -> H2D
+    -> moves -> D2H -> decode -> reassemble), the reference's default 50 x nodes local moves per cycle (run.cpp:669-672).
+    Reported beside `value`, never as it."""
+    import delphy_amd as d
+    b = d.EmatBackend(sc.num_sites)
+    run = d.EmatRun(b, sc.tree, sc.ref, 20261001)
+    run.set_num_parts(args.parts)
+    run.set_max_part_nodes(args.max_part_nodes)
+    run.set_hky(sc.mu, sc.kappa, sc.pi)
+    run.set_pop_model(sc.pop)
+    per_cycle = 50 * sc.tree.num_nodes
+    run.do_mcmc_steps(per_cycle, per_cycle)          # warm-up cycle: allocations, first launch
+    t0 = time.perf_counter()
+    run.do_mcmc_steps(cycles * per_cycle, per_cycle)
+    dt = time.perf_counter() - t0
+    run.close(); b.close()
+    return {"value": cycles * per_cycle / dt, "unit": "moves/s", "cycles": cycles, "moves_per_cycle": per_cycle, "ms_per_cycle": dt / cycles * 1e3,
+            "what": "emat_run_do_mcmc_steps: host repartition + upload + %d local moves + download + reassemble per cycle (no global moves), wall clock" % per_cycle}
 
 
 def main():
@@ -104,8 +152,6 @@ def main():
     # The reference cuts the tree into as many parts as it has workers (tools/delphy.cpp:130-132); here a worker is a
     # wavefront slot, ~4 000 per GPU, so the request grows with the number of GPUs.  The tree is the same at every N
     # ("strong" scaling); the partitioner's minimum part size (10 branches) caps what a 100k-tip tree can yield.
-    if args.parts is None:
-        args.parts = min(8192 * world, 16384)   # this tree yields ~13 000 parts at most; asking for more only unbalances them
     allreduce = None
     if shared_gpu:
         def allreduce(arr, op):
@@ -157,12 +203,19 @@ def main():
     bytes_per_launch = (stats1["algorithmic_bytes"] - stats0["algorithmic_bytes"]) / max(1, launches)
     avg_ms = float(np.mean(ev_ms)) if ev_ms else float("nan")
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None
+    traffic, traffic_source = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    # the committed PMC figure was collected on the default single-GPU workload: only quote it for that one
+    # PMC counters cannot be read from inside this process: the figure comes from the committed rocprofv3 --pmc passes
+    # of this same command (scripts/profile.sh) and is stamped with the kernel build it was measured on; it is quoted
+    # only for the default single-GPU workload and only while the device code is the one that was profiled
     if os.path.exists(pmc_path) and world == 1 and args.workload == "C4" and args.tips is None and args.parts == 8192 and args.moves_per_part == 1000 and args.max_part_nodes == 0 and not (args.no_topology or args.only_displace or args.no_lds):
         try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            pm = json.load(open(pmc_path))
+            if pm.get("device_code_sha16") in (None, device_code_sha16()):
+                traffic = pm.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, device code %s)" % (pm.get("profile_dir", "pmc_latest.json"), pm.get("device_code_sha16", "unstamped"))
+            else:
+                traffic_source = "stale: profiles/pmc_latest.json was measured on device code %s, this is %s" % (pm.get("device_code_sha16"), device_code_sha16())
         except Exception:
             traffic = None
     bad = stats1["bad_parts"]
@@ -170,6 +223,9 @@ def main():
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_base = cpu_baseline(sc, args.parts, 20261001, args.cpu_seconds, eng.t_step)
+    inclusive = None
+    if rank == 0 and world == 1 and not args.no_inclusive:
+        inclusive = inclusive_cycles(sc, args)
 
     if rank == 0:
         out = {
@@ -193,9 +249,14 @@ def main():
                 "lds_staging": not args.no_lds,
                 "parallelism": "parts sharded over %d GPU(s), one wavefront per part" % world,
             },
+            # "bound" names the yardstick the contract asks for; "limiter" says what actually limits the kernel
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_source,
+                         "limiter": "instruction issue and LDS / L2 latency: a part's chain is serial and runs on one lane of its wavefront (the wave's other lanes "
+                                    "take part in slab staging and in the candidate scan + study of SPR moves); residency is capped by LDS at 16 parts per CU",
                          "kernel": "k_run_moves", "kernel_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
             "cpu_baseline": cpu_base,
+            "inclusive": inclusive,
             "check": {"log_G": log_G, "log_augmented_coalescent_prior": log_prior, "parts_stopped": bad},
         }
         print(json.dumps(out))

@@ -1261,20 +1261,236 @@ EMAT_D void wave_make_study(Ctx& c, Spr1Frame& fr, SVec<Region> regions) {
   __syncthreads();
 }
 
+// ---- the candidate scan, level by level ---------------------------------------------------------------------------------
+// study_seed_fill's local scan (at most one counted mutation crossed: 99 % of the scans) is a depth-first walk over the
+// tree of regions around the starting point; what a region contributes, and which neighbours it hands on to, depends only
+// on the region and on the state its pusher handed over.  So the walk is done breadth-first instead, one region per lane
+// and level (ballot + prefix popcount place each lane's up to three successors in the next level), and the depth-first
+// ORDER -- which the study's sums and the region pick depend on -- is restored afterwards: subtree sizes bottom-up, then
+// positions top-down (a region is followed by the subtree of its LAST-pushed successor first, as on a stack).  The
+// region list that comes out is the serial one entry for entry.
+struct alignas(16) ScanItem {
+  int branch, mut_idx, pb, w;            // target region, pusher's branch, pusher's (mut_idx & 0xffff) | crossings << 16 | delta-set size << 18; after processing: the item's own
+  int child_begin, nch_vis, sz, pos;     // successors [child_begin, child_begin + (nch_vis & 3)), visited flag in bit 8; subtree size; depth-first position
+};
+static_assert(sizeof(ScanItem) == 32, "ScanItem must be two 16-byte groups");
+
+EMAT_D bool wave_local_scan(Ctx& c, Spr1Frame& fr) {
+  const int lane = wave_lane();
+  const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int X = fr.X, root = hdr_of(c)->root;
+  SVec<IvRec> miss = fr.missing_at_X;
+  SVec<SdRec> del = fr.deltas;
+  if (del.n >= 8000) return false;
+  // the two sets every region is checked against go to the front of the move's LDS block
+  uint32_t front = 0;
+  if (fr.hot.p != nullptr) {
+    const uint32_t b_miss = ((uint32_t)miss.n * (uint32_t)sizeof(IvRec) + 15u) & ~15u, b_del = ((uint32_t)del.n * (uint32_t)sizeof(SdRec) + 15u) & ~15u;
+    if (b_miss + b_del + 512u <= fr.hot.bytes) {
+      IvRec* mi = (IvRec*)fr.hot.p; SdRec* di = (SdRec*)(fr.hot.p + b_miss);
+      for (int i = lane; i < miss.n; i += 64) mi[i] = miss.p[i];
+      for (int i = lane; i < del.n; i += 64) di[i] = del.p[i];
+      miss.p = mi; del.p = di; front = b_miss + b_del;
+      __syncthreads();
+    }
+  }
+  bool done = false;
+  ScanItem* items = nullptr; int* lvl = nullptr; int total = 0, nlev = 0;
+  uint8_t* hbm_lo = nullptr;   // lower end of the HBM span when the items sit at its top (regions then come from below)
+  for (int attempt = 0; attempt < 2 && !done; ++attempt) {
+    uint8_t* base; uint32_t bytes;
+    if (attempt == 0) {
+      if (fr.hot.p == nullptr || front == 0 || fr.hot.bytes - front < 24u * 36u) continue;
+      base = fr.hot.p + front; bytes = (fr.hot.bytes - front) & ~15u;
+    } else {
+      const uint32_t g0 = (c.sc_top + 15u) & ~15u, g1 = hdr_of(c)->scratch_end & ~15u;
+      if (g1 < g0 + 8192u) return false;
+      const uint32_t span = g1 - g0, skip = (span / 96u * 48u) & ~15u;   // regions (48 B each) below, items + levels (36 B each) above
+      base = c.G + g0 + skip; bytes = span - skip; hbm_lo = c.G + g0;
+    }
+    const int cap = (int)(bytes / 36u);
+    items = (ScanItem*)base; lvl = (int*)(base + (size_t)cap * sizeof(ScanItem));
+    if (lane == 0) { ScanItem it; it.branch = fr.init_branch; it.mut_idx = 0; it.pb = k_no_node; it.w = 0xffff | (0 << 16) | (del.n << 18); it.child_begin = 0; it.nch_vis = 0; it.sz = 0; it.pos = 0; items[0] = it; }
+    __syncthreads();
+    total = 1; nlev = 0;
+    int lo = 0, hi = 1; bool overflow = false;
+    while (lo < hi && !overflow) {
+      if (nlev >= cap) { overflow = true; break; }
+      if (lane == 0) lvl[nlev] = lo;
+      ++nlev;
+      int new_total = total;
+      for (int chunk = lo; chunk < hi && !overflow; chunk += 64) {
+        const int k = chunk + lane;
+        const bool act = k < hi;
+        int nch = 0, tb[3], tmi[3], branch = 0, mut_idx = 0, fs = 0, size = 0; bool visited = false;
+        if (act) {
+          const int4 a4 = *(const int4*)&items[k];
+          branch = a4.x; mut_idx = a4.y;
+          const int pb = a4.z, pmi = (int)(int16_t)(a4.w & 0xffff);
+          fs = (a4.w >> 16) & 3; size = (int)((uint32_t)a4.w >> 18);
+          // move_to_neighbor (spr_study.cpp:43-91)
+          if (pb != k_no_node && branch == pb) {
+            const MutRec* m = muts_of(c, branch);
+            const bool down = (mut_idx == pmi + 1);
+            if (!down && mut_idx != pmi - 1) EMAT_FAIL(c, k_part_internal);
+            const MutRec mm = m[down ? pmi : mut_idx];
+            if (!iv_contains(miss.p, miss.n, mm.site)) {
+              if (fs == 0) {
+                const int new_from = down ? (int)mm.to : (int)mm.from;
+                const int kk = sd_lower_bound(del.p, del.n, mm.site);
+                const bool present = kk < del.n && del.p[kk].site == mm.site;
+                size = del.n + (present ? (new_from == (int)del.p[kk].to ? -1 : 0) : +1);
+              }
+              fs += 1;
+            }
+          }
+          visited = !(branch == X || fs > 1);
+          if (visited) {   // seed_neighbors_except (spr_study.cpp:103-128), in push order
+            const int nm = nmuts(c, branch);
+            if (branch != root) {
+              if (mut_idx > 0) { if (!(branch == pb && mut_idx - 1 == pmi)) { tb[nch] = branch; tmi[nch] = mut_idx - 1; ++nch; } }
+              else { const int ub = nodes_of(c)[branch].parent, umi = nmuts(c, ub); if (!(ub == pb && umi == pmi)) { tb[nch] = ub; tmi[nch] = umi; ++nch; } }
+            }
+            if (mut_idx < nm) { if (!(branch == pb && mut_idx + 1 == pmi)) { tb[nch] = branch; tmi[nch] = mut_idx + 1; ++nch; } }
+            else if (!is_tip(c, branch)) {
+              const int c0 = nodes_of(c)[branch].child0, c1 = nodes_of(c)[branch].child1;
+              if (!(c0 == pb && 0 == pmi)) { tb[nch] = c0; tmi[nch] = 0; ++nch; }
+              if (!(c1 == pb && 0 == pmi)) { tb[nch] = c1; tmi[nch] = 0; ++nch; }
+            }
+          }
+        }
+        const uint64_t b0 = __ballot(act && (nch & 1)), b1 = __ballot(act && (nch & 2));
+        const int off = __popcll(b0 & below) + 2 * __popcll(b1 & below);
+        const int tot = __popcll(b0) + 2 * __popcll(b1);
+        if (new_total + tot > cap) { overflow = true; break; }
+        if (act) {
+          const int w_own = (mut_idx & 0xffff) | (fs << 16) | (size << 18);
+          for (int j = 0; j < nch; ++j) {
+            ScanItem* ch = &items[new_total + off + j];
+            *(int4*)ch = make_int4(tb[j], tmi[j], branch, w_own);
+            *((int4*)ch + 1) = make_int4(0, 0, 0, 0);
+          }
+          items[k].w = w_own;
+          *((int4*)&items[k] + 1) = make_int4(new_total + off, nch | (visited ? 256 : 0), 0, 0);
+        }
+        new_total += tot;
+      }
+      __syncthreads();
+      lo = hi; hi = new_total; total = new_total;
+    }
+    done = !overflow;
+  }
+  if (!done || c.failed) return false;
+  // subtree sizes, deepest level first
+  for (int l = nlev - 1; l >= 0; --l) {
+    const int lo = lvl[l], hi = l + 1 < nlev ? lvl[l + 1] : total;
+    for (int k = lo + lane; k < hi; k += 64) {
+      const int4 b4 = *((const int4*)&items[k] + 1);
+      int sz = 0;
+      if (b4.y & 256) { sz = 1; for (int j = 0; j < (b4.y & 3); ++j) sz += items[b4.x + j].sz; }
+      items[k].sz = sz;
+    }
+    __syncthreads();
+  }
+  // depth-first positions, top level first: a region, then its successors' subtrees from the last pushed to the first
+  for (int l = 0; l < nlev; ++l) {
+    const int lo = lvl[l], hi = l + 1 < nlev ? lvl[l + 1] : total;
+    for (int k = lo + lane; k < hi; k += 64) {
+      const int4 b4 = *((const int4*)&items[k] + 1);
+      if (!(b4.y & 256)) continue;
+      int running = b4.w + 1;
+      for (int j = (b4.y & 3) - 1; j >= 0; --j) { const int szc = items[b4.x + j].sz; if (szc > 0) { items[b4.x + j].pos = running; running += szc; } }
+    }
+    __syncthreads();
+  }
+  const int V = items[0].sz;
+  // the region records, in depth-first order
+  SVec<Region>* shared = &fr.study.regions;
+  if (lane == 0) {
+    SVec<Region> r; r.n = 0; r.cap = 0; r.p = nullptr;
+    if (hbm_lo != nullptr) {   // the items occupy the top of the HBM span: the regions take its bottom
+      if ((size_t)V * sizeof(Region) + 16 <= (size_t)((uint8_t*)items - hbm_lo)) { r.p = (Region*)hbm_lo; r.cap = V; c.sc_top = (uint32_t)(hbm_lo - c.G) + (((uint32_t)V * (uint32_t)sizeof(Region) + 15u) & ~15u); }
+      else EMAT_FAIL(c, k_part_overflow);
+    } else r = sc_vec<Region>(c, V);
+    *shared = r;
+  }
+  __syncthreads();
+  if (c.failed) return true;   // nothing more to do: the move is abandoned
+  Region* res = shared->p;
+  for (int k = lane; k < total; k += 64) {
+    const ScanItem it = items[k];
+    if (!(it.nch_vis & 256)) continue;
+    Region* r = &res[it.pos];
+    *(int4*)r = make_int4(it.branch, it.mut_idx, (int)((uint32_t)it.w >> 18), 0);
+    *(double2*)&r->t_min = make_double2(region_t_min(c, it.branch, it.mut_idx), region_t_max(c, it.branch, it.mut_idx));
+  }
+  __syncthreads();
+  // account_for_Xs_detachment (spr_study.cpp:130-209) and remove_regions_in_Xs_future (:211-224): one read-modify-compact
+  // pass, 64 regions at a time, the survivors keeping their order (ballot + prefix popcount)
+  int w = 0;
+  {
+    const bool can_change_root = fr.can_change_root;
+    const int P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
+    const int nGP = nmuts(c, P);
+    const int nS = (P == root) ? nmuts(c, S) : 0;
+    const double t_min_P_end = (P != root) ? region_t_min(c, P, nGP) : 0.0;
+    const double t_X = fr.t_X;
+    for (int chunk = 0; chunk < V; chunk += 64) {
+      const int i = chunk + lane;
+      bool keep = false; int4 head = make_int4(0, 0, 0, 0); double2 times = make_double2(0.0, 0.0);
+      if (i < V) {
+        head = *(const int4*)&res[i]; times = *(const double2*)&res[i].t_min;
+        int branch = head.x, mut_idx = head.y;
+        keep = true;
+        if (!can_change_root && branch == root) keep = false;
+        else if (branch == S || branch == P) {
+          if (P != root) {
+            if (branch == S) { if (mut_idx == 0) times.x = t_min_P_end; mut_idx += nGP; }
+            else { if (mut_idx == nGP) keep = false; else branch = S; }
+          } else {
+            if (!can_change_root) { if (branch == P) keep = false; }
+            else {
+              if (branch == S && mut_idx == nS) { mut_idx += nGP; times.x = k_neg_dbl_max; }
+              else keep = false;
+            }
+          }
+        }
+        if (keep) { if (times.x >= t_X) keep = false; else { if (times.y > t_X) times.y = t_X; head.x = branch; head.y = mut_idx; } }
+      }
+      const uint64_t m = __ballot(keep);
+      if (keep) { Region* r = &res[w + __popcll(m & below)]; *(int4*)r = head; *(double2*)&r->t_min = times; }
+      w += __popcll(m);
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    shared->n = w;
+    sc_trim(c, *shared);
+    c.bytes += (int64_t)(64 + 16) * V;
+  }
+  __syncthreads();
+  return true;
+}
+
 // The wave-wide part of an SPR1 move: candidate scan (study_seed_fill) and study of the regions it found.
 EMAT_DN void wave_scan_and_study(Ctx& c) {
   Spr1Frame& fr = *(Spr1Frame*)c.frame;
   const int lane = wave_lane();
   SVec<Region>* shared = &fr.study.regions;
-  if (lane == 0) {
-    EMAT_PHASE_BEGIN();
-    *shared = study_seed_fill(c, fr.X, fr.t_X, fr.missing_at_X, fr.limit, fr.init_branch, 0, fr.deltas, fr.can_change_root, fr.hot);
-    EMAT_PHASE(c, 6);
 #ifdef EMAT_PROFILE_PHASES
-    hdr_of(c)->phase_ticks[13] += shared->n;
+  const long long ph0 = clock64();
 #endif
+  bool scanned = false;
+#ifndef EMAT_SERIAL_SCAN
+  if (fr.limit == 1) scanned = wave_local_scan(c, fr);
+#endif
+  if (!scanned) {   // the 1 % of scans without a limit on the mutations crossed (and local ones that found no room): serial, on lane 0
+    if (lane == 0) *shared = study_seed_fill(c, fr.X, fr.t_X, fr.missing_at_X, fr.limit, fr.init_branch, 0, fr.deltas, fr.can_change_root, fr.hot);
+    __syncthreads();
   }
-  __syncthreads();
+#ifdef EMAT_PROFILE_PHASES
+  if (lane == 0) { hdr_of(c)->phase_ticks[6] += clock64() - ph0; hdr_of(c)->phase_ticks[13] += shared->n; }
+#endif
   const SVec<Region> regions = *shared;
   wave_make_study(c, fr, regions);
 }
