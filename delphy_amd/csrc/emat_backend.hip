@@ -108,8 +108,10 @@ __device__ inline const double* stage_tables(const KernelArgs& a, double* lds_ta
 #ifndef EMAT_WAVES_PER_EU
 #define EMAT_WAVES_PER_EU 4
 #endif
-// Room a part staged with an LDS-local heap limit (below) must have above its used heap to be worth staging whole.
-constexpr uint32_t k_lds_heap_room = 2048;
+// Room the list heap of an LDS-staged part keeps above its used size (measured at C4: 2048 -> 288, 1024 -> 296, 768 -> 287,
+// 512 -> 282 M moves/s: less room leaves more LDS to the moves' scratch arena, too little sends parts through heap
+// compactions and the HBM fall-back leg).
+constexpr uint32_t k_lds_heap_room = 1024;
 
 __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
   const int lane = threadIdx.x;
@@ -133,8 +135,11 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
     const uint32_t hbm_heap_end = gh->heap_end;
     uint32_t lds_heap_end = 0;
     if (can_stage && allow_whole) {
-      if (hbm_heap_end <= area) lds_heap_end = hbm_heap_end;
-      else if (gh->heap_top + k_lds_heap_room <= area) lds_heap_end = area & ~15u;
+      // the list heap keeps k_lds_heap_room bytes to grow into (or its whole capacity, if smaller); what is left of the
+      // area is the moves' LDS scratch arena -- without one, every temporary of an SPR move is an HBM round trip
+      const uint32_t want = (gh->heap_top + k_lds_heap_room + 15u) & ~15u;
+      if (hbm_heap_end <= area) lds_heap_end = hbm_heap_end < want ? hbm_heap_end : want;
+      else if (want <= area) lds_heap_end = want;
     }
     const bool staged = lds_heap_end != 0;
     const bool prefix = can_stage && !staged && gh->heap_begin <= area;
@@ -511,6 +516,11 @@ struct emat_backend {
                                                      // class always extends to the largest part (its staging area is still that percentile's size)
   uint32_t cfg_lds_max = 96 * 1024;                  // EMAT_LDS_MAX (tuning knob): largest staging area; larger parts run out of HBM
   bool order_valid = false;         // d_order holds the current parts, largest first
+  std::vector<int32_t> h_order;     // host copy of d_order
+  bool last_launch_uniform = false; // the last launch ran the same number of moves on every part (its durations are comparable)
+  bool cfg_order_by_time = false;   // EMAT_ORDER_BY_TIME (tuning knob): re-sort the launch order by measured durations at every synchronisation
+                                    // (measured at C4: 292 vs 296 M moves/s -- with two parts per slot the slot that ran the longest part
+                                    // still takes one more; off by default)
   bool pass_pending = false;        // a launch has not been checked for stopped parts yet (finish_pass)
   emat_status fatal_status = EMAT_OK;   // a part stopped INSIDE a move: its tree is untrustworthy, and every run / getter keeps
   std::string fatal_message;            // failing with this until the parts are uploaded afresh (emat_begin_upload)
@@ -718,6 +728,23 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
 // stops BEFORE a move with its state intact (status 101): it is given twice the room and the rest of its moves, up
 // to four times.  Any other status means an invariant broke inside a move; that is reported, loudly, and the caller
 // must not use the part's tree.
+// Launch order for the NEXT passes from the durations measured in the last one: within each size class, the part that
+// took longest goes first.  The dispatcher hands workgroups to free slots in index order, so this is longest-processing-
+// time-first list scheduling with real times instead of the size proxy (correlation 0.44 at C4); a chain's cost changes
+// slowly from pass to pass.  Called with the stream idle.
+emat_status refresh_order_from_ticks(emat_backend* h) {
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  const size_t n = h->parts.size();
+  if (!h->order_valid || n == 0 || !h->cfg_order_by_time) return EMAT_OK;
+  std::vector<int64_t> ticks(n);
+  HIP_TRY(hipMemcpy(ticks.data(), h->d_part_ticks.p, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+  std::vector<int32_t>& order = h->h_order;
+  for (int c = 0; c < h->num_classes; ++c)
+    std::stable_sort(order.begin() + h->class_begin[c], order.begin() + h->class_begin[c + 1], [&](int a, int b) { return ticks[a] > ticks[b]; });
+  HIP_TRY(h->d_order.upload(order.data(), order.size()));
+  return EMAT_OK;
+}
+
 emat_status finish_pass(emat_backend* h) {
   if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   if (h->fatal_status != EMAT_OK) return fail(h, h->fatal_status, h->fatal_message);
@@ -731,7 +758,7 @@ emat_status finish_pass(emat_backend* h) {
     h->pass_pending = false;
     size_t stopped = 0, fatal = n;
     for (size_t p = 0; p < n; ++p) if (status[p] != 0) { ++stopped; if (status[p] != k_part_need_space && fatal == n) fatal = p; }
-    if (stopped == 0) return EMAT_OK;
+    if (stopped == 0) { if (round == 0 && h->last_launch_uniform) (void)refresh_order_from_ticks(h); return EMAT_OK; }
     h->host_slabs_current = false; h->headers_current = false;
     emat_status st = pull_from_device(h); if (st) return st;
     if (fatal != n) {
@@ -951,6 +978,7 @@ emat_status build_order(emat_backend* h) {
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->persistent_bytes[a] > h->persistent_bytes[b]; });
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(h->d_order.upload(order.data(), order.size()));
+  h->h_order = order;
   h->order_valid = true;
   return EMAT_OK;
 }
@@ -973,6 +1001,7 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
   if (counts) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(h->d_moves_for_part.upload(counts->data(), counts->size())); a.moves_for_part = h->d_moves_for_part.p; }
   else for (size_t p = 0; p < h->parts.size(); ++p) h->parts[p].expected_moves += per_part + (p == 0 ? extra0 : 0);
   h->pass_pending = true;
+  h->last_launch_uniform = counts == nullptr;
   HIP_TRY(hipEventRecord(h->ev_start, h->stream));
   {
     const size_t sh_max = shmem_for(*std::max_element(h->class_lds, h->class_lds + h->num_classes));
@@ -1046,6 +1075,7 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   }
   if (const char* e = getenv("EMAT_LDS_MAX")) h->cfg_lds_max = (uint32_t)atoi(e) & ~511u;
   if (const char* e = getenv("EMAT_GIANTS")) h->cfg_giants = atoi(e) != 0;
+  if (const char* e = getenv("EMAT_ORDER_BY_TIME")) h->cfg_order_by_time = atoi(e) != 0;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return EMAT_ERR_HIP; h->num_cus = prop.multiProcessorCount; }
   if (hipStreamCreate(&h->stream) != hipSuccess) return EMAT_ERR_HIP;
   for (hipEvent_t* e : {&h->ev_start, &h->ev_stop}) if (hipEventCreate(e) != hipSuccess) return EMAT_ERR_HIP;

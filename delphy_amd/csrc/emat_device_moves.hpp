@@ -6,6 +6,9 @@
 namespace emat {
 namespace EMAT_DEV_NS {
 
+#ifndef EMAT_HOT_BYTES
+#define EMAT_HOT_BYTES 1536   // LDS block an SPR1 move sets aside for its candidate scans (sets searched per region, scan items, regions)
+#endif
 enum { k_inner_node_displace = 0, k_tip_displace = 1, k_branch_reform = 2, k_subtree_slide = 3, k_spr1 = 4 };
 
 EMAT_D void begin_move(Ctx& c, int kind) { hdr_of(c)->proposed[kind]++; c.tr_kind = (double)kind; c.tr_node = -1.0; c.tr_acc = 0.0; c.tr_log_mh = __builtin_nan(""); }
@@ -312,7 +315,7 @@ EMAT_DN void spr1_move_begin(Ctx& c) {
   c.frame = (uint8_t*)frp;
   fr.X = X; fr.t_X = nodes_of(c)[X].t; fr.P = P; fr.old_t_P = nodes_of(c)[P].t; fr.old_S = sibling_of(c, P, X); fr.old_G = nodes_of(c)[P].parent;
   fr.limit = limit; fr.f = 0.8 /* annealing factor */; fr.t_max_tip = c.t_max_tip; fr.can_change_root = c.includes_run_root;
-  fr.hot = (limit == 1) ? sc_reserve_hot(c, 1536) : HotBlock{nullptr, 0};
+  fr.hot = (limit == 1) ? sc_reserve_hot(c, EMAT_HOT_BYTES) : HotBlock{nullptr, 0};
   fr.old_graft = analyze_graft(c, X);
   peel_graft(c, fr.old_graft);
   EMAT_PHASE(c, 5);
