@@ -1248,6 +1248,10 @@ emat_status emat_run_moves_per_part(emat_backend* h, int64_t moves_per_part) {
   if (!h || moves_per_part < 0) return EMAT_ERR_INVALID_ARGUMENT;
   return launch_moves(h, moves_per_part, 0);
 }
+emat_status emat_run_moves_split(emat_backend* h, int64_t moves_per_part, int64_t extra_moves_part0) {
+  if (!h || moves_per_part < 0 || extra_moves_part0 < 0) return EMAT_ERR_INVALID_ARGUMENT;
+  return launch_moves(h, moves_per_part, extra_moves_part0);
+}
 emat_status emat_synchronize(emat_backend* h) {
   if (!h) return EMAT_ERR_INVALID_ARGUMENT;
   if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");

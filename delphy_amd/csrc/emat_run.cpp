@@ -117,6 +117,10 @@ struct RunDriver {
   int root_part = -1;
   uint64_t epoch = 0;
   bool parts_uploaded = false, model_pushed = false, coal_built = false;
+  // A run sharded over several processes (one GPU each): every process holds the whole tree and cuts it
+  // identically; the attached backend only gets the parts [part_lo, part_hi) (backend part id = part - part_lo).
+  int shard_rank = 0, shard_world = 1, part_lo = 0, part_hi = 0;
+  std::vector<uint64_t> part_epoch;   // epoch at which each part's subtree was last refreshed (downloaded or received)
 
   double t_max_tip() const { double t = -INFINITY; for (auto& n : tree.nodes) if (n.is_tip() && n.t_max > t) t = n.t_max; return t; }   // phylo_tree_calc.cpp:636-644
 
@@ -421,18 +425,93 @@ struct RunDriver {
     coal_built = true;
     return EMAT_OK;
   }
+  void shard_block(int n) {   // contiguous block of the parts for this process (sizes differ by at most one)
+    const int base = n / shard_world, rem = n % shard_world;
+    part_lo = shard_rank * base + std::min(shard_rank, rem);
+    part_hi = part_lo + base + (shard_rank < rem ? 1 : 0);
+  }
   emat_status upload_parts() {
     if (!backend) return EMAT_OK;
-    emat_status st = bk(emat_begin_upload(backend, (int)subtrees.size())); if (st) return st;
+    const int nloc = part_hi - part_lo;
+    if (nloc <= 0) return fail(EMAT_ERR_STATE, "this rank holds no parts: fewer parts than processes");
+    emat_status st = bk(emat_begin_upload(backend, nloc)); if (st) return st;
     std::atomic<int> bad{EMAT_OK};
-    parallel_for((int)subtrees.size(), [&](int p) {   // emat_part_upload is safe to call concurrently for distinct parts
+    parallel_for(nloc, [&](int q) {   // emat_part_upload is safe to call concurrently for distinct parts
+      const int p = part_lo + q;
       emat_flat_tree v = subtrees[p].view();
-      emat_status s1 = emat_part_upload(backend, p, &v, p == root_part ? 1 : 0, part_seeds[p]);
+      emat_status s1 = emat_part_upload(backend, q, &v, p == root_part ? 1 : 0, part_seeds[p]);
       if (s1 != EMAT_OK) bad.store(s1);
     });
     if (bad.load() != EMAT_OK) return bk((emat_status)bad.load());
     st = bk(emat_end_upload(backend)); if (st) return st;
     parts_uploaded = true;
+    return EMAT_OK;
+  }
+  // Bring the subtrees of the local parts up to date with the device.
+  emat_status download_local_parts() {
+    if (!(backend && parts_uploaded)) return EMAT_OK;
+    int32_t nn0, nm0, ni0, nf0;
+    emat_status st0 = bk(emat_part_get_sizes(backend, 0, &nn0, &nm0, &ni0, &nf0)); if (st0) return st0;   // one D2H of all slabs, before the threads start
+    std::atomic<int> bad{EMAT_OK};
+    parallel_for(part_hi - part_lo, [&](int q) {
+      int32_t nn, nm, ni, nf;
+      emat_status st = emat_part_get_sizes(backend, q, &nn, &nm, &ni, &nf); if (st) { bad.store(st); return; }
+      FlatTree f; f.allocate(nn, nm, ni, nf);
+      emat_flat_tree v = f.view();
+      st = emat_part_download(backend, q, &v); if (st) { bad.store(st); return; }
+      f.root = v.root;
+      subtrees[part_lo + q] = std::move(f);
+      part_epoch[part_lo + q] = epoch;
+    });
+    if (bad.load() != EMAT_OK) return bk((emat_status)bad.load());
+    return EMAT_OK;
+  }
+  // ---- exchange format of part subtrees between processes: per part {int32 id, nodes, muts, intervals, from_states, root, 0, 0}
+  //      followed by the FlatTree arrays, every array padded to 8 bytes -----------------------------------------------------
+  static uint64_t pad8(uint64_t x) { return (x + 7u) & ~(uint64_t)7u; }
+  static uint64_t packed_bytes(const FlatTree& t) {
+    const uint64_t n = t.num_nodes(), m = t.num_muts(), i = t.num_intervals(), f = t.num_from_states();
+    return 32 + 3 * pad8(4 * n) + 8 * n + 2 * pad8(4 * n) + 3 * pad8(4 * (n + 1)) + pad8(4 * m) + 2 * pad8(m) + 8 * m + 2 * pad8(4 * i) + pad8(4 * f) + pad8(f);
+  }
+  template <class T> static void put(uint8_t*& w, const std::vector<T>& v) { std::memcpy(w, v.data(), v.size() * sizeof(T)); w += pad8(v.size() * sizeof(T)); }
+  template <class T> static bool get(const uint8_t*& r, const uint8_t* end, std::vector<T>& v, size_t count) {
+    if ((uint64_t)(end - r) < pad8(count * sizeof(T))) return false;
+    v.resize(count); std::memcpy(v.data(), r, count * sizeof(T)); r += pad8(count * sizeof(T)); return true;
+  }
+  emat_status pack_local_parts(uint8_t* buf, uint64_t cap, uint64_t* needed) {
+    emat_status st = download_local_parts(); if (st) return st;
+    uint64_t tot = 0;
+    for (int p = part_lo; p < part_hi; ++p) tot += packed_bytes(subtrees[p]);
+    if (needed) *needed = tot;
+    if (!buf || cap < tot) return buf ? fail(EMAT_ERR_BUFFER_TOO_SMALL, "emat_run_pack_local_parts: buffer too small") : EMAT_OK;
+    uint8_t* w = buf;
+    for (int p = part_lo; p < part_hi; ++p) {
+      const FlatTree& t = subtrees[p];
+      int32_t hdr[8] = {p, t.num_nodes(), t.num_muts(), t.num_intervals(), t.num_from_states(), t.root, 0, 0};
+      std::memcpy(w, hdr, 32); w += 32;
+      put(w, t.parent); put(w, t.child0); put(w, t.child1); put(w, t.t); put(w, t.t_min); put(w, t.t_max);
+      put(w, t.mut_offset); put(w, t.mut_site); put(w, t.mut_from); put(w, t.mut_to); put(w, t.mut_t);
+      put(w, t.miss_offset); put(w, t.miss_start); put(w, t.miss_end); put(w, t.mfs_offset); put(w, t.mfs_site); put(w, t.mfs_state);
+    }
+    return EMAT_OK;
+  }
+  emat_status unpack_parts(const uint8_t* buf, uint64_t bytes) {
+    const uint8_t* r = buf; const uint8_t* end = buf + bytes;
+    while (r < end) {
+      if (end - r < 32) return fail(EMAT_ERR_INVALID_ARGUMENT, "emat_run_unpack_parts: truncated part header");
+      int32_t hdr[8]; std::memcpy(hdr, r, 32); r += 32;
+      const int p = hdr[0]; const size_t n = (size_t)hdr[1], m = (size_t)hdr[2], i = (size_t)hdr[3], f = (size_t)hdr[4];
+      if (p < 0 || p >= (int)subtrees.size() || hdr[1] != (int)parts[p].orig.size() || hdr[2] < 0 || hdr[3] < 0 || hdr[4] < 0) return fail(EMAT_ERR_INVALID_ARGUMENT, "emat_run_unpack_parts: part does not belong to the current partition");
+      FlatTree t; t.root = hdr[5];
+      bool ok = get(r, end, t.parent, n) && get(r, end, t.child0, n) && get(r, end, t.child1, n) && get(r, end, t.t, n) && get(r, end, t.t_min, n) && get(r, end, t.t_max, n)
+             && get(r, end, t.mut_offset, n + 1) && get(r, end, t.mut_site, m) && get(r, end, t.mut_from, m) && get(r, end, t.mut_to, m) && get(r, end, t.mut_t, m)
+             && get(r, end, t.miss_offset, n + 1) && get(r, end, t.miss_start, i) && get(r, end, t.miss_end, i) && get(r, end, t.mfs_offset, n + 1) && get(r, end, t.mfs_site, f) && get(r, end, t.mfs_state, f);
+      if (!ok) return fail(EMAT_ERR_INVALID_ARGUMENT, "emat_run_unpack_parts: truncated part");
+      emat_flat_tree v = t.view();
+      if (!validate_flat_tree(v, L).empty()) return fail(EMAT_ERR_INVALID_ARGUMENT, "emat_run_unpack_parts: part " + std::to_string(p) + " is not a valid tree");
+      subtrees[p] = std::move(t);
+      part_epoch[p] = epoch;
+    }
     return EMAT_OK;
   }
 
@@ -461,13 +540,16 @@ struct RunDriver {
       t3 = now();
     } catch (const std::exception& ex) { return fail(EMAT_ERR_INTERNAL, ex.what()); }
     parts_uploaded = false; coal_built = false;
+    shard_block((int)subtrees.size());
+    part_epoch.assign(subtrees.size(), 0);
     if (backend) {
       emat_status st;
       if (!model_pushed) { st = push_model(); if (st) return st; }
       t4 = now();
       st = upload_parts(); if (st) return st;
       t5 = now();
-      st = build_coalescent(); if (st) return st;
+      // a sharded run builds the coalescent parts in stages, with all-reduces the caller owns in between (emat_run_coalescent_begin)
+      if (shard_world == 1) { st = build_coalescent(); if (st) return st; }
     }
     if (verbose) fprintf(stderr, "[emat_run] repartition: stencils %.1f ms | partition_tree + normalize_root %.1f ms | build_subtrees %.1f ms | push_model %.1f ms | upload_parts %.1f ms | build_coalescent %.1f ms\n",
                          ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, now()));
@@ -480,22 +562,11 @@ struct RunDriver {
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     auto t0 = now(), t1 = t0, t2 = t0;
     try {
-      if (backend && parts_uploaded) {
-        int32_t nn0, nm0, ni0, nf0;
-        emat_status st0 = bk(emat_part_get_sizes(backend, 0, &nn0, &nm0, &ni0, &nf0)); if (st0) return st0;   // one D2H of all slabs, before the threads start
-        t1 = now();
-        std::atomic<int> bad{EMAT_OK};
-        parallel_for((int)subtrees.size(), [&](int p) {
-          int32_t nn, nm, ni, nf;
-          emat_status st = emat_part_get_sizes(backend, p, &nn, &nm, &ni, &nf); if (st) { bad.store(st); return; }
-          FlatTree f; f.allocate(nn, nm, ni, nf);
-          emat_flat_tree v = f.view();
-          st = emat_part_download(backend, p, &v); if (st) { bad.store(st); return; }
-          f.root = v.root;
-          subtrees[p] = std::move(f);
-        });
-        if (bad.load() != EMAT_OK) return bk((emat_status)bad.load());
-      }
+      if (backend && parts_uploaded) { emat_status st0 = download_local_parts(); if (st0) return st0; }
+      t1 = now();
+      if (shard_world > 1 && backend)
+        for (size_t p = 0; p < subtrees.size(); ++p)
+          if (part_epoch[p] != epoch) return fail(EMAT_ERR_STATE, "part " + std::to_string(p) + " of another rank was not received this cycle (emat_run_unpack_parts)");
       t2 = now();
       for (size_t p = 0; p < subtrees.size(); ++p) if ((size_t)subtrees[p].num_nodes() != parts[p].orig.size()) return fail(EMAT_ERR_INTERNAL, "subtree size changed");
       // Every node of the whole tree is a non-root node of exactly one part (the run's root: the root of the root part),
@@ -632,9 +703,51 @@ emat_status emat_run_moves(emat_run* r, int64_t count) {
   return r->d.bk(emat_run_local_moves(r->d.backend, count));
 }
 emat_status emat_run_reassemble(emat_run* r) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; return r->d.reassemble(); }
+
+emat_status emat_run_set_shard(emat_run* r, int32_t rank, int32_t world) {
+  if (!r || world < 1 || rank < 0 || rank >= world) return EMAT_ERR_INVALID_ARGUMENT;
+  r->d.shard_rank = rank; r->d.shard_world = world; r->d.parts_uploaded = false;
+  return EMAT_OK;
+}
+emat_status emat_run_shard_range(emat_run* r, int32_t* part_lo, int32_t* part_hi, int32_t* local_root_part) {
+  if (!r) return EMAT_ERR_INVALID_ARGUMENT;
+  if (part_lo) *part_lo = r->d.part_lo;
+  if (part_hi) *part_hi = r->d.part_hi;
+  if (local_root_part) *local_root_part = (r->d.root_part >= r->d.part_lo && r->d.root_part < r->d.part_hi) ? r->d.root_part - r->d.part_lo : -1;
+  return EMAT_OK;
+}
+emat_status emat_run_coalescent_begin(emat_run* r, double* local_t_min, double* local_t_max) {
+  if (!r || !local_t_min || !local_t_max) return EMAT_ERR_INVALID_ARGUMENT;
+  RunDriver& d = r->d;
+  if (!d.backend) return d.fail(EMAT_ERR_NO_DEVICE, "no backend attached");
+  if (!d.parts_uploaded) return d.fail(EMAT_ERR_STATE, "repartition first");
+  if (!d.have_pop) return d.fail(EMAT_ERR_STATE, "emat_run_set_pop_model must be called first");
+  emat_pop_model pm = d.pop; pm.skygrid_x = d.sky_x.data(); pm.skygrid_gamma = d.sky_g.data();
+  const int local_root = (d.root_part >= d.part_lo && d.root_part < d.part_hi) ? d.root_part - d.part_lo : -1;
+  emat_status st = d.bk(emat_coalescent_begin(d.backend, &pm, local_root, d.t_step_set ? d.t_step : d.default_t_step(), local_t_min, local_t_max));
+  if (st == EMAT_OK) d.coal_built = true;   // the caller finishes the stages on the backend
+  return st;
+}
+emat_status emat_run_moves_sharded(emat_run* r, int64_t count) {   // Run::run_local_moves (run.cpp:682-693) over ALL parts of the run
+  if (!r || count < 0) return EMAT_ERR_INVALID_ARGUMENT;
+  RunDriver& d = r->d;
+  if (!d.backend) return d.fail(EMAT_ERR_NO_DEVICE, "no backend attached: the host driver never runs moves itself");
+  if (!d.parts_uploaded) return d.fail(EMAT_ERR_STATE, "repartition first");
+  const int64_t P = (int64_t)d.subtrees.size(), sub = count / P, rem = count - P * sub;
+  return d.bk(emat_run_moves_split(d.backend, sub, d.part_lo == 0 ? rem : 0));   // the remainder goes to part 0 of the run
+}
+emat_status emat_run_pack_local_parts(emat_run* r, uint8_t* buf, uint64_t capacity, uint64_t* bytes_needed) {
+  if (!r) return EMAT_ERR_INVALID_ARGUMENT;
+  try { return r->d.pack_local_parts(buf, capacity, bytes_needed); } catch (const std::exception& ex) { return r->d.fail(EMAT_ERR_INTERNAL, ex.what()); }
+}
+emat_status emat_run_unpack_parts(emat_run* r, const uint8_t* buf, uint64_t bytes) {
+  if (!r || (!buf && bytes)) return EMAT_ERR_INVALID_ARGUMENT;
+  try { return r->d.unpack_parts(buf, bytes); } catch (const std::exception& ex) { return r->d.fail(EMAT_ERR_INTERNAL, ex.what()); }
+}
 emat_status emat_run_do_mcmc_steps(emat_run* r, int64_t steps, int64_t per_cycle) {   // run.cpp:622-657 minus global moves
   if (!r || steps < 0) return EMAT_ERR_INVALID_ARGUMENT;
   if (!r->d.backend) return r->d.fail(EMAT_ERR_NO_DEVICE, "no backend attached");
+  if (r->d.shard_world > 1) return r->d.fail(EMAT_ERR_STATE, "a sharded run is cycled by its caller, who owns the collectives (see emat_host.h)");
   if (per_cycle <= 0) per_cycle = 50 * (int64_t)r->d.tree.nodes.size();
   int64_t done = 0;
   while (done < steps) {

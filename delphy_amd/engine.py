@@ -251,6 +251,9 @@ def load_library():
         "emat_run_repartition": [R], "emat_run_num_parts": [R, P(i32), P(i32)],
         "emat_run_part_sizes": [R, i32, P(i32), P(i32), P(i32), P(i32)], "emat_run_part_get": [R, i32, P(_FlatTreeC), P(i32), P(u64)],
         "emat_run_part_put": [R, i32, P(_FlatTreeC)], "emat_run_push_params": [R], "emat_run_moves": [R, i64], "emat_run_reassemble": [R],
+        "emat_run_set_shard": [R, i32, i32], "emat_run_shard_range": [R, P(i32), P(i32), P(i32)], "emat_run_coalescent_begin": [R, P(dbl), P(dbl)],
+        "emat_run_moves_sharded": [R, i64], "emat_run_pack_local_parts": [R, P(C.c_uint8), u64, P(u64)], "emat_run_unpack_parts": [R, P(C.c_uint8), u64],
+        "emat_run_moves_split": [B, i64, i64],
         "emat_run_do_mcmc_steps": [R, i64, i64], "emat_run_tree_sizes": [R, P(i32), P(i32), P(i32), P(i32)],
         "emat_run_tree_get": [R, P(_FlatTreeC), P(C.c_uint8)], "emat_run_t_max_tip": [R, P(dbl)],
     }
@@ -406,6 +409,9 @@ class EmatBackend:
 
     def run_local_moves(self, count: int):
         self._ck(self._lib.emat_run_local_moves(self._h, count), "emat_run_local_moves")
+
+    def run_moves_split(self, moves_per_part: int, extra_moves_part0: int):
+        self._ck(self._lib.emat_run_moves_split(self._h, moves_per_part, extra_moves_part0), "emat_run_moves_split")
 
     def run_moves_per_part(self, moves: int):
         self._ck(self._lib.emat_run_moves_per_part(self._h, moves), "emat_run_moves_per_part")
@@ -594,6 +600,34 @@ class EmatRun:
 
     def reassemble(self):
         self._ck(self._lib.emat_run_reassemble(self._h), "emat_run_reassemble")
+
+    # ---- a run sharded over several processes (include/emat_host.h) ----
+    def set_shard(self, rank: int, world: int):
+        self._ck(self._lib.emat_run_set_shard(self._h, rank, world), "emat_run_set_shard")
+
+    def shard_range(self):
+        lo, hi, lr = C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._lib.emat_run_shard_range(self._h, C.byref(lo), C.byref(hi), C.byref(lr)), "emat_run_shard_range")
+        return lo.value, hi.value, lr.value
+
+    def coalescent_begin(self):
+        lo, hi = C.c_double(), C.c_double()
+        self._ck(self._lib.emat_run_coalescent_begin(self._h, C.byref(lo), C.byref(hi)), "emat_run_coalescent_begin")
+        return lo.value, hi.value
+
+    def run_moves_sharded(self, count: int):
+        self._ck(self._lib.emat_run_moves_sharded(self._h, count), "emat_run_moves_sharded")
+
+    def pack_local_parts(self) -> np.ndarray:
+        need = C.c_uint64()
+        self._ck(self._lib.emat_run_pack_local_parts(self._h, None, 0, C.byref(need)), "emat_run_pack_local_parts")
+        buf = np.zeros(int(need.value), np.uint8)
+        self._ck(self._lib.emat_run_pack_local_parts(self._h, _ptr(buf, C.c_uint8), buf.shape[0], C.byref(need)), "emat_run_pack_local_parts")
+        return buf
+
+    def unpack_parts(self, buf: np.ndarray):
+        buf = np.ascontiguousarray(buf, np.uint8)
+        self._ck(self._lib.emat_run_unpack_parts(self._h, _ptr(buf, C.c_uint8), buf.shape[0]), "emat_run_unpack_parts")
 
     def do_mcmc_steps(self, steps: int, local_moves_per_cycle: int = -1):
         self._ck(self._lib.emat_run_do_mcmc_steps(self._h, steps, local_moves_per_cycle), "emat_run_do_mcmc_steps")

@@ -1,16 +1,22 @@
-"""Sharding of a partitioned EMAT over the GPUs of one node.
+"""One EMAT run sharded over the GPUs of a node: one process per GPU.
 
-One process per GPU.  Every rank partitions the (deterministic, seeded) tree identically with the host
-driver, keeps a contiguous block of the parts, and runs them on its own GPU.  Parts are independent between
-`repartition` and `reassemble` (reference core/run.cpp:682-693), so the data path has no collective; the only
-exchanges are the tiny all-reduces of the augmented coalescent grid when the parts are (re)built
-(reference core/very_scalable_coalescent.cpp:153-219) and of the two log-posterior totals
-(reference core/run.cpp:340-348).  `allreduce` is injected so that the same code runs over RCCL
-(bench.py, backend "nccl") and over gloo in the CPU tests.
+Every rank holds the whole tree and the same host driver state (include/emat_host.h), cuts the tree identically, and keeps
+a contiguous block of the parts on its own GPU.  Between `repartition` and `reassemble` the parts are independent
+(reference core/run.cpp:682-693), so the data path has no collective.  Per cycle the ranks exchange:
+
+  * the three tiny reductions of the augmented coalescent grid when the parts are (re)built
+    (reference core/very_scalable_coalescent.cpp:153-219): MIN / MAX of the time range, SUM of k_bar, SUM of k_twiddle_bar;
+  * the parts themselves on the way back (reference Run::reassemble needs every part's tree, run.cpp:195-256): one
+    all-gather of the serialised local parts, after which every rank reassembles the same whole tree;
+  * SUM of the two log-posterior totals (reference run.cpp:340-348).
+
+All of the run logic is behind the C-ABI (emat_run_set_shard, _coalescent_begin, _moves_sharded, _pack_local_parts,
+_unpack_parts, _reassemble); this module only owns the collectives, which are injected (`allreduce`, `allgather_bytes`)
+so that the same code runs over RCCL (bench.py: backend "nccl") and over gloo in the CPU tests.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional
+from typing import Callable, List, Optional
 
 import numpy as np
 
@@ -19,13 +25,13 @@ from .scenarios import Scenario
 
 
 def block_range(num_items: int, rank: int, world: int):
-    """Contiguous block of `num_items` owned by `rank` (sizes differ by at most one)."""
+    """Contiguous block of `num_items` owned by `rank` (sizes differ by at most one); the rule of emat_run_set_shard."""
     base, rem = divmod(num_items, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _torch_allreduce(device: str):
+def _torch_collectives(device: str):
     import torch
     import torch.distributed as dist
 
@@ -33,19 +39,36 @@ def _torch_allreduce(device: str):
         t = torch.from_numpy(np.ascontiguousarray(arr)).to(device)
         dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op])
         return t.cpu().numpy()
-    return allreduce
+
+    def allgather_bytes(buf: np.ndarray) -> List[np.ndarray]:
+        world = dist.get_world_size()
+        sizes = torch.tensor([buf.shape[0]], dtype=torch.int64, device=device)
+        all_sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes)
+        n = [int(s.item()) for s in all_sizes]
+        padded = torch.zeros(max(n), dtype=torch.uint8, device=device)
+        padded[: buf.shape[0]] = torch.from_numpy(buf).to(device)
+        out = [torch.zeros(max(n), dtype=torch.uint8, device=device) for _ in range(world)]
+        dist.all_gather(out, padded)
+        return [o[: n[r]].cpu().numpy() for r, o in enumerate(out)]
+    return allreduce, allgather_bytes
 
 
 class ShardedEngine:
     def __init__(self, sc: Scenario, num_parts: int, seed: int, rank: int = 0, world: int = 1, device: int = 0, use_lds: bool = True,
                  allreduce: Optional[Callable[[np.ndarray, str], np.ndarray]] = None, trace_moves: int = 0, t_step: Optional[float] = None,
-                 max_part_nodes: int = 0):
+                 max_part_nodes: int = 0, allgather_bytes: Optional[Callable[[np.ndarray], List[np.ndarray]]] = None):
         self.sc, self.num_parts_requested, self.seed, self.rank, self.world = sc, num_parts, seed, rank, world
         self.t_step = t_step if t_step is not None else sc.default_t_step()
-        if allreduce is None:
-            allreduce = (lambda a, op: a) if world == 1 else _torch_allreduce("cuda:%d" % device)
-        self.allreduce = allreduce
+        if world == 1:
+            allreduce = allreduce or (lambda a, op: a)
+            allgather_bytes = allgather_bytes or (lambda b: [b])
+        elif allreduce is None or allgather_bytes is None:
+            ar, ag = _torch_collectives("cuda:%d" % device)
+            allreduce, allgather_bytes = allreduce or ar, allgather_bytes or ag
+        self.allreduce, self.allgather_bytes = allreduce, allgather_bytes
         self.backend = EmatBackend(sc.num_sites, device=device, use_lds=use_lds, trace_moves=trace_moves)
+        self.run = EmatRun(self.backend, sc.tree, sc.ref, seed)
         self.total_parts = 0
         self.num_local_parts = 0
         self.part_lo = self.part_hi = 0
@@ -53,39 +76,44 @@ class ShardedEngine:
         self.topology = True
         self.only_displace = False
         self.max_part_nodes = max_part_nodes   # not in the reference: cut larger parts further (0 = the reference's rule)
+        self._configured = False
 
     def close(self):
+        self.run.close()
         self.backend.close()
 
-    def setup(self):
-        sc = self.sc
-        run = EmatRun(None, sc.tree, sc.ref, self.seed)   # host-only driver: same partition on every rank
+    def _configure(self):
+        sc, run = self.sc, self.run
         run.set_num_parts(self.num_parts_requested)
         run.set_max_part_nodes(self.max_part_nodes)
-        run.repartition()
-        n, root_part = run.num_parts()
-        self.total_parts, self.root_part = n, root_part
-        self.part_lo, self.part_hi = block_range(n, self.rank, self.world)
-        parts, incl, seeds = [], [], []
-        for i in range(self.part_lo, self.part_hi):
-            t, r, s = run.part(i)
-            parts.append(t); incl.append(r); seeds.append(s)
-        _, ref = run.tree()
-        run.close()
-        self.num_local_parts = len(parts)
-        self.local_sizes = [p.num_nodes for p in parts]
-        b = self.backend
-        b.set_ref_sequence(ref)
-        b.set_hky(sc.mu, sc.kappa, sc.pi, sc.nu_l)
-        b.set_flags(sc.t_max_tip, self.only_displace, self.topology)
-        b.upload_parts(parts, incl, seeds)
+        run.set_hky(sc.mu, sc.kappa, sc.pi, sc.nu_l)
+        run.set_pop_model(sc.pop)
+        run.set_coalescent_t_step(self.t_step)
+        run.set_flags(self.only_displace, self.topology)
+        run.set_shard(self.rank, self.world)
+        self._configured = True
+
+    def repartition(self):
+        """Cut the tree (identically on every rank), upload this rank's parts, build their coalescent parts across ranks."""
+        if not self._configured:
+            self._configure()
+        self.run.repartition()
+        self.total_parts, self.root_part = self.run.num_parts()
+        self.part_lo, self.part_hi, self.local_root = self.run.shard_range()
+        self.num_local_parts = self.part_hi - self.part_lo
         self.build_coalescent()
+
+    def setup(self):
+        """First cut + upload (what bench.py and the probes call before timing resident passes)."""
+        self.repartition()
+        self.local_sizes = [self.run.part(self.part_lo + p)[0].num_nodes for p in range(self.num_local_parts)]
 
     def build_coalescent(self):
         """very_scalable_coalescent.cpp:85-232 with its three cross-part reductions done as all-reduces."""
         b = self.backend
-        local_root = self.root_part - self.part_lo if self.part_lo <= self.root_part < self.part_hi else -1
-        lo, hi = b.coalescent_begin(self.sc.pop, local_root, self.t_step)
+        if self.world == 1:
+            return   # emat_run_repartition built them in one go
+        lo, hi = self.run.coalescent_begin()
         lo = float(self.allreduce(np.array([lo]), "min")[0])
         hi = float(self.allreduce(np.array([hi]), "max")[0])
         b.coalescent_set_range(lo, hi)
@@ -95,6 +123,25 @@ class ShardedEngine:
         k_tw = b.coalescent_sample(k_bar, num_active)
         k_tw = self.allreduce(k_tw, "sum")
         b.coalescent_finish(k_tw)
+
+    def reassemble(self):
+        """Every rank receives every other rank's parts and gathers the same whole tree (reference run.cpp:195-256)."""
+        if self.world > 1:
+            mine = self.run.pack_local_parts()
+            for r, buf in enumerate(self.allgather_bytes(mine)):
+                if r != self.rank:
+                    self.run.unpack_parts(buf)
+        self.run.reassemble()
+
+    def cycle(self, local_moves: int):
+        """One cycle of reference Run::do_mcmc_steps without its global moves (run.cpp:622-657)."""
+        self.repartition()
+        self.run.run_moves_sharded(local_moves)
+        self.reassemble()
+        return self.global_totals()
+
+    def tree(self):
+        return self.run.tree()
 
     def local_stats(self):
         tot = dict(algorithmic_bytes=0, moves_done=0, bad_parts=0, proposed=[0] * 5, accepted=[0] * 5)
@@ -120,3 +167,13 @@ class ShardedEngine:
         g, a = self.backend.totals()
         v = self.allreduce(np.array([g, a]), "sum")
         return float(v[0]), float(v[1])
+
+    def scalable_coalescent_log_prior(self, t_ref: float):
+        """Whole-tree grid prior (reference Run::calc_cur_log_coalescent_prior) from parts spread over the ranks."""
+        b = self.backend
+        _, _, first = b.scalable_coalescent_partial(t_ref, self.t_step, 0, 0)
+        first = int(self.allreduce(np.array([first], np.int64), "min")[0])
+        kb, logs, _ = b.scalable_coalescent_partial(t_ref, self.t_step, first, -first)
+        kb = self.allreduce(kb, "sum")
+        logs = float(self.allreduce(np.array([logs]), "sum")[0])
+        return b.scalable_coalescent_log_prior_from_grid(t_ref, self.t_step, first, kb, logs)

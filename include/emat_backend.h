@@ -160,6 +160,9 @@ emat_status emat_coalescent_finish(emat_backend* h, const double* k_twiddle_bar 
 emat_status emat_run_local_moves(emat_backend* h, int64_t count);
 /* Same, with an explicit number of moves per part (all parts the same). */
 emat_status emat_run_moves_per_part(emat_backend* h, int64_t moves_per_part);
+/* Same, plus `extra_moves_part0` more on this handle's part 0: the split of Run::run_local_moves when the run's parts are
+ * spread over several handles (the handle holding the run's part 0 gets the remainder). */
+emat_status emat_run_moves_split(emat_backend* h, int64_t moves_per_part, int64_t extra_moves_part0);
 /* Waits for the launches issued so far and checks that every part ran its chain to completion.  A part that ran out of
  * list-heap or scratch space stops BEFORE a move with its state intact; it is re-materialised with twice the room and
  * the rest of its moves run, transparently (up to four doublings, then EMAT_ERR_CAPACITY).  A part that stopped INSIDE

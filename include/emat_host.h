@@ -83,6 +83,29 @@ emat_status emat_run_push_params(emat_run* r);
 emat_status emat_run_moves(emat_run* r, int64_t count);
 /* Gather the parts back into the whole tree; with a backend attached the parts are downloaded first. */
 emat_status emat_run_reassemble(emat_run* r);
+/* ---- one run over several processes, one GPU each ---------------------------------------------------
+ * Every process creates the same run (same tree, same seed) with its own backend and calls emat_run_set_shard once.
+ * The partition is then computed identically everywhere, but a process uploads only its contiguous block of parts
+ * (emat_run_shard_range; backend part id = part - part_lo).  One cycle (reference run.cpp:622-657) is
+ *
+ *   emat_run_repartition                                     every rank, no communication
+ *   emat_run_coalescent_begin -> all-reduce MIN / MAX        the staged form of emat_build_coalescent_parts
+ *   emat_coalescent_set_range / _local_grid -> all-reduce SUM / _sample -> all-reduce SUM / _finish   (on the backend)
+ *   emat_run_moves_sharded(count)                            count / parts moves on every part of the run, remainder on part 0
+ *   emat_run_pack_local_parts -> all-gather of the byte buffers -> emat_run_unpack_parts for every other rank's buffer
+ *   emat_run_reassemble                                      every rank ends up with the same whole tree
+ *   emat_get_totals on the backend -> all-reduce SUM (2 doubles)
+ *
+ * The collectives (RCCL over xGMI, or gloo in tests) belong to the caller: delphy_amd/sharding.py drives them through
+ * torch.distributed.  emat_run_do_mcmc_steps is the single-process cycle and refuses a sharded run. */
+emat_status emat_run_set_shard(emat_run* r, int32_t rank, int32_t world);
+emat_status emat_run_shard_range(emat_run* r, int32_t* part_lo, int32_t* part_hi, int32_t* local_root_part /* -1: the root part lives on another rank */);
+emat_status emat_run_coalescent_begin(emat_run* r, double* local_t_min, double* local_t_max);
+emat_status emat_run_moves_sharded(emat_run* r, int64_t count);
+/* Serialises this rank's parts as they are on its device now.  Call with buf = NULL to learn the size. */
+emat_status emat_run_pack_local_parts(emat_run* r, uint8_t* buf, uint64_t capacity, uint64_t* bytes_needed);
+emat_status emat_run_unpack_parts(emat_run* r, const uint8_t* buf, uint64_t bytes);
+
 /* repartition -> [push params, local moves, reassemble] per cycle of `local_moves_per_cycle` moves
  * (<= 0: 50 x nodes, the reference default run.cpp:669-672), repartitioning at every cycle boundary. */
 emat_status emat_run_do_mcmc_steps(emat_run* r, int64_t steps, int64_t local_moves_per_cycle);

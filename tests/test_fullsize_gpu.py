@@ -6,6 +6,8 @@
   * the same seed gives bit-identical results twice, and the LDS-staged and HBM-resident paths agree bit for bit;
   * the whole cycle repartition -> moves -> reassemble through the host driver keeps the full tree valid.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -161,3 +163,61 @@ def test_c5_one_gpu_sampled_trajectories_and_whole_run_properties():
         assert rel_close(G_inc, G_re, 1e-9) and rel_close(A_inc, A_re, 1e-9), (G_inc, G_re, A_inc, A_re)
     finally:
         gpu.close(); orc.close()
+
+
+def _sharded_gpu_worker(rank, world, port, out_dir, cycles, moves):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # two ranks share cuda:0 here, which RCCL refuses: the collectives go over gloo
+    from test_sharding_gloo import gloo_collectives, _tree_fields
+    allreduce, allgather_bytes = gloo_collectives()
+    sc = make_scenario("C3", num_tips=1500, num_sites=29903, uncertain_tips=0.1)
+    eng = ShardedEngine(sc, num_parts=48, seed=97, rank=rank, world=world, device=0, allreduce=allreduce, allgather_bytes=allgather_bytes)
+    res = {}
+    for cyc in range(cycles):
+        G, A = eng.cycle(moves)
+        res["c%d_totals" % cyc] = np.array([G, A])
+    t, ref = eng.tree()
+    for k, v in _tree_fields(t).items():
+        res[k] = v
+    res["root"] = np.array([t.root]); res["ref"] = ref
+    tips = t.child0 == -1
+    res["grid_prior"] = np.array([eng.scalable_coalescent_log_prior(float(np.max(t.t[tips])))])
+    np.savez(os.path.join(out_dir, "gpu_rank%d.npz" % rank), **res)
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_two_process_cycles_on_one_gpu_match_the_single_process_run(tmp_path):
+    """The multi-rank control flow with real moves: two processes (sharing the one GPU of the test box, collectives over
+    gloo) run three cycles repartition -> staged coalescent build -> moves on their own parts -> exchange of the parts ->
+    reassemble.  Both ranks must end with the same tree, and it must be the tree a single process computes: the chains
+    are per part and seeded per part, so sharding changes nothing but the association of two cross-rank sums."""
+    import torch.multiprocessing as mp
+    from test_sharding_gloo import _tree_fields
+    cycles, moves = 3, 48 * 400
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_sharded_gpu_worker, args=(2, port, str(tmp_path), cycles, moves), nprocs=2, join=True)
+    z = [np.load(os.path.join(str(tmp_path), "gpu_rank%d.npz" % r)) for r in range(2)]
+    sc = make_scenario("C3", num_tips=1500, num_sites=29903, uncertain_tips=0.1)
+    single = ShardedEngine(sc, num_parts=48, seed=97)
+    tot = [single.cycle(moves) for _ in range(cycles)]
+    t, ref = single.tree()
+    tips = t.child0 == -1
+    grid = single.scalable_coalescent_log_prior(float(np.max(t.t[tips])))
+    for r in range(2):
+        assert int(z[r]["root"][0]) == t.root and np.array_equal(z[r]["ref"], ref)
+        for k, v in _tree_fields(t).items():
+            if k in ("t", "mut_t"):
+                fin = np.abs(v) < 1e300
+                assert np.array_equal(fin, np.abs(z[r][k]) < 1e300) and rel_close(z[r][k][fin], v[fin], 1e-9), (r, k)
+            else:
+                assert np.array_equal(z[r][k], v), (r, k)
+        for cyc in range(cycles):
+            assert rel_close(z[r]["c%d_totals" % cyc], np.array(tot[cyc]), 1e-9), (r, cyc, z[r]["c%d_totals" % cyc], tot[cyc])
+        assert rel_close(z[r]["grid_prior"], np.array([grid]), 1e-9)
+    for k in _tree_fields(t):
+        assert np.array_equal(z[0][k], z[1][k]), k       # the two ranks hold bit-identical trees
+    single.close()
