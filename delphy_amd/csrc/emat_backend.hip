@@ -198,13 +198,20 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
       if (staged) {
         H->heap_end = hbm_heap_end;
         if (H->status == k_part_need_space && lds_heap_end < hbm_heap_end && H->heap_top <= hbm_heap_end) { H->status = 0; a.part_status[part] = 0; again = 1; }
+        // A list outgrew the LDS-local heap limit INSIDE a move: the staged state is lost, but nothing of this leg has
+        // reached the HBM copy of the slab yet (moves only write HBM scratch), and the chain is a deterministic function
+        // of that copy.  Drop the LDS state and run the leg again from HBM with the heap at its full capacity there.
+        else if (H->status == k_part_overflow && lds_heap_end < hbm_heap_end) { a.part_status[part] = 0; again = 2; }
       }
       *lds_flag = again;
     }
     __syncthreads();
-    if (staged) wave_copy16(gslab, lds_slab, ((const SlabHeader*)lds_slab)->heap_top, lane);
-    else if (prefix) wave_copy16(gslab, lds_slab, staged_bytes, lane);
-    if (*lds_flag == 0) break;
+    const int again_all = *lds_flag;
+    if (again_all != 2) {
+      if (staged) wave_copy16(gslab, lds_slab, ((const SlabHeader*)lds_slab)->heap_top, lane);
+      else if (prefix) wave_copy16(gslab, lds_slab, staged_bytes, lane);
+    }
+    if (again_all == 0) break;
     allow_whole = false;
   }
 }
@@ -382,6 +389,72 @@ __global__ void __launch_bounds__(k_wave) k_num_muts_l(KernelArgs a, int32_t* ou
   }
 }
 
+// ---- calc_Ttwiddle_l (phylo_tree_calc.cpp:176-222) over a partitioned tree ----------------------------------------------
+// The reference starts every site at q_ref T_total and corrects it per mutation / missation with the branch length BELOW
+// that point -- a quantity that crosses part boundaries.  A part gets, for every tip that is the cut node of a part below
+// it, the total branch length hanging there (`ext`; the run driver computes it from k_part_lengths' sums and the tree of
+// parts); with that its nodes' "length below" follow from one post-order pass, and the corrections are local again:
+//   S[site]   += (q_to - q_from) T_below(mutation)                      and  (q_ref - q_from) T_below(branch) per from_state
+//   D[start]  += T_below(branch),  D[end] -= T_below(branch)            per missing interval (the host's prefix sum over D
+//                                                                       is R[l], and Ttwiddle_l = q_ref (T_total - R) + S)
+// A part's root is skipped unless it is the run's root: a cut node's own branch belongs to the part above it.
+__global__ void __launch_bounds__(k_wave) k_part_lengths(KernelArgs a, double* out) {
+  const int part = blockIdx.x, lane = threadIdx.x;
+  const uint8_t* slab = a.slabs + a.slab_off[part];
+  const SlabHeader* H = (const SlabHeader*)slab; const NodeRec* N = (const NodeRec*)(slab + H->off_nodes);
+  double acc = 0.0;
+  for (int i = lane; i < H->n_nodes; i += k_wave) if (i != H->root) acc += N[i].t - N[N[i].parent].t;
+  acc = wave_sum(acc);
+  if (lane == 0) out[part] = acc;
+}
+__global__ void __launch_bounds__(k_wave) k_ttwiddle_l(KernelArgs a, const int32_t* ext_off, const int32_t* ext_node, const double* ext_val, double* S, double* D, double* t_root_out) {
+  __shared__ __attribute__((aligned(16))) double lds_tables[k_lds_tables_bytes / 8];
+  const int part = blockIdx.x, lane = threadIdx.x;
+  uint8_t* slab = a.slabs + a.slab_off[part];
+  const double* tables = stage_tables(a, lds_tables, lane);
+  __syncthreads();
+  dev::Ctx c;
+  init_ctx(c, slab, slab, a, tables);
+  const int n = c.H->n_nodes, root = c.H->root;
+  double* Tw = (double*)(slab + c.H->scratch_begin);   // [n]: total branch length of the WHOLE tree below each node
+  for (int i = lane; i < n; i += k_wave) Tw[i] = 0.0;
+  __syncthreads();
+  for (int k = ext_off[part] + lane; k < ext_off[part + 1]; k += k_wave) Tw[ext_node[k]] = ext_val[k];
+  __syncthreads();
+  if (lane == 0) {   // children before parents, without a stack
+    int cur = root, from = dev::k_no_node;   // `from`: the node we arrived from (parent on the way down, a child on the way up)
+    while (cur != dev::k_no_node) {
+      const int par = c.N[cur].parent;
+      int next;
+      if (from == par && !dev::is_tip(c, cur)) next = c.N[cur].child0;
+      else if (!dev::is_tip(c, cur) && from == c.N[cur].child0) next = c.N[cur].child1;
+      else {   // a tip, or both children done: the node is complete
+        if (cur != root) Tw[par] += (c.N[cur].t - c.N[par].t) + Tw[cur];
+        next = cur == root ? dev::k_no_node : par;
+      }
+      from = cur; cur = next;
+    }
+    if (c.includes_run_root && t_root_out) *t_root_out = Tw[root];
+  }
+  __syncthreads();
+  for (int i = lane; i < n; i += k_wave) {
+    if (i == root && !c.includes_run_root) continue;
+    const bool top = i == root;
+    const double t_i = c.N[i].t, below = Tw[i];
+    const MutRec* m = dev::muts_of(c, i);
+    for (int j = 0; j < dev::nmuts(c, i); ++j) {
+      const int l = m[j].site;
+      const double T_below_mut = below + (top ? 0.0 : t_i - m[j].t);
+      atomicAdd(&S[l], (dev::q_a(c, l, m[j].to) - dev::q_a(c, l, m[j].from)) * T_below_mut);
+    }
+    const double T_below_miss = below + (top ? 0.0 : t_i - c.N[c.N[i].parent].t);
+    const IvRec* iv = dev::miss_of(c, i);
+    for (int j = 0; j < (int)c.N[i].miss.cnt; ++j) { atomicAdd(&D[iv[j].start], T_below_miss); atomicAdd(&D[iv[j].end], -T_below_miss); }
+    const FsRec* fs = dev::mfs_of(c, i);
+    for (int j = 0; j < (int)c.N[i].mfs.cnt; ++j) { const int l = fs[j].site; atomicAdd(&S[l], (dev::q_a(c, l, c.ref[l]) - dev::q_a(c, l, fs[j].state)) * T_below_miss); }
+  }
+}
+
 // ---- Scalable_coalescent_prior (scalable_coalescent.cpp:88-138, 163-187), one part per workgroup ----------------------
 // The whole-tree grid prior is -sum_cells dt kbar (kbar - 1) / (2 Nbar) - sum_inner log N(t), where kbar_j, the mean number
 // of lineages in cell j = [t_ref + j dt, t_ref + (j + 1) dt), j < 0, is 1 (the lineage above the root) plus, for every
@@ -438,6 +511,21 @@ __global__ void __launch_bounds__(k_wave) k_scalable_prior(KernelArgs a, double 
 __global__ void k_debug_gamma(const double* a, const double* x, double* out, int n, int mode) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = mode == 0 ? dev::gamma_q(a[i], x[i]) : dev::gamma_q_inv(a[i], x[i]);
+}
+
+// ---- test hooks: the device's population-model and interval-set routines on plain inputs (emat_debug_pop, _interval_op) --
+__global__ void k_debug_pop(PopTable pt, int op, const double* a, const double* b, double* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = op == 0 ? dev::pop_at_time(pt, a[i]) : dev::pop_integral(pt, a[i], b[i]);
+}
+__global__ void k_debug_interval_op(int op, const IvRec* A, int nA, const IvRec* B, int nB, int site, IvRec* out, int* n_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (op == 1) *n_out = dev::iv_merge(out, A, nA, B, nB);
+  else if (op == 2) *n_out = dev::iv_intersect(out, A, nA, B, nB);
+  else if (op == 3) *n_out = dev::iv_subtract(out, A, nA, B, nB);
+  else if (op == 5) *n_out = dev::iv_contains(A, nA, site) ? 1 : 0;
+  else if (op == 6) *n_out = dev::iv_intersects(A, nA, B, nB) ? 1 : 0;
+  else *n_out = -1;
 }
 
 // =================================================================================================
@@ -1416,6 +1504,68 @@ emat_status emat_get_num_muts_l(emat_backend* h, int32_t* num_muts_l) {
   return EMAT_OK;
 }
 
+/* calc_Ttwiddle_l on the device (header: emat_get_part_tree_lengths / emat_Ttwiddle_l_partial / emat_Ttwiddle_l_finish) */
+emat_status emat_get_part_tree_lengths(emat_backend* h, double* tree_length_of_part) {
+  if (!h || !tree_length_of_part) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  emat_status st = sync_model_to_device(h); if (st) return st;
+  st = materialize(h); if (st) return st;
+  if (h->pass_pending) { st = finish_pass(h); if (st) return st; }
+  const size_t n = h->parts.size();
+  DevBuf<double> d_out; HIP_TRY(d_out.alloc(n));
+  KernelArgs a = make_args(h);
+  hipLaunchKernelGGL(k_part_lengths, dim3((unsigned)n), dim3(k_wave), 0, h->stream, a, d_out.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(tree_length_of_part, d_out.p, n * sizeof(double), hipMemcpyDeviceToHost));
+  return EMAT_OK;
+}
+emat_status emat_Ttwiddle_l_partial(emat_backend* h, const int32_t* ext_offset, const int32_t* ext_node, const double* ext_length,
+                                    double* S, double* R, double* tree_length_below_root) {
+  if (!h || !ext_offset || !S || !R) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  emat_status st = sync_model_to_device(h); if (st) return st;
+  st = materialize(h); if (st) return st;
+  if (h->pass_pending) { st = finish_pass(h); if (st) return st; }
+  const size_t n = h->parts.size(); const size_t L = (size_t)h->L;
+  const int32_t n_ext = ext_offset[n];
+  if (n_ext < 0 || (n_ext > 0 && (!ext_node || !ext_length))) return EMAT_ERR_INVALID_ARGUMENT;
+  for (size_t p = 0; p < n; ++p) {
+    if (ext_offset[p] > ext_offset[p + 1]) return EMAT_ERR_INVALID_ARGUMENT;
+    for (int32_t k = ext_offset[p]; k < ext_offset[p + 1]; ++k) if (ext_node[k] < 0 || ext_node[k] >= h->parts[p].tree.num_nodes()) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "ext_node out of range");
+    const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + h->parts[p].slab_off);
+    if ((uint64_t)h->parts[p].tree.num_nodes() * 8u > (uint64_t)h->parts[p].slab_bytes - H->scratch_begin) return fail(h, EMAT_ERR_CAPACITY, "scratch region too small for the length table");
+  }
+  DevBuf<int32_t> d_off, d_node; DevBuf<double> d_val, d_S, d_D, d_T;
+  HIP_TRY(d_off.upload(ext_offset, n + 1)); HIP_TRY(d_node.upload(ext_node, (size_t)n_ext)); HIP_TRY(d_val.upload(ext_length, (size_t)n_ext));
+  HIP_TRY(d_S.alloc(L)); HIP_TRY(d_D.alloc(L + 1)); HIP_TRY(d_T.alloc(1));
+  HIP_TRY(hipMemsetAsync(d_S.p, 0, L * sizeof(double), h->stream)); HIP_TRY(hipMemsetAsync(d_D.p, 0, (L + 1) * sizeof(double), h->stream)); HIP_TRY(hipMemsetAsync(d_T.p, 0, sizeof(double), h->stream));
+  KernelArgs a = make_args(h);
+  hipLaunchKernelGGL(k_ttwiddle_l, dim3((unsigned)n), dim3(k_wave), 0, h->stream, a, d_off.p, d_node.p, d_val.p, d_S.p, d_D.p, d_T.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::vector<double> D(L + 1);
+  HIP_TRY(hipMemcpy(S, d_S.p, L * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(D.data(), d_D.p, (L + 1) * sizeof(double), hipMemcpyDeviceToHost));
+  double run = 0.0;
+  for (size_t l = 0; l < L; ++l) { run += D[l]; R[l] = run; }
+  if (tree_length_below_root && h->root_part >= 0) HIP_TRY(hipMemcpy(tree_length_below_root, d_T.p, sizeof(double), hipMemcpyDeviceToHost));
+  return EMAT_OK;
+}
+emat_status emat_Ttwiddle_l_finish(emat_backend* h, const double* S_sum, const double* R_sum, double tree_length, double* Ttwiddle_l) {
+  if (!h || !S_sum || !R_sum || !Ttwiddle_l) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!h->have_ref || !h->have_evo) return fail(h, EMAT_ERR_STATE, "set_ref_sequence and set_evo first");
+  for (int l = 0; l < h->L; ++l) {
+    const double q_ref = -h->q[(size_t)h->partition_for_site[l] * 16 + (size_t)h->ref[l] * 5];   // q^(l)_a of the reference state
+    Ttwiddle_l[l] = q_ref * (tree_length - R_sum[l]) + S_sum[l];
+  }
+  return EMAT_OK;
+}
+
 /* Scalable_coalescent_prior on the device (header: emat_scalable_coalescent_partial / _log_prior / emat_get_scalable_coalescent_log_prior) */
 emat_status emat_scalable_coalescent_partial(emat_backend* h, double t_ref, double t_step, int32_t first_cell, int32_t num_cells,
                                              double* k_bar_partial, double* sum_neg_log_pop, int32_t* first_cell_needed) {
@@ -1505,6 +1655,46 @@ emat_status emat_debug_gamma(emat_backend* h, int32_t mode, int32_t n, const dou
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return EMAT_OK;
+}
+/* test hooks (header: emat_debug_pop, emat_debug_interval_op) */
+emat_status emat_debug_pop(emat_backend* h, const emat_pop_model* pm, int32_t op, int32_t n, const double* a, const double* b, double* out) {
+  if (!h || !pm || n < 0 || (op != 0 && op != 1) || (n > 0 && (!a || !b || !out))) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
+  if (n == 0) return EMAT_OK;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  HostPopModel hp;
+  try { hp = HostPopModel::from_c(*pm); } catch (const std::exception& ex) { return fail(h, EMAT_ERR_INVALID_ARGUMENT, ex.what()); }
+  DevBuf<double> dx, dg, da, db, dout;
+  HIP_TRY(dx.upload(hp.x.data(), hp.x.size())); HIP_TRY(dg.upload(hp.gamma.data(), hp.gamma.size()));
+  HIP_TRY(da.upload(a, (size_t)n)); HIP_TRY(db.upload(b, (size_t)n)); HIP_TRY(dout.alloc((size_t)n));
+  PopTable pt{};
+  pt.kind = hp.kind; pt.skygrid_type = hp.skygrid_type; pt.skygrid_num_knots = (int)hp.x.size();
+  for (int i = 0; i < 4; ++i) pt.p[i] = hp.p[i];
+  pt.t_c = hp.t_c; pt.skygrid_x = dx.p; pt.skygrid_gamma = dg.p;
+  pt.skygrid_inv_dx = (hp.x.size() >= 2 && hp.x.back() > hp.x.front()) ? (double)(hp.x.size() - 1) / (hp.x.back() - hp.x.front()) : 0.0;
+  hipLaunchKernelGGL(k_debug_pop, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, pt, (int)op, da.p, db.p, dout.p, (int)n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return EMAT_OK;
+}
+emat_status emat_debug_interval_op(emat_backend* h, int32_t op, const int32_t* a, int32_t na, const int32_t* b, int32_t nb, int32_t* out, int32_t* n_out) {
+  if (!h || !n_out || na < 0 || nb < 0 || (na > 0 && !a) || (nb > 0 && !b) || !out) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  DevBuf<IvRec> dA, dB, dO; DevBuf<int> dn;
+  HIP_TRY(dA.upload((const IvRec*)a, (size_t)na)); HIP_TRY(dB.upload((const IvRec*)b, (size_t)(op == 5 ? 0 : nb))); HIP_TRY(dO.alloc((size_t)(na + nb + 1))); HIP_TRY(dn.alloc(1));
+  hipLaunchKernelGGL(k_debug_interval_op, dim3(1), dim3(64), 0, h->stream, (int)op, dA.p, (int)na, dB.p, (int)(op == 5 ? 0 : nb), op == 5 && nb > 0 ? b[0] : 0, dO.p, dn.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  int cnt = 0;
+  HIP_TRY(hipMemcpy(&cnt, dn.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (cnt < 0) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_debug_interval_op: unknown op");
+  *n_out = cnt;
+  if (op <= 3 && cnt > 0) HIP_TRY(hipMemcpy(out, dO.p, (size_t)cnt * sizeof(IvRec), hipMemcpyDeviceToHost));
   return EMAT_OK;
 }
 /* debugging aid (not part of the boundary): how many parts the next launch runs with each code variant

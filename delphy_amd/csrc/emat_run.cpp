@@ -736,6 +736,55 @@ emat_status emat_run_moves_sharded(emat_run* r, int64_t count) {   // Run::run_l
   const int64_t P = (int64_t)d.subtrees.size(), sub = count / P, rem = count - P * sub;
   return d.bk(emat_run_moves_split(d.backend, sub, d.part_lo == 0 ? rem : 0));   // the remainder goes to part 0 of the run
 }
+// For calc_Ttwiddle_l: the whole-tree branch length hanging below every boundary tip of the LOCAL parts, from the lengths
+// inside every part of the run and the tree of parts (a part's boundary tips are the cut nodes of the parts below it).
+emat_status emat_run_Ttwiddle_ext(emat_run* r, const double* tree_length_of_part, int32_t* ext_offset, int32_t* ext_node, double* ext_length, int32_t capacity, int32_t* count) {
+  if (!r || !tree_length_of_part || !ext_offset || !count || capacity < 0 || (capacity > 0 && (!ext_node || !ext_length))) return EMAT_ERR_INVALID_ARGUMENT;
+  RunDriver& d = r->d;
+  const int P = (int)d.subtrees.size();
+  if (P == 0) return d.fail(EMAT_ERR_STATE, "repartition first");
+  std::vector<int32_t> part_of_cut(d.tree.nodes.size(), -1);
+  for (int p = 0; p < P; ++p) part_of_cut[d.parts[p].cut_point] = p;
+  // children of each part in the tree of parts: (subtree node, part below)
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> kids(P);
+  for (int p = 0; p < P; ++p) {
+    const FlatTree& st = d.subtrees[p];
+    for (int s = 0; s < st.num_nodes(); ++s) if (st.is_tip(s) && s != st.root) { const int q = part_of_cut[d.parts[p].orig[s]]; if (q >= 0 && q != p) kids[p].push_back({s, q}); }
+  }
+  // total length below each part's cut node: its own branches plus everything below its boundary tips (children first)
+  std::vector<double> below(P, -1.0);
+  std::vector<std::pair<int, size_t>> stack; stack.push_back({d.root_part, 0});
+  while (!stack.empty()) {
+    auto& [p, k] = stack.back();
+    if (k < kids[p].size()) { const int q = kids[p][k].second; ++k; stack.push_back({q, 0}); }
+    else { double t = tree_length_of_part[p]; for (auto& kv : kids[p]) t += below[kv.second]; below[p] = t; stack.pop_back(); }
+  }
+  int32_t n = 0;
+  for (int p = d.part_lo; p < d.part_hi; ++p) {
+    ext_offset[p - d.part_lo] = n;
+    for (auto& kv : kids[p]) { if (n < capacity) { ext_node[n] = kv.first; ext_length[n] = below[kv.second]; } ++n; }
+  }
+  ext_offset[d.part_hi - d.part_lo] = n;
+  *count = n;
+  return n <= capacity ? EMAT_OK : d.fail(EMAT_ERR_BUFFER_TOO_SMALL, "emat_run_Ttwiddle_ext: arrays too small");
+}
+// calc_Ttwiddle_l of the whole tree from the parts on the device (single process).
+emat_status emat_run_get_Ttwiddle_l(emat_run* r, double* Ttwiddle_l) {
+  if (!r || !Ttwiddle_l) return EMAT_ERR_INVALID_ARGUMENT;
+  RunDriver& d = r->d;
+  if (!d.backend) return d.fail(EMAT_ERR_NO_DEVICE, "no backend attached");
+  if (!d.parts_uploaded) return d.fail(EMAT_ERR_STATE, "repartition first");
+  if (d.shard_world > 1) return d.fail(EMAT_ERR_STATE, "a sharded run gathers the part lengths and sums S, R across ranks itself (see emat_backend.h)");
+  const int P = (int)d.subtrees.size();
+  std::vector<double> len(P);
+  emat_status st = d.bk(emat_get_part_tree_lengths(d.backend, len.data())); if (st) return st;
+  std::vector<int32_t> off(P + 1), node(P); std::vector<double> val(P); int32_t cnt = 0;
+  st = emat_run_Ttwiddle_ext(r, len.data(), off.data(), node.data(), val.data(), P, &cnt); if (st) return st;
+  std::vector<double> S(d.L), R(d.L); double T = 0.0;
+  st = d.bk(emat_Ttwiddle_l_partial(d.backend, off.data(), node.data(), val.data(), S.data(), R.data(), &T)); if (st) return st;
+  return d.bk(emat_Ttwiddle_l_finish(d.backend, S.data(), R.data(), T, Ttwiddle_l));
+}
+
 emat_status emat_run_pack_local_parts(emat_run* r, uint8_t* buf, uint64_t capacity, uint64_t* bytes_needed) {
   if (!r) return EMAT_ERR_INVALID_ARGUMENT;
   try { return r->d.pack_local_parts(buf, capacity, bytes_needed); } catch (const std::exception& ex) { return r->d.fail(EMAT_ERR_INTERNAL, ex.what()); }

@@ -241,6 +241,7 @@ def load_library():
         "emat_part_get_stats": [B, i32, P(_PartStatsC)], "emat_part_get_trace": [B, i32, P(i32), P(dbl)],
         "emat_last_run_ms": [B, P(dbl)], "emat_last_kernel_ms": [B, P(dbl), P(i32)],
         "emat_debug_gamma": [B, i32, i32, P(dbl), P(dbl), P(dbl)],
+        "emat_debug_pop": [B, P(_PopModelC), i32, i32, P(dbl), P(dbl), P(dbl)], "emat_debug_interval_op": [B, i32, P(i32), i32, P(i32), i32, P(i32), P(i32)],
         "emat_get_num_muts_l": [B, P(i32)], "emat_get_scalable_coalescent_log_prior": [B, dbl, dbl, P(dbl)],
         "emat_scalable_coalescent_partial": [B, dbl, dbl, i32, i32, P(dbl), P(dbl), P(i32)],
         "emat_scalable_coalescent_log_prior": [B, dbl, dbl, i32, i32, P(dbl), dbl, P(dbl)],
@@ -253,7 +254,9 @@ def load_library():
         "emat_run_part_put": [R, i32, P(_FlatTreeC)], "emat_run_push_params": [R], "emat_run_moves": [R, i64], "emat_run_reassemble": [R],
         "emat_run_set_shard": [R, i32, i32], "emat_run_shard_range": [R, P(i32), P(i32), P(i32)], "emat_run_coalescent_begin": [R, P(dbl), P(dbl)],
         "emat_run_moves_sharded": [R, i64], "emat_run_pack_local_parts": [R, P(C.c_uint8), u64, P(u64)], "emat_run_unpack_parts": [R, P(C.c_uint8), u64],
-        "emat_run_moves_split": [B, i64, i64],
+        "emat_run_moves_split": [B, i64, i64], "emat_run_get_Ttwiddle_l": [R, P(dbl)], "emat_run_Ttwiddle_ext": [R, P(dbl), P(i32), P(i32), P(dbl), i32, P(i32)],
+        "emat_get_part_tree_lengths": [B, P(dbl)], "emat_Ttwiddle_l_partial": [B, P(i32), P(i32), P(dbl), P(dbl), P(dbl), P(dbl)],
+        "emat_Ttwiddle_l_finish": [B, P(dbl), P(dbl), dbl, P(dbl)],
         "emat_run_do_mcmc_steps": [R, i64, i64], "emat_run_tree_sizes": [R, P(i32), P(i32), P(i32), P(i32)],
         "emat_run_tree_get": [R, P(_FlatTreeC), P(C.c_uint8)], "emat_run_t_max_tip": [R, P(dbl)],
     }
@@ -456,6 +459,26 @@ class EmatBackend:
         self._ck(self._lib.emat_get_scalable_coalescent_log_prior(self._h, t_ref, t_step, C.byref(v)), "emat_get_scalable_coalescent_log_prior")
         return float(v.value)
 
+    def part_tree_lengths(self, num_parts: int) -> np.ndarray:
+        out = np.zeros(num_parts)
+        self._ck(self._lib.emat_get_part_tree_lengths(self._h, out.ctypes.data_as(C.POINTER(C.c_double))), "emat_get_part_tree_lengths")
+        return out
+
+    def Ttwiddle_l_partial(self, ext_offset, ext_node, ext_length):
+        """(S, R, total tree length if this handle holds the run's root else 0) over the parts of this handle."""
+        off = np.ascontiguousarray(ext_offset, np.int32); node = np.ascontiguousarray(ext_node, np.int32); val = np.ascontiguousarray(ext_length, np.float64)
+        if node.shape[0] == 0:
+            node = np.zeros(1, np.int32); val = np.zeros(1)
+        S = np.zeros(self.num_sites); Rv = np.zeros(self.num_sites); T = C.c_double(0.0); dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int32)
+        self._ck(self._lib.emat_Ttwiddle_l_partial(self._h, off.ctypes.data_as(ip), node.ctypes.data_as(ip), val.ctypes.data_as(dp), S.ctypes.data_as(dp), Rv.ctypes.data_as(dp), C.byref(T)),
+                 "emat_Ttwiddle_l_partial")
+        return S, Rv, float(T.value)
+
+    def Ttwiddle_l_finish(self, S, R, tree_length: float) -> np.ndarray:
+        S = np.ascontiguousarray(S, np.float64); R = np.ascontiguousarray(R, np.float64); out = np.zeros(self.num_sites); dp = C.POINTER(C.c_double)
+        self._ck(self._lib.emat_Ttwiddle_l_finish(self._h, S.ctypes.data_as(dp), R.ctypes.data_as(dp), tree_length, out.ctypes.data_as(dp)), "emat_Ttwiddle_l_finish")
+        return out
+
     def scalable_coalescent_partial(self, t_ref: float, t_step: float, first_cell: int, num_cells: int):
         """(partial k_bar grid over [first_cell, first_cell + num_cells), sum of -log N(t) over inner nodes, first cell needed)."""
         kb = np.zeros(max(num_cells, 1)); logs = C.c_double(); need = C.c_int32()
@@ -468,6 +491,21 @@ class EmatBackend:
         self._ck(self._lib.emat_scalable_coalescent_log_prior(self._h, t_ref, t_step, first_cell, kb.shape[0], kb.ctypes.data_as(C.POINTER(C.c_double)), sum_neg_log_pop, C.byref(v)),
                  "emat_scalable_coalescent_log_prior")
         return float(v.value)
+
+    def debug_pop(self, pop: PopModel, op: int, a, b) -> np.ndarray:
+        """Test hook: the device's pop_at_time (op 0) / pop_integral (op 1), point by point."""
+        a = np.ascontiguousarray(a, np.float64); b = np.ascontiguousarray(b, np.float64); out = np.zeros_like(a)
+        m = pop.c_struct(); dp = C.POINTER(C.c_double)
+        self._ck(self._lib.emat_debug_pop(self._h, C.byref(m), op, a.shape[0], a.ctypes.data_as(dp), b.ctypes.data_as(dp), out.ctypes.data_as(dp)), "emat_debug_pop")
+        return out
+
+    def debug_interval_op(self, op: int, a, b):
+        """Test hook: the device's interval-set algebra; sets as lists of [start, end)."""
+        A = np.ascontiguousarray(np.asarray(a, np.int32).reshape(-1, 2)); Bv = np.ascontiguousarray(np.asarray(b, np.int32).reshape(-1))
+        nb = Bv.shape[0] if op == 5 else Bv.shape[0] // 2
+        out = np.zeros((A.shape[0] + nb + 1, 2), np.int32); n = C.c_int32(); ip = C.POINTER(C.c_int32)
+        self._ck(self._lib.emat_debug_interval_op(self._h, op, A.ctypes.data_as(ip), A.shape[0], Bv.ctypes.data_as(ip), nb, out.ctypes.data_as(ip), C.byref(n)), "emat_debug_interval_op")
+        return out[: n.value].tolist() if op <= 3 else bool(n.value)
 
     def debug_gamma(self, mode: int, a, x_or_q) -> np.ndarray:
         """Test hook: the device's gamma_q (mode 0) / gamma_q_inv (mode 1), point by point."""
@@ -600,6 +638,21 @@ class EmatRun:
 
     def reassemble(self):
         self._ck(self._lib.emat_run_reassemble(self._h), "emat_run_reassemble")
+
+    def Ttwiddle_l(self) -> np.ndarray:
+        """calc_Ttwiddle_l of the whole tree, computed from the parts on the device (single process)."""
+        out = np.zeros(self.num_sites)
+        self._ck(self._lib.emat_run_get_Ttwiddle_l(self._h, out.ctypes.data_as(C.POINTER(C.c_double))), "emat_run_get_Ttwiddle_l")
+        return out
+
+    def Ttwiddle_ext(self, tree_length_of_part: np.ndarray, num_local_parts: int):
+        """(ext_offset, ext_node, ext_length) of this rank's parts for emat_Ttwiddle_l_partial."""
+        tl = np.ascontiguousarray(tree_length_of_part, np.float64)
+        cap = tl.shape[0] + 1
+        off = np.zeros(num_local_parts + 1, np.int32); node = np.zeros(cap, np.int32); val = np.zeros(cap); cnt = C.c_int32()
+        self._ck(self._lib.emat_run_Ttwiddle_ext(self._h, tl.ctypes.data_as(C.POINTER(C.c_double)), off.ctypes.data_as(C.POINTER(C.c_int32)), node.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                 val.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(cnt)), "emat_run_Ttwiddle_ext")
+        return off, node[: cnt.value], val[: cnt.value]
 
     # ---- a run sharded over several processes (include/emat_host.h) ----
     def set_shard(self, rank: int, world: int):

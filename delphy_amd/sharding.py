@@ -168,6 +168,17 @@ class ShardedEngine:
         v = self.allreduce(np.array([g, a]), "sum")
         return float(v[0]), float(v[1])
 
+    def Ttwiddle_l(self):
+        """calc_Ttwiddle_l of the whole tree from parts spread over the ranks (reference phylo_tree_calc.cpp:176-222)."""
+        b = self.backend
+        lengths = np.zeros(self.total_parts)
+        lengths[self.part_lo: self.part_hi] = b.part_tree_lengths(self.num_local_parts)
+        lengths = self.allreduce(lengths, "sum")                                  # every rank needs every part's length
+        off, node, val = self.run.Ttwiddle_ext(lengths, self.num_local_parts)
+        S, R, T = b.Ttwiddle_l_partial(off, node, val)
+        S = self.allreduce(S, "sum"); R = self.allreduce(R, "sum"); T = float(self.allreduce(np.array([T]), "sum")[0])
+        return b.Ttwiddle_l_finish(S, R, T)
+
     def scalable_coalescent_log_prior(self, t_ref: float):
         """Whole-tree grid prior (reference Run::calc_cur_log_coalescent_prior) from parts spread over the ranks."""
         b = self.backend

@@ -198,6 +198,22 @@ emat_status emat_get_global_stats(emat_backend* h, int32_t num_partitions, doubl
  * (the deltas above a part's root are not mutations).  With parts on several handles the caller adds the vectors. */
 emat_status emat_get_num_muts_l(emat_backend* h, int32_t* num_muts_l /*[num_sites]*/);
 
+/* replaces: calc_Ttwiddle_l (reference phylo_tree_calc.cpp:176-222; with calc_num_muts_l the input of the site-rate moves,
+ * run.cpp:1109, 1184): Ttwiddle^(l) = sum_a q^(l)_a T^(l)_a, the escape-rate-weighted time site l spends in each state.
+ * The reference corrects q_ref T_total per mutation / missation by the branch length BELOW that point, which crosses
+ * part boundaries, so the computation is staged (the run driver, who knows the tree of parts, wraps it:
+ * emat_run_get_Ttwiddle_l):
+ *   emat_get_part_tree_lengths   sum of the branch lengths inside each part;
+ *   emat_Ttwiddle_l_partial      given, for every part, the tips that are cut nodes of parts below and the whole-tree
+ *                                branch length hanging at each (CSR: ext_offset[num_parts + 1], ext_node, ext_length), the
+ *                                per-site sums S and R over this handle's parts and, on the handle holding the run's root,
+ *                                the total tree length;
+ *   emat_Ttwiddle_l_finish       Ttwiddle_l = q_ref (T_total - R) + S from the sums over ALL handles (all-reduce SUM). */
+emat_status emat_get_part_tree_lengths(emat_backend* h, double* tree_length_of_part /*[num_parts]*/);
+emat_status emat_Ttwiddle_l_partial(emat_backend* h, const int32_t* ext_offset, const int32_t* ext_node, const double* ext_length,
+                                    double* S /*[num_sites]*/, double* R /*[num_sites]*/, double* tree_length_below_root /* may be NULL */);
+emat_status emat_Ttwiddle_l_finish(emat_backend* h, const double* S_sum, const double* R_sum, double tree_length, double* Ttwiddle_l /*[num_sites]*/);
+
 /* replaces: Run::calc_cur_log_coalescent_prior (reference run.cpp:455-465), i.e. Scalable_coalescent_prior::calc_log_prior
  * (scalable_coalescent.cpp:163-187) with every node displaced to its current time (:88-138): the whole-tree grid prior
  *   - sum_cells t_step kbar (kbar - 1) / (2 Nbar)  -  sum over inner nodes of log N(t),
@@ -264,6 +280,14 @@ emat_status emat_last_kernel_ms(emat_backend* h, double* ms, int32_t* num_parts_
  * boost::math::gamma_q / gamma_q_inv (Boost 1.84, reference safe_gamma_math.h:46,68; reached from spr_study.cpp:368,463,544),
  * whose source is not part of the reference tree; tests/test_parity_gpu.py sweeps them over tests/golden/gamma_q.json. */
 emat_status emat_debug_gamma(emat_backend* h, int32_t mode, int32_t n, const double* a, const double* x_or_q, double* out);
+/* The device's population-model routines, point by point (reference pop_model.cpp:18-145, 247-330): op 0: out[i] = N(a[i])
+ * (pop_at_time); op 1: out[i] = integral of N over [a[i], b[i]] (pop_integral).  tests/ sweeps them over the reference's
+ * own expectations (tests/golden/reference_expectations.json). */
+emat_status emat_debug_pop(emat_backend* h, const emat_pop_model* pop_model, int32_t op, int32_t n, const double* a, const double* b, double* out);
+/* The device's interval-set algebra on two valid sets given as (start, end) pairs (reference interval_set.h:130-138, 238-500):
+ * op 1 merge, 2 intersect, 3 subtract -> pairs in `out` (room for na + nb + 1 pairs), *n_out = their number; op 5 contains
+ * (site b[0]), 6 sets intersect -> *n_out = 0 / 1. */
+emat_status emat_debug_interval_op(emat_backend* h, int32_t op, const int32_t* a, int32_t na, const int32_t* b, int32_t nb, int32_t* out, int32_t* n_out);
 
 #ifdef __cplusplus
 }

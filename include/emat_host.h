@@ -106,6 +106,14 @@ emat_status emat_run_moves_sharded(emat_run* r, int64_t count);
 emat_status emat_run_pack_local_parts(emat_run* r, uint8_t* buf, uint64_t capacity, uint64_t* bytes_needed);
 emat_status emat_run_unpack_parts(emat_run* r, const uint8_t* buf, uint64_t bytes);
 
+/* replaces: calc_Ttwiddle_l(tree_, evo_) (reference phylo_tree_calc.cpp:176-222, called at run.cpp:1109, 1184) while the parts
+ * are on the device: the driver knows the tree of parts, which the staged engine calls need (emat_backend.h).  Single process;
+ * a sharded run all-gathers emat_get_part_tree_lengths, calls emat_run_Ttwiddle_ext + emat_Ttwiddle_l_partial on every rank,
+ * all-reduces S, R and the root's tree length, and finishes anywhere. */
+emat_status emat_run_get_Ttwiddle_l(emat_run* r, double* Ttwiddle_l /*[num_sites]*/);
+emat_status emat_run_Ttwiddle_ext(emat_run* r, const double* tree_length_of_part /*[all parts of the run]*/, int32_t* ext_offset /*[local parts + 1]*/,
+                                  int32_t* ext_node, double* ext_length, int32_t capacity, int32_t* count);
+
 /* repartition -> [push params, local moves, reassemble] per cycle of `local_moves_per_cycle` moves
  * (<= 0: 50 x nodes, the reference default run.cpp:669-672), repartitioning at every cycle boundary. */
 emat_status emat_run_do_mcmc_steps(emat_run* r, int64_t steps, int64_t local_moves_per_cycle);

@@ -267,6 +267,58 @@ inline int calc_num_muts(const Phylo_tree& tree) {   // :577-585
   for (int i = 0; i < tree.size(); ++i) if (i != tree.root) n += (int)tree.at(i).mutations.size();
   return n;
 }
+// Total branch length below every node (first loop of calc_T_l_a / calc_Ttwiddle_l, :130-142, :179-189), children before parents.
+inline std::vector<double> calc_T_below_node(const Phylo_tree& tree) {
+  std::vector<double> T(tree.size(), 0.0);
+  std::vector<std::pair<Node_index, int>> stack; stack.push_back({tree.root, 0});
+  while (!stack.empty()) {
+    auto& [node, k] = stack.back();
+    if (tree.at(node).is_tip() || k == 2) {
+      double sum = 0.0;
+      if (!tree.at(node).is_tip()) for (Node_index ch : tree.at(node).children) sum += (tree.at(ch).t - tree.at(node).t) + T[ch];
+      T[node] = sum;
+      stack.pop_back();
+    } else { Node_index ch = tree.at(node).children[k]; ++k; stack.push_back({ch, 0}); }
+  }
+  return T;
+}
+inline std::vector<std::array<double, 4>> calc_T_l_a(const Phylo_tree& tree) {   // :130-174
+  auto T_below_node = calc_T_below_node(tree);
+  std::vector<std::array<double, 4>> T_l_a(tree.num_sites(), std::array<double, 4>{0.0, 0.0, 0.0, 0.0});
+  const double T = T_below_node[tree.root];
+  for (int l = 0; l < tree.num_sites(); ++l) T_l_a[l][tree.ref_sequence[l]] = T;
+  for (int node = 0; node < tree.size(); ++node) {
+    for (const auto& m : tree.at(node).mutations) {
+      double T_below_mut = T_below_node[node] + (node == tree.root ? 0.0 : tree.at(node).t - m.t);
+      T_l_a[m.site][m.from] -= T_below_mut;
+      T_l_a[m.site][m.to] += T_below_mut;
+    }
+    double T_below_miss = T_below_node[node] + (node == tree.root ? 0.0 : tree.at(node).t - tree.at_parent_of(node).t);
+    for (const auto& iv : tree.at(node).missations.intervals.v) for (int l = iv.first; l < iv.second; ++l) T_l_a[l][tree.ref_sequence[l]] -= T_below_miss;
+    for (const auto& [l, from] : tree.at(node).missations.from_states) { T_l_a[l][tree.ref_sequence[l]] += T_below_miss; T_l_a[l][from] -= T_below_miss; }
+  }
+  return T_l_a;
+}
+inline std::vector<double> calc_Ttwiddle_l(const Phylo_tree& tree, const Global_evo_model& evo) {   // :176-222
+  auto T_below_node = calc_T_below_node(tree);
+  std::vector<double> Ttwiddle_l(tree.num_sites(), 0.0);
+  const double T = T_below_node[tree.root];
+  for (int l = 0; l < tree.num_sites(); ++l) Ttwiddle_l[l] = evo.q_l_a(l, tree.ref_sequence[l]) * T;
+  for (int node = 0; node < tree.size(); ++node) {
+    for (const auto& m : tree.at(node).mutations) {
+      double T_below_mut = T_below_node[node] + (node == tree.root ? 0.0 : tree.at(node).t - m.t);
+      Ttwiddle_l[m.site] -= evo.q_l_a(m.site, m.from) * T_below_mut;
+      Ttwiddle_l[m.site] += evo.q_l_a(m.site, m.to) * T_below_mut;
+    }
+    double T_below_miss = T_below_node[node] + (node == tree.root ? 0.0 : tree.at(node).t - tree.at_parent_of(node).t);
+    for (const auto& iv : tree.at(node).missations.intervals.v) for (int l = iv.first; l < iv.second; ++l) Ttwiddle_l[l] -= evo.q_l_a(l, tree.ref_sequence[l]) * T_below_miss;
+    for (const auto& [l, from] : tree.at(node).missations.from_states) {
+      Ttwiddle_l[l] += evo.q_l_a(l, tree.ref_sequence[l]) * T_below_miss;   // undo ref_seq assumption
+      Ttwiddle_l[l] -= evo.q_l_a(l, from) * T_below_miss;                   // apply correct from_state
+    }
+  }
+  return Ttwiddle_l;
+}
 inline std::vector<int> calc_num_muts_l(const Phylo_tree& tree) {   // :612-622
   std::vector<int> r(tree.num_sites(), 0);
   for (int i = 0; i < tree.size(); ++i) if (i != tree.root) for (const auto& m : tree.at(i).mutations) ++r[m.site];   // "mutations" above the root are deltas from the reference sequence

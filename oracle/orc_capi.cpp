@@ -183,6 +183,13 @@ int orc_global_stats(orc_engine* e, int P, double* Ttwiddle_beta_a /*[P][4]*/, i
   ORC_CATCH
 }
 
+/* calc_Ttwiddle_l (phylo_tree_calc.cpp:176-222) on the tree of ONE part (upload the whole tree as a single part). */
+int orc_Ttwiddle_l(orc_engine* e, int part_id, double* out /*[L]*/) {
+  ORC_TRY
+  auto v = calc_Ttwiddle_l(e->parts.at(part_id)->subrun->tree, e->evo);
+  for (int l = 0; l < e->L; ++l) out[l] = v[l];
+  ORC_CATCH
+}
 /* calc_num_muts_l summed over the parts (the deltas above a part's root are not mutations). */
 int orc_num_muts_l(orc_engine* e, int* out /*[L]*/) {
   ORC_TRY
@@ -296,6 +303,25 @@ double orc_gamma_q_inv(double a, double q) { return safe_gamma_q_inv(a, q); }
 double orc_pop_at_time(const emat_pop_model* pm, double t) { return make_pop_model(*pm)->pop_at_time(t); }
 double orc_pop_integral(const emat_pop_model* pm, double a, double b) { return make_pop_model(*pm)->pop_integral(a, b); }
 double orc_intensity_integral(const emat_pop_model* pm, double a, double b) { return make_pop_model(*pm)->intensity_integral(a, b); }
+/* Interval-set algebra of the oracle on plain arrays (pairs start, end).  op 0: insert the pairs of `a` one by one into an
+ * empty set (Interval_set::insert, interval_set.h:96-125); 1 merge, 2 intersect, 3 subtract (a, b already valid sets);
+ * 4 is_subset_of, 5 contains (site b[0]), 6 interval_sets_intersect -> out[0] = 0 / 1.  Returns the number of pairs written. */
+int orc_interval_op(int op, const int* a, int na, const int* b, int nb, int* out, int cap) {
+  Interval_set A, B, R;
+  if (op == 0) { for (int i = 0; i < na; ++i) A.insert(Site_interval{a[2 * i], a[2 * i + 1]}); R = A; }
+  else {
+    for (int i = 0; i < na; ++i) A.v.push_back({a[2 * i], a[2 * i + 1]});
+    if (op != 5) for (int i = 0; i < nb; ++i) B.v.push_back({b[2 * i], b[2 * i + 1]});
+    if (op == 1) merge_interval_sets(R, A, B);
+    else if (op == 2) intersect_interval_sets(R, A, B);
+    else if (op == 3) subtract_interval_sets(R, A, B);
+    else { if (cap < 1) return -1; out[0] = op == 4 ? interval_set_is_subset_of(A, B) : op == 5 ? A.contains(b[0]) : interval_sets_intersect(A, B); return 1; }
+  }
+  if ((int)R.v.size() > cap) return -1;
+  for (size_t i = 0; i < R.v.size(); ++i) { out[2 * i] = R.v[i].first; out[2 * i + 1] = R.v[i].second; }
+  return (int)R.v.size();
+}
+
 void orc_rng_block(uint64_t key, uint64_t counter, uint32_t out[4]) { Rng::philox4x32_10(counter, key, out); }
 
 }  // extern "C"

@@ -235,6 +235,18 @@ TEST(calc_fixture_global_move_statistics) {
   EXPECT(total == calc_num_muts(t));
   // phylo_tree_calc_tests.cpp:471-482: A0T on r->x, T0C on x->a, A0T and T0G on r->c; A1G on x->b; C2A above the root is not a mutation
   EXPECT(calc_num_muts_l(t) == (std::vector<int>{4, 1, 0, 0}));
+  // phylo_tree_calc_tests.cpp:286-313 (calc_T_l_a) and :315-326 (calc_Ttwiddle_l = sum_a q^(l)_a T^(l)_a)
+  double eT[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  eT[0][sA] += 0.5; eT[0][sT] += 0.5; eT[0][sT] += 0.5; eT[0][sC] += 0.5; eT[0][sT] += 2.0; eT[0][sA] += 1.0; eT[0][sT] += 1.0; eT[0][sG] += 2.0;
+  eT[1][sA] += 1.0; eT[1][sA] += 1.0; eT[1][sA] += 1.0; eT[1][sG] += 1.0;   // site 1 missing below the r->c attachment point
+  eT[2][sA] += 4.0;                                                          // site 2 missing below r->x; site 3 missing everywhere
+  auto T_l_a = calc_T_l_a(t);
+  auto Ttw = calc_Ttwiddle_l(t, evo);
+  for (int l = 0; l < 4; ++l) {
+    double expect_tw = 0.0;
+    for (int a2 = 0; a2 < 4; ++a2) { EXPECT_NEAR(T_l_a[l][a2], eT[l][a2], 1e-6); expect_tw += evo.q_l_a(l, (State)a2) * eT[l][a2]; }
+    EXPECT_NEAR(Ttw[l], expect_tw, 1e-6);
+  }
 }
 TEST(calc_fixture_log_G_and_lambda) {
   auto t = complex_tree(false);

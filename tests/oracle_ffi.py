@@ -33,7 +33,7 @@ def lib():
             "orc_part_get_coalescent": [E, C.c_int, P(C.c_int), P(dbl), P(dbl), P(dbl), P(dbl), P(C.c_int), P(dbl), P(dbl)],
             "orc_part_get_stats": [E, C.c_int, P(_PartStatsC)], "orc_part_get_trace": [E, C.c_int, P(C.c_int), P(dbl)],
             "orc_part_check": [E, C.c_int, C.c_char_p, C.c_int],
-            "orc_num_muts_l": [E, P(C.c_int)], "orc_scalable_log_prior": [E, C.c_int, dbl, dbl, P(dbl)],
+            "orc_Ttwiddle_l": [E, C.c_int, P(dbl)], "orc_num_muts_l": [E, P(C.c_int)], "orc_scalable_log_prior": [E, C.c_int, dbl, dbl, P(dbl)],
         }
         for n, a in sigs.items():
             f = getattr(L, n); f.argtypes = a; f.restype = C.c_int
@@ -44,6 +44,7 @@ def lib():
             getattr(L, n).argtypes = [P(_PopModelC), dbl]; getattr(L, n).restype = dbl
         for n in ("orc_pop_integral", "orc_intensity_integral"):
             getattr(L, n).argtypes = [P(_PopModelC), dbl, dbl]; getattr(L, n).restype = dbl
+        L.orc_interval_op.argtypes = [C.c_int, P(C.c_int), C.c_int, P(C.c_int), C.c_int, P(C.c_int), C.c_int]; L.orc_interval_op.restype = C.c_int
         L.orc_rng_block.argtypes = [u64, u64, P(C.c_uint32)]; L.orc_rng_block.restype = None
         _lib = L
     return _lib
@@ -122,6 +123,11 @@ class OracleEngine:
         self._ck(self.L.orc_global_stats(self.h, num_partitions, _ptr(T, C.c_double), _ptr(M, C.c_int64), C.byref(nm)), "global_stats")
         return T, M, int(nm.value)
 
+    def Ttwiddle_l(self, part):
+        out = np.zeros(self.num_sites)
+        self._ck(self.L.orc_Ttwiddle_l(self.h, part, _ptr(out, C.c_double)), "Ttwiddle_l")
+        return out
+
     def num_muts_l(self):
         out = np.zeros(self.num_sites, np.int32)
         self._ck(self.L.orc_num_muts_l(self.h, _ptr(out, C.c_int)), "num_muts_l")
@@ -165,3 +171,13 @@ class OracleEngine:
         buf = C.create_string_buffer(512)
         rc = self.L.orc_part_check(self.h, part, buf, 512)
         return rc, buf.value.decode()
+
+
+def interval_op(op, a, b=()):
+    """The oracle's interval-set algebra on lists of [start, end): op 0 insert sequence, 1 merge, 2 intersect, 3 subtract ->
+    list of pairs; 4 is_subset_of, 5 contains (b = [site]), 6 intersects -> bool."""
+    A = np.ascontiguousarray(np.asarray(a, np.int32).reshape(-1)); B = np.ascontiguousarray(np.asarray(b, np.int32).reshape(-1))
+    out = np.zeros(A.shape[0] + B.shape[0] + 2, np.int32)
+    n = lib().orc_interval_op(op, _ptr(A, C.c_int), A.shape[0] // 2, _ptr(B, C.c_int), B.shape[0] if op == 5 else B.shape[0] // 2, _ptr(out, C.c_int), out.shape[0] // 2)
+    assert n >= 0
+    return out[: 2 * n].reshape(-1, 2).tolist() if op <= 3 else bool(out[0])

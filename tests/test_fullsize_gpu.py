@@ -185,6 +185,8 @@ def _sharded_gpu_worker(rank, world, port, out_dir, cycles, moves):
     res["root"] = np.array([t.root]); res["ref"] = ref
     tips = t.child0 == -1
     res["grid_prior"] = np.array([eng.scalable_coalescent_log_prior(float(np.max(t.t[tips])))])
+    eng.repartition()
+    res["Ttwiddle_l"] = eng.Ttwiddle_l()
     np.savez(os.path.join(out_dir, "gpu_rank%d.npz" % rank), **res)
     eng.close()
     dist.destroy_process_group()
@@ -207,7 +209,10 @@ def test_two_process_cycles_on_one_gpu_match_the_single_process_run(tmp_path):
     t, ref = single.tree()
     tips = t.child0 == -1
     grid = single.scalable_coalescent_log_prior(float(np.max(t.t[tips])))
+    single.repartition()
+    ttw = single.Ttwiddle_l()
     for r in range(2):
+        assert rel_close(z[r]["Ttwiddle_l"], ttw, 1e-9)
         assert int(z[r]["root"][0]) == t.root and np.array_equal(z[r]["ref"], ref)
         for k, v in _tree_fields(t).items():
             if k in ("t", "mut_t"):

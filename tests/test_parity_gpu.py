@@ -259,3 +259,41 @@ def test_global_stats_wait_for_regrown_parts(monkeypatch):
         assert all(gpu.part_stats(p)["moves_done"] == 4000 for p in range(len(parts)))
     finally:
         gpu.close(); orc.close()
+
+
+def test_mid_size_parts_with_lists_outgrowing_the_lds_heap_room():
+    """Parts of 60-100 nodes on a 29 903-site genome are staged in LDS with a 1 KB heap reserve; a move whose lists outgrow
+    it mid-way drops the staged state and the leg is re-run from the (untouched) HBM copy.  Whether or not that happens in
+    these 64 x 4000 moves, the result must be the oracle's move for move."""
+    sc = make_scenario("C3", num_tips=2000, num_sites=29903, uncertain_tips=0.2)
+    run_parity(sc, 64, 4000, seed=4242, trace=0)
+
+
+def test_Ttwiddle_l_of_the_whole_tree_from_the_parts():
+    """calc_Ttwiddle_l (phylo_tree_calc.cpp:176-222) needs the branch length BELOW every mutation, which
+    crosses part boundaries: the run driver feeds the engine the length hanging below every boundary tip.  Against the
+    oracle's restatement on the reassembled whole tree, before and after moves, with site-rate heterogeneity and two
+    kinds of population model; the statistic does not depend on how the tree is cut."""
+    for name, kw, nparts in (("C1", dict(num_tips=150, num_sites=3000), 5), ("C3", dict(num_tips=900, num_sites=6000, uncertain_tips=0.2), 40)):
+        sc = make_scenario(name, **kw)
+        b = d.EmatBackend(sc.num_sites)
+        run = d.EmatRun(b, sc.tree, sc.ref, 61)
+        run.set_num_parts(nparts); run.set_hky(sc.mu, sc.kappa, sc.pi); run.set_pop_model(sc.pop)
+        try:
+            for cyc in range(3):
+                run.repartition()
+                n, _ = run.num_parts()
+                if cyc > 0:
+                    run.run_moves(n * 800)
+                got = run.Ttwiddle_l()
+                run.reassemble()
+                whole, ref = run.tree()
+                orc = OracleEngine(sc.num_sites)
+                sc2 = make_scenario(name, **kw); sc2.tree, sc2.ref = whole, ref
+                configure(orc, sc2, ref, [whole], [True], [1], 0)
+                want = orc.Ttwiddle_l(0)
+                orc.close()
+                assert rel_close(got, want, 1e-9), (name, cyc, float(np.max(np.abs(got - want))))
+                assert np.all(want >= 0) and want.max() > 0
+        finally:
+            run.close(); b.close()
