@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = []
-    for hdr in ("emat_backend.h", "emat_host.h"):
+    for hdr in ("emat_backend.h", "emat_host.h", "emat_dphy.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names += re.findall(r"\b(?:emat_status|const char\*|void)\s+(emat_\w+)\s*\(", text)
