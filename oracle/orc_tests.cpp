@@ -837,6 +837,240 @@ TEST(pop_models_literals) {
   EXPECT_NEAR(ll.intensity_integral(2.5, 3.5), seg(-7, -3, 2, 4, 2.5, 3.5), 1e-12);
 }
 // HKY model: rows sum to zero, detailed balance pi_a q_ab = pi_b q_ba, mean rate 1 (evo_hky.cpp:7-50)
+// ---- tree editing sessions: the reference's own ten cases (tests/tree_editing_tests.cpp:127-1115) ----------------
+// Each case rebuilds the reference's fixture (same topology, times, mutations and missations), plays the same
+// sequence of elementary edits and checks the same expectations, plus tree integrity, lambda_i and the per-node
+// missing-site counts as the reference's cases do at their end.
+struct EditCtx {
+  Phylo_tree tree, old_tree; Global_evo_model evo; std::vector<double> cumQ, lambda_i; std::vector<int> num_missing;
+  explicit EditCtx(Phylo_tree t) : tree(std::move(t)), evo(fixture_evo()) { rebase(); }
+  void rebase() {   // after a per-case tweak of the fixture
+    old_tree = tree;
+    cumQ = calc_cum_Q_l_for_sequence(tree.ref_sequence, evo);
+    lambda_i = calc_lambda_i(tree, evo, cumQ);
+    num_missing = calc_num_sites_missing_at_every_node(tree);
+  }
+  Tree_editing_session session(Node_index X) { return Tree_editing_session(tree, X, evo, lambda_i, cumQ, num_missing); }
+  void check_derived() {
+    EXPECT(check_phylo_tree_integrity(tree).empty());
+    for (int n = 0; n < tree.size(); ++n) EXPECT_NEAR(lambda_i[n], calc_lambda_at_node(tree, n, evo, cumQ), 1e-6);
+    EXPECT(num_missing == calc_num_sites_missing_at_every_node(tree));
+  }
+  using Elems = std::vector<std::pair<int, State>>;
+  Elems missing_at(Node_index n) const {   // Missation_map::slow_elements (mutations.h): every missing site with its from-state
+    Elems r;
+    for (auto& iv : tree.at(n).missations.intervals.v)
+      for (int l = iv.first; l < iv.second; ++l) r.push_back({l, tree.at(n).missations.get_from_state(l, tree.ref_sequence)});
+    return r;
+  }
+  bool muts_are(Node_index n, Mutation_list want) const { return tree.at(n).mutations == want; }
+  bool same_muts(Node_index n) const { return tree.at(n).mutations == old_tree.at(n).mutations; }
+  bool same_miss(Node_index n) const { return tree.at(n).missations == old_tree.at(n).missations; }
+  bool same_t(Node_index n) const { return tree.at(n).t == old_tree.at(n).t; }
+};
+// tree_editing_tests.cpp:58-124
+static Phylo_tree edit_simple_tree() {
+  Phylo_tree t(5);
+  t.root = r_; t.ref_sequence = {sA, sC, sA, sA};
+  set_inner(t, r_, k_no_node, x_, c_, -1.0); t.at(r_).mutations = {Mutation{sC, 1, sA, NEG}};
+  set_inner(t, x_, r_, a_, b_, 0.0); t.at(x_).mutations = {Mutation{sA, 0, sT, -0.5}}; miss(t, x_, {{2, sA}});
+  set_tip(t, a_, x_, 1.0); t.at(a_).mutations = {Mutation{sT, 0, sC, 0.5}};
+  set_tip(t, b_, x_, 2.0); t.at(b_).mutations = {Mutation{sA, 1, sG, 1.0}};
+  set_tip(t, c_, r_, 3.0); t.at(c_).mutations = {Mutation{sA, 0, sG, 1.0}}; miss(t, c_, {{1, sA}});
+  return t;
+}
+TEST(tree_editing_slide_up_simple) {   // :127-190
+  EditCtx C(edit_simple_tree());
+  auto e = C.session(a_); e.slide_P_along_branch(-1.0); e.end();
+  EXPECT(C.same_t(a_)); EXPECT(C.same_t(b_)); EXPECT(C.same_t(c_)); EXPECT(C.same_t(r_));
+  EXPECT_NEAR(C.tree.at(x_).t, -1.0, 1e-6);
+  EXPECT(C.muts_are(a_, {Mutation{sA, 0, sC, 0.0}}));
+  EXPECT(C.muts_are(b_, {Mutation{sA, 0, sT, -0.5}, Mutation{sA, 1, sG, 1.0}}));
+  EXPECT(C.same_muts(c_)); EXPECT(C.tree.at(x_).mutations.empty()); EXPECT(C.same_muts(r_));
+  for (int n : {a_, b_, c_, x_, r_}) EXPECT(C.same_miss(n));
+  C.check_derived();
+}
+TEST(tree_editing_slide_up_missation_kills_mutation) {   // :192-258
+  EditCtx C(edit_simple_tree());
+  C.tree.at(a_).mutations = {}; C.tree.at(a_).missations.clear(); miss(C.tree, a_, {{0, sT}});
+  EXPECT(check_phylo_tree_integrity(C.tree).empty());
+  C.rebase();
+  auto e = C.session(a_); e.slide_P_along_branch(-1.0); e.end();
+  EXPECT(C.same_t(a_)); EXPECT(C.same_t(b_)); EXPECT(C.same_t(c_)); EXPECT(C.same_t(r_));
+  EXPECT_NEAR(C.tree.at(x_).t, -1.0, 1e-6);
+  EXPECT(C.tree.at(a_).mutations.empty());
+  EXPECT(C.muts_are(b_, {Mutation{sA, 0, sT, -0.5}, Mutation{sA, 1, sG, 1.0}}));
+  EXPECT(C.same_muts(c_)); EXPECT(C.tree.at(x_).mutations.empty()); EXPECT(C.same_muts(r_));
+  EXPECT(C.missing_at(a_) == (EditCtx::Elems{{0, sA}}));
+  for (int n : {b_, c_, x_, r_}) EXPECT(C.same_miss(n));
+  C.check_derived();
+}
+TEST(tree_editing_slide_up_against_edge_mutation) {   // :836-899
+  EditCtx C(edit_simple_tree());
+  C.tree.at(x_).mutations = {Mutation{sA, 0, sT, C.tree.at(r_).t}};
+  EXPECT(check_phylo_tree_integrity(C.tree).empty());
+  C.rebase();
+  auto e = C.session(a_); e.slide_P_along_branch(C.tree.at(r_).t); e.end();
+  EXPECT(C.same_t(a_)); EXPECT(C.same_t(b_)); EXPECT(C.same_t(c_)); EXPECT(C.same_t(r_));
+  EXPECT_NEAR(C.tree.at(x_).t, -1.0, 1e-6);
+  EXPECT(C.muts_are(a_, {Mutation{sA, 0, sC, 0.0}}));
+  EXPECT(C.muts_are(b_, {Mutation{sA, 0, sT, -1.0}, Mutation{sA, 1, sG, 1.0}}));
+  EXPECT(C.same_muts(c_)); EXPECT(C.tree.at(x_).mutations.empty()); EXPECT(C.same_muts(r_));
+  for (int n : {a_, b_, c_, x_, r_}) EXPECT(C.same_miss(n));
+  C.check_derived();
+}
+// tree_editing_tests.cpp:262-345 (x at t = 0) and :676-760 (the SPR fixture: the same tree with x at t = 1)
+namespace hf { enum { r = 0, x = 1, y = 2, a = 3, b = 4, c = 5, d = 6 }; }
+static Phylo_tree edit_hop_flip_tree(double t_x) {
+  using namespace hf;
+  Phylo_tree t(7);
+  t.root = r; t.ref_sequence = {sA, sC, sA, sT};
+  set_inner(t, r, k_no_node, y, d, -1.0);
+  set_inner(t, y, r, x, c, 0.0); t.at(y).mutations = {Mutation{sA, 2, sG, -0.75}, Mutation{sT, 3, sA, -0.25}};
+  set_inner(t, x, y, a, b, t_x); miss(t, x, {{2, sG}});
+  set_tip(t, a, x, 2.0); miss(t, a, {{0, sA}});
+  set_tip(t, b, x, 3.0); t.at(b).mutations = {Mutation{sA, 3, sC, 2.0}}; miss(t, b, {{1, sC}});
+  set_tip(t, c, y, 1.0); miss(t, c, {{1, sC}});
+  set_tip(t, d, r, -0.5);
+  return t;
+}
+static void expect_parents(EditCtx& C, std::vector<int> want) {
+  for (int n = 0; n < C.tree.size(); ++n) EXPECT(C.tree.at(n).parent == want[n]);
+}
+static void expect_after_hop(EditCtx& C) {   // what :389-431 and :602-644 both expect
+  using namespace hf;
+  for (int n = 0; n < 7; ++n) EXPECT(C.same_t(n));
+  for (int n : {a, b, c, d, r}) EXPECT(C.same_muts(n));
+  EXPECT(C.tree.at(x).mutations == C.old_tree.at(y).mutations);
+  EXPECT(C.tree.at(y).mutations == C.old_tree.at(x).mutations);
+  EXPECT(C.missing_at(a) == (EditCtx::Elems{{0, sA}, {2, sG}}));
+  EXPECT(C.missing_at(b) == (EditCtx::Elems{{2, sG}}));
+  EXPECT(C.tree.at(c).missations.empty()); EXPECT(C.same_miss(d)); EXPECT(C.same_miss(r));
+  EXPECT(C.tree.at(x).missations.empty());
+  EXPECT(C.missing_at(y) == (EditCtx::Elems{{1, sC}}));
+  //                r        x  y  a  b  c  d
+  expect_parents(C, {k_no_node, r, x, x, y, y, r});
+  EXPECT(C.tree.root == r);
+  C.check_derived();
+}
+TEST(tree_editing_hop_up) {   // :347-431
+  EditCtx C(edit_hop_flip_tree(0.0));
+  EXPECT(check_phylo_tree_integrity(C.tree).empty());
+  auto e = C.session(hf::a); e.hop_up(); e.end();
+  expect_after_hop(C);
+}
+TEST(tree_editing_hop_down) {   // :560-644
+  EditCtx C(edit_hop_flip_tree(0.0));
+  auto e = C.session(hf::c); e.hop_down(hf::b); e.end();
+  expect_after_hop(C);
+}
+TEST(tree_editing_flip) {   // :433-558
+  using namespace hf;
+  EditCtx C(edit_hop_flip_tree(0.0));
+  auto e = C.session(b); e.flip(); e.end();
+  for (int n = 0; n < 7; ++n) EXPECT(C.same_t(n));
+  EXPECT(C.same_muts(a)); EXPECT(C.muts_are(b, {Mutation{sA, 3, sC, 1.5}}));
+  for (int n : {c, d, x, y, r}) EXPECT(C.same_muts(n));   // an upstream flip does not swap the x and y mutations
+  EXPECT(C.missing_at(a) == (EditCtx::Elems{{0, sA}, {2, sG}}));
+  EXPECT(C.missing_at(b) == (EditCtx::Elems{{2, sG}}));
+  EXPECT(C.tree.at(c).missations.empty()); EXPECT(C.same_miss(d)); EXPECT(C.same_miss(r));
+  EXPECT(C.missing_at(x) == (EditCtx::Elems{{1, sC}}));
+  EXPECT(C.tree.at(y).missations.empty());
+  expect_parents(C, {k_no_node, y, r, y, x, x, r});
+  EXPECT(C.tree.root == r);
+  C.check_derived();
+}
+TEST(tree_editing_spr) {   // :762-834
+  using namespace hf;
+  EditCtx C(edit_hop_flip_tree(1.0));
+  EXPECT(check_phylo_tree_integrity(C.tree).empty());
+  auto e = C.session(a);
+  e.slide_P_along_branch(C.tree.at(y).t);
+  e.hop_up();
+  e.slide_P_along_branch(C.tree.at(r).t);
+  e.slide_P_along_branch(C.tree.at(y).t);
+  e.hop_down(b);
+  e.flip();
+  e.slide_P_along_branch(0.5);
+  e.end();
+  for (int n : {a, b, c, d, y, r}) EXPECT(C.same_t(n));
+  EXPECT(C.tree.at(x).t == 0.5);
+  EXPECT(C.tree.at(a).mutations.empty());
+  EXPECT(C.muts_are(b, {Mutation{sA, 3, sC, 2.0}}));
+  EXPECT(C.tree.at(c).mutations.empty()); EXPECT(C.tree.at(x).mutations.empty());
+  for (int n : {d, y, r}) EXPECT(C.same_muts(n));
+  EXPECT(C.missing_at(a) == (EditCtx::Elems{{0, sA}, {2, sG}}));
+  EXPECT(C.missing_at(b) == (EditCtx::Elems{{1, sC}, {2, sG}}));
+  EXPECT(C.missing_at(c) == (EditCtx::Elems{{1, sC}}));
+  EXPECT(C.tree.at(x).missations.empty());
+  for (int n : {d, y, r}) EXPECT(C.same_miss(n));
+  expect_parents(C, {k_no_node, y, r, x, y, x, r});
+  EXPECT(C.tree.root == r);
+  C.check_derived();
+}
+// tree_editing_tests.cpp:901-962
+static Phylo_tree edit_slide_down_tree() {
+  Phylo_tree t(5);
+  t.root = r_; t.ref_sequence = {sA, sA, sA, sA};
+  set_inner(t, r_, k_no_node, x_, c_, 0.0);
+  set_inner(t, x_, r_, a_, b_, 1.0); t.at(x_).mutations = {Mutation{sA, 0, sT, 0.5}};
+  set_tip(t, a_, x_, 4.0); t.at(a_).mutations = {Mutation{sA, 1, sG, 4.0}}; miss(t, a_, {{0, sT}});
+  set_tip(t, b_, x_, 3.0); t.at(b_).mutations = {Mutation{sA, 1, sC, 1.5}, Mutation{sT, 0, sG, 2.5}};
+  set_tip(t, c_, r_, 0.5);
+  return t;
+}
+TEST(tree_editing_slide_down) {   // :964-1000 (tip b is the lower end of the branch the junction slides down)
+  EditCtx C(edit_slide_down_tree());
+  EXPECT(check_phylo_tree_integrity(C.tree).empty());
+  auto e = C.session(a_); e.slide_P_along_branch(3.0); e.end();
+  EXPECT(C.same_t(a_)); EXPECT(C.same_t(b_)); EXPECT(C.same_t(c_)); EXPECT(C.same_t(r_));
+  EXPECT_NEAR(C.tree.at(x_).t, 3.0, 1e-6);
+  EXPECT(C.muts_are(a_, {Mutation{sC, 1, sG, 3.5}}));
+  EXPECT(C.tree.at(b_).mutations.empty()); EXPECT(C.same_muts(c_));
+  EXPECT(C.muts_are(x_, {Mutation{sA, 0, sT, 0.5}, Mutation{sA, 1, sC, 1.5}, Mutation{sT, 0, sG, 2.5}}));
+  EXPECT(C.same_muts(r_));
+  EXPECT(C.missing_at(a_) == (EditCtx::Elems{{0, sG}}));
+  for (int n : {b_, c_, x_, r_}) EXPECT(C.same_miss(n));
+  C.check_derived();
+}
+TEST(tree_editing_slide_down_against_edge_mutation) {   // :1002-1047
+  EditCtx C(edit_slide_down_tree());
+  C.tree.at(b_).mutations = {Mutation{sA, 1, sC, 1.5}, Mutation{sT, 0, sG, C.tree.at(b_).t}};
+  EXPECT(check_phylo_tree_integrity(C.tree).empty());
+  C.rebase();
+  auto e = C.session(a_); e.slide_P_along_branch(C.tree.at(b_).t); e.end();
+  EXPECT(C.same_t(a_)); EXPECT(C.same_t(b_)); EXPECT(C.same_t(c_)); EXPECT(C.same_t(r_));
+  EXPECT_NEAR(C.tree.at(x_).t, 3.0, 1e-6);
+  EXPECT(C.muts_are(a_, {Mutation{sC, 1, sG, 3.5}}));
+  EXPECT(C.tree.at(b_).mutations.empty()); EXPECT(C.same_muts(c_));
+  EXPECT(C.muts_are(x_, {Mutation{sA, 0, sT, 0.5}, Mutation{sA, 1, sC, 1.5}, Mutation{sT, 0, sG, 3.0}}));
+  EXPECT(C.same_muts(r_));
+  EXPECT(C.missing_at(a_) == (EditCtx::Elems{{0, sG}}));
+  for (int n : {b_, c_, x_, r_}) EXPECT(C.same_miss(n));
+  C.check_derived();
+}
+TEST(tree_editing_slide_down_root) {   // :1049-1115 (X = x: its parent is the root, which slides down the root-c branch)
+  EditCtx C(edit_slide_down_tree());
+  C.tree.at(c_).t = 0.9; C.tree.at(c_).t_min = C.tree.at(c_).t_max = 0.9f;
+  C.tree.at(x_).mutations = {Mutation{sC, 1, sA, 0.5}};
+  C.tree.at(r_).mutations = {Mutation{sA, 0, sT, NEG}, Mutation{sA, 1, sC, NEG}};
+  C.tree.at(c_).mutations = {Mutation{sC, 1, sA, 0.02}, Mutation{sA, 2, sG, 0.05}};
+  C.tree.at(a_).mutations = {Mutation{sA, 1, sG, 4.0}};
+  C.tree.at(b_).mutations = {Mutation{sA, 1, sC, 1.5}, Mutation{sT, 0, sG, 2.5}};
+  EXPECT(check_phylo_tree_integrity(C.tree).empty());
+  C.rebase();
+  auto e = C.session(x_); e.slide_P_along_branch(0.5); e.end();
+  EXPECT(C.same_t(a_)); EXPECT(C.same_t(b_)); EXPECT(C.same_t(c_)); EXPECT(C.same_t(x_));
+  EXPECT_NEAR(C.tree.at(r_).t, 0.5, 1e-6);
+  EXPECT(C.same_muts(a_)); EXPECT(C.same_muts(b_));
+  EXPECT(C.tree.at(c_).mutations.empty());
+  EXPECT(C.muts_are(x_, {Mutation{sG, 2, sA, 0.75}}));
+  auto rm = C.tree.at(r_).mutations; sort_mutations(rm);   // the reference compares these unordered
+  EXPECT(rm == (Mutation_list{Mutation{sA, 0, sT, NEG}, Mutation{sA, 2, sG, NEG}}));
+  for (int n : {a_, b_, c_, x_, r_}) EXPECT(C.same_miss(n));
+  C.check_derived();
+}
+
 TEST(hky_model_properties) {
   Hky_model h; h.mu = 1e-3; h.kappa = 5.0; double pi[4] = {0.3, 0.2, 0.2, 0.3}; for (int a = 0; a < 4; ++a) h.pi_a[a] = pi[a];
   auto m = h.derive_site_evo_model();
