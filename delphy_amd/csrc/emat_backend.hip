@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -108,6 +110,10 @@ __device__ inline const double* stage_tables(const KernelArgs& a, double* lds_ta
 #ifndef EMAT_WAVES_PER_EU
 #define EMAT_WAVES_PER_EU 4
 #endif
+// Every kernel that calls into the out-of-line device functions carries the same occupancy target: the register budget
+// of a callee is the tightest one among its callers' targets only if ALL its callers have one (the debug kernels share
+// `dev::` code with k_run_moves).  HIP's __launch_bounds__ second argument is ignored by the AMDGPU backend.
+#define EMAT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(EMAT_WAVES_PER_EU, EMAT_WAVES_PER_EU)))
 // Room the list heap of an LDS-staged part keeps above its used size (measured at C4: 2048 -> 288, 1024 -> 296, 768 -> 287,
 // 512 -> 282 M moves/s: less room leaves more LDS to the moves' scratch arena, too little sends parts through heap
 // compactions and the HBM fall-back leg).
@@ -215,10 +221,10 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
     allow_whole = false;
   }
 }
-__global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves(KernelArgs a) { run_moves_body(a); }
+__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY k_run_moves(KernelArgs a) { run_moves_body(a); }
 // Same body under another name for the side launches of the size classes (the "giants", §4 of DESIGN.md), so that
 // profiles keep the statistics of the main launch -- the one bench.py's roofline is about -- apart.
-__global__ void __launch_bounds__(k_wave, EMAT_WAVES_PER_EU) k_run_moves_side(KernelArgs a) { run_moves_body(a); }
+__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY k_run_moves_side(KernelArgs a) { run_moves_body(a); }
 
 // ---- sufficient statistics of the global moves (calc_Ttwiddle_beta_a phylo_tree_calc.cpp:288-369, calc_num_muts_beta_ab
 //      :599-610, calc_num_muts :577-585), one part per workgroup ---------------------------------------------------------
@@ -508,13 +514,13 @@ __global__ void __launch_bounds__(k_wave) k_scalable_prior(KernelArgs a, double 
 }
 
 // ---- test hook: the device's incomplete-gamma routines evaluated point by point (emat_debug_gamma) ----------------------
-__global__ void k_debug_gamma(const double* a, const double* x, double* out, int n, int mode) {
+__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY k_debug_gamma(const double* a, const double* x, double* out, int n, int mode) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = mode == 0 ? dev::gamma_q(a[i], x[i]) : dev::gamma_q_inv(a[i], x[i]);
 }
 
 // ---- test hooks: the device's population-model and interval-set routines on plain inputs (emat_debug_pop, _interval_op) --
-__global__ void k_debug_pop(PopTable pt, int op, const double* a, const double* b, double* out, int n) {
+__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY k_debug_pop(PopTable pt, int op, const double* a, const double* b, double* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = op == 0 ? dev::pop_at_time(pt, a[i]) : dev::pop_integral(pt, a[i], b[i]);
 }
@@ -527,6 +533,10 @@ __global__ void k_debug_interval_op(int op, const IvRec* A, int nA, const IvRec*
   else if (op == 6) *n_out = dev::iv_intersects(A, nA, B, nB) ? 1 : 0;
   else *n_out = -1;
 }
+
+}  // namespace emat
+#include "emat_gtree_kernels.hpp"   // the whole tree in HBM: cutting it into part slabs and gathering the parts back
+namespace emat {
 
 // =================================================================================================
 // Host side
@@ -582,6 +592,34 @@ struct PartHost {
   std::vector<double> trace;       // the part's move trace so far (4 doubles per move), carried over re-materialisations
   int64_t expected_moves = 0;      // moves requested of this part since its upload
   double space_boost = 1.0;        // multiplier of the heap and scratch capacities; doubled when the part ran out of space
+};
+
+// The whole tree in HBM (emat_gtree_kernels.hpp) with the host mirrors the partitioner and the coalescent builder need:
+// topology and node times, a few MB per cycle instead of every list of every node.
+struct GTreeHost {
+  bool resident = false;            // emat_tree_upload was called
+  bool parts_live = false;          // the slabs hold the parts of `partition` (between emat_tree_repartition and emat_tree_reassemble)
+  int32_t n = 0;
+  DevBuf<int32_t> parent, c0, c1, root; DevBuf<double> t; DevBuf<float> t_min, t_max; DevBuf<GList> muts, miss, mfs;
+  DevBuf<MutRec> mut_heap; DevBuf<IvRec> iv_heap; DevBuf<FsRec> fs_heap; DevBuf<uint32_t> tops; DevBuf<int32_t> status;
+  uint32_t used[3] = {0, 0, 0};     // records in use in the three heaps
+  // current partition
+  int32_t P = 0, root_part = -1;
+  DevBuf<int32_t> part_off, orig, kid0, kid1;
+  DevBuf<GMeasure> measure; DevBuf<MutRec> pool_muts; DevBuf<IvRec> pool_ivs; DevBuf<uint32_t> pool_tops;
+  DevBuf<GPartDesc> desc; DevBuf<uint8_t> cells;
+  DevBuf<GRootDelta> root_deltas; DevBuf<int32_t> n_root_deltas;
+  // host mirrors
+  std::vector<int32_t> h_parent, h_c0, h_c1; std::vector<double> h_t; std::vector<float> h_t_min, h_t_max; int32_t h_root = EMAT_NO_NODE;
+  GTreeDev dev() {
+    GTreeDev g{};
+    g.n_nodes = n; g.root = root.p; g.parent = parent.p; g.c0 = c0.p; g.c1 = c1.p; g.t = t.p; g.t_min = t_min.p; g.t_max = t_max.p;
+    g.muts = muts.p; g.miss = miss.p; g.mfs = mfs.p; g.mut_heap = mut_heap.p; g.iv_heap = iv_heap.p; g.fs_heap = fs_heap.p;
+    g.mut_cap = (uint32_t)mut_heap.n; g.iv_cap = (uint32_t)iv_heap.n; g.fs_cap = (uint32_t)fs_heap.n; g.tops = tops.p;
+    return g;
+  }
+  GPartition partition() { GPartition q{}; q.num_parts = P; q.root_part = root_part; q.part_off = part_off.p; q.orig = orig.p; q.kid0 = kid0.p; q.kid1 = kid1.p; return q; }
+  GPools pools() { GPools q{}; q.muts = pool_muts.p; q.ivs = pool_ivs.p; q.mut_cap = (uint32_t)pool_muts.n; q.iv_cap = (uint32_t)pool_ivs.n; q.tops = pool_tops.p; return q; }
 };
 
 }  // namespace emat
@@ -642,6 +680,7 @@ struct emat_backend {
   std::unique_ptr<CoalBuilder> coal_builder;
   // dense copy of every part's slab header (k_gather_headers): what the scalar getters read instead of the slabs
   DevBuf<uint8_t> d_headers; std::vector<uint8_t> h_headers; bool headers_current = false;
+  GTreeHost gt;                     // the whole tree, when it lives in HBM (emat_tree_upload)
 
   void set_error(const std::string& s) { last_error = s; }
 };
@@ -922,49 +961,30 @@ emat_status pull_headers(emat_backend* h) {
 }
 inline const SlabHeader* header_of(const emat_backend* h, size_t part) { return (const SlabHeader*)(h->h_headers.data() + part * sizeof(SlabHeader)); }
 
-// Encode all parts and push them to the device.
-emat_status materialize(emat_backend* h) {
-  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
-  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
-  if (h->slabs_on_device) return EMAT_OK;
-  auto set_error = [&](const std::string& s) { h->set_error(s); };
-  if (!h->have_ref || !h->have_evo) return fail(h, EMAT_ERR_STATE, "set_ref_sequence and set_evo must precede running");
-  if (!h->have_coal) return fail(h, EMAT_ERR_STATE, "emat_build_coalescent_parts must precede running");
+// Capacities of one part's slab: what a move may need on top of the part's present content.
+struct SlabGeo { uint32_t heap, scratch; int cell_cap; uint32_t bytes; };
+SlabGeo slab_geometry(const emat_backend* h, int n, int num_muts, uint32_t content, int nc, bool includes_run_root, double space_boost) {
   const double slack = h->cfg.slab_slack > 0 ? h->cfg.slab_slack : 3.0;
   const int trace_cap = h->cfg.trace_moves > 0 ? h->cfg.trace_moves : 0;
-  uint64_t off = 0; h->max_slab_bytes = 0; h->persistent_bytes.assign(h->parts.size(), 0); h->prefix_bytes.assign(h->parts.size(), 0);
-  struct Geo { uint32_t heap, scratch; int cell_cap; };
-  std::vector<Geo> geo(h->parts.size());
-  for (size_t p = 0; p < h->parts.size(); ++p) {
-    PartHost& ph = h->parts[p];
-    const int n = ph.tree.num_nodes();
-    const uint32_t content = heap_content_bytes(ph.tree);
-    Geo g;
-    g.heap = a16((uint32_t)(ph.space_boost * std::max<double>(2048.0, content * slack + h->cfg_heap_per_node * n)));
-    // worst case of one move: an unlimited SPR scan visits every (branch, inter-mutation segment) region of the
-    // part (48 B each) with a DFS stack of up to 4 items per region (12 B each), next to two graft analyses
-    const uint32_t regions_max = (uint32_t)n + (uint32_t)ph.tree.num_muts();
-    g.scratch = a16((uint32_t)(ph.space_boost * std::max<uint32_t>(8192u, 128u * regions_max + 4u * content + 256u * (uint32_t)n)));
-    int nc = (int)ph.coal.k_bar_p.size();
-    g.cell_cap = ph.includes_run_root ? nc + std::max(512, nc) : nc;   // room for the root part's grid to grow into the past (a part that outgrows it stops with status 103)
-    geo[p] = g;
-    uint32_t bytes = (uint32_t)sizeof(SlabHeader) + (uint32_t)n * (uint32_t)sizeof(NodeRec) + a16((uint32_t)g.cell_cap * k_cell_bytes) + a16((uint32_t)trace_cap * 32u) + g.heap + g.scratch;
-    ph.slab_off = off; ph.slab_bytes = bytes; off += bytes;
-    h->persistent_bytes[p] = bytes - g.scratch;
-    h->prefix_bytes[p] = bytes - g.scratch - g.heap;
-    h->max_slab_bytes = std::max(h->max_slab_bytes, bytes);
-  }
-  HIP_TRY(h->h_slabs.resize(off));
-  std::vector<uint64_t> offs(h->parts.size());
-  parallel_for((int)h->parts.size(), [&](int p) {
-    PartHost& ph = h->parts[p];
-    offs[p] = ph.slab_off;
-    encode_slab(*h, ph, h->h_slabs.data() + ph.slab_off, ph.slab_bytes, geo[p].heap, geo[p].scratch, geo[p].cell_cap, trace_cap);
-    // carry the statistics over re-materialisations
-    SlabHeader* H = (SlabHeader*)(h->h_slabs.data() + ph.slab_off);
-    H->moves_done = ph.stats.moves_done; for (int k = 0; k < 5; ++k) { H->proposed[k] = ph.stats.proposed[k]; H->accepted[k] = ph.stats.accepted[k]; }
-    H->alg_bytes = ph.stats.algorithmic_bytes; H->device_ticks = ph.stats.device_ticks;
-  });
+  SlabGeo g;
+  g.heap = a16((uint32_t)(space_boost * std::max<double>(2048.0, content * slack + h->cfg_heap_per_node * n)));
+  // worst case of one move: an unlimited SPR scan visits every (branch, inter-mutation segment) region of the
+  // part (48 B each) with a DFS stack of up to 4 items per region (12 B each), next to two graft analyses
+  const uint32_t regions_max = (uint32_t)n + (uint32_t)num_muts;
+  g.scratch = a16((uint32_t)(space_boost * std::max<uint32_t>(8192u, 128u * regions_max + 4u * content + 256u * (uint32_t)n)));
+  g.cell_cap = includes_run_root ? nc + std::max(512, nc) : nc;   // room for the root part's grid to grow into the past (a part that outgrows it stops with status 103)
+  g.bytes = (uint32_t)sizeof(SlabHeader) + (uint32_t)n * (uint32_t)sizeof(NodeRec) + a16((uint32_t)g.cell_cap * k_cell_bytes) + a16((uint32_t)trace_cap * 32u) + g.heap + g.scratch;
+  return g;
+}
+void place_slab(emat_backend* h, size_t p, const SlabGeo& g, uint64_t& off) {
+  PartHost& ph = h->parts[p];
+  ph.slab_off = off; ph.slab_bytes = g.bytes; off += g.bytes;
+  h->persistent_bytes[p] = g.bytes - g.scratch;
+  h->prefix_bytes[p] = g.bytes - g.scratch - g.heap;
+  h->max_slab_bytes = std::max(h->max_slab_bytes, g.bytes);
+}
+// Size classes over the parts sorted by persistent size (descending): which parts share a launch and an LDS staging area.
+void assign_size_classes(emat_backend* h) {
   {   // size classes over the parts sorted by persistent size (descending): class c closes at percentile cfg_class_pct[c]
     std::vector<uint32_t> v = h->persistent_bytes;
     std::sort(v.begin(), v.end());
@@ -1033,6 +1053,36 @@ emat_status materialize(emat_backend* h) {
       fprintf(stderr, "\n");
     }
   }
+}
+
+// Encode all parts and push them to the device.
+emat_status materialize(emat_backend* h) {
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (h->slabs_on_device) return EMAT_OK;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  if (!h->have_ref || !h->have_evo) return fail(h, EMAT_ERR_STATE, "set_ref_sequence and set_evo must precede running");
+  if (!h->have_coal) return fail(h, EMAT_ERR_STATE, "emat_build_coalescent_parts must precede running");
+  const int trace_cap = h->cfg.trace_moves > 0 ? h->cfg.trace_moves : 0;
+  uint64_t off = 0; h->max_slab_bytes = 0; h->persistent_bytes.assign(h->parts.size(), 0); h->prefix_bytes.assign(h->parts.size(), 0);
+  std::vector<SlabGeo> geo(h->parts.size());
+  for (size_t p = 0; p < h->parts.size(); ++p) {
+    PartHost& ph = h->parts[p];
+    geo[p] = slab_geometry(h, ph.tree.num_nodes(), ph.tree.num_muts(), heap_content_bytes(ph.tree), (int)ph.coal.k_bar_p.size(), ph.includes_run_root, ph.space_boost);
+    place_slab(h, p, geo[p], off);
+  }
+  HIP_TRY(h->h_slabs.resize(off));
+  std::vector<uint64_t> offs(h->parts.size());
+  parallel_for((int)h->parts.size(), [&](int p) {
+    PartHost& ph = h->parts[p];
+    offs[p] = ph.slab_off;
+    encode_slab(*h, ph, h->h_slabs.data() + ph.slab_off, ph.slab_bytes, geo[p].heap, geo[p].scratch, geo[p].cell_cap, trace_cap);
+    // carry the statistics over re-materialisations
+    SlabHeader* H = (SlabHeader*)(h->h_slabs.data() + ph.slab_off);
+    H->moves_done = ph.stats.moves_done; for (int k = 0; k < 5; ++k) { H->proposed[k] = ph.stats.proposed[k]; H->accepted[k] = ph.stats.accepted[k]; }
+    H->alg_bytes = ph.stats.algorithmic_bytes; H->device_ticks = ph.stats.device_ticks;
+  });
+  assign_size_classes(h);
   h->order_valid = false;
   HIP_TRY(h->d_slabs.upload(h->h_slabs.data(), h->h_slabs.size()));
   HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
@@ -1223,7 +1273,7 @@ emat_status emat_begin_upload(emat_backend* h, int32_t num_parts) {
   h->coal_builder.reset();
   h->fatal_status = EMAT_OK; h->fatal_message.clear(); h->pass_pending = false;
   h->parts.clear(); h->parts.resize(num_parts);
-  h->uploads_expected = num_parts; h->root_part = -1;
+  h->uploads_expected = num_parts; h->root_part = -1; h->gt.parts_live = false;
   h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false; h->have_coal = false; h->derived_valid = false;
   return EMAT_OK;
 }
@@ -1761,3 +1811,5 @@ emat_status emat_last_run_ms(emat_backend* h, double* ms) {
 }
 
 }  // extern "C"
+
+#include "emat_gtree_host.hpp"

@@ -1,0 +1,330 @@
+// emat_gtree_host.hpp -- host side of the HBM-resident whole tree: upload / download, and the two halves
+// of a cycle -- cutting the tree into part slabs and gathering the parts back -- as kernels (emat_gtree_kernels.hpp)
+// around the few things that stay on the host: slab geometry, size classes, and the coalescent cell tables, which are
+// built from a skeleton (topology + times) of every part with the same code as on the host path.
+//
+// Included at the end of emat_backend.hip.
+#ifndef EMAT_GTREE_HOST_HPP_
+#define EMAT_GTREE_HOST_HPP_
+
+namespace {
+
+const char* gt_status_text(int32_t s) {
+  switch (s) {
+    case k_gt_cut_state_overflow: return "the sequence state at a cut point is larger than the device path holds (k_gt_max_cut_intervals / k_gt_max_cut_deltas)";
+    case k_gt_pool_overflow: return "cut-state pool overflow";
+    case k_gt_list_too_long: return "a node list exceeds the 16-bit list capacity";
+    case k_gt_inconsistent: return "inconsistent mutation chain above a cut point, or a part whose node count changed";
+    case k_gt_heap_overflow: return "list heap overflow";
+    case k_gt_root_deltas_overflow: return "too many changes of the root sequence in one cycle";
+    default: return "unknown";
+  }
+}
+
+emat_status gt_require(emat_backend* h, bool need_resident) {
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (need_resident && !h->gt.resident) return fail(h, EMAT_ERR_STATE, "emat_tree_upload first");
+  return EMAT_OK;
+}
+
+emat_status gt_fetch_mirrors(emat_backend* h) {
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  GTreeHost& G = h->gt;
+  const size_t n = (size_t)G.n;
+  G.h_parent.resize(n); G.h_c0.resize(n); G.h_c1.resize(n); G.h_t.resize(n);
+  HIP_TRY(hipMemcpy(G.h_parent.data(), G.parent.p, n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(G.h_c0.data(), G.c0.p, n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(G.h_c1.data(), G.c1.p, n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(G.h_t.data(), G.t.p, n * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&G.h_root, G.root.p, 4, hipMemcpyDeviceToHost));
+  return EMAT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+emat_status emat_tree_upload(emat_backend* h, const emat_flat_tree* tree) {
+  if (!h || !tree) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, false); if (st) return st;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  const std::string msg = validate_flat_tree(*tree, h->L);
+  if (!msg.empty()) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_upload: " + msg);
+  const int n = tree->num_nodes;
+  if (tree->mut_offset[tree->root + 1] != tree->mut_offset[tree->root])
+    return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_upload: the root node must carry no mutations (fold them into the reference sequence first: Run::normalize_root)");
+  const size_t nm = (size_t)tree->mut_offset[n], ni = (size_t)tree->miss_offset[n], nf = (size_t)tree->mfs_offset[n];
+  std::vector<GList> lm(n), li(n), lf(n);
+  std::vector<MutRec> rm(nm); std::vector<IvRec> ri(ni); std::vector<FsRec> rf(nf);
+  for (int i = 0; i < n; ++i) {
+    lm[i] = GList{(uint32_t)tree->mut_offset[i], (uint32_t)(tree->mut_offset[i + 1] - tree->mut_offset[i])};
+    li[i] = GList{(uint32_t)tree->miss_offset[i], (uint32_t)(tree->miss_offset[i + 1] - tree->miss_offset[i])};
+    lf[i] = GList{(uint32_t)tree->mfs_offset[i], (uint32_t)(tree->mfs_offset[i + 1] - tree->mfs_offset[i])};
+    if (lm[i].cnt > k_gt_max_list || li[i].cnt > k_gt_max_list || lf[i].cnt > k_gt_max_list) return fail(h, EMAT_ERR_CAPACITY, "a node list exceeds the 16-bit list capacity");
+  }
+  for (size_t k = 0; k < nm; ++k) { MutRec r{}; r.t = tree->mut_t[k]; r.site = tree->mut_site[k]; r.from = tree->mut_from[k]; r.to = tree->mut_to[k]; rm[k] = r; }
+  for (size_t k = 0; k < ni; ++k) ri[k] = IvRec{tree->miss_start[k], tree->miss_end[k]};
+  for (size_t k = 0; k < nf; ++k) { FsRec r{}; r.site = tree->mfs_site[k]; r.state = tree->mfs_state[k]; rf[k] = r; }
+  GTreeHost& G = h->gt;
+  if (h->stream) HIP_TRY(hipStreamSynchronize(h->stream));
+  G.n = n;
+  HIP_TRY(G.parent.upload(tree->parent, n)); HIP_TRY(G.c0.upload(tree->child0, n)); HIP_TRY(G.c1.upload(tree->child1, n));
+  HIP_TRY(G.t.upload(tree->t, n)); HIP_TRY(G.t_min.upload(tree->t_min, n)); HIP_TRY(G.t_max.upload(tree->t_max, n));
+  HIP_TRY(G.root.upload(&tree->root, 1));
+  HIP_TRY(G.muts.upload(lm.data(), n)); HIP_TRY(G.miss.upload(li.data(), n)); HIP_TRY(G.mfs.upload(lf.data(), n));
+  // the moves create and destroy list records: room for twice the present content plus a record per node
+  HIP_TRY(G.mut_heap.alloc(2 * nm + (size_t)n + 1024)); HIP_TRY(G.iv_heap.alloc(2 * ni + (size_t)n + 1024)); HIP_TRY(G.fs_heap.alloc(2 * nf + (size_t)n + 1024));
+  if (nm) HIP_TRY(hipMemcpy(G.mut_heap.p, rm.data(), nm * sizeof(MutRec), hipMemcpyHostToDevice));
+  if (ni) HIP_TRY(hipMemcpy(G.iv_heap.p, ri.data(), ni * sizeof(IvRec), hipMemcpyHostToDevice));
+  if (nf) HIP_TRY(hipMemcpy(G.fs_heap.p, rf.data(), nf * sizeof(FsRec), hipMemcpyHostToDevice));
+  G.used[0] = (uint32_t)nm; G.used[1] = (uint32_t)ni; G.used[2] = (uint32_t)nf;
+  HIP_TRY(G.tops.upload(G.used, 3));
+  { int32_t z = 0; HIP_TRY(G.status.upload(&z, 1)); }
+  G.h_parent.assign(tree->parent, tree->parent + n); G.h_c0.assign(tree->child0, tree->child0 + n); G.h_c1.assign(tree->child1, tree->child1 + n);
+  G.h_t.assign(tree->t, tree->t + n); G.h_t_min.assign(tree->t_min, tree->t_min + n); G.h_t_max.assign(tree->t_max, tree->t_max + n);
+  G.h_root = tree->root;
+  G.resident = true; G.parts_live = false;
+  return EMAT_OK;
+}
+
+emat_status emat_tree_get_sizes(emat_backend* h, int32_t* nn, int32_t* nm, int32_t* ni, int32_t* nf) {
+  if (!h) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, true); if (st) return st;
+  if (h->gt.parts_live) return fail(h, EMAT_ERR_STATE, "the parts are out on their slabs: emat_tree_reassemble first");
+  if (nn) *nn = h->gt.n;
+  if (nm) *nm = (int32_t)h->gt.used[0];
+  if (ni) *ni = (int32_t)h->gt.used[1];
+  if (nf) *nf = (int32_t)h->gt.used[2];
+  return EMAT_OK;
+}
+
+emat_status emat_tree_download(emat_backend* h, emat_flat_tree* out, uint8_t* ref_sequence) {
+  if (!h || !out) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, true); if (st) return st;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  GTreeHost& G = h->gt;
+  if (G.parts_live) return fail(h, EMAT_ERR_STATE, "the parts are out on their slabs: emat_tree_reassemble first");
+  const int n = G.n;
+  if (out->num_nodes < n || out->cap_muts < (int32_t)G.used[0] || out->cap_intervals < (int32_t)G.used[1] || out->cap_from_states < (int32_t)G.used[2]) return EMAT_ERR_BUFFER_TOO_SMALL;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::vector<GList> lm(n), li(n), lf(n);
+  std::vector<MutRec> rm(G.used[0]); std::vector<IvRec> ri(G.used[1]); std::vector<FsRec> rf(G.used[2]);
+  HIP_TRY(hipMemcpy(lm.data(), G.muts.p, (size_t)n * sizeof(GList), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(li.data(), G.miss.p, (size_t)n * sizeof(GList), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(lf.data(), G.mfs.p, (size_t)n * sizeof(GList), hipMemcpyDeviceToHost));
+  if (!rm.empty()) HIP_TRY(hipMemcpy(rm.data(), G.mut_heap.p, rm.size() * sizeof(MutRec), hipMemcpyDeviceToHost));
+  if (!ri.empty()) HIP_TRY(hipMemcpy(ri.data(), G.iv_heap.p, ri.size() * sizeof(IvRec), hipMemcpyDeviceToHost));
+  if (!rf.empty()) HIP_TRY(hipMemcpy(rf.data(), G.fs_heap.p, rf.size() * sizeof(FsRec), hipMemcpyDeviceToHost));
+  out->num_nodes = n; out->root = G.h_root;
+  std::copy(G.h_parent.begin(), G.h_parent.end(), out->parent); std::copy(G.h_c0.begin(), G.h_c0.end(), out->child0); std::copy(G.h_c1.begin(), G.h_c1.end(), out->child1);
+  std::copy(G.h_t.begin(), G.h_t.end(), out->t); std::copy(G.h_t_min.begin(), G.h_t_min.end(), out->t_min); std::copy(G.h_t_max.begin(), G.h_t_max.end(), out->t_max);
+  int32_t km = 0, ki = 0, kf = 0;
+  out->mut_offset[0] = 0; out->miss_offset[0] = 0; out->mfs_offset[0] = 0;
+  for (int i = 0; i < n; ++i) {   // the heaps hold the lists in the order the parts wrote them: back into node order
+    if ((size_t)lm[i].off + lm[i].cnt > rm.size() || (size_t)li[i].off + li[i].cnt > ri.size() || (size_t)lf[i].off + lf[i].cnt > rf.size()) return fail(h, EMAT_ERR_INTERNAL, "emat_tree_download: list outside its heap");
+    for (uint32_t k = 0; k < lm[i].cnt; ++k, ++km) { const MutRec& r = rm[lm[i].off + k]; out->mut_t[km] = r.t; out->mut_site[km] = r.site; out->mut_from[km] = r.from; out->mut_to[km] = r.to; }
+    for (uint32_t k = 0; k < li[i].cnt; ++k, ++ki) { out->miss_start[ki] = ri[li[i].off + k].start; out->miss_end[ki] = ri[li[i].off + k].end; }
+    for (uint32_t k = 0; k < lf[i].cnt; ++k, ++kf) { out->mfs_site[kf] = rf[lf[i].off + k].site; out->mfs_state[kf] = rf[lf[i].off + k].state; }
+    out->mut_offset[i + 1] = km; out->miss_offset[i + 1] = ki; out->mfs_offset[i + 1] = kf;
+  }
+  if (ref_sequence) std::copy(h->ref.begin(), h->ref.end(), ref_sequence);
+  return EMAT_OK;
+}
+
+emat_status emat_tree_get_topology(emat_backend* h, int32_t* parent, int32_t* child0, int32_t* child1, double* t, int32_t* root) {
+  if (!h) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, true); if (st) return st;
+  const GTreeHost& G = h->gt;
+  if (G.parts_live) return fail(h, EMAT_ERR_STATE, "the parts are out on their slabs: emat_tree_reassemble first");
+  if (parent) std::copy(G.h_parent.begin(), G.h_parent.end(), parent);
+  if (child0) std::copy(G.h_c0.begin(), G.h_c0.end(), child0);
+  if (child1) std::copy(G.h_c1.begin(), G.h_c1.end(), child1);
+  if (t) std::copy(G.h_t.begin(), G.h_t.end(), t);
+  if (root) *root = G.h_root;
+  return EMAT_OK;
+}
+
+emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int32_t* part_offset, const int32_t* orig, const int32_t* kid0, const int32_t* kid1,
+                                  int32_t root_part, const uint64_t* seeds, const emat_pop_model* pm, double t_step) {
+  if (!h || num_parts <= 0 || !part_offset || !orig || !kid0 || !kid1 || !seeds || !pm || !(t_step > 0.0) || root_part < 0 || root_part >= num_parts) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, true); if (st) return st;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  if (h->cfg.max_parts > 0 && num_parts > h->cfg.max_parts) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "more parts than cfg.max_parts");
+  if (!h->have_ref || !h->have_evo) return fail(h, EMAT_ERR_STATE, "set_ref_sequence and set_evo must precede emat_tree_repartition");
+  GTreeHost& G = h->gt;
+  const int P = num_parts, n = G.n;
+  const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = now();
+  // every node is a non-root node of exactly one part; the run's root is the root of the root part
+  if (part_offset[0] != 0 || (int64_t)part_offset[P] != (int64_t)n + P - 1) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_repartition: the parts do not cover the tree");
+  const size_t total = (size_t)part_offset[P];
+  {
+    std::atomic<int> bad{0};
+    parallel_for(P, [&](int p) {
+      const int b = part_offset[p], np = part_offset[p + 1] - b;
+      if (np < 1) { bad.store(1); return; }
+      for (int s = 0; s < np; ++s) {
+        const int32_t o = orig[b + s], k0 = kid0[b + s], k1 = kid1[b + s];
+        if (o < 0 || o >= n || (k0 == EMAT_NO_NODE) != (k1 == EMAT_NO_NODE)) { bad.store(1); return; }
+        if (k0 != EMAT_NO_NODE && (k0 <= 0 || k0 >= np || k1 <= 0 || k1 >= np || G.h_c0[o] == EMAT_NO_NODE)) { bad.store(1); return; }
+      }
+    }, 64);
+    if (bad.load() || orig[part_offset[root_part]] != G.h_root) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_repartition: malformed partition");
+  }
+  if (h->stream) HIP_TRY(hipStreamSynchronize(h->stream));
+  try { h->pop = HostPopModel::from_c(*pm); } catch (const std::exception& ex) { return fail(h, EMAT_ERR_INVALID_ARGUMENT, ex.what()); }
+  h->have_pop = true; h->model_dirty = true;
+  st = sync_model_to_device(h); if (st) return st;
+  G.P = P; G.root_part = root_part; G.parts_live = false;
+  HIP_TRY(G.part_off.upload(part_offset, (size_t)P + 1)); HIP_TRY(G.orig.upload(orig, total)); HIP_TRY(G.kid0.upload(kid0, total)); HIP_TRY(G.kid1.upload(kid1, total));
+  HIP_TRY(G.measure.alloc(P));
+  HIP_TRY(G.pool_muts.alloc(std::max<size_t>(G.pool_muts.n, (size_t)64 * P + 4096))); HIP_TRY(G.pool_ivs.alloc(std::max<size_t>(G.pool_ivs.n, (size_t)64 * P + 4096)));
+  HIP_TRY(G.pool_tops.alloc(2));
+  const auto t1 = now();
+  auto launch_measure = [&]() -> emat_status {
+    HIP_TRY(hipMemsetAsync(G.pool_tops.p, 0, 2 * sizeof(uint32_t), h->stream));
+    hipLaunchKernelGGL(k_gt_measure, dim3((unsigned)P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const uint8_t*)h->d_ref.p, G.measure.p);
+    HIP_TRY(hipGetLastError());
+    return EMAT_OK;
+  };
+  st = launch_measure(); if (st) return st;
+  // while the device measures: skeletons of the parts (topology + times), and from them the coalescent cell tables
+  h->coal_builder.reset();
+  h->fatal_status = EMAT_OK; h->fatal_message.clear(); h->pass_pending = false;
+  h->parts.clear(); h->parts.resize(P);
+  h->uploads_expected = 0; h->root_part = root_part;
+  h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false; h->have_coal = false; h->derived_valid = false;
+  parallel_for(P, [&](int p) {
+    PartHost& ph = h->parts[p];
+    const int b = part_offset[p], np = part_offset[p + 1] - b;
+    FlatTree& t = ph.tree;
+    t.resize_nodes(np); t.root = 0;
+    for (int s = 0; s < np; ++s) {
+      const int32_t o = orig[b + s], k0 = kid0[b + s], k1 = kid1[b + s];
+      t.child0[s] = k0; t.child1[s] = k1;
+      if (k0 != EMAT_NO_NODE) { t.parent[k0] = s; t.parent[k1] = s; }
+      t.t[s] = G.h_t[o];
+      if (k0 == EMAT_NO_NODE && G.h_c0[o] != EMAT_NO_NODE) { t.t_min[s] = (float)G.h_t[o]; t.t_max[s] = (float)G.h_t[o]; }
+      else { t.t_min[s] = G.h_t_min[o]; t.t_max[s] = G.h_t_max[o]; }
+    }
+    ph.includes_run_root = p == root_part;
+    ph.rng.key = seeds[p]; ph.rng.counter = 0; ph.rng.spare = 0; ph.rng.has_spare = false;
+    ph.uploaded = true; ph.stats = emat_part_stats{}; ph.expected_moves = 0; ph.space_boost = 1.0; ph.trace.clear();
+  }, 64);
+  const auto t2 = now();
+  try {
+    std::vector<const FlatTree*> trees; std::vector<HostRng*> rngs;
+    for (auto& ph : h->parts) { trees.push_back(&ph.tree); rngs.push_back(&ph.rng); }
+    auto cps = make_coalescent_parts(trees, root_part, h->pop, rngs, t_step);
+    for (int p = 0; p < P; ++p) h->parts[p].coal = std::move(cps[p]);
+  } catch (const std::exception& ex) { return fail(h, EMAT_ERR_INVALID_ARGUMENT, ex.what()); }
+  h->have_coal = true;
+  const auto t3 = now();
+  std::vector<GMeasure> me(P);
+  for (int attempt = 0;; ++attempt) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(me.data(), G.measure.p, (size_t)P * sizeof(GMeasure), hipMemcpyDeviceToHost));
+    int32_t worst = k_gt_ok; int who = -1;
+    for (int p = 0; p < P; ++p) if (me[p].status != k_gt_ok && (worst == k_gt_ok || me[p].status != k_gt_pool_overflow)) { worst = me[p].status; who = p; if (worst != k_gt_pool_overflow) break; }
+    if (worst == k_gt_ok) break;
+    if (worst != k_gt_pool_overflow || attempt == 4) return fail(h, worst == k_gt_cut_state_overflow || worst == k_gt_list_too_long ? EMAT_ERR_CAPACITY : EMAT_ERR_INTERNAL,
+                                                                  "emat_tree_repartition: part " + std::to_string(who) + ": " + gt_status_text(worst));
+    uint32_t tops[2];
+    HIP_TRY(hipMemcpy(tops, G.pool_tops.p, sizeof(tops), hipMemcpyDeviceToHost));   // the atomics kept counting: what the pools need
+    HIP_TRY(G.pool_muts.alloc((size_t)tops[0] * 2 + 4096)); HIP_TRY(G.pool_ivs.alloc((size_t)tops[1] * 2 + 4096));
+    st = launch_measure(); if (st) return st;
+  }
+  const auto t4 = now();
+  // geometry, placement, size classes: as for host-encoded parts
+  const int trace_cap = h->cfg.trace_moves > 0 ? h->cfg.trace_moves : 0;
+  uint64_t off = 0; h->max_slab_bytes = 0; h->persistent_bytes.assign(P, 0); h->prefix_bytes.assign(P, 0);
+  std::vector<GPartDesc> desc(P); std::vector<uint64_t> offs(P);
+  uint64_t cells_bytes = 0;
+  for (int p = 0; p < P; ++p) {
+    PartHost& ph = h->parts[p];
+    const int nc = (int)ph.coal.k_bar_p.size();
+    const SlabGeo g = slab_geometry(h, me[p].n_nodes, me[p].num_muts, me[p].content_bytes, nc, ph.includes_run_root, ph.space_boost);
+    place_slab(h, (size_t)p, g, off);
+    offs[p] = ph.slab_off;
+    GPartDesc d{};
+    d.slab_bytes = g.bytes; d.heap_bytes = g.heap; d.scratch_bytes = g.scratch; d.cell_cap = g.cell_cap; d.trace_cap = trace_cap;
+    d.flags = ph.includes_run_root ? k_flag_includes_run_root : 0u;
+    d.rng_key = ph.rng.key; d.rng_counter = ph.rng.counter; d.rng_spare = ph.rng.spare; d.rng_has_spare = ph.rng.has_spare ? 1u : 0u;
+    d.cell_first = ph.coal.cell_first; d.n_cells = nc; d.n_cells_total = ph.coal.n_cells_total; d.t_ref = ph.coal.t_ref; d.t_step = ph.coal.t_step;
+    d.cells_off = cells_bytes; cells_bytes += (uint64_t)nc * 32u + (((uint64_t)nc * 4u + 7u) & ~(uint64_t)7u);
+    desc[p] = d;
+  }
+  assign_size_classes(h);
+  h->order_valid = false;
+  std::vector<uint8_t> cells(cells_bytes);
+  parallel_for(P, [&](int p) {
+    const HostCoalPart& c = h->parts[p].coal; const size_t nc = c.k_bar_p.size();
+    double* w = (double*)(cells.data() + desc[p].cells_off);
+    std::copy(c.k_bar_p.begin(), c.k_bar_p.end(), w); std::copy(c.k_twiddle_bar_p.begin(), c.k_twiddle_bar_p.end(), w + nc);
+    std::copy(c.k_twiddle_bar.begin(), c.k_twiddle_bar.end(), w + 2 * nc); std::copy(c.popsize_bar.begin(), c.popsize_bar.end(), w + 3 * nc);
+    std::copy(c.num_active_parts.begin(), c.num_active_parts.end(), (int32_t*)(w + 4 * nc));
+  }, 64);
+  HIP_TRY(G.desc.upload(desc.data(), (size_t)P)); HIP_TRY(G.cells.upload(cells.data(), cells.size()));
+  HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
+  HIP_TRY(h->d_slabs.alloc(off)); HIP_TRY(h->h_slabs.resize(off));
+  HIP_TRY(h->d_part_ticks.alloc(2 * (size_t)P)); HIP_TRY(hipMemsetAsync(h->d_part_ticks.p, 0, 2 * (size_t)P * sizeof(int64_t), h->stream));
+  HIP_TRY(h->d_part_status.alloc((size_t)P)); HIP_TRY(hipMemsetAsync(h->d_part_status.p, 0, (size_t)P * sizeof(int32_t), h->stream));
+  hipLaunchKernelGGL(k_gt_build, dim3((unsigned)P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const GMeasure*)G.measure.p, (const GPartDesc*)G.desc.p,
+                     (const uint8_t*)G.cells.p, h->d_slabs.p, (const uint64_t*)h->d_slab_off.p);
+  HIP_TRY(hipGetLastError());
+  h->slabs_on_device = true; h->host_slabs_current = false; h->headers_current = false; h->derived_valid = false;
+  G.parts_live = true;
+  if (verbose) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    fprintf(stderr, "[emat] tree_repartition: checks + uploads %.1f ms | skeletons %.1f ms | coalescent cells %.1f ms | wait for k_gt_measure %.1f ms | geometry + cells + k_gt_build %.1f ms\n",
+            ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
+  }
+  return EMAT_OK;
+}
+
+emat_status emat_tree_reassemble(emat_backend* h, int32_t* num_root_deltas, int32_t* site, uint8_t* from, uint8_t* to, int32_t capacity) {
+  if (!h || (capacity > 0 && (!site || !from || !to))) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, true); if (st) return st;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  GTreeHost& G = h->gt;
+  if (!G.parts_live) return fail(h, EMAT_ERR_STATE, "emat_tree_repartition first");
+  if ((int)h->parts.size() != G.P) return fail(h, EMAT_ERR_STATE, "the parts on the device are not the ones emat_tree_repartition made");
+  st = finish_pass(h); if (st) return st;          // every chain ran to completion (or was given more room and finished)
+  st = materialize(h); if (st) return st;          // (a recovery leaves the parts decoded on the host: back onto their slabs)
+  HIP_TRY(G.root_deltas.alloc(k_gt_max_root_deltas)); HIP_TRY(G.n_root_deltas.alloc(1));
+  int32_t status = 0, nd = 0;
+  for (int attempt = 0;; ++attempt) {
+    HIP_TRY(hipMemsetAsync(G.tops.p, 0, 3 * sizeof(uint32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(G.status.p, 0, sizeof(int32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(G.n_root_deltas.p, 0, sizeof(int32_t), h->stream));
+    hipLaunchKernelGGL(k_gt_gather, dim3((unsigned)G.P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), (const uint8_t*)h->d_slabs.p, (const uint64_t*)h->d_slab_off.p,
+                       h->d_ref.p, G.root_deltas.p, G.n_root_deltas.p, G.status.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(&status, G.status.p, sizeof(status), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(G.used, G.tops.p, sizeof(G.used), hipMemcpyDeviceToHost));
+    if (status == k_gt_ok) break;
+    if (status != k_gt_heap_overflow || attempt == 2) return fail(h, EMAT_ERR_INTERNAL, std::string("emat_tree_reassemble: ") + gt_status_text(status));
+    // the atomics kept counting: G.used is what the heaps need (nothing of the old content is read by the gather)
+    HIP_TRY(G.mut_heap.alloc((size_t)G.used[0] * 2 + 1024)); HIP_TRY(G.iv_heap.alloc((size_t)G.used[1] * 2 + 1024)); HIP_TRY(G.fs_heap.alloc((size_t)G.used[2] * 2 + 1024));
+  }
+  HIP_TRY(hipMemcpy(&nd, G.n_root_deltas.p, sizeof(nd), hipMemcpyDeviceToHost));
+  std::vector<GRootDelta> rd((size_t)nd);
+  if (nd > 0) HIP_TRY(hipMemcpy(rd.data(), G.root_deltas.p, (size_t)nd * sizeof(GRootDelta), hipMemcpyDeviceToHost));
+  if (nd > 0) {   // the reference sequence moved with the root sequence: its derived tables follow (the device copy of `ref` is already current)
+    for (const GRootDelta& d : rd) h->ref[d.site] = d.to;
+    refresh_ref_derived(h);
+  }
+  st = gt_fetch_mirrors(h); if (st) return st;
+  G.parts_live = false;
+  if (num_root_deltas) *num_root_deltas = nd;
+  if (nd > capacity) return capacity > 0 || num_root_deltas == nullptr ? fail(h, EMAT_ERR_BUFFER_TOO_SMALL, "emat_tree_reassemble: more root changes than the caller has room for (the tree itself is complete; emat_tree_download returns the reference sequence)") : EMAT_OK;
+  for (int k = 0; k < nd; ++k) { site[k] = rd[k].site; from[k] = rd[k].from; to[k] = rd[k].to; }
+  return EMAT_OK;
+}
+
+}  // extern "C"
+#endif  // EMAT_GTREE_HOST_HPP_

@@ -1,0 +1,352 @@
+// emat_gtree_kernels.hpp -- the whole tree resident in HBM: cutting it into part slabs and gathering the parts back
+// without a host round trip of nodes, mutations and missations.
+//
+// Reference: Run::repartition (core/run.cpp:110-193) copies every part's nodes out of the whole Phylo_tree into a
+// Subrun's tree, giving each sub-root the sequence state at its cut point (reconstruct_missing_sites_at /
+// view_of_sequence_at, core/phylo_tree_calc.cpp:19-56); Run::reassemble (core/run.cpp:195-256) copies them back.
+// Here the whole tree lives in HBM as node arrays + three record heaps, a partition is three int arrays from the host
+// (which only ever sees the topology), and one wavefront per part does the copying in both directions.
+//
+// Included by emat_backend.hip (needs emat_slab.hpp and k_wave).
+#ifndef EMAT_GTREE_KERNELS_HPP_
+#define EMAT_GTREE_KERNELS_HPP_
+
+namespace emat {
+
+struct GList { uint32_t off, cnt; };   // records [off, off + cnt) of the heap of its kind
+
+struct GTreeDev {
+  int32_t n_nodes;
+  int32_t* root;                     // [1]
+  int32_t* parent; int32_t* c0; int32_t* c1;
+  double* t; const float* t_min; const float* t_max;
+  GList* muts; GList* miss; GList* mfs;   // per node
+  MutRec* mut_heap; IvRec* iv_heap; FsRec* fs_heap;
+  uint32_t mut_cap, iv_cap, fs_cap;
+  uint32_t* tops;                    // [3] next free record of each heap (a gather rebuilds all three from zero)
+};
+
+struct GPartition {
+  int32_t num_parts, root_part;
+  const int32_t* part_off;           // [P + 1] into orig / kid0 / kid1
+  const int32_t* orig;               // part-local node -> whole-tree node; local node 0 is the part's cut point
+  const int32_t* kid0; const int32_t* kid1;   // part-local children (EMAT_NO_NODE for the part's tips)
+};
+
+enum GStatus : int32_t { k_gt_ok = 0, k_gt_cut_state_overflow = 1, k_gt_pool_overflow = 2, k_gt_list_too_long = 3, k_gt_inconsistent = 4, k_gt_heap_overflow = 5, k_gt_root_deltas_overflow = 6 };
+
+struct GMeasure {                    // per part, written by k_gt_measure
+  int32_t n_nodes, num_muts;
+  uint32_t content_bytes;            // heap bytes of the part's lists, every list rounded up to 16 (encode_slab's layout)
+  uint32_t root_muts_off, root_muts_cnt, root_miss_off, root_miss_cnt;   // the cut point's state, in the pools
+  int32_t status;
+};
+
+struct GPools { MutRec* muts; IvRec* ivs; uint32_t mut_cap, iv_cap; uint32_t* tops; /* [2] */ };
+
+struct GPartDesc {                   // per part, from the host: geometry of the slab + what its header starts with
+  uint32_t slab_bytes, heap_bytes, scratch_bytes;
+  int32_t cell_cap, trace_cap;
+  uint32_t flags;
+  uint64_t rng_key, rng_counter, rng_spare; uint32_t rng_has_spare;
+  int32_t cell_first, n_cells, n_cells_total;
+  double t_ref, t_step;
+  uint64_t cells_off;                // byte offset of the part's packed cells: 4 double arrays [n_cells] then 1 int32 array [n_cells]
+};
+
+constexpr int k_gt_max_cut_intervals = 1024;
+constexpr int k_gt_max_cut_deltas = 1024;
+constexpr int k_gt_max_root_deltas = 256;
+constexpr uint32_t k_gt_max_list = 16000;   // ListRef counts are 16 bits (same limit as emat_part_upload)
+
+__device__ inline uint32_t gt_a16(uint32_t x) { return (x + 15u) & ~15u; }
+__device__ inline bool gt_iv_contains(const IvRec* v, int n, int l) {   // sorted, disjoint, half-open
+  int lo = 0, hi = n;
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (v[mid].start <= l) lo = mid + 1; else hi = mid; }
+  return lo > 0 && l < v[lo - 1].end;
+}
+__device__ inline uint32_t wave_incl_scan_u32(uint32_t x, int lane) {
+  for (int d = 1; d < k_wave; d <<= 1) { uint32_t y = __shfl_up(x, d, k_wave); if (lane >= d) x += y; }
+  return x;
+}
+__device__ inline uint32_t wave_sum_u32(uint32_t x) {
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, k_wave);
+  return __shfl(x, 0, k_wave);
+}
+
+// ---- pass 1 of a repartition: the state at every cut point + how much list content every part holds ------------
+// State at a cut point c = the sites missing at c (union of the missations from c up to the root) and the net changes
+// reference sequence -> sequence at c, sorted by site, over the sites present at c.  The walk goes UP from c, so later
+// mutations are met first: a site's entry keeps the `to` of the first mutation met and takes the `from` of every
+// further one; entries that end with from == to cancel.
+struct GCutDelta { int32_t site; uint8_t from, to; uint16_t pad; };
+
+__global__ void __launch_bounds__(k_wave) k_gt_measure(GTreeDev g, GPartition pt, GPools pools, const uint8_t* ref, GMeasure* out) {
+  __shared__ IvRec acc[2][k_gt_max_cut_intervals];
+  __shared__ GCutDelta dl[k_gt_max_cut_deltas];
+  __shared__ int sh[4];
+  __shared__ uint32_t sh_off[2];
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int base = pt.part_off[p], n = pt.part_off[p + 1] - base;
+  if (lane == 0) {
+    int status = k_gt_ok, cur_buf = 0, n_acc = 0, n_dl = 0;
+    const int32_t tree_root = g.root[0];
+    for (int32_t cur = pt.orig[base]; cur != EMAT_NO_NODE && status == k_gt_ok; cur = g.parent[cur]) {
+      const GList mi = g.miss[cur], mu = g.muts[cur];
+      if (mi.cnt != 0) {   // union with merging of touching intervals (interval_set.h:238-288)
+        const IvRec* B = g.iv_heap + mi.off; const IvRec* A = acc[cur_buf]; IvRec* O = acc[cur_buf ^ 1];
+        uint32_t ia = 0, ib = 0; int no = 0; bool inside = false; int cs = 0, ce = 0;
+        while (!(ia == (uint32_t)n_acc && ib == mi.cnt)) {
+          const bool useA = (ia == (uint32_t)n_acc) ? false : (ib == mi.cnt) ? true : (A[ia].start <= B[ib].start);
+          const IvRec f = useA ? A[ia] : B[ib];
+          if (!inside) { cs = f.start; ce = f.end; if (useA) ++ia; else ++ib; inside = true; }
+          else if (f.start <= ce) { ce = f.end > ce ? f.end : ce; if (useA) ++ia; else ++ib; }
+          else { if (no >= k_gt_max_cut_intervals) { status = k_gt_cut_state_overflow; break; } O[no++] = IvRec{cs, ce}; inside = false; }
+        }
+        if (inside) { if (no >= k_gt_max_cut_intervals) status = k_gt_cut_state_overflow; else O[no++] = IvRec{cs, ce}; }
+        cur_buf ^= 1; n_acc = no;
+      }
+      if (cur != tree_root) {   // what the root node carries are not events (they are folded into the reference at every gather)
+        const MutRec* M = g.mut_heap + mu.off;
+        for (int k = (int)mu.cnt - 1; k >= 0 && status == k_gt_ok; --k) {
+          const MutRec m = M[k];
+          int lo = 0, hi = n_dl;
+          while (lo < hi) { int mid = (lo + hi) >> 1; if (dl[mid].site < m.site) lo = mid + 1; else hi = mid; }
+          if (lo < n_dl && dl[lo].site == m.site) { if (dl[lo].from != m.to) status = k_gt_inconsistent; dl[lo].from = m.from; }
+          else if (n_dl >= k_gt_max_cut_deltas) status = k_gt_cut_state_overflow;
+          else { for (int j = n_dl; j > lo; --j) dl[j] = dl[j - 1]; dl[lo] = GCutDelta{m.site, m.from, m.to, 0}; ++n_dl; }
+        }
+      } else if (mu.cnt != 0) status = k_gt_inconsistent;
+    }
+    // what the sub-root of the part carries (run.cpp:141-153): the missing sites, and the net changes over the present ones
+    int n_keep = 0;
+    const IvRec* A = acc[cur_buf];
+    if (status == k_gt_ok) {
+      for (int k = 0; k < n_dl; ++k) {
+        const GCutDelta d = dl[k];
+        if (d.from == d.to || gt_iv_contains(A, n_acc, d.site)) continue;
+        if (d.from != ref[d.site]) { status = k_gt_inconsistent; break; }
+        dl[n_keep++] = d;
+      }
+    }
+    uint32_t om = 0, oi = 0;
+    if (status == k_gt_ok) {
+      om = atomicAdd(&pools.tops[0], (uint32_t)n_keep); oi = atomicAdd(&pools.tops[1], (uint32_t)n_acc);
+      if (om + (uint32_t)n_keep > pools.mut_cap || oi + (uint32_t)n_acc > pools.iv_cap) status = k_gt_pool_overflow;
+      if ((uint32_t)n_keep > k_gt_max_list || (uint32_t)n_acc > k_gt_max_list) status = k_gt_list_too_long;
+    }
+    sh[0] = status; sh[1] = n_keep; sh[2] = n_acc; sh[3] = cur_buf; sh_off[0] = om; sh_off[1] = oi;
+    GMeasure m{}; m.n_nodes = n; m.root_muts_off = om; m.root_muts_cnt = (uint32_t)n_keep; m.root_miss_off = oi; m.root_miss_cnt = (uint32_t)n_acc; m.status = status;
+    out[p] = m;
+  }
+  __syncthreads();
+  const int status = sh[0], n_keep = sh[1], n_acc = sh[2];
+  if (status != k_gt_ok) return;
+  const IvRec* A = acc[sh[3]];
+  const uint32_t pool_m = sh_off[0], pool_i = sh_off[1];
+  for (int k = lane; k < n_keep; k += k_wave) { const GCutDelta d = dl[k]; MutRec r; r.t = -1.7976931348623157e308; r.site = d.site; r.from = d.from; r.to = d.to; r.pad = 0; pools.muts[pool_m + k] = r; }
+  for (int k = lane; k < n_acc; k += k_wave) pools.ivs[pool_i + k] = A[k];
+  // list content of the other nodes
+  uint32_t content = 0, nm_tot = 0; int bad = 0;
+  for (int s = 1 + lane; s < n; s += k_wave) {
+    const int32_t o = pt.orig[base + s];
+    const uint32_t nm = g.muts[o].cnt, ni = g.miss[o].cnt, nf = g.mfs[o].cnt;
+    if (nm > k_gt_max_list || ni > k_gt_max_list || nf > k_gt_max_list) bad = 1;
+    content += gt_a16(nm * 16u) + gt_a16(ni * 8u) + gt_a16(nf * 8u); nm_tot += nm;
+  }
+  content = wave_sum_u32(content); nm_tot = wave_sum_u32(nm_tot); bad = (int)wave_sum_u32((uint32_t)bad);
+  if (lane == 0) {
+    out[p].content_bytes = content + gt_a16((uint32_t)n_keep * 16u) + gt_a16((uint32_t)n_acc * 8u);
+    out[p].num_muts = (int32_t)(nm_tot + (uint32_t)n_keep);
+    if (bad) out[p].status = k_gt_list_too_long;
+  }
+}
+
+// ---- pass 2: write every part's slab, byte for byte what encode_slab writes for the same part -----------------------
+__global__ void __launch_bounds__(k_wave) k_gt_build(GTreeDev g, GPartition pt, GPools pools, const GMeasure* measure, const GPartDesc* desc, const uint8_t* cells,
+                                                     uint8_t* slabs, const uint64_t* slab_off) {
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int base = pt.part_off[p], n = pt.part_off[p + 1] - base;
+  const GPartDesc d = desc[p]; const GMeasure me = measure[p];
+  uint8_t* slab = slabs + slab_off[p];
+  {   // everything but the scratch tail starts out zero
+    uint4* z = (uint4*)slab; const uint32_t n16 = (d.slab_bytes - d.scratch_bytes) / 16u;
+    for (uint32_t i = lane; i < n16; i += k_wave) z[i] = uint4{0u, 0u, 0u, 0u};
+  }
+  __syncthreads();
+  SlabHeader* H = (SlabHeader*)slab;
+  uint32_t off = (uint32_t)sizeof(SlabHeader);
+  const uint32_t off_nodes = off; off += (uint32_t)n * (uint32_t)sizeof(NodeRec);
+  const uint32_t off_cells = off; off += gt_a16((uint32_t)d.cell_cap * k_cell_bytes);
+  const uint32_t off_trace = off; off += gt_a16((uint32_t)d.trace_cap * 32u);
+  const uint32_t heap_begin = off;
+  NodeRec* N = (NodeRec*)(slab + off_nodes);
+  uint32_t carry = 0;
+  for (int s0 = 0; s0 < n; s0 += k_wave) {
+    const int s = s0 + lane;
+    uint32_t nm = 0, ni = 0, nf = 0; int32_t o = EMAT_NO_NODE;
+    GList lm{0, 0}, li{0, 0}, lf{0, 0};
+    if (s < n) {
+      o = pt.orig[base + s];
+      if (s == 0) { nm = me.root_muts_cnt; ni = me.root_miss_cnt; }
+      else { lm = g.muts[o]; li = g.miss[o]; lf = g.mfs[o]; nm = lm.cnt; ni = li.cnt; nf = lf.cnt; }
+    }
+    const uint32_t bm = gt_a16(nm * 16u), bi = gt_a16(ni * 8u), bf = gt_a16(nf * 8u), bytes = bm + bi + bf;
+    const uint32_t incl = wave_incl_scan_u32(bytes, lane);
+    const uint32_t top = heap_begin + carry + incl - bytes;
+    carry += __shfl(incl, k_wave - 1, k_wave);
+    if (s < n) {
+      NodeRec& r = N[s];
+      const int32_t k0 = pt.kid0[base + s], k1 = pt.kid1[base + s];
+      r.child0 = k0; r.child1 = k1;
+      if (s == 0) r.parent = EMAT_NO_NODE;
+      if (k0 != EMAT_NO_NODE) { N[k0].parent = s; N[k1].parent = s; }
+      const double t = g.t[o];
+      r.t = t;
+      if (k0 == EMAT_NO_NODE && g.c0[o] != EMAT_NO_NODE) { r.t_min = (float)t; r.t_max = (float)t; }   // frozen boundary node (run.cpp:165-168)
+      else { r.t_min = g.t_min[o]; r.t_max = g.t_max[o]; }
+      r.muts.off = top; r.muts.cnt = (uint16_t)nm; r.muts.cap = (uint16_t)(bm / 16u);
+      r.miss.off = top + bm; r.miss.cnt = (uint16_t)ni; r.miss.cap = (uint16_t)(bi / 8u);
+      r.mfs.off = top + bm + bi; r.mfs.cnt = (uint16_t)nf; r.mfs.cap = (uint16_t)(bf / 8u);
+      const MutRec* sm = s == 0 ? pools.muts + me.root_muts_off : g.mut_heap + lm.off;
+      const IvRec* si = s == 0 ? pools.ivs + me.root_miss_off : g.iv_heap + li.off;
+      const FsRec* sf = g.fs_heap + lf.off;
+      MutRec* dm = (MutRec*)(slab + top); IvRec* di = (IvRec*)(slab + top + bm); FsRec* df = (FsRec*)(slab + top + bm + bi);
+      for (uint32_t k = 0; k < nm; ++k) dm[k] = sm[k];
+      for (uint32_t k = 0; k < ni; ++k) di[k] = si[k];
+      for (uint32_t k = 0; k < nf; ++k) df[k] = sf[k];
+    }
+  }
+  {   // coalescent window (encode_slab's cell table)
+    const double* src = (const double*)(cells + d.cells_off);
+    double* cb = (double*)(slab + off_cells);
+    const int nc = d.n_cells, cap = d.cell_cap;
+    const int32_t* na = (const int32_t*)(src + 4 * (size_t)nc);
+    for (int w = lane; w < nc; w += k_wave) {
+      const double pb = src[3 * (size_t)nc + w];
+      cb[w] = src[w]; cb[cap + w] = src[(size_t)nc + w]; cb[2 * cap + w] = src[2 * (size_t)nc + w]; cb[3 * cap + w] = pb;
+      cb[4 * cap + w] = d.t_step / pb;
+      ((int32_t*)(cb + 5 * cap))[w] = na[w];
+    }
+  }
+  if (lane == 0) {
+    H->magic = k_slab_magic; H->slab_bytes = d.slab_bytes; H->n_nodes = n; H->root = 0;
+    H->flags = d.flags; H->status = 0; H->rng_key = d.rng_key; H->rng_counter = d.rng_counter; H->rng_spare = d.rng_spare; H->rng_has_spare = d.rng_has_spare;
+    H->off_nodes = off_nodes; H->off_cells = off_cells; H->off_trace = off_trace;
+    H->heap_begin = heap_begin; H->heap_top = heap_begin + carry; H->heap_end = heap_begin + d.heap_bytes;
+    H->scratch_begin = H->heap_end; H->scratch_end = H->scratch_begin + d.scratch_bytes;
+    H->cell_first = d.cell_first; H->n_cells = d.n_cells; H->cell_cap = d.cell_cap; H->n_cells_total = d.n_cells_total;
+    H->t_ref = d.t_ref; H->t_step = d.t_step;
+    H->trace_cap = d.trace_cap; H->trace_len = 0;
+  }
+}
+
+// ---- gather: every part writes the nodes it owns back into the whole tree (run.cpp:195-256) ---------------------------
+// Every node of the whole tree is a non-root node of exactly one part (the run's root: the root of the root part); that
+// part writes its time, lists and child links, and the parent links of its children.  The three heaps are rebuilt from
+// zero, each part reserving its share with one atomic per heap.  What the run's root carries afterwards -- the changes
+// reference sequence -> root sequence -- is folded into the reference on the way (Run::normalize_root +
+// rereference_to_root_sequence, run.cpp:258-265, phylo_tree.cpp:299-322): the root ends up without mutations, and the
+// from-states of every missation that covers a changed site are rewritten (mutations.h:212-232).
+struct GRootDelta { int32_t site; uint8_t from, to; uint16_t pad; };
+
+// from-states of one node after the reference changed at the sites of R (sorted by site); writes them to `out` when it
+// is not null; returns their number
+__device__ inline uint32_t gt_rereferenced_from_states(const FsRec* fs, uint32_t nf, const IvRec* miss, uint32_t ni, const GRootDelta* R, int nR, FsRec* out) {
+  if (ni == 0 || nR == 0) { if (out) for (uint32_t k = 0; k < nf; ++k) out[k] = fs[k]; return nf; }
+  uint32_t k = 0, w = 0;
+  for (int j = 0; j < nR; ++j) {
+    const GRootDelta d = R[j];
+    if (!gt_iv_contains(miss, (int)ni, d.site)) continue;
+    while (k < nf && fs[k].site < d.site) { if (out) out[w] = fs[k]; ++w; ++k; }
+    if (k < nf && fs[k].site == d.site) { if (fs[k].state != d.to) { if (out) out[w] = fs[k]; ++w; } ++k; }   // it now equals the reference: dropped
+    else if (d.from != d.to) { if (out) { FsRec f{}; f.site = d.site; f.state = d.from; out[w] = f; } ++w; }      // it was the old reference state
+  }
+  while (k < nf) { if (out) out[w] = fs[k]; ++w; ++k; }
+  return w;
+}
+
+__global__ void __launch_bounds__(k_wave) k_gt_gather(GTreeDev g, GPartition pt, const uint8_t* slabs, const uint64_t* slab_off, uint8_t* ref,
+                                                      GRootDelta* root_deltas_out, int32_t* n_root_deltas_out, int32_t* status_out) {
+  __shared__ GRootDelta R[k_gt_max_root_deltas];
+  __shared__ uint32_t sh_base[3];
+  __shared__ int sh_nR;
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int base = pt.part_off[p], n = pt.part_off[p + 1] - base;
+  const uint8_t* slab = slabs + slab_off[p];
+  const SlabHeader* H = (const SlabHeader*)slab;
+  const NodeRec* N = (const NodeRec*)(slab + H->off_nodes);
+  const bool is_root_part = p == pt.root_part;
+  {
+    const uint8_t* rs = slabs + slab_off[pt.root_part];
+    const SlabHeader* Hr = (const SlabHeader*)rs;
+    const NodeRec& rn = ((const NodeRec*)(rs + Hr->off_nodes))[Hr->root];
+    const int nR = rn.muts.cnt;
+    if (nR > k_gt_max_root_deltas) { if (lane == 0) atomicMax(status_out, (int32_t)k_gt_root_deltas_overflow); return; }
+    const MutRec* M = (const MutRec*)(rs + rn.muts.off);
+    for (int k = lane; k < nR; k += k_wave) { GRootDelta d{}; d.site = M[k].site; d.from = M[k].from; d.to = M[k].to; R[k] = d; }
+    if (lane == 0) sh_nR = nR;
+  }
+  __syncthreads();
+  const int nR = sh_nR;
+  if (H->n_nodes != n) { if (lane == 0) atomicMax(status_out, (int32_t)k_gt_inconsistent); return; }
+  const int local_root = H->root;
+  // totals of the part -> its share of the three heaps
+  uint32_t tm = 0, ti = 0, tf = 0;
+  for (int s = lane; s < n; s += k_wave) {
+    const bool is_lr = s == local_root;
+    if (is_lr && !is_root_part) continue;
+    const NodeRec& r = N[s];
+    tm += is_lr ? 0u : r.muts.cnt; ti += r.miss.cnt;
+    tf += gt_rereferenced_from_states((const FsRec*)(slab + r.mfs.off), r.mfs.cnt, (const IvRec*)(slab + r.miss.off), r.miss.cnt, R, nR, nullptr);
+  }
+  tm = wave_sum_u32(tm); ti = wave_sum_u32(ti); tf = wave_sum_u32(tf);
+  if (lane == 0) {
+    sh_base[0] = atomicAdd(&g.tops[0], tm); sh_base[1] = atomicAdd(&g.tops[1], ti); sh_base[2] = atomicAdd(&g.tops[2], tf);
+    if (sh_base[0] + tm > g.mut_cap || sh_base[1] + ti > g.iv_cap || sh_base[2] + tf > g.fs_cap) { atomicMax(status_out, (int32_t)k_gt_heap_overflow); sh_base[0] = 0xffffffffu; }
+  }
+  __syncthreads();
+  if (sh_base[0] == 0xffffffffu) return;
+  uint32_t cm = sh_base[0], ci = sh_base[1], cf = sh_base[2];
+  for (int s0 = 0; s0 < n; s0 += k_wave) {
+    const int s = s0 + lane;
+    uint32_t nm = 0, ni = 0, nf = 0; bool owns = false;
+    if (s < n) {
+      const bool is_lr = s == local_root;
+      owns = !is_lr || is_root_part;
+      if (owns) {
+        const NodeRec& r = N[s];
+        nm = is_lr ? 0u : r.muts.cnt; ni = r.miss.cnt;
+        nf = gt_rereferenced_from_states((const FsRec*)(slab + r.mfs.off), r.mfs.cnt, (const IvRec*)(slab + r.miss.off), r.miss.cnt, R, nR, nullptr);
+      }
+    }
+    const uint32_t im = wave_incl_scan_u32(nm, lane), ii = wave_incl_scan_u32(ni, lane), iff = wave_incl_scan_u32(nf, lane);
+    const uint32_t om = cm + im - nm, oi = ci + ii - ni, of = cf + iff - nf;
+    cm += __shfl(im, k_wave - 1, k_wave); ci += __shfl(ii, k_wave - 1, k_wave); cf += __shfl(iff, k_wave - 1, k_wave);
+    if (s < n) {
+      const NodeRec& r = N[s];
+      const int32_t o = pt.orig[base + s];
+      if (owns) {
+        g.t[o] = r.t;
+        g.muts[o] = GList{om, nm}; g.miss[o] = GList{oi, ni}; g.mfs[o] = GList{of, nf};
+        const MutRec* sm = (const MutRec*)(slab + r.muts.off); const IvRec* si = (const IvRec*)(slab + r.miss.off);
+        for (uint32_t k = 0; k < nm; ++k) g.mut_heap[om + k] = sm[k];
+        for (uint32_t k = 0; k < ni; ++k) g.iv_heap[oi + k] = si[k];
+        gt_rereferenced_from_states((const FsRec*)(slab + r.mfs.off), r.mfs.cnt, si, r.miss.cnt, R, nR, g.fs_heap + of);
+      }
+      if (r.child0 != EMAT_NO_NODE) {
+        const int32_t l = pt.orig[base + r.child0], rr = pt.orig[base + r.child1];
+        g.c0[o] = l; g.c1[o] = rr; g.parent[l] = o; g.parent[rr] = o;
+      }
+    }
+  }
+  if (is_root_part && lane == 0) {
+    const int32_t nr = pt.orig[base + local_root];
+    g.root[0] = nr; g.parent[nr] = EMAT_NO_NODE;
+    for (int k = 0; k < nR; ++k) { ref[R[k].site] = R[k].to; root_deltas_out[k] = R[k]; }
+    n_root_deltas_out[0] = nR;
+  }
+}
+
+}  // namespace emat
+#endif  // EMAT_GTREE_KERNELS_HPP_

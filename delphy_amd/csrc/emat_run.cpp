@@ -121,36 +121,39 @@ struct RunDriver {
   // identically; the attached backend only gets the parts [part_lo, part_hi) (backend part id = part - part_lo).
   int shard_rank = 0, shard_world = 1, part_lo = 0, part_hi = 0;
   std::vector<uint64_t> part_epoch;   // epoch at which each part's subtree was last refreshed (downloaded or received)
+  // The whole tree resident in HBM (emat_tree_* of the backend): this driver then only sees topology and
+  // node times (tp_* below); `tree` is brought up to date on demand (ensure_host_tree).
+  bool device_tree = false, device_tree_uploaded = false, host_tree_stale = false;
 
   double t_max_tip() const { double t = -INFINITY; for (auto& n : tree.nodes) if (n.is_tip() && n.t_max > t) t = n.t_max; return t; }   // phylo_tree_calc.cpp:636-644
 
   // tree_partitioning.h:139-194
   std::vector<int32_t> generate_random_partition_stencil() {
     std::vector<int32_t> cuts;
-    const int N = (int)tree.nodes.size();
+    const int N = (int)tp_parent.size();   // needs sync_topology()
     std::vector<int> descendants(N, 0);
     long num_branches_left = N; int num_parts_left = num_parts;
     struct Item { int32_t node; int csf; };
-    std::vector<Item> stack; stack.push_back({tree.root, -1});
+    std::vector<Item> stack; stack.push_back({tp_root, -1});
     bool done = false;
     while (!stack.empty() && !done) {
       Item it = stack.back(); stack.pop_back();
-      const HNode& nd = tree.nodes[it.node];
-      const int nch = nd.is_tip() ? 0 : 2;
+      const int32_t nd_c0 = tp_c0[it.node], nd_c1 = tp_c1[it.node];
+      const int nch = nd_c0 == EMAT_NO_NODE ? 0 : 2;
       if (it.csf == -1) {
         stack.push_back({it.node, nch});
         if (nch == 2) {
-          if (bitgen.next() >> 63) { stack.push_back({nd.c0, -1}); stack.push_back({it.node, 1}); stack.push_back({nd.c1, -1}); stack.push_back({it.node, 0}); }
-          else { stack.push_back({nd.c1, -1}); stack.push_back({it.node, 1}); stack.push_back({nd.c0, -1}); stack.push_back({it.node, 0}); }
+          if (bitgen.next() >> 63) { stack.push_back({nd_c0, -1}); stack.push_back({it.node, 1}); stack.push_back({nd_c1, -1}); stack.push_back({it.node, 0}); }
+          else { stack.push_back({nd_c1, -1}); stack.push_back({it.node, 1}); stack.push_back({nd_c0, -1}); stack.push_back({it.node, 0}); }
         }
         continue;
       }
       if (it.csf != nch) continue;   // only post-order visits matter
       const int node = it.node;
-      if (node == tree.root) break;
+      if (node == tp_root) break;
       if ((int)cuts.size() == num_parts - 1) break;
       descendants[node] = 1;
-      if (nch == 2) descendants[node] += descendants[nd.c0] + descendants[nd.c1];
+      if (nch == 2) descendants[node] += descendants[nd_c0] + descendants[nd_c1];
       long min_subtree_size = std::max(10L, num_branches_left / (num_parts_left + 1));
       if (descendants[node] >= min_subtree_size) {
         bool allowed = true;
@@ -176,14 +179,14 @@ struct RunDriver {
   // part sizes drift as the tree is re-hung.
   std::vector<int32_t> refine_stencil(std::vector<int32_t> cuts) const {   // needs sync_topology()
     if (max_part_nodes <= 0) return cuts;
-    const int N = (int)tree.nodes.size();
+    const int N = (int)tp_parent.size();
     const int limit = std::max(max_part_nodes, 21);
     std::vector<char> is_cut(N, 0);
     for (int32_t c : cuts) is_cut[c] = 1;
-    is_cut[tree.root] = 1;
+    is_cut[tp_root] = 1;
     // size[v]: nodes of v's part that lie in v's subtree (a cut child counts as one: it is a tip of this part)
     std::vector<int32_t> size(N, 1), order; order.reserve(N);
-    { std::vector<int32_t> st; st.push_back(tree.root);
+    { std::vector<int32_t> st; st.push_back(tp_root);
       while (!st.empty()) { int32_t v = st.back(); st.pop_back(); order.push_back(v); if (tp_c0[v] != EMAT_NO_NODE) { st.push_back(tp_c0[v]); st.push_back(tp_c1[v]); } } }
     for (auto it = order.rbegin(); it != order.rend(); ++it) {
       const int32_t k0 = tp_c0[*it], k1 = tp_c1[*it];
@@ -219,17 +222,17 @@ struct RunDriver {
   // tree_partitioning.h:88-135 and :196-239
   void partition_tree(const std::vector<int32_t>& stencil) {
     int root_idx = (int)stencil.size(); bool root_in = false;
-    for (size_t i = 0; i < stencil.size(); ++i) if (stencil[i] == tree.root) { root_in = true; root_idx = (int)i; break; }
+    for (size_t i = 0; i < stencil.size(); ++i) if (stencil[i] == tp_root) { root_in = true; root_idx = (int)i; break; }
     const int P = (int)stencil.size() + (root_in ? 0 : 1);
-    std::vector<char> is_cut(tree.nodes.size(), 0);
+    std::vector<char> is_cut(tp_parent.size(), 0);
     for (int32_t c : stencil) is_cut[c] = 1;
-    if (!root_in) { is_cut[tree.root] = 1; root_idx = P - 1; }
+    if (!root_in) { is_cut[tp_root] = 1; root_idx = P - 1; }
     root_part = root_idx;
     parts.assign(P, PartMap{});
     part_kids.assign(P, {});
     parallel_for(P, [&](int i) {   // every part walks down from its own cut point: independent
       PartMap& pm = parts[i];
-      pm.cut_point = (i == root_part) ? tree.root : stencil[i];
+      pm.cut_point = (i == root_part) ? tp_root : stencil[i];
       struct W { int32_t src, dst; };
       std::vector<W> work; pm.orig.clear(); pm.orig.push_back(pm.cut_point);
       work.push_back({pm.cut_point, 0});
@@ -251,11 +254,30 @@ struct RunDriver {
   std::vector<std::vector<std::pair<int32_t, int32_t>>> part_kids;
   // Compact copy of the whole tree's topology (the node records carry three vectors each and are 100+ bytes apart:
   // walking them misses the cache at every step).  Rebuilt at the start of every repartition.
-  std::vector<int32_t> tp_parent, tp_c0, tp_c1;
+  std::vector<int32_t> tp_parent, tp_c0, tp_c1; std::vector<double> tp_t; int32_t tp_root = EMAT_NO_NODE;
   void sync_topology() {
     const int N = (int)tree.nodes.size();
-    tp_parent.resize(N); tp_c0.resize(N); tp_c1.resize(N);
-    parallel_for(N, [&](int v) { const HNode& nd = tree.nodes[v]; tp_parent[v] = nd.parent; tp_c0[v] = nd.c0; tp_c1[v] = nd.c1; }, 4096);
+    tp_parent.resize(N); tp_c0.resize(N); tp_c1.resize(N); tp_t.resize(N); tp_root = tree.root;
+    parallel_for(N, [&](int v) { const HNode& nd = tree.nodes[v]; tp_parent[v] = nd.parent; tp_c0[v] = nd.c0; tp_c1[v] = nd.c1; tp_t[v] = nd.t; }, 4096);
+  }
+  emat_status fetch_device_topology() {   // device-resident tree: what the backend mirrored at its last upload / reassemble
+    const size_t N = tree.nodes.size();
+    tp_parent.resize(N); tp_c0.resize(N); tp_c1.resize(N); tp_t.resize(N);
+    return bk(emat_tree_get_topology(backend, tp_parent.data(), tp_c0.data(), tp_c1.data(), tp_t.data(), &tp_root));
+  }
+  // `tree` (and `ref`) as of the last reassemble, when the authoritative copy lives on the device
+  emat_status ensure_host_tree() {
+    if (!device_tree || !host_tree_stale) return EMAT_OK;
+    int32_t nn, nm, ni, nf;
+    emat_status st = bk(emat_tree_get_sizes(backend, &nn, &nm, &ni, &nf)); if (st) return st;
+    FlatTree f; f.allocate(nn, nm, ni, nf);
+    emat_flat_tree v = f.view();
+    st = bk(emat_tree_download(backend, &v, ref.data())); if (st) return st;
+    f.root = v.root;
+    emat_flat_tree fv = f.view();
+    tree = HTree::from_view(fv);
+    host_tree_stale = false;
+    return EMAT_OK;
   }
 
   // Run::normalize_root + rereference_to_root_sequence (run.cpp:258-265, phylo_tree.cpp:309-322)
@@ -336,6 +358,11 @@ struct RunDriver {
     }, 8);
   }
 
+  uint64_t seed_for_part(int p) const {   // a fresh RNG stream per part and cycle
+    uint64_t z = seed ^ (0x9E3779B97F4A7C15ull * (epoch + 1)) ^ ((uint64_t)p << 32 | (uint64_t)p);
+    SplitMix64 sm(z);
+    return sm.next();
+  }
   void build_subtrees() {   // run.cpp:131-184
     const int P = (int)parts.size();
     subtrees.clear(); subtrees.resize(P); part_seeds.assign(P, 0);
@@ -384,9 +411,7 @@ struct RunDriver {
       }
       st.parent[0] = EMAT_NO_NODE;
       subtrees[p] = std::move(st);
-      uint64_t z = seed ^ (0x9E3779B97F4A7C15ull * (epoch + 1)) ^ ((uint64_t)p << 32 | (uint64_t)p);
-      SplitMix64 sm(z);
-      part_seeds[p] = sm.next();
+      part_seeds[p] = seed_for_part(p);
     };
     parallel_for(P, build_one);
   }
@@ -413,7 +438,7 @@ struct RunDriver {
     return EMAT_OK;
   }
   double default_t_step() const {   // Run keeps ~400 cells over the tree span (run.cpp:20, :734-747)
-    double lo = tree.nodes[tree.root].t, hi = t_max_tip();
+    double lo = device_tree && !tp_t.empty() ? tp_t[tp_root] : tree.nodes[tree.root].t, hi = t_max_tip();
     double span = hi - lo; if (!(span > 0)) span = 1.0;
     return std::max(span / 400.0, 1.0 / 400.0);
   }
@@ -515,11 +540,29 @@ struct RunDriver {
     return EMAT_OK;
   }
 
-  emat_status repartition() {   // run.cpp:110-193 (+ refresh_partition_stencils :87-108)
+  // The same cycle with the whole tree resident in HBM: the host draws and applies the stencil on the topology alone
+  // and hands the parts over as three int arrays; nodes, mutations and missations never leave the device.
+  emat_status repartition_device() {
     const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    auto t0 = now(), t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0;
+    auto t0 = now();
+    if (!backend) return fail(EMAT_ERR_NO_DEVICE, "a device-resident tree needs a backend");
+    if (shard_world > 1) return fail(EMAT_ERR_STATE, "a sharded run keeps the whole tree on every host (emat_host.h)");
+    if (!have_pop) return fail(EMAT_ERR_STATE, "emat_run_set_pop_model must be called first");
+    emat_status st;
+    if (!device_tree_uploaded) {
+      normalize_root();
+      if (!model_pushed) { st = push_model(); if (st) return st; }
+      FlatTree f = tree.to_flat();
+      emat_flat_tree v = f.view();
+      st = bk(emat_tree_upload(backend, &v)); if (st) return st;
+      device_tree_uploaded = true; host_tree_stale = false;
+    }
+    if (!model_pushed) { st = push_model(); if (st) return st; }
+    st = fetch_device_topology(); if (st) return st;
+    auto t1 = now();
+    std::vector<int32_t> part_off, orig, kid0, kid1;
     try {
       if (stencils.empty() || stencil_refresh_countdown <= 0) {
         stencils.clear();
@@ -527,7 +570,57 @@ struct RunDriver {
         stencil_refresh_countdown = 200;
       }
       --stencil_refresh_countdown;
+      const std::vector<int32_t> stencil = refine_stencil(stencils[bitgen.below((int)stencils.size())]);
+      part_kids.clear();
+      partition_tree(stencil);
+      ++epoch;
+    } catch (const std::exception& ex) { return fail(EMAT_ERR_INTERNAL, ex.what()); }
+    auto t2 = now();
+    const int P = (int)parts.size();
+    part_off.assign(P + 1, 0);
+    for (int p = 0; p < P; ++p) part_off[p + 1] = part_off[p] + (int32_t)parts[p].orig.size();
+    orig.resize(part_off[P]); kid0.resize(part_off[P]); kid1.resize(part_off[P]);
+    part_seeds.assign(P, 0);
+    parallel_for(P, [&](int p) {
+      const int b = part_off[p], n = (int)parts[p].orig.size();
+      for (int s = 0; s < n; ++s) { orig[b + s] = parts[p].orig[s]; kid0[b + s] = part_kids[p][s].first; kid1[b + s] = part_kids[p][s].second; }
+      part_seeds[p] = seed_for_part(p);
+    }, 64);
+    subtrees.clear();
+    shard_block(P);
+    part_epoch.assign(P, 0);
+    emat_pop_model pm = pop; pm.skygrid_x = sky_x.data(); pm.skygrid_gamma = sky_g.data();
+    auto t3 = now();
+    st = bk(emat_tree_repartition(backend, P, part_off.data(), orig.data(), kid0.data(), kid1.data(), root_part, part_seeds.data(), &pm, t_step_set ? t_step : default_t_step()));
+    if (st) return st;
+    parts_uploaded = true; coal_built = true; host_tree_stale = true;
+    if (verbose) fprintf(stderr, "[emat_run] repartition (device tree): upload / topology %.1f ms | stencil + partition_tree %.1f ms | flatten %.1f ms | emat_tree_repartition %.1f ms\n",
+                         ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
+    return EMAT_OK;
+  }
+  emat_status reassemble_device() {
+    if (!parts_uploaded) return fail(EMAT_ERR_STATE, "repartition first");
+    int32_t nd = 0; int32_t site[256]; uint8_t from[256], to[256];
+    emat_status st = bk(emat_tree_reassemble(backend, &nd, site, from, to, 256)); if (st) return st;
+    for (int k = 0; k < nd; ++k) ref[site[k]] = to[k];
+    parts_uploaded = false; host_tree_stale = true;
+    return EMAT_OK;
+  }
+
+  emat_status repartition() {   // run.cpp:110-193 (+ refresh_partition_stencils :87-108)
+    const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto t0 = now(), t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0;
+    if (device_tree) return repartition_device();
+    try {
       sync_topology();
+      if (stencils.empty() || stencil_refresh_countdown <= 0) {
+        stencils.clear();
+        for (int i = 0; i < 10; ++i) stencils.push_back(generate_random_partition_stencil());
+        stencil_refresh_countdown = 200;
+      }
+      --stencil_refresh_countdown;
       const std::vector<int32_t> stencil = refine_stencil(stencils[bitgen.below((int)stencils.size())]);
       part_kids.clear();
       t1 = now();
@@ -561,6 +654,7 @@ struct RunDriver {
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     auto t0 = now(), t1 = t0, t2 = t0;
+    if (device_tree) return reassemble_device();
     try {
       if (backend && parts_uploaded) { emat_status st0 = download_local_parts(); if (st0) return st0; }
       t1 = now();
@@ -657,9 +751,27 @@ emat_status emat_run_set_pop_model(emat_run* r, const emat_pop_model* pm) {
 emat_status emat_run_set_coalescent_t_step(emat_run* r, double t_step) { if (!r || !(t_step > 0)) return EMAT_ERR_INVALID_ARGUMENT; r->d.t_step = t_step; r->d.t_step_set = true; return EMAT_OK; }
 emat_status emat_run_set_flags(emat_run* r, int32_t odin, int32_t topo) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; r->d.only_displacing_inner_nodes = odin; r->d.topology_moves_enabled = topo; r->d.model_pushed = false; return EMAT_OK; }
 
+emat_status emat_run_set_device_tree(emat_run* r, int32_t on) {
+  if (!r) return EMAT_ERR_INVALID_ARGUMENT;
+  RunDriver& d = r->d;
+  if (on) {
+    if (!d.backend) return d.fail(EMAT_ERR_NO_DEVICE, "a device-resident tree needs a backend");
+    if (d.shard_world > 1) return d.fail(EMAT_ERR_STATE, "a sharded run keeps the whole tree on every host");
+    if (d.parts_uploaded) return d.fail(EMAT_ERR_STATE, "reassemble first");
+    d.device_tree = true; d.device_tree_uploaded = false;   // uploaded at the next repartition
+    return EMAT_OK;
+  }
+  if (d.device_tree) {
+    if (d.parts_uploaded) return d.fail(EMAT_ERR_STATE, "reassemble first");
+    emat_status st = d.ensure_host_tree(); if (st) return st;
+    d.device_tree = false; d.device_tree_uploaded = false;
+  }
+  return EMAT_OK;
+}
 emat_status emat_run_repartition(emat_run* r) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; return r->d.repartition(); }
 emat_status emat_run_num_parts(emat_run* r, int32_t* n, int32_t* root_part) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; if (n) *n = (int)r->d.parts.size(); if (root_part) *root_part = r->d.root_part; return EMAT_OK; }
 emat_status emat_run_part_sizes(emat_run* r, int32_t p, int32_t* nn, int32_t* nm, int32_t* ni, int32_t* nf) {
+  if (r && r->d.device_tree) return r->d.fail(EMAT_ERR_STATE, "with a device-resident tree the parts exist only on the device (emat_part_get_sizes / emat_part_download of the backend)");
   if (!r || p < 0 || p >= (int)r->d.subtrees.size()) return EMAT_ERR_INVALID_ARGUMENT;
   const FlatTree& t = r->d.subtrees[p];
   if (nn) *nn = t.num_nodes(); if (nm) *nm = t.num_muts(); if (ni) *ni = t.num_intervals(); if (nf) *nf = t.num_from_states();
@@ -806,17 +918,19 @@ emat_status emat_run_do_mcmc_steps(emat_run* r, int64_t steps, int64_t per_cycle
     st = r->d.reassemble(); if (st) return st;
     done += k;
   }
-  r->d.normalize_root();
+  if (!r->d.device_tree) r->d.normalize_root();   // (a device-resident tree is normalised by every reassemble)
   return EMAT_OK;
 }
 emat_status emat_run_tree_sizes(emat_run* r, int32_t* nn, int32_t* nm, int32_t* ni, int32_t* nf) {
   if (!r) return EMAT_ERR_INVALID_ARGUMENT;
+  { emat_status st = r->d.ensure_host_tree(); if (st) return st; }
   int m = 0, i = 0, f = 0; for (auto& nd : r->d.tree.nodes) { m += (int)nd.muts.size(); i += (int)nd.miss.size(); f += (int)nd.mfs.size(); }
   if (nn) *nn = (int)r->d.tree.nodes.size(); if (nm) *nm = m; if (ni) *ni = i; if (nf) *nf = f;
   return EMAT_OK;
 }
 emat_status emat_run_tree_get(emat_run* r, emat_flat_tree* out, uint8_t* ref) {
   if (!r || !out) return EMAT_ERR_INVALID_ARGUMENT;
+  { emat_status st = r->d.ensure_host_tree(); if (st) return st; }
   if (ref) std::copy(r->d.ref.begin(), r->d.ref.end(), ref);
   return copy_out(r->d.tree.to_flat(), out);
 }

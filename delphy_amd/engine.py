@@ -259,6 +259,11 @@ def load_library():
         "emat_Ttwiddle_l_finish": [B, P(dbl), P(dbl), dbl, P(dbl)],
         "emat_run_do_mcmc_steps": [R, i64, i64], "emat_run_tree_sizes": [R, P(i32), P(i32), P(i32), P(i32)],
         "emat_run_tree_get": [R, P(_FlatTreeC), P(C.c_uint8)], "emat_run_t_max_tip": [R, P(dbl)],
+        "emat_run_set_device_tree": [R, i32],
+        "emat_tree_upload": [B, P(_FlatTreeC)], "emat_tree_get_sizes": [B, P(i32), P(i32), P(i32), P(i32)], "emat_tree_download": [B, P(_FlatTreeC), P(C.c_uint8)],
+        "emat_tree_get_topology": [B, P(i32), P(i32), P(i32), P(dbl), P(i32)],
+        "emat_tree_repartition": [B, i32, P(i32), P(i32), P(i32), P(i32), i32, P(u64), P(_PopModelC), dbl],
+        "emat_tree_reassemble": [B, P(i32), P(i32), P(C.c_uint8), P(C.c_uint8), i32],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -681,6 +686,10 @@ class EmatRun:
     def unpack_parts(self, buf: np.ndarray):
         buf = np.ascontiguousarray(buf, np.uint8)
         self._ck(self._lib.emat_run_unpack_parts(self._h, _ptr(buf, C.c_uint8), buf.shape[0]), "emat_run_unpack_parts")
+
+    def set_device_tree(self, on: bool = True):
+        """keep the authoritative tree in HBM; cycles then move only the partition and the topology."""
+        self._ck(self._lib.emat_run_set_device_tree(self._h, int(on)), "emat_run_set_device_tree")
 
     def do_mcmc_steps(self, steps: int, local_moves_per_cycle: int = -1):
         self._ck(self._lib.emat_run_do_mcmc_steps(self._h, steps, local_moves_per_cycle), "emat_run_do_mcmc_steps")

@@ -171,6 +171,42 @@ emat_status emat_run_moves_split(emat_backend* h, int64_t moves_per_part, int64_
  * aborts in that situation. */
 emat_status emat_synchronize(emat_backend* h);
 
+/* ---- The whole tree resident in HBM -------------------------------------------------------------
+ * Run::repartition (core/run.cpp:110-193) copies every part out of the whole Phylo_tree into its Subrun's tree and
+ * Run::reassemble (core/run.cpp:195-256) copies the parts back; through emat_part_upload / emat_part_download that is a
+ * host round trip of every node, mutation and missation per cycle.  With the tree uploaded ONCE, a cycle needs from the
+ * host only the partition itself -- which nodes form which part -- and moves topology + node times (a few MB) back:
+ *
+ *   emat_tree_upload            the whole tree -> HBM (node arrays + three record heaps); the root node must carry no
+ *                               mutations (Run::normalize_root, run.cpp:258-265)
+ *   emat_tree_get_topology      parent / children / node times / root, as of the last upload or reassemble: what
+ *                               generate_random_partition_stencil and partition_tree (tree_partitioning.h:88-239) read
+ *   emat_tree_repartition       run.cpp:110-193 + reset_very_scalable_coalescent_parts (run.cpp:277-293): the parts as
+ *                               CSR over part-local nodes -- `orig` maps a part's node to the tree's node, local node 0
+ *                               being the part's cut point, `kid0` / `kid1` are part-local children (EMAT_NO_NODE at the
+ *                               part's tips).  One kernel computes the sequence state at every cut point
+ *                               (phylo_tree_calc.cpp:19-56) and sizes the parts, a second writes the slabs -- byte for
+ *                               byte what emat_part_upload + emat_build_coalescent_parts + the first launch would have
+ *                               produced for the same parts and seeds.  The coalescent cell tables are built on the host
+ *                               from topology + times.
+ *   emat_tree_reassemble        run.cpp:195-256 + normalize_root: every part writes the nodes it owns back, the record
+ *                               heaps are rebuilt, the changes of the root sequence are folded into the reference
+ *                               sequence on the device (and reported, so that the caller's copy can follow)
+ *   emat_tree_download          the whole tree (and its reference sequence) back as a flat tree
+ *
+ * Between emat_tree_repartition and emat_tree_reassemble the backend holds ordinary parts: every run / getter /
+ * reduction entry point above works on them unchanged. */
+emat_status emat_tree_upload(emat_backend* h, const emat_flat_tree* tree);
+emat_status emat_tree_get_sizes(emat_backend* h, int32_t* num_nodes, int32_t* num_muts, int32_t* num_intervals, int32_t* num_from_states);
+emat_status emat_tree_download(emat_backend* h, emat_flat_tree* out, uint8_t* ref_sequence /* [num_sites] or NULL */);
+emat_status emat_tree_get_topology(emat_backend* h, int32_t* parent, int32_t* child0, int32_t* child1, double* t, int32_t* root);
+emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int32_t* part_offset /* [num_parts + 1] */, const int32_t* orig,
+                                  const int32_t* kid0, const int32_t* kid1, int32_t root_part, const uint64_t* seeds /* [num_parts] */,
+                                  const emat_pop_model* pop_model, double t_step);
+/* `site` / `from` / `to` [capacity] receive the changes of the reference sequence (old state, new state); any of the
+ * output arguments may be NULL / 0 when the caller reads the sequence through emat_tree_download instead. */
+emat_status emat_tree_reassemble(emat_backend* h, int32_t* num_root_deltas, int32_t* site, uint8_t* from, uint8_t* to, int32_t capacity);
+
 /* Forces the from-scratch recomputation that Subrun::validate_derived_quantities() performs
  * after set_evo / set_coalescent_prior_part (reference subrun.cpp:17-26).  Called implicitly
  * by the run functions when the derived quantities are stale. */

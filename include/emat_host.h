@@ -70,6 +70,13 @@ emat_status emat_run_set_pop_model(emat_run* r, const emat_pop_model* pm);
 emat_status emat_run_set_coalescent_t_step(emat_run* r, double t_step);
 emat_status emat_run_set_flags(emat_run* r, int32_t only_displacing_inner_nodes, int32_t topology_moves_enabled);
 
+/* keep the authoritative tree in HBM (emat_tree_* of the backend).  From the next emat_run_repartition on,
+ * a cycle moves only the partition to the device and topology + node times back: emat_run_repartition draws and applies
+ * the stencil on the topology and calls emat_tree_repartition, emat_run_reassemble calls emat_tree_reassemble (which also
+ * does Run::normalize_root's work).  emat_run_tree_get / emat_run_tree_sizes download the tree when asked;
+ * emat_run_part_* (host copies of the parts) are not available.  Same seeds, same partitions, same trees as the host
+ * cycle, bit for bit.  `on` = 0 brings the tree back to the host.  Single-process runs only. */
+emat_status emat_run_set_device_tree(emat_run* r, int32_t on);
 /* Cut the tree into parts and (when a backend is attached) upload them and build their coalescent parts. */
 emat_status emat_run_repartition(emat_run* r);
 emat_status emat_run_num_parts(emat_run* r, int32_t* num_parts, int32_t* root_part_index);
