@@ -99,24 +99,34 @@ def cpu_baseline(sc, num_parts, seed, target_seconds, t_step):
 
 
 def inclusive_cycles(sc, args, cycles=3):
-    """Whole cycles through the host run driver (emat_run_do_mcmc_steps: repartition -> subtree build -> slab encode -> H2D
-    -> moves -> D2H -> decode -> reassemble), the reference's default 50 x nodes local moves per cycle (run.cpp:669-672).
-    Reported beside `value`, never as it."""
+    """Whole cycles through the host run driver (emat_run_do_mcmc_steps), the reference's default 50 x nodes local moves per
+    cycle (run.cpp:669-672), wall clock.  Two ways: with the whole tree resident in HBM (the host draws the
+    partition on the topology, kernels cut the part slabs and gather them back) and with the tree on the host (subtree
+    build -> slab encode -> H2D -> moves -> D2H -> decode -> reassemble).  Reported beside `value`, never as it."""
     import delphy_amd as d
-    b = d.EmatBackend(sc.num_sites)
-    run = d.EmatRun(b, sc.tree, sc.ref, 20261001)
-    run.set_num_parts(args.parts)
-    run.set_max_part_nodes(args.max_part_nodes)
-    run.set_hky(sc.mu, sc.kappa, sc.pi)
-    run.set_pop_model(sc.pop)
     per_cycle = 50 * sc.tree.num_nodes
-    run.do_mcmc_steps(per_cycle, per_cycle)          # warm-up cycle: allocations, first launch
-    t0 = time.perf_counter()
-    run.do_mcmc_steps(cycles * per_cycle, per_cycle)
-    dt = time.perf_counter() - t0
-    run.close(); b.close()
-    return {"value": cycles * per_cycle / dt, "unit": "moves/s", "cycles": cycles, "moves_per_cycle": per_cycle, "ms_per_cycle": dt / cycles * 1e3,
-            "what": "emat_run_do_mcmc_steps: host repartition + upload + %d local moves + download + reassemble per cycle (no global moves), wall clock" % per_cycle}
+
+    def one(device_tree):
+        b = d.EmatBackend(sc.num_sites)
+        run = d.EmatRun(b, sc.tree, sc.ref, 20261001)
+        run.set_num_parts(args.parts)
+        run.set_max_part_nodes(args.max_part_nodes)
+        run.set_hky(sc.mu, sc.kappa, sc.pi)
+        run.set_pop_model(sc.pop)
+        if device_tree:
+            run.set_device_tree(True)
+        run.do_mcmc_steps(per_cycle, per_cycle)          # warm-up cycle: allocations, first launch, tree upload
+        t0 = time.perf_counter()
+        run.do_mcmc_steps(cycles * per_cycle, per_cycle)
+        dt = time.perf_counter() - t0
+        run.close(); b.close()
+        return {"value": cycles * per_cycle / dt, "unit": "moves/s", "ms_per_cycle": dt / cycles * 1e3}
+
+    dev, host = one(True), one(False)
+    return {"value": dev["value"], "unit": "moves/s", "cycles": cycles, "moves_per_cycle": per_cycle, "ms_per_cycle": dev["ms_per_cycle"],
+            "what": "emat_run_do_mcmc_steps with the tree resident in HBM: stencil + partition on the host's copy of the topology, part slabs cut and "
+                    "gathered back by kernels, %d local moves per cycle (no global moves), wall clock" % per_cycle,
+            "host_tree": dict(host, what="the same cycles with the tree on the host: subtree build + slab encode + H2D + moves + D2H + decode + reassemble")}
 
 
 def main():

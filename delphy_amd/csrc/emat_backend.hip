@@ -9,12 +9,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -63,6 +65,7 @@ struct KernelArgs {
   const int64_t* moves_for_part;  // [num_parts] or null: per-part counts of a recovery launch (overrides moves_per_part / extra_moves_part0)
   int32_t* part_status;           // [num_parts] status every part ended its chain with (0 = ran to completion)
   int64_t extra_moves_part0;      // remainder of Run::run_local_moves goes to part 0 (run.cpp:683-689)
+  int32_t one_more_below;         // parts [0, one_more_below) do one move more (emat_run_moves_even)
 };
 
 constexpr int k_wave = 64;
@@ -128,7 +131,7 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
   const int part = a.order[blockIdx.x];
   uint8_t* gslab = a.slabs + a.slab_off[part];
   SlabHeader* gh = (SlabHeader*)gslab;
-  const int64_t target = a.moves_for_part ? a.moves_for_part[part] : a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0);
+  const int64_t target = a.moves_for_part ? a.moves_for_part[part] : a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0) + (part < a.one_more_below ? 1 : 0);
   const int64_t done_at_start = gh->moves_done;
   const uint32_t area = a.lds_slab_bytes;
   const bool can_stage = tables_staged && area != 0 && gh->off_nodes == (uint32_t)sizeof(SlabHeader);
@@ -605,7 +608,8 @@ struct GTreeHost {
   uint32_t used[3] = {0, 0, 0};     // records in use in the three heaps
   // current partition
   int32_t P = 0, root_part = -1;
-  DevBuf<int32_t> part_off, orig, kid0, kid1;
+  DevBuf<int32_t> part_off, orig, kid0, kid1, lpar;
+  DevBuf<double> co_kbar, co_ktw, co_k_bar, co_k_tw, co_popsize; DevBuf<int32_t> co_num_active;   // the coalescent grid, when it is built on the device
   DevBuf<GMeasure> measure; DevBuf<MutRec> pool_muts; DevBuf<IvRec> pool_ivs; DevBuf<uint32_t> pool_tops;
   DevBuf<GPartDesc> desc; DevBuf<uint8_t> cells;
   DevBuf<GRootDelta> root_deltas; DevBuf<int32_t> n_root_deltas;
@@ -618,7 +622,7 @@ struct GTreeHost {
     g.mut_cap = (uint32_t)mut_heap.n; g.iv_cap = (uint32_t)iv_heap.n; g.fs_cap = (uint32_t)fs_heap.n; g.tops = tops.p;
     return g;
   }
-  GPartition partition() { GPartition q{}; q.num_parts = P; q.root_part = root_part; q.part_off = part_off.p; q.orig = orig.p; q.kid0 = kid0.p; q.kid1 = kid1.p; return q; }
+  GPartition partition() { GPartition q{}; q.num_parts = P; q.root_part = root_part; q.part_off = part_off.p; q.orig = orig.p; q.kid0 = kid0.p; q.kid1 = kid1.p; q.lpar = lpar.p; return q; }
   GPools pools() { GPools q{}; q.muts = pool_muts.p; q.ivs = pool_ivs.p; q.mut_cap = (uint32_t)pool_muts.n; q.iv_cap = (uint32_t)pool_ivs.n; q.tops = pool_tops.p; return q; }
 };
 
@@ -634,10 +638,11 @@ struct emat_backend {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int num_cus = 0;
   // size classes: parts sorted by persistent size; class c stages up to class_lds[c] bytes per part and runs on its own stream
-  static constexpr int k_max_classes = 4;
-  hipStream_t class_stream[k_max_classes] = {nullptr, nullptr, nullptr, nullptr};   // class 0 runs on `stream`
-  hipEvent_t ev_fork = nullptr, ev_join[k_max_classes] = {nullptr, nullptr, nullptr, nullptr};
-  int num_classes = 1; int class_begin[k_max_classes + 1] = {0, 0, 0, 0, 0}; uint32_t class_lds[k_max_classes] = {0, 0, 0, 0};
+  static constexpr int k_max_classes = 3;
+  hipStream_t class_stream[k_max_classes] = {};   // class 0 runs on `stream`; the others on streams shared by every handle of the device (side_stream)
+  hipEvent_t ev_fork = nullptr, ev_join[k_max_classes] = {};
+  int num_classes = 1; int class_begin[k_max_classes + 1] = {}; uint32_t class_lds[k_max_classes] = {};
+  std::vector<int> class_of;        // per part
   std::vector<int> cfg_class_pct{60};                // EMAT_LDS_CLASSES (tuning knob): percentiles of persistent size that close each class; the last
                                                      // class always extends to the largest part (its staging area is still that percentile's size)
   uint32_t cfg_lds_max = 96 * 1024;                  // EMAT_LDS_MAX (tuning knob): largest staging area; larger parts run out of HBM
@@ -681,6 +686,7 @@ struct emat_backend {
   // dense copy of every part's slab header (k_gather_headers): what the scalar getters read instead of the slabs
   DevBuf<uint8_t> d_headers; std::vector<uint8_t> h_headers; bool headers_current = false;
   GTreeHost gt;                     // the whole tree, when it lives in HBM (emat_tree_upload)
+  bool cfg_gt_host_coal = false;    // EMAT_TREE_HOST_COALESCENT=1: emat_tree_repartition builds the coalescent tables on the host (bit-identical to the host cycle; tests)
 
   void set_error(const std::string& s) { last_error = s; }
 };
@@ -780,6 +786,18 @@ void decode_slab(PartHost& ph, const uint8_t* slab) {
 
 emat_status fail(emat_backend* h, emat_status st, const std::string& msg) { h->set_error(msg); return st; }
 
+// The streams the side launches of a pass fork onto: one small pool per device for the whole process.  The runtime maps
+// streams onto a handful of hardware queues (four by default) and two streams on one queue run one after the other, so
+// handles that come and go must not each bring streams of their own.  (The current device is the caller's.)
+hipStream_t side_stream(int device, int i) {
+  static std::mutex mu;
+  static std::vector<std::array<hipStream_t, emat_backend::k_max_classes - 1>> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  if ((int)pool.size() <= device) pool.resize((size_t)device + 1, std::array<hipStream_t, emat_backend::k_max_classes - 1>{});
+  if (!pool[device][i] && hipStreamCreate(&pool[device][i]) != hipSuccess) return nullptr;
+  return pool[device][i];
+}
+
 // Several handles may live in one process, one per GPU: every entry point that talks to the device selects its own first.
 inline bool bind_device(emat_backend* h) { return h->host_only || hipSetDevice(h->cfg.device) == hipSuccess; }
 
@@ -841,7 +859,7 @@ KernelArgs make_args(emat_backend* h) {
   a.evo.ref_sequence = h->d_ref.p; a.evo.partition_for_site = h->d_part.p; a.evo.nu_l = h->d_nu.p; a.evo.cum_Q_l = h->d_cumQ.p;
   a.evo.mu = h->d_mu.p; a.evo.pi = h->d_pi.p; a.evo.q = h->d_q.p;
   a.pop = h->d_pop.p; a.flags = h->flags; a.num_parts = (int)h->parts.size();
-  a.lds_slab_bytes = 0; a.lds_scratch_bytes = 0; a.moves_per_part = 0; a.extra_moves_part0 = 0;
+  a.lds_slab_bytes = 0; a.lds_scratch_bytes = 0; a.moves_per_part = 0; a.extra_moves_part0 = 0; a.one_more_below = 0;
   return a;
 }
 
@@ -849,7 +867,7 @@ KernelArgs make_args(emat_backend* h) {
 emat_status pull_from_device(emat_backend* h);
 emat_status pull_headers(emat_backend* h);
 emat_status materialize(emat_backend* h);
-emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, const std::vector<int64_t>* counts);
+emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, const std::vector<int64_t>* counts, int32_t one_more_below);
 
 // After a launch: did every part run its chain to completion?  A part that ran out of list-heap or scratch space
 // stops BEFORE a move with its state intact (status 101): it is given twice the room and the rest of its moves, up
@@ -885,6 +903,21 @@ emat_status finish_pass(emat_backend* h) {
     h->pass_pending = false;
     size_t stopped = 0, fatal = n;
     for (size_t p = 0; p < n; ++p) if (status[p] != 0) { ++stopped; if (status[p] != k_part_need_space && fatal == n) fatal = p; }
+    if (stopped == 0 && getenv("EMAT_VERBOSE")) {   // what bounded the pass: the slowest chains next to the mean
+      std::vector<int64_t> ticks(2 * n);
+      HIP_TRY(hipMemcpy(ticks.data(), h->d_part_ticks.p, 2 * n * sizeof(int64_t), hipMemcpyDeviceToHost));
+      std::vector<int> idx(n); std::iota(idx.begin(), idx.end(), 0);
+      std::partial_sort(idx.begin(), idx.begin() + std::min<size_t>(4, n), idx.end(), [&](int a, int b) { return ticks[a] > ticks[b]; });
+      double sum = 0; int64_t first = INT64_MAX, last = 0;
+      for (size_t p = 0; p < n; ++p) { sum += (double)ticks[p]; first = std::min(first, ticks[n + p]); last = std::max(last, ticks[n + p] + ticks[p]); }
+      float kms = 0.f; (void)hipEventElapsedTime(&kms, h->ev_start, h->ev_stop);
+      fprintf(stderr, "[emat] pass: %.1f ms on the device (first start to last end %.1f ms) | chains: mean %.2f ms, slowest", kms, (last - first) / 1e5, sum / n / 1e5);
+      for (size_t k = 0; k < std::min<size_t>(4, n); ++k) fprintf(stderr, " %.1f ms from %.1f (part %d, %d nodes%s)", ticks[idx[k]] / 1e5, (ticks[n + idx[k]] - first) / 1e5, idx[k], h->parts[idx[k]].tree.num_nodes(), idx[k] == h->root_part ? ", root part" : "");
+      std::partial_sort(idx.begin(), idx.begin() + std::min<size_t>(3, n), idx.end(), [&](int a, int b) { return ticks[n + a] + ticks[a] > ticks[n + b] + ticks[b]; });
+      fprintf(stderr, " | last to end:");
+      for (size_t k = 0; k < std::min<size_t>(3, n); ++k) fprintf(stderr, " part %d (%d nodes, %u B) %.1f ms from %.1f", idx[k], h->parts[idx[k]].tree.num_nodes(), h->persistent_bytes[idx[k]], ticks[idx[k]] / 1e5, (ticks[n + idx[k]] - first) / 1e5);
+      fprintf(stderr, "\n");
+    }
     if (stopped == 0) { if (round == 0 && h->last_launch_uniform) (void)refresh_order_from_ticks(h); return EMAT_OK; }
     h->host_slabs_current = false; h->headers_current = false;
     emat_status st = pull_from_device(h); if (st) return st;
@@ -905,7 +938,7 @@ emat_status finish_pass(emat_backend* h) {
     }
     if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] %zu part(s) ran out of slab space: re-materialising with more room and running the rest of their moves\n", stopped);
     h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false;   // every part is re-encoded from its decoded state (tree, RNG, cells, statistics)
-    st = launch_moves(h, 0, 0, &counts); if (st) return st;
+    st = launch_moves(h, 0, 0, &counts, 0); if (st) return st;
   }
   return EMAT_OK;
 }
@@ -983,75 +1016,86 @@ void place_slab(emat_backend* h, size_t p, const SlabGeo& g, uint64_t& off) {
   h->prefix_bytes[p] = g.bytes - g.scratch - g.heap;
   h->max_slab_bytes = std::max(h->max_slab_bytes, g.bytes);
 }
-// Size classes over the parts sorted by persistent size (descending): which parts share a launch and an LDS staging area.
+// Size classes: which parts share a launch and an LDS staging area.  Class 0 has the largest area; the last class (the
+// "main" one) holds the bulk of the parts.  Sets h->class_of / class_lds / class_begin; build_order lays the launch
+// order out class by class.
 void assign_size_classes(emat_backend* h) {
-  {   // size classes over the parts sorted by persistent size (descending): class c closes at percentile cfg_class_pct[c]
-    std::vector<uint32_t> v = h->persistent_bytes;
-    std::sort(v.begin(), v.end());
-    const size_t n = v.size();
-    h->num_classes = 0;
-    size_t lo = 0;   // ascending rank where the current class starts
-    std::vector<std::pair<size_t, uint32_t>> asc;   // (end rank, staging bytes), ascending sizes
+  const size_t n = h->parts.size();
+  std::vector<uint32_t> v = h->persistent_bytes;
+  std::sort(v.begin(), v.end());
+  h->class_of.assign(n, 0);
+  std::vector<uint32_t> areas;   // per class, descending
+  const uint32_t lds_cu = 160u * 1024u, overhead = k_lds_slab_off + (h->cfg.use_lds ? h->cfg_lds_scratch : 0u);
+  auto area_for = [&](uint32_t k) {   // the staging area of a workgroup when k of them share a CU (LDS is allocated in 512-byte granules)
+    const uint32_t share = (lds_cu / k) & ~511u;
+    return share <= overhead ? 0u : std::min<uint32_t>((share - overhead) & ~15u, h->cfg_lds_max & ~15u);
+  };
+  if (!h->cfg.use_lds || n == 0) areas.push_back(0u);
+  else if (h->cfg_class_pct.size() > 1) {
+    // tuning knob EMAT_LDS_CLASSES="p1,p2,...": classes by rank of persistent size, class c closing at percentile p_c and
+    // staging that percentile's size
+    std::vector<std::pair<uint32_t, uint32_t>> asc;   // (largest persistent size of the class, staging bytes), ascending
+    size_t lo = 0;
     for (size_t ci = 0; ci < h->cfg_class_pct.size(); ++ci) {
       const int pct = h->cfg_class_pct[ci];
       const bool last = ci + 1 == h->cfg_class_pct.size() || (int)asc.size() + 1 == emat_backend::k_max_classes;
       size_t hi = std::min(n, (n * (size_t)pct + 99) / 100);
-      if (pct >= 100) hi = n;
+      if (pct >= 100 || last) hi = n;
       if (hi <= lo) { if (last) break; continue; }
-      uint32_t need = (v[hi - 1] + 511u) & ~511u;
+      uint32_t need = (v[(last ? std::min(n, (n * (size_t)pct + 99) / 100) : hi) - 1] + 511u) & ~511u;
       if (need > h->cfg_lds_max) need = h->cfg_lds_max & ~511u;   // larger parts: prefix-staged or HBM only
-      asc.push_back({last ? n : hi, need});
+      asc.push_back({v[hi - 1], need});
       lo = hi;
       if (last) break;
     }
-    if (asc.empty()) asc.push_back({n, 0u});
-    asc.back().first = n;
-    if (asc.size() == 1 && asc[0].second != 0) {
-      // One class (the default): the percentile only says which parts MUST fit whole.  LDS is the resource that limits
-      // residency, so take the most workgroups per CU (up to the 16 the VGPR budget allows) whose share of the 160 KiB
-      // still holds that percentile, and give every workgroup its whole share: larger parts than asked for get staged
-      // whole at no cost in occupancy, the rest stage their prefix.
-      const uint32_t lds_cu = 160u * 1024u, prefix = k_lds_slab_off + (h->cfg.use_lds ? h->cfg_lds_scratch : 0u);
-      const uint32_t need = asc[0].second;
-      for (uint32_t k = 4u * EMAT_WAVES_PER_EU; k >= 1; --k) {   // 4 SIMDs x waves per SIMD allowed by the VGPR budget (one wave per workgroup)
-        const uint32_t share = (lds_cu / k) & ~511u;   // LDS is allocated in 512-byte granules
-        if (share <= prefix) continue;
-        const uint32_t area = std::min<uint32_t>((share - prefix) & ~15u, h->cfg_lds_max & ~15u);
-        if (area >= need || k == 1) { asc[0].second = area; break; }
+    if (asc.empty()) asc.push_back({v.back(), 0u});
+    const int nc = (int)asc.size();
+    for (int c = 0; c < nc; ++c) areas.push_back(asc[nc - 1 - c].second);
+    for (size_t p = 0; p < n; ++p) { int c = 0; while (c + 1 < nc && h->persistent_bytes[p] > asc[c].first) ++c; h->class_of[p] = nc - 1 - c; }
+  } else {
+    // The default.  The percentile only says which parts MUST fit whole.  LDS is the resource that limits residency, so
+    // take the most workgroups per CU (up to the 16 the VGPR budget allows) whose share of the 160 KiB still holds that
+    // percentile, and give every workgroup its whole share: larger parts than asked for get staged whole at no cost in
+    // occupancy, the rest stage their prefix.
+    const int pct = h->cfg_class_pct.empty() ? 60 : h->cfg_class_pct[0];
+    const size_t hi = pct >= 100 ? n : std::max<size_t>(1, std::min(n, (n * (size_t)pct + 99) / 100));
+    const uint32_t need = std::min<uint32_t>((v[hi - 1] + 511u) & ~511u, h->cfg_lds_max & ~511u);
+    uint32_t main_area = 0;
+    for (uint32_t k = 4u * EMAT_WAVES_PER_EU; k >= 1; --k) {   // 4 SIMDs x waves per SIMD allowed by the VGPR budget (one wave per workgroup)
+      const uint32_t area = area_for(k);
+      if (area == 0) continue;
+      if (area >= need || k == 1) { main_area = area; break; }
+    }
+    // Giants: a part whose fixed-size prefix (header, nodes, cells) does not fit the area would run entirely out of HBM,
+    // at less than half the speed, and -- every part doing the same number of moves -- hold up the whole pass.  They
+    // get launches of their own, with areas for 8 and for 1 workgroup per CU: each giant takes the smaller area if it
+    // holds its prefix.  (One area sized for the largest giant, as in round 1, put every giant at one workgroup per CU,
+    // and a partition that has drifted for a while holds hundreds of them: passes of 52 ms instead of 32 at C4.  More
+    // than two side launches would need more concurrent streams than the runtime has hardware queues -- four by default,
+    // GPU_MAX_HW_QUEUES -- and streams that share a queue run one after the other.)
+    std::vector<uint32_t> ladder;
+    if (h->cfg_giants) for (uint32_t k : {8u, 1u}) { const uint32_t a = area_for(k); if (a > main_area && (ladder.empty() || a > ladder.back())) ladder.push_back(a); }
+    std::vector<int> rung_of(n, -1); std::vector<int> used(ladder.size(), 0);
+    if (!ladder.empty())
+      for (size_t p = 0; p < n; ++p) if (h->prefix_bytes[p] > main_area) {
+        size_t r = 0; while (r + 1 < ladder.size() && ladder[r] < h->prefix_bytes[p]) ++r;
+        rung_of[p] = (int)r; used[r] = 1;
       }
-      // Giants: a part whose fixed-size prefix does not fit the area would run entirely out of HBM, at less than half
-      // the speed, and -- every part doing the same number of moves -- hold up the whole pass.  Such parts (a handful
-      // per partition) form a class of their own with an area sized for the largest of them.
-      if (h->cfg_giants) {
-        uint32_t smallest_giant = 0xffffffffu, largest = 0;
-        for (size_t p = 0; p < n; ++p) if (h->prefix_bytes[p] > asc[0].second) smallest_giant = std::min(smallest_giant, h->persistent_bytes[p]);
-        if (smallest_giant != 0xffffffffu) {
-          size_t first = std::lower_bound(v.begin(), v.end(), smallest_giant) - v.begin();   // ascending rank where the class starts
-          if (first > 0 && first < n) {
-            for (size_t i = first; i < n; ++i) largest = std::max(largest, v[i]);
-            const uint32_t giant_area = std::min<uint32_t>((largest + 511u) & ~511u, h->cfg_lds_max & ~511u);
-            const uint32_t main_area = asc[0].second;
-            asc.clear();
-            asc.push_back({first, main_area});
-            asc.push_back({n, giant_area});
-          }
-        }
-      }
-    }
-    if (!h->cfg.use_lds) { asc.clear(); asc.push_back({n, 0u}); }
-    // launch order is descending size: class 0 = the largest parts
-    h->num_classes = (int)asc.size();
-    for (int c = 0; c < h->num_classes; ++c) {
-      const auto& a = asc[h->num_classes - 1 - c];
-      h->class_lds[c] = a.second;
-      h->class_begin[c + 1] = (int)(n - (h->num_classes - 1 - c > 0 ? asc[h->num_classes - 2 - c].first : 0));
-    }
-    h->class_begin[0] = 0;
-    if (getenv("EMAT_VERBOSE")) {
-      fprintf(stderr, "[emat] parts %zu persistent bytes p50 %u p90 %u p99 %u max %u | classes:", n, v[n / 2], v[n * 9 / 10], v[n * 99 / 100], v.back());
-      for (int c = 0; c < h->num_classes; ++c) fprintf(stderr, " [%d parts, LDS %u]", h->class_begin[c + 1] - h->class_begin[c], h->class_lds[c]);
-      fprintf(stderr, "\n");
-    }
+    std::vector<int> class_of_rung(ladder.size(), -1);
+    for (int r = (int)ladder.size() - 1; r >= 0; --r) if (used[r] && (int)areas.size() + 1 < emat_backend::k_max_classes) { class_of_rung[r] = (int)areas.size(); areas.push_back(ladder[r]); }
+    const int main_class = (int)areas.size();
+    areas.push_back(main_area);
+    for (size_t p = 0; p < n; ++p) h->class_of[p] = rung_of[p] >= 0 && class_of_rung[rung_of[p]] >= 0 ? class_of_rung[rung_of[p]] : main_class;
+  }
+  h->num_classes = (int)areas.size();
+  std::vector<int> count(h->num_classes, 0);
+  for (size_t p = 0; p < n; ++p) ++count[h->class_of[p]];
+  h->class_begin[0] = 0;
+  for (int c = 0; c < h->num_classes; ++c) { h->class_lds[c] = areas[c]; h->class_begin[c + 1] = h->class_begin[c] + count[c]; }
+  if (getenv("EMAT_VERBOSE") && n > 0) {
+    fprintf(stderr, "[emat] parts %zu persistent bytes p50 %u p90 %u p99 %u max %u | classes:", n, v[n / 2], v[n * 9 / 10], v[n * 99 / 100], v.back());
+    for (int c = 0; c < h->num_classes; ++c) fprintf(stderr, " [%d parts, LDS %u]", h->class_begin[c + 1] - h->class_begin[c], h->class_lds[c]);
+    fprintf(stderr, "\n");
   }
 }
 
@@ -1113,7 +1157,7 @@ emat_status build_order(emat_backend* h) {
   const int n = (int)h->parts.size();
   std::vector<int32_t> order(n);
   std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->persistent_bytes[a] > h->persistent_bytes[b]; });
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->class_of[a] != h->class_of[b] ? h->class_of[a] < h->class_of[b] : h->persistent_bytes[a] > h->persistent_bytes[b]; });
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(h->d_order.upload(order.data(), order.size()));
   h->h_order = order;
@@ -1121,7 +1165,7 @@ emat_status build_order(emat_backend* h) {
   return EMAT_OK;
 }
 
-emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, const std::vector<int64_t>* counts = nullptr) {
+emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, const std::vector<int64_t>* counts = nullptr, int32_t one_more_below = 0) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
   if (h->fatal_status != EMAT_OK) return fail(h, h->fatal_status, h->fatal_message);
@@ -1134,10 +1178,10 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
     if (shmem_for(h->class_lds[c]) > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower EMAT_LDS_MAX or disable use_lds");
   if (!h->order_valid) { st = build_order(h); if (st) return st; }
   KernelArgs a = make_args(h);
-  a.moves_per_part = per_part; a.extra_moves_part0 = extra0;
+  a.moves_per_part = per_part; a.extra_moves_part0 = extra0; a.one_more_below = one_more_below;
   a.lds_scratch_bytes = lds_scratch;
   if (counts) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(h->d_moves_for_part.upload(counts->data(), counts->size())); a.moves_for_part = h->d_moves_for_part.p; }
-  else for (size_t p = 0; p < h->parts.size(); ++p) h->parts[p].expected_moves += per_part + (p == 0 ? extra0 : 0);
+  else for (size_t p = 0; p < h->parts.size(); ++p) h->parts[p].expected_moves += per_part + (p == 0 ? extra0 : 0) + ((int64_t)p < one_more_below ? 1 : 0);
   h->pass_pending = true;
   h->last_launch_uniform = counts == nullptr;
   HIP_TRY(hipEventRecord(h->ev_start, h->stream));
@@ -1151,32 +1195,21 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
     // Order matters: a side class holds few, large workgroups (tens of KB of LDS each), which can only be placed while
     // the CUs are not yet packed with the 10 KB workgroups of the main class -- arriving second they would wait for
     // several neighbours to finish (measured: the root part started 10-15 ms into the pass).  So the side classes are
-    // launched first, on the engine's own stream, and the main class forks onto a second stream; the timing events on
-    // the engine's stream bracket the fork and the join.
+    // launched first, largest area first, class 0 on the engine's own stream and every other class forked onto a
+    // stream of its own (they run side by side); the timing events on the engine's stream bracket the fork and the joins.
     HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
-    bool forked = false;
     for (int c = 0; c < h->num_classes; ++c) {
-      const bool is_main = c == main_class;
       const int lo = h->class_begin[c], cnt = h->class_begin[c + 1] - lo;
       if (cnt <= 0) continue;
       KernelArgs b = a;
       b.order = a.order + lo; b.lds_slab_bytes = h->class_lds[c];
-      if (is_main && h->num_classes > 1) {
-        hipStream_t sm = h->class_stream[1];
-        HIP_TRY(hipStreamWaitEvent(sm, h->ev_fork, 0));
-        hipLaunchKernelGGL(k_run_moves, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(h->ev_join[1], sm));
-        forked = true;
-      } else if (is_main) {
-        hipLaunchKernelGGL(k_run_moves, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), h->stream, b);
-        HIP_TRY(hipGetLastError());
-      } else {   // side classes share the engine's stream: they are few and short-listed, and run back to back
-        hipLaunchKernelGGL(k_run_moves_side, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), h->stream, b);
-        HIP_TRY(hipGetLastError());
-      }
+      hipStream_t sm = c == 0 ? h->stream : h->class_stream[c];
+      if (c != 0) HIP_TRY(hipStreamWaitEvent(sm, h->ev_fork, 0));
+      if (c == main_class) hipLaunchKernelGGL(k_run_moves, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
+      else hipLaunchKernelGGL(k_run_moves_side, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
+      HIP_TRY(hipGetLastError());
+      if (c != 0) { HIP_TRY(hipEventRecord(h->ev_join[c], sm)); HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[c], 0)); }
     }
-    if (forked) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[1], 0));
   }
   HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
   h->host_slabs_current = false; h->headers_current = false;
@@ -1213,13 +1246,14 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   }
   if (const char* e = getenv("EMAT_LDS_MAX")) h->cfg_lds_max = (uint32_t)atoi(e) & ~511u;
   if (const char* e = getenv("EMAT_GIANTS")) h->cfg_giants = atoi(e) != 0;
+  if (const char* e = getenv("EMAT_TREE_HOST_COALESCENT")) h->cfg_gt_host_coal = atoi(e) != 0;
   if (const char* e = getenv("EMAT_ORDER_BY_TIME")) h->cfg_order_by_time = atoi(e) != 0;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return EMAT_ERR_HIP; h->num_cus = prop.multiProcessorCount; }
   if (hipStreamCreate(&h->stream) != hipSuccess) return EMAT_ERR_HIP;
   for (hipEvent_t* e : {&h->ev_start, &h->ev_stop}) if (hipEventCreate(e) != hipSuccess) return EMAT_ERR_HIP;
   if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return EMAT_ERR_HIP;
   for (int c = 1; c < emat_backend::k_max_classes; ++c) {
-    if (hipStreamCreate(&h->class_stream[c]) != hipSuccess) return EMAT_ERR_HIP;
+    if (!(h->class_stream[c] = side_stream(cfg->device, c - 1))) return EMAT_ERR_HIP;
     if (hipEventCreateWithFlags(&h->ev_join[c], hipEventDisableTiming) != hipSuccess) return EMAT_ERR_HIP;
   }
   *out = h.release();
@@ -1231,7 +1265,7 @@ emat_status emat_backend_destroy(emat_backend* h) {
   (void)hipSetDevice(h->cfg.device);
   if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
   for (int c = 1; c < emat_backend::k_max_classes; ++c) {
-    if (h->class_stream[c]) { (void)hipStreamSynchronize(h->class_stream[c]); (void)hipStreamDestroy(h->class_stream[c]); }
+    if (h->class_stream[c]) (void)hipStreamSynchronize(h->class_stream[c]);   // shared with the other handles of the device: never destroyed
     if (h->ev_join[c]) (void)hipEventDestroy(h->ev_join[c]);
   }
   for (hipEvent_t e : {h->ev_start, h->ev_stop, h->ev_fork}) if (e) (void)hipEventDestroy(e);
@@ -1389,6 +1423,10 @@ emat_status emat_run_moves_per_part(emat_backend* h, int64_t moves_per_part) {
 emat_status emat_run_moves_split(emat_backend* h, int64_t moves_per_part, int64_t extra_moves_part0) {
   if (!h || moves_per_part < 0 || extra_moves_part0 < 0) return EMAT_ERR_INVALID_ARGUMENT;
   return launch_moves(h, moves_per_part, extra_moves_part0);
+}
+emat_status emat_run_moves_even(emat_backend* h, int64_t moves_per_part, int32_t one_more_below) {
+  if (!h || moves_per_part < 0 || one_more_below < 0 || one_more_below > (int64_t)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  return launch_moves(h, moves_per_part, 0, nullptr, one_more_below);
 }
 emat_status emat_synchronize(emat_backend* h) {
   if (!h) return EMAT_ERR_INVALID_ARGUMENT;
@@ -1755,7 +1793,7 @@ emat_status emat_debug_variant_counts(emat_backend* h, int32_t* out3) {
   st = materialize(h); if (st) return st;
   st = pull_from_device(h); if (st) return st;
   out3[0] = out3[1] = out3[2] = 0;
-  const uint32_t area = h->class_lds[std::min(1, h->num_classes - 1)];
+  const uint32_t area = h->class_lds[h->num_classes - 1];
   const bool tables = h->num_partitions <= k_max_lds_partitions;
   for (auto& ph : h->parts) {
     const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + ph.slab_off);

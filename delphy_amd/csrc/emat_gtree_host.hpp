@@ -179,7 +179,16 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
   h->have_pop = true; h->model_dirty = true;
   st = sync_model_to_device(h); if (st) return st;
   G.P = P; G.root_part = root_part; G.parts_live = false;
+  const bool device_coal = !h->cfg_gt_host_coal;
   HIP_TRY(G.part_off.upload(part_offset, (size_t)P + 1)); HIP_TRY(G.orig.upload(orig, total)); HIP_TRY(G.kid0.upload(kid0, total)); HIP_TRY(G.kid1.upload(kid1, total));
+  if (device_coal) {
+    std::vector<int32_t> lpar(total, EMAT_NO_NODE);
+    parallel_for(P, [&](int p) {
+      const int b = part_offset[p], np = part_offset[p + 1] - b;
+      for (int s = 0; s < np; ++s) if (kid0[b + s] != EMAT_NO_NODE) { lpar[b + kid0[b + s]] = s; lpar[b + kid1[b + s]] = s; }
+    }, 64);
+    HIP_TRY(G.lpar.upload(lpar.data(), total));
+  }
   HIP_TRY(G.measure.alloc(P));
   HIP_TRY(G.pool_muts.alloc(std::max<size_t>(G.pool_muts.n, (size_t)64 * P + 4096))); HIP_TRY(G.pool_ivs.alloc(std::max<size_t>(G.pool_ivs.n, (size_t)64 * P + 4096)));
   HIP_TRY(G.pool_tops.alloc(2));
@@ -201,8 +210,9 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
     PartHost& ph = h->parts[p];
     const int b = part_offset[p], np = part_offset[p + 1] - b;
     FlatTree& t = ph.tree;
-    t.resize_nodes(np); t.root = 0;
-    for (int s = 0; s < np; ++s) {
+    if (!device_coal) t.resize_nodes(np);   // (with the tables built on the device the host never needs the part's tree: a pull decodes it from the slab)
+    t.root = 0;
+    for (int s = 0; s < np && !device_coal; ++s) {
       const int32_t o = orig[b + s], k0 = kid0[b + s], k1 = kid1[b + s];
       t.child0[s] = k0; t.child1[s] = k1;
       if (k0 != EMAT_NO_NODE) { t.parent[k0] = s; t.parent[k1] = s; }
@@ -215,7 +225,7 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
     ph.uploaded = true; ph.stats = emat_part_stats{}; ph.expected_moves = 0; ph.space_boost = 1.0; ph.trace.clear();
   }, 64);
   const auto t2 = now();
-  try {
+  if (!device_coal) try {
     std::vector<const FlatTree*> trees; std::vector<HostRng*> rngs;
     for (auto& ph : h->parts) { trees.push_back(&ph.tree); rngs.push_back(&ph.rng); }
     auto cps = make_coalescent_parts(trees, root_part, h->pop, rngs, t_step);
@@ -243,6 +253,32 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
   uint64_t off = 0; h->max_slab_bytes = 0; h->persistent_bytes.assign(P, 0); h->prefix_bytes.assign(P, 0);
   std::vector<GPartDesc> desc(P); std::vector<uint64_t> offs(P);
   uint64_t cells_bytes = 0;
+  GCoal co{};
+  std::vector<int> first_active(P, 0);
+  if (device_coal) {
+    // CoalBuilder::local_range / set_range / local_grid's cell ranges from the parts' time ranges (plain arithmetic: the
+    // same numbers as on the host); the tables themselves are filled by k_gt_coal_* below
+    using namespace coal_detail;
+    double all_min = std::numeric_limits<double>::max(), all_max = -std::numeric_limits<double>::max();
+    for (int p = 0; p < P; ++p) { all_min = std::min(all_min, me[p].t_min); all_max = std::max(all_max, me[p].t_max); }
+    co.t_ref = all_max; co.t_step = t_step; co.num_cells = cell_for(all_min, all_max, t_step) + 1;
+    uint64_t pool = 0;
+    for (int p = 0; p < P; ++p) {
+      HostCoalPart& c = h->parts[p].coal;
+      const int fc = cell_for(me[p].t_max, co.t_ref, t_step), lc = cell_for(p == root_part ? all_min : me[p].t_min, co.t_ref, t_step);
+      if (!(0 <= fc && fc <= lc && lc < co.num_cells)) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "coalescent grid: bad cell range");
+      const int wf = std::min(fc, std::max(0, cell_for(me[p].t_max_exact, co.t_ref, t_step)));
+      first_active[p] = fc;
+      c = HostCoalPart{}; c.cell_first = wf; c.n_cells_total = lc + 1; c.t_ref = co.t_ref; c.t_step = t_step;
+      c.k_bar_p.resize((size_t)(lc - wf + 1));   // only its length is used before the next pull decodes the real tables
+      h->parts[p].rng.counter = (uint64_t)(lc - fc + 1);   // one Philox block per Gaussian draw
+      desc[p].cells_off = pool; pool += (uint64_t)(lc - wf + 1);
+    }
+    HIP_TRY(G.co_kbar.alloc(pool)); HIP_TRY(G.co_ktw.alloc(pool));
+    HIP_TRY(G.co_k_bar.alloc(co.num_cells)); HIP_TRY(G.co_k_tw.alloc(co.num_cells)); HIP_TRY(G.co_popsize.alloc(co.num_cells)); HIP_TRY(G.co_num_active.alloc(co.num_cells));
+    co.kbar_pool = G.co_kbar.p; co.ktw_pool = G.co_ktw.p; co.k_bar = G.co_k_bar.p; co.k_tw = G.co_k_tw.p; co.popsize = G.co_popsize.p; co.num_active = G.co_num_active.p;
+    co.status = G.status.p;
+  }
   for (int p = 0; p < P; ++p) {
     PartHost& ph = h->parts[p];
     const int nc = (int)ph.coal.k_bar_p.size();
@@ -254,33 +290,52 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
     d.flags = ph.includes_run_root ? k_flag_includes_run_root : 0u;
     d.rng_key = ph.rng.key; d.rng_counter = ph.rng.counter; d.rng_spare = ph.rng.spare; d.rng_has_spare = ph.rng.has_spare ? 1u : 0u;
     d.cell_first = ph.coal.cell_first; d.n_cells = nc; d.n_cells_total = ph.coal.n_cells_total; d.t_ref = ph.coal.t_ref; d.t_step = ph.coal.t_step;
-    d.cells_off = cells_bytes; cells_bytes += (uint64_t)nc * 32u + (((uint64_t)nc * 4u + 7u) & ~(uint64_t)7u);
+    if (device_coal) { d.cells_off = desc[p].cells_off; d.coal_first_active = first_active[p]; }
+    else { d.cells_off = cells_bytes; cells_bytes += (uint64_t)nc * 32u + (((uint64_t)nc * 4u + 7u) & ~(uint64_t)7u); d.coal_first_active = ph.coal.cell_first; }
     desc[p] = d;
   }
+  const auto t5 = now();
   assign_size_classes(h);
   h->order_valid = false;
+  const auto t6 = now();
   std::vector<uint8_t> cells(cells_bytes);
-  parallel_for(P, [&](int p) {
+  if (!device_coal) parallel_for(P, [&](int p) {
     const HostCoalPart& c = h->parts[p].coal; const size_t nc = c.k_bar_p.size();
     double* w = (double*)(cells.data() + desc[p].cells_off);
     std::copy(c.k_bar_p.begin(), c.k_bar_p.end(), w); std::copy(c.k_twiddle_bar_p.begin(), c.k_twiddle_bar_p.end(), w + nc);
     std::copy(c.k_twiddle_bar.begin(), c.k_twiddle_bar.end(), w + 2 * nc); std::copy(c.popsize_bar.begin(), c.popsize_bar.end(), w + 3 * nc);
     std::copy(c.num_active_parts.begin(), c.num_active_parts.end(), (int32_t*)(w + 4 * nc));
   }, 64);
+  const auto t7 = now();
   HIP_TRY(G.desc.upload(desc.data(), (size_t)P)); HIP_TRY(G.cells.upload(cells.data(), cells.size()));
   HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
   HIP_TRY(h->d_slabs.alloc(off)); HIP_TRY(h->h_slabs.resize(off));
   HIP_TRY(h->d_part_ticks.alloc(2 * (size_t)P)); HIP_TRY(hipMemsetAsync(h->d_part_ticks.p, 0, 2 * (size_t)P * sizeof(int64_t), h->stream));
   HIP_TRY(h->d_part_status.alloc((size_t)P)); HIP_TRY(hipMemsetAsync(h->d_part_status.p, 0, (size_t)P * sizeof(int32_t), h->stream));
+  if (device_coal) {
+    HIP_TRY(hipMemsetAsync(G.status.p, 0, sizeof(int32_t), h->stream));
+    const unsigned cell_blocks = (unsigned)co.num_cells;
+    hipLaunchKernelGGL(k_gt_coal_kbar, dim3((unsigned)P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), (const GPartDesc*)G.desc.p, co);
+    hipLaunchKernelGGL(k_gt_coal_grid, dim3(cell_blocks), dim3(k_wave), 0, h->stream, P, (const GPartDesc*)G.desc.p, co, (const PopTable*)h->d_pop.p);
+    hipLaunchKernelGGL(k_gt_coal_draw, dim3((unsigned)P), dim3(k_wave), 0, h->stream, (const GPartDesc*)G.desc.p, co);
+    hipLaunchKernelGGL(k_gt_coal_ktw, dim3(cell_blocks), dim3(k_wave), 0, h->stream, P, (const GPartDesc*)G.desc.p, co);
+    HIP_TRY(hipGetLastError());
+  }
   hipLaunchKernelGGL(k_gt_build, dim3((unsigned)P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const GMeasure*)G.measure.p, (const GPartDesc*)G.desc.p,
-                     (const uint8_t*)G.cells.p, h->d_slabs.p, (const uint64_t*)h->d_slab_off.p);
+                     (const uint8_t*)G.cells.p, co, h->d_slabs.p, (const uint64_t*)h->d_slab_off.p);
   HIP_TRY(hipGetLastError());
+  if (device_coal) {   // a lineage outside its part's window, or a grid whose last cell no part is active in: the host builder throws on both
+    int32_t cst = 0;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(&cst, G.status.p, sizeof(cst), hipMemcpyDeviceToHost));
+    if (cst != k_gt_ok) { h->slabs_on_device = false; h->parts.clear(); return fail(h, EMAT_ERR_INVALID_ARGUMENT, "coalescent grid: a lineage outside its part's cells, or an inactive final cell"); }
+  }
   h->slabs_on_device = true; h->host_slabs_current = false; h->headers_current = false; h->derived_valid = false;
   G.parts_live = true;
   if (verbose) {
     HIP_TRY(hipStreamSynchronize(h->stream));
-    fprintf(stderr, "[emat] tree_repartition: checks + uploads %.1f ms | skeletons %.1f ms | coalescent cells %.1f ms | wait for k_gt_measure %.1f ms | geometry + cells + k_gt_build %.1f ms\n",
-            ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
+    fprintf(stderr, "[emat] tree_repartition: checks + uploads %.1f ms | part records %.1f ms | host coalescent tables %.1f ms | wait for k_gt_measure %.1f ms | geometry %.1f ms | size classes %.1f ms | "
+                    "packing %.1f ms | uploads + kernels %.1f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, t6), ms(t6, t7), ms(t7, now()));
   }
   return EMAT_OK;
 }
@@ -290,11 +345,16 @@ emat_status emat_tree_reassemble(emat_backend* h, int32_t* num_root_deltas, int3
   emat_status st = gt_require(h, true); if (st) return st;
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   GTreeHost& G = h->gt;
+  const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = now();
   if (!G.parts_live) return fail(h, EMAT_ERR_STATE, "emat_tree_repartition first");
   if ((int)h->parts.size() != G.P) return fail(h, EMAT_ERR_STATE, "the parts on the device are not the ones emat_tree_repartition made");
   st = finish_pass(h); if (st) return st;          // every chain ran to completion (or was given more room and finished)
   st = materialize(h); if (st) return st;          // (a recovery leaves the parts decoded on the host: back onto their slabs)
   HIP_TRY(G.root_deltas.alloc(k_gt_max_root_deltas)); HIP_TRY(G.n_root_deltas.alloc(1));
+  const auto t1 = now();
   int32_t status = 0, nd = 0;
   for (int attempt = 0;; ++attempt) {
     HIP_TRY(hipMemsetAsync(G.tops.p, 0, 3 * sizeof(uint32_t), h->stream));
@@ -311,6 +371,7 @@ emat_status emat_tree_reassemble(emat_backend* h, int32_t* num_root_deltas, int3
     // the atomics kept counting: G.used is what the heaps need (nothing of the old content is read by the gather)
     HIP_TRY(G.mut_heap.alloc((size_t)G.used[0] * 2 + 1024)); HIP_TRY(G.iv_heap.alloc((size_t)G.used[1] * 2 + 1024)); HIP_TRY(G.fs_heap.alloc((size_t)G.used[2] * 2 + 1024));
   }
+  const auto t2 = now();
   HIP_TRY(hipMemcpy(&nd, G.n_root_deltas.p, sizeof(nd), hipMemcpyDeviceToHost));
   std::vector<GRootDelta> rd((size_t)nd);
   if (nd > 0) HIP_TRY(hipMemcpy(rd.data(), G.root_deltas.p, (size_t)nd * sizeof(GRootDelta), hipMemcpyDeviceToHost));
@@ -318,8 +379,11 @@ emat_status emat_tree_reassemble(emat_backend* h, int32_t* num_root_deltas, int3
     for (const GRootDelta& d : rd) h->ref[d.site] = d.to;
     refresh_ref_derived(h);
   }
+  const auto t3 = now();
   st = gt_fetch_mirrors(h); if (st) return st;
   G.parts_live = false;
+  if (verbose) fprintf(stderr, "[emat] tree_reassemble: wait for the moves + status check %.1f ms | k_gt_gather %.1f ms | root changes (%d) + reference tables %.1f ms | topology + times D2H %.1f ms\n",
+                       ms(t0, t1), ms(t1, t2), nd, ms(t2, t3), ms(t3, now()));
   if (num_root_deltas) *num_root_deltas = nd;
   if (nd > capacity) return capacity > 0 || num_root_deltas == nullptr ? fail(h, EMAT_ERR_BUFFER_TOO_SMALL, "emat_tree_reassemble: more root changes than the caller has room for (the tree itself is complete; emat_tree_download returns the reference sequence)") : EMAT_OK;
   for (int k = 0; k < nd; ++k) { site[k] = rd[k].site; from[k] = rd[k].from; to[k] = rd[k].to; }

@@ -31,6 +31,7 @@ struct GPartition {
   const int32_t* part_off;           // [P + 1] into orig / kid0 / kid1
   const int32_t* orig;               // part-local node -> whole-tree node; local node 0 is the part's cut point
   const int32_t* kid0; const int32_t* kid1;   // part-local children (EMAT_NO_NODE for the part's tips)
+  const int32_t* lpar;               // part-local parent (EMAT_NO_NODE for local node 0), or null when the coalescent tables come from the host
 };
 
 enum GStatus : int32_t { k_gt_ok = 0, k_gt_cut_state_overflow = 1, k_gt_pool_overflow = 2, k_gt_list_too_long = 3, k_gt_inconsistent = 4, k_gt_heap_overflow = 5, k_gt_root_deltas_overflow = 6 };
@@ -40,6 +41,7 @@ struct GMeasure {                    // per part, written by k_gt_measure
   uint32_t content_bytes;            // heap bytes of the part's lists, every list rounded up to 16 (encode_slab's layout)
   uint32_t root_muts_off, root_muts_cnt, root_miss_off, root_miss_cnt;   // the cut point's state, in the pools
   int32_t status;
+  double t_min, t_max, t_max_exact;  // CoalBuilder::local_range: tips count with their float bounds, t_max_exact is the latest node time in full precision
 };
 
 struct GPools { MutRec* muts; IvRec* ivs; uint32_t mut_cap, iv_cap; uint32_t* tops; /* [2] */ };
@@ -51,7 +53,17 @@ struct GPartDesc {                   // per part, from the host: geometry of the
   uint64_t rng_key, rng_counter, rng_spare; uint32_t rng_has_spare;
   int32_t cell_first, n_cells, n_cells_total;
   double t_ref, t_step;
-  uint64_t cells_off;                // byte offset of the part's packed cells: 4 double arrays [n_cells] then 1 int32 array [n_cells]
+  uint64_t cells_off;                // host tables: byte offset of the part's packed cells (4 double arrays [n_cells] then 1 int32 array [n_cells]);
+                                     // device tables: index of the part's window in the k_bar_p / k_twiddle_bar_p pools
+  int32_t coal_first_active;         // the reference's first_cell of the part (>= cell_first): where it is active and draws k_twiddle_bar_p
+  int32_t pad;
+};
+
+struct GCoal {                       // the whole grid, built on the device (null pointers: the tables came from the host, packed in `cells`)
+  int32_t num_cells; double t_ref, t_step;
+  double* kbar_pool; double* ktw_pool;   // every part's window [cell_first, n_cells_total), back to back (GPartDesc::cells_off)
+  double* k_bar; double* k_tw; double* popsize; int32_t* num_active;   // [num_cells]
+  int32_t* status;
 };
 
 constexpr int k_gt_max_cut_intervals = 1024;
@@ -155,7 +167,22 @@ __global__ void __launch_bounds__(k_wave) k_gt_measure(GTreeDev g, GPartition pt
     content += gt_a16(nm * 16u) + gt_a16(ni * 8u) + gt_a16(nf * 8u); nm_tot += nm;
   }
   content = wave_sum_u32(content); nm_tot = wave_sum_u32(nm_tot); bad = (int)wave_sum_u32((uint32_t)bad);
+  // the part's time range (CoalBuilder::local_range): a tip of the PART counts with its float bounds -- a frozen boundary
+  // node has t_min = t_max = (float)t (run.cpp:165-168)
+  double lo = 1.7976931348623157e308, hi = -1.7976931348623157e308, hi_exact = -1.7976931348623157e308;
+  for (int s = lane; s < n; s += k_wave) {
+    const int32_t o = pt.orig[base + s];
+    const double t = g.t[o];
+    double a = t, b = t;
+    if (pt.kid0[base + s] == EMAT_NO_NODE) { if (g.c0[o] != EMAT_NO_NODE) { a = (double)(float)t; b = a; } else { a = (double)g.t_min[o]; b = (double)g.t_max[o]; } }
+    lo = a < lo ? a : lo; hi = b > hi ? b : hi; hi_exact = t > hi_exact ? t : hi_exact;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double l2 = __shfl_down(lo, off, k_wave), h2 = __shfl_down(hi, off, k_wave), e2 = __shfl_down(hi_exact, off, k_wave);
+    lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; hi_exact = e2 > hi_exact ? e2 : hi_exact;
+  }
   if (lane == 0) {
+    out[p].t_min = lo; out[p].t_max = hi; out[p].t_max_exact = hi_exact;
     out[p].content_bytes = content + gt_a16((uint32_t)n_keep * 16u) + gt_a16((uint32_t)n_acc * 8u);
     out[p].num_muts = (int32_t)(nm_tot + (uint32_t)n_keep);
     if (bad) out[p].status = k_gt_list_too_long;
@@ -163,7 +190,7 @@ __global__ void __launch_bounds__(k_wave) k_gt_measure(GTreeDev g, GPartition pt
 }
 
 // ---- pass 2: write every part's slab, byte for byte what encode_slab writes for the same part -----------------------
-__global__ void __launch_bounds__(k_wave) k_gt_build(GTreeDev g, GPartition pt, GPools pools, const GMeasure* measure, const GPartDesc* desc, const uint8_t* cells,
+__global__ void __launch_bounds__(k_wave) k_gt_build(GTreeDev g, GPartition pt, GPools pools, const GMeasure* measure, const GPartDesc* desc, const uint8_t* cells, GCoal co,
                                                      uint8_t* slabs, const uint64_t* slab_off) {
   const int p = blockIdx.x, lane = threadIdx.x;
   const int base = pt.part_off[p], n = pt.part_off[p + 1] - base;
@@ -217,7 +244,18 @@ __global__ void __launch_bounds__(k_wave) k_gt_build(GTreeDev g, GPartition pt, 
       for (uint32_t k = 0; k < nf; ++k) df[k] = sf[k];
     }
   }
-  {   // coalescent window (encode_slab's cell table)
+  if (co.kbar_pool) {   // coalescent window out of the grid built on the device (k_gt_coal_*)
+    double* cb = (double*)(slab + off_cells);
+    const int nc = d.n_cells, cap = d.cell_cap;
+    const double* kb = co.kbar_pool + d.cells_off; const double* kt = co.ktw_pool + d.cells_off;
+    for (int w = lane; w < nc; w += k_wave) {
+      const int c = d.cell_first + w;
+      const double pb = co.popsize[c];
+      cb[w] = kb[w]; cb[cap + w] = kt[w]; cb[2 * cap + w] = co.k_tw[c]; cb[3 * cap + w] = pb;
+      cb[4 * cap + w] = d.t_step / pb;
+      ((int32_t*)(cb + 5 * cap))[w] = co.num_active[c];
+    }
+  } else {   // coalescent window as the host packed it (encode_slab's cell table)
     const double* src = (const double*)(cells + d.cells_off);
     double* cb = (double*)(slab + off_cells);
     const int nc = d.n_cells, cap = d.cell_cap;
@@ -239,6 +277,96 @@ __global__ void __launch_bounds__(k_wave) k_gt_build(GTreeDev g, GPartition pt, 
     H->t_ref = d.t_ref; H->t_step = d.t_step;
     H->trace_cap = d.trace_cap; H->trace_len = 0;
   }
+}
+
+// ---- the coalescent grid on the device (Run::reset_very_scalable_coalescent_parts, run.cpp:277-293;
+//      very_scalable_coalescent.cpp:85-232; staged on the host in emat_host_model.hpp's CoalBuilder) ---------------------------
+// k_gt_coal_kbar: every part's lineage counts over its window of cells.  One lane per cell, each walking the part's nodes
+// in index order -- the order in which the reference adds the intervals, so that every cell's sum is the reference's sum.
+__device__ inline int gt_cell_for(double t, double t_ref, double t_step) { return (int)floor((t_ref - t) / t_step); }
+__device__ inline double gt_cell_ubound(int c, double t_ref, double t_step) { return t_ref - t_step * c; }
+__device__ inline double gt_cell_lbound(int c, double t_ref, double t_step) { return gt_cell_ubound(c, t_ref, t_step) - t_step; }
+// what add_interval(ts, te, +1) (very_scalable_coalescent.cpp:37-79) adds to cell i of a part whose last cell is `last`
+__device__ inline double gt_interval_share(double ts, double te, int i, int last, double t_ref, double t_step, int first_stored, int32_t* status) {
+  if (ts < te) { const double x = ts; ts = te; te = x; }
+  const int cs = gt_cell_for(ts, t_ref, t_step);
+  int ce = last;
+  if (te != gt_cell_lbound(ce, t_ref, t_step)) ce = gt_cell_for(te, t_ref, t_step);
+  if (cs < first_stored || ce > last || cs > ce) { atomicMax(status, (int32_t)k_gt_inconsistent); return 0.0; }
+  if (i < cs || i > ce) return 0.0;
+  if (cs == ce) return (ts - te) / t_step;
+  if (i == cs) return (ts - gt_cell_lbound(cs, t_ref, t_step)) / t_step;
+  if (i == ce) return (gt_cell_ubound(ce, t_ref, t_step) - te) / t_step;
+  return 1.0;
+}
+__global__ void __launch_bounds__(k_wave) k_gt_coal_kbar(GTreeDev g, GPartition pt, const GPartDesc* desc, GCoal co) {
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int base = pt.part_off[p], n = pt.part_off[p + 1] - base;
+  const GPartDesc d = desc[p];
+  const int first = d.cell_first, last = d.n_cells_total - 1;
+  double* kb = co.kbar_pool + d.cells_off;
+  for (int i = first + lane; i <= last; i += k_wave) {
+    double k = 0.0;
+    for (int s = 1; s < n; ++s) {
+      const double share = gt_interval_share(g.t[pt.orig[base + pt.lpar[base + s]]], g.t[pt.orig[base + s]], i, last, co.t_ref, co.t_step, first, co.status);
+      if (share != 0.0) k += share;   // (adding 0.0 would not change k either: kept out for speed)
+    }
+    if (p == pt.root_part) k += gt_interval_share(gt_cell_lbound(co.num_cells - 1, co.t_ref, co.t_step), g.t[pt.orig[base]], i, last, co.t_ref, co.t_step, first, co.status);
+    kb[i - first] = k;
+  }
+}
+// k_gt_coal_grid: one wavefront per cell of the whole grid -- sum of the parts' counts, number of active parts, mean
+// population size.  Lane l adds up the parts l, l + 64, ... in ascending order and the 64 partial sums are folded in a
+// fixed tree: the same bits on every run (the reference's plain part-order sum differs from it by rounding only).
+__device__ inline double gt_wave_fold(double x) {
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, k_wave);
+  return x;   // valid in lane 0
+}
+__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY k_gt_coal_grid(int num_parts, const GPartDesc* desc, GCoal co, const PopTable* pop) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  double k = 0.0; uint32_t active = 0;
+  for (int p = lane; p < num_parts; p += k_wave) {
+    const int first = desc[p].cell_first, fa = desc[p].coal_first_active, last = desc[p].n_cells_total - 1;
+    if (c >= first && c <= last) k += co.kbar_pool[desc[p].cells_off + (uint64_t)(c - first)];
+    if (c >= fa && c <= last) ++active;
+  }
+  k = gt_wave_fold(k); active = wave_sum_u32(active);
+  if (lane != 0) return;
+  co.k_bar[c] = k; co.num_active[c] = (int32_t)active;
+  co.popsize[c] = dev::pop_integral(*pop, gt_cell_lbound(c, co.t_ref, co.t_step), gt_cell_ubound(c, co.t_ref, co.t_step)) / co.t_step;
+  if (c == co.num_cells - 1 && active == 0) atomicMax(co.status, (int32_t)k_gt_inconsistent);
+}
+// k_gt_coal_draw: every part draws k_twiddle_bar_p over its active cells from its own stream.  A Gaussian takes one whole
+// Philox block (emat_device_core.hpp `gaussian`), so draw j of a fresh stream is block j: one lane per cell.
+__global__ void __launch_bounds__(k_wave) k_gt_coal_draw(const GPartDesc* desc, GCoal co) {
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const GPartDesc d = desc[p];
+  const int first = d.cell_first, fa = d.coal_first_active, last = d.n_cells_total - 1;
+  const double* kb = co.kbar_pool + d.cells_off; double* kt = co.ktw_pool + d.cells_off;
+  for (int i = first + lane; i <= last; i += k_wave) {
+    double v = 0.0;
+    if (i >= fa) {
+      const int na = co.num_active[i];
+      const double mu = kb[i - first] - co.k_bar[i] / na;
+      const double sigma = sqrt(co.popsize[i] / (na * co.t_step));
+      uint32_t w[4];
+      dev::philox4x32_10((uint64_t)(i - fa), d.rng_key, w);
+      const uint64_t a = (uint64_t)w[0] | ((uint64_t)w[1] << 32), b = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+      const double u1 = dev::to_oc(a), u2 = dev::to_co(b);
+      v = mu + sigma * (sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925 * u2));
+    }
+    kt[i - first] = v;
+  }
+}
+__global__ void __launch_bounds__(k_wave) k_gt_coal_ktw(int num_parts, const GPartDesc* desc, GCoal co) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  double k = 0.0;
+  for (int p = lane; p < num_parts; p += k_wave) {
+    const int first = desc[p].cell_first, fa = desc[p].coal_first_active, last = desc[p].n_cells_total - 1;
+    if (c >= fa && c <= last) k += co.ktw_pool[desc[p].cells_off + (uint64_t)(c - first)];
+  }
+  k = gt_wave_fold(k);
+  if (lane == 0) co.k_tw[c] = k;
 }
 
 // ---- gather: every part writes the nodes it owns back into the whole tree (run.cpp:195-256) ---------------------------

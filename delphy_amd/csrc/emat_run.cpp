@@ -607,6 +607,13 @@ struct RunDriver {
     return EMAT_OK;
   }
 
+  // Run::run_local_moves (run.cpp:682-693) with the remainder of count / parts spread one move per part instead of all
+  // on part 0 (emat_run_moves_even explains why)
+  emat_status run_moves(int64_t count) {
+    const int64_t P = shard_world > 1 ? (int64_t)(part_hi - part_lo) : (int64_t)parts.size(), sub = count / P;   // (a sharded run goes through emat_run_moves_sharded)
+    return bk(emat_run_moves_even(backend, sub, (int32_t)(count - P * sub)));
+  }
+
   emat_status repartition() {   // run.cpp:110-193 (+ refresh_partition_stencils :87-108)
     const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -812,7 +819,7 @@ emat_status emat_run_moves(emat_run* r, int64_t count) {
   if (!r || count < 0) return EMAT_ERR_INVALID_ARGUMENT;
   if (!r->d.backend) return r->d.fail(EMAT_ERR_NO_DEVICE, "no backend attached: the host driver never runs moves itself");
   if (!r->d.parts_uploaded) return r->d.fail(EMAT_ERR_STATE, "repartition first");
-  return r->d.bk(emat_run_local_moves(r->d.backend, count));
+  return r->d.run_moves(count);
 }
 emat_status emat_run_reassemble(emat_run* r) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; return r->d.reassemble(); }
 
@@ -846,7 +853,8 @@ emat_status emat_run_moves_sharded(emat_run* r, int64_t count) {   // Run::run_l
   if (!d.backend) return d.fail(EMAT_ERR_NO_DEVICE, "no backend attached: the host driver never runs moves itself");
   if (!d.parts_uploaded) return d.fail(EMAT_ERR_STATE, "repartition first");
   const int64_t P = (int64_t)d.subtrees.size(), sub = count / P, rem = count - P * sub;
-  return d.bk(emat_run_moves_split(d.backend, sub, d.part_lo == 0 ? rem : 0));   // the remainder goes to part 0 of the run
+  // the remainder is spread one move per part over the first parts of the run (see emat_run_moves_even)
+  return d.bk(emat_run_moves_even(d.backend, sub, (int32_t)std::max<int64_t>(0, std::min<int64_t>(rem - d.part_lo, d.part_hi - d.part_lo))));
 }
 // For calc_Ttwiddle_l: the whole-tree branch length hanging below every boundary tip of the LOCAL parts, from the lengths
 // inside every part of the run and the tree of parts (a part's boundary tips are the cut nodes of the parts below it).
@@ -911,12 +919,19 @@ emat_status emat_run_do_mcmc_steps(emat_run* r, int64_t steps, int64_t per_cycle
   if (r->d.shard_world > 1) return r->d.fail(EMAT_ERR_STATE, "a sharded run is cycled by its caller, who owns the collectives (see emat_host.h)");
   if (per_cycle <= 0) per_cycle = 50 * (int64_t)r->d.tree.nodes.size();
   int64_t done = 0;
+  const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   while (done < steps) {
+    const auto t0 = now();
     emat_status st = r->d.repartition(); if (st) return st;
+    const auto t1 = now();
     int64_t k = std::min(per_cycle, steps - done);
-    st = r->d.bk(emat_run_local_moves(r->d.backend, k)); if (st) return st;
+    st = r->d.run_moves(k); if (st) return st;
+    const auto t2 = now();
     st = r->d.reassemble(); if (st) return st;
     done += k;
+    if (verbose) fprintf(stderr, "[emat_run] cycle: repartition %.1f ms | launch of the moves %.1f ms | reassemble (waits for the moves) %.1f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, now()));
   }
   if (!r->d.device_tree) r->d.normalize_root();   // (a device-resident tree is normalised by every reassemble)
   return EMAT_OK;

@@ -163,6 +163,11 @@ emat_status emat_run_moves_per_part(emat_backend* h, int64_t moves_per_part);
 /* Same, plus `extra_moves_part0` more on this handle's part 0: the split of Run::run_local_moves when the run's parts are
  * spread over several handles (the handle holding the run's part 0 gets the remainder). */
 emat_status emat_run_moves_split(emat_backend* h, int64_t moves_per_part, int64_t extra_moves_part0);
+/* NOT the reference's rule: `moves_per_part` moves on every part and one more on the parts [0, one_more_below).  The
+ * reference hands the whole remainder of count / parts to subrun 0 -- at most parts - 1 moves, nothing next to a subrun's
+ * share at 8 threads, but six times a part's share at 8 000 parts, where that one chain then sets the length of the pass
+ * (measured at C4: 62 ms instead of 34).  Spreading the remainder one move per part runs the same total. */
+emat_status emat_run_moves_even(emat_backend* h, int64_t moves_per_part, int32_t one_more_below);
 /* Waits for the launches issued so far and checks that every part ran its chain to completion.  A part that ran out of
  * list-heap or scratch space stops BEFORE a move with its state intact; it is re-materialised with twice the room and
  * the rest of its moves run, transparently (up to four doublings, then EMAT_ERR_CAPACITY).  A part that stopped INSIDE

@@ -8,7 +8,7 @@
  *     (core/tree_partitioning.h:139-239)
  *   Run::repartition (core/run.cpp:110-193)                emat_run_repartition
  *   Run::push_global_params_to_subruns (run.cpp:267-275)   emat_run_push_params
- *   Run::run_local_moves (run.cpp:682-693)                 emat_run_moves        -> emat_run_local_moves of the backend
+ *   Run::run_local_moves (run.cpp:682-693)                 emat_run_moves        -> emat_run_moves_even of the backend (remainder spread over the parts)
  *   Run::reassemble (run.cpp:195-256)                      emat_run_reassemble
  *   Run::do_mcmc_steps without the global moves            emat_run_do_mcmc_steps
  *     (run.cpp:622-657; global moves are out of scope)
@@ -98,7 +98,7 @@ emat_status emat_run_reassemble(emat_run* r);
  *   emat_run_repartition                                     every rank, no communication
  *   emat_run_coalescent_begin -> all-reduce MIN / MAX        the staged form of emat_build_coalescent_parts
  *   emat_coalescent_set_range / _local_grid -> all-reduce SUM / _sample -> all-reduce SUM / _finish   (on the backend)
- *   emat_run_moves_sharded(count)                            count / parts moves on every part of the run, remainder on part 0
+ *   emat_run_moves_sharded(count)                            count / parts moves on every part of the run, the remainder one move each on the first parts
  *   emat_run_pack_local_parts -> all-gather of the byte buffers -> emat_run_unpack_parts for every other rank's buffer
  *   emat_run_reassemble                                      every rank ends up with the same whole tree
  *   emat_get_totals on the backend -> all-reduce SUM (2 doubles)

@@ -1,11 +1,18 @@
 """the whole tree resident in HBM (emat_tree_* / emat_run_set_device_tree).  The checker is the host cycle
 (Run::repartition / Run::reassemble restated in emat_run.cpp, itself checked against the oracle in test_host_driver.py and
-test_fullsize_gpu.py): same seeds => same partitions, same slabs, same moves, same trees, bit for bit."""
+test_fullsize_gpu.py): same seeds => same partitions, same slabs, same moves, same trees, bit for bit -- with the
+coalescent tables built by the host's code (EMAT_TREE_HOST_COALESCENT=1).  By default they are built by kernels, whose
+exp / log / cos differ from glibc's in the last place: those tables are compared with the host's within 1e-12, and whole
+runs on them are checked through the oracle's from-scratch recomputation."""
+import os
+
 import numpy as np
 import pytest
 
 import delphy_amd as d
 from delphy_amd.scenarios import make_scenario
+from helpers import configure, rel_close
+from oracle_ffi import OracleEngine
 
 pytestmark = pytest.mark.gpu
 
@@ -13,8 +20,16 @@ FIELDS = ("parent", "child0", "child1", "t", "t_min", "t_max", "mut_offset", "mu
           "miss_offset", "miss_start", "miss_end", "mfs_offset", "mfs_site", "mfs_state")
 
 
-def _run(sc, seed, parts, device_tree, max_part_nodes=0):
-    b = d.EmatBackend(sc.num_sites)
+def _run(sc, seed, parts, device_tree, max_part_nodes=0, host_coalescent=True):
+    old = os.environ.get("EMAT_TREE_HOST_COALESCENT")
+    os.environ["EMAT_TREE_HOST_COALESCENT"] = "1" if host_coalescent else "0"    # read when the backend is created
+    try:
+        b = d.EmatBackend(sc.num_sites)
+    finally:
+        if old is None:
+            del os.environ["EMAT_TREE_HOST_COALESCENT"]
+        else:
+            os.environ["EMAT_TREE_HOST_COALESCENT"] = old
     run = d.EmatRun(b, sc.tree, sc.ref, seed)
     run.set_num_parts(parts)
     if max_part_nodes:
@@ -96,3 +111,59 @@ def test_tree_round_trip_and_root_sequence_changes():
     _same_tree(th, td, "after leaving HBM")
     for r in (rh, rd): r.close()
     for b in (bh, bd): b.close()
+
+
+def test_coalescent_tables_built_on_the_device():
+    """k_gt_coal_*: every part's window of the grid against CoalBuilder's (same cells, same windows, lineage counts and
+    activity counts exact, Gaussian draws and population integrals to 1e-12), the parts' RNG streams left at the same
+    position, and the trees untouched by it."""
+    for name, kw, parts in (("C3", dict(num_tips=3000, num_sites=29903, uncertain_tips=0.1), 96), ("C2", dict(num_tips=1610, num_sites=18959), 40),
+                            ("C1", dict(num_tips=150, num_sites=3000, uncertain_tips=0.3), 3)):
+        sc = make_scenario(name, **kw)
+        bh, rh = _run(sc, 5, parts, False)
+        bd, rd = _run(sc, 5, parts, True, host_coalescent=False)
+        rh.repartition(); rd.repartition()
+        n, root_part = rh.num_parts()
+        assert (n, root_part) == rd.num_parts()
+        bh.recalc_derived(); bd.recalc_derived()          # (puts the host path's parts on their slabs too)
+        for p in range(n):
+            _same_tree(bh.part_download(p), bd.part_download(p), "%s part %d" % (name, p))
+            ch, cd = bh.part_coalescent(p), bd.part_coalescent(p)
+            assert ch["t_ref"] == cd["t_ref"] and ch["t_step"] == cd["t_step"], (name, p)
+            assert np.array_equal(ch["k_bar_p"], cd["k_bar_p"]), (name, p)
+            assert np.array_equal(ch["num_active_parts"], cd["num_active_parts"]), (name, p)
+            for k in ("k_twiddle_bar_p", "k_twiddle_bar", "popsize_bar"):
+                a, b = np.asarray(ch[k]), np.asarray(cd[k])
+                assert a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)), (name, p, k)
+                ok = ~np.isnan(a)
+                assert np.all(np.abs(a[ok] - b[ok]) <= 1e-12 * np.maximum(1.0, np.abs(a[ok]))), (name, p, k, np.max(np.abs(a[ok] - b[ok])))
+            assert bh.part_stats(p)["rng_draws"] == bd.part_stats(p)["rng_draws"], (name, p)
+        gh, gd = bh.totals(), bd.totals()
+        assert gh[0] == gd[0] and rel_close(gh[1], gd[1], 1e-11), (name, gh, gd)
+        for r in (rh, rd): r.close()
+        for b in (bh, bd): b.close()
+
+
+def test_whole_cycles_on_the_device_built_tables():
+    """The default path end to end: six cycles, then the tree that comes back from HBM is a valid EMAT by the oracle's
+    integrity check, the incremental totals of a fresh pass equal the from-scratch ones, and the tips are where they were."""
+    sc = make_scenario("C3", num_tips=3000, num_sites=29903, uncertain_tips=0.1)
+    b, run = _run(sc, 9, 128, True, host_coalescent=False)
+    run.do_mcmc_steps(6 * 128 * 500, 128 * 500)
+    tree, ref = run.tree()
+    assert tree.num_nodes == sc.tree.num_nodes and not np.array_equal(tree.parent, sc.tree.parent)
+    tips = tree.child0 == -1
+    assert np.array_equal(tips, sc.tree.child0 == -1)
+    assert np.array_equal(tree.t_min, sc.tree.t_min) and np.array_equal(tree.t_max, sc.tree.t_max)
+    assert np.all(tree.t[tips] >= tree.t_min[tips] - 1e-2) and np.all(tree.t[tips] <= tree.t_max[tips] + 1e-2)
+    chk = OracleEngine(sc.num_sites)
+    sc.tree, sc.ref = tree, ref
+    configure(chk, sc, ref, [tree], [True], [1], 0)
+    rc, msg = chk.part_check(0)
+    assert rc == 0, msg
+    # one more pass: incremental log G / prior against the recomputation
+    run.repartition(); run.run_moves(128 * 300); b.synchronize()
+    inc = b.totals(); b.recalc_derived(); rec = b.totals()
+    assert rel_close(inc[0], rec[0], 1e-9) and rel_close(inc[1], rec[1], 1e-9), (inc, rec)
+    run.reassemble()
+    chk.close(); run.close(); b.close()

@@ -8,7 +8,7 @@ import pytest
 
 import delphy_amd as d
 from delphy_amd.scenarios import make_scenario
-from helpers import configure, rel_close, run_parity, split_parts
+from helpers import assert_trees_match, configure, rel_close, run_parity, split_parts
 from oracle_ffi import OracleEngine
 
 pytestmark = pytest.mark.gpu
@@ -124,6 +124,26 @@ def test_run_local_moves_remainder_goes_to_part_zero():
     """Run::run_local_moves (run.cpp:682-693): count / parts moves on every part, the remainder on part 0."""
     sc = make_scenario("C1", num_tips=80, num_sites=3000)
     run_parity(sc, 3, 1, seed=41, total_moves=3 * 1500 + 2, trace=0)
+
+
+def test_run_moves_even_spreads_the_remainder_one_move_per_part():
+    """emat_run_moves_even: the same number of moves on every part and one more on the first parts; each part's chain is the
+    oracle's chain of that length."""
+    sc = make_scenario("C1", num_tips=120, num_sites=3000)
+    parts, incl, seeds, root_part, ref = split_parts(sc, 5, 43)
+    gpu = d.EmatBackend(sc.num_sites)
+    orc = OracleEngine(sc.num_sites)
+    try:
+        configure(gpu, sc, ref, parts, incl, seeds, root_part)
+        configure(orc, sc, ref, parts, incl, seeds, root_part)
+        gpu.run_moves_even(700, 3); gpu.synchronize()
+        counts = [700 + (1 if p < 3 else 0) for p in range(len(parts))]
+        orc.run_moves_counts(counts)
+        for p in range(len(parts)):
+            assert gpu.part_stats(p)["moves_done"] == counts[p]
+            assert_trees_match(gpu.part_download(p), orc.part_download(p), 1e-9, "part %d" % p)
+    finally:
+        gpu.close(); orc.close()
 
 
 def _stats_parity(sc, num_parts, moves, seed, evo=None, P=1):
