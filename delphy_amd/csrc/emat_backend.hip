@@ -590,7 +590,8 @@ struct PartHost {
   bool uploaded = false;
   // slab geometry
   uint64_t slab_off = 0;
-  uint32_t slab_bytes = 0;
+  uint32_t slab_bytes = 0, scratch_bytes = 0;
+  int32_t n_nodes = 0;             // (the tree itself may live only on the device: emat_tree_repartition)
   emat_part_stats stats{};
   std::vector<double> trace;       // the part's move trace so far (4 doubles per move), carried over re-materialisations
   int64_t expected_moves = 0;      // moves requested of this part since its upload
@@ -912,10 +913,10 @@ emat_status finish_pass(emat_backend* h) {
       for (size_t p = 0; p < n; ++p) { sum += (double)ticks[p]; first = std::min(first, ticks[n + p]); last = std::max(last, ticks[n + p] + ticks[p]); }
       float kms = 0.f; (void)hipEventElapsedTime(&kms, h->ev_start, h->ev_stop);
       fprintf(stderr, "[emat] pass: %.1f ms on the device (first start to last end %.1f ms) | chains: mean %.2f ms, slowest", kms, (last - first) / 1e5, sum / n / 1e5);
-      for (size_t k = 0; k < std::min<size_t>(4, n); ++k) fprintf(stderr, " %.1f ms from %.1f (part %d, %d nodes%s)", ticks[idx[k]] / 1e5, (ticks[n + idx[k]] - first) / 1e5, idx[k], h->parts[idx[k]].tree.num_nodes(), idx[k] == h->root_part ? ", root part" : "");
+      for (size_t k = 0; k < std::min<size_t>(4, n); ++k) fprintf(stderr, " %.1f ms from %.1f (part %d, %d nodes%s)", ticks[idx[k]] / 1e5, (ticks[n + idx[k]] - first) / 1e5, idx[k], h->parts[idx[k]].n_nodes, idx[k] == h->root_part ? ", root part" : "");
       std::partial_sort(idx.begin(), idx.begin() + std::min<size_t>(3, n), idx.end(), [&](int a, int b) { return ticks[n + a] + ticks[a] > ticks[n + b] + ticks[b]; });
       fprintf(stderr, " | last to end:");
-      for (size_t k = 0; k < std::min<size_t>(3, n); ++k) fprintf(stderr, " part %d (%d nodes, %u B) %.1f ms from %.1f", idx[k], h->parts[idx[k]].tree.num_nodes(), h->persistent_bytes[idx[k]], ticks[idx[k]] / 1e5, (ticks[n + idx[k]] - first) / 1e5);
+      for (size_t k = 0; k < std::min<size_t>(3, n); ++k) fprintf(stderr, " part %d (%d nodes, %u B) %.1f ms from %.1f", idx[k], h->parts[idx[k]].n_nodes, h->persistent_bytes[idx[k]], ticks[idx[k]] / 1e5, (ticks[n + idx[k]] - first) / 1e5);
       fprintf(stderr, "\n");
     }
     if (stopped == 0) { if (round == 0 && h->last_launch_uniform) (void)refresh_order_from_ticks(h); return EMAT_OK; }
@@ -1011,7 +1012,7 @@ SlabGeo slab_geometry(const emat_backend* h, int n, int num_muts, uint32_t conte
 }
 void place_slab(emat_backend* h, size_t p, const SlabGeo& g, uint64_t& off) {
   PartHost& ph = h->parts[p];
-  ph.slab_off = off; ph.slab_bytes = g.bytes; off += g.bytes;
+  ph.slab_off = off; ph.slab_bytes = g.bytes; ph.scratch_bytes = g.scratch; off += g.bytes;
   h->persistent_bytes[p] = g.bytes - g.scratch;
   h->prefix_bytes[p] = g.bytes - g.scratch - g.heap;
   h->max_slab_bytes = std::max(h->max_slab_bytes, g.bytes);
@@ -1322,7 +1323,7 @@ emat_status emat_part_upload(emat_backend* h, int32_t part_id, const emat_flat_t
   }
   PartHost& ph = h->parts[part_id];
   if (ph.uploaded) return fail(h, EMAT_ERR_STATE, "part uploaded twice");
-  ph.tree = FlatTree::from_view(*subtree);
+  ph.tree = FlatTree::from_view(*subtree); ph.n_nodes = subtree->num_nodes;
   ph.includes_run_root = includes_run_root != 0;
   ph.rng.key = seed; ph.rng.counter = 0; ph.rng.spare = 0; ph.rng.has_spare = false;
   ph.uploaded = true; ph.stats = emat_part_stats{}; ph.expected_moves = 0; ph.space_boost = 1.0; ph.trace.clear();
@@ -1548,10 +1549,8 @@ emat_status emat_get_global_stats(emat_backend* h, int32_t num_partitions, doubl
   st = materialize(h); if (st) return st;
   if (h->pass_pending) { st = finish_pass(h); if (st) return st; }   // statistics of chains that finished their moves, or a loud failure
   const int W = 4 * num_partitions;
-  for (auto& ph : h->parts) {   // the per-node table lives in the part's scratch region
-    const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + ph.slab_off);
-    if ((uint64_t)ph.tree.num_nodes() * W * 8u > (uint64_t)ph.slab_bytes - H->scratch_begin) return fail(h, EMAT_ERR_CAPACITY, "scratch region too small for the statistics table");
-  }
+  for (auto& ph : h->parts)   // the per-node table lives in the part's scratch region
+    if ((uint64_t)ph.n_nodes * W * 8u > (uint64_t)ph.scratch_bytes) return fail(h, EMAT_ERR_CAPACITY, "scratch region too small for the statistics table");
   const size_t n = h->parts.size();
   if (h->d_stats.n < n * k_stats_row) { std::vector<double> z(n * k_stats_row, 0.0); HIP_TRY(h->d_stats.upload(z.data(), z.size())); }
   KernelArgs a = make_args(h);
@@ -1624,9 +1623,8 @@ emat_status emat_Ttwiddle_l_partial(emat_backend* h, const int32_t* ext_offset, 
   if (n_ext < 0 || (n_ext > 0 && (!ext_node || !ext_length))) return EMAT_ERR_INVALID_ARGUMENT;
   for (size_t p = 0; p < n; ++p) {
     if (ext_offset[p] > ext_offset[p + 1]) return EMAT_ERR_INVALID_ARGUMENT;
-    for (int32_t k = ext_offset[p]; k < ext_offset[p + 1]; ++k) if (ext_node[k] < 0 || ext_node[k] >= h->parts[p].tree.num_nodes()) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "ext_node out of range");
-    const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + h->parts[p].slab_off);
-    if ((uint64_t)h->parts[p].tree.num_nodes() * 8u > (uint64_t)h->parts[p].slab_bytes - H->scratch_begin) return fail(h, EMAT_ERR_CAPACITY, "scratch region too small for the length table");
+    for (int32_t k = ext_offset[p]; k < ext_offset[p + 1]; ++k) if (ext_node[k] < 0 || ext_node[k] >= h->parts[p].n_nodes) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "ext_node out of range");
+    if ((uint64_t)h->parts[p].n_nodes * 8u > (uint64_t)h->parts[p].scratch_bytes) return fail(h, EMAT_ERR_CAPACITY, "scratch region too small for the length table");
   }
   DevBuf<int32_t> d_off, d_node; DevBuf<double> d_val, d_S, d_D, d_T;
   HIP_TRY(d_off.upload(ext_offset, n + 1)); HIP_TRY(d_node.upload(ext_node, (size_t)n_ext)); HIP_TRY(d_val.upload(ext_length, (size_t)n_ext));

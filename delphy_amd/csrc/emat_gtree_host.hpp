@@ -220,7 +220,7 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
       if (k0 == EMAT_NO_NODE && G.h_c0[o] != EMAT_NO_NODE) { t.t_min[s] = (float)G.h_t[o]; t.t_max[s] = (float)G.h_t[o]; }
       else { t.t_min[s] = G.h_t_min[o]; t.t_max[s] = G.h_t_max[o]; }
     }
-    ph.includes_run_root = p == root_part;
+    ph.includes_run_root = p == root_part; ph.n_nodes = np;
     ph.rng.key = seeds[p]; ph.rng.counter = 0; ph.rng.spare = 0; ph.rng.has_spare = false;
     ph.uploaded = true; ph.stats = emat_part_stats{}; ph.expected_moves = 0; ph.space_boost = 1.0; ph.trace.clear();
   }, 64);

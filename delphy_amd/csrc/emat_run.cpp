@@ -861,15 +861,16 @@ emat_status emat_run_moves_sharded(emat_run* r, int64_t count) {   // Run::run_l
 emat_status emat_run_Ttwiddle_ext(emat_run* r, const double* tree_length_of_part, int32_t* ext_offset, int32_t* ext_node, double* ext_length, int32_t capacity, int32_t* count) {
   if (!r || !tree_length_of_part || !ext_offset || !count || capacity < 0 || (capacity > 0 && (!ext_node || !ext_length))) return EMAT_ERR_INVALID_ARGUMENT;
   RunDriver& d = r->d;
-  const int P = (int)d.subtrees.size();
-  if (P == 0) return d.fail(EMAT_ERR_STATE, "repartition first");
+  const int P = (int)d.parts.size();
+  if (P == 0 || (int)d.part_kids.size() != P) return d.fail(EMAT_ERR_STATE, "repartition first");
   std::vector<int32_t> part_of_cut(d.tree.nodes.size(), -1);
   for (int p = 0; p < P; ++p) part_of_cut[d.parts[p].cut_point] = p;
-  // children of each part in the tree of parts: (subtree node, part below)
+  // children of each part in the tree of parts: (subtree node, part below).  A part's tips stay tips whatever the moves
+  // do, so the partition's own record of them (which also exists when the parts themselves live only on the device) serves.
   std::vector<std::vector<std::pair<int32_t, int32_t>>> kids(P);
   for (int p = 0; p < P; ++p) {
-    const FlatTree& st = d.subtrees[p];
-    for (int s = 0; s < st.num_nodes(); ++s) if (st.is_tip(s) && s != st.root) { const int q = part_of_cut[d.parts[p].orig[s]]; if (q >= 0 && q != p) kids[p].push_back({s, q}); }
+    const auto& pk = d.part_kids[p];
+    for (int s = 1; s < (int)pk.size(); ++s) if (pk[s].first == EMAT_NO_NODE) { const int q = part_of_cut[d.parts[p].orig[s]]; if (q >= 0 && q != p) kids[p].push_back({s, q}); }
   }
   // total length below each part's cut node: its own branches plus everything below its boundary tips (children first)
   std::vector<double> below(P, -1.0);
@@ -895,7 +896,7 @@ emat_status emat_run_get_Ttwiddle_l(emat_run* r, double* Ttwiddle_l) {
   if (!d.backend) return d.fail(EMAT_ERR_NO_DEVICE, "no backend attached");
   if (!d.parts_uploaded) return d.fail(EMAT_ERR_STATE, "repartition first");
   if (d.shard_world > 1) return d.fail(EMAT_ERR_STATE, "a sharded run gathers the part lengths and sums S, R across ranks itself (see emat_backend.h)");
-  const int P = (int)d.subtrees.size();
+  const int P = (int)d.parts.size();
   std::vector<double> len(P);
   emat_status st = d.bk(emat_get_part_tree_lengths(d.backend, len.data())); if (st) return st;
   std::vector<int32_t> off(P + 1), node(P); std::vector<double> val(P); int32_t cnt = 0;

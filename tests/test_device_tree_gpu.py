@@ -167,3 +167,28 @@ def test_whole_cycles_on_the_device_built_tables():
     assert rel_close(inc[0], rec[0], 1e-9) and rel_close(inc[1], rec[1], 1e-9), (inc, rec)
     run.reassemble()
     chk.close(); run.close(); b.close()
+
+
+def test_global_move_statistics_from_parts_cut_on_the_device():
+    """SURVEY 8(f).1 on top of 8(f).2: calc_Ttwiddle_l, calc_num_muts_l, calc_Ttwiddle_beta_a / calc_num_muts_ab computed from
+    the parts while they are on the device, against the oracle's whole-tree values on the tree that comes back from HBM."""
+    sc = make_scenario("C3", num_tips=900, num_sites=6000, uncertain_tips=0.2)
+    b, run = _run(sc, 61, 40, True, host_coalescent=False)
+    for cyc in range(3):
+        run.repartition()
+        n, _ = run.num_parts()
+        run.run_moves(n * 800)
+        got_T, got_n = run.Ttwiddle_l(), b.num_muts_l()
+        Tg, Mg, ng = b.global_stats(1)
+        run.reassemble()
+        whole, ref = run.tree()
+        orc = OracleEngine(sc.num_sites)
+        sc2 = make_scenario("C3", num_tips=900, num_sites=6000, uncertain_tips=0.2); sc2.tree, sc2.ref = whole, ref
+        configure(orc, sc2, ref, [whole], [True], [1], 0)
+        want_T, want_n = orc.Ttwiddle_l(0), orc.num_muts_l()
+        To, Mo, no = orc.global_stats(1)
+        orc.close()
+        assert rel_close(got_T, want_T, 1e-9), (cyc, float(np.max(np.abs(got_T - want_T))))
+        assert np.array_equal(got_n, want_n), cyc
+        assert ng == no and np.array_equal(Mg, Mo) and rel_close(Tg, To, 1e-9), cyc
+    run.close(); b.close()
