@@ -607,6 +607,7 @@ struct GTreeHost {
   DevBuf<int32_t> parent, c0, c1, root; DevBuf<double> t; DevBuf<float> t_min, t_max; DevBuf<GList> muts, miss, mfs;
   DevBuf<MutRec> mut_heap; DevBuf<IvRec> iv_heap; DevBuf<FsRec> fs_heap; DevBuf<uint32_t> tops; DevBuf<int32_t> status;
   uint32_t used[3] = {0, 0, 0};     // records in use in the three heaps
+  int32_t pool_regrows = 0, heap_regrows = 0;
   // current partition
   int32_t P = 0, root_part = -1;
   DevBuf<int32_t> part_off, orig, kid0, kid1, lpar;

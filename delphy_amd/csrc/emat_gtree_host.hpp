@@ -74,7 +74,8 @@ emat_status emat_tree_upload(emat_backend* h, const emat_flat_tree* tree) {
   HIP_TRY(G.root.upload(&tree->root, 1));
   HIP_TRY(G.muts.upload(lm.data(), n)); HIP_TRY(G.miss.upload(li.data(), n)); HIP_TRY(G.mfs.upload(lf.data(), n));
   // the moves create and destroy list records: room for twice the present content plus a record per node
-  HIP_TRY(G.mut_heap.alloc(2 * nm + (size_t)n + 1024)); HIP_TRY(G.iv_heap.alloc(2 * ni + (size_t)n + 1024)); HIP_TRY(G.fs_heap.alloc(2 * nf + (size_t)n + 1024));
+  const bool tight = getenv("EMAT_TREE_TIGHT") != nullptr;   // testing aid: no room at all, so that the growth paths run
+  HIP_TRY(G.mut_heap.alloc(tight ? nm + 1 : 2 * nm + (size_t)n + 1024)); HIP_TRY(G.iv_heap.alloc(tight ? ni + 1 : 2 * ni + (size_t)n + 1024)); HIP_TRY(G.fs_heap.alloc(tight ? nf + 1 : 2 * nf + (size_t)n + 1024));
   if (nm) HIP_TRY(hipMemcpy(G.mut_heap.p, rm.data(), nm * sizeof(MutRec), hipMemcpyHostToDevice));
   if (ni) HIP_TRY(hipMemcpy(G.iv_heap.p, ri.data(), ni * sizeof(IvRec), hipMemcpyHostToDevice));
   if (nf) HIP_TRY(hipMemcpy(G.fs_heap.p, rf.data(), nf * sizeof(FsRec), hipMemcpyHostToDevice));
@@ -190,7 +191,8 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
     HIP_TRY(G.lpar.upload(lpar.data(), total));
   }
   HIP_TRY(G.measure.alloc(P));
-  HIP_TRY(G.pool_muts.alloc(std::max<size_t>(G.pool_muts.n, (size_t)64 * P + 4096))); HIP_TRY(G.pool_ivs.alloc(std::max<size_t>(G.pool_ivs.n, (size_t)64 * P + 4096)));
+  { const size_t room = getenv("EMAT_TREE_TIGHT") ? 1 : (size_t)64 * P + 4096;
+    HIP_TRY(G.pool_muts.alloc(std::max<size_t>(G.pool_muts.n, room))); HIP_TRY(G.pool_ivs.alloc(std::max<size_t>(G.pool_ivs.n, room))); }
   HIP_TRY(G.pool_tops.alloc(2));
   const auto t1 = now();
   auto launch_measure = [&]() -> emat_status {
@@ -245,6 +247,7 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
     uint32_t tops[2];
     HIP_TRY(hipMemcpy(tops, G.pool_tops.p, sizeof(tops), hipMemcpyDeviceToHost));   // the atomics kept counting: what the pools need
     HIP_TRY(G.pool_muts.alloc((size_t)tops[0] * 2 + 4096)); HIP_TRY(G.pool_ivs.alloc((size_t)tops[1] * 2 + 4096));
+    ++G.pool_regrows;
     st = launch_measure(); if (st) return st;
   }
   const auto t4 = now();
@@ -370,6 +373,7 @@ emat_status emat_tree_reassemble(emat_backend* h, int32_t* num_root_deltas, int3
     if (status != k_gt_heap_overflow || attempt == 2) return fail(h, EMAT_ERR_INTERNAL, std::string("emat_tree_reassemble: ") + gt_status_text(status));
     // the atomics kept counting: G.used is what the heaps need (nothing of the old content is read by the gather)
     HIP_TRY(G.mut_heap.alloc((size_t)G.used[0] * 2 + 1024)); HIP_TRY(G.iv_heap.alloc((size_t)G.used[1] * 2 + 1024)); HIP_TRY(G.fs_heap.alloc((size_t)G.used[2] * 2 + 1024));
+    ++G.heap_regrows;
   }
   const auto t2 = now();
   HIP_TRY(hipMemcpy(&nd, G.n_root_deltas.p, sizeof(nd), hipMemcpyDeviceToHost));
@@ -387,6 +391,13 @@ emat_status emat_tree_reassemble(emat_backend* h, int32_t* num_root_deltas, int3
   if (num_root_deltas) *num_root_deltas = nd;
   if (nd > capacity) return capacity > 0 || num_root_deltas == nullptr ? fail(h, EMAT_ERR_BUFFER_TOO_SMALL, "emat_tree_reassemble: more root changes than the caller has room for (the tree itself is complete; emat_tree_download returns the reference sequence)") : EMAT_OK;
   for (int k = 0; k < nd; ++k) { site[k] = rd[k].site; from[k] = rd[k].from; to[k] = rd[k].to; }
+  return EMAT_OK;
+}
+
+/* debugging aid (not part of the boundary): how often the cut-state pools and the list heaps had to grow */
+emat_status emat_debug_tree_counters(emat_backend* h, int32_t* out2) {
+  if (!h || !out2) return EMAT_ERR_INVALID_ARGUMENT;
+  out2[0] = h->gt.pool_regrows; out2[1] = h->gt.heap_regrows;
   return EMAT_OK;
 }
 

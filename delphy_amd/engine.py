@@ -259,7 +259,7 @@ def load_library():
         "emat_Ttwiddle_l_finish": [B, P(dbl), P(dbl), dbl, P(dbl)],
         "emat_run_do_mcmc_steps": [R, i64, i64], "emat_run_tree_sizes": [R, P(i32), P(i32), P(i32), P(i32)],
         "emat_run_tree_get": [R, P(_FlatTreeC), P(C.c_uint8)], "emat_run_t_max_tip": [R, P(dbl)],
-        "emat_run_set_device_tree": [R, i32], "emat_run_moves_even": [B, i64, i32],
+        "emat_run_set_device_tree": [R, i32], "emat_run_moves_even": [B, i64, i32], "emat_debug_tree_counters": [B, P(i32)],
         "emat_tree_upload": [B, P(_FlatTreeC)], "emat_tree_get_sizes": [B, P(i32), P(i32), P(i32), P(i32)], "emat_tree_download": [B, P(_FlatTreeC), P(C.c_uint8)],
         "emat_tree_get_topology": [B, P(i32), P(i32), P(i32), P(dbl), P(i32)],
         "emat_tree_repartition": [B, i32, P(i32), P(i32), P(i32), P(i32), i32, P(u64), P(_PopModelC), dbl],
@@ -426,6 +426,12 @@ class EmatBackend:
 
     def synchronize(self):
         self._ck(self._lib.emat_synchronize(self._h), "emat_synchronize")
+
+    def tree_counters(self):
+        """(growths of the cut-state pools, growths of the list heaps) of the HBM-resident tree: testing aid."""
+        out = np.zeros(2, np.int32)
+        self._ck(self._lib.emat_debug_tree_counters(self._h, _ptr(out, C.c_int32)), "emat_debug_tree_counters")
+        return int(out[0]), int(out[1])
 
     def run_moves_even(self, moves_per_part: int, one_more_below: int):
         """`moves_per_part` moves on every part, one more on the parts [0, one_more_below) (not the reference's remainder rule)."""

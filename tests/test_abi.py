@@ -57,3 +57,18 @@ def test_product_never_references_the_oracle():
                 if re.search(r"oracle_ffi|orc_capi|libemat_oracle|#include\s+\"[^\"]*orc_", txt):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_the_hbm_resident_tree_has_no_host_fallback():
+    """emat_tree_* on a handle without a device: loud EMAT_ERR_NO_DEVICE, never a CPU path."""
+    import numpy as np
+    import delphy_amd as d
+    from delphy_amd.scenarios import make_scenario
+    sc = make_scenario("C1", num_tips=20, num_sites=300)
+    b = d.EmatBackend(sc.num_sites, device=-1)
+    run = d.EmatRun(b, sc.tree, sc.ref, 1)
+    run.set_num_parts(2); run.set_hky(sc.mu, sc.kappa, sc.pi); run.set_pop_model(sc.pop)
+    run.set_device_tree(True)
+    with pytest.raises(d.EmatError, match="EMAT_ERR_NO_DEVICE"):
+        run.repartition()
+    run.close(); b.close()

@@ -192,3 +192,46 @@ def test_global_move_statistics_from_parts_cut_on_the_device():
         assert np.array_equal(got_n, want_n), cyc
         assert ng == no and np.array_equal(Mg, Mo) and rel_close(Tg, To, 1e-9), cyc
     run.close(); b.close()
+
+
+def test_pools_and_heaps_grow_when_they_run_out(monkeypatch):
+    """EMAT_TREE_TIGHT starts the cut-state pools and the three list heaps without any room: the kernels report the
+    overflow, the host doubles the buffers and runs them again, and the cycles still equal the host cycles bit for bit."""
+    monkeypatch.setenv("EMAT_TREE_TIGHT", "1")
+    sc = make_scenario("C3", num_tips=1500, num_sites=29903, uncertain_tips=0.1)
+    bh, rh = _run(sc, 13, 64, False)
+    bd, rd = _run(sc, 13, 64, True)
+    for cycle in range(4):
+        rh.do_mcmc_steps(64 * 800, 64 * 800); rd.do_mcmc_steps(64 * 800, 64 * 800)
+        th, refh = rh.tree(); td, refd = rd.tree()
+        _same_tree(th, td, "cycle %d" % cycle)
+        assert np.array_equal(refh, refd), cycle
+    pool_regrows, heap_regrows = bd.tree_counters()
+    assert pool_regrows >= 1 and heap_regrows >= 1, (pool_regrows, heap_regrows)
+    for r in (rh, rd): r.close()
+    for b in (bh, bd): b.close()
+
+
+def test_the_whole_tree_as_one_part_and_a_two_tip_tree():
+    """Edge cases of the cutting: a single part (the cut point is the root, the synthetic sub-root lists are the root's own
+    missations) and the smallest tree there is."""
+    sc = make_scenario("C1", num_tips=60, num_sites=2000, uncertain_tips=0.5)
+    bh, rh = _run(sc, 3, 1, False)
+    bd, rd = _run(sc, 3, 1, True)
+    for cycle in range(3):
+        rh.do_mcmc_steps(4000, 4000); rd.do_mcmc_steps(4000, 4000)
+        th, refh = rh.tree(); td, refd = rd.tree()
+        _same_tree(th, td, "one part, cycle %d" % cycle)
+        assert np.array_equal(refh, refd)
+    for r in (rh, rd): r.close()
+    for b in (bh, bd): b.close()
+    sc = make_scenario("C1", num_tips=2, num_sites=500)
+    bh, rh = _run(sc, 3, 1, False)
+    bd, rd = _run(sc, 3, 1, True)
+    for r in (rh, rd): r.set_coalescent_t_step(20.0)     # (the root of a two-tip tree wanders: a grid of 400 cells over the tips' span would be outgrown)
+    rh.do_mcmc_steps(500, 500); rd.do_mcmc_steps(500, 500)
+    th, refh = rh.tree(); td, refd = rd.tree()
+    _same_tree(th, td, "two tips")
+    assert np.array_equal(refh, refd)
+    for r in (rh, rd): r.close()
+    for b in (bh, bd): b.close()
