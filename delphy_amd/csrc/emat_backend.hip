@@ -1670,7 +1670,8 @@ emat_status emat_scalable_coalescent_partial(emat_backend* h, double t_ref, doub
   const double ratio = h->parts[0].coal.t_step > 0.0 ? h->parts[0].coal.t_step / t_step : 1.0;
   for (size_t p = 0; p < n; ++p) {
     const PartHost& ph = h->parts[p];
-    const double cells_vs = (double)(ph.includes_run_root ? 2 * ph.coal.k_bar_p.size() + 512 : ph.coal.k_bar_p.size());
+    const size_t window = (size_t)std::max(0, ph.coal.n_cells_total - ph.coal.cell_first);   // (= k_bar_p.size(); the vectors themselves may live only on the device)
+    const double cells_vs = (double)(ph.includes_run_root ? 2 * window + 512 : window);
     cap[p] = (uint32_t)std::min<double>(1e7, std::ceil(cells_vs * ratio) + 4.0);
     off[p] = tot; tot += cap[p];
   }

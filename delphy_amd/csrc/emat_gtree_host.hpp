@@ -205,7 +205,8 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
   // while the device measures: skeletons of the parts (topology + times), and from them the coalescent cell tables
   h->coal_builder.reset();
   h->fatal_status = EMAT_OK; h->fatal_message.clear(); h->pass_pending = false;
-  h->parts.clear(); h->parts.resize(P);
+  if (!device_coal) h->parts.clear();   // (with the tables built on the device the records hold no vectors worth freeing and re-allocating 8 000 times per cycle)
+  h->parts.resize(P);
   h->uploads_expected = 0; h->root_part = root_part;
   h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false; h->have_coal = false; h->derived_valid = false;
   parallel_for(P, [&](int p) {
@@ -213,6 +214,7 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
     const int b = part_offset[p], np = part_offset[p + 1] - b;
     FlatTree& t = ph.tree;
     if (!device_coal) t.resize_nodes(np);   // (with the tables built on the device the host never needs the part's tree: a pull decodes it from the slab)
+    else if (t.num_nodes() != 0) t = FlatTree{};   // left over from a pull of the previous partition
     t.root = 0;
     for (int s = 0; s < np && !device_coal; ++s) {
       const int32_t o = orig[b + s], k0 = kid0[b + s], k1 = kid1[b + s];
@@ -257,7 +259,7 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
   std::vector<GPartDesc> desc(P); std::vector<uint64_t> offs(P);
   uint64_t cells_bytes = 0;
   GCoal co{};
-  std::vector<int> first_active(P, 0);
+  std::vector<int> first_active(P, 0), num_cells_of(P, 0);
   if (device_coal) {
     // CoalBuilder::local_range / set_range / local_grid's cell ranges from the parts' time ranges (plain arithmetic: the
     // same numbers as on the host); the tables themselves are filled by k_gt_coal_* below
@@ -272,8 +274,9 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
       if (!(0 <= fc && fc <= lc && lc < co.num_cells)) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "coalescent grid: bad cell range");
       const int wf = std::min(fc, std::max(0, cell_for(me[p].t_max_exact, co.t_ref, t_step)));
       first_active[p] = fc;
-      c = HostCoalPart{}; c.cell_first = wf; c.n_cells_total = lc + 1; c.t_ref = co.t_ref; c.t_step = t_step;
-      c.k_bar_p.resize((size_t)(lc - wf + 1));   // only its length is used before the next pull decodes the real tables
+      if (!c.k_bar_p.empty()) c = HostCoalPart{};   // (tables decoded by a pull of the previous partition)
+      c.cell_first = wf; c.n_cells_total = lc + 1; c.t_ref = co.t_ref; c.t_step = t_step;
+      num_cells_of[p] = lc - wf + 1;
       h->parts[p].rng.counter = (uint64_t)(lc - fc + 1);   // one Philox block per Gaussian draw
       desc[p].cells_off = pool; pool += (uint64_t)(lc - wf + 1);
     }
@@ -284,7 +287,7 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
   }
   for (int p = 0; p < P; ++p) {
     PartHost& ph = h->parts[p];
-    const int nc = (int)ph.coal.k_bar_p.size();
+    const int nc = device_coal ? num_cells_of[p] : (int)ph.coal.k_bar_p.size();
     const SlabGeo g = slab_geometry(h, me[p].n_nodes, me[p].num_muts, me[p].content_bytes, nc, ph.includes_run_root, ph.space_boost);
     place_slab(h, (size_t)p, g, off);
     offs[p] = ph.slab_off;

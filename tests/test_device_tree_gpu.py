@@ -235,3 +235,25 @@ def test_the_whole_tree_as_one_part_and_a_two_tip_tree():
     assert np.array_equal(refh, refd)
     for r in (rh, rd): r.close()
     for b in (bh, bd): b.close()
+
+
+def test_whole_tree_grid_prior_from_parts_cut_on_the_device():
+    """Row a20 on top of 8(f).2: Scalable_coalescent_prior's log-prior from the parts on the device, against the oracle's
+    whole-tree value on the tree that comes back."""
+    sc = make_scenario("C3", num_tips=900, num_sites=6000, uncertain_tips=0.2)
+    b, run = _run(sc, 67, 40, True, host_coalescent=False)
+    t_step = sc.default_t_step()
+    for cyc in range(2):
+        run.repartition()
+        n, _ = run.num_parts()
+        run.run_moves(n * 600)
+        got = b.scalable_coalescent_log_prior(sc.t_max_tip, t_step)
+        run.reassemble()
+        whole, ref = run.tree()
+        orc = OracleEngine(sc.num_sites)
+        sc2 = make_scenario("C3", num_tips=900, num_sites=6000, uncertain_tips=0.2); sc2.tree, sc2.ref = whole, ref
+        configure(orc, sc2, ref, [whole], [True], [1], 0)
+        want = orc.scalable_log_prior(0, sc.t_max_tip, t_step)
+        orc.close()
+        assert rel_close(got, want, 1e-9), (cyc, got, want)
+    run.close(); b.close()
