@@ -172,8 +172,18 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
         // scratch arena of its moves; scratch that does not fit goes to the part's HBM scratch region as before
         const uint32_t used = (lds_heap_end + 15u) & ~15u;
         c.A = lds_slab + used; c.a_end = area + a.lds_scratch_bytes - used;
-      } else if (prefix) init_ctx(*(dev_mix::Ctx*)(emat_lds + k_lds_ctx_off), lds_slab, gslab, a, lds_tables);
-      else init_ctx(*(dev::Ctx*)(emat_lds + k_lds_ctx_off), gslab, gslab, a, tables_staged ? lds_tables : nullptr);
+      } else if (prefix) {
+        // the prefix leaves the rest of the staging area free: the moves' first-level arena, as for a staged part (before
+        // round 2's end these parts -- 40-60 nodes, the slowest chains of a pass -- ran every candidate scan through HBM)
+        dev_mix::Ctx& c = *(dev_mix::Ctx*)(emat_lds + k_lds_ctx_off);
+        init_ctx(c, lds_slab, gslab, a, lds_tables);
+        const uint32_t used = (gh->heap_begin + 15u) & ~15u;
+        c.A = lds_slab + used; c.a_end = area + a.lds_scratch_bytes - used;
+      } else {
+        dev::Ctx& c = *(dev::Ctx*)(emat_lds + k_lds_ctx_off);
+        init_ctx(c, gslab, gslab, a, tables_staged ? lds_tables : nullptr);
+        if (area + a.lds_scratch_bytes != 0) { c.A = lds_slab; c.a_end = area + a.lds_scratch_bytes; }   // nothing of the part is staged: the whole area is arena
+      }
       ((dev::Ctx*)(emat_lds + k_lds_ctx_off))->moves_left = H->status == 0 ? target - (H->moves_done - done_at_start) : 0;   // the three Ctx types share one layout
       tick0 = wall_clock64();
       if (is_root_part) __builtin_amdgcn_s_setprio(3);
@@ -688,6 +698,7 @@ struct emat_backend {
   // dense copy of every part's slab header (k_gather_headers): what the scalar getters read instead of the slabs
   DevBuf<uint8_t> d_headers; std::vector<uint8_t> h_headers; bool headers_current = false;
   GTreeHost gt;                     // the whole tree, when it lives in HBM (emat_tree_upload)
+  int cfg_parts_per_cu = 0;         // EMAT_PARTS_PER_CU (tuning knob): workgroups of the main class per CU, instead of the percentile rule
   bool cfg_gt_host_coal = false;    // EMAT_TREE_HOST_COALESCENT=1: emat_tree_repartition builds the coalescent tables on the host (bit-identical to the host cycle; tests)
 
   void set_error(const std::string& s) { last_error = s; }
@@ -1068,6 +1079,7 @@ void assign_size_classes(emat_backend* h) {
       if (area == 0) continue;
       if (area >= need || k == 1) { main_area = area; break; }
     }
+    if (h->cfg_parts_per_cu > 0 && area_for((uint32_t)h->cfg_parts_per_cu) != 0) main_area = area_for((uint32_t)h->cfg_parts_per_cu);   // EMAT_PARTS_PER_CU
     // Giants: a part whose fixed-size prefix (header, nodes, cells) does not fit the area would run entirely out of HBM,
     // at less than half the speed, and -- every part doing the same number of moves -- hold up the whole pass.  They
     // get launches of their own, with areas for 8 and for 1 workgroup per CU: each giant takes the smaller area if it
@@ -1249,6 +1261,7 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   if (const char* e = getenv("EMAT_LDS_MAX")) h->cfg_lds_max = (uint32_t)atoi(e) & ~511u;
   if (const char* e = getenv("EMAT_GIANTS")) h->cfg_giants = atoi(e) != 0;
   if (const char* e = getenv("EMAT_TREE_HOST_COALESCENT")) h->cfg_gt_host_coal = atoi(e) != 0;
+  if (const char* e = getenv("EMAT_PARTS_PER_CU")) h->cfg_parts_per_cu = std::max(0, std::min(4 * EMAT_WAVES_PER_EU, atoi(e)));
   if (const char* e = getenv("EMAT_ORDER_BY_TIME")) h->cfg_order_by_time = atoi(e) != 0;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return EMAT_ERR_HIP; h->num_cus = prop.multiProcessorCount; }
   if (hipStreamCreate(&h->stream) != hipSuccess) return EMAT_ERR_HIP;
@@ -1818,6 +1831,7 @@ emat_status emat_debug_phase_ticks(emat_backend* h, int32_t part_id, int64_t* ou
   const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + h->parts[part_id].slab_off);
 #ifdef EMAT_PROFILE_PHASES
   for (int i = 0; i < 16; ++i) out16[i] = H->phase_ticks[i];
+  if (getenv("EMAT_PHASE_EXTRA")) for (int i = 0; i < 8; ++i) out16[i] = ((const int64_t*)H->reserved)[i];   // scan counters instead
 #else
   (void)H; for (int i = 0; i < 16; ++i) out16[i] = 0;   // phase counters exist only in -DEMAT_PROFILE_PHASES builds
 #endif

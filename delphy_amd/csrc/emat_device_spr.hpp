@@ -1380,6 +1380,9 @@ EMAT_D bool wave_local_scan(Ctx& c, Spr1Frame& fr) {
     }
     done = !overflow;
   }
+#ifdef EMAT_PROFILE_PHASES
+  if (lane == 0) { int64_t* ex = (int64_t*)hdr_of(c)->reserved; ex[0] += 1; ex[1] += miss.n; ex[2] += del.n; ex[3] += total; ex[4] += nlev; ex[5] += (hbm_lo != nullptr) ? 1 : 0; ex[6] += done ? 0 : 1; ex[7] += (front == 0) ? 1 : 0; }
+#endif
   if (!done || c.failed) return false;
   // subtree sizes, deepest level first
   for (int l = nlev - 1; l >= 0; --l) {

@@ -285,6 +285,12 @@ def slow_phase_probe(nparts=8192, moves=1000, top=6):
         tot = v[14] + v[15]
         print("part %d nodes %d dur %.2f ms proposed %s | regions/study %.1f" % (p, eng.local_sizes[p], dur[p], st[p]["proposed"], v[13] / max(1, 2 * st[p]["proposed"][4])))
         print("    " + " | ".join("%s %.1f%%" % (names[i], 100 * v[i] / tot) for i in list(range(0, 3)) + list(range(4, 13)) + [14, 15]))
+        os.environ["EMAT_PHASE_EXTRA"] = "1"
+        lib.emat_debug_phase_ticks(eng.backend.handle, int(p), buf)
+        del os.environ["EMAT_PHASE_EXTRA"]
+        e = np.array(list(buf), dtype=np.float64); k = max(1.0, e[0])
+        print("    wave scans %d: missing intervals at X %.1f, site deltas %.1f, items %.1f, levels %.1f, in HBM %d, fell back to serial %d, sets not in LDS %d | scan ticks per scan %.0f"
+              % (e[0], e[1] / k, e[2] / k, e[3] / k, e[4] / k, e[5], e[6], e[7], v[6] / k))
     eng.close()
 
 
