@@ -221,16 +221,21 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
         // reached the HBM copy of the slab yet (moves only write HBM scratch), and the chain is a deterministic function
         // of that copy.  Drop the LDS state and run the leg again from HBM with the heap at its full capacity there.
         else if (H->status == k_part_overflow && lds_heap_end < hbm_heap_end) { a.part_status[part] = 0; again = 2; }
+        // The root part's coalescent grid outgrew its capacity (the root wandered further into the past than the room the
+        // host left): the same argument -- the HBM copy still is the consistent state this launch found -- lets the
+        // host re-materialise the part with more cells and run its moves again (first leg only: a second leg follows a
+        // write-back).
+        else if (H->status == k_part_cell_overflow && leg == 0) { a.part_status[part] = k_part_need_cells; again = 3; }
       }
       *lds_flag = again;
     }
     __syncthreads();
     const int again_all = *lds_flag;
-    if (again_all != 2) {
+    if (again_all < 2) {
       if (staged) wave_copy16(gslab, lds_slab, ((const SlabHeader*)lds_slab)->heap_top, lane);
       else if (prefix) wave_copy16(gslab, lds_slab, staged_bytes, lane);
     }
-    if (again_all == 0) break;
+    if (again_all == 0 || again_all == 3) break;
     allow_whole = false;
   }
 }
@@ -606,6 +611,7 @@ struct PartHost {
   std::vector<double> trace;       // the part's move trace so far (4 doubles per move), carried over re-materialisations
   int64_t expected_moves = 0;      // moves requested of this part since its upload
   double space_boost = 1.0;        // multiplier of the heap and scratch capacities; doubled when the part ran out of space
+  int cell_boost = 1;              // multiplier of the room the root part's grid gets to grow into; quadrupled when it ran out
 };
 
 // The whole tree in HBM (emat_gtree_kernels.hpp) with the host mirrors the partitioner and the coalescent builder need:
@@ -915,7 +921,7 @@ emat_status finish_pass(emat_backend* h) {
     HIP_TRY(hipMemcpy(status.data(), h->d_part_status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     h->pass_pending = false;
     size_t stopped = 0, fatal = n;
-    for (size_t p = 0; p < n; ++p) if (status[p] != 0) { ++stopped; if (status[p] != k_part_need_space && fatal == n) fatal = p; }
+    for (size_t p = 0; p < n; ++p) if (status[p] != 0) { ++stopped; if (status[p] != k_part_need_space && status[p] != k_part_need_cells && fatal == n) fatal = p; }
     if (stopped == 0 && getenv("EMAT_VERBOSE")) {   // what bounded the pass: the slowest chains next to the mean
       std::vector<int64_t> ticks(2 * n);
       HIP_TRY(hipMemcpy(ticks.data(), h->d_part_ticks.p, 2 * n * sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -945,11 +951,11 @@ emat_status finish_pass(emat_backend* h) {
     std::vector<int64_t> counts(n, 0);
     for (size_t p = 0; p < n; ++p) if (status[p] != 0) {
       PartHost& ph = h->parts[p];
-      ph.space_boost *= 2.0;
+      if (status[p] == k_part_need_cells) ph.cell_boost *= 4; else ph.space_boost *= 2.0;
       counts[p] = ph.expected_moves - ph.stats.moves_done;
       ph.stats.status = 0;
     }
-    if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] %zu part(s) ran out of slab space: re-materialising with more room and running the rest of their moves\n", stopped);
+    if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] %zu part(s) ran out of slab space or grid cells: re-materialising with more room and running the rest of their moves\n", stopped);
     h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false;   // every part is re-encoded from its decoded state (tree, RNG, cells, statistics)
     st = launch_moves(h, 0, 0, &counts, 0); if (st) return st;
   }
@@ -1009,7 +1015,7 @@ inline const SlabHeader* header_of(const emat_backend* h, size_t part) { return 
 
 // Capacities of one part's slab: what a move may need on top of the part's present content.
 struct SlabGeo { uint32_t heap, scratch; int cell_cap; uint32_t bytes; };
-SlabGeo slab_geometry(const emat_backend* h, int n, int num_muts, uint32_t content, int nc, bool includes_run_root, double space_boost) {
+SlabGeo slab_geometry(const emat_backend* h, int n, int num_muts, uint32_t content, int nc, bool includes_run_root, double space_boost, int cell_boost = 1) {
   const double slack = h->cfg.slab_slack > 0 ? h->cfg.slab_slack : 3.0;
   const int trace_cap = h->cfg.trace_moves > 0 ? h->cfg.trace_moves : 0;
   SlabGeo g;
@@ -1018,7 +1024,7 @@ SlabGeo slab_geometry(const emat_backend* h, int n, int num_muts, uint32_t conte
   // part (48 B each) with a DFS stack of up to 4 items per region (12 B each), next to two graft analyses
   const uint32_t regions_max = (uint32_t)n + (uint32_t)num_muts;
   g.scratch = a16((uint32_t)(space_boost * std::max<uint32_t>(8192u, 128u * regions_max + 4u * content + 256u * (uint32_t)n)));
-  g.cell_cap = includes_run_root ? nc + std::max(512, nc) : nc;   // room for the root part's grid to grow into the past (a part that outgrows it stops with status 103)
+  g.cell_cap = includes_run_root ? nc + cell_boost * std::max(512, nc) : nc;   // room for the root part's grid to grow into the past (a part that outgrows it stops with status 103 / 105)
   g.bytes = (uint32_t)sizeof(SlabHeader) + (uint32_t)n * (uint32_t)sizeof(NodeRec) + a16((uint32_t)g.cell_cap * k_cell_bytes) + a16((uint32_t)trace_cap * 32u) + g.heap + g.scratch;
   return g;
 }
@@ -1126,7 +1132,7 @@ emat_status materialize(emat_backend* h) {
   std::vector<SlabGeo> geo(h->parts.size());
   for (size_t p = 0; p < h->parts.size(); ++p) {
     PartHost& ph = h->parts[p];
-    geo[p] = slab_geometry(h, ph.tree.num_nodes(), ph.tree.num_muts(), heap_content_bytes(ph.tree), (int)ph.coal.k_bar_p.size(), ph.includes_run_root, ph.space_boost);
+    geo[p] = slab_geometry(h, ph.tree.num_nodes(), ph.tree.num_muts(), heap_content_bytes(ph.tree), (int)ph.coal.k_bar_p.size(), ph.includes_run_root, ph.space_boost, ph.cell_boost);
     place_slab(h, p, geo[p], off);
   }
   HIP_TRY(h->h_slabs.resize(off));
@@ -1340,7 +1346,7 @@ emat_status emat_part_upload(emat_backend* h, int32_t part_id, const emat_flat_t
   ph.tree = FlatTree::from_view(*subtree); ph.n_nodes = subtree->num_nodes;
   ph.includes_run_root = includes_run_root != 0;
   ph.rng.key = seed; ph.rng.counter = 0; ph.rng.spare = 0; ph.rng.has_spare = false;
-  ph.uploaded = true; ph.stats = emat_part_stats{}; ph.expected_moves = 0; ph.space_boost = 1.0; ph.trace.clear();
+  ph.uploaded = true; ph.stats = emat_part_stats{}; ph.expected_moves = 0; ph.space_boost = 1.0; ph.cell_boost = 1; ph.trace.clear();
   if (ph.includes_run_root) h->root_part = part_id;
   return EMAT_OK;
 }

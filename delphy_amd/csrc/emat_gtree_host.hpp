@@ -226,7 +226,7 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
     }
     ph.includes_run_root = p == root_part; ph.n_nodes = np;
     ph.rng.key = seeds[p]; ph.rng.counter = 0; ph.rng.spare = 0; ph.rng.has_spare = false;
-    ph.uploaded = true; ph.stats = emat_part_stats{}; ph.expected_moves = 0; ph.space_boost = 1.0; ph.trace.clear();
+    ph.uploaded = true; ph.stats = emat_part_stats{}; ph.expected_moves = 0; ph.space_boost = 1.0; ph.cell_boost = 1; ph.trace.clear();
   }, 64);
   const auto t2 = now();
   if (!device_coal) try {

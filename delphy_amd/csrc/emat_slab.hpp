@@ -26,7 +26,9 @@ enum PartStatus : int32_t {
   k_part_need_space = 101,     // stopped BEFORE a move: heap reserve or scratch too small (state is consistent)
   k_part_overflow = 102,       // a container overflowed INSIDE a move (state is not trustworthy)
   k_part_cell_overflow = 103,  // root part needed more coalescent cells than its capacity
-  k_part_internal = 104        // an invariant that the reference CHECKs failed
+  k_part_internal = 104,       // an invariant that the reference CHECKs failed
+  k_part_need_cells = 105      // reported for 103 when the part ran on a staged copy: its slab in HBM is still the state the launch
+                               // found (a consistent one, before a move), so the host can give it more cells and run its moves again
 };
 
 enum SlabFlags : uint32_t { k_flag_includes_run_root = 1u };

@@ -228,7 +228,7 @@ def test_the_whole_tree_as_one_part_and_a_two_tip_tree():
     sc = make_scenario("C1", num_tips=2, num_sites=500)
     bh, rh = _run(sc, 3, 1, False)
     bd, rd = _run(sc, 3, 1, True)
-    for r in (rh, rd): r.set_coalescent_t_step(20.0)     # (the root of a two-tip tree wanders: a grid of 400 cells over the tips' span would be outgrown)
+    for r in (rh, rd): r.set_coalescent_t_step(0.5)      # the root of a two-tip tree wanders by hundreds of such cells per cycle: the grid's room is outgrown and regrown
     rh.do_mcmc_steps(500, 500); rd.do_mcmc_steps(500, 500)
     th, refh = rh.tree(); td, refd = rd.tree()
     _same_tree(th, td, "two tips")
