@@ -170,7 +170,9 @@ emat_status emat_run_moves_split(emat_backend* h, int64_t moves_per_part, int64_
 emat_status emat_run_moves_even(emat_backend* h, int64_t moves_per_part, int32_t one_more_below);
 /* Waits for the launches issued so far and checks that every part ran its chain to completion.  A part that ran out of
  * list-heap or scratch space stops BEFORE a move with its state intact; it is re-materialised with twice the room and
- * the rest of its moves run, transparently (up to four doublings, then EMAT_ERR_CAPACITY).  A part that stopped INSIDE
+ * the rest of its moves run, transparently (up to four doublings, then EMAT_ERR_CAPACITY).  The same happens when the
+ * root part's coalescent grid outgrows the room it was given to grow into the past (four times the room per retry),
+ * provided the part ran on a staged copy of its slab.  A part that stopped INSIDE
  * a move (an invariant the reference CHECKs, or the root part's cell table overflowing) makes this -- and every getter,
  * all of which synchronise first -- fail with EMAT_ERR_INTERNAL / EMAT_ERR_CAPACITY naming the part; the reference
  * aborts in that situation. */
