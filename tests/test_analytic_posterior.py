@@ -211,3 +211,99 @@ def test_coalescent_posterior_of_n_tips_through_partitioned_cycles_on_the_gpu():
         lam = float(chk.part_derived(0, tree.num_nodes)[0][0])
         chk.close(); run.close(); b.close()
         _check_n(lam, np.array(hs), np.array(Ts))
+
+
+# ---- two tips that DIFFER at m sites ---------------------------------------------------------------------------------
+# Both dated exactly t = 0.  To first order in mu h every differing site contributes a factor proportional to the total
+# branch length 2h (one mutation, somewhere on either branch; by reversibility both placements weigh the same), every other
+# site exp(-2 q mu h), the prior exp(-h/N):  h ~ Gamma(m + 1, 1/N + 2 lambda),  E[h] = (m + 1) / rate,  sd = sqrt(m + 1) / rate.
+# What this one reaches that the others do not: explicit mutations -- their times bound the displacement of the root and
+# are re-drawn by branch reforms, they hop between the two branches through the root (the root sequence and with it the
+# reference sequence change: Run::normalize_root), and each carries its log(mu q_ab) in log G.
+M_DIFF = 3
+
+
+def _two_tips_differing(ref, rng):
+    t = d.FlatTree.empty(3, M_DIFF, 0, 0)
+    t.root = 0
+    t.child0[0], t.child1[0] = 1, 2
+    t.parent[1] = t.parent[2] = 0
+    t.t[:] = (-120.0, 0.0, 0.0)
+    t.t_min[:] = (-3.4028234663852886e38, 0.0, 0.0)
+    t.t_max[:] = (3.4028234663852886e38, 0.0, 0.0)
+    sites = np.sort(rng.choice(L, size=M_DIFF, replace=False))
+    times = np.sort(rng.uniform(-119.0, -1.0, size=M_DIFF))
+    order = np.argsort(times, kind="stable")          # mutations of a branch are sorted by (t, site)
+    t.mut_offset[:] = (0, 0, 0, M_DIFF)               # all on the branch to node 2
+    for k, j in enumerate(order):
+        t.mut_site[k] = sites[j]; t.mut_from[k] = ref[sites[j]]; t.mut_to[k] = (ref[sites[j]] + 1 + (sites[j] % 3)) % 4; t.mut_t[k] = times[j]
+    return t
+
+
+def _chain_differing(make_engine, via_run_driver, seed, cycles=5000):
+    rng = np.random.default_rng(seed)
+    ref = rng.choice(4, size=L, p=PI).astype(np.uint8)
+    tree = _two_tips_differing(ref, rng)
+    sc = Scenario("two differing tips", tree, ref, 0.0, MU, KAPPA, PI, d.PopModel.const(N_POP), L)
+    hs, on_first, ref_changed = [], [], False
+    if via_run_driver:      # the whole cycle, reference sequence re-normalised by the driver
+        b = make_engine()
+        run = d.EmatRun(b, tree, ref, seed)
+        run.set_num_parts(1); run.set_hky(MU, KAPPA, PI); run.set_pop_model(d.PopModel.const(N_POP)); run.set_coalescent_t_step(T_STEP)
+        run.set_device_tree(True)
+        for c in range(cycles):
+            run.do_mcmc_steps(30, 30)
+            tr, cur_ref = run.tree()
+            hs.append(-float(tr.t[tr.root])); on_first.append(int(tr.mut_offset[2] - tr.mut_offset[1]))
+            ref_changed = ref_changed or not np.array_equal(cur_ref, ref)
+            assert tr.mut_offset[-1] >= M_DIFF
+        run.close(); b.close()
+    else:                   # one part handed to the engine cycle after cycle; the root keeps its deltas from `ref`
+        eng = make_engine()
+        for c in range(cycles):
+            sc.tree = tree
+            configure(eng, sc, ref, [tree], [True], [seed * 7919 + c], 0, t_step=T_STEP)
+            eng.run_moves_per_part(30)
+            tree = eng.part_download(0)
+            hs.append(-float(tree.t[tree.root]))
+            r = tree.root; kids = (tree.child0[r], tree.child1[r])
+            on_first.append(int(tree.mut_offset[kids[0] + 1] - tree.mut_offset[kids[0]]))
+            ref_changed = ref_changed or tree.mut_offset[r + 1] > tree.mut_offset[r]
+        eng.close()
+    return np.array(hs), np.array(on_first), ref_changed, ref
+
+
+def _check_differing(hs, on_first, ref_changed, lam):
+    burn = len(hs) // 10
+    hs, on_first = hs[burn:], on_first[burn:]
+    rate = 1.0 / N_POP + 2.0 * lam
+    want, want_sd = (M_DIFF + 1) / rate, math.sqrt(M_DIFF + 1) / rate
+    se = _batch_se(hs)
+    assert abs(hs.mean() - want) < 4.0 * se + 0.03 * want, "root height: mean %.2f, closed form %.2f (se %.2f)" % (hs.mean(), want, se)
+    assert abs(hs.std() - want_sd) < 0.08 * want_sd + 4.0 * se, "root height: sd %.2f, closed form %.2f" % (hs.std(), want_sd)
+    # each mutation sits on either branch with probability 1/2
+    assert abs(on_first.mean() - M_DIFF / 2.0) < 0.15, "mutations on the first branch: %.2f of %d on average" % (on_first.mean(), M_DIFF)
+    assert ref_changed, "no mutation ever crossed the root: the test does not exercise the re-rooting of sequences"
+
+
+def _lambda_of(ref):
+    chk = OracleEngine(L)
+    t = _two_tips()
+    sc = Scenario("x", t, ref, B, MU, KAPPA, PI, d.PopModel.const(N_POP), L)
+    configure(chk, sc, ref, [t], [True], [1], 0, t_step=T_STEP)
+    lam = float(chk.part_derived(0, 3)[0][0])
+    chk.close()
+    return lam
+
+
+def test_two_differing_tips_posterior_closed_form_on_the_oracle():
+    hs, on_first, ref_changed, ref = _chain_differing(lambda: OracleEngine(L), False, 31)
+    _check_differing(hs, on_first, ref_changed, _lambda_of(ref))
+
+
+@pytest.mark.gpu
+def test_two_differing_tips_posterior_closed_form_on_the_gpu():
+    hs, on_first, ref_changed, ref = _chain_differing(lambda: d.EmatBackend(L), False, 37)
+    _check_differing(hs, on_first, ref_changed, _lambda_of(ref))
+    hs, on_first, ref_changed, ref = _chain_differing(lambda: d.EmatBackend(L), True, 41)      # whole cycles, tree resident in HBM
+    _check_differing(hs, on_first, ref_changed, _lambda_of(ref))
