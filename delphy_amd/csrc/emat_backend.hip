@@ -239,10 +239,10 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
     allow_whole = false;
   }
 }
-__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY k_run_moves(KernelArgs a) { run_moves_body(a); }
+__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY EMAT_NOTAIL k_run_moves(KernelArgs a) { run_moves_body(a); }
 // Same body under another name for the side launches of the size classes (the "giants", §4 of DESIGN.md), so that
 // profiles keep the statistics of the main launch -- the one bench.py's roofline is about -- apart.
-__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY k_run_moves_side(KernelArgs a) { run_moves_body(a); }
+__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY EMAT_NOTAIL k_run_moves_side(KernelArgs a) { run_moves_body(a); }
 
 // ---- sufficient statistics of the global moves (calc_Ttwiddle_beta_a phylo_tree_calc.cpp:288-369, calc_num_muts_beta_ab
 //      :599-610, calc_num_muts :577-585), one part per workgroup ---------------------------------------------------------

@@ -39,6 +39,9 @@ constexpr uint32_t k_lds_slab_off = k_lds_ctx_off + k_lds_ctx_bytes;
 #define EMAT_D static __device__ inline
 #define EMAT_DN static __device__ __noinline__
 #define EMAT_DF static __device__ __forceinline__
+// A function whose calls must not be marked as tail calls: its callees then qualify for LLVM's no-callee-saved-registers
+// optimisation.  The top of the call tree carries it; below, calls keep the standard convention.
+#define EMAT_NOTAIL __attribute__((disable_tail_calls))
 #endif  // EMAT_DEVICE_COMMON_ONCE_
 
 namespace emat {

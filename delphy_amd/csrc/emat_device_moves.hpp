@@ -439,7 +439,7 @@ EMAT_DN bool compact_heap(Ctx& c) {
 
 // Subrun::mcmc_sub_iteration (subrun.cpp:98-121).  Returns false when the part must stop.  An SPR1 move parks itself
 // twice for the wave's scan + study (c.svc != 0 on return): the next call resumes it.
-EMAT_D bool mcmc_sub_iteration(Ctx& c) {
+EMAT_NOTAIL EMAT_D bool mcmc_sub_iteration(Ctx& c) {
 #ifdef EMAT_PROFILE_PHASES
   const long long _mv0 = clock64();
 #endif
@@ -487,7 +487,7 @@ EMAT_D bool mcmc_sub_iteration(Ctx& c) {
 // whatever their caller kept in registers would be spilled and reloaded around each of them.
 // Returns with c.svc != 0 when the current move waits for the wave (the kernel serves it and calls again), else when the
 // moves are done or the part had to stop.
-EMAT_DN void run_chain_loop(Ctx& c) {
+EMAT_NOTAIL EMAT_DN void run_chain_loop(Ctx& c) {
   c.svc = 0;
   for (;;) {
     if (c.phase == 0) { if (c.moves_left <= 0) return; c.moves_left -= 1; }
