@@ -1837,7 +1837,7 @@ emat_status emat_debug_phase_ticks(emat_backend* h, int32_t part_id, int64_t* ou
   const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + h->parts[part_id].slab_off);
 #ifdef EMAT_PROFILE_PHASES
   for (int i = 0; i < 16; ++i) out16[i] = H->phase_ticks[i];
-  if (getenv("EMAT_PHASE_EXTRA")) for (int i = 0; i < 8; ++i) out16[i] = ((const int64_t*)H->reserved)[i];   // scan counters instead
+  if (getenv("EMAT_PHASE_EXTRA")) for (int i = 0; i < 16; ++i) out16[i] = ((const int64_t*)H->reserved)[i];   // scan and arena counters instead
 #else
   (void)H; for (int i = 0; i < 16; ++i) out16[i] = 0;   // phase counters exist only in -DEMAT_PROFILE_PHASES builds
 #endif

@@ -125,9 +125,11 @@ EMAT_D void fail_at(Ctx& c, int status, int line) {
 #define EMAT_FAIL(c, st) fail_at((c), (st), __LINE__)
 #define EMAT_CHECK(c, cond) do { if (!(cond)) fail_at((c), ::emat::k_part_internal, __LINE__); } while (0)
 #ifdef EMAT_PROFILE_PHASES
+#define EMAT_COUNT(c, k, v) (((int64_t*)hdr_of(c)->reserved)[k] += (int64_t)(v))
 #define EMAT_PHASE_BEGIN() long long _ph_t0 = clock64()
 #define EMAT_PHASE(c, k) do { long long _t = clock64(); hdr_of(c)->phase_ticks[k] += _t - _ph_t0; _ph_t0 = _t; } while (0)
 #else
+#define EMAT_COUNT(c, k, v) do {} while (0)
 #define EMAT_PHASE_BEGIN() do {} while (0)
 #define EMAT_PHASE(c, k) do {} while (0)
 #endif
@@ -188,8 +190,9 @@ EMAT_D void sc_reset(Ctx& c) { c.a_top = 0; c.sc_top = hdr_of(c)->scratch_begin;
 EMAT_D bool sc_in_lds(const Ctx& c, const void* p) { return c.A != nullptr && (const uint8_t*)p >= c.A && (const uint8_t*)p < c.A + c.a_end; }
 EMAT_D uint8_t* sc_alloc(Ctx& c, uint32_t bytes) {
   uint32_t b = (bytes + 15u) & ~15u;
-  if (c.a_top + b <= c.a_end) { uint8_t* p = c.A + c.a_top; c.a_top += b; return p; }
+  if (c.a_top + b <= c.a_end) { uint8_t* p = c.A + c.a_top; c.a_top += b; EMAT_COUNT(c, 9, b); return p; }
   if (c.sc_top + b > hdr_of(c)->scratch_end) { EMAT_FAIL(c, k_part_overflow); return c.G + hdr_of(c)->scratch_begin; }
+  EMAT_COUNT(c, 8, b);
   uint8_t* p = c.G + c.sc_top;
   c.sc_top += b;
   return p;
@@ -198,8 +201,9 @@ template <class T> EMAT_D SVec<T> sc_vec(Ctx& c, int cap) {
   SVec<T> v; v.n = 0;
   uint32_t bytes = (uint32_t)cap * (uint32_t)sizeof(T);
   uint32_t b = (bytes + 15u) & ~15u;
-  if (cap >= 0 && c.a_top + b <= c.a_end) { v.p = (T*)(c.A + c.a_top); v.cap = cap; c.a_top += b; return v; }
+  if (cap >= 0 && c.a_top + b <= c.a_end) { v.p = (T*)(c.A + c.a_top); v.cap = cap; c.a_top += b; EMAT_COUNT(c, 9, b); return v; }
   if (cap < 0 || c.sc_top + b > hdr_of(c)->scratch_end) { EMAT_FAIL(c, k_part_overflow); v.p = (T*)(c.G + hdr_of(c)->scratch_begin); v.cap = 0; return v; }
+  EMAT_COUNT(c, 8, b);
   v.p = (T*)(c.G + c.sc_top); v.cap = cap; c.sc_top += b;
   return v;
 }
@@ -220,8 +224,8 @@ template <class T> EMAT_D SVec<T> sc_open(Ctx& c, int max_elems, int min_lds_ele
 // give back the unused tail of the most recent allocation in its arena
 template <class T> EMAT_D void sc_trim(Ctx& c, SVec<T>& v) {
   uint32_t used = ((uint32_t)v.n * (uint32_t)sizeof(T) + 15u) & ~15u;
-  if (sc_in_lds(c, v.p)) c.a_top = (uint32_t)((uint8_t*)v.p - c.A) + used;
-  else c.sc_top = (uint32_t)((uint8_t*)v.p - c.G) + used;
+  if (sc_in_lds(c, v.p)) { c.a_top = (uint32_t)((uint8_t*)v.p - c.A) + used; EMAT_COUNT(c, 9, used); }
+  else { c.sc_top = (uint32_t)((uint8_t*)v.p - c.G) + used; EMAT_COUNT(c, 8, used); EMAT_COUNT(c, 11, 1); }
   v.cap = v.n;
 }
 // Two containers growing towards each other inside one arena (results upwards from `lo`, a work stack downwards
@@ -257,7 +261,7 @@ EMAT_D ScSpan sc_span_hbm(Ctx& c) {
 EMAT_D void sc_span_commit(Ctx& c, const ScSpan& s, uint32_t used_bytes) {
   uint32_t u = (used_bytes + 15u) & ~15u;
   if (s.reserved) return;   // the block stays reserved
-  if (s.lds) c.a_top = (uint32_t)(s.lo - c.A) + u; else c.sc_top = (uint32_t)(s.lo - c.G) + u;
+  if (s.lds) { c.a_top = (uint32_t)(s.lo - c.A) + u; EMAT_COUNT(c, 9, u); } else { c.sc_top = (uint32_t)(s.lo - c.G) + u; EMAT_COUNT(c, 8, u); EMAT_COUNT(c, 12, 1); }
 }
 
 // ---- persistent per-node lists in the slab heap ---------------------------------------------------------

@@ -193,7 +193,7 @@ EMAT_D SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) {
   return out;
 }
 
-template <bool kRoot> EMAT_DN void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
+template <bool kRoot> EMAT_NOTAIL EMAT_DN void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
   begin_move(c, k_branch_reform);
   if (hdr_of(c)->n_nodes < 3) return;
   const int X = pick_random_node(c);
@@ -251,7 +251,7 @@ EMAT_DN SVec<int> enumerate_descendant_branches_straddling(Ctx& c, int P, double
   return out;
 }
 
-EMAT_DN void subtree_slide_move(Ctx& c) {   // subrun.cpp:352-448
+EMAT_NOTAIL EMAT_DN void subtree_slide_move(Ctx& c) {   // subrun.cpp:352-448
   begin_move(c, k_subtree_slide);
   if (hdr_of(c)->n_nodes < 2) return;
   const int X = pick_random_node(c);
