@@ -66,6 +66,11 @@ struct KernelArgs {
   int32_t* part_status;           // [num_parts] status every part ended its chain with (0 = ran to completion)
   int64_t extra_moves_part0;      // remainder of Run::run_local_moves goes to part 0 (run.cpp:683-689)
   int32_t one_more_below;         // parts [0, one_more_below) do one move more (emat_run_moves_even)
+  // A pass cut into `chunks` tickets per part (EMAT_CHUNKS): workgroup b runs ticket b / class_stride of part order[b % class_stride];
+  // ticket c of a part starts when ticket c - 1 has written the slab back (chunk_done[part] == c).  Shorter tickets pack the
+  // slots better at the end of a pass; the chain -- one RNG stream per part, state in the slab -- is the same chain.
+  int32_t chunks, class_count, class_stride;
+  int32_t* chunk_done;            // [num_parts], zeroed before the launch
 };
 
 constexpr int k_wave = 64;
@@ -128,14 +133,32 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
   const bool tables_staged = stage_tables(a, lds_tables, lane) != nullptr;
   uint8_t* lds_slab = emat_lds + k_lds_slab_off;
   int* lds_flag = (int*)(emat_lds + k_lds_ctx_off + k_lds_ctx_bytes - 16);   // spare tail of the context slot: lane 0 -> all lanes
-  const int part = a.order[blockIdx.x];
+  const int chunk = a.chunks > 1 ? (int)blockIdx.x / a.class_stride : 0, slot = a.chunks > 1 ? (int)blockIdx.x % a.class_stride : (int)blockIdx.x;
+  if (a.chunks > 1 && slot >= a.class_count) return;   // padding: the stride is a multiple of 8 so that a part's tickets land on one XCD
+  const int part = a.order[slot];
   uint8_t* gslab = a.slabs + a.slab_off[part];
   SlabHeader* gh = (SlabHeader*)gslab;
-  const int64_t target = a.moves_for_part ? a.moves_for_part[part] : a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0) + (part < a.one_more_below ? 1 : 0);
-  const int64_t done_at_start = gh->moves_done;
+  const int64_t pass_target = a.moves_for_part ? a.moves_for_part[part] : a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0) + (part < a.one_more_below ? 1 : 0);
+  int64_t target = pass_target, done_at_start;
+  if (a.chunks > 1) {
+    if (chunk > 0) {   // the ticket before this one must have written the part's slab back
+      // (workgroups are dispatched in index order, so that ticket is running or done: the wait cannot deadlock; it is
+      // bounded all the same -- about ten seconds -- and a part whose turn never came is reported, not waited for)
+      if (lane == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(&a.chunk_done[part], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(64); ++spins; }
+        if (spins >= (1 << 22)) { a.part_status[part] = k_part_internal; *lds_flag = -1; } else *lds_flag = 0;
+      }
+      __syncthreads();
+      if (*lds_flag == -1) return;
+    } else if (lane == 0) gh->pad0 = (uint32_t)gh->moves_done;   // where the pass picked the part up (low bits: a pass is far shorter than 2^32 moves)
+    __syncthreads();
+    target = pass_target * (chunk + 1) / a.chunks;   // cumulative over the tickets so far
+    done_at_start = gh->moves_done - (int64_t)(uint32_t)((uint32_t)gh->moves_done - gh->pad0);
+  } else done_at_start = gh->moves_done;
   const uint32_t area = a.lds_slab_bytes;
   const bool can_stage = tables_staged && area != 0 && gh->off_nodes == (uint32_t)sizeof(SlabHeader);
-  if (lane == 0) { a.part_ticks[part] = 0; a.part_ticks[a.num_parts + part] = (int64_t)wall_clock64(); }   // duration, start (emat_debug_part_ticks)
+  if (lane == 0 && chunk == 0) { a.part_ticks[part] = 0; a.part_ticks[a.num_parts + part] = (int64_t)wall_clock64(); }   // duration, start (emat_debug_part_ticks)
   // Up to two legs: a part whose USED state fits the staging area but whose heap capacity does not is staged whole with
   // an LDS-local heap limit; should its lists outgrow that, it is written back and finishes with its heap in HBM.
   bool allow_whole = true;
@@ -237,6 +260,10 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
     }
     if (again_all == 0 || again_all == 3) break;
     allow_whole = false;
+  }
+  if (a.chunks > 1) {   // hand the part to its next ticket: the slab is in HBM again
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(&a.chunk_done[part], chunk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 __global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY EMAT_NOTAIL k_run_moves(KernelArgs a) { run_moves_body(a); }
@@ -704,6 +731,8 @@ struct emat_backend {
   // dense copy of every part's slab header (k_gather_headers): what the scalar getters read instead of the slabs
   DevBuf<uint8_t> d_headers; std::vector<uint8_t> h_headers; bool headers_current = false;
   GTreeHost gt;                     // the whole tree, when it lives in HBM (emat_tree_upload)
+  int cfg_chunks = 2;               // EMAT_CHUNKS (tuning knob): tickets per part and pass (main class; measured at C4: 1 -> 311, 2 -> 338, 3 -> 340, 4 -> 331, 8 -> 301 M moves/s)
+  DevBuf<int32_t> d_chunk_done;
   int cfg_parts_per_cu = 0;         // EMAT_PARTS_PER_CU (tuning knob): workgroups of the main class per CU, instead of the percentile rule
   bool cfg_gt_host_coal = false;    // EMAT_TREE_HOST_COALESCENT=1: emat_tree_repartition builds the coalescent tables on the host (bit-identical to the host cycle; tests)
 
@@ -878,7 +907,7 @@ KernelArgs make_args(emat_backend* h) {
   a.evo.ref_sequence = h->d_ref.p; a.evo.partition_for_site = h->d_part.p; a.evo.nu_l = h->d_nu.p; a.evo.cum_Q_l = h->d_cumQ.p;
   a.evo.mu = h->d_mu.p; a.evo.pi = h->d_pi.p; a.evo.q = h->d_q.p;
   a.pop = h->d_pop.p; a.flags = h->flags; a.num_parts = (int)h->parts.size();
-  a.lds_slab_bytes = 0; a.lds_scratch_bytes = 0; a.moves_per_part = 0; a.extra_moves_part0 = 0; a.one_more_below = 0;
+  a.lds_slab_bytes = 0; a.lds_scratch_bytes = 0; a.moves_per_part = 0; a.extra_moves_part0 = 0; a.one_more_below = 0; a.chunks = 1; a.class_count = 0; a.class_stride = 0; a.chunk_done = nullptr;
   return a;
 }
 
@@ -1217,16 +1246,22 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
     // several neighbours to finish (measured: the root part started 10-15 ms into the pass).  So the side classes are
     // launched first, largest area first, class 0 on the engine's own stream and every other class forked onto a
     // stream of its own (they run side by side); the timing events on the engine's stream bracket the fork and the joins.
+    const int chunks = (counts == nullptr && per_part >= 4 * h->cfg_chunks) ? h->cfg_chunks : 1;
+    if (chunks > 1) { HIP_TRY(h->d_chunk_done.alloc(h->parts.size())); HIP_TRY(hipMemsetAsync(h->d_chunk_done.p, 0, h->parts.size() * sizeof(int32_t), h->stream)); }
     HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
     for (int c = 0; c < h->num_classes; ++c) {
       const int lo = h->class_begin[c], cnt = h->class_begin[c + 1] - lo;
       if (cnt <= 0) continue;
       KernelArgs b = a;
       b.order = a.order + lo; b.lds_slab_bytes = h->class_lds[c];
+      // (only the main class: a side class has fewer workgroups than the device has room for, so all its tickets would be
+      // resident at once and the waiting ones would sit on tens of KB of LDS each -- measured: cycles of 72 ms instead of 37)
+      b.chunks = c == main_class ? chunks : 1; b.class_count = cnt; b.class_stride = (cnt + 7) & ~7; b.chunk_done = h->d_chunk_done.p;
+      const unsigned grid = b.chunks > 1 ? (unsigned)(b.chunks * b.class_stride) : (unsigned)cnt;
       hipStream_t sm = c == 0 ? h->stream : h->class_stream[c];
       if (c != 0) HIP_TRY(hipStreamWaitEvent(sm, h->ev_fork, 0));
-      if (c == main_class) hipLaunchKernelGGL(k_run_moves, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
-      else hipLaunchKernelGGL(k_run_moves_side, dim3((unsigned)cnt), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
+      if (c == main_class) hipLaunchKernelGGL(k_run_moves, dim3(grid), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
+      else hipLaunchKernelGGL(k_run_moves_side, dim3(grid), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
       HIP_TRY(hipGetLastError());
       if (c != 0) { HIP_TRY(hipEventRecord(h->ev_join[c], sm)); HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[c], 0)); }
     }
@@ -1267,6 +1302,7 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   if (const char* e = getenv("EMAT_LDS_MAX")) h->cfg_lds_max = (uint32_t)atoi(e) & ~511u;
   if (const char* e = getenv("EMAT_GIANTS")) h->cfg_giants = atoi(e) != 0;
   if (const char* e = getenv("EMAT_TREE_HOST_COALESCENT")) h->cfg_gt_host_coal = atoi(e) != 0;
+  if (const char* e = getenv("EMAT_CHUNKS")) h->cfg_chunks = std::max(1, std::min(64, atoi(e)));
   if (const char* e = getenv("EMAT_PARTS_PER_CU")) h->cfg_parts_per_cu = std::max(0, std::min(4 * EMAT_WAVES_PER_EU, atoi(e)));
   if (const char* e = getenv("EMAT_ORDER_BY_TIME")) h->cfg_order_by_time = atoi(e) != 0;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return EMAT_ERR_HIP; h->num_cus = prop.multiProcessorCount; }
