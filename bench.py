@@ -257,6 +257,7 @@ def main():
                                total_parts, sc.tree.num_nodes, args.moves_per_part),
                 "parts_per_gpu": local_parts, "max_part_nodes": args.max_part_nodes,
                 "lds_staging": not args.no_lds,
+                "tickets_per_part_and_pass": int(os.environ.get("EMAT_CHUNKS", "2")),
                 "parallelism": "parts sharded over %d GPU(s), one wavefront per part" % world,
             },
             # "bound" names the yardstick the contract asks for; "limiter" says what actually limits the kernel
