@@ -1857,6 +1857,23 @@ emat_status emat_debug_variant_counts(emat_backend* h, int32_t* out3) {
   }
   return EMAT_OK;
 }
+/* debugging aid: how much LDS arena the moves of every main-class part start with (bytes; -1 for parts of side classes) */
+emat_status emat_debug_arena_bytes(emat_backend* h, int32_t* out_n) {
+  if (!h || !out_n || h->host_only) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = sync_model_to_device(h); if (st) return st;
+  st = materialize(h); if (st) return st;
+  st = pull_from_device(h); if (st) return st;
+  const uint32_t area = h->class_lds[h->num_classes - 1];
+  for (size_t p = 0; p < h->parts.size(); ++p) {
+    const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + h->parts[p].slab_off);
+    if (h->class_of[p] != h->num_classes - 1) { out_n[p] = -1; continue; }
+    const uint32_t want = (H->heap_top + k_lds_heap_room + 15u) & ~15u;
+    uint32_t used;
+    if (H->heap_end <= area) used = std::min(H->heap_end, want); else if (want <= area) used = want; else used = (H->heap_begin + 15u) & ~15u;
+    out_n[p] = used <= area ? (int32_t)(area - ((used + 15u) & ~15u)) : 0;
+  }
+  return EMAT_OK;
+}
 /* debugging aid (not part of the boundary): duration and start tick (100 MHz wall clock) of every part in the last pass */
 emat_status emat_debug_part_ticks(emat_backend* h, int64_t* out_2n) {
   if (!h || !out_2n || h->host_only || !h->slabs_on_device) return EMAT_ERR_INVALID_ARGUMENT;
