@@ -609,9 +609,21 @@ EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:582-
   g.S = S; g.t_P = t_P;
   int depth = 0, path_muts = 0;
   for (int cur = X; cur != k_no_node; cur = nodes_of(c)[cur].parent) { ++depth; if (c.includes_run_root || nodes_of(c)[cur].parent != k_no_node) path_muts += nmuts(c, cur); }
-  g.bi = (BranchInfo*)sc_alloc(c, (uint32_t)(depth + 2) * (uint32_t)sizeof(BranchInfo));
+  // The hot path rarely climbs more than two or three branches (it ends where the sibling's missing sites are used up), while
+  // the path to the part's root is 5-15 long: room for four entries to start with, doubled when they run out (the
+  // abandoned array stays in the arena until the move ends) -- 104 bytes per entry of an arena of a few KB.
+  int bi_cap = depth + 2 < 4 ? depth + 2 : 4;
+  g.bi = (BranchInfo*)sc_alloc(c, (uint32_t)bi_cap * (uint32_t)sizeof(BranchInfo));
   if (c.failed) return g;
-  const int bi_cap = depth + 2;
+  auto bi_room = [&]() {
+    if (g.nbi < bi_cap) return;
+    if (bi_cap >= depth + 2) { EMAT_FAIL(c, k_part_overflow); return; }
+    const int ncap = 2 * bi_cap < depth + 2 ? 2 * bi_cap : depth + 2;
+    BranchInfo* nb = (BranchInfo*)sc_alloc(c, (uint32_t)ncap * (uint32_t)sizeof(BranchInfo));
+    if (c.failed) return;
+    for (int i = 0; i < g.nbi; ++i) nb[i] = g.bi[i];
+    g.bi = nb; bi_cap = ncap;
+  };
   {
     BranchInfo& PX = g.bi[g.nbi++]; bi_init(PX);
     PX.A = P; PX.B = X; PX.is_open = false; PX.T_to_X = t_X - t_P;
@@ -633,7 +645,7 @@ EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:582-
   int cur = P, parent = nodes_of(c)[cur].parent, sibling = sibling_of(c, parent, cur);
   double partial_lambda = next_pl_B;
   while (sl_iv.n != 0 && !c.failed) {
-    if (g.nbi >= bi_cap) { EMAT_FAIL(c, k_part_overflow); break; }
+    bi_room(); if (c.failed) break;
     BranchInfo& bi = g.bi[g.nbi++]; bi_init(bi);
     bi.A = parent; bi.B = cur; bi.is_open = false; bi.T_to_X = t_X - nodes_of(c)[parent].t;
     bi.warm = sl_iv;
@@ -654,7 +666,7 @@ EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:582-
     } else {
       if (!c.includes_run_root) { bi.hot = bi.warm; bi.pl_A += partial_lambda; }
       else if (sl_iv.n != 0) {
-        if (g.nbi >= bi_cap) { EMAT_FAIL(c, k_part_overflow); break; }
+        bi_room(); if (c.failed) break;
         BranchInfo& fo = g.bi[g.nbi++]; bi_init(fo);
         fo.A = k_no_node; fo.B = hdr_of(c)->root; fo.is_open = true; fo.T_to_X = t_X - nodes_of(c)[parent].t;
         fo.warm = sl_iv; fo.hot = sl_iv; fo.pl_A = partial_lambda;
