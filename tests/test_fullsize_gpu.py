@@ -165,6 +165,42 @@ def test_c5_one_gpu_sampled_trajectories_and_whole_run_properties():
         gpu.close(); orc.close()
 
 
+def test_c5_whole_cycles_with_the_tree_resident_in_hbm():
+    """Config C5 through two whole cycles (repartition -> moves -> reassemble) without the tree ever leaving the device
+    (SURVEY 8(f).2): 2 000 000 nodes cut into ~80 000 parts by kernels and gathered back; what comes back is a valid EMAT
+    with the same tips, and a pass on a fresh partition keeps incremental and recomputed totals together."""
+    sc = make_scenario("C5")
+    b = d.EmatBackend(sc.num_sites)
+    run = d.EmatRun(b, sc.tree, sc.ref, 20261005)
+    run.set_num_parts(81920); run.set_hky(sc.mu, sc.kappa, sc.pi); run.set_pop_model(sc.pop)
+    run.set_device_tree(True)
+    try:
+        run.do_mcmc_steps(2 * 81920 * 100, 81920 * 100)
+        tree, ref = run.tree()
+        assert tree.num_nodes == sc.tree.num_nodes
+        tips = tree.child0 == -1
+        assert np.array_equal(tips, sc.tree.child0 == -1) and np.array_equal(tree.t_min, sc.tree.t_min) and np.array_equal(tree.t_max, sc.tree.t_max)
+        assert not np.array_equal(tree.parent, sc.tree.parent) and not np.array_equal(tree.t, sc.tree.t)
+        # structure: every non-root node hangs below an older parent that lists it as a child
+        nonroot = np.arange(tree.num_nodes) != tree.root
+        par = tree.parent[nonroot]
+        assert np.all(par >= 0) and tree.parent[tree.root] == -1
+        assert np.all((tree.child0[par] == np.flatnonzero(nonroot)) | (tree.child1[par] == np.flatnonzero(nonroot)))
+        assert np.all(tree.t[par] <= tree.t[nonroot])
+        # mutations stay on their branches, sorted in time
+        nm = np.diff(tree.mut_offset)
+        owner = np.repeat(np.arange(tree.num_nodes), nm)
+        keep = owner != tree.root
+        assert np.all(tree.mut_t[keep] >= tree.t[tree.parent[owner[keep]]]) and np.all(tree.mut_t[keep] <= tree.t[owner[keep]])
+        assert np.all(tree.mut_from != tree.mut_to)
+        run.repartition(); n, _ = run.num_parts(); run.run_moves(n * 50); b.synchronize()
+        inc = b.totals(); b.recalc_derived(); rec = b.totals()
+        assert rel_close(inc[0], rec[0], 1e-9) and rel_close(inc[1], rec[1], 1e-9), (inc, rec)
+        run.reassemble()
+    finally:
+        run.close(); b.close()
+
+
 def _sharded_gpu_worker(rank, world, port, out_dir, cycles, moves):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
