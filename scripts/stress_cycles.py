@@ -2,7 +2,8 @@
 """Soak test on the GPU: many repartition -> moves -> reassemble cycles of the C++ run driver on a large tree, then the
 whole tree is checked with the oracle's restatement of the reference's tree-integrity rules (phylo_tree.cpp:18-126) and
 the engine's incremental log-posterior totals are compared with a from-scratch evaluation after every cycle.
-Usage: scripts/stress_cycles.py [workload=C4] [cycles=20] [parts=8192] [max_part_nodes=100]"""
+Usage: scripts/stress_cycles.py [workload=C4] [cycles=20] [parts=8192] [max_part_nodes=100] [device_tree=0]
+(EMAT_SLACK=1.05 EMAT_HEAP_PER_NODE=8 in the environment starves the list heaps, so that the out-of-space recoveries run too.)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,14 +17,19 @@ workload = sys.argv[1] if len(sys.argv) > 1 else "C4"
 cycles = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 parts = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
 limit = int(sys.argv[4]) if len(sys.argv) > 4 else 100
+device_tree = len(sys.argv) > 5 and sys.argv[5] == "1"
 sc = make_scenario(workload)
 b = d.EmatBackend(sc.num_sites)
 run = d.EmatRun(b, sc.tree, sc.ref, 777)
 run.set_num_parts(parts); run.set_max_part_nodes(limit)
 run.set_hky(sc.mu, sc.kappa, sc.pi); run.set_pop_model(sc.pop)
+if device_tree:
+    run.set_device_tree(True)
 t0 = time.perf_counter()
 for cyc in range(cycles):
-    run.repartition(); n, _ = run.num_parts(); run.push_params()
+    run.repartition(); n, _ = run.num_parts()
+    if not device_tree:
+        run.push_params()
     run.run_moves(n * 1000); b.synchronize()
     g_inc, a_inc = b.totals()
     b.recalc_derived(); g_new, a_new = b.totals()

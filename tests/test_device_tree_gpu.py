@@ -257,3 +257,21 @@ def test_whole_tree_grid_prior_from_parts_cut_on_the_device():
         orc.close()
         assert rel_close(got, want, 1e-9), (cyc, got, want)
     run.close(); b.close()
+
+
+def test_out_of_space_recoveries_inside_cycles(monkeypatch):
+    """List heaps sized with almost no slack (EMAT_SLACK / EMAT_HEAP_PER_NODE): in every pass a good share of the parts stops
+    before a move for lack of room, is given more and runs the rest of its moves -- across tickets, on slabs that were cut
+    on the device -- and the cycles still equal the host cycles bit for bit (a chain does not depend on where it paused)."""
+    monkeypatch.setenv("EMAT_SLACK", "1.05")
+    monkeypatch.setenv("EMAT_HEAP_PER_NODE", "8")
+    sc = make_scenario("C3", num_tips=3000, num_sites=29903, uncertain_tips=0.1)
+    bh, rh = _run(sc, 19, 128, False)
+    bd, rd = _run(sc, 19, 128, True)
+    for cycle in range(4):
+        rh.do_mcmc_steps(128 * 1500, 128 * 1500); rd.do_mcmc_steps(128 * 1500, 128 * 1500)
+        th, refh = rh.tree(); td, refd = rd.tree()
+        _same_tree(th, td, "cycle %d" % cycle)
+        assert np.array_equal(refh, refd), cycle
+    for r in (rh, rd): r.close()
+    for b in (bh, bd): b.close()
