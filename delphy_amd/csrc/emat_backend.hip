@@ -22,6 +22,9 @@
 #include <vector>
 
 #include "../../include/emat_backend.h"
+#ifdef EMAT_PROFILE_PHASES
+namespace emat { __device__ unsigned long long g_arena_site_bytes[2048][2]; }   // [source line & 2047][0 = LDS arena, 1 = HBM scratch], all parts
+#endif
 // The device code is compiled three times (see emat_device_core.hpp): `dev_lds` for parts whose whole persistent slab
 // is staged in LDS, `dev_mix` for larger parts of which only header + nodes + cells are staged, and `dev` for parts
 // that run entirely on their HBM slab (and for k_recalc_derived).
@@ -1856,6 +1859,18 @@ emat_status emat_debug_variant_counts(emat_backend* h, int32_t* out3) {
     if (can && (H->heap_end <= area || H->heap_top + k_lds_heap_room <= area)) ++out3[0]; else if (can && H->heap_begin <= area) ++out3[1]; else ++out3[2];
   }
   return EMAT_OK;
+}
+/* debugging aid (profiling builds): bytes the moves' arena handed out per allocating source line, [line & 2047][LDS, HBM] */
+emat_status emat_debug_arena_sites(emat_backend* h, uint64_t* out_4096) {
+  if (!h || !out_4096 || h->host_only) return EMAT_ERR_INVALID_ARGUMENT;
+#ifdef EMAT_PROFILE_PHASES
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpyFromSymbol(out_4096, HIP_SYMBOL(::emat::g_arena_site_bytes), sizeof(unsigned long long) * 4096));
+  return EMAT_OK;
+#else
+  return fail(h, EMAT_ERR_STATE, "built without -DEMAT_PROFILE_PHASES");
+#endif
 }
 /* debugging aid: how much LDS arena the moves of every main-class part start with (bytes; -1 for parts of side classes) */
 emat_status emat_debug_arena_bytes(emat_backend* h, int32_t* out_n) {

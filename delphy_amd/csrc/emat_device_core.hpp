@@ -125,10 +125,12 @@ EMAT_D void fail_at(Ctx& c, int status, int line) {
 #define EMAT_FAIL(c, st) fail_at((c), (st), __LINE__)
 #define EMAT_CHECK(c, cond) do { if (!(cond)) fail_at((c), ::emat::k_part_internal, __LINE__); } while (0)
 #ifdef EMAT_PROFILE_PHASES
+#define EMAT_SITE(line, hbm, v) atomicAdd(&::emat::g_arena_site_bytes[(line) & 2047][(hbm) ? 1 : 0], (unsigned long long)(v))
 #define EMAT_COUNT(c, k, v) (((int64_t*)hdr_of(c)->reserved)[k] += (int64_t)(v))
 #define EMAT_PHASE_BEGIN() long long _ph_t0 = clock64()
 #define EMAT_PHASE(c, k) do { long long _t = clock64(); hdr_of(c)->phase_ticks[k] += _t - _ph_t0; _ph_t0 = _t; } while (0)
 #else
+#define EMAT_SITE(line, hbm, v) do {} while (0)
 #define EMAT_COUNT(c, k, v) do {} while (0)
 #define EMAT_PHASE_BEGIN() do {} while (0)
 #define EMAT_PHASE(c, k) do {} while (0)
@@ -188,22 +190,22 @@ EMAT_D ScMark sc_mark(const Ctx& c) { ScMark m; m.a = c.a_top; m.g = c.sc_top; r
 EMAT_D void sc_release(Ctx& c, ScMark m) { c.a_top = m.a; c.sc_top = m.g; }
 EMAT_D void sc_reset(Ctx& c) { c.a_top = 0; c.sc_top = hdr_of(c)->scratch_begin; }
 EMAT_D bool sc_in_lds(const Ctx& c, const void* p) { return c.A != nullptr && (const uint8_t*)p >= c.A && (const uint8_t*)p < c.A + c.a_end; }
-EMAT_D uint8_t* sc_alloc(Ctx& c, uint32_t bytes) {
+EMAT_D uint8_t* sc_alloc(Ctx& c, uint32_t bytes, int line = __builtin_LINE()) {
   uint32_t b = (bytes + 15u) & ~15u;
-  if (c.a_top + b <= c.a_end) { uint8_t* p = c.A + c.a_top; c.a_top += b; EMAT_COUNT(c, 9, b); return p; }
+  if (c.a_top + b <= c.a_end) { uint8_t* p = c.A + c.a_top; c.a_top += b; EMAT_COUNT(c, 9, b); EMAT_SITE(line, 0, b); return p; }
   if (c.sc_top + b > hdr_of(c)->scratch_end) { EMAT_FAIL(c, k_part_overflow); return c.G + hdr_of(c)->scratch_begin; }
-  EMAT_COUNT(c, 8, b);
+  EMAT_COUNT(c, 8, b); EMAT_SITE(line, 1, b);
   uint8_t* p = c.G + c.sc_top;
   c.sc_top += b;
   return p;
 }
-template <class T> EMAT_D SVec<T> sc_vec(Ctx& c, int cap) {
+template <class T> EMAT_D SVec<T> sc_vec(Ctx& c, int cap, int line = __builtin_LINE()) {
   SVec<T> v; v.n = 0;
   uint32_t bytes = (uint32_t)cap * (uint32_t)sizeof(T);
   uint32_t b = (bytes + 15u) & ~15u;
-  if (cap >= 0 && c.a_top + b <= c.a_end) { v.p = (T*)(c.A + c.a_top); v.cap = cap; c.a_top += b; EMAT_COUNT(c, 9, b); return v; }
+  if (cap >= 0 && c.a_top + b <= c.a_end) { v.p = (T*)(c.A + c.a_top); v.cap = cap; c.a_top += b; EMAT_COUNT(c, 9, b); EMAT_SITE(line, 0, b); return v; }
   if (cap < 0 || c.sc_top + b > hdr_of(c)->scratch_end) { EMAT_FAIL(c, k_part_overflow); v.p = (T*)(c.G + hdr_of(c)->scratch_begin); v.cap = 0; return v; }
-  EMAT_COUNT(c, 8, b);
+  EMAT_COUNT(c, 8, b); EMAT_SITE(line, 1, b);
   v.p = (T*)(c.G + c.sc_top); v.cap = cap; c.sc_top += b;
   return v;
 }
@@ -222,10 +224,10 @@ template <class T> EMAT_D SVec<T> sc_open(Ctx& c, int max_elems, int min_lds_ele
   return v;
 }
 // give back the unused tail of the most recent allocation in its arena
-template <class T> EMAT_D void sc_trim(Ctx& c, SVec<T>& v) {
+template <class T> EMAT_D void sc_trim(Ctx& c, SVec<T>& v, int line = __builtin_LINE()) {
   uint32_t used = ((uint32_t)v.n * (uint32_t)sizeof(T) + 15u) & ~15u;
-  if (sc_in_lds(c, v.p)) { c.a_top = (uint32_t)((uint8_t*)v.p - c.A) + used; EMAT_COUNT(c, 9, used); }
-  else { c.sc_top = (uint32_t)((uint8_t*)v.p - c.G) + used; EMAT_COUNT(c, 8, used); EMAT_COUNT(c, 11, 1); }
+  if (sc_in_lds(c, v.p)) { c.a_top = (uint32_t)((uint8_t*)v.p - c.A) + used; EMAT_COUNT(c, 9, used); EMAT_SITE(line, 0, used); }
+  else { c.sc_top = (uint32_t)((uint8_t*)v.p - c.G) + used; EMAT_COUNT(c, 8, used); EMAT_COUNT(c, 11, 1); EMAT_SITE(line, 1, used); }
   v.cap = v.n;
 }
 // Two containers growing towards each other inside one arena (results upwards from `lo`, a work stack downwards
@@ -258,10 +260,10 @@ EMAT_D ScSpan sc_span_hbm(Ctx& c) {
   if (s.hi < s.lo) s.hi = s.lo;
   return s;
 }
-EMAT_D void sc_span_commit(Ctx& c, const ScSpan& s, uint32_t used_bytes) {
+EMAT_D void sc_span_commit(Ctx& c, const ScSpan& s, uint32_t used_bytes, int line = __builtin_LINE()) {
   uint32_t u = (used_bytes + 15u) & ~15u;
   if (s.reserved) return;   // the block stays reserved
-  if (s.lds) { c.a_top = (uint32_t)(s.lo - c.A) + u; EMAT_COUNT(c, 9, u); } else { c.sc_top = (uint32_t)(s.lo - c.G) + u; EMAT_COUNT(c, 8, u); EMAT_COUNT(c, 12, 1); }
+  if (s.lds) { c.a_top = (uint32_t)(s.lo - c.A) + u; EMAT_COUNT(c, 9, u); EMAT_SITE(line, 0, u); } else { c.sc_top = (uint32_t)(s.lo - c.G) + u; EMAT_COUNT(c, 8, u); EMAT_COUNT(c, 12, 1); EMAT_SITE(line, 1, u); }
 }
 
 // ---- persistent per-node lists in the slab heap ---------------------------------------------------------
