@@ -735,6 +735,7 @@ struct emat_backend {
   DevBuf<uint8_t> d_headers; std::vector<uint8_t> h_headers; bool headers_current = false;
   GTreeHost gt;                     // the whole tree, when it lives in HBM (emat_tree_upload)
   int cfg_chunks = 2;               // EMAT_CHUNKS (tuning knob): tickets per part and pass (main class; measured at C4: 1 -> 311, 2 -> 338, 3 -> 340, 4 -> 331, 8 -> 301 M moves/s)
+  bool cfg_chunks_forced = false;   // EMAT_CHUNKS was given: tickets also when the parts are fewer than the wave slots (tests)
   DevBuf<int32_t> d_chunk_done;
   int cfg_parts_per_cu = 0;         // EMAT_PARTS_PER_CU (tuning knob): workgroups of the main class per CU, instead of the percentile rule
   bool cfg_gt_host_coal = false;    // EMAT_TREE_HOST_COALESCENT=1: emat_tree_repartition builds the coalescent tables on the host (bit-identical to the host cycle; tests)
@@ -1249,7 +1250,10 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
     // several neighbours to finish (measured: the root part started 10-15 ms into the pass).  So the side classes are
     // launched first, largest area first, class 0 on the engine's own stream and every other class forked onto a
     // stream of its own (they run side by side); the timing events on the engine's stream bracket the fork and the joins.
-    const int chunks = (counts == nullptr && per_part >= 4 * h->cfg_chunks) ? h->cfg_chunks : 1;
+    // Tickets pay when there are more parts than wave slots (4 waves x 4 SIMDs per CU): with fewer, every part has a slot to
+    // itself from the start and a second ticket could only wait behind its first while holding another slot.
+    const int main_count = h->class_begin[h->num_classes] - h->class_begin[h->num_classes - 1];
+    const int chunks = (counts == nullptr && per_part >= 4 * h->cfg_chunks && (h->cfg_chunks_forced || main_count > 4 * EMAT_WAVES_PER_EU * h->num_cus)) ? h->cfg_chunks : 1;
     if (chunks > 1) { HIP_TRY(h->d_chunk_done.alloc(h->parts.size())); HIP_TRY(hipMemsetAsync(h->d_chunk_done.p, 0, h->parts.size() * sizeof(int32_t), h->stream)); }
     HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
     for (int c = 0; c < h->num_classes; ++c) {
@@ -1305,7 +1309,7 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   if (const char* e = getenv("EMAT_LDS_MAX")) h->cfg_lds_max = (uint32_t)atoi(e) & ~511u;
   if (const char* e = getenv("EMAT_GIANTS")) h->cfg_giants = atoi(e) != 0;
   if (const char* e = getenv("EMAT_TREE_HOST_COALESCENT")) h->cfg_gt_host_coal = atoi(e) != 0;
-  if (const char* e = getenv("EMAT_CHUNKS")) h->cfg_chunks = std::max(1, std::min(64, atoi(e)));
+  if (const char* e = getenv("EMAT_CHUNKS")) { h->cfg_chunks = std::max(1, std::min(64, atoi(e))); h->cfg_chunks_forced = true; }
   if (const char* e = getenv("EMAT_PARTS_PER_CU")) h->cfg_parts_per_cu = std::max(0, std::min(4 * EMAT_WAVES_PER_EU, atoi(e)));
   if (const char* e = getenv("EMAT_ORDER_BY_TIME")) h->cfg_order_by_time = atoi(e) != 0;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return EMAT_ERR_HIP; h->num_cus = prop.multiProcessorCount; }

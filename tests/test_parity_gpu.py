@@ -317,3 +317,12 @@ def test_Ttwiddle_l_of_the_whole_tree_from_the_parts():
                 assert np.all(want >= 0) and want.max() > 0
         finally:
             run.close(); b.close()
+
+
+def test_a_pass_in_tickets_is_the_same_chain(monkeypatch):
+    """EMAT_CHUNKS: every part's pass cut into 1, 3 and 7 tickets that hand the slab over through HBM -- move for move the
+    oracle's chain each time (the trace, the tree, the counters and the RNG position do not know about the cuts)."""
+    sc = make_scenario("C3", num_tips=1200, num_sites=8000, uncertain_tips=0.2)
+    for chunks in ("1", "3", "7"):
+        monkeypatch.setenv("EMAT_CHUNKS", chunks)
+        run_parity(sc, 48, 1001, seed=53, trace=1001)
