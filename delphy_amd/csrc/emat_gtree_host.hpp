@@ -174,6 +174,11 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
       }
     }, 64);
     if (bad.load() || orig[part_offset[root_part]] != G.h_root) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_repartition: malformed partition");
+    // every node is owned exactly once: as a non-root node of its part, the run's root as the root of the root part
+    std::vector<uint8_t> owned((size_t)n, 0);
+    for (int p = 0; p < P && !bad.load(); ++p)
+      for (int s = (p == root_part ? 0 : 1), b = part_offset[p], np = part_offset[p + 1] - b; s < np; ++s) { if (owned[orig[b + s]]++) { bad.store(1); break; } }
+    if (bad.load()) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_repartition: a node belongs to two parts");
   }
   if (h->stream) HIP_TRY(hipStreamSynchronize(h->stream));
   try { h->pop = HostPopModel::from_c(*pm); } catch (const std::exception& ex) { return fail(h, EMAT_ERR_INVALID_ARGUMENT, ex.what()); }

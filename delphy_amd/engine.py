@@ -427,6 +427,43 @@ class EmatBackend:
     def synchronize(self):
         self._ck(self._lib.emat_synchronize(self._h), "emat_synchronize")
 
+    # ---- the whole tree resident in HBM (include/emat_backend.h: emat_tree_*) ----
+    def tree_upload(self, tree: FlatTree):
+        v = tree.c_view()
+        self._ck(self._lib.emat_tree_upload(self._h, C.byref(v)), "emat_tree_upload")
+
+    def tree_topology(self):
+        n, nm, ni, nf = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._lib.emat_tree_get_sizes(self._h, C.byref(n), C.byref(nm), C.byref(ni), C.byref(nf)), "emat_tree_get_sizes")
+        parent, c0, c1 = (np.zeros(n.value, np.int32) for _ in range(3))
+        t = np.zeros(n.value); root = C.c_int32()
+        self._ck(self._lib.emat_tree_get_topology(self._h, _ptr(parent, C.c_int32), _ptr(c0, C.c_int32), _ptr(c1, C.c_int32), _ptr(t, C.c_double), C.byref(root)), "emat_tree_get_topology")
+        return parent, c0, c1, t, int(root.value)
+
+    def tree_repartition(self, part_offset, orig, kid0, kid1, root_part: int, seeds, pop: PopModel, t_step: float):
+        po, og, k0, k1 = (np.ascontiguousarray(a, np.int32) for a in (part_offset, orig, kid0, kid1))
+        sd = np.ascontiguousarray(seeds, np.uint64)
+        m = pop.c_struct()
+        self._ck(self._lib.emat_tree_repartition(self._h, int(po.shape[0]) - 1, _ptr(po, C.c_int32), _ptr(og, C.c_int32), _ptr(k0, C.c_int32), _ptr(k1, C.c_int32),
+                                                 root_part, _ptr(sd, C.c_uint64), C.byref(m), t_step), "emat_tree_repartition")
+
+    def tree_reassemble(self, capacity: int = 256):
+        n = C.c_int32()
+        site = np.zeros(capacity, np.int32); frm = np.zeros(capacity, np.uint8); to = np.zeros(capacity, np.uint8)
+        self._ck(self._lib.emat_tree_reassemble(self._h, C.byref(n), _ptr(site, C.c_int32), _ptr(frm, C.c_uint8), _ptr(to, C.c_uint8), capacity), "emat_tree_reassemble")
+        k = n.value
+        return site[:k].copy(), frm[:k].copy(), to[:k].copy()
+
+    def tree_download(self):
+        n, nm, ni, nf = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._lib.emat_tree_get_sizes(self._h, C.byref(n), C.byref(nm), C.byref(ni), C.byref(nf)), "emat_tree_get_sizes")
+        t = FlatTree.empty(n.value, nm.value, ni.value, nf.value)
+        v = t.c_view()
+        ref = np.zeros(self.num_sites, np.uint8)
+        self._ck(self._lib.emat_tree_download(self._h, C.byref(v), _ptr(ref, C.c_uint8)), "emat_tree_download")
+        t.root = v.root
+        return t.trimmed(), ref
+
     def tree_counters(self):
         """(growths of the cut-state pools, growths of the list heaps) of the HBM-resident tree: testing aid."""
         out = np.zeros(2, np.int32)

@@ -275,3 +275,99 @@ def test_out_of_space_recoveries_inside_cycles(monkeypatch):
         assert np.array_equal(refh, refd), cycle
     for r in (rh, rd): r.close()
     for b in (bh, bd): b.close()
+
+
+def _whole_tree_as_one_part(parent, c0, c1, root):
+    """partition_tree's numbering for a single part: local 0 = root, children get consecutive indices when their parent is
+    expanded, right child expanded first."""
+    orig, kid0, kid1 = [root], [-1], [-1]
+    work = [(root, 0)]
+    while work:
+        src, dst = work.pop()
+        if c0[src] < 0:
+            continue
+        dl = len(orig); orig.append(int(c0[src])); dr = len(orig); orig.append(int(c1[src]))
+        kid0 += [-1, -1]; kid1 += [-1, -1]
+        kid0[dst], kid1[dst] = dl, dr
+        work.append((int(c0[src]), dl)); work.append((int(c1[src]), dr))
+    return np.array([0, len(orig)], np.int32), np.array(orig, np.int32), np.array(kid0, np.int32), np.array(kid1, np.int32)
+
+
+def test_the_c_abi_of_the_resident_tree_directly():
+    """emat_tree_upload / _get_topology / _repartition / _reassemble / _download without the run driver: the partition is
+    made here, in Python; the part it yields is the one emat_part_upload makes of the same subtree; after the moves the tree
+    that comes back equals that part, relabelled; malformed partitions are refused."""
+    sc = make_scenario("C1", num_tips=120, num_sites=3000, uncertain_tips=0.3)
+    old = os.environ.get("EMAT_TREE_HOST_COALESCENT"); os.environ["EMAT_TREE_HOST_COALESCENT"] = "1"
+    try:
+        bd = d.EmatBackend(sc.num_sites)
+    finally:
+        if old is None: del os.environ["EMAT_TREE_HOST_COALESCENT"]
+        else: os.environ["EMAT_TREE_HOST_COALESCENT"] = old
+    bh = d.EmatBackend(sc.num_sites)
+    t_step = sc.default_t_step()
+    for b in (bd, bh):
+        b.set_ref_sequence(sc.ref); b.set_hky(sc.mu, sc.kappa, sc.pi); b.set_flags(sc.t_max_tip)
+    bd.tree_upload(sc.tree)
+    t0, r0 = bd.tree_download()
+    _same_tree(t0, sc.tree, "upload -> download")
+    assert np.array_equal(r0, sc.ref)
+    parent, c0, c1, t, root = bd.tree_topology()
+    assert root == sc.tree.root and np.array_equal(parent, sc.tree.parent) and np.array_equal(t, sc.tree.t)
+    po, orig, k0, k1 = _whole_tree_as_one_part(parent, c0, c1, root)
+    # malformed partitions
+    with pytest.raises(d.EmatError, match="EMAT_ERR_INVALID_ARGUMENT"):
+        bad = orig.copy(); bad[5] = bad[6]
+        bd.tree_repartition(po, bad, k0, k1, 0, [7], sc.pop, t_step)
+    with pytest.raises(d.EmatError, match="EMAT_ERR_INVALID_ARGUMENT"):
+        bd.tree_repartition(np.array([0, len(orig) - 2], np.int32), orig[:-2], k0[:-2], k1[:-2], 0, [7], sc.pop, t_step)
+    bd.tree_repartition(po, orig, k0, k1, 0, [7], sc.pop, t_step)
+    # the same part through the host path: the subtree in the partition's numbering
+    inv = np.empty(len(orig), np.int64); inv[orig] = np.arange(len(orig))
+    sub = d.FlatTree.empty(len(orig), int(sc.tree.mut_offset[-1]), int(sc.tree.miss_offset[-1]), int(sc.tree.mfs_offset[-1]))
+    sub.root = 0
+    km = ki = kf = 0
+    for s, o in enumerate(orig):
+        sub.parent[s] = -1 if o == root else inv[sc.tree.parent[o]]
+        sub.child0[s], sub.child1[s] = k0[s], k1[s]
+        sub.t[s], sub.t_min[s], sub.t_max[s] = sc.tree.t[o], sc.tree.t_min[o], sc.tree.t_max[o]
+        for a, b_, dst in (("mut_offset", ("mut_site", "mut_from", "mut_to", "mut_t"), "m"), ("miss_offset", ("miss_start", "miss_end"), "i"), ("mfs_offset", ("mfs_site", "mfs_state"), "f")):
+            lo, hi = getattr(sc.tree, a)[o], getattr(sc.tree, a)[o + 1]
+            k = {"m": km, "i": ki, "f": kf}[dst]
+            for f in b_:
+                getattr(sub, f)[k:k + hi - lo] = getattr(sc.tree, f)[lo:hi]
+            if dst == "m": km += hi - lo
+            elif dst == "i": ki += hi - lo
+            else: kf += hi - lo
+        sub.mut_offset[s + 1], sub.miss_offset[s + 1], sub.mfs_offset[s + 1] = km, ki, kf
+    sub = sub.trimmed()
+    bh.upload_parts([sub], [True], [7]); bh.build_coalescent_parts(sc.pop, 0, t_step)
+    bh.recalc_derived(); bd.recalc_derived()
+    _same_tree(bh.part_download(0), bd.part_download(0), "the part")
+    assert bh.totals() == bd.totals()
+    for b in (bh, bd):
+        b.run_moves_per_part(4000); b.synchronize()
+    ph = bh.part_download(0)
+    _same_tree(ph, bd.part_download(0), "after the moves")
+    site, frm, to = bd.tree_reassemble()
+    whole, ref = bd.tree_download()
+    # the part, relabelled back to the tree's node numbers, with the root's deltas folded into the reference
+    assert whole.root == orig[ph.root]
+    for s, o in enumerate(orig):
+        assert whole.t[o] == ph.t[s]
+        if ph.child0[s] >= 0:
+            assert whole.child0[o] == orig[ph.child0[s]] and whole.child1[o] == orig[ph.child1[s]]
+        lo, hi = ph.mut_offset[s], ph.mut_offset[s + 1]
+        if s == ph.root:
+            assert whole.mut_offset[o + 1] == whole.mut_offset[o]
+            assert sorted(zip(ph.mut_site[lo:hi], ph.mut_from[lo:hi], ph.mut_to[lo:hi])) == sorted(zip(site, frm, to))
+        else:
+            wl, wh = whole.mut_offset[o], whole.mut_offset[o + 1]
+            assert np.array_equal(whole.mut_site[wl:wh], ph.mut_site[lo:hi]) and np.array_equal(whole.mut_t[wl:wh], ph.mut_t[lo:hi])
+        il, ih = ph.miss_offset[s], ph.miss_offset[s + 1]; wl, wh = whole.miss_offset[o], whole.miss_offset[o + 1]
+        assert np.array_equal(whole.miss_start[wl:wh], ph.miss_start[il:ih]) and np.array_equal(whole.miss_end[wl:wh], ph.miss_end[il:ih])
+    want_ref = sc.ref.copy(); want_ref[site] = to
+    assert np.array_equal(ref, want_ref) and np.array_equal(frm, sc.ref[site])
+    with pytest.raises(d.EmatError, match="EMAT_ERR_STATE"):
+        bd.tree_reassemble()                  # nothing is out on slabs any more
+    bd.close(); bh.close()
