@@ -148,13 +148,18 @@ emat_status emat_tree_get_topology(emat_backend* h, int32_t* parent, int32_t* ch
 
 emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int32_t* part_offset, const int32_t* orig, const int32_t* kid0, const int32_t* kid1,
                                   int32_t root_part, const uint64_t* seeds, const emat_pop_model* pm, double t_step) {
+  return emat_tree_repartition_range(h, num_parts, part_offset, orig, kid0, kid1, root_part, seeds, pm, t_step, 0, num_parts);
+}
+emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, const int32_t* part_offset, const int32_t* orig, const int32_t* kid0, const int32_t* kid1,
+                                        int32_t root_part, const uint64_t* seeds, const emat_pop_model* pm, double t_step, int32_t part_lo, int32_t part_hi) {
   if (!h || num_parts <= 0 || !part_offset || !orig || !kid0 || !kid1 || !seeds || !pm || !(t_step > 0.0) || root_part < 0 || root_part >= num_parts) return EMAT_ERR_INVALID_ARGUMENT;
+  if (part_lo < 0 || part_hi > num_parts || part_lo >= part_hi) return EMAT_ERR_INVALID_ARGUMENT;
   emat_status st = gt_require(h, true); if (st) return st;
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   if (h->cfg.max_parts > 0 && num_parts > h->cfg.max_parts) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "more parts than cfg.max_parts");
   if (!h->have_ref || !h->have_evo) return fail(h, EMAT_ERR_STATE, "set_ref_sequence and set_evo must precede emat_tree_repartition");
   GTreeHost& G = h->gt;
-  const int P = num_parts, n = G.n;
+  const int P = num_parts, n = G.n, lo = part_lo, hi = part_hi, nloc = hi - lo;   // this process runs the parts [lo, hi): local part q is part lo + q
   const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -186,6 +191,9 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
   st = sync_model_to_device(h); if (st) return st;
   G.P = P; G.root_part = root_part; G.parts_live = false;
   const bool device_coal = !h->cfg_gt_host_coal;
+  if (nloc != P && !device_coal) return fail(h, EMAT_ERR_STATE, "a block of the parts needs the coalescent tables built on the device (EMAT_TREE_HOST_COALESCENT builds them from all parts on the host)");
+  G.lo = lo; G.hi = hi;
+  G.h_part_off.assign(part_offset, part_offset + P + 1); G.h_orig.assign(orig, orig + total); G.h_kid0.assign(kid0, kid0 + total);
   HIP_TRY(G.part_off.upload(part_offset, (size_t)P + 1)); HIP_TRY(G.orig.upload(orig, total)); HIP_TRY(G.kid0.upload(kid0, total)); HIP_TRY(G.kid1.upload(kid1, total));
   if (device_coal) {
     std::vector<int32_t> lpar(total, EMAT_NO_NODE);
@@ -211,11 +219,12 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
   h->coal_builder.reset();
   h->fatal_status = EMAT_OK; h->fatal_message.clear(); h->pass_pending = false;
   if (!device_coal) h->parts.clear();   // (with the tables built on the device the records hold no vectors worth freeing and re-allocating 8 000 times per cycle)
-  h->parts.resize(P);
-  h->uploads_expected = 0; h->root_part = root_part;
+  h->parts.resize(nloc);
+  h->uploads_expected = 0; h->root_part = (root_part >= lo && root_part < hi) ? root_part - lo : -1;
   h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false; h->have_coal = false; h->derived_valid = false;
-  parallel_for(P, [&](int p) {
-    PartHost& ph = h->parts[p];
+  parallel_for(nloc, [&](int q) {
+    const int p = lo + q;
+    PartHost& ph = h->parts[q];
     const int b = part_offset[p], np = part_offset[p + 1] - b;
     FlatTree& t = ph.tree;
     if (!device_coal) t.resize_nodes(np);   // (with the tables built on the device the host never needs the part's tree: a pull decodes it from the slab)
@@ -238,7 +247,7 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
     std::vector<const FlatTree*> trees; std::vector<HostRng*> rngs;
     for (auto& ph : h->parts) { trees.push_back(&ph.tree); rngs.push_back(&ph.rng); }
     auto cps = make_coalescent_parts(trees, root_part, h->pop, rngs, t_step);
-    for (int p = 0; p < P; ++p) h->parts[p].coal = std::move(cps[p]);
+    for (int p = 0; p < P; ++p) h->parts[p].coal = std::move(cps[p]);   // (host tables: lo = 0, hi = P)
   } catch (const std::exception& ex) { return fail(h, EMAT_ERR_INVALID_ARGUMENT, ex.what()); }
   h->have_coal = true;
   const auto t3 = now();
@@ -260,8 +269,8 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
   const auto t4 = now();
   // geometry, placement, size classes: as for host-encoded parts
   const int trace_cap = h->cfg.trace_moves > 0 ? h->cfg.trace_moves : 0;
-  uint64_t off = 0; h->max_slab_bytes = 0; h->persistent_bytes.assign(P, 0); h->prefix_bytes.assign(P, 0);
-  std::vector<GPartDesc> desc(P); std::vector<uint64_t> offs(P);
+  uint64_t off = 0; h->max_slab_bytes = 0; h->persistent_bytes.assign(nloc, 0); h->prefix_bytes.assign(nloc, 0);
+  std::vector<GPartDesc> desc(P); std::vector<uint64_t> offs(nloc);
   uint64_t cells_bytes = 0;
   GCoal co{};
   std::vector<int> first_active(P, 0), num_cells_of(P, 0);
@@ -273,35 +282,39 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
     for (int p = 0; p < P; ++p) { all_min = std::min(all_min, me[p].t_min); all_max = std::max(all_max, me[p].t_max); }
     co.t_ref = all_max; co.t_step = t_step; co.num_cells = cell_for(all_min, all_max, t_step) + 1;
     uint64_t pool = 0;
-    for (int p = 0; p < P; ++p) {
-      HostCoalPart& c = h->parts[p].coal;
+    for (int p = 0; p < P; ++p) {   // the grid is the whole run's: every process builds all of it (it has the whole tree), identically
       const int fc = cell_for(me[p].t_max, co.t_ref, t_step), lc = cell_for(p == root_part ? all_min : me[p].t_min, co.t_ref, t_step);
       if (!(0 <= fc && fc <= lc && lc < co.num_cells)) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "coalescent grid: bad cell range");
       const int wf = std::min(fc, std::max(0, cell_for(me[p].t_max_exact, co.t_ref, t_step)));
       first_active[p] = fc;
-      if (!c.k_bar_p.empty()) c = HostCoalPart{};   // (tables decoded by a pull of the previous partition)
-      c.cell_first = wf; c.n_cells_total = lc + 1; c.t_ref = co.t_ref; c.t_step = t_step;
       num_cells_of[p] = lc - wf + 1;
-      h->parts[p].rng.counter = (uint64_t)(lc - fc + 1);   // one Philox block per Gaussian draw
-      desc[p].cells_off = pool; pool += (uint64_t)(lc - wf + 1);
+      GPartDesc& d = desc[p];
+      d.cell_first = wf; d.n_cells = lc - wf + 1; d.n_cells_total = lc + 1; d.t_ref = co.t_ref; d.t_step = t_step; d.coal_first_active = fc;
+      d.rng_key = seeds[p]; d.cells_off = pool; pool += (uint64_t)(lc - wf + 1);
+      if (p >= lo && p < hi) {
+        HostCoalPart& c = h->parts[p - lo].coal;
+        if (!c.k_bar_p.empty()) c = HostCoalPart{};   // (tables decoded by a pull of the previous partition)
+        c.cell_first = wf; c.n_cells_total = lc + 1; c.t_ref = co.t_ref; c.t_step = t_step;
+        h->parts[p - lo].rng.counter = (uint64_t)(lc - fc + 1);   // one Philox block per Gaussian draw
+      }
     }
     HIP_TRY(G.co_kbar.alloc(pool)); HIP_TRY(G.co_ktw.alloc(pool));
     HIP_TRY(G.co_k_bar.alloc(co.num_cells)); HIP_TRY(G.co_k_tw.alloc(co.num_cells)); HIP_TRY(G.co_popsize.alloc(co.num_cells)); HIP_TRY(G.co_num_active.alloc(co.num_cells));
     co.kbar_pool = G.co_kbar.p; co.ktw_pool = G.co_ktw.p; co.k_bar = G.co_k_bar.p; co.k_tw = G.co_k_tw.p; co.popsize = G.co_popsize.p; co.num_active = G.co_num_active.p;
     co.status = G.status.p;
   }
-  for (int p = 0; p < P; ++p) {
-    PartHost& ph = h->parts[p];
+  for (int p = lo; p < hi; ++p) {
+    PartHost& ph = h->parts[p - lo];
     const int nc = device_coal ? num_cells_of[p] : (int)ph.coal.k_bar_p.size();
     const SlabGeo g = slab_geometry(h, me[p].n_nodes, me[p].num_muts, me[p].content_bytes, nc, ph.includes_run_root, ph.space_boost);
-    place_slab(h, (size_t)p, g, off);
-    offs[p] = ph.slab_off;
-    GPartDesc d{};
+    place_slab(h, (size_t)(p - lo), g, off);
+    offs[p - lo] = ph.slab_off;
+    GPartDesc d = desc[p];
     d.slab_bytes = g.bytes; d.heap_bytes = g.heap; d.scratch_bytes = g.scratch; d.cell_cap = g.cell_cap; d.trace_cap = trace_cap;
     d.flags = ph.includes_run_root ? k_flag_includes_run_root : 0u;
     d.rng_key = ph.rng.key; d.rng_counter = ph.rng.counter; d.rng_spare = ph.rng.spare; d.rng_has_spare = ph.rng.has_spare ? 1u : 0u;
     d.cell_first = ph.coal.cell_first; d.n_cells = nc; d.n_cells_total = ph.coal.n_cells_total; d.t_ref = ph.coal.t_ref; d.t_step = ph.coal.t_step;
-    if (device_coal) { d.cells_off = desc[p].cells_off; d.coal_first_active = first_active[p]; }
+    if (device_coal) { d.coal_first_active = first_active[p]; }
     else { d.cells_off = cells_bytes; cells_bytes += (uint64_t)nc * 32u + (((uint64_t)nc * 4u + 7u) & ~(uint64_t)7u); d.coal_first_active = ph.coal.cell_first; }
     desc[p] = d;
   }
@@ -321,8 +334,8 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
   HIP_TRY(G.desc.upload(desc.data(), (size_t)P)); HIP_TRY(G.cells.upload(cells.data(), cells.size()));
   HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
   HIP_TRY(h->d_slabs.alloc(off)); HIP_TRY(h->h_slabs.resize(off));
-  HIP_TRY(h->d_part_ticks.alloc(2 * (size_t)P)); HIP_TRY(hipMemsetAsync(h->d_part_ticks.p, 0, 2 * (size_t)P * sizeof(int64_t), h->stream));
-  HIP_TRY(h->d_part_status.alloc((size_t)P)); HIP_TRY(hipMemsetAsync(h->d_part_status.p, 0, (size_t)P * sizeof(int32_t), h->stream));
+  HIP_TRY(h->d_part_ticks.alloc(2 * (size_t)nloc)); HIP_TRY(hipMemsetAsync(h->d_part_ticks.p, 0, 2 * (size_t)nloc * sizeof(int64_t), h->stream));
+  HIP_TRY(h->d_part_status.alloc((size_t)nloc)); HIP_TRY(hipMemsetAsync(h->d_part_status.p, 0, (size_t)nloc * sizeof(int32_t), h->stream));
   if (device_coal) {
     HIP_TRY(hipMemsetAsync(G.status.p, 0, sizeof(int32_t), h->stream));
     const unsigned cell_blocks = (unsigned)co.num_cells;
@@ -332,8 +345,8 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
     hipLaunchKernelGGL(k_gt_coal_ktw, dim3(cell_blocks), dim3(k_wave), 0, h->stream, P, (const GPartDesc*)G.desc.p, co);
     HIP_TRY(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_gt_build, dim3((unsigned)P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const GMeasure*)G.measure.p, (const GPartDesc*)G.desc.p,
-                     (const uint8_t*)G.cells.p, co, h->d_slabs.p, (const uint64_t*)h->d_slab_off.p);
+  hipLaunchKernelGGL(k_gt_build, dim3((unsigned)nloc), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const GMeasure*)G.measure.p, (const GPartDesc*)G.desc.p,
+                     (const uint8_t*)G.cells.p, co, h->d_slabs.p, (const uint64_t*)h->d_slab_off.p, lo);
   HIP_TRY(hipGetLastError());
   if (device_coal) {   // a lineage outside its part's window, or a grid whose last cell no part is active in: the host builder throws on both
     int32_t cst = 0;
@@ -351,28 +364,58 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
   return EMAT_OK;
 }
 
-emat_status emat_tree_reassemble(emat_backend* h, int32_t* num_root_deltas, int32_t* site, uint8_t* from, uint8_t* to, int32_t capacity) {
-  if (!h || (capacity > 0 && (!site || !from || !to))) return EMAT_ERR_INVALID_ARGUMENT;
-  emat_status st = gt_require(h, true); if (st) return st;
+// ---- gathering the parts back: in one go (emat_tree_reassemble), or in the steps between which several processes exchange
+//      what each of them ran (emat_tree_get_root_deltas, emat_tree_gather_local, emat_tree_export_nodes / _apply_nodes, _end) ------
+}  // extern "C"
+namespace {
+
+// the heaps must keep what they hold (the nodes gathered so far) when they grow
+template <class T> emat_status gt_grow_keeping(emat_backend* h, DevBuf<T>& buf, size_t used, size_t want) {
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  if (want <= buf.n) return EMAT_OK;
+  DevBuf<T> bigger;
+  HIP_TRY(bigger.alloc(want));
+  if (used) HIP_TRY(hipMemcpy(bigger.p, buf.p, used * sizeof(T), hipMemcpyDeviceToDevice));
+  std::swap(buf.p, bigger.p); std::swap(buf.n, bigger.n);
+  return EMAT_OK;
+}
+
+emat_status gt_root_deltas(emat_backend* h, std::vector<GRootDelta>& rd, bool& owner) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   GTreeHost& G = h->gt;
-  const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
-  auto now = [] { return std::chrono::steady_clock::now(); };
-  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-  const auto t0 = now();
-  if (!G.parts_live) return fail(h, EMAT_ERR_STATE, "emat_tree_repartition first");
-  if ((int)h->parts.size() != G.P) return fail(h, EMAT_ERR_STATE, "the parts on the device are not the ones emat_tree_repartition made");
-  st = finish_pass(h); if (st) return st;          // every chain ran to completion (or was given more room and finished)
-  st = materialize(h); if (st) return st;          // (a recovery leaves the parts decoded on the host: back onto their slabs)
+  owner = G.root_part >= G.lo && G.root_part < G.hi;
+  rd.clear();
+  if (!owner) return EMAT_OK;
   HIP_TRY(G.root_deltas.alloc(k_gt_max_root_deltas)); HIP_TRY(G.n_root_deltas.alloc(1));
-  const auto t1 = now();
+  HIP_TRY(hipMemsetAsync(G.status.p, 0, sizeof(int32_t), h->stream));
+  HIP_TRY(hipMemsetAsync(G.n_root_deltas.p, 0, sizeof(int32_t), h->stream));
+  hipLaunchKernelGGL(k_gt_root_deltas, dim3(1), dim3(k_wave), 0, h->stream, (const uint8_t*)h->d_slabs.p, (const uint64_t*)h->d_slab_off.p, G.root_part - G.lo, G.root_deltas.p, G.n_root_deltas.p, G.status.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
   int32_t status = 0, nd = 0;
+  HIP_TRY(hipMemcpy(&status, G.status.p, sizeof(status), hipMemcpyDeviceToHost));
+  if (status != k_gt_ok) return fail(h, EMAT_ERR_CAPACITY, std::string("emat_tree_reassemble: ") + gt_status_text(status));
+  HIP_TRY(hipMemcpy(&nd, G.n_root_deltas.p, sizeof(nd), hipMemcpyDeviceToHost));
+  rd.resize((size_t)nd);
+  if (nd > 0) HIP_TRY(hipMemcpy(rd.data(), G.root_deltas.p, (size_t)nd * sizeof(GRootDelta), hipMemcpyDeviceToHost));
+  return EMAT_OK;
+}
+
+// every local part writes the nodes it owns into this process's copy of the tree; the heaps are rebuilt from zero
+emat_status gt_gather_local(emat_backend* h, const std::vector<GRootDelta>& rd) {
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  GTreeHost& G = h->gt;
+  const int nloc = G.hi - G.lo;
+  HIP_TRY(G.root_deltas.alloc(k_gt_max_root_deltas)); HIP_TRY(G.n_root_deltas.alloc(1)); HIP_TRY(G.root_deltas_in.alloc(k_gt_max_root_deltas));
+  if ((int)rd.size() > k_gt_max_root_deltas) return fail(h, EMAT_ERR_CAPACITY, std::string("emat_tree_reassemble: ") + gt_status_text(k_gt_root_deltas_overflow));
+  if (!rd.empty()) HIP_TRY(hipMemcpy(G.root_deltas_in.p, rd.data(), rd.size() * sizeof(GRootDelta), hipMemcpyHostToDevice));
+  int32_t status = 0;
   for (int attempt = 0;; ++attempt) {
     HIP_TRY(hipMemsetAsync(G.tops.p, 0, 3 * sizeof(uint32_t), h->stream));
     HIP_TRY(hipMemsetAsync(G.status.p, 0, sizeof(int32_t), h->stream));
     HIP_TRY(hipMemsetAsync(G.n_root_deltas.p, 0, sizeof(int32_t), h->stream));
-    hipLaunchKernelGGL(k_gt_gather, dim3((unsigned)G.P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), (const uint8_t*)h->d_slabs.p, (const uint64_t*)h->d_slab_off.p,
-                       h->d_ref.p, G.root_deltas.p, G.n_root_deltas.p, G.status.p);
+    hipLaunchKernelGGL(k_gt_gather, dim3((unsigned)nloc), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), (const uint8_t*)h->d_slabs.p, (const uint64_t*)h->d_slab_off.p,
+                       h->d_ref.p, G.root_deltas.p, G.n_root_deltas.p, G.status.p, G.lo, (const GRootDelta*)G.root_deltas_in.p, (int)rd.size());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(&status, G.status.p, sizeof(status), hipMemcpyDeviceToHost));
@@ -383,23 +426,165 @@ emat_status emat_tree_reassemble(emat_backend* h, int32_t* num_root_deltas, int3
     HIP_TRY(G.mut_heap.alloc((size_t)G.used[0] * 2 + 1024)); HIP_TRY(G.iv_heap.alloc((size_t)G.used[1] * 2 + 1024)); HIP_TRY(G.fs_heap.alloc((size_t)G.used[2] * 2 + 1024));
     ++G.heap_regrows;
   }
-  const auto t2 = now();
-  HIP_TRY(hipMemcpy(&nd, G.n_root_deltas.p, sizeof(nd), hipMemcpyDeviceToHost));
-  std::vector<GRootDelta> rd((size_t)nd);
-  if (nd > 0) HIP_TRY(hipMemcpy(rd.data(), G.root_deltas.p, (size_t)nd * sizeof(GRootDelta), hipMemcpyDeviceToHost));
-  if (nd > 0) {   // the reference sequence moved with the root sequence: its derived tables follow (the device copy of `ref` is already current)
+  if (!rd.empty()) {   // the reference sequence moved with the root sequence: its derived tables follow
     for (const GRootDelta& d : rd) h->ref[d.site] = d.to;
+    HIP_TRY(hipMemcpy(h->d_ref.p, h->ref.data(), h->ref.size(), hipMemcpyHostToDevice));
     refresh_ref_derived(h);
   }
-  const auto t3 = now();
-  st = gt_fetch_mirrors(h); if (st) return st;
-  G.parts_live = false;
-  if (verbose) fprintf(stderr, "[emat] tree_reassemble: wait for the moves + status check %.1f ms | k_gt_gather %.1f ms | root changes (%d) + reference tables %.1f ms | topology + times D2H %.1f ms\n",
-                       ms(t0, t1), ms(t1, t2), nd, ms(t2, t3), ms(t3, now()));
+  return EMAT_OK;
+}
+
+emat_status gt_reassemble_end(emat_backend* h) {
+  emat_status st = gt_fetch_mirrors(h); if (st) return st;
+  h->gt.parts_live = false;
+  return EMAT_OK;
+}
+
+emat_status gt_reassemble_begin(emat_backend* h) {
+  GTreeHost& G = h->gt;
+  if (!G.parts_live) return fail(h, EMAT_ERR_STATE, "emat_tree_repartition first");
+  if ((int)h->parts.size() != G.hi - G.lo) return fail(h, EMAT_ERR_STATE, "the parts on the device are not the ones emat_tree_repartition made");
+  emat_status st = finish_pass(h); if (st) return st;   // every chain ran to completion (or was given more room and finished)
+  return materialize(h);                                // (a recovery leaves the parts decoded on the host: back onto their slabs)
+}
+
+}  // namespace
+extern "C" {
+
+emat_status emat_tree_reassemble(emat_backend* h, int32_t* num_root_deltas, int32_t* site, uint8_t* from, uint8_t* to, int32_t capacity) {
+  if (!h || (capacity > 0 && (!site || !from || !to))) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, true); if (st) return st;
+  GTreeHost& G = h->gt;
+  const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = now();
+  if (G.parts_live && (G.lo != 0 || G.hi != G.P)) return fail(h, EMAT_ERR_STATE, "this process holds a block of the parts: the other processes' nodes must be exchanged (emat_tree_gather_local, _export_nodes, _apply_nodes, _reassemble_end)");
+  st = gt_reassemble_begin(h); if (st) return st;
+  const auto t1 = now();
+  std::vector<GRootDelta> rd; bool owner = false;
+  st = gt_root_deltas(h, rd, owner); if (st) return st;
+  st = gt_gather_local(h, rd); if (st) return st;
+  const auto t2 = now();
+  st = gt_reassemble_end(h); if (st) return st;
+  const int nd = (int)rd.size();
+  if (verbose) fprintf(stderr, "[emat] tree_reassemble: wait for the moves + status check %.1f ms | root changes (%d) + k_gt_gather + reference tables %.1f ms | topology + times D2H %.1f ms\n",
+                       ms(t0, t1), nd, ms(t1, t2), ms(t2, now()));
   if (num_root_deltas) *num_root_deltas = nd;
   if (nd > capacity) return capacity > 0 || num_root_deltas == nullptr ? fail(h, EMAT_ERR_BUFFER_TOO_SMALL, "emat_tree_reassemble: more root changes than the caller has room for (the tree itself is complete; emat_tree_download returns the reference sequence)") : EMAT_OK;
   for (int k = 0; k < nd; ++k) { site[k] = rd[k].site; from[k] = rd[k].from; to[k] = rd[k].to; }
   return EMAT_OK;
+}
+
+emat_status emat_tree_get_root_deltas(emat_backend* h, int32_t* num_root_deltas, int32_t* site, uint8_t* from, uint8_t* to, int32_t capacity) {
+  if (!h || !num_root_deltas || (capacity > 0 && (!site || !from || !to))) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, true); if (st) return st;
+  st = gt_reassemble_begin(h); if (st) return st;
+  std::vector<GRootDelta> rd; bool owner = false;
+  st = gt_root_deltas(h, rd, owner); if (st) return st;
+  *num_root_deltas = owner ? (int32_t)rd.size() : -1;
+  if ((int)rd.size() > capacity) return fail(h, EMAT_ERR_BUFFER_TOO_SMALL, "emat_tree_get_root_deltas: arrays too small");
+  for (size_t k = 0; k < rd.size(); ++k) { site[k] = rd[k].site; from[k] = rd[k].from; to[k] = rd[k].to; }
+  return EMAT_OK;
+}
+
+emat_status emat_tree_gather_local(emat_backend* h, int32_t num_root_deltas, const int32_t* site, const uint8_t* from, const uint8_t* to) {
+  if (!h || num_root_deltas < 0 || (num_root_deltas > 0 && (!site || !from || !to))) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, true); if (st) return st;
+  st = gt_reassemble_begin(h); if (st) return st;
+  std::vector<GRootDelta> rd((size_t)num_root_deltas);
+  for (int k = 0; k < num_root_deltas; ++k) { GRootDelta d{}; d.site = site[k]; d.from = from[k]; d.to = to[k]; rd[k] = d; }
+  return gt_gather_local(h, rd);
+}
+
+// buffer: { uint32 magic, uint32 n_entries, uint32 tops[3], int32 new_root, uint32 pad[2] } GNodeExport[n_entries] MutRec[tops0] IvRec[tops1] FsRec[tops2]
+emat_status emat_tree_export_nodes(emat_backend* h, uint8_t* buf, uint64_t capacity, uint64_t* bytes_needed) {
+  if (!h || !bytes_needed) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, true); if (st) return st;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  GTreeHost& G = h->gt;
+  if (!G.parts_live) return fail(h, EMAT_ERR_STATE, "emat_tree_repartition and emat_tree_gather_local first");
+  // one entry per node of every local part (k_gt_export's comment says what an entry carries)
+  std::vector<uint32_t> ids;
+  for (int p = G.lo; p < G.hi; ++p) {
+    const int b = G.h_part_off[p], np = G.h_part_off[p + 1] - b;
+    for (int s = 0; s < np; ++s) {
+      uint32_t id = (uint32_t)G.h_orig[b + s];
+      if (s != 0 || p == G.root_part) id |= k_gt_export_owns;   // (the gather made sure a part that is not the root part still has local node 0 as its root)
+      if (G.h_kid0[b + s] != EMAT_NO_NODE) id |= k_gt_export_links;
+      ids.push_back(id);
+    }
+  }
+  const uint64_t n = ids.size();
+  const uint64_t need = 32 + n * sizeof(GNodeExport) + (uint64_t)G.used[0] * sizeof(MutRec) + (uint64_t)G.used[1] * sizeof(IvRec) + (uint64_t)G.used[2] * sizeof(FsRec);
+  *bytes_needed = need;
+  if (!buf) return EMAT_OK;
+  if (capacity < need) return fail(h, EMAT_ERR_BUFFER_TOO_SMALL, "emat_tree_export_nodes: buffer too small");
+  DevBuf<uint32_t> d_ids; DevBuf<GNodeExport> d_out;
+  HIP_TRY(d_ids.upload(ids.data(), n)); HIP_TRY(d_out.alloc(n));
+  hipLaunchKernelGGL(k_gt_export, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, G.dev(), (const uint32_t*)d_ids.p, (int)n, d_out.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  uint32_t hdr[8] = {0x454E4F44u, (uint32_t)n, G.used[0], G.used[1], G.used[2], 0u, 0u, 0u};
+  int32_t new_root = EMAT_NO_NODE;
+  if (G.root_part >= G.lo && G.root_part < G.hi) HIP_TRY(hipMemcpy(&new_root, G.root.p, sizeof(new_root), hipMemcpyDeviceToHost));
+  std::memcpy(&hdr[5], &new_root, 4);
+  uint8_t* w = buf;
+  std::memcpy(w, hdr, 32); w += 32;
+  if (n) HIP_TRY(hipMemcpy(w, d_out.p, n * sizeof(GNodeExport), hipMemcpyDeviceToHost));
+  w += n * sizeof(GNodeExport);
+  if (G.used[0]) HIP_TRY(hipMemcpy(w, G.mut_heap.p, (size_t)G.used[0] * sizeof(MutRec), hipMemcpyDeviceToHost));
+  w += (size_t)G.used[0] * sizeof(MutRec);
+  if (G.used[1]) HIP_TRY(hipMemcpy(w, G.iv_heap.p, (size_t)G.used[1] * sizeof(IvRec), hipMemcpyDeviceToHost));
+  w += (size_t)G.used[1] * sizeof(IvRec);
+  if (G.used[2]) HIP_TRY(hipMemcpy(w, G.fs_heap.p, (size_t)G.used[2] * sizeof(FsRec), hipMemcpyDeviceToHost));
+  return EMAT_OK;
+}
+
+emat_status emat_tree_apply_nodes(emat_backend* h, const uint8_t* buf, uint64_t bytes) {
+  if (!h || !buf || bytes < 32) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, true); if (st) return st;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  GTreeHost& G = h->gt;
+  if (!G.parts_live) return fail(h, EMAT_ERR_STATE, "emat_tree_repartition and emat_tree_gather_local first");
+  uint32_t hdr[8]; std::memcpy(hdr, buf, 32);
+  const uint64_t n = hdr[1], m0 = hdr[2], m1 = hdr[3], m2 = hdr[4];
+  int32_t new_root; std::memcpy(&new_root, &hdr[5], 4);
+  if (hdr[0] != 0x454E4F44u || bytes != 32 + n * sizeof(GNodeExport) + m0 * sizeof(MutRec) + m1 * sizeof(IvRec) + m2 * sizeof(FsRec)) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_apply_nodes: not a buffer of emat_tree_export_nodes");
+  if (new_root != EMAT_NO_NODE && (new_root < 0 || new_root >= G.n)) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_apply_nodes: root out of range");
+  const GNodeExport* e = (const GNodeExport*)(buf + 32);
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint32_t o = e[i].node_and_flags & k_gt_export_node_mask;
+    const bool owns = (e[i].node_and_flags & k_gt_export_owns) != 0, links = (e[i].node_and_flags & k_gt_export_links) != 0;
+    if (o >= (uint32_t)G.n || (links && (e[i].c0 < 0 || e[i].c0 >= G.n || e[i].c1 < 0 || e[i].c1 >= G.n)) ||
+        (owns && ((uint64_t)e[i].muts.off + e[i].muts.cnt > m0 || (uint64_t)e[i].miss.off + e[i].miss.cnt > m1 || (uint64_t)e[i].mfs.off + e[i].mfs.cnt > m2)))
+      return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_apply_nodes: entry out of range");
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  st = gt_grow_keeping(h, G.mut_heap, G.used[0], (size_t)G.used[0] + m0 > G.mut_heap.n ? ((size_t)G.used[0] + m0) * 2 : G.mut_heap.n); if (st) return st;
+  st = gt_grow_keeping(h, G.iv_heap, G.used[1], (size_t)G.used[1] + m1 > G.iv_heap.n ? ((size_t)G.used[1] + m1) * 2 : G.iv_heap.n); if (st) return st;
+  st = gt_grow_keeping(h, G.fs_heap, G.used[2], (size_t)G.used[2] + m2 > G.fs_heap.n ? ((size_t)G.used[2] + m2) * 2 : G.fs_heap.n); if (st) return st;
+  const uint8_t* r = buf + 32 + n * sizeof(GNodeExport);
+  if (m0) HIP_TRY(hipMemcpy(G.mut_heap.p + G.used[0], r, m0 * sizeof(MutRec), hipMemcpyHostToDevice));
+  r += m0 * sizeof(MutRec);
+  if (m1) HIP_TRY(hipMemcpy(G.iv_heap.p + G.used[1], r, m1 * sizeof(IvRec), hipMemcpyHostToDevice));
+  r += m1 * sizeof(IvRec);
+  if (m2) HIP_TRY(hipMemcpy(G.fs_heap.p + G.used[2], r, m2 * sizeof(FsRec), hipMemcpyHostToDevice));
+  DevBuf<GNodeExport> d_in;
+  HIP_TRY(d_in.upload(e, n));
+  hipLaunchKernelGGL(k_gt_apply, dim3((unsigned)((n + 255) / 256 + 1)), dim3(256), 0, h->stream, G.dev(), (const GNodeExport*)d_in.p, (int)n, G.used[0], G.used[1], G.used[2], new_root);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  G.used[0] += (uint32_t)m0; G.used[1] += (uint32_t)m1; G.used[2] += (uint32_t)m2;
+  HIP_TRY(hipMemcpy(G.tops.p, G.used, sizeof(G.used), hipMemcpyHostToDevice));
+  return EMAT_OK;
+}
+
+emat_status emat_tree_reassemble_end(emat_backend* h) {
+  if (!h) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, true); if (st) return st;
+  if (!h->gt.parts_live) return fail(h, EMAT_ERR_STATE, "emat_tree_repartition first");
+  return gt_reassemble_end(h);
 }
 
 /* debugging aid (not part of the boundary): how often the cut-state pools and the list heaps had to grow */

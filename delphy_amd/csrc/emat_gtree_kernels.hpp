@@ -191,11 +191,12 @@ __global__ void __launch_bounds__(k_wave) k_gt_measure(GTreeDev g, GPartition pt
 
 // ---- pass 2: write every part's slab, byte for byte what encode_slab writes for the same part -----------------------
 __global__ void __launch_bounds__(k_wave) k_gt_build(GTreeDev g, GPartition pt, GPools pools, const GMeasure* measure, const GPartDesc* desc, const uint8_t* cells, GCoal co,
-                                                     uint8_t* slabs, const uint64_t* slab_off) {
-  const int p = blockIdx.x, lane = threadIdx.x;
+                                                     uint8_t* slabs, const uint64_t* slab_off, int part_base) {
+  // (a process that holds only the parts [part_base, part_base + gridDim.x) of the run builds only their slabs: its slab q is part part_base + q)
+  const int q = blockIdx.x, p = part_base + q, lane = threadIdx.x;
   const int base = pt.part_off[p], n = pt.part_off[p + 1] - base;
   const GPartDesc d = desc[p]; const GMeasure me = measure[p];
-  uint8_t* slab = slabs + slab_off[p];
+  uint8_t* slab = slabs + slab_off[q];
   {   // everything but the scratch tail starts out zero
     uint4* z = (uint4*)slab; const uint32_t n16 = (d.slab_bytes - d.scratch_bytes) / 16u;
     for (uint32_t i = lane; i < n16; i += k_wave) z[i] = uint4{0u, 0u, 0u, 0u};
@@ -395,18 +396,25 @@ __device__ inline uint32_t gt_rereferenced_from_states(const FsRec* fs, uint32_t
 }
 
 __global__ void __launch_bounds__(k_wave) k_gt_gather(GTreeDev g, GPartition pt, const uint8_t* slabs, const uint64_t* slab_off, uint8_t* ref,
-                                                      GRootDelta* root_deltas_out, int32_t* n_root_deltas_out, int32_t* status_out) {
+                                                      GRootDelta* root_deltas_out, int32_t* n_root_deltas_out, int32_t* status_out,
+                                                      int part_base, const GRootDelta* R_in, int nR_in) {
+  // `part_base`: slab q of this process is part part_base + q of the run.  `R_in` (or null): the changes of the root sequence,
+  // when the part that holds the run's root lives in another process (which published them); else they are read off its slab.
   __shared__ GRootDelta R[k_gt_max_root_deltas];
   __shared__ uint32_t sh_base[3];
   __shared__ int sh_nR;
-  const int p = blockIdx.x, lane = threadIdx.x;
+  const int q = blockIdx.x, p = part_base + q, lane = threadIdx.x;
   const int base = pt.part_off[p], n = pt.part_off[p + 1] - base;
-  const uint8_t* slab = slabs + slab_off[p];
+  const uint8_t* slab = slabs + slab_off[q];
   const SlabHeader* H = (const SlabHeader*)slab;
   const NodeRec* N = (const NodeRec*)(slab + H->off_nodes);
   const bool is_root_part = p == pt.root_part;
-  {
-    const uint8_t* rs = slabs + slab_off[pt.root_part];
+  if (R_in != nullptr) {
+    if (nR_in > k_gt_max_root_deltas) { if (lane == 0) atomicMax(status_out, (int32_t)k_gt_root_deltas_overflow); return; }
+    for (int k = lane; k < nR_in; k += k_wave) R[k] = R_in[k];
+    if (lane == 0) sh_nR = nR_in;
+  } else {
+    const uint8_t* rs = slabs + slab_off[pt.root_part - part_base];
     const SlabHeader* Hr = (const SlabHeader*)rs;
     const NodeRec& rn = ((const NodeRec*)(rs + Hr->off_nodes))[Hr->root];
     const int nR = rn.muts.cnt;
@@ -417,7 +425,7 @@ __global__ void __launch_bounds__(k_wave) k_gt_gather(GTreeDev g, GPartition pt,
   }
   __syncthreads();
   const int nR = sh_nR;
-  if (H->n_nodes != n) { if (lane == 0) atomicMax(status_out, (int32_t)k_gt_inconsistent); return; }
+  if (H->n_nodes != n || (!is_root_part && H->root != 0)) { if (lane == 0) atomicMax(status_out, (int32_t)k_gt_inconsistent); return; }
   const int local_root = H->root;
   // totals of the part -> its share of the three heaps
   uint32_t tm = 0, ti = 0, tf = 0;
@@ -474,6 +482,44 @@ __global__ void __launch_bounds__(k_wave) k_gt_gather(GTreeDev g, GPartition pt,
     for (int k = 0; k < nR; ++k) { ref[R[k].site] = R[k].to; root_deltas_out[k] = R[k]; }
     n_root_deltas_out[0] = nR;
   }
+}
+
+// ---- one run over several processes, every one with the whole tree in its HBM: after gathering its own parts a process
+//      hands the nodes it owns to the others (compact per-node arrays + its three heap segments) and takes theirs -------------
+__global__ void __launch_bounds__(k_wave) k_gt_root_deltas(const uint8_t* slabs, const uint64_t* slab_off, int root_slab, GRootDelta* out, int32_t* n_out, int32_t* status_out) {
+  const uint8_t* rs = slabs + slab_off[root_slab];
+  const SlabHeader* Hr = (const SlabHeader*)rs;
+  const NodeRec& rn = ((const NodeRec*)(rs + Hr->off_nodes))[Hr->root];
+  const int nR = rn.muts.cnt;
+  if (nR > k_gt_max_root_deltas) { if (threadIdx.x == 0) atomicMax(status_out, (int32_t)k_gt_root_deltas_overflow); return; }
+  const MutRec* M = (const MutRec*)(rs + rn.muts.off);
+  for (int k = threadIdx.x; k < nR; k += k_wave) { GRootDelta d{}; d.site = M[k].site; d.from = M[k].from; d.to = M[k].to; out[k] = d; }
+  if (threadIdx.x == 0) n_out[0] = nR;
+}
+// One entry per node of every part the process ran: what the part OWNS of the node (time and lists: every node but the part's
+// root, unless it is the run's root) and what it LINKS (children: every node that is inner within the part, its root
+// included).  A cut node therefore appears twice, possibly in two processes: owned by the part above, linked by the one below.
+constexpr uint32_t k_gt_export_owns = 1u << 30, k_gt_export_links = 1u << 31, k_gt_export_node_mask = (1u << 30) - 1u;
+struct GNodeExport { uint32_t node_and_flags; int32_t c0, c1, pad; double t; GList muts, miss, mfs; };   // 48 B
+__global__ void k_gt_export(GTreeDev g, const uint32_t* ids, int n, GNodeExport* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t id = ids[i]; const int32_t o = (int32_t)(id & k_gt_export_node_mask);
+  GNodeExport e{}; e.node_and_flags = id; e.c0 = g.c0[o]; e.c1 = g.c1[o]; e.t = g.t[o]; e.muts = g.muts[o]; e.miss = g.miss[o]; e.mfs = g.mfs[o];
+  out[i] = e;
+}
+// the lists of the nodes in `in` were appended to this process's heaps at bases `shift`
+__global__ void k_gt_apply(GTreeDev g, const GNodeExport* in, int n, uint32_t shift_m, uint32_t shift_i, uint32_t shift_f, int32_t new_root) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && new_root != EMAT_NO_NODE) { g.root[0] = new_root; g.parent[new_root] = EMAT_NO_NODE; }
+  if (i >= n) return;
+  const GNodeExport e = in[i];
+  const int32_t o = (int32_t)(e.node_and_flags & k_gt_export_node_mask);
+  if (e.node_and_flags & k_gt_export_owns) {
+    g.t[o] = e.t;
+    g.muts[o] = GList{e.muts.off + shift_m, e.muts.cnt}; g.miss[o] = GList{e.miss.off + shift_i, e.miss.cnt}; g.mfs[o] = GList{e.mfs.off + shift_f, e.mfs.cnt};
+  }
+  if (e.node_and_flags & k_gt_export_links) { g.c0[o] = e.c0; g.c1[o] = e.c1; g.parent[e.c0] = o; g.parent[e.c1] = o; }
 }
 
 }  // namespace emat

@@ -548,7 +548,6 @@ struct RunDriver {
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     auto t0 = now();
     if (!backend) return fail(EMAT_ERR_NO_DEVICE, "a device-resident tree needs a backend");
-    if (shard_world > 1) return fail(EMAT_ERR_STATE, "a sharded run keeps the whole tree on every host (emat_host.h)");
     if (!have_pop) return fail(EMAT_ERR_STATE, "emat_run_set_pop_model must be called first");
     emat_status st;
     if (!device_tree_uploaded) {
@@ -591,7 +590,8 @@ struct RunDriver {
     part_epoch.assign(P, 0);
     emat_pop_model pm = pop; pm.skygrid_x = sky_x.data(); pm.skygrid_gamma = sky_g.data();
     auto t3 = now();
-    st = bk(emat_tree_repartition(backend, P, part_off.data(), orig.data(), kid0.data(), kid1.data(), root_part, part_seeds.data(), &pm, t_step_set ? t_step : default_t_step()));
+    // (a sharded run: every process has the whole tree in its HBM and cuts it identically; it builds the slabs of its own block of parts only)
+    st = bk(emat_tree_repartition_range(backend, P, part_off.data(), orig.data(), kid0.data(), kid1.data(), root_part, part_seeds.data(), &pm, t_step_set ? t_step : default_t_step(), part_lo, part_hi));
     if (st) return st;
     parts_uploaded = true; coal_built = true; host_tree_stale = true;
     if (verbose) fprintf(stderr, "[emat_run] repartition (device tree): upload / topology %.1f ms | stencil + partition_tree %.1f ms | flatten %.1f ms | emat_tree_repartition %.1f ms\n",
@@ -600,6 +600,7 @@ struct RunDriver {
   }
   emat_status reassemble_device() {
     if (!parts_uploaded) return fail(EMAT_ERR_STATE, "repartition first");
+    if (shard_world > 1) return fail(EMAT_ERR_STATE, "a sharded run with the tree on the devices gathers in steps, with the exchange between them (emat_tree_get_root_deltas ... emat_tree_reassemble_end, then emat_run_note_device_reassembled)");
     int32_t nd = 0; int32_t site[256]; uint8_t from[256], to[256];
     emat_status st = bk(emat_tree_reassemble(backend, &nd, site, from, to, 256)); if (st) return st;
     for (int k = 0; k < nd; ++k) ref[site[k]] = to[k];
@@ -763,7 +764,6 @@ emat_status emat_run_set_device_tree(emat_run* r, int32_t on) {
   RunDriver& d = r->d;
   if (on) {
     if (!d.backend) return d.fail(EMAT_ERR_NO_DEVICE, "a device-resident tree needs a backend");
-    if (d.shard_world > 1) return d.fail(EMAT_ERR_STATE, "a sharded run keeps the whole tree on every host");
     if (d.parts_uploaded) return d.fail(EMAT_ERR_STATE, "reassemble first");
     d.device_tree = true; d.device_tree_uploaded = false;   // uploaded at the next repartition
     return EMAT_OK;
@@ -773,6 +773,14 @@ emat_status emat_run_set_device_tree(emat_run* r, int32_t on) {
     emat_status st = d.ensure_host_tree(); if (st) return st;
     d.device_tree = false; d.device_tree_uploaded = false;
   }
+  return EMAT_OK;
+}
+emat_status emat_run_note_device_reassembled(emat_run* r, int32_t num_root_deltas, const int32_t* site, const uint8_t* to) {
+  if (!r || num_root_deltas < 0 || (num_root_deltas > 0 && (!site || !to))) return EMAT_ERR_INVALID_ARGUMENT;
+  RunDriver& d = r->d;
+  if (!d.device_tree || !d.parts_uploaded) return d.fail(EMAT_ERR_STATE, "no device-resident parts are out");
+  for (int k = 0; k < num_root_deltas; ++k) { if (site[k] < 0 || site[k] >= d.L || to[k] > 3) return EMAT_ERR_INVALID_ARGUMENT; d.ref[site[k]] = to[k]; }
+  d.parts_uploaded = false; d.host_tree_stale = true;
   return EMAT_OK;
 }
 emat_status emat_run_repartition(emat_run* r) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; return r->d.repartition(); }
@@ -852,7 +860,7 @@ emat_status emat_run_moves_sharded(emat_run* r, int64_t count) {   // Run::run_l
   RunDriver& d = r->d;
   if (!d.backend) return d.fail(EMAT_ERR_NO_DEVICE, "no backend attached: the host driver never runs moves itself");
   if (!d.parts_uploaded) return d.fail(EMAT_ERR_STATE, "repartition first");
-  const int64_t P = (int64_t)d.subtrees.size(), sub = count / P, rem = count - P * sub;
+  const int64_t P = (int64_t)d.parts.size(), sub = count / P, rem = count - P * sub;
   // the remainder is spread one move per part over the first parts of the run (see emat_run_moves_even)
   return d.bk(emat_run_moves_even(d.backend, sub, (int32_t)std::max<int64_t>(0, std::min<int64_t>(rem - d.part_lo, d.part_hi - d.part_lo))));
 }

@@ -264,6 +264,10 @@ def load_library():
         "emat_tree_get_topology": [B, P(i32), P(i32), P(i32), P(dbl), P(i32)],
         "emat_tree_repartition": [B, i32, P(i32), P(i32), P(i32), P(i32), i32, P(u64), P(_PopModelC), dbl],
         "emat_tree_reassemble": [B, P(i32), P(i32), P(C.c_uint8), P(C.c_uint8), i32],
+        "emat_tree_repartition_range": [B, i32, P(i32), P(i32), P(i32), P(i32), i32, P(u64), P(_PopModelC), dbl, i32, i32],
+        "emat_tree_get_root_deltas": [B, P(i32), P(i32), P(C.c_uint8), P(C.c_uint8), i32], "emat_tree_gather_local": [B, i32, P(i32), P(C.c_uint8), P(C.c_uint8)],
+        "emat_tree_export_nodes": [B, P(C.c_uint8), u64, P(u64)], "emat_tree_apply_nodes": [B, P(C.c_uint8), u64], "emat_tree_reassemble_end": [B],
+        "emat_run_note_device_reassembled": [R, i32, P(i32), P(C.c_uint8)],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -453,6 +457,31 @@ class EmatBackend:
         self._ck(self._lib.emat_tree_reassemble(self._h, C.byref(n), _ptr(site, C.c_int32), _ptr(frm, C.c_uint8), _ptr(to, C.c_uint8), capacity), "emat_tree_reassemble")
         k = n.value
         return site[:k].copy(), frm[:k].copy(), to[:k].copy()
+
+    def tree_root_deltas(self, capacity: int = 256):
+        """(site, from, to) on the process that holds the root part, None elsewhere."""
+        n = C.c_int32()
+        site = np.zeros(capacity, np.int32); frm = np.zeros(capacity, np.uint8); to = np.zeros(capacity, np.uint8)
+        self._ck(self._lib.emat_tree_get_root_deltas(self._h, C.byref(n), _ptr(site, C.c_int32), _ptr(frm, C.c_uint8), _ptr(to, C.c_uint8), capacity), "emat_tree_get_root_deltas")
+        return None if n.value < 0 else (site[:n.value].copy(), frm[:n.value].copy(), to[:n.value].copy())
+
+    def tree_gather_local(self, site, frm, to):
+        site = np.ascontiguousarray(site, np.int32); frm = np.ascontiguousarray(frm, np.uint8); to = np.ascontiguousarray(to, np.uint8)
+        self._ck(self._lib.emat_tree_gather_local(self._h, int(site.shape[0]), _ptr(site, C.c_int32), _ptr(frm, C.c_uint8), _ptr(to, C.c_uint8)), "emat_tree_gather_local")
+
+    def tree_export_nodes(self) -> np.ndarray:
+        need = C.c_uint64()
+        self._ck(self._lib.emat_tree_export_nodes(self._h, None, 0, C.byref(need)), "emat_tree_export_nodes")
+        buf = np.zeros(int(need.value), np.uint8)
+        self._ck(self._lib.emat_tree_export_nodes(self._h, _ptr(buf, C.c_uint8), buf.shape[0], C.byref(need)), "emat_tree_export_nodes")
+        return buf
+
+    def tree_apply_nodes(self, buf: np.ndarray):
+        buf = np.ascontiguousarray(buf, np.uint8)
+        self._ck(self._lib.emat_tree_apply_nodes(self._h, _ptr(buf, C.c_uint8), buf.shape[0]), "emat_tree_apply_nodes")
+
+    def tree_reassemble_end(self):
+        self._ck(self._lib.emat_tree_reassemble_end(self._h), "emat_tree_reassemble_end")
 
     def tree_download(self):
         n, nm, ni, nf = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -737,6 +766,10 @@ class EmatRun:
     def set_device_tree(self, on: bool = True):
         """keep the authoritative tree in HBM; cycles then move only the partition and the topology."""
         self._ck(self._lib.emat_run_set_device_tree(self._h, int(on)), "emat_run_set_device_tree")
+
+    def note_device_reassembled(self, site, to):
+        site = np.ascontiguousarray(site, np.int32); to = np.ascontiguousarray(to, np.uint8)
+        self._ck(self._lib.emat_run_note_device_reassembled(self._h, int(site.shape[0]), _ptr(site, C.c_int32), _ptr(to, C.c_uint8)), "emat_run_note_device_reassembled")
 
     def do_mcmc_steps(self, steps: int, local_moves_per_cycle: int = -1):
         self._ck(self._lib.emat_run_do_mcmc_steps(self._h, steps, local_moves_per_cycle), "emat_run_do_mcmc_steps")

@@ -57,7 +57,7 @@ def _torch_collectives(device: str):
 class ShardedEngine:
     def __init__(self, sc: Scenario, num_parts: int, seed: int, rank: int = 0, world: int = 1, device: int = 0, use_lds: bool = True,
                  allreduce: Optional[Callable[[np.ndarray, str], np.ndarray]] = None, trace_moves: int = 0, t_step: Optional[float] = None,
-                 max_part_nodes: int = 0, allgather_bytes: Optional[Callable[[np.ndarray], List[np.ndarray]]] = None):
+                 max_part_nodes: int = 0, allgather_bytes: Optional[Callable[[np.ndarray], List[np.ndarray]]] = None, device_tree: bool = False):
         self.sc, self.num_parts_requested, self.seed, self.rank, self.world = sc, num_parts, seed, rank, world
         self.t_step = t_step if t_step is not None else sc.default_t_step()
         if world == 1:
@@ -76,6 +76,7 @@ class ShardedEngine:
         self.topology = True
         self.only_displace = False
         self.max_part_nodes = max_part_nodes   # not in the reference: cut larger parts further (0 = the reference's rule)
+        self.device_tree = device_tree         # every rank keeps the whole tree in its HBM; ranks exchange node updates, not part trees
         self._configured = False
 
     def close(self):
@@ -91,6 +92,8 @@ class ShardedEngine:
         run.set_coalescent_t_step(self.t_step)
         run.set_flags(self.only_displace, self.topology)
         run.set_shard(self.rank, self.world)
+        if self.device_tree:
+            run.set_device_tree(True)
         self._configured = True
 
     def repartition(self):
@@ -101,12 +104,13 @@ class ShardedEngine:
         self.total_parts, self.root_part = self.run.num_parts()
         self.part_lo, self.part_hi, self.local_root = self.run.shard_range()
         self.num_local_parts = self.part_hi - self.part_lo
-        self.build_coalescent()
+        if not self.device_tree:      # (with the tree on the devices every rank builds the whole grid itself, identically: no exchange)
+            self.build_coalescent()
 
     def setup(self):
         """First cut + upload (what bench.py and the probes call before timing resident passes)."""
         self.repartition()
-        self.local_sizes = [self.run.part(self.part_lo + p)[0].num_nodes for p in range(self.num_local_parts)]
+        self.local_sizes = [self.backend.part_stats(p)["num_nodes"] if self.device_tree else self.run.part(self.part_lo + p)[0].num_nodes for p in range(self.num_local_parts)]
 
     def build_coalescent(self):
         """very_scalable_coalescent.cpp:85-232 with its three cross-part reductions done as all-reduces."""
@@ -126,6 +130,24 @@ class ShardedEngine:
 
     def reassemble(self):
         """Every rank receives every other rank's parts and gathers the same whole tree (reference run.cpp:195-256)."""
+        if self.device_tree and self.world > 1:
+            # the trees stay on the devices: the rank with the root part publishes how the root sequence changed, every rank gathers
+            # its own parts into its own copy of the tree, and the ranks exchange what their parts own (include/emat_backend.h)
+            b = self.backend
+            rd = b.tree_root_deltas()
+            mine = np.zeros(0, np.uint8) if rd is None else np.concatenate([np.array([len(rd[0])], np.int32).view(np.uint8), rd[0].view(np.uint8), rd[1], rd[2]])
+            owner = [g for g in self.allgather_bytes(mine) if g.shape[0] > 0]
+            assert len(owner) == 1, "exactly one rank holds the root part"
+            k = int(owner[0][:4].view(np.int32)[0])
+            site = owner[0][4:4 + 4 * k].view(np.int32).copy(); frm = owner[0][4 + 4 * k:4 + 5 * k].copy(); to = owner[0][4 + 5 * k:4 + 6 * k].copy()
+            b.tree_gather_local(site, frm, to)
+            exported = b.tree_export_nodes()
+            for r, buf in enumerate(self.allgather_bytes(exported)):
+                if r != self.rank:
+                    b.tree_apply_nodes(buf)
+            b.tree_reassemble_end()
+            self.run.note_device_reassembled(site, to)
+            return
         if self.world > 1:
             mine = self.run.pack_local_parts()
             for r, buf in enumerate(self.allgather_bytes(mine)):

@@ -213,6 +213,25 @@ emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int3
 /* `site` / `from` / `to` [capacity] receive the changes of the reference sequence (old state, new state); any of the
  * output arguments may be NULL / 0 when the caller reads the sequence through emat_tree_download instead. */
 emat_status emat_tree_reassemble(emat_backend* h, int32_t* num_root_deltas, int32_t* site, uint8_t* from, uint8_t* to, int32_t capacity);
+/* One run over several processes, one GPU each, EVERY one with the whole tree in its HBM (the tree is a few tens of MB; what
+ * is worth sharding is the moves).  Every process cuts the same partition and calls emat_tree_repartition_range with its own
+ * block [part_lo, part_hi) of the parts (backend part id = part - part_lo): the sequence states at the cut points and the
+ * coalescent grid are computed for the whole run by every process -- identically, no exchange -- and only the slabs of the
+ * block are built.  After the moves:
+ *   emat_tree_get_root_deltas     on the process that holds the root part (*num_root_deltas = -1 elsewhere); the caller
+ *                                 hands the result to every process
+ *   emat_tree_gather_local        every process: its own parts back into its copy of the tree (heaps rebuilt from zero)
+ *   emat_tree_export_nodes        every process: what its parts own and link, as one buffer (buf = NULL: size only)
+ *   emat_tree_apply_nodes         every process, once per OTHER process's buffer (an all-gather, the caller's)
+ *   emat_tree_reassemble_end      every process: mirrors refreshed; every copy of the tree holds the same nodes again
+ * (lists sit at different heap offsets in different processes, which nothing depends on). */
+emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, const int32_t* part_offset, const int32_t* orig, const int32_t* kid0, const int32_t* kid1,
+                                        int32_t root_part, const uint64_t* seeds, const emat_pop_model* pop_model, double t_step, int32_t part_lo, int32_t part_hi);
+emat_status emat_tree_get_root_deltas(emat_backend* h, int32_t* num_root_deltas, int32_t* site, uint8_t* from, uint8_t* to, int32_t capacity);
+emat_status emat_tree_gather_local(emat_backend* h, int32_t num_root_deltas, const int32_t* site, const uint8_t* from, const uint8_t* to);
+emat_status emat_tree_export_nodes(emat_backend* h, uint8_t* buf, uint64_t capacity, uint64_t* bytes_needed);
+emat_status emat_tree_apply_nodes(emat_backend* h, const uint8_t* buf, uint64_t bytes);
+emat_status emat_tree_reassemble_end(emat_backend* h);
 
 /* Forces the from-scratch recomputation that Subrun::validate_derived_quantities() performs
  * after set_evo / set_coalescent_prior_part (reference subrun.cpp:17-26).  Called implicitly

@@ -75,8 +75,13 @@ emat_status emat_run_set_flags(emat_run* r, int32_t only_displacing_inner_nodes,
  * the stencil on the topology and calls emat_tree_repartition, emat_run_reassemble calls emat_tree_reassemble (which also
  * does Run::normalize_root's work).  emat_run_tree_get / emat_run_tree_sizes download the tree when asked;
  * emat_run_part_* (host copies of the parts) are not available.  Same seeds, same partitions, same trees as the host
- * cycle, bit for bit.  `on` = 0 brings the tree back to the host.  Single-process runs only. */
+ * cycle, bit for bit.  `on` = 0 brings the tree back to the host. */
 emat_status emat_run_set_device_tree(emat_run* r, int32_t on);
+/* A sharded run with the tree on the devices: emat_run_repartition cuts every process's own block of parts out of its own
+ * copy of the tree (emat_tree_repartition_range); the gather goes through the backend's staged calls with the caller's
+ * exchange between them (emat_backend.h: emat_tree_get_root_deltas ... emat_tree_reassemble_end; delphy_amd/sharding.py),
+ * after which this tells the driver that the parts are back and which sites of the reference sequence changed. */
+emat_status emat_run_note_device_reassembled(emat_run* r, int32_t num_root_deltas, const int32_t* site, const uint8_t* to);
 /* Cut the tree into parts and (when a backend is attached) upload them and build their coalescent parts. */
 emat_status emat_run_repartition(emat_run* r);
 emat_status emat_run_num_parts(emat_run* r, int32_t* num_parts, int32_t* root_part_index);

@@ -201,7 +201,7 @@ def test_c5_whole_cycles_with_the_tree_resident_in_hbm():
         run.close(); b.close()
 
 
-def _sharded_gpu_worker(rank, world, port, out_dir, cycles, moves):
+def _sharded_gpu_worker(rank, world, port, out_dir, cycles, moves, device_tree=False):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -210,7 +210,7 @@ def _sharded_gpu_worker(rank, world, port, out_dir, cycles, moves):
     from test_sharding_gloo import gloo_collectives, _tree_fields
     allreduce, allgather_bytes = gloo_collectives()
     sc = make_scenario("C3", num_tips=1500, num_sites=29903, uncertain_tips=0.1)
-    eng = ShardedEngine(sc, num_parts=48, seed=97, rank=rank, world=world, device=0, allreduce=allreduce, allgather_bytes=allgather_bytes)
+    eng = ShardedEngine(sc, num_parts=48, seed=97, rank=rank, world=world, device=0, allreduce=allreduce, allgather_bytes=allgather_bytes, device_tree=device_tree)
     res = {}
     for cyc in range(cycles):
         G, A = eng.cycle(moves)
@@ -261,4 +261,29 @@ def test_two_process_cycles_on_one_gpu_match_the_single_process_run(tmp_path):
         assert rel_close(z[r]["grid_prior"], np.array([grid]), 1e-9)
     for k in _tree_fields(t):
         assert np.array_equal(z[0][k], z[1][k]), k       # the two ranks hold bit-identical trees
+    single.close()
+
+
+def test_two_process_cycles_with_the_tree_on_the_devices(tmp_path):
+    """The same two processes with the whole tree resident in each one's HBM (SURVEY 8(f).2 + 8(e)): every rank cuts its own
+    block of parts out of its own copy, and after the moves the ranks exchange node updates -- what their parts own and link --
+    instead of part trees.  Chains, seeds and kernels are those of the single-process run with the tree in HBM, so both
+    ranks must end with exactly its tree and reference sequence, cycle totals included."""
+    import torch.multiprocessing as mp
+    from test_sharding_gloo import _tree_fields
+    cycles, moves = 3, 48 * 400
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_sharded_gpu_worker, args=(2, port, str(tmp_path), cycles, moves, True), nprocs=2, join=True)
+    z = [np.load(os.path.join(str(tmp_path), "gpu_rank%d.npz" % r)) for r in range(2)]
+    sc = make_scenario("C3", num_tips=1500, num_sites=29903, uncertain_tips=0.1)
+    single = ShardedEngine(sc, num_parts=48, seed=97, device_tree=True)
+    tot = [single.cycle(moves) for _ in range(cycles)]
+    t, ref = single.tree()
+    assert not np.array_equal(t.parent, sc.tree.parent)
+    for r in range(2):
+        assert int(z[r]["root"][0]) == t.root and np.array_equal(z[r]["ref"], ref)
+        for k, v in _tree_fields(t).items():
+            assert np.array_equal(z[r][k], v), (r, k)
+        for cyc in range(cycles):
+            assert rel_close(z[r]["c%d_totals" % cyc], np.array(tot[cyc]), 1e-9), (r, cyc)
     single.close()
