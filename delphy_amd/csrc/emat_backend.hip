@@ -653,13 +653,14 @@ struct GTreeHost {
   DevBuf<int32_t> parent, c0, c1, root; DevBuf<double> t; DevBuf<float> t_min, t_max; DevBuf<GList> muts, miss, mfs;
   DevBuf<MutRec> mut_heap; DevBuf<IvRec> iv_heap; DevBuf<FsRec> fs_heap; DevBuf<uint32_t> tops; DevBuf<int32_t> status;
   uint32_t used[3] = {0, 0, 0};     // records in use in the three heaps
-  int32_t pool_regrows = 0, heap_regrows = 0;
+  int32_t pool_regrows = 0, heap_regrows = 0, large_measures = 0;
   // current partition
   int32_t P = 0, root_part = -1, lo = 0, hi = 0;   // this process runs the parts [lo, hi) of the partition
   std::vector<int32_t> h_part_off, h_orig, h_kid0;
   DevBuf<GRootDelta> root_deltas_in;
   DevBuf<int32_t> part_off, orig, kid0, kid1, lpar;
   DevBuf<double> co_kbar, co_ktw, co_k_bar, co_k_tw, co_popsize; DevBuf<int32_t> co_num_active;   // the coalescent grid, when it is built on the device
+  DevBuf<int32_t> measure_list;
   DevBuf<GMeasure> measure; DevBuf<MutRec> pool_muts; DevBuf<IvRec> pool_ivs; DevBuf<uint32_t> pool_tops;
   DevBuf<GPartDesc> desc; DevBuf<uint8_t> cells;
   DevBuf<GRootDelta> root_deltas; DevBuf<int32_t> n_root_deltas;

@@ -210,7 +210,14 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
   const auto t1 = now();
   auto launch_measure = [&]() -> emat_status {
     HIP_TRY(hipMemsetAsync(G.pool_tops.p, 0, 2 * sizeof(uint32_t), h->stream));
-    hipLaunchKernelGGL(k_gt_measure, dim3((unsigned)P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const uint8_t*)h->d_ref.p, G.measure.p);
+    hipLaunchKernelGGL((k_gt_measure<k_gt_small_cut_intervals, k_gt_small_cut_deltas>), dim3((unsigned)P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const uint8_t*)h->d_ref.p, G.measure.p, (const int32_t*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return EMAT_OK;
+  };
+  // the parts whose cut-point state did not fit the small kernel's LDS: once more, with the full capacities
+  auto remeasure_large = [&](const std::vector<int32_t>& list) -> emat_status {
+    HIP_TRY(G.measure_list.upload(list.data(), list.size()));
+    hipLaunchKernelGGL((k_gt_measure<k_gt_max_cut_intervals, k_gt_max_cut_deltas>), dim3((unsigned)list.size()), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const uint8_t*)h->d_ref.p, G.measure.p, (const int32_t*)G.measure_list.p);
     HIP_TRY(hipGetLastError());
     return EMAT_OK;
   };
@@ -252,9 +259,20 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
   h->have_coal = true;
   const auto t3 = now();
   std::vector<GMeasure> me(P);
+  bool large_done = false;
   for (int attempt = 0;; ++attempt) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(me.data(), G.measure.p, (size_t)P * sizeof(GMeasure), hipMemcpyDeviceToHost));
+    {
+      std::vector<int32_t> large;
+      for (int p = 0; p < P; ++p) if (me[p].status == k_gt_cut_state_overflow) large.push_back(p);
+      if (!large.empty() && !large_done) {
+        large_done = true; G.large_measures += (int32_t)large.size();
+        st = remeasure_large(large); if (st) return st;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpy(me.data(), G.measure.p, (size_t)P * sizeof(GMeasure), hipMemcpyDeviceToHost));
+      }
+    }
     int32_t worst = k_gt_ok; int who = -1;
     for (int p = 0; p < P; ++p) if (me[p].status != k_gt_ok && (worst == k_gt_ok || me[p].status != k_gt_pool_overflow)) { worst = me[p].status; who = p; if (worst != k_gt_pool_overflow) break; }
     if (worst == k_gt_ok) break;
@@ -263,7 +281,7 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
     uint32_t tops[2];
     HIP_TRY(hipMemcpy(tops, G.pool_tops.p, sizeof(tops), hipMemcpyDeviceToHost));   // the atomics kept counting: what the pools need
     HIP_TRY(G.pool_muts.alloc((size_t)tops[0] * 2 + 4096)); HIP_TRY(G.pool_ivs.alloc((size_t)tops[1] * 2 + 4096));
-    ++G.pool_regrows;
+    ++G.pool_regrows; large_done = false;
     st = launch_measure(); if (st) return st;
   }
   const auto t4 = now();
@@ -588,9 +606,9 @@ emat_status emat_tree_reassemble_end(emat_backend* h) {
 }
 
 /* debugging aid (not part of the boundary): how often the cut-state pools and the list heaps had to grow */
-emat_status emat_debug_tree_counters(emat_backend* h, int32_t* out2) {
-  if (!h || !out2) return EMAT_ERR_INVALID_ARGUMENT;
-  out2[0] = h->gt.pool_regrows; out2[1] = h->gt.heap_regrows;
+emat_status emat_debug_tree_counters(emat_backend* h, int32_t* out3) {
+  if (!h || !out3) return EMAT_ERR_INVALID_ARGUMENT;
+  out3[0] = h->gt.pool_regrows; out3[1] = h->gt.heap_regrows; out3[2] = h->gt.large_measures;
   return EMAT_OK;
 }
 

@@ -66,8 +66,8 @@ struct GCoal {                       // the whole grid, built on the device (nul
   int32_t* status;
 };
 
-constexpr int k_gt_max_cut_intervals = 1024;
-constexpr int k_gt_max_cut_deltas = 1024;
+constexpr int k_gt_max_cut_intervals = 1024, k_gt_small_cut_intervals = 256;
+constexpr int k_gt_max_cut_deltas = 1024, k_gt_small_cut_deltas = 256;
 constexpr int k_gt_max_root_deltas = 256;
 constexpr uint32_t k_gt_max_list = 16000;   // ListRef counts are 16 bits (same limit as emat_part_upload)
 
@@ -93,12 +93,16 @@ __device__ inline uint32_t wave_sum_u32(uint32_t x) {
 // further one; entries that end with from == to cancel.
 struct GCutDelta { int32_t site; uint8_t from, to; uint16_t pad; };
 
-__global__ void __launch_bounds__(k_wave) k_gt_measure(GTreeDev g, GPartition pt, GPools pools, const uint8_t* ref, GMeasure* out) {
-  __shared__ IvRec acc[2][k_gt_max_cut_intervals];
-  __shared__ GCutDelta dl[k_gt_max_cut_deltas];
+// Compiled twice: with room for a few hundred intervals and changes (6 KB of LDS: 26 workgroups per CU -- what bounds the kernel
+// is how many pointer chases are in flight) for all parts, and with the full capacities for the parts that overflowed it
+// (`part_list`, or null for all parts).
+template <int kMaxIv, int kMaxDl>
+__global__ void __launch_bounds__(k_wave) k_gt_measure(GTreeDev g, GPartition pt, GPools pools, const uint8_t* ref, GMeasure* out, const int32_t* part_list) {
+  __shared__ IvRec acc[2][kMaxIv];
+  __shared__ GCutDelta dl[kMaxDl];
   __shared__ int sh[4];
   __shared__ uint32_t sh_off[2];
-  const int p = blockIdx.x, lane = threadIdx.x;
+  const int p = part_list ? part_list[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
   const int base = pt.part_off[p], n = pt.part_off[p + 1] - base;
   if (lane == 0) {
     int status = k_gt_ok, cur_buf = 0, n_acc = 0, n_dl = 0;
@@ -113,9 +117,9 @@ __global__ void __launch_bounds__(k_wave) k_gt_measure(GTreeDev g, GPartition pt
           const IvRec f = useA ? A[ia] : B[ib];
           if (!inside) { cs = f.start; ce = f.end; if (useA) ++ia; else ++ib; inside = true; }
           else if (f.start <= ce) { ce = f.end > ce ? f.end : ce; if (useA) ++ia; else ++ib; }
-          else { if (no >= k_gt_max_cut_intervals) { status = k_gt_cut_state_overflow; break; } O[no++] = IvRec{cs, ce}; inside = false; }
+          else { if (no >= kMaxIv) { status = k_gt_cut_state_overflow; break; } O[no++] = IvRec{cs, ce}; inside = false; }
         }
-        if (inside) { if (no >= k_gt_max_cut_intervals) status = k_gt_cut_state_overflow; else O[no++] = IvRec{cs, ce}; }
+        if (inside) { if (no >= kMaxIv) status = k_gt_cut_state_overflow; else O[no++] = IvRec{cs, ce}; }
         cur_buf ^= 1; n_acc = no;
       }
       if (cur != tree_root) {   // what the root node carries are not events (they are folded into the reference at every gather)
@@ -125,7 +129,7 @@ __global__ void __launch_bounds__(k_wave) k_gt_measure(GTreeDev g, GPartition pt
           int lo = 0, hi = n_dl;
           while (lo < hi) { int mid = (lo + hi) >> 1; if (dl[mid].site < m.site) lo = mid + 1; else hi = mid; }
           if (lo < n_dl && dl[lo].site == m.site) { if (dl[lo].from != m.to) status = k_gt_inconsistent; dl[lo].from = m.from; }
-          else if (n_dl >= k_gt_max_cut_deltas) status = k_gt_cut_state_overflow;
+          else if (n_dl >= kMaxDl) status = k_gt_cut_state_overflow;
           else { for (int j = n_dl; j > lo; --j) dl[j] = dl[j - 1]; dl[lo] = GCutDelta{m.site, m.from, m.to, 0}; ++n_dl; }
         }
       } else if (mu.cnt != 0) status = k_gt_inconsistent;

@@ -494,10 +494,11 @@ class EmatBackend:
         return t.trimmed(), ref
 
     def tree_counters(self):
-        """(growths of the cut-state pools, growths of the list heaps) of the HBM-resident tree: testing aid."""
-        out = np.zeros(2, np.int32)
+        """(growths of the cut-state pools, growths of the list heaps, cut-point states that needed the large kernel) of the
+        HBM-resident tree: testing aid."""
+        out = np.zeros(3, np.int32)
         self._ck(self._lib.emat_debug_tree_counters(self._h, _ptr(out, C.c_int32)), "emat_debug_tree_counters")
-        return int(out[0]), int(out[1])
+        return int(out[0]), int(out[1]), int(out[2])
 
     def run_moves_even(self, moves_per_part: int, one_more_below: int):
         """`moves_per_part` moves on every part, one more on the parts [0, one_more_below) (not the reference's remainder rule)."""

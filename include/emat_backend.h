@@ -350,9 +350,10 @@ emat_status emat_debug_pop(emat_backend* h, const emat_pop_model* pop_model, int
  * op 1 merge, 2 intersect, 3 subtract -> pairs in `out` (room for na + nb + 1 pairs), *n_out = their number; op 5 contains
  * (site b[0]), 6 sets intersect -> *n_out = 0 / 1. */
 emat_status emat_debug_interval_op(emat_backend* h, int32_t op, const int32_t* a, int32_t na, const int32_t* b, int32_t nb, int32_t* out, int32_t* n_out);
-/* How often the cut-state pools (out2[0]) and the list heaps (out2[1]) of the HBM-resident tree had to grow; with
- * EMAT_TREE_TIGHT set in the environment they start without any room, so that tests reach those paths. */
-emat_status emat_debug_tree_counters(emat_backend* h, int32_t* out2);
+/* How often the cut-state pools (out3[0]) and the list heaps (out3[1]) of the HBM-resident tree had to grow (with
+ * EMAT_TREE_TIGHT set in the environment they start without any room, so that tests reach those paths), and how many
+ * cut-point states needed the large variant of k_gt_measure (out3[2]). */
+emat_status emat_debug_tree_counters(emat_backend* h, int32_t* out3);
 
 #ifdef __cplusplus
 }

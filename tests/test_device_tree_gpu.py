@@ -206,7 +206,7 @@ def test_pools_and_heaps_grow_when_they_run_out(monkeypatch):
         th, refh = rh.tree(); td, refd = rd.tree()
         _same_tree(th, td, "cycle %d" % cycle)
         assert np.array_equal(refh, refd), cycle
-    pool_regrows, heap_regrows = bd.tree_counters()
+    pool_regrows, heap_regrows, _ = bd.tree_counters()
     assert pool_regrows >= 1 and heap_regrows >= 1, (pool_regrows, heap_regrows)
     for r in (rh, rd): r.close()
     for b in (bh, bd): b.close()
@@ -371,3 +371,24 @@ def test_the_c_abi_of_the_resident_tree_directly():
     with pytest.raises(d.EmatError, match="EMAT_ERR_STATE"):
         bd.tree_reassemble()                  # nothing is out on slabs any more
     bd.close(); bh.close()
+
+
+def test_cut_point_states_larger_than_the_small_kernel_holds():
+    """A fast-evolving genome: the path from the root to a cut point carries hundreds of mutations, more net changes than the
+    LDS of the first k_gt_measure pass holds; those parts go through its large variant, and the cycles still equal the host's."""
+    from delphy_amd.engine import SynthParams, make_synthetic_emat
+    from delphy_amd.scenarios import Scenario, PI, KAPPA
+    p = SynthParams(num_tips=400, num_sites=12000, tip_span=365.0, pop_n0=365.0, pop_growth=0.0, mu=5e-3 / 365.0, gaps_per_tip=2, mean_gap_len=60.0, seed=20261099)
+    p.pi = PI; p.kappa = KAPPA
+    tree, ref, tmax = make_synthetic_emat(p)
+    sc = Scenario("hot", tree, ref, tmax, p.mu, p.kappa, PI, d.PopModel.exp(tmax, 365.0, 0.0, 0.0), p.num_sites)
+    bh, rh = _run(sc, 29, 12, False)
+    bd, rd = _run(sc, 29, 12, True)
+    for cycle in range(2):
+        rh.do_mcmc_steps(12 * 600, 12 * 600); rd.do_mcmc_steps(12 * 600, 12 * 600)
+        th, refh = rh.tree(); td, refd = rd.tree()
+        _same_tree(th, td, "cycle %d" % cycle)
+        assert np.array_equal(refh, refd), cycle
+    assert bd.tree_counters()[2] >= 1, "no cut-point state outgrew the small kernel: the test does not reach the large one (%d mutations on the tree)" % tree.mut_offset[-1]
+    for r in (rh, rd): r.close()
+    for b in (bh, bd): b.close()
