@@ -656,7 +656,9 @@ struct GTreeHost {
   int32_t pool_regrows = 0, heap_regrows = 0, large_measures = 0;
   // current partition
   int32_t P = 0, root_part = -1, lo = 0, hi = 0;   // this process runs the parts [lo, hi) of the partition
-  std::vector<int32_t> h_part_off, h_orig, h_kid0;
+  std::vector<int32_t> h_part_off, h_orig, h_kid0, h_kid1;   // host copies (h_orig / h_kid* only when the partition came from the host or was asked for)
+  bool partition_on_device = false;   // made by emat_tree_partition
+  DevBuf<int32_t> lidx;
   DevBuf<GRootDelta> root_deltas_in;
   DevBuf<int32_t> part_off, orig, kid0, kid1, lpar;
   DevBuf<double> co_kbar, co_ktw, co_k_bar, co_k_tw, co_popsize; DevBuf<int32_t> co_num_active;   // the coalescent grid, when it is built on the device

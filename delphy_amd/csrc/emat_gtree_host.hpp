@@ -146,13 +146,86 @@ emat_status emat_tree_get_topology(emat_backend* h, int32_t* parent, int32_t* ch
   return EMAT_OK;
 }
 
+emat_status emat_tree_partition(emat_backend* h, int32_t num_cuts, const int32_t* cut_nodes, int32_t* num_parts, int32_t* root_part, int32_t* part_sizes) {
+  if (!h || num_cuts < 0 || (num_cuts > 0 && !cut_nodes) || !num_parts || !root_part) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, true); if (st) return st;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  GTreeHost& G = h->gt;
+  if (G.parts_live) return fail(h, EMAT_ERR_STATE, "the parts are out on their slabs: emat_tree_reassemble first");
+  const int n = G.n;
+  // partition_tree's rule for the run's root (tree_partitioning.h:196-239): a part of its own at the end unless the stencil names it
+  std::vector<uint8_t> is_cut((size_t)n, 0);
+  std::vector<int32_t> cut_of_part(cut_nodes, cut_nodes + num_cuts);
+  int rp = -1;
+  for (int i = 0; i < num_cuts; ++i) {
+    const int32_t c = cut_nodes[i];
+    if (c < 0 || c >= n || is_cut[c] || G.h_c0[c] == EMAT_NO_NODE) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_partition: cut nodes must be distinct inner nodes");
+    is_cut[c] = 1;
+    if (c == G.h_root && rp < 0) rp = i;
+  }
+  if (rp < 0) { is_cut[G.h_root] = 1; rp = num_cuts; cut_of_part.push_back(G.h_root); }
+  const int P = (int)cut_of_part.size();
+  if (h->cfg.max_parts > 0 && P > h->cfg.max_parts) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "more parts than cfg.max_parts");
+  if (h->stream) HIP_TRY(hipStreamSynchronize(h->stream));
+  DevBuf<uint8_t> d_is_cut; DevBuf<int32_t> d_cut, d_sizes;
+  HIP_TRY(d_is_cut.upload(is_cut.data(), (size_t)n)); HIP_TRY(d_cut.upload(cut_of_part.data(), (size_t)P)); HIP_TRY(d_sizes.alloc((size_t)P));
+  const size_t total = (size_t)n + (size_t)P - 1;
+  HIP_TRY(G.part_off.alloc((size_t)P + 1)); HIP_TRY(G.orig.alloc(total)); HIP_TRY(G.kid0.alloc(total)); HIP_TRY(G.kid1.alloc(total)); HIP_TRY(G.lpar.alloc(total)); HIP_TRY(G.lidx.alloc((size_t)n));
+  const unsigned blocks = (unsigned)((P + 63) / 64);
+  hipLaunchKernelGGL(k_gt_partition, dim3(blocks), dim3(64), 0, h->stream, G.dev(), (const uint8_t*)d_is_cut.p, (const int32_t*)d_cut.p, P, 0, d_sizes.p,
+                     (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::vector<int32_t> sizes((size_t)P);
+  HIP_TRY(hipMemcpy(sizes.data(), d_sizes.p, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToHost));
+  G.h_part_off.assign((size_t)P + 1, 0);
+  for (int p = 0; p < P; ++p) { if (sizes[p] < 1) return fail(h, EMAT_ERR_INTERNAL, "emat_tree_partition: empty part"); G.h_part_off[p + 1] = G.h_part_off[p] + sizes[p]; }
+  if ((size_t)G.h_part_off[P] != total) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_partition: the cut nodes do not partition the tree (a cut below another part's tip?)");
+  HIP_TRY(hipMemcpy(G.part_off.p, G.h_part_off.data(), ((size_t)P + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_gt_partition, dim3(blocks), dim3(64), 0, h->stream, G.dev(), (const uint8_t*)d_is_cut.p, (const int32_t*)d_cut.p, P, 1, (int32_t*)nullptr,
+                     (const int32_t*)G.part_off.p, G.orig.p, G.kid0.p, G.kid1.p, G.lpar.p, G.lidx.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));   // (the temporaries above go out of scope)
+  G.P = P; G.root_part = rp; G.partition_on_device = true; G.h_orig.clear(); G.h_kid0.clear();
+  *num_parts = P; *root_part = rp;
+  if (part_sizes) std::copy(sizes.begin(), sizes.end(), part_sizes);
+  return EMAT_OK;
+}
+
+namespace { emat_status gt_partition_to_host(emat_backend* h) {   // the arrays of a partition made on the device, when the host wants them after all
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  GTreeHost& G = h->gt;
+  if (!G.h_orig.empty() || G.P == 0) return EMAT_OK;
+  const size_t total = (size_t)G.h_part_off[G.P];
+  G.h_orig.resize(total); G.h_kid0.resize(total); G.h_kid1.resize(total);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(G.h_orig.data(), G.orig.p, total * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(G.h_kid0.data(), G.kid0.p, total * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(G.h_kid1.data(), G.kid1.p, total * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return EMAT_OK;
+} }
+
+emat_status emat_tree_get_partition(emat_backend* h, int32_t* part_offset, int32_t* orig, int32_t* kid0, int32_t* kid1) {
+  if (!h) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, true); if (st) return st;
+  GTreeHost& G = h->gt;
+  if (G.P == 0) return fail(h, EMAT_ERR_STATE, "no partition yet");
+  st = gt_partition_to_host(h); if (st) return st;
+  if (part_offset) std::copy(G.h_part_off.begin(), G.h_part_off.end(), part_offset);
+  if (orig) std::copy(G.h_orig.begin(), G.h_orig.end(), orig);
+  if (kid0) std::copy(G.h_kid0.begin(), G.h_kid0.end(), kid0);
+  if (kid1) std::copy(G.h_kid1.begin(), G.h_kid1.end(), kid1);
+  return EMAT_OK;
+}
+
 emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int32_t* part_offset, const int32_t* orig, const int32_t* kid0, const int32_t* kid1,
                                   int32_t root_part, const uint64_t* seeds, const emat_pop_model* pm, double t_step) {
   return emat_tree_repartition_range(h, num_parts, part_offset, orig, kid0, kid1, root_part, seeds, pm, t_step, 0, num_parts);
 }
 emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, const int32_t* part_offset, const int32_t* orig, const int32_t* kid0, const int32_t* kid1,
                                         int32_t root_part, const uint64_t* seeds, const emat_pop_model* pm, double t_step, int32_t part_lo, int32_t part_hi) {
-  if (!h || num_parts <= 0 || !part_offset || !orig || !kid0 || !kid1 || !seeds || !pm || !(t_step > 0.0) || root_part < 0 || root_part >= num_parts) return EMAT_ERR_INVALID_ARGUMENT;
+  const bool made_here = part_offset == nullptr && orig == nullptr && kid0 == nullptr && kid1 == nullptr;   // the partition of emat_tree_partition, already on the device
+  if (!h || num_parts <= 0 || (!made_here && (!part_offset || !orig || !kid0 || !kid1)) || !seeds || !pm || !(t_step > 0.0) || root_part < 0 || root_part >= num_parts) return EMAT_ERR_INVALID_ARGUMENT;
   if (part_lo < 0 || part_hi > num_parts || part_lo >= part_hi) return EMAT_ERR_INVALID_ARGUMENT;
   emat_status st = gt_require(h, true); if (st) return st;
   auto set_error = [&](const std::string& s) { h->set_error(s); };
@@ -164,10 +237,14 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t0 = now();
+  if (made_here) {
+    if (!G.partition_on_device || G.P != P || G.root_part != root_part) return fail(h, EMAT_ERR_STATE, "emat_tree_partition first (with no arrays given, its partition is the one that is cut)");
+    part_offset = G.h_part_off.data();
+  }
   // every node is a non-root node of exactly one part; the run's root is the root of the root part
   if (part_offset[0] != 0 || (int64_t)part_offset[P] != (int64_t)n + P - 1) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_repartition: the parts do not cover the tree");
   const size_t total = (size_t)part_offset[P];
-  {
+  if (!made_here) {
     std::atomic<int> bad{0};
     parallel_for(P, [&](int p) {
       const int b = part_offset[p], np = part_offset[p + 1] - b;
@@ -193,9 +270,10 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
   const bool device_coal = !h->cfg_gt_host_coal;
   if (nloc != P && !device_coal) return fail(h, EMAT_ERR_STATE, "a block of the parts needs the coalescent tables built on the device (EMAT_TREE_HOST_COALESCENT builds them from all parts on the host)");
   G.lo = lo; G.hi = hi;
-  G.h_part_off.assign(part_offset, part_offset + P + 1); G.h_orig.assign(orig, orig + total); G.h_kid0.assign(kid0, kid0 + total);
-  HIP_TRY(G.part_off.upload(part_offset, (size_t)P + 1)); HIP_TRY(G.orig.upload(orig, total)); HIP_TRY(G.kid0.upload(kid0, total)); HIP_TRY(G.kid1.upload(kid1, total));
-  if (device_coal) {
+  if (!made_here) { G.h_part_off.assign(part_offset, part_offset + P + 1); G.h_orig.assign(orig, orig + total); G.h_kid0.assign(kid0, kid0 + total); G.h_kid1.assign(kid1, kid1 + total); G.partition_on_device = false; part_offset = G.h_part_off.data(); }
+  if (!made_here) { HIP_TRY(G.part_off.upload(part_offset, (size_t)P + 1)); HIP_TRY(G.orig.upload(orig, total)); HIP_TRY(G.kid0.upload(kid0, total)); HIP_TRY(G.kid1.upload(kid1, total)); }
+  if (made_here && !device_coal) { st = gt_partition_to_host(h); if (st) return st; orig = G.h_orig.data(); kid0 = G.h_kid0.data(); kid1 = G.h_kid1.data(); }   // the host builder wants skeletons
+  if (device_coal && !made_here) {
     std::vector<int32_t> lpar(total, EMAT_NO_NODE);
     parallel_for(P, [&](int p) {
       const int b = part_offset[p], np = part_offset[p + 1] - b;
@@ -523,6 +601,7 @@ emat_status emat_tree_export_nodes(emat_backend* h, uint8_t* buf, uint64_t capac
   GTreeHost& G = h->gt;
   if (!G.parts_live) return fail(h, EMAT_ERR_STATE, "emat_tree_repartition and emat_tree_gather_local first");
   // one entry per node of every local part (k_gt_export's comment says what an entry carries)
+  st = gt_partition_to_host(h); if (st) return st;
   std::vector<uint32_t> ids;
   for (int p = G.lo; p < G.hi; ++p) {
     const int b = G.h_part_off[p], np = G.h_part_off[p + 1] - b;

@@ -86,6 +86,40 @@ __device__ inline uint32_t wave_sum_u32(uint32_t x) {
   return __shfl(x, 0, k_wave);
 }
 
+// ---- partition_tree (tree_partitioning.h:88-135) on the device: one thread per part walks its part down from the cut point,
+//      depth first, right child first -- the order in which the host's LIFO work list expands nodes -- handing out part-local
+//      indices exactly as it does (two consecutive ones to the children of every node it expands).  No stack: in a binary
+//      tree with parent links the way back up is known.  mode 0 counts the part's nodes, mode 1 writes the arrays.
+__global__ void k_gt_partition(GTreeDev g, const uint8_t* is_cut, const int32_t* cut_of_part, int num_parts, int mode, int32_t* sizes,
+                               const int32_t* part_off, int32_t* orig, int32_t* kid0, int32_t* kid1, int32_t* lpar, int32_t* lidx) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= num_parts) return;
+  const int32_t cut = cut_of_part[p];
+  const int b = mode ? part_off[p] : 0;
+  int cnt = 1;
+  if (mode) { orig[b] = cut; lpar[b] = EMAT_NO_NODE; }
+  int32_t cur = cut; int dst = 0;
+  for (;;) {
+    const int32_t k0 = g.c0[cur], k1 = g.c1[cur];
+    if (k0 != EMAT_NO_NODE && (!is_cut[cur] || cur == cut)) {   // expanded: its children join the part
+      const int dl = cnt, dr = cnt + 1; cnt += 2;
+      if (mode) { orig[b + dl] = k0; orig[b + dr] = k1; kid0[b + dst] = dl; kid1[b + dst] = dr; lpar[b + dl] = dst; lpar[b + dr] = dst; lidx[k0] = dl; lidx[k1] = dr; }
+      cur = k1; dst = dr;
+      continue;
+    }
+    if (mode) { kid0[b + dst] = EMAT_NO_NODE; kid1[b + dst] = EMAT_NO_NODE; }   // a tip of the part
+    bool done = false;
+    for (;;) {   // back up to the nearest ancestor whose left subtree is still to do
+      if (cur == cut) { done = true; break; }
+      const int32_t par = g.parent[cur];
+      if (cur == g.c1[par]) { cur = g.c0[par]; dst = mode ? lidx[cur] : 0; break; }
+      cur = par;
+    }
+    if (done) break;
+  }
+  if (!mode) sizes[p] = cnt;
+}
+
 // ---- pass 1 of a repartition: the state at every cut point + how much list content every part holds ------------
 // State at a cut point c = the sites missing at c (union of the missations from c up to the root) and the net changes
 // reference sequence -> sequence at c, sorted by site, over the sites present at c.  The walk goes UP from c, so later

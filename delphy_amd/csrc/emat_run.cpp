@@ -124,6 +124,22 @@ struct RunDriver {
   // The whole tree resident in HBM (emat_tree_* of the backend): this driver then only sees topology and
   // node times (tp_* below); `tree` is brought up to date on demand (ensure_host_tree).
   bool device_tree = false, device_tree_uploaded = false, host_tree_stale = false;
+  bool partition_on_device = false;   // the current partition was made by emat_tree_partition: parts[p].orig / part_kids are filled on demand
+  emat_status ensure_partition_on_host() {
+    if (!partition_on_device || parts.empty() || !parts[0].orig.empty()) return EMAT_OK;
+    const int P = (int)parts.size();
+    std::vector<int32_t> off((size_t)P + 1);
+    emat_status st = bk(emat_tree_get_partition(backend, off.data(), nullptr, nullptr, nullptr)); if (st) return st;
+    std::vector<int32_t> orig((size_t)off[P]), k0((size_t)off[P]), k1((size_t)off[P]);
+    st = bk(emat_tree_get_partition(backend, nullptr, orig.data(), k0.data(), k1.data())); if (st) return st;
+    part_kids.assign(P, {});
+    for (int p = 0; p < P; ++p) {
+      parts[p].orig.assign(orig.begin() + off[p], orig.begin() + off[p + 1]);
+      part_kids[p].resize((size_t)(off[p + 1] - off[p]));
+      for (int s = 0; s < off[p + 1] - off[p]; ++s) part_kids[p][s] = {k0[off[p] + s], k1[off[p] + s]};
+    }
+    return EMAT_OK;
+  }
 
   double t_max_tip() const { double t = -INFINITY; for (auto& n : tree.nodes) if (n.is_tip() && n.t_max > t) t = n.t_max; return t; }   // phylo_tree_calc.cpp:636-644
 
@@ -571,11 +587,35 @@ struct RunDriver {
       --stencil_refresh_countdown;
       const std::vector<int32_t> stencil = refine_stencil(stencils[bitgen.below((int)stencils.size())]);
       part_kids.clear();
-      partition_tree(stencil);
+      // partition_tree itself: on the device (one thread per part) unless the parts are few and large, where one host thread
+      // per part is the better fit
+      const size_t N = tp_parent.size();
+      if (stencil.size() + 1 >= 64 && N / (stencil.size() + 1) <= 2048) {
+        int32_t P = 0, rp = -1;
+        emat_status st1 = bk(emat_tree_partition(backend, (int32_t)stencil.size(), stencil.data(), &P, &rp, nullptr)); if (st1) return st1;
+        parts.assign((size_t)P, PartMap{});
+        for (int p = 0; p < P; ++p) parts[p].cut_point = p < (int)stencil.size() ? stencil[p] : tp_root;
+        root_part = rp; partition_on_device = true;
+      } else { partition_tree(stencil); partition_on_device = false; }
       ++epoch;
     } catch (const std::exception& ex) { return fail(EMAT_ERR_INTERNAL, ex.what()); }
     auto t2 = now();
     const int P = (int)parts.size();
+    if (partition_on_device) {
+      part_seeds.assign(P, 0);
+      for (int p = 0; p < P; ++p) part_seeds[p] = seed_for_part(p);
+      subtrees.clear();
+      shard_block(P);
+      part_epoch.assign(P, 0);
+      emat_pop_model pm = pop; pm.skygrid_x = sky_x.data(); pm.skygrid_gamma = sky_g.data();
+      auto t3 = now();
+      st = bk(emat_tree_repartition_range(backend, P, nullptr, nullptr, nullptr, nullptr, root_part, part_seeds.data(), &pm, t_step_set ? t_step : default_t_step(), part_lo, part_hi));
+      if (st) return st;
+      parts_uploaded = true; coal_built = true; host_tree_stale = true;
+      if (verbose) fprintf(stderr, "[emat_run] repartition (device tree): upload / topology %.1f ms | stencil + emat_tree_partition %.1f ms | seeds %.1f ms | emat_tree_repartition %.1f ms\n",
+                           ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
+      return EMAT_OK;
+    }
     part_off.assign(P + 1, 0);
     for (int p = 0; p < P; ++p) part_off[p + 1] = part_off[p] + (int32_t)parts[p].orig.size();
     orig.resize(part_off[P]); kid0.resize(part_off[P]); kid1.resize(part_off[P]);
@@ -621,6 +661,7 @@ struct RunDriver {
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     auto t0 = now(), t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0;
     if (device_tree) return repartition_device();
+    partition_on_device = false;
     try {
       sync_topology();
       if (stencils.empty() || stencil_refresh_countdown <= 0) {
@@ -869,6 +910,7 @@ emat_status emat_run_moves_sharded(emat_run* r, int64_t count) {   // Run::run_l
 emat_status emat_run_Ttwiddle_ext(emat_run* r, const double* tree_length_of_part, int32_t* ext_offset, int32_t* ext_node, double* ext_length, int32_t capacity, int32_t* count) {
   if (!r || !tree_length_of_part || !ext_offset || !count || capacity < 0 || (capacity > 0 && (!ext_node || !ext_length))) return EMAT_ERR_INVALID_ARGUMENT;
   RunDriver& d = r->d;
+  { emat_status st = d.ensure_partition_on_host(); if (st) return st; }
   const int P = (int)d.parts.size();
   if (P == 0 || (int)d.part_kids.size() != P) return d.fail(EMAT_ERR_STATE, "repartition first");
   std::vector<int32_t> part_of_cut(d.tree.nodes.size(), -1);

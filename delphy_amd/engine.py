@@ -264,6 +264,7 @@ def load_library():
         "emat_tree_get_topology": [B, P(i32), P(i32), P(i32), P(dbl), P(i32)],
         "emat_tree_repartition": [B, i32, P(i32), P(i32), P(i32), P(i32), i32, P(u64), P(_PopModelC), dbl],
         "emat_tree_reassemble": [B, P(i32), P(i32), P(C.c_uint8), P(C.c_uint8), i32],
+        "emat_tree_partition": [B, i32, P(i32), P(i32), P(i32), P(i32)], "emat_tree_get_partition": [B, P(i32), P(i32), P(i32), P(i32)],
         "emat_tree_repartition_range": [B, i32, P(i32), P(i32), P(i32), P(i32), i32, P(u64), P(_PopModelC), dbl, i32, i32],
         "emat_tree_get_root_deltas": [B, P(i32), P(i32), P(C.c_uint8), P(C.c_uint8), i32], "emat_tree_gather_local": [B, i32, P(i32), P(C.c_uint8), P(C.c_uint8)],
         "emat_tree_export_nodes": [B, P(C.c_uint8), u64, P(u64)], "emat_tree_apply_nodes": [B, P(C.c_uint8), u64], "emat_tree_reassemble_end": [B],
@@ -457,6 +458,19 @@ class EmatBackend:
         self._ck(self._lib.emat_tree_reassemble(self._h, C.byref(n), _ptr(site, C.c_int32), _ptr(frm, C.c_uint8), _ptr(to, C.c_uint8), capacity), "emat_tree_reassemble")
         k = n.value
         return site[:k].copy(), frm[:k].copy(), to[:k].copy()
+
+    def tree_partition(self, cut_nodes):
+        """partition_tree on the device: (num_parts, root_part, part_offset, orig, kid0, kid1) for the given cut nodes."""
+        cuts = np.ascontiguousarray(cut_nodes, np.int32)
+        n, r = C.c_int32(), C.c_int32()
+        sizes = np.zeros(cuts.shape[0] + 1, np.int32)
+        self._ck(self._lib.emat_tree_partition(self._h, int(cuts.shape[0]), _ptr(cuts, C.c_int32), C.byref(n), C.byref(r), _ptr(sizes, C.c_int32)), "emat_tree_partition")
+        off = np.zeros(n.value + 1, np.int32)
+        self._ck(self._lib.emat_tree_get_partition(self._h, _ptr(off, C.c_int32), None, None, None), "emat_tree_get_partition")
+        orig, k0, k1 = (np.zeros(int(off[-1]), np.int32) for _ in range(3))
+        self._ck(self._lib.emat_tree_get_partition(self._h, None, _ptr(orig, C.c_int32), _ptr(k0, C.c_int32), _ptr(k1, C.c_int32)), "emat_tree_get_partition")
+        assert np.array_equal(np.diff(off), sizes[:n.value])
+        return n.value, r.value, off, orig, k0, k1
 
     def tree_root_deltas(self, capacity: int = 256):
         """(site, from, to) on the process that holds the root part, None elsewhere."""

@@ -207,6 +207,13 @@ emat_status emat_tree_upload(emat_backend* h, const emat_flat_tree* tree);
 emat_status emat_tree_get_sizes(emat_backend* h, int32_t* num_nodes, int32_t* num_muts, int32_t* num_intervals, int32_t* num_from_states);
 emat_status emat_tree_download(emat_backend* h, emat_flat_tree* out, uint8_t* ref_sequence /* [num_sites] or NULL */);
 emat_status emat_tree_get_topology(emat_backend* h, int32_t* parent, int32_t* child0, int32_t* child1, double* t, int32_t* root);
+/* partition_tree (tree_partitioning.h:88-135, 196-239) on the device, for callers that only have the cut nodes of a stencil:
+ * one thread per part walks the part down from its cut point and numbers its nodes exactly as the reference's work list does.
+ * Part i has cut node cut_nodes[i]; unless the stencil names the run's root, the root part comes last.  The arrays stay on
+ * the device: emat_tree_repartition(_range) cuts THIS partition when it is given NULL for part_offset / orig / kid0 / kid1;
+ * emat_tree_get_partition downloads them (any pointer may be NULL). */
+emat_status emat_tree_partition(emat_backend* h, int32_t num_cuts, const int32_t* cut_nodes, int32_t* num_parts, int32_t* root_part, int32_t* part_sizes /* [num_cuts + 1] or NULL */);
+emat_status emat_tree_get_partition(emat_backend* h, int32_t* part_offset, int32_t* orig, int32_t* kid0, int32_t* kid1);
 emat_status emat_tree_repartition(emat_backend* h, int32_t num_parts, const int32_t* part_offset /* [num_parts + 1] */, const int32_t* orig,
                                   const int32_t* kid0, const int32_t* kid1, int32_t root_part, const uint64_t* seeds /* [num_parts] */,
                                   const emat_pop_model* pop_model, double t_step);

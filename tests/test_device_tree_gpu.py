@@ -392,3 +392,49 @@ def test_cut_point_states_larger_than_the_small_kernel_holds():
     assert bd.tree_counters()[2] >= 1, "no cut-point state outgrew the small kernel: the test does not reach the large one (%d mutations on the tree)" % tree.mut_offset[-1]
     for r in (rh, rd): r.close()
     for b in (bh, bd): b.close()
+
+
+def _partition_in_python(parent, c0, c1, root, cuts):
+    """tree_partitioning.h:88-135 / 196-239 written out once more, independently of both the host driver and the kernel."""
+    is_cut = np.zeros(len(parent), bool); is_cut[list(cuts)] = True
+    cut_of_part = list(cuts)
+    if root in cuts: root_part = cuts.index(root)
+    else: is_cut[root] = True; root_part = len(cuts); cut_of_part.append(root)
+    off, orig, kid0, kid1 = [0], [], [], []
+    for cut in cut_of_part:
+        po, k0, k1 = [cut], [-1], [-1]
+        work = [(cut, 0)]
+        while work:
+            src, dst = work.pop()
+            if c0[src] < 0 or (is_cut[src] and src != cut):
+                continue
+            dl = len(po); po.append(int(c0[src])); dr = len(po); po.append(int(c1[src]))
+            k0 += [-1, -1]; k1 += [-1, -1]
+            k0[dst], k1[dst] = dl, dr
+            work.append((int(c0[src]), dl)); work.append((int(c1[src]), dr))
+        orig += po; kid0 += k0; kid1 += k1; off.append(len(orig))
+    return len(cut_of_part), root_part, np.array(off, np.int32), np.array(orig, np.int32), np.array(kid0, np.int32), np.array(kid1, np.int32)
+
+
+def test_partition_tree_on_the_device():
+    """emat_tree_partition against partition_tree written out in Python: no cut at all (one part), random inner nodes as cuts
+    (nested ones included), a stencil that names the root, and cut lists that are refused."""
+    sc = make_scenario("C3", num_tips=2500, num_sites=2000)
+    b = d.EmatBackend(sc.num_sites)
+    b.set_ref_sequence(sc.ref); b.set_hky(sc.mu, sc.kappa, sc.pi); b.set_flags(sc.t_max_tip)
+    b.tree_upload(sc.tree)
+    parent, c0, c1, t, root = b.tree_topology()
+    inner = np.flatnonzero(c0 >= 0)
+    rng = np.random.default_rng(2)
+    some = [int(x) for x in rng.choice(inner[inner != root], size=25, replace=False)]
+    for cuts in ([], some, some[:7] + [root] + some[7:12]):
+        got = b.tree_partition(cuts)
+        want = _partition_in_python(parent, c0, c1, root, cuts)
+        assert got[0] == want[0] and got[1] == want[1]
+        for g, w in zip(got[2:], want[2:]):
+            assert np.array_equal(g, w)
+    with pytest.raises(d.EmatError, match="EMAT_ERR_INVALID_ARGUMENT"):
+        b.tree_partition([some[0], some[0]])
+    with pytest.raises(d.EmatError, match="EMAT_ERR_INVALID_ARGUMENT"):
+        b.tree_partition([int(np.flatnonzero(c0 < 0)[0])])        # a tip is not a cut point
+    b.close()
