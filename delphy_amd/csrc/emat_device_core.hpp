@@ -741,15 +741,8 @@ template <bool kGrow = true> EMAT_DF void coal_tip_displaced(Ctx& c, double old_
 
 // ---- incomplete gamma (replaces Boost gamma_q / gamma_q_inv used at spr_study.cpp:368,463,544;
 //      series / modified-Lentz continued fraction, inverse by Halley steps) --------------------------------------------
-EMAT_DN double gamma_q(double a, double x) {
-  if (x == 0.0) return 1.0;
-  if (isinf(x)) return 0.0;
-  const double lg = lgamma(a);
-  if (x < a + 1.0) {
-    double ap = a, sum = 1.0 / a, del = sum;
-    for (int n = 0; n < 100000; ++n) { ap += 1.0; del *= x / ap; sum += del; if (fabs(del) < fabs(sum) * 1e-17) break; }
-    return 1.0 - sum * exp(-x + a * log(x) - lg);
-  }
+// the continued fraction's value h: Q(a, x) = exp(-x + a log x - lgamma(a)) * h for x >= a + 1
+EMAT_DN double gamma_q_fraction(double a, double x) {
   const double FPMIN = 1e-300;
   double b = x + 1.0 - a, cc = 1.0 / FPMIN, d = 1.0 / b, h = d;
   for (int i = 1; i < 100000; ++i) {
@@ -761,12 +754,42 @@ EMAT_DN double gamma_q(double a, double x) {
     double del = d * cc; h *= del;
     if (fabs(del - 1.0) < 1e-16) break;
   }
-  return exp(-x + a * log(x) - lg) * h;
+  return h;
+}
+EMAT_DN double gamma_q(double a, double x) {
+  if (x == 0.0) return 1.0;
+  if (isinf(x)) return 0.0;
+  const double lg = lgamma(a);
+  if (x < a + 1.0) {
+    double ap = a, sum = 1.0 / a, del = sum;
+    for (int n = 0; n < 100000; ++n) { ap += 1.0; del *= x / ap; sum += del; if (fabs(del) < fabs(sum) * 1e-17) break; }
+    return 1.0 - sum * exp(-x + a * log(x) - lg);
+  }
+  return exp(-x + a * log(x) - lg) * gamma_q_fraction(a, x);
 }
 EMAT_DN double gamma_q_inv(double a, double q) {
   if (q == 0.0) return k_inf;
   if (q == 1.0) return 0.0;
   const double lg = lgamma(a);
+  if (q < 1e-3) {
+    // Far upper tail (the reference's own test asks for Q down to 1e-300, safe_gamma_math_tests.cpp:83-95,247-262):
+    // Newton on log Q(a, x) = log q, log Q = -x + a log x - lgamma(a) + log h taken from the continued fraction without
+    // ever forming Q, and d/dx log Q = -density / Q = -1 / (x h); the steps close in on the root from one side.
+    const double lq = log(q);
+    double x = a + 1.0, h = gamma_q_fraction(a, x), prev = 0.0;
+    if (-x + a * log(x) - lg + log(h) > lq) {   // the root lies where the fraction converges
+      for (int j = 0; j < 100; ++j) {
+        double dx = (-x + a * log(x) - lg + log(h) - lq) * x * h;
+        double xn = x + dx;
+        if (xn < a + 1.0) xn = a + 1.0;
+        bool done = fabs(xn - x) <= 1e-14 * xn || (j > 2 && fabs(dx) >= fabs(prev));
+        x = xn; prev = dx;
+        if (done) break;
+        h = gamma_q_fraction(a, x);
+      }
+      return x;
+    }
+  }
   const double p = 1.0 - q;
   double x;
   if (a > 1.0) {

@@ -607,6 +607,21 @@ struct K_truncated_poisson_distribution {
 // ---- incomplete gamma (replaces Boost.Math 1.84 gamma_q / gamma_q_inv, reference
 //      core/safe_gamma_math.h:45-139; algorithm: series for x < a+1, modified-Lentz continued
 //      fraction otherwise [Numerical Recipes 3e s6.2]; inverse by Halley iterations on P or Q) --
+// the continued fraction's value h: Q(a, x) = exp(-x + a log x - lgamma(a)) * h for x >= a + 1
+inline double gamma_q_fraction(double a, double x) {
+  const double FPMIN = 1e-300;
+  double b = x + 1.0 - a, c = 1.0 / FPMIN, d = 1.0 / b, h = d;
+  for (int i = 1; i < 100000; ++i) {
+    double an = -i * (i - a);
+    b += 2.0;
+    d = an * d + b; if (std::fabs(d) < FPMIN) d = FPMIN;
+    c = b + an / c; if (std::fabs(c) < FPMIN) c = FPMIN;
+    d = 1.0 / d;
+    double del = d * c; h *= del;
+    if (std::fabs(del - 1.0) < 1e-16) break;
+  }
+  return h;
+}
 inline double gamma_q(double a, double x) {
   ORC_CHECK(a > 0.0 && x >= 0.0);
   if (x == 0.0) return 1.0;
@@ -621,18 +636,7 @@ inline double gamma_q(double a, double x) {
     double P = sum * std::exp(-x + a * std::log(x) - lg);
     return 1.0 - P;
   }
-  const double FPMIN = 1e-300;
-  double b = x + 1.0 - a, c = 1.0 / FPMIN, d = 1.0 / b, h = d;
-  for (int i = 1; i < 100000; ++i) {
-    double an = -i * (i - a);
-    b += 2.0;
-    d = an * d + b; if (std::fabs(d) < FPMIN) d = FPMIN;
-    c = b + an / c; if (std::fabs(c) < FPMIN) c = FPMIN;
-    d = 1.0 / d;
-    double del = d * c; h *= del;
-    if (std::fabs(del - 1.0) < 1e-16) break;
-  }
-  return std::exp(-x + a * std::log(x) - lg) * h;
+  return std::exp(-x + a * std::log(x) - lg) * gamma_q_fraction(a, x);
 }
 inline double safe_gamma_q(double a, double x) { return gamma_q(a, x); }
 // x such that Q(a, x) = q
@@ -641,6 +645,26 @@ inline double safe_gamma_q_inv(double a, double q) {
   if (q == 0.0) return std::numeric_limits<double>::infinity();
   if (q == 1.0) return 0.0;
   const double lg = std::lgamma(a);
+  if (q < 1e-3) {
+    // Far upper tail (the reference's own test asks for Q down to 1e-300, safe_gamma_math_tests.cpp:83-95,247-262):
+    // Newton on log Q(a, x) = log q, with log Q = -x + a log x - lgamma(a) + log h taken from the continued fraction
+    // without ever forming Q, and d/dx log Q = -density / Q = -1 / (x h).  log Q is monotone and concave (a >= 1) or
+    // convex (a < 1) in x, so the steps close in on the root from one side after the first.
+    const double lq = std::log(q);
+    double x = a + 1.0, h = gamma_q_fraction(a, x), prev = 0.0;
+    if (-x + a * std::log(x) - lg + std::log(h) > lq) {   // the root lies where the fraction converges
+      for (int j = 0; j < 100; ++j) {
+        double dx = (-x + a * std::log(x) - lg + std::log(h) - lq) * x * h;
+        double xn = x + dx;
+        if (xn < a + 1.0) xn = a + 1.0;
+        bool done = std::fabs(xn - x) <= 1e-14 * xn || (j > 2 && std::fabs(dx) >= std::fabs(prev));
+        x = xn; prev = dx;
+        if (done) break;
+        h = gamma_q_fraction(a, x);
+      }
+      return x;
+    }
+  }
   const double p = 1.0 - q;
   double x;
   // initial guess (NR3 invgammp)

@@ -1095,6 +1095,18 @@ TEST(distributions_support_and_means) {
   { double s = 0, s2 = 0; int n = 400000; for (int i = 0; i < n; ++i) { double z = rng.gaussian(1.0, 2.0); s += z; s2 += z * z; } EXPECT_NEAR(s / n, 1.0, 2e-2); EXPECT_NEAR(s2 / n - (s / n) * (s / n), 4.0, 5e-2); }
   // truncated gamma sampler stays in range and round-trips the inverse
   for (int i = 0; i < 2000; ++i) { double x = safe_sample_truncated_gamma(1.8, 0.3, 0.5, 40.0, rng); EXPECT(x >= 0.5 && x <= 40.0); }
+  // the reference's own sampler cases (safe_gamma_math_tests.cpp:126-179): basic, large alpha, a sweep starting at the mean,
+  // an unbounded upper end -- and one deep in the tail, where every uniform draw in Q is below 1e-100
+  for (int i = 0; i < 100; ++i) { double x = safe_sample_truncated_gamma(5.0, 2.0, 1.0, 10.0, rng); EXPECT(x >= 1.0 && x <= 10.0); }
+  for (int i = 0; i < 100; ++i) { double x = safe_sample_truncated_gamma(271.4, 1.0, 100.0, 500.0, rng); EXPECT(x >= 100.0 && x <= 500.0); }
+  for (double alpha : {1.0, 5.0, 10.0, 50.0, 100.0}) for (double beta : {0.5, 1.0, 2.0, 5.0}) {
+    double lo = alpha / beta, hi = lo + 10.0;
+    for (int i = 0; i < 10; ++i) { double x = safe_sample_truncated_gamma(alpha, beta, lo, hi, rng); EXPECT(x >= lo && x <= hi); }
+  }
+  for (int i = 0; i < 100; ++i) { double x = safe_sample_truncated_gamma(5.0, 1.0, 1.0, std::numeric_limits<double>::infinity(), rng); EXPECT(x >= 1.0); }
+  { double s = 0; int n = 20000;   // Gamma(11, 1) conditioned on [300, 400]: density ~ x^10 e^-x, log-density slope -r = 10/300 - 1, curvature -c = -10/300^2: mean = 300 + 1/r - 2c/r^3
+    for (int i = 0; i < n; ++i) { double x = safe_sample_truncated_gamma(11.0, 1.0, 300.0, 400.0, rng); EXPECT(x > 300.0 && x < 400.0); s += x; }
+    EXPECT_NEAR(s / n, 300.0 + 1.0 / (1.0 - 10.0 / 300.0) - 2.0 * 10.0 / (300.0 * 300.0) / std::pow(1.0 - 10.0 / 300.0, 3), 3e-2); }
   for (double a : {0.5, 1.0, 1.8, 4.2, 25.0}) for (double q : {1e-8, 1e-3, 0.2, 0.5, 0.9, 0.999}) { double x = safe_gamma_q_inv(a, q); EXPECT_NEAR(gamma_q(a, x), q, 1e-11 * std::max(1.0, 1.0 / q) * q + 1e-13); }
 }
 // mutational-history sampler: endpoint constraints (spr_move_tests.cpp:1795-2002)

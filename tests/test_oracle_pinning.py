@@ -31,6 +31,60 @@ def test_gamma_q_against_scipy_golden_vectors():
         assert abs(L.orc_gamma_q(row["a"], got) - row["q"]) <= 1e-11 * row["q"] + 1e-14
 
 
+def check_gamma_reference_cases(gamma_q, gamma_q_inv):
+    """Every point and assertion of the reference's test of its incomplete-gamma wrappers
+    (/root/reference/tests/safe_gamma_math_tests.cpp:34-262, kept as data in tests/golden/gamma_reference_cases.json),
+    applied to `gamma_q(a[], x[])` / `gamma_q_inv(a[], q[])`.  Beyond what the reference asserts, the sweeps are also held
+    to scipy's values wherever the problem is well conditioned."""
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "gamma_reference_cases.json")))
+    rows = g["q"]
+    got = gamma_q([r["a"] for r in rows], [r["x"] for r in rows])
+    for r, v in zip(rows, got):
+        assert np.isfinite(v) and 0.0 <= v <= 1.0, (r, v)
+        if r["kind"] == "near":
+            assert abs(v - r["q"]) <= r["tol"], (r, v)                         # the reference's assertion
+        assert abs(v - r["q"]) <= 1e-12 + 1e-9 * r["q"], (r, v)               # and scipy's value, relative in the tails
+    rows = g["q_inv"]
+    a = [r["a"] for r in rows]
+    got = gamma_q_inv(a, [r["q"] for r in rows])
+    back = gamma_q(a, [min(v, 1e300) for v in got])
+    for r, v, q in zip(rows, got, back):
+        if r["kind"] == "exact":
+            assert v == np.inf, (r, v)
+            continue
+        assert np.isfinite(v) and v >= 0.0, (r, v)
+        if r["kind"] == "near":
+            assert abs(v - r["x"]) <= r["tol"], (r, v)
+            continue
+        if r["kind"] == "finite":
+            assert v > 0.0, (r, v)
+        tol = r["tol"] if r["kind"] == "q_back" else 1e-10 * r["q"] + 1e-15
+        assert abs(q - r["q"]) <= tol, (r, v, q)                                # Q(a, Q_inv(a, Q)) = Q (InvExtremeQ)
+        if 1.0 - r["q"] >= 1e-6:                                                # x itself, where 1 - Q still carries digits
+            assert abs(v - r["x"]) <= 1e-8 * max(1.0, r["x"]), (r, v)
+    rows = g["roundtrip"]
+    a = [r["a"] for r in rows]
+    got = gamma_q_inv(a, gamma_q(a, [r["x"] for r in rows]))
+    for r, v in zip(rows, got):
+        assert abs(v - r["x"]) <= r["tol"], (r, v)
+    for r in g["log_integral"]:                                                # safe_log_gamma_integral = log(Q(x_min) - Q(x_max))
+        hi, lo = gamma_q([r["a"], r["a"]], [r["x_min"], r["x_max"]])
+        assert hi >= lo
+        with np.errstate(divide="ignore"):
+            v = float(np.log(hi - lo))
+        if r["log"] == "-inf":
+            assert v == -np.inf, (r, v)
+        else:
+            assert abs(v - r["log"]) <= r["tol"], (r, v)
+
+
+def test_gamma_q_on_the_reference_tests_own_points():
+    L = oracle_ffi.lib()
+    check_gamma_reference_cases(lambda a, x: [L.orc_gamma_q(ai, xi) for ai, xi in zip(a, x)],
+                                lambda a, q: [L.orc_gamma_q_inv(ai, qi) for ai, qi in zip(a, q)])
+    # the sampler built on them stays inside its bounds (safe_gamma_math_tests.cpp:126-179 run inside oracle/orc_tests.cpp)
+
+
 def test_rng_stream_known_answer():
     # Philox4x32-10 known-answer test (Random123 kat_vectors: counter = 0, key = 0)
     import ctypes as C

@@ -216,6 +216,18 @@ def test_device_gamma_q_against_scipy_golden_vectors():
         b.close()
 
 
+def test_device_gamma_q_on_the_reference_tests_own_points():
+    """Every point and assertion of the reference's own test of its incomplete-gamma wrappers (safe_gamma_math_tests.cpp:34-262,
+    kept as data in tests/golden/gamma_reference_cases.json), on the device's routines: Q down to 1e-300 and up to 1 - 1e-15,
+    a up to 1000, x up to 1e5 -- the same checker the oracle passes in tests/test_oracle_pinning.py."""
+    from test_oracle_pinning import check_gamma_reference_cases
+    b = d.EmatBackend(100)
+    try:
+        check_gamma_reference_cases(lambda a, x: list(b.debug_gamma(0, a, x)), lambda a, q: list(b.debug_gamma(1, a, q)))
+    finally:
+        b.close()
+
+
 def test_whole_tree_coalescent_prior_and_per_site_mutation_counts_from_the_parts():
     """SURVEY 8 rows a20 and (f).1: Scalable_coalescent_prior::calc_log_prior (the whole-tree grid prior Run keeps beside the
     per-part ones, run.cpp:455-465) and calc_num_muts_l, computed on the device from the PARTS, against the oracle's
