@@ -23,6 +23,14 @@
 
 #include "../../include/emat_backend.h"
 #ifdef EMAT_PROFILE_PHASES
+namespace emat {
+__device__ unsigned long long g_fn_ticks[3 * 2048][2];   // EMAT_TIMED scopes: [header * 2048 + line][ticks, calls], all parts
+struct FnTimer {   // inclusive ticks and calls of the enclosing scope, keyed by (header, source line); lane 0 only
+  int key; long long t0;
+  __device__ FnTimer(int k) : key(k), t0(clock64()) {}
+  __device__ ~FnTimer() { if (threadIdx.x == 0) { atomicAdd(&g_fn_ticks[key][0], (unsigned long long)(clock64() - t0)); atomicAdd(&g_fn_ticks[key][1], 1ull); } }
+};
+}
 namespace emat { __device__ unsigned long long g_arena_site_bytes[2048][2]; }   // [source line & 2047][0 = LDS arena, 1 = HBM scratch], all parts
 #endif
 // The device code is compiled three times (see emat_device_core.hpp): `dev_lds` for parts whose whole persistent slab
@@ -1876,6 +1884,20 @@ emat_status emat_debug_arena_sites(emat_backend* h, uint64_t* out_4096) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpyFromSymbol(out_4096, HIP_SYMBOL(::emat::g_arena_site_bytes), sizeof(unsigned long long) * 4096));
+  return EMAT_OK;
+#else
+  return fail(h, EMAT_ERR_STATE, "built without -DEMAT_PROFILE_PHASES");
+#endif
+}
+/* debugging aid (profiling builds): inclusive ticks and calls of the EMAT_TIMED scopes, [header * 2048 + line & 2047][ticks, calls]; read and cleared */
+emat_status emat_debug_fn_ticks(emat_backend* h, uint64_t* out_12288) {
+  if (!h || !out_12288 || h->host_only) return EMAT_ERR_INVALID_ARGUMENT;
+#ifdef EMAT_PROFILE_PHASES
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpyFromSymbol(out_12288, HIP_SYMBOL(::emat::g_fn_ticks), sizeof(unsigned long long) * 12288));
+  std::vector<unsigned long long> z(12288, 0);
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(::emat::g_fn_ticks), z.data(), sizeof(unsigned long long) * 12288));
   return EMAT_OK;
 #else
   return fail(h, EMAT_ERR_STATE, "built without -DEMAT_PROFILE_PHASES");

@@ -129,7 +129,9 @@ EMAT_D void fail_at(Ctx& c, int status, int line) {
 #define EMAT_COUNT(c, k, v) (((int64_t*)hdr_of(c)->reserved)[k] += (int64_t)(v))
 #define EMAT_PHASE_BEGIN() long long _ph_t0 = clock64()
 #define EMAT_PHASE(c, k) do { long long _t = clock64(); hdr_of(c)->phase_ticks[k] += _t - _ph_t0; _ph_t0 = _t; } while (0)
+#define EMAT_TIMED(file_id) ::emat::FnTimer _fn_timer((file_id) * 2048 + (__LINE__ & 2047))
 #else
+#define EMAT_TIMED(file_id) do {} while (0)
 #define EMAT_SITE(line, hbm, v) do {} while (0)
 #define EMAT_COUNT(c, k, v) do {} while (0)
 #define EMAT_PHASE_BEGIN() do {} while (0)
@@ -508,7 +510,7 @@ EMAT_D bool is_site_missing_at(Ctx& c, int node, int l) {   // cpp:58-65
   return false;
 }
 // cpp:41-56; result in scratch
-EMAT_DN SVec<IvRec> reconstruct_missing_sites_at(Ctx& c, int node) {
+EMAT_DN SVec<IvRec> reconstruct_missing_sites_at(Ctx& c, int node) { EMAT_TIMED(0);
   int total = 0;
   for (int cur = node; cur != k_no_node; cur = nodes_of(c)[cur].parent) total += (int)nodes_of(c)[cur].miss.cnt;
   SVec<IvRec> a = sc_vec<IvRec>(c, total + 1), b = sc_vec<IvRec>(c, total + 1);
@@ -580,12 +582,49 @@ EMAT_DF double pop_at_time(const PopTable& p, double t) {
   if (p.kind == 1) { double v = p.p[1] * exp((t - p.p[0]) * p.p[2]); return p.p[3] > v ? p.p[3] : v; }
   return exp(skygrid_log_N(p, t));
 }
-// log(N(t_new) / N(t_old)) (very_scalable_coalescent.cpp:323).  For the skygrid N = exp(log_N), so the ratio is
-// formed in log space directly; the other models go through pop_at_time as the reference does.
-EMAT_DF double log_pop_ratio(const PopTable& p, double t_new, double t_old) {
-  if (p.kind == 0) return 0.0;
-  if (p.kind == 2) return skygrid_log_N(p, t_new) - skygrid_log_N(p, t_old);
-  return log(pop_at_time(p, t_new) / pop_at_time(p, t_old));
+// log(N(t_new) / N(t_old)) (very_scalable_coalescent.cpp:323).  For the skygrid N = exp(log_N), so the ratio is formed in
+// log space directly; the other models go through pop_at_time's formula as the reference does.  Written for the lane that
+// runs a chain, and read through the scalar unit.  The model's table is a few hundred bytes
+// of read-only global memory that every wavefront of the device reads: as ordinary loads, its fields, the pointers to the
+// knots and the knots themselves are a chain of a dozen dependent vector loads per time (measured: 16 % of all chain time
+// at C4, section 8 of DESIGN.md).  Only one lane is active here, so the time and every address are uniform by construction;
+// saying so (readfirstlane) and reading through the constant address space turns the chain into s_load from the scalar
+// cache.  (Same operations in the same order as skygrid_log_N / pop_at_time.)
+#define EMAT_CONST_AS __attribute__((address_space(4)))
+template <class T> EMAT_DF const EMAT_CONST_AS T* uniform_const_ptr(const T* p) {
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return (const EMAT_CONST_AS T*)(((uint64_t)hi << 32) | lo);
+}
+EMAT_DF double uniform_f64(double v) {
+  const uint64_t a = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+EMAT_DF double skygrid_log_N_uniform(const EMAT_CONST_AS PopTable* p, double t) {   // skygrid_interval + skygrid_log_N
+  const EMAT_CONST_AS double* x = uniform_const_ptr((const double*)p->skygrid_x);
+  const EMAT_CONST_AS double* ga = uniform_const_ptr((const double*)p->skygrid_gamma);
+  const int n = p->skygrid_num_knots, M = n - 1;
+  const double g = (t - x[0]) * p->skygrid_inv_dx;
+  int k = __builtin_amdgcn_readfirstlane(g > 0.0 ? (g < (double)n ? (int)g : n) : 0);   // NaN -> 0
+  while (k > 0 && !(x[k - 1] < t)) --k;
+  while (k < n && x[k] < t) ++k;
+  if (k == 0) return ga[0];
+  if (k > M) return ga[M];
+  if (p->skygrid_type == 1) return ga[k];
+  const double cc = (t - x[k - 1]) / (x[k] - x[k - 1]);
+  return (1 - cc) * ga[k - 1] + cc * ga[k];
+}
+EMAT_DF double log_pop_ratio_uniform(const PopTable* pp, double t_new, double t_old) {
+  const EMAT_CONST_AS PopTable* p = uniform_const_ptr(pp);
+  const int kind = p->kind;
+  if (kind == 0) return 0.0;
+  t_new = uniform_f64(t_new); t_old = uniform_f64(t_old);
+  if (kind == 2) return skygrid_log_N_uniform(p, t_new) - skygrid_log_N_uniform(p, t_old);
+  const double t0 = p->p[0], n0 = p->p[1], gr = p->p[2], floor_n = p->p[3];
+  double a = n0 * exp((t_new - t0) * gr); a = floor_n > a ? floor_n : a;
+  double b = n0 * exp((t_old - t0) * gr); b = floor_n > b ? floor_n : b;
+  return log(a / b);
 }
 EMAT_D double exp_unclamped_int(const PopTable& p, double a, double b) { double n0 = p.p[1], g = p.p[2], t0 = p.p[0]; return n0 / g * exp(g * (a - t0)) * expm1(g * (b - a)); }
 EMAT_DN double skygrid_log_int_N(const PopTable& p, double a, double b) {   // pop_model.cpp:247-330 with gamma_eff = gamma
@@ -696,7 +735,7 @@ EMAT_DF double coal_cell_term(const Ctx& c, const Cells& k, int w, double new_k,
       - (k.ktw_p[w] * na - k.ktw[w] + 0.5) * (new_k - old_k));
 }
 // cpp:388-459
-template <bool kGrow = true> EMAT_DF double coal_delta_on_add_interval(Ctx& c, double min_t, double max_t, double delta_k) {
+template <bool kGrow = true> EMAT_DF double coal_delta_on_add_interval(Ctx& c, double min_t, double max_t, double delta_k) { EMAT_TIMED(0);
   { int cm = cell_for(c, max_t); if (cm < hdr_of(c)->cell_first || cm >= hdr_of(c)->n_cells_total) { EMAT_FAIL(c, k_part_internal); return 0.0; } }
   coal_ensure_space<kGrow>(c, min_t);
   if (c.failed) return 0.0;
@@ -720,11 +759,12 @@ template <bool kGrow = true> EMAT_DF double coal_delta_on_add_interval(Ctx& c, d
     d -= coal_cell_term(c, k, i - first, new_k, old_k);
   }
   c.bytes += 36 * (int64_t)(cell_end - cell_start + 1);
+  EMAT_COUNT(c, 13, cell_end - cell_start + 1); EMAT_COUNT(c, 14, 1);
   return d;
 }
-template <bool kGrow = true> EMAT_DF double coal_delta_displace_coalescence(Ctx& c, double old_t, double new_t) {   // cpp:310-326
+template <bool kGrow = true> EMAT_DF double coal_delta_displace_coalescence(Ctx& c, double old_t, double new_t) { EMAT_TIMED(0);   // cpp:310-326
   double d = (old_t <= new_t) ? coal_delta_on_add_interval<kGrow>(c, old_t, new_t, -1.0) : coal_delta_on_add_interval<kGrow>(c, new_t, old_t, +1.0);
-  d -= log_pop_ratio(*c.pop, new_t, old_t);
+  { EMAT_TIMED(0); d -= log_pop_ratio_uniform(c.pop, new_t, old_t); }
   return d;
 }
 template <bool kGrow = true> EMAT_DF double coal_delta_displace_tip(Ctx& c, double old_t, double new_t) {           // cpp:337-353

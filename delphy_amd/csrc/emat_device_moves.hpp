@@ -29,7 +29,7 @@ EMAT_D double bounded_exponential(Ctx& c, double lambda, double a, double b) {
 EMAT_D int pick_random_node(Ctx& c) { return uniform_int(c, hdr_of(c)->n_nodes); }
 
 // subrun.cpp:683-742
-EMAT_NOTAIL EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new_t, double alpha_ratio) {
+EMAT_NOTAIL EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new_t, double alpha_ratio) { EMAT_TIMED(2);
   if (X == hdr_of(c)->root) return;
   if (!c.includes_run_root) if (nodes_of(c)[X].parent == hdr_of(c)->root || new_branch == hdr_of(c)->root) return;
   const double t_X = nodes_of(c)[X].t;
@@ -251,7 +251,7 @@ EMAT_DN SVec<int> enumerate_descendant_branches_straddling(Ctx& c, int P, double
   return out;
 }
 
-EMAT_NOTAIL EMAT_DN void subtree_slide_move(Ctx& c) {   // subrun.cpp:352-448
+EMAT_NOTAIL EMAT_DN void subtree_slide_move(Ctx& c) { EMAT_TIMED(2);   // subrun.cpp:352-448
   begin_move(c, k_subtree_slide);
   if (hdr_of(c)->n_nodes < 2) return;
   const int X = pick_random_node(c);
@@ -293,7 +293,7 @@ EMAT_NOTAIL EMAT_DN void subtree_slide_move(Ctx& c) {   // subrun.cpp:352-448
 // subrun.cpp:492-675 in three stretches on lane 0; between them the whole wave scans for candidate regions and weighs them
 // (wave_scan_and_study).  A stretch that ends the move clears c.phase; one that parks it sets c.phase and c.svc.
 EMAT_D void spr1_park(Ctx& c, int phase) { c.phase = (uint8_t)phase; c.svc = 1; }
-EMAT_NOTAIL EMAT_DN void spr1_move_begin(Ctx& c) {
+EMAT_NOTAIL EMAT_DN void spr1_move_begin(Ctx& c) { EMAT_TIMED(2);
   begin_move(c, k_spr1);
   c.phase = 0;
   if (hdr_of(c)->n_nodes < 2) return;
@@ -332,7 +332,7 @@ EMAT_NOTAIL EMAT_DN void spr1_move_begin(Ctx& c) {
   if (c.failed) return;
   spr1_park(c, 1);   // -> scan from the old sibling, study; resumes in spr1_move_propose
 }
-EMAT_NOTAIL EMAT_DN void spr1_move_propose(Ctx& c) {
+EMAT_NOTAIL EMAT_DN void spr1_move_propose(Ctx& c) { EMAT_TIMED(2);
   Spr1Frame& fr = *(Spr1Frame*)c.frame;
   c.phase = 0;
   if (c.failed) return;
@@ -365,7 +365,7 @@ EMAT_NOTAIL EMAT_DN void spr1_move_propose(Ctx& c) {
   if (c.failed) return;
   spr1_park(c, 2);   // -> scan from the new sibling, study; resumes in spr1_move_finish
 }
-EMAT_NOTAIL EMAT_DN void spr1_move_finish(Ctx& c) {
+EMAT_NOTAIL EMAT_DN void spr1_move_finish(Ctx& c) { EMAT_TIMED(2);
   Spr1Frame& fr = *(Spr1Frame*)c.frame;
   c.phase = 0;
   if (c.failed) return;

@@ -27,7 +27,7 @@ EMAT_DN void fsv_set(Ctx& c, SVec<FsRec>& v, int l, int from) {   // Missation_m
 }
 
 // Rebuild the root's "mutations" (ref -> root deltas, t = -DBL_MAX) from a delta list, in site order.
-EMAT_DN void set_root_muts_from_deltas(Ctx& c, int root, const SVec<SdRec>& d) {
+EMAT_DN void set_root_muts_from_deltas(Ctx& c, int root, const SVec<SdRec>& d) { EMAT_TIMED(1);
   ListRef& r = nodes_of(c)[root].muts;
   list_reserve<MutRec>(c, r, d.n);
   if (c.failed) return;
@@ -35,7 +35,7 @@ EMAT_DN void set_root_muts_from_deltas(Ctx& c, int root, const SVec<SdRec>& d) {
   for (int i = 0; i < d.n; ++i) { EMAT_CHECK(c, c.ref[d.p[i].site] == d.p[i].from); m[i] = make_mut(d.p[i].from, d.p[i].site, d.p[i].to, k_neg_dbl_max); }
   r.cnt = (uint16_t)d.n;
 }
-EMAT_DN SVec<SdRec> deltas_from_root_muts(Ctx& c, int root, int extra_cap) {
+EMAT_DN SVec<SdRec> deltas_from_root_muts(Ctx& c, int root, int extra_cap) { EMAT_TIMED(1);
   SVec<SdRec> d = sc_vec<SdRec>(c, nmuts(c, root) + extra_cap + 1);
   const MutRec* m = muts_of(c, root);
   for (int i = 0; i < nmuts(c, root); ++i) sd_push_back(c, d, m[i].site, m[i].from, m[i].to);
@@ -245,7 +245,7 @@ EMAT_D void edit_hop_down(Ctx& c, Edit& e, int SS) {   // tree_editing.cpp:280-2
   edit_do_hop_up(c, sibling_of(c, U, SS));
 }
 // spr_move.cpp:1101-1156
-EMAT_DN void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) {
+EMAT_DN void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) { EMAT_TIMED(1);
   if (c.failed) return;
   EMAT_CHECK(c, X != hdr_of(c)->root);
   const int P = nodes_of(c)[X].parent, G = nodes_of(c)[P].parent, S = sibling_of(c, P, X);
@@ -357,7 +357,7 @@ EMAT_DN void sample_site_trajectory(Ctx& c, SVec<MutRec>& out, int l, int from, 
   for (int i = 0; i < n; ++i) { push(c, out, make_mut((uint8_t)prev, l, states[i], times[i])); prev = states[i]; }
 }
 // spr_move.cpp:1164-1370; result appended into a fresh open-ended scratch vector (caller trims)
-EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double mu, const SVec<SdRec>& deltas) {
+EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double mu, const SVec<SdRec>& deltas) { EMAT_TIMED(1);
   SVec<MutRec> out = sc_open<MutRec>(c, 4096, 4 * deltas.n + 48 + 36);   // + the staging area of sample_site_trajectory
   if (c.failed) return out;
   if (deltas.n != 0) {
@@ -386,7 +386,7 @@ EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double m
   return out;
 }
 // spr_move.cpp:1372-1407
-EMAT_DN SVec<MutRec> sample_unconstrained_mutational_history(Ctx& c, int L, double T, double mu) {
+EMAT_DN SVec<MutRec> sample_unconstrained_mutational_history(Ctx& c, int L, double T, double mu) { EMAT_TIMED(1);
   SVec<MutRec> out = sc_open<MutRec>(c, 4096, 96);
   if (c.failed) return out;
   double t = 0.0;
@@ -406,7 +406,7 @@ EMAT_DN SVec<MutRec> sample_unconstrained_mutational_history(Ctx& c, int L, doub
   return out;
 }
 // spr_move.cpp:1409-1439
-EMAT_DN void adjust_mutational_history(Ctx& c, SVec<MutRec>& h, const SVec<SdRec>& deltas, int end_branch, double end_t) {
+EMAT_DN void adjust_mutational_history(Ctx& c, SVec<MutRec>& h, const SVec<SdRec>& deltas, int end_branch, double end_t) { EMAT_TIMED(1);
   for (int i = h.n - 1; i >= 0; --i) {
     MutRec& m = h.p[i];
     m.t += end_t;
@@ -442,7 +442,7 @@ EMAT_D double log_alpha_mut_term(double mu_p, int L, double T, int M, bool is_op
 }
 
 // ---- rooty grafts -----------------------------------------------------------------------------------------
-EMAT_DN Graft start_rooty_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:91-205
+EMAT_DN Graft start_rooty_graft_analysis(Ctx& c, int X) { EMAT_TIMED(1);   // spr_move.cpp:91-205
   Graft g; g.X = X; g.rooty = true; g.delta_log_G = g.log_alpha_mut = 0.0;
   const int P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
   const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t, t_S = nodes_of(c)[S].t;
@@ -498,7 +498,7 @@ EMAT_D void recompute_open_pl_A(Ctx& c, BranchInfo& bi) {   // spr_move.cpp:234-
   bi.pl_A = bi.pl_X;
   for (int i = bi.hot_muts.n - 1; i >= 0; --i) bi.pl_A += dq(c, bi.hot_muts.p[i].site, bi.hot_muts.p[i].to, bi.hot_muts.p[i].from);
 }
-EMAT_DN void propose_new_rooty_graft_mutations(Ctx& c, Graft& g) {   // spr_move.cpp:207-244
+EMAT_DN void propose_new_rooty_graft_mutations(Ctx& c, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:207-244
   const int X = g.X, P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
   for (int idx = 0; idx < g.nbi && !c.failed; ++idx) {
     BranchInfo& bi = g.bi[idx];
@@ -516,7 +516,7 @@ EMAT_DN void propose_new_rooty_graft_mutations(Ctx& c, Graft& g) {   // spr_move
   }
 }
 EMAT_D double log_pi_ratio(const Ctx& c, const MutRec& m) { return log(pi_a(c, m.site, m.from) / pi_a(c, m.site, m.to)); }
-EMAT_DN void finish_rooty_graft_analysis(Ctx& c, Graft& g) {   // spr_move.cpp:246-316
+EMAT_DN void finish_rooty_graft_analysis(Ctx& c, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:246-316
   if (c.failed) return;
   const int X = g.X, P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
   const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t, t_S = nodes_of(c)[S].t;
@@ -540,7 +540,7 @@ EMAT_DN void finish_rooty_graft_analysis(Ctx& c, Graft& g) {   // spr_move.cpp:2
     g.log_alpha_mut += log_alpha_mut_term(c.mu_prop, iv_num_sites(bi.hot.p, bi.hot.n), bi.T_to_X, bi.hot_muts.n, bi.is_open, bi.hot_deltas.n);
   }
 }
-EMAT_DN void peel_rooty_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:318-431
+EMAT_DN void peel_rooty_graft(Ctx& c, const Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:318-431
   if (c.failed) return;
   const int X = g.X, P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
   const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t;
@@ -564,7 +564,7 @@ EMAT_DN void peel_rooty_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:318-43
   nodes_of(c)[P].lambda = calc_lambda_at_node(c, P);
   sc_release(c, mark);
 }
-EMAT_DN void apply_rooty_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:433-547
+EMAT_DN void apply_rooty_graft(Ctx& c, const Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:433-547
   if (c.failed) return;
   const int X = g.X, P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
   const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t, t_S = nodes_of(c)[S].t;
@@ -599,7 +599,7 @@ EMAT_DN void apply_rooty_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:433-5
 }
 
 // ---- inner grafts -----------------------------------------------------------------------------------------
-EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:582-738
+EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) { EMAT_TIMED(1);   // spr_move.cpp:582-738
   Graft g; g.X = X; g.rooty = false; g.delta_log_G = g.log_alpha_mut = 0.0; g.nbi = 0; g.bi = nullptr;
   const int P = nodes_of(c)[X].parent;
   EMAT_CHECK(c, X != hdr_of(c)->root && P != hdr_of(c)->root);
@@ -705,7 +705,7 @@ EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) {   // spr_move.cpp:582-
   }
   return g;
 }
-EMAT_DN void propose_new_inner_graft_mutations(Ctx& c, Graft& g) {   // spr_move.cpp:740-785
+EMAT_DN void propose_new_inner_graft_mutations(Ctx& c, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:740-785
   const int X = g.X;
   for (int idx = 0; idx < g.nbi && !c.failed; ++idx) {
     BranchInfo& bi = g.bi[idx];
@@ -727,7 +727,7 @@ EMAT_DN void propose_new_inner_graft_mutations(Ctx& c, Graft& g) {   // spr_move
     recompute_open_pl_A(c, bi);
   }
 }
-EMAT_DN void finish_inner_graft_analysis(Ctx& c, Graft& g) {   // spr_move.cpp:787-836
+EMAT_DN void finish_inner_graft_analysis(Ctx& c, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:787-836
   if (c.failed || g.nbi == 0) return;
   const int X = g.X; const double t_X = nodes_of(c)[X].t;
   g.delta_log_G = 0.0;
@@ -746,7 +746,7 @@ EMAT_D void recalc_lambda_along_hot_path(Ctx& c, const Graft& g) {   // spr_move
   for (int i = 0; i + 1 < g.nbi; ++i) { int A = g.bi[i].A, B = g.bi[i].B; nodes_of(c)[A].lambda = nodes_of(c)[B].lambda - delta_lambda_across_branch(c, B); }
 }
 EMAT_D void erase_marked_muts(Ctx& c, int node) { MutRec* m = muts_of(c, node); int n = nmuts(c, node), w = 0; for (int i = 0; i < n; ++i) if (m[i].site != -1) m[w++] = m[i]; nodes_of(c)[node].muts.cnt = (uint16_t)w; }
-EMAT_DN void peel_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:838-953
+EMAT_DN void peel_inner_graft(Ctx& c, const Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:838-953
   if (c.failed || g.nbi == 0) return;
   const int X = g.X, P = nodes_of(c)[X].parent, root = hdr_of(c)->root;
   const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t;
@@ -795,7 +795,7 @@ EMAT_DN void peel_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:838-95
   recalc_lambda_along_hot_path(c, g);
   sc_release(c, mark);
 }
-EMAT_DN void apply_inner_graft(Ctx& c, const Graft& g) {   // spr_move.cpp:955-1069
+EMAT_DN void apply_inner_graft(Ctx& c, const Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:955-1069
   if (c.failed || g.nbi == 0) return;
   const int X = g.X, root = hdr_of(c)->root;
   const BranchInfo& fin = g.bi[g.nbi - 1];
@@ -857,7 +857,7 @@ EMAT_D int count_min_mutations(const Ctx& c, const Graft& g) {
   int r = 0; for (int i = 0; i < g.nbi; ++i) if (!g.bi[i].is_open) r += g.bi[i].hot_deltas.n; return r;
 }
 // summarize_closed_mutations: fresh scratch delta list with room for `extra` more entries
-EMAT_DN SVec<SdRec> summarize_closed_mutations(Ctx& c, const Graft& g, int extra) {
+EMAT_DN SVec<SdRec> summarize_closed_mutations(Ctx& c, const Graft& g, int extra) { EMAT_TIMED(1);
   int tot = 0;
   if (g.rooty) tot = g.bi[k_SPX].hot_deltas.n; else for (int i = 0; i < g.nbi; ++i) if (!g.bi[i].is_open) tot += g.bi[i].hot_deltas.n;
   SVec<SdRec> r = sc_vec<SdRec>(c, tot + extra + 1);
@@ -1110,7 +1110,7 @@ EMAT_D double safe_log_gamma_integral(Ctx& c, double a, double x_min, double x_m
   return log(Q_hi - Q_lo);
 }
 constexpr double k_ln2 = 0.693147180559945309417232121458176568;
-EMAT_DN Study make_study(Ctx& c, SVec<Region> regions, int num_missing_at_X, double lambda_X, double f, double t_X, double t_max_tip) {   // spr_study.cpp:226-385
+EMAT_DN Study make_study(Ctx& c, SVec<Region> regions, int num_missing_at_X, double lambda_X, double f, double t_X, double t_max_tip) { EMAT_TIMED(1);   // spr_study.cpp:226-385
   Study st; st.regions = regions; st.lambda_X = lambda_X; st.f = f; st.t_X = t_X; st.t_max_tip = t_max_tip; st.log_Wmax = 0.0; st.sum_W = 0.0;
   st.mu = lambda_X / (c.L - num_missing_at_X);
   if (c.failed) return st;

@@ -115,7 +115,8 @@ def size_probe(nparts=8192, moves=1000):
     import ctypes as C
     from delphy_amd.sharding import ShardedEngine
     sc = make_scenario("C4")
-    eng = ShardedEngine(sc, num_parts=nparts, seed=20261001)
+    world, rank = int(os.environ.get("EMAT_PROBE_WORLD", "1")), int(os.environ.get("EMAT_PROBE_RANK", "0"))   # one GPU of N, emulated (scripts/scale_probe.py)
+    eng = ShardedEngine(sc, num_parts=nparts, seed=20261001, rank=rank, world=world, device_tree=world > 1, allreduce=lambda a, op: a, allgather_bytes=lambda b: [b])
     eng.setup()
     eng.backend.run_moves_per_part(moves); eng.backend.synchronize()
     lib = d.load_library()
@@ -268,7 +269,8 @@ def slow_phase_probe(nparts=8192, moves=1000, top=6):
     import ctypes as C
     from delphy_amd.sharding import ShardedEngine
     sc = make_scenario("C4")
-    eng = ShardedEngine(sc, num_parts=nparts, seed=20261001)
+    world, rank = int(os.environ.get("EMAT_PROBE_WORLD", "1")), int(os.environ.get("EMAT_PROBE_RANK", "0"))   # one GPU of N, emulated (scripts/scale_probe.py)
+    eng = ShardedEngine(sc, num_parts=nparts, seed=20261001, rank=rank, world=world, device_tree=world > 1, allreduce=lambda a, op: a, allgather_bytes=lambda b: [b])
     eng.setup()
     eng.backend.run_moves_per_part(moves); eng.backend.synchronize()
     lib = d.load_library()
@@ -298,3 +300,59 @@ def slow_phase_probe(nparts=8192, moves=1000, top=6):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "slowphase":
     slow_phase_probe()
+
+
+def fn_probe(nparts=8192, moves=1000):
+    """Inclusive time per instrumented device function (EMAT_TIMED scopes of the -DEMAT_PROFILE_PHASES library, EMAT_LIB_PATH),
+    summed over all parts of a pass, next to the time of all simple and all topology moves."""
+    import ctypes as C
+    from delphy_amd.sharding import ShardedEngine
+    sc = make_scenario("C4")
+    world, rank = int(os.environ.get("EMAT_PROBE_WORLD", "1")), int(os.environ.get("EMAT_PROBE_RANK", "0"))
+    eng = ShardedEngine(sc, num_parts=nparts, seed=20261001, rank=rank, world=world, device_tree=world > 1, allreduce=lambda a, op: a, allgather_bytes=lambda b: [b])
+    eng.setup()
+    lib = d.load_library()
+    lib.emat_debug_fn_ticks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.emat_debug_phase_ticks.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    buf = (C.c_uint64 * 12288)()
+    eng.backend.run_moves_per_part(moves); eng.backend.synchronize()
+    assert lib.emat_debug_fn_ticks(eng.backend.handle, buf) == 0   # clears
+    ph0 = np.zeros((eng.num_local_parts, 16)); pb = (C.c_int64 * 16)()
+    for p in range(eng.num_local_parts):
+        lib.emat_debug_phase_ticks(eng.backend.handle, p, pb); ph0[p] = list(pb)
+    eng.backend.run_moves_per_part(moves); eng.backend.synchronize()
+    assert lib.emat_debug_fn_ticks(eng.backend.handle, buf) == 0
+    ph1 = np.zeros((eng.num_local_parts, 16))
+    for p in range(eng.num_local_parts):
+        lib.emat_debug_phase_ticks(eng.backend.handle, p, pb); ph1[p] = list(pb)
+    dph = (ph1 - ph0).sum(axis=0)
+    simple, topo = dph[14], dph[15]
+    a = np.array(list(buf), dtype=np.float64).reshape(3 * 2048, 2)
+    files = ["emat_device_core.hpp", "emat_device_spr.hpp", "emat_device_moves.hpp"]
+    src = [open(os.path.join(ROOT, "delphy_amd", "csrc", f)).read().split("\n") for f in files]
+    rows = []
+    for k in np.nonzero(a[:, 1])[0]:
+        f, line = divmod(int(k), 2048)
+        text = src[f][line - 1] if line - 1 < len(src[f]) else "?"
+        import re
+        m = re.search(r"(\w+)\s*\([^()]*(\([^()]*\))?[^()]*\)\s*\{ EMAT_TIMED", text)
+        rows.append((a[k, 0], a[k, 1], (m.group(1) if m else text[:40]) + " (%s:%d)" % (files[f].replace("emat_device_", ""), line)))
+    rows.sort(reverse=True)
+    dticks = sum(eng.backend.part_stats(p)["device_ticks"] for p in range(eng.num_local_parts))
+    print("pass %.2f ms; chains %.3g ticks of 10 ns over both passes" % (eng.backend.last_run_ms(), dticks))
+    print("parts %d, moves %d: simple moves %.3g ticks, topology moves %.3g ticks (%.1f%% of chain time)" % (eng.num_local_parts, moves, simple, topo, 100 * topo / (simple + topo)))
+    ntopo = sum(sum(eng.backend.part_stats(p)["proposed"][3:5]) for p in range(eng.num_local_parts)) / 2.0
+    os.environ["EMAT_PHASE_EXTRA"] = "1"
+    ex = np.zeros(16)
+    for p in range(eng.num_local_parts):
+        lib.emat_debug_phase_ticks(eng.backend.handle, p, pb); ex += np.array(list(pb), dtype=np.float64)
+    del os.environ["EMAT_PHASE_EXTRA"]
+    print("coalescent delta: %.0f calls over both passes, %.2f cells per call" % (ex[14], ex[13] / max(1.0, ex[14])))
+    print("%-62s %10s %12s %10s %8s" % ("function (inclusive)", "% of topo", "calls/tmove", "ticks/call", "% chain"))
+    for t, n, name in rows:
+        print("%-62s %9.1f%% %12.2f %10.0f %7.1f%%" % (name, 100 * t / topo, n / ntopo, t / n, 100 * t / (simple + topo)))
+    eng.close()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "fn":
+    fn_probe()
