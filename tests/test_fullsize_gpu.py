@@ -287,3 +287,40 @@ def test_two_process_cycles_with_the_tree_on_the_devices(tmp_path):
         for cyc in range(cycles):
             assert rel_close(z[r]["c%d_totals" % cyc], np.array(tot[cyc]), 1e-9), (r, cyc)
     single.close()
+
+
+def _rccl_worker(rank, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from delphy_amd.sharding import _torch_collectives
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    allreduce, allgather_bytes = _torch_collectives("cuda:0")
+    x = np.array([1.5, -2.25, 1e300, -1e-300])
+    res = {"min": allreduce(x, "min"), "max": allreduce(x, "max"), "sum": allreduce(x, "sum"),
+           "isum": allreduce(np.array([7, -3, 2**40], np.int64), "sum")}
+    blob = np.frombuffer(os.urandom(100003), np.uint8).copy()
+    got = allgather_bytes(blob)
+    res["gather_ok"] = np.array([len(got) == 1 and np.array_equal(got[0], blob)])
+    empty = allgather_bytes(np.zeros(0, np.uint8))
+    res["empty_ok"] = np.array([len(empty) == 1 and empty[0].shape[0] == 0])
+    dist.barrier(); torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rccl.npz"), **res)
+    dist.destroy_process_group()
+
+
+def test_the_collectives_of_a_sharded_run_over_rccl(tmp_path):
+    """What bench.py --gpus N and ShardedEngine put on the wire, through RCCL itself (backend "nccl") rather than gloo: f64 MIN /
+    MAX / SUM, int64 SUM, the variable-length byte all-gather (empty contributions included) and the barrier.  One rank -- the
+    test box has one GPU and RCCL refuses two ranks on a device -- so this pins dtype / operator support and the device
+    plumbing, not the transport."""
+    import torch.multiprocessing as mp
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_rccl_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    z = np.load(os.path.join(str(tmp_path), "rccl.npz"))
+    x = np.array([1.5, -2.25, 1e300, -1e-300])
+    for k in ("min", "max", "sum"):
+        assert np.array_equal(z[k], x), k
+    assert np.array_equal(z["isum"], np.array([7, -3, 2**40], np.int64))
+    assert bool(z["gather_ok"][0]) and bool(z["empty_ok"][0])
