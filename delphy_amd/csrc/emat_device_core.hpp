@@ -87,11 +87,13 @@ struct Ctx {
   uint32_t a_top, a_end;      // byte offsets from A
   uint32_t sc_top;            // HBM arena bump pointer (byte offset from G)
   bool failed;
+  bool mv_rng_had_spare;      // RNG position at the first draw of the current move: (mv_rng_ctr, mv_rng_had_spare), see stop_for_cells
   // statistics
   int64_t bytes;
   // trace of the current move
   double tr_kind, tr_node, tr_acc, tr_log_mh;
   int64_t moves_left;         // moves of the current launch still to do (run_chain_loop keeps nothing in registers across a move)
+  uint64_t mv_rng_ctr;
 };
 
 static_assert(sizeof(Ctx) + 16 <= k_lds_ctx_bytes, "context outgrew its LDS slot (the last 16 bytes are the kernel's flag word)");
@@ -161,6 +163,11 @@ EMAT_D uint64_t rng_next64(Ctx& c) {
   c.rng_spare = (uint64_t)w[2] | ((uint64_t)w[3] << 32); c.rng_has_spare = true;
   return (uint64_t)w[0] | ((uint64_t)w[1] << 32);
 }
+// Rewind the stream to where the current move drew its first number (the spare half-block is recomputed, not stored).
+EMAT_DN void rng_rewind_to_move_start(Ctx& c) {
+  c.rng_ctr = c.mv_rng_ctr; c.rng_has_spare = c.mv_rng_had_spare;
+  if (c.rng_has_spare) { uint32_t w[4]; philox4x32_10(c.rng_ctr - 1, c.rng_key, w); c.rng_spare = (uint64_t)w[2] | ((uint64_t)w[3] << 32); }
+}
 EMAT_D double to_co(uint64_t a) { return (double)(a >> 11) * 0x1.0p-53; }
 EMAT_D double to_oo(uint64_t a) { return ((double)(a >> 12) + 0.5) * 0x1.0p-52; }
 EMAT_D double to_oc(uint64_t a) { return ((double)(a >> 11) + 1.0) * 0x1.0p-53; }
@@ -211,7 +218,7 @@ template <class T> EMAT_D SVec<T> sc_vec(Ctx& c, int cap, int line = __builtin_L
   v.p = (T*)(c.G + c.sc_top); v.cap = cap; c.sc_top += b;
   return v;
 }
-template <class T> EMAT_D void push(Ctx& c, SVec<T>& v, const T& x) { if (v.n < v.cap) v.p[v.n++] = x; else EMAT_FAIL(c, k_part_overflow); }
+template <class T> EMAT_D void push(Ctx& c, SVec<T>& v, const T& x, int line = __builtin_LINE()) { if (v.n < v.cap) v.p[v.n++] = x; else fail_at(c, k_part_overflow, line); }   // reports the caller's line
 // An open-ended vector: takes (up to `max_elems` of) the free space of one arena -- the LDS arena when it still
 // has at least `min_lds_elems` elements of room, else the HBM arena -- and must be trimmed with sc_trim.
 template <class T> EMAT_D SVec<T> sc_open(Ctx& c, int max_elems, int min_lds_elems) {
@@ -708,6 +715,22 @@ EMAT_DN void coal_grow(Ctx& c, int cell) {
       hdr_of(c)->n_cells_total = i + 1; hdr_of(c)->n_cells = w + 1;
     }
   }
+}
+// The root part's grid grows towards the past when a move puts a coalescence beyond its last cell (coal_grow), and the
+// slab holds room for `cell_cap` cells.  The moves that can do that ask BEFORE they change anything whether the new time
+// fits; when it does not, the part stops as if the move had never started -- its bookkeeping undone, the RNG rewound to
+// the move's first draw -- with k_part_need_cells, the host re-materialises the part with more cells, and the move runs
+// again from the same stream position: the chain stays the chain the reference's unbounded vectors would give.
+EMAT_DF bool coal_needs_cells(const Ctx& c, double t) {
+  if (!c.includes_run_root) return false;
+  const int cell = cell_for(c, t);
+  return cell >= hdr_of(c)->n_cells_total && cell - hdr_of(c)->cell_first >= hdr_of(c)->cell_cap;
+}
+EMAT_DN void stop_for_cells(Ctx& c, int kind) {
+  rng_rewind_to_move_start(c);
+  hdr_of(c)->proposed[kind]--;
+  c.failed = true;
+  if (hdr_of(c)->status == 0) hdr_of(c)->status = k_part_need_cells;
 }
 // cpp:37-79 on k_bar_p
 EMAT_DF void coal_add_interval(Ctx& c, double t_start, double t_end, double delta_k) {

@@ -38,6 +38,7 @@ EMAT_NOTAIL EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new
   const int old_S = sibling_of(c, P, X);
   const double new_t_P = new_t;
   if (new_t_P == t_X || new_t_P == nodes_of(c)[new_branch].t || (P != hdr_of(c)->root && new_t_P == nodes_of(c)[nodes_of(c)[P].parent].t)) return;
+  if (coal_needs_cells(c, new_t_P)) { stop_for_cells(c, (int)c.tr_kind); return; }   // before the graft is peeled: nothing has changed yet
   c.mu_prop = nodes_of(c)[hdr_of(c)->root].lambda / (c.L - nodes_of(c)[hdr_of(c)->root].n_missing);
   EMAT_PHASE_BEGIN();
   Graft old_graft = analyze_graft(c, X);
@@ -117,6 +118,7 @@ template <bool kRoot> EMAT_DN void inner_node_displace_move(Ctx& c) {   // subru
     log_alpha_ratio = d_logG_dt * (new_t - old_t);
   }
   if (new_t == t_min || new_t == t_max) return;
+  if (kRoot) { if (coal_needs_cells(c, new_t)) { stop_for_cells(c, k_inner_node_displace); return; } }   // nothing has changed yet
   double delta_log_G = d_logG_dt * (new_t - old_t);
   double delta_log_prior = coal_delta_displace_coalescence<kRoot>(c, old_t, new_t);
   if (c.failed) return;
@@ -353,6 +355,7 @@ EMAT_NOTAIL EMAT_DN void spr1_move_propose(Ctx& c) { EMAT_TIMED(2);
   if (c.failed) return;
   EMAT_PHASE(c, 7);
   if (new_t_P == fr.t_X || new_t_P == t_new_S || new_t_P == t_new_G) { apply_graft(c, fr.old_graft); return; }
+  if (coal_needs_cells(c, new_t_P)) { apply_graft(c, fr.old_graft); if (!c.failed) stop_for_cells(c, k_spr1); return; }   // the old graft goes back on, as after a rejection
   spr_move_topology(c, X, new_S, new_t_P);
   EMAT_PHASE(c, 8);
   fr.new_graft = propose_new_graft(c, X);
@@ -456,6 +459,7 @@ EMAT_NOTAIL EMAT_D bool mcmc_sub_iteration(Ctx& c) {
     }
   }
   sc_reset(c);
+  c.mv_rng_ctr = c.rng_ctr; c.mv_rng_had_spare = c.rng_has_spare;
   c.tr_kind = -1.0; c.tr_node = -1.0; c.tr_acc = 0.0; c.tr_log_mh = __builtin_nan("");
   if (c.only_displacing_inner_nodes) { if (c.includes_run_root) inner_node_displace_move<true>(c); else inner_node_displace_move<false>(c); }
   else {
@@ -473,6 +477,7 @@ EMAT_NOTAIL EMAT_D bool mcmc_sub_iteration(Ctx& c) {
 #endif
   if (c.svc != 0 && !c.failed) return true;   // parked: the move is not over
   c.phase = 0; c.svc = 0;
+  if (hdr_of(c)->status == k_part_need_cells) return false;   // stopped before the move changed anything (stop_for_cells): not a move
   if (hdr_of(c)->trace_len < hdr_of(c)->trace_cap) {
     double* tr = (double*)(slab_of(c) + hdr_of(c)->off_trace) + 4 * hdr_of(c)->trace_len;
     tr[0] = c.tr_kind; tr[1] = c.tr_node; tr[2] = c.tr_acc; tr[3] = c.tr_log_mh;

@@ -358,7 +358,11 @@ EMAT_DN void sample_site_trajectory(Ctx& c, SVec<MutRec>& out, int l, int from, 
 }
 // spr_move.cpp:1164-1370; result appended into a fresh open-ended scratch vector (caller trims)
 EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double mu, const SVec<SdRec>& deltas) { EMAT_TIMED(1);
-  SVec<MutRec> out = sc_open<MutRec>(c, 4096, 4 * deltas.n + 48 + 36);   // + the staging area of sample_site_trajectory
+  // room: the constrained sites (one mutation each, rarely three), the L (mu T)^2 / 2 other sites expected to be hit twice or
+  // more on a long branch, and the staging area of sample_site_trajectory; the LDS arena only if it holds all that
+  const double twice = 0.5 * (double)L * (mu * T) * (mu * T);
+  const int want = 4 * deltas.n + 48 + 36 + (twice < 1e6 ? (int)(3.0 * twice + 6.0 * sqrt(3.0 * twice)) : (1 << 20));
+  SVec<MutRec> out = sc_open<MutRec>(c, want > 2048 ? 2 * want : 4096, want);
   if (c.failed) return out;
   if (deltas.n != 0) {
     KTruncPoisson ge1 = ktp_make(mu * T, 1);
@@ -387,7 +391,10 @@ EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double m
 }
 // spr_move.cpp:1372-1407
 EMAT_DN SVec<MutRec> sample_unconstrained_mutational_history(Ctx& c, int L, double T, double mu) { EMAT_TIMED(1);
-  SVec<MutRec> out = sc_open<MutRec>(c, 4096, 96);
+  // about mu L T mutations: the LDS arena only if it has room for that many and their spread, else the part's HBM scratch
+  const double expect = mu * (double)L * T;
+  const int want = expect < 1e6 ? (int)(expect + 6.0 * sqrt(expect)) + 96 : (1 << 20);
+  SVec<MutRec> out = sc_open<MutRec>(c, want > 2048 ? 2 * want : 4096, want);
   if (c.failed) return out;
   double t = 0.0;
   int guard = 0;

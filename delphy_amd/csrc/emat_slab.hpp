@@ -27,8 +27,9 @@ enum PartStatus : int32_t {
   k_part_overflow = 102,       // a container overflowed INSIDE a move (state is not trustworthy)
   k_part_cell_overflow = 103,  // root part needed more coalescent cells than its capacity
   k_part_internal = 104,       // an invariant that the reference CHECKs failed
-  k_part_need_cells = 105      // reported for 103 when the part ran on a staged copy: its slab in HBM is still the state the launch
-                               // found (a consistent one, before a move), so the host can give it more cells and run its moves again
+  k_part_need_cells = 105      // stopped BEFORE a move that would have grown the root part's grid past its capacity (state is consistent,
+                               // the move undone and its RNG rewound: stop_for_cells); also reported for a 103 of a staged first leg, whose
+                               // slab in HBM is still the state the launch found.  The host gives the part more cells and runs the rest.
 };
 
 enum SlabFlags : uint32_t { k_flag_includes_run_root = 1u };

@@ -190,6 +190,79 @@ def test_parts_that_run_out_of_slab_space_are_regrown_and_finish(monkeypatch):
     run_parity(sc, 2, 4000, trace=4000)   # the trace survives the re-materialisation too
 
 
+@pytest.mark.parametrize("use_lds", [True, False])
+def test_root_grid_outgrowing_its_slab_room_stops_before_the_move_and_is_regrown(use_lds):
+    """The reference's coalescent vectors grow without bound when the root moves into the past (very_scalable_coalescent.cpp:
+    259-299); a slab holds room for a fixed number of cells.  With almost no signal in the data (60 sites, a handful of
+    mutations) one root move can displace the root by the whole span of the tree -- hundreds of cells at this cell width.
+    The moves that can do that ask before they change anything, the part stops with the move undone and its RNG rewound, the
+    host re-materialises it with more cells and the move runs again: the chain is still the oracle's, move for move, for the
+    staged part and for the part run from HBM (which has no earlier copy to fall back on)."""
+    import delphy_amd.engine as e
+    from delphy_amd.scenarios import Scenario, KAPPA, PI
+    par = e.SynthParams(num_tips=120, num_sites=60, tip_span=30.0, pop_n0=400.0, pop_growth=0.0, mu=2e-5, gaps_per_tip=1, mean_gap_len=4.0, seed=3)
+    par.pi, par.kappa = PI, KAPPA
+    tree, ref, tmax = e.make_synthetic_emat(par)
+    sc = Scenario("deep-root", tree, ref, tmax, par.mu, KAPPA, PI, d.PopModel.exp(tmax, 400.0, 0.0, 0.0), 60)
+    t_step = sc.default_t_step() * 0.25
+    for nparts in (1, 5):
+        parts, incl, seeds, root_part, ref2 = split_parts(sc, nparts, 7)
+        orc = OracleEngine(sc.num_sites)
+        configure(orc, sc, ref2, parts, incl, seeds, root_part, t_step)
+        cells0 = orc.part_coalescent(root_part)["k_bar_p"].shape[0]
+        orc.run_moves_per_part(4000, threads=1)
+        cells1 = orc.part_coalescent(root_part)["k_bar_p"].shape[0]
+        orc.close()
+        assert cells1 > cells0 + max(512, cells0), (cells0, cells1)   # past the room a freshly cut slab has: the device must have regrown it
+        run_parity(sc, nparts, 4000, seed=7, trace=4000, use_lds=use_lds, t_step=t_step)
+
+
+def test_randomised_scenarios_move_for_move():
+    """A seeded sweep over what the fixed scenarios hold constant: tree size, genome length, mutation density, gap density,
+    tip-date uncertainty, the population model (constant / exponential with a floor / skygrid staircase / skygrid
+    log-linear with an irregular knot spacing), the coalescent cell width, the number of parts and LDS staging on / off.
+    Every case is compared move for move (trace) and quantity for quantity like the fixed ones."""
+    import delphy_amd.engine as e
+    from delphy_amd.scenarios import Scenario, KAPPA, PI
+    rng = np.random.default_rng(20261002)
+    kinds = 0
+    for case in range(20):
+        tips = int(rng.integers(12, 320))
+        sites = int(rng.choice([60, 300, 2000, 9000]))
+        span = float(rng.choice([30.0, 365.0, 1500.0]))
+        mu = float(10 ** rng.uniform(-3.6, -2.0)) / 365.0 * (30000.0 / max(sites, 300)) ** 0.5
+        par = e.SynthParams(num_tips=tips, num_sites=sites, tip_span=span, pop_n0=float(10 ** rng.uniform(1.5, 3.5)), pop_growth=float(rng.choice([0.0, 1.0, 5.0])) / 365.0,
+                            mu=mu, gaps_per_tip=int(rng.integers(0, 5)), mean_gap_len=float(max(2.0, sites * 10 ** rng.uniform(-2.5, -0.8))), seed=int(rng.integers(1, 2**31)))
+        par.pi, par.kappa = PI, KAPPA
+        if rng.random() < 0.5:
+            par.frac_uncertain_tips, par.tip_date_uncertainty = float(rng.uniform(0.05, 0.6)), float(rng.uniform(0.5, 20.0))
+        tree, ref, tmax = e.make_synthetic_emat(par)
+        while tree.mut_site.shape[0] > 40 * tips:   # keep the densest case at ~40 mutations per tip: beyond that a move takes the device milliseconds
+            mu /= 4.0; par.mu = mu
+            tree, ref, tmax = e.make_synthetic_emat(par)
+        kind = case % 4
+        if kind == 0:
+            pop = d.PopModel.exp(tmax, par.pop_n0, 0.0, 0.0)
+        elif kind == 1:
+            pop = d.PopModel.exp(tmax, par.pop_n0, float(rng.uniform(0.2, 4.0)) / 365.0, float(rng.choice([0.0, 1.0, par.pop_n0 / 50])))
+        else:
+            knots = int(rng.integers(2, 40))
+            x = np.sort(tmax - span * 1.3 * rng.uniform(0.0, 1.0, knots)); x[-1] = tmax
+            x = np.unique(x)
+            gamma = np.log(par.pop_n0) + rng.normal(0.0, 0.5, x.shape[0])
+            pop = d.PopModel.skygrid(x, gamma, log_linear=(kind == 3))
+        sc = Scenario("R%d" % case, tree, ref, tmax, mu, KAPPA, PI, pop, sites)
+        nparts = int(min(max(1, tips // 12), rng.integers(1, 14)))
+        t_step = sc.default_t_step() * float(rng.choice([0.25, 1.0, 4.0]))
+        seed = int(rng.integers(1, 10**6))
+        try:
+            run_parity(sc, nparts, 1500, seed=seed, trace=1500, use_lds=bool(case % 5), t_step=t_step)
+        except Exception as ex:
+            raise AssertionError("case %d (tips %d, sites %d, span %g, pop kind %d, parts %d, t_step %g, seed %d): %s" % (case, tips, sites, span, kind, nparts, t_step, seed, ex)) from ex
+        kinds |= 1 << kind
+    assert kinds == 15
+
+
 def test_device_gamma_q_against_scipy_golden_vectors():
     """The device's own gamma_q / gamma_q_inv (they replace Boost's, whose source is not in the reference tree) swept over
     the same scipy vectors and tolerances the oracle's are pinned to (tests/test_oracle_pinning.py; the reference compares
