@@ -82,6 +82,10 @@ struct KernelArgs {
   // slots better at the end of a pass; the chain -- one RNG stream per part, state in the slab -- is the same chain.
   int32_t chunks, class_count, class_stride;
   int32_t* chunk_done;            // [num_parts], zeroed before the launch
+  // Room for a copy of every slab's persistent prefix, at the slab's own offset: a leg that runs on the HBM slab itself (part
+  // not staged whole) saves it there first, so that a container overflowing INSIDE a move can be answered by putting the
+  // leg's starting state back and asking the host for more room, as for a staged leg (which never touches the HBM copy).
+  uint8_t* snaps;
 };
 
 constexpr int k_wave = 64;
@@ -190,6 +194,9 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
     // fixed-size prefix up to the list heap; scratch always stays in HBM
     const uint32_t staged_bytes = staged ? gh->heap_top : (prefix ? gh->heap_begin : 0u);
     if (staged_bytes) wave_copy16(lds_slab, gslab, staged_bytes, lane);
+    // a leg that works on the HBM slab itself keeps a copy of what it found (header, nodes, cells, trace, lists in use)
+    uint8_t* const snap = (!staged && a.snaps != nullptr) ? a.snaps + a.slab_off[part] : nullptr;
+    if (snap != nullptr) wave_copy16(snap, gslab, (gh->heap_top + 15u) & ~15u, lane);
     __syncthreads();
     SlabHeader* H = (staged || prefix) ? (SlabHeader*)lds_slab : gh;
     // The root part is one chain like any other, but its moves walk long runs of coalescent cells (deep branches span
@@ -218,7 +225,9 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
         init_ctx(c, gslab, gslab, a, tables_staged ? lds_tables : nullptr);
         if (area + a.lds_scratch_bytes != 0) { c.A = lds_slab; c.a_end = area + a.lds_scratch_bytes; }   // nothing of the part is staged: the whole area is arena
       }
-      ((dev::Ctx*)(emat_lds + k_lds_ctx_off))->moves_left = H->status == 0 ? target - (H->moves_done - done_at_start) : 0;   // the three Ctx types share one layout
+      // (a later ticket of a part whose earlier one had to stop does nothing: the host gives the part more room and the rest of its moves)
+      const bool stopped_before = chunk > 0 && a.part_status[part] != 0;
+      ((dev::Ctx*)(emat_lds + k_lds_ctx_off))->moves_left = (H->status == 0 && !stopped_before) ? target - (H->moves_done - done_at_start) : 0;   // the three Ctx types share one layout
       tick0 = wall_clock64();
       if (is_root_part) __builtin_amdgcn_s_setprio(3);
     }
@@ -246,7 +255,7 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
       const int64_t dt = (int64_t)(wall_clock64() - tick0);
       H->device_ticks += dt;
       a.part_ticks[part] += dt;
-      a.part_status[part] = H->status;
+      if (!(chunk > 0 && a.part_status[part] != 0)) a.part_status[part] = H->status;   // an idle ticket leaves the earlier ticket's verdict alone
       int again = 0;
       if (staged) {
         H->heap_end = hbm_heap_end;
@@ -260,6 +269,12 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
         // host re-materialise the part with more cells and run its moves again (first leg only: a second leg follows a
         // write-back).
         else if (H->status == k_part_cell_overflow && leg == 0) { a.part_status[part] = k_part_need_cells; again = 3; }
+        // Anything else that overflowed inside a move of a staged leg (the heap at its full capacity, the scratch region):
+        // the HBM copy is the leg's starting state just the same -- more room from the host, and the moves again.
+        else if (H->status == k_part_overflow) { a.part_status[part] = k_part_need_space; again = 3; }
+      } else if (snap != nullptr && (H->status == k_part_overflow || H->status == k_part_cell_overflow)) {
+        // the leg ran on the HBM slab: its starting state goes back in from the copy taken above
+        a.part_status[part] = H->status == k_part_cell_overflow ? k_part_need_cells : k_part_need_space; again = 4;
       }
       *lds_flag = again;
     }
@@ -269,6 +284,7 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
       if (staged) wave_copy16(gslab, lds_slab, ((const SlabHeader*)lds_slab)->heap_top, lane);
       else if (prefix) wave_copy16(gslab, lds_slab, staged_bytes, lane);
     }
+    if (again_all == 4) { wave_copy16(gslab, snap, (((const SlabHeader*)snap)->heap_top + 15u) & ~15u, lane); break; }
     if (again_all == 0 || again_all == 3) break;
     allow_whole = false;
   }
@@ -732,7 +748,7 @@ struct emat_backend {
   int uploads_expected = 0;
   int root_part = -1;
   PinnedBytes h_slabs;
-  DevBuf<uint8_t> d_slabs; DevBuf<uint64_t> d_slab_off; DevBuf<int32_t> d_order, d_part_status; DevBuf<int64_t> d_part_ticks, d_moves_for_part;
+  DevBuf<uint8_t> d_slabs, d_snaps; DevBuf<uint64_t> d_slab_off; DevBuf<int32_t> d_order, d_part_status; DevBuf<int64_t> d_part_ticks, d_moves_for_part;
   bool slabs_on_device = false;     // device slabs are materialised
   bool host_slabs_current = false;  // h_slabs mirrors the device
   bool derived_valid = false;
@@ -924,7 +940,7 @@ KernelArgs make_args(emat_backend* h) {
   a.evo.ref_sequence = h->d_ref.p; a.evo.partition_for_site = h->d_part.p; a.evo.nu_l = h->d_nu.p; a.evo.cum_Q_l = h->d_cumQ.p;
   a.evo.mu = h->d_mu.p; a.evo.pi = h->d_pi.p; a.evo.q = h->d_q.p;
   a.pop = h->d_pop.p; a.flags = h->flags; a.num_parts = (int)h->parts.size();
-  a.lds_slab_bytes = 0; a.lds_scratch_bytes = 0; a.moves_per_part = 0; a.extra_moves_part0 = 0; a.one_more_below = 0; a.chunks = 1; a.class_count = 0; a.class_stride = 0; a.chunk_done = nullptr;
+  a.lds_slab_bytes = 0; a.lds_scratch_bytes = 0; a.moves_per_part = 0; a.extra_moves_part0 = 0; a.one_more_below = 0; a.chunks = 1; a.class_count = 0; a.class_stride = 0; a.chunk_done = nullptr; a.snaps = nullptr;
   return a;
 }
 
@@ -1243,9 +1259,10 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
   for (int c = 0; c < h->num_classes; ++c)
     if (shmem_for(h->class_lds[c]) > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower EMAT_LDS_MAX or disable use_lds");
   if (!h->order_valid) { st = build_order(h); if (st) return st; }
+  HIP_TRY(h->d_snaps.alloc(h->d_slabs.n));
   KernelArgs a = make_args(h);
   a.moves_per_part = per_part; a.extra_moves_part0 = extra0; a.one_more_below = one_more_below;
-  a.lds_scratch_bytes = lds_scratch;
+  a.lds_scratch_bytes = lds_scratch; a.snaps = h->d_snaps.p;
   if (counts) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(h->d_moves_for_part.upload(counts->data(), counts->size())); a.moves_for_part = h->d_moves_for_part.p; }
   else for (size_t p = 0; p < h->parts.size(); ++p) h->parts[p].expected_moves += per_part + (p == 0 ? extra0 : 0) + ((int64_t)p < one_more_below ? 1 : 0);
   h->pass_pending = true;

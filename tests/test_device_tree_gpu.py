@@ -438,3 +438,52 @@ def test_partition_tree_on_the_device():
     with pytest.raises(d.EmatError, match="EMAT_ERR_INVALID_ARGUMENT"):
         b.tree_partition([int(np.flatnonzero(c0 < 0)[0])])        # a tip is not a cut point
     b.close()
+
+
+def test_randomised_cycles_with_the_tree_in_hbm_equal_the_host_cycles():
+    """The cycle test above over a seeded sweep of what it holds constant: tree size (down to a dozen tips), genome length,
+    mutation and gap density, tip-date uncertainty, population model, number of parts (one part up to as many as the tree
+    yields), moves per cycle.  Same seeds => the tree and the reference that come back from HBM are the host cycle's."""
+    import delphy_amd.engine as e
+    from delphy_amd.scenarios import Scenario, KAPPA, PI
+    rng = np.random.default_rng(20261003)
+    for case in range(14):
+        tips = int(rng.integers(12, 900))
+        sites = int(rng.choice([80, 500, 3000, 29903]))
+        span = float(rng.choice([60.0, 365.0, 900.0]))
+        mu = float(10 ** rng.uniform(-3.4, -2.3)) / 365.0 * (30000.0 / max(sites, 300)) ** 0.5
+        par = e.SynthParams(num_tips=tips, num_sites=sites, tip_span=span, pop_n0=float(10 ** rng.uniform(1.5, 3.0)), pop_growth=float(rng.choice([0.0, 2.0])) / 365.0,
+                            mu=mu, gaps_per_tip=int(rng.integers(0, 4)), mean_gap_len=float(max(2.0, sites * 10 ** rng.uniform(-2.5, -1.0))), seed=int(rng.integers(1, 2**31)))
+        par.pi, par.kappa = PI, KAPPA
+        if rng.random() < 0.5:
+            par.frac_uncertain_tips, par.tip_date_uncertainty = float(rng.uniform(0.05, 0.5)), float(rng.uniform(0.5, 10.0))
+        tree, ref, tmax = e.make_synthetic_emat(par)
+        while tree.mut_site.shape[0] > 30 * tips:
+            mu /= 4.0; par.mu = mu
+            tree, ref, tmax = e.make_synthetic_emat(par)
+        kind = case % 3
+        if kind == 0:
+            pop = d.PopModel.exp(tmax, par.pop_n0, 0.0, 0.0)
+        elif kind == 1:
+            pop = d.PopModel.exp(tmax, par.pop_n0, float(rng.uniform(0.2, 3.0)) / 365.0, 1.0)
+        else:
+            x = np.unique(np.append(np.sort(tmax - span * 1.3 * rng.uniform(0.0, 1.0, int(rng.integers(2, 30)))), tmax))
+            pop = d.PopModel.skygrid(x, np.log(par.pop_n0) + rng.normal(0.0, 0.4, x.shape[0]), log_linear=bool(case % 2))
+        sc = Scenario("R%d" % case, tree, ref, tmax, mu, KAPPA, PI, pop, sites)
+        parts = int(rng.choice([1, 2, 7, 32, 4096]))
+        seed = int(rng.integers(1, 10**6))
+        per_cycle = int(rng.choice([500, 5000, 20 * tips]))
+        what = "case %d (tips %d, sites %d, parts %d, pop kind %d, seed %d, %d moves per cycle)" % (case, tips, sites, parts, kind, seed, per_cycle)
+        bh, rh = _run(sc, seed, parts, False)
+        bd, rd = _run(sc, seed, parts, True)
+        try:
+            for cycle in range(4):
+                rh.do_mcmc_steps(per_cycle, per_cycle); rd.do_mcmc_steps(per_cycle, per_cycle)
+                th, refh = rh.tree(); td, refd = rd.tree()
+                _same_tree(th, td, "%s cycle %d" % (what, cycle))
+                assert np.array_equal(refh, refd), (what, cycle)
+        except d.EmatError as ex:
+            raise AssertionError("%s: %s" % (what, ex)) from ex
+        finally:
+            for r in (rh, rd): r.close()
+            for b in (bh, bd): b.close()

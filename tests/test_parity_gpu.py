@@ -191,6 +191,23 @@ def test_parts_that_run_out_of_slab_space_are_regrown_and_finish(monkeypatch):
 
 
 @pytest.mark.parametrize("use_lds", [True, False])
+def test_containers_overflowing_inside_a_move_are_answered_with_more_room(monkeypatch, use_lds):
+    """With no slack at all and 1 KB of reserve, single moves need more list heap than the check before the move holds back
+    (status 102, INSIDE a move).  A staged leg never touched the HBM copy of its slab; a leg that runs on the HBM slab
+    itself (here: staging switched off) took a copy of its starting state first.  Either way the part's starting state is
+    what the host finds, it doubles the room and runs the moves again: a complete pass, still the oracle's chain."""
+    import delphy_amd.engine as e
+    monkeypatch.setenv("EMAT_SLACK", "1.0")
+    monkeypatch.setenv("EMAT_HEAP_PER_NODE", "0")
+    par = e.SynthParams(num_tips=60, num_sites=9000, tip_span=30.0, pop_n0=300.0, pop_growth=0.0, mu=6e-3 / 365.0, gaps_per_tip=1, mean_gap_len=60.0, seed=99)
+    from delphy_amd.scenarios import Scenario, KAPPA, PI
+    par.pi, par.kappa = PI, KAPPA
+    tree, ref, tmax = e.make_synthetic_emat(par)
+    sc = Scenario("tight", tree, ref, tmax, par.mu, KAPPA, PI, d.PopModel.exp(tmax, 300.0, 1.0 / 365.0, 1.0), 9000)
+    run_parity(sc, 3, 3000, seed=5, trace=3000, use_lds=use_lds)
+
+
+@pytest.mark.parametrize("use_lds", [True, False])
 def test_root_grid_outgrowing_its_slab_room_stops_before_the_move_and_is_regrown(use_lds):
     """The reference's coalescent vectors grow without bound when the root moves into the past (very_scalable_coalescent.cpp:
     259-299); a slab holds room for a fixed number of cells.  With almost no signal in the data (60 sites, a handful of
@@ -220,7 +237,8 @@ def test_root_grid_outgrowing_its_slab_room_stops_before_the_move_and_is_regrown
 def test_randomised_scenarios_move_for_move():
     """A seeded sweep over what the fixed scenarios hold constant: tree size, genome length, mutation density, gap density,
     tip-date uncertainty, the population model (constant / exponential with a floor / skygrid staircase / skygrid
-    log-linear with an irregular knot spacing), the coalescent cell width, the number of parts and LDS staging on / off.
+    log-linear with an irregular knot spacing), the coalescent cell width, site-rate heterogeneity, one or two site
+    partitions, the number of parts and LDS staging on / off.
     Every case is compared move for move (trace) and quantity for quantity like the fixed ones."""
     import delphy_amd.engine as e
     from delphy_amd.scenarios import Scenario, KAPPA, PI
@@ -255,8 +273,15 @@ def test_randomised_scenarios_move_for_move():
         nparts = int(min(max(1, tips // 12), rng.integers(1, 14)))
         t_step = sc.default_t_step() * float(rng.choice([0.25, 1.0, 4.0]))
         seed = int(rng.integers(1, 10**6))
+        nu_l = 0.2 + 1.8 * rng.random(sites) if case % 3 == 1 else None                  # site-rate heterogeneity
+        evo = None
+        if case % 6 == 5:                                                                 # two site partitions with their own mu and HKY tables
+            pi2 = rng.dirichlet([4.0, 4.0, 4.0, 4.0])
+            evo = (np.array([mu, float(rng.uniform(0.3, 3.0)) * mu]), np.stack([np.asarray(PI, np.float64), pi2]),
+                   np.stack([d.hky_q_matrix(KAPPA, PI), d.hky_q_matrix(float(rng.uniform(1.0, 8.0)), pi2)]),
+                   (np.arange(sites) // max(1, sites // 7) % 2).astype(np.int32))
         try:
-            run_parity(sc, nparts, 1500, seed=seed, trace=1500, use_lds=bool(case % 5), t_step=t_step)
+            run_parity(sc, nparts, 1500, seed=seed, trace=1500, use_lds=bool(case % 5), t_step=t_step, nu_l=nu_l, evo=evo)
         except Exception as ex:
             raise AssertionError("case %d (tips %d, sites %d, span %g, pop kind %d, parts %d, t_step %g, seed %d): %s" % (case, tips, sites, span, kind, nparts, t_step, seed, ex)) from ex
         kinds |= 1 << kind
