@@ -483,15 +483,16 @@ emat_status gt_root_deltas(emat_backend* h, std::vector<GRootDelta>& rd, bool& o
   rd.clear();
   if (!owner) return EMAT_OK;
   HIP_TRY(G.root_deltas.alloc(k_gt_max_root_deltas)); HIP_TRY(G.n_root_deltas.alloc(1));
-  HIP_TRY(hipMemsetAsync(G.status.p, 0, sizeof(int32_t), h->stream));
-  HIP_TRY(hipMemsetAsync(G.n_root_deltas.p, 0, sizeof(int32_t), h->stream));
-  hipLaunchKernelGGL(k_gt_root_deltas, dim3(1), dim3(k_wave), 0, h->stream, (const uint8_t*)h->d_slabs.p, (const uint64_t*)h->d_slab_off.p, G.root_part - G.lo, G.root_deltas.p, G.n_root_deltas.p, G.status.p);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  int32_t status = 0, nd = 0;
-  HIP_TRY(hipMemcpy(&status, G.status.p, sizeof(status), hipMemcpyDeviceToHost));
-  if (status != k_gt_ok) return fail(h, EMAT_ERR_CAPACITY, std::string("emat_tree_reassemble: ") + gt_status_text(status));
-  HIP_TRY(hipMemcpy(&nd, G.n_root_deltas.p, sizeof(nd), hipMemcpyDeviceToHost));
+  int32_t nd = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {   // nearly always a handful; a cycle that changed more root sites than there is room gets the room and is read again
+    HIP_TRY(hipMemsetAsync(G.n_root_deltas.p, 0, sizeof(int32_t), h->stream));
+    hipLaunchKernelGGL(k_gt_root_deltas, dim3(1), dim3(k_wave), 0, h->stream, (const uint8_t*)h->d_slabs.p, (const uint64_t*)h->d_slab_off.p, G.root_part - G.lo, G.root_deltas.p, (int)G.root_deltas.n, G.n_root_deltas.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(&nd, G.n_root_deltas.p, sizeof(nd), hipMemcpyDeviceToHost));
+    if ((size_t)nd <= G.root_deltas.n) break;
+    HIP_TRY(G.root_deltas.alloc((size_t)nd));
+  }
   rd.resize((size_t)nd);
   if (nd > 0) HIP_TRY(hipMemcpy(rd.data(), G.root_deltas.p, (size_t)nd * sizeof(GRootDelta), hipMemcpyDeviceToHost));
   return EMAT_OK;
@@ -502,8 +503,8 @@ emat_status gt_gather_local(emat_backend* h, const std::vector<GRootDelta>& rd) 
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   GTreeHost& G = h->gt;
   const int nloc = G.hi - G.lo;
-  HIP_TRY(G.root_deltas.alloc(k_gt_max_root_deltas)); HIP_TRY(G.n_root_deltas.alloc(1)); HIP_TRY(G.root_deltas_in.alloc(k_gt_max_root_deltas));
-  if ((int)rd.size() > k_gt_max_root_deltas) return fail(h, EMAT_ERR_CAPACITY, std::string("emat_tree_reassemble: ") + gt_status_text(k_gt_root_deltas_overflow));
+  const size_t room = std::max<size_t>(rd.size(), (size_t)k_gt_max_root_deltas);
+  HIP_TRY(G.root_deltas.alloc(room)); HIP_TRY(G.n_root_deltas.alloc(1)); HIP_TRY(G.root_deltas_in.alloc(room));
   if (!rd.empty()) HIP_TRY(hipMemcpy(G.root_deltas_in.p, rd.data(), rd.size() * sizeof(GRootDelta), hipMemcpyHostToDevice));
   int32_t status = 0;
   for (int attempt = 0;; ++attempt) {

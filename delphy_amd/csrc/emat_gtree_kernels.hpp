@@ -68,7 +68,7 @@ struct GCoal {                       // the whole grid, built on the device (nul
 
 constexpr int k_gt_max_cut_intervals = 1024, k_gt_small_cut_intervals = 256;
 constexpr int k_gt_max_cut_deltas = 1024, k_gt_small_cut_deltas = 256;
-constexpr int k_gt_max_root_deltas = 256;
+constexpr int k_gt_max_root_deltas = 256;   // how many changes of the root sequence k_gt_gather caches in LDS (more are read from HBM)
 constexpr uint32_t k_gt_max_list = 16000;   // ListRef counts are 16 bits (same limit as emat_part_upload)
 
 __device__ inline uint32_t gt_a16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -447,9 +447,10 @@ __global__ void __launch_bounds__(k_wave) k_gt_gather(GTreeDev g, GPartition pt,
   const SlabHeader* H = (const SlabHeader*)slab;
   const NodeRec* N = (const NodeRec*)(slab + H->off_nodes);
   const bool is_root_part = p == pt.root_part;
+  const GRootDelta* Rp = R;   // the changes of the root sequence: in LDS when they fit (nearly always a handful), else read where they lie
   if (R_in != nullptr) {
-    if (nR_in > k_gt_max_root_deltas) { if (lane == 0) atomicMax(status_out, (int32_t)k_gt_root_deltas_overflow); return; }
-    for (int k = lane; k < nR_in; k += k_wave) R[k] = R_in[k];
+    if (nR_in > k_gt_max_root_deltas) Rp = R_in;
+    else for (int k = lane; k < nR_in; k += k_wave) R[k] = R_in[k];
     if (lane == 0) sh_nR = nR_in;
   } else {
     const uint8_t* rs = slabs + slab_off[pt.root_part - part_base];
@@ -472,7 +473,7 @@ __global__ void __launch_bounds__(k_wave) k_gt_gather(GTreeDev g, GPartition pt,
     if (is_lr && !is_root_part) continue;
     const NodeRec& r = N[s];
     tm += is_lr ? 0u : r.muts.cnt; ti += r.miss.cnt;
-    tf += gt_rereferenced_from_states((const FsRec*)(slab + r.mfs.off), r.mfs.cnt, (const IvRec*)(slab + r.miss.off), r.miss.cnt, R, nR, nullptr);
+    tf += gt_rereferenced_from_states((const FsRec*)(slab + r.mfs.off), r.mfs.cnt, (const IvRec*)(slab + r.miss.off), r.miss.cnt, Rp, nR, nullptr);
   }
   tm = wave_sum_u32(tm); ti = wave_sum_u32(ti); tf = wave_sum_u32(tf);
   if (lane == 0) {
@@ -491,7 +492,7 @@ __global__ void __launch_bounds__(k_wave) k_gt_gather(GTreeDev g, GPartition pt,
       if (owns) {
         const NodeRec& r = N[s];
         nm = is_lr ? 0u : r.muts.cnt; ni = r.miss.cnt;
-        nf = gt_rereferenced_from_states((const FsRec*)(slab + r.mfs.off), r.mfs.cnt, (const IvRec*)(slab + r.miss.off), r.miss.cnt, R, nR, nullptr);
+        nf = gt_rereferenced_from_states((const FsRec*)(slab + r.mfs.off), r.mfs.cnt, (const IvRec*)(slab + r.miss.off), r.miss.cnt, Rp, nR, nullptr);
       }
     }
     const uint32_t im = wave_incl_scan_u32(nm, lane), ii = wave_incl_scan_u32(ni, lane), iff = wave_incl_scan_u32(nf, lane);
@@ -506,7 +507,7 @@ __global__ void __launch_bounds__(k_wave) k_gt_gather(GTreeDev g, GPartition pt,
         const MutRec* sm = (const MutRec*)(slab + r.muts.off); const IvRec* si = (const IvRec*)(slab + r.miss.off);
         for (uint32_t k = 0; k < nm; ++k) g.mut_heap[om + k] = sm[k];
         for (uint32_t k = 0; k < ni; ++k) g.iv_heap[oi + k] = si[k];
-        gt_rereferenced_from_states((const FsRec*)(slab + r.mfs.off), r.mfs.cnt, si, r.miss.cnt, R, nR, g.fs_heap + of);
+        gt_rereferenced_from_states((const FsRec*)(slab + r.mfs.off), r.mfs.cnt, si, r.miss.cnt, Rp, nR, g.fs_heap + of);
       }
       if (r.child0 != EMAT_NO_NODE) {
         const int32_t l = pt.orig[base + r.child0], rr = pt.orig[base + r.child1];
@@ -517,21 +518,21 @@ __global__ void __launch_bounds__(k_wave) k_gt_gather(GTreeDev g, GPartition pt,
   if (is_root_part && lane == 0) {
     const int32_t nr = pt.orig[base + local_root];
     g.root[0] = nr; g.parent[nr] = EMAT_NO_NODE;
-    for (int k = 0; k < nR; ++k) { ref[R[k].site] = R[k].to; root_deltas_out[k] = R[k]; }
+    for (int k = 0; k < nR; ++k) { ref[Rp[k].site] = Rp[k].to; root_deltas_out[k] = Rp[k]; }
     n_root_deltas_out[0] = nR;
   }
 }
 
 // ---- one run over several processes, every one with the whole tree in its HBM: after gathering its own parts a process
 //      hands the nodes it owns to the others (compact per-node arrays + its three heap segments) and takes theirs -------------
-__global__ void __launch_bounds__(k_wave) k_gt_root_deltas(const uint8_t* slabs, const uint64_t* slab_off, int root_slab, GRootDelta* out, int32_t* n_out, int32_t* status_out) {
+// Writes as many of the changes as `out` holds (`cap`) and reports how many there are: the caller comes again with more room.
+__global__ void __launch_bounds__(k_wave) k_gt_root_deltas(const uint8_t* slabs, const uint64_t* slab_off, int root_slab, GRootDelta* out, int cap, int32_t* n_out) {
   const uint8_t* rs = slabs + slab_off[root_slab];
   const SlabHeader* Hr = (const SlabHeader*)rs;
   const NodeRec& rn = ((const NodeRec*)(rs + Hr->off_nodes))[Hr->root];
   const int nR = rn.muts.cnt;
-  if (nR > k_gt_max_root_deltas) { if (threadIdx.x == 0) atomicMax(status_out, (int32_t)k_gt_root_deltas_overflow); return; }
   const MutRec* M = (const MutRec*)(rs + rn.muts.off);
-  for (int k = threadIdx.x; k < nR; k += k_wave) { GRootDelta d{}; d.site = M[k].site; d.from = M[k].from; d.to = M[k].to; out[k] = d; }
+  for (int k = threadIdx.x; k < nR && k < cap; k += k_wave) { GRootDelta d{}; d.site = M[k].site; d.from = M[k].from; d.to = M[k].to; out[k] = d; }
   if (threadIdx.x == 0) n_out[0] = nR;
 }
 // One entry per node of every part the process ran: what the part OWNS of the node (time and lists: every node but the part's

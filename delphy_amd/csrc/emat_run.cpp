@@ -641,8 +641,9 @@ struct RunDriver {
   emat_status reassemble_device() {
     if (!parts_uploaded) return fail(EMAT_ERR_STATE, "repartition first");
     if (shard_world > 1) return fail(EMAT_ERR_STATE, "a sharded run with the tree on the devices gathers in steps, with the exchange between them (emat_tree_get_root_deltas ... emat_tree_reassemble_end, then emat_run_note_device_reassembled)");
-    int32_t nd = 0; int32_t site[256]; uint8_t from[256], to[256];
-    emat_status st = bk(emat_tree_reassemble(backend, &nd, site, from, to, 256)); if (st) return st;
+    int32_t nd = 0;   // at most one change per site
+    std::vector<int32_t> site(ref.size()); std::vector<uint8_t> from(ref.size()), to(ref.size());
+    emat_status st = bk(emat_tree_reassemble(backend, &nd, site.data(), from.data(), to.data(), (int32_t)ref.size())); if (st) return st;
     for (int k = 0; k < nd; ++k) ref[site[k]] = to[k];
     parts_uploaded = false; host_tree_stale = true;
     return EMAT_OK;

@@ -452,7 +452,8 @@ class EmatBackend:
         self._ck(self._lib.emat_tree_repartition(self._h, int(po.shape[0]) - 1, _ptr(po, C.c_int32), _ptr(og, C.c_int32), _ptr(k0, C.c_int32), _ptr(k1, C.c_int32),
                                                  root_part, _ptr(sd, C.c_uint64), C.byref(m), t_step), "emat_tree_repartition")
 
-    def tree_reassemble(self, capacity: int = 256):
+    def tree_reassemble(self, capacity: Optional[int] = None):
+        capacity = self.num_sites if capacity is None else capacity   # at most one change of the root sequence per site
         n = C.c_int32()
         site = np.zeros(capacity, np.int32); frm = np.zeros(capacity, np.uint8); to = np.zeros(capacity, np.uint8)
         self._ck(self._lib.emat_tree_reassemble(self._h, C.byref(n), _ptr(site, C.c_int32), _ptr(frm, C.c_uint8), _ptr(to, C.c_uint8), capacity), "emat_tree_reassemble")
@@ -472,8 +473,9 @@ class EmatBackend:
         assert np.array_equal(np.diff(off), sizes[:n.value])
         return n.value, r.value, off, orig, k0, k1
 
-    def tree_root_deltas(self, capacity: int = 256):
+    def tree_root_deltas(self, capacity: Optional[int] = None):
         """(site, from, to) on the process that holds the root part, None elsewhere."""
+        capacity = self.num_sites if capacity is None else capacity
         n = C.c_int32()
         site = np.zeros(capacity, np.int32); frm = np.zeros(capacity, np.uint8); to = np.zeros(capacity, np.uint8)
         self._ck(self._lib.emat_tree_get_root_deltas(self._h, C.byref(n), _ptr(site, C.c_int32), _ptr(frm, C.c_uint8), _ptr(to, C.c_uint8), capacity), "emat_tree_get_root_deltas")

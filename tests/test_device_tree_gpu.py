@@ -446,8 +446,8 @@ def test_randomised_cycles_with_the_tree_in_hbm_equal_the_host_cycles():
     yields), moves per cycle.  Same seeds => the tree and the reference that come back from HBM are the host cycle's."""
     import delphy_amd.engine as e
     from delphy_amd.scenarios import Scenario, KAPPA, PI
-    rng = np.random.default_rng(20261003)
-    for case in range(14):
+    rng = np.random.default_rng(int(os.environ.get("EMAT_FUZZ_SEED", "20261003")))   # EMAT_FUZZ_SEED / EMAT_FUZZ_CASES: longer hunts by hand
+    for case in range(int(os.environ.get("EMAT_FUZZ_CASES", "14"))):
         tips = int(rng.integers(12, 900))
         sites = int(rng.choice([80, 500, 3000, 29903]))
         span = float(rng.choice([60.0, 365.0, 900.0]))
@@ -487,3 +487,55 @@ def test_randomised_cycles_with_the_tree_in_hbm_equal_the_host_cycles():
         finally:
             for r in (rh, rd): r.close()
             for b in (bh, bd): b.close()
+
+
+@pytest.mark.parametrize("num_changes", [100, 700])
+def test_gather_rereferences_missing_data_for_any_number_of_root_changes(num_changes):
+    """emat_tree_gather_local folds the changes of the root sequence into the reference and re-references every node's missing
+    data (Run::normalize_root -> Missation_map::ref_seq_changed): a missing site whose recorded state now equals the
+    reference loses its record, one that had none (it followed the old reference) gains one with the old state.  The gather
+    caches up to 256 changes in LDS and reads longer lists from HBM: both paths against a restatement in numpy, with changes
+    injected through the C-ABI on a tree whose tips miss a fifth of the genome."""
+    import delphy_amd.engine as e
+    from delphy_amd.scenarios import Scenario, KAPPA, PI
+    par = e.SynthParams(num_tips=150, num_sites=4000, tip_span=200.0, pop_n0=300.0, pop_growth=0.0, mu=2e-3 / 365.0, gaps_per_tip=4, mean_gap_len=200.0, seed=12)
+    par.pi, par.kappa = PI, KAPPA
+    tree, ref, tmax = e.make_synthetic_emat(par)
+    sc = Scenario("gaps", tree, ref, tmax, par.mu, KAPPA, PI, d.PopModel.exp(tmax, 300.0, 0.0, 0.0), 4000)
+    b = d.EmatBackend(sc.num_sites)
+    b.set_ref_sequence(sc.ref); b.set_hky(sc.mu, sc.kappa, sc.pi); b.set_flags(sc.t_max_tip)
+    b.tree_upload(sc.tree)
+    parent, c0, c1, t, root = b.tree_topology()
+    po, orig, k0, k1 = _whole_tree_as_one_part(parent, c0, c1, root)
+    b.tree_repartition(po, orig, k0, k1, 0, [7], sc.pop, sc.default_t_step())
+    rng = np.random.default_rng(num_changes)
+    mutated = set(int(x) for x in sc.tree.mut_site)                     # keep clear of sites that carry mutations: the injected change is not one the moves made
+    site = np.array(sorted(rng.choice([l for l in range(sc.num_sites) if l not in mutated], num_changes, replace=False)), np.int32)
+    frm = sc.ref[site].astype(np.uint8)
+    to = ((frm + rng.integers(1, 4, num_changes)) % 4).astype(np.uint8)
+    assert b.tree_root_deltas()[0].shape[0] == 0                       # no moves were run
+    b.tree_gather_local(site, frm, to)
+    b.tree_reassemble_end()
+    got, got_ref = b.tree_download()
+    want_ref = sc.ref.copy(); want_ref[site] = to
+    assert np.array_equal(got_ref, want_ref)
+    for f in ("parent", "child0", "child1", "t", "mut_offset", "mut_site", "mut_from", "mut_to", "mut_t", "miss_offset", "miss_start", "miss_end"):
+        assert np.array_equal(getattr(got, f), getattr(sc.tree, f)), f
+    touched = 0
+    change = {int(l): (int(a), int(c)) for l, a, c in zip(site, frm, to)}
+    for n in range(sc.tree.num_nodes):
+        iv = [(int(sc.tree.miss_start[k]), int(sc.tree.miss_end[k])) for k in range(sc.tree.miss_offset[n], sc.tree.miss_offset[n + 1])]
+        fs = {int(sc.tree.mfs_site[k]): int(sc.tree.mfs_state[k]) for k in range(sc.tree.mfs_offset[n], sc.tree.mfs_offset[n + 1])}
+        for l, (a, c) in change.items():
+            if any(lo <= l < hi for lo, hi in iv):
+                touched += 1
+                if l in fs:
+                    if fs[l] == c: del fs[l]
+                else:
+                    fs[l] = a
+        lo, hi = got.mfs_offset[n], got.mfs_offset[n + 1]
+        assert list(zip(got.mfs_site[lo:hi].tolist(), got.mfs_state[lo:hi].tolist())) == sorted(fs.items()), n
+    assert touched > num_changes // 4
+    b.close()
+
+

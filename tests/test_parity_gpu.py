@@ -3,6 +3,8 @@
 Bar (BASELINE.json north_star): mutation counts, site indices, states, interval endpoints, topology, move
 decisions and RNG consumption bit-exact; log-posterior quantities and times within 1e-9 relative.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -175,6 +177,33 @@ def test_global_move_statistics():
     _stats_parity(sc, 5, 1000, seed=47, evo=evo, P=2)
 
 
+def test_randomised_global_move_statistics():
+    """The reductions of SURVEY 8(f).1 over the random scenarios of the sweeps (site rates, two partitions, every population
+    model, 1 to 13 parts), before and after moves."""
+    from helpers import random_scenario
+    rng = np.random.default_rng(int(os.environ.get("EMAT_FUZZ_SEED", "20261004")))
+    for case in range(int(os.environ.get("EMAT_FUZZ_CASES", "12"))):
+        sc, nu_l, evo, what = random_scenario(rng, case)
+        nparts = int(min(max(1, sc.tree.num_nodes // 24), rng.integers(1, 14)))
+        parts, incl, seeds, root_part, ref = split_parts(sc, nparts, int(rng.integers(1, 10**6)))
+        gpu = d.EmatBackend(sc.num_sites); orc = OracleEngine(sc.num_sites)
+        P = 2 if evo is not None else 1
+        try:
+            configure(gpu, sc, ref, parts, incl, seeds, root_part, None, nu_l=nu_l, evo=evo)
+            configure(orc, sc, ref, parts, incl, seeds, root_part, None, nu_l=nu_l, evo=evo)
+            for rounds in range(2):
+                Tg, Mg, ng = gpu.global_stats(P)
+                To, Mo, no = orc.global_stats(P)
+                assert ng == no and np.array_equal(Mg, Mo), (what, Mg.tolist(), Mo.tolist())
+                assert rel_close(Tg, To, 1e-9), (what, Tg.tolist(), To.tolist())
+                assert rel_close(np.array(gpu.totals()), np.array(orc.totals()), 1e-9), what
+                gpu.run_moves_per_part(800); gpu.synchronize(); orc.run_moves_per_part(800, threads=4)
+        except d.EmatError as ex:
+            raise AssertionError("%s: %s" % (what, ex)) from ex
+        finally:
+            gpu.close(); orc.close()
+
+
 def test_parts_that_run_out_of_slab_space_are_regrown_and_finish(monkeypatch):
     """A part whose list heap is too small stops BEFORE a move (status 101, state intact); the engine must notice at the
     next synchronisation, give it more room and run the rest of its moves -- the caller sees a complete pass whose
@@ -235,56 +264,25 @@ def test_root_grid_outgrowing_its_slab_room_stops_before_the_move_and_is_regrown
 
 
 def test_randomised_scenarios_move_for_move():
-    """A seeded sweep over what the fixed scenarios hold constant: tree size, genome length, mutation density, gap density,
-    tip-date uncertainty, the population model (constant / exponential with a floor / skygrid staircase / skygrid
-    log-linear with an irregular knot spacing), the coalescent cell width, site-rate heterogeneity, one or two site
-    partitions, the number of parts and LDS staging on / off.
-    Every case is compared move for move (trace) and quantity for quantity like the fixed ones."""
-    import delphy_amd.engine as e
-    from delphy_amd.scenarios import Scenario, KAPPA, PI
-    rng = np.random.default_rng(20261002)
+    """A seeded sweep over what the fixed scenarios hold constant (helpers.random_scenario): tree size, genome length,
+    mutation density, gap density, tip-date uncertainty, the population model (constant / exponential with a floor /
+    skygrid staircase / skygrid log-linear with an irregular knot spacing), site-rate heterogeneity, one or two site
+    partitions -- and here the coalescent cell width, the number of parts and LDS staging on / off.  Every case is compared
+    move for move (trace) and quantity for quantity like the fixed ones.  (This sweep found the two capacity holes that
+    DESIGN.md section 4 describes: a root grid outgrowing its slab and containers overflowing inside a move.)"""
+    from helpers import random_scenario
+    rng = np.random.default_rng(int(os.environ.get("EMAT_FUZZ_SEED", "20261002")))   # EMAT_FUZZ_SEED / EMAT_FUZZ_CASES: longer hunts by hand
     kinds = 0
-    for case in range(20):
-        tips = int(rng.integers(12, 320))
-        sites = int(rng.choice([60, 300, 2000, 9000]))
-        span = float(rng.choice([30.0, 365.0, 1500.0]))
-        mu = float(10 ** rng.uniform(-3.6, -2.0)) / 365.0 * (30000.0 / max(sites, 300)) ** 0.5
-        par = e.SynthParams(num_tips=tips, num_sites=sites, tip_span=span, pop_n0=float(10 ** rng.uniform(1.5, 3.5)), pop_growth=float(rng.choice([0.0, 1.0, 5.0])) / 365.0,
-                            mu=mu, gaps_per_tip=int(rng.integers(0, 5)), mean_gap_len=float(max(2.0, sites * 10 ** rng.uniform(-2.5, -0.8))), seed=int(rng.integers(1, 2**31)))
-        par.pi, par.kappa = PI, KAPPA
-        if rng.random() < 0.5:
-            par.frac_uncertain_tips, par.tip_date_uncertainty = float(rng.uniform(0.05, 0.6)), float(rng.uniform(0.5, 20.0))
-        tree, ref, tmax = e.make_synthetic_emat(par)
-        while tree.mut_site.shape[0] > 40 * tips:   # keep the densest case at ~40 mutations per tip: beyond that a move takes the device milliseconds
-            mu /= 4.0; par.mu = mu
-            tree, ref, tmax = e.make_synthetic_emat(par)
-        kind = case % 4
-        if kind == 0:
-            pop = d.PopModel.exp(tmax, par.pop_n0, 0.0, 0.0)
-        elif kind == 1:
-            pop = d.PopModel.exp(tmax, par.pop_n0, float(rng.uniform(0.2, 4.0)) / 365.0, float(rng.choice([0.0, 1.0, par.pop_n0 / 50])))
-        else:
-            knots = int(rng.integers(2, 40))
-            x = np.sort(tmax - span * 1.3 * rng.uniform(0.0, 1.0, knots)); x[-1] = tmax
-            x = np.unique(x)
-            gamma = np.log(par.pop_n0) + rng.normal(0.0, 0.5, x.shape[0])
-            pop = d.PopModel.skygrid(x, gamma, log_linear=(kind == 3))
-        sc = Scenario("R%d" % case, tree, ref, tmax, mu, KAPPA, PI, pop, sites)
-        nparts = int(min(max(1, tips // 12), rng.integers(1, 14)))
+    for case in range(int(os.environ.get("EMAT_FUZZ_CASES", "20"))):
+        sc, nu_l, evo, what = random_scenario(rng, case)
+        nparts = int(min(max(1, (sc.tree.num_nodes + 1) // 24), rng.integers(1, 14)))
         t_step = sc.default_t_step() * float(rng.choice([0.25, 1.0, 4.0]))
         seed = int(rng.integers(1, 10**6))
-        nu_l = 0.2 + 1.8 * rng.random(sites) if case % 3 == 1 else None                  # site-rate heterogeneity
-        evo = None
-        if case % 6 == 5:                                                                 # two site partitions with their own mu and HKY tables
-            pi2 = rng.dirichlet([4.0, 4.0, 4.0, 4.0])
-            evo = (np.array([mu, float(rng.uniform(0.3, 3.0)) * mu]), np.stack([np.asarray(PI, np.float64), pi2]),
-                   np.stack([d.hky_q_matrix(KAPPA, PI), d.hky_q_matrix(float(rng.uniform(1.0, 8.0)), pi2)]),
-                   (np.arange(sites) // max(1, sites // 7) % 2).astype(np.int32))
         try:
             run_parity(sc, nparts, 1500, seed=seed, trace=1500, use_lds=bool(case % 5), t_step=t_step, nu_l=nu_l, evo=evo)
         except Exception as ex:
-            raise AssertionError("case %d (tips %d, sites %d, span %g, pop kind %d, parts %d, t_step %g, seed %d): %s" % (case, tips, sites, span, kind, nparts, t_step, seed, ex)) from ex
-        kinds |= 1 << kind
+            raise AssertionError("%s, parts %d, t_step %g, seed %d: %s" % (what, nparts, t_step, seed, ex)) from ex
+        kinds |= 1 << (case % 4)
     assert kinds == 15
 
 
