@@ -606,6 +606,7 @@ struct RunDriver {
       for (int p = 0; p < P; ++p) part_seeds[p] = seed_for_part(p);
       subtrees.clear();
       shard_block(P);
+      if (part_hi <= part_lo) return fail(EMAT_ERR_STATE, "this rank holds no parts: fewer parts than processes");
       part_epoch.assign(P, 0);
       emat_pop_model pm = pop; pm.skygrid_x = sky_x.data(); pm.skygrid_gamma = sky_g.data();
       auto t3 = now();
@@ -627,6 +628,7 @@ struct RunDriver {
     }, 64);
     subtrees.clear();
     shard_block(P);
+    if (part_hi <= part_lo) return fail(EMAT_ERR_STATE, "this rank holds no parts: fewer parts than processes");
     part_epoch.assign(P, 0);
     emat_pop_model pm = pop; pm.skygrid_x = sky_x.data(); pm.skygrid_gamma = sky_g.data();
     auto t3 = now();
