@@ -66,8 +66,8 @@ struct GCoal {                       // the whole grid, built on the device (nul
   int32_t* status;
 };
 
-constexpr int k_gt_max_cut_intervals = 1024, k_gt_small_cut_intervals = 256;
-constexpr int k_gt_max_cut_deltas = 1024, k_gt_small_cut_deltas = 256;
+constexpr int k_gt_max_cut_intervals = 2048, k_gt_small_cut_intervals = 256;   // the large variant fills the 64 KB of static LDS a workgroup may declare
+constexpr int k_gt_max_cut_deltas = 3968, k_gt_small_cut_deltas = 256;
 constexpr int k_gt_max_root_deltas = 256;   // how many changes of the root sequence k_gt_gather caches in LDS (more are read from HBM)
 constexpr uint32_t k_gt_max_list = 16000;   // ListRef counts are 16 bits (same limit as emat_part_upload)
 
