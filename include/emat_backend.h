@@ -168,14 +168,16 @@ emat_status emat_run_moves_split(emat_backend* h, int64_t moves_per_part, int64_
  * share at 8 threads, but six times a part's share at 8 000 parts, where that one chain then sets the length of the pass
  * (measured at C4: 62 ms instead of 34).  Spreading the remainder one move per part runs the same total. */
 emat_status emat_run_moves_even(emat_backend* h, int64_t moves_per_part, int32_t one_more_below);
-/* Waits for the launches issued so far and checks that every part ran its chain to completion.  A part that ran out of
- * list-heap or scratch space stops BEFORE a move with its state intact; it is re-materialised with twice the room and
- * the rest of its moves run, transparently (up to four doublings, then EMAT_ERR_CAPACITY).  The same happens when the
- * root part's coalescent grid outgrows the room it was given to grow into the past (four times the room per retry),
- * provided the part ran on a staged copy of its slab.  A part that stopped INSIDE
- * a move (an invariant the reference CHECKs, or the root part's cell table overflowing) makes this -- and every getter,
- * all of which synchronise first -- fail with EMAT_ERR_INTERNAL / EMAT_ERR_CAPACITY naming the part; the reference
- * aborts in that situation. */
+/* Waits for the launches issued so far and checks that every part ran its chain to completion.  The reference's containers
+ * grow without bound; a slab has fixed room.  A part that runs out of it -- list heap, scratch, or the cells the root part's
+ * coalescent grid grows into the past -- is re-materialised with more room (twice; four times the cells) and the rest of
+ * its moves run, transparently, up to four times (then EMAT_ERR_CAPACITY): it either stopped BEFORE a move (the heap
+ * reserve is checked there, and the moves that can grow the grid ask before they change anything), or a container
+ * overflowed INSIDE a move and the state its leg started from was put back (the untouched HBM copy of a staged part, a
+ * shadow copy for a part run on its HBM slab).  Either way the chain continues exactly as it would have with unbounded
+ * containers.  A part that broke an invariant the reference CHECKs makes this -- and every getter, all of which
+ * synchronise first -- fail with EMAT_ERR_INTERNAL naming the part and the device source line; the reference aborts in that
+ * situation. */
 emat_status emat_synchronize(emat_backend* h);
 
 /* ---- The whole tree resident in HBM -------------------------------------------------------------
