@@ -627,15 +627,16 @@ emat_status emat_tree_export_nodes(emat_backend* h, uint8_t* buf, uint64_t capac
   int32_t new_root = EMAT_NO_NODE;
   if (G.root_part >= G.lo && G.root_part < G.hi) HIP_TRY(hipMemcpy(&new_root, G.root.p, sizeof(new_root), hipMemcpyDeviceToHost));
   std::memcpy(&hdr[5], &new_root, 4);
+  // `buf` may be host memory or device memory (a buffer the caller hands to RCCL as it is): the copy kind is resolved by the runtime
   uint8_t* w = buf;
-  std::memcpy(w, hdr, 32); w += 32;
-  if (n) HIP_TRY(hipMemcpy(w, d_out.p, n * sizeof(GNodeExport), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(w, hdr, 32, hipMemcpyDefault)); w += 32;
+  if (n) HIP_TRY(hipMemcpy(w, d_out.p, n * sizeof(GNodeExport), hipMemcpyDefault));
   w += n * sizeof(GNodeExport);
-  if (G.used[0]) HIP_TRY(hipMemcpy(w, G.mut_heap.p, (size_t)G.used[0] * sizeof(MutRec), hipMemcpyDeviceToHost));
+  if (G.used[0]) HIP_TRY(hipMemcpy(w, G.mut_heap.p, (size_t)G.used[0] * sizeof(MutRec), hipMemcpyDefault));
   w += (size_t)G.used[0] * sizeof(MutRec);
-  if (G.used[1]) HIP_TRY(hipMemcpy(w, G.iv_heap.p, (size_t)G.used[1] * sizeof(IvRec), hipMemcpyDeviceToHost));
+  if (G.used[1]) HIP_TRY(hipMemcpy(w, G.iv_heap.p, (size_t)G.used[1] * sizeof(IvRec), hipMemcpyDefault));
   w += (size_t)G.used[1] * sizeof(IvRec);
-  if (G.used[2]) HIP_TRY(hipMemcpy(w, G.fs_heap.p, (size_t)G.used[2] * sizeof(FsRec), hipMemcpyDeviceToHost));
+  if (G.used[2]) HIP_TRY(hipMemcpy(w, G.fs_heap.p, (size_t)G.used[2] * sizeof(FsRec), hipMemcpyDefault));
   return EMAT_OK;
 }
 
@@ -645,12 +646,19 @@ emat_status emat_tree_apply_nodes(emat_backend* h, const uint8_t* buf, uint64_t 
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   GTreeHost& G = h->gt;
   if (!G.parts_live) return fail(h, EMAT_ERR_STATE, "emat_tree_repartition and emat_tree_gather_local first");
-  uint32_t hdr[8]; std::memcpy(hdr, buf, 32);
+  // `buf` may be host or device memory (what an all-gather on device buffers delivers): the header and the entries are checked on
+  // the host either way (a few MB at most), the three heap segments go where they belong without touching it
+  bool on_device = false;
+  { hipPointerAttribute_t at{}; if (hipPointerGetAttributes(&at, buf) == hipSuccess) on_device = at.type == hipMemoryTypeDevice; else (void)hipGetLastError(); }
+  uint32_t hdr[8];
+  HIP_TRY(hipMemcpy(hdr, buf, 32, hipMemcpyDefault));
   const uint64_t n = hdr[1], m0 = hdr[2], m1 = hdr[3], m2 = hdr[4];
   int32_t new_root; std::memcpy(&new_root, &hdr[5], 4);
   if (hdr[0] != 0x454E4F44u || bytes != 32 + n * sizeof(GNodeExport) + m0 * sizeof(MutRec) + m1 * sizeof(IvRec) + m2 * sizeof(FsRec)) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_apply_nodes: not a buffer of emat_tree_export_nodes");
   if (new_root != EMAT_NO_NODE && (new_root < 0 || new_root >= G.n)) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_apply_nodes: root out of range");
-  const GNodeExport* e = (const GNodeExport*)(buf + 32);
+  std::vector<GNodeExport> staged;
+  if (on_device && n) { staged.resize(n); HIP_TRY(hipMemcpy(staged.data(), buf + 32, n * sizeof(GNodeExport), hipMemcpyDeviceToHost)); }
+  const GNodeExport* e = on_device ? staged.data() : (const GNodeExport*)(buf + 32);
   for (uint64_t i = 0; i < n; ++i) {
     const uint32_t o = e[i].node_and_flags & k_gt_export_node_mask;
     const bool owns = (e[i].node_and_flags & k_gt_export_owns) != 0, links = (e[i].node_and_flags & k_gt_export_links) != 0;
@@ -663,13 +671,14 @@ emat_status emat_tree_apply_nodes(emat_backend* h, const uint8_t* buf, uint64_t 
   st = gt_grow_keeping(h, G.iv_heap, G.used[1], (size_t)G.used[1] + m1 > G.iv_heap.n ? ((size_t)G.used[1] + m1) * 2 : G.iv_heap.n); if (st) return st;
   st = gt_grow_keeping(h, G.fs_heap, G.used[2], (size_t)G.used[2] + m2 > G.fs_heap.n ? ((size_t)G.used[2] + m2) * 2 : G.fs_heap.n); if (st) return st;
   const uint8_t* r = buf + 32 + n * sizeof(GNodeExport);
-  if (m0) HIP_TRY(hipMemcpy(G.mut_heap.p + G.used[0], r, m0 * sizeof(MutRec), hipMemcpyHostToDevice));
+  if (m0) HIP_TRY(hipMemcpy(G.mut_heap.p + G.used[0], r, m0 * sizeof(MutRec), hipMemcpyDefault));
   r += m0 * sizeof(MutRec);
-  if (m1) HIP_TRY(hipMemcpy(G.iv_heap.p + G.used[1], r, m1 * sizeof(IvRec), hipMemcpyHostToDevice));
+  if (m1) HIP_TRY(hipMemcpy(G.iv_heap.p + G.used[1], r, m1 * sizeof(IvRec), hipMemcpyDefault));
   r += m1 * sizeof(IvRec);
-  if (m2) HIP_TRY(hipMemcpy(G.fs_heap.p + G.used[2], r, m2 * sizeof(FsRec), hipMemcpyHostToDevice));
+  if (m2) HIP_TRY(hipMemcpy(G.fs_heap.p + G.used[2], r, m2 * sizeof(FsRec), hipMemcpyDefault));
   DevBuf<GNodeExport> d_in;
-  HIP_TRY(d_in.upload(e, n));
+  HIP_TRY(d_in.alloc(n));
+  if (n) HIP_TRY(hipMemcpy(d_in.p, buf + 32, n * sizeof(GNodeExport), hipMemcpyDefault));
   hipLaunchKernelGGL(k_gt_apply, dim3((unsigned)((n + 255) / 256 + 1)), dim3(256), 0, h->stream, G.dev(), (const GNodeExport*)d_in.p, (int)n, G.used[0], G.used[1], G.used[2], new_root);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));

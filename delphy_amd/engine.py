@@ -496,6 +496,20 @@ class EmatBackend:
         buf = np.ascontiguousarray(buf, np.uint8)
         self._ck(self._lib.emat_tree_apply_nodes(self._h, _ptr(buf, C.c_uint8), buf.shape[0]), "emat_tree_apply_nodes")
 
+    # the same exchange on raw addresses -- device memory (e.g. a torch tensor's data_ptr()) or host memory
+    def tree_export_size(self) -> int:
+        need = C.c_uint64()
+        self._ck(self._lib.emat_tree_export_nodes(self._h, None, 0, C.byref(need)), "emat_tree_export_nodes")
+        return int(need.value)
+
+    def tree_export_nodes_into(self, address: int, capacity: int) -> int:
+        need = C.c_uint64()
+        self._ck(self._lib.emat_tree_export_nodes(self._h, C.cast(C.c_void_p(address), C.POINTER(C.c_uint8)), capacity, C.byref(need)), "emat_tree_export_nodes")
+        return int(need.value)
+
+    def tree_apply_nodes_at(self, address: int, nbytes: int):
+        self._ck(self._lib.emat_tree_apply_nodes(self._h, C.cast(C.c_void_p(address), C.POINTER(C.c_uint8)), nbytes), "emat_tree_apply_nodes")
+
     def tree_reassemble_end(self):
         self._ck(self._lib.emat_tree_reassemble_end(self._h), "emat_tree_reassemble_end")
 

@@ -54,10 +54,30 @@ def _torch_collectives(device: str):
     return allreduce, allgather_bytes
 
 
+def _torch_device_allgather(device: str):
+    """All-gather of variable-length byte buffers that STAY on the device: `fill(tensor)` writes this rank's contribution
+    into a device tensor of `nbytes`; returns one device tensor per rank (RCCL all-gather of the padded buffers)."""
+    import torch
+    import torch.distributed as dist
+
+    def allgather_device(nbytes: int, fill):
+        world = dist.get_world_size()
+        sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([nbytes], dtype=torch.int64, device=device))
+        n = [int(x.item()) for x in sizes]
+        mine = torch.empty(max(max(n), 1), dtype=torch.uint8, device=device)
+        fill(mine)
+        out = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(out, mine)
+        return [o[: n[r]] for r, o in enumerate(out)]
+    return allgather_device
+
+
 class ShardedEngine:
     def __init__(self, sc: Scenario, num_parts: int, seed: int, rank: int = 0, world: int = 1, device: int = 0, use_lds: bool = True,
                  allreduce: Optional[Callable[[np.ndarray, str], np.ndarray]] = None, trace_moves: int = 0, t_step: Optional[float] = None,
-                 max_part_nodes: int = 0, allgather_bytes: Optional[Callable[[np.ndarray], List[np.ndarray]]] = None, device_tree: bool = False):
+                 max_part_nodes: int = 0, allgather_bytes: Optional[Callable[[np.ndarray], List[np.ndarray]]] = None, device_tree: bool = False,
+                 allgather_device: Optional[Callable] = None):
         self.sc, self.num_parts_requested, self.seed, self.rank, self.world = sc, num_parts, seed, rank, world
         self.t_step = t_step if t_step is not None else sc.default_t_step()
         if world == 1:
@@ -66,7 +86,10 @@ class ShardedEngine:
         elif allreduce is None or allgather_bytes is None:
             ar, ag = _torch_collectives("cuda:%d" % device)
             allreduce, allgather_bytes = allreduce or ar, allgather_bytes or ag
+            if allgather_device is None and device_tree:
+                allgather_device = _torch_device_allgather("cuda:%d" % device)   # RCCL: the node exchange of a cycle never leaves the devices
         self.allreduce, self.allgather_bytes = allreduce, allgather_bytes
+        self.allgather_device = allgather_device   # (nbytes, fill(tensor)) -> [device tensor per rank], or None: exchange through host buffers
         self.backend = EmatBackend(sc.num_sites, device=device, use_lds=use_lds, trace_moves=trace_moves)
         self.run = EmatRun(self.backend, sc.tree, sc.ref, seed)
         self.total_parts = 0
@@ -141,10 +164,17 @@ class ShardedEngine:
             k = int(owner[0][:4].view(np.int32)[0])
             site = owner[0][4:4 + 4 * k].view(np.int32).copy(); frm = owner[0][4 + 4 * k:4 + 5 * k].copy(); to = owner[0][4 + 5 * k:4 + 6 * k].copy()
             b.tree_gather_local(site, frm, to)
-            exported = b.tree_export_nodes()
-            for r, buf in enumerate(self.allgather_bytes(exported)):
-                if r != self.rank:
-                    b.tree_apply_nodes(buf)
+            if self.allgather_device is not None:
+                # device buffers end to end: the export kernels write into the tensor RCCL sends, the apply kernels read what it delivered
+                need = b.tree_export_size()
+                for r, t in enumerate(self.allgather_device(need, lambda mine: b.tree_export_nodes_into(mine.data_ptr(), int(mine.numel())))):
+                    if r != self.rank:
+                        b.tree_apply_nodes_at(t.data_ptr(), int(t.numel()))
+            else:
+                exported = b.tree_export_nodes()
+                for r, buf in enumerate(self.allgather_bytes(exported)):
+                    if r != self.rank:
+                        b.tree_apply_nodes(buf)
             b.tree_reassemble_end()
             self.run.note_device_reassembled(site, to)
             return

@@ -305,6 +305,9 @@ def _rccl_worker(rank, port, out_dir):
     res["gather_ok"] = np.array([len(got) == 1 and np.array_equal(got[0], blob)])
     empty = allgather_bytes(np.zeros(0, np.uint8))
     res["empty_ok"] = np.array([len(empty) == 1 and empty[0].shape[0] == 0])
+    from delphy_amd.sharding import _torch_device_allgather
+    dev = _torch_device_allgather("cuda:0")(blob.shape[0], lambda t: t[: blob.shape[0]].copy_(torch.from_numpy(blob)))
+    res["device_gather_ok"] = np.array([len(dev) == 1 and dev[0].is_cuda and np.array_equal(dev[0].cpu().numpy(), blob)])
     dist.barrier(); torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, "rccl.npz"), **res)
     dist.destroy_process_group()
@@ -323,4 +326,54 @@ def test_the_collectives_of_a_sharded_run_over_rccl(tmp_path):
     for k in ("min", "max", "sum"):
         assert np.array_equal(z[k], x), k
     assert np.array_equal(z["isum"], np.array([7, -3, 2**40], np.int64))
-    assert bool(z["gather_ok"][0]) and bool(z["empty_ok"][0])
+    assert bool(z["gather_ok"][0]) and bool(z["empty_ok"][0]) and bool(z["device_gather_ok"][0])
+
+
+def test_node_exchange_of_a_sharded_run_through_device_buffers():
+    """The exchange after the moves of a sharded run with the tree in HBM, on DEVICE buffers: emat_tree_export_nodes writes into
+    device memory (what a rank would hand to RCCL as it is), emat_tree_apply_nodes reads device memory (what the all-gather
+    delivers).  Three ranks' worth of engines in this one process (the test box has one GPU), their buffers torch tensors on
+    cuda:0, stepped through three cycles by hand exactly as ShardedEngine.reassemble does: every rank ends with the tree of
+    the single-process run."""
+    import torch
+    from test_sharding_gloo import _tree_fields
+    world, cycles, moves = 3, 3, 48 * 300
+    sc = make_scenario("C3", num_tips=1500, num_sites=29903, uncertain_tips=0.1)
+    single = ShardedEngine(sc, num_parts=48, seed=97, device_tree=True)
+    for _ in range(cycles):
+        single.cycle(moves)
+    want, want_ref = single.tree()
+    single.close()
+    ident = lambda a, op: a
+    engs = [ShardedEngine(sc, num_parts=48, seed=97, rank=r, world=world, device=0, allreduce=ident, allgather_bytes=lambda b: [b], device_tree=True) for r in range(world)]
+    try:
+        for cyc in range(cycles):
+            for e in engs:
+                e.repartition(); e.run.run_moves_sharded(moves)
+            rds = [e.backend.tree_root_deltas() for e in engs]
+            owners = [rd for rd in rds if rd is not None]
+            assert len(owners) == 1
+            site, frm, to = owners[0]
+            for e in engs:
+                e.backend.tree_gather_local(site, frm, to)
+            bufs = []
+            for e in engs:
+                need = e.backend.tree_export_size()
+                t = torch.empty(need, dtype=torch.uint8, device="cuda:0")
+                assert e.backend.tree_export_nodes_into(t.data_ptr(), need) == need
+                bufs.append(t)
+            torch.cuda.synchronize()
+            for r, e in enumerate(engs):
+                for q in range(world):
+                    if q != r:
+                        e.backend.tree_apply_nodes_at(bufs[q].data_ptr(), int(bufs[q].numel()))
+                e.backend.tree_reassemble_end()
+                e.run.note_device_reassembled(site, to)
+        for r, e in enumerate(engs):
+            t, ref = e.tree()
+            assert t.root == want.root and np.array_equal(ref, want_ref), r
+            for k, v in _tree_fields(want).items():
+                assert np.array_equal(_tree_fields(t)[k], v), (r, k)
+    finally:
+        for e in engs:
+            e.close()
