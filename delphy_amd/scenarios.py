@@ -8,7 +8,7 @@ from typing import Optional
 
 import numpy as np
 
-from .engine import FlatTree, PopModel, SynthParams, make_synthetic_emat
+from .engine import FlatTree, PopModel, SynthParams, hky_q_matrix, make_synthetic_emat
 
 # Stationary frequencies A, C, G, T.  Deliberately NOT symmetric: with pi_A = pi_T and pi_C = pi_G the HKY escape rates of A and T
 # (and of C and G) coincide, so re-timing an A<->T mutation changes log G by exactly zero up to rounding noise, and the sign of
@@ -84,3 +84,40 @@ def make_scenario(name: str, num_tips: Optional[int] = None, num_sites: Optional
     else:
         pop = _skygrid(tmax, p.tip_span * 1.2, 200.0 * 365.0, log_linear=skygrid_log_linear)   # N of the order of the generating model's over the sampled period
     return Scenario(name, tree, ref, tmax, p.mu, p.kappa, PI, pop, p.num_sites)
+
+
+def random_scenario(rng, case, max_tips=320, density_cap=40):
+    """A seeded random scenario for the sweeps: tree size, genome length, time span, mutation / gap density, tip-date
+    uncertainty and population model all vary (the fixed configurations C1-C5 hold most of them constant)."""
+    tips = int(rng.integers(12, max_tips))
+    sites = int(rng.choice([60, 300, 2000, 9000]))
+    span = float(rng.choice([30.0, 365.0, 1500.0]))
+    mu = float(10 ** rng.uniform(-3.6, -2.0)) / 365.0 * (30000.0 / max(sites, 300)) ** 0.5
+    par = SynthParams(num_tips=tips, num_sites=sites, tip_span=span, pop_n0=float(10 ** rng.uniform(1.5, 3.5)), pop_growth=float(rng.choice([0.0, 1.0, 5.0])) / 365.0,
+                        mu=mu, gaps_per_tip=int(rng.integers(0, 5)), mean_gap_len=float(max(2.0, sites * 10 ** rng.uniform(-2.5, -0.8))), seed=int(rng.integers(1, 2**31)))
+    par.pi, par.kappa = PI, KAPPA
+    if rng.random() < 0.5:
+        par.frac_uncertain_tips, par.tip_date_uncertainty = float(rng.uniform(0.05, 0.6)), float(rng.uniform(0.5, 20.0))
+    tree, ref, tmax = make_synthetic_emat(par)
+    while tree.mut_site.shape[0] > density_cap * tips:   # beyond that a move takes the device milliseconds
+        mu /= 4.0; par.mu = mu
+        tree, ref, tmax = make_synthetic_emat(par)
+    kind = case % 4
+    if kind == 0:
+        pop = PopModel.exp(tmax, par.pop_n0, 0.0, 0.0)
+    elif kind == 1:
+        pop = PopModel.exp(tmax, par.pop_n0, float(rng.uniform(0.2, 4.0)) / 365.0, float(rng.choice([0.0, 1.0, par.pop_n0 / 50])))
+    else:
+        x = np.unique(np.append(np.sort(tmax - span * 1.3 * rng.uniform(0.0, 1.0, int(rng.integers(2, 40)))), tmax))
+        pop = PopModel.skygrid(x, np.log(par.pop_n0) + rng.normal(0.0, 0.5, x.shape[0]), log_linear=(kind == 3))
+    sc = Scenario("R%d" % case, tree, ref, tmax, mu, KAPPA, PI, pop, sites)
+    nu_l = 0.2 + 1.8 * rng.random(sites) if case % 3 == 1 else None
+    evo = None
+    if case % 6 == 5:
+        pi2 = rng.dirichlet([4.0, 4.0, 4.0, 4.0])
+        evo = (np.array([mu, float(rng.uniform(0.3, 3.0)) * mu]), np.stack([np.asarray(PI, np.float64), pi2]),
+               np.stack([hky_q_matrix(KAPPA, PI), hky_q_matrix(float(rng.uniform(1.0, 8.0)), pi2)]),
+               (np.arange(sites) // max(1, sites // 7) % 2).astype(np.int32))
+    what = "case %d (tips %d, sites %d, span %g, %d mutations, pop kind %d%s%s)" % (case, tips, sites, span, tree.mut_site.shape[0], kind,
+                                                                                   ", site rates" if nu_l is not None else "", ", two partitions" if evo is not None else "")
+    return sc, nu_l, evo, what

@@ -7,11 +7,11 @@ import tempfile
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # (tests/: the gloo collectives of test_sharding_gloo)
 
 
 def scenario(seed, case):
-    from helpers import random_scenario
+    from delphy_amd.scenarios import random_scenario
     rng = np.random.default_rng([seed, case])
     sc, nu_l, evo, what = random_scenario(rng, case * 4 + int(rng.integers(0, 4)), max_tips=700)   # (site rates / two partitions are not wired through ShardedEngine: the scenario's own model is used)
     parts = int(rng.choice([3, 5, 12, 40]))
