@@ -264,7 +264,7 @@ def test_root_grid_outgrowing_its_slab_room_stops_before_the_move_and_is_regrown
 
 
 def test_randomised_scenarios_move_for_move():
-    """A seeded sweep over what the fixed scenarios hold constant (helpers.random_scenario): tree size, genome length,
+    """A seeded sweep over what the fixed scenarios hold constant (delphy_amd.scenarios.random_scenario): tree size, genome length,
     mutation density, gap density, tip-date uncertainty, the population model (constant / exponential with a floor /
     skygrid staircase / skygrid log-linear with an irregular knot spacing), site-rate heterogeneity, one or two site
     partitions -- and here the coalescent cell width, the number of parts and LDS staging on / off.  Every case is compared
