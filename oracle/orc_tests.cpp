@@ -684,6 +684,47 @@ TEST(vsc_add_interval_cells) {   // very_scalable_coalescent_tests.cpp:29-97: pa
   for (double v : k) EXPECT_NEAR(v, 1.0, 1e-12);
   EXPECT(vsc::cell_for(9.999, 10.0, 1.0) == 0 && vsc::cell_for(9.0, 10.0, 1.0) == 1 && vsc::cell_for(10.0, 10.0, 1.0) == 0);
 }
+// very_scalable_coalescent_tests.cpp:11-97 with the reference's own numbers: cells (6,8] (4,6] (2,4] (0,2] for t_ref = 8, t_step = 2
+TEST(vsc_reference_cells_and_add_interval_cases) {
+  const double t_ref = 8.0, t_step = 2.0;
+  EXPECT(vsc::cell_for(7.5, t_ref, t_step) == 0); EXPECT(vsc::cell_for(6.1, t_ref, t_step) == 0); EXPECT(vsc::cell_for(5.9, t_ref, t_step) == 1);
+  EXPECT(vsc::cell_for(2.5, t_ref, t_step) == 2); EXPECT(vsc::cell_for(3.5, t_ref, t_step) == 2);
+  EXPECT_NEAR(vsc::cell_lbound(0, t_ref, t_step), 6.0, 1e-6); EXPECT_NEAR(vsc::cell_ubound(0, t_ref, t_step), 8.0, 1e-6);
+  EXPECT_NEAR(vsc::cell_lbound(1, t_ref, t_step), 4.0, 1e-6); EXPECT_NEAR(vsc::cell_ubound(1, t_ref, t_step), 6.0, 1e-6);
+  struct Case { double a, b; double want[4]; };
+  const Case cases[] = {{2.0, 4.0, {0.0, 0.0, 2.0, 0.0}},     // add_interval_single_whole_cell
+                        {2.0, 6.0, {0.0, 2.0, 2.0, 0.0}},     // add_interval_two_whole_cells
+                        {3.0, 3.5, {0.0, 0.0, 0.5, 0.0}},     // add_interval_single_partial_cell
+                        {3.5, 5.0, {0.0, 1.0, 0.5, 0.0}},     // add_interval_two_partial_cells
+                        {3.5, 7.0, {1.0, 2.0, 0.5, 0.0}}};    // add_interval_two_partial_cells_and_one_whole_cell
+  for (const Case& c : cases) {
+    std::vector<double> cells(4, 0.0);
+    vsc::add_interval(c.a, c.b, +2.0, cells, t_ref, t_step);
+    for (int i = 0; i < 4; ++i) EXPECT_NEAR(cells[i], c.want[i], 1e-15);
+  }
+}
+// distributions_tests.cpp:12-66 as the reference runs it: bounds of the bounded exponential, and for the K-truncated Poisson the ratio of
+// the counts of k = K and k = K + 1 (K = max(min_k, floor(lambda))) within three sigma of (K + 1) / lambda, for all twenty combinations
+TEST(distributions_reference_cases) {
+  Rng rng; rng.key = 12345;
+  const double lambda = 2.3, inf = std::numeric_limits<double>::infinity();
+  for (int i = 0; i < 1000; ++i) {
+    { Bounded_exponential_distribution d{+lambda, -inf, 5.0}; EXPECT(d(rng) <= 5.0); }
+    { Bounded_exponential_distribution d{-lambda, 3.0, +inf}; EXPECT(d(rng) >= 3.0); }
+    { Bounded_exponential_distribution d{lambda, 2.0, 5.0}; double x = d(rng); EXPECT(x >= 2.0 && x <= 5.0); }
+  }
+  for (double lam : {0.01, 0.1, 1.0, 10.0}) for (int min_k : {0, 1, 2, 5, 20}) {
+    const int K = std::max(min_k, (int)std::floor(lam));
+    long count_K = 0, count_K1 = 0;
+    K_truncated_poisson_distribution d{lam, min_k};
+    for (int sample = 0; sample < 100000; ++sample) { int k = d(rng); EXPECT(k >= min_k); if (k == K) ++count_K; else if (k == K + 1) ++count_K1; }
+    EXPECT(count_K >= 10); EXPECT(count_K1 >= 10);
+    const double upper = (count_K + 3 * std::sqrt((double)count_K)) / (count_K1 - 3 * std::sqrt((double)count_K1));
+    const double lower = (count_K - 3 * std::sqrt((double)count_K)) / (count_K1 + 3 * std::sqrt((double)count_K1));
+    const double expected = 1.0 / (lam / (K + 1));
+    EXPECT(lower < expected); EXPECT(upper > expected);
+  }
+}
 static Phylo_tree ladder_tree(int n_tips, double dt) {   // tips at t=0, coalescences at -dt, -2dt, ...
   Phylo_tree t(2 * n_tips - 1);
   t.ref_sequence = {sA};
