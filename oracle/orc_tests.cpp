@@ -169,6 +169,48 @@ TEST(missation_map_semantics) {
   auto M = merge_missations_nondestructively(A, C);
   EXPECT(M.intervals.v == (std::vector<Site_interval>{{1, 3}}) && M.from_states.at(2) == sA);
 }
+// missation_map_tests.cpp:17-124 with the reference's own cases (subtract_missations_nondestructively, :126-137, is not on the path)
+static std::vector<std::pair<int, State>> elements_of(const Missation_map& m, const std::vector<State>& ref) {   // slow_elements(ref_seq)
+  std::vector<std::pair<int, State>> out;
+  for (const auto& iv : m.intervals.v) for (int l = iv.first; l < iv.second; ++l) out.push_back({l, m.get_from_state(l, ref)});
+  return out;
+}
+TEST(missation_map_reference_cases) {
+  { Missation_map m; EXPECT(m.empty()); }                                                   // empty
+  { std::vector<State> ref{sA, sC, sG, sT};                                                 // simple
+    Missation_map m; m.insert(0, sA, ref); m.insert(1, sG, ref);
+    EXPECT(m.intervals.v == (std::vector<Site_interval>{{0, 2}}));
+    EXPECT(m.from_states.size() == 1 && m.from_states.at(1) == sG); }
+  { std::vector<State> ref(7, sA);                                                          // missation_map_basics
+    Missation_map m; m.insert(4, sA, ref); m.insert(6, sC, ref); m.insert(2, sG, ref); m.insert(4, sA, ref);
+    EXPECT(m.num_intervals() == 3 && m.num_sites() == 3);
+    EXPECT(m.intervals.v == (std::vector<Site_interval>{{2, 3}, {4, 5}, {6, 7}}));
+    EXPECT(m.from_states == (std::map<Site_index, State>{{2, sG}, {6, sC}}));
+    EXPECT(m.get_from_state(2, ref) == sG && m.get_from_state(4, ref) == sA && m.get_from_state(6, ref) == sC);
+    m.insert(3, sT, ref);
+    EXPECT(m.num_intervals() == 2 && m.num_sites() == 4);
+    EXPECT(m.intervals.v == (std::vector<Site_interval>{{2, 5}, {6, 7}}));
+    EXPECT(m.from_states == (std::map<Site_index, State>{{2, sG}, {3, sT}, {6, sC}}));
+    EXPECT(m.contains(3) && !m.contains(5));
+    ref[2] = sG; m.ref_seq_changed(2, sA, sG);
+    ref[3] = sC; m.ref_seq_changed(3, sA, sC);
+    ref[4] = sT; m.ref_seq_changed(4, sA, sT);
+    ref[5] = sC; m.ref_seq_changed(5, sA, sC);
+    ref[6] = sC; m.ref_seq_changed(6, sA, sC);
+    EXPECT(m.num_intervals() == 2 && m.num_sites() == 4);
+    EXPECT(m.intervals.v == (std::vector<Site_interval>{{2, 5}, {6, 7}}));
+    EXPECT(m.from_states == (std::map<Site_index, State>{{3, sT}, {4, sA}})); }
+  { std::vector<State> ref{sT, sT, sT};                                                     // factor_out_common_missations
+    Missation_map A, B, C; A.insert(0, sA, ref); A.insert(1, sC, ref); B.insert(0, sA, ref); B.insert(2, sG, ref);
+    factor_out_common_missations(A, B, C);
+    EXPECT(elements_of(A, ref) == (std::vector<std::pair<int, State>>{{1, sC}}));
+    EXPECT(elements_of(B, ref) == (std::vector<std::pair<int, State>>{{2, sG}}));
+    EXPECT(elements_of(C, ref) == (std::vector<std::pair<int, State>>{{0, sA}})); }
+  { std::vector<State> ref{sA, sA, sA};                                                     // merge_missations_nondestructively
+    Missation_map A, B; A.insert(0, sA, ref); A.insert(1, sC, ref); B.insert(2, sG, ref);
+    auto M = merge_missations_nondestructively(A, B);
+    EXPECT(elements_of(M, ref) == (std::vector<std::pair<int, State>>{{0, sA}, {1, sC}, {2, sG}})); }
+}
 // site_deltas_tests.cpp: composition and cancellation
 TEST(site_deltas_algebra) {
   Site_deltas d;
