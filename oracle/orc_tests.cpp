@@ -211,6 +211,39 @@ TEST(missation_map_reference_cases) {
     auto M = merge_missations_nondestructively(A, B);
     EXPECT(elements_of(M, ref) == (std::vector<std::pair<int, State>>{{0, sA}, {1, sC}, {2, sG}})); }
 }
+// site_deltas_tests.cpp:115-277 and :297-314 with the reference's own sequences of pushes and pops: the start of a delta list is moved
+// step by step along  ATA -A0T- -T1A- -A2G- -T0A- -A1C- ACG  and back
+TEST(site_deltas_reference_push_pop_append) {
+  using SD = std::map<Site_index, Site_delta>;
+  auto is = [](const Site_deltas& d, const SD& want) { return SD(d.begin(), d.end()) == want; };
+  { Site_deltas d;                                                                       // push_pop_front_site_deltas
+    push_front_site_deltas({1, sA, sC}, d); EXPECT(is(d, {{1, {sA, sC}}}));
+    push_front_site_deltas({0, sT, sA}, d); EXPECT(is(d, {{0, {sT, sA}}, {1, {sA, sC}}}));
+    push_front_site_deltas({2, sA, sG}, d); EXPECT(is(d, {{0, {sT, sA}}, {1, {sA, sC}}, {2, {sA, sG}}}));
+    push_front_site_deltas({1, sT, sA}, d); EXPECT(is(d, {{0, {sT, sA}}, {1, {sT, sC}}, {2, {sA, sG}}}));
+    push_front_site_deltas({0, sA, sT}, d); EXPECT(is(d, {{1, {sT, sC}}, {2, {sA, sG}}}));
+    pop_front_site_deltas({0, sA, sT}, d); EXPECT(is(d, {{0, {sT, sA}}, {1, {sT, sC}}, {2, {sA, sG}}}));
+    pop_front_site_deltas({1, sT, sA}, d); EXPECT(is(d, {{0, {sT, sA}}, {1, {sA, sC}}, {2, {sA, sG}}}));
+    pop_front_site_deltas({2, sA, sG}, d); EXPECT(is(d, {{0, {sT, sA}}, {1, {sA, sC}}}));
+    pop_front_site_deltas({0, sT, sA}, d); EXPECT(is(d, {{1, {sA, sC}}}));
+    pop_front_site_deltas({1, sA, sC}, d); EXPECT(d.empty()); }
+  { Site_deltas d;                                                                       // push_pop_back_site_deltas
+    push_back_site_deltas({0, sA, sT}, d); EXPECT(is(d, {{0, {sA, sT}}}));
+    push_back_site_deltas({1, sT, sA}, d); EXPECT(is(d, {{0, {sA, sT}}, {1, {sT, sA}}}));
+    push_back_site_deltas({2, sA, sG}, d); EXPECT(is(d, {{0, {sA, sT}}, {1, {sT, sA}}, {2, {sA, sG}}}));
+    push_back_site_deltas({0, sT, sA}, d); EXPECT(is(d, {{1, {sT, sA}}, {2, {sA, sG}}}));
+    push_back_site_deltas({1, sA, sC}, d); EXPECT(is(d, {{1, {sT, sC}}, {2, {sA, sG}}}));
+    pop_back_site_deltas({1, sA, sC}, d); EXPECT(is(d, {{1, {sT, sA}}, {2, {sA, sG}}}));
+    pop_back_site_deltas({0, sT, sA}, d); EXPECT(is(d, {{0, {sA, sT}}, {1, {sT, sA}}, {2, {sA, sG}}}));
+    pop_back_site_deltas({2, sA, sG}, d); EXPECT(is(d, {{0, {sA, sT}}, {1, {sT, sA}}}));
+    pop_back_site_deltas({1, sT, sA}, d); EXPECT(is(d, {{0, {sA, sT}}}));
+    pop_back_site_deltas({0, sA, sT}, d); EXPECT(d.empty()); }
+  { Site_deltas d1, d2;                                                                  // append_site_deltas
+    d1.insert({0, {sA, sT}}); d1.insert({2, {sC, sG}});
+    d2.insert({0, {sT, sA}}); d2.insert({1, {sG, sA}}); d2.insert({2, {sG, sT}});
+    append_site_deltas(d1, d2);
+    EXPECT(is(d1, {{1, {sG, sA}}, {2, {sC, sT}}})); }
+}
 // site_deltas_tests.cpp: composition and cancellation
 TEST(site_deltas_algebra) {
   Site_deltas d;
