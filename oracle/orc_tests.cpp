@@ -244,6 +244,46 @@ TEST(site_deltas_reference_push_pop_append) {
     append_site_deltas(d1, d2);
     EXPECT(is(d1, {{1, {sG, sA}}, {2, {sC, sT}}})); }
 }
+// site_deltas_tests.cpp:14-113 (fixture: ref AAAA, no missing data) and :279-295, :316-405 with the reference's own table of deltas
+static Phylo_tree site_deltas_fixture() {
+  Phylo_tree t(5);
+  t.root = r_; t.ref_sequence = {sA, sA, sA, sA};
+  set_inner(t, r_, k_no_node, x_, c_, -1.0);
+  set_inner(t, x_, r_, a_, b_, 0.0); t.at(x_).mutations = {Mutation{sA, 0, sT, -0.5}};
+  set_tip(t, a_, x_, 1.0); t.at(a_).mutations = {Mutation{sT, 0, sC, 0.5}};
+  set_tip(t, b_, x_, 2.0); t.at(b_).mutations = {Mutation{sA, 1, sG, 1.0}};
+  set_tip(t, c_, r_, 3.0); t.at(c_).mutations = {Mutation{sA, 0, sT, 0.0}, Mutation{sT, 0, sG, 1.0}};
+  return t;
+}
+TEST(site_deltas_reference_fixture_cases) {
+  using SD = std::map<Site_index, Site_delta>;
+  auto t = site_deltas_fixture();
+  auto is = [](const Site_deltas& d, const SD& want) { return SD(d.begin(), d.end()) == want; };
+  // displace_site_delta_starts: up to the root the deltas turn the reference into the node's sequence; down again they cancel
+  const std::vector<State> seqs[5] = {{sA, sA, sA, sA}, {sT, sA, sA, sA}, {sC, sA, sA, sA}, {sT, sG, sA, sA}, {sG, sA, sA, sA}};   // r x a b c
+  for (int i : {a_, b_, c_, x_}) {
+    Site_deltas d;
+    displace_site_deltas_start_upwards(t, d, t.node_loc(i), t.node_loc(r_));
+    auto seq = t.ref_sequence;
+    for (auto& [l, dl] : d) { EXPECT(dl.from != dl.to && dl.from == seq[l]); seq[l] = dl.to; }
+    EXPECT(seq == seqs[i]);
+    displace_site_deltas_start_downwards(t, d, t.node_loc(r_), t.node_loc(i));
+    EXPECT(d.empty());
+  }
+  // calc_site_deltas_between, every ordered pair of nodes
+  const SD none{};
+  const SD want[5][5] = {   // [from][to], order r x a b c
+      /* r */ {none, {{0, {sA, sT}}}, {{0, {sA, sC}}}, {{0, {sA, sT}}, {1, {sA, sG}}}, {{0, {sA, sG}}}},
+      /* x */ {{{0, {sT, sA}}}, none, {{0, {sT, sC}}}, {{1, {sA, sG}}}, {{0, {sT, sG}}}},
+      /* a */ {{{0, {sC, sA}}}, {{0, {sC, sT}}}, none, {{0, {sC, sT}}, {1, {sA, sG}}}, {{0, {sC, sG}}}},
+      /* b */ {{{0, {sT, sA}}, {1, {sG, sA}}}, {{1, {sG, sA}}}, {{0, {sT, sC}}, {1, {sG, sA}}}, none, {{0, {sT, sG}}, {1, {sG, sA}}}},
+      /* c */ {{{0, {sG, sA}}}, {{0, {sG, sT}}}, {{0, {sG, sC}}}, {{0, {sG, sT}}, {1, {sA, sG}}}, none}};
+  for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) EXPECT(is(calc_site_deltas_between(t, i, j), want[i][j]));
+  // a few tricky tree locations
+  EXPECT(is(calc_site_deltas_between(t, Phylo_tree_loc{r_, -2.0}, Phylo_tree_loc{c_, 0.5}), {{0, {sA, sT}}}));
+  EXPECT(is(calc_site_deltas_between(t, Phylo_tree_loc{c_, 0.5}, Phylo_tree_loc{x_, 0.0}), none));
+  EXPECT(is(calc_site_deltas_between(t, Phylo_tree_loc{b_, 1.5}, Phylo_tree_loc{c_, 0.5}), {{1, {sG, sA}}}));
+}
 // site_deltas_tests.cpp: composition and cancellation
 TEST(site_deltas_algebra) {
   Site_deltas d;
