@@ -409,6 +409,17 @@ TEST(calc_fixture_log_G_and_lambda) {
   EXPECT_NEAR(calc_path_log_G(t, r_, a_, evo, li, rf),
               calc_branch_log_G(t, a_, li[a_], evo, rf) + calc_branch_log_G(t, x_, li[x_], evo, rf), 1e-12);
 }
+// phylo_tree_calc_tests.cpp:139-143 (a reversion on the way to a tip "used to crash") and :773-781 (latest tip time, with an uncertain tip)
+TEST(calc_reversion_and_max_tip_time) {
+  auto t = complex_tree(false);
+  t.at(a_).mutations = {Mutation{sT, 0, sA, 0.5}};   // r -- A0T -- x -- T0A -- a
+  auto seq = view_of_sequence_at(t, a_);
+  EXPECT(seq == (std::vector<State>{sA, sA, sA, sA}));   // (this variant of the fixture has reference AACA and the root delta C2A: AAAA at the root, as in the reference's test)
+  auto u = complex_tree(false);
+  EXPECT(calc_max_tip_time(u) == u.at(c_).t);
+  u.at(c_).t_max = (float)(u.at(c_).t + 10.0);
+  EXPECT(calc_max_tip_time(u) != u.at(c_).t && calc_max_tip_time(u) == (double)u.at(c_).t_max);
+}
 TEST(calc_state_frequencies) {   // phylo_tree_calc_tests.cpp:179-189
   std::vector<State> seq{sA, sC, sC, sG, sG, sG, sT, sT, sT, sT};
   auto evo = make_global_evo_model({0, 1, 0, 1, 2, 0, 1, 2, 3, 0});
