@@ -119,6 +119,17 @@ def test_trajectory_parity_on_the_benchmark_workload():
     run_parity(sc, 8192, 1000, seed=20261001, trace=1000)
 
 
+@pytest.mark.parametrize("num_parts,moves", [(8, 20000), (64, 5000)])
+def test_c4_reference_partition_count(num_parts, moves):
+    """Config C4 as BASELINE.json states it: the 100 000-tip tree cut into 8 subtrees (the reference's policy of as many
+    parts as workers, tools/delphy.cpp:130-132; run.cpp:682-693) -- parts of ~25 000 nodes, nothing staged in LDS,
+    unlimited candidate scans over a whole part (about six per part in 20 000 moves) -- and into 64; every move of every part against the oracle."""
+    from helpers import run_parity
+    sc = make_scenario("C4")
+    st = run_parity(sc, num_parts, moves, seed=20261001, trace=moves)
+    assert st["moves_done"] == moves and st["proposed"][4] > moves // 64     # SPR1 moves, ~1 % of them with an unlimited scan
+
+
 def test_trajectory_parity_at_c2_full_size():
     """Config C2 exactly as SURVEY 8(d) states it (1 610 tips, 18 959 sites, exponential growth with a minimum population):
     64 parts x 20 000 moves, every move of every part against the oracle."""
