@@ -6,7 +6,10 @@ A "step" is one `emat_run_local_moves` pass (reference Run::run_local_moves, cor
 slabs already resident in HBM.  Default workload = config C4 of SURVEY section 8(d): a seeded synthetic
 100k-tip SARS-CoV-2-like EMAT (29 903 sites, HKY + skygrid) cut by the reference's tree-partitioning rule.
 
-N > 1 (launched by torchrun, one rank per GPU): the SAME partition at every N (8192 parts requested, 7 955 obtained),
+N > 1: one rank per GPU over RCCL.  Launched either by the driver (`python -m torch.distributed.run ... bench.py --gpus N`:
+RANK / WORLD_SIZE come from the environment) or as plain `python bench.py --gpus N`: the parent then starts the N ranks
+itself through torch.distributed.run BEFORE touching any GPU, relays rank 0's JSON line and exits with the children's code.
+The SAME partition at every N (8192 parts requested, 7 955 obtained),
 sharded across ranks in contiguous blocks; the only cross-rank exchange is the per-cycle coalescent-grid all-reduce
 (<= a few KB) done before the timed region and a 2-double all-reduce of the log-posterior totals after it.
 Tree and partition are fixed as N grows => "scaling": "strong".
@@ -25,14 +28,13 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 
 def device_code_sha16():
-    """Identifies the device code a PMC profile belongs to: sha256 over the HIP sources the kernels are built from."""
-    import hashlib
-    h = hashlib.sha256()
-    src = os.path.join(ROOT, "delphy_amd", "csrc")
-    for f in sorted(os.listdir(src)):
-        if f.endswith((".hip", ".hpp")) or f == "Makefile":
-            h.update(open(os.path.join(src, f), "rb").read())
-    return h.hexdigest()[:16]
+    """Identifies the device code a PMC profile belongs to: the id csrc/Makefile stamps into the library (emat_build_id),
+    recomputed from the sources the kernels are compiled from."""
+    from delphy_amd.engine import source_build_id
+    return source_build_id()
+
+
+DEFAULT_PARTS = {"C1": 8, "C2": 128, "C3": 1024, "C4": 8192, "C5": 81920}
 
 
 def parse():
@@ -42,7 +44,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C4", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--tips", type=int, default=None, help="override the number of tips (debug)")
-    ap.add_argument("--parts", type=int, default=8192, help="number of partition parts requested from the partitioner (the same at every N: strong scaling of one decomposition)")
+    ap.add_argument("--parts", type=int, default=None, help="number of partition parts requested from the partitioner (the same at every N: strong scaling of one decomposition); "
+                    "default 8192 at C4, 81920 at C5 (about 25 nodes per part)")
     ap.add_argument("--moves-per-part", type=int, default=1000)
     ap.add_argument("--max-part-nodes", type=int, default=0, help="not in the reference: cut parts larger than this further (0 = the reference's partitioning rule)")
     ap.add_argument("--no-lds", action="store_true")
@@ -51,7 +54,42 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-time budget of each CPU baseline sample")
     ap.add_argument("--no-inclusive", action="store_true", help="skip the host-cycle-inclusive figure (repartition + moves + reassemble through the run driver)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.parts is None:
+        args.parts = DEFAULT_PARTS[args.workload]
+    return args
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks (one per GPU) as children through
+    torch.distributed.run and relay what they print.  Nothing in this process may initialise the GPU -- counting devices
+    does not -- and the children are started as ordinary subprocesses, never by exec."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get("EMAT_BENCH_SHARED_GPU") != "1":
+        raise SystemExit("bench.py --gpus %d: this node has %d GPU(s) (EMAT_BENCH_SHARED_GPU=1 runs the ranks on one GPU over gloo as a plumbing check)" % (args.gpus, have))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stdout.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line)
+    sys.stdout.flush()
+    return rc
 
 
 def _time_oracle(sc, num_parts, seed, target_seconds, t_step, threads, pilot):
@@ -131,6 +169,8 @@ def inclusive_cycles(sc, args, cycles=3):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -144,6 +184,8 @@ def main():
     shared_gpu = world > 1 and os.environ.get("EMAT_BENCH_SHARED_GPU") == "1"
     if shared_gpu:
         local_rank = 0
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the EMAT engine has no CPU fallback (rank %d of %d)" % (rank, world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -151,12 +193,17 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the EMAT engine has no CPU fallback")
 
     import delphy_amd as d
     from delphy_amd.scenarios import make_scenario
     from delphy_amd.sharding import ShardedEngine
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs" % (args.gpus, world), file=sys.stderr)
+    # a prebuilt library that was not compiled from the sources beside it would make every number here describe other code
+    build_id = d.library_build_id()
+    if build_id != d.source_build_id() and os.environ.get("EMAT_ALLOW_STALE_LIB") != "1":
+        raise SystemExit("bench.py: %s was built from device code %s, the sources are %s: rebuild (python -c 'import __graft_entry__ as g; g.build()')"
+                         % (d.library_path(), build_id, d.source_build_id()))
 
     sc = make_scenario(args.workload, num_tips=args.tips)
     # The reference cuts the tree into as many parts as it has workers (tools/delphy.cpp:130-132); here a worker is a
@@ -198,7 +245,16 @@ def main():
         eng.backend.synchronize()
         ev_ms.append(eng.backend.last_run_ms())
     stats1 = eng.local_stats()
+    rank_ms = [dt / args.steps * 1e3]
+    rank_kernel_ms = [float(np.mean(ev_ms)) if ev_ms else float("nan")]
+    rank_parts = [eng.num_local_parts]
     if world > 1:
+        mine = torch.tensor([dt / args.steps * 1e3, rank_kernel_ms[0], float(eng.num_local_parts)], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(e[0].item()) for e in every]
+        rank_kernel_ms = [float(e[1].item()) for e in every]
+        rank_parts = [int(e[2].item()) for e in every]
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -218,16 +274,19 @@ def main():
     # PMC counters cannot be read from inside this process: the figure comes from the committed rocprofv3 --pmc passes
     # of this same command (scripts/profile.sh) and is stamped with the kernel build it was measured on; it is quoted
     # only for the default single-GPU workload and only while the device code is the one that was profiled
-    if os.path.exists(pmc_path) and world == 1 and args.workload == "C4" and args.tips is None and args.parts == 8192 and args.moves_per_part == 1000 and args.max_part_nodes == 0 and not (args.no_topology or args.only_displace or args.no_lds):
+    if world == 1 and args.workload == "C4" and args.tips is None and args.parts == 8192 and args.moves_per_part == 1000 and args.max_part_nodes == 0 and not (args.no_topology or args.only_displace or args.no_lds):
         try:
             pm = json.load(open(pmc_path))
-            if pm.get("device_code_sha16") in (None, device_code_sha16()):
+            stamp = pm.get("device_code_sha16")
+            if stamp is None:
+                traffic_source = "unstamped: profiles/pmc_latest.json does not say which device code it was measured on"
+            elif stamp == build_id:
                 traffic = pm.get("hbm_bytes_per_launch")
-                traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, device code %s)" % (pm.get("profile_dir", "pmc_latest.json"), pm.get("device_code_sha16", "unstamped"))
+                traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on the library with emat_build_id %s)" % (pm.get("profile_dir", "pmc_latest.json"), stamp)
             else:
-                traffic_source = "stale: profiles/pmc_latest.json was measured on device code %s, this is %s" % (pm.get("device_code_sha16"), device_code_sha16())
-        except Exception:
-            traffic = None
+                traffic_source = "stale: profiles/pmc_latest.json was measured on device code %s, the loaded library is %s" % (stamp, build_id)
+        except Exception as e:
+            traffic, traffic_source = None, "unreadable profiles/pmc_latest.json: %s" % e
     bad = stats1["bad_parts"]
 
     cpu_base = None
@@ -259,7 +318,10 @@ def main():
                 "lds_staging": not args.no_lds,
                 "tickets_per_part_and_pass": int(os.environ.get("EMAT_CHUNKS", "2")),
                 "parallelism": "parts sharded over %d GPU(s), one wavefront per part" % world,
+                "collectives": ("gloo on one shared GPU (plumbing check)" if shared_gpu else "RCCL, world size %d" % dist.get_world_size()) if world > 1 else "none (one rank)",
+                "emat_build_id": build_id,
             },
+            "per_rank": {"ms_per_step": rank_ms, "kernel_ms": rank_kernel_ms, "parts": rank_parts},
             # "bound" names the yardstick the contract asks for; "limiter" says what actually limits the kernel
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_source,

@@ -14,7 +14,9 @@ from .engine import (  # noqa: F401
     SynthParams,
     build_library,
     hky_q_matrix,
+    library_build_id,
     library_path,
     load_library,
     make_synthetic_emat,
+    source_build_id,
 )

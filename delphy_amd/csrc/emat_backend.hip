@@ -1367,6 +1367,10 @@ emat_status emat_backend_destroy(emat_backend* h) {
   return EMAT_OK;
 }
 const char* emat_last_error(const emat_backend* h) { return h ? h->last_error.c_str() : "null backend"; }
+#ifndef EMAT_BUILD_ID
+#define EMAT_BUILD_ID "unstamped"
+#endif
+const char* emat_build_id(void) { return EMAT_BUILD_ID; }
 
 emat_status emat_set_ref_sequence(emat_backend* h, const uint8_t* ref, int32_t num_sites) {
   if (!h || !ref || num_sites != h->L) return EMAT_ERR_INVALID_ARGUMENT;

@@ -33,6 +33,23 @@ def library_path() -> str:
     return os.environ.get("EMAT_LIB_PATH") or os.path.join(_HERE, _LIB_NAME)
 
 
+_DEVSRC = ("emat_backend.hip", "emat_device_core.hpp", "emat_device_moves.hpp", "emat_device_spr.hpp", "emat_slab.hpp", "emat_gtree_kernels.hpp")
+
+
+def source_build_id() -> str:
+    """The id csrc/Makefile would stamp into a library built from the sources as they are now (same files, same order)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in _DEVSRC:
+        h.update(open(os.path.join(_CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def library_build_id() -> str:
+    """emat_build_id() of the loaded library: the device sources it was compiled from."""
+    return load_library().emat_build_id().decode()
+
+
 def build_library(force: bool = False) -> str:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     path = library_path()
@@ -276,6 +293,8 @@ def load_library():
         fn.restype = C.c_int
     lib.emat_last_error.argtypes = [B]
     lib.emat_last_error.restype = C.c_char_p
+    lib.emat_build_id.argtypes = []
+    lib.emat_build_id.restype = C.c_char_p
     lib.emat_run_last_error.argtypes = [R]
     lib.emat_run_last_error.restype = C.c_char_p
     lib.emat_synth_destroy.argtypes = [S]

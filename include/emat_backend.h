@@ -101,6 +101,10 @@ typedef struct emat_backend emat_backend;
 emat_status emat_backend_create(const emat_config* cfg, emat_backend** out);
 emat_status emat_backend_destroy(emat_backend* h);
 const char* emat_last_error(const emat_backend* h);   /* human-readable text for the last failure */
+/* First 16 hex digits of the SHA-256 of the sources the kernels of THIS library were compiled from (csrc/Makefile: DEVSRC, in
+ * that order); "unstamped" for a build that bypassed the Makefile.  bench.py refuses a library whose id differs from the
+ * sources beside it, and quotes a committed PMC profile only for the id the profile was measured on. */
+const char* emat_build_id(void);
 
 /* ---- shared, read-only inputs ----------------------------------------------------------- */
 /* replaces: `subtree.ref_sequence = ref_seq` (reference run.cpp:139-140) */

@@ -1,0 +1,47 @@
+"""bench.py --gpus N starts N ranks itself when no launcher did (CPU: the ranks stop at the missing GPU, loudly)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra):
+    env = dict(os.environ, **env_extra)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_gpus_flag_spawns_that_many_ranks():
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-side check of the launcher (on a GPU box the -m gpu test runs the real thing)")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"EMAT_BENCH_SHARED_GPU": "1"})
+    assert r.returncode != 0                              # no GPU here: every rank must refuse, not fall back
+    assert "rank 0 of 2" in r.stderr and "rank 1 of 2" in r.stderr, r.stderr[-2000:]
+    assert '"metric"' not in r.stdout
+
+
+def test_gpus_flag_refuses_more_ranks_than_gpus():
+    import torch
+    r = _run(["--gpus", "64"], {})
+    assert r.returncode != 0 and "this node has %d GPU" % torch.cuda.device_count() in r.stderr
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_one_gpu_of_the_test_box():
+    """`python bench.py --gpus 2` as the driver would type it, on a one-GPU box (both ranks share cuda:0, collectives
+    over gloo: the control flow of a 2-rank run, not RCCL): one JSON line, n_gpus 2, both ranks' parts and times."""
+    import json
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-inclusive"], {"EMAT_BENCH_SHARED_GPU": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and len(out["per_rank"]["ms_per_step"]) == 2
+    assert sum(out["per_rank"]["parts"]) > 7000 and out["check"]["parts_stopped"] == 0
+    assert out["value"] > 0
