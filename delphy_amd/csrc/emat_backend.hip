@@ -1610,6 +1610,17 @@ emat_status emat_part_get_coalescent(emat_backend* h, int32_t part_id, int32_t* 
   if (t_step) *t_step = cp.t_step;
   return EMAT_OK;
 }
+emat_status emat_part_get_rng(emat_backend* h, int32_t part_id, uint64_t* key, uint64_t* counter, uint64_t* spare, int32_t* has_spare) {
+  if (!h || part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only || !h->slabs_on_device) return fail(h, EMAT_ERR_STATE, "emat_part_get_rng: the parts are not on a device");
+  emat_status st = pull_headers(h); if (st) return st;
+  const SlabHeader* H = header_of(h, (size_t)part_id);
+  if (key) *key = H->rng_key;
+  if (counter) *counter = H->rng_counter;
+  if (spare) *spare = H->rng_spare;
+  if (has_spare) *has_spare = (int32_t)H->rng_has_spare;
+  return EMAT_OK;
+}
 emat_status emat_part_get_stats(emat_backend* h, int32_t part_id, emat_part_stats* out) {
   if (!h || !out || part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
   emat_status st = pull_headers(h); if (st) return st;

@@ -255,6 +255,7 @@ def load_library():
         "emat_part_get_sizes": [B, i32, P(i32), P(i32), P(i32), P(i32)], "emat_part_download": [B, i32, P(_FlatTreeC)],
         "emat_part_get_derived": [B, i32, P(dbl), P(i32), P(dbl), P(dbl)],
         "emat_part_get_coalescent": [B, i32, P(i32), P(dbl), P(dbl), P(dbl), P(dbl), P(i32), P(dbl), P(dbl)],
+        "emat_part_get_rng": [B, i32, P(u64), P(u64), P(u64), P(i32)],
         "emat_part_get_stats": [B, i32, P(_PartStatsC)], "emat_part_get_trace": [B, i32, P(i32), P(dbl)],
         "emat_last_run_ms": [B, P(dbl)], "emat_last_kernel_ms": [B, P(dbl), P(i32)],
         "emat_debug_gamma": [B, i32, i32, P(dbl), P(dbl), P(dbl)],
@@ -676,6 +677,12 @@ class EmatBackend:
         self._ck(self._lib.emat_part_get_stats(self._h, part, C.byref(s)), "emat_part_get_stats")
         return dict(status=s.status, num_nodes=s.num_nodes, moves_done=s.moves_done, proposed=list(s.proposed), accepted=list(s.accepted),
                     algorithmic_bytes=s.algorithmic_bytes, rng_draws=s.rng_draws, device_ticks=s.device_ticks)
+
+    def part_rng(self, part: int) -> dict:
+        """Where the part's Philox stream stands: key, blocks consumed, pending half block."""
+        k, c, sp, hs = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int32()
+        self._ck(self._lib.emat_part_get_rng(self._h, part, C.byref(k), C.byref(c), C.byref(sp), C.byref(hs)), "emat_part_get_rng")
+        return dict(key=int(k.value), counter=int(c.value), spare=int(sp.value), has_spare=bool(hs.value))
 
     def part_trace(self, part: int, cap: int) -> np.ndarray:
         n = C.c_int32(cap)

@@ -327,6 +327,12 @@ emat_status emat_part_get_coalescent(emat_backend* h, int32_t part_id, int32_t* 
                                      double* popsize_bar, int32_t* num_active_parts,
                                      double* t_ref, double* t_step);
 
+/* Where a part's random stream stands (reference: the Subrun's own bit generator, run.cpp:112-114, 182-183): Philox4x32-10 keyed
+ * by `key`; `counter` blocks consumed; the unconsumed second 64-bit half of the last block if `has_spare`.  With it, the part's
+ * tree and its coalescent arrays, a checker can replay the part's chain from exactly the state the device starts from --
+ * also when the parts were cut and their tables built by kernels (emat_tree_repartition).  Any pointer may be NULL. */
+emat_status emat_part_get_rng(emat_backend* h, int32_t part_id, uint64_t* key, uint64_t* counter, uint64_t* spare, int32_t* has_spare);
+
 /* Per-part status and move counters. */
 typedef struct emat_part_stats {
   int32_t status;                /* 0 = OK; otherwise an emat_status raised inside the kernel */

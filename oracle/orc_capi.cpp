@@ -127,6 +127,30 @@ int orc_build_coalescent_parts(orc_engine* e, const emat_pop_model* pm, int root
   ORC_CATCH
 }
 
+// One part's coalescent arrays and RNG position handed in from outside (tests: the tables the DEVICE built for the part, read
+// back through emat_part_get_coalescent / emat_part_get_rng), instead of built here: the chain that follows is then a function
+// of the same inputs as the device's.  Cells outside the window the device keeps arrive as NaN: a chain that reads one shows.
+int orc_set_coalescent_part(orc_engine* e, const emat_pop_model* pm, int part_id, int includes_tree_root, int num_cells,
+                            const double* k_bar_p, const double* k_tw_p, const double* k_tw, const double* popsize_bar, const int* num_active,
+                            double t_ref, double t_step, uint64_t rng_counter, uint64_t rng_spare, int rng_has_spare) {
+  ORC_TRY
+  ORC_CHECK(part_id >= 0 && part_id < (int)e->parts.size());
+  if (e->coal_parts.size() != e->parts.size()) {
+    ORC_CHECK(e->coal_parts.empty());   // (pointers into the vector are held by the subruns: sized once)
+    e->coal_parts.resize(e->parts.size());
+    e->pop_model = make_pop_model(*pm);
+  }
+  auto& cp = e->coal_parts[part_id]; auto& pt = *e->parts[part_id];
+  cp.pop_model = e->pop_model; cp.subtree = &pt.subrun->tree; cp.prng = &pt.rng; cp.includes_tree_root = includes_tree_root != 0;
+  cp.k_bar_p.assign(k_bar_p, k_bar_p + num_cells); cp.k_twiddle_bar_p.assign(k_tw_p, k_tw_p + num_cells);
+  cp.k_twiddle_bar.assign(k_tw, k_tw + num_cells); cp.popsize_bar.assign(popsize_bar, popsize_bar + num_cells);
+  cp.num_active_parts.assign(num_active, num_active + num_cells);
+  cp.t_ref = t_ref; cp.t_step = t_step;
+  pt.rng.counter = rng_counter; pt.rng.spare = rng_spare; pt.rng.has_spare = rng_has_spare != 0;
+  pt.subrun->set_coalescent_prior_part(&cp);
+  ORC_CATCH
+}
+
 int orc_recalc_derived(orc_engine* e) {
   ORC_TRY
   for (auto& pt : e->parts) { pt->subrun->invalidate_derived_quantities(); pt->subrun->validate_derived_quantities(); }

@@ -123,4 +123,39 @@ def run_parity(sc, num_parts, moves_per_part, seed=11, topology=True, only_displ
         gpu.close(); orc.close()
 
 
+def replay_device_parts_in_the_oracle(sc, b, run, ref, moves_total, trace):
+    """Hand the oracle exactly what the device starts a pass from -- every part's tree as the kernels cut it, the coalescent
+    tables as the kernels built them, the position of every part's random stream -- run the pass on both, compare everything."""
+    n, root_part = run.num_parts()
+    trees = [b.part_download(p) for p in range(n)]
+    rngs = [b.part_rng(p) for p in range(n)]
+    orc = OracleEngine(sc.num_sites, trace_moves=trace)
+    try:
+        orc.set_ref_sequence(ref); orc.set_hky(sc.mu, sc.kappa, sc.pi); orc.set_flags(sc.t_max_tip)
+        orc.upload_parts(trees, [p == root_part for p in range(n)], [r["key"] for r in rngs])
+        for p in range(n):
+            tab = b.part_coalescent(p)
+            # the device keeps the cells of the part's own time window; outside it the part has no lineages (k_bar_p = 0), the
+            # shared vectors are reported as unknown (NaN / -1), and the reference's sum over ALL cells gets 0 from each such
+            # cell whatever they hold: give them neutral values (a chain that wandered out there would differ from the device's)
+            out = tab["num_active_parts"] < 0
+            assert np.all(tab["k_bar_p"][out] == 0.0) and np.all(tab["k_twiddle_bar_p"][out] == 0.0)
+            tab["k_twiddle_bar"] = np.where(out, 0.0, tab["k_twiddle_bar"]); tab["popsize_bar"] = np.where(out, 1.0, tab["popsize_bar"])
+            tab["num_active_parts"] = np.where(out, 0, tab["num_active_parts"])
+            assert not np.any(np.isnan(tab["k_twiddle_bar"])) and not np.any(np.isnan(tab["popsize_bar"]))
+            orc.set_coalescent_part(sc.pop, p, p == root_part, tab, rngs[p])
+        for p in range(n):       # from-scratch derived quantities on the tables both sides now share
+            lg, ng, Gg, Ag = b.part_derived(p, trees[p].num_nodes)
+            lo, no, Go, Ao = orc.part_derived(p, trees[p].num_nodes)
+            assert np.array_equal(ng, no) and rel_close(lg, lo, 1e-11) and rel_close(Gg, Go, 1e-9) and rel_close(Ag, Ao, 1e-9), (p, Gg, Go, Ag, Ao)
+        run.run_moves(moves_total); b.synchronize()
+        counts = np.full(n, moves_total // n, np.int64); counts[: moves_total % n] += 1      # emat_run_moves spreads the remainder one move per part
+        orc.run_moves_counts(counts, threads=4)
+        for p in range(n):
+            compare_part(b, orc, p, trees[p].num_nodes, trace, 1e-9, int(counts[p]))
+    finally:
+        orc.close()
+    return n
+
+
 from delphy_amd.scenarios import random_scenario  # noqa: E402,F401  (the seeded random scenarios of the sweeps)

@@ -27,6 +27,7 @@ def lib():
             "orc_set_flags": [E, dbl, C.c_int, C.c_int], "orc_begin_upload": [E, C.c_int],
             "orc_part_upload": [E, C.c_int, P(_FlatTreeC), C.c_int, u64], "orc_end_upload": [E],
             "orc_build_coalescent_parts": [E, P(_PopModelC), C.c_int, dbl], "orc_recalc_derived": [E],
+            "orc_set_coalescent_part": [E, P(_PopModelC), C.c_int, C.c_int, C.c_int, P(dbl), P(dbl), P(dbl), P(dbl), P(C.c_int), dbl, dbl, u64, u64, C.c_int],
             "orc_run_moves": [E, P(i64), C.c_int, C.c_int], "orc_get_totals": [E, P(dbl), P(dbl)], "orc_global_stats": [E, C.c_int, P(dbl), P(i64), P(i64)],
             "orc_part_get_sizes": [E, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)], "orc_part_download": [E, C.c_int, P(_FlatTreeC)],
             "orc_part_get_derived": [E, C.c_int, P(dbl), P(C.c_int), P(dbl), P(dbl)],
@@ -94,6 +95,14 @@ class OracleEngine:
     def build_coalescent_parts(self, pop: PopModel, root_part_index, t_step):
         m = pop.c_struct()
         self._ck(self.L.orc_build_coalescent_parts(self.h, C.byref(m), root_part_index, t_step), "build_coalescent_parts")
+
+    def set_coalescent_part(self, pop: PopModel, part, includes_tree_root, tables: dict, rng: dict):
+        """The part's coalescent arrays (as EmatBackend.part_coalescent returns them) and RNG position (EmatBackend.part_rng) from outside."""
+        m = pop.c_struct()
+        kb, kt, k, ps = (np.ascontiguousarray(tables[n], np.float64) for n in ("k_bar_p", "k_twiddle_bar_p", "k_twiddle_bar", "popsize_bar"))
+        na = np.ascontiguousarray(tables["num_active_parts"], np.int32)
+        self._ck(self.L.orc_set_coalescent_part(self.h, C.byref(m), part, int(includes_tree_root), kb.shape[0], _ptr(kb, C.c_double), _ptr(kt, C.c_double), _ptr(k, C.c_double),
+                                                _ptr(ps, C.c_double), _ptr(na, C.c_int), tables["t_ref"], tables["t_step"], rng["counter"], rng["spare"], int(rng["has_spare"])), "set_coalescent_part")
 
     def recalc_derived(self):
         self._ck(self.L.orc_recalc_derived(self.h), "recalc_derived")

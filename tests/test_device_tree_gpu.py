@@ -11,7 +11,7 @@ import pytest
 
 import delphy_amd as d
 from delphy_amd.scenarios import make_scenario
-from helpers import configure, rel_close
+from helpers import configure, rel_close, replay_device_parts_in_the_oracle
 from oracle_ffi import OracleEngine
 
 pytestmark = pytest.mark.gpu
@@ -167,6 +167,35 @@ def test_whole_cycles_on_the_device_built_tables():
     assert rel_close(inc[0], rec[0], 1e-9) and rel_close(inc[1], rec[1], 1e-9), (inc, rec)
     run.reassemble()
     chk.close(); run.close(); b.close()
+
+
+@pytest.mark.parametrize("name,kw,parts", [("C3", dict(num_tips=3000, num_sites=29903, uncertain_tips=0.1), 128),
+                                           ("C2", dict(num_tips=1610, num_sites=18959), 40),
+                                           ("C1", dict(num_tips=150, num_sites=3000, uncertain_tips=0.3), 3)])
+def test_default_device_tree_path_move_for_move_against_the_oracle(name, kw, parts):
+    """The DEFAULT path (parts cut by kernels, coalescent tables built by kernels -- no EMAT_TREE_HOST_COALESCENT) compared
+    move for move with the oracle over four cycles: before every pass the oracle is given the parts, tables and RNG
+    positions the device holds, then both run the pass: traces, counters, RNG consumption, trees, totals."""
+    sc = make_scenario(name, **kw)
+    old = os.environ.pop("EMAT_TREE_HOST_COALESCENT", None)
+    try:
+        b = d.EmatBackend(sc.num_sites, trace_moves=600)
+    finally:
+        if old is not None:
+            os.environ["EMAT_TREE_HOST_COALESCENT"] = old
+    run = d.EmatRun(b, sc.tree, sc.ref, 9)
+    run.set_num_parts(parts); run.set_hky(sc.mu, sc.kappa, sc.pi); run.set_pop_model(sc.pop)
+    run.set_device_tree(True)
+    ref = sc.ref
+    try:
+        for cycle in range(4):
+            run.repartition()
+            n = replay_device_parts_in_the_oracle(sc, b, run, ref, parts * 600 + 7, 600)
+            assert n >= 2
+            run.reassemble()
+            _, ref = run.tree()
+    finally:
+        run.close(); b.close()
 
 
 def test_global_move_statistics_from_parts_cut_on_the_device():
