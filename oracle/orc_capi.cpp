@@ -6,6 +6,7 @@
 #include <thread>
 
 #include "../include/emat_backend.h"
+#include "orc_run.hpp"
 #include "orc_subrun.hpp"
 
 using namespace orc;
@@ -242,16 +243,12 @@ int orc_get_totals(orc_engine* e, double* log_G, double* log_aug) {
   ORC_CATCH
 }
 
-int orc_part_get_sizes(orc_engine* e, int part_id, int* num_nodes, int* num_muts, int* num_intervals, int* num_from_states) {
-  auto& t = e->parts.at(part_id)->subrun->tree;
+static void tree_sizes(const Phylo_tree& t, int* num_nodes, int* num_muts, int* num_intervals, int* num_from_states) {
   int nm = 0, ni = 0, nf = 0;
   for (int i = 0; i < t.size(); ++i) { nm += (int)t.at(i).mutations.size(); ni += t.at(i).missations.num_intervals(); nf += (int)t.at(i).missations.from_states.size(); }
   *num_nodes = t.size(); *num_muts = nm; *num_intervals = ni; *num_from_states = nf;
-  return EMAT_OK;
 }
-int orc_part_download(orc_engine* e, int part_id, emat_flat_tree* out) {
-  ORC_TRY
-  auto& t = e->parts.at(part_id)->subrun->tree;
+static void tree_to_flat(const Phylo_tree& t, emat_flat_tree* out) {
   ORC_CHECK(out->num_nodes == t.size());
   out->root = t.root;
   int km = 0, ki = 0, kf = 0;
@@ -265,6 +262,14 @@ int orc_part_download(orc_engine* e, int part_id, emat_flat_tree* out) {
     for (auto& [l, s] : nd.missations.from_states) { ORC_CHECK(kf < out->cap_from_states); out->mfs_site[kf] = l; out->mfs_state[kf] = s; ++kf; }
     out->mut_offset[i + 1] = km; out->miss_offset[i + 1] = ki; out->mfs_offset[i + 1] = kf;
   }
+}
+int orc_part_get_sizes(orc_engine* e, int part_id, int* num_nodes, int* num_muts, int* num_intervals, int* num_from_states) {
+  tree_sizes(e->parts.at(part_id)->subrun->tree, num_nodes, num_muts, num_intervals, num_from_states);
+  return EMAT_OK;
+}
+int orc_part_download(orc_engine* e, int part_id, emat_flat_tree* out) {
+  ORC_TRY
+  tree_to_flat(e->parts.at(part_id)->subrun->tree, out);
   ORC_CATCH
 }
 int orc_part_get_derived(orc_engine* e, int part_id, double* lambda_i, int* num_missing, double* log_G, double* log_aug) {
@@ -348,4 +353,73 @@ int orc_interval_op(int op, const int* a, int na, const int* b, int nb, int* out
 
 void orc_rng_block(uint64_t key, uint64_t counter, uint32_t out[4]) { Rng::philox4x32_10(counter, key, out); }
 
+
+// ---- orc_run.hpp: Run::repartition / reassemble / normalize_root and tree_partitioning.h -----------------------------------------
+struct orc_run { Run run; std::vector<Phylo_tree> subrun_trees; std::string last_error; };
+#define RUN_TRY try {
+#define RUN_CATCH } catch (const std::exception& ex) { r->last_error = ex.what(); return EMAT_ERR_INTERNAL; } return EMAT_OK;
+
+int orc_run_create(const emat_flat_tree* tree, const uint8_t* ref, int num_sites, uint64_t seed, int num_parts, orc_run** out) {
+  try {
+    std::vector<State> rs(ref, ref + num_sites);
+    *out = new orc_run{Run(tree_from_flat(*tree, rs), seed, num_parts), {}, {}};
+  } catch (const std::exception&) { return EMAT_ERR_INTERNAL; }
+  return EMAT_OK;
+}
+int orc_run_destroy(orc_run* r) { delete r; return EMAT_OK; }
+const char* orc_run_last_error(orc_run* r) { return r->last_error.c_str(); }
+int orc_run_repartition(orc_run* r) {
+  RUN_TRY
+  r->run.repartition();
+  r->subrun_trees = r->run.subtrees;      // until orc_run_part_put says otherwise the Subruns made no move
+  RUN_CATCH
+}
+int orc_run_num_parts(orc_run* r, int* num_parts, int* root_part) { *num_parts = (int)r->run.tree_partition.parts.size(); *root_part = r->run.tree_partition.root_part_index; return EMAT_OK; }
+// the stencil in use is not kept by Run; the cut points of the parts are (Partition_part_info)
+int orc_run_part_sizes(orc_run* r, int p, int* num_nodes, int* num_muts, int* num_intervals, int* num_from_states) {
+  RUN_TRY
+  tree_sizes(r->run.subtrees.at(p), num_nodes, num_muts, num_intervals, num_from_states);
+  RUN_CATCH
+}
+// the subtree a Subrun is constructed from, the map subtree node -> tree node, and the part's cut point
+int orc_run_part_get(orc_run* r, int p, emat_flat_tree* out, int* orig_tree_index, int* cut_point) {
+  RUN_TRY
+  tree_to_flat(r->run.subtrees.at(p), out);
+  const auto& part = r->run.tree_partition.parts.at(p);
+  if (orig_tree_index) for (int i = 0; i < part.size(); ++i) orig_tree_index[i] = part.nodes[i].orig_tree_index;
+  if (cut_point) *cut_point = part.cut_point;
+  RUN_CATCH
+}
+// the tree a Subrun holds after its moves
+int orc_run_part_put(orc_run* r, int p, const emat_flat_tree* subtree) {
+  RUN_TRY
+  r->subrun_trees.at(p) = tree_from_flat(*subtree, r->run.tree.ref_sequence);
+  RUN_CATCH
+}
+int orc_run_reassemble(orc_run* r) {
+  RUN_TRY
+  r->run.reassemble(r->subrun_trees);
+  RUN_CATCH
+}
+int orc_run_normalize_root(orc_run* r) {
+  RUN_TRY
+  r->run.normalize_root();
+  RUN_CATCH
+}
+int orc_run_tree_sizes(orc_run* r, int* num_nodes, int* num_muts, int* num_intervals, int* num_from_states) {
+  tree_sizes(r->run.tree, num_nodes, num_muts, num_intervals, num_from_states); return EMAT_OK;
+}
+int orc_run_tree_get(orc_run* r, emat_flat_tree* out, uint8_t* ref_sequence) {
+  RUN_TRY
+  tree_to_flat(r->run.tree, out);
+  if (ref_sequence) std::copy(r->run.tree.ref_sequence.begin(), r->run.tree.ref_sequence.end(), ref_sequence);
+  RUN_CATCH
+}
+// the reference's integrity rules (phylo_tree.cpp:18-136) on the whole tree the Run holds
+int orc_run_tree_check(orc_run* r, char* msg, int msg_cap) {
+  std::string m;
+  try { m = check_phylo_tree_integrity(r->run.tree); } catch (const std::exception& ex) { m = ex.what(); }
+  std::snprintf(msg, msg_cap, "%s", m.c_str());
+  return m.empty() ? 0 : 1;
+}
 }  // extern "C"

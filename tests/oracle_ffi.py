@@ -190,3 +190,76 @@ def interval_op(op, a, b=()):
     n = lib().orc_interval_op(op, _ptr(A, C.c_int), A.shape[0] // 2, _ptr(B, C.c_int), B.shape[0] if op == 5 else B.shape[0] // 2, _ptr(out, C.c_int), out.shape[0] // 2)
     assert n >= 0
     return out[: 2 * n].reshape(-1, 2).tolist() if op <= 3 else bool(out[0])
+
+
+class OracleRun:
+    """oracle/orc_run.hpp: the reference's Run::repartition / reassemble / normalize_root and tree_partitioning.h restated."""
+
+    def __init__(self, tree: FlatTree, ref, seed, num_parts):
+        self.L = lib()
+        E = C.c_void_p
+        if not hasattr(self.L, "_run_sigs"):
+            i = C.c_int; P = C.POINTER
+            for n, a in {"orc_run_create": [P(_FlatTreeC), P(C.c_uint8), i, C.c_uint64, i, P(E)], "orc_run_destroy": [E], "orc_run_repartition": [E],
+                         "orc_run_num_parts": [E, P(i), P(i)], "orc_run_part_sizes": [E, i, P(i), P(i), P(i), P(i)],
+                         "orc_run_part_get": [E, i, P(_FlatTreeC), P(i), P(i)], "orc_run_part_put": [E, i, P(_FlatTreeC)], "orc_run_reassemble": [E],
+                         "orc_run_normalize_root": [E], "orc_run_tree_sizes": [E, P(i), P(i), P(i), P(i)], "orc_run_tree_get": [E, P(_FlatTreeC), P(C.c_uint8)],
+                         "orc_run_tree_check": [E, C.c_char_p, i]}.items():
+                f = getattr(self.L, n); f.argtypes = a; f.restype = C.c_int
+            self.L.orc_run_last_error.argtypes = [E]; self.L.orc_run_last_error.restype = C.c_char_p
+            self.L._run_sigs = True
+        self.num_sites = int(np.asarray(ref).shape[0])
+        ref = np.ascontiguousarray(ref, np.uint8)
+        v = tree.c_view()
+        self.h = E()
+        assert self.L.orc_run_create(C.byref(v), _ptr(ref, C.c_uint8), self.num_sites, int(seed), int(num_parts), C.byref(self.h)) == 0
+
+    def close(self):
+        if self.h:
+            self.L.orc_run_destroy(self.h); self.h = None
+
+    def _ck(self, st, what):
+        if st != 0:
+            raise RuntimeError("%s failed: %s" % (what, self.L.orc_run_last_error(self.h).decode()))
+
+    def repartition(self):
+        self._ck(self.L.orc_run_repartition(self.h), "run_repartition")
+
+    def num_parts(self):
+        n, r = C.c_int(), C.c_int()
+        self.L.orc_run_num_parts(self.h, C.byref(n), C.byref(r))
+        return n.value, r.value
+
+    def part(self, p):
+        """(subtree the Subrun is made from, subtree node -> tree node, cut point)"""
+        n, nm, ni, nf = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._ck(self.L.orc_run_part_sizes(self.h, p, C.byref(n), C.byref(nm), C.byref(ni), C.byref(nf)), "run_part_sizes")
+        t = FlatTree.empty(n.value, nm.value, ni.value, nf.value)
+        v = t.c_view(); orig = np.zeros(n.value, np.int32); cut = C.c_int()
+        self._ck(self.L.orc_run_part_get(self.h, p, C.byref(v), _ptr(orig, C.c_int), C.byref(cut)), "run_part_get")
+        t.root = v.root
+        return t.trimmed(), orig, cut.value
+
+    def part_put(self, p, subtree: FlatTree):
+        v = subtree.c_view()
+        self._ck(self.L.orc_run_part_put(self.h, p, C.byref(v)), "run_part_put")
+
+    def reassemble(self):
+        self._ck(self.L.orc_run_reassemble(self.h), "run_reassemble")
+
+    def normalize_root(self):
+        self._ck(self.L.orc_run_normalize_root(self.h), "run_normalize_root")
+
+    def tree(self):
+        n, nm, ni, nf = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.L.orc_run_tree_sizes(self.h, C.byref(n), C.byref(nm), C.byref(ni), C.byref(nf))
+        t = FlatTree.empty(n.value, nm.value, ni.value, nf.value)
+        v = t.c_view(); ref = np.zeros(self.num_sites, np.uint8)
+        self._ck(self.L.orc_run_tree_get(self.h, C.byref(v), _ptr(ref, C.c_uint8)), "run_tree_get")
+        t.root = v.root
+        return t.trimmed(), ref
+
+    def check(self):
+        buf = C.create_string_buffer(512)
+        rc = self.L.orc_run_tree_check(self.h, buf, 512)
+        return rc, buf.value.decode()

@@ -198,6 +198,38 @@ def test_default_device_tree_path_move_for_move_against_the_oracle(name, kw, par
         run.close(); b.close()
 
 
+@pytest.mark.parametrize("name,kw,parts", [("C3", dict(num_tips=3000, num_sites=29903, uncertain_tips=0.1), 128),
+                                           ("C1", dict(num_tips=200, num_sites=3000, uncertain_tips=0.2), 4)])
+def test_device_tree_cycles_against_the_restated_reference_run(name, kw, parts):
+    """The kernels that cut the HBM-resident tree and gather it back (k_gt_partition / _measure / _build / _gather) against
+    oracle/orc_run.hpp -- the reference's Run::repartition / reassemble / normalize_root restated step by step: every part
+    the device cuts is the oracle's subtree bit for bit (nodes, frozen cut nodes, synthetic sub-root lists), and the tree
+    and reference sequence the device gathers after its moves are what the oracle's reassemble makes of the same parts."""
+    from oracle_ffi import OracleRun
+    sc = make_scenario(name, **kw)
+    b, run = _run(sc, 7, parts, True, host_coalescent=False)
+    orun = OracleRun(sc.tree, sc.ref, 7 ^ 0xD1B54A32D192ED03, parts)
+    try:
+        for cycle in range(5 if name == "C3" else 12):
+            run.repartition(); orun.repartition()
+            n, root_part = run.num_parts()
+            assert (n, root_part) == orun.num_parts(), cycle
+            for p in range(n):
+                _same_tree(b.part_download(p), orun.part(p)[0], "cycle %d part %d as cut" % (cycle, p))
+            run.run_moves(n * 500); b.synchronize()
+            for p in range(n):
+                orun.part_put(p, b.part_download(p))
+            run.reassemble(); orun.reassemble()
+            orun.normalize_root()               # the device folds what the root carries into the reference while it gathers
+            (td, refd), (to, refo) = run.tree(), orun.tree()
+            _same_tree(td, to, "cycle %d gathered" % cycle)
+            assert np.array_equal(refd, refo), cycle
+            rc, msg = orun.check()
+            assert rc == 0, msg
+    finally:
+        run.close(); b.close(); orun.close()
+
+
 def test_global_move_statistics_from_parts_cut_on_the_device():
     """SURVEY 8(f).1 on top of 8(f).2: calc_Ttwiddle_l, calc_num_muts_l, calc_Ttwiddle_beta_a / calc_num_muts_ab computed from
     the parts while they are on the device, against the oracle's whole-tree values on the tree that comes back from HBM."""
