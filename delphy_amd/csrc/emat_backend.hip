@@ -384,7 +384,11 @@ __global__ void __launch_bounds__(k_wave) k_global_stats(KernelArgs a) {
 // Lanes stride over the part's nodes: branch-local work (delta lambda across the branch, missing-site count,
 // branch log-G, log N(t)) is embarrassingly parallel; only the pre-order accumulation of lambda_i /
 // n_missing down the tree is a dependent chain, walked by lane 0 without a stack.
-__global__ void __launch_bounds__(k_wave) k_recalc_derived(KernelArgs a) {
+// kCheck = true is the reference's check_derived_quantities (subrun.cpp:28-56; forced in release builds by --v0-paranoid,
+// run.h:220-224): the same recomputation, but into the part's scratch region, compared with what the moves maintained
+// incrementally, and reported per part in check_out[part][4] = {max |d lambda_i| / L, |d log_G|, |d log prior|, number of
+// nodes whose missing-site count differs}; the slab itself is left as it is.
+template <bool kCheck> __device__ __forceinline__ void recalc_derived_body(const KernelArgs& a, double* check_out) {
   __shared__ __attribute__((aligned(16))) double lds_tables[k_lds_tables_bytes / 8];
   const int lane = threadIdx.x;
   const int part = blockIdx.x;
@@ -394,22 +398,27 @@ __global__ void __launch_bounds__(k_wave) k_recalc_derived(KernelArgs a) {
   dev::Ctx c;
   init_ctx(c, slab, slab, a, tables);
   const int n = c.H->n_nodes, root = c.H->root;
+  // where the recomputed per-node values go: the node records themselves, or (check) two arrays in the scratch region
+  double* lam_of = kCheck ? (double*)(slab + c.H->scratch_begin) : nullptr;
+  int32_t* nmiss_of = kCheck ? (int32_t*)(slab + c.H->scratch_begin + (size_t)n * 8u) : nullptr;
+  auto LAM = [&](int i) -> double& { return kCheck ? lam_of[i] : c.N[i].lambda; };
+  auto NMISS = [&](int i) -> int32_t& { return kCheck ? nmiss_of[i] : c.N[i].n_missing; };
   // phase A: per-branch deltas
   for (int i = lane; i < n; i += k_wave) {
-    c.N[i].lambda = dev::delta_lambda_across_branch(c, i);
-    c.N[i].n_missing = dev::iv_num_sites(dev::miss_of(c, i), (int)c.N[i].miss.cnt);
+    LAM(i) = dev::delta_lambda_across_branch(c, i);
+    NMISS(i) = dev::iv_num_sites(dev::miss_of(c, i), (int)c.N[i].miss.cnt);
   }
   __syncthreads();
   // phase B: pre-order prefix (phylo_tree_calc.cpp:420-436, :67-76)
   if (lane == 0) {
     int cur = root;
-    c.N[root].lambda = c.cumQ[c.L] + c.N[root].lambda;
+    LAM(root) = c.cumQ[c.L] + LAM(root);
     while (cur != dev::k_no_node) {
       if (!dev::is_tip(c, cur)) {
         for (int k = 0; k < 2; ++k) {
           int ch = k == 0 ? c.N[cur].child0 : c.N[cur].child1;
-          c.N[ch].lambda = c.N[cur].lambda + c.N[ch].lambda;
-          c.N[ch].n_missing = c.N[cur].n_missing + c.N[ch].n_missing;
+          LAM(ch) = LAM(cur) + LAM(ch);
+          NMISS(ch) = NMISS(cur) + NMISS(ch);
         }
         cur = c.N[cur].child0;
       } else {
@@ -424,7 +433,7 @@ __global__ void __launch_bounds__(k_wave) k_recalc_derived(KernelArgs a) {
   // phase C: log G and the coalescent partial prior
   double acc_G = 0.0, acc_prior = 0.0;
   for (int i = lane; i < n; i += k_wave) {
-    if (i != root) acc_G += dev::branch_log_G(c, c.N[c.N[i].parent].t, c.N[i].t, c.N[i].lambda, dev::muts_of(c, i), dev::nmuts(c, i));
+    if (i != root) acc_G += dev::branch_log_G(c, c.N[c.N[i].parent].t, c.N[i].t, LAM(i), dev::muts_of(c, i), dev::nmuts(c, i));
     if (!dev::is_tip(c, i)) acc_prior -= log(dev::pop_at_time(*c.pop, c.N[i].t));
   }
   {
@@ -435,13 +444,33 @@ __global__ void __launch_bounds__(k_wave) k_recalc_derived(KernelArgs a) {
     }
   }
   acc_G = wave_sum(acc_G); acc_prior = wave_sum(acc_prior);
+  double dev_lambda = 0.0; int bad_missing = 0;
+  if (kCheck) {
+    for (int i = lane; i < n; i += k_wave) {
+      const double dl = fabs(c.N[i].lambda - lam_of[i]) / (double)c.L;
+      if (!(dl <= dev_lambda)) dev_lambda = dl;                     // (a NaN on either side shows as NaN)
+      if (c.N[i].n_missing != nmiss_of[i]) ++bad_missing;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const double o = __shfl_down(dev_lambda, off, k_wave); if (!(o <= dev_lambda)) dev_lambda = o;
+      bad_missing += __shfl_down(bad_missing, off, k_wave);
+    }
+  }
   if (lane == 0) {
     double lg = acc_G;
     if (c.includes_run_root) lg = dev::calc_log_root_prior(c, a.ref_freqs, a.evo.num_partitions) + acc_G;
-    c.H->log_G = lg;
-    c.H->log_aug_prior = acc_prior;
+    if (kCheck) {
+      double* o = check_out + 4 * (size_t)part;
+      o[0] = dev_lambda; o[1] = fabs(c.H->log_G - lg); o[2] = fabs(c.H->log_aug_prior - acc_prior); o[3] = (double)bad_missing;
+      if (c.H->log_G == lg) o[1] = 0.0;                             // (-inf on both sides is agreement)
+    } else {
+      c.H->log_G = lg;
+      c.H->log_aug_prior = acc_prior;
+    }
   }
 }
+__global__ void __launch_bounds__(k_wave) k_recalc_derived(KernelArgs a) { recalc_derived_body<false>(a, nullptr); }
+__global__ void __launch_bounds__(k_wave) k_check_derived(KernelArgs a, double* check_out) { recalc_derived_body<true>(a, check_out); }
 
 // ---- compact copies of what the host reads most often, so that it does not have to download the slabs for them ----------
 // Every part's 256-byte header (status, counters, log_G, log prior, RNG position) into one dense array.
@@ -1540,6 +1569,44 @@ emat_status emat_recalc_derived(emat_backend* h) {
   return launch_recalc(h);
 }
 
+// The reference's Subrun::check_derived_quantities (subrun.cpp:28-56) for every part, on the device, without the oracle and
+// without touching the state: `tol_scale` multiplies the reference's own tolerances (1e-8 per site on lambda_i, 1e-6 on
+// log_G, 1e-5 on the augmented coalescent prior; missing-site counts exact).
+emat_status emat_check_derived(emat_backend* h, double tol_scale, int32_t* worst_part, double* worst4) {
+  if (!h || !(tol_scale > 0.0)) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  emat_status st = emat_synchronize(h); if (st) return st;
+  if (!h->slabs_on_device || !h->derived_valid) return fail(h, EMAT_ERR_STATE, "emat_check_derived: nothing has been maintained incrementally yet (run moves first)");
+  st = sync_model_to_device(h); if (st) return st;
+  const size_t n = h->parts.size();
+  for (auto& ph : h->parts) if ((uint64_t)ph.tree.num_nodes() * 12u > (uint64_t)ph.scratch_bytes) return fail(h, EMAT_ERR_CAPACITY, "scratch region too small for the check");
+  DevBuf<double> d_out; HIP_TRY(d_out.alloc(4 * n));
+  KernelArgs a = make_args(h);
+  hipLaunchKernelGGL(k_check_derived, dim3((unsigned)n), dim3(k_wave), 0, h->stream, a, d_out.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::vector<double> out(4 * n);
+  HIP_TRY(hipMemcpy(out.data(), d_out.p, out.size() * sizeof(double), hipMemcpyDeviceToHost));
+  const double tol[4] = {1e-8 * tol_scale, 1e-6 * tol_scale, 1e-5 * tol_scale, 0.5};
+  static const char* what[4] = {"lambda_i (per site)", "log_G", "log_augmented_coalescent_prior", "num_sites_missing (nodes that differ)"};
+  int bad_part = -1, bad_q = -1; double worst_ratio = -1.0; int wp = 0;
+  for (size_t p = 0; p < n; ++p) for (int q = 0; q < 4; ++q) {
+    const double v = out[4 * p + q], ratio = v / tol[q];
+    if (!(ratio <= worst_ratio)) { worst_ratio = ratio; wp = (int)p; }      // NaN counts as worst
+    if (!(v < tol[q]) && bad_part < 0) { bad_part = (int)p; bad_q = q; }
+  }
+  if (worst_part) *worst_part = bad_part >= 0 ? bad_part : wp;
+  if (worst4) for (int q = 0; q < 4; ++q) worst4[q] = out[4 * (size_t)(bad_part >= 0 ? bad_part : wp) + q];
+  if (bad_part >= 0) {
+    char buf[256]; snprintf(buf, sizeof buf, "emat_check_derived: part %d: incremental %s differs from its recomputation by %.3g (tolerance %.3g)", bad_part, what[bad_q], out[4 * (size_t)bad_part + bad_q], tol[bad_q]);
+    return fail(h, EMAT_ERR_INTERNAL, buf);
+  }
+  return EMAT_OK;
+}
+
 emat_status emat_get_totals(emat_backend* h, double* log_G, double* log_aug) {
   if (!h) return EMAT_ERR_INVALID_ARGUMENT;
   if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
@@ -1608,6 +1675,17 @@ emat_status emat_part_get_coalescent(emat_backend* h, int32_t part_id, int32_t* 
   }
   if (t_ref) *t_ref = cp.t_ref;
   if (t_step) *t_step = cp.t_step;
+  return EMAT_OK;
+}
+emat_status emat_debug_slab_layout(emat_backend* h, int32_t part_id, uint32_t* out8) {
+  if (!h || !out8 || part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!h->have_coal) return fail(h, EMAT_ERR_STATE, "no coalescent parts built");
+  const PartHost& ph = h->parts[part_id];
+  const int trace_cap = h->cfg.trace_moves > 0 ? h->cfg.trace_moves : 0;
+  const uint32_t content = heap_content_bytes(ph.tree);
+  const SlabGeo g = slab_geometry(h, ph.tree.num_nodes(), ph.tree.num_muts(), content, (int)ph.coal.k_bar_p.size(), ph.includes_run_root, ph.space_boost, ph.cell_boost);
+  out8[0] = (uint32_t)sizeof(SlabHeader); out8[1] = (uint32_t)ph.tree.num_nodes() * (uint32_t)sizeof(NodeRec); out8[2] = a16((uint32_t)g.cell_cap * k_cell_bytes);
+  out8[3] = a16((uint32_t)trace_cap * 32u); out8[4] = content; out8[5] = g.heap; out8[6] = g.scratch; out8[7] = (uint32_t)g.cell_cap;
   return EMAT_OK;
 }
 emat_status emat_part_get_rng(emat_backend* h, int32_t part_id, uint64_t* key, uint64_t* counter, uint64_t* spare, int32_t* has_spare) {

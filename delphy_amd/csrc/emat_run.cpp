@@ -111,6 +111,7 @@ struct RunDriver {
   bool have_pop = false; emat_pop_model pop{}; std::vector<double> sky_x, sky_g;
   double t_step = 1.0; bool t_step_set = false;
   int only_displacing_inner_nodes = 0, topology_moves_enabled = 1;
+  bool paranoid = false;   // Run::paranoid (run.h:220-224): check the incrementally maintained quantities of every part after every pass
   // partition state
   std::vector<std::vector<int32_t>> stencils; int64_t stencil_refresh_countdown = 0;
   std::vector<PartMap> parts; std::vector<FlatTree> subtrees; std::vector<uint64_t> part_seeds;   // parts stay flat (SoA + CSR) end to end
@@ -967,6 +968,7 @@ emat_status emat_run_unpack_parts(emat_run* r, const uint8_t* buf, uint64_t byte
   if (!r || (!buf && bytes)) return EMAT_ERR_INVALID_ARGUMENT;
   try { return r->d.unpack_parts(buf, bytes); } catch (const std::exception& ex) { return r->d.fail(EMAT_ERR_INTERNAL, ex.what()); }
 }
+emat_status emat_run_set_paranoid(emat_run* r, int32_t on) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; r->d.paranoid = on != 0; return EMAT_OK; }
 emat_status emat_run_do_mcmc_steps(emat_run* r, int64_t steps, int64_t per_cycle) {   // run.cpp:622-657 minus global moves
   if (!r || steps < 0) return EMAT_ERR_INVALID_ARGUMENT;
   if (!r->d.backend) return r->d.fail(EMAT_ERR_NO_DEVICE, "no backend attached");
@@ -982,6 +984,7 @@ emat_status emat_run_do_mcmc_steps(emat_run* r, int64_t steps, int64_t per_cycle
     const auto t1 = now();
     int64_t k = std::min(per_cycle, steps - done);
     st = r->d.run_moves(k); if (st) return st;
+    if (r->d.paranoid) { st = r->d.bk(emat_check_derived(r->d.backend, 1.0, nullptr, nullptr)); if (st) return st; }
     const auto t2 = now();
     st = r->d.reassemble(); if (st) return st;
     done += k;

@@ -255,7 +255,7 @@ def load_library():
         "emat_part_get_sizes": [B, i32, P(i32), P(i32), P(i32), P(i32)], "emat_part_download": [B, i32, P(_FlatTreeC)],
         "emat_part_get_derived": [B, i32, P(dbl), P(i32), P(dbl), P(dbl)],
         "emat_part_get_coalescent": [B, i32, P(i32), P(dbl), P(dbl), P(dbl), P(dbl), P(i32), P(dbl), P(dbl)],
-        "emat_part_get_rng": [B, i32, P(u64), P(u64), P(u64), P(i32)],
+        "emat_part_get_rng": [B, i32, P(u64), P(u64), P(u64), P(i32)], "emat_check_derived": [B, dbl, P(i32), P(dbl)], "emat_debug_slab_layout": [B, i32, P(C.c_uint32)],
         "emat_part_get_stats": [B, i32, P(_PartStatsC)], "emat_part_get_trace": [B, i32, P(i32), P(dbl)],
         "emat_last_run_ms": [B, P(dbl)], "emat_last_kernel_ms": [B, P(dbl), P(i32)],
         "emat_debug_gamma": [B, i32, i32, P(dbl), P(dbl), P(dbl)],
@@ -286,7 +286,7 @@ def load_library():
         "emat_tree_repartition_range": [B, i32, P(i32), P(i32), P(i32), P(i32), i32, P(u64), P(_PopModelC), dbl, i32, i32],
         "emat_tree_get_root_deltas": [B, P(i32), P(i32), P(C.c_uint8), P(C.c_uint8), i32], "emat_tree_gather_local": [B, i32, P(i32), P(C.c_uint8), P(C.c_uint8)],
         "emat_tree_export_nodes": [B, P(C.c_uint8), u64, P(u64)], "emat_tree_apply_nodes": [B, P(C.c_uint8), u64], "emat_tree_reassemble_end": [B],
-        "emat_run_note_device_reassembled": [R, i32, P(i32), P(C.c_uint8)],
+        "emat_run_note_device_reassembled": [R, i32, P(i32), P(C.c_uint8)], "emat_run_set_paranoid": [R, i32],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -557,6 +557,12 @@ class EmatBackend:
     def recalc_derived(self):
         self._ck(self._lib.emat_recalc_derived(self._h), "emat_recalc_derived")
 
+    def check_derived(self, tol_scale: float = 1.0):
+        """The reference's check_derived_quantities on the device (raises EmatError when a part is off); returns (part, deviations)."""
+        wp = C.c_int32(); w4 = (C.c_double * 4)()
+        self._ck(self._lib.emat_check_derived(self._h, tol_scale, C.byref(wp), w4), "emat_check_derived")
+        return wp.value, [float(x) for x in w4]
+
     def last_run_ms(self) -> float:
         ms = C.c_double()
         self._ck(self._lib.emat_last_run_ms(self._h, C.byref(ms)), "emat_last_run_ms")
@@ -678,6 +684,11 @@ class EmatBackend:
         return dict(status=s.status, num_nodes=s.num_nodes, moves_done=s.moves_done, proposed=list(s.proposed), accepted=list(s.accepted),
                     algorithmic_bytes=s.algorithmic_bytes, rng_draws=s.rng_draws, device_ticks=s.device_ticks)
 
+    def debug_slab_layout(self, part: int) -> dict:
+        out = (C.c_uint32 * 8)()
+        self._ck(self._lib.emat_debug_slab_layout(self._h, part, out), "emat_debug_slab_layout")
+        return dict(zip(("header", "nodes", "cells", "trace", "heap_used", "heap_cap", "scratch", "num_cells"), [int(x) for x in out]))
+
     def part_rng(self, part: int) -> dict:
         """Where the part's Philox stream stands: key, blocks consumed, pending half block."""
         k, c, sp, hs = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int32()
@@ -745,6 +756,9 @@ class EmatRun:
 
     def set_flags(self, only_displacing_inner_nodes: bool = False, topology_moves_enabled: bool = True):
         self._ck(self._lib.emat_run_set_flags(self._h, int(only_displacing_inner_nodes), int(topology_moves_enabled)), "emat_run_set_flags")
+
+    def set_paranoid(self, on: bool = True):
+        self._ck(self._lib.emat_run_set_paranoid(self._h, 1 if on else 0), "emat_run_set_paranoid")
 
     def repartition(self):
         self._ck(self._lib.emat_run_repartition(self._h), "emat_run_repartition")

@@ -253,6 +253,16 @@ emat_status emat_tree_reassemble_end(emat_backend* h);
  * by the run functions when the derived quantities are stale. */
 emat_status emat_recalc_derived(emat_backend* h);
 
+/* replaces: Subrun::check_derived_quantities (reference subrun.cpp:28-56), which debug builds run after every move and
+ * --v0-paranoid forces in release builds (run.h:220-224, cmdline.cpp:177).  Every part's lambda_i, num_sites_missing, log_G
+ * and augmented coalescent prior are recomputed from scratch ON THE DEVICE into scratch memory and compared with what the
+ * moves maintained incrementally; the state is not touched, nothing but this library is involved.  `tol_scale` multiplies
+ * the reference's own tolerances (|d lambda_i| / L < 1e-8, |d log_G| < 1e-6, |d prior| < 1e-5; missing-site counts exact).
+ * Returns EMAT_OK, or EMAT_ERR_INTERNAL with emat_last_error naming the first offending part and quantity.
+ * `*worst_part` / `worst4` (either may be NULL): that part -- or, when all is well, the part closest to a tolerance -- and
+ * its four deviations {lambda per site, log_G, prior, nodes with a wrong missing-site count}. */
+emat_status emat_check_derived(emat_backend* h, double tol_scale, int32_t* worst_part, double* worst4);
+
 /* ---- results ---------------------------------------------------------------------------- */
 /* replaces: sum of subrun.log_G() / subrun.log_augmented_coalescent_prior()
  * (reference run.cpp:340-348) */
@@ -375,6 +385,10 @@ emat_status emat_debug_interval_op(emat_backend* h, int32_t op, const int32_t* a
  * EMAT_TREE_TIGHT set in the environment they start without any room, so that tests reach those paths), and how many
  * cut-point states needed the large variant of k_gt_measure (out3[2]). */
 emat_status emat_debug_tree_counters(emat_backend* h, int32_t* out3);
+
+/* Byte breakdown of one part's slab as the backend lays it out (works on host-only handles too): header, node records, coalescent
+ * cell table, trace ring, list-heap content, list-heap capacity, scratch, and the number of cells kept. */
+emat_status emat_debug_slab_layout(emat_backend* h, int32_t part_id, uint32_t* out8);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,9 @@ emat_status emat_run_set_hky(emat_run* r, double mu, double kappa, const double 
 emat_status emat_run_set_pop_model(emat_run* r, const emat_pop_model* pm);
 emat_status emat_run_set_coalescent_t_step(emat_run* r, double t_step);
 emat_status emat_run_set_flags(emat_run* r, int32_t only_displacing_inner_nodes, int32_t topology_moves_enabled);
+/* Run::set_paranoid (reference run.h:220-224; CLI flag --v0-paranoid, cmdline.cpp:177): emat_run_do_mcmc_steps then runs
+ * emat_check_derived on every part after every pass of local moves and stops with its error if one is off. */
+emat_status emat_run_set_paranoid(emat_run* r, int32_t on);
 
 /* keep the authoritative tree in HBM (emat_tree_* of the backend).  From the next emat_run_repartition on,
  * a cycle moves only the partition to the device and topology + node times back: emat_run_repartition draws and applies

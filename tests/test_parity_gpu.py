@@ -434,3 +434,31 @@ def test_a_pass_in_tickets_is_the_same_chain(monkeypatch):
     for chunks in ("1", "3", "7"):
         monkeypatch.setenv("EMAT_CHUNKS", chunks)
         run_parity(sc, 48, 1001, seed=53, trace=1001)
+
+
+def test_check_derived_is_the_references_paranoid_check_on_the_device():
+    """emat_check_derived (Subrun::check_derived_quantities, subrun.cpp:28-56; --v0-paranoid): after thousands of moves the
+    incrementally maintained lambda_i / log_G / prior / missing-site counts of every part agree with a from-scratch
+    recomputation within the reference's tolerances -- found without the oracle and without touching the state; with the
+    tolerances shrunk far below round-off the same call fails and names the part; a run in paranoid mode cycles cleanly."""
+    sc = make_scenario("C3", num_tips=2000, num_sites=29903, uncertain_tips=0.1)
+    parts, incl, seeds, root_part, ref = split_parts(sc, 64, 5)
+    b = d.EmatBackend(sc.num_sites)
+    configure(b, sc, ref, parts, incl, seeds, root_part)
+    b.run_moves_per_part(3000); b.synchronize()
+    before = [b.part_derived(p, parts[p].num_nodes) for p in (0, root_part)]
+    part, dev4 = b.check_derived(1.0)
+    assert 0 <= part < len(parts) and dev4[3] == 0 and dev4[0] < 1e-8 and dev4[1] < 1e-6 and dev4[2] < 1e-5
+    assert max(dev4[:3]) > 0.0                                   # round-off is there: the comparison is not of a value with itself
+    after = [b.part_derived(p, parts[p].num_nodes) for p in (0, root_part)]
+    for x, y in zip(before, after):                              # the check leaves the incremental values alone
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2] and x[3] == y[3]
+    with pytest.raises(d.EmatError, match="emat_check_derived: part"):
+        b.check_derived(1e-12)
+    b.close()
+    b = d.EmatBackend(sc.num_sites)
+    run = d.EmatRun(b, sc.tree, sc.ref, 3)
+    run.set_num_parts(64); run.set_hky(sc.mu, sc.kappa, sc.pi); run.set_pop_model(sc.pop)
+    run.set_device_tree(True); run.set_paranoid(True)
+    run.do_mcmc_steps(3 * 64 * 800, 64 * 800)
+    run.close(); b.close()
