@@ -128,7 +128,7 @@ __device__ inline const double* stage_tables(const KernelArgs& a, double* lds_ta
 // ---- the hot path: `moves` sub-iterations on every part -------------------------------------------------
 // One wavefront (= one workgroup) per part.  Every part is its own Markov chain with its own RNG stream, so the
 // launch schedule does not change any result.  The chain itself is serial and runs on lane 0; all 64 lanes move the
-// slab between HBM and LDS.  Dynamic LDS layout: [HKY tables][context][staged slab][optional scratch arena]; the
+// slab between HBM and LDS.  LDS layout: static [HKY tables], static [context], dynamic [staged slab][optional scratch arena]; all
 // first three sit at compile-time offsets, which is what lets the `dev_lds` variant address them with DS instructions.
 #ifndef EMAT_WAVES_PER_EU
 #define EMAT_WAVES_PER_EU 4
@@ -144,10 +144,10 @@ constexpr uint32_t k_lds_heap_room = 1024;
 
 __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
   const int lane = threadIdx.x;
-  double* lds_tables = (double*)emat_lds;
+  double* lds_tables = (double*)emat_lds_tables;
   const bool tables_staged = stage_tables(a, lds_tables, lane) != nullptr;
-  uint8_t* lds_slab = emat_lds + k_lds_slab_off;
-  int* lds_flag = (int*)(emat_lds + k_lds_ctx_off + k_lds_ctx_bytes - 16);   // spare tail of the context slot: lane 0 -> all lanes
+  uint8_t* lds_slab = emat_lds;
+  int* lds_flag = (int*)(emat_lds_ctx + k_lds_ctx_bytes - 16);   // spare tail of the context slot: lane 0 -> all lanes
   const int chunk = a.chunks > 1 ? (int)blockIdx.x / a.class_stride : 0, slot = a.chunks > 1 ? (int)blockIdx.x % a.class_stride : (int)blockIdx.x;
   if (a.chunks > 1 && slot >= a.class_count) return;   // padding: the stride is a multiple of 8 so that a part's tickets land on one XCD
   const int part = a.order[slot];
@@ -206,7 +206,7 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
     if (lane == 0) {
       // The context lives in LDS, not in private memory: it is touched by almost every instruction.
       if (staged) {
-        dev_lds::Ctx& c = *(dev_lds::Ctx*)(emat_lds + k_lds_ctx_off);
+        dev_lds::Ctx& c = *(dev_lds::Ctx*)(emat_lds_ctx);
         init_ctx(c, lds_slab, gslab, a, lds_tables);
         H->heap_end = lds_heap_end;
         // whatever the part leaves unused of the staging area (plus the optional extra arena) serves as the first-level
@@ -216,18 +216,18 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
       } else if (prefix) {
         // the prefix leaves the rest of the staging area free: the moves' first-level arena, as for a staged part (before
         // round 2's end these parts -- 40-60 nodes, the slowest chains of a pass -- ran every candidate scan through HBM)
-        dev_mix::Ctx& c = *(dev_mix::Ctx*)(emat_lds + k_lds_ctx_off);
+        dev_mix::Ctx& c = *(dev_mix::Ctx*)(emat_lds_ctx);
         init_ctx(c, lds_slab, gslab, a, lds_tables);
         const uint32_t used = (gh->heap_begin + 15u) & ~15u;
         c.A = lds_slab + used; c.a_end = area + a.lds_scratch_bytes - used;
       } else {
-        dev::Ctx& c = *(dev::Ctx*)(emat_lds + k_lds_ctx_off);
+        dev::Ctx& c = *(dev::Ctx*)(emat_lds_ctx);
         init_ctx(c, gslab, gslab, a, tables_staged ? lds_tables : nullptr);
         if (area + a.lds_scratch_bytes != 0) { c.A = lds_slab; c.a_end = area + a.lds_scratch_bytes; }   // nothing of the part is staged: the whole area is arena
       }
       // (a later ticket of a part whose earlier one had to stop does nothing: the host gives the part more room and the rest of its moves)
       const bool stopped_before = chunk > 0 && a.part_status[part] != 0;
-      ((dev::Ctx*)(emat_lds + k_lds_ctx_off))->moves_left = (H->status == 0 && !stopped_before) ? target - (H->moves_done - done_at_start) : 0;   // the three Ctx types share one layout
+      ((dev::Ctx*)(emat_lds_ctx))->moves_left = (H->status == 0 && !stopped_before) ? target - (H->moves_done - done_at_start) : 0;   // the three Ctx types share one layout
       tick0 = wall_clock64();
       if (is_root_part) __builtin_amdgcn_s_setprio(3);
     }
@@ -236,20 +236,20 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
     // scan and study of an SPR move), all 64 lanes do that work and lane 0 picks the move up again.
     for (;;) {
       if (lane == 0) {
-        if (staged) dev_lds::run_chain_loop(*(dev_lds::Ctx*)(emat_lds + k_lds_ctx_off));
-        else if (prefix) dev_mix::run_chain_loop(*(dev_mix::Ctx*)(emat_lds + k_lds_ctx_off));
-        else dev::run_chain_loop(*(dev::Ctx*)(emat_lds + k_lds_ctx_off));
+        if (staged) dev_lds::run_chain_loop(*(dev_lds::Ctx*)(emat_lds_ctx));
+        else if (prefix) dev_mix::run_chain_loop(*(dev_mix::Ctx*)(emat_lds_ctx));
+        else dev::run_chain_loop(*(dev::Ctx*)(emat_lds_ctx));
       }
       __syncthreads();
-      if (((const dev::Ctx*)(emat_lds + k_lds_ctx_off))->svc == 0) break;
-      if (staged) dev_lds::wave_scan_and_study(*(dev_lds::Ctx*)(emat_lds + k_lds_ctx_off));
-      else if (prefix) dev_mix::wave_scan_and_study(*(dev_mix::Ctx*)(emat_lds + k_lds_ctx_off));
-      else dev::wave_scan_and_study(*(dev::Ctx*)(emat_lds + k_lds_ctx_off));
+      if (((const dev::Ctx*)(emat_lds_ctx))->svc == 0) break;
+      if (staged) dev_lds::wave_scan_and_study(*(dev_lds::Ctx*)(emat_lds_ctx));
+      else if (prefix) dev_mix::wave_scan_and_study(*(dev_mix::Ctx*)(emat_lds_ctx));
+      else dev::wave_scan_and_study(*(dev::Ctx*)(emat_lds_ctx));
       __syncthreads();
     }
     if (lane == 0) {
       if (is_root_part) __builtin_amdgcn_s_setprio(0);
-      const dev::Ctx& c = *(const dev::Ctx*)(emat_lds + k_lds_ctx_off);
+      const dev::Ctx& c = *(const dev::Ctx*)(emat_lds_ctx);
       H->rng_counter = c.rng_ctr; H->rng_spare = c.rng_spare; H->rng_has_spare = c.rng_has_spare ? 1u : 0u;
       H->alg_bytes += c.bytes;
       const int64_t dt = (int64_t)(wall_clock64() - tick0);
@@ -1135,7 +1135,7 @@ void assign_size_classes(emat_backend* h) {
   std::sort(v.begin(), v.end());
   h->class_of.assign(n, 0);
   std::vector<uint32_t> areas;   // per class, descending
-  const uint32_t lds_cu = 160u * 1024u, overhead = k_lds_slab_off + (h->cfg.use_lds ? h->cfg_lds_scratch : 0u);
+  const uint32_t lds_cu = 160u * 1024u, overhead = k_lds_static_bytes + (h->cfg.use_lds ? h->cfg_lds_scratch : 0u);
   auto area_for = [&](uint32_t k) {   // the staging area of a workgroup when k of them share a CU (LDS is allocated in 512-byte granules)
     const uint32_t share = (lds_cu / k) & ~511u;
     return share <= overhead ? 0u : std::min<uint32_t>((share - overhead) & ~15u, h->cfg_lds_max & ~15u);
@@ -1284,9 +1284,9 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
   st = materialize(h); if (st) return st;
   if (!h->derived_valid) { st = launch_recalc(h); if (st) return st; }
   const uint32_t lds_scratch = h->cfg.use_lds ? h->cfg_lds_scratch : 0u;
-  auto shmem_for = [&](uint32_t slab_area) { return (size_t)k_lds_slab_off + slab_area + lds_scratch; };
+  auto shmem_for = [&](uint32_t slab_area) { return (size_t)slab_area + lds_scratch; };   // the dynamic block; tables and context are static LDS
   for (int c = 0; c < h->num_classes; ++c)
-    if (shmem_for(h->class_lds[c]) > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower EMAT_LDS_MAX or disable use_lds");
+    if (shmem_for(h->class_lds[c]) + k_lds_static_bytes > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower EMAT_LDS_MAX or disable use_lds");
   if (!h->order_valid) { st = build_order(h); if (st) return st; }
   HIP_TRY(h->d_snaps.alloc(h->d_slabs.n));
   KernelArgs a = make_args(h);

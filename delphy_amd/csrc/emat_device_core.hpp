@@ -29,12 +29,17 @@
 #ifndef EMAT_DEVICE_COMMON_ONCE_
 #define EMAT_DEVICE_COMMON_ONCE_
 namespace emat {
-// The workgroup's dynamic LDS block: [HKY tables][context][staged slab ...][optional scratch arena]
+// LDS of a workgroup: two STATIC objects -- the HKY tables and the context -- and the dynamic block [staged slab ...][scratch
+// arena].  They are separate objects on purpose: stores into the slab through a computed index (a node's time, a list entry)
+// then provably do not touch the context, so the compiler may keep context fields (RNG position, failure flag, byte counter,
+// arena marks) in registers across them instead of reloading each from LDS after every such store -- inside one array of bytes
+// every variable-index store may alias everything.
 extern __shared__ __attribute__((aligned(16))) uint8_t emat_lds[];
 constexpr uint32_t k_lds_tables_bytes = k_max_lds_partitions * (1 + 4 + 16) * 8;   // mu, pi, q per site partition
-constexpr uint32_t k_lds_ctx_off = k_lds_tables_bytes;
 constexpr uint32_t k_lds_ctx_bytes = 256;
-constexpr uint32_t k_lds_slab_off = k_lds_ctx_off + k_lds_ctx_bytes;
+constexpr uint32_t k_lds_static_bytes = k_lds_tables_bytes + k_lds_ctx_bytes;      // what every k_run_moves workgroup holds besides its dynamic block
+__shared__ __attribute__((aligned(16))) uint8_t emat_lds_tables[k_lds_tables_bytes];
+__shared__ __attribute__((aligned(16))) uint8_t emat_lds_ctx[k_lds_ctx_bytes];
 }  // namespace emat
 #define EMAT_D static __device__ inline
 #define EMAT_DN static __device__ __noinline__
@@ -99,16 +104,16 @@ struct Ctx {
 static_assert(sizeof(Ctx) + 16 <= k_lds_ctx_bytes, "context outgrew its LDS slot (the last 16 bytes are the kernel's flag word)");
 // Base pointers of the part's persistent state.
 #if EMAT_VARIANT_LDS
-EMAT_DF uint8_t* slab_of(const Ctx&) { return emat_lds + k_lds_slab_off; }
-EMAT_DF SlabHeader* hdr_of(const Ctx&) { return (SlabHeader*)(emat_lds + k_lds_slab_off); }
-EMAT_DF NodeRec* nodes_of(const Ctx&) { return (NodeRec*)(emat_lds + k_lds_slab_off + sizeof(SlabHeader)); }   // off_nodes == sizeof(SlabHeader), checked at launch
-EMAT_DF const double* mu_of(const Ctx&) { return (const double*)emat_lds; }
-EMAT_DF const double* pi_of(const Ctx&) { return (const double*)emat_lds + k_max_lds_partitions; }
-EMAT_DF const double* q_of(const Ctx&) { return (const double*)emat_lds + k_max_lds_partitions * 5; }
+EMAT_DF uint8_t* slab_of(const Ctx&) { return emat_lds; }
+EMAT_DF SlabHeader* hdr_of(const Ctx&) { return (SlabHeader*)emat_lds; }
+EMAT_DF NodeRec* nodes_of(const Ctx&) { return (NodeRec*)(emat_lds + sizeof(SlabHeader)); }   // off_nodes == sizeof(SlabHeader), checked at launch
+EMAT_DF const double* mu_of(const Ctx&) { return (const double*)emat_lds_tables; }
+EMAT_DF const double* pi_of(const Ctx&) { return (const double*)emat_lds_tables + k_max_lds_partitions; }
+EMAT_DF const double* q_of(const Ctx&) { return (const double*)emat_lds_tables + k_max_lds_partitions * 5; }
 #if EMAT_VARIANT_LDS == 2
 EMAT_DF uint8_t* heap_base_of(const Ctx& c) { return c.G; }   // list offsets are slab-relative: same numbers, HBM base
 #else
-EMAT_DF uint8_t* heap_base_of(const Ctx&) { return emat_lds + k_lds_slab_off; }
+EMAT_DF uint8_t* heap_base_of(const Ctx&) { return emat_lds; }
 #endif
 #else
 EMAT_DF uint8_t* heap_base_of(const Ctx& c) { return c.S; }
@@ -659,7 +664,7 @@ EMAT_DN double skygrid_log_int_N(const PopTable& p, double a, double b) {   // p
   }
   return log(result) + bias;
 }
-EMAT_DN double pop_integral(const PopTable& p, double a, double b) {
+EMAT_NOTAIL EMAT_DN double pop_integral(const PopTable& p, double a, double b) {
   if (p.kind == 0) return (b - a) * p.p[0];
   if (p.kind == 1) {   // pop_model.cpp:43-91
     double n0 = p.p[1], g = p.p[2], t0 = p.p[0], min_pop = p.p[3], t_c = p.t_c;
@@ -696,13 +701,13 @@ EMAT_D double cell_lbound(const Ctx& c, int cell) { return cell_ubound(c, cell) 
 // `kGrow` = the caller may be running the part that holds the run's root.  Parts that do not can never append cells, and
 // their simple moves are compiled with kGrow = false so that they contain no call at all (leaf functions: no return
 // address or frame pointer to save).
-EMAT_DN void coal_grow(Ctx& c, int cell);
+EMAT_NOTAIL EMAT_DN void coal_grow(Ctx& c, int cell);
 template <bool kGrow = true> EMAT_DF void coal_ensure_space(Ctx& c, double t) {
   int cell = cell_for(c, t);
   if (kGrow) { if (cell >= hdr_of(c)->n_cells_total && c.includes_run_root) coal_grow(c, cell); }   // rare: the root moved past the grid
   if (cell < hdr_of(c)->cell_first || cell >= hdr_of(c)->n_cells_total) EMAT_FAIL(c, k_part_internal);
 }
-EMAT_DN void coal_grow(Ctx& c, int cell) {
+EMAT_NOTAIL EMAT_DN void coal_grow(Ctx& c, int cell) {
   {
     Cells k = cells_of(c);
     while (hdr_of(c)->n_cells_total <= cell) {

@@ -28,40 +28,59 @@ EMAT_D double bounded_exponential(Ctx& c, double lambda, double a, double b) {
 }
 EMAT_D int pick_random_node(Ctx& c) { return uniform_int(c, hdr_of(c)->n_nodes); }
 
-// subrun.cpp:683-742
+// subrun.cpp:683-742.  What the move keeps across its calls (the two grafts, the nodes and times it started from) lives in a
+// frame of the scratch arena, read back through the context after every call -- like an SPR1 move's Spr1Frame -- instead of
+// in registers that every call would make the compiler spill to private memory: with one lane active every private dword
+// dirties a 64-byte line of its own.
+struct CoreFrame {
+  int X, new_branch, P, old_S;
+  double new_t, alpha_ratio, old_t_P, d_prior, log_mh;
+  Graft old_graft, new_graft;
+};
+#ifndef EMAT_CF
+#define EMAT_CF(c) (*(CoreFrame*)(c).frame)
+#endif
 EMAT_NOTAIL EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new_t, double alpha_ratio) { EMAT_TIMED(2);
   if (X == hdr_of(c)->root) return;
   if (!c.includes_run_root) if (nodes_of(c)[X].parent == hdr_of(c)->root || new_branch == hdr_of(c)->root) return;
-  const double t_X = nodes_of(c)[X].t;
-  const int P = nodes_of(c)[X].parent;
-  const double old_t_P = nodes_of(c)[P].t;
-  const int old_S = sibling_of(c, P, X);
-  const double new_t_P = new_t;
-  if (new_t_P == t_X || new_t_P == nodes_of(c)[new_branch].t || (P != hdr_of(c)->root && new_t_P == nodes_of(c)[nodes_of(c)[P].parent].t)) return;
-  if (coal_needs_cells(c, new_t_P)) { stop_for_cells(c, (int)c.tr_kind); return; }   // before the graft is peeled: nothing has changed yet
+  {
+    const double t_X = nodes_of(c)[X].t;
+    const int P = nodes_of(c)[X].parent;
+    const double new_t_P = new_t;
+    if (new_t_P == t_X || new_t_P == nodes_of(c)[new_branch].t || (P != hdr_of(c)->root && new_t_P == nodes_of(c)[nodes_of(c)[P].parent].t)) return;
+    if (coal_needs_cells(c, new_t_P)) { stop_for_cells(c, (int)c.tr_kind); return; }   // before the graft is peeled: nothing has changed yet
+    CoreFrame* f = (CoreFrame*)sc_alloc(c, (uint32_t)sizeof(CoreFrame));
+    if (c.failed) return;
+    c.frame = (uint8_t*)f;
+    f->X = X; f->new_branch = new_branch; f->P = P; f->old_S = sibling_of(c, P, X);
+    f->new_t = new_t; f->alpha_ratio = alpha_ratio; f->old_t_P = nodes_of(c)[P].t;
+  }
   c.mu_prop = nodes_of(c)[hdr_of(c)->root].lambda / (c.L - nodes_of(c)[hdr_of(c)->root].n_missing);
   EMAT_PHASE_BEGIN();
-  Graft old_graft = analyze_graft(c, X);
-  peel_graft(c, old_graft);
+  analyze_graft(c, EMAT_CF(c).X, EMAT_CF(c).old_graft);
+  peel_graft(c, EMAT_CF(c).old_graft);
   EMAT_PHASE(c, 0);
-  spr_move_topology(c, X, new_branch, new_t);
+  spr_move_topology(c, EMAT_CF(c).X, EMAT_CF(c).new_branch, EMAT_CF(c).new_t);
   EMAT_PHASE(c, 1);
-  Graft new_graft = propose_new_graft(c, X);
+  propose_new_graft(c, EMAT_CF(c).X, EMAT_CF(c).new_graft);
   EMAT_PHASE(c, 2);
   if (c.failed) return;
-  double d_prior = coal_delta_displace_coalescence(c, old_t_P, new_t);
-  double log_mh = (new_graft.delta_log_G - new_graft.log_alpha_mut) - (old_graft.delta_log_G - old_graft.log_alpha_mut) + log(alpha_ratio) + d_prior;
+  EMAT_CF(c).d_prior = coal_delta_displace_coalescence(c, EMAT_CF(c).old_t_P, EMAT_CF(c).new_t);
+  {
+    const CoreFrame& f = EMAT_CF(c);
+    EMAT_CF(c).log_mh = (f.new_graft.delta_log_G - f.new_graft.log_alpha_mut) - (f.old_graft.delta_log_G - f.old_graft.log_alpha_mut) + log(f.alpha_ratio) + f.d_prior;
+  }
   if (c.failed) return;
-  bool acc = mh_accept(c, log_mh);
-  if (c.tr_kind == (double)k_subtree_slide) note_move(c, X, log_mh, acc, k_subtree_slide);
+  const bool acc = mh_accept(c, EMAT_CF(c).log_mh);
+  if (c.tr_kind == (double)k_subtree_slide) note_move(c, EMAT_CF(c).X, EMAT_CF(c).log_mh, acc, k_subtree_slide);
   if (acc) {
-    apply_graft(c, new_graft);
-    hdr_of(c)->log_G -= old_graft.delta_log_G; hdr_of(c)->log_G += new_graft.delta_log_G;
-    hdr_of(c)->log_aug_prior += d_prior;
-    coal_coalescence_displaced(c, old_t_P, new_t);
+    apply_graft(c, EMAT_CF(c).new_graft);
+    hdr_of(c)->log_G -= EMAT_CF(c).old_graft.delta_log_G; hdr_of(c)->log_G += EMAT_CF(c).new_graft.delta_log_G;
+    hdr_of(c)->log_aug_prior += EMAT_CF(c).d_prior;
+    coal_coalescence_displaced(c, EMAT_CF(c).old_t_P, EMAT_CF(c).new_t);
   } else {
-    spr_move_topology(c, X, old_S, old_t_P);
-    apply_graft(c, old_graft);
+    spr_move_topology(c, EMAT_CF(c).X, EMAT_CF(c).old_S, EMAT_CF(c).old_t_P);
+    apply_graft(c, EMAT_CF(c).old_graft);
   }
   EMAT_PHASE(c, 4);
 }
@@ -70,7 +89,7 @@ EMAT_NOTAIL EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new
 // displaced, its coalescent grid may grow, branch reforms next to the root go through spr_move_core) and kRoot = false for
 // every other part, where none of that can happen: those versions contain no call and no root-only code, so they are
 // leaf functions without a stack frame.
-template <bool kRoot> EMAT_DN void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
+template <bool kRoot> EMAT_NOTAIL EMAT_DN void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
   begin_move(c, k_inner_node_displace);
   int node;
   { int guard = 0; do { node = pick_random_node(c); } while (is_tip(c, node) && guard++ < (1 << 26)); }
@@ -133,7 +152,7 @@ template <bool kRoot> EMAT_DN void inner_node_displace_move(Ctx& c) {   // subru
   }
 }
 
-template <bool kRoot> EMAT_DN void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
+template <bool kRoot> EMAT_NOTAIL EMAT_DN void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
   begin_move(c, k_tip_displace);
   int node;
   { int guard = 0; do { node = pick_random_node(c); } while (!is_tip(c, node) && guard++ < (1 << 26)); }
@@ -318,7 +337,7 @@ EMAT_NOTAIL EMAT_DN void spr1_move_begin(Ctx& c) { EMAT_TIMED(2);
   fr.X = X; fr.t_X = nodes_of(c)[X].t; fr.P = P; fr.old_t_P = nodes_of(c)[P].t; fr.old_S = sibling_of(c, P, X); fr.old_G = nodes_of(c)[P].parent;
   fr.limit = limit; fr.f = 0.8 /* annealing factor */; fr.t_max_tip = c.t_max_tip; fr.can_change_root = c.includes_run_root;
   fr.hot = (limit == 1) ? sc_reserve_hot(c, EMAT_HOT_BYTES) : HotBlock{nullptr, 0};
-  fr.old_graft = analyze_graft(c, X);
+  analyze_graft(c, X, fr.old_graft);
   peel_graft(c, fr.old_graft);
   EMAT_PHASE(c, 5);
   if (c.failed) return;
@@ -358,7 +377,7 @@ EMAT_NOTAIL EMAT_DN void spr1_move_propose(Ctx& c) { EMAT_TIMED(2);
   if (coal_needs_cells(c, new_t_P)) { apply_graft(c, fr.old_graft); if (!c.failed) stop_for_cells(c, k_spr1); return; }   // the old graft goes back on, as after a rejection
   spr_move_topology(c, X, new_S, new_t_P);
   EMAT_PHASE(c, 8);
-  fr.new_graft = propose_new_graft(c, X);
+  propose_new_graft(c, X, fr.new_graft);
   EMAT_PHASE(c, 9);
   if (c.failed) return;
   EMAT_CHECK(c, nodes_of(c)[X].parent == P);

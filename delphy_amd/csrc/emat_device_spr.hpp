@@ -449,14 +449,14 @@ EMAT_D double log_alpha_mut_term(double mu_p, int L, double T, int M, bool is_op
 }
 
 // ---- rooty grafts -----------------------------------------------------------------------------------------
-EMAT_DN Graft start_rooty_graft_analysis(Ctx& c, int X) { EMAT_TIMED(1);   // spr_move.cpp:91-205
-  Graft g; g.X = X; g.rooty = true; g.delta_log_G = g.log_alpha_mut = 0.0;
+EMAT_DN void start_rooty_graft_analysis(Ctx& c, int X, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:91-205
+  g.X = X; g.rooty = true; g.delta_log_G = g.log_alpha_mut = 0.0;
   const int P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
   const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t, t_S = nodes_of(c)[S].t;
   g.S = S; g.t_P = t_P;
   EMAT_CHECK(c, P == hdr_of(c)->root && c.includes_run_root);
   g.bi = (BranchInfo*)sc_alloc(c, 3 * sizeof(BranchInfo)); g.nbi = 3;
-  if (c.failed) { g.nbi = 0; return g; }
+  if (c.failed) { g.nbi = 0; return; }
   for (int i = 0; i < 3; ++i) bi_init(g.bi[i]);
   const MutRec* mX = muts_of(c, X); const int nX = nmuts(c, X);
   const MutRec* mS = muts_of(c, S); const int nS = nmuts(c, S);
@@ -493,7 +493,7 @@ EMAT_DN Graft start_rooty_graft_analysis(Ctx& c, int X) { EMAT_TIMED(1);   // sp
   }
   for (int i = 0; i < nX; ++i) if (iv_contains(SPX.hot.p, SPX.hot.n, mX[i].site)) { push(c, SPX.hot_muts, mX[i]); sd_push_back(c, SPX.hot_deltas, mX[i].site, mX[i].from, mX[i].to); }
   c.bytes += 3 * 64 + 16 * (nX + nS) + 24 * ((int)nodes_of(c)[X].miss.cnt + (int)nodes_of(c)[S].miss.cnt + (int)nodes_of(c)[P].miss.cnt);
-  return g;
+  return;
 }
 EMAT_D void filter_not_hot(SVec<MutRec>& v, const SVec<IvRec>& hot) { int w = 0; for (int i = 0; i < v.n; ++i) if (iv_contains(hot.p, hot.n, v.p[i].site)) v.p[w++] = v.p[i]; v.n = w; }
 EMAT_D SVec<MutRec> sample_history_for(Ctx& c, const BranchInfo& bi) {
@@ -606,11 +606,11 @@ EMAT_DN void apply_rooty_graft(Ctx& c, const Graft& g) { EMAT_TIMED(1);   // spr
 }
 
 // ---- inner grafts -----------------------------------------------------------------------------------------
-EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) { EMAT_TIMED(1);   // spr_move.cpp:582-738
-  Graft g; g.X = X; g.rooty = false; g.delta_log_G = g.log_alpha_mut = 0.0; g.nbi = 0; g.bi = nullptr;
+EMAT_DN void start_inner_graft_analysis(Ctx& c, int X, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:582-738
+  g.X = X; g.rooty = false; g.delta_log_G = g.log_alpha_mut = 0.0; g.nbi = 0; g.bi = nullptr;
   const int P = nodes_of(c)[X].parent;
   EMAT_CHECK(c, X != hdr_of(c)->root && P != hdr_of(c)->root);
-  if (c.failed) return g;
+  if (c.failed) return;
   const int S = sibling_of(c, P, X);
   const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t;
   g.S = S; g.t_P = t_P;
@@ -621,7 +621,7 @@ EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) { EMAT_TIMED(1);   // sp
   // abandoned array stays in the arena until the move ends) -- 104 bytes per entry of an arena of a few KB.
   int bi_cap = depth + 2 < 4 ? depth + 2 : 4;
   g.bi = (BranchInfo*)sc_alloc(c, (uint32_t)bi_cap * (uint32_t)sizeof(BranchInfo));
-  if (c.failed) return g;
+  if (c.failed) return;
   auto bi_room = [&]() {
     if (g.nbi < bi_cap) return;
     if (bi_cap >= depth + 2) { EMAT_FAIL(c, k_part_overflow); return; }
@@ -681,7 +681,7 @@ EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) { EMAT_TIMED(1);   // sp
       sl_iv.n = 0; sl_fs.n = 0;
     }
   }
-  if (c.failed) return g;
+  if (c.failed) return;
   // distribute hot mutations along the hot path (spr_move.cpp:700-735): gather (mutation, owner), then split by owner
   struct Owned { MutRec m; int owner; int pad; };
   SVec<Owned> tmp = sc_vec<Owned>(c, path_muts + 1);
@@ -710,7 +710,7 @@ EMAT_DN Graft start_inner_graft_analysis(Ctx& c, int X) { EMAT_TIMED(1);   // sp
       bi.pl_X += dq(c, m.site, m.from, m.to);
     }
   }
-  return g;
+  return;
 }
 EMAT_DN void propose_new_inner_graft_mutations(Ctx& c, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:740-785
   const int X = g.X;
@@ -845,17 +845,14 @@ EMAT_DN void apply_inner_graft(Ctx& c, const Graft& g) { EMAT_TIMED(1);   // spr
 
 // ---- dispatch (spr_move.cpp:9-89, 549-580, 1071-1099) -------------------------------------------------------
 EMAT_D bool is_rooty(const Ctx& c, int X) { return nodes_of(c)[X].parent == hdr_of(c)->root; }
-EMAT_D Graft analyze_graft(Ctx& c, int X) {
-  Graft g;
-  if (is_rooty(c, X)) { g = start_rooty_graft_analysis(c, X); finish_rooty_graft_analysis(c, g); }
-  else { g = start_inner_graft_analysis(c, X); finish_inner_graft_analysis(c, g); }
-  return g;
+// The graft is written where the caller keeps it (an arena frame): no copy through the caller's private stack.
+EMAT_D void analyze_graft(Ctx& c, int X, Graft& g) {
+  if (is_rooty(c, X)) { start_rooty_graft_analysis(c, X, g); finish_rooty_graft_analysis(c, g); }
+  else { start_inner_graft_analysis(c, X, g); finish_inner_graft_analysis(c, g); }
 }
-EMAT_D Graft propose_new_graft(Ctx& c, int X) {
-  Graft g;
-  if (is_rooty(c, X)) { g = start_rooty_graft_analysis(c, X); if (!c.failed) propose_new_rooty_graft_mutations(c, g); finish_rooty_graft_analysis(c, g); }
-  else { g = start_inner_graft_analysis(c, X); if (!c.failed) propose_new_inner_graft_mutations(c, g); finish_inner_graft_analysis(c, g); }
-  return g;
+EMAT_D void propose_new_graft(Ctx& c, int X, Graft& g) {
+  if (is_rooty(c, X)) { start_rooty_graft_analysis(c, X, g); if (!c.failed) propose_new_rooty_graft_mutations(c, g); finish_rooty_graft_analysis(c, g); }
+  else { start_inner_graft_analysis(c, X, g); if (!c.failed) propose_new_inner_graft_mutations(c, g); finish_inner_graft_analysis(c, g); }
 }
 EMAT_D void peel_graft(Ctx& c, const Graft& g) { if (is_rooty(c, g.X)) peel_rooty_graft(c, g); else peel_inner_graft(c, g); }
 EMAT_D void apply_graft(Ctx& c, const Graft& g) { if (is_rooty(c, g.X)) apply_rooty_graft(c, g); else apply_inner_graft(c, g); }
@@ -1117,6 +1114,20 @@ EMAT_D double safe_log_gamma_integral(Ctx& c, double a, double x_min, double x_m
   return log(Q_hi - Q_lo);
 }
 constexpr double k_ln2 = 0.693147180559945309417232121458176568;
+// log-weight of a region above the root (spr_study.cpp:336-370): truncated-Gamma weight through lgamma and the incomplete
+// gamma function, or the power law below x_max = 0.01.  Out of line: its register appetite (lgamma, pow, log1p and the
+// continued fraction) would otherwise make every study -- all 64 lanes -- spill around a branch that only the part holding
+// the run's root ever takes.
+EMAT_DN double root_region_log_weight(Ctx& c, const Study& st, const Region& r) {
+  const double f = st.f, lambda_X = st.lambda_X;
+  const int m = r.min_muts;
+  RootRegionParams p = root_region_params(c, st, r);
+  if (p.x_max < 0.01) {
+    double alpha = f * m + 1;
+    return -k_ln2 + log(f * lambda_X) + f * m * log(st.mu / 3) + alpha * log(p.s_max) + log1p(-pow(p.s_min / p.s_max, alpha)) - log(alpha);
+  }
+  return -k_ln2 + f * m * log(st.mu / (3 * lambda_X * f)) + lgamma(f * m + 1) + safe_log_gamma_integral(c, f * m + 1, p.x_min, p.x_max);
+}
 EMAT_DN Study make_study(Ctx& c, SVec<Region> regions, int num_missing_at_X, double lambda_X, double f, double t_X, double t_max_tip) { EMAT_TIMED(1);   // spr_study.cpp:226-385
   Study st; st.regions = regions; st.lambda_X = lambda_X; st.f = f; st.t_X = t_X; st.t_max_tip = t_max_tip; st.log_Wmax = 0.0; st.sum_W = 0.0;
   st.mu = lambda_X / (c.L - num_missing_at_X);
@@ -1131,15 +1142,7 @@ EMAT_DN Study make_study(Ctx& c, SVec<Region> regions, int num_missing_at_X, dou
     if (r.t_min != k_neg_dbl_max) {
       double t_prime = 0.5 * (r.t_min + r.t_max);
       logW = log(f * lambda_X * (r.t_max - r.t_min)) + f * (-lambda_X * (t_X - t_prime) + m * log(st.mu * (t_X - t_prime) / 3));
-    } else {
-      RootRegionParams p = root_region_params(c, st, r);
-      if (p.x_max < 0.01) {
-        double alpha = f * m + 1;
-        logW = -k_ln2 + log(f * lambda_X) + f * m * log(st.mu / 3) + alpha * log(p.s_max) + log1p(-pow(p.s_min / p.s_max, alpha)) - log(alpha);
-      } else {
-        logW = -k_ln2 + f * m * log(st.mu / (3 * lambda_X * f)) + lgamma(f * m + 1) + safe_log_gamma_integral(c, f * m + 1, p.x_min, p.x_max);
-      }
-    }
+    } else logW = root_region_log_weight(c, st, r);
     regions.p[i].logW = logW;
     if (i == 0) log_Wmax = logW; else if (log_Wmax < logW) log_Wmax = logW;
   }
@@ -1249,15 +1252,7 @@ EMAT_D void wave_make_study(Ctx& c, Spr1Frame& fr, SVec<Region> regions) {
     if (r.t_min != k_neg_dbl_max) {
       double t_prime = 0.5 * (r.t_min + r.t_max);
       logW = log(f * lambda_X * (r.t_max - r.t_min)) + f * (-lambda_X * (t_X - t_prime) + m * log(mu * (t_X - t_prime) / 3));
-    } else {
-      RootRegionParams p = root_region_params(c, st, r);
-      if (p.x_max < 0.01) {
-        double alpha = f * m + 1;
-        logW = -k_ln2 + log(f * lambda_X) + f * m * log(mu / 3) + alpha * log(p.s_max) + log1p(-pow(p.s_min / p.s_max, alpha)) - log(alpha);
-      } else {
-        logW = -k_ln2 + f * m * log(mu / (3 * lambda_X * f)) + lgamma(f * m + 1) + safe_log_gamma_integral(c, f * m + 1, p.x_min, p.x_max);
-      }
-    }
+    } else logW = root_region_log_weight(c, st, r);
     regions.p[i].logW = logW;
     if (logW == logW) { if (!any || my_max < logW) my_max = logW; any = true; }   // NaNs never replace the running maximum
   }
