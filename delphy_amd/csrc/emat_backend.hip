@@ -100,8 +100,10 @@ __device__ inline double wave_sum(double x) {
 }
 
 // Fills the model pointers of a context; HKY tables come from LDS when they were staged.
-template <class CtxT> __device__ inline void init_ctx(CtxT& c, uint8_t* slab, uint8_t* gslab, const KernelArgs& a, const double* lds_tables) {
-  c.S = slab; c.G = gslab; c.H = (SlabHeader*)slab; c.N = (NodeRec*)(slab + c.H->off_nodes);
+// `slab` = where slab offsets resolve for the generic code variant (the HBM slab); the LDS variants address header, nodes and
+// lists through compile-time LDS addresses and only need `H` here, to pick up the RNG position and flags.
+template <class CtxT> __device__ inline void init_ctx(CtxT& c, uint8_t* slab, uint8_t* gslab, const KernelArgs& a, const double* lds_tables, SlabHeader* H = nullptr) {
+  c.S = slab; c.G = gslab; c.H = H != nullptr ? H : (SlabHeader*)slab; c.N = (NodeRec*)(slab + c.H->off_nodes);
   c.L = a.evo.num_sites;
   c.ref = (const __attribute__((address_space(1))) uint8_t*)a.evo.ref_sequence; c.part = (const __attribute__((address_space(1))) uint8_t*)a.evo.partition_for_site;
   c.nu = (const __attribute__((address_space(1))) double*)a.evo.nu_l; c.cumQ = (const __attribute__((address_space(1))) double*)a.evo.cum_Q_l;
@@ -193,12 +195,13 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
     // stage the persistent state (header, nodes, cells, trace, list heap) -- or, for a part too large for that, its
     // fixed-size prefix up to the list heap; scratch always stays in HBM
     const uint32_t staged_bytes = staged ? gh->heap_top : (prefix ? gh->heap_begin : 0u);
-    if (staged_bytes) wave_copy16(lds_slab, gslab, staged_bytes, lane);
+    if (staged_bytes) { wave_copy16(emat_lds_hdr, gslab, (uint32_t)sizeof(SlabHeader), lane); wave_copy16(lds_slab, gslab + sizeof(SlabHeader), staged_bytes - (uint32_t)sizeof(SlabHeader), lane); }
     // a leg that works on the HBM slab itself keeps a copy of what it found (header, nodes, cells, trace, lists in use)
     uint8_t* const snap = (!staged && a.snaps != nullptr) ? a.snaps + a.slab_off[part] : nullptr;
     if (snap != nullptr) wave_copy16(snap, gslab, (gh->heap_top + 15u) & ~15u, lane);
     __syncthreads();
-    SlabHeader* H = (staged || prefix) ? (SlabHeader*)lds_slab : gh;
+    SlabHeader* const lds_hdr = (SlabHeader*)emat_lds_hdr;
+    SlabHeader* H = (staged || prefix) ? lds_hdr : gh;
     // The root part is one chain like any other, but its moves walk long runs of coalescent cells (deep branches span
     // hundreds of cells): compute-bound, the longest chain of its launch.  Let its wave win issue arbitration on its SIMD.
     const bool is_root_part = (gh->flags & k_flag_includes_run_root) != 0;
@@ -207,23 +210,23 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
       // The context lives in LDS, not in private memory: it is touched by almost every instruction.
       if (staged) {
         dev_lds::Ctx& c = *(dev_lds::Ctx*)(emat_lds_ctx);
-        init_ctx(c, lds_slab, gslab, a, lds_tables);
+        init_ctx(c, gslab, gslab, a, lds_tables, lds_hdr);
         H->heap_end = lds_heap_end;
         // whatever the part leaves unused of the staging area (plus the optional extra arena) serves as the first-level
         // scratch arena of its moves; scratch that does not fit goes to the part's HBM scratch region as before
         const uint32_t used = (lds_heap_end + 15u) & ~15u;
-        c.A = lds_slab + used; c.a_end = area + a.lds_scratch_bytes - used;
+        c.A = lds_slab + (used - (uint32_t)sizeof(SlabHeader)); c.a_end = area + a.lds_scratch_bytes - used;
       } else if (prefix) {
         // the prefix leaves the rest of the staging area free: the moves' first-level arena, as for a staged part (before
         // round 2's end these parts -- 40-60 nodes, the slowest chains of a pass -- ran every candidate scan through HBM)
         dev_mix::Ctx& c = *(dev_mix::Ctx*)(emat_lds_ctx);
-        init_ctx(c, lds_slab, gslab, a, lds_tables);
+        init_ctx(c, gslab, gslab, a, lds_tables, lds_hdr);
         const uint32_t used = (gh->heap_begin + 15u) & ~15u;
-        c.A = lds_slab + used; c.a_end = area + a.lds_scratch_bytes - used;
+        c.A = lds_slab + (used - (uint32_t)sizeof(SlabHeader)); c.a_end = area + a.lds_scratch_bytes - used;
       } else {
         dev::Ctx& c = *(dev::Ctx*)(emat_lds_ctx);
         init_ctx(c, gslab, gslab, a, tables_staged ? lds_tables : nullptr);
-        if (area + a.lds_scratch_bytes != 0) { c.A = lds_slab; c.a_end = area + a.lds_scratch_bytes; }   // nothing of the part is staged: the whole area is arena
+        if (area + a.lds_scratch_bytes > (uint32_t)sizeof(SlabHeader)) { c.A = lds_slab; c.a_end = area + a.lds_scratch_bytes - (uint32_t)sizeof(SlabHeader); }   // nothing of the part is staged: the whole dynamic block is arena
       }
       // (a later ticket of a part whose earlier one had to stop does nothing: the host gives the part more room and the rest of its moves)
       const bool stopped_before = chunk > 0 && a.part_status[part] != 0;
@@ -281,8 +284,8 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
     __syncthreads();
     const int again_all = *lds_flag;
     if (again_all < 2) {
-      if (staged) wave_copy16(gslab, lds_slab, ((const SlabHeader*)lds_slab)->heap_top, lane);
-      else if (prefix) wave_copy16(gslab, lds_slab, staged_bytes, lane);
+      const uint32_t out_bytes = staged ? ((const SlabHeader*)emat_lds_hdr)->heap_top : (prefix ? staged_bytes : 0u);
+      if (out_bytes) { wave_copy16(gslab, emat_lds_hdr, (uint32_t)sizeof(SlabHeader), lane); wave_copy16(gslab + sizeof(SlabHeader), lds_slab, out_bytes - (uint32_t)sizeof(SlabHeader), lane); }
     }
     if (again_all == 4) { wave_copy16(gslab, snap, (((const SlabHeader*)snap)->heap_top + 15u) & ~15u, lane); break; }
     if (again_all == 0 || again_all == 3) break;
@@ -1284,9 +1287,10 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
   st = materialize(h); if (st) return st;
   if (!h->derived_valid) { st = launch_recalc(h); if (st) return st; }
   const uint32_t lds_scratch = h->cfg.use_lds ? h->cfg_lds_scratch : 0u;
-  auto shmem_for = [&](uint32_t slab_area) { return (size_t)slab_area + lds_scratch; };   // the dynamic block; tables and context are static LDS
+  // the dynamic block: the slab image beyond its header + the arena; tables, context and the header image are static LDS
+  auto shmem_for = [&](uint32_t slab_area) { return (size_t)(slab_area > (uint32_t)sizeof(SlabHeader) ? slab_area - (uint32_t)sizeof(SlabHeader) : 0u) + lds_scratch; };
   for (int c = 0; c < h->num_classes; ++c)
-    if (shmem_for(h->class_lds[c]) + k_lds_static_bytes > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower EMAT_LDS_MAX or disable use_lds");
+    if (shmem_for(h->class_lds[c]) + k_lds_static_bytes + sizeof(SlabHeader) > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower EMAT_LDS_MAX or disable use_lds");
   if (!h->order_valid) { st = build_order(h); if (st) return st; }
   HIP_TRY(h->d_snaps.alloc(h->d_slabs.n));
   KernelArgs a = make_args(h);

@@ -37,9 +37,13 @@ namespace emat {
 extern __shared__ __attribute__((aligned(16))) uint8_t emat_lds[];
 constexpr uint32_t k_lds_tables_bytes = k_max_lds_partitions * (1 + 4 + 16) * 8;   // mu, pi, q per site partition
 constexpr uint32_t k_lds_ctx_bytes = 256;
-constexpr uint32_t k_lds_static_bytes = k_lds_tables_bytes + k_lds_ctx_bytes;      // what every k_run_moves workgroup holds besides its dynamic block
+constexpr uint32_t k_lds_static_bytes = k_lds_tables_bytes + k_lds_ctx_bytes;      // what every k_run_moves workgroup holds besides the slab image and the arena
 __shared__ __attribute__((aligned(16))) uint8_t emat_lds_tables[k_lds_tables_bytes];
 __shared__ __attribute__((aligned(16))) uint8_t emat_lds_ctx[k_lds_ctx_bytes];
+// The staged slab's HEADER is a third static object, for the same reason: its fields (root, node count, the coalescent
+// window, heap marks, counters) are read all the time and must not look clobbered by every store into nodes or lists.
+// The dynamic block then starts with slab byte sizeof(SlabHeader): slab offset `off` lives at emat_lds + off - sizeof(SlabHeader).
+__shared__ __attribute__((aligned(16))) uint8_t emat_lds_hdr[sizeof(SlabHeader)];
 }  // namespace emat
 #define EMAT_D static __device__ inline
 #define EMAT_DN static __device__ __noinline__
@@ -104,20 +108,20 @@ struct Ctx {
 static_assert(sizeof(Ctx) + 16 <= k_lds_ctx_bytes, "context outgrew its LDS slot (the last 16 bytes are the kernel's flag word)");
 // Base pointers of the part's persistent state.
 #if EMAT_VARIANT_LDS
-EMAT_DF uint8_t* slab_of(const Ctx&) { return emat_lds; }
-EMAT_DF SlabHeader* hdr_of(const Ctx&) { return (SlabHeader*)emat_lds; }
-EMAT_DF NodeRec* nodes_of(const Ctx&) { return (NodeRec*)(emat_lds + sizeof(SlabHeader)); }   // off_nodes == sizeof(SlabHeader), checked at launch
+EMAT_DF uint8_t* slab_at(const Ctx&, uint32_t off) { return emat_lds + (off - (uint32_t)sizeof(SlabHeader)); }   // slab byte `off` (beyond the header)
+EMAT_DF SlabHeader* hdr_of(const Ctx&) { return (SlabHeader*)emat_lds_hdr; }
+EMAT_DF NodeRec* nodes_of(const Ctx&) { return (NodeRec*)emat_lds; }   // off_nodes == sizeof(SlabHeader), checked at launch
 EMAT_DF const double* mu_of(const Ctx&) { return (const double*)emat_lds_tables; }
 EMAT_DF const double* pi_of(const Ctx&) { return (const double*)emat_lds_tables + k_max_lds_partitions; }
 EMAT_DF const double* q_of(const Ctx&) { return (const double*)emat_lds_tables + k_max_lds_partitions * 5; }
 #if EMAT_VARIANT_LDS == 2
-EMAT_DF uint8_t* heap_base_of(const Ctx& c) { return c.G; }   // list offsets are slab-relative: same numbers, HBM base
+EMAT_DF uint8_t* heap_at(const Ctx& c, uint32_t off) { return c.G + off; }   // list offsets are slab-relative: same numbers, HBM base
 #else
-EMAT_DF uint8_t* heap_base_of(const Ctx&) { return emat_lds; }
+EMAT_DF uint8_t* heap_at(const Ctx& c, uint32_t off) { return slab_at(c, off); }
 #endif
 #else
-EMAT_DF uint8_t* heap_base_of(const Ctx& c) { return c.S; }
-EMAT_DF uint8_t* slab_of(const Ctx& c) { return c.S; }
+EMAT_DF uint8_t* heap_at(const Ctx& c, uint32_t off) { return c.S + off; }
+EMAT_DF uint8_t* slab_at(const Ctx& c, uint32_t off) { return c.S + off; }
 EMAT_DF SlabHeader* hdr_of(const Ctx& c) { return c.H; }
 EMAT_DF NodeRec* nodes_of(const Ctx& c) { return c.N; }
 EMAT_DF const double* mu_of(const Ctx& c) { return c.mu; }
@@ -288,14 +292,14 @@ EMAT_D uint32_t heap_alloc(Ctx& c, uint32_t bytes) {
   hdr_of(c)->heap_top += b;
   return off;
 }
-template <class T> EMAT_D T* list_ptr(Ctx& c, const ListRef& r) { return (T*)(heap_base_of(c) + r.off); }
+template <class T> EMAT_D T* list_ptr(Ctx& c, const ListRef& r) { return (T*)heap_at(c, r.off); }
 template <class T> EMAT_D void list_reserve(Ctx& c, ListRef& r, int want) {
   if (want <= (int)r.cap) return;
   int nc = (int)r.cap * 2; if (nc < want) nc = want; if (nc < 4) nc = 4;
   if (nc > 65535) { if (want > 65535) { EMAT_FAIL(c, k_part_overflow); return; } nc = 65535; }
   uint32_t off = heap_alloc(c, (uint32_t)nc * (uint32_t)sizeof(T));
   if (c.failed) return;
-  T* dst = (T*)(heap_base_of(c) + off); const T* src = (const T*)(heap_base_of(c) + r.off);
+  T* dst = (T*)heap_at(c, off); const T* src = (const T*)heap_at(c, r.off);
   for (int i = 0; i < (int)r.cnt; ++i) dst[i] = src[i];
   r.off = off; r.cap = (uint16_t)nc;
 }
@@ -318,9 +322,9 @@ template <class T> EMAT_D void list_erase_prefix(Ctx& c, ListRef& r, int k) {
 }
 EMAT_D void swap_lists(ListRef& a, ListRef& b) { ListRef t = a; a = b; b = t; }
 
-EMAT_D MutRec* muts_of(Ctx& c, int n) { return (MutRec*)(heap_base_of(c) + nodes_of(c)[n].muts.off); }
-EMAT_D IvRec* miss_of(Ctx& c, int n) { return (IvRec*)(heap_base_of(c) + nodes_of(c)[n].miss.off); }
-EMAT_D FsRec* mfs_of(Ctx& c, int n) { return (FsRec*)(heap_base_of(c) + nodes_of(c)[n].mfs.off); }
+EMAT_D MutRec* muts_of(Ctx& c, int n) { return (MutRec*)heap_at(c, nodes_of(c)[n].muts.off); }
+EMAT_D IvRec* miss_of(Ctx& c, int n) { return (IvRec*)heap_at(c, nodes_of(c)[n].miss.off); }
+EMAT_D FsRec* mfs_of(Ctx& c, int n) { return (FsRec*)heap_at(c, nodes_of(c)[n].mfs.off); }
 EMAT_D int nmuts(const Ctx& c, int n) { return (int)nodes_of(c)[n].muts.cnt; }
 EMAT_D bool is_tip(const Ctx& c, int n) { return nodes_of(c)[n].child0 == k_no_node; }
 EMAT_D int sibling_of(Ctx& c, int parent, int x) {
@@ -690,7 +694,7 @@ EMAT_NOTAIL EMAT_DN double pop_integral(const PopTable& p, double a, double b) {
 struct Cells { double* kbar_p; double* ktw_p; double* ktw; double* popsize; double* ts_over_pop; int32_t* nactive; };
 EMAT_D Cells cells_of(Ctx& c) {
   Cells k; int cap = hdr_of(c)->cell_cap;
-  double* base = (double*)(slab_of(c) + hdr_of(c)->off_cells);
+  double* base = (double*)slab_at(c, hdr_of(c)->off_cells);
   k.kbar_p = base; k.ktw_p = base + cap; k.ktw = base + 2 * cap; k.popsize = base + 3 * cap; k.ts_over_pop = base + 4 * cap; k.nactive = (int32_t*)(base + 5 * cap);
   return k;
 }

@@ -437,7 +437,7 @@ EMAT_DN bool compact_heap(Ctx& c) {
     const uint32_t es[3] = {16u, 8u, 8u};
     for (int k = 0; k < 3; ++k) {
       uint32_t bytes = (uint32_t)refs[k]->cnt * es[k];
-      const uint64_t* src = (const uint64_t*)(heap_base_of(c) + refs[k]->off); uint64_t* dst = (uint64_t*)(stage + w);
+      const uint64_t* src = (const uint64_t*)heap_at(c, refs[k]->off); uint64_t* dst = (uint64_t*)(stage + w);
       for (uint32_t q = 0; q < bytes / 8; ++q) dst[q] = src[q];
       w += (bytes + 15u) & ~15u;
     }
@@ -448,7 +448,7 @@ EMAT_DN bool compact_heap(Ctx& c) {
     const uint32_t es[3] = {16u, 8u, 8u};
     for (int k = 0; k < 3; ++k) {
       uint32_t bytes = (uint32_t)refs[k]->cnt * es[k], padded = (bytes + 15u) & ~15u;
-      const uint64_t* src = (const uint64_t*)(stage + r); uint64_t* dst = (uint64_t*)(heap_base_of(c) + top);
+      const uint64_t* src = (const uint64_t*)(stage + r); uint64_t* dst = (uint64_t*)heap_at(c, top);
       for (uint32_t q = 0; q < bytes / 8; ++q) dst[q] = src[q];
       refs[k]->off = top; refs[k]->cap = (uint16_t)(padded / es[k]);
       top += padded; r += padded;
@@ -498,7 +498,7 @@ EMAT_NOTAIL EMAT_D bool mcmc_sub_iteration(Ctx& c) {
   c.phase = 0; c.svc = 0;
   if (hdr_of(c)->status == k_part_need_cells) return false;   // stopped before the move changed anything (stop_for_cells): not a move
   if (hdr_of(c)->trace_len < hdr_of(c)->trace_cap) {
-    double* tr = (double*)(slab_of(c) + hdr_of(c)->off_trace) + 4 * hdr_of(c)->trace_len;
+    double* tr = (double*)slab_at(c, hdr_of(c)->off_trace) + 4 * hdr_of(c)->trace_len;
     tr[0] = c.tr_kind; tr[1] = c.tr_node; tr[2] = c.tr_acc; tr[3] = c.tr_log_mh;
     hdr_of(c)->trace_len++;
   }
