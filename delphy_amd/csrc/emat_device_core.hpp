@@ -150,6 +150,14 @@ EMAT_D void fail_at(Ctx& c, int status, int line) {
 #endif
 #endif
 
+// One copy of each transcendental per code variant: the OCML bodies are 60-150 instructions and were inlined at every call
+// site, and the instruction cache of a CU pair is 64 KB for 32 resident chains that are all somewhere else in the code
+// (measured: simple moves 15 % smaller, +1.5 % moves/s; taking the ten Philox rounds out of line as well costs more in
+// calls than it saves in fetches).
+EMAT_DN double m_log(double x) { return ::log(x); }
+EMAT_DN double m_exp(double x) { return ::exp(x); }
+EMAT_DN double m_log1p(double x) { return ::log1p(x); }
+EMAT_DN double m_expm1(double x) { return ::expm1(x); }
 // ---- RNG: identical stream to the parity oracle (oracle/orc_core.hpp `Rng`) -------------------------
 EMAT_D void philox4x32_10(uint64_t ctr, uint64_t key, uint32_t out[4]) {
   uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;
@@ -189,13 +197,13 @@ EMAT_D int uniform_int(Ctx& c, int n) { return (int)__umul64hi(rng_next64(c), (u
 EMAT_D double gaussian(Ctx& c, double mean, double sigma) {
   uint64_t a = rng_next64(c), b = rng_next64(c);
   double u1 = to_oc(a), u2 = to_co(b);
-  double r = sqrt(-2.0 * log(u1));
+  double r = sqrt(-2.0 * m_log(u1));
   return mean + sigma * (r * cos(6.283185307179586476925 * u2));
 }
-EMAT_D double exponential(Ctx& c, double rate) { return -log(u01_oc(c)) / rate; }
+EMAT_D double exponential(Ctx& c, double rate) { return -m_log(u01_oc(c)) / rate; }
 EMAT_D int poisson(Ctx& c, double lambda) {
   double u = u01_co(c);
-  double p = exp(-lambda), F = p;
+  double p = m_exp(-lambda), F = p;
   int k = 0;
   while (u >= F && k < 100000) { ++k; p *= lambda / k; F += p; }
   return k;
@@ -510,7 +518,7 @@ EMAT_D double branch_log_G(const Ctx& c, double t_P, double t_X, double lambda_X
   for (int i = nm - 1; i >= 0; --i) {
     int l = m[i].site;
     r -= mu_of(c)[c.part[l]] * c.nu[l] * (q_a(c, l, m[i].from) - q_a(c, l, m[i].to)) * (m[i].t - t_P);
-    r += log(mu_of(c)[c.part[l]] * c.nu[l] * q_ab(c, l, m[i].from, m[i].to));
+    r += m_log(mu_of(c)[c.part[l]] * c.nu[l] * q_ab(c, l, m[i].from, m[i].to));
   }
   return r;
 }
@@ -595,8 +603,8 @@ EMAT_DF double skygrid_log_N(const PopTable& p, double t) {
 }
 EMAT_DF double pop_at_time(const PopTable& p, double t) {
   if (p.kind == 0) return p.p[0];
-  if (p.kind == 1) { double v = p.p[1] * exp((t - p.p[0]) * p.p[2]); return p.p[3] > v ? p.p[3] : v; }
-  return exp(skygrid_log_N(p, t));
+  if (p.kind == 1) { double v = p.p[1] * m_exp((t - p.p[0]) * p.p[2]); return p.p[3] > v ? p.p[3] : v; }
+  return m_exp(skygrid_log_N(p, t));
 }
 // log(N(t_new) / N(t_old)) (very_scalable_coalescent.cpp:323).  For the skygrid N = exp(log_N), so the ratio is formed in
 // log space directly; the other models go through pop_at_time's formula as the reference does.  Written for the lane that
@@ -638,11 +646,11 @@ EMAT_DF double log_pop_ratio_uniform(const PopTable* pp, double t_new, double t_
   t_new = uniform_f64(t_new); t_old = uniform_f64(t_old);
   if (kind == 2) return skygrid_log_N_uniform(p, t_new) - skygrid_log_N_uniform(p, t_old);
   const double t0 = p->p[0], n0 = p->p[1], gr = p->p[2], floor_n = p->p[3];
-  double a = n0 * exp((t_new - t0) * gr); a = floor_n > a ? floor_n : a;
-  double b = n0 * exp((t_old - t0) * gr); b = floor_n > b ? floor_n : b;
-  return log(a / b);
+  double a = n0 * m_exp((t_new - t0) * gr); a = floor_n > a ? floor_n : a;
+  double b = n0 * m_exp((t_old - t0) * gr); b = floor_n > b ? floor_n : b;
+  return m_log(a / b);
 }
-EMAT_D double exp_unclamped_int(const PopTable& p, double a, double b) { double n0 = p.p[1], g = p.p[2], t0 = p.p[0]; return n0 / g * exp(g * (a - t0)) * expm1(g * (b - a)); }
+EMAT_D double exp_unclamped_int(const PopTable& p, double a, double b) { double n0 = p.p[1], g = p.p[2], t0 = p.p[0]; return n0 / g * m_exp(g * (a - t0)) * m_expm1(g * (b - a)); }
 EMAT_DN double skygrid_log_int_N(const PopTable& p, double a, double b) {   // pop_model.cpp:247-330 with gamma_eff = gamma
   const double* x = p.skygrid_x; const double* ge = p.skygrid_gamma;
   int M = p.skygrid_num_knots - 1;
@@ -654,19 +662,19 @@ EMAT_DN double skygrid_log_int_N(const PopTable& p, double a, double b) {   // p
   for (int k = ka; k <= kb; ++k) {
     double lo = k > 0 ? (a > x[k - 1] ? a : x[k - 1]) : a;
     double hi = k <= M ? (b < x[k] ? b : x[k]) : b;
-    if (k == 0) result += exp(-bias + ge[0]) * (hi - lo);
-    else if (k == M + 1) result += exp(-bias + ge[M]) * (hi - lo);
-    else if (p.skygrid_type == 1) result += exp(-bias + ge[k]) * (hi - lo);
-    else if (ge[k] == ge[k - 1]) result += exp(-bias + ge[k]) * (hi - lo);
+    if (k == 0) result += m_exp(-bias + ge[0]) * (hi - lo);
+    else if (k == M + 1) result += m_exp(-bias + ge[M]) * (hi - lo);
+    else if (p.skygrid_type == 1) result += m_exp(-bias + ge[k]) * (hi - lo);
+    else if (ge[k] == ge[k - 1]) result += m_exp(-bias + ge[k]) * (hi - lo);
     else {
       double c_lo = (lo - x[k - 1]) / (x[k] - x[k - 1]), c_hi = (hi - x[k - 1]) / (x[k] - x[k - 1]);
       double G_lo = (1 - c_lo) * ge[k - 1] + c_lo * ge[k], G_hi = (1 - c_hi) * ge[k - 1] + c_hi * ge[k];
       double D = G_hi - G_lo;
-      if (D == 0.0) result += exp(-bias + G_lo) * (hi - lo);
-      else result += exp(-bias + G_lo) * (hi - lo) * (expm1(D) / D);
+      if (D == 0.0) result += m_exp(-bias + G_lo) * (hi - lo);
+      else result += m_exp(-bias + G_lo) * (hi - lo) * (m_expm1(D) / D);
     }
   }
-  return log(result) + bias;
+  return m_log(result) + bias;
 }
 EMAT_NOTAIL EMAT_DN double pop_integral(const PopTable& p, double a, double b) {
   if (p.kind == 0) return (b - a) * p.p[0];
@@ -677,13 +685,13 @@ EMAT_NOTAIL EMAT_DN double pop_integral(const PopTable& p, double a, double b) {
     if (g > 0.0) {
       if (b <= t_c) return (b - a) * min_pop;
       if (a >= t_c) return exp_unclamped_int(p, a, b);
-      return (t_c - a) * min_pop + n0 / g * exp(g * (t_c - t0)) * expm1(g * (b - t_c));
+      return (t_c - a) * min_pop + n0 / g * m_exp(g * (t_c - t0)) * m_expm1(g * (b - t_c));
     }
     if (a >= t_c) return (b - a) * min_pop;
     if (b <= t_c) return exp_unclamped_int(p, a, b);
-    return n0 / g * exp(g * (a - t0)) * expm1(g * (t_c - a)) + (b - t_c) * min_pop;
+    return n0 / g * m_exp(g * (a - t0)) * m_expm1(g * (t_c - a)) + (b - t_c) * min_pop;
   }
-  return exp(skygrid_log_int_N(p, a, b));
+  return m_exp(skygrid_log_int_N(p, a, b));
 }
 
 // ---- per-part coalescent prior (very_scalable_coalescent.cpp:14-79, 259-459) ----------------------------------------
@@ -835,9 +843,9 @@ EMAT_DN double gamma_q(double a, double x) {
   if (x < a + 1.0) {
     double ap = a, sum = 1.0 / a, del = sum;
     for (int n = 0; n < 100000; ++n) { ap += 1.0; del *= x / ap; sum += del; if (fabs(del) < fabs(sum) * 1e-17) break; }
-    return 1.0 - sum * exp(-x + a * log(x) - lg);
+    return 1.0 - sum * m_exp(-x + a * m_log(x) - lg);
   }
-  return exp(-x + a * log(x) - lg) * gamma_q_fraction(a, x);
+  return m_exp(-x + a * m_log(x) - lg) * gamma_q_fraction(a, x);
 }
 EMAT_DN double gamma_q_inv(double a, double q) {
   if (q == 0.0) return k_inf;
@@ -847,11 +855,11 @@ EMAT_DN double gamma_q_inv(double a, double q) {
     // Far upper tail (the reference's own test asks for Q down to 1e-300, safe_gamma_math_tests.cpp:83-95,247-262):
     // Newton on log Q(a, x) = log q, log Q = -x + a log x - lgamma(a) + log h taken from the continued fraction without
     // ever forming Q, and d/dx log Q = -density / Q = -1 / (x h); the steps close in on the root from one side.
-    const double lq = log(q);
+    const double lq = m_log(q);
     double x = a + 1.0, h = gamma_q_fraction(a, x), prev = 0.0;
-    if (-x + a * log(x) - lg + log(h) > lq) {   // the root lies where the fraction converges
+    if (-x + a * m_log(x) - lg + m_log(h) > lq) {   // the root lies where the fraction converges
       for (int j = 0; j < 100; ++j) {
-        double dx = (-x + a * log(x) - lg + log(h) - lq) * x * h;
+        double dx = (-x + a * m_log(x) - lg + m_log(h) - lq) * x * h;
         double xn = x + dx;
         if (xn < a + 1.0) xn = a + 1.0;
         bool done = fabs(xn - x) <= 1e-14 * xn || (j > 2 && fabs(dx) >= fabs(prev));
@@ -866,7 +874,7 @@ EMAT_DN double gamma_q_inv(double a, double q) {
   double x;
   if (a > 1.0) {
     double pp = (p < 0.5) ? p : q;
-    double t = sqrt(-2.0 * log(pp));
+    double t = sqrt(-2.0 * m_log(pp));
     double xg = (2.30753 + t * 0.27061) / (1.0 + t * (0.99229 + t * 0.04481)) - t;
     if (p < 0.5) xg = -xg;
     double v = a * pow(1.0 - 1.0 / (9.0 * a) - xg / (3.0 * sqrt(a)), 3.0);
@@ -874,13 +882,13 @@ EMAT_DN double gamma_q_inv(double a, double q) {
   } else {
     double t = 1.0 - a * (0.253 + a * 0.12);
     if (p < t) x = pow(p / t, 1.0 / a);
-    else x = 1.0 - log(1.0 - (p - t) / (1.0 - t));
+    else x = 1.0 - m_log(1.0 - (p - t) / (1.0 - t));
   }
   const double a1 = a - 1.0;
   for (int j = 0; j < 60; ++j) {
     if (x <= 0.0) x = 1e-300;
     double err = gamma_q(a, x) - q;
-    double tdens = exp(-x + a1 * log(x) - lg);
+    double tdens = m_exp(-x + a1 * m_log(x) - lg);
     if (tdens == 0.0) break;
     double u = -err / tdens;
     double w = u * (a1 / x - 1.0);

@@ -13,7 +13,7 @@ enum { k_inner_node_displace = 0, k_tip_displace = 1, k_branch_reform = 2, k_sub
 
 EMAT_D void begin_move(Ctx& c, int kind) { hdr_of(c)->proposed[kind]++; c.tr_kind = (double)kind; c.tr_node = -1.0; c.tr_acc = 0.0; c.tr_log_mh = __builtin_nan(""); }
 EMAT_D void note_move(Ctx& c, int node, double log_mh, bool acc, int kind) { c.tr_node = (double)node; c.tr_log_mh = log_mh; c.tr_acc = acc ? 1.0 : 0.0; if (acc) hdr_of(c)->accepted[kind]++; }
-EMAT_D bool mh_accept(Ctx& c, double log_mh) { return log_mh >= 0.0 || uniform_co(c, 0.0, 1.0) < exp(log_mh); }
+EMAT_D bool mh_accept(Ctx& c, double log_mh) { return log_mh >= 0.0 || uniform_co(c, 0.0, 1.0) < m_exp(log_mh); }
 
 // distributions.h:38-69
 EMAT_D double bounded_exponential(Ctx& c, double lambda, double a, double b) {
@@ -21,9 +21,9 @@ EMAT_D double bounded_exponential(Ctx& c, double lambda, double a, double b) {
   double ltr = lambda * (b - a);
   double x;
   if (lambda == 0.0) x = a + u * (b - a);
-  else if (lambda > 0 && ltr > 100) x = b + log(u) / lambda;
-  else if (lambda < 0 && ltr < -100) x = a + log(u) / lambda;
-  else x = a + log1p(u * (exp(ltr) - 1)) / lambda;
+  else if (lambda > 0 && ltr > 100) x = b + m_log(u) / lambda;
+  else if (lambda < 0 && ltr < -100) x = a + m_log(u) / lambda;
+  else x = a + m_log1p(u * (m_exp(ltr) - 1)) / lambda;
   return x < a ? a : (b < x ? b : x);
 }
 EMAT_D int pick_random_node(Ctx& c) { return uniform_int(c, hdr_of(c)->n_nodes); }
@@ -68,7 +68,7 @@ EMAT_NOTAIL EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new
   EMAT_CF(c).d_prior = coal_delta_displace_coalescence(c, EMAT_CF(c).old_t_P, EMAT_CF(c).new_t);
   {
     const CoreFrame& f = EMAT_CF(c);
-    EMAT_CF(c).log_mh = (f.new_graft.delta_log_G - f.new_graft.log_alpha_mut) - (f.old_graft.delta_log_G - f.old_graft.log_alpha_mut) + log(f.alpha_ratio) + f.d_prior;
+    EMAT_CF(c).log_mh = (f.new_graft.delta_log_G - f.new_graft.log_alpha_mut) - (f.old_graft.delta_log_G - f.old_graft.log_alpha_mut) + m_log(f.alpha_ratio) + f.d_prior;
   }
   if (c.failed) return;
   const bool acc = mh_accept(c, EMAT_CF(c).log_mh);
@@ -540,7 +540,7 @@ EMAT_DN double calc_log_root_prior(Ctx& c, const int32_t* ref_freqs, int P) {
       const FsRec* fs = mfs_of(c, root);
       for (int i = 0; i < (int)nodes_of(c)[root].mfs.cnt; ++i) if ((int)c.part[fs[i].site] == p) { if ((int)c.ref[fs[i].site] == a) ++f; if ((int)fs[i].state == a) --f; }
       double pa = pi_of(c)[p * 4 + a];
-      if (pa != 0.0) result += f * log(pa);
+      if (pa != 0.0) result += f * m_log(pa);
       else if (f != 0) return -k_inf;
     }
   }

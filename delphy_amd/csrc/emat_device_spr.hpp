@@ -313,7 +313,7 @@ EMAT_DN KTruncPoisson ktp_make(double lambda, int min_k) {
   KTruncPoisson d; d.lambda = lambda; d.min_k = min_k; d.normalization = 0.0; d.term_before_min_k = 0.0; d.max_k = 0.0;
   if ((double)min_k <= lambda) return d;
   d.max_k = (10.0 * min_k > 10.0 * lambda) ? 10.0 * min_k : 10.0 * lambda;
-  double last_term = 1.0, em1 = expm1(lambda);
+  double last_term = 1.0, em1 = m_expm1(lambda);
   d.normalization = em1;
   for (int k = 1; k < min_k; ++k) { last_term *= lambda / k; d.normalization -= last_term; }
   d.term_before_min_k = last_term;
@@ -369,8 +369,8 @@ EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double m
     for (int i = 0; i < deltas.n && !c.failed; ++i) { bool acc; sample_site_trajectory(c, out, deltas.p[i].site, deltas.p[i].from, deltas.p[i].to, ge1, T, true, acc); }
   }
   double muT = mu * T;
-  double p_0 = exp(-muT), p_1 = muT * p_0;
-  double log_one_minus_p_tricky = (muT < 1e-4) ? -0.5 * muT * muT : -muT - log1p(-p_1);
+  double p_0 = m_exp(-muT), p_1 = muT * p_0;
+  double log_one_minus_p_tricky = (muT < 1e-4) ? -0.5 * muT * muT : -muT - m_log1p(-p_1);
   int l = 0;
   if ((double)L * muT * muT < 2e-6) l = L;
   int guard = 0;
@@ -440,10 +440,10 @@ enum { k_PX = 0, k_PS = 1, k_SPX = 2 };
 
 EMAT_D void bi_init(BranchInfo& b) { b.A = b.B = k_no_node; b.is_open = false; b.T_to_X = b.pl_A = b.pl_X = 0.0; b.warm.p = nullptr; b.warm.n = b.warm.cap = 0; b.hot = b.warm; b.hot_muts.p = nullptr; b.hot_muts.n = b.hot_muts.cap = 0; b.hot_deltas.p = nullptr; b.hot_deltas.n = b.hot_deltas.cap = 0; }
 EMAT_D double log_alpha_mut_term(double mu_p, int L, double T, int M, bool is_open, int d) {   // spr_move.cpp:296-315, 809-835
-  double r = -mu_p * L * T + M * log(mu_p / 3);
+  double r = -mu_p * L * T + M * m_log(mu_p / 3);
   if (!is_open) {
-    double P_AC = -0.25 * expm1(-4. / 3. * mu_p * T);
-    r -= (L - d) * log1p(-3 * P_AC) + d * log(P_AC);
+    double P_AC = -0.25 * m_expm1(-4. / 3. * mu_p * T);
+    r -= (L - d) * m_log1p(-3 * P_AC) + d * m_log(P_AC);
   }
   return r;
 }
@@ -522,7 +522,7 @@ EMAT_DN void propose_new_rooty_graft_mutations(Ctx& c, Graft& g) { EMAT_TIMED(1)
     }
   }
 }
-EMAT_D double log_pi_ratio(const Ctx& c, const MutRec& m) { return log(pi_a(c, m.site, m.from) / pi_a(c, m.site, m.to)); }
+EMAT_D double log_pi_ratio(const Ctx& c, const MutRec& m) { return m_log(pi_a(c, m.site, m.from) / pi_a(c, m.site, m.to)); }
 EMAT_DN void finish_rooty_graft_analysis(Ctx& c, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:246-316
   if (c.failed) return;
   const int X = g.X, P = nodes_of(c)[X].parent, S = sibling_of(c, P, X);
@@ -1111,7 +1111,7 @@ EMAT_D RootRegionParams root_region_params(Ctx& c, const Study& st, const Region
 EMAT_D double safe_log_gamma_integral(Ctx& c, double a, double x_min, double x_max) {   // safe_gamma_math.h:82-90
   EMAT_CHECK(c, x_min < x_max);
   double Q_hi = gamma_q(a, x_min), Q_lo = gamma_q(a, x_max);
-  return log(Q_hi - Q_lo);
+  return m_log(Q_hi - Q_lo);
 }
 constexpr double k_ln2 = 0.693147180559945309417232121458176568;
 // log-weight of a region above the root (spr_study.cpp:336-370): truncated-Gamma weight through lgamma and the incomplete
@@ -1124,9 +1124,9 @@ EMAT_DN double root_region_log_weight(Ctx& c, const Study& st, const Region& r) 
   RootRegionParams p = root_region_params(c, st, r);
   if (p.x_max < 0.01) {
     double alpha = f * m + 1;
-    return -k_ln2 + log(f * lambda_X) + f * m * log(st.mu / 3) + alpha * log(p.s_max) + log1p(-pow(p.s_min / p.s_max, alpha)) - log(alpha);
+    return -k_ln2 + m_log(f * lambda_X) + f * m * m_log(st.mu / 3) + alpha * m_log(p.s_max) + m_log1p(-pow(p.s_min / p.s_max, alpha)) - m_log(alpha);
   }
-  return -k_ln2 + f * m * log(st.mu / (3 * lambda_X * f)) + lgamma(f * m + 1) + safe_log_gamma_integral(c, f * m + 1, p.x_min, p.x_max);
+  return -k_ln2 + f * m * m_log(st.mu / (3 * lambda_X * f)) + lgamma(f * m + 1) + safe_log_gamma_integral(c, f * m + 1, p.x_min, p.x_max);
 }
 EMAT_DN Study make_study(Ctx& c, SVec<Region> regions, int num_missing_at_X, double lambda_X, double f, double t_X, double t_max_tip) { EMAT_TIMED(1);   // spr_study.cpp:226-385
   Study st; st.regions = regions; st.lambda_X = lambda_X; st.f = f; st.t_X = t_X; st.t_max_tip = t_max_tip; st.log_Wmax = 0.0; st.sum_W = 0.0;
@@ -1141,7 +1141,7 @@ EMAT_DN Study make_study(Ctx& c, SVec<Region> regions, int num_missing_at_X, dou
     double logW;
     if (r.t_min != k_neg_dbl_max) {
       double t_prime = 0.5 * (r.t_min + r.t_max);
-      logW = log(f * lambda_X * (r.t_max - r.t_min)) + f * (-lambda_X * (t_X - t_prime) + m * log(st.mu * (t_X - t_prime) / 3));
+      logW = m_log(f * lambda_X * (r.t_max - r.t_min)) + f * (-lambda_X * (t_X - t_prime) + m * m_log(st.mu * (t_X - t_prime) / 3));
     } else logW = root_region_log_weight(c, st, r);
     regions.p[i].logW = logW;
     if (i == 0) log_Wmax = logW; else if (log_Wmax < logW) log_Wmax = logW;
@@ -1150,7 +1150,7 @@ EMAT_DN Study make_study(Ctx& c, SVec<Region> regions, int num_missing_at_X, dou
   if (regions.n > 0) {
     st.log_Wmax = log_Wmax;
     for (int i = 0; i < regions.n; ++i) {
-      const double lw = regions.p[i].logW - log_Wmax, W = exp(lw);
+      const double lw = regions.p[i].logW - log_Wmax, W = m_exp(lw);
       *(double2*)&regions.p[i].logW = make_double2(lw, W);
       st.sum_W += W;
     }
@@ -1193,16 +1193,16 @@ EMAT_D int study_find_region(const Study& st, int branch, double t) {   // spr_s
 }
 EMAT_DN double study_log_alpha_in_region(Ctx& c, const Study& st, int idx, double t) {   // spr_study.cpp:486-549
   const Region& r = st.regions.p[idx];
-  double log_p_region = r.logW - log(st.sum_W);
-  if (r.t_min != k_neg_dbl_max) return log_p_region - log(r.t_max - r.t_min);
+  double log_p_region = r.logW - m_log(st.sum_W);
+  if (r.t_min != k_neg_dbl_max) return log_p_region - m_log(r.t_max - r.t_min);
   RootRegionParams p = root_region_params(c, st, r);
   double s = st.t_X - t + p.t_S - t;
   if (s > p.s_max + 1e-6) return -k_inf;
   if (p.x_max < 0.01) {
     double alpha = p.f * p.m + 1;
-    return log_p_region + k_ln2 + log(alpha) + (alpha - 1) * log(s) + -alpha * log(p.s_max) + -log1p(-pow(p.s_min / p.s_max, alpha));
+    return log_p_region + k_ln2 + m_log(alpha) + (alpha - 1) * m_log(s) + -alpha * m_log(p.s_max) + -m_log1p(-pow(p.s_min / p.s_max, alpha));
   }
-  return log_p_region + k_ln2 + log(st.lambda_X * p.f) + p.f * p.m * log(st.lambda_X * p.f * s) + -st.lambda_X * p.f * s
+  return log_p_region + k_ln2 + m_log(st.lambda_X * p.f) + p.f * p.m * m_log(st.lambda_X * p.f * s) + -st.lambda_X * p.f * s
       + -lgamma(p.f * p.m + 1) - safe_log_gamma_integral(c, p.f * p.m + 1, p.x_min, p.x_max);
 }
 
@@ -1251,7 +1251,7 @@ EMAT_D void wave_make_study(Ctx& c, Spr1Frame& fr, SVec<Region> regions) {
     double logW;
     if (r.t_min != k_neg_dbl_max) {
       double t_prime = 0.5 * (r.t_min + r.t_max);
-      logW = log(f * lambda_X * (r.t_max - r.t_min)) + f * (-lambda_X * (t_X - t_prime) + m * log(mu * (t_X - t_prime) / 3));
+      logW = m_log(f * lambda_X * (r.t_max - r.t_min)) + f * (-lambda_X * (t_X - t_prime) + m * m_log(mu * (t_X - t_prime) / 3));
     } else logW = root_region_log_weight(c, st, r);
     regions.p[i].logW = logW;
     if (logW == logW) { if (!any || my_max < logW) my_max = logW; any = true; }   // NaNs never replace the running maximum
@@ -1262,7 +1262,7 @@ EMAT_D void wave_make_study(Ctx& c, Spr1Frame& fr, SVec<Region> regions) {
   { const double first = regions.p[0].logW; if (first != first) log_Wmax = first; }   // a NaN in front stays (every later comparison is false)
   // pass 2: normalise by the maximum, weights
   for (int i = lane; i < regions.n; i += 64) {
-    const double lw = regions.p[i].logW - log_Wmax, W = exp(lw);
+    const double lw = regions.p[i].logW - log_Wmax, W = m_exp(lw);
     *(double2*)&regions.p[i].logW = make_double2(lw, W);
   }
   __syncthreads();
