@@ -12,6 +12,7 @@
 #include <set>
 
 #include "../delphy_amd/csrc/synth.hpp"
+#include "orc_build.hpp"
 #include "orc_subrun.hpp"
 
 using namespace orc;
@@ -1350,6 +1351,123 @@ static void run_chain(int tips, int sites, uint64_t seed, bool includes_root, in
 }
 TEST(subrun_chain_invariants_root_part) { for (int s = 0; s < 4; ++s) run_chain(24, 150, 900 + s, true, 6000, s); }
 TEST(subrun_chain_invariants_non_root_part) { for (int s = 0; s < 3; ++s) run_chain(30, 150, 950 + s, false, 6000, s % 2); }
+
+
+// =================================================================================================
+// Initial-tree construction (orc_build.hpp): the reference's own fix_up_missations cases, with its fixtures and its
+// expected lists (tests/phylo_tree_tests.cpp:539-760), then the UShER-like builder under the check the reference
+// itself closes it with
+// =================================================================================================
+static Phylo_tree three_node_tree(std::vector<State> ref) {   // r = 0 at t = 0 with tips a = 1 (t = 1) and b = 2 (t = 2)
+  Phylo_tree t(3); t.root = 0; t.ref_sequence = ref;
+  set_inner(t, 0, k_no_node, 1, 2, 0.0); set_tip(t, 1, 0, 1.0); set_tip(t, 2, 0, 2.0);
+  return t;
+}
+static Phylo_tree phylo_tree_tests_complex_tree() {   // phylo_tree_tests.cpp:80-165 (c carries one mutation A0G here)
+  auto t = complex_tree(false);
+  t.at(c_).mutations = {Mutation{sA, 0, sG, 1.0}};
+  return t;
+}
+static std::string consistent_missations(const Phylo_tree& t) {   // assert_missation_consistency + the rest of the integrity rules
+  return check_phylo_tree_integrity(t);
+}
+TEST(fix_up_missations_reference_cases) {
+  {   // :539-550 trivial
+    Phylo_tree t(1); t.ref_sequence = {sA, sA, sA, sA}; t.root = 0; set_tip(t, 0, k_no_node, 0.0);
+    fix_up_missations(t);
+    EXPECT(t.at(0).mutations.empty()); EXPECT(t.at(0).missations.empty());
+  }
+  {   // :552-599 a missation that repeats one above it goes
+    auto t = three_node_tree({sT});
+    miss(t, 0, {{0, sT}}); miss(t, 2, {{0, sT}});
+    fix_up_missations(t);
+    EXPECT(elements_of(t.at(0).missations, t.ref_sequence) == (std::vector<std::pair<int, State>>{{0, sT}}));
+    EXPECT(t.at(1).missations.empty()); EXPECT(t.at(2).missations.empty());
+    EXPECT(consistent_missations(t).empty());
+  }
+  {   // :601-652 a mutation below a missation of its site is dropped
+    auto t = three_node_tree({sA, sA});
+    miss(t, 0, {{0, sA}});
+    t.at(1).mutations = {Mutation{sA, 0, sT, 0.5}};
+    t.at(2).mutations = {Mutation{sA, 1, sC, 1.0}};
+    fix_up_missations(t);
+    EXPECT(t.at(0).mutations.empty());
+    EXPECT(elements_of(t.at(0).missations, t.ref_sequence) == (std::vector<std::pair<int, State>>{{0, sA}}));
+    EXPECT(t.at(1).mutations.empty()); EXPECT(t.at(1).missations.empty());
+    EXPECT(t.at(2).mutations == (Mutation_list{Mutation{sA, 1, sC, 1.0}})); EXPECT(t.at(2).missations.empty());
+    EXPECT(consistent_missations(t).empty());
+  }
+  {   // :654-701 a missation on both children moves up once
+    auto t = three_node_tree({sA});
+    miss(t, 1, {{0, sA}}); miss(t, 2, {{0, sA}});
+    fix_up_missations(t);
+    EXPECT(elements_of(t.at(0).missations, t.ref_sequence) == (std::vector<std::pair<int, State>>{{0, sA}}));
+    EXPECT(t.at(1).missations.empty()); EXPECT(t.at(2).missations.empty());
+    EXPECT(consistent_missations(t).empty());
+  }
+  {   // :703-730 merge up twice and drop the mutations that end up below a missation
+    auto t = phylo_tree_tests_complex_tree();
+    miss(t, a_, {{0, sT}}); miss(t, b_, {{0, sT}});
+    fix_up_missations(t);
+    EXPECT(t.at(a_).missations.empty()); EXPECT(t.at(a_).mutations.empty());
+    EXPECT(t.at(b_).missations.empty()); EXPECT(t.at(b_).mutations == (Mutation_list{Mutation{sA, 1, sG, 1.0}}));
+    EXPECT(elements_of(t.at(x_).missations, t.ref_sequence) == (std::vector<std::pair<int, State>>{{0, sA}, {2, sA}}));
+    EXPECT(t.at(x_).mutations.empty());
+  }
+  {   // :732-760 two mutations on one logical branch stay two
+    auto t = phylo_tree_tests_complex_tree();
+    t.at(a_).missations.clear(); miss(t, a_, {{1, sA}});
+    t.at(a_).mutations = {Mutation{sA, 0, sC, +0.5}};
+    t.at(x_).mutations = {Mutation{sA, 1, sG, -0.5}};
+    t.at(b_).mutations = {Mutation{sG, 1, sC, 1.0}};
+    fix_up_missations(t);
+    EXPECT(check_phylo_tree_integrity(t).empty());
+    EXPECT(t.at(x_).mutations == (Mutation_list{Mutation{sA, 1, sG, -0.5}}));
+    EXPECT(t.at(b_).mutations == (Mutation_list{Mutation{sG, 1, sC, 1.0}}));
+  }
+}
+
+// tip descriptors of a synthetic EMAT: what a MAPLE file of its tips would hold (deltas against the reference sequence at
+// the sites the tip has, its missing intervals, its date range)
+static std::vector<Tip_desc> tip_descs_of(const Phylo_tree& t) {
+  std::vector<Tip_desc> out;
+  for (int n = 0; n < t.size(); ++n) if (t.at(n).is_tip()) {
+    Tip_desc d; d.t_min = t.at(n).t_min; d.t_max = t.at(n).t_max;
+    d.missations.intervals = reconstruct_missing_sites_at(t, n);
+    auto seq = view_of_sequence_at(t, n);
+    for (int l = 0; l < t.num_sites(); ++l) if (seq[l] != t.ref_sequence[l] && !d.missations.intervals.contains(l)) d.seq_deltas.push_back(Seq_delta(l, t.ref_sequence[l], seq[l]));
+    out.push_back(std::move(d));
+  }
+  return out;
+}
+TEST(build_usher_like_tree_reproduces_its_tip_descriptors) {
+  for (int seed = 0; seed < 8; ++seed) {
+    emat::SynthParams p; p.num_tips = 12 + 37 * seed; p.num_sites = seed % 2 ? 300 : 2000; p.mu = (seed % 3 ? 6e-4 : 2e-3) / 365.0 * 365.0 / 365.0; p.gaps_per_tip = seed % 4; p.mean_gap_len = 25;
+    p.seed = 4100 + seed; if (seed >= 4) { p.tip_date_uncertainty = 6.0; p.frac_uncertain_tips = 0.4; }
+    auto R = emat::make_synthetic_emat(p);
+    auto src = tree_from_flat(R.tree, R.ref_sequence);
+    auto descs = tip_descs_of(src);
+    EXPECT((int)descs.size() == p.num_tips);
+    Rng rng; rng.key = 77 + seed;
+    auto t = build_usher_like_tree(src.ref_sequence, descs, rng);
+    EXPECT(t.size() == 2 * p.num_tips - 1);
+    auto msg = check_phylo_tree_integrity(t);
+    if (!msg.empty()) std::printf("  seed %d integrity: %s\n", seed, msg.c_str());
+    EXPECT(msg.empty());
+    msg = check_phylo_tree_matches_tip_descs(t, src.ref_sequence, descs);
+    if (!msg.empty()) std::printf("  seed %d: %s\n", seed, msg.c_str());
+    EXPECT(msg.empty());
+    // the builder grafts where the fewest mutations are needed: a loose sanity bound on the mutations it needs against the tree the tips came from (tips with a quarter of their sites missing are placed blindly there and cost later tips extra mutations)
+    if (!(calc_num_muts(t) <= 3 * calc_num_muts(src) + 10)) std::printf("  seed %d: %d mutations against %d in the source tree\n", seed, calc_num_muts(t), calc_num_muts(src));
+    EXPECT(calc_num_muts(t) <= 3 * calc_num_muts(src) + 10);
+    // deterministic given the stream
+    Rng rng2; rng2.key = 77 + seed;
+    auto t2 = build_usher_like_tree(src.ref_sequence, descs, rng2);
+    bool same = t2.root == t.root;
+    for (int n = 0; n < t.size() && same; ++n) same = t.at(n).parent == t2.at(n).parent && t.at(n).t == t2.at(n).t && t.at(n).mutations == t2.at(n).mutations && t.at(n).missations == t2.at(n).missations;
+    EXPECT(same);
+  }
+}
 
 int main(int argc, char** argv) {
   const char* only = argc > 1 ? argv[1] : nullptr;
