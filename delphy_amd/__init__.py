@@ -12,6 +12,7 @@ from .engine import (  # noqa: F401
     FlatTree,
     PopModel,
     SynthParams,
+    TipDescs,
     build_library,
     hky_q_matrix,
     library_build_id,

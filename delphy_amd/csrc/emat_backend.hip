@@ -20,6 +20,8 @@
 #include <numeric>
 #include <string>
 #include <vector>
+#include <map>
+#include <stdexcept>
 
 #include "../../include/emat_backend.h"
 #ifdef EMAT_PROFILE_PHASES
@@ -640,6 +642,7 @@ __global__ void k_debug_interval_op(int op, const IvRec* A, int nA, const IvRec*
 
 }  // namespace emat
 #include "emat_gtree_kernels.hpp"   // the whole tree in HBM: cutting it into part slabs and gathering the parts back
+#include "emat_build.hpp"           // initial-tree construction: the graft loop as a kernel, the finishing passes on the host
 namespace emat {
 
 // =================================================================================================
@@ -795,6 +798,7 @@ struct emat_backend {
   // dense copy of every part's slab header (k_gather_headers): what the scalar getters read instead of the slabs
   DevBuf<uint8_t> d_headers; std::vector<uint8_t> h_headers; bool headers_current = false;
   GTreeHost gt;                     // the whole tree, when it lives in HBM (emat_tree_upload)
+  BuiltTree built;                  // what emat_tree_build_usher_like made, until it is fetched (emat_tree_built_get)
   int cfg_chunks = 2;               // EMAT_CHUNKS (tuning knob): tickets per part and pass (main class; measured at C4: 1 -> 311, 2 -> 338, 3 -> 340, 4 -> 331, 8 -> 301 M moves/s)
   bool cfg_chunks_forced = false;   // EMAT_CHUNKS was given: tickets also when the parts are fewer than the wave slots (tests)
   DevBuf<int32_t> d_chunk_done;
@@ -2084,3 +2088,4 @@ emat_status emat_last_run_ms(emat_backend* h, double* ms) {
 }  // extern "C"
 
 #include "emat_gtree_host.hpp"
+#include "emat_build_host.hpp"

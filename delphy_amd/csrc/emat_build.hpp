@@ -1,0 +1,380 @@
+// emat_build.hpp -- SURVEY.md 8(f).4: initial-tree construction, the reference's UShER-like builder
+// (build_usher_like_tree, core/phylo_tree.cpp:796-1049) behind emat_tree_build_usher_like.
+//
+// The builder grafts the tips one by one where they need the fewest new mutations.  Each placement is one UNLIMITED candidate
+// scan from the root (Spr_study_builder::seed_fill_from, spr_study.cpp:9-128) -- the whole tree built so far -- which makes the
+// loop O(tips x nodes): that loop runs on the device.  What the scan computes for a region (branch b, segment between its
+// mutations) is the number of sites at which the sequence there differs from the new tip's, over the sites the tip has; that
+// number changes by -1 / 0 / +1 per mutation crossed, so for a whole tree it is a per-branch sum (all nodes side by side)
+// followed by a prefix sum down the tree -- pointer jumping, log2(depth) rounds -- instead of the reference's depth-first walk
+// with a hash map.  The walk's ORDER matters as well (among the regions that tie for the minimum the reference picks by
+// cumulative length in visiting order, a floating-point sum): the visiting order is the pre-order with the second child first
+// and a branch's segments in time order, so a node's position is again a prefix sum down the tree (1 + the size of the sibling
+// subtree that is visited before it), computed by the same pointer jumping; the tying regions are then laid out in that order
+// by a block-wide scan, and ONE thread adds their lengths in order, draws, and makes the graft (three nodes change).
+// One workgroup of 1024 threads runs the whole loop without returning to the host (no launch per tip, no grid-wide barrier).
+//
+// The O(nodes) passes after the loop -- fix_up_missations (phylo_tree.cpp:414-507), pseudo_date (dates.cpp:63-82),
+// randomize_mutation_times (phylo_tree.cpp:567-644) -- are host C++ below: they run once, like the partitioning the reference
+// also keeps on the host.  Random numbers: one Philox stream (the engine's), consumed in the reference's order of draws; its
+// hash-map iterations run in ascending site order.  Product code: shares nothing with oracle/orc_build.hpp, which restates the
+// same reference functions as the checker.
+#ifndef EMAT_BUILD_HPP_
+#define EMAT_BUILD_HPP_
+
+namespace emat {
+
+struct BDelta { int32_t site; uint8_t from, to; uint16_t pad; };   // one entry of a Site_deltas map, kept sorted by site
+
+struct BuildDev {
+  int32_t n_tips, L;
+  const uint8_t* ref;
+  const int32_t* d_off; const int32_t* d_site; const uint8_t* d_to;      // tips' deltas against the reference sequence, CSR, ascending site
+  const int32_t* m_off; const int32_t* m_start; const int32_t* m_end;   // tips' missing intervals, CSR
+  // the tree under construction (2 n - 1 nodes: tips 0 .. n-1, the inner node made for tip X is X + n - 1)
+  int32_t* root; int32_t* parent; int32_t* c0; int32_t* c1; double* t; int32_t* sz;
+  uint32_t* ml_off; int32_t* ml_cnt; MutRec* pool; uint32_t pool_cap; uint32_t* pool_top;
+  // per-tip work arrays [2 n - 1]
+  int32_t* delta; int32_t* vD[2]; int32_t* vP[2]; int32_t* anc[2]; int32_t* inv; int32_t* cnt; int32_t* off;
+  // the regions that tie for the fewest mutations, in visiting order
+  int32_t* tie_node; double* tie_tmin; double* tie_tmax; uint32_t tie_cap;
+  // the grafting thread's own buffers
+  int32_t* path; BDelta* sd; uint32_t sd_cap;
+  uint64_t* rng;      // [4] key, counter, spare, has_spare
+  int32_t* status;    // [2] 0 = ok | 1 mutation pool full | 2 delta buffer full | 3 tie list full | 4 inconsistent input; [1] = tip at which it happened
+};
+
+struct BRng {   // the engine's stream (emat_device_core.hpp rng_next64 and friends), for the one thread that draws
+  uint64_t key, ctr, spare; bool has_spare;
+  __device__ uint64_t next64() {
+    if (has_spare) { has_spare = false; return spare; }
+    uint32_t w[4]; dev::philox4x32_10(ctr++, key, w);
+    spare = (uint64_t)w[2] | ((uint64_t)w[3] << 32); has_spare = true;
+    return (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+  }
+  __device__ double uniform_co(double lo, double hi) { return lo + (hi - lo) * ((double)(next64() >> 11) * 0x1.0p-53); }
+  __device__ double uniform_oc(double lo, double hi) { return lo + (hi - lo) * (((double)(next64() >> 11) + 1.0) * 0x1.0p-53); }
+  __device__ double uniform_oo(double lo, double hi) { return lo + (hi - lo) * (((double)(next64() >> 12) + 0.5) * 0x1.0p-52); }
+};
+
+// state of the new tip at a site: its delta there, else the reference sequence
+__device__ inline int b_tip_state(const BuildDev& b, int dx0, int dxn, int site) {
+  int lo = 0, hi = dxn;
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (b.d_site[dx0 + mid] < site) lo = mid + 1; else hi = mid; }
+  return (lo < dxn && b.d_site[dx0 + lo] == site) ? (int)b.d_to[dx0 + lo] : (int)b.ref[site];
+}
+__device__ inline bool b_tip_missing(const BuildDev& b, int mx0, int mxn, int site) {
+  int lo = 0, hi = mxn;   // first interval with start > site
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (site < b.m_start[mx0 + mid]) hi = mid; else lo = mid + 1; }
+  return lo > 0 && site < b.m_end[mx0 + lo - 1];
+}
+// change of the distance to the new tip across one mutation, walking down (spr_study.cpp:43-91: only sites the tip has count)
+__device__ inline int b_step(const BuildDev& b, int dx0, int dxn, int mx0, int mxn, const MutRec& m) {
+  if (b_tip_missing(b, mx0, mxn, m.site)) return 0;
+  const int x = b_tip_state(b, dx0, dxn, m.site);
+  return ((int)m.to != x ? 1 : 0) - ((int)m.from != x ? 1 : 0);
+}
+// site_deltas.h:43-65 on a sorted array: put `from -> to` IN FRONT of the delta list
+__device__ inline bool b_push_front(BDelta* sd, int& n, uint32_t cap, int site, int from, int to, bool& inconsistent) {
+  int lo = 0, hi = n;
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (sd[mid].site < site) lo = mid + 1; else hi = mid; }
+  if (lo < n && sd[lo].site == site) {
+    if (to != (int)sd[lo].from) inconsistent = true;
+    sd[lo].from = (uint8_t)from;
+    if (sd[lo].from == sd[lo].to) { for (int i = lo; i + 1 < n; ++i) sd[i] = sd[i + 1]; --n; }
+    return true;
+  }
+  if ((uint32_t)n >= cap) return false;
+  for (int i = n; i > lo; --i) sd[i] = sd[i - 1];
+  sd[lo].site = site; sd[lo].from = (uint8_t)from; sd[lo].to = (uint8_t)to; sd[lo].pad = 0; ++n;
+  return true;
+}
+
+constexpr int k_build_threads = 1024;
+
+// Tips [first_tip, last_tip) are grafted onto the tree that holds tips 0 .. first_tip - 1 (the host sets up the first two).
+__global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev b, int first_tip, int last_tip) {
+  const int tid = threadIdx.x, NT = k_build_threads, n = b.n_tips;
+  __shared__ int s_min, s_carry, s_total, s_stop;
+  __shared__ int s_scan[2][k_build_threads];
+  BRng rng; rng.key = b.rng[0]; rng.ctr = b.rng[1]; rng.spare = b.rng[2]; rng.has_spare = b.rng[3] != 0;   // (thread 0's copy is the one that counts)
+  if (tid == 0) s_stop = 0;
+  __syncthreads();
+  for (int X = first_tip; X < last_tip; ++X) {
+    const int nl = 2 * X - 1;                                      // nodes linked so far: tips 0 .. X-1 and inner nodes n .. n + X - 2
+    auto node_of = [&](int i) { return i < X ? i : n + (i - X); };
+    const int dx0 = b.d_off[X], dxn = b.d_off[X + 1] - dx0, mx0 = b.m_off[X], mxn = b.m_off[X + 1] - mx0;
+    const double t_X = b.t[X];
+    const int root = *b.root;
+    // (1) per branch: how the distance to X changes across it; the increments of the two prefix sums down the tree
+    for (int i = tid; i < nl; i += NT) {
+      const int v = node_of(i);
+      const MutRec* m = b.pool + b.ml_off[v]; const int nm = b.ml_cnt[v];
+      int d = 0;
+      for (int k = 0; k < nm; ++k) d += b_step(b, dx0, dxn, mx0, mxn, m[k]);
+      b.delta[v] = d;
+      const int par = b.parent[v];
+      b.vD[0][v] = v == root ? dxn : d;                              // at the root the distance is the number of X's own deltas
+      b.vP[0][v] = v == root ? 0 : 1 + (b.c0[par] == v ? b.sz[b.c1[par]] : 0);   // the second child's subtree is visited first
+      b.anc[0][v] = par;
+    }
+    __syncthreads();
+    // (2) both prefix sums by pointer jumping: after round r a node holds the sum over its 2^r nearest ancestors-or-self
+    int cur = 0;
+    for (;;) {
+      int any = 0;
+      for (int i = tid; i < nl; i += NT) {
+        const int v = node_of(i), a = b.anc[cur][v];
+        if (a != EMAT_NO_NODE) {
+          b.vD[cur ^ 1][v] = b.vD[cur][v] + b.vD[cur][a]; b.vP[cur ^ 1][v] = b.vP[cur][v] + b.vP[cur][a]; b.anc[cur ^ 1][v] = b.anc[cur][a];
+          any = 1;
+        } else { b.vD[cur ^ 1][v] = b.vD[cur][v]; b.vP[cur ^ 1][v] = b.vP[cur][v]; b.anc[cur ^ 1][v] = EMAT_NO_NODE; }
+      }
+      cur ^= 1;
+      if (!__syncthreads_or(any)) break;
+    }
+    const int32_t* Dend = b.vD[cur]; const int32_t* pre = b.vP[cur];
+    // (3) the fewest mutations any region offers.  A region of branch v is the stretch before its k-th mutation (k = 0 .. nm);
+    // regions in X's future do not count, the one that straddles t_X ends there (spr_study.cpp:211-224)
+    if (tid == 0) s_min = 0x7fffffff;
+    __syncthreads();
+    {
+      int local = 0x7fffffff;
+      for (int i = tid; i < nl; i += NT) {
+        const int v = node_of(i);
+        if (v == root) { if (dxn < local) local = dxn; continue; }   // the region above the root is always there
+        const MutRec* m = b.pool + b.ml_off[v]; const int nm = b.ml_cnt[v];
+        int D = Dend[v] - b.delta[v];
+        double tmin = b.t[b.parent[v]];
+        for (int k = 0; k <= nm; ++k) {
+          if (!(tmin >= t_X) && D < local) local = D;
+          if (k < nm) { D += b_step(b, dx0, dxn, mx0, mxn, m[k]); tmin = m[k].t; }
+        }
+      }
+      atomicMin(&s_min, local);
+    }
+    __syncthreads();
+    const int all_min = s_min;
+    const bool above_root = dxn == all_min;                          // "always pick above the root if that's a possibility" (:938-942)
+    int n_tie = 0;
+    if (!above_root) {
+      // (4) the tying regions in visiting order: count per node, exclusive scan over the visiting positions, write
+      for (int i = tid; i < nl; i += NT) {
+        const int v = node_of(i);
+        int c = 0;
+        if (v != root) {
+          const MutRec* m = b.pool + b.ml_off[v]; const int nm = b.ml_cnt[v];
+          int D = Dend[v] - b.delta[v];
+          double tmin = b.t[b.parent[v]];
+          for (int k = 0; k <= nm; ++k) {
+            if (!(tmin >= t_X) && D == all_min) ++c;
+            if (k < nm) { D += b_step(b, dx0, dxn, mx0, mxn, m[k]); tmin = m[k].t; }
+          }
+        }
+        b.cnt[pre[v]] = c; b.inv[pre[v]] = v;
+      }
+      if (tid == 0) s_carry = 0;
+      __syncthreads();
+      for (int base = 0; base < nl; base += NT) {                   // block-wide exclusive scan, NT positions at a time
+        const int p = base + tid;
+        const int mine = p < nl ? b.cnt[p] : 0;
+        int src = 0;
+        s_scan[0][tid] = mine;
+        __syncthreads();
+        for (int ofs = 1; ofs < NT; ofs <<= 1) {
+          s_scan[src ^ 1][tid] = s_scan[src][tid] + (tid >= ofs ? s_scan[src][tid - ofs] : 0);
+          src ^= 1;
+          __syncthreads();
+        }
+        if (p < nl) b.off[p] = s_carry + s_scan[src][tid] - mine;
+        __syncthreads();
+        if (tid == NT - 1) s_carry += s_scan[src][NT - 1];
+        __syncthreads();
+      }
+      if (tid == 0) { s_total = s_carry; if ((uint32_t)s_carry > b.tie_cap) { b.status[0] = 3; b.status[1] = X; s_stop = 1; } }
+      __syncthreads();
+      if (s_stop) return;
+      n_tie = s_total;
+      for (int p = tid; p < nl; p += NT) {
+        if (b.cnt[p] == 0) continue;
+        const int v = b.inv[p];
+        const MutRec* m = b.pool + b.ml_off[v]; const int nm = b.ml_cnt[v];
+        int D = Dend[v] - b.delta[v], o = b.off[p];
+        double tmin = b.t[b.parent[v]];
+        for (int k = 0; k <= nm; ++k) {
+          const double tmax = k < nm ? m[k].t : b.t[v];
+          if (!(tmin >= t_X) && D == all_min) { b.tie_node[o] = v; b.tie_tmin[o] = tmin; b.tie_tmax[o] = tmax > t_X ? t_X : tmax; ++o; }
+          if (k < nm) { D += b_step(b, dx0, dxn, mx0, mxn, m[k]); tmin = m[k].t; }
+        }
+      }
+      __syncthreads();
+    }
+    // (5) one thread picks the region and makes the graft (:925-1030)
+    if (tid == 0) {
+      const int P = X + n - 1;
+      int S; double t_P; int nsd = 0; bool bad = false, full = false;
+      for (int k = 0; k < dxn; ++k) { b.sd[k].site = b.d_site[dx0 + k]; b.sd[k].from = b.ref[b.d_site[dx0 + k]]; b.sd[k].to = b.d_to[dx0 + k]; b.sd[k].pad = 0; }   // deltas root -> X
+      nsd = dxn;
+      if (above_root) {
+        S = root;
+        const double t_P_guess = t_X - (double)nsd * 13.0, t_S = b.t[S];
+        t_P = (t_P_guess < t_S ? t_P_guess : t_S) - 1.0;
+        *b.root = P; b.parent[P] = EMAT_NO_NODE;
+        b.ml_off[P] = b.ml_off[S]; b.ml_cnt[P] = b.ml_cnt[S]; b.ml_cnt[S] = 0;      // the root's list moves up with the root (it is empty while building)
+      } else {
+        double tot_min_T = 0.0;
+        for (int i = 0; i < n_tie; ++i) tot_min_T += b.tie_tmax[i] - b.tie_tmin[i];
+        const double insertion_cum_t = rng.uniform_co(0.0, tot_min_T);
+        double so_far_min_T = 0.0; int chosen = -1;
+        for (int i = 0; i < n_tie; ++i) { so_far_min_T += b.tie_tmax[i] - b.tie_tmin[i]; if (insertion_cum_t <= so_far_min_T) { chosen = i; break; } }
+        if (chosen < 0) { b.status[0] = 4; b.status[1] = X; s_stop = 1; }
+        else {
+          S = b.tie_node[chosen];
+          t_P = rng.uniform_oo(b.tie_tmin[chosen], b.tie_tmax[chosen]);
+          // deltas (S, t_P) -> X: the mutations on the way down from the root are put in front, inverted (site_deltas.cpp:40-80)
+          int np = 0;
+          for (int v = S; v != EMAT_NO_NODE; v = b.parent[v]) b.path[np++] = v;
+          const double t_root = b.t[root];
+          for (int i = np - 1; i >= 0 && !full; --i) {
+            const MutRec* m = b.pool + b.ml_off[b.path[i]]; const int nm = b.ml_cnt[b.path[i]];
+            for (int k = 0; k < nm; ++k) if (t_root <= m[k].t && m[k].t <= t_P) { if (!b_push_front(b.sd, nsd, b.sd_cap, m[k].site, m[k].to, m[k].from, bad)) { full = true; break; } }
+          }
+          const int G = b.parent[S];
+          const int U = b.c0[G] == S ? b.c1[G] : b.c0[G];
+          b.c0[G] = P; b.c1[G] = U; b.parent[P] = G;
+          int split = 0;                                               // the mutations of G-S before t_P now sit on G-P
+          { const MutRec* m = b.pool + b.ml_off[S]; const int nm = b.ml_cnt[S]; while (split < nm && !(m[split].t > t_P)) ++split; }
+          b.ml_off[P] = b.ml_off[S]; b.ml_cnt[P] = split; b.ml_off[S] += (uint32_t)split; b.ml_cnt[S] -= split;
+        }
+      }
+      if (!s_stop) {
+        if (full) { b.status[0] = 2; b.status[1] = X; s_stop = 1; }
+        else if (bad) { b.status[0] = 4; b.status[1] = X; s_stop = 1; }
+      }
+      if (!s_stop) {
+        b.t[P] = t_P; b.c0[P] = X; b.c1[P] = S; b.parent[X] = P; b.parent[S] = P;
+        b.sz[X] = 1; b.sz[P] = b.sz[S] + 2;
+        for (int a = b.parent[P]; a != EMAT_NO_NODE; a = b.parent[a]) b.sz[a] += 2;
+        // the mutations X needs, at random times on P-X, sorted by (t, site) (:1015-1021)
+        const uint32_t o = *b.pool_top;
+        if (o + (uint32_t)nsd > b.pool_cap) { b.status[0] = 1; b.status[1] = X; s_stop = 1; }
+        else {
+          MutRec* mx = b.pool + o;
+          for (int k = 0; k < nsd; ++k) {
+            MutRec r; r.t = rng.uniform_oc(t_P, t_X); r.site = b.sd[k].site; r.from = b.sd[k].from; r.to = b.sd[k].to; r.pad = 0;
+            int j = k - 1;                                             // stable insertion by (t, site)
+            while (j >= 0 && (r.t < mx[j].t || (r.t == mx[j].t && r.site < mx[j].site))) { mx[j + 1] = mx[j]; --j; }
+            mx[j + 1] = r;
+          }
+          b.ml_off[X] = o; b.ml_cnt[X] = nsd; *b.pool_top = o + (uint32_t)nsd;
+        }
+      }
+    }
+    __syncthreads();
+    if (s_stop) break;
+  }
+  if (tid == 0) { b.rng[1] = rng.ctr; b.rng[2] = rng.spare; b.rng[3] = rng.has_spare ? 1u : 0u; }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------
+struct BuiltTree { FlatTree tree; bool valid = false; };
+
+struct BHostMut { double t; int32_t site; uint8_t from, to; };
+struct BHostNode {
+  int32_t parent = EMAT_NO_NODE, c0 = EMAT_NO_NODE, c1 = EMAT_NO_NODE;
+  double t = 0.0; float t_min = -FLT_MAX, t_max = FLT_MAX;
+  std::vector<BHostMut> muts; std::vector<std::pair<int32_t, int32_t>> miss; std::vector<std::pair<int32_t, uint8_t>> mfs;
+};
+using BIvs = std::vector<std::pair<int32_t, int32_t>>;
+inline bool b_iv_contains(const BIvs& v, int l) {
+  auto it = std::upper_bound(v.begin(), v.end(), l, [](int x, const std::pair<int32_t, int32_t>& iv) { return x < iv.first; });
+  return it != v.begin() && l < std::prev(it)->second;
+}
+inline BIvs b_iv_merge(const BIvs& A, const BIvs& B) {        // union; touching intervals coalesce (interval_set.h:238-288)
+  BIvs all(A); all.insert(all.end(), B.begin(), B.end());
+  std::sort(all.begin(), all.end());
+  BIvs out;
+  for (auto& iv : all) { if (!out.empty() && iv.first <= out.back().second) out.back().second = std::max(out.back().second, iv.second); else out.push_back(iv); }
+  return out;
+}
+inline BIvs b_iv_intersect(const BIvs& A, const BIvs& B) {
+  BIvs out; size_t i = 0, j = 0;
+  while (i < A.size() && j < B.size()) {
+    int s = std::max(A[i].first, B[j].first), e = std::min(A[i].second, B[j].second);
+    if (s < e) out.push_back({s, e});
+    if (A[i].second <= B[j].second) ++i; else ++j;
+  }
+  return out;
+}
+inline BIvs b_iv_subtract(const BIvs& A, const BIvs& B) {
+  BIvs out; size_t j = 0;
+  for (auto [s, e] : A) {
+    while (j < B.size() && B[j].second <= s) ++j;
+    int cs = s;
+    for (size_t k = j; k < B.size() && B[k].first < e; ++k) { if (B[k].first > cs) out.push_back({cs, B[k].first}); cs = std::max(cs, B[k].second); if (cs >= e) break; }
+    if (cs < e) out.push_back({cs, e});
+  }
+  return out;
+}
+
+// fix_up_missations (phylo_tree.cpp:414-507) by its meaning: (1) what both children miss moves up to their parent, leaves first;
+// (2) root first, a branch keeps only the missing sites that nothing above it already misses; (3) root first again, with the
+// sequence carried along: mutations at sites missing at or above their branch go, and every missation's from-state is the state
+// just above its branch where that differs from the reference sequence.
+inline void b_fix_up_missations(std::vector<BHostNode>& N, int root, const std::vector<uint8_t>& ref) {
+  std::vector<int> pre; pre.reserve(N.size());
+  { std::vector<int> st{root}; while (!st.empty()) { int v = st.back(); st.pop_back(); pre.push_back(v); if (N[v].c0 != EMAT_NO_NODE) { st.push_back(N[v].c1); st.push_back(N[v].c0); } } }
+  for (auto it = pre.rbegin(); it != pre.rend(); ++it) {           // children before parents
+    BHostNode& nd = N[*it];
+    if (nd.c0 == EMAT_NO_NODE) continue;
+    BIvs common = b_iv_intersect(N[nd.c0].miss, N[nd.c1].miss);
+    if (common.empty()) continue;
+    N[nd.c0].miss = b_iv_subtract(N[nd.c0].miss, common); N[nd.c1].miss = b_iv_subtract(N[nd.c1].miss, common);
+    nd.miss = b_iv_merge(nd.miss, common);
+  }
+  // (2) + (3) in one walk: the set missing above a branch and the sequence at its start, kept per depth
+  struct Frame { int node; int stage; BIvs missing_above; };
+  std::map<int32_t, uint8_t> seq;                                   // sites where the running sequence differs from `ref`
+  auto state = [&](int l) { auto f = seq.find(l); return f != seq.end() ? f->second : ref[l]; };
+  auto put = [&](int l, uint8_t s) { if (s == ref[l]) seq.erase(l); else seq[l] = s; };
+  std::vector<Frame> st; st.push_back({root, 0, {}});
+  while (!st.empty()) {
+    Frame& f = st.back(); BHostNode& nd = N[f.node];
+    if (f.stage == 0) {
+      nd.miss = b_iv_subtract(nd.miss, f.missing_above);
+      BIvs missing_here = b_iv_merge(f.missing_above, nd.miss);
+      nd.mfs.clear();
+      for (auto [s, e] : nd.miss) for (auto it = seq.lower_bound(s); it != seq.end() && it->first < e; ++it) nd.mfs.push_back({it->first, it->second});
+      nd.muts.erase(std::remove_if(nd.muts.begin(), nd.muts.end(), [&](const BHostMut& m) { return b_iv_contains(missing_here, m.site); }), nd.muts.end());
+      for (auto& m : nd.muts) { if (m.from != state(m.site)) throw std::runtime_error("mutation chain broken while fixing up missations"); put(m.site, m.to); }
+      f.stage = 1;
+      if (nd.c0 != EMAT_NO_NODE) { const int a = nd.c0, c = nd.c1; st.push_back({c, 0, missing_here}); st.push_back({a, 0, std::move(missing_here)}); }
+      // (st may have reallocated: do not touch f / nd below)
+    } else {
+      for (auto it = nd.muts.rbegin(); it != nd.muts.rend(); ++it) put(it->site, it->from);
+      st.pop_back();
+    }
+  }
+}
+// randomize_branch_mutation_times (phylo_tree.cpp:579-644): fresh uniform times on a branch; when a site mutates more than once
+// on it, that site's times are drawn together, sorted, and handed out in the old order
+inline void b_randomize_branch(BHostNode& nd, double t_P, HostRng& rng) {
+  auto uni_oc = [&](double lo, double hi) { return lo + (hi - lo) * (((double)(rng.next64() >> 11) + 1.0) * 0x1.0p-53); };
+  const double t_X = nd.t;
+  std::map<int32_t, int> counts; bool complicated = false;
+  for (auto& m : nd.muts) if (++counts[m.site] > 1) complicated = true;
+  std::vector<BHostMut> out;
+  if (!complicated) for (auto& m : nd.muts) out.push_back(BHostMut{uni_oc(t_P, t_X), m.site, m.from, m.to});
+  else for (auto& [l, c] : counts) {
+    std::vector<double> ts;
+    for (auto& m : nd.muts) if (m.site == l) ts.push_back(uni_oc(t_P, t_X));
+    std::sort(ts.begin(), ts.end());
+    size_t k = 0;
+    for (auto& m : nd.muts) if (m.site == l) out.push_back(BHostMut{ts[k++], m.site, m.from, m.to});
+  }
+  std::stable_sort(out.begin(), out.end(), [](const BHostMut& a, const BHostMut& b) { return a.t < b.t || (a.t == b.t && a.site < b.site); });
+  nd.muts = std::move(out);
+}
+
+}  // namespace emat
+#endif  // EMAT_BUILD_HPP_

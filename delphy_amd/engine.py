@@ -33,7 +33,7 @@ def library_path() -> str:
     return os.environ.get("EMAT_LIB_PATH") or os.path.join(_HERE, _LIB_NAME)
 
 
-_DEVSRC = ("emat_backend.hip", "emat_device_core.hpp", "emat_device_moves.hpp", "emat_device_spr.hpp", "emat_slab.hpp", "emat_gtree_kernels.hpp")
+_DEVSRC = ("emat_backend.hip", "emat_device_core.hpp", "emat_device_moves.hpp", "emat_device_spr.hpp", "emat_slab.hpp", "emat_gtree_kernels.hpp", "emat_build.hpp")
 
 
 def source_build_id() -> str:
@@ -77,6 +77,29 @@ class _FlatTreeC(C.Structure):
 class _PopModelC(C.Structure):
     _fields_ = [("kind", C.c_int32), ("p", C.c_double * 4), ("skygrid_type", C.c_int32), ("skygrid_num_knots", C.c_int32),
                 ("skygrid_x", C.POINTER(C.c_double)), ("skygrid_gamma", C.POINTER(C.c_double))]
+
+
+class _TipDescsC(C.Structure):
+    _fields_ = [("num_tips", C.c_int32), ("t_min", C.POINTER(C.c_float)), ("t_max", C.POINTER(C.c_float)),
+                ("delta_offset", C.POINTER(C.c_int32)), ("delta_site", C.POINTER(C.c_int32)), ("delta_to", C.POINTER(C.c_uint8)),
+                ("miss_offset", C.POINTER(C.c_int32)), ("miss_start", C.POINTER(C.c_int32)), ("miss_end", C.POINTER(C.c_int32))]
+
+
+class TipDescs:
+    """The builder's input (include/emat_backend.h: emat_tip_descs; reference Tip_desc): per tip a date range, its differences
+    from the reference sequence (CSR, ascending sites) and its missing intervals (CSR)."""
+
+    def __init__(self, t_min, t_max, delta_offset, delta_site, delta_to, miss_offset, miss_start, miss_end):
+        self.t_min = np.ascontiguousarray(t_min, np.float32); self.t_max = np.ascontiguousarray(t_max, np.float32)
+        self.delta_offset = np.ascontiguousarray(delta_offset, np.int32); self.delta_site = np.ascontiguousarray(delta_site, np.int32)
+        self.delta_to = np.ascontiguousarray(delta_to, np.uint8)
+        self.miss_offset = np.ascontiguousarray(miss_offset, np.int32); self.miss_start = np.ascontiguousarray(miss_start, np.int32)
+        self.miss_end = np.ascontiguousarray(miss_end, np.int32)
+        self.num_tips = int(self.t_min.shape[0])
+
+    def c_struct(self) -> "_TipDescsC":
+        return _TipDescsC(self.num_tips, _ptr(self.t_min, C.c_float), _ptr(self.t_max, C.c_float), _ptr(self.delta_offset, C.c_int32), _ptr(self.delta_site, C.c_int32),
+                          _ptr(self.delta_to, C.c_uint8), _ptr(self.miss_offset, C.c_int32), _ptr(self.miss_start, C.c_int32), _ptr(self.miss_end, C.c_int32))
 
 
 class _ConfigC(C.Structure):
@@ -255,6 +278,7 @@ def load_library():
         "emat_part_get_sizes": [B, i32, P(i32), P(i32), P(i32), P(i32)], "emat_part_download": [B, i32, P(_FlatTreeC)],
         "emat_part_get_derived": [B, i32, P(dbl), P(i32), P(dbl), P(dbl)],
         "emat_part_get_coalescent": [B, i32, P(i32), P(dbl), P(dbl), P(dbl), P(dbl), P(i32), P(dbl), P(dbl)],
+        "emat_tree_build_usher_like": [B, P(_TipDescsC), u64], "emat_tree_built_sizes": [B, P(i32), P(i32), P(i32), P(i32)], "emat_tree_built_get": [B, P(_FlatTreeC)],
         "emat_part_get_rng": [B, i32, P(u64), P(u64), P(u64), P(i32)], "emat_check_derived": [B, dbl, P(i32), P(dbl)], "emat_debug_slab_layout": [B, i32, P(C.c_uint32)],
         "emat_part_get_stats": [B, i32, P(_PartStatsC)], "emat_part_get_trace": [B, i32, P(i32), P(dbl)],
         "emat_last_run_ms": [B, P(dbl)], "emat_last_kernel_ms": [B, P(dbl), P(i32)],
@@ -683,6 +707,18 @@ class EmatBackend:
         self._ck(self._lib.emat_part_get_stats(self._h, part, C.byref(s)), "emat_part_get_stats")
         return dict(status=s.status, num_nodes=s.num_nodes, moves_done=s.moves_done, proposed=list(s.proposed), accepted=list(s.accepted),
                     algorithmic_bytes=s.algorithmic_bytes, rng_draws=s.rng_draws, device_ticks=s.device_ticks)
+
+    def build_usher_like(self, tips: "TipDescs", seed: int) -> "FlatTree":
+        """the reference's UShER-like initial tree from tip descriptors (set_ref_sequence first); the graft loop runs on the device."""
+        td = tips.c_struct()
+        self._ck(self._lib.emat_tree_build_usher_like(self._h, C.byref(td), seed), "emat_tree_build_usher_like")
+        n, nm, ni, nf = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._lib.emat_tree_built_sizes(self._h, C.byref(n), C.byref(nm), C.byref(ni), C.byref(nf)), "emat_tree_built_sizes")
+        t = FlatTree.empty(n.value, nm.value, ni.value, nf.value)
+        v = t.c_view()
+        self._ck(self._lib.emat_tree_built_get(self._h, C.byref(v)), "emat_tree_built_get")
+        t.root = v.root
+        return t.trimmed()
 
     def debug_slab_layout(self, part: int) -> dict:
         out = (C.c_uint32 * 8)()

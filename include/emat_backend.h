@@ -386,6 +386,32 @@ emat_status emat_debug_interval_op(emat_backend* h, int32_t op, const int32_t* a
  * cut-point states needed the large variant of k_gt_measure (out3[2]). */
 emat_status emat_debug_tree_counters(emat_backend* h, int32_t* out3);
 
+/* ---- initial-tree construction ------------------------------------------------------------------------
+ * replaces: build_usher_like_tree (reference core/phylo_tree.cpp:796-1049; --v0-init-method old_usher_like through
+ * build_rough_initial_tree_from_maple, cmdline.cpp:88-121) with its closing passes fix_up_missations (:414-507), pseudo_date
+ * (dates.cpp:63-82) and randomize_mutation_times (:567-644).
+ * Tip descriptors (reference Tip_desc, phylo_tree.h:137-143, as io.cpp's MAPLE reader fills them): per tip its date range, its
+ * differences from the reference sequence of emat_set_ref_sequence (ascending sites; `from` is the reference state) and its
+ * missing intervals (sorted, disjoint, non-adjacent).  Tips become nodes 0 .. num_tips-1 in this order, the inner node created
+ * for tip X is X + num_tips - 1.  The O(tips x nodes) graft loop runs on the device; the tree is a function of (descriptors,
+ * seed).  Input that the reference rejects (site out of range, delta onto the reference state, a site both missing and changed,
+ * t_min > t_max, fewer than two tips) is EMAT_ERR_INVALID_ARGUMENT with emat_last_error saying which tip. */
+typedef struct emat_tip_descs {
+  int32_t num_tips;
+  const float*   t_min;          /* [num_tips] */
+  const float*   t_max;          /* [num_tips] */
+  const int32_t* delta_offset;   /* [num_tips+1] CSR into delta_site / delta_to */
+  const int32_t* delta_site;
+  const uint8_t* delta_to;
+  const int32_t* miss_offset;    /* [num_tips+1] CSR into miss_start / miss_end */
+  const int32_t* miss_start;
+  const int32_t* miss_end;
+} emat_tip_descs;
+emat_status emat_tree_build_usher_like(emat_backend* h, const emat_tip_descs* tips, uint64_t seed);
+/* The tree it made, as a flat tree (for emat_run_create / emat_tree_upload): sizes, then the arrays. */
+emat_status emat_tree_built_sizes(emat_backend* h, int32_t* num_nodes, int32_t* num_muts, int32_t* num_intervals, int32_t* num_from_states);
+emat_status emat_tree_built_get(emat_backend* h, emat_flat_tree* out);
+
 /* Byte breakdown of one part's slab as the backend lays it out (works on host-only handles too): header, node records, coalescent
  * cell table, trace ring, list-heap content, list-heap capacity, scratch, and the number of cells kept. */
 emat_status emat_debug_slab_layout(emat_backend* h, int32_t part_id, uint32_t* out8);

@@ -283,5 +283,19 @@ inline Phylo_tree build_usher_like_tree(const std::vector<State>& ref_sequence, 
   return tree;
 }
 
+// Tip descriptors of an existing EMAT: what a MAPLE file of its tips would hold -- each tip's deltas against the reference
+// sequence at the sites it has, its missing intervals, its date range.  (Test scenarios are generated as trees; this turns
+// one into the builder's input.)
+inline std::vector<Tip_desc> tip_descs_of(const Phylo_tree& t) {
+  std::vector<Tip_desc> out;
+  for (int n = 0; n < t.size(); ++n) if (t.at(n).is_tip()) {
+    Tip_desc d; d.t_min = t.at(n).t_min; d.t_max = t.at(n).t_max;
+    d.missations.intervals = reconstruct_missing_sites_at(t, n);
+    for (auto& [l, dl] : deltas_ref_to_loc(t, t.node_loc(n))) if (!d.missations.intervals.contains(l)) d.seq_deltas.push_back(Seq_delta(l, t.ref_sequence[l], dl.to));
+    out.push_back(std::move(d));
+  }
+  return out;
+}
+
 }  // namespace orc
 #endif  // ORC_BUILD_HPP_

@@ -6,6 +6,7 @@
 #include <thread>
 
 #include "../include/emat_backend.h"
+#include "orc_build.hpp"
 #include "orc_run.hpp"
 #include "orc_subrun.hpp"
 
@@ -419,6 +420,68 @@ int orc_run_tree_get(orc_run* r, emat_flat_tree* out, uint8_t* ref_sequence) {
 int orc_run_tree_check(orc_run* r, char* msg, int msg_cap) {
   std::string m;
   try { m = check_phylo_tree_integrity(r->run.tree); } catch (const std::exception& ex) { m = ex.what(); }
+  std::snprintf(msg, msg_cap, "%s", m.c_str());
+  return m.empty() ? 0 : 1;
+}
+
+// ---- orc_build.hpp: the UShER-like initial-tree builder ---------------------------------------------------------------------------
+struct orc_build { std::vector<State> ref; std::vector<Tip_desc> descs; Phylo_tree tree; std::string last_error; };
+#define BUILD_TRY try {
+#define BUILD_CATCH } catch (const std::exception& ex) { r->last_error = ex.what(); return EMAT_ERR_INTERNAL; } return EMAT_OK;
+static std::vector<Tip_desc> descs_from_c(const emat_tip_descs& td, const std::vector<State>& ref) {
+  std::vector<Tip_desc> out(td.num_tips);
+  for (int i = 0; i < td.num_tips; ++i) {
+    out[i].t_min = td.t_min[i]; out[i].t_max = td.t_max[i];
+    for (int k = td.delta_offset[i]; k < td.delta_offset[i + 1]; ++k) out[i].seq_deltas.push_back(Seq_delta(td.delta_site[k], ref.at(td.delta_site[k]), td.delta_to[k]));
+    for (int k = td.miss_offset[i]; k < td.miss_offset[i + 1]; ++k) out[i].missations.intervals.v.push_back({td.miss_start[k], td.miss_end[k]});
+  }
+  return out;
+}
+int orc_build_create(const uint8_t* ref, int num_sites, orc_build** out) { *out = new orc_build; (*out)->ref.assign(ref, ref + num_sites); return EMAT_OK; }
+int orc_build_destroy(orc_build* r) { delete r; return EMAT_OK; }
+const char* orc_build_last_error(orc_build* r) { return r->last_error.c_str(); }
+// descriptors of the tips of a tree (tips in node order): sizes first (null arrays), then the arrays
+int orc_build_descs_from_tree(orc_build* r, const emat_flat_tree* tree, int* num_tips, int* num_deltas, int* num_intervals) {
+  BUILD_TRY
+  r->descs = tip_descs_of(tree_from_flat(*tree, r->ref));
+  int nd = 0, ni = 0;
+  for (auto& d : r->descs) { nd += (int)d.seq_deltas.size(); ni += d.missations.num_intervals(); }
+  *num_tips = (int)r->descs.size(); *num_deltas = nd; *num_intervals = ni;
+  BUILD_CATCH
+}
+int orc_build_descs_get(orc_build* r, float* t_min, float* t_max, int* delta_offset, int* delta_site, uint8_t* delta_to, int* miss_offset, int* miss_start, int* miss_end) {
+  BUILD_TRY
+  int kd = 0, ki = 0; delta_offset[0] = miss_offset[0] = 0;
+  for (size_t i = 0; i < r->descs.size(); ++i) {
+    auto& d = r->descs[i];
+    t_min[i] = d.t_min; t_max[i] = d.t_max;
+    for (auto& s : d.seq_deltas) { delta_site[kd] = s.site; delta_to[kd] = s.to; ++kd; }
+    for (auto& [a, b] : d.missations.intervals.v) { miss_start[ki] = a; miss_end[ki] = b; ++ki; }
+    delta_offset[i + 1] = kd; miss_offset[i + 1] = ki;
+  }
+  BUILD_CATCH
+}
+int orc_build_usher_like(orc_build* r, const emat_tip_descs* td, uint64_t seed, int* num_nodes, int* num_muts, int* num_intervals, int* num_from_states) {
+  BUILD_TRY
+  r->descs = descs_from_c(*td, r->ref);
+  Rng rng; rng.key = seed;
+  r->tree = build_usher_like_tree(r->ref, r->descs, rng);
+  tree_sizes(r->tree, num_nodes, num_muts, num_intervals, num_from_states);
+  BUILD_CATCH
+}
+int orc_build_tree_get(orc_build* r, emat_flat_tree* out) {
+  BUILD_TRY
+  tree_to_flat(r->tree, out);
+  BUILD_CATCH
+}
+// the reference's closing checks of the builder on ANY tree (e.g. the device's): integrity rules + every tip reproduces its descriptor
+int orc_build_check(orc_build* r, const emat_flat_tree* tree, const emat_tip_descs* td, char* msg, int msg_cap) {
+  std::string m;
+  try {
+    auto t = tree_from_flat(*tree, r->ref);
+    m = check_phylo_tree_integrity(t);
+    if (m.empty()) m = check_phylo_tree_matches_tip_descs(t, r->ref, descs_from_c(*td, r->ref));
+  } catch (const std::exception& ex) { m = ex.what(); }
   std::snprintf(msg, msg_cap, "%s", m.c_str());
   return m.empty() ? 0 : 1;
 }

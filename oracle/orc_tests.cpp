@@ -1427,19 +1427,6 @@ TEST(fix_up_missations_reference_cases) {
   }
 }
 
-// tip descriptors of a synthetic EMAT: what a MAPLE file of its tips would hold (deltas against the reference sequence at
-// the sites the tip has, its missing intervals, its date range)
-static std::vector<Tip_desc> tip_descs_of(const Phylo_tree& t) {
-  std::vector<Tip_desc> out;
-  for (int n = 0; n < t.size(); ++n) if (t.at(n).is_tip()) {
-    Tip_desc d; d.t_min = t.at(n).t_min; d.t_max = t.at(n).t_max;
-    d.missations.intervals = reconstruct_missing_sites_at(t, n);
-    auto seq = view_of_sequence_at(t, n);
-    for (int l = 0; l < t.num_sites(); ++l) if (seq[l] != t.ref_sequence[l] && !d.missations.intervals.contains(l)) d.seq_deltas.push_back(Seq_delta(l, t.ref_sequence[l], seq[l]));
-    out.push_back(std::move(d));
-  }
-  return out;
-}
 TEST(build_usher_like_tree_reproduces_its_tip_descriptors) {
   for (int seed = 0; seed < 8; ++seed) {
     emat::SynthParams p; p.num_tips = 12 + 37 * seed; p.num_sites = seed % 2 ? 300 : 2000; p.mu = (seed % 3 ? 6e-4 : 2e-3) / 365.0 * 365.0 / 365.0; p.gaps_per_tip = seed % 4; p.mean_gap_len = 25;

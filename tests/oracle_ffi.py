@@ -263,3 +263,59 @@ class OracleRun:
         buf = C.create_string_buffer(512)
         rc = self.L.orc_run_tree_check(self.h, buf, 512)
         return rc, buf.value.decode()
+
+
+class OracleBuild:
+    """oracle/orc_build.hpp: the reference's build_usher_like_tree (with fix_up_missations, pseudo_date, randomize_mutation_times)
+    restated, the tip descriptors of an existing tree, and the reference's closing checks of the builder."""
+
+    def __init__(self, ref):
+        from delphy_amd.engine import _TipDescsC
+        self.L = lib()
+        E = C.c_void_p
+        if not hasattr(self.L, "_build_sigs"):
+            i = C.c_int; P = C.POINTER
+            for n, a in {"orc_build_create": [P(C.c_uint8), i, P(E)], "orc_build_destroy": [E],
+                         "orc_build_descs_from_tree": [E, P(_FlatTreeC), P(i), P(i), P(i)],
+                         "orc_build_descs_get": [E, P(C.c_float), P(C.c_float), P(i), P(i), P(C.c_uint8), P(i), P(i), P(i)],
+                         "orc_build_usher_like": [E, P(_TipDescsC), C.c_uint64, P(i), P(i), P(i), P(i)], "orc_build_tree_get": [E, P(_FlatTreeC)],
+                         "orc_build_check": [E, P(_FlatTreeC), P(_TipDescsC), C.c_char_p, i]}.items():
+                f = getattr(self.L, n); f.argtypes = a; f.restype = C.c_int
+            self.L.orc_build_last_error.argtypes = [E]; self.L.orc_build_last_error.restype = C.c_char_p
+            self.L._build_sigs = True
+        ref = np.ascontiguousarray(ref, np.uint8)
+        self.h = E()
+        assert self.L.orc_build_create(_ptr(ref, C.c_uint8), ref.shape[0], C.byref(self.h)) == 0
+
+    def close(self):
+        if self.h:
+            self.L.orc_build_destroy(self.h); self.h = None
+
+    def _ck(self, st, what):
+        if st != 0:
+            raise RuntimeError("%s failed: %s" % (what, self.L.orc_build_last_error(self.h).decode()))
+
+    def tip_descs_of(self, tree: FlatTree):
+        from delphy_amd.engine import TipDescs
+        v = tree.c_view(); n, nd, ni = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self.L.orc_build_descs_from_tree(self.h, C.byref(v), C.byref(n), C.byref(nd), C.byref(ni)), "descs_from_tree")
+        tmin, tmax = np.zeros(n.value, np.float32), np.zeros(n.value, np.float32)
+        doff, dsite, dto = np.zeros(n.value + 1, np.int32), np.zeros(max(nd.value, 1), np.int32), np.zeros(max(nd.value, 1), np.uint8)
+        moff, ms, me = np.zeros(n.value + 1, np.int32), np.zeros(max(ni.value, 1), np.int32), np.zeros(max(ni.value, 1), np.int32)
+        self._ck(self.L.orc_build_descs_get(self.h, _ptr(tmin, C.c_float), _ptr(tmax, C.c_float), _ptr(doff, C.c_int), _ptr(dsite, C.c_int), _ptr(dto, C.c_uint8),
+                                            _ptr(moff, C.c_int), _ptr(ms, C.c_int), _ptr(me, C.c_int)), "descs_get")
+        return TipDescs(tmin, tmax, doff, dsite[: nd.value], dto[: nd.value], moff, ms[: ni.value], me[: ni.value])
+
+    def build_usher_like(self, tips, seed) -> FlatTree:
+        td = tips.c_struct(); n, nm, ni, nf = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._ck(self.L.orc_build_usher_like(self.h, C.byref(td), int(seed), C.byref(n), C.byref(nm), C.byref(ni), C.byref(nf)), "build_usher_like")
+        t = FlatTree.empty(n.value, nm.value, ni.value, nf.value)
+        v = t.c_view()
+        self._ck(self.L.orc_build_tree_get(self.h, C.byref(v)), "build_tree_get")
+        t.root = v.root
+        return t.trimmed()
+
+    def check(self, tree: FlatTree, tips):
+        v = tree.c_view(); td = tips.c_struct(); buf = C.create_string_buffer(512)
+        rc = self.L.orc_build_check(self.h, C.byref(v), C.byref(td), buf, 512)
+        return rc, buf.value.decode()

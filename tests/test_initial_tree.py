@@ -1,0 +1,87 @@
+"""SURVEY 8(f).4, initial-tree construction: emat_tree_build_usher_like (graft loop on the device) against the oracle's restatement
+of the reference's build_usher_like_tree (oracle/orc_build.hpp, pinned to the reference's fix_up_missations cases): same
+descriptors + same seed => the same tree, bit for bit -- topology, node times, every mutation with its time, every missation and
+from-state; and the reference's own closing checks of the builder (tree integrity, every tip reproduces its descriptor)."""
+import numpy as np
+import pytest
+
+import delphy_amd as d
+from delphy_amd.scenarios import make_scenario
+from oracle_ffi import OracleBuild
+
+FIELDS = ("parent", "child0", "child1", "t", "t_min", "t_max", "mut_offset", "mut_site", "mut_from", "mut_to", "mut_t",
+          "miss_offset", "miss_start", "miss_end", "mfs_offset", "mfs_site", "mfs_state")
+
+
+def build_both(sc, seed):
+    ob = OracleBuild(sc.ref)
+    tips = ob.tip_descs_of(sc.tree)
+    b = d.EmatBackend(sc.num_sites)
+    try:
+        b.set_ref_sequence(sc.ref)
+        got = b.build_usher_like(tips, seed)
+        want = ob.build_usher_like(tips, seed)
+        assert got.root == want.root
+        for f in FIELDS:
+            x, y = getattr(got, f), getattr(want, f)
+            assert x.shape == y.shape and np.array_equal(x, y), "%s differs (seed %d)" % (f, seed)
+        rc, msg = ob.check(got, tips)
+        assert rc == 0, msg
+        return got, tips
+    finally:
+        b.close(); ob.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", [("C1", dict(num_tips=12, num_sites=300)), ("C1", dict(num_tips=100, num_sites=30000, uncertain_tips=0.3)),
+                                     ("C2", dict(num_tips=1610, num_sites=18959)), ("C3", dict(num_tips=3000, num_sites=29903, uncertain_tips=0.1))])
+def test_device_builder_equals_the_restated_reference(name, kw):
+    sc = make_scenario(name, **kw)
+    for seed in (1, 20261001):
+        tree, tips = build_both(sc, seed)
+        assert tree.num_nodes == 2 * tips.num_tips - 1 and np.all(tree.child0[: tips.num_tips] == -1)
+
+
+@pytest.mark.gpu
+def test_c3_built_on_the_device_and_run():
+    """Config C3 as a whole (10 000 tips, 29 903 sites) from its tip descriptors, equal to the oracle's tree bit for bit; the
+    tree then goes through a cycle of local moves like any other."""
+    sc = make_scenario("C3")
+    tree, tips = build_both(sc, 7)
+    assert tips.num_tips == 10000
+    b = d.EmatBackend(sc.num_sites)
+    run = d.EmatRun(b, tree, sc.ref, 3)
+    run.set_num_parts(512); run.set_hky(sc.mu, sc.kappa, sc.pi); run.set_pop_model(sc.pop)
+    run.set_device_tree(True); run.set_paranoid(True)
+    run.do_mcmc_steps(512 * 200, 512 * 200)
+    run.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_descriptors_the_reference_rejects():
+    sc = make_scenario("C1", num_tips=12, num_sites=300)
+    ob = OracleBuild(sc.ref); tips = ob.tip_descs_of(sc.tree); ob.close()
+    b = d.EmatBackend(sc.num_sites); b.set_ref_sequence(sc.ref)
+    def broken(**kw):
+        t = d.TipDescs(tips.t_min.copy(), tips.t_max.copy(), tips.delta_offset.copy(), tips.delta_site.copy(), tips.delta_to.copy(),
+                       tips.miss_offset.copy(), tips.miss_start.copy(), tips.miss_end.copy())
+        for k, f in kw.items():
+            f(getattr(t, k))
+        return t
+    k = int(np.flatnonzero(np.diff(tips.delta_offset) > 0)[0]); j = int(tips.delta_offset[k])
+    def to_ref(a): a[j] = sc.ref[tips.delta_site[j]]
+    def out_of_range(a): a[j] = sc.num_sites
+    def swap_dates(a): a[0] = tips.t_max[0] + 10.0
+    for bad, what in ((broken(delta_to=to_ref), "equal 'from' and 'to'"), (broken(delta_site=out_of_range), "outside"), (broken(t_min=swap_dates), "t_min > t_max")):
+        with pytest.raises(d.EmatError, match=what):
+            b.build_usher_like(bad, 1)
+    b.close()
+
+
+def test_builder_has_no_host_fallback():
+    sc = make_scenario("C1", num_tips=12, num_sites=300)
+    ob = OracleBuild(sc.ref); tips = ob.tip_descs_of(sc.tree); ob.close()
+    b = d.EmatBackend(sc.num_sites, device=-1); b.set_ref_sequence(sc.ref)
+    with pytest.raises(d.EmatError, match="NO_DEVICE"):
+        b.build_usher_like(tips, 1)
+    b.close()
