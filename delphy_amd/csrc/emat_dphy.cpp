@@ -206,56 +206,69 @@ emat_status emat_dphy_params_flatbuffer(const emat_dphy_params* q, int32_t L, ui
 }
 
 // ---- the file (Delphy_output, delphy_output.cpp:94-141) ------------------------------------------------------------------
-struct emat_dphy_writer { FILE* f; };
+// Every write is checked: a full disk must not leave a truncated run file behind a row of EMAT_OKs.  Lengths are 32-bit in the
+// format (doc/dphy_file_format.md), so a buffer that does not fit one is refused rather than truncated.
+struct emat_dphy_writer { FILE* f; bool failed; };
 
-static void w_u32(FILE* f, uint32_t v) { uint8_t b[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)}; std::fwrite(b, 1, 4, f); }
-static void w_u64(FILE* f, uint64_t v) { w_u32(f, (uint32_t)v); w_u32(f, (uint32_t)(v >> 32)); }
-static void w_str(FILE* f, const char* s) { const size_t n = std::strlen(s); w_u32(f, (uint32_t)n); std::fwrite(s, 1, n, f); }
+static bool w_bytes(emat_dphy_writer* w, const void* p, size_t n) { if (w->failed) return false; if (n && std::fwrite(p, 1, n, w->f) != n) w->failed = true; return !w->failed; }
+static bool w_u32(emat_dphy_writer* w, uint32_t v) { uint8_t b[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)}; return w_bytes(w, b, 4); }
+static bool w_u64(emat_dphy_writer* w, uint64_t v) { return w_u32(w, (uint32_t)v) && w_u32(w, (uint32_t)(v >> 32)); }
+static bool w_str(emat_dphy_writer* w, const char* s) { const size_t n = std::strlen(s); if (n > 0xffffffffull) { w->failed = true; return false; } return w_u32(w, (uint32_t)n) && w_bytes(w, s, n); }
+static bool fits_u32(size_t n) { return n <= 0xffffffffull; }
 
 emat_status emat_dphy_open(const char* path, const char* core_version, int32_t build_number, const char* commit, int32_t steps_per_sample,
                            const emat_dphy_params* q, const emat_flat_tree* tree, const char* const* names, emat_dphy_writer** out) {
   if (!path || !core_version || !commit || !q || !tree_ok(tree) || !out) return EMAT_ERR_INVALID_ARGUMENT;
   uint64_t n = 0;
   emat_status st = emat_dphy_tree_info_flatbuffer(tree, names, nullptr, 0, &n); if (st) return st;
+  if (!fits_u32((size_t)n)) return EMAT_ERR_CAPACITY;
   std::vector<uint8_t> info((size_t)n);
   st = emat_dphy_tree_info_flatbuffer(tree, names, info.data(), n, &n); if (st) return st;
   FILE* f = std::fopen(path, "wb");
-  if (!f) return EMAT_ERR_INVALID_ARGUMENT;
-  std::fwrite("DPHY", 1, 4, f);
-  w_u32(f, 3);                                            // save format version
-  w_str(f, core_version); w_u32(f, (uint32_t)build_number); w_str(f, commit);
-  w_u32(f, 0);                                            // knee index
-  w_u32(f, (uint32_t)steps_per_sample);
-  w_u32(f, q->alpha_move_enabled ? 1u : 0u); w_u32(f, 0u /* mpox hack: not modelled */); w_u32(f, q->mu_move_enabled ? 1u : 0u);
-  { const float mu = (float)q->mu; uint32_t bits; std::memcpy(&bits, &mu, 4); w_u32(f, bits); }
-  w_u32(f, (uint32_t)info.size()); std::fwrite(info.data(), 1, info.size(), f);
-  *out = new emat_dphy_writer{f};
+  if (!f) return EMAT_ERR_IO;
+  emat_dphy_writer* w = new emat_dphy_writer{f, false};
+  w_bytes(w, "DPHY", 4);
+  w_u32(w, 3);                                            // save format version
+  w_str(w, core_version); w_u32(w, (uint32_t)build_number); w_str(w, commit);
+  w_u32(w, 0);                                            // knee index
+  w_u32(w, (uint32_t)steps_per_sample);
+  w_u32(w, q->alpha_move_enabled ? 1u : 0u); w_u32(w, 0u /* mpox hack: not modelled */); w_u32(w, q->mu_move_enabled ? 1u : 0u);
+  { const float mu = (float)q->mu; uint32_t bits; std::memcpy(&bits, &mu, 4); w_u32(w, bits); }
+  w_u32(w, (uint32_t)info.size()); w_bytes(w, info.data(), info.size());
+  if (w->failed) { std::fclose(f); delete w; return EMAT_ERR_IO; }
+  *out = w;
   return EMAT_OK;
 }
 emat_status emat_dphy_write_state(emat_dphy_writer* w, const emat_flat_tree* tree, const uint8_t* ref, int32_t L, const emat_dphy_params* q) {
   if (!w || !w->f) return EMAT_ERR_INVALID_ARGUMENT;
+  if (w->failed) return EMAT_ERR_IO;
   uint64_t nt = 0, np = 0;
   emat_status st = emat_dphy_tree_flatbuffer(tree, ref, L, nullptr, 0, &nt); if (st) return st;
   st = emat_dphy_params_flatbuffer(q, L, nullptr, 0, &np); if (st) return st;
+  if (!fits_u32((size_t)nt) || !fits_u32((size_t)np)) return EMAT_ERR_CAPACITY;
   std::vector<uint8_t> bt((size_t)nt), bp((size_t)np);
   st = emat_dphy_tree_flatbuffer(tree, ref, L, bt.data(), nt, &nt); if (st) return st;
   st = emat_dphy_params_flatbuffer(q, L, bp.data(), np, &np); if (st) return st;
-  w_u32(w->f, (uint32_t)bt.size()); w_u32(w->f, (uint32_t)bp.size());
-  std::fwrite(bt.data(), 1, bt.size(), w->f); std::fwrite(bp.data(), 1, bp.size(), w->f);
-  return EMAT_OK;
+  w_u32(w, (uint32_t)bt.size()); w_u32(w, (uint32_t)bp.size());
+  w_bytes(w, bt.data(), bt.size()); w_bytes(w, bp.data(), bp.size());
+  if (!w->failed && std::fflush(w->f) != 0) w->failed = true;
+  return w->failed ? EMAT_ERR_IO : EMAT_OK;
 }
 emat_status emat_dphy_close(emat_dphy_writer* w) {
   if (!w) return EMAT_OK;
+  bool ok = !w->failed;
   if (w->f) {
-    const uint64_t end = (uint64_t)std::ftell(w->f);
-    w_u32(w->f, 0);                                       // no more trees
-    w_str(w->f, "{\"confidence\":90,\"topology\":0,\"presentation\":0,\"spacing\":0,\"colorBy\":0,\"burnin\":0,\"metadataPresent\":0,"
-                "\"metadataText\":null,\"metadataFile\":null,\"metadataDelimiter\":null,\"selectedMDField\":-1,\"metadataColors\":{}}");
-    w_u64(w->f, end);
-    std::fclose(w->f);
+    const long end = std::ftell(w->f);
+    if (end < 0) { w->failed = true; ok = false; }
+    w_u32(w, 0);                                          // no more trees
+    w_str(w, "{\"confidence\":90,\"topology\":0,\"presentation\":0,\"spacing\":0,\"colorBy\":0,\"burnin\":0,\"metadataPresent\":0,"
+             "\"metadataText\":null,\"metadataFile\":null,\"metadataDelimiter\":null,\"selectedMDField\":-1,\"metadataColors\":{}}");
+    w_u64(w, (uint64_t)(end < 0 ? 0 : end));
+    ok = ok && !w->failed;
+    if (std::fclose(w->f) != 0) ok = false;
   }
   delete w;
-  return EMAT_OK;
+  return ok ? EMAT_OK : EMAT_ERR_IO;
 }
 
 }  // extern "C"

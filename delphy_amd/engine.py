@@ -25,7 +25,7 @@ class EmatError(RuntimeError):
 
 STATUS_NAMES = {
     0: "EMAT_OK", 1: "EMAT_ERR_INVALID_ARGUMENT", 2: "EMAT_ERR_NO_DEVICE", 3: "EMAT_ERR_HIP", 4: "EMAT_ERR_STATE",
-    5: "EMAT_ERR_CAPACITY", 6: "EMAT_ERR_INTERNAL", 7: "EMAT_ERR_BUFFER_TOO_SMALL",
+    5: "EMAT_ERR_CAPACITY", 6: "EMAT_ERR_INTERNAL", 7: "EMAT_ERR_BUFFER_TOO_SMALL", 8: "EMAT_ERR_IO",
 }
 
 

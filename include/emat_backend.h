@@ -34,7 +34,8 @@ typedef enum emat_status {
   EMAT_ERR_STATE = 4,            /* call sequence violated (e.g. run before upload) */
   EMAT_ERR_CAPACITY = 5,         /* a part ran out of slab space; see emat_part_get_status */
   EMAT_ERR_INTERNAL = 6,
-  EMAT_ERR_BUFFER_TOO_SMALL = 7
+  EMAT_ERR_BUFFER_TOO_SMALL = 7,
+  EMAT_ERR_IO = 8                /* a file could not be opened, written in full, or closed (include/emat_dphy.h) */
 } emat_status;
 
 /* Flat (struct-of-arrays, CSR) image of one `Phylo_tree` (reference core/phylo_tree.h:14-64).

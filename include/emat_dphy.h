@@ -63,6 +63,9 @@ emat_status emat_dphy_params_flatbuffer(const emat_dphy_params* params, int32_t 
 
 /* The file itself. */
 typedef struct emat_dphy_writer emat_dphy_writer;
+/* Errors: EMAT_ERR_IO when the file cannot be opened, a write or the final close falls short (every write is checked; a writer
+ * that has failed once keeps answering EMAT_ERR_IO); EMAT_ERR_CAPACITY for a buffer whose length does not fit the format's
+ * 32-bit length fields. */
 emat_status emat_dphy_open(const char* path, const char* core_version, int32_t build_number, const char* commit,
                            int32_t steps_per_sample, const emat_dphy_params* params_for_flags,
                            const emat_flat_tree* tree, const char* const* names, emat_dphy_writer** out);

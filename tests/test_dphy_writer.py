@@ -1,7 +1,8 @@
-"""`.dphy` files written from flat SoA trees (include/emat_dphy.h), read back with a small FlatBuffers
-reader written from the wire format: every field of the Tree / TreeInfo / Params buffers (reference core/api.fbs) and
-the file layout of doc/dphy_file_format.md (version 3).  The reader also applies the structural checks of the
-FlatBuffers verifier (offsets inside the buffer, scalars aligned, vtables consistent)."""
+"""`.dphy` files written from flat SoA trees (include/emat_dphy.h), verified and decoded against the REFERENCE's
+schema: tests/golden/api_schema.json holds the vtable slots, types, defaults, alignments and struct layouts of its generated
+header core/api_generated.h (flatc's output for core/api.fbs), extracted by tests/golden/make_api_schema.py -- the reader
+below is driven by that table and knows no field number of its own, so writer and checker share no field table.  Also the file
+layout of doc/dphy_file_format.md (version 3), and what becomes of times that float32 cannot hold (api.fbs:13-29)."""
 import ctypes as C
 import json
 import os
@@ -30,62 +31,130 @@ class DphyParams(C.Structure):
                 ("log_other_priors", dbl), ("log_coalescent_prior", dbl), ("log_G", dbl), ("total_branch_length", dbl)]
 
 
-class Fb:
-    """Reader of one size-prefixed FlatBuffer."""
-    def __init__(self, data):
+SCHEMA = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "api_schema.json")))
+
+
+class FbError(AssertionError):
+    pass
+
+
+class Decoded:
+    """One size-prefixed FlatBuffer verified and decoded against tests/golden/api_schema.json -- the vtable slots, types, defaults,
+    alignments and struct layouts of the REFERENCE's generated header (core/api_generated.h), extracted by
+    tests/golden/make_api_schema.py; nothing here knows a field number.  The checks are those of flatbuffers::Verifier
+    (VerifyTableStart / VerifyField / VerifyOffset / VerifyVector / VerifyString / union verification), plus one the
+    writer owes its readers: no vtable slot the schema does not know."""
+
+    def __init__(self, data, root_table):
         self.b = bytes(data)
+        n = len(self.b)
+        self._req(n >= 8 and n % 8 == 0, "buffer length")
         (size,) = struct.unpack_from("<I", self.b, 0)
-        assert size + 4 == len(self.b) and len(self.b) % 8 == 0
-        self.root = 4 + self._u32(4)
+        self._req(size + 4 == n, "size prefix")
+        self.value = self.table(4 + self._uoffset(4), root_table)
+
+    def _req(self, ok, what):
+        if not ok:
+            raise FbError("FlatBuffer verification failed: " + what)
 
     def _u32(self, p):
-        assert 0 <= p and p + 4 <= len(self.b) and p % 4 == 0
+        self._req(0 <= p and p + 4 <= len(self.b) and p % 4 == 0, "u32 at %d" % p)
         return struct.unpack_from("<I", self.b, p)[0]
 
-    def field(self, table, fid):
-        """Position of field `fid` of the table at `table`, or None if absent."""
-        assert table % 4 == 0
-        (so,) = struct.unpack_from("<i", self.b, table)
-        vt = table - so
-        assert 0 <= vt and vt % 2 == 0
-        vsize, tsize = struct.unpack_from("<HH", self.b, vt)
-        assert vsize >= 4 and vt + vsize <= len(self.b) and table + tsize <= len(self.b)
-        if 4 + 2 * fid + 2 > vsize:
-            return None
-        (off,) = struct.unpack_from("<H", self.b, vt + 4 + 2 * fid)
-        assert off < tsize
-        return table + off if off else None
+    def _uoffset(self, p):
+        o = self._u32(p)
+        self._req(o > 0 and p + o < len(self.b), "offset at %d" % p)
+        return o
 
-    def scalar(self, table, fid, fmt, default):
-        p = self.field(table, fid)
-        if p is None:
-            return default
-        assert p % struct.calcsize(fmt) == 0, "misaligned scalar"
-        return struct.unpack_from("<" + fmt, self.b, p)[0]
+    def struct_dtype(self, name):
+        st = SCHEMA["structs"][name]
+        dt = np.dtype({"names": [f["name"] for f in st["fields"]], "formats": ["<" + f["fmt"] if f["size"] > 1 else f["fmt"] for f in st["fields"]],
+                       "offsets": [f["offset"] for f in st["fields"]], "itemsize": st["size"]})
+        return dt, st["align"]
 
-    def ref(self, table, fid):
-        p = self.field(table, fid)
-        if p is None:
-            return None
-        t = p + self._u32(p)
-        assert t > p and t < len(self.b)
-        return t
-
-    def vector(self, pos, dtype):
+    def vector(self, pos, elem_size, elem_align):
         n = self._u32(pos)
-        dt = np.dtype(dtype)
-        assert (pos + 4) % min(dt.alignment if dt.fields is None else 4, 8) == 0 and pos + 4 + n * dt.itemsize <= len(self.b)
-        return np.frombuffer(self.b, dt, n, pos + 4)
+        self._req((pos + 4) % elem_align == 0, "vector data alignment at %d" % pos)
+        self._req(pos + 4 + n * elem_size <= len(self.b), "vector extent at %d" % pos)
+        return n
 
     def string(self, pos):
-        n = self._u32(pos)
-        assert self.b[pos + 4 + n] == 0
+        n = self.vector(pos, 1, 1)
+        self._req(pos + 4 + n < len(self.b) and self.b[pos + 4 + n] == 0, "string terminator")
         return self.b[pos + 4: pos + 4 + n].decode()
 
+    def table(self, pos, name):
+        fields = SCHEMA["tables"][name]["fields"]
+        self._req(pos % 4 == 0 and 0 <= pos and pos + 4 <= len(self.b), "table position")
+        (so,) = struct.unpack_from("<i", self.b, pos)
+        vt = pos - so
+        self._req(0 <= vt and vt % 2 == 0 and vt + 4 <= len(self.b), "vtable position")
+        vsize, tsize = struct.unpack_from("<HH", self.b, vt)
+        self._req(vsize >= 4 and vsize % 2 == 0 and vt + vsize <= len(self.b) and pos + tsize <= len(self.b), "vtable / table extent")
+        known = {f["vt"] for f in fields.values()}
+        for slot in range(4, vsize, 2):
+            (off,) = struct.unpack_from("<H", self.b, vt + slot)
+            self._req(off == 0 or slot in known, "%s: vtable slot %d is not in the reference's schema" % (name, slot))
+        out = {}
+        for fname, f in fields.items():
+            off = struct.unpack_from("<H", self.b, vt + f["vt"])[0] if f["vt"] + 2 <= vsize else 0
+            if f["kind"] == "scalar":
+                if off == 0:
+                    out[fname] = f["default"]
+                    continue
+                p = pos + off
+                self._req(off + f["size"] <= tsize and p % f["align"] == 0, "%s.%s: scalar extent / alignment" % (name, fname))
+                out[fname] = struct.unpack_from("<" + f["fmt"], self.b, p)[0]
+                continue
+            if off == 0:
+                out[fname] = None
+                continue
+            self._req(off + 4 <= tsize, "%s.%s: offset extent" % (name, fname))
+            tgt = pos + off + self._uoffset(pos + off)
+            if f["kind"] == "string":
+                out[fname] = self.string(tgt)
+            elif f["kind"] == "vector_of_scalars":
+                n = self.vector(tgt, f["size"], f["size"])
+                out[fname] = np.frombuffer(self.b, np.dtype("<" + f["fmt"]) if f["size"] > 1 else np.dtype(f["fmt"]), n, tgt + 4)
+            elif f["kind"] == "vector_of_structs":
+                dt, align = self.struct_dtype(f["struct"])
+                n = self.vector(tgt, dt.itemsize, align)
+                out[fname] = np.frombuffer(self.b, dt, n, tgt + 4)
+            elif f["kind"] == "vector_of_tables":
+                n = self.vector(tgt, 4, 4)
+                out[fname] = [self.table(tgt + 4 + 4 * i + self._uoffset(tgt + 4 + 4 * i), f["table"]) for i in range(n)]
+            elif f["kind"] == "table":
+                out[fname] = self.table(tgt, f["table"])
+            elif f["kind"] == "union":
+                out[fname] = tgt      # resolved below, once its discriminator is known
+        for fname, f in fields.items():
+            if f["kind"] != "union":
+                continue
+            kind = out[f["type_field"]]
+            members = {v: k for k, v in SCHEMA["unions"][f["union"]].items()}
+            if kind == 0:
+                self._req(out[fname] is None, "%s.%s: value without a type" % (name, fname))
+            else:
+                self._req(kind in members and out[fname] is not None, "%s.%s: union type %d" % (name, fname, kind))
+                out[fname] = (members[kind], self.table(out[fname], members[kind]))
+        return out
 
-NODE = np.dtype([("parent", "<i4"), ("left", "<i4"), ("right", "<i4"), ("t", "<f4")])
-MUT = np.dtype([("branch", "<i4"), ("site", "<i4"), ("from", "u1"), ("to", "u1"), ("pad", "<u2"), ("t", "<f4")])
-MISS = np.dtype([("branch", "<i4"), ("start", "<i4"), ("end", "<i4")])
+
+def test_the_schema_is_the_references():
+    """tests/golden/api_schema.json is what make_api_schema.py extracts from the reference's generated header (checked where the
+    reference is at hand), and it says what api.fbs says about a few fields one can read off the schema text."""
+    ref_hdr = "/root/reference/core/api_generated.h"
+    if os.path.exists(ref_hdr):
+        import subprocess, sys, tempfile, shutil
+        with tempfile.TemporaryDirectory() as tmp:
+            shutil.copy(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_api_schema.py"), tmp)
+            subprocess.run([sys.executable, os.path.join(tmp, "make_api_schema.py"), ref_hdr], check=True, capture_output=True)
+            assert json.load(open(os.path.join(tmp, "api_schema.json"))) == SCHEMA
+    P = SCHEMA["tables"]["Params"]["fields"]
+    assert P["step"]["vt"] == 4 and P["mu_prior_alpha"]["vt"] == 4 + 2 * 38 and P["mu_prior_alpha"]["default"] == 1.0 and P["num_local_moves_per_global_move"]["default"] == -1
+    assert P["pop_model"]["vt"] == 4 + 2 * 30 and P["pop_model_type"]["vt"] == 4 + 2 * 29 and P["mu_move_enabled"]["default"] == 1
+    assert SCHEMA["structs"]["Node"]["size"] == 16 and SCHEMA["structs"]["Mutation"]["size"] == 16 and SCHEMA["structs"]["MissationInterval"]["size"] == 12
+    assert [f["name"] for f in SCHEMA["structs"]["Mutation"]["fields"]] == ["branch", "site", "from", "to", "padding0", "t"]
 
 
 def _call(fn, *args):
@@ -109,45 +178,52 @@ def _lib():
     return L
 
 
+def _f32(x):
+    """static_cast<float>(double) as api.cpp:60-72 does it: round to nearest even, overflow to +-inf."""
+    with np.errstate(over="ignore"):
+        return np.asarray(x, np.float64).astype(np.float32)
+
+
 def _check_tree(buf, tree, ref):
-    fb = Fb(buf)
-    nodes = fb.vector(fb.ref(fb.root, 0), NODE); muts = fb.vector(fb.ref(fb.root, 1), MUT); miss = fb.vector(fb.ref(fb.root, 2), MISS)
-    seq = fb.vector(fb.ref(fb.root, 3), "u1")
-    assert fb.scalar(fb.root, 4, "i", 0) == tree.root
-    assert np.array_equal(nodes["parent"], tree.parent) and np.array_equal(nodes["left"], tree.child0) and np.array_equal(nodes["right"], tree.child1)
-    assert np.array_equal(nodes["t"], tree.t.astype(np.float32))                       # float32 times, api.fbs:13-18
+    t = Decoded(buf, "Tree").value
+    nodes, muts, miss = t["nodes"], t["mutations"], t["missation_intervals"]
+    assert t["root_node"] == tree.root
+    assert np.array_equal(nodes["parent"], tree.parent) and np.array_equal(nodes["left_child"], tree.child0) and np.array_equal(nodes["right_child"], tree.child1)
+    assert np.array_equal(nodes["t"], _f32(tree.t))                                  # float32 times, api.fbs:13-18
     branch_of = np.repeat(np.arange(tree.num_nodes), np.diff(tree.mut_offset))
     assert np.array_equal(muts["branch"], branch_of) and np.array_equal(muts["site"], tree.mut_site)
-    assert np.array_equal(muts["from"], tree.mut_from) and np.array_equal(muts["to"], tree.mut_to) and np.array_equal(muts["t"], tree.mut_t.astype(np.float32))
+    assert np.array_equal(muts["from"], tree.mut_from) and np.array_equal(muts["to"], tree.mut_to) and np.array_equal(muts["t"], _f32(tree.mut_t))
+    assert np.all(muts["padding0"] == 0)
     assert np.array_equal(miss["branch"], np.repeat(np.arange(tree.num_nodes), np.diff(tree.miss_offset)))
-    assert np.array_equal(miss["start"], tree.miss_start) and np.array_equal(miss["end"], tree.miss_end)
-    assert np.array_equal(seq, ref)
+    assert np.array_equal(miss["start_site"], tree.miss_start) and np.array_equal(miss["end_site"], tree.miss_end)
+    assert np.array_equal(t["ref_seq"], ref)
 
 
 def _check_params(buf, q, L):
-    fb = Fb(buf); r = fb.root
-    assert fb.scalar(r, 0, "q", 0) == q.step and fb.scalar(r, 1, "q", -1) == q.num_local_moves_per_global_move and fb.scalar(r, 2, "i", 0) == q.num_parts
-    assert fb.scalar(r, 3, "d", 0.0) == q.mu and fb.scalar(r, 38, "d", 1.0) == q.mu_prior_alpha and fb.scalar(r, 4, "d", 0.0) == q.alpha
-    assert fb.scalar(r, 6, "d", 0.0) == q.hky_kappa and [fb.scalar(r, 7 + a, "d", 0.0) for a in range(4)] == list(q.hky_pi)
-    assert fb.scalar(r, 14, "B", 0) == q.topology_moves_enabled and fb.scalar(r, 25, "B", 1) == q.mu_move_enabled
-    assert fb.scalar(r, 20, "d", 0.0) == q.log_G and fb.scalar(r, 19, "d", 0.0) == q.log_coalescent_prior
-    assert fb.scalar(r, 17, "d", 0.0) == q.log_G + q.log_coalescent_prior + q.log_other_priors and fb.scalar(r, 21, "d", 0.0) == q.total_branch_length
-    assert fb.scalar(r, 43, "d", 0.0) == q.pop_g_prior_scale and fb.scalar(r, 44, "d", 0.0) == q.pop_g_min
-    kind = fb.scalar(r, 29, "B", 0); pm = fb.ref(r, 30)
+    r = Decoded(buf, "Params").value
+    same = ("step", "num_local_moves_per_global_move", "num_parts", "mu", "mu_prior_alpha", "mu_prior_beta", "alpha", "hky_kappa", "pop_inv_n0_prior_alpha", "pop_inv_n0_prior_beta",
+            "pop_g_prior_mu", "pop_g_prior_scale", "pop_g_min", "pop_g_max", "skygrid_tau", "skygrid_tau_prior_alpha", "skygrid_tau_prior_beta", "skygrid_low_gamma_barrier_loc",
+            "skygrid_low_gamma_barrier_scale", "skygrid_inv_nbar_prior_alpha", "skygrid_inv_nbar_prior_beta", "only_displacing_inner_nodes", "topology_moves_enabled",
+            "repartitioning_enabled", "alpha_move_enabled", "mu_move_enabled", "final_pop_size_move_enabled", "pop_growth_rate_move_enabled", "skygrid_tau_move_enabled",
+            "skygrid_low_gamma_barrier_enabled", "log_other_priors", "log_coalescent_prior", "log_G", "total_branch_length")
+    for name in same:
+        assert r[name.lower()] == getattr(q, name), name
+    assert [r["hky_pi_" + a] for a in "acgt"] == list(q.hky_pi)
+    assert r["log_posterior"] == q.log_G + q.log_coalescent_prior + q.log_other_priors            # run_to_api_params, api.cpp:293-297
+    assert r["mpox_hack_enabled"] == 0 and r["mpox_mu"] == 0.0 and r["mpox_mu_star"] == 0.0
+    kind, pm = r["pop_model"]
     if q.pop_model.kind == 2:
-        assert kind == 2 and fb.scalar(pm, 0, "b", 1) == q.pop_model.skygrid_type
         n = q.pop_model.skygrid_num_knots
-        assert np.array_equal(fb.vector(fb.ref(pm, 1), "<f8"), np.ctypeslib.as_array(q.pop_model.skygrid_x, (n,)))
-        assert np.array_equal(fb.vector(fb.ref(pm, 2), "<f8"), np.ctypeslib.as_array(q.pop_model.skygrid_gamma, (n,)))
-        assert fb.field(r, 26) is None
+        assert kind == "SkygridPopModel" and pm["type"] == q.pop_model.skygrid_type
+        assert np.array_equal(pm["x_k"], np.ctypeslib.as_array(q.pop_model.skygrid_x, (n,))) and np.array_equal(pm["gamma_k"], np.ctypeslib.as_array(q.pop_model.skygrid_gamma, (n,)))
+        assert r["pop_t0"] == 0.0 and r["pop_n0"] == 0.0 and r["pop_g"] == 0.0          # the deprecated copies stay absent
     else:
-        assert kind == 1 and [fb.scalar(pm, k, "d", 0.0) for k in range(4)] == list(q.pop_model.p)
-        assert fb.scalar(r, 26, "d", 0.0) == q.pop_model.p[0] and fb.scalar(r, 11, "d", 0.0) == q.pop_model.p[1] and fb.scalar(r, 12, "d", 0.0) == q.pop_model.p[2]
-    nu = fb.ref(r, 5)
+        assert kind == "ExpPopModel" and [pm["t0"], pm["n0"], pm["g"], pm["min_pop"]] == list(q.pop_model.p)
+        assert (r["pop_t0"], r["pop_n0"], r["pop_g"]) == (q.pop_model.p[0], q.pop_model.p[1], q.pop_model.p[2])
     if q.nu and not all(q.nu[l] == 1.0 for l in range(L)):
-        assert np.array_equal(fb.vector(nu, "<f8"), np.ctypeslib.as_array(q.nu, (L,)))
+        assert np.array_equal(r["nu"], np.ctypeslib.as_array(q.nu, (L,)))
     else:
-        assert nu is None
+        assert r["nu"] is None
 
 
 def test_tree_info_and_params_flatbuffers_round_trip():
@@ -156,21 +232,17 @@ def test_tree_info_and_params_flatbuffers_round_trip():
         sc = make_scenario(name, **kw)
         v = sc.tree.c_view(); ref = np.ascontiguousarray(sc.ref, np.uint8)
         _check_tree(_call(L.emat_dphy_tree_flatbuffer, C.byref(v), ref.ctypes.data_as(C.POINTER(C.c_uint8)), sc.num_sites), sc.tree, ref)
-        info = Fb(_call(L.emat_dphy_tree_info_flatbuffer, C.byref(v), None))
-        vec = info.ref(info.root, 0)
-        offs = info.vector(vec, "<u4")
-        assert offs.shape[0] == sc.tree.num_nodes
+        infos = Decoded(_call(L.emat_dphy_tree_info_flatbuffer, C.byref(v), None), "TreeInfo").value["node_infos"]
+        assert len(infos) == sc.tree.num_nodes
         uncertain = 0
-        for i in range(sc.tree.num_nodes):
-            t = vec + 4 + 4 * i + int(offs[i])
-            nm = info.string(info.ref(t, 0))
+        for i, ni in enumerate(infos):
             tip = sc.tree.child0[i] == -1
-            assert nm == ("TIP_%d" % i if tip else "")
+            assert ni["name"] == ("TIP_%d" % i if tip else "")
             if tip and sc.tree.t_min[i] != sc.tree.t_max[i]:
-                assert info.scalar(t, 1, "B", 0) == 1 and info.scalar(t, 2, "f", 0.0) == sc.tree.t_min[i] and info.scalar(t, 3, "f", 0.0) == sc.tree.t_max[i]
+                assert ni["has_uncertain_t"] == 1 and ni["t_min"] == sc.tree.t_min[i] and ni["t_max"] == sc.tree.t_max[i]
                 uncertain += 1
             else:
-                assert info.scalar(t, 1, "B", 0) == 0
+                assert ni["has_uncertain_t"] == 0
         assert uncertain == int(np.sum((sc.tree.child0 == -1) & (sc.tree.t_min != sc.tree.t_max)))
         q = DphyParams(); L.emat_dphy_params_defaults(C.byref(q))
         q.step = 123456789012; q.num_parts = 7955; q.mu = sc.mu; q.hky_kappa = sc.kappa
@@ -208,7 +280,7 @@ def test_dphy_file_layout(tmp_path):
     (mu,) = struct.unpack_from("<f", b, p); p += 4
     assert (knee, sps, alpha_on, mpox, mu_on) == (0, 1000000, 0, 0, 1) and mu == np.float32(2e-6)
     (n_info,) = struct.unpack_from("<I", b, p); p += 4
-    Fb(b[p: p + n_info]); p += n_info
+    assert len(Decoded(b[p: p + n_info], "TreeInfo").value["node_infos"]) == sc.tree.num_nodes; p += n_info
     steps = []
     while True:
         (l1,) = struct.unpack_from("<I", b, p)
@@ -217,8 +289,47 @@ def test_dphy_file_layout(tmp_path):
             break
         (l2,) = struct.unpack_from("<I", b, p + 4); p += 8
         _check_tree(b[p: p + l1], sc.tree, ref); p += l1
-        fb = Fb(b[p: p + l2]); steps.append(fb.scalar(fb.root, 0, "q", 0)); p += l2
+        steps.append(Decoded(b[p: p + l2], "Params").value["step"]); p += l2
     assert steps == [1000000, 2000000, 3000000]
     meta, p = rd_str(p)
     assert json.loads(meta)["confidence"] == 90
     assert struct.unpack_from("<Q", b, p)[0] == sentinel and p + 8 == len(b)
+
+
+def test_times_are_rounded_to_float32_as_the_reference_rounds_them():
+    """api.fbs stores node and mutation times as float32; phylo_tree_to_api_tree converts with static_cast<float> (api.cpp:60-72):
+    round to nearest, ties to even, and a root "mutation" at -DBL_MAX overflows to -inf.  Times chosen on and around ties."""
+    L = _lib()
+    sc = make_scenario("C1", num_tips=6, num_sites=40)
+    tree = sc.tree
+    ulp = 2.0 ** -23                                                   # float32 spacing in [1, 2)
+    hard = np.array([1.0 + ulp / 2, 1.0 + 3 * ulp / 2, 1.0 + ulp / 2 + 2.0 ** -40, 737.123456789, -100000.3, 16777217.0, 0.1, -0.0, 1e-46, 3.4028235677973366e38])
+    tree.t[: min(tree.num_nodes, hard.shape[0])] = hard[: min(tree.num_nodes, hard.shape[0])]
+    if tree.mut_t.shape[0]:
+        tree.mut_t[: min(tree.mut_t.shape[0], hard.shape[0])] = hard[: min(tree.mut_t.shape[0], hard.shape[0])][::-1]
+        tree.mut_t[-1] = -1.7976931348623157e308                       # what a root delta carries (spr_move.cpp:422-425)
+    v = tree.c_view(); ref = np.ascontiguousarray(sc.ref, np.uint8)
+    buf = _call(L.emat_dphy_tree_flatbuffer, C.byref(v), ref.ctypes.data_as(C.POINTER(C.c_uint8)), sc.num_sites)
+    _check_tree(buf, tree, ref)
+    t = Decoded(buf, "Tree").value
+    assert t["nodes"]["t"][0] == np.float32(1.0) and t["nodes"]["t"][1] == np.float32(1.0 + 2 * ulp) and t["nodes"]["t"][2] == np.float32(1.0 + ulp)   # ties to even, above a tie rounds up
+    if tree.mut_t.shape[0]:
+        assert np.isneginf(t["mutations"]["t"][-1])
+
+
+def test_io_failures_are_reported(tmp_path):
+    """A run file that cannot be opened or written in full is EMAT_ERR_IO (8), not EMAT_OK (/dev/full: every write fails at flush)."""
+    L = _lib()
+    sc = make_scenario("C1", num_tips=40, num_sites=500)
+    v = sc.tree.c_view(); ref = np.ascontiguousarray(sc.ref, np.uint8)
+    q = DphyParams(); L.emat_dphy_params_defaults(C.byref(q)); pm = sc.pop.c_struct(); q.pop_model = pm
+    w = C.c_void_p()
+    assert L.emat_dphy_open(os.path.join(str(tmp_path), "no", "such", "dir", "run.dphy").encode(), b"1", 1, b"c", 1, C.byref(q), C.byref(v), None, C.byref(w)) == 8
+    if os.path.exists("/dev/full"):
+        rc = L.emat_dphy_open(b"/dev/full", b"1", 1, b"c", 1, C.byref(q), C.byref(v), None, C.byref(w))
+        if rc == 0:       # the preamble sat in stdio's buffer: the first flush finds out
+            rc = L.emat_dphy_write_state(w, C.byref(v), ref.ctypes.data_as(C.POINTER(C.c_uint8)), sc.num_sites, C.byref(q))
+            assert rc == 8
+            assert L.emat_dphy_close(w) == 8
+        else:
+            assert rc == 8
