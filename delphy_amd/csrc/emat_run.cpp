@@ -111,6 +111,7 @@ struct RunDriver {
   bool have_pop = false; emat_pop_model pop{}; std::vector<double> sky_x, sky_g;
   double t_step = 1.0; bool t_step_set = false;
   int only_displacing_inner_nodes = 0, topology_moves_enabled = 1;
+  bool reference_remainder = false;   // the remainder of count / parts goes to part 0 as in Run::run_local_moves (run.cpp:683-689), instead of one move per part
   bool paranoid = false;   // Run::paranoid (run.h:220-224): check the incrementally maintained quantities of every part after every pass
   // partition state
   std::vector<std::vector<int32_t>> stencils; int64_t stencil_refresh_countdown = 0;
@@ -656,6 +657,7 @@ struct RunDriver {
   // on part 0 (emat_run_moves_even explains why)
   emat_status run_moves(int64_t count) {
     const int64_t P = shard_world > 1 ? (int64_t)(part_hi - part_lo) : (int64_t)parts.size(), sub = count / P;   // (a sharded run goes through emat_run_moves_sharded)
+    if (reference_remainder) return bk(emat_run_local_moves(backend, count));
     return bk(emat_run_moves_even(backend, sub, (int32_t)(count - P * sub)));
   }
 
@@ -968,6 +970,7 @@ emat_status emat_run_unpack_parts(emat_run* r, const uint8_t* buf, uint64_t byte
   if (!r || (!buf && bytes)) return EMAT_ERR_INVALID_ARGUMENT;
   try { return r->d.unpack_parts(buf, bytes); } catch (const std::exception& ex) { return r->d.fail(EMAT_ERR_INTERNAL, ex.what()); }
 }
+emat_status emat_run_set_reference_remainder(emat_run* r, int32_t on) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; r->d.reference_remainder = on != 0; return EMAT_OK; }
 emat_status emat_run_set_paranoid(emat_run* r, int32_t on) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; r->d.paranoid = on != 0; return EMAT_OK; }
 emat_status emat_run_do_mcmc_steps(emat_run* r, int64_t steps, int64_t per_cycle) {   // run.cpp:622-657 minus global moves
   if (!r || steps < 0) return EMAT_ERR_INVALID_ARGUMENT;

@@ -310,7 +310,7 @@ def load_library():
         "emat_tree_repartition_range": [B, i32, P(i32), P(i32), P(i32), P(i32), i32, P(u64), P(_PopModelC), dbl, i32, i32],
         "emat_tree_get_root_deltas": [B, P(i32), P(i32), P(C.c_uint8), P(C.c_uint8), i32], "emat_tree_gather_local": [B, i32, P(i32), P(C.c_uint8), P(C.c_uint8)],
         "emat_tree_export_nodes": [B, P(C.c_uint8), u64, P(u64)], "emat_tree_apply_nodes": [B, P(C.c_uint8), u64], "emat_tree_reassemble_end": [B],
-        "emat_run_note_device_reassembled": [R, i32, P(i32), P(C.c_uint8)], "emat_run_set_paranoid": [R, i32],
+        "emat_run_note_device_reassembled": [R, i32, P(i32), P(C.c_uint8)], "emat_run_set_paranoid": [R, i32], "emat_run_set_reference_remainder": [R, i32],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -792,6 +792,10 @@ class EmatRun:
 
     def set_flags(self, only_displacing_inner_nodes: bool = False, topology_moves_enabled: bool = True):
         self._ck(self._lib.emat_run_set_flags(self._h, int(only_displacing_inner_nodes), int(topology_moves_enabled)), "emat_run_set_flags")
+
+    def set_reference_remainder(self, on: bool = True):
+        """The remainder of count / parts goes to part 0 as in Run::run_local_moves (default: one move each on the first parts)."""
+        self._ck(self._lib.emat_run_set_reference_remainder(self._h, 1 if on else 0), "emat_run_set_reference_remainder")
 
     def set_paranoid(self, on: bool = True):
         self._ck(self._lib.emat_run_set_paranoid(self._h, 1 if on else 0), "emat_run_set_paranoid")

@@ -66,9 +66,14 @@ def _torch_device_allgather(device: str):
         dist.all_gather(sizes, torch.tensor([nbytes], dtype=torch.int64, device=device))
         n = [int(x.item()) for x in sizes]
         mine = torch.empty(max(max(n), 1), dtype=torch.uint8, device=device)
+        # The engine's kernels run on the engine's own HIP stream, the collective on torch's current stream: neither orders
+        # itself after the other.  `fill` ends with the engine's stream synchronised (emat_tree_export_nodes waits for its
+        # kernels); the waits below close the other two gaps whatever stream the caller made current.
+        torch.cuda.current_stream(device).synchronize()      # `mine` is allocated and nobody else is writing it
         fill(mine)
         out = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(out, mine)
+        torch.cuda.current_stream(device).synchronize()      # RCCL has delivered before the apply kernels read `out`
         return [o[: n[r]] for r, o in enumerate(out)]
     return allgather_device
 

@@ -240,7 +240,10 @@ emat_status emat_tree_reassemble(emat_backend* h, int32_t* num_root_deltas, int3
  *   emat_tree_reassemble_end      every process: mirrors refreshed; every copy of the tree holds the same nodes again
  * (lists sit at different heap offsets in different processes, which nothing depends on).  `buf` of emat_tree_export_nodes /
  * emat_tree_apply_nodes may be host memory or device memory: with device buffers the exchange is one RCCL all-gather on
- * what the kernels wrote, and nothing but a 32-byte header and the per-node records (for validation) crosses PCIe. */
+ * what the kernels wrote, and nothing but a 32-byte header and the per-node records (for validation) crosses PCIe.
+ * Streams: the engine launches on a stream of its own.  emat_tree_export_nodes returns with its kernels finished (the buffer
+ * may be handed to a collective on any stream); emat_tree_apply_nodes reads `buf` from the engine's stream as soon as it is
+ * called, so the caller must have waited for whatever produced a DEVICE buffer (e.g. the all-gather on its own stream). */
 emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, const int32_t* part_offset, const int32_t* orig, const int32_t* kid0, const int32_t* kid1,
                                         int32_t root_part, const uint64_t* seeds, const emat_pop_model* pop_model, double t_step, int32_t part_lo, int32_t part_hi);
 emat_status emat_tree_get_root_deltas(emat_backend* h, int32_t* num_root_deltas, int32_t* site, uint8_t* from, uint8_t* to, int32_t capacity);

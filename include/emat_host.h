@@ -69,6 +69,12 @@ emat_status emat_run_set_hky(emat_run* r, double mu, double kappa, const double 
 emat_status emat_run_set_pop_model(emat_run* r, const emat_pop_model* pm);
 emat_status emat_run_set_coalescent_t_step(emat_run* r, double t_step);
 emat_status emat_run_set_flags(emat_run* r, int32_t only_displacing_inner_nodes, int32_t topology_moves_enabled);
+/* How emat_run_moves / emat_run_do_mcmc_steps split `count` moves over P parts.  Default (0): count / P on every part and the
+ * remainder one move each on the first parts -- NOT the reference's rule, which gives the whole remainder to subrun 0
+ * (Run::run_local_moves, run.cpp:683-689): harmless with 8 parts, but with thousands of parts it makes part 0 the longest
+ * chain of every pass by a factor of several.  1: the reference's rule, for runs that must reproduce its per-part move counts
+ * (emat_run_local_moves of the backend).  Sharded runs (emat_run_moves_sharded) always spread. */
+emat_status emat_run_set_reference_remainder(emat_run* r, int32_t on);
 /* Run::set_paranoid (reference run.h:220-224; CLI flag --v0-paranoid, cmdline.cpp:177): emat_run_do_mcmc_steps then runs
  * emat_check_derived on every part after every pass of local moves and stops with its error if one is off. */
 emat_status emat_run_set_paranoid(emat_run* r, int32_t on);
