@@ -288,6 +288,20 @@ def main():
         except Exception as e:
             traffic, traffic_source = None, "unreadable profiles/pmc_latest.json: %s" % e
     bad = stats1["bad_parts"]
+    # what a move buys: effective samples per second at the benchmark's part density next to the reference's few-part policy, from the
+    # committed posterior-equivalence run (scripts/posterior_check.py; a 500-tip tree, so its moves/s are not this workload's)
+    mixing = None
+    mix_path = os.path.join(ROOT, "profiles", "posterior_latest.json")
+    if rank == 0 and os.path.exists(mix_path):
+        try:
+            pc = json.load(open(mix_path))
+            mixing = {"source": "profiles/posterior_latest.json (scripts/posterior_check.py: %d tips, %d retained samples per arm, one per cycle of 50 x nodes moves)" % (pc["tips"], pc["configs"][0]["retained"]),
+                      "worst_abs_z_between_arms": pc.get("worst_abs_z"),
+                      "arms": [{"parts": c["parts"], "frozen_fraction": c["frozen_fraction"], "moves_per_s": c["moves_per_s"],
+                                "ess_per_s": {k: v["ess_per_s"] for k, v in c["stats"].items()},
+                                "ess_per_million_moves": {k: v["ess_per_million_moves"] for k, v in c["stats"].items()}} for c in pc["configs"]]}
+        except Exception as e:
+            mixing = {"error": "unreadable profiles/posterior_latest.json: %s" % e}
 
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -330,6 +344,7 @@ def main():
                          "kernel": "k_run_moves", "kernel_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
             "cpu_baseline": cpu_base,
             "inclusive": inclusive,
+            "mixing": mixing,
             "check": {"log_G": log_G, "log_augmented_coalescent_prior": log_prior, "parts_stopped": bad},
         }
         print(json.dumps(out))
