@@ -70,6 +70,7 @@ struct KernelArgs {
   double* stats_out;              // [num_parts][k_stats_row]: per-part output of k_global_stats
   EvoTable evo;
   const PopTable* pop;
+  SharedCells shared;             // the run-wide coalescent cell arrays (every part but the root part reads them here)
   RunFlags flags;
   int32_t num_parts;
   uint32_t lds_slab_bytes;        // capacity of the LDS staging area (0 = never stage)
@@ -112,6 +113,7 @@ template <class CtxT> __device__ inline void init_ctx(CtxT& c, uint8_t* slab, ui
   if (lds_tables) { c.mu = lds_tables; c.pi = lds_tables + k_max_lds_partitions; c.q = lds_tables + k_max_lds_partitions * 5; }
   else { c.mu = a.evo.mu; c.pi = a.evo.pi; c.q = a.evo.q; }
   c.pop = a.pop;
+  c.sh_ktw = a.shared.k_twiddle_bar; c.sh_tsop = a.shared.ts_over_pop; c.sh_nact = a.shared.num_active_parts;
   c.t_max_tip = a.flags.t_max_tip;
   c.only_displacing_inner_nodes = a.flags.only_displacing_inner_nodes != 0;
   c.topology_moves_enabled = a.flags.topology_moves_enabled != 0;
@@ -442,10 +444,15 @@ template <bool kCheck> __device__ __forceinline__ void recalc_derived_body(const
     if (!dev::is_tip(c, i)) acc_prior -= log(dev::pop_at_time(*c.pop, c.N[i].t));
   }
   {
-    dev::Cells k = dev::cells_of(c);
+    // (lanes take different cells here: the shared arrays are read with ordinary loads, not through the scalar cache)
+    const int cap = c.H->cell_cap, first = c.H->cell_first;
+    const double* base = (const double*)(slab + c.H->off_cells);
+    const double* kbar_p = base; const double* ktw_p = base + cap;
     for (int w = lane; w < c.H->n_cells; w += k_wave) {   // very_scalable_coalescent.cpp:355-386
-      double na = (double)k.nactive[w];
-      acc_prior -= k.ts_over_pop[w] * (+0.5 * (k.kbar_p[w] * k.kbar_p[w]) * na - (k.ktw_p[w] * na - k.ktw[w] + 0.5) * k.kbar_p[w]);
+      double na, tsop, ktw;
+      if (c.includes_run_root) { na = (double)((const int32_t*)(base + 5 * cap))[w]; tsop = base[4 * cap + w]; ktw = base[2 * cap + w]; }
+      else { na = (double)a.shared.num_active_parts[first + w]; tsop = a.shared.ts_over_pop[first + w]; ktw = a.shared.k_twiddle_bar[first + w]; }
+      acc_prior -= tsop * (+0.5 * (kbar_p[w] * kbar_p[w]) * na - (ktw_p[w] * na - ktw + 0.5) * kbar_p[w]);
     }
   }
   acc_G = wave_sum(acc_G); acc_prior = wave_sum(acc_prior);
@@ -720,7 +727,7 @@ struct GTreeHost {
   DevBuf<int32_t> lidx;
   DevBuf<GRootDelta> root_deltas_in;
   DevBuf<int32_t> part_off, orig, kid0, kid1, lpar;
-  DevBuf<double> co_kbar, co_ktw, co_k_bar, co_k_tw, co_popsize; DevBuf<int32_t> co_num_active;   // the coalescent grid, when it is built on the device
+  DevBuf<double> co_kbar, co_ktw, co_k_bar, co_k_tw, co_popsize, co_tsop; DevBuf<int32_t> co_num_active;   // the coalescent grid, when it is built on the device
   DevBuf<int32_t> measure_list;
   DevBuf<GMeasure> measure; DevBuf<MutRec> pool_muts; DevBuf<IvRec> pool_ivs; DevBuf<uint32_t> pool_tops;
   DevBuf<GPartDesc> desc; DevBuf<uint8_t> cells;
@@ -790,6 +797,12 @@ struct emat_backend {
   uint32_t max_slab_bytes = 0;
   std::vector<uint32_t> persistent_bytes;   // per part: slab size without scratch
   std::vector<uint32_t> prefix_bytes;       // per part: header + nodes + cells + trace (what the prefix-staged variant keeps in LDS)
+  std::vector<uint32_t> used_bytes;         // per part: prefix + list content (what a part staged whole brings into LDS)
+  // SharedCells: host mirror (absolute cell index) and the device copy the kernels read
+  std::vector<double> sh_ktw, sh_popsize, sh_tsop; std::vector<int32_t> sh_nact;
+  DevBuf<double> d_sh_ktw, d_sh_tsop; DevBuf<int32_t> d_sh_nact;
+  SharedCells shared_dev{nullptr, nullptr, nullptr, 0};   // what make_args hands the kernels (the HBM-resident tree points it at its own grid arrays)
+  uint32_t cfg_side_arena = 0;              // EMAT_SIDE_ARENA (tuning knob): a part that would be left with less arena than this in the main area joins the giants' 8-per-CU class
   bool cfg_giants = true;                   // EMAT_GIANTS (tuning knob): parts that cannot even stage their prefix get a class of their own
   double cfg_heap_per_node = 64.0;  // EMAT_HEAP_PER_NODE: heap bytes per node on top of slack x content
   uint32_t cfg_lds_scratch = 0;     // EMAT_LDS_SCRATCH (tuning knob): per-part LDS scratch arena; 0 = all scratch in HBM (measured best at C4)
@@ -823,7 +836,7 @@ void encode_slab(const emat_backend& B, const PartHost& ph, uint8_t* slab, uint3
   H->status = 0; H->rng_key = ph.rng.key; H->rng_counter = ph.rng.counter; H->rng_spare = ph.rng.spare; H->rng_has_spare = ph.rng.has_spare ? 1u : 0u;
   uint32_t off = sizeof(SlabHeader);
   H->off_nodes = off; off += (uint32_t)n * (uint32_t)sizeof(NodeRec);
-  H->off_cells = off; off += a16((uint32_t)cell_cap * k_cell_bytes);
+  H->off_cells = off; off += a16((uint32_t)cell_cap * cell_bytes_for(ph.includes_run_root));
   H->off_trace = off; off += a16((uint32_t)trace_cap * 32u);
   H->heap_begin = off; H->heap_end = off + heap_bytes;
   H->scratch_begin = H->heap_end; H->scratch_end = H->scratch_begin + scratch_bytes;
@@ -855,7 +868,9 @@ void encode_slab(const emat_backend& B, const PartHost& ph, uint8_t* slab, uint3
   double* cb = (double*)(slab + H->off_cells);
   const int nc = (int)ph.coal.k_bar_p.size();
   for (int w = 0; w < nc; ++w) {
-    cb[w] = ph.coal.k_bar_p[w]; cb[cell_cap + w] = ph.coal.k_twiddle_bar_p[w]; cb[2 * cell_cap + w] = ph.coal.k_twiddle_bar[w]; cb[3 * cell_cap + w] = ph.coal.popsize_bar[w];
+    cb[w] = ph.coal.k_bar_p[w]; cb[cell_cap + w] = ph.coal.k_twiddle_bar_p[w];
+    if (!ph.includes_run_root) continue;      // the run-wide arrays live once per device (SharedCells); the root part, which may append cells, keeps its own
+    cb[2 * cell_cap + w] = ph.coal.k_twiddle_bar[w]; cb[3 * cell_cap + w] = ph.coal.popsize_bar[w];
     cb[4 * cell_cap + w] = ph.coal.t_step / ph.coal.popsize_bar[w];   // the factor every cell term starts with, divided once
     ((int32_t*)(cb + 5 * cell_cap))[w] = ph.coal.num_active_parts[w];
   }
@@ -870,7 +885,7 @@ uint32_t heap_content_bytes(const FlatTree& t) {
 }
 
 // Decode the device image of a part back into its host FlatTree + coalescent window + rng + stats.
-void decode_slab(PartHost& ph, const uint8_t* slab) {
+void decode_slab(PartHost& ph, const uint8_t* slab, const double* shared_ktw, const double* shared_popsize, const int32_t* shared_nact) {
   const SlabHeader* H = (const SlabHeader*)slab;
   const NodeRec* N = (const NodeRec*)(slab + H->off_nodes);
   const int n = H->n_nodes;
@@ -896,9 +911,15 @@ void decode_slab(PartHost& ph, const uint8_t* slab) {
   const int nc = H->n_cells, cap = H->cell_cap;
   const double* cb = (const double*)(slab + H->off_cells);
   ph.coal.n_cells_total = H->n_cells_total;
-  ph.coal.k_bar_p.assign(cb, cb + nc); ph.coal.k_twiddle_bar_p.assign(cb + cap, cb + cap + nc); ph.coal.k_twiddle_bar.assign(cb + 2 * cap, cb + 2 * cap + nc);
-  ph.coal.popsize_bar.assign(cb + 3 * cap, cb + 3 * cap + nc);
-  const int32_t* na = (const int32_t*)(cb + 5 * cap); ph.coal.num_active_parts.assign(na, na + nc);
+  ph.coal.k_bar_p.assign(cb, cb + nc); ph.coal.k_twiddle_bar_p.assign(cb + cap, cb + cap + nc);
+  if ((H->flags & k_flag_includes_run_root) != 0) {
+    ph.coal.k_twiddle_bar.assign(cb + 2 * cap, cb + 2 * cap + nc); ph.coal.popsize_bar.assign(cb + 3 * cap, cb + 3 * cap + nc);
+    const int32_t* na = (const int32_t*)(cb + 5 * cap); ph.coal.num_active_parts.assign(na, na + nc);
+  } else if (shared_ktw != nullptr) {   // the window of the device's shared arrays (they do not change while the parts run)
+    const int f = H->cell_first;
+    ph.coal.k_twiddle_bar.assign(shared_ktw + f, shared_ktw + f + nc); ph.coal.popsize_bar.assign(shared_popsize + f, shared_popsize + f + nc);
+    ph.coal.num_active_parts.assign(shared_nact + f, shared_nact + f + nc);
+  }
 }
 
 emat_status fail(emat_backend* h, emat_status st, const std::string& msg) { h->set_error(msg); return st; }
@@ -975,7 +996,7 @@ KernelArgs make_args(emat_backend* h) {
   a.evo.num_sites = h->L; a.evo.num_partitions = h->num_partitions;
   a.evo.ref_sequence = h->d_ref.p; a.evo.partition_for_site = h->d_part.p; a.evo.nu_l = h->d_nu.p; a.evo.cum_Q_l = h->d_cumQ.p;
   a.evo.mu = h->d_mu.p; a.evo.pi = h->d_pi.p; a.evo.q = h->d_q.p;
-  a.pop = h->d_pop.p; a.flags = h->flags; a.num_parts = (int)h->parts.size();
+  a.pop = h->d_pop.p; a.shared = h->shared_dev; a.flags = h->flags; a.num_parts = (int)h->parts.size();
   a.lds_slab_bytes = 0; a.lds_scratch_bytes = 0; a.moves_per_part = 0; a.extra_moves_part0 = 0; a.one_more_below = 0; a.chunks = 1; a.class_count = 0; a.class_stride = 0; a.chunk_done = nullptr; a.snaps = nullptr;
   return a;
 }
@@ -1077,7 +1098,7 @@ emat_status pull_from_device_impl(emat_backend* h) {
     PartHost& ph = h->parts[p];
     const uint8_t* slab = h->h_slabs.data() + ph.slab_off;
     const SlabHeader* H = (const SlabHeader*)slab;
-    decode_slab(ph, slab);
+    decode_slab(ph, slab, h->sh_ktw.empty() ? nullptr : h->sh_ktw.data(), h->sh_popsize.data(), h->sh_nact.data());
     ph.stats.status = H->status; ph.stats.num_nodes = H->n_nodes; ph.stats.moves_done = H->moves_done;
     for (int k = 0; k < 5; ++k) { ph.stats.proposed[k] = H->proposed[k]; ph.stats.accepted[k] = H->accepted[k]; }
     ph.stats.algorithmic_bytes = H->alg_bytes; ph.stats.rng_draws = (int64_t)H->rng_counter; ph.stats.device_ticks = H->device_ticks;
@@ -1123,10 +1144,12 @@ SlabGeo slab_geometry(const emat_backend* h, int n, int num_muts, uint32_t conte
   const uint32_t regions_max = (uint32_t)n + (uint32_t)num_muts;
   g.scratch = a16((uint32_t)(space_boost * std::max<uint32_t>(8192u, 128u * regions_max + 4u * content + 256u * (uint32_t)n)));
   g.cell_cap = includes_run_root ? nc + cell_boost * std::max(512, nc) : nc;   // room for the root part's grid to grow into the past (a part that outgrows it stops with status 103 / 105)
-  g.bytes = (uint32_t)sizeof(SlabHeader) + (uint32_t)n * (uint32_t)sizeof(NodeRec) + a16((uint32_t)g.cell_cap * k_cell_bytes) + a16((uint32_t)trace_cap * 32u) + g.heap + g.scratch;
+  g.bytes = (uint32_t)sizeof(SlabHeader) + (uint32_t)n * (uint32_t)sizeof(NodeRec) + a16((uint32_t)g.cell_cap * cell_bytes_for(includes_run_root)) + a16((uint32_t)trace_cap * 32u) + g.heap + g.scratch;
   return g;
 }
-void place_slab(emat_backend* h, size_t p, const SlabGeo& g, uint64_t& off) {
+void place_slab(emat_backend* h, size_t p, const SlabGeo& g, uint64_t& off, uint32_t content_bytes) {
+  if (h->used_bytes.size() <= p) h->used_bytes.resize(p + 1, 0u);
+  h->used_bytes[p] = g.bytes - g.scratch - g.heap + content_bytes;
   PartHost& ph = h->parts[p];
   ph.slab_off = off; ph.slab_bytes = g.bytes; ph.scratch_bytes = g.scratch; off += g.bytes;
   h->persistent_bytes[p] = g.bytes - g.scratch;
@@ -1195,7 +1218,7 @@ void assign_size_classes(emat_backend* h) {
     if (h->cfg_giants) for (uint32_t k : {8u, 1u}) { const uint32_t a = area_for(k); if (a > main_area && (ladder.empty() || a > ladder.back())) ladder.push_back(a); }
     std::vector<int> rung_of(n, -1); std::vector<int> used(ladder.size(), 0);
     if (!ladder.empty())
-      for (size_t p = 0; p < n; ++p) if (h->prefix_bytes[p] > main_area) {
+      for (size_t p = 0; p < n; ++p) if (h->prefix_bytes[p] > main_area || (h->cfg_side_arena != 0 && p < h->used_bytes.size() && h->used_bytes[p] + k_lds_heap_room + h->cfg_side_arena > main_area)) {
         size_t r = 0; while (r + 1 < ladder.size() && ladder[r] < h->prefix_bytes[p]) ++r;
         rung_of[p] = (int)r; used[r] = 1;
       }
@@ -1217,6 +1240,27 @@ void assign_size_classes(emat_backend* h) {
   }
 }
 
+// The run-wide coalescent cell arrays (SharedCells, emat_slab.hpp) from the host's copies of the parts: every part carries the
+// run's values over its own window, and the windows agree where they overlap.
+emat_status upload_shared_cells(emat_backend* h) {
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  int total = 0;
+  for (const PartHost& ph : h->parts) total = std::max(total, ph.coal.cell_first + (int)ph.coal.k_twiddle_bar.size());
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  h->sh_ktw.assign((size_t)total, nan); h->sh_popsize.assign((size_t)total, nan); h->sh_tsop.assign((size_t)total, nan); h->sh_nact.assign((size_t)total, -1);
+  for (const PartHost& ph : h->parts) {
+    const HostCoalPart& c = ph.coal;
+    for (size_t w = 0; w < c.k_twiddle_bar.size(); ++w) {
+      const size_t i = (size_t)c.cell_first + w;
+      if (ph.includes_run_root && h->sh_nact[i] >= 0) continue;   // (cells the root part appended carry its own values: never over another part's)
+      h->sh_ktw[i] = c.k_twiddle_bar[w]; h->sh_popsize[i] = c.popsize_bar[w]; h->sh_tsop[i] = c.t_step / c.popsize_bar[w]; h->sh_nact[i] = c.num_active_parts[w];
+    }
+  }
+  HIP_TRY(h->d_sh_ktw.upload(h->sh_ktw.data(), h->sh_ktw.size())); HIP_TRY(h->d_sh_tsop.upload(h->sh_tsop.data(), h->sh_tsop.size())); HIP_TRY(h->d_sh_nact.upload(h->sh_nact.data(), h->sh_nact.size()));
+  h->shared_dev = SharedCells{h->d_sh_ktw.p, h->d_sh_tsop.p, h->d_sh_nact.p, total};
+  return EMAT_OK;
+}
+
 // Encode all parts and push them to the device.
 emat_status materialize(emat_backend* h) {
   if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
@@ -1231,7 +1275,7 @@ emat_status materialize(emat_backend* h) {
   for (size_t p = 0; p < h->parts.size(); ++p) {
     PartHost& ph = h->parts[p];
     geo[p] = slab_geometry(h, ph.tree.num_nodes(), ph.tree.num_muts(), heap_content_bytes(ph.tree), (int)ph.coal.k_bar_p.size(), ph.includes_run_root, ph.space_boost, ph.cell_boost);
-    place_slab(h, p, geo[p], off);
+    place_slab(h, p, geo[p], off, heap_content_bytes(ph.tree));
   }
   HIP_TRY(h->h_slabs.resize(off));
   std::vector<uint64_t> offs(h->parts.size());
@@ -1246,6 +1290,7 @@ emat_status materialize(emat_backend* h) {
   });
   assign_size_classes(h);
   h->order_valid = false;
+  { emat_status st = upload_shared_cells(h); if (st) return st; }
   HIP_TRY(h->d_slabs.upload(h->h_slabs.data(), h->h_slabs.size()));
   HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
   { std::vector<int64_t> z(2 * h->parts.size(), 0); HIP_TRY(h->d_part_ticks.upload(z.data(), z.size())); }
@@ -1375,6 +1420,7 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   }
   if (const char* e = getenv("EMAT_LDS_MAX")) h->cfg_lds_max = (uint32_t)atoi(e) & ~511u;
   if (const char* e = getenv("EMAT_GIANTS")) h->cfg_giants = atoi(e) != 0;
+  if (const char* e = getenv("EMAT_SIDE_ARENA")) h->cfg_side_arena = (uint32_t)atoi(e);
   if (const char* e = getenv("EMAT_TREE_HOST_COALESCENT")) h->cfg_gt_host_coal = atoi(e) != 0;
   if (const char* e = getenv("EMAT_CHUNKS")) { h->cfg_chunks = std::max(1, std::min(64, atoi(e))); h->cfg_chunks_forced = true; }
   if (const char* e = getenv("EMAT_PARTS_PER_CU")) h->cfg_parts_per_cu = std::max(0, std::min(4 * EMAT_WAVES_PER_EU, atoi(e)));
@@ -1692,7 +1738,7 @@ emat_status emat_debug_slab_layout(emat_backend* h, int32_t part_id, uint32_t* o
   const int trace_cap = h->cfg.trace_moves > 0 ? h->cfg.trace_moves : 0;
   const uint32_t content = heap_content_bytes(ph.tree);
   const SlabGeo g = slab_geometry(h, ph.tree.num_nodes(), ph.tree.num_muts(), content, (int)ph.coal.k_bar_p.size(), ph.includes_run_root, ph.space_boost, ph.cell_boost);
-  out8[0] = (uint32_t)sizeof(SlabHeader); out8[1] = (uint32_t)ph.tree.num_nodes() * (uint32_t)sizeof(NodeRec); out8[2] = a16((uint32_t)g.cell_cap * k_cell_bytes);
+  out8[0] = (uint32_t)sizeof(SlabHeader); out8[1] = (uint32_t)ph.tree.num_nodes() * (uint32_t)sizeof(NodeRec); out8[2] = a16((uint32_t)g.cell_cap * cell_bytes_for(ph.includes_run_root));
   out8[3] = a16((uint32_t)trace_cap * 32u); out8[4] = content; out8[5] = g.heap; out8[6] = g.scratch; out8[7] = (uint32_t)g.cell_cap;
   return EMAT_OK;
 }

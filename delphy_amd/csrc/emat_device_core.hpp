@@ -36,7 +36,7 @@ namespace emat {
 // every variable-index store may alias everything.
 extern __shared__ __attribute__((aligned(16))) uint8_t emat_lds[];
 constexpr uint32_t k_lds_tables_bytes = k_max_lds_partitions * (1 + 4 + 16) * 8;   // mu, pi, q per site partition
-constexpr uint32_t k_lds_ctx_bytes = 256;
+constexpr uint32_t k_lds_ctx_bytes = 288;
 constexpr uint32_t k_lds_static_bytes = k_lds_tables_bytes + k_lds_ctx_bytes;      // what every k_run_moves workgroup holds besides the slab image and the arena
 __shared__ __attribute__((aligned(16))) uint8_t emat_lds_tables[k_lds_tables_bytes];
 __shared__ __attribute__((aligned(16))) uint8_t emat_lds_ctx[k_lds_ctx_bytes];
@@ -59,6 +59,17 @@ namespace EMAT_DEV_NS {
 constexpr double k_neg_dbl_max = -1.7976931348623157e308;
 constexpr double k_inf = __builtin_huge_val();
 constexpr int k_no_node = -1;
+
+#ifndef EMAT_CONST_AS
+#define EMAT_CONST_AS __attribute__((address_space(4)))
+#endif
+// A pointer every active lane agrees on, retyped to the constant address space: loads through it are scalar loads (s_load, the
+// scalar cache) instead of vector loads.
+template <class T> EMAT_DF const EMAT_CONST_AS T* uniform_const_ptr(const T* p) {
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return (const EMAT_CONST_AS T*)(((uint64_t)hi << 32) | lo);
+}
 
 // ---- per-wave context ----------------------------------------------------------------------------
 struct Ctx {
@@ -103,6 +114,8 @@ struct Ctx {
   double tr_kind, tr_node, tr_acc, tr_log_mh;
   int64_t moves_left;         // moves of the current launch still to do (run_chain_loop keeps nothing in registers across a move)
   uint64_t mv_rng_ctr;
+  // the run-wide cell arrays (SharedCells, emat_slab.hpp): absolute cell index; the root part has its own copies in its slab
+  const double* sh_ktw; const double* sh_tsop; const int32_t* sh_nact;
 };
 
 static_assert(sizeof(Ctx) + 16 <= k_lds_ctx_bytes, "context outgrew its LDS slot (the last 16 bytes are the kernel's flag word)");
@@ -614,12 +627,6 @@ EMAT_DF double pop_at_time(const PopTable& p, double t) {
 // at C4, section 8 of DESIGN.md).  Only one lane is active here, so the time and every address are uniform by construction;
 // saying so (readfirstlane) and reading through the constant address space turns the chain into s_load from the scalar
 // cache.  (Same operations in the same order as skygrid_log_N / pop_at_time.)
-#define EMAT_CONST_AS __attribute__((address_space(4)))
-template <class T> EMAT_DF const EMAT_CONST_AS T* uniform_const_ptr(const T* p) {
-  const uint64_t a = (uint64_t)p;
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-  return (const EMAT_CONST_AS T*)(((uint64_t)hi << 32) | lo);
-}
 EMAT_DF double uniform_f64(double v) {
   const uint64_t a = __builtin_bit_cast(uint64_t, v);
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
@@ -699,11 +706,18 @@ EMAT_NOTAIL EMAT_DN double pop_integral(const PopTable& p, double a, double b) {
 // identically zero for the whole residency, so those cells contribute nothing (cpp:355-386).  The window starts at the
 // cell of the part's latest node time in full precision or at the reference's first_cell, whichever comes first
 // (emat_host_model.hpp, CoalBuilder::local_grid).
-struct Cells { double* kbar_p; double* ktw_p; double* ktw; double* popsize; double* ts_over_pop; int32_t* nactive; };
+struct Cells {
+  double* kbar_p; double* ktw_p;                                            // the part's own arrays, window index
+  double* ktw; double* popsize; double* ts_over_pop; int32_t* nactive;      // root part only: its own copies, window index
+  const EMAT_CONST_AS double* sh_ktw; const EMAT_CONST_AS double* sh_tsop; const EMAT_CONST_AS int32_t* sh_nact;   // every other part: the device's table, absolute index
+  int first; bool local;
+};
 EMAT_D Cells cells_of(Ctx& c) {
-  Cells k; int cap = hdr_of(c)->cell_cap;
+  Cells k; const int cap = hdr_of(c)->cell_cap;
   double* base = (double*)slab_at(c, hdr_of(c)->off_cells);
-  k.kbar_p = base; k.ktw_p = base + cap; k.ktw = base + 2 * cap; k.popsize = base + 3 * cap; k.ts_over_pop = base + 4 * cap; k.nactive = (int32_t*)(base + 5 * cap);
+  k.kbar_p = base; k.ktw_p = base + cap; k.first = hdr_of(c)->cell_first; k.local = c.includes_run_root;
+  if (k.local) { k.ktw = base + 2 * cap; k.popsize = base + 3 * cap; k.ts_over_pop = base + 4 * cap; k.nactive = (int32_t*)(base + 5 * cap); k.sh_ktw = nullptr; k.sh_tsop = nullptr; k.sh_nact = nullptr; }
+  else { k.ktw = nullptr; k.popsize = nullptr; k.ts_over_pop = nullptr; k.nactive = nullptr; k.sh_ktw = uniform_const_ptr(c.sh_ktw); k.sh_tsop = uniform_const_ptr(c.sh_tsop); k.sh_nact = uniform_const_ptr(c.sh_nact); }
   return k;
 }
 EMAT_D int cell_for(const Ctx& c, double t) { return (int)floor((hdr_of(c)->t_ref - t) / hdr_of(c)->t_step); }
@@ -769,10 +783,12 @@ EMAT_DF void coal_add_interval(Ctx& c, double t_start, double t_end, double delt
   c.bytes += 8 * (int64_t)(cell_end - cell_start + 1);
 }
 EMAT_DF double coal_cell_term(const Ctx& c, const Cells& k, int w, double new_k, double old_k) {
-  double na = (double)k.nactive[w];
-  return k.ts_over_pop[w] * (   // == t_step / popsize_bar[w], the same double, divided when the cell was made
+  double na, tsop, ktw;   // num_active_parts, t_step / popsize_bar (the same double, divided when the cell was made), k_twiddle_bar
+  if (k.local) { na = (double)k.nactive[w]; tsop = k.ts_over_pop[w]; ktw = k.ktw[w]; }
+  else { const int i = __builtin_amdgcn_readfirstlane(k.first + w); na = (double)k.sh_nact[i]; tsop = k.sh_tsop[i]; ktw = k.sh_ktw[i]; }
+  return tsop * (
       +0.5 * (new_k * new_k - old_k * old_k) * na
-      - (k.ktw_p[w] * na - k.ktw[w] + 0.5) * (new_k - old_k));
+      - (k.ktw_p[w] * na - ktw + 0.5) * (new_k - old_k));
 }
 // cpp:388-459
 template <bool kGrow = true> EMAT_DF double coal_delta_on_add_interval(Ctx& c, double min_t, double max_t, double delta_k) { EMAT_TIMED(0);

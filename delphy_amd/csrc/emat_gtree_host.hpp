@@ -395,15 +395,15 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
       }
     }
     HIP_TRY(G.co_kbar.alloc(pool)); HIP_TRY(G.co_ktw.alloc(pool));
-    HIP_TRY(G.co_k_bar.alloc(co.num_cells)); HIP_TRY(G.co_k_tw.alloc(co.num_cells)); HIP_TRY(G.co_popsize.alloc(co.num_cells)); HIP_TRY(G.co_num_active.alloc(co.num_cells));
-    co.kbar_pool = G.co_kbar.p; co.ktw_pool = G.co_ktw.p; co.k_bar = G.co_k_bar.p; co.k_tw = G.co_k_tw.p; co.popsize = G.co_popsize.p; co.num_active = G.co_num_active.p;
+    HIP_TRY(G.co_k_bar.alloc(co.num_cells)); HIP_TRY(G.co_k_tw.alloc(co.num_cells)); HIP_TRY(G.co_popsize.alloc(co.num_cells)); HIP_TRY(G.co_num_active.alloc(co.num_cells)); HIP_TRY(G.co_tsop.alloc(co.num_cells));
+    co.kbar_pool = G.co_kbar.p; co.ktw_pool = G.co_ktw.p; co.k_bar = G.co_k_bar.p; co.k_tw = G.co_k_tw.p; co.popsize = G.co_popsize.p; co.num_active = G.co_num_active.p; co.ts_over_pop = G.co_tsop.p;
     co.status = G.status.p;
   }
   for (int p = lo; p < hi; ++p) {
     PartHost& ph = h->parts[p - lo];
     const int nc = device_coal ? num_cells_of[p] : (int)ph.coal.k_bar_p.size();
     const SlabGeo g = slab_geometry(h, me[p].n_nodes, me[p].num_muts, me[p].content_bytes, nc, ph.includes_run_root, ph.space_boost);
-    place_slab(h, (size_t)(p - lo), g, off);
+    place_slab(h, (size_t)(p - lo), g, off, me[p].content_bytes);
     offs[p - lo] = ph.slab_off;
     GPartDesc d = desc[p];
     d.slab_bytes = g.bytes; d.heap_bytes = g.heap; d.scratch_bytes = g.scratch; d.cell_cap = g.cell_cap; d.trace_cap = trace_cap;
@@ -449,7 +449,13 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(&cst, G.status.p, sizeof(cst), hipMemcpyDeviceToHost));
     if (cst != k_gt_ok) { h->slabs_on_device = false; h->parts.clear(); return fail(h, EMAT_ERR_INVALID_ARGUMENT, "coalescent grid: a lineage outside its part's cells, or an inactive final cell"); }
-  }
+    // the run-wide cell arrays ARE the grid the kernels just built: the moves read them in place; a few KB of host mirror for the getters
+    const size_t nc = (size_t)co.num_cells;
+    h->sh_ktw.resize(nc); h->sh_popsize.resize(nc); h->sh_tsop.resize(nc); h->sh_nact.resize(nc);
+    HIP_TRY(hipMemcpy(h->sh_ktw.data(), G.co_k_tw.p, nc * 8, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(h->sh_popsize.data(), G.co_popsize.p, nc * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h->sh_tsop.data(), G.co_tsop.p, nc * 8, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(h->sh_nact.data(), G.co_num_active.p, nc * 4, hipMemcpyDeviceToHost));
+    h->shared_dev = SharedCells{G.co_k_tw.p, G.co_tsop.p, G.co_num_active.p, co.num_cells};
+  } else { emat_status st2 = upload_shared_cells(h); if (st2) return st2; }
   h->slabs_on_device = true; h->host_slabs_current = false; h->headers_current = false; h->derived_valid = false;
   G.parts_live = true;
   if (verbose) {

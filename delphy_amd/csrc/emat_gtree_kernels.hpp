@@ -63,6 +63,7 @@ struct GCoal {                       // the whole grid, built on the device (nul
   int32_t num_cells; double t_ref, t_step;
   double* kbar_pool; double* ktw_pool;   // every part's window [cell_first, n_cells_total), back to back (GPartDesc::cells_off)
   double* k_bar; double* k_tw; double* popsize; int32_t* num_active;   // [num_cells]
+  double* ts_over_pop;                 // [num_cells] t_step / popsize: with k_tw and num_active the SharedCells the moves read
   int32_t* status;
 };
 
@@ -243,7 +244,8 @@ __global__ void __launch_bounds__(k_wave) k_gt_build(GTreeDev g, GPartition pt, 
   SlabHeader* H = (SlabHeader*)slab;
   uint32_t off = (uint32_t)sizeof(SlabHeader);
   const uint32_t off_nodes = off; off += (uint32_t)n * (uint32_t)sizeof(NodeRec);
-  const uint32_t off_cells = off; off += gt_a16((uint32_t)d.cell_cap * k_cell_bytes);
+  const bool root_part = (d.flags & k_flag_includes_run_root) != 0;
+  const uint32_t off_cells = off; off += gt_a16((uint32_t)d.cell_cap * (root_part ? k_cell_bytes_root : k_cell_bytes_own));
   const uint32_t off_trace = off; off += gt_a16((uint32_t)d.trace_cap * 32u);
   const uint32_t heap_begin = off;
   NodeRec* N = (NodeRec*)(slab + off_nodes);
@@ -289,8 +291,10 @@ __global__ void __launch_bounds__(k_wave) k_gt_build(GTreeDev g, GPartition pt, 
     const double* kb = co.kbar_pool + d.cells_off; const double* kt = co.ktw_pool + d.cells_off;
     for (int w = lane; w < nc; w += k_wave) {
       const int c = d.cell_first + w;
+      cb[w] = kb[w]; cb[cap + w] = kt[w];
+      if (!root_part) continue;          // the run-wide arrays are read from the grid itself (SharedCells); the root part keeps its own copies
       const double pb = co.popsize[c];
-      cb[w] = kb[w]; cb[cap + w] = kt[w]; cb[2 * cap + w] = co.k_tw[c]; cb[3 * cap + w] = pb;
+      cb[2 * cap + w] = co.k_tw[c]; cb[3 * cap + w] = pb;
       cb[4 * cap + w] = d.t_step / pb;
       ((int32_t*)(cb + 5 * cap))[w] = co.num_active[c];
     }
@@ -300,8 +304,10 @@ __global__ void __launch_bounds__(k_wave) k_gt_build(GTreeDev g, GPartition pt, 
     const int nc = d.n_cells, cap = d.cell_cap;
     const int32_t* na = (const int32_t*)(src + 4 * (size_t)nc);
     for (int w = lane; w < nc; w += k_wave) {
+      cb[w] = src[w]; cb[cap + w] = src[(size_t)nc + w];
+      if (!root_part) continue;
       const double pb = src[3 * (size_t)nc + w];
-      cb[w] = src[w]; cb[cap + w] = src[(size_t)nc + w]; cb[2 * cap + w] = src[2 * (size_t)nc + w]; cb[3 * cap + w] = pb;
+      cb[2 * cap + w] = src[2 * (size_t)nc + w]; cb[3 * cap + w] = pb;
       cb[4 * cap + w] = d.t_step / pb;
       ((int32_t*)(cb + 5 * cap))[w] = na[w];
     }
@@ -373,6 +379,7 @@ __global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY k_gt_coal_grid(int num_
   if (lane != 0) return;
   co.k_bar[c] = k; co.num_active[c] = (int32_t)active;
   co.popsize[c] = dev::pop_integral(*pop, gt_cell_lbound(c, co.t_ref, co.t_step), gt_cell_ubound(c, co.t_ref, co.t_step)) / co.t_step;
+  co.ts_over_pop[c] = co.t_step / co.popsize[c];
   if (c == co.num_cells - 1 && active == 0) atomicMax(co.status, (int32_t)k_gt_inconsistent);
 }
 // k_gt_coal_draw: every part draws k_twiddle_bar_p over its active cells from its own stream.  A Gaussian takes one whole

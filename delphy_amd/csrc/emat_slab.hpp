@@ -8,7 +8,7 @@
 // A slab is ONE relocatable byte blob per part (all internal references are byte offsets), so that a
 // workgroup can stream it into LDS with one coalesced copy, run its chain there, and stream it back:
 //
-//   [SlabHeader 256 B][NodeRec x n_nodes (64 B each)][cell table (5 arrays x cell_cap)]
+//   [SlabHeader 256 B][NodeRec x n_nodes (64 B each)][cell table (2 arrays x cell_cap; the root part: 6 arrays)]
 //   [trace ring][list heap: 16-B mutation / 8-B interval / 8-B from-state records][scratch]
 //
 // Plain C++ (no HIP types) because the host encoder and the kernels share it.
@@ -81,7 +81,7 @@ struct SlabHeader {
   double log_aug_prior;
   // regions (byte offsets from slab base)
   uint32_t off_nodes;
-  uint32_t off_cells;          // 4 double arrays [cell_cap] then 1 int32 array [cell_cap]
+  uint32_t off_cells;          // the part's own two double arrays [cell_cap] (k_bar_p, k_twiddle_bar_p); the root part: 5 double arrays then 1 int32 array
   uint32_t off_trace;
   uint32_t heap_begin, heap_top, heap_end;
   uint32_t scratch_begin, scratch_end;
@@ -129,9 +129,23 @@ struct EvoTable {               // reference Global_evo_model (core/evo_model.h:
   const double* pi;                   // [P][4]
   const double* q;                    // [P][4][4]
 };
-// coalescent cell table of a part: 5 double arrays (k_bar_p, k_twiddle_bar_p, k_twiddle_bar, popsize_bar, t_step / popsize_bar)
-// + 1 int32 array (num_active_parts), each `cell_cap` long
-constexpr uint32_t k_cell_bytes = 5 * 8 + 4;
+// Coalescent cell table of a part.  Of the six vectors of the reference's Very_scalable_coalescent_prior_part
+// (very_scalable_coalescent.h:47-56) only two are the part's own -- k_bar_p, which its moves update, and k_twiddle_bar_p; the
+// others (k_twiddle_bar, popsize_bar, num_active_parts, and t_step / popsize_bar kept beside them) are the same for every
+// part of the run -- the reference shares them through pointers too -- and live ONCE per device (SharedCells), indexed by
+// absolute cell and read through the scalar cache: a slab carries 16 bytes per cell instead of 44, which is what lets the
+// parts with the longest time spans (60-120 cells: the slowest chains of a pass) keep an LDS arena for their topology moves.
+// The part that holds the run's root is the exception: it may APPEND cells while it runs (ensure_space, cpp:259-299), with
+// values only it knows, so it keeps all six arrays in its own slab, `cell_cap` long each.
+constexpr uint32_t k_cell_bytes_own = 2 * 8;
+constexpr uint32_t k_cell_bytes_root = 5 * 8 + 4;
+inline uint32_t cell_bytes_for(bool includes_run_root) { return includes_run_root ? k_cell_bytes_root : k_cell_bytes_own; }
+struct SharedCells {            // one per device; [num_cells] each, absolute cell index
+  const double* k_twiddle_bar;
+  const double* ts_over_pop;    // t_step / popsize_bar, divided once when the grid is built
+  const int32_t* num_active_parts;
+  int32_t num_cells;
+};
 constexpr int k_max_lds_partitions = 2;   // HKY tables of up to this many site partitions are staged in LDS
 
 struct PopTable {               // reference Pop_model family (core/pop_model.h)
