@@ -12,7 +12,8 @@
 // and a branch's segments in time order, so a node's position is again a prefix sum down the tree (1 + the size of the sibling
 // subtree that is visited before it), computed by the same pointer jumping; the tying regions are then laid out in that order
 // by a block-wide scan, and ONE thread adds their lengths in order, draws, and makes the graft (three nodes change).
-// One workgroup of 1024 threads runs the whole loop without returning to the host (no launch per tip, no grid-wide barrier).
+// One launch runs the whole loop without returning to the host: up to one workgroup of 1 024 threads per CU, all resident,
+// meeting at a barrier of their own between the phases of a tip (a counter in HBM that only grows; about twenty meetings per tip).
 //
 // The O(nodes) passes after the loop -- fix_up_missations (phylo_tree.cpp:414-507), pseudo_date (dates.cpp:63-82),
 // randomize_mutation_times (phylo_tree.cpp:567-644) -- are host C++ below: they run once, like the partitioning the reference
@@ -41,7 +42,10 @@ struct BuildDev {
   // the grafting thread's own buffers
   int32_t* path; BDelta* sd; uint32_t sd_cap;
   uint64_t* rng;      // [4] key, counter, spare, has_spare
-  int32_t* status;    // [2] 0 = ok | 1 mutation pool full | 2 delta buffer full | 3 tie list full | 4 inconsistent input; [1] = tip at which it happened
+  int32_t* status;    // [2] 0 = ok | 1 mutation pool full | 2 delta buffer full | 3 tie list full | 4 inconsistent input | 5 a workgroup never arrived; [1] = tip at which it happened
+  // what the workgroups of the launch share besides the tree: the meeting counter, the running minimum, one word per pointer-jumping
+  // round, every workgroup's share of the tying regions, and the grafting thread's verdict on the tip
+  unsigned long long* grid_counter; int32_t* gmin; int32_t* pj_flag; int32_t* blk_sum; int32_t* stop_flag;
 };
 
 struct BRng {   // the engine's stream (emat_device_core.hpp rng_next64 and friends), for the one thread that draws
@@ -92,22 +96,51 @@ __device__ inline bool b_push_front(BDelta* sd, int& n, uint32_t cap, int site, 
 
 constexpr int k_build_threads = 1024;
 
+// All workgroups of the launch meet here (they are all resident: at most one per CU is launched): a counter that only grows --
+// after the k-th meeting it stands at k x workgroups -- so nothing is ever reset.  The wait is bounded: a workgroup that never
+// arrives (it cannot, short of a fault) makes the others give up and say so instead of hanging the device.
+struct BGrid {
+  unsigned long long* counter; int32_t* status; unsigned long long blocks, meetings;
+  __device__ bool sync() {
+    __syncthreads();
+    ++meetings;
+    if (blocks > 1) {
+      __shared__ int s_ok;
+      if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(counter, 1ull);
+        const unsigned long long target = meetings * blocks;
+        int spins = 0;
+        while (atomicAdd(counter, 0ull) < target && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(1); ++spins; }
+        s_ok = spins < (1 << 22) ? 1 : 0;
+        if (!s_ok) status[0] = 5;
+      }
+      __syncthreads();
+      __threadfence();          // what the other workgroups wrote before they arrived is visible from here on (L1 invalidated)
+      return s_ok != 0;
+    }
+    return true;
+  }
+};
+
 // Tips [first_tip, last_tip) are grafted onto the tree that holds tips 0 .. first_tip - 1 (the host sets up the first two).
 __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev b, int first_tip, int last_tip) {
   const int tid = threadIdx.x, NT = k_build_threads, n = b.n_tips;
-  __shared__ int s_min, s_carry, s_total, s_stop;
+  const int nb = (int)gridDim.x, blk = (int)blockIdx.x, gtid = blk * NT + tid, GT = nb * NT;
+  __shared__ int s_carry, s_base, s_stop;
   __shared__ int s_scan[2][k_build_threads];
-  BRng rng; rng.key = b.rng[0]; rng.ctr = b.rng[1]; rng.spare = b.rng[2]; rng.has_spare = b.rng[3] != 0;   // (thread 0's copy is the one that counts)
-  if (tid == 0) s_stop = 0;
-  __syncthreads();
+  BGrid grid{b.grid_counter, b.status, (unsigned long long)nb, 0ull};
+  BRng rng; rng.key = b.rng[0]; rng.ctr = b.rng[1]; rng.spare = b.rng[2]; rng.has_spare = b.rng[3] != 0;   // (the grafting thread's copy is the one that counts)
+  const bool grafter = blk == 0 && tid == 0;
   for (int X = first_tip; X < last_tip; ++X) {
     const int nl = 2 * X - 1;                                      // nodes linked so far: tips 0 .. X-1 and inner nodes n .. n + X - 2
     auto node_of = [&](int i) { return i < X ? i : n + (i - X); };
     const int dx0 = b.d_off[X], dxn = b.d_off[X + 1] - dx0, mx0 = b.m_off[X], mxn = b.m_off[X + 1] - mx0;
     const double t_X = b.t[X];
     const int root = *b.root;
+    if (grafter) *b.gmin = 0x7fffffff;
     // (1) per branch: how the distance to X changes across it; the increments of the two prefix sums down the tree
-    for (int i = tid; i < nl; i += NT) {
+    for (int i = gtid; i < nl; i += GT) {
       const int v = node_of(i);
       const MutRec* m = b.pool + b.ml_off[v]; const int nm = b.ml_cnt[v];
       int d = 0;
@@ -118,12 +151,13 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
       b.vP[0][v] = v == root ? 0 : 1 + (b.c0[par] == v ? b.sz[b.c1[par]] : 0);   // the second child's subtree is visited first
       b.anc[0][v] = par;
     }
-    __syncthreads();
-    // (2) both prefix sums by pointer jumping: after round r a node holds the sum over its 2^r nearest ancestors-or-self
+    if (!grid.sync()) return;
+    // (2) both prefix sums by pointer jumping: after round r a node holds the sum over its 2^r nearest ancestors-or-self.
+    // "Somebody still had an ancestor to jump to" is a per-round word stamped with the tip's number (tips only go up: no reset).
     int cur = 0;
-    for (;;) {
+    for (int round = 0; round < 40; ++round) {
       int any = 0;
-      for (int i = tid; i < nl; i += NT) {
+      for (int i = gtid; i < nl; i += GT) {
         const int v = node_of(i), a = b.anc[cur][v];
         if (a != EMAT_NO_NODE) {
           b.vD[cur ^ 1][v] = b.vD[cur][v] + b.vD[cur][a]; b.vP[cur ^ 1][v] = b.vP[cur][v] + b.vP[cur][a]; b.anc[cur ^ 1][v] = b.anc[cur][a];
@@ -131,16 +165,16 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
         } else { b.vD[cur ^ 1][v] = b.vD[cur][v]; b.vP[cur ^ 1][v] = b.vP[cur][v]; b.anc[cur ^ 1][v] = EMAT_NO_NODE; }
       }
       cur ^= 1;
-      if (!__syncthreads_or(any)) break;
+      if (__syncthreads_or(any) && tid == 0) atomicMax(&b.pj_flag[round], X);
+      if (!grid.sync()) return;
+      if (__hip_atomic_load(&b.pj_flag[round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != X) break;
     }
     const int32_t* Dend = b.vD[cur]; const int32_t* pre = b.vP[cur];
     // (3) the fewest mutations any region offers.  A region of branch v is the stretch before its k-th mutation (k = 0 .. nm);
     // regions in X's future do not count, the one that straddles t_X ends there (spr_study.cpp:211-224)
-    if (tid == 0) s_min = 0x7fffffff;
-    __syncthreads();
     {
       int local = 0x7fffffff;
-      for (int i = tid; i < nl; i += NT) {
+      for (int i = gtid; i < nl; i += GT) {
         const int v = node_of(i);
         if (v == root) { if (dxn < local) local = dxn; continue; }   // the region above the root is always there
         const MutRec* m = b.pool + b.ml_off[v]; const int nm = b.ml_cnt[v];
@@ -151,15 +185,15 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
           if (k < nm) { D += b_step(b, dx0, dxn, mx0, mxn, m[k]); tmin = m[k].t; }
         }
       }
-      atomicMin(&s_min, local);
+      for (int ofs = 32; ofs > 0; ofs >>= 1) { const int o = __shfl_down(local, ofs, 64); if (o < local) local = o; }
+      if ((tid & 63) == 0 && local != 0x7fffffff) atomicMin(b.gmin, local);
     }
-    __syncthreads();
-    const int all_min = s_min;
+    if (!grid.sync()) return;
+    const int all_min = __hip_atomic_load(b.gmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool above_root = dxn == all_min;                          // "always pick above the root if that's a possibility" (:938-942)
-    int n_tie = 0;
     if (!above_root) {
       // (4) the tying regions in visiting order: count per node, exclusive scan over the visiting positions, write
-      for (int i = tid; i < nl; i += NT) {
+      for (int i = gtid; i < nl; i += GT) {
         const int v = node_of(i);
         int c = 0;
         if (v != root) {
@@ -173,11 +207,14 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
         }
         b.cnt[pre[v]] = c; b.inv[pre[v]] = v;
       }
+      if (!grid.sync()) return;
+      // every workgroup scans its own stretch of the visiting positions, NT at a time, and publishes its total
+      const int chunk = ((nl + nb - 1) / nb + NT - 1) / NT * NT, p_lo = blk * chunk, p_hi = p_lo + chunk < nl ? p_lo + chunk : nl;
       if (tid == 0) s_carry = 0;
       __syncthreads();
-      for (int base = 0; base < nl; base += NT) {                   // block-wide exclusive scan, NT positions at a time
+      for (int base = p_lo; base < p_hi; base += NT) {
         const int p = base + tid;
-        const int mine = p < nl ? b.cnt[p] : 0;
+        const int mine = p < p_hi ? b.cnt[p] : 0;
         int src = 0;
         s_scan[0][tid] = mine;
         __syncthreads();
@@ -186,36 +223,39 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
           src ^= 1;
           __syncthreads();
         }
-        if (p < nl) b.off[p] = s_carry + s_scan[src][tid] - mine;
+        if (p < p_hi) b.off[p] = s_carry + s_scan[src][tid] - mine;
         __syncthreads();
         if (tid == NT - 1) s_carry += s_scan[src][NT - 1];
         __syncthreads();
       }
-      if (tid == 0) { s_total = s_carry; if ((uint32_t)s_carry > b.tie_cap) { b.status[0] = 3; b.status[1] = X; s_stop = 1; } }
+      if (tid == 0) b.blk_sum[blk] = s_carry;
+      if (!grid.sync()) return;
+      if (tid == 0) { int base = 0; for (int q = 0; q < blk; ++q) base += b.blk_sum[q]; s_base = base; }
       __syncthreads();
-      if (s_stop) return;
-      n_tie = s_total;
-      for (int p = tid; p < nl; p += NT) {
+      for (int p = p_lo + tid; p < p_hi; p += NT) {
         if (b.cnt[p] == 0) continue;
         const int v = b.inv[p];
         const MutRec* m = b.pool + b.ml_off[v]; const int nm = b.ml_cnt[v];
-        int D = Dend[v] - b.delta[v], o = b.off[p];
+        int D = Dend[v] - b.delta[v], o = s_base + b.off[p];
         double tmin = b.t[b.parent[v]];
         for (int k = 0; k <= nm; ++k) {
           const double tmax = k < nm ? m[k].t : b.t[v];
-          if (!(tmin >= t_X) && D == all_min) { b.tie_node[o] = v; b.tie_tmin[o] = tmin; b.tie_tmax[o] = tmax > t_X ? t_X : tmax; ++o; }
+          if (!(tmin >= t_X) && D == all_min) { if ((uint32_t)o < b.tie_cap) { b.tie_node[o] = v; b.tie_tmin[o] = tmin; b.tie_tmax[o] = tmax > t_X ? t_X : tmax; } ++o; }
           if (k < nm) { D += b_step(b, dx0, dxn, mx0, mxn, m[k]); tmin = m[k].t; }
         }
       }
-      __syncthreads();
+      if (!grid.sync()) return;
     }
     // (5) one thread picks the region and makes the graft (:925-1030)
-    if (tid == 0) {
+    if (grafter) {
       const int P = X + n - 1;
-      int S; double t_P; int nsd = 0; bool bad = false, full = false;
+      int S = root; double t_P = 0.0; int nsd = 0; bool bad = false, full = false, stop = false;
+      int n_tie = 0;
+      if (!above_root) { for (int q = 0; q < nb; ++q) n_tie += b.blk_sum[q]; if ((uint32_t)n_tie > b.tie_cap) { b.status[0] = 3; b.status[1] = X; stop = true; } }
       for (int k = 0; k < dxn; ++k) { b.sd[k].site = b.d_site[dx0 + k]; b.sd[k].from = b.ref[b.d_site[dx0 + k]]; b.sd[k].to = b.d_to[dx0 + k]; b.sd[k].pad = 0; }   // deltas root -> X
       nsd = dxn;
-      if (above_root) {
+      if (stop) {}
+      else if (above_root) {
         S = root;
         const double t_P_guess = t_X - (double)nsd * 13.0, t_S = b.t[S];
         t_P = (t_P_guess < t_S ? t_P_guess : t_S) - 1.0;
@@ -227,7 +267,7 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
         const double insertion_cum_t = rng.uniform_co(0.0, tot_min_T);
         double so_far_min_T = 0.0; int chosen = -1;
         for (int i = 0; i < n_tie; ++i) { so_far_min_T += b.tie_tmax[i] - b.tie_tmin[i]; if (insertion_cum_t <= so_far_min_T) { chosen = i; break; } }
-        if (chosen < 0) { b.status[0] = 4; b.status[1] = X; s_stop = 1; }
+        if (chosen < 0) { b.status[0] = 4; b.status[1] = X; stop = true; }
         else {
           S = b.tie_node[chosen];
           t_P = rng.uniform_oo(b.tie_tmin[chosen], b.tie_tmax[chosen]);
@@ -247,17 +287,17 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
           b.ml_off[P] = b.ml_off[S]; b.ml_cnt[P] = split; b.ml_off[S] += (uint32_t)split; b.ml_cnt[S] -= split;
         }
       }
-      if (!s_stop) {
-        if (full) { b.status[0] = 2; b.status[1] = X; s_stop = 1; }
-        else if (bad) { b.status[0] = 4; b.status[1] = X; s_stop = 1; }
+      if (!stop) {
+        if (full) { b.status[0] = 2; b.status[1] = X; stop = true; }
+        else if (bad) { b.status[0] = 4; b.status[1] = X; stop = true; }
       }
-      if (!s_stop) {
+      if (!stop) {
         b.t[P] = t_P; b.c0[P] = X; b.c1[P] = S; b.parent[X] = P; b.parent[S] = P;
         b.sz[X] = 1; b.sz[P] = b.sz[S] + 2;
         for (int a = b.parent[P]; a != EMAT_NO_NODE; a = b.parent[a]) b.sz[a] += 2;
         // the mutations X needs, at random times on P-X, sorted by (t, site) (:1015-1021)
         const uint32_t o = *b.pool_top;
-        if (o + (uint32_t)nsd > b.pool_cap) { b.status[0] = 1; b.status[1] = X; s_stop = 1; }
+        if (o + (uint32_t)nsd > b.pool_cap) { b.status[0] = 1; b.status[1] = X; stop = true; }
         else {
           MutRec* mx = b.pool + o;
           for (int k = 0; k < nsd; ++k) {
@@ -269,11 +309,14 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
           b.ml_off[X] = o; b.ml_cnt[X] = nsd; *b.pool_top = o + (uint32_t)nsd;
         }
       }
+      *b.stop_flag = stop ? X : 0;
     }
+    if (!grid.sync()) return;
+    if (tid == 0) s_stop = __hip_atomic_load(b.stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (s_stop) break;
+    if (s_stop != 0) break;
   }
-  if (tid == 0) { b.rng[1] = rng.ctr; b.rng[2] = rng.spare; b.rng[3] = rng.has_spare ? 1u : 0u; }
+  if (grafter) { b.rng[1] = rng.ctr; b.rng[2] = rng.spare; b.rng[3] = rng.has_spare ? 1u : 0u; }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------

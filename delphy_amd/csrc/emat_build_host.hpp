@@ -11,6 +11,7 @@ const char* build_status_text(int32_t s) {
     case 2: return "site-delta buffer full";
     case 3: return "more tying regions than the list holds";
     case 4: return "inconsistent mutation chain (tip descriptors against the reference sequence)";
+    case 5: return "a workgroup of the builder never reached a barrier";
     default: return "unknown";
   }
 }
@@ -89,13 +90,19 @@ emat_status build_usher_like(emat_backend* h, const emat_tip_descs& td, uint64_t
     for (DevBuf<int32_t>* w : {&d_delta, &d_vD0, &d_vD1, &d_vP0, &d_vP1, &d_a0, &d_a1, &d_inv, &d_cnt, &d_off, &d_path}) HIP_TRY(w->alloc((size_t)N + 1));
     HIP_TRY(d_tnode.alloc(tie_cap)); HIP_TRY(d_tmin.alloc(tie_cap)); HIP_TRY(d_tmax.alloc(tie_cap)); HIP_TRY(d_sd.alloc(sd_cap));
     HIP_TRY(d_rng.upload(rng0, 4)); HIP_TRY(d_status.upload(status0, 2));
+    // one workgroup per 1 024 nodes of the finished tree, at most one per CU (all of them must be resident: they meet at barriers)
+    int blocks = std::max(1, std::min(h->num_cus > 0 ? h->num_cus : 1, (N + k_build_threads - 1) / k_build_threads));
+    if (const char* e = getenv("EMAT_BUILD_BLOCKS")) blocks = std::max(1, std::min(atoi(e), h->num_cus > 0 ? h->num_cus : 1));
+    DevBuf<int32_t> d_shared; HIP_TRY(d_shared.alloc(8 + 64 + (size_t)blocks));
+    HIP_TRY(hipMemsetAsync(d_shared.p, 0, (8 + 64 + (size_t)blocks) * sizeof(int32_t), h->stream));
     BuildDev b;
     b.n_tips = n; b.L = L; b.ref = d_ref.p; b.d_off = d_doff.p; b.d_site = d_dsite.p; b.d_to = d_dto.p; b.m_off = d_moff.p; b.m_start = d_mstart.p; b.m_end = d_mend.p;
     b.root = d_root.p; b.parent = d_parent.p; b.c0 = d_c0.p; b.c1 = d_c1.p; b.t = d_t.p; b.sz = d_sz.p; b.ml_off = d_mloff.p; b.ml_cnt = d_mlcnt.p; b.pool = d_pool.p; b.pool_cap = pool_cap; b.pool_top = d_top.p;
     b.delta = d_delta.p; b.vD[0] = d_vD0.p; b.vD[1] = d_vD1.p; b.vP[0] = d_vP0.p; b.vP[1] = d_vP1.p; b.anc[0] = d_a0.p; b.anc[1] = d_a1.p; b.inv = d_inv.p; b.cnt = d_cnt.p; b.off = d_off.p;
     b.tie_node = d_tnode.p; b.tie_tmin = d_tmin.p; b.tie_tmax = d_tmax.p; b.tie_cap = tie_cap; b.path = d_path.p; b.sd = d_sd.p; b.sd_cap = sd_cap; b.rng = d_rng.p; b.status = d_status.p;
+    b.grid_counter = (unsigned long long*)d_shared.p; b.gmin = d_shared.p + 2; b.stop_flag = d_shared.p + 3; b.pj_flag = d_shared.p + 8; b.blk_sum = d_shared.p + 8 + 64;
     if (n > 2) {
-      hipLaunchKernelGGL(k_build_usher_graft, dim3(1), dim3(k_build_threads), 0, h->stream, b, 2, n);
+      hipLaunchKernelGGL(k_build_usher_graft, dim3((unsigned)blocks), dim3(k_build_threads), 0, h->stream, b, 2, n);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(h->stream));
     }

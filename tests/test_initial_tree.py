@@ -85,3 +85,13 @@ def test_builder_has_no_host_fallback():
     with pytest.raises(d.EmatError, match="NO_DEVICE"):
         b.build_usher_like(tips, 1)
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks", ["1", "3", "16", "200"])
+def test_any_number_of_workgroups_builds_the_same_tree(blocks, monkeypatch):
+    """The graft loop runs on 1 .. one-per-CU workgroups that meet at a barrier of their own between the phases of a tip
+    (EMAT_BUILD_BLOCKS overrides the default of one per 1 024 nodes): the tree does not depend on how many."""
+    monkeypatch.setenv("EMAT_BUILD_BLOCKS", blocks)
+    sc = make_scenario("C3", num_tips=1500, num_sites=29903, uncertain_tips=0.1)
+    build_both(sc, 11)
