@@ -46,6 +46,7 @@ struct BuildDev {
   // what the workgroups of the launch share besides the tree: the meeting counter, the running minimum, one word per pointer-jumping
   // round, every workgroup's share of the tying regions, and the grafting thread's verdict on the tip
   unsigned long long* grid_counter; int32_t* gmin; int32_t* pj_flag; int32_t* blk_sum; int32_t* stop_flag;
+  long long* prof;    // [8] 100 MHz ticks of the grafting thread: whole loop, waiting for the parallel phases, tie sums, path + deltas, links + sizes, mutations; pointer-jumping rounds; tying regions
 };
 
 struct BRng {   // the engine's stream (emat_device_core.hpp rng_next64 and friends), for the one thread that draws
@@ -138,6 +139,7 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
     const int dx0 = b.d_off[X], dxn = b.d_off[X + 1] - dx0, mx0 = b.m_off[X], mxn = b.m_off[X + 1] - mx0;
     const double t_X = b.t[X];
     const int root = *b.root;
+    const long long t_tip0 = grafter ? (long long)wall_clock64() : 0ll;
     if (grafter) *b.gmin = 0x7fffffff;
     // (1) per branch: how the distance to X changes across it; the increments of the two prefix sums down the tree
     for (int i = gtid; i < nl; i += GT) {
@@ -166,6 +168,7 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
       }
       cur ^= 1;
       if (__syncthreads_or(any) && tid == 0) atomicMax(&b.pj_flag[round], X);
+      if (grafter) b.prof[6] += 1;
       if (!grid.sync()) return;
       if (__hip_atomic_load(&b.pj_flag[round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != X) break;
     }
@@ -248,6 +251,8 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
     }
     // (5) one thread picks the region and makes the graft (:925-1030)
     if (grafter) {
+      const long long tg0 = (long long)wall_clock64();
+      b.prof[1] += tg0 - t_tip0;
       const int P = X + n - 1;
       int S = root; double t_P = 0.0; int nsd = 0; bool bad = false, full = false, stop = false;
       int n_tie = 0;
@@ -263,10 +268,12 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
         b.ml_off[P] = b.ml_off[S]; b.ml_cnt[P] = b.ml_cnt[S]; b.ml_cnt[S] = 0;      // the root's list moves up with the root (it is empty while building)
       } else {
         double tot_min_T = 0.0;
+        b.prof[7] += n_tie;
         for (int i = 0; i < n_tie; ++i) tot_min_T += b.tie_tmax[i] - b.tie_tmin[i];
         const double insertion_cum_t = rng.uniform_co(0.0, tot_min_T);
         double so_far_min_T = 0.0; int chosen = -1;
         for (int i = 0; i < n_tie; ++i) { so_far_min_T += b.tie_tmax[i] - b.tie_tmin[i]; if (insertion_cum_t <= so_far_min_T) { chosen = i; break; } }
+        const long long tg1 = (long long)wall_clock64(); b.prof[2] += tg1 - tg0;
         if (chosen < 0) { b.status[0] = 4; b.status[1] = X; stop = true; }
         else {
           S = b.tie_node[chosen];
@@ -285,8 +292,10 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
           int split = 0;                                               // the mutations of G-S before t_P now sit on G-P
           { const MutRec* m = b.pool + b.ml_off[S]; const int nm = b.ml_cnt[S]; while (split < nm && !(m[split].t > t_P)) ++split; }
           b.ml_off[P] = b.ml_off[S]; b.ml_cnt[P] = split; b.ml_off[S] += (uint32_t)split; b.ml_cnt[S] -= split;
+          b.prof[3] += (long long)wall_clock64() - tg1;
         }
       }
+      const long long tg2 = (long long)wall_clock64();
       if (!stop) {
         if (full) { b.status[0] = 2; b.status[1] = X; stop = true; }
         else if (bad) { b.status[0] = 4; b.status[1] = X; stop = true; }
@@ -295,6 +304,7 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
         b.t[P] = t_P; b.c0[P] = X; b.c1[P] = S; b.parent[X] = P; b.parent[S] = P;
         b.sz[X] = 1; b.sz[P] = b.sz[S] + 2;
         for (int a = b.parent[P]; a != EMAT_NO_NODE; a = b.parent[a]) b.sz[a] += 2;
+        const long long tg3 = (long long)wall_clock64(); b.prof[4] += tg3 - tg2;
         // the mutations X needs, at random times on P-X, sorted by (t, site) (:1015-1021)
         const uint32_t o = *b.pool_top;
         if (o + (uint32_t)nsd > b.pool_cap) { b.status[0] = 1; b.status[1] = X; stop = true; }
@@ -308,8 +318,10 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
           }
           b.ml_off[X] = o; b.ml_cnt[X] = nsd; *b.pool_top = o + (uint32_t)nsd;
         }
+        b.prof[5] += (long long)wall_clock64() - tg3;
       }
       *b.stop_flag = stop ? X : 0;
+      b.prof[0] += (long long)wall_clock64() - t_tip0;
     }
     if (!grid.sync()) return;
     if (tid == 0) s_stop = __hip_atomic_load(b.stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -90,8 +90,10 @@ emat_status build_usher_like(emat_backend* h, const emat_tip_descs& td, uint64_t
     for (DevBuf<int32_t>* w : {&d_delta, &d_vD0, &d_vD1, &d_vP0, &d_vP1, &d_a0, &d_a1, &d_inv, &d_cnt, &d_off, &d_path}) HIP_TRY(w->alloc((size_t)N + 1));
     HIP_TRY(d_tnode.alloc(tie_cap)); HIP_TRY(d_tmin.alloc(tie_cap)); HIP_TRY(d_tmax.alloc(tie_cap)); HIP_TRY(d_sd.alloc(sd_cap));
     HIP_TRY(d_rng.upload(rng0, 4)); HIP_TRY(d_status.upload(status0, 2));
-    // one workgroup per 1 024 nodes of the finished tree, at most one per CU (all of them must be resident: they meet at barriers)
-    int blocks = std::max(1, std::min(h->num_cus > 0 ? h->num_cus : 1, (N + k_build_threads - 1) / k_build_threads));
+    // one workgroup per 2 048 nodes of the finished tree, at most one per four CUs (all of them must be resident: they meet at
+    // barriers, and a meeting costs more the more workgroups attend: measured at 30 000 tips, 0.73 / 0.56 / 0.51 / 0.59 ms per tip
+    // on 8 / 16 / 32 / 59 workgroups)
+    int blocks = std::max(1, std::min(std::max(1, h->num_cus / 4), (N + 2 * k_build_threads - 1) / (2 * k_build_threads)));
     if (const char* e = getenv("EMAT_BUILD_BLOCKS")) blocks = std::max(1, std::min(atoi(e), h->num_cus > 0 ? h->num_cus : 1));
     DevBuf<int32_t> d_shared; HIP_TRY(d_shared.alloc(8 + 64 + (size_t)blocks));
     HIP_TRY(hipMemsetAsync(d_shared.p, 0, (8 + 64 + (size_t)blocks) * sizeof(int32_t), h->stream));
@@ -100,6 +102,8 @@ emat_status build_usher_like(emat_backend* h, const emat_tip_descs& td, uint64_t
     b.root = d_root.p; b.parent = d_parent.p; b.c0 = d_c0.p; b.c1 = d_c1.p; b.t = d_t.p; b.sz = d_sz.p; b.ml_off = d_mloff.p; b.ml_cnt = d_mlcnt.p; b.pool = d_pool.p; b.pool_cap = pool_cap; b.pool_top = d_top.p;
     b.delta = d_delta.p; b.vD[0] = d_vD0.p; b.vD[1] = d_vD1.p; b.vP[0] = d_vP0.p; b.vP[1] = d_vP1.p; b.anc[0] = d_a0.p; b.anc[1] = d_a1.p; b.inv = d_inv.p; b.cnt = d_cnt.p; b.off = d_off.p;
     b.tie_node = d_tnode.p; b.tie_tmin = d_tmin.p; b.tie_tmax = d_tmax.p; b.tie_cap = tie_cap; b.path = d_path.p; b.sd = d_sd.p; b.sd_cap = sd_cap; b.rng = d_rng.p; b.status = d_status.p;
+    DevBuf<long long> d_prof; HIP_TRY(d_prof.alloc(8)); HIP_TRY(hipMemsetAsync(d_prof.p, 0, 8 * sizeof(long long), h->stream));
+    b.prof = d_prof.p;
     b.grid_counter = (unsigned long long*)d_shared.p; b.gmin = d_shared.p + 2; b.stop_flag = d_shared.p + 3; b.pj_flag = d_shared.p + 8; b.blk_sum = d_shared.p + 8 + 64;
     if (n > 2) {
       hipLaunchKernelGGL(k_build_usher_graft, dim3((unsigned)blocks), dim3(k_build_threads), 0, h->stream, b, 2, n);
@@ -108,6 +112,12 @@ emat_status build_usher_like(emat_backend* h, const emat_tip_descs& td, uint64_t
     }
     int32_t status[2];
     HIP_TRY(hipMemcpy(status, d_status.p, sizeof status, hipMemcpyDeviceToHost));
+    if (getenv("EMAT_VERBOSE") && n > 2) {
+      long long pr[8]; HIP_TRY(hipMemcpy(pr, d_prof.p, sizeof pr, hipMemcpyDeviceToHost));
+      const double k = 1e-5 / (double)(n - 2);   // ticks of 10 ns -> ms per tip
+      fprintf(stderr, "[emat] build_usher_like: %d tips on %d workgroups, per tip: %.3f ms = parallel phases + barriers %.3f | tie sums %.3f (%.1f tying regions) | path + deltas %.3f | links + sizes %.3f | mutations %.3f | %.1f pointer-jumping rounds\n",
+              n, blocks, pr[0] * k, pr[1] * k, pr[2] * k, (double)pr[7] / (n - 2), pr[3] * k, pr[4] * k, pr[5] * k, (double)pr[6] / (n - 2));
+    }
     if (status[0] == 1) { pool_cap *= 2; tie_cap = (uint32_t)N + pool_cap; continue; }
     if (status[0] == 2) { sd_cap *= 4; continue; }
     if (status[0] == 3) { tie_cap *= 2; continue; }

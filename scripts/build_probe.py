@@ -13,7 +13,8 @@ tips_n = int(sys.argv[2]) if len(sys.argv) > 2 else None
 sc = make_scenario(name, num_tips=tips_n)
 ob = OracleBuild(sc.ref); tips = ob.tip_descs_of(sc.tree)
 b = d.EmatBackend(sc.num_sites); b.set_ref_sequence(sc.ref)
-b.build_usher_like(tips, 1)      # warm-up (first launch, allocations)
+if tips.num_tips <= 30000:
+    b.build_usher_like(tips, 1)      # warm-up (first launch, allocations)
 t0 = time.perf_counter(); tree = b.build_usher_like(tips, 7); t_dev = time.perf_counter() - t0
 skip_cpu = tips.num_tips > 30000
 if not skip_cpu:
