@@ -46,6 +46,7 @@ struct BuildDev {
   // what the workgroups of the launch share besides the tree: the meeting counter, the running minimum, one word per pointer-jumping
   // round, every workgroup's share of the tying regions, and the grafting thread's verdict on the tip
   unsigned long long* grid_counter; int32_t* gmin; int32_t* pj_flag; int32_t* blk_sum; int32_t* stop_flag;
+  int32_t* grafted_below; int32_t* pre_buf;   // the node the previous tip was grafted above (EMAT_NO_NODE: none), and which vP buffer holds that scan's positions
   long long* prof;    // [8] 100 MHz ticks of the grafting thread: whole loop, waiting for the parallel phases, tie sums, path + deltas, links + sizes, mutations; pointer-jumping rounds; tying regions
 };
 
@@ -141,6 +142,21 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
     const int root = *b.root;
     const long long t_tip0 = grafter ? (long long)wall_clock64() : 0ll;
     if (grafter) *b.gmin = 0x7fffffff;
+    // (0) the graft of the previous tip made every ancestor of its new inner node two nodes larger.  The ancestors of a node are
+    // the nodes whose stretch of the visiting order contains it -- position and subtree size are still those of the previous
+    // tip's scan -- so all nodes check themselves side by side instead of one thread climbing to the root.
+    {
+      const int S_prev = __hip_atomic_load(b.grafted_below, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (S_prev != EMAT_NO_NODE) {      // (no node: the tip went above the root, or this is the launch's first tip)
+        const int32_t* pre_prev = b.vP[*b.pre_buf];
+        const int pS = pre_prev[S_prev], n_prev = nl - 2;
+        for (int i = gtid; i < n_prev; i += GT) {
+          const int a = i < X - 1 ? i : n + (i - (X - 1));             // the nodes linked before the previous graft
+          if (a != S_prev && pre_prev[a] <= pS && pS < pre_prev[a] + b.sz[a]) b.sz[a] += 2;
+        }
+        if (!grid.sync()) return;
+      }
+    }
     // (1) per branch: how the distance to X changes across it; the increments of the two prefix sums down the tree
     for (int i = gtid; i < nl; i += GT) {
       const int v = node_of(i);
@@ -303,7 +319,7 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
       if (!stop) {
         b.t[P] = t_P; b.c0[P] = X; b.c1[P] = S; b.parent[X] = P; b.parent[S] = P;
         b.sz[X] = 1; b.sz[P] = b.sz[S] + 2;
-        for (int a = b.parent[P]; a != EMAT_NO_NODE; a = b.parent[a]) b.sz[a] += 2;
+        *b.grafted_below = above_root ? EMAT_NO_NODE : S; *b.pre_buf = cur;     // the ancestors' sizes follow at the start of the next tip (0)
         const long long tg3 = (long long)wall_clock64(); b.prof[4] += tg3 - tg2;
         // the mutations X needs, at random times on P-X, sorted by (t, site) (:1015-1021)
         const uint32_t o = *b.pool_top;

@@ -104,7 +104,8 @@ emat_status build_usher_like(emat_backend* h, const emat_tip_descs& td, uint64_t
     b.tie_node = d_tnode.p; b.tie_tmin = d_tmin.p; b.tie_tmax = d_tmax.p; b.tie_cap = tie_cap; b.path = d_path.p; b.sd = d_sd.p; b.sd_cap = sd_cap; b.rng = d_rng.p; b.status = d_status.p;
     DevBuf<long long> d_prof; HIP_TRY(d_prof.alloc(8)); HIP_TRY(hipMemsetAsync(d_prof.p, 0, 8 * sizeof(long long), h->stream));
     b.prof = d_prof.p;
-    b.grid_counter = (unsigned long long*)d_shared.p; b.gmin = d_shared.p + 2; b.stop_flag = d_shared.p + 3; b.pj_flag = d_shared.p + 8; b.blk_sum = d_shared.p + 8 + 64;
+    { const int32_t none = EMAT_NO_NODE; HIP_TRY(hipMemcpyAsync(d_shared.p + 4, &none, sizeof none, hipMemcpyHostToDevice, h->stream)); HIP_TRY(hipStreamSynchronize(h->stream)); }
+    b.grid_counter = (unsigned long long*)d_shared.p; b.gmin = d_shared.p + 2; b.stop_flag = d_shared.p + 3; b.grafted_below = d_shared.p + 4; b.pre_buf = d_shared.p + 5; b.pj_flag = d_shared.p + 8; b.blk_sum = d_shared.p + 8 + 64;
     if (n > 2) {
       hipLaunchKernelGGL(k_build_usher_graft, dim3((unsigned)blocks), dim3(k_build_threads), 0, h->stream, b, 2, n);
       HIP_TRY(hipGetLastError());

@@ -16,7 +16,7 @@ b = d.EmatBackend(sc.num_sites); b.set_ref_sequence(sc.ref)
 if tips.num_tips <= 30000:
     b.build_usher_like(tips, 1)      # warm-up (first launch, allocations)
 t0 = time.perf_counter(); tree = b.build_usher_like(tips, 7); t_dev = time.perf_counter() - t0
-skip_cpu = tips.num_tips > 30000
+skip_cpu = tips.num_tips > 30000 or os.environ.get("EMAT_PROBE_NO_ORACLE") == "1"
 if not skip_cpu:
     t0 = time.perf_counter(); ot = ob.build_usher_like(tips, 7); t_cpu = time.perf_counter() - t0
 rc, msg = ob.check(tree, tips)

@@ -95,3 +95,18 @@ def test_any_number_of_workgroups_builds_the_same_tree(blocks, monkeypatch):
     monkeypatch.setenv("EMAT_BUILD_BLOCKS", blocks)
     sc = make_scenario("C3", num_tips=1500, num_sites=29903, uncertain_tips=0.1)
     build_both(sc, 11)
+
+
+@pytest.mark.gpu
+def test_randomised_descriptors():
+    """Seeded random scenarios (tree size, genome length, time span, mutation and gap density, tip-date uncertainty all vary):
+    the device's tree equals the oracle's and passes the reference's closing checks.  EMAT_FUZZ_SEED / EMAT_FUZZ_CASES for longer hunts."""
+    import os
+    from delphy_amd.scenarios import random_scenario
+    rng = np.random.default_rng(int(os.environ.get("EMAT_FUZZ_SEED", "20261007")))
+    for case in range(int(os.environ.get("EMAT_FUZZ_CASES", "16"))):
+        sc, _, _, what = random_scenario(rng, case, max_tips=600)
+        try:
+            build_both(sc, 1000 + case)
+        except AssertionError as e:
+            raise AssertionError("%s: %s" % (what, e))
