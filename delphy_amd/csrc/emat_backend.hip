@@ -24,7 +24,14 @@
 #include <stdexcept>
 
 #include "../../include/emat_backend.h"
-#ifdef EMAT_PROFILE_PHASES
+// 1: every lane of the wave runs the chain, all with the same values (the chain's code does not depend on the lane);
+// 0: lane 0 alone.  With one lane active every non-leaf device function saves and restores the INACTIVE lanes of the
+// VGPR it parks its return address in (s_xor_saveexec + scratch_store / scratch_load + s_waitcnt vmcnt(0)); with all
+// lanes active that save has nothing to store.
+#ifndef EMAT_CHAIN_ON_ALL_LANES
+#define EMAT_CHAIN_ON_ALL_LANES 0
+#endif
+#if defined(EMAT_PROFILE_PHASES) || defined(EMAT_COUNT_CALLS)
 namespace emat {
 __device__ unsigned long long g_fn_ticks[3 * 2048][2];   // EMAT_TIMED scopes: [header * 2048 + line][ticks, calls], all parts
 struct FnTimer {   // inclusive ticks and calls of the enclosing scope, keyed by (header, source line); lane 0 only
@@ -33,6 +40,8 @@ struct FnTimer {   // inclusive ticks and calls of the enclosing scope, keyed by
   __device__ ~FnTimer() { if (threadIdx.x == 0) { atomicAdd(&g_fn_ticks[key][0], (unsigned long long)(clock64() - t0)); atomicAdd(&g_fn_ticks[key][1], 1ull); } }
 };
 }
+#endif
+#ifdef EMAT_PROFILE_PHASES
 namespace emat { __device__ unsigned long long g_arena_site_bytes[2048][2]; }   // [source line & 2047][0 = LDS arena, 1 = HBM scratch], all parts
 #endif
 // The device code is compiled three times (see emat_device_core.hpp): `dev_lds` for parts whose whole persistent slab
@@ -148,7 +157,7 @@ __device__ inline const double* stage_tables(const KernelArgs& a, double* lds_ta
 // compactions and the HBM fall-back leg).
 constexpr uint32_t k_lds_heap_room = 1024;
 
-__device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
+template <bool kSide> __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
   const int lane = threadIdx.x;
   double* lds_tables = (double*)emat_lds_tables;
   const bool tables_staged = stage_tables(a, lds_tables, lane) != nullptr;
@@ -208,7 +217,9 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
     SlabHeader* H = (staged || prefix) ? lds_hdr : gh;
     // The root part is one chain like any other, but its moves walk long runs of coalescent cells (deep branches span
     // hundreds of cells): compute-bound, the longest chain of its launch.  Let its wave win issue arbitration on its SIMD.
-    const bool is_root_part = (gh->flags & k_flag_includes_run_root) != 0;
+    // (So are the parts of the side classes -- the giants of a partition, a few dozen among thousands: at the reference's
+    // rule every part does the same number of moves, theirs cost two or three times a small part's, and the pass waits for them.)
+    const bool raise_prio = kSide || (gh->flags & k_flag_includes_run_root) != 0;
     uint64_t tick0 = 0;
     if (lane == 0) {
       // The context lives in LDS, not in private memory: it is touched by almost every instruction.
@@ -236,13 +247,13 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
       const bool stopped_before = chunk > 0 && a.part_status[part] != 0;
       ((dev::Ctx*)(emat_lds_ctx))->moves_left = (H->status == 0 && !stopped_before) ? target - (H->moves_done - done_at_start) : 0;   // the three Ctx types share one layout
       tick0 = wall_clock64();
-      if (is_root_part) __builtin_amdgcn_s_setprio(3);
+      if (raise_prio) __builtin_amdgcn_s_setprio(3);
     }
     __syncthreads();
     // The chain: stretches of moves on lane 0; whenever a move parks itself for work the whole wave shares (the candidate
     // scan and study of an SPR move), all 64 lanes do that work and lane 0 picks the move up again.
     for (;;) {
-      if (lane == 0) {
+      if (EMAT_CHAIN_ON_ALL_LANES || lane == 0) {
         if (staged) dev_lds::run_chain_loop(*(dev_lds::Ctx*)(emat_lds_ctx));
         else if (prefix) dev_mix::run_chain_loop(*(dev_mix::Ctx*)(emat_lds_ctx));
         else dev::run_chain_loop(*(dev::Ctx*)(emat_lds_ctx));
@@ -255,7 +266,7 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
       __syncthreads();
     }
     if (lane == 0) {
-      if (is_root_part) __builtin_amdgcn_s_setprio(0);
+      if (raise_prio) __builtin_amdgcn_s_setprio(0);
       const dev::Ctx& c = *(const dev::Ctx*)(emat_lds_ctx);
       H->rng_counter = c.rng_ctr; H->rng_spare = c.rng_spare; H->rng_has_spare = c.rng_has_spare ? 1u : 0u;
       H->alg_bytes += c.bytes;
@@ -300,10 +311,10 @@ __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
     if (lane == 0) __hip_atomic_store(&a.chunk_done[part], chunk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY EMAT_NOTAIL k_run_moves(KernelArgs a) { run_moves_body(a); }
+__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY EMAT_NOTAIL k_run_moves(KernelArgs a) { run_moves_body<false>(a); }
 // Same body under another name for the side launches of the size classes (the "giants", §4 of DESIGN.md), so that
 // profiles keep the statistics of the main launch -- the one bench.py's roofline is about -- apart.
-__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY EMAT_NOTAIL k_run_moves_side(KernelArgs a) { run_moves_body(a); }
+__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY EMAT_NOTAIL k_run_moves_side(KernelArgs a) { run_moves_body<true>(a); }
 
 // ---- sufficient statistics of the global moves (calc_Ttwiddle_beta_a phylo_tree_calc.cpp:288-369, calc_num_muts_beta_ab
 //      :599-610, calc_num_muts :577-585), one part per workgroup ---------------------------------------------------------
@@ -2056,7 +2067,7 @@ emat_status emat_debug_arena_sites(emat_backend* h, uint64_t* out_4096) {
 /* debugging aid (profiling builds): inclusive ticks and calls of the EMAT_TIMED scopes, [header * 2048 + line & 2047][ticks, calls]; read and cleared */
 emat_status emat_debug_fn_ticks(emat_backend* h, uint64_t* out_12288) {
   if (!h || !out_12288 || h->host_only) return EMAT_ERR_INVALID_ARGUMENT;
-#ifdef EMAT_PROFILE_PHASES
+#if defined(EMAT_PROFILE_PHASES) || defined(EMAT_COUNT_CALLS)
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpyFromSymbol(out_12288, HIP_SYMBOL(::emat::g_fn_ticks), sizeof(unsigned long long) * 12288));

@@ -51,6 +51,11 @@ __shared__ __attribute__((aligned(16))) uint8_t emat_lds_hdr[sizeof(SlabHeader)]
 // A function whose calls must not be marked as tail calls: its callees then qualify for LLVM's no-callee-saved-registers
 // optimisation.  The top of the call tree carries it; below, calls keep the standard convention.
 #define EMAT_NOTAIL __attribute__((disable_tail_calls))
+// -DEMAT_COUNT_CALLS: scripts/count_calls.py puts EMAT_CALLED(header) at the top of every device function of a copy of these
+// headers; calls are counted per (header, line) in g_fn_ticks[..][1] and read with emat_debug_fn_ticks.
+#ifdef EMAT_COUNT_CALLS
+#define EMAT_CALLED(file_id) do { if (threadIdx.x == 0) atomicAdd(&::emat::g_fn_ticks[(file_id) * 2048 + (__LINE__ & 2047)][1], 1ull); } while (0)
+#endif
 #endif  // EMAT_DEVICE_COMMON_ONCE_
 
 namespace emat {
@@ -261,6 +266,20 @@ template <class T> EMAT_D SVec<T> sc_open(Ctx& c, int max_elems, int min_lds_ele
   v.p = (T*)(c.G + g0); v.cap = room_g < max_elems ? room_g : max_elems; c.sc_top = hdr_of(c)->scratch_end;
   if (v.cap <= 0) { v.cap = 0; EMAT_FAIL(c, k_part_overflow); }
   return v;
+}
+// An open vector in the LDS arena ran out of room: move it to the part's HBM scratch region (the rest of which it takes,
+// up to `max_elems`) and give the LDS arena back.  False when it already was in HBM or HBM has no more room than it had.
+template <class T> EMAT_D bool sc_open_migrate(Ctx& c, SVec<T>& v, int max_elems) {
+  if (!sc_in_lds(c, v.p)) return false;
+  uint32_t g0 = (c.sc_top + 15u) & ~15u;
+  int room_g = hdr_of(c)->scratch_end > g0 ? (int)((hdr_of(c)->scratch_end - g0) / sizeof(T)) : 0;
+  if (room_g > max_elems) room_g = max_elems;
+  if (room_g <= v.cap) return false;
+  T* np = (T*)(c.G + g0);
+  for (int i = 0; i < v.n; ++i) np[i] = v.p[i];
+  c.a_top = (uint32_t)((uint8_t*)v.p - c.A);
+  v.p = np; v.cap = room_g; c.sc_top = hdr_of(c)->scratch_end;
+  return true;
 }
 // give back the unused tail of the most recent allocation in its arena
 template <class T> EMAT_D void sc_trim(Ctx& c, SVec<T>& v, int line = __builtin_LINE()) {

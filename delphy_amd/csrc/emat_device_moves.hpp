@@ -87,9 +87,19 @@ EMAT_NOTAIL EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new
 
 // The three simple moves are compiled twice: kRoot = true for the part that holds the run's root (its root node may be
 // displaced, its coalescent grid may grow, branch reforms next to the root go through spr_move_core) and kRoot = false for
-// every other part, where none of that can happen: those versions contain no call and no root-only code, so they are
-// leaf functions without a stack frame.
-template <bool kRoot> EMAT_NOTAIL EMAT_DN void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
+// every other part, where none of that can happen: those versions contain no root-only code, and their only calls are the
+// out-of-line transcendentals (m_log, m_exp, ...).
+// (-DEMAT_SIMPLE_MOVES_INLINE puts them inside run_chain_loop instead, which spares each simple move the whole-wave save
+// of the VGPR a non-leaf function parks its return address in -- scripts/micro/wwm.hip: ~490 cycles per call with one lane
+// active -- and costs 128 VGPRs and 544 B of scratch instead of 64 and 432: measured +0.3 %, not taken.)
+#ifndef EMAT_SIMPLE_MOVE
+#ifdef EMAT_SIMPLE_MOVES_INLINE
+#define EMAT_SIMPLE_MOVE EMAT_NOTAIL EMAT_DF
+#else
+#define EMAT_SIMPLE_MOVE EMAT_NOTAIL EMAT_DN
+#endif
+#endif
+template <bool kRoot> EMAT_SIMPLE_MOVE void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
   begin_move(c, k_inner_node_displace);
   int node;
   { int guard = 0; do { node = pick_random_node(c); } while (is_tip(c, node) && guard++ < (1 << 26)); }
@@ -152,7 +162,7 @@ template <bool kRoot> EMAT_NOTAIL EMAT_DN void inner_node_displace_move(Ctx& c) 
   }
 }
 
-template <bool kRoot> EMAT_NOTAIL EMAT_DN void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
+template <bool kRoot> EMAT_SIMPLE_MOVE void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
   begin_move(c, k_tip_displace);
   int node;
   { int guard = 0; do { node = pick_random_node(c); } while (!is_tip(c, node) && guard++ < (1 << 26)); }
@@ -214,7 +224,7 @@ EMAT_D SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) {
   return out;
 }
 
-template <bool kRoot> EMAT_NOTAIL EMAT_DN void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
+template <bool kRoot> EMAT_SIMPLE_MOVE void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
   begin_move(c, k_branch_reform);
   if (hdr_of(c)->n_nodes < 3) return;
   const int X = pick_random_node(c);
@@ -336,7 +346,14 @@ EMAT_NOTAIL EMAT_DN void spr1_move_begin(Ctx& c) { EMAT_TIMED(2);
   c.frame = (uint8_t*)frp;
   fr.X = X; fr.t_X = nodes_of(c)[X].t; fr.P = P; fr.old_t_P = nodes_of(c)[P].t; fr.old_S = sibling_of(c, P, X); fr.old_G = nodes_of(c)[P].parent;
   fr.limit = limit; fr.f = 0.8 /* annealing factor */; fr.t_max_tip = c.t_max_tip; fr.can_change_root = c.includes_run_root;
-  fr.hot = (limit == 1) ? sc_reserve_hot(c, EMAT_HOT_BYTES) : HotBlock{nullptr, 0};
+  // a part that leaves much of its staging area free (the large parts of a side class, whose scans run to hundreds of items)
+  // sets aside half of what is free instead of the fixed block
+  {
+    const uint32_t a0 = (c.a_top + 15u) & ~15u, free_b = c.a_end > a0 ? c.a_end - a0 : 0u;
+    uint32_t hot_b = EMAT_HOT_BYTES;
+    if (free_b / 2 > hot_b) hot_b = (free_b / 2 < 32768u ? free_b / 2 : 32768u) & ~15u;
+    fr.hot = (limit == 1) ? sc_reserve_hot(c, hot_b) : HotBlock{nullptr, 0};
+  }
   analyze_graft(c, X, fr.old_graft);
   peel_graft(c, fr.old_graft);
   EMAT_PHASE(c, 5);

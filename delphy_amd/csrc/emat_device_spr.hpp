@@ -331,38 +331,42 @@ EMAT_DN int ktp_sample(Ctx& c, const KTruncPoisson& d) {
   while (k < d.max_k) { term *= d.lambda / k; cum += term; if (cum > u) break; ++k; }
   return k;
 }
-EMAT_D void sort_doubles(double* p, int n) { for (int i = 1; i < n; ++i) { double x = p[i]; int j = i - 1; while (j >= 0 && p[j] > x) { p[j + 1] = p[j]; --j; } p[j + 1] = x; } }
 
-// Appends to `out` (open-ended scratch vector); returns false on overflow.  States of a trajectory are
-// drawn first (rejection on the end state), then its times, exactly as spr_move.cpp:1181-1227.
+// Appends to `out` (open-ended scratch vector).  States of a trajectory are drawn first (rejection on the end state), then
+// its times, exactly as spr_move.cpp:1181-1227.  Both are staged IN PLACE, in the records they end up in (`to` and `t` of
+// out.p[out.n ..]); a vector that started in the LDS arena and runs out of room moves to the part's HBM scratch.
+constexpr int k_open_max = 1 << 20;   // most elements an open vector of a sampler takes of an arena (the arena's free space bounds it first)
+EMAT_D bool open_room(Ctx& c, SVec<MutRec>& out, int extra) {
+  if (out.cap - out.n >= extra) return true;
+  if (sc_open_migrate(c, out, k_open_max) && out.cap - out.n >= extra) return true;
+  EMAT_FAIL(c, k_part_overflow); return false;
+}
 EMAT_DN void sample_site_trajectory(Ctx& c, SVec<MutRec>& out, int l, int from, int to, const KTruncPoisson& dist, double T, bool accept_only_if_match, bool& accepted) {
-  // to_states and times are staged at the far end of `out`'s spare capacity (576 bytes = 36 records), not on the stack
-  constexpr int k_stage_recs = (64 * 8 + 64) / (int)sizeof(MutRec);
-  if (out.cap - out.n < k_stage_recs + 1) { EMAT_FAIL(c, k_part_overflow); accepted = false; return; }
-  double* times = (double*)(out.p + (out.cap - k_stage_recs));
-  uint8_t* states = (uint8_t*)(times + 64);
   int n = 0; int s = from;
   int guard = 0;
   while (guard++ < (1 << 26)) {
     n = ktp_sample(c, dist);
+    if (!open_room(c, out, n)) { accepted = false; return; }
+    MutRec* rec = out.p + out.n;
     s = from;
-    for (int i = 0; i < n; ++i) { s = choose_different_state(c, s); if (i < 64) states[i] = (uint8_t)s; }
+    for (int i = 0; i < n; ++i) { s = choose_different_state(c, s); rec[i].to = (uint8_t)s; }
     if (s == to) { accepted = true; break; }
     if (!accept_only_if_match) { accepted = false; return; }   // caller restarts from scratch on its own terms
   }
-  if (n > 64 || out.cap - out.n < k_stage_recs + n) { EMAT_FAIL(c, k_part_overflow); return; }
-  for (int i = 0; i < n; ++i) times[i] = uniform_co(c, -T, 0.0);
-  sort_doubles(times, n);
+  MutRec* rec = out.p + out.n;
+  for (int i = 0; i < n; ++i) rec[i].t = uniform_co(c, -T, 0.0);
+  for (int i = 1; i < n; ++i) { double x = rec[i].t; int j = i - 1; while (j >= 0 && rec[j].t > x) { rec[j + 1].t = rec[j].t; --j; } rec[j + 1].t = x; }   // the times alone: the states keep their order
   int prev = from;
-  for (int i = 0; i < n; ++i) { push(c, out, make_mut((uint8_t)prev, l, states[i], times[i])); prev = states[i]; }
+  for (int i = 0; i < n; ++i) { const int st = rec[i].to; rec[i] = make_mut((uint8_t)prev, l, (uint8_t)st, rec[i].t); prev = st; }
+  out.n += n;
 }
 // spr_move.cpp:1164-1370; result appended into a fresh open-ended scratch vector (caller trims)
 EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double mu, const SVec<SdRec>& deltas) { EMAT_TIMED(1);
-  // room: the constrained sites (one mutation each, rarely three), the L (mu T)^2 / 2 other sites expected to be hit twice or
-  // more on a long branch, and the staging area of sample_site_trajectory; the LDS arena only if it holds all that
+  // the LDS arena if it has room for the constrained sites (one mutation each, rarely three) and the L (mu T)^2 / 2 other sites
+  // expected to be hit twice or more on a long branch; should more turn up, the vector moves to HBM (open_room)
   const double twice = 0.5 * (double)L * (mu * T) * (mu * T);
-  const int want = 4 * deltas.n + 48 + 36 + (twice < 1e6 ? (int)(3.0 * twice + 6.0 * sqrt(3.0 * twice)) : (1 << 20));
-  SVec<MutRec> out = sc_open<MutRec>(c, want > 2048 ? 2 * want : 4096, want);
+  const int want = 2 * deltas.n + 8 + (twice < 1e6 ? (int)(3.0 * twice + 6.0 * sqrt(3.0 * twice)) : (1 << 20));
+  SVec<MutRec> out = sc_open<MutRec>(c, k_open_max, want);
   if (c.failed) return out;
   if (deltas.n != 0) {
     KTruncPoisson ge1 = ktp_make(mu * T, 1);
@@ -391,10 +395,10 @@ EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double m
 }
 // spr_move.cpp:1372-1407
 EMAT_DN SVec<MutRec> sample_unconstrained_mutational_history(Ctx& c, int L, double T, double mu) { EMAT_TIMED(1);
-  // about mu L T mutations: the LDS arena only if it has room for that many and their spread, else the part's HBM scratch
+  // about mu L T mutations: the LDS arena if it has room for that many and their spread (else, or if more turn up, HBM scratch)
   const double expect = mu * (double)L * T;
-  const int want = expect < 1e6 ? (int)(expect + 6.0 * sqrt(expect)) + 96 : (1 << 20);
-  SVec<MutRec> out = sc_open<MutRec>(c, want > 2048 ? 2 * want : 4096, want);
+  const int want = expect < 1e6 ? (int)(expect + 6.0 * sqrt(expect)) + 8 : (1 << 20);
+  SVec<MutRec> out = sc_open<MutRec>(c, k_open_max, want);
   if (c.failed) return out;
   double t = 0.0;
   int guard = 0;
@@ -406,6 +410,7 @@ EMAT_DN SVec<MutRec> sample_unconstrained_mutational_history(Ctx& c, int L, doub
     int s = 0;
     for (int i = out.n - 1; i >= 0; --i) if (out.p[i].site == l) { s = out.p[i].from; break; }
     int ns = choose_different_state(c, s);
+    if (out.n == out.cap && !sc_open_migrate(c, out, k_open_max)) { EMAT_FAIL(c, k_part_overflow); break; }
     push(c, out, make_mut((uint8_t)ns, l, (uint8_t)s, t));
   }
   for (int i = 0, j = out.n - 1; i < j; ++i, --j) { MutRec tmp = out.p[i]; out.p[i] = out.p[j]; out.p[j] = tmp; }

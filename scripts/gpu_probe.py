@@ -356,3 +356,41 @@ def fn_probe(nparts=8192, moves=1000):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "fn":
     fn_probe()
+
+
+def arena_probe(nparts=8192, moves=1000):
+    """Where the scratch of the topology moves comes from, over ALL parts of a pass (-DEMAT_PROFILE_PHASES library): bytes taken
+    from the LDS arena and from the part's HBM scratch region per topology move, and the allocation sites that went to HBM."""
+    import ctypes as C
+    from delphy_amd.sharding import ShardedEngine
+    sc = make_scenario("C4")
+    eng = ShardedEngine(sc, num_parts=nparts, seed=20261001, rank=0, world=1, device_tree=False, allreduce=lambda a, op: a, allgather_bytes=lambda b: [b])
+    eng.setup()
+    eng.backend.run_moves_per_part(moves); eng.backend.synchronize()
+    lib = d.load_library()
+    lib.emat_debug_phase_ticks.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    lib.emat_debug_arena_sites.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    buf = (C.c_int64 * 16)(); tot = np.zeros(16); topo = 0
+    os.environ["EMAT_PHASE_EXTRA"] = "1"
+    per_part = []
+    for p in range(eng.num_local_parts):
+        lib.emat_debug_phase_ticks(eng.backend.handle, p, buf); e = np.array(list(buf), dtype=np.float64); tot += e
+        st = eng.backend.part_stats(p); t = st["proposed"][3] + st["proposed"][4]; topo += t
+        per_part.append((e[8], e[9], t))
+    del os.environ["EMAT_PHASE_EXTRA"]
+    print("topology moves %d | arena bytes per topology move: %.0f from HBM scratch, %.0f from LDS | open vectors trimmed in HBM %d, spans committed in HBM %d"
+          % (topo, tot[8] / topo, tot[9] / topo, tot[11], tot[12]))
+    pp = np.array(per_part); frac = (pp[:, 0] > 0).mean()
+    print("parts with any HBM scratch: %.1f%%; share of HBM bytes in the top 1%% of parts: %.1f%%" % (100 * frac, 100 * np.sort(pp[:, 0])[-max(1, len(pp) // 100):].sum() / max(1.0, pp[:, 0].sum())))
+    sites = (C.c_uint64 * 4096)()
+    if lib.emat_debug_arena_sites(eng.backend.handle, sites) == 0:
+        a = np.array(list(sites), dtype=np.float64).reshape(2048, 2)
+        order = np.argsort(-a[:, 1])[:12]
+        print("allocation sites by HBM bytes (source line & 2047: HBM bytes per topology move, LDS bytes per topology move)")
+        for k in order:
+            if a[k, 0] + a[k, 1] > 0: print("   line %4d: %8.0f %8.0f" % (k, a[k, 1] / topo, a[k, 0] / topo))
+    eng.close()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "arena":
+    arena_probe()
