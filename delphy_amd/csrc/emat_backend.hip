@@ -1364,8 +1364,16 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
   {
     const size_t sh_max = shmem_for(*std::max_element(h->class_lds, h->class_lds + h->num_classes));
     if (sh_max > 48 * 1024) {
-      HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_max));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves_side, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_max));
+      // the attribute belongs to the kernel on this device, not to the handle: raised when a request exceeds what any handle of
+      // the process has asked for so far (two driver calls that used to sit in front of every pass)
+      static std::mutex mu; static size_t granted[64] = {};
+      std::lock_guard<std::mutex> lock(mu);
+      size_t& g = granted[h->cfg.device & 63];
+      if (sh_max > g) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_max));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_run_moves_side, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_max));
+        g = sh_max;
+      }
     }
     const int main_class = h->num_classes - 1;   // the last class holds the bulk of the parts
     // Order matters: a side class holds few, large workgroups (tens of KB of LDS each), which can only be placed while
