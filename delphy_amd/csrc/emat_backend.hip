@@ -494,6 +494,14 @@ template <bool kCheck> __device__ __forceinline__ void recalc_derived_body(const
 }
 __global__ void __launch_bounds__(k_wave) k_recalc_derived(KernelArgs a) { recalc_derived_body<false>(a, nullptr); }
 __global__ void __launch_bounds__(k_wave) k_check_derived(KernelArgs a, double* check_out) { recalc_derived_body<true>(a, check_out); }
+// test hook (emat_debug_tree_query): the moves' own find_MRCA_of / descends_from on one part's slab, query by query
+__global__ void __launch_bounds__(k_wave) k_debug_tree_query(KernelArgs a, int part, int op, const int32_t* qa, const int32_t* qb, int32_t* out, int n) {
+  if (threadIdx.x != 0) return;
+  uint8_t* slab = a.slabs + a.slab_off[part];
+  dev::Ctx c;
+  init_ctx(c, slab, slab, a, nullptr);
+  for (int i = 0; i < n; ++i) out[i] = op == 0 ? dev::find_MRCA_of(c, qa[i], qb[i]) : (dev::descends_from(c, qa[i], qb[i]) ? 1 : 0);
+}
 
 // ---- compact copies of what the host reads most often, so that it does not have to download the slabs for them ----------
 // Every part's 256-byte header (status, counters, log_G, log prior, RNG position) into one dense array.
@@ -2041,6 +2049,28 @@ emat_status emat_debug_interval_op(emat_backend* h, int32_t op, const int32_t* a
   if (cnt < 0) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_debug_interval_op: unknown op");
   *n_out = cnt;
   if (op <= 3 && cnt > 0) HIP_TRY(hipMemcpy(out, dO.p, (size_t)cnt * sizeof(IvRec), hipMemcpyDeviceToHost));
+  return EMAT_OK;
+}
+/* test hook (header: emat_debug_tree_query) */
+emat_status emat_debug_tree_query(emat_backend* h, int32_t part_id, int32_t op, int32_t n, const int32_t* a, const int32_t* b, int32_t* out) {
+  if (!h || n < 0 || (op != 0 && op != 1) || (n > 0 && (!a || !b || !out))) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
+  if (part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  const int nn = h->parts[part_id].n_nodes;
+  for (int i = 0; i < n; ++i) if (a[i] < -1 || a[i] >= nn || b[i] < -1 || b[i] >= nn) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_debug_tree_query: node index out of range");
+  if (n == 0) return EMAT_OK;
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  emat_status st = emat_synchronize(h); if (st) return st;
+  st = sync_model_to_device(h); if (st) return st;
+  st = materialize(h); if (st) return st;
+  DevBuf<int32_t> da, db, dout;
+  HIP_TRY(da.upload(a, (size_t)n)); HIP_TRY(db.upload(b, (size_t)n)); HIP_TRY(dout.alloc((size_t)n));
+  KernelArgs ka = make_args(h);
+  hipLaunchKernelGGL(k_debug_tree_query, dim3(1), dim3(k_wave), 0, h->stream, ka, (int)part_id, (int)op, da.p, db.p, dout.p, (int)n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
   return EMAT_OK;
 }
 /* debugging aid (not part of the boundary): how many parts the next launch runs with each code variant

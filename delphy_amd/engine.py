@@ -284,6 +284,7 @@ def load_library():
         "emat_last_run_ms": [B, P(dbl)], "emat_last_kernel_ms": [B, P(dbl), P(i32)],
         "emat_debug_gamma": [B, i32, i32, P(dbl), P(dbl), P(dbl)],
         "emat_debug_pop": [B, P(_PopModelC), i32, i32, P(dbl), P(dbl), P(dbl)], "emat_debug_interval_op": [B, i32, P(i32), i32, P(i32), i32, P(i32), P(i32)],
+        "emat_debug_tree_query": [B, i32, i32, i32, P(i32), P(i32), P(i32)],
         "emat_get_num_muts_l": [B, P(i32)], "emat_get_scalable_coalescent_log_prior": [B, dbl, dbl, P(dbl)],
         "emat_scalable_coalescent_partial": [B, dbl, dbl, i32, i32, P(dbl), P(dbl), P(i32)],
         "emat_scalable_coalescent_log_prior": [B, dbl, dbl, i32, i32, P(dbl), dbl, P(dbl)],
@@ -668,6 +669,12 @@ class EmatBackend:
         out = np.zeros((A.shape[0] + nb + 1, 2), np.int32); n = C.c_int32(); ip = C.POINTER(C.c_int32)
         self._ck(self._lib.emat_debug_interval_op(self._h, op, A.ctypes.data_as(ip), A.shape[0], Bv.ctypes.data_as(ip), nb, out.ctypes.data_as(ip), C.byref(n)), "emat_debug_interval_op")
         return out[: n.value].tolist() if op <= 3 else bool(n.value)
+
+    def debug_tree_query(self, part: int, op: int, a, b) -> np.ndarray:
+        """Test hook: the moves' find_MRCA_of (op 0) / descends_from (op 1) on a resident part; -1 = no node."""
+        a = np.ascontiguousarray(a, np.int32); b = np.ascontiguousarray(b, np.int32); out = np.zeros_like(a); ip = C.POINTER(C.c_int32)
+        self._ck(self._lib.emat_debug_tree_query(self._h, part, op, a.shape[0], a.ctypes.data_as(ip), b.ctypes.data_as(ip), out.ctypes.data_as(ip)), "emat_debug_tree_query")
+        return out
 
     def debug_gamma(self, mode: int, a, x_or_q) -> np.ndarray:
         """Test hook: the device's gamma_q (mode 0) / gamma_q_inv (mode 1), point by point."""

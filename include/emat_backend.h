@@ -381,6 +381,10 @@ emat_status emat_debug_gamma(emat_backend* h, int32_t mode, int32_t n, const dou
  * (pop_at_time); op 1: out[i] = integral of N over [a[i], b[i]] (pop_integral).  tests/ sweeps them over the reference's
  * own expectations (tests/golden/reference_expectations.json). */
 emat_status emat_debug_pop(emat_backend* h, const emat_pop_model* pop_model, int32_t op, int32_t n, const double* a, const double* b, double* out);
+/* The moves' own tree queries on one resident part, query by query (reference phylo_tree.cpp:204-280, 292-299): op 0: out[i] =
+ * find_MRCA_of(a[i], b[i]); op 1: out[i] = descends_from(a[i], b[i]) (0 / 1); -1 stands for k_no_node.  tests/ runs them over the
+ * reference's own table of cases (phylo_tree_tests.cpp:365-525). */
+emat_status emat_debug_tree_query(emat_backend* h, int32_t part_id, int32_t op, int32_t n, const int32_t* a, const int32_t* b, int32_t* out);
 /* The device's interval-set algebra on two valid sets given as (start, end) pairs (reference interval_set.h:130-138, 238-500):
  * op 1 merge, 2 intersect, 3 subtract -> pairs in `out` (room for na + nb + 1 pairs), *n_out = their number; op 5 contains
  * (site b[0]), 6 sets intersect -> *n_out = 0 / 1. */

@@ -236,6 +236,14 @@ int orc_scalable_log_prior(orc_engine* e, int part_id, double t_ref, double t_st
   ORC_CATCH
 }
 
+/* find_MRCA_of (op 0) / descends_from (op 1) on the tree of one part, query by query; -1 = k_no_node (phylo_tree.cpp:204-280, 292-299) */
+int orc_tree_query(orc_engine* e, int part_id, int op, int n, const int* a, const int* b, int* out) {
+  ORC_TRY
+  const Phylo_tree& tree = e->parts.at(part_id)->subrun->tree;
+  for (int i = 0; i < n; ++i) out[i] = op == 0 ? (int)find_MRCA_of(tree, (Node_index)a[i], (Node_index)b[i]) : (descends_from(tree, (Node_index)a[i], (Node_index)b[i]) ? 1 : 0);
+  ORC_CATCH
+}
+
 int orc_get_totals(orc_engine* e, double* log_G, double* log_aug) {
   ORC_TRY
   double g = 0.0, a = 0.0;

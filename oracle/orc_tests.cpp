@@ -1427,6 +1427,53 @@ TEST(fix_up_missations_reference_cases) {
   }
 }
 
+// phylo_tree_tests.cpp:365-525: find_MRCA_of and descends_from over every pair of {a, b, c, x, r, no node} of the fixture tree, with
+// the fixture's times and with all times equal (where the walk can no longer be steered by time), plus the tree-location forms.
+TEST(find_MRCA_of_and_descends_from_reference_tables) {
+  const Node_index order[6] = {a_, b_, c_, x_, r_, k_no_node};
+  const Node_index N = k_no_node;
+  const Node_index mrca[6][6] = {{a_, x_, r_, x_, r_, N}, {x_, b_, r_, x_, r_, N}, {r_, r_, c_, r_, r_, N}, {x_, x_, r_, x_, r_, N}, {r_, r_, r_, r_, r_, N}, {N, N, N, N, N, N}};
+  const bool desc[6][6] = {{1, 0, 0, 1, 1, 1}, {0, 1, 0, 1, 1, 1}, {0, 0, 1, 0, 1, 1}, {0, 0, 0, 1, 1, 1}, {0, 0, 0, 0, 1, 1}, {0, 0, 0, 0, 0, 1}};
+  for (int equal_times = 0; equal_times < 2; ++equal_times) {
+    auto t = phylo_tree_tests_complex_tree();
+    if (equal_times) for (int n = 0; n < t.size(); ++n) { t.at(n).t = 0.0; if (t.at(n).is_tip()) t.at(n).t_min = t.at(n).t_max = 0.0; }
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) EXPECT(find_MRCA_of(t, order[i], order[j]) == mrca[i][j]);
+    if (!equal_times) for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) EXPECT(descends_from(t, order[i], order[j]) == desc[i][j]);
+  }
+  auto t = phylo_tree_tests_complex_tree();
+  auto node_loc = [&](Node_index n) { return Phylo_tree_loc{n, t.at(n).t}; };
+  EXPECT(find_MRCA_of(t, Phylo_tree_loc{a_, 1.0}, Phylo_tree_loc{a_, 1.0}) == node_loc(a_));
+  EXPECT(find_MRCA_of(t, Phylo_tree_loc{a_, 1.0}, Phylo_tree_loc{a_, 0.5}) == (Phylo_tree_loc{a_, 0.5}));
+  EXPECT(find_MRCA_of(t, Phylo_tree_loc{a_, 0.5}, Phylo_tree_loc{b_, 1.0}) == node_loc(x_));
+  EXPECT(find_MRCA_of(t, Phylo_tree_loc{a_, 0.5}, Phylo_tree_loc{c_, 1.0}) == node_loc(r_));
+  EXPECT(find_MRCA_of(t, Phylo_tree_loc{a_, 0.5}, Phylo_tree_loc{x_, 0.0}) == node_loc(x_));
+  EXPECT(find_MRCA_of(t, Phylo_tree_loc{a_, 0.5}, Phylo_tree_loc{x_, -0.5}) == (Phylo_tree_loc{x_, -0.5}));
+  EXPECT(find_MRCA_of(t, Phylo_tree_loc{a_, 0.5}, Phylo_tree_loc{r_, -1.0}) == node_loc(r_));
+  EXPECT(find_MRCA_of(t, Phylo_tree_loc{a_, 0.5}, Phylo_tree_loc{r_, -1.5}) == (Phylo_tree_loc{r_, -1.5}));
+  const struct { Phylo_tree_loc x, a; bool expect; } locs[] = {
+      {{a_, 1.0}, {a_, 1.0}, true}, {{a_, 1.0}, {a_, 0.5}, true}, {{a_, 0.5}, {a_, 1.0}, false}, {{a_, 0.5}, {b_, 1.0}, false}, {{a_, 0.5}, {c_, 1.0}, false},
+      {{a_, 0.5}, {x_, 0.0}, true}, {{a_, 0.5}, {x_, -0.5}, true}, {{a_, 0.5}, {r_, -1.0}, true}, {{a_, 0.5}, {r_, -1.5}, true}};
+  for (auto& q : locs) EXPECT(descends_from(t, q.x, q.a) == q.expect);
+}
+// phylo_tree_tests.cpp:287-363, 527-537: what the integrity check accepts (the fixture; two mutations of one site on one branch) and
+// every broken tree the reference's assert_mutation_consistency / assert_missation_consistency tests expect to die on.
+TEST(phylo_tree_integrity_reference_cases) {
+  EXPECT(check_phylo_tree_integrity(phylo_tree_tests_complex_tree()).empty());
+  { auto t = phylo_tree_tests_complex_tree(); t.at(x_).mutations = {Mutation{sA, 0, sC, -0.75}, Mutation{sC, 0, sT, -0.25}}; EXPECT(check_phylo_tree_integrity(t).empty()); }
+  const Mutation bad_muts[] = {
+      Mutation{sA, 0, sA, -0.5},    // from == to
+      Mutation{sA, -15, sT, -0.5},  // site < 0
+      Mutation{sA, 15, sT, -0.5},   // site >= genome size
+      Mutation{sA, 0, sT, -1.5},    // before the parent's time
+      Mutation{sA, 0, sT, +1.5},    // after the node's time
+      Mutation{sC, 0, sT, -0.5}};   // `from` is not the state above (the root has A at site 0)
+  for (auto& m : bad_muts) { auto t = phylo_tree_tests_complex_tree(); t.at(x_).mutations = {m}; EXPECT(!check_phylo_tree_integrity(t).empty()); }
+  { auto t = phylo_tree_tests_complex_tree(); t.at(a_).missations.clear(); miss(t, a_, {{2, sA}}); EXPECT(!check_phylo_tree_integrity(t).empty()); }   // below A2N of r->x
+  { auto t = phylo_tree_tests_complex_tree(); t.at(x_).missations.clear(); miss(t, x_, {{0, sA}}); EXPECT(!check_phylo_tree_integrity(t).empty()); }   // A0T is on the same branch
+  { auto t = phylo_tree_tests_complex_tree(); t.at(x_).missations.clear(); miss(t, x_, {{1, sA}}); t.at(c_).missations.clear(); EXPECT(!check_phylo_tree_integrity(t).empty()); }   // A1G on x->b below it
+  { auto t = phylo_tree_tests_complex_tree(); t.at(x_).missations.clear(); miss(t, x_, {{2, sA}}); t.at(c_).missations.clear(); miss(t, c_, {{2, sA}}); EXPECT(!check_phylo_tree_integrity(t).empty()); }   // on every branch out of r
+}
+
 TEST(build_usher_like_tree_reproduces_its_tip_descriptors) {
   for (int seed = 0; seed < 8; ++seed) {
     emat::SynthParams p; p.num_tips = 12 + 37 * seed; p.num_sites = seed % 2 ? 300 : 2000; p.mu = (seed % 3 ? 6e-4 : 2e-3) / 365.0 * 365.0 / 365.0; p.gaps_per_tip = seed % 4; p.mean_gap_len = 25;

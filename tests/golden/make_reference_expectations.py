@@ -10,7 +10,8 @@ the numbers.  Covered:
                                        Const, Exp (+ min_pop) and Skygrid (staircase, log-linear) models, and the
                                        constructor arguments the reference rejects (std::invalid_argument);
   * tests/interval_set_tests.cpp       inserts, contains, merge, intersect, subtract, is_subset_of, slow_elements;
-  * tests/scalable_coalescent_tests.cpp  the `log_prior` case: node times, tip flags and the three expected priors.
+  * tests/scalable_coalescent_tests.cpp  the `log_prior` case: node times, tip flags and the three expected priors;
+  * tests/phylo_tree_tests.cpp         the fixture tree's topology and times, and the find_MRCA_of / descends_from tables over its nodes.
 
 Not covered here (kept as C++ in oracle/orc_tests.cpp, which restates the fixtures): tests that build trees
 (tree_editing, spr_study, spr_move, phylo_tree_calc, missation_map, site_deltas), printing and derivative tests (off the path).
@@ -219,12 +220,43 @@ def scalable_coalescent_case():
     return {"test": name, "pop": env["pop"], "num_tips": int(env["num_tips"]), "t_ref": 0.0, "t_step": 1.0, "stages": stages}
 
 
+def phylo_tree_query_cases():
+    """tests/phylo_tree_tests.cpp: the fixture tree of Phylo_tree_complex_test (topology and node times only) and the tables of
+    find_MRCA_of(tree, P, Q) / descends_from(tree, X, A) over pairs of its nodes and k_no_node (-1), with the fixture's times
+    and with every time set to 0."""
+    path = os.path.join(REF, "tests", "phylo_tree_tests.cpp")
+    src = strip_comments(open(path).read())
+    fx = src[src.index("class Phylo_tree_complex_test"):]
+    fx = fx[: fx.index("\n};") + 3]
+    idx = {m.group(1): int(m.group(2)) for m in re.finditer(r"static constexpr Node_index (\w+) = (\d+);", fx)}
+    idx["k_no_node"] = -1
+    n = len(idx) - 1
+    parent, kids, t = [-1] * n, [[-1, -1] for _ in range(n)], [0.0] * n
+    for m in re.finditer(r"tree\.at\((\w+)\)\.parent = (\w+);", fx): parent[idx[m.group(1)]] = idx[m.group(2)]
+    for m in re.finditer(r"tree\.at\((\w+)\)\.children = \{(\w+), (\w+)\};", fx): kids[idx[m.group(1)]] = [idx[m.group(2)], idx[m.group(3)]]
+    for m in re.finditer(r"tree\.at\((\w+)\)\.t = (?:tree\.at\(\w+\)\.t_min = tree\.at\(\w+\)\.t_max = )?(-?[0-9.]+);", fx): t[idx[m.group(1)]] = float(m.group(2))
+    root = idx[re.search(r"tree\.root = (\w+);", fx).group(1)]
+    blocks = {b[0]: b for b in test_blocks(path)}
+    def table(test, fn, pat_expect):
+        out = []
+        for m in re.finditer(r"EXPECT_THAT\(%s\(tree, (\w+), (\w+)\), %s\)" % (fn, pat_expect), blocks[test][2]):
+            e = m.group(3)
+            out.append([idx[m.group(1)], idx[m.group(2)], idx[e] if e in idx else int(e == "true")])
+        return out
+    mrca = table("find_MRCA_of_nodes", "find_MRCA_of", r"testing::Eq\((\w+)\)")
+    mrca_eq = table("find_MRCA_of_nodes_all_times_equal", "find_MRCA_of", r"testing::Eq\((\w+)\)")
+    desc = table("descends_from_nodes", "descends_from", r"(true|false)")
+    assert len(mrca) == 36 and len(mrca_eq) == 36 and len(desc) == 36, (len(mrca), len(mrca_eq), len(desc))
+    return {"names": {k: v for k, v in idx.items()}, "root": root, "parent": parent, "children": kids, "t": t,
+            "find_MRCA_of": mrca, "find_MRCA_of_all_times_equal": mrca_eq, "descends_from": desc}
+
+
 if __name__ == "__main__":
     pop, sk1 = pop_model_cases()
     iv, sk2 = interval_set_cases()
     sc = scalable_coalescent_case()
     out = {"source": "expectations of the reference's tests/pop_model_tests.cpp, interval_set_tests.cpp, scalable_coalescent_tests.cpp, evaluated by tests/golden/make_reference_expectations.py",
-           "pop_model": pop, "interval_set": iv, "scalable_coalescent": sc,
+           "pop_model": pop, "interval_set": iv, "scalable_coalescent": sc, "phylo_tree_queries": phylo_tree_query_cases(),
            "not_converted": {"pop_model_tests.cpp": sk1, "interval_set_tests.cpp": sk2, "why": "accessors, printing, iterator-identity and derivative expectations (off the hot path)"}}
     json.dump(out, open(OUT, "w"), indent=0)
     print("pop_model cases %d (skipped %d) | interval_set cases %d (skipped %d) | scalable_coalescent stages %d" % (len(pop), sk1, len(iv), sk2, len(sc["stages"])))

@@ -35,6 +35,7 @@ def lib():
             "orc_part_get_stats": [E, C.c_int, P(_PartStatsC)], "orc_part_get_trace": [E, C.c_int, P(C.c_int), P(dbl)],
             "orc_part_check": [E, C.c_int, C.c_char_p, C.c_int],
             "orc_Ttwiddle_l": [E, C.c_int, P(dbl)], "orc_num_muts_l": [E, P(C.c_int)], "orc_scalable_log_prior": [E, C.c_int, dbl, dbl, P(dbl)],
+            "orc_tree_query": [E, C.c_int, C.c_int, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int)],
         }
         for n, a in sigs.items():
             f = getattr(L, n); f.argtypes = a; f.restype = C.c_int
@@ -146,6 +147,11 @@ class OracleEngine:
         v = C.c_double()
         self._ck(self.L.orc_scalable_log_prior(self.h, part, t_ref, t_step, C.byref(v)), "scalable_log_prior")
         return v.value
+
+    def tree_query(self, part, op, a, b):
+        a = np.ascontiguousarray(a, np.int32); b = np.ascontiguousarray(b, np.int32); out = np.zeros_like(a); ip = C.POINTER(C.c_int)
+        self._ck(self.L.orc_tree_query(self.h, part, op, a.shape[0], a.ctypes.data_as(ip), b.ctypes.data_as(ip), out.ctypes.data_as(ip)), "tree_query")
+        return out
 
     def part_download(self, part):
         n, nm, ni, nf = C.c_int(), C.c_int(), C.c_int(), C.c_int()

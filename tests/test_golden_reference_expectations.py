@@ -184,3 +184,42 @@ def test_device_population_models_against_the_reference_expectations():
         assert checked >= 80
     finally:
         b.close()
+
+
+def _fixture_tree(q, all_times_equal):
+    n = len(q["parent"])
+    tree = d.FlatTree.empty(n, 0, 0, 0)
+    tree.root = q["root"]; tree.parent[:] = q["parent"]
+    tree.child0[:] = [k[0] for k in q["children"]]; tree.child1[:] = [k[1] for k in q["children"]]
+    tree.t[:] = 0.0 if all_times_equal else q["t"]
+    tips = [i for i in range(n) if q["children"][i][0] < 0]
+    tree.t_min[tips] = tree.t[tips].astype(np.float32); tree.t_max[tips] = tree.t[tips].astype(np.float32)
+    return tree
+
+
+def _tree_queries_through(engine_cls, **kw):
+    """phylo_tree_tests.cpp:365-525 as data: the three tables of the reference over its fixture tree (with its times, and with
+    every time zero), asked of `engine_cls` query by query."""
+    q = G["phylo_tree_queries"]
+    for table, op, equal in (("find_MRCA_of", 0, False), ("find_MRCA_of_all_times_equal", 0, True), ("descends_from", 1, False)):
+        rows = np.array(q[table], np.int32)
+        assert rows.shape == (36, 3)
+        e = engine_cls(50, **kw)
+        try:
+            e.set_ref_sequence(np.zeros(50, np.uint8)); e.set_hky(1e-3, 2.0, (0.25, 0.25, 0.25, 0.25)); e.set_flags(3.0)
+            e.upload_parts([_fixture_tree(q, equal)], [True], [1])
+            e.build_coalescent_parts(d.PopModel.const(10.0), 0, 1.0)
+            got = e.debug_tree_query(0, op, rows[:, 0], rows[:, 1]) if isinstance(e, d.EmatBackend) else e.tree_query(0, op, rows[:, 0], rows[:, 1])
+        finally:
+            e.close()
+        assert got.tolist() == rows[:, 2].tolist(), (table, [(r.tolist(), int(g)) for r, g in zip(rows, got) if r[2] != g])
+
+
+def test_tree_query_expectations_of_the_reference():
+    _tree_queries_through(oracle_ffi.OracleEngine)
+
+
+@pytest.mark.gpu
+def test_device_tree_queries_against_the_reference_expectations():
+    """The same tables against the moves' own find_MRCA_of / descends_from on the device (emat_debug_tree_query)."""
+    _tree_queries_through(d.EmatBackend)
