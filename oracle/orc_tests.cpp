@@ -1474,6 +1474,36 @@ TEST(phylo_tree_integrity_reference_cases) {
   { auto t = phylo_tree_tests_complex_tree(); t.at(x_).missations.clear(); miss(t, x_, {{2, sA}}); t.at(c_).missations.clear(); miss(t, c_, {{2, sA}}); EXPECT(!check_phylo_tree_integrity(t).empty()); }   // on every branch out of r
 }
 
+// sequence_overlay_tests.cpp:17-79, 198-208 -- the semantics the builder relies on (orc_build.hpp's Seq_overlay): reads fall through
+// to the base sequence, a write that differs is one delta, a write that restores the base state is none.
+TEST(sequence_overlay_reference_semantics) {
+  { const std::vector<State> base; Seq_overlay o(base); EXPECT(o.deltas.empty()); EXPECT(o.base == &base); }
+  { const std::vector<State> base{sA, sC, sG, sT}; const Seq_overlay o(base);
+    EXPECT(o.get(0) == sA); EXPECT(o.get(1) == sC); EXPECT(o.get(2) == sG); EXPECT(o.get(3) == sT); EXPECT(o.deltas.empty()); }
+  { const std::vector<State> base{sA, sA}; Seq_overlay o(base); o.set(1, sC);
+    EXPECT(o.get(0) == sA); EXPECT(o.get(1) == sC); EXPECT(o.deltas.size() == 1); }
+  { const std::vector<State> base{sA, sA}; Seq_overlay o(base); o.set(1, sC); o.set(1, base[1]);
+    EXPECT(o.get(0) == sA); EXPECT(o.get(1) == sA); EXPECT(o.deltas.empty()); }
+  { const std::vector<State> base{sA, sC, sG, sT}; Seq_overlay o(base); o.set(0, sT); o.set(3, sA);
+    std::vector<State> m; for (int l = 0; l < 4; ++l) m.push_back(o.get(l));
+    EXPECT(m == (std::vector<State>{sT, sC, sG, sA})); EXPECT(base == (std::vector<State>{sA, sC, sG, sT})); }
+}
+
+// tree_tests.cpp:88-162: the orders in which the path's traversals visit a three-node tree (root a = index 2 with children b = 1, c = 0)
+// and visit nothing of an empty one.
+TEST(tree_traversal_orders_of_the_reference) {
+  { Phylo_tree t(0); EXPECT(pre_order(t).empty()); EXPECT(post_order(t).empty()); int visits = 0; traversal(t, [&](Node_index, int) { ++visits; }); EXPECT(visits == 0); }
+  Phylo_tree t(3);
+  const Node_index c = 0, b = 1, a = 2;
+  t.ref_sequence = {sA}; t.root = a;
+  set_inner(t, a, k_no_node, b, c, 0.0); set_tip(t, b, a, 1.0); set_tip(t, c, a, 1.0);
+  EXPECT(pre_order(t) == (std::vector<Node_index>{a, b, c}));
+  EXPECT(post_order(t) == (std::vector<Node_index>{b, c, a}));
+  std::vector<std::pair<Node_index, int>> seen;
+  traversal(t, [&](Node_index n, int children_so_far) { seen.push_back({n, children_so_far}); });
+  EXPECT(seen == (std::vector<std::pair<Node_index, int>>{{a, 0}, {b, 0}, {a, 1}, {c, 0}, {a, 2}}));
+}
+
 TEST(build_usher_like_tree_reproduces_its_tip_descriptors) {
   for (int seed = 0; seed < 8; ++seed) {
     emat::SynthParams p; p.num_tips = 12 + 37 * seed; p.num_sites = seed % 2 ? 300 : 2000; p.mu = (seed % 3 ? 6e-4 : 2e-3) / 365.0 * 365.0 / 365.0; p.gaps_per_tip = seed % 4; p.mean_gap_len = 25;
