@@ -106,6 +106,12 @@ __device__ inline void wave_copy16(uint8_t* dst, const uint8_t* src, uint32_t by
   const uint4* s = (const uint4*)src; uint4* d = (uint4*)dst;
   for (uint32_t i = lane; i < bytes / 16; i += k_wave) d[i] = s[i];
 }
+// The same copy with stores that are written through to where every XCD sees them (agent-scope atomics, 8 bytes each): what a
+// ticket hands to the next one goes out this way, so that handing over needs no write-back of the XCD's whole L2 (below).
+__device__ inline void wave_copy8_through(uint8_t* dst, const uint8_t* src, uint32_t bytes, int lane) {
+  const uint64_t* s = (const uint64_t*)src; uint64_t* d = (uint64_t*)dst;
+  for (uint32_t i = lane; i < bytes / 8; i += k_wave) __hip_atomic_store(&d[i], s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ inline double wave_sum(double x) {
   for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, k_wave);
   return __shfl(x, 0, k_wave);
@@ -166,6 +172,12 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
   const int chunk = a.chunks > 1 ? (int)blockIdx.x / a.class_stride : 0, slot = a.chunks > 1 ? (int)blockIdx.x % a.class_stride : (int)blockIdx.x;
   if (a.chunks > 1 && slot >= a.class_count) return;   // padding: the stride is a multiple of 8 so that a part's tickets land on one XCD
   const int part = a.order[slot];
+  // Per-part words that one ticket of a part writes and the next reads (status, chain ticks): agent-scope atomics, which every
+  // XCD sees without a cache write-back.
+  auto st_status = [&](int32_t v) { __hip_atomic_store(&a.part_status[part], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto ld_status = [&]() -> int32_t { return __hip_atomic_load(&a.part_status[part], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto st_ticks = [&](int64_t v) { __hip_atomic_store(&a.part_ticks[part], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto ld_ticks = [&]() -> int64_t { return __hip_atomic_load(&a.part_ticks[part], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   uint8_t* gslab = a.slabs + a.slab_off[part];
   SlabHeader* gh = (SlabHeader*)gslab;
   const int64_t pass_target = a.moves_for_part ? a.moves_for_part[part] : a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0) + (part < a.one_more_below ? 1 : 0);
@@ -177,7 +189,7 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
       if (lane == 0) {
         int spins = 0;
         while (__hip_atomic_load(&a.chunk_done[part], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(64); ++spins; }
-        if (spins >= (1 << 22)) { a.part_status[part] = k_part_internal; *lds_flag = -1; } else *lds_flag = 0;
+        if (spins >= (1 << 22)) { st_status(k_part_internal); *lds_flag = -1; } else *lds_flag = 0;
       }
       __syncthreads();
       if (*lds_flag == -1) return;
@@ -188,10 +200,11 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
   } else done_at_start = gh->moves_done;
   const uint32_t area = a.lds_slab_bytes;
   const bool can_stage = tables_staged && area != 0 && gh->off_nodes == (uint32_t)sizeof(SlabHeader);
-  if (lane == 0 && chunk == 0) { a.part_ticks[part] = 0; a.part_ticks[a.num_parts + part] = (int64_t)wall_clock64(); }   // duration, start (emat_debug_part_ticks)
+  if (lane == 0 && chunk == 0) { st_ticks(0); a.part_ticks[a.num_parts + part] = (int64_t)wall_clock64(); }   // duration, start (emat_debug_part_ticks)
   // Up to two legs: a part whose USED state fits the staging area but whose heap capacity does not is staged whole with
   // an LDS-local heap limit; should its lists outgrow that, it is written back and finishes with its heap in HBM.
   bool allow_whole = true;
+  bool plain_hbm_writes = false;   // some leg of this ticket changed the part's state in HBM with ordinary (cached) stores
   for (int leg = 0; leg < 2; ++leg) {
     __syncthreads();
     const uint32_t hbm_heap_end = gh->heap_end;
@@ -204,6 +217,7 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
       else if (want <= area) lds_heap_end = want;
     }
     const bool staged = lds_heap_end != 0;
+    if (!staged) plain_hbm_writes = true;   // this leg edits lists (or everything) in the HBM slab itself, with ordinary stores
     const bool prefix = can_stage && !staged && gh->heap_begin <= area;
     // stage the persistent state (header, nodes, cells, trace, list heap) -- or, for a part too large for that, its
     // fixed-size prefix up to the list heap; scratch always stays in HBM
@@ -244,7 +258,7 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
         if (area + a.lds_scratch_bytes > (uint32_t)sizeof(SlabHeader)) { c.A = lds_slab; c.a_end = area + a.lds_scratch_bytes - (uint32_t)sizeof(SlabHeader); }   // nothing of the part is staged: the whole dynamic block is arena
       }
       // (a later ticket of a part whose earlier one had to stop does nothing: the host gives the part more room and the rest of its moves)
-      const bool stopped_before = chunk > 0 && a.part_status[part] != 0;
+      const bool stopped_before = chunk > 0 && ld_status() != 0;
       ((dev::Ctx*)(emat_lds_ctx))->moves_left = (H->status == 0 && !stopped_before) ? target - (H->moves_done - done_at_start) : 0;   // the three Ctx types share one layout
       tick0 = wall_clock64();
       if (raise_prio) __builtin_amdgcn_s_setprio(3);
@@ -272,27 +286,27 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
       H->alg_bytes += c.bytes;
       const int64_t dt = (int64_t)(wall_clock64() - tick0);
       H->device_ticks += dt;
-      a.part_ticks[part] += dt;
-      if (!(chunk > 0 && a.part_status[part] != 0)) a.part_status[part] = H->status;   // an idle ticket leaves the earlier ticket's verdict alone
+      st_ticks(ld_ticks() + dt);
+      if (!(chunk > 0 && ld_status() != 0)) st_status(H->status);   // an idle ticket leaves the earlier ticket's verdict alone
       int again = 0;
       if (staged) {
         H->heap_end = hbm_heap_end;
-        if (H->status == k_part_need_space && lds_heap_end < hbm_heap_end && H->heap_top <= hbm_heap_end) { H->status = 0; a.part_status[part] = 0; again = 1; }
+        if (H->status == k_part_need_space && lds_heap_end < hbm_heap_end && H->heap_top <= hbm_heap_end) { H->status = 0; st_status(0); again = 1; }
         // A list outgrew the LDS-local heap limit INSIDE a move: the staged state is lost, but nothing of this leg has
         // reached the HBM copy of the slab yet (moves only write HBM scratch), and the chain is a deterministic function
         // of that copy.  Drop the LDS state and run the leg again from HBM with the heap at its full capacity there.
-        else if (H->status == k_part_overflow && lds_heap_end < hbm_heap_end) { a.part_status[part] = 0; again = 2; }
+        else if (H->status == k_part_overflow && lds_heap_end < hbm_heap_end) { st_status(0); again = 2; }
         // The root part's coalescent grid outgrew its capacity (the root wandered further into the past than the room the
         // host left): the same argument -- the HBM copy still is the consistent state this launch found -- lets the
         // host re-materialise the part with more cells and run its moves again (first leg only: a second leg follows a
         // write-back).
-        else if (H->status == k_part_cell_overflow && leg == 0) { a.part_status[part] = k_part_need_cells; again = 3; }
+        else if (H->status == k_part_cell_overflow && leg == 0) { st_status(k_part_need_cells); again = 3; }
         // Anything else that overflowed inside a move of a staged leg (the heap at its full capacity, the scratch region):
         // the HBM copy is the leg's starting state just the same -- more room from the host, and the moves again.
-        else if (H->status == k_part_overflow) { a.part_status[part] = k_part_need_space; again = 3; }
+        else if (H->status == k_part_overflow) { st_status(k_part_need_space); again = 3; }
       } else if (snap != nullptr && (H->status == k_part_overflow || H->status == k_part_cell_overflow)) {
         // the leg ran on the HBM slab: its starting state goes back in from the copy taken above
-        a.part_status[part] = H->status == k_part_cell_overflow ? k_part_need_cells : k_part_need_space; again = 4;
+        st_status(H->status == k_part_cell_overflow ? k_part_need_cells : k_part_need_space); again = 4;
       }
       *lds_flag = again;
     }
@@ -300,7 +314,8 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
     const int again_all = *lds_flag;
     if (again_all < 2) {
       const uint32_t out_bytes = staged ? ((const SlabHeader*)emat_lds_hdr)->heap_top : (prefix ? staged_bytes : 0u);
-      if (out_bytes) { wave_copy16(gslab, emat_lds_hdr, (uint32_t)sizeof(SlabHeader), lane); wave_copy16(gslab + sizeof(SlabHeader), lds_slab, out_bytes - (uint32_t)sizeof(SlabHeader), lane); }
+      if (out_bytes && a.chunks > 1) { wave_copy8_through(gslab, emat_lds_hdr, (uint32_t)sizeof(SlabHeader), lane); wave_copy8_through(gslab + sizeof(SlabHeader), lds_slab, out_bytes - (uint32_t)sizeof(SlabHeader), lane); }
+      else if (out_bytes) { wave_copy16(gslab, emat_lds_hdr, (uint32_t)sizeof(SlabHeader), lane); wave_copy16(gslab + sizeof(SlabHeader), lds_slab, out_bytes - (uint32_t)sizeof(SlabHeader), lane); }
     }
     if (again_all == 4) { wave_copy16(gslab, snap, (((const SlabHeader*)snap)->heap_top + 15u) & ~15u, lane); break; }
     if (again_all == 0 || again_all == 3) break;
@@ -308,7 +323,14 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
   }
   if (a.chunks > 1) {   // hand the part to its next ticket: the slab is in HBM again
     __syncthreads();
-    if (lane == 0) __hip_atomic_store(&a.chunk_done[part], chunk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // An agent-scope release writes back every dirty line of this XCD's L2 -- among them the private-memory lines of the 500
+    // other chains resident there -- once per ticket: half of a pass's HBM write traffic.  A ticket whose
+    // part was staged has sent everything the next ticket reads through write-through stores (the slab image, status, ticks):
+    // it only waits for those to be acknowledged.  One that edited lists in HBM directly keeps the full release.
+    if (lane == 0) {
+      if (plain_hbm_writes) __hip_atomic_store(&a.chunk_done[part], chunk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); __hip_atomic_store(&a.chunk_done[part], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
   }
 }
 __global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY EMAT_NOTAIL k_run_moves(KernelArgs a) { run_moves_body<false>(a); }

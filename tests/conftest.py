@@ -22,12 +22,19 @@ def _gpu_count():
         return 0
 
 
+_gpu_tests_will_run = False
+
+
 def pytest_collection_modifyitems(config, items):
-    gpu_items = [it for it in items if "gpu" in it.keywords]
+    global _gpu_tests_will_run
+    gpu_items = [it for it in items if "gpu" in it.keywords and not any(m.name == "skip" for m in it.iter_markers())]
+    selected = config.getoption("-m") or ""
     if gpu_items and _gpu_count() == 0:
         skip = pytest.mark.skip(reason="no HIP device: the engine has no CPU fallback (run with -m gpu on an MI355X)")
         for it in gpu_items:
             it.add_marker(skip)
+    elif gpu_items and "not gpu" not in selected:
+        _gpu_tests_will_run = True
 
 
 @pytest.fixture(scope="session", autouse=True)
@@ -37,4 +44,9 @@ def _built():
     import delphy_amd
     if not os.path.exists(delphy_amd.library_path()):
         delphy_amd.build_library()
+    if _gpu_tests_will_run:
+        # torch brings a HIP runtime of its own: it is initialised before the engine's library first touches the device, in whatever
+        # order the tests run (the other way round, `torch.cuda` found no device in a process that had been using the engine for a while)
+        import torch
+        torch.cuda.init()
     yield
