@@ -188,7 +188,9 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
       // bounded all the same -- about ten seconds -- and a part whose turn never came is reported, not waited for)
       if (lane == 0) {
         int spins = 0;
+        const uint64_t w0 = wall_clock64();
         while (__hip_atomic_load(&a.chunk_done[part], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(64); ++spins; }
+        if (spins > 0) atomicAdd((unsigned long long*)&a.chunk_done[((a.num_parts + 1) & ~1) + 2 * (blockIdx.x & 63)], (unsigned long long)(wall_clock64() - w0));   // (EMAT_VERBOSE: slot time spent waiting)
         if (spins >= (1 << 22)) { st_status(k_part_internal); *lds_flag = -1; } else *lds_flag = 0;
       }
       __syncthreads();
@@ -853,7 +855,7 @@ struct emat_backend {
   DevBuf<uint8_t> d_headers; std::vector<uint8_t> h_headers; bool headers_current = false;
   GTreeHost gt;                     // the whole tree, when it lives in HBM (emat_tree_upload)
   BuiltTree built;                  // what emat_tree_build_usher_like made, until it is fetched (emat_tree_built_get)
-  int cfg_chunks = 2;               // EMAT_CHUNKS (tuning knob): tickets per part and pass (main class; measured at C4: 1 -> 311, 2 -> 338, 3 -> 340, 4 -> 331, 8 -> 301 M moves/s)
+  int cfg_chunks = 3;               // EMAT_CHUNKS (tuning knob): tickets per part and pass (main class; measured at C4 once a ticket's release no longer wrote the L2 back: 2 -> 378, 3 -> 383, 6 -> 382, 10 -> 379, 16 -> 365, 32 -> 322 M moves/s; before: 1 -> 311, 2 -> 338, 3 -> 340, 4 -> 331, 8 -> 301)
   bool cfg_chunks_forced = false;   // EMAT_CHUNKS was given: tickets also when the parts are fewer than the wave slots (tests)
   DevBuf<int32_t> d_chunk_done;
   int cfg_parts_per_cu = 0;         // EMAT_PARTS_PER_CU (tuning knob): workgroups of the main class per CU, instead of the percentile rule
@@ -1090,6 +1092,11 @@ emat_status finish_pass(emat_backend* h) {
       double sum = 0; int64_t first = INT64_MAX, last = 0;
       for (size_t p = 0; p < n; ++p) { sum += (double)ticks[p]; first = std::min(first, ticks[n + p]); last = std::max(last, ticks[n + p] + ticks[p]); }
       float kms = 0.f; (void)hipEventElapsedTime(&kms, h->ev_start, h->ev_stop);
+      if (h->d_chunk_done.n >= n + 130) {
+        std::vector<int32_t> w(130); HIP_TRY(hipMemcpy(w.data(), h->d_chunk_done.p + n, 130 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        double wait = 0; for (int i = 0; i < 64; ++i) { unsigned long long v; memcpy(&v, &w[(n & 1) + 2 * i], 8); wait += (double)v; }   // (the counters start at the next even index)
+        fprintf(stderr, "[emat] tickets waited %.2f s of slot time for their predecessors (%.1f %% of %d slots x pass)\n", wait / 1e8, 100.0 * wait / 1e5 / (kms * 16.0 * h->num_cus), 16 * h->num_cus);
+      }
       fprintf(stderr, "[emat] pass: %.1f ms on the device (first start to last end %.1f ms) | chains: mean %.2f ms, slowest", kms, (last - first) / 1e5, sum / n / 1e5);
       for (size_t k = 0; k < std::min<size_t>(4, n); ++k) fprintf(stderr, " %.1f ms from %.1f (part %d, %d nodes%s)", ticks[idx[k]] / 1e5, (ticks[n + idx[k]] - first) / 1e5, idx[k], h->parts[idx[k]].n_nodes, idx[k] == h->root_part ? ", root part" : "");
       std::partial_sort(idx.begin(), idx.begin() + std::min<size_t>(3, n), idx.end(), [&](int a, int b) { return ticks[n + a] + ticks[a] > ticks[n + b] + ticks[b]; });
@@ -1415,7 +1422,7 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
     // itself from the start and a second ticket could only wait behind its first while holding another slot.
     const int main_count = h->class_begin[h->num_classes] - h->class_begin[h->num_classes - 1];
     const int chunks = (counts == nullptr && per_part >= 4 * h->cfg_chunks && (h->cfg_chunks_forced || main_count > 4 * EMAT_WAVES_PER_EU * h->num_cus)) ? h->cfg_chunks : 1;
-    if (chunks > 1) { HIP_TRY(h->d_chunk_done.alloc(h->parts.size())); HIP_TRY(hipMemsetAsync(h->d_chunk_done.p, 0, h->parts.size() * sizeof(int32_t), h->stream)); }
+    if (chunks > 1) { HIP_TRY(h->d_chunk_done.alloc(h->parts.size() + 130)); HIP_TRY(hipMemsetAsync(h->d_chunk_done.p, 0, (h->parts.size() + 130) * sizeof(int32_t), h->stream)); }   // + 64 eight-byte counters of waiting time
     HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
     for (int c = 0; c < h->num_classes; ++c) {
       const int lo = h->class_begin[c], cnt = h->class_begin[c + 1] - lo;
