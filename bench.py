@@ -330,7 +330,7 @@ def main():
                                total_parts, sc.tree.num_nodes, args.moves_per_part),
                 "parts_per_gpu": local_parts, "max_part_nodes": args.max_part_nodes,
                 "lds_staging": not args.no_lds,
-                "tickets_per_part_and_pass": int(os.environ.get("EMAT_CHUNKS", "3")),
+                "tickets_per_part_and_pass": int(os.environ.get("EMAT_CHUNKS", "4")),
                 "parallelism": "parts sharded over %d GPU(s), one wavefront per part" % world,
                 "collectives": ("gloo on one shared GPU (plumbing check)" if shared_gpu else "RCCL, world size %d" % dist.get_world_size()) if world > 1 else "none (one rank)",
                 "emat_build_id": build_id,

@@ -92,7 +92,7 @@ struct KernelArgs {
   // A pass cut into `chunks` tickets per part (EMAT_CHUNKS): workgroup b runs ticket b / class_stride of part order[b % class_stride];
   // ticket c of a part starts when ticket c - 1 has written the slab back (chunk_done[part] == c).  Shorter tickets pack the
   // slots better at the end of a pass; the chain -- one RNG stream per part, state in the slab -- is the same chain.
-  int32_t chunks, class_count, class_stride;
+  int32_t chunks, class_count, class_stride, taper;
   int32_t* chunk_done;            // [num_parts], zeroed before the launch
   // Room for a copy of every slab's persistent prefix, at the slab's own offset: a leg that runs on the HBM slab itself (part
   // not staged whole) saves it there first, so that a container overflowing INSIDE a move can be answered by putting the
@@ -197,7 +197,10 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
       if (*lds_flag == -1) return;
     } else if (lane == 0) gh->pad0 = (uint32_t)gh->moves_done;   // where the pass picked the part up (low bits: a pass is far shorter than 2^32 moves)
     __syncthreads();
-    target = pass_target * (chunk + 1) / a.chunks;   // cumulative over the tickets so far
+    // cumulative over the tickets so far.  The tickets of a part shrink in the ratio n : n-1 : ... : 1, so that the jobs that start
+    // last -- the ones a pass ends with -- are the shortest (equal tickets: EMAT_TICKET_TAPER=0)
+    if (a.taper) { const int64_t nn = a.chunks, done_w = (int64_t)(chunk + 1) * (2 * nn - chunk), all_w = nn * (nn + 1); target = chunk + 1 == a.chunks ? pass_target : pass_target * done_w / all_w; }
+    else target = pass_target * (chunk + 1) / a.chunks;
     done_at_start = gh->moves_done - (int64_t)(uint32_t)((uint32_t)gh->moves_done - gh->pad0);
   } else done_at_start = gh->moves_done;
   const uint32_t area = a.lds_slab_bytes;
@@ -855,7 +858,8 @@ struct emat_backend {
   DevBuf<uint8_t> d_headers; std::vector<uint8_t> h_headers; bool headers_current = false;
   GTreeHost gt;                     // the whole tree, when it lives in HBM (emat_tree_upload)
   BuiltTree built;                  // what emat_tree_build_usher_like made, until it is fetched (emat_tree_built_get)
-  int cfg_chunks = 3;               // EMAT_CHUNKS (tuning knob): tickets per part and pass (main class; measured at C4 once a ticket's release no longer wrote the L2 back: 2 -> 378, 3 -> 383, 6 -> 382, 10 -> 379, 16 -> 365, 32 -> 322 M moves/s; before: 1 -> 311, 2 -> 338, 3 -> 340, 4 -> 331, 8 -> 301)
+  bool cfg_taper = true;            // EMAT_TICKET_TAPER: tickets of a part in the ratio n : ... : 1 instead of equal
+  int cfg_chunks = 4;               // EMAT_CHUNKS (tuning knob): tickets per part and pass (main class; measured at C4 once a ticket's release no longer wrote the L2 back, equal tickets: 2 -> 378, 3 -> 384, 6 -> 382, 10 -> 379, 16 -> 365, 32 -> 322 M moves/s; tapered: 3 -> 390, 4 -> 392, 5 -> 388; before: 1 -> 311, 2 -> 338, 3 -> 340, 4 -> 331, 8 -> 301)
   bool cfg_chunks_forced = false;   // EMAT_CHUNKS was given: tickets also when the parts are fewer than the wave slots (tests)
   DevBuf<int32_t> d_chunk_done;
   int cfg_parts_per_cu = 0;         // EMAT_PARTS_PER_CU (tuning knob): workgroups of the main class per CU, instead of the percentile rule
@@ -1431,6 +1435,7 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
       b.order = a.order + lo; b.lds_slab_bytes = h->class_lds[c];
       // (only the main class: a side class has fewer workgroups than the device has room for, so all its tickets would be
       // resident at once and the waiting ones would sit on tens of KB of LDS each -- measured: cycles of 72 ms instead of 37)
+      b.taper = h->cfg_taper ? 1 : 0;
       b.chunks = c == main_class ? chunks : 1; b.class_count = cnt; b.class_stride = (cnt + 7) & ~7; b.chunk_done = h->d_chunk_done.p;
       const unsigned grid = b.chunks > 1 ? (unsigned)(b.chunks * b.class_stride) : (unsigned)cnt;
       hipStream_t sm = c == 0 ? h->stream : h->class_stream[c];
@@ -1478,6 +1483,7 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   if (const char* e = getenv("EMAT_GIANTS")) h->cfg_giants = atoi(e) != 0;
   if (const char* e = getenv("EMAT_SIDE_ARENA")) h->cfg_side_arena = (uint32_t)atoi(e);
   if (const char* e = getenv("EMAT_TREE_HOST_COALESCENT")) h->cfg_gt_host_coal = atoi(e) != 0;
+  if (const char* e = getenv("EMAT_TICKET_TAPER")) h->cfg_taper = atoi(e) != 0;
   if (const char* e = getenv("EMAT_CHUNKS")) { h->cfg_chunks = std::max(1, std::min(64, atoi(e))); h->cfg_chunks_forced = true; }
   if (const char* e = getenv("EMAT_PARTS_PER_CU")) h->cfg_parts_per_cu = std::max(0, std::min(4 * EMAT_WAVES_PER_EU, atoi(e)));
   if (const char* e = getenv("EMAT_ORDER_BY_TIME")) h->cfg_order_by_time = atoi(e) != 0;
