@@ -101,6 +101,7 @@ struct KernelArgs {
 };
 
 constexpr int k_wave = 64;
+constexpr int k_ticket_log = 8;   // tickets per part whose workgroup entry / exit ticks are kept (emat_debug_ticket_ticks)
 
 __device__ inline void wave_copy16(uint8_t* dst, const uint8_t* src, uint32_t bytes, int lane) {
   const uint4* s = (const uint4*)src; uint4* d = (uint4*)dst;
@@ -174,6 +175,7 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
   const int part = a.order[slot];
   // Per-part words that one ticket of a part writes and the next reads (status, chain ticks): agent-scope atomics, which every
   // XCD sees without a cache write-back.
+  if (lane == 0 && chunk < k_ticket_log) a.part_ticks[(size_t)(2 + 2 * chunk) * a.num_parts + part] = (int64_t)wall_clock64();   // the workgroup is resident from here ...
   auto st_status = [&](int32_t v) { __hip_atomic_store(&a.part_status[part], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   auto ld_status = [&]() -> int32_t { return __hip_atomic_load(&a.part_status[part], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   auto st_ticks = [&](int64_t v) { __hip_atomic_store(&a.part_ticks[part], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -326,6 +328,7 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
     if (again_all == 0 || again_all == 3) break;
     allow_whole = false;
   }
+  if (lane == 0 && chunk < k_ticket_log) a.part_ticks[(size_t)(3 + 2 * chunk) * a.num_parts + part] = (int64_t)wall_clock64();   // ... to here
   if (a.chunks > 1) {   // hand the part to its next ticket: the slab is in HBM again
     __syncthreads();
     // An agent-scope release writes back every dirty line of this XCD's L2 -- among them the private-memory lines of the 500
@@ -848,7 +851,7 @@ struct emat_backend {
   std::vector<double> sh_ktw, sh_popsize, sh_tsop; std::vector<int32_t> sh_nact;
   DevBuf<double> d_sh_ktw, d_sh_tsop; DevBuf<int32_t> d_sh_nact;
   SharedCells shared_dev{nullptr, nullptr, nullptr, 0};   // what make_args hands the kernels (the HBM-resident tree points it at its own grid arrays)
-  uint32_t cfg_side_arena = 0;              // EMAT_SIDE_ARENA (tuning knob): a part that would be left with less arena than this in the main area joins the giants' 8-per-CU class
+  uint32_t cfg_side_arena = 1;              // EMAT_SIDE_ARENA (tuning knob; 0 = off): a part that would be left with less arena than this in the main area joins the giants' 8-per-CU class.  The default, 1 byte, moves exactly the parts that cannot be staged WHOLE there (0.5 % at C4): with their lists in HBM they were the last chains of every pass (19.6 ms where the rest was done by 19.9: pass 21.5 -> 20.1 ms); 1-4 KB moves hundreds and loses
   bool cfg_giants = true;                   // EMAT_GIANTS (tuning knob): parts that cannot even stage their prefix get a class of their own
   double cfg_heap_per_node = 64.0;  // EMAT_HEAP_PER_NODE: heap bytes per node on top of slack x content
   uint32_t cfg_lds_scratch = 0;     // EMAT_LDS_SCRATCH (tuning knob): per-part LDS scratch arena; 0 = all scratch in HBM (measured best at C4)
@@ -1345,7 +1348,7 @@ emat_status materialize(emat_backend* h) {
   { emat_status st = upload_shared_cells(h); if (st) return st; }
   HIP_TRY(h->d_slabs.upload(h->h_slabs.data(), h->h_slabs.size()));
   HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
-  { std::vector<int64_t> z(2 * h->parts.size(), 0); HIP_TRY(h->d_part_ticks.upload(z.data(), z.size())); }
+  { std::vector<int64_t> z((2 + 2 * k_ticket_log) * h->parts.size(), 0); HIP_TRY(h->d_part_ticks.upload(z.data(), z.size())); }   // + entry / exit ticks of the first k_ticket_log tickets of every part
   { std::vector<int32_t> z(h->parts.size(), 0); HIP_TRY(h->d_part_status.upload(z.data(), z.size())); }
   h->slabs_on_device = true; h->host_slabs_current = true; h->derived_valid = false;
   return EMAT_OK;
@@ -2175,6 +2178,15 @@ emat_status emat_debug_part_ticks(emat_backend* h, int64_t* out_2n) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out_2n, h->d_part_ticks.p, sizeof(int64_t) * 2 * h->parts.size(), hipMemcpyDeviceToHost));
+  return EMAT_OK;
+}
+/* debugging aid: workgroup entry and exit ticks (100 MHz) of the first 8 tickets of every part in the last pass, out[(2 * ticket + {0, 1}) * num_parts + part] */
+emat_status emat_debug_ticket_ticks(emat_backend* h, int64_t* out_16n) {
+  if (!h || !out_16n || h->host_only || !h->slabs_on_device) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out_16n, h->d_part_ticks.p + 2 * h->parts.size(), sizeof(int64_t) * 2 * k_ticket_log * h->parts.size(), hipMemcpyDeviceToHost));
   return EMAT_OK;
 }
 /* debugging aid (not part of the boundary): phase profile of a part, see EMAT_PROFILE_PHASES */

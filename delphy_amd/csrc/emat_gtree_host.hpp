@@ -430,7 +430,7 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
   HIP_TRY(G.desc.upload(desc.data(), (size_t)P)); HIP_TRY(G.cells.upload(cells.data(), cells.size()));
   HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
   HIP_TRY(h->d_slabs.alloc(off)); HIP_TRY(h->h_slabs.resize(off));
-  HIP_TRY(h->d_part_ticks.alloc(2 * (size_t)nloc)); HIP_TRY(hipMemsetAsync(h->d_part_ticks.p, 0, 2 * (size_t)nloc * sizeof(int64_t), h->stream));
+  HIP_TRY(h->d_part_ticks.alloc((2 + 2 * k_ticket_log) * (size_t)nloc)); HIP_TRY(hipMemsetAsync(h->d_part_ticks.p, 0, (2 + 2 * k_ticket_log) * (size_t)nloc * sizeof(int64_t), h->stream));
   HIP_TRY(h->d_part_status.alloc((size_t)nloc)); HIP_TRY(hipMemsetAsync(h->d_part_status.p, 0, (size_t)nloc * sizeof(int32_t), h->stream));
   if (device_coal) {
     HIP_TRY(hipMemsetAsync(G.status.p, 0, sizeof(int32_t), h->stream));

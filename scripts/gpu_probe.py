@@ -394,3 +394,43 @@ def arena_probe(nparts=8192, moves=1000):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "arena":
     arena_probe()
+
+
+def ticket_timeline_probe(nparts=8192, moves=1000):
+    """Occupancy of a pass WITH tickets: resident workgroups of the move kernels over time, from the entry and exit ticks of every
+    ticket (emat_debug_ticket_ticks), next to the slot time the chains themselves account for."""
+    import ctypes as C
+    from delphy_amd.sharding import ShardedEngine
+    sc = make_scenario("C4")
+    eng = ShardedEngine(sc, num_parts=nparts, seed=20261001)
+    eng.setup()
+    for _ in range(2):
+        eng.backend.run_moves_per_part(moves); eng.backend.synchronize()
+    ms = eng.backend.last_run_ms(); n = eng.num_local_parts
+    lib = d.load_library()
+    lib.emat_debug_ticket_ticks.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.emat_debug_part_ticks.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    buf = (C.c_int64 * (16 * n))(); assert lib.emat_debug_ticket_ticks(eng.backend.handle, buf) == 0
+    pt = (C.c_int64 * (2 * n))(); assert lib.emat_debug_part_ticks(eng.backend.handle, pt) == 0
+    a = np.array(list(buf), dtype=np.float64).reshape(8, 2, n) / 1e5   # ms
+    chain = np.array(list(pt), dtype=np.float64)[:n] / 1e5
+    used = a[:, 1, :] > 0
+    t0 = a[:, 0, :][used].min()
+    ent, ext = a[:, 0, :][used] - t0, a[:, 1, :][used] - t0
+    print("pass %.2f ms; parts %d; tickets logged %d; last exit %.2f ms; resident slot time %.1f s, of which chains %.1f s" % (ms, n, int(used.sum()), ext.max(), (ext - ent).sum() / 1e3, chain.sum() / 1e3))
+    per_ticket = [(a[k, 1, :] - a[k, 0, :])[used[k]] for k in range(8) if used[k].any()]
+    print("ticket durations (ms), mean per ticket index:", ["%.2f" % x.mean() for x in per_ticket])
+    flat = [(a[k, 1, p] - t0, k, p) for k in range(8) for p in range(n) if used[k, p]]
+    flat.sort(reverse=True)
+    sizes = np.array(eng.local_sizes)
+    for e, k, p in flat[:8]:
+        print("   last exits: part %5d (%d nodes%s) ticket %d entered %.2f exited %.2f ms; the part's chain ticks %.2f ms over all its tickets" % (p, sizes[p], ", root part" if p == eng.root_part - eng.part_lo else "", k, a[k, 0, p] - t0, e, chain[p]))
+    edges = np.linspace(0, ext.max(), 41)
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        mid = 0.5 * (lo + hi)
+        print("  t=%5.2f ms  resident %5d  entered in bin %5d" % (mid, int(((ent <= mid) & (ext > mid)).sum()), int(((ent >= lo) & (ent < hi)).sum())))
+    eng.close()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tickets":
+    ticket_timeline_probe()
