@@ -266,7 +266,11 @@ def main():
 
     # roofline of the dominant kernel (k_run_moves): algorithmic bytes counted by the kernel per executed move
     launches = args.steps + len(ev_ms)
-    bytes_per_launch = (stats1["algorithmic_bytes"] - stats0["algorithmic_bytes"]) / max(1, launches)
+    # (of the parts that ran in that kernel: the few parts of the side classes run beside it in k_run_moves_side)
+    in_main = eng.backend.main_class_mask(eng.num_local_parts)
+    per_part = np.array(stats1["algorithmic_bytes_of_part"], np.float64) - np.array(stats0["algorithmic_bytes_of_part"], np.float64)
+    bytes_per_launch = float(per_part[in_main].sum()) / max(1, launches)
+    bytes_per_launch_all = float(per_part.sum()) / max(1, launches)
     avg_ms = float(np.mean(ev_ms)) if ev_ms else float("nan")
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic, traffic_source = None, None
@@ -341,7 +345,8 @@ def main():
                          "traffic_source": traffic_source,
                          "limiter": "instruction issue and LDS / L2 latency: a part's chain is serial and runs on one lane of its wavefront (the wave's other lanes "
                                     "take part in slab staging and in the candidate scan + study of SPR moves); residency is capped by LDS at 16 parts per CU",
-                         "kernel": "k_run_moves", "kernel_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "kernel": "k_run_moves", "kernel_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "parts_in_kernel": int(in_main.sum()), "algorithmic_bytes_per_pass_all_parts": bytes_per_launch_all},
             "cpu_baseline": cpu_base,
             "inclusive": inclusive,
             "mixing": mixing,

@@ -727,6 +727,13 @@ class EmatBackend:
         t.root = v.root
         return t.trimmed()
 
+    def main_class_mask(self, num_parts: int) -> np.ndarray:
+        """Debugging aid: which resident parts run in the main launch (k_run_moves) rather than in a side class (k_run_moves_side)."""
+        out = np.zeros(num_parts, np.int32)
+        self._lib.emat_debug_arena_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        self._ck(self._lib.emat_debug_arena_bytes(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))), "emat_debug_arena_bytes")
+        return out >= 0
+
     def debug_slab_layout(self, part: int) -> dict:
         out = (C.c_uint32 * 8)()
         self._ck(self._lib.emat_debug_slab_layout(self._h, part, out), "emat_debug_slab_layout")
