@@ -187,13 +187,18 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
   if (a.chunks > 1) {
     if (chunk > 0) {   // the ticket before this one must have written the part's slab back
       // (workgroups are dispatched in index order, so that ticket is running or done: the wait cannot deadlock; it is
-      // bounded all the same -- about ten seconds -- and a part whose turn never came is reported, not waited for)
+      // bounded all the same, and a part whose turn never came is reported, not waited for)
       if (lane == 0) {
-        int spins = 0;
+        // (bounded by wall-clock time -- two minutes of the 100 MHz counter -- not by a number of polls: a forced ticket count on a
+        // handful of huge parts that run out of HBM makes the earlier tickets of a part take seconds, found by the fuzz rounds)
         const uint64_t w0 = wall_clock64();
-        while (__hip_atomic_load(&a.chunk_done[part], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(64); ++spins; }
-        if (spins > 0) atomicAdd((unsigned long long*)&a.chunk_done[((a.num_parts + 1) & ~1) + 2 * (blockIdx.x & 63)], (unsigned long long)(wall_clock64() - w0));   // (EMAT_VERBOSE: slot time spent waiting)
-        if (spins >= (1 << 22)) { st_status(k_part_internal); *lds_flag = -1; } else *lds_flag = 0;
+        bool waited = false, gave_up = false;
+        while (__hip_atomic_load(&a.chunk_done[part], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+          __builtin_amdgcn_s_sleep(64); waited = true;
+          if (wall_clock64() - w0 > 12000000000ull) { gave_up = true; break; }
+        }
+        if (waited) atomicAdd((unsigned long long*)&a.chunk_done[((a.num_parts + 1) & ~1) + 2 * (blockIdx.x & 63)], (unsigned long long)(wall_clock64() - w0));   // (EMAT_VERBOSE: slot time spent waiting)
+        if (gave_up) { st_status(k_part_internal); *lds_flag = -1; } else *lds_flag = 0;
       }
       __syncthreads();
       if (*lds_flag == -1) return;
