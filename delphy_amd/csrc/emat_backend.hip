@@ -826,6 +826,8 @@ struct emat_backend {
                                     // (measured at C4: 292 vs 296 M moves/s -- with two parts per slot the slot that ran the longest part
                                     // still takes one more; off by default)
   bool pass_pending = false;        // a launch has not been checked for stopped parts yet (finish_pass)
+  bool sides_in_flight = false;     // side-class launches that the engine's own stream has not been made to wait for yet (join_side_classes)
+  bool sides_must_fork = true;      // the side streams have not seen what the engine's stream did since the last pass was checked
   emat_status fatal_status = EMAT_OK;   // a part stopped INSIDE a move: its tree is untrustworthy, and every run / getter keeps
   std::string fatal_message;            // failing with this until the parts are uploaded afresh (emat_begin_upload)
   double last_run_ms = 0.0;
@@ -1083,6 +1085,17 @@ emat_status refresh_order_from_ticks(emat_backend* h) {
   return EMAT_OK;
 }
 
+// The side classes of a pass run on streams of their own and the engine's stream does not wait for them when the pass is launched
+// (the next pass of the main class need not, and they are the longest chains of a pass): whoever is about to read or change
+// slabs on the engine's stream joins them first.
+emat_status join_side_classes(emat_backend* h) {
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  if (!h->sides_in_flight) return EMAT_OK;
+  for (int c = 1; c < emat_backend::k_max_classes; ++c) if (h->class_stream[c]) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[c], 0));
+  h->sides_in_flight = false;
+  return EMAT_OK;
+}
+
 emat_status finish_pass(emat_backend* h) {
   if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   if (h->fatal_status != EMAT_OK) return fail(h, h->fatal_status, h->fatal_message);
@@ -1091,6 +1104,8 @@ emat_status finish_pass(emat_backend* h) {
   const size_t n = h->parts.size();
   std::vector<int32_t> status(n);
   for (int round = 0; round < 5; ++round) {
+    { emat_status js = join_side_classes(h); if (js) return js; }
+    h->sides_must_fork = true;
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(status.data(), h->d_part_status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     h->pass_pending = false;
@@ -1109,7 +1124,7 @@ emat_status finish_pass(emat_backend* h) {
         double wait = 0; for (int i = 0; i < 64; ++i) { unsigned long long v; memcpy(&v, &w[(n & 1) + 2 * i], 8); wait += (double)v; }   // (the counters start at the next even index)
         fprintf(stderr, "[emat] tickets waited %.2f s of slot time for their predecessors (%.1f %% of %d slots x pass)\n", wait / 1e8, 100.0 * wait / 1e5 / (kms * 16.0 * h->num_cus), 16 * h->num_cus);
       }
-      fprintf(stderr, "[emat] pass: %.1f ms on the device (first start to last end %.1f ms) | chains: mean %.2f ms, slowest", kms, (last - first) / 1e5, sum / n / 1e5);
+      fprintf(stderr, "[emat] pass: main class %.1f ms on the device (all chains: first start to last end %.1f ms) | chains: mean %.2f ms, slowest", kms, (last - first) / 1e5, sum / n / 1e5);
       for (size_t k = 0; k < std::min<size_t>(4, n); ++k) fprintf(stderr, " %.1f ms from %.1f (part %d, %d nodes%s)", ticks[idx[k]] / 1e5, (ticks[n + idx[k]] - first) / 1e5, idx[k], h->parts[idx[k]].n_nodes, idx[k] == h->root_part ? ", root part" : "");
       std::partial_sort(idx.begin(), idx.begin() + std::min<size_t>(3, n), idx.end(), [&](int a, int b) { return ticks[n + a] + ticks[a] > ticks[n + b] + ticks[b]; });
       fprintf(stderr, " | last to end:");
@@ -1394,7 +1409,7 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
   if (h->fatal_status != EMAT_OK) return fail(h, h->fatal_status, h->fatal_message);
   emat_status st = sync_model_to_device(h); if (st) return st;
   st = materialize(h); if (st) return st;
-  if (!h->derived_valid) { st = launch_recalc(h); if (st) return st; }
+  if (!h->derived_valid) { st = join_side_classes(h); if (st) return st; h->sides_must_fork = true; st = launch_recalc(h); if (st) return st; }
   const uint32_t lds_scratch = h->cfg.use_lds ? h->cfg_lds_scratch : 0u;
   // the dynamic block: the slab image beyond its header + the arena; tables, context and the header image are static LDS
   auto shmem_for = [&](uint32_t slab_area) { return (size_t)(slab_area > (uint32_t)sizeof(SlabHeader) ? slab_area - (uint32_t)sizeof(SlabHeader) : 0u) + lds_scratch; };
@@ -1405,7 +1420,7 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
   KernelArgs a = make_args(h);
   a.moves_per_part = per_part; a.extra_moves_part0 = extra0; a.one_more_below = one_more_below;
   a.lds_scratch_bytes = lds_scratch; a.snaps = h->d_snaps.p;
-  if (counts) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(h->d_moves_for_part.upload(counts->data(), counts->size())); a.moves_for_part = h->d_moves_for_part.p; }
+  if (counts) { st = join_side_classes(h); if (st) return st; h->sides_must_fork = true; HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(h->d_moves_for_part.upload(counts->data(), counts->size())); a.moves_for_part = h->d_moves_for_part.p; }
   else for (size_t p = 0; p < h->parts.size(); ++p) h->parts[p].expected_moves += per_part + (p == 0 ? extra0 : 0) + ((int64_t)p < one_more_below ? 1 : 0);
   h->pass_pending = true;
   h->last_launch_uniform = counts == nullptr;
@@ -1428,8 +1443,12 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
     // Order matters: a side class holds few, large workgroups (tens of KB of LDS each), which can only be placed while
     // the CUs are not yet packed with the 10 KB workgroups of the main class -- arriving second they would wait for
     // several neighbours to finish (measured: the root part started 10-15 ms into the pass).  So the side classes are
-    // launched first, largest area first, class 0 on the engine's own stream and every other class forked onto a
-    // stream of its own (they run side by side); the timing events on the engine's stream bracket the fork and the joins.
+    // launched first, largest area first, each on a stream of its own, the main class last on the engine's stream.  The
+    // engine's stream does not wait for them here (join_side_classes): a side class only ever follows its own previous launch
+    // -- the parts of different classes have nothing to do with each other -- so that in back-to-back passes the main class of the
+    // next pass starts when the main class of this one ends, and the side launches of the next pass, queued behind their
+    // predecessors, find their LDS while this pass's main class drains.  They wait for the engine's stream only when it did
+    // something since the last pass was checked (uploads, recalculation: sides_must_fork).  The timing events bracket the main class.
     // Tickets pay when there are more parts than wave slots (4 waves x 4 SIMDs per CU): with fewer, every part has a slot to
     // itself from the start and a second ticket could only wait behind its first while holding another slot.
     const int main_count = h->class_begin[h->num_classes] - h->class_begin[h->num_classes - 1];
@@ -1446,13 +1465,15 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
       b.taper = h->cfg_taper ? 1 : 0;
       b.chunks = c == main_class ? chunks : 1; b.class_count = cnt; b.class_stride = (cnt + 7) & ~7; b.chunk_done = h->d_chunk_done.p;
       const unsigned grid = b.chunks > 1 ? (unsigned)(b.chunks * b.class_stride) : (unsigned)cnt;
-      hipStream_t sm = c == 0 ? h->stream : h->class_stream[c];
-      if (c != 0) HIP_TRY(hipStreamWaitEvent(sm, h->ev_fork, 0));
+      const bool side = c != main_class;
+      hipStream_t sm = side ? h->class_stream[c + 1] : h->stream;
+      if (side && h->sides_must_fork) HIP_TRY(hipStreamWaitEvent(sm, h->ev_fork, 0));
       if (c == main_class) hipLaunchKernelGGL(k_run_moves, dim3(grid), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
       else hipLaunchKernelGGL(k_run_moves_side, dim3(grid), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
       HIP_TRY(hipGetLastError());
-      if (c != 0) { HIP_TRY(hipEventRecord(h->ev_join[c], sm)); HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[c], 0)); }
+      if (side) { HIP_TRY(hipEventRecord(h->ev_join[c + 1], sm)); h->sides_in_flight = true; }
     }
+    h->sides_must_fork = false;
   }
   HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
   h->host_slabs_current = false; h->headers_current = false;
@@ -2181,6 +2202,7 @@ emat_status emat_debug_part_ticks(emat_backend* h, int64_t* out_2n) {
   if (!h || !out_2n || h->host_only || !h->slabs_on_device) return EMAT_ERR_INVALID_ARGUMENT;
   if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   auto set_error = [&](const std::string& s) { h->set_error(s); };
+  { emat_status js = join_side_classes(h); if (js) return js; }
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out_2n, h->d_part_ticks.p, sizeof(int64_t) * 2 * h->parts.size(), hipMemcpyDeviceToHost));
   return EMAT_OK;
@@ -2190,6 +2212,7 @@ emat_status emat_debug_ticket_ticks(emat_backend* h, int64_t* out_16n) {
   if (!h || !out_16n || h->host_only || !h->slabs_on_device) return EMAT_ERR_INVALID_ARGUMENT;
   if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   auto set_error = [&](const std::string& s) { h->set_error(s); };
+  { emat_status js = join_side_classes(h); if (js) return js; }
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out_16n, h->d_part_ticks.p + 2 * h->parts.size(), sizeof(int64_t) * 2 * k_ticket_log * h->parts.size(), hipMemcpyDeviceToHost));
   return EMAT_OK;

@@ -365,8 +365,9 @@ emat_status emat_part_get_stats(emat_backend* h, int32_t part_id, emat_part_stat
 emat_status emat_part_get_trace(emat_backend* h, int32_t part_id, int32_t* num_moves /*in/out*/,
                                 double* trace /*[4*num_moves]*/);
 
-/* Duration of the last emat_run_* launch measured with HIP events on the engine's own stream
- * (milliseconds), and the kernel's name for cross-checking against rocprofv3. */
+/* Duration of the last emat_run_* launch measured with HIP events on the engine's own stream (milliseconds): the launch of the
+ * main size class.  The few parts of the side classes run beside it on streams of their own and are waited for by whatever next
+ * reads or changes the parts (emat_synchronize, emat_tree_reassemble, the getters), not by the next emat_run_* call. */
 emat_status emat_last_run_ms(emat_backend* h, double* ms);
 /* Duration of the dominant kernel (k_run_moves, the bulk size class) inside the last pass, and how many parts it ran. */
 emat_status emat_last_kernel_ms(emat_backend* h, double* ms, int32_t* num_parts_in_kernel);
