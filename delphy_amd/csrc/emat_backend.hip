@@ -1575,7 +1575,7 @@ emat_status emat_set_flags(emat_backend* h, double t_max_tip, int32_t only_displ
 emat_status emat_begin_upload(emat_backend* h, int32_t num_parts) {
   if (!h || num_parts <= 0) return EMAT_ERR_INVALID_ARGUMENT;
   if (h->cfg.max_parts > 0 && num_parts > h->cfg.max_parts) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "more parts than cfg.max_parts");
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->stream) { (void)join_side_classes(h); h->sides_must_fork = true; (void)hipStreamSynchronize(h->stream); }   // (a pass still in flight is discarded with the parts, but not written over)
   h->coal_builder.reset();
   h->fatal_status = EMAT_OK; h->fatal_message.clear(); h->pass_pending = false;
   h->parts.clear(); h->parts.resize(num_parts);

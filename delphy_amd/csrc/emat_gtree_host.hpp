@@ -299,6 +299,8 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
     HIP_TRY(hipGetLastError());
     return EMAT_OK;
   };
+  st = join_side_classes(h); if (st) return st;   // (side launches of a pass nobody gathered: the slabs are about to be rebuilt)
+  h->sides_must_fork = true;
   st = launch_measure(); if (st) return st;
   // while the device measures: skeletons of the parts (topology + times), and from them the coalescent cell tables
   h->coal_builder.reset();
