@@ -910,6 +910,7 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
   const bool local_scan = (max_muts_from_start == 1);
   ScSpan span;
   uint32_t front = 0;
+  bool in_block = false;   // (not `front != 0`: both sets are often empty -- no missing interval at X, no site delta -- and the block is there all the same)
   if (local_scan && hot.p != nullptr) {
     const uint32_t need = (((uint32_t)missing_at_X_in.n * (uint32_t)sizeof(IvRec) + 15u) & ~15u) + (((uint32_t)deltas_in.n * (uint32_t)sizeof(SdRec) + 15u) & ~15u);
     if (need + 512u <= hot.bytes) {
@@ -917,11 +918,11 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
       front = ((uint32_t)missing_at_X_in.n * (uint32_t)sizeof(IvRec) + 15u) & ~15u;
       SdRec* di = (SdRec*)(hot.p + front); for (int i = 0; i < deltas_in.n; ++i) di[i] = deltas_in.p[i];
       missing_at_X.p = mi; deltas_local.p = di; deltas_local.cap = deltas_in.n;
-      front = need;
+      front = need; in_block = true;
     }
   }
-  SVec<SdRec>& deltas = (front != 0) ? deltas_local : deltas_in;
-  if (front != 0) { span.lo = hot.p + front; span.hi = hot.p + (hot.bytes & ~15u); span.lds = true; span.reserved = true; }
+  SVec<SdRec>& deltas = in_block ? deltas_local : deltas_in;
+  if (in_block) { span.lo = hot.p + front; span.hi = hot.p + (hot.bytes & ~15u); span.lds = true; span.reserved = true; }
   else span = local_scan ? sc_span(c, 1024) : sc_span_hbm(c);
 #ifdef EMAT_PROFILE_PHASES
   if (span.lds) hdr_of(c)->phase_ticks[3] += 1;   // scans that start in the LDS arena
@@ -1303,13 +1304,14 @@ EMAT_D bool wave_local_scan(Ctx& c, Spr1Frame& fr) {
   if (del.n >= 8000) return false;
   // the two sets every region is checked against go to the front of the move's LDS block
   uint32_t front = 0;
+  bool in_block = false;   // (see study_seed_fill: empty sets still have their place in the block)
   if (fr.hot.p != nullptr) {
     const uint32_t b_miss = ((uint32_t)miss.n * (uint32_t)sizeof(IvRec) + 15u) & ~15u, b_del = ((uint32_t)del.n * (uint32_t)sizeof(SdRec) + 15u) & ~15u;
     if (b_miss + b_del + 512u <= fr.hot.bytes) {
       IvRec* mi = (IvRec*)fr.hot.p; SdRec* di = (SdRec*)(fr.hot.p + b_miss);
       for (int i = lane; i < miss.n; i += 64) mi[i] = miss.p[i];
       for (int i = lane; i < del.n; i += 64) di[i] = del.p[i];
-      miss.p = mi; del.p = di; front = b_miss + b_del;
+      miss.p = mi; del.p = di; front = b_miss + b_del; in_block = true;
       __syncthreads();
     }
   }
@@ -1319,7 +1321,7 @@ EMAT_D bool wave_local_scan(Ctx& c, Spr1Frame& fr) {
   for (int attempt = 0; attempt < 2 && !done; ++attempt) {
     uint8_t* base; uint32_t bytes;
     if (attempt == 0) {
-      if (fr.hot.p == nullptr || front == 0 || fr.hot.bytes - front < 24u * 36u) continue;
+      if (fr.hot.p == nullptr || !in_block || fr.hot.bytes - front < 24u * 36u) continue;
       base = fr.hot.p + front; bytes = (fr.hot.bytes - front) & ~15u;
     } else {
       const uint32_t g0 = (c.sc_top + 15u) & ~15u, g1 = hdr_of(c)->scratch_end & ~15u;
@@ -1400,7 +1402,7 @@ EMAT_D bool wave_local_scan(Ctx& c, Spr1Frame& fr) {
     done = !overflow;
   }
 #ifdef EMAT_PROFILE_PHASES
-  if (lane == 0) { int64_t* ex = (int64_t*)hdr_of(c)->reserved; ex[0] += 1; ex[1] += miss.n; ex[2] += del.n; ex[3] += total; ex[4] += nlev; ex[5] += (hbm_lo != nullptr) ? 1 : 0; ex[6] += done ? 0 : 1; ex[7] += (front == 0) ? 1 : 0; }
+  if (lane == 0) { int64_t* ex = (int64_t*)hdr_of(c)->reserved; ex[0] += 1; ex[1] += miss.n; ex[2] += del.n; ex[3] += total; ex[4] += nlev; ex[5] += (hbm_lo != nullptr) ? 1 : 0; ex[6] += done ? 0 : 1; ex[7] += in_block ? 0 : 1; }
 #endif
   if (!done || c.failed) return false;
   // subtree sizes, deepest level first

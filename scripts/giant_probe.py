@@ -25,7 +25,7 @@ names = ["core:analyze+peel", "core:topology", "core:propose", "scans in LDS", "
          "spr1:topology", "spr1:propose", "spr1:seed_fill post", "spr1:study post+alpha", "spr1:accept+apply", "regions (count)", "ALL simple moves", "ALL topology moves"]
 buf = (C.c_int64 * 16)()
 print("parts %d | chain ms: median %.2f p99 %.2f max %.2f | corr(duration, nodes) %.2f" % (n, np.median(dur), np.percentile(dur, 99), dur.max(), np.corrcoef(dur, nodes)[0, 1]))
-sel = list(np.argsort(-dur)[:5]) + list(np.argsort(dur)[n // 2: n // 2 + 2])
+sel = list(np.argsort(-nodes)[:3]) + list(np.argsort(-dur)[:3]) + list(np.argsort(dur)[n // 2: n // 2 + 1])
 for p in sel:
     lib.emat_debug_phase_ticks(b.handle, int(p), buf); v = np.array(list(buf), dtype=np.float64)
     prop = st[p]["proposed"]; tot = v[14] + v[15]
