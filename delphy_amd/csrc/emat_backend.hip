@@ -93,6 +93,7 @@ struct KernelArgs {
   // ticket c of a part starts when ticket c - 1 has written the slab back (chunk_done[part] == c).  Shorter tickets pack the
   // slots better at the end of a pass; the chain -- one RNG stream per part, state in the slab -- is the same chain.
   int32_t chunks, class_count, class_stride, taper;
+  int32_t cum_w[8];               // cumulative ticket weights (EMAT_TICKET_WEIGHTS) or zeros
   int32_t* chunk_done;            // [num_parts], zeroed before the launch
   // Room for a copy of every slab's persistent prefix, at the slab's own offset: a leg that runs on the HBM slab itself (part
   // not staged whole) saves it there first, so that a container overflowing INSIDE a move can be answered by putting the
@@ -206,7 +207,8 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
     __syncthreads();
     // cumulative over the tickets so far.  The tickets of a part shrink in the ratio n : n-1 : ... : 1, so that the jobs that start
     // last -- the ones a pass ends with -- are the shortest (equal tickets: EMAT_TICKET_TAPER=0)
-    if (a.taper) { const int64_t nn = a.chunks, done_w = (int64_t)(chunk + 1) * (2 * nn - chunk), all_w = nn * (nn + 1); target = chunk + 1 == a.chunks ? pass_target : pass_target * done_w / all_w; }
+    if (a.cum_w[0] > 0) target = chunk + 1 == a.chunks ? pass_target : pass_target * a.cum_w[chunk] / a.cum_w[a.chunks - 1];   // a table of weights (the default for four tickets, or EMAT_TICKET_WEIGHTS="w1,w2,...")
+    else if (a.taper) { const int64_t nn = a.chunks, done_w = (int64_t)(chunk + 1) * (2 * nn - chunk), all_w = nn * (nn + 1); target = chunk + 1 == a.chunks ? pass_target : pass_target * done_w / all_w; }
     else target = pass_target * (chunk + 1) / a.chunks;
     done_at_start = gh->moves_done - (int64_t)(uint32_t)((uint32_t)gh->moves_done - gh->pad0);
   } else done_at_start = gh->moves_done;
@@ -868,7 +870,7 @@ struct emat_backend {
   DevBuf<uint8_t> d_headers; std::vector<uint8_t> h_headers; bool headers_current = false;
   GTreeHost gt;                     // the whole tree, when it lives in HBM (emat_tree_upload)
   BuiltTree built;                  // what emat_tree_build_usher_like made, until it is fetched (emat_tree_built_get)
-  bool cfg_taper = true;            // EMAT_TICKET_TAPER: tickets of a part in the ratio n : ... : 1 instead of equal
+  bool cfg_taper = true;            // EMAT_TICKET_TAPER: tickets of a part shrink (10 : 6 : 3 : 1 for four tickets, else n : ... : 1) instead of being equal
   int cfg_chunks = 4;               // EMAT_CHUNKS (tuning knob): tickets per part and pass (main class; measured at C4 once a ticket's release no longer wrote the L2 back, equal tickets: 2 -> 378, 3 -> 384, 6 -> 382, 10 -> 379, 16 -> 365, 32 -> 322 M moves/s; tapered: 3 -> 390, 4 -> 392, 5 -> 388; before: 1 -> 311, 2 -> 338, 3 -> 340, 4 -> 331, 8 -> 301)
   bool cfg_chunks_forced = false;   // EMAT_CHUNKS was given: tickets also when the parts are fewer than the wave slots (tests)
   DevBuf<int32_t> d_chunk_done;
@@ -1463,6 +1465,9 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
       // (only the main class: a side class has fewer workgroups than the device has room for, so all its tickets would be
       // resident at once and the waiting ones would sit on tens of KB of LDS each -- measured: cycles of 72 ms instead of 37)
       b.taper = h->cfg_taper ? 1 : 0;
+      for (int k = 0; k < 8; ++k) b.cum_w[k] = 0;
+      if (h->cfg_taper && chunks == 4) { b.cum_w[0] = 10; b.cum_w[1] = 16; b.cum_w[2] = 19; b.cum_w[3] = 20; }   // 10 : 6 : 3 : 1 (measured best of the ratios tried)
+      if (const char* e = getenv("EMAT_TICKET_WEIGHTS")) { int acc = 0, k = 0; for (const char* q = e; *q && k < 8;) { acc += std::max(1, atoi(q)); b.cum_w[k++] = acc; while (*q && *q != ',') ++q; if (*q == ',') ++q; } if (k != chunks) for (int j = 0; j < 8; ++j) b.cum_w[j] = 0; }
       b.chunks = c == main_class ? chunks : 1; b.class_count = cnt; b.class_stride = (cnt + 7) & ~7; b.chunk_done = h->d_chunk_done.p;
       const unsigned grid = b.chunks > 1 ? (unsigned)(b.chunks * b.class_stride) : (unsigned)cnt;
       const bool side = c != main_class;
