@@ -60,14 +60,37 @@ def parse():
     return args
 
 
+def count_gpus_without_touching_them():
+    """Number of GPUs of this node read from the KFD topology in sysfs (a node with a non-zero `simd_count` is a GPU), cut down
+    by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when those are set: no HIP or HSA call, so the process that asks stays free
+    of any GPU state (torch.cuda.device_count() falls through to hipGetDeviceCount on ROCm, which initialises the runtime).
+    -1 when the topology cannot be read (no amdgpu driver: then the question is asked of a short-lived child instead)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            props = dict(ln.split() for ln in open(os.path.join(base, node, "properties")) if len(ln.split()) == 2)
+            n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+    except OSError:
+        return -1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks (one per GPU) as children through
-    torch.distributed.run and relay what they print.  Nothing in this process may initialise the GPU -- counting devices
-    does not -- and the children are started as ordinary subprocesses, never by exec."""
+    torch.distributed.run and relay what they print.  Nothing in this process initialises the GPU -- the devices are counted
+    in sysfs, or by a short-lived child when sysfs has no KFD topology -- and the children are started as ordinary
+    subprocesses, never by exec."""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()
+    have = count_gpus_without_touching_them()
+    if have < 0:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
+        have = int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
     if have < args.gpus and os.environ.get("EMAT_BENCH_SHARED_GPU") != "1":
         raise SystemExit("bench.py --gpus %d: this node has %d GPU(s) (EMAT_BENCH_SHARED_GPU=1 runs the ranks on one GPU over gloo as a plumbing check)" % (args.gpus, have))
     with socket.socket() as so:
@@ -273,7 +296,7 @@ def main():
     bytes_per_launch_all = float(per_part.sum()) / max(1, launches)
     avg_ms = float(np.mean(ev_ms)) if ev_ms else float("nan")
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic, traffic_source = None, None
+    traffic, traffic_source, traffic_read, traffic_write = None, None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     # PMC counters cannot be read from inside this process: the figure comes from the committed rocprofv3 --pmc passes
     # of this same command (scripts/profile.sh) and is stamped with the kernel build it was measured on; it is quoted
@@ -286,6 +309,10 @@ def main():
                 traffic_source = "unstamped: profiles/pmc_latest.json does not say which device code it was measured on"
             elif stamp == build_id:
                 traffic = pm.get("hbm_bytes_per_launch")
+                # reads and writes apart: their sum can sit near the algorithmic bytes while each is far from its own share
+                # (the state lives in LDS: few reads; private frames of the topology moves: many writes)
+                if pm.get("FETCH_SIZE_KiB") is not None and pm.get("WRITE_SIZE_KiB") is not None:
+                    traffic_read, traffic_write = 2.0 * pm["FETCH_SIZE_KiB"] * 1024.0, pm["WRITE_SIZE_KiB"] * 1024.0
                 traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on the library with emat_build_id %s)" % (pm.get("profile_dir", "pmc_latest.json"), stamp)
             else:
                 traffic_source = "stale: profiles/pmc_latest.json was measured on device code %s, the loaded library is %s" % (stamp, build_id)
@@ -299,7 +326,9 @@ def main():
     if rank == 0 and os.path.exists(mix_path):
         try:
             pc = json.load(open(mix_path))
-            mixing = {"source": "profiles/posterior_latest.json (scripts/posterior_check.py: %d tips, %d retained samples per arm, one per cycle of 50 x nodes moves)" % (pc["tips"], pc["configs"][0]["retained"]),
+            mixing = {"measured_on_emat_build_id": pc.get("emat_build_id"),
+                      "stale": pc.get("emat_build_id") != build_id,   # a sampler property, not a kernel timing: quoted either way, but marked when the device code has changed since
+                      "source": "profiles/posterior_latest.json (scripts/posterior_check.py: %d tips, %d retained samples per arm, one per cycle of 50 x nodes moves)" % (pc["tips"], pc["configs"][0]["retained"]),
                       "worst_abs_z_between_arms": pc.get("worst_abs_z"),
                       "arms": [{"parts": c["parts"], "frozen_fraction": c["frozen_fraction"], "moves_per_s": c["moves_per_s"],
                                 "ess_per_s": {k: v["ess_per_s"] for k, v in c["stats"].items()},
@@ -342,7 +371,7 @@ def main():
             "per_rank": {"ms_per_step": rank_ms, "kernel_ms": rank_kernel_ms, "parts": rank_parts},
             # "bound" names the yardstick the contract asks for; "limiter" says what actually limits the kernel
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_source,
+                         "traffic_read": traffic_read, "traffic_write": traffic_write, "traffic_source": traffic_source,
                          "limiter": "instruction issue and LDS / L2 latency: a part's chain is serial and runs on one lane of its wavefront (the wave's other lanes "
                                     "take part in slab staging and in the candidate scan + study of SPR moves); residency is capped by LDS at 16 parts per CU",
                          "kernel": "k_run_moves", "kernel_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -93,6 +93,7 @@ struct KernelArgs {
   // ticket c of a part starts when ticket c - 1 has written the slab back (chunk_done[part] == c).  Shorter tickets pack the
   // slots better at the end of a pass; the chain -- one RNG stream per part, state in the slab -- is the same chain.
   int32_t chunks, class_count, class_stride, taper;
+  int32_t full_release;           // EMAT_TICKET_RELEASE=full: every ticket hands its part over with an agent-scope RELEASE (the path that needs no assumption about where workgroups run)
   int32_t cum_w[8];               // cumulative ticket weights (EMAT_TICKET_WEIGHTS) or zeros
   int32_t* chunk_done;            // [num_parts], zeroed before the launch
   // Room for a copy of every slab's persistent prefix, at the slab's own offset: a leg that runs on the HBM slab itself (part
@@ -203,7 +204,7 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
       }
       __syncthreads();
       if (*lds_flag == -1) return;
-    } else if (lane == 0) gh->pad0 = (uint32_t)gh->moves_done;   // where the pass picked the part up (low bits: a pass is far shorter than 2^32 moves)
+    } else if (lane == 0) __hip_atomic_store(&gh->pad0, (uint32_t)gh->moves_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // where the pass picked the part up (low bits: a pass is far shorter than 2^32 moves); written through like everything else a later ticket reads
     __syncthreads();
     // cumulative over the tickets so far.  The tickets of a part shrink in the ratio n : n-1 : ... : 1, so that the jobs that start
     // last -- the ones a pass ends with -- are the shortest (equal tickets: EMAT_TICKET_TAPER=0)
@@ -343,7 +344,7 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
     // part was staged has sent everything the next ticket reads through write-through stores (the slab image, status, ticks):
     // it only waits for those to be acknowledged.  One that edited lists in HBM directly keeps the full release.
     if (lane == 0) {
-      if (plain_hbm_writes) __hip_atomic_store(&a.chunk_done[part], chunk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (plain_hbm_writes || a.full_release) __hip_atomic_store(&a.chunk_done[part], chunk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); __hip_atomic_store(&a.chunk_done[part], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     }
   }
@@ -872,6 +873,8 @@ struct emat_backend {
   BuiltTree built;                  // what emat_tree_build_usher_like made, until it is fetched (emat_tree_built_get)
   bool cfg_taper = true;            // EMAT_TICKET_TAPER: tickets of a part shrink (10 : 6 : 3 : 1 for four tickets, else n : ... : 1) instead of being equal
   int cfg_chunks = 4;               // EMAT_CHUNKS (tuning knob): tickets per part and pass (main class; measured at C4 once a ticket's release no longer wrote the L2 back, equal tickets: 2 -> 378, 3 -> 384, 6 -> 382, 10 -> 379, 16 -> 365, 32 -> 322 M moves/s; tapered: 3 -> 390, 4 -> 392, 5 -> 388; before: 1 -> 311, 2 -> 338, 3 -> 340, 4 -> 331, 8 -> 301)
+  bool cfg_ticket_spread = false;   // EMAT_TICKET_XCD_SPREAD=1 (tests): odd ticket stride, a part's tickets on different XCDs
+  bool cfg_ticket_full_release = false;   // EMAT_TICKET_RELEASE=full: agent-scope release at every hand-over
   bool cfg_chunks_forced = false;   // EMAT_CHUNKS was given: tickets also when the parts are fewer than the wave slots (tests)
   DevBuf<int32_t> d_chunk_done;
   int cfg_parts_per_cu = 0;         // EMAT_PARTS_PER_CU (tuning knob): workgroups of the main class per CU, instead of the percentile rule
@@ -910,15 +913,16 @@ void encode_slab(const emat_backend& B, const PartHost& ph, uint8_t* slab, uint3
     r.parent = t.parent[i]; r.child0 = t.child0[i]; r.child1 = t.child1[i];
     r.t_min = t.t_min[i]; r.t_max = t.t_max[i]; r.t = t.t[i]; r.lambda = 0.0; r.n_missing = 0;
     int nm = t.mut_offset[i + 1] - t.mut_offset[i], ni = t.miss_offset[i + 1] - t.miss_offset[i], nf = t.mfs_offset[i + 1] - t.mfs_offset[i];
-    r.muts.off = top; r.muts.cnt = (uint16_t)nm; r.muts.cap = (uint16_t)(a16(nm * 16u) / 16u);
+    // (counts were checked against k_max_list_len by the caller, materialize)
+    r.muts.off = top; r.muts.cnt = (uint16_t)nm; r.muts.cap = list_cap_for(a16(nm * 16u), 16u);
     MutRec* m = (MutRec*)(slab + top);
     for (int k = 0; k < nm; ++k) { int s = t.mut_offset[i] + k; m[k].t = t.mut_t[s]; m[k].site = t.mut_site[s]; m[k].from = t.mut_from[s]; m[k].to = t.mut_to[s]; m[k].pad = 0; }
     top += a16(nm * 16u);
-    r.miss.off = top; r.miss.cnt = (uint16_t)ni; r.miss.cap = (uint16_t)(a16(ni * 8u) / 8u);
+    r.miss.off = top; r.miss.cnt = (uint16_t)ni; r.miss.cap = list_cap_for(a16(ni * 8u), 8u);
     IvRec* iv = (IvRec*)(slab + top);
     for (int k = 0; k < ni; ++k) { int s = t.miss_offset[i] + k; iv[k].start = t.miss_start[s]; iv[k].end = t.miss_end[s]; }
     top += a16(ni * 8u);
-    r.mfs.off = top; r.mfs.cnt = (uint16_t)nf; r.mfs.cap = (uint16_t)(a16(nf * 8u) / 8u);
+    r.mfs.off = top; r.mfs.cnt = (uint16_t)nf; r.mfs.cap = list_cap_for(a16(nf * 8u), 8u);
     FsRec* fs = (FsRec*)(slab + top);
     for (int k = 0; k < nf; ++k) { int s = t.mfs_offset[i] + k; fs[k].site = t.mfs_site[s]; fs[k].state = t.mfs_state[s]; }
     top += a16(nf * 8u);
@@ -1138,9 +1142,11 @@ emat_status finish_pass(emat_backend* h) {
     emat_status st = pull_from_device(h); if (st) return st;
     if (fatal != n) {
       const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + h->parts[fatal].slab_off);
-      h->fatal_status = status[fatal] == k_part_cell_overflow ? EMAT_ERR_CAPACITY : EMAT_ERR_INTERNAL;
+      h->fatal_status = (status[fatal] == k_part_cell_overflow || status[fatal] == k_part_list_limit) ? EMAT_ERR_CAPACITY : EMAT_ERR_INTERNAL;
       h->fatal_message = "part " + std::to_string(fatal) + " stopped inside a move with status " + std::to_string(status[fatal]) + " (device source line " + std::to_string(H->fail_line) +
                          "); " + std::to_string(stopped) + " part(s) stopped in all";
+      if (status[fatal] == k_part_list_limit)
+        h->fatal_message += ": a per-node list would exceed " + std::to_string(k_max_list_len) + " entries (16-bit list counts, emat_slab.hpp): nothing was truncated, the run cannot continue";
       return fail(h, h->fatal_status, h->fatal_message);
     }
     if (round == 4) return fail(h, EMAT_ERR_CAPACITY, std::to_string(stopped) + " part(s) still out of slab space after four doublings");
@@ -1351,6 +1357,9 @@ emat_status materialize(emat_backend* h) {
   std::vector<SlabGeo> geo(h->parts.size());
   for (size_t p = 0; p < h->parts.size(); ++p) {
     PartHost& ph = h->parts[p];
+    // encode_slab writes 16-bit list counts: what reaches it was accepted at upload (<= k_max_list_upload) or came back from the
+    // device (whose lists stop at k_max_list_len: k_part_list_limit) -- checked here all the same, so that no count is ever cut
+    { emat_flat_tree v = ph.tree.view(); const std::string lim = flat_tree_list_limit(v, (int32_t)k_max_list_len); if (!lim.empty()) return fail(h, EMAT_ERR_CAPACITY, "part " + std::to_string(p) + ": " + lim); }
     geo[p] = slab_geometry(h, ph.tree.num_nodes(), ph.tree.num_muts(), heap_content_bytes(ph.tree), (int)ph.coal.k_bar_p.size(), ph.includes_run_root, ph.space_boost, ph.cell_boost);
     place_slab(h, p, geo[p], off, heap_content_bytes(ph.tree));
   }
@@ -1381,6 +1390,11 @@ emat_status launch_recalc(emat_backend* h) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   emat_status st = sync_model_to_device(h); if (st) return st;
   st = materialize(h); if (st) return st;
+  // the kernel rewrites lambda, missing-site counts and the totals of EVERY part, the parts of the side classes included: their
+  // launches of the last pass must have ended, and their next ones must follow this one (every caller -- emat_recalc_derived
+  // directly after emat_run_* as well -- goes through here)
+  st = join_side_classes(h); if (st) return st;
+  h->sides_must_fork = true;
   KernelArgs a = make_args(h);
   hipLaunchKernelGGL(k_recalc_derived, dim3((unsigned)h->parts.size()), dim3(k_wave), 0, h->stream, a);
   HIP_TRY(hipGetLastError());
@@ -1469,6 +1483,12 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
       if (h->cfg_taper && chunks == 4) { b.cum_w[0] = 10; b.cum_w[1] = 16; b.cum_w[2] = 19; b.cum_w[3] = 20; }   // 10 : 6 : 3 : 1 (measured best of the ratios tried)
       if (const char* e = getenv("EMAT_TICKET_WEIGHTS")) { int acc = 0, k = 0; for (const char* q = e; *q && k < 8;) { acc += std::max(1, atoi(q)); b.cum_w[k++] = acc; while (*q && *q != ',') ++q; if (*q == ',') ++q; } if (k != chunks) for (int j = 0; j < 8; ++j) b.cum_w[j] = 0; }
       b.chunks = c == main_class ? chunks : 1; b.class_count = cnt; b.class_stride = (cnt + 7) & ~7; b.chunk_done = h->d_chunk_done.p;
+      // Testing knobs.  EMAT_TICKET_XCD_SPREAD=1 makes the stride odd, so that consecutive tickets of a part land on DIFFERENT XCDs
+      // (workgroups go round the eight XCDs by index): the hand-over then has to cross L2s, which the default placement avoids
+      // but does not rely on -- what a ticket hands over goes out through agent-scope write-through stores and the next ticket
+      // acquires at agent scope.  EMAT_TICKET_RELEASE=full takes the plain agent-scope release for every ticket.
+      if (h->cfg_ticket_spread) b.class_stride = cnt | 1;
+      b.full_release = h->cfg_ticket_full_release ? 1 : 0;
       const unsigned grid = b.chunks > 1 ? (unsigned)(b.chunks * b.class_stride) : (unsigned)cnt;
       const bool side = c != main_class;
       hipStream_t sm = side ? h->class_stream[c + 1] : h->stream;
@@ -1519,6 +1539,8 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   if (const char* e = getenv("EMAT_TREE_HOST_COALESCENT")) h->cfg_gt_host_coal = atoi(e) != 0;
   if (const char* e = getenv("EMAT_TICKET_TAPER")) h->cfg_taper = atoi(e) != 0;
   if (const char* e = getenv("EMAT_CHUNKS")) { h->cfg_chunks = std::max(1, std::min(64, atoi(e))); h->cfg_chunks_forced = true; }
+  if (const char* e = getenv("EMAT_TICKET_XCD_SPREAD")) h->cfg_ticket_spread = atoi(e) != 0;
+  if (const char* e = getenv("EMAT_TICKET_RELEASE")) h->cfg_ticket_full_release = strcmp(e, "full") == 0;
   if (const char* e = getenv("EMAT_PARTS_PER_CU")) h->cfg_parts_per_cu = std::max(0, std::min(4 * EMAT_WAVES_PER_EU, atoi(e)));
   if (const char* e = getenv("EMAT_ORDER_BY_TIME")) h->cfg_order_by_time = atoi(e) != 0;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return EMAT_ERR_HIP; h->num_cus = prop.multiProcessorCount; }
@@ -1593,10 +1615,8 @@ emat_status emat_part_upload(emat_backend* h, int32_t part_id, const emat_flat_t
   if (h->uploads_expected <= 0) return fail(h, EMAT_ERR_STATE, "emat_begin_upload must precede emat_part_upload");
   std::string msg = validate_flat_tree(*subtree, h->L);
   if (!msg.empty()) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "part " + std::to_string(part_id) + ": " + msg);
-  for (int i = 0; i < subtree->num_nodes; ++i) {
-    int nm = subtree->mut_offset[i + 1] - subtree->mut_offset[i], ni = subtree->miss_offset[i + 1] - subtree->miss_offset[i], nf = subtree->mfs_offset[i + 1] - subtree->mfs_offset[i];
-    if (nm > 16000 || ni > 16000 || nf > 16000) return fail(h, EMAT_ERR_CAPACITY, "a node list exceeds the 16-bit list capacity");
-  }
+  msg = flat_tree_list_limit(*subtree, (int32_t)k_max_list_upload);
+  if (!msg.empty()) return fail(h, EMAT_ERR_CAPACITY, "part " + std::to_string(part_id) + ": " + msg);
   PartHost& ph = h->parts[part_id];
   if (ph.uploaded) return fail(h, EMAT_ERR_STATE, "part uploaded twice");
   ph.tree = FlatTree::from_view(*subtree); ph.n_nodes = subtree->num_nodes;

@@ -333,10 +333,13 @@ EMAT_D uint32_t heap_alloc(Ctx& c, uint32_t bytes) {
   return off;
 }
 template <class T> EMAT_D T* list_ptr(Ctx& c, const ListRef& r) { return (T*)heap_at(c, r.off); }
+// Every write of a list's count goes through here: it must fit the capacity the list was given (list_reserve: at most
+// k_max_list_len, or the part stops with k_part_list_limit), so no count is ever cut to 16 bits unseen.
+EMAT_D void set_list_cnt(Ctx& c, ListRef& r, int n) { if ((uint32_t)n > (uint32_t)r.cap) { EMAT_FAIL(c, k_part_internal); return; } r.cnt = (uint16_t)n; }
 template <class T> EMAT_D void list_reserve(Ctx& c, ListRef& r, int want) {
   if (want <= (int)r.cap) return;
   int nc = (int)r.cap * 2; if (nc < want) nc = want; if (nc < 4) nc = 4;
-  if (nc > 65535) { if (want > 65535) { EMAT_FAIL(c, k_part_overflow); return; } nc = 65535; }
+  if (nc > (int)k_max_list_len) { if (want > (int)k_max_list_len) { EMAT_FAIL(c, k_part_list_limit); return; } nc = (int)k_max_list_len; }   // a ListRef counts in 16 bits: stop, never wrap
   uint32_t off = heap_alloc(c, (uint32_t)nc * (uint32_t)sizeof(T));
   if (c.failed) return;
   T* dst = (T*)heap_at(c, off); const T* src = (const T*)heap_at(c, r.off);
@@ -353,12 +356,12 @@ template <class T> EMAT_D void list_assign(Ctx& c, ListRef& r, const T* src, int
   if (c.failed) return;
   T* dst = list_ptr<T>(c, r);
   for (int i = 0; i < n; ++i) dst[i] = src[i];
-  r.cnt = (uint16_t)n;
+  set_list_cnt(c, r, n);
 }
 template <class T> EMAT_D void list_erase_prefix(Ctx& c, ListRef& r, int k) {
   T* p = list_ptr<T>(c, r);
   for (int i = k; i < (int)r.cnt; ++i) p[i - k] = p[i];
-  r.cnt = (uint16_t)((int)r.cnt - k);
+  set_list_cnt(c, r, (int)r.cnt - k);
 }
 EMAT_D void swap_lists(ListRef& a, ListRef& b) { ListRef t = a; a = b; b = t; }
 
@@ -488,10 +491,10 @@ EMAT_DN void miss_set_from_state(Ctx& c, int node, int l, int from) {
     v = mfs_of(c, node);
     for (int i = n; i > k; --i) v[i] = v[i - 1];
     v[k].site = l; v[k].state = (uint8_t)from; v[k].pad[0] = v[k].pad[1] = v[k].pad[2] = 0;
-    r.cnt = (uint16_t)(n + 1);
+    set_list_cnt(c, r, n + 1);
   } else if (present) {
     for (int i = k; i + 1 < n; ++i) v[i] = v[i + 1];
-    r.cnt = (uint16_t)(n - 1);
+    set_list_cnt(c, r, n - 1);
   }
 }
 

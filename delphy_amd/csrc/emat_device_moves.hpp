@@ -467,7 +467,7 @@ EMAT_DN bool compact_heap(Ctx& c) {
       uint32_t bytes = (uint32_t)refs[k]->cnt * es[k], padded = (bytes + 15u) & ~15u;
       const uint64_t* src = (const uint64_t*)(stage + r); uint64_t* dst = (uint64_t*)heap_at(c, top);
       for (uint32_t q = 0; q < bytes / 8; ++q) dst[q] = src[q];
-      refs[k]->off = top; refs[k]->cap = (uint16_t)(padded / es[k]);
+      refs[k]->off = top; refs[k]->cap = list_cap_for(padded, es[k]);
       top += padded; r += padded;
     }
   }

@@ -33,7 +33,7 @@ EMAT_DN void set_root_muts_from_deltas(Ctx& c, int root, const SVec<SdRec>& d) {
   if (c.failed) return;
   MutRec* m = list_ptr<MutRec>(c, r);
   for (int i = 0; i < d.n; ++i) { EMAT_CHECK(c, c.ref[d.p[i].site] == d.p[i].from); m[i] = make_mut(d.p[i].from, d.p[i].site, d.p[i].to, k_neg_dbl_max); }
-  r.cnt = (uint16_t)d.n;
+  set_list_cnt(c, r, d.n);
 }
 EMAT_DN SVec<SdRec> deltas_from_root_muts(Ctx& c, int root, int extra_cap) { EMAT_TIMED(1);
   SVec<SdRec> d = sc_vec<SdRec>(c, nmuts(c, root) + extra_cap + 1);
@@ -156,8 +156,8 @@ EMAT_DN void edit_slide_P_along_branch(Ctx& c, Edit& e, double new_t_P) {   // t
         else miss_set_from_state(c, X, m.site, m.from);
         nodes_of(c)[P].lambda += dq(c, m.site, m.to, m.from);
       }
-      nodes_of(c)[S].muts.cnt = (uint16_t)(nS + kept);
-      nodes_of(c)[P].muts.cnt = (uint16_t)first;
+      set_list_cnt(c, nodes_of(c)[S].muts, nS + kept);
+      set_list_cnt(c, nodes_of(c)[P].muts, first);
       (void)k;
     }
   } else {
@@ -296,7 +296,7 @@ EMAT_DN void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) { EMAT_TIM
       if (!c.failed) {
         MutRec* m = muts_of(c, X);
         for (int i = 0; i < e.deltas.n; ++i) m[i] = make_mut(e.deltas.p[i].from, e.deltas.p[i].site, e.deltas.p[i].to, mut_t);
-        nodes_of(c)[X].muts.cnt = (uint16_t)e.deltas.n;
+        set_list_cnt(c, nodes_of(c)[X].muts, e.deltas.n);
       }
     }
   }
@@ -570,7 +570,7 @@ EMAT_DN void peel_rooty_graft(Ctx& c, const Graft& g) { EMAT_TIMED(1);   // spr_
   if (!c.failed) {
     MutRec* m = muts_of(c, X);
     for (int i = 0; i < SPX.hot_deltas.n; ++i) m[i] = make_mut(SPX.hot_deltas.p[i].from, SPX.hot_deltas.p[i].site, SPX.hot_deltas.p[i].to, t_mut_X);
-    nodes_of(c)[X].muts.cnt = (uint16_t)SPX.hot_deltas.n;
+    set_list_cnt(c, nodes_of(c)[X].muts, SPX.hot_deltas.n);
   }
   set_root_muts_from_deltas(c, P, r2r);
   nodes_of(c)[P].lambda = calc_lambda_at_node(c, P);
@@ -757,7 +757,7 @@ EMAT_DN void finish_inner_graft_analysis(Ctx& c, Graft& g) { EMAT_TIMED(1);   //
 EMAT_D void recalc_lambda_along_hot_path(Ctx& c, const Graft& g) {   // spr_move.cpp:943-950, 1059-1066
   for (int i = 0; i + 1 < g.nbi; ++i) { int A = g.bi[i].A, B = g.bi[i].B; nodes_of(c)[A].lambda = nodes_of(c)[B].lambda - delta_lambda_across_branch(c, B); }
 }
-EMAT_D void erase_marked_muts(Ctx& c, int node) { MutRec* m = muts_of(c, node); int n = nmuts(c, node), w = 0; for (int i = 0; i < n; ++i) if (m[i].site != -1) m[w++] = m[i]; nodes_of(c)[node].muts.cnt = (uint16_t)w; }
+EMAT_D void erase_marked_muts(Ctx& c, int node) { MutRec* m = muts_of(c, node); int n = nmuts(c, node), w = 0; for (int i = 0; i < n; ++i) if (m[i].site != -1) m[w++] = m[i]; set_list_cnt(c, nodes_of(c)[node].muts, w); }
 EMAT_DN void peel_inner_graft(Ctx& c, const Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:838-953
   if (c.failed || g.nbi == 0) return;
   const int X = g.X, P = nodes_of(c)[X].parent, root = hdr_of(c)->root;
@@ -929,7 +929,7 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
 #endif
   res.p = (Region*)span.lo;
   const int root = hdr_of(c)->root;
-  if (local_scan && deltas.n < 8000) {
+  if (local_scan && deltas.n < k_scan_max_deltas) {
     // ---- local scan (99 % of the scans): at most one counted mutation is crossed inside the scope, so the cur->X delta
     // set is never modified and its size follows from the INITIAL set (+1 if the crossed site is new, -1 if the
     // crossing cancels the entry, 0 if it only rewrites it; site_deltas.h:43-83).  That removes the need to undo
@@ -958,7 +958,7 @@ EMAT_DN SVec<Region> study_seed_fill(Ctx& c, int X, double t_X, const SVec<IvRec
     push_item(init_branch, init_mut_idx, k_no_node, -1, 0, deltas.n);
     while (sp > 0 && !c.failed) {
       const int4 it = stack_top[-sp]; --sp;
-      const int branch = it.x, mut_idx = it.y, pb = it.z, pmi = (int)(int16_t)(it.w & 0xffff);
+      const int branch = it.x, mut_idx = it.y, pb = it.z, pmi = (int)(it.w & 0xffff);   // (16 unsigned bits: a list holds at most k_max_list_len = 65 535 entries; the first item's 0xffff is never looked at, its pusher being k_no_node)
       int fs = (it.w >> 16) & 3, size = (int)((uint32_t)it.w >> 18);
       // move_to_neighbor (spr_study.cpp:43-91)
       if (pb != k_no_node && branch == pb) {
@@ -1301,7 +1301,7 @@ EMAT_D bool wave_local_scan(Ctx& c, Spr1Frame& fr) {
   const int X = fr.X, root = hdr_of(c)->root;
   SVec<IvRec> miss = fr.missing_at_X;
   SVec<SdRec> del = fr.deltas;
-  if (del.n >= 8000) return false;
+  if (del.n >= k_scan_max_deltas) return false;
   // the two sets every region is checked against go to the front of the move's LDS block
   uint32_t front = 0;
   bool in_block = false;   // (see study_seed_fill: empty sets still have their place in the block)
@@ -1347,7 +1347,7 @@ EMAT_D bool wave_local_scan(Ctx& c, Spr1Frame& fr) {
         if (act) {
           const int4 a4 = *(const int4*)&items[k];
           branch = a4.x; mut_idx = a4.y;
-          const int pb = a4.z, pmi = (int)(int16_t)(a4.w & 0xffff);
+          const int pb = a4.z, pmi = (int)(a4.w & 0xffff);   // (unsigned: see study_seed_fill)
           fs = (a4.w >> 16) & 3; size = (int)((uint32_t)a4.w >> 18);
           // move_to_neighbor (spr_study.cpp:43-91)
           if (pb != k_no_node && branch == pb) {

@@ -13,7 +13,7 @@ const char* gt_status_text(int32_t s) {
   switch (s) {
     case k_gt_cut_state_overflow: return "the sequence state at a cut point is larger than the device path holds (k_gt_max_cut_intervals / k_gt_max_cut_deltas)";
     case k_gt_pool_overflow: return "cut-state pool overflow";
-    case k_gt_list_too_long: return "a node list exceeds the 16-bit list capacity";
+    case k_gt_list_too_long: return "a node list (the synthetic delta or missation list of a part's sub-root included) exceeds the 16 000 entries the engine accepts per node and list (16-bit list counts)";
     case k_gt_inconsistent: return "inconsistent mutation chain above a cut point, or a part whose node count changed";
     case k_gt_heap_overflow: return "list heap overflow";
     case k_gt_root_deltas_overflow: return "too many changes of the root sequence in one cycle";
@@ -51,6 +51,7 @@ emat_status emat_tree_upload(emat_backend* h, const emat_flat_tree* tree) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   const std::string msg = validate_flat_tree(*tree, h->L);
   if (!msg.empty()) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_upload: " + msg);
+  { const std::string lim = flat_tree_list_limit(*tree, (int32_t)k_max_list_upload); if (!lim.empty()) return fail(h, EMAT_ERR_CAPACITY, "emat_tree_upload: " + lim); }
   const int n = tree->num_nodes;
   if (tree->mut_offset[tree->root + 1] != tree->mut_offset[tree->root])
     return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_upload: the root node must carry no mutations (fold them into the reference sequence first: Run::normalize_root)");
@@ -61,7 +62,6 @@ emat_status emat_tree_upload(emat_backend* h, const emat_flat_tree* tree) {
     lm[i] = GList{(uint32_t)tree->mut_offset[i], (uint32_t)(tree->mut_offset[i + 1] - tree->mut_offset[i])};
     li[i] = GList{(uint32_t)tree->miss_offset[i], (uint32_t)(tree->miss_offset[i + 1] - tree->miss_offset[i])};
     lf[i] = GList{(uint32_t)tree->mfs_offset[i], (uint32_t)(tree->mfs_offset[i + 1] - tree->mfs_offset[i])};
-    if (lm[i].cnt > k_gt_max_list || li[i].cnt > k_gt_max_list || lf[i].cnt > k_gt_max_list) return fail(h, EMAT_ERR_CAPACITY, "a node list exceeds the 16-bit list capacity");
   }
   for (size_t k = 0; k < nm; ++k) { MutRec r{}; r.t = tree->mut_t[k]; r.site = tree->mut_site[k]; r.from = tree->mut_from[k]; r.to = tree->mut_to[k]; rm[k] = r; }
   for (size_t k = 0; k < ni; ++k) ri[k] = IvRec{tree->miss_start[k], tree->miss_end[k]};

@@ -70,7 +70,7 @@ struct GCoal {                       // the whole grid, built on the device (nul
 constexpr int k_gt_max_cut_intervals = 2048, k_gt_small_cut_intervals = 256;   // the large variant fills the 64 KB of static LDS a workgroup may declare
 constexpr int k_gt_max_cut_deltas = 3968, k_gt_small_cut_deltas = 256;
 constexpr int k_gt_max_root_deltas = 256;   // how many changes of the root sequence k_gt_gather caches in LDS (more are read from HBM)
-constexpr uint32_t k_gt_max_list = 16000;   // ListRef counts are 16 bits (same limit as emat_part_upload)
+constexpr uint32_t k_gt_max_list = k_max_list_upload;   // ListRef counts are 16 bits (same limit as emat_part_upload)
 
 __device__ inline uint32_t gt_a16(uint32_t x) { return (x + 15u) & ~15u; }
 __device__ inline bool gt_iv_contains(const IvRec* v, int n, int l) {   // sorted, disjoint, half-open
@@ -273,9 +273,10 @@ __global__ void __launch_bounds__(k_wave) k_gt_build(GTreeDev g, GPartition pt, 
       r.t = t;
       if (k0 == EMAT_NO_NODE && g.c0[o] != EMAT_NO_NODE) { r.t_min = (float)t; r.t_max = (float)t; }   // frozen boundary node (run.cpp:165-168)
       else { r.t_min = g.t_min[o]; r.t_max = g.t_max[o]; }
-      r.muts.off = top; r.muts.cnt = (uint16_t)nm; r.muts.cap = (uint16_t)(bm / 16u);
-      r.miss.off = top + bm; r.miss.cnt = (uint16_t)ni; r.miss.cap = (uint16_t)(bi / 8u);
-      r.mfs.off = top + bm + bi; r.mfs.cnt = (uint16_t)nf; r.mfs.cap = (uint16_t)(bf / 8u);
+      // (k_gt_measure refused every part with a list above k_gt_max_list: status k_gt_list_too_long, reported by the host)
+      r.muts.off = top; r.muts.cnt = (uint16_t)nm; r.muts.cap = list_cap_for(bm, 16u);
+      r.miss.off = top + bm; r.miss.cnt = (uint16_t)ni; r.miss.cap = list_cap_for(bi, 8u);
+      r.mfs.off = top + bm + bi; r.mfs.cnt = (uint16_t)nf; r.mfs.cap = list_cap_for(bf, 8u);
       const MutRec* sm = s == 0 ? pools.muts + me.root_muts_off : g.mut_heap + lm.off;
       const IvRec* si = s == 0 ? pools.ivs + me.root_miss_off : g.iv_heap + li.off;
       const FsRec* sf = g.fs_heap + lf.off;

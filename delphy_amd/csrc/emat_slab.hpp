@@ -27,6 +27,8 @@ enum PartStatus : int32_t {
   k_part_overflow = 102,       // a container overflowed INSIDE a move (state is not trustworthy)
   k_part_cell_overflow = 103,  // root part needed more coalescent cells than its capacity
   k_part_internal = 104,       // an invariant that the reference CHECKs failed
+  k_part_list_limit = 106,     // a per-node list would exceed what a ListRef can count (k_max_list_len): fatal, reported as EMAT_ERR_CAPACITY
+                               // with the limit named -- never truncated
   k_part_need_cells = 105      // stopped BEFORE a move that would have grown the root part's grid past its capacity (state is consistent,
                                // the move undone and its RNG rewound: stop_for_cells); also reported for a 103 of a staged first leg, whose
                                // slab in HBM is still the state the launch found.  The host gives the part more cells and runs the rest.
@@ -40,6 +42,16 @@ struct ListRef {
   uint16_t cnt;
   uint16_t cap;
 };
+
+// What the 16-bit counts allow.  Everything that writes a ListRef count goes through a check against these (set_list_cnt on the
+// device, the encoders on the host and in k_gt_build); the boundary accepts lists up to k_max_list_upload entries per node, which
+// leaves a list room to grow four-fold before the device stops the part with k_part_list_limit.
+constexpr uint32_t k_max_list_len = 65535;      // ListRef::cnt / cap
+constexpr uint32_t k_max_list_upload = 16000;   // per-node list length accepted by emat_part_upload / emat_tree_upload / a repartition
+// Candidate-scan items pack {pusher's mutation index: 16 unsigned bits -- any index a list can have --, crossings: 2 bits, size of the
+// site-delta set: 14 bits}; scans whose delta set is not far below 2^14 take the general (unpacked) algorithm instead.
+constexpr int k_scan_max_deltas = 8000;
+constexpr uint16_t list_cap_for(uint32_t padded_bytes, uint32_t elem_bytes) { return (uint16_t)(padded_bytes / elem_bytes > k_max_list_len ? k_max_list_len : padded_bytes / elem_bytes); }   // (constexpr: host and device)
 
 struct MutRec {     // 16 B   (reference Mutation{from, site, to, t}, core/mutations.h:21-29)
   double t;

@@ -119,5 +119,18 @@ inline std::string validate_flat_tree(const emat_flat_tree& v, int32_t num_sites
   return "";
 }
 
+// No node may carry more than `max_list` mutations, missation intervals or from-states: the engine's per-node list counts are 16 bits
+// wide (ListRef, emat_slab.hpp), so a longer list is refused at the boundary -- loudly, with the numbers -- never truncated.
+// (A genome longer than SARS-CoV-2's can get there: a sub-root's synthetic delta list has up to one entry per site.)  "" when fine.
+inline std::string flat_tree_list_limit(const emat_flat_tree& v, int32_t max_list) {
+  for (int32_t i = 0; i < v.num_nodes; ++i) {
+    const int32_t nm = v.mut_offset[i + 1] - v.mut_offset[i], ni = v.miss_offset[i + 1] - v.miss_offset[i], nf = v.mfs_offset[i + 1] - v.mfs_offset[i];
+    if (nm > max_list || ni > max_list || nf > max_list)
+      return "node " + std::to_string(i) + " carries " + std::to_string(nm) + " mutations, " + std::to_string(ni) + " missation intervals and " + std::to_string(nf) +
+             " from-states: the engine holds at most " + std::to_string(max_list) + " entries per node and list (16-bit list counts)";
+  }
+  return "";
+}
+
 }  // namespace emat
 #endif  // EMAT_FLAT_TREE_HPP_

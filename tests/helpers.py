@@ -123,9 +123,10 @@ def run_parity(sc, num_parts, moves_per_part, seed=11, topology=True, only_displ
         gpu.close(); orc.close()
 
 
-def replay_device_parts_in_the_oracle(sc, b, run, ref, moves_total, trace):
+def replay_device_parts_in_the_oracle(sc, b, run, ref, moves_total, trace, oracle_parts=None):
     """Hand the oracle exactly what the device starts a pass from -- every part's tree as the kernels cut it, the coalescent
-    tables as the kernels built them, the position of every part's random stream -- run the pass on both, compare everything."""
+    tables as the kernels built them, the position of every part's random stream -- run the pass on both, compare everything.
+    `oracle_parts`: a list that receives the ORACLE's part trees after the pass (what its own moves made of them)."""
     n, root_part = run.num_parts()
     trees = [b.part_download(p) for p in range(n)]
     rngs = [b.part_rng(p) for p in range(n)]
@@ -153,6 +154,8 @@ def replay_device_parts_in_the_oracle(sc, b, run, ref, moves_total, trace):
         orc.run_moves_counts(counts, threads=4)
         for p in range(n):
             compare_part(b, orc, p, trees[p].num_nodes, trace, 1e-9, int(counts[p]))
+            if oracle_parts is not None:
+                oracle_parts.append(orc.part_download(p))
     finally:
         orc.close()
     return n

@@ -256,6 +256,33 @@ def test_tree_info_and_params_flatbuffers_round_trip():
         _check_params(_call(L.emat_dphy_params_flatbuffer, C.byref(q), sc.num_sites), q, sc.num_sites)
 
 
+def read_dphy(path):
+    """The version-3 container of doc/dphy_file_format.md: (preamble fields, TreeInfo buffer, [(Tree buffer, Params buffer)], metadata
+    JSON); checks the magic, the sentinel and the trailing offset that points at it."""
+    b = open(path, "rb").read()
+    assert b[:4] == b"DPHY" and struct.unpack_from("<I", b, 4)[0] == 3
+    p = 8
+    def rd_str(p):
+        (n,) = struct.unpack_from("<I", b, p); return b[p + 4: p + 4 + n].decode(), p + 4 + n
+    hdr = {}
+    hdr["version"], p = rd_str(p); (hdr["build"],) = struct.unpack_from("<I", b, p); p += 4; hdr["commit"], p = rd_str(p)
+    hdr["knee"], hdr["steps_per_sample"], hdr["alpha_on"], hdr["mpox"], hdr["mu_on"] = struct.unpack_from("<5I", b, p); p += 20
+    (hdr["mu"],) = struct.unpack_from("<f", b, p); p += 4
+    (n_info,) = struct.unpack_from("<I", b, p); p += 4
+    info = b[p: p + n_info]; p += n_info
+    states = []
+    while True:
+        (l1,) = struct.unpack_from("<I", b, p)
+        if l1 == 0:
+            sentinel = p; p += 4
+            break
+        (l2,) = struct.unpack_from("<I", b, p + 4); p += 8
+        states.append((b[p: p + l1], b[p + l1: p + l1 + l2])); p += l1 + l2
+    meta, p = rd_str(p)
+    assert struct.unpack_from("<Q", b, p)[0] == sentinel and p + 8 == len(b)
+    return hdr, info, states, meta
+
+
 def test_dphy_file_layout(tmp_path):
     L = _lib()
     sc = make_scenario("C1", num_tips=40, num_sites=500)
@@ -269,31 +296,16 @@ def test_dphy_file_layout(tmp_path):
         q.step = 1000000 * (s + 1)
         assert L.emat_dphy_write_state(w, C.byref(v), ref.ctypes.data_as(C.POINTER(C.c_uint8)), sc.num_sites, C.byref(q)) == 0
     assert L.emat_dphy_close(w) == 0
-    b = open(path, "rb").read()
-    assert b[:4] == b"DPHY" and struct.unpack_from("<I", b, 4)[0] == 3
-    p = 8
-    def rd_str(p):
-        (n,) = struct.unpack_from("<I", b, p); return b[p + 4: p + 4 + n].decode(), p + 4 + n
-    ver, p = rd_str(p); (build,) = struct.unpack_from("<I", b, p); p += 4; commit, p = rd_str(p)
-    assert (ver, build, commit) == ("1.3.7", 2047, "abc1234")
-    knee, sps, alpha_on, mpox, mu_on = struct.unpack_from("<5I", b, p); p += 20
-    (mu,) = struct.unpack_from("<f", b, p); p += 4
-    assert (knee, sps, alpha_on, mpox, mu_on) == (0, 1000000, 0, 0, 1) and mu == np.float32(2e-6)
-    (n_info,) = struct.unpack_from("<I", b, p); p += 4
-    assert len(Decoded(b[p: p + n_info], "TreeInfo").value["node_infos"]) == sc.tree.num_nodes; p += n_info
+    hdr, info, states, meta = read_dphy(path)
+    assert (hdr["version"], hdr["build"], hdr["commit"]) == ("1.3.7", 2047, "abc1234")
+    assert (hdr["knee"], hdr["steps_per_sample"], hdr["alpha_on"], hdr["mpox"], hdr["mu_on"]) == (0, 1000000, 0, 0, 1) and hdr["mu"] == np.float32(2e-6)
+    assert len(Decoded(info, "TreeInfo").value["node_infos"]) == sc.tree.num_nodes
     steps = []
-    while True:
-        (l1,) = struct.unpack_from("<I", b, p)
-        if l1 == 0:
-            sentinel = p; p += 4
-            break
-        (l2,) = struct.unpack_from("<I", b, p + 4); p += 8
-        _check_tree(b[p: p + l1], sc.tree, ref); p += l1
-        steps.append(Decoded(b[p: p + l2], "Params").value["step"]); p += l2
+    for tree_buf, params_buf in states:
+        _check_tree(tree_buf, sc.tree, ref)
+        steps.append(Decoded(params_buf, "Params").value["step"])
     assert steps == [1000000, 2000000, 3000000]
-    meta, p = rd_str(p)
     assert json.loads(meta)["confidence"] == 90
-    assert struct.unpack_from("<Q", b, p)[0] == sentinel and p + 8 == len(b)
 
 
 def test_times_are_rounded_to_float32_as_the_reference_rounds_them():

@@ -462,3 +462,47 @@ def test_check_derived_is_the_references_paranoid_check_on_the_device():
     run.set_device_tree(True); run.set_paranoid(True)
     run.do_mcmc_steps(3 * 64 * 800, 64 * 800)
     run.close(); b.close()
+
+
+def test_recalc_derived_right_after_a_pass_waits_for_the_side_classes():
+    """emat_run_* -> emat_recalc_derived -> emat_run_* -> emat_check_derived with no getter or synchronize in between.  The side
+    classes of a pass (the root part, the giants) run on streams of their own that the engine's stream does not wait for at
+    launch time; k_recalc_derived rewrites lambda / missing counts / totals of EVERY part, so it has to join them first and
+    the next pass's side launches have to follow it.  Same calls with a synchronize after each give the result to compare with
+    (the recomputation is deterministic, so the two engines must agree bit for bit)."""
+    sc = make_scenario("C3", num_tips=1500, num_sites=12000, uncertain_tips=0.1)
+    parts, incl, seeds, root_part, ref = split_parts(sc, 40, 9)
+    a = d.EmatBackend(sc.num_sites); b = d.EmatBackend(sc.num_sites)
+    try:
+        configure(a, sc, ref, parts, incl, seeds, root_part); configure(b, sc, ref, parts, incl, seeds, root_part)
+        for _ in range(3):
+            a.run_moves_per_part(2500); a.recalc_derived(); a.run_moves_per_part(500)
+            b.run_moves_per_part(2500); b.synchronize(); b.recalc_derived(); b.synchronize(); b.run_moves_per_part(500); b.synchronize()
+        part, dev4 = a.check_derived(1.0)
+        assert dev4[3] == 0
+        assert a.totals() == b.totals()
+        for p in (0, root_part, len(parts) - 1):
+            assert_trees_match(a.part_download(p), b.part_download(p), 0.0, "part %d" % p)
+            la, na, Ga, Aa = a.part_derived(p, parts[p].num_nodes); lb, nb, Gb, Ab = b.part_derived(p, parts[p].num_nodes)
+            assert np.array_equal(la, lb) and np.array_equal(na, nb) and Ga == Gb and Aa == Ab
+    finally:
+        a.close(); b.close()
+
+
+@pytest.mark.parametrize("release", ["fast", "full"])
+def test_tickets_handed_over_across_xcds_are_the_same_chain(monkeypatch, release):
+    """The default launch puts the tickets of a part on one XCD (ticket stride a multiple of 8); nothing may DEPEND on that.
+    EMAT_TICKET_XCD_SPREAD=1 makes the stride odd, so that every hand-over crosses from one XCD's L2 to another's -- through the
+    write-through stores + agent-scope acquire of the default path ("fast") and through the plain agent-scope release ("full",
+    EMAT_TICKET_RELEASE) -- with 5 and 8 tickets per part and pass, on parts that are staged whole, by their prefix, and not at
+    all (EMAT_LDS_MAX).  Every chain must still be the oracle's, move for move."""
+    monkeypatch.setenv("EMAT_TICKET_XCD_SPREAD", "1")
+    monkeypatch.setenv("EMAT_TICKET_RELEASE", release)
+    sc = make_scenario("C3", num_tips=1500, num_sites=8000, uncertain_tips=0.2)
+    for chunks, lds_max in (("5", None), ("8", "6144")):
+        monkeypatch.setenv("EMAT_CHUNKS", chunks)
+        if lds_max is None:
+            monkeypatch.delenv("EMAT_LDS_MAX", raising=False)
+        else:
+            monkeypatch.setenv("EMAT_LDS_MAX", lds_max)
+        run_parity(sc, 61, 1203, seed=59, trace=1203)     # 61 parts: an odd stride whatever the class sizes
