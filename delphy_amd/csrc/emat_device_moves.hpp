@@ -205,7 +205,7 @@ EMAT_D SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) {
   bool complicated = false;
   for (int i = 0; i < n && !complicated; ++i) for (int j = i + 1; j < n; ++j) if (old[i].site == old[j].site) { complicated = true; break; }
   if (!complicated) {
-    for (int i = 0; i < n; ++i) push(c, out, make_mut(old[i].from, old[i].site, old[i].to, uniform_oc(c, t_P, t_X)));
+    for (int i = 0; i < n; ++i) { MutRec r = make_mut(old[i].from, old[i].site, old[i].to, uniform_oc(c, t_P, t_X)); r.pad = (uint16_t)i; push(c, out, r); }   // pad: where it came from (reform_factors)
   } else {
     // distinct sites in ascending order; per site, fresh sorted times assigned in the old order
     int prev_site = -1;
@@ -215,7 +215,7 @@ EMAT_D SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) {
       if (l == 0x7fffffff) break;
       prev_site = l;
       int first = out.n, k = 0;
-      for (int i = 0; i < n; ++i) if (old[i].site == l) { push(c, out, make_mut(old[i].from, old[i].site, old[i].to, uniform_oc(c, t_P, t_X))); ++k; }
+      for (int i = 0; i < n; ++i) if (old[i].site == l) { MutRec r = make_mut(old[i].from, old[i].site, old[i].to, uniform_oc(c, t_P, t_X)); r.pad = (uint16_t)i; push(c, out, r); ++k; }
       // sort just the times of this site's block
       for (int a = first + 1; a < first + k && a < out.n; ++a) { double x = out.p[a].t; int b = a - 1; while (b >= first && out.p[b].t > x) { out.p[b + 1].t = out.p[b].t; --b; } out.p[b + 1].t = x; }
     }
@@ -224,6 +224,34 @@ EMAT_D SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) {
   return out;
 }
 
+// What a mutation contributes to a branch's log G besides its time (phylo_tree_calc.h:185-206): A = mu nu (q_from - q_to), the
+// factor of (t - t_P), and B = log(mu nu q_from,to).  A branch reform evaluates the reference's sum twice -- over the branch's
+// mutations as they are and as re-timed -- and both lists hold the SAME mutations (randomize_branch_mutation_times only draws
+// new times): the factors are gathered once, all per-site loads of the branch in one round trip (they used to be one L2 round trip
+// and one logarithm per mutation and list, in sequence), and each sum then runs in its own order over the same operands -- bit
+// for bit the reference's two numbers.  A re-timed mutation carries the index of the one it came from in its `pad` field.
+struct ReformFactors { double* A; double* B; };
+EMAT_D ReformFactors reform_factors(Ctx& c, const MutRec* m, int n) {
+  ReformFactors f; f.A = (double*)sc_alloc(c, (uint32_t)n * 16u); f.B = f.A + n;
+  if (c.failed) return f;
+  for (int j0 = 0; j0 < n; j0 += 4) {
+    int l[4]; int pa[4]; double nu[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) l[k] = m[j0 + k < n ? j0 + k : n - 1].site;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { pa[k] = (int)c.part[l[k]]; nu[k] = c.nu[l[k]]; }     // eight independent loads in flight
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (j0 + k < n) {
+      const MutRec& mm = m[j0 + k];
+      const double mn = mu_of(c)[pa[k]] * nu[k];
+      const double* q = q_of(c) + pa[k] * 16;
+      f.A[j0 + k] = mn * (-q[(int)mm.from * 5] - -q[(int)mm.to * 5]);      // mu nu (q_a(from) - q_a(to)), q_a = -q_aa
+      f.B[j0 + k] = mn * q[(int)mm.from * 4 + (int)mm.to];                 // the logarithm's argument; taken below
+    }
+  }
+  for (int j = 0; j < n; ++j) f.B[j] = m_log(f.B[j]);
+  return f;
+}
 template <bool kRoot> EMAT_SIMPLE_MOVE void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
   begin_move(c, k_branch_reform);
   if (hdr_of(c)->n_nodes < 3) return;
@@ -235,15 +263,39 @@ template <bool kRoot> EMAT_SIMPLE_MOVE void branch_reform_move(Ctx& c) {   // su
   const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t;
   // in a part without the run's root, spr_move_core returns at once for a branch next to the subroot (subrun.cpp:689-697)
   if (kRoot) { if (P == hdr_of(c)->root) { spr_move_core(c, X, S, t_P, 1.0); if (c.failed) return; } }
+  const double lam = nodes_of(c)[X].lambda;
+  const int n = nmuts(c, X);
+  if (n == 0) {
+    // nothing to re-time (six branches in ten at C4): the reference's two branch_log_G are one and the same number, no random
+    // number is drawn, and the empty list replaces itself
+    const double g = -lam * (t_X - t_P), delta_log_G = g - g;
+    c.bytes += 2 * 64;
+    const bool acc = mh_accept(c, delta_log_G);
+    note_move(c, X, delta_log_G, acc, k_branch_reform);
+    if (acc) hdr_of(c)->log_G += delta_log_G;
+    return;
+  }
+#ifdef EMAT_X_NO_FACTORS
   SVec<MutRec> nm = randomize_branch_mutation_times(c, X);
   if (c.failed) return;
-  const double lam = nodes_of(c)[X].lambda;
-  double delta_log_G = branch_log_G(c, t_P, t_X, lam, nm.p, nm.n) - branch_log_G(c, t_P, t_X, lam, muts_of(c, X), nmuts(c, X));
+  const double delta_log_G = branch_log_G(c, t_P, t_X, lam, nm.p, nm.n) - branch_log_G(c, t_P, t_X, lam, muts_of(c, X), nmuts(c, X));
+#else
+  const ReformFactors f = reform_factors(c, muts_of(c, X), n);
+  SVec<MutRec> nm = randomize_branch_mutation_times(c, X);
+  if (c.failed) return;
+  double g_new = -lam * (t_X - t_P), g_old = g_new;
+  { const MutRec* m = nm.p; for (int i = nm.n - 1; i >= 0; --i) { const int j = (int)m[i].pad; g_new -= f.A[j] * (m[i].t - t_P); g_new += f.B[j]; } }
+  { const MutRec* m = muts_of(c, X); for (int i = n - 1; i >= 0; --i) { g_old -= f.A[i] * (m[i].t - t_P); g_old += f.B[i]; } }
+  const double delta_log_G = g_new - g_old;
+#endif
   c.bytes += 2 * 64 + 2 * 16 * nm.n;
   double log_mh = delta_log_G;
   bool acc = mh_accept(c, log_mh);
   note_move(c, X, log_mh, acc, k_branch_reform);
-  if (acc) { list_assign<MutRec>(c, nodes_of(c)[X].muts, nm.p, nm.n); hdr_of(c)->log_G += delta_log_G; c.bytes += 16 * nm.n; }
+  if (acc) {
+    for (int i = 0; i < nm.n; ++i) nm.p[i].pad = 0;
+    list_assign<MutRec>(c, nodes_of(c)[X].muts, nm.p, nm.n); hdr_of(c)->log_G += delta_log_G; c.bytes += 16 * nm.n;
+  }
 }
 
 // subrun.cpp:325-350, iterative with an explicit stack in scratch
@@ -509,7 +561,7 @@ EMAT_NOTAIL EMAT_D bool mcmc_sub_iteration(Ctx& c) {
   }
   }
 #ifdef EMAT_PROFILE_PHASES
-  hdr_of(c)->phase_ticks[(c.tr_kind >= 3.0) ? 15 : 14] += clock64() - _mv0;
+  { const long long _dt = clock64() - _mv0; hdr_of(c)->phase_ticks[(c.tr_kind >= 3.0) ? 15 : 14] += _dt; if (c.tr_kind == 0.0) EMAT_COUNT(c, 10, _dt); else if (c.tr_kind == 1.0) EMAT_COUNT(c, 15, _dt); }   // (inner-node / tip displacements apart: reserved[10], [15])
 #endif
   if (c.svc != 0 && !c.failed) return true;   // parked: the move is not over
   c.phase = 0; c.svc = 0;

@@ -293,6 +293,9 @@ def slow_phase_probe(nparts=8192, moves=1000, top=6):
         e = np.array(list(buf), dtype=np.float64); k = max(1.0, e[0])
         print("    wave scans %d: missing intervals at X %.1f, site deltas %.1f, items %.1f, levels %.1f, in HBM %d, fell back to serial %d, sets not in LDS %d | scan ticks per scan %.0f"
               % (e[0], e[1] / k, e[2] / k, e[3] / k, e[4] / k, e[5], e[6], e[7], v[6] / k))
+        pr = st[p]["proposed"]
+        print("    ticks per move: inner-node displacement %.0f, tip displacement %.0f, branch reform %.0f, subtree slide + SPR1 %.0f | cells per coalescent delta %.1f (%.2f deltas per move)"
+              % (e[10] / max(1, pr[0]), e[15] / max(1, pr[1]), (v[14] - e[10] - e[15]) / max(1, pr[2]), v[15] / max(1, pr[3] + pr[4]), e[13] / max(1.0, e[14]), e[14] / max(1, sum(pr))))
         topo = max(1, st[p]["proposed"][3] + st[p]["proposed"][4])
         print("    arena bytes per topology move: %.0f from HBM scratch, %.0f from LDS (open vectors trimmed in HBM %d, spans committed in HBM %d)" % (e[8] / topo, e[9] / topo, e[11], e[12]))
     eng.close()
