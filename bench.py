@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--only-displace", action="store_true", help="diagnostic: only inner-node displacement moves")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-time budget of each CPU baseline sample")
+    ap.add_argument("--verify-parts", type=int, default=4, help="N > 1: parts per rank whose final trees are compared with a one-GPU run of the same partition on rank 0 "
+                    "(outside the timed region; the counters of ALL parts are compared whatever this says; 0 = no check)")
     ap.add_argument("--no-inclusive", action="store_true", help="skip the host-cycle-inclusive figure (repartition + moves + reassemble through the run driver)")
     args = ap.parse_args()
     if args.parts is None:
@@ -190,6 +192,80 @@ def inclusive_cycles(sc, args, cycles=3):
             "host_tree": dict(host, what="the same cycles with the tree on the host: subtree build + slab encode + H2D + moves + D2H + decode + reassemble")}
 
 
+def _part_digest(backend, p):
+    """What a part's chain left behind, as numbers that survive a float64 tensor: 48 bits of a hash of everything discrete (topology,
+    sites, states, interval endpoints), the sum of its node times, its log G and augmented prior, its move and random-draw counts."""
+    import hashlib
+    import numpy as np
+    t = backend.part_download(p)
+    h = hashlib.sha256()
+    for a in (t.parent, t.child0, t.child1, t.mut_offset, t.mut_site, t.mut_from, t.mut_to, t.miss_offset, t.miss_start, t.miss_end, t.mfs_offset, t.mfs_site, t.mfs_state):
+        h.update(np.ascontiguousarray(a).tobytes())
+    _, _, log_G, log_aug = backend.part_derived(p, t.num_nodes)
+    st = backend.part_stats(p)
+    return [float(int.from_bytes(h.digest()[:6], "little")), float(np.sum(t.t)), log_G, log_aug, float(st["moves_done"]), float(st["rng_draws"])]
+
+
+def scale_check(args, sc, eng, passes, world, rank, shared_gpu, dist, torch):
+    """N > 1: is what the N ranks computed what ONE GPU computes?  Every chain is a deterministic function of its part, its seed and
+    the coalescent tables, so after the same number of passes a part must be the same part wherever it ran.  Every rank reports the
+    move and random-draw counters of all its parts and the digests of `--verify-parts` of them (plus the root part); rank 0 then
+    runs the whole partition alone on its own GPU, outside the timed region, and compares: counters of every part exactly,
+    everything discrete of the sampled parts exactly, times / log G / prior to rounding (the cross-rank sums of the coalescent grid
+    associate differently from the one-rank sum: last-place differences in the tables)."""
+    import numpy as np
+    from delphy_amd.sharding import ShardedEngine
+    dev = "cpu" if shared_gpu else "cuda"
+    nloc, lo = eng.num_local_parts, eng.part_lo
+    k = max(0, min(args.verify_parts, nloc))
+    sample = sorted(set([int(round(i * (nloc - 1) / max(1, k - 1))) for i in range(k)] + ([eng.local_root] if eng.local_root >= 0 else [])))
+    width = max(1, args.verify_parts) + 1
+    dig = np.full((width, 7), -1.0)
+    for j, p in enumerate(sample):
+        dig[j] = [float(lo + p)] + _part_digest(eng.backend, p)
+    cap = (eng.total_parts + world - 1) // world + 1
+    ctr = np.full((cap, 3), -1.0)
+    for p in range(nloc):
+        st = eng.backend.part_stats(p)
+        ctr[p] = [float(lo + p), float(st["moves_done"]), float(st["rng_draws"])]
+    mine = torch.from_numpy(np.concatenate([dig.reshape(-1), ctr.reshape(-1)])).to(dev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    out = None
+    if rank == 0:
+        ref = ShardedEngine(sc, num_parts=args.parts, seed=20261001, rank=0, world=1, device=eng.backend_device, use_lds=not args.no_lds, max_part_nodes=args.max_part_nodes)
+        ref.topology, ref.only_displace = eng.topology, eng.only_displace
+        ref.setup()
+        for _ in range(passes):
+            ref.backend.run_moves_per_part(args.moves_per_part)
+        ref.backend.synchronize()
+        ref_ctr = np.array([[ref.backend.part_stats(p)["moves_done"], ref.backend.part_stats(p)["rng_draws"]] for p in range(ref.num_local_parts)], np.float64)
+        seen, ranks_seen, ctr_bad, verified, discrete_bad, max_rel = np.zeros(ref.num_local_parts, bool), 0, 0, 0, 0, 0.0
+        for r, e in enumerate(every):
+            e = e.cpu().numpy()
+            d_r, c_r = e[: width * 7].reshape(width, 7), e[width * 7:].reshape(cap, 3)
+            c_r = c_r[c_r[:, 0] >= 0]
+            ranks_seen += 1 if c_r.shape[0] > 0 else 0
+            ids = c_r[:, 0].astype(np.int64)
+            seen[ids] = True
+            ctr_bad += int(np.sum((c_r[:, 1] != ref_ctr[ids, 0]) | (c_r[:, 2] != ref_ctr[ids, 1])))
+            for row in d_r[d_r[:, 0] >= 0]:
+                want = _part_digest(ref.backend, int(row[0]))
+                verified += 1
+                discrete_bad += int(row[1] != want[0] or row[5] != want[4] or row[6] != want[5])
+                for a, b in zip(row[2:5], want[1:4]):
+                    max_rel = max(max_rel, abs(a - b) / max(1.0, abs(a), abs(b)))
+        out = {"ranks_seen": ranks_seen, "rccl_world": dist.get_world_size(), "backend": dist.get_backend(), "passes_compared": passes,
+               "parts_of_the_run": int(ref.num_local_parts), "parts_reported": int(seen.sum()), "parts_with_other_move_or_draw_counts": ctr_bad,
+               "parts_verified": verified, "parts_whose_trees_differ": discrete_bad, "max_rel_err": max_rel,
+               "ok": bool(seen.all() and ranks_seen == world and ctr_bad == 0 and discrete_bad == 0 and max_rel < 1e-9),
+               "reference": "the same partition and passes on rank 0's GPU alone (world = 1), outside the timed region: move and random-draw counts of every part, "
+                            "topology / sites / states / intervals (hashed) and node times, log G, augmented prior of the sampled parts and of the root part"}
+        ref.close()
+    dist.barrier()
+    return out
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -286,6 +362,10 @@ def main():
     moves_timed_all = total_parts * args.moves_per_part * args.steps
     value = moves_timed_all / dt
     log_G, log_prior = eng.global_totals()
+    check_scale = None
+    if world > 1 and args.verify_parts > 0:
+        eng.backend_device = local_rank
+        check_scale = scale_check(args, sc, eng, args.warmup + args.steps + len(ev_ms), world, rank, shared_gpu, dist, torch)
 
     # roofline of the dominant kernel (k_run_moves): algorithmic bytes counted by the kernel per executed move
     launches = args.steps + len(ev_ms)
@@ -380,6 +460,7 @@ def main():
             "inclusive": inclusive,
             "mixing": mixing,
             "check": {"log_G": log_G, "log_augmented_coalescent_prior": log_prior, "parts_stopped": bad},
+            "scale_check": check_scale,
         }
         print(json.dumps(out))
     if world > 1:

@@ -8,6 +8,7 @@ without the built library or without a HIP device raises.
 from .engine import (  # noqa: F401
     EmatBackend,
     EmatError,
+    EmatMultiRun,
     EmatRun,
     FlatTree,
     PopModel,

@@ -313,6 +313,15 @@ def load_library():
         "emat_tree_export_nodes": [B, P(C.c_uint8), u64, P(u64)], "emat_tree_apply_nodes": [B, P(C.c_uint8), u64], "emat_tree_reassemble_end": [B],
         "emat_run_note_device_reassembled": [R, i32, P(i32), P(C.c_uint8)], "emat_run_set_paranoid": [R, i32], "emat_run_set_reference_remainder": [R, i32],
     }
+    M = C.c_void_p
+    sigs.update({
+        "emat_run_create_multi": [P(i32), i32, P(_ConfigC), P(_FlatTreeC), P(C.c_uint8), i32, u64, i32, P(M)], "emat_multi_destroy": [M],
+        "emat_multi_set_num_parts": [M, i32], "emat_multi_set_max_part_nodes": [M, i32], "emat_multi_set_hky": [M, dbl, dbl, P(dbl), P(dbl)], "emat_multi_set_pop_model": [M, P(_PopModelC)],
+        "emat_multi_set_coalescent_t_step": [M, dbl], "emat_multi_set_flags": [M, i32, i32], "emat_multi_set_paranoid": [M, i32],
+        "emat_multi_repartition": [M], "emat_multi_run_moves": [M, i64], "emat_multi_check_derived": [M, dbl], "emat_multi_reassemble": [M],
+        "emat_multi_get_totals": [M, P(dbl), P(dbl)], "emat_multi_do_mcmc_steps": [M, i64, i64],
+        "emat_multi_tree_sizes": [M, P(i32), P(i32), P(i32), P(i32)], "emat_multi_tree_get": [M, i32, P(_FlatTreeC), P(C.c_uint8)],
+    })
     for name, args in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = args
@@ -323,6 +332,11 @@ def load_library():
     lib.emat_build_id.restype = C.c_char_p
     lib.emat_run_last_error.argtypes = [R]
     lib.emat_run_last_error.restype = C.c_char_p
+    lib.emat_multi_last_error.argtypes = [M]; lib.emat_multi_last_error.restype = C.c_char_p
+    lib.emat_multi_exchange.argtypes = [M]; lib.emat_multi_exchange.restype = C.c_char_p
+    lib.emat_multi_num_shards.argtypes = [M]; lib.emat_multi_num_shards.restype = C.c_int32
+    lib.emat_multi_backend.argtypes = [M, i32]; lib.emat_multi_backend.restype = C.c_void_p
+    lib.emat_multi_shard.argtypes = [M, i32]; lib.emat_multi_shard.restype = C.c_void_p
     lib.emat_synth_destroy.argtypes = [S]
     lib.emat_synth_destroy.restype = None
     _lib = lib
@@ -913,3 +927,97 @@ class EmatRun:
         t = C.c_double()
         self._ck(self._lib.emat_run_t_max_tip(self._h, C.byref(t)), "emat_run_t_max_tip")
         return float(t.value)
+
+
+class EmatMultiRun:
+    """One run over several GPUs of ONE process (include/emat_host.h, emat_run_create_multi): n backends with the whole tree in the HBM
+    of each, the exchanges of a cycle done in C++ over RCCL ("rccl"), through host buffers ("host"), or whichever applies ("auto")."""
+    EXCHANGE = {"host": 0, "rccl": 1, "auto": 2}
+
+    def __init__(self, devices: Sequence[int], tree: FlatTree, ref_sequence: np.ndarray, seed: int, exchange: str = "auto", trace_moves: int = 0, use_lds: bool = True):
+        self._lib = load_library()
+        self._ref = np.ascontiguousarray(ref_sequence, np.uint8)
+        self.num_sites = int(self._ref.shape[0])
+        dev = np.ascontiguousarray(devices, np.int32)
+        cfg = _ConfigC(0, self.num_sites, 0, 0.0, trace_moves, 1 if use_lds else 0)
+        self._h = C.c_void_p()
+        v = tree.c_view()
+        st = self._lib.emat_run_create_multi(_ptr(dev, C.c_int32), int(dev.shape[0]), C.byref(cfg), C.byref(v), _ptr(self._ref, C.c_uint8), self.num_sites, int(seed),
+                                             self.EXCHANGE[exchange], C.byref(self._h))
+        if st != 0:
+            raise EmatError("emat_run_create_multi failed: %s (the engine needs HIP devices; exchange \"rccl\" needs librccl.so and one device per shard)" % STATUS_NAMES.get(st, st))
+        self.num_shards = int(self._lib.emat_multi_num_shards(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.emat_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st: int, what: str):
+        if st != 0:
+            msg = self._lib.emat_multi_last_error(self._h)
+            raise EmatError("%s: %s (%s)" % (what, STATUS_NAMES.get(st, st), msg.decode() if msg else ""))
+
+    @property
+    def exchange(self) -> str:
+        return self._lib.emat_multi_exchange(self._h).decode()
+
+    def backend_handle(self, shard: int):
+        return self._lib.emat_multi_backend(self._h, shard)
+
+    def set_num_parts(self, n: int):
+        self._ck(self._lib.emat_multi_set_num_parts(self._h, n), "emat_multi_set_num_parts")
+
+    def set_hky(self, mu: float, kappa: float, pi, nu_l=None):
+        pi = np.ascontiguousarray(pi, np.float64)
+        nu = None if nu_l is None else np.ascontiguousarray(nu_l, np.float64)
+        self._ck(self._lib.emat_multi_set_hky(self._h, mu, kappa, _ptr(pi, C.c_double), None if nu is None else _ptr(nu, C.c_double)), "emat_multi_set_hky")
+
+    def set_pop_model(self, pop: PopModel):
+        m = pop.c_struct()
+        self._ck(self._lib.emat_multi_set_pop_model(self._h, C.byref(m)), "emat_multi_set_pop_model")
+
+    def set_coalescent_t_step(self, t_step: float):
+        self._ck(self._lib.emat_multi_set_coalescent_t_step(self._h, t_step), "emat_multi_set_coalescent_t_step")
+
+    def set_flags(self, only_displacing_inner_nodes: bool = False, topology_moves_enabled: bool = True):
+        self._ck(self._lib.emat_multi_set_flags(self._h, int(only_displacing_inner_nodes), int(topology_moves_enabled)), "emat_multi_set_flags")
+
+    def set_paranoid(self, on: bool = True):
+        self._ck(self._lib.emat_multi_set_paranoid(self._h, int(on)), "emat_multi_set_paranoid")
+
+    def repartition(self):
+        self._ck(self._lib.emat_multi_repartition(self._h), "emat_multi_repartition")
+
+    def run_moves(self, count: int):
+        self._ck(self._lib.emat_multi_run_moves(self._h, count), "emat_multi_run_moves")
+
+    def check_derived(self, tol_scale: float = 1.0):
+        self._ck(self._lib.emat_multi_check_derived(self._h, tol_scale), "emat_multi_check_derived")
+
+    def reassemble(self):
+        self._ck(self._lib.emat_multi_reassemble(self._h), "emat_multi_reassemble")
+
+    def totals(self):
+        g, a = C.c_double(), C.c_double()
+        self._ck(self._lib.emat_multi_get_totals(self._h, C.byref(g), C.byref(a)), "emat_multi_get_totals")
+        return float(g.value), float(a.value)
+
+    def do_mcmc_steps(self, steps: int, local_moves_per_cycle: int = -1):
+        self._ck(self._lib.emat_multi_do_mcmc_steps(self._h, steps, local_moves_per_cycle), "emat_multi_do_mcmc_steps")
+
+    def tree(self, shard: int = 0):
+        n, nm, ni, nf = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._lib.emat_multi_tree_sizes(self._h, C.byref(n), C.byref(nm), C.byref(ni), C.byref(nf)), "emat_multi_tree_sizes")
+        t = FlatTree.empty(n.value, nm.value, ni.value, nf.value)
+        v = t.c_view()
+        ref = np.zeros(self.num_sites, np.uint8)
+        self._ck(self._lib.emat_multi_tree_get(self._h, shard, C.byref(v), _ptr(ref, C.c_uint8)), "emat_multi_tree_get")
+        t.root = v.root
+        return t.trimmed(), ref

@@ -127,6 +127,45 @@ emat_status emat_run_moves_sharded(emat_run* r, int64_t count);
 emat_status emat_run_pack_local_parts(emat_run* r, uint8_t* buf, uint64_t capacity, uint64_t* bytes_needed);
 emat_status emat_run_unpack_parts(emat_run* r, const uint8_t* buf, uint64_t bytes);
 
+/* ---- one run over several GPUs of ONE process (delphy_amd/csrc/emat_multi.cpp) --------------------------------------------
+ * replaces: the thread pool behind Run::run_local_moves (reference core/run.cpp:682-693: one task per Subrun, in-process) for a
+ * C++ `Run` that owns several MI355X.  n backends, one per entry of `devices` (cfg->device is ignored), every one with the whole
+ * tree in its HBM and a contiguous block of the partition's parts; the exchanges of a sharded cycle (above) are done inside, in
+ * C++: an all-gather of what every shard's parts own -- emat_tree_export_nodes writes into the device buffer that
+ * ncclAllGather sends over xGMI, emat_tree_apply_nodes reads what arrived -- and an ncclAllReduce of the two log-posterior
+ * totals.  `exchange`: EMAT_EXCHANGE_RCCL (librccl.so is loaded at run time with dlopen: no link-time dependency),
+ * EMAT_EXCHANGE_HOST (the same steps through host buffers: what two backends sharing one device must use, RCCL taking one
+ * rank per device), or EMAT_EXCHANGE_AUTO (RCCL when every shard has a device of its own and the library loads).
+ * One cycle = emat_multi_repartition, emat_multi_run_moves (returns with the kernels of every GPU in flight),
+ * emat_multi_reassemble; emat_multi_do_mcmc_steps strings them together as Run::do_mcmc_steps does (run.cpp:622-657, without the
+ * global moves).  The shards' own handles stay reachable for everything else (emat_multi_backend / emat_multi_shard: statistics of
+ * the global moves, paranoid checks, part downloads).  Entry points are not thread-safe with respect to each other. */
+typedef struct emat_multi emat_multi;
+enum { EMAT_EXCHANGE_HOST = 0, EMAT_EXCHANGE_RCCL = 1, EMAT_EXCHANGE_AUTO = 2 };
+emat_status emat_run_create_multi(const int32_t* devices, int32_t n, const emat_config* cfg, const emat_flat_tree* tree, const uint8_t* ref_sequence,
+                                  int32_t num_sites, uint64_t seed, int32_t exchange, emat_multi** out);
+emat_status emat_multi_destroy(emat_multi* m);
+const char* emat_multi_last_error(const emat_multi* m);
+const char* emat_multi_exchange(const emat_multi* m);          /* what the exchange goes through, in words */
+int32_t emat_multi_num_shards(const emat_multi* m);
+emat_backend* emat_multi_backend(emat_multi* m, int32_t shard);
+emat_run* emat_multi_shard(emat_multi* m, int32_t shard);
+emat_status emat_multi_set_num_parts(emat_multi* m, int32_t num_parts);
+emat_status emat_multi_set_max_part_nodes(emat_multi* m, int32_t max_nodes);
+emat_status emat_multi_set_hky(emat_multi* m, double mu, double kappa, const double pi[4], const double* nu_l);
+emat_status emat_multi_set_pop_model(emat_multi* m, const emat_pop_model* pm);
+emat_status emat_multi_set_coalescent_t_step(emat_multi* m, double t_step);
+emat_status emat_multi_set_flags(emat_multi* m, int32_t only_displacing_inner_nodes, int32_t topology_moves_enabled);
+emat_status emat_multi_set_paranoid(emat_multi* m, int32_t on);
+emat_status emat_multi_repartition(emat_multi* m);
+emat_status emat_multi_run_moves(emat_multi* m, int64_t count);
+emat_status emat_multi_check_derived(emat_multi* m, double tol_scale);
+emat_status emat_multi_reassemble(emat_multi* m);
+emat_status emat_multi_get_totals(emat_multi* m, double* log_G, double* log_augmented_coalescent_prior);
+emat_status emat_multi_do_mcmc_steps(emat_multi* m, int64_t steps, int64_t local_moves_per_cycle);
+emat_status emat_multi_tree_sizes(emat_multi* m, int32_t* num_nodes, int32_t* num_muts, int32_t* num_intervals, int32_t* num_from_states);
+emat_status emat_multi_tree_get(emat_multi* m, int32_t shard, emat_flat_tree* out, uint8_t* ref_sequence /*[L]*/);
+
 /* replaces: calc_Ttwiddle_l(tree_, evo_) (reference phylo_tree_calc.cpp:176-222, called at run.cpp:1109, 1184) while the parts
  * are on the device: the driver knows the tree of parts, which the staged engine calls need (emat_backend.h).  Single process;
  * a sharded run all-gathers emat_get_part_tree_lengths, calls emat_run_Ttwiddle_ext + emat_Ttwiddle_l_partial on every rank,

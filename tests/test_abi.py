@@ -15,7 +15,7 @@ def declared_symbols():
     for hdr in ("emat_backend.h", "emat_host.h", "emat_dphy.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        names += re.findall(r"\b(?:emat_status|const char\*|void)\s+(emat_\w+)\s*\(", text)
+        names += re.findall(r"\b(?:emat_status|const char\*|void|int32_t|emat_backend\*|emat_run\*)\s+(emat_\w+)\s*\(", text)
     return sorted(set(names))
 
 

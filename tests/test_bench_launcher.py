@@ -28,7 +28,7 @@ def test_gpus_flag_spawns_that_many_ranks():
 def test_gpus_flag_refuses_more_ranks_than_gpus():
     import torch
     r = _run(["--gpus", "64"], {})
-    assert r.returncode != 0 and "this node has %d GPU" % torch.cuda.device_count() in r.stderr
+    assert r.returncode != 0 and "this node has %d GPU" % torch.cuda.device_count() in r.stderr     # (counted in sysfs, or by a child: the launcher itself never touches a GPU)
 
 
 import pytest  # noqa: E402
@@ -47,3 +47,7 @@ def test_two_ranks_on_the_one_gpu_of_the_test_box():
     assert out["n_gpus"] == 2 and len(out["per_rank"]["ms_per_step"]) == 2
     assert sum(out["per_rank"]["parts"]) > 7000 and out["check"]["parts_stopped"] == 0
     assert out["value"] > 0
+    # the run checks itself: what the two ranks computed is what one rank computes (bench.py scale_check)
+    sc = out["scale_check"]
+    assert sc["ok"] and sc["ranks_seen"] == 2 and sc["parts_reported"] == sc["parts_of_the_run"] == sum(out["per_rank"]["parts"])
+    assert sc["parts_with_other_move_or_draw_counts"] == 0 and sc["parts_whose_trees_differ"] == 0 and sc["parts_verified"] >= 8 and sc["max_rel_err"] < 1e-9
