@@ -45,8 +45,8 @@ struct BuildDev {
   int32_t* status;    // [2] 0 = ok | 1 mutation pool full | 2 delta buffer full | 3 tie list full | 4 inconsistent input | 5 a workgroup never arrived; [1] = tip at which it happened
   // what the workgroups of the launch share besides the tree: the meeting counter, the running minimum, one word per pointer-jumping
   // round, every workgroup's share of the tying regions, and the grafting thread's verdict on the tip
-  unsigned long long* grid_counter; int32_t* gmin; int32_t* pj_flag; int32_t* blk_sum; int32_t* stop_flag;
-  int32_t* grafted_below; int32_t* pre_buf;   // the node the previous tip was grafted above (EMAT_NO_NODE: none), and which vP buffer holds that scan's positions
+  unsigned long long* grid_counter; int32_t* gmin; int32_t* blk_sum; int32_t* blk_sum2; int32_t* stop_flag;
+  int32_t* gdesc;     // [8] the previous graft, for phase A: the node it went above (EMAT_NO_NODE: none yet), that node's position and subtree size before, "swapped with its sibling", the sibling's size
   long long* prof;    // [8] 100 MHz ticks of the grafting thread: whole loop, waiting for the parallel phases, tie sums, path + deltas, links + sizes, mutations; pointer-jumping rounds; tying regions
 };
 
@@ -97,8 +97,10 @@ __device__ inline bool b_push_front(BDelta* sd, int& n, uint32_t cap, int site, 
 }
 
 constexpr int k_build_threads = 1024;
+constexpr int k_g_sd = 1024, k_g_pm = 1536, k_g_path = 1024;   // LDS staging of the graft step: site deltas, path mutations / X's new mutations, path nodes
 
-// All workgroups of the launch meet here (they are all resident: at most one per CU is launched): a counter that only grows --
+// All workgroups of the launch meet here (they are all resident: a cooperative launch, hipLaunchCooperativeKernel, of at most one
+// workgroup per CU -- the runtime refuses a grid it cannot hold at once): a counter that only grows --
 // after the k-th meeting it stands at k x workgroups -- so nothing is ever reset.  The wait is bounded: a workgroup that never
 // arrives (it cannot, short of a fault) makes the others give up and say so instead of hanging the device.
 struct BGrid {
@@ -112,9 +114,11 @@ struct BGrid {
         __threadfence();
         atomicAdd(counter, 1ull);
         const unsigned long long target = meetings * blocks;
-        int spins = 0;
-        while (atomicAdd(counter, 0ull) < target && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(1); ++spins; }
-        s_ok = spins < (1 << 22) ? 1 : 0;
+        // (bounded by wall-clock time -- a minute of the 100 MHz counter -- not by a number of polls: the grafting thread's serial
+        // stretch on a tip with thousands of deltas is legitimately long)
+        const uint64_t w0 = wall_clock64(); bool gave_up = false;
+        while (atomicAdd(counter, 0ull) < target) { __builtin_amdgcn_s_sleep(1); if (wall_clock64() - w0 > 6000000000ull) { gave_up = true; break; } }
+        s_ok = gave_up ? 0 : 1;
         if (!s_ok) status[0] = 5;
       }
       __syncthreads();
@@ -131,6 +135,10 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
   const int nb = (int)gridDim.x, blk = (int)blockIdx.x, gtid = blk * NT + tid, GT = nb * NT;
   __shared__ int s_carry, s_base, s_stop;
   __shared__ int s_scan[2][k_build_threads];
+  __shared__ int s_cb[256];                                          // running totals of the workgroups' stretches (at most one workgroup per CU)
+  // what the grafting thread works on, staged by its workgroup (step 5)
+  __shared__ BDelta s_sd[k_g_sd]; __shared__ MutRec s_pm[k_g_pm]; __shared__ int s_path[k_g_path]; __shared__ int s_pcnt[k_g_path];
+  __shared__ double s_len[k_build_threads]; __shared__ int s_gi[8]; __shared__ double s_gd[2];
   BGrid grid{b.grid_counter, b.status, (unsigned long long)nb, 0ull};
   BRng rng; rng.key = b.rng[0]; rng.ctr = b.rng[1]; rng.spare = b.rng[2]; rng.has_spare = b.rng[3] != 0;   // (the grafting thread's copy is the one that counts)
   const bool grafter = blk == 0 && tid == 0;
@@ -142,59 +150,77 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
     const int root = *b.root;
     const long long t_tip0 = grafter ? (long long)wall_clock64() : 0ll;
     if (grafter) *b.gmin = 0x7fffffff;
-    // (0) the graft of the previous tip made every ancestor of its new inner node two nodes larger.  The ancestors of a node are
-    // the nodes whose stretch of the visiting order contains it -- position and subtree size are still those of the previous
-    // tip's scan -- so all nodes check themselves side by side instead of one thread climbing to the root.
+    // (A) Positions in the visiting order and subtree sizes are kept from tip to tip: the previous graft put two nodes into the
+    // order (its new inner node P in front of the subtree it was hung above, its tip behind that subtree), made every ancestor of P
+    // two nodes larger and -- when the subtree was its parent's second child, which the new inner node is not -- swapped it with its
+    // sibling's subtree (c0 = P, c1 = the sibling: the second child is visited first).  Every node brings ITSELF up to date from
+    // the grafting thread's record of that graft, side by side.  (Until round 4 the positions were recomputed from scratch for every
+    // tip, by pointer jumping over log2(depth) rounds with a meeting of all workgroups after each: eleven of a tip's twenty meetings.)
+    // Then, per branch: how the distance to X changes across it, entered into a difference array over the visiting positions
+    // (+d where the subtree starts, -d where it ends): the distance at a node is the running sum up to its position.
+    int32_t* const pre_of = b.vP[0];
+    int32_t* const E = b.vD[X & 1];                                  // zeroed while the previous tip was being placed
     {
-      const int S_prev = __hip_atomic_load(b.grafted_below, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (S_prev != EMAT_NO_NODE) {      // (no node: the tip went above the root, or this is the launch's first tip)
-        const int32_t* pre_prev = b.vP[*b.pre_buf];
-        const int pS = pre_prev[S_prev], n_prev = nl - 2;
-        for (int i = gtid; i < n_prev; i += GT) {
-          const int a = i < X - 1 ? i : n + (i - (X - 1));             // the nodes linked before the previous graft
-          if (a != S_prev && pre_prev[a] <= pS && pS < pre_prev[a] + b.sz[a]) b.sz[a] += 2;
+      const int g_S = __hip_atomic_load(&b.gdesc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int g_pS = b.gdesc[1], g_zS = b.gdesc[2], g_swap = b.gdesc[3], g_zU = b.gdesc[4];
+      for (int i = gtid; i < nl; i += GT) {
+        const int v = node_of(i);
+        int p = pre_of[v], z = b.sz[v];
+        if (g_S != EMAT_NO_NODE && v != X - 1 && v != n + X - 2) {     // (the previous graft's own two nodes were given their values by the grafting thread)
+          if (v != g_S && p <= g_pS && g_pS < p + z) z += 2;            // an ancestor of the graft point
+          if (!g_swap) { if (p >= g_pS + g_zS) p += 2; else if (p >= g_pS) p += 1; }
+          else { if (p >= g_pS + g_zS + g_zU) p += 2; else if (p >= g_pS + g_zS) p -= g_zS; else if (p >= g_pS) p += g_zU + 1; }
+          pre_of[v] = p; b.sz[v] = z;
         }
-        if (!grid.sync()) return;
+        const MutRec* m = b.pool + b.ml_off[v]; const int nm = b.ml_cnt[v];
+        int d = 0;
+        for (int k = 0; k < nm; ++k) d += b_step(b, dx0, dxn, mx0, mxn, m[k]);
+        b.delta[v] = d;
+        if (v == root) atomicAdd(&E[0], dxn);                        // at the root the distance is the number of X's own deltas
+        else if (d != 0) { atomicAdd(&E[p], d); atomicAdd(&E[p + z], -d); }
       }
-    }
-    // (1) per branch: how the distance to X changes across it; the increments of the two prefix sums down the tree
-    for (int i = gtid; i < nl; i += GT) {
-      const int v = node_of(i);
-      const MutRec* m = b.pool + b.ml_off[v]; const int nm = b.ml_cnt[v];
-      int d = 0;
-      for (int k = 0; k < nm; ++k) d += b_step(b, dx0, dxn, mx0, mxn, m[k]);
-      b.delta[v] = d;
-      const int par = b.parent[v];
-      b.vD[0][v] = v == root ? dxn : d;                              // at the root the distance is the number of X's own deltas
-      b.vP[0][v] = v == root ? 0 : 1 + (b.c0[par] == v ? b.sz[b.c1[par]] : 0);   // the second child's subtree is visited first
-      b.anc[0][v] = par;
     }
     if (!grid.sync()) return;
-    // (2) both prefix sums by pointer jumping: after round r a node holds the sum over its 2^r nearest ancestors-or-self.
-    // "Somebody still had an ancestor to jump to" is a per-round word stamped with the tip's number (tips only go up: no reset).
-    int cur = 0;
-    for (int round = 0; round < 40; ++round) {
-      int any = 0;
-      for (int i = gtid; i < nl; i += GT) {
-        const int v = node_of(i), a = b.anc[cur][v];
-        if (a != EMAT_NO_NODE) {
-          b.vD[cur ^ 1][v] = b.vD[cur][v] + b.vD[cur][a]; b.vP[cur ^ 1][v] = b.vP[cur][v] + b.vP[cur][a]; b.anc[cur ^ 1][v] = b.anc[cur][a];
-          any = 1;
-        } else { b.vD[cur ^ 1][v] = b.vD[cur][v]; b.vP[cur ^ 1][v] = b.vP[cur][v]; b.anc[cur ^ 1][v] = EMAT_NO_NODE; }
+    // (B) running sum of the difference array: every workgroup scans its own stretch of the positions, 1 024 at a time, and
+    // publishes its total; a node's distance is its stretch's running sum plus the totals of the stretches before
+    const int chunk = ((nl + nb - 1) / nb + NT - 1) / NT * NT, p_lo = blk * chunk, p_hi = p_lo + chunk < nl ? p_lo + chunk : nl;
+    int32_t* const PS = b.anc[0];
+    {
+      if (tid == 0) s_carry = 0;
+      __syncthreads();
+      for (int base = p_lo; base < p_hi; base += NT) {
+        const int p = base + tid;
+        const int mine = p < p_hi ? E[p] : 0;
+        int src = 0;
+        s_scan[0][tid] = mine;
+        __syncthreads();
+        for (int ofs = 1; ofs < NT; ofs <<= 1) {
+          s_scan[src ^ 1][tid] = s_scan[src][tid] + (tid >= ofs ? s_scan[src][tid - ofs] : 0);
+          src ^= 1;
+          __syncthreads();
+        }
+        if (p < p_hi) PS[p] = s_carry + s_scan[src][tid];
+        __syncthreads();
+        if (tid == NT - 1) s_carry += s_scan[src][NT - 1];
+        __syncthreads();
       }
-      cur ^= 1;
-      if (__syncthreads_or(any) && tid == 0) atomicMax(&b.pj_flag[round], X);
-      if (grafter) b.prof[6] += 1;
-      if (!grid.sync()) return;
-      if (__hip_atomic_load(&b.pj_flag[round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != X) break;
+      if (tid == 0) b.blk_sum2[blk] = s_carry;
     }
-    const int32_t* Dend = b.vD[cur]; const int32_t* pre = b.vP[cur];
+    if (!grid.sync()) return;
+    for (int q = tid; q < nb; q += NT) s_cb[q] = b.blk_sum2[q];
+    __syncthreads();
+    if (tid == 0) { int acc = 0; for (int q = 0; q < nb; ++q) { const int t2 = s_cb[q]; s_cb[q] = acc; acc += t2; } }
+    __syncthreads();
+    { int32_t* const En = b.vD[(X & 1) ^ 1]; const int ez = nl + 4 < 2 * n ? nl + 4 : 2 * n; for (int i = gtid; i < ez; i += GT) En[i] = 0; }   // the next tip's difference array (two nodes more)
+    int32_t* const Dend = b.anc[1];                                  // distance to X at every node (the end of its branch)
+    const int32_t* pre = pre_of;
     // (3) the fewest mutations any region offers.  A region of branch v is the stretch before its k-th mutation (k = 0 .. nm);
     // regions in X's future do not count, the one that straddles t_X ends there (spr_study.cpp:211-224)
     {
       int local = 0x7fffffff;
       for (int i = gtid; i < nl; i += GT) {
         const int v = node_of(i);
+        { const int p = pre[v]; Dend[v] = PS[p] + s_cb[p / chunk]; }
         if (v == root) { if (dxn < local) local = dxn; continue; }   // the region above the root is always there
         const MutRec* m = b.pool + b.ml_off[v]; const int nm = b.ml_cnt[v];
         int D = Dend[v] - b.delta[v];
@@ -228,7 +254,6 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
       }
       if (!grid.sync()) return;
       // every workgroup scans its own stretch of the visiting positions, NT at a time, and publishes its total
-      const int chunk = ((nl + nb - 1) / nb + NT - 1) / NT * NT, p_lo = blk * chunk, p_hi = p_lo + chunk < nl ? p_lo + chunk : nl;
       if (tid == 0) s_carry = 0;
       __syncthreads();
       for (int base = p_lo; base < p_hi; base += NT) {
@@ -265,79 +290,156 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
       }
       if (!grid.sync()) return;
     }
-    // (5) one thread picks the region and makes the graft (:925-1030)
-    if (grafter) {
-      const long long tg0 = (long long)wall_clock64();
-      b.prof[1] += tg0 - t_tip0;
+    // (5) the first workgroup picks the region and makes the graft (:925-1030).  One thread decides -- the sums over the tying regions,
+    // the draws and the composition of the deltas are sequential by definition -- but it works on LDS: the workgroup's other threads
+    // stage what it reads (the tying regions' lengths, the mutations on the path from the root to the graft point, X's own deltas)
+    // and carry what it wrote back out (X's new mutations).  Inputs too large for the staging areas take the same steps on the
+    // buffers in HBM, as before round 4 (0.42 ms of a tip's 1.13 ms at C4 went into those single-lane HBM round trips).
+    if (blk == 0) {
       const int P = X + n - 1;
-      int S = root; double t_P = 0.0; int nsd = 0; bool bad = false, full = false, stop = false;
-      int n_tie = 0;
-      if (!above_root) { for (int q = 0; q < nb; ++q) n_tie += b.blk_sum[q]; if ((uint32_t)n_tie > b.tie_cap) { b.status[0] = 3; b.status[1] = X; stop = true; } }
-      for (int k = 0; k < dxn; ++k) { b.sd[k].site = b.d_site[dx0 + k]; b.sd[k].from = b.ref[b.d_site[dx0 + k]]; b.sd[k].to = b.d_to[dx0 + k]; b.sd[k].pad = 0; }   // deltas root -> X
-      nsd = dxn;
-      if (stop) {}
-      else if (above_root) {
-        S = root;
-        const double t_P_guess = t_X - (double)nsd * 13.0, t_S = b.t[S];
-        t_P = (t_P_guess < t_S ? t_P_guess : t_S) - 1.0;
-        *b.root = P; b.parent[P] = EMAT_NO_NODE;
-        b.ml_off[P] = b.ml_off[S]; b.ml_cnt[P] = b.ml_cnt[S]; b.ml_cnt[S] = 0;      // the root's list moves up with the root (it is empty while building)
-      } else {
-        double tot_min_T = 0.0;
+      const long long tg0 = grafter ? (long long)wall_clock64() : 0ll;
+      if (grafter) {
+        b.prof[1] += tg0 - t_tip0;
+        int n_tie = 0; int stop = 0;
+        if (!above_root) { for (int q = 0; q < nb; ++q) n_tie += b.blk_sum[q]; if ((uint32_t)n_tie > b.tie_cap) { b.status[0] = 3; b.status[1] = X; stop = 1; } }
+        s_gi[0] = n_tie; s_gi[1] = stop; s_gi[2] = -1 /* chosen */; s_gi[3] = 0 /* found */;
         b.prof[7] += n_tie;
-        for (int i = 0; i < n_tie; ++i) tot_min_T += b.tie_tmax[i] - b.tie_tmin[i];
-        const double insertion_cum_t = rng.uniform_co(0.0, tot_min_T);
-        double so_far_min_T = 0.0; int chosen = -1;
-        for (int i = 0; i < n_tie; ++i) { so_far_min_T += b.tie_tmax[i] - b.tie_tmin[i]; if (insertion_cum_t <= so_far_min_T) { chosen = i; break; } }
-        const long long tg1 = (long long)wall_clock64(); b.prof[2] += tg1 - tg0;
-        if (chosen < 0) { b.status[0] = 4; b.status[1] = X; stop = true; }
-        else {
-          S = b.tie_node[chosen];
-          t_P = rng.uniform_oo(b.tie_tmin[chosen], b.tie_tmax[chosen]);
-          // deltas (S, t_P) -> X: the mutations on the way down from the root are put in front, inverted (site_deltas.cpp:40-80)
-          int np = 0;
-          for (int v = S; v != EMAT_NO_NODE; v = b.parent[v]) b.path[np++] = v;
-          const double t_root = b.t[root];
+      }
+      __syncthreads();
+      const int n_tie = s_gi[0];
+      int S = root; double t_P = 0.0;
+      if (s_gi[1] == 0 && !above_root) {
+        // the total length of the tying regions, in visiting order, then the region the draw falls into: 1 024 lengths at a time
+        double tot_min_T = 0.0;
+        for (int base = 0; base < n_tie; base += NT) {
+          if (base + tid < n_tie) s_len[tid] = b.tie_tmax[base + tid] - b.tie_tmin[base + tid];
+          __syncthreads();
+          if (grafter) { const int m = n_tie - base < NT ? n_tie - base : NT; for (int i = 0; i < m; ++i) tot_min_T += s_len[i]; }
+          __syncthreads();
+        }
+        double insertion_cum_t = 0.0, so_far_min_T = 0.0;
+        if (grafter) insertion_cum_t = rng.uniform_co(0.0, tot_min_T);
+        for (int base = 0; base < n_tie; base += NT) {
+          if (s_gi[3] != 0) break;                                      // (uniform: written before the previous barrier)
+          if (base + tid < n_tie) s_len[tid] = b.tie_tmax[base + tid] - b.tie_tmin[base + tid];
+          __syncthreads();
+          if (grafter) { const int m = n_tie - base < NT ? n_tie - base : NT; for (int i = 0; i < m; ++i) { so_far_min_T += s_len[i]; if (insertion_cum_t <= so_far_min_T) { s_gi[2] = base + i; s_gi[3] = 1; break; } } }
+          __syncthreads();
+        }
+        if (grafter) {
+          b.prof[2] += (long long)wall_clock64() - tg0;
+          const int chosen = s_gi[2];
+          if (chosen < 0) { b.status[0] = 4; b.status[1] = X; s_gi[1] = 1; }
+          else {
+            S = b.tie_node[chosen];
+            t_P = rng.uniform_oo(b.tie_tmin[chosen], b.tie_tmax[chosen]);
+            int np = 0;
+            for (int v = S; v != EMAT_NO_NODE; v = b.parent[v]) { if (np < k_g_path) s_path[np] = v; b.path[np] = v; ++np; }
+            s_gi[4] = S; s_gi[5] = np; s_gd[0] = t_P;
+          }
+        }
+        __syncthreads();
+      }
+      const long long tg1 = grafter ? (long long)wall_clock64() : 0ll;
+      int stop = s_gi[1];
+      BDelta* sd = b.sd; int nsd = dxn; bool bad = false, full = false;
+      if (!stop && !above_root) {
+        // deltas (S, t_P) -> X: X's own deltas against the root sequence, with the mutations on the way down from the root put in
+        // front, inverted (site_deltas.cpp:40-80) -- root first, each branch's mutations in time order, up to t_P
+        S = s_gi[4]; t_P = s_gd[0];
+        const int np = s_gi[5];
+        const double t_root = b.t[root];
+        bool in_lds = np <= k_g_path;
+        if (in_lds) {
+          for (int i = tid; i < np; i += NT) {
+            const MutRec* m = b.pool + b.ml_off[s_path[i]]; const int nm = b.ml_cnt[s_path[i]];
+            int c = 0; for (int k = 0; k < nm; ++k) if (t_root <= m[k].t && m[k].t <= t_P) ++c;
+            s_pcnt[i] = c;
+          }
+          __syncthreads();
+          if (grafter) { int acc = 0; for (int i = np - 1; i >= 0; --i) { const int c = s_pcnt[i]; s_pcnt[i] = acc; acc += c; } s_gi[6] = acc; }
+          __syncthreads();
+          in_lds = s_gi[6] <= k_g_pm && dxn + s_gi[6] <= k_g_sd;
+        }
+        if (in_lds) {
+          for (int i = tid; i < np; i += NT) {
+            const MutRec* m = b.pool + b.ml_off[s_path[i]]; const int nm = b.ml_cnt[s_path[i]];
+            int o = s_pcnt[i]; for (int k = 0; k < nm; ++k) if (t_root <= m[k].t && m[k].t <= t_P) s_pm[o++] = m[k];
+          }
+          for (int k = tid; k < dxn; k += NT) { BDelta d; d.site = b.d_site[dx0 + k]; d.from = b.ref[d.site]; d.to = b.d_to[dx0 + k]; d.pad = 0; s_sd[k] = d; }
+          __syncthreads();
+          sd = s_sd;
+          if (grafter) { const int tot = s_gi[6]; for (int j = 0; j < tot && !full; ++j) { if (!b_push_front(s_sd, nsd, (uint32_t)k_g_sd, s_pm[j].site, s_pm[j].to, s_pm[j].from, bad)) full = true; } }
+        } else if (grafter) {
+          for (int k = 0; k < dxn; ++k) { b.sd[k].site = b.d_site[dx0 + k]; b.sd[k].from = b.ref[b.d_site[dx0 + k]]; b.sd[k].to = b.d_to[dx0 + k]; b.sd[k].pad = 0; }
           for (int i = np - 1; i >= 0 && !full; --i) {
             const MutRec* m = b.pool + b.ml_off[b.path[i]]; const int nm = b.ml_cnt[b.path[i]];
             for (int k = 0; k < nm; ++k) if (t_root <= m[k].t && m[k].t <= t_P) { if (!b_push_front(b.sd, nsd, b.sd_cap, m[k].site, m[k].to, m[k].from, bad)) { full = true; break; } }
           }
+        }
+        if (grafter) {
           const int G = b.parent[S];
           const int U = b.c0[G] == S ? b.c1[G] : b.c0[G];
+          // what the graft does to the visiting order (phase A of the next tip): S's subtree makes room for P in front of it and for
+          // X behind it; had it been G's second child (visited first), it now comes after its sibling's subtree
+          { const int pS = pre_of[S], zS = b.sz[S], swap = b.c1[G] == S ? 1 : 0, zU = b.sz[U];
+            b.gdesc[1] = pS; b.gdesc[2] = zS; b.gdesc[3] = swap; b.gdesc[4] = zU;
+            pre_of[P] = swap ? pS + zU : pS; pre_of[X] = (swap ? pS + zU : pS) + 1 + zS; }
           b.c0[G] = P; b.c1[G] = U; b.parent[P] = G;
           int split = 0;                                               // the mutations of G-S before t_P now sit on G-P
           { const MutRec* m = b.pool + b.ml_off[S]; const int nm = b.ml_cnt[S]; while (split < nm && !(m[split].t > t_P)) ++split; }
           b.ml_off[P] = b.ml_off[S]; b.ml_cnt[P] = split; b.ml_off[S] += (uint32_t)split; b.ml_cnt[S] -= split;
           b.prof[3] += (long long)wall_clock64() - tg1;
         }
-      }
-      const long long tg2 = (long long)wall_clock64();
-      if (!stop) {
-        if (full) { b.status[0] = 2; b.status[1] = X; stop = true; }
-        else if (bad) { b.status[0] = 4; b.status[1] = X; stop = true; }
-      }
-      if (!stop) {
-        b.t[P] = t_P; b.c0[P] = X; b.c1[P] = S; b.parent[X] = P; b.parent[S] = P;
-        b.sz[X] = 1; b.sz[P] = b.sz[S] + 2;
-        *b.grafted_below = above_root ? EMAT_NO_NODE : S; *b.pre_buf = cur;     // the ancestors' sizes follow at the start of the next tip (0)
-        const long long tg3 = (long long)wall_clock64(); b.prof[4] += tg3 - tg2;
-        // the mutations X needs, at random times on P-X, sorted by (t, site) (:1015-1021)
-        const uint32_t o = *b.pool_top;
-        if (o + (uint32_t)nsd > b.pool_cap) { b.status[0] = 1; b.status[1] = X; stop = true; }
-        else {
-          MutRec* mx = b.pool + o;
-          for (int k = 0; k < nsd; ++k) {
-            MutRec r; r.t = rng.uniform_oc(t_P, t_X); r.site = b.sd[k].site; r.from = b.sd[k].from; r.to = b.sd[k].to; r.pad = 0;
-            int j = k - 1;                                             // stable insertion by (t, site)
-            while (j >= 0 && (r.t < mx[j].t || (r.t == mx[j].t && r.site < mx[j].site))) { mx[j + 1] = mx[j]; --j; }
-            mx[j + 1] = r;
-          }
-          b.ml_off[X] = o; b.ml_cnt[X] = nsd; *b.pool_top = o + (uint32_t)nsd;
+      } else if (!stop) {
+        // above the root: X's deltas against the root sequence are the mutations it needs
+        const bool in_lds = dxn <= k_g_sd;
+        if (in_lds) { for (int k = tid; k < dxn; k += NT) { BDelta d; d.site = b.d_site[dx0 + k]; d.from = b.ref[d.site]; d.to = b.d_to[dx0 + k]; d.pad = 0; s_sd[k] = d; } sd = s_sd; }
+        else if (grafter) for (int k = 0; k < dxn; ++k) { b.sd[k].site = b.d_site[dx0 + k]; b.sd[k].from = b.ref[b.d_site[dx0 + k]]; b.sd[k].to = b.d_to[dx0 + k]; b.sd[k].pad = 0; }
+        if (grafter) {
+          S = root;
+          const double t_P_guess = t_X - (double)nsd * 13.0, t_S = b.t[S];
+          t_P = (t_P_guess < t_S ? t_P_guess : t_S) - 1.0;
+          *b.root = P; b.parent[P] = EMAT_NO_NODE;
+          b.ml_off[P] = b.ml_off[S]; b.ml_cnt[P] = b.ml_cnt[S]; b.ml_cnt[S] = 0;      // the root's list moves up with the root (it is empty while building)
+          { const int zS = b.sz[S]; b.gdesc[1] = 0; b.gdesc[2] = zS; b.gdesc[3] = 0; b.gdesc[4] = 0; pre_of[P] = 0; pre_of[X] = zS + 1; }   // P first, the old tree, X last
         }
-        b.prof[5] += (long long)wall_clock64() - tg3;
       }
-      *b.stop_flag = stop ? X : 0;
-      b.prof[0] += (long long)wall_clock64() - t_tip0;
+      __syncthreads();
+      if (grafter) {
+        const long long tg2 = (long long)wall_clock64();
+        if (!stop) {
+          if (full) { b.status[0] = 2; b.status[1] = X; stop = 1; }
+          else if (bad) { b.status[0] = 4; b.status[1] = X; stop = 1; }
+        }
+        s_gi[7] = -1;                                                  // where X's mutations go in the pool (-1: nothing to copy)
+        if (!stop) {
+          b.t[P] = t_P; b.c0[P] = X; b.c1[P] = S; b.parent[X] = P; b.parent[S] = P;
+          b.sz[X] = 1; b.sz[P] = b.sz[S] + 2;
+          __hip_atomic_store(&b.gdesc[0], S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // positions and ancestors' sizes follow at the start of the next tip (A)
+          const long long tg3 = (long long)wall_clock64(); b.prof[4] += tg3 - tg2;
+          // the mutations X needs, at random times on P-X, sorted by (t, site) (:1015-1021)
+          const uint32_t o = *b.pool_top;
+          if (o + (uint32_t)nsd > b.pool_cap) { b.status[0] = 1; b.status[1] = X; stop = 1; }
+          else {
+            const bool stage = nsd <= k_g_pm;                            // sorted in LDS, copied out by the whole workgroup
+            MutRec* mx = stage ? s_pm : b.pool + o;
+            for (int k = 0; k < nsd; ++k) {
+              MutRec r; r.t = rng.uniform_oc(t_P, t_X); r.site = sd[k].site; r.from = sd[k].from; r.to = sd[k].to; r.pad = 0;
+              int j = k - 1;                                             // stable insertion by (t, site)
+              while (j >= 0 && (r.t < mx[j].t || (r.t == mx[j].t && r.site < mx[j].site))) { mx[j + 1] = mx[j]; --j; }
+              mx[j + 1] = r;
+            }
+            b.ml_off[X] = o; b.ml_cnt[X] = nsd; *b.pool_top = o + (uint32_t)nsd;
+            if (stage) { s_gi[7] = (int)o; s_gi[6] = nsd; }
+          }
+          b.prof[5] += (long long)wall_clock64() - tg3;
+        }
+        *b.stop_flag = stop ? X : 0;
+        b.prof[0] += (long long)wall_clock64() - t_tip0;
+      }
+      __syncthreads();
+      if (s_gi[7] >= 0) { MutRec* dst = b.pool + (uint32_t)s_gi[7]; const int cnt = s_gi[6]; for (int k = tid; k < cnt; k += NT) dst[k] = s_pm[k]; }
     }
     if (!grid.sync()) return;
     if (tid == 0) s_stop = __hip_atomic_load(b.stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

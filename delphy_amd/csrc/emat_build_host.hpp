@@ -95,8 +95,11 @@ emat_status build_usher_like(emat_backend* h, const emat_tip_descs& td, uint64_t
     // on 8 / 16 / 32 / 59 workgroups)
     int blocks = std::max(1, std::min(std::max(1, h->num_cus / 4), (N + 2 * k_build_threads - 1) / (2 * k_build_threads)));
     if (const char* e = getenv("EMAT_BUILD_BLOCKS")) blocks = std::max(1, std::min(atoi(e), h->num_cus > 0 ? h->num_cus : 1));
-    DevBuf<int32_t> d_shared; HIP_TRY(d_shared.alloc(8 + 64 + (size_t)blocks));
-    HIP_TRY(hipMemsetAsync(d_shared.p, 0, (8 + 64 + (size_t)blocks) * sizeof(int32_t), h->stream));
+    DevBuf<int32_t> d_shared; HIP_TRY(d_shared.alloc(8 + 64 + 2 * (size_t)blocks));
+    HIP_TRY(hipMemsetAsync(d_shared.p, 0, (8 + 64 + 2 * (size_t)blocks) * sizeof(int32_t), h->stream));
+    // the difference arrays start out zero; the first three nodes' places in the visiting order (the root, then its second child, then its first)
+    HIP_TRY(hipMemsetAsync(d_vD0.p, 0, ((size_t)N + 1) * sizeof(int32_t), h->stream)); HIP_TRY(hipMemsetAsync(d_vD1.p, 0, ((size_t)N + 1) * sizeof(int32_t), h->stream));
+    { std::vector<int32_t> pre0((size_t)N + 1, 0); pre0[(size_t)n] = 0; pre0[1] = 1; pre0[0] = 2; HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(d_vP0.p, pre0.data(), pre0.size() * sizeof(int32_t), hipMemcpyHostToDevice)); }
     BuildDev b;
     b.n_tips = n; b.L = L; b.ref = d_ref.p; b.d_off = d_doff.p; b.d_site = d_dsite.p; b.d_to = d_dto.p; b.m_off = d_moff.p; b.m_start = d_mstart.p; b.m_end = d_mend.p;
     b.root = d_root.p; b.parent = d_parent.p; b.c0 = d_c0.p; b.c1 = d_c1.p; b.t = d_t.p; b.sz = d_sz.p; b.ml_off = d_mloff.p; b.ml_cnt = d_mlcnt.p; b.pool = d_pool.p; b.pool_cap = pool_cap; b.pool_top = d_top.p;
@@ -104,11 +107,13 @@ emat_status build_usher_like(emat_backend* h, const emat_tip_descs& td, uint64_t
     b.tie_node = d_tnode.p; b.tie_tmin = d_tmin.p; b.tie_tmax = d_tmax.p; b.tie_cap = tie_cap; b.path = d_path.p; b.sd = d_sd.p; b.sd_cap = sd_cap; b.rng = d_rng.p; b.status = d_status.p;
     DevBuf<long long> d_prof; HIP_TRY(d_prof.alloc(8)); HIP_TRY(hipMemsetAsync(d_prof.p, 0, 8 * sizeof(long long), h->stream));
     b.prof = d_prof.p;
-    { const int32_t none = EMAT_NO_NODE; HIP_TRY(hipMemcpyAsync(d_shared.p + 4, &none, sizeof none, hipMemcpyHostToDevice, h->stream)); HIP_TRY(hipStreamSynchronize(h->stream)); }
-    b.grid_counter = (unsigned long long*)d_shared.p; b.gmin = d_shared.p + 2; b.stop_flag = d_shared.p + 3; b.grafted_below = d_shared.p + 4; b.pre_buf = d_shared.p + 5; b.pj_flag = d_shared.p + 8; b.blk_sum = d_shared.p + 8 + 64;
+    { const int32_t none = EMAT_NO_NODE; HIP_TRY(hipMemcpyAsync(d_shared.p + 8, &none, sizeof none, hipMemcpyHostToDevice, h->stream)); HIP_TRY(hipStreamSynchronize(h->stream)); }
+    b.grid_counter = (unsigned long long*)d_shared.p; b.gmin = d_shared.p + 2; b.stop_flag = d_shared.p + 3; b.gdesc = d_shared.p + 8; b.blk_sum = d_shared.p + 8 + 64; b.blk_sum2 = d_shared.p + 8 + 64 + blocks;
     if (n > 2) {
-      hipLaunchKernelGGL(k_build_usher_graft, dim3((unsigned)blocks), dim3(k_build_threads), 0, h->stream, b, 2, n);
-      HIP_TRY(hipGetLastError());
+      // a cooperative launch: the runtime guarantees that every workgroup is resident at once (they meet at barriers of their own)
+      int first_tip = 2, last_tip = n;
+      void* args[3] = {(void*)&b, (void*)&first_tip, (void*)&last_tip};
+      HIP_TRY(hipLaunchCooperativeKernel((const void*)k_build_usher_graft, dim3((unsigned)blocks), dim3(k_build_threads), args, 0, h->stream));
       HIP_TRY(hipStreamSynchronize(h->stream));
     }
     int32_t status[2];
@@ -116,12 +121,13 @@ emat_status build_usher_like(emat_backend* h, const emat_tip_descs& td, uint64_t
     if (getenv("EMAT_VERBOSE") && n > 2) {
       long long pr[8]; HIP_TRY(hipMemcpy(pr, d_prof.p, sizeof pr, hipMemcpyDeviceToHost));
       const double k = 1e-5 / (double)(n - 2);   // ticks of 10 ns -> ms per tip
-      fprintf(stderr, "[emat] build_usher_like: %d tips on %d workgroups, per tip: %.3f ms = parallel phases + barriers %.3f | tie sums %.3f (%.1f tying regions) | path + deltas %.3f | links + sizes %.3f | mutations %.3f | %.1f pointer-jumping rounds\n",
-              n, blocks, pr[0] * k, pr[1] * k, pr[2] * k, (double)pr[7] / (n - 2), pr[3] * k, pr[4] * k, pr[5] * k, (double)pr[6] / (n - 2));
+      fprintf(stderr, "[emat] build_usher_like: %d tips on %d workgroups, per tip: %.3f ms = parallel phases + barriers %.3f | tie sums %.3f (%.1f tying regions) | path + deltas %.3f | links + sizes %.3f | mutations %.3f\n",
+              n, blocks, pr[0] * k, pr[1] * k, pr[2] * k, (double)pr[7] / (n - 2), pr[3] * k, pr[4] * k, pr[5] * k);
     }
     if (status[0] == 1) { pool_cap *= 2; tie_cap = (uint32_t)N + pool_cap; continue; }
     if (status[0] == 2) { sd_cap *= 4; continue; }
     if (status[0] == 3) { tie_cap *= 2; continue; }
+    if (status[0] == 5) return fail(h, EMAT_ERR_INTERNAL, std::string("emat_tree_build_usher_like: ") + build_status_text(status[0]) + " at tip " + std::to_string(status[1]));
     if (status[0] != 0) return fail(h, EMAT_ERR_INVALID_ARGUMENT, std::string("emat_tree_build_usher_like: ") + build_status_text(status[0]) + " at tip " + std::to_string(status[1]));
     // back to the host for the passes that run once
     int32_t root = 0; uint64_t rng1[4];
@@ -182,6 +188,8 @@ emat_status emat_tree_build_usher_like(emat_backend* h, const emat_tip_descs* ti
   const std::string bad = validate_tip_descs(*tips, h->ref);
   if (!bad.empty()) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_build_usher_like: " + bad);
   if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  // the builder's workgroups must all be resident: nothing of this handle may still be running (a pass, its side launches)
+  { emat_status st = emat_synchronize(h); if (st) return st; }
   return build_usher_like(h, *tips, seed);
 }
 emat_status emat_tree_built_sizes(emat_backend* h, int32_t* num_nodes, int32_t* num_muts, int32_t* num_intervals, int32_t* num_from_states) {

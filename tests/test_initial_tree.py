@@ -110,3 +110,40 @@ def test_randomised_descriptors():
             build_both(sc, 1000 + case)
         except AssertionError as e:
             raise AssertionError("%s: %s" % (what, e))
+
+
+@pytest.mark.gpu
+def test_c4_built_on_the_device():
+    """SURVEY 8(f).4 at the size the row names: config C4's 100 000 tips from their descriptors.  The oracle's restatement of the
+    reference's builder is quadratic on one host core (38 s for 10 000 tips: hours here), so at full size the checks are the
+    reference's own closing checks of the builder (phylo_tree.cpp:138-202: tree integrity, every tip reproduces its descriptor)
+    and what the graft loop must conserve -- and the oracle is run on a 1/20 sample: the first 5 000 tip descriptors of the same
+    configuration, whose tree must equal the device's bit for bit.  Time is printed and bounded loosely (round 4: the loop keeps
+    positions and subtree sizes from tip to tip instead of recomputing them by pointer jumping, and the grafting thread works in LDS)."""
+    import time
+    sc = make_scenario("C4")
+    ob = OracleBuild(sc.ref)
+    tips = ob.tip_descs_of(sc.tree)
+    assert tips.num_tips == 100000
+    b = d.EmatBackend(sc.num_sites)
+    try:
+        b.set_ref_sequence(sc.ref)
+        t0 = time.perf_counter(); tree = b.build_usher_like(tips, 7); dt = time.perf_counter() - t0
+        print("C4 initial tree: %d tips in %.1f s on the device, %d mutations" % (tips.num_tips, dt, tree.mut_site.shape[0]))
+        assert dt < 100.0, dt
+        assert tree.num_nodes == 2 * tips.num_tips - 1 and np.all(tree.child0[: tips.num_tips] == -1) and np.all(tree.child0[tips.num_tips:] >= 0)
+        rc, msg = ob.check(tree, tips)
+        assert rc == 0, msg
+        # the 1/20 sample against the oracle
+        k = 5000
+        d_hi, m_hi = int(tips.delta_offset[k]), int(tips.miss_offset[k])
+        head = d.TipDescs(tips.t_min[:k].copy(), tips.t_max[:k].copy(), tips.delta_offset[: k + 1].copy(), tips.delta_site[:d_hi].copy(), tips.delta_to[:d_hi].copy(),
+                          tips.miss_offset[: k + 1].copy(), tips.miss_start[:m_hi].copy(), tips.miss_end[:m_hi].copy())
+        got = b.build_usher_like(head, 7)
+        want = ob.build_usher_like(head, 7)
+        assert got.root == want.root
+        for f in FIELDS:
+            x, y = getattr(got, f), getattr(want, f)
+            assert x.shape == y.shape and np.array_equal(x, y), "%s differs on the 5 000-tip sample" % f
+    finally:
+        b.close(); ob.close()
