@@ -63,22 +63,25 @@ struct BRng {   // the engine's stream (emat_device_core.hpp rng_next64 and frie
   __device__ double uniform_oo(double lo, double hi) { return lo + (hi - lo) * (((double)(next64() >> 12) + 0.5) * 0x1.0p-52); }
 };
 
+// The new tip X as the scan sees it: its deltas against the reference sequence and its missing intervals -- staged in LDS by every
+// workgroup at the start of the tip when they fit (every mutation of the tree is looked up in them four times per tip), else in HBM.
+struct BTip { const int32_t* dsite; const uint8_t* dto; int dn; const int32_t* mstart; const int32_t* mend; int mn; const uint8_t* ref; };
 // state of the new tip at a site: its delta there, else the reference sequence
-__device__ inline int b_tip_state(const BuildDev& b, int dx0, int dxn, int site) {
-  int lo = 0, hi = dxn;
-  while (lo < hi) { int mid = (lo + hi) >> 1; if (b.d_site[dx0 + mid] < site) lo = mid + 1; else hi = mid; }
-  return (lo < dxn && b.d_site[dx0 + lo] == site) ? (int)b.d_to[dx0 + lo] : (int)b.ref[site];
+__device__ inline int b_tip_state(const BTip& x, int site) {
+  int lo = 0, hi = x.dn;
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (x.dsite[mid] < site) lo = mid + 1; else hi = mid; }
+  return (lo < x.dn && x.dsite[lo] == site) ? (int)x.dto[lo] : (int)x.ref[site];
 }
-__device__ inline bool b_tip_missing(const BuildDev& b, int mx0, int mxn, int site) {
-  int lo = 0, hi = mxn;   // first interval with start > site
-  while (lo < hi) { int mid = (lo + hi) >> 1; if (site < b.m_start[mx0 + mid]) hi = mid; else lo = mid + 1; }
-  return lo > 0 && site < b.m_end[mx0 + lo - 1];
+__device__ inline bool b_tip_missing(const BTip& x, int site) {
+  int lo = 0, hi = x.mn;   // first interval with start > site
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (site < x.mstart[mid]) hi = mid; else lo = mid + 1; }
+  return lo > 0 && site < x.mend[lo - 1];
 }
 // change of the distance to the new tip across one mutation, walking down (spr_study.cpp:43-91: only sites the tip has count)
-__device__ inline int b_step(const BuildDev& b, int dx0, int dxn, int mx0, int mxn, const MutRec& m) {
-  if (b_tip_missing(b, mx0, mxn, m.site)) return 0;
-  const int x = b_tip_state(b, dx0, dxn, m.site);
-  return ((int)m.to != x ? 1 : 0) - ((int)m.from != x ? 1 : 0);
+__device__ inline int b_step(const BTip& x, const MutRec& m) {
+  if (b_tip_missing(x, m.site)) return 0;
+  const int st = b_tip_state(x, m.site);
+  return ((int)m.to != st ? 1 : 0) - ((int)m.from != st ? 1 : 0);
 }
 // site_deltas.h:43-65 on a sorted array: put `from -> to` IN FRONT of the delta list
 __device__ inline bool b_push_front(BDelta* sd, int& n, uint32_t cap, int site, int from, int to, bool& inconsistent) {
@@ -97,7 +100,37 @@ __device__ inline bool b_push_front(BDelta* sd, int& n, uint32_t cap, int site, 
 }
 
 constexpr int k_build_threads = 1024;
+constexpr int k_x_deltas = 2048, k_x_miss = 256;                  // the new tip's descriptor held in LDS by every workgroup
 constexpr int k_g_sd = 1024, k_g_pm = 1536, k_g_path = 1024;   // LDS staging of the graft step: site deltas, path mutations / X's new mutations, path nodes
+
+
+// Inclusive sum over the 1 024 threads of a workgroup: a shuffle scan inside every wavefront, the sixteen wave totals scanned by
+// the first wave, two meetings of the workgroup in all (the ten-step ladder through LDS this replaces had one after every step).
+__device__ inline int b_block_scan_incl(int mine, int* s_wave /* [16] */, int tid) {
+  const int lane = tid & 63, w = tid >> 6;
+  int x = mine;
+  for (int ofs = 1; ofs < 64; ofs <<= 1) { const int y = __shfl_up(x, ofs, 64); if (lane >= ofs) x += y; }
+  if (lane == 63) s_wave[w] = x;
+  __syncthreads();
+  if (w == 0) { int t2 = lane < 16 ? s_wave[lane] : 0; for (int ofs = 1; ofs < 16; ofs <<= 1) { const int y = __shfl_up(t2, ofs, 64); if (lane >= ofs) t2 += y; } if (lane < 16) s_wave[lane] = t2; }
+  __syncthreads();
+  return x + (w > 0 ? s_wave[w - 1] : 0);
+}
+
+// Bitonic sort of up to 64 (key, payload) pairs, one per lane of ONE wavefront, in registers (compare-exchange through lane
+// shuffles: no LDS round trips, no meeting of the workgroup); `descending` puts the largest key in lane 0.  Keys must be distinct
+// (or equal only among padding, whose payloads do not matter).
+__device__ inline void b_wave_sort(uint32_t& key, int& val, int n_pow2, bool descending) {
+  const int lane = (int)(threadIdx.x & 63);
+  for (int k2 = 2; k2 <= n_pow2; k2 <<= 1)
+    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+      const uint32_t ok = (uint32_t)__shfl_xor((int)key, j2, 64); const int ov = __shfl_xor(val, j2, 64);
+      const bool lower = (lane & j2) == 0, up = ((lane & k2) == 0) != descending;      // `up`: this block sorts ascending
+      const bool take_min = lower == up;
+      const bool swap = take_min ? ok < key : ok > key;
+      if (swap) { key = ok; val = ov; }
+    }
+}
 
 // All workgroups of the launch meet here (they are all resident: a cooperative launch, hipLaunchCooperativeKernel, of at most one
 // workgroup per CU -- the runtime refuses a grid it cannot hold at once): a counter that only grows --
@@ -117,7 +150,9 @@ struct BGrid {
         // (bounded by wall-clock time -- a minute of the 100 MHz counter -- not by a number of polls: the grafting thread's serial
         // stretch on a tip with thousands of deltas is legitimately long)
         const uint64_t w0 = wall_clock64(); bool gave_up = false;
-        while (atomicAdd(counter, 0ull) < target) { __builtin_amdgcn_s_sleep(1); if (wall_clock64() - w0 > 6000000000ull) { gave_up = true; break; } }
+        // (polled with loads, not read-modify-writes: sixty-odd workgroups hammering one word with atomics queue up in front of the
+        // arrival of the workgroup everybody is waiting for)
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) { __builtin_amdgcn_s_sleep(4); if (wall_clock64() - w0 > 6000000000ull) { gave_up = true; break; } }
         s_ok = gave_up ? 0 : 1;
         if (!s_ok) status[0] = 5;
       }
@@ -134,7 +169,8 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
   const int tid = threadIdx.x, NT = k_build_threads, n = b.n_tips;
   const int nb = (int)gridDim.x, blk = (int)blockIdx.x, gtid = blk * NT + tid, GT = nb * NT;
   __shared__ int s_carry, s_base, s_stop;
-  __shared__ int s_scan[2][k_build_threads];
+  __shared__ int s_wave[16];
+  __shared__ int32_t s_xs[k_x_deltas]; __shared__ uint8_t s_xto[k_x_deltas]; __shared__ int32_t s_xms[k_x_miss]; __shared__ int32_t s_xme[k_x_miss];   // the new tip (BTip)
   __shared__ int s_cb[256];                                          // running totals of the workgroups' stretches (at most one workgroup per CU)
   // what the grafting thread works on, staged by its workgroup (step 5)
   __shared__ BDelta s_sd[k_g_sd]; __shared__ MutRec s_pm[k_g_pm]; __shared__ int s_path[k_g_path]; __shared__ int s_pcnt[k_g_path];
@@ -148,6 +184,13 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
     const int dx0 = b.d_off[X], dxn = b.d_off[X + 1] - dx0, mx0 = b.m_off[X], mxn = b.m_off[X + 1] - mx0;
     const double t_X = b.t[X];
     const int root = *b.root;
+    BTip xt{b.d_site + dx0, b.d_to + dx0, dxn, b.m_start + mx0, b.m_end + mx0, mxn, b.ref};
+    if (dxn <= k_x_deltas && mxn <= k_x_miss) {
+      for (int k = tid; k < dxn; k += NT) { s_xs[k] = xt.dsite[k]; s_xto[k] = xt.dto[k]; }
+      for (int k = tid; k < mxn; k += NT) { s_xms[k] = xt.mstart[k]; s_xme[k] = xt.mend[k]; }
+      __syncthreads();
+      xt.dsite = s_xs; xt.dto = s_xto; xt.mstart = s_xms; xt.mend = s_xme;
+    }
     const long long t_tip0 = grafter ? (long long)wall_clock64() : 0ll;
     if (grafter) *b.gmin = 0x7fffffff;
     // (A) Positions in the visiting order and subtree sizes are kept from tip to tip: the previous graft put two nodes into the
@@ -174,7 +217,7 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
         }
         const MutRec* m = b.pool + b.ml_off[v]; const int nm = b.ml_cnt[v];
         int d = 0;
-        for (int k = 0; k < nm; ++k) d += b_step(b, dx0, dxn, mx0, mxn, m[k]);
+        for (int k = 0; k < nm; ++k) d += b_step(xt, m[k]);
         b.delta[v] = d;
         if (v == root) atomicAdd(&E[0], dxn);                        // at the root the distance is the number of X's own deltas
         else if (d != 0) { atomicAdd(&E[p], d); atomicAdd(&E[p + z], -d); }
@@ -191,17 +234,10 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
       for (int base = p_lo; base < p_hi; base += NT) {
         const int p = base + tid;
         const int mine = p < p_hi ? E[p] : 0;
-        int src = 0;
-        s_scan[0][tid] = mine;
+        const int incl = b_block_scan_incl(mine, s_wave, tid);
+        if (p < p_hi) PS[p] = s_carry + incl;
         __syncthreads();
-        for (int ofs = 1; ofs < NT; ofs <<= 1) {
-          s_scan[src ^ 1][tid] = s_scan[src][tid] + (tid >= ofs ? s_scan[src][tid - ofs] : 0);
-          src ^= 1;
-          __syncthreads();
-        }
-        if (p < p_hi) PS[p] = s_carry + s_scan[src][tid];
-        __syncthreads();
-        if (tid == NT - 1) s_carry += s_scan[src][NT - 1];
+        if (tid == NT - 1) s_carry += incl;
         __syncthreads();
       }
       if (tid == 0) b.blk_sum2[blk] = s_carry;
@@ -227,7 +263,7 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
         double tmin = b.t[b.parent[v]];
         for (int k = 0; k <= nm; ++k) {
           if (!(tmin >= t_X) && D < local) local = D;
-          if (k < nm) { D += b_step(b, dx0, dxn, mx0, mxn, m[k]); tmin = m[k].t; }
+          if (k < nm) { D += b_step(xt, m[k]); tmin = m[k].t; }
         }
       }
       for (int ofs = 32; ofs > 0; ofs >>= 1) { const int o = __shfl_down(local, ofs, 64); if (o < local) local = o; }
@@ -247,7 +283,7 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
           double tmin = b.t[b.parent[v]];
           for (int k = 0; k <= nm; ++k) {
             if (!(tmin >= t_X) && D == all_min) ++c;
-            if (k < nm) { D += b_step(b, dx0, dxn, mx0, mxn, m[k]); tmin = m[k].t; }
+            if (k < nm) { D += b_step(xt, m[k]); tmin = m[k].t; }
           }
         }
         b.cnt[pre[v]] = c; b.inv[pre[v]] = v;
@@ -259,17 +295,10 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
       for (int base = p_lo; base < p_hi; base += NT) {
         const int p = base + tid;
         const int mine = p < p_hi ? b.cnt[p] : 0;
-        int src = 0;
-        s_scan[0][tid] = mine;
+        const int incl = b_block_scan_incl(mine, s_wave, tid);
+        if (p < p_hi) b.off[p] = s_carry + incl - mine;
         __syncthreads();
-        for (int ofs = 1; ofs < NT; ofs <<= 1) {
-          s_scan[src ^ 1][tid] = s_scan[src][tid] + (tid >= ofs ? s_scan[src][tid - ofs] : 0);
-          src ^= 1;
-          __syncthreads();
-        }
-        if (p < p_hi) b.off[p] = s_carry + s_scan[src][tid] - mine;
-        __syncthreads();
-        if (tid == NT - 1) s_carry += s_scan[src][NT - 1];
+        if (tid == NT - 1) s_carry += incl;
         __syncthreads();
       }
       if (tid == 0) b.blk_sum[blk] = s_carry;
@@ -285,7 +314,7 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
         for (int k = 0; k <= nm; ++k) {
           const double tmax = k < nm ? m[k].t : b.t[v];
           if (!(tmin >= t_X) && D == all_min) { if ((uint32_t)o < b.tie_cap) { b.tie_node[o] = v; b.tie_tmin[o] = tmin; b.tie_tmax[o] = tmax > t_X ? t_X : tmax; } ++o; }
-          if (k < nm) { D += b_step(b, dx0, dxn, mx0, mxn, m[k]); tmin = m[k].t; }
+          if (k < nm) { D += b_step(xt, m[k]); tmin = m[k].t; }
         }
       }
       if (!grid.sync()) return;
@@ -295,9 +324,11 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
     // stage what it reads (the tying regions' lengths, the mutations on the path from the root to the graft point, X's own deltas)
     // and carry what it wrote back out (X's new mutations).  Inputs too large for the staging areas take the same steps on the
     // buffers in HBM, as before round 4 (0.42 ms of a tip's 1.13 ms at C4 went into those single-lane HBM round trips).
+    const int P = X + n - 1;
+    const long long tg0 = grafter ? (long long)wall_clock64() : 0ll;
+    int S = root; double t_P = 0.0;
+    long long tg1 = 0;
     if (blk == 0) {
-      const int P = X + n - 1;
-      const long long tg0 = grafter ? (long long)wall_clock64() : 0ll;
       if (grafter) {
         b.prof[1] += tg0 - t_tip0;
         int n_tie = 0; int stop = 0;
@@ -307,7 +338,6 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
       }
       __syncthreads();
       const int n_tie = s_gi[0];
-      int S = root; double t_P = 0.0;
       if (s_gi[1] == 0 && !above_root) {
         // the total length of the tying regions, in visiting order, then the region the draw falls into: 1 024 lengths at a time
         double tot_min_T = 0.0;
@@ -327,20 +357,57 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
           __syncthreads();
         }
         if (grafter) {
-          b.prof[2] += (long long)wall_clock64() - tg0;
+          tg1 = (long long)wall_clock64(); b.prof[2] += tg1 - tg0;
           const int chosen = s_gi[2];
           if (chosen < 0) { b.status[0] = 4; b.status[1] = X; s_gi[1] = 1; }
           else {
             S = b.tie_node[chosen];
             t_P = rng.uniform_oo(b.tie_tmin[chosen], b.tie_tmax[chosen]);
-            int np = 0;
-            for (int v = S; v != EMAT_NO_NODE; v = b.parent[v]) { if (np < k_g_path) s_path[np] = v; b.path[np] = v; ++np; }
-            s_gi[4] = S; s_gi[5] = np; s_gd[0] = t_P;
+            s_gi[4] = S; s_gd[0] = t_P;
           }
         }
         __syncthreads();
       }
-      const long long tg1 = grafter ? (long long)wall_clock64() : 0ll;
+      if (!above_root && s_gi[1] == 0) {
+        {
+          // the path from the graft point up to the root: not walked (a chain of dependent loads as long as the tree is deep) but FOUND --
+          // the ancestors of S are the nodes whose stretch of the visiting order contains S's place -- by the whole workgroup, and put
+          // in order by their own places (the deeper, the later in the visiting order).  (Spreading the search over all workgroups
+          // costs two more meetings and was measured no faster at C4.)
+          const int S0 = s_gi[4], pS = pre_of[S0];
+          uint32_t* const pk = (uint32_t*)s_len;
+          if (tid == 0) s_gi[5] = 0;
+          __syncthreads();
+          for (int i0 = tid; i0 < nl; i0 += 8 * NT) {                   // eight nodes per thread at a time: sixteen loads in flight, not one round trip after another
+            int vv[8], pp[8], zz[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT; vv[u] = node_of(i < nl ? i : nl - 1); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { pp[u] = pre_of[vv[u]]; zz[u] = b.sz[vv[u]]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * NT < nl && pp[u] <= pS && pS < pp[u] + zz[u]) { const int slot = atomicAdd(&s_gi[5], 1); if (slot < k_g_path) { pk[slot] = (uint32_t)pp[u] + 1u; s_path[slot] = vv[u]; } }
+          }
+          __syncthreads();
+          const int np = s_gi[5];
+          if (np <= k_g_path) {
+            int P2 = 2; while (P2 < np) P2 <<= 1;
+            if (tid >= np && tid < P2) { pk[tid] = 0u; s_path[tid] = EMAT_NO_NODE; }
+            __syncthreads();
+            if (P2 <= 64) {                                              // (the usual case: one wavefront sorts in registers)
+              if (tid < 64) { uint32_t key = tid < P2 ? pk[tid] : 0u; int val = tid < P2 ? s_path[tid] : EMAT_NO_NODE; b_wave_sort(key, val, P2, true); if (tid < P2) { pk[tid] = key; s_path[tid] = val; } }
+              __syncthreads();
+            } else
+            for (int k2 = 2; k2 <= P2; k2 <<= 1)
+              for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                if (tid < P2) { const int q = tid ^ j2; if (q > tid) { const uint32_t a1 = pk[tid], a2 = pk[q]; const bool down = (tid & k2) == 0; if ((a1 < a2) == down) { pk[tid] = a2; pk[q] = a1; const int t1 = s_path[tid]; s_path[tid] = s_path[q]; s_path[q] = t1; } } }
+                __syncthreads();
+              }
+          } else if (grafter) { int k = 0; for (int v = S0; v != EMAT_NO_NODE; v = b.parent[v]) b.path[k++] = v; }   // deeper than the staging area: walked, into HBM
+          __syncthreads();
+          if (grafter) b.prof[6] += (long long)wall_clock64() - tg1;     // finding the path
+        }
+      }
+      if (grafter && tg1 == 0) tg1 = (long long)wall_clock64();
       int stop = s_gi[1];
       BDelta* sd = b.sd; int nsd = dxn; bool bad = false, full = false;
       if (!stop && !above_root) {
@@ -369,7 +436,70 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
           for (int k = tid; k < dxn; k += NT) { BDelta d; d.site = b.d_site[dx0 + k]; d.from = b.ref[d.site]; d.to = b.d_to[dx0 + k]; d.pad = 0; s_sd[k] = d; }
           __syncthreads();
           sd = s_sd;
-          if (grafter) { const int tot = s_gi[6]; for (int j = 0; j < tot && !full; ++j) { if (!b_push_front(s_sd, nsd, (uint32_t)k_g_sd, s_pm[j].site, s_pm[j].to, s_pm[j].from, bad)) full = true; } }
+          const int T = s_gi[6];
+          if (T > 0 && T <= 1024 && dxn < 1024 && b.L < (1 << 22)) {
+            // What a run of push_front calls leaves at a site depends on that site's entry and on its own mutations, in path order,
+            // alone: the sites are independent.  So: sort the path's mutations by (site, place on the path) -- a bitonic sort
+            // in LDS --, let one thread per site run that site's calls (the same operations in the same order as the one-by-one
+            // list edits, broken chains flagged the same way), and merge what is left with X's untouched deltas by rank.
+            uint32_t* const keys = (uint32_t*)s_len; uint32_t* const rres = keys + 1024;      // s_len: 8 KB
+            int* const cDex = s_path; int* const cRex = s_pcnt;                               // free once the path is staged
+            int P2 = 2; while (P2 < T) P2 <<= 1;
+            if (tid < P2) keys[tid] = tid < T ? ((uint32_t)s_pm[tid].site << 10) | (uint32_t)tid : 0xFFFFFFFFu;
+            if (tid < 1024) rres[tid] = 0u;
+            __syncthreads();
+            if (P2 <= 64) {
+              if (tid < 64) { uint32_t key = tid < P2 ? keys[tid] : 0xFFFFFFFFu; int val = 0; b_wave_sort(key, val, P2, false); if (tid < P2) keys[tid] = key; }
+              __syncthreads();
+            } else
+            for (int k2 = 2; k2 <= P2; k2 <<= 1)
+              for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                if (tid < P2) { const int q = tid ^ j2; if (q > tid) { const uint32_t a1 = keys[tid], a2 = keys[q]; const bool up = (tid & k2) == 0; if ((a1 > a2) == up) { keys[tid] = a2; keys[q] = a1; } } }
+                __syncthreads();
+              }
+            if (tid == 0) s_gi[3] = 0;                                 // "a chain was broken"
+            __syncthreads();
+            if (tid < T && (tid == 0 || (keys[tid] >> 10) != (keys[tid - 1] >> 10))) {
+              const int site = (int)(keys[tid] >> 10);
+              int lo = 0, hi = dxn;
+              while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_sd[mid].site < site) lo = mid + 1; else hi = mid; }
+              bool has = lo < dxn && s_sd[lo].site == site;
+              int from = has ? (int)s_sd[lo].from : 0, to = has ? (int)s_sd[lo].to : 0;
+              if (has) s_sd[lo].pad = 1;                               // replaced by what this run leaves
+              bool broke = false;
+              for (int q = tid; q < T && (int)(keys[q] >> 10) == site; ++q) {
+                const MutRec& m = s_pm[keys[q] & 1023u];
+                if (has) { if ((int)m.from != from) broke = true; from = (int)m.to; if (from == to) has = false; }      // b_push_front(site, m.to, m.from) on an entry
+                else { has = true; from = (int)m.to; to = (int)m.from; }                                               // ... and on none
+              }
+              if (broke) s_gi[3] = 1;
+              rres[tid] = has ? (1u << 16) | ((uint32_t)from << 8) | (uint32_t)to : 0u;
+            }
+            __syncthreads();
+            // ranks: kept deltas of X and kept run results, each in site order
+            { const int keepD = tid < dxn && s_sd[tid].pad == 0 ? 1 : 0; const int incl = b_block_scan_incl(keepD, s_wave, tid); if (tid < dxn) cDex[tid] = incl - keepD; if (tid == dxn) cDex[dxn] = incl; __syncthreads(); }
+            { const int keepR = tid < T && (rres[tid] >> 16) != 0u ? 1 : 0; const int incl = b_block_scan_incl(keepR, s_wave, tid); if (tid < T) cRex[tid] = incl - keepR; if (tid == T) cRex[T] = incl; __syncthreads(); }
+            BDelta* const outp = (BDelta*)s_pm;                        // the path's mutations are spent
+            const int totD = dxn < 1024 ? cDex[dxn] : 0;
+            const int totR = T < 1024 ? cRex[T] : cRex[1023] + ((rres[1023] >> 16) != 0u ? 1 : 0);
+            __syncthreads();
+            if (tid < dxn && s_sd[tid].pad == 0) {
+              const uint32_t want = (uint32_t)s_sd[tid].site << 10;
+              int lo = 0, hi = T; while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
+              outp[cDex[tid] + (lo < T ? cRex[lo] : totR)] = s_sd[tid];
+            }
+            if (tid < T && (rres[tid] >> 16) != 0u) {
+              const int site = (int)(keys[tid] >> 10);
+              int lo = 0, hi = dxn; while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_sd[mid].site < site) lo = mid + 1; else hi = mid; }
+              BDelta d; d.site = site; d.from = (uint8_t)((rres[tid] >> 8) & 255u); d.to = (uint8_t)(rres[tid] & 255u); d.pad = 0;
+              outp[cRex[tid] + (lo < dxn ? cDex[lo] : totD)] = d;
+            }
+            __syncthreads();
+            nsd = totD + totR;
+            for (int k = tid; k < nsd; k += NT) s_sd[k] = outp[k];
+            if (s_gi[3] != 0) bad = true;
+            __syncthreads();
+          } else if (grafter) { for (int j = 0; j < T && !full; ++j) { if (!b_push_front(s_sd, nsd, (uint32_t)k_g_sd, s_pm[j].site, s_pm[j].to, s_pm[j].from, bad)) full = true; } }
         } else if (grafter) {
           for (int k = 0; k < dxn; ++k) { b.sd[k].site = b.d_site[dx0 + k]; b.sd[k].from = b.ref[b.d_site[dx0 + k]]; b.sd[k].to = b.d_to[dx0 + k]; b.sd[k].pad = 0; }
           for (int i = np - 1; i >= 0 && !full; --i) {

@@ -121,8 +121,8 @@ emat_status build_usher_like(emat_backend* h, const emat_tip_descs& td, uint64_t
     if (getenv("EMAT_VERBOSE") && n > 2) {
       long long pr[8]; HIP_TRY(hipMemcpy(pr, d_prof.p, sizeof pr, hipMemcpyDeviceToHost));
       const double k = 1e-5 / (double)(n - 2);   // ticks of 10 ns -> ms per tip
-      fprintf(stderr, "[emat] build_usher_like: %d tips on %d workgroups, per tip: %.3f ms = parallel phases + barriers %.3f | tie sums %.3f (%.1f tying regions) | path + deltas %.3f | links + sizes %.3f | mutations %.3f\n",
-              n, blocks, pr[0] * k, pr[1] * k, pr[2] * k, (double)pr[7] / (n - 2), pr[3] * k, pr[4] * k, pr[5] * k);
+      fprintf(stderr, "[emat] build_usher_like: %d tips on %d workgroups, per tip: %.3f ms = parallel phases + barriers %.3f | tie sums %.3f (%.1f tying regions) | path + deltas %.3f (finding the path %.3f) | links + sizes %.3f | mutations %.3f\n",
+              n, blocks, pr[0] * k, pr[1] * k, pr[2] * k, (double)pr[7] / (n - 2), pr[3] * k, pr[6] * k, pr[4] * k, pr[5] * k);
     }
     if (status[0] == 1) { pool_cap *= 2; tie_cap = (uint32_t)N + pool_cap; continue; }
     if (status[0] == 2) { sd_cap *= 4; continue; }
