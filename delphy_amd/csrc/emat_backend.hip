@@ -166,6 +166,15 @@ __device__ inline const double* stage_tables(const KernelArgs& a, double* lds_ta
 // compactions and the HBM fall-back leg).
 constexpr uint32_t k_lds_heap_room = 1024;
 
+// Which XCD (accelerator complex) this wavefront runs on: hardware register XCC_ID (id 20, bits 3:0).  The eight XCDs of an
+// MI355X have an L2 each, and what a ticket hands to its successor through write-through stores is only guaranteed to be seen by a
+// successor behind the SAME L2 (a cross-XCD hand-over through that path was caught reading a stale slab by
+// tests/test_parity_gpu.py::test_tickets_handed_over_across_xcds..., about once in twenty passes): the cheap hand-over is therefore
+// only taken when the launch puts a part's tickets on one XCD -- checked, not assumed: the host verifies once per device how
+// workgroups are dealt to XCDs (k_probe_xcc), and every ticket checks that its predecessor ran where it runs itself.
+__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15u); }
+__global__ void k_probe_xcc(int32_t* out) { if (threadIdx.x == 0) out[blockIdx.x] = xcc_id(); }
+
 template <bool kSide> __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
   const int lane = threadIdx.x;
   double* lds_tables = (double*)emat_lds_tables;
@@ -195,10 +204,13 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
         // handful of huge parts that run out of HBM makes the earlier tickets of a part take seconds, found by the fuzz rounds)
         const uint64_t w0 = wall_clock64();
         bool waited = false, gave_up = false;
-        while (__hip_atomic_load(&a.chunk_done[part], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+        int32_t seen;
+        while (((seen = __hip_atomic_load(&a.chunk_done[part], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) & 0xff) < chunk) {
           __builtin_amdgcn_s_sleep(64); waited = true;
           if (wall_clock64() - w0 > 12000000000ull) { gave_up = true; break; }
         }
+        // the predecessor handed the part over without writing its L2 back: it must have run behind this very L2
+        if (!gave_up && (seen & 0x100) != 0 && ((seen >> 12) & 15) != xcc_id()) { gave_up = true; gh->fail_line = -(int32_t)__LINE__; }
         if (waited) atomicAdd((unsigned long long*)&a.chunk_done[((a.num_parts + 1) & ~1) + 2 * (blockIdx.x & 63)], (unsigned long long)(wall_clock64() - w0));   // (EMAT_VERBOSE: slot time spent waiting)
         if (gave_up) { st_status(k_part_internal); *lds_flag = -1; } else *lds_flag = 0;
       }
@@ -345,7 +357,7 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
     // it only waits for those to be acknowledged.  One that edited lists in HBM directly keeps the full release.
     if (lane == 0) {
       if (plain_hbm_writes || a.full_release) __hip_atomic_store(&a.chunk_done[part], chunk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); __hip_atomic_store(&a.chunk_done[part], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); __hip_atomic_store(&a.chunk_done[part], (chunk + 1) | 0x100 | (xcc_id() << 12), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     }
   }
 }
@@ -813,6 +825,7 @@ struct emat_backend {
   hipStream_t stream = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int num_cus = 0;
+  int xcc_count = 0;                // XCDs that workgroups are dealt to round robin (probe_xcc_dealing); 0: not so, or unknown -> tickets always hand over with a full release
   // size classes: parts sorted by persistent size; class c stages up to class_lds[c] bytes per part and runs on its own stream
   static constexpr int k_max_classes = 3;
   hipStream_t class_stream[k_max_classes] = {};   // class 0 runs on `stream`; the others on streams shared by every handle of the device (side_stream)
@@ -1145,6 +1158,9 @@ emat_status finish_pass(emat_backend* h) {
       h->fatal_status = (status[fatal] == k_part_cell_overflow || status[fatal] == k_part_list_limit) ? EMAT_ERR_CAPACITY : EMAT_ERR_INTERNAL;
       h->fatal_message = "part " + std::to_string(fatal) + " stopped inside a move with status " + std::to_string(status[fatal]) + " (device source line " + std::to_string(H->fail_line) +
                          "); " + std::to_string(stopped) + " part(s) stopped in all";
+      if (H->fail_line < 0)
+        h->fatal_message += ": a ticket found that its predecessor had handed the part over on another XCD (the cheap hand-over is only valid behind one L2; the device did not "
+                            "deal this launch's workgroups to its XCDs as probed): run with EMAT_TICKET_RELEASE=full";
       if (status[fatal] == k_part_list_limit)
         h->fatal_message += ": a per-node list would exceed " + std::to_string(k_max_list_len) + " entries (16-bit list counts, emat_slab.hpp): nothing was truncated, the run cannot continue";
       return fail(h, h->fatal_status, h->fatal_message);
@@ -1385,6 +1401,30 @@ emat_status materialize(emat_backend* h) {
   return EMAT_OK;
 }
 
+// How this device deals the workgroups of a launch to its XCDs: the number of XCDs if workgroup b runs on XCD b mod that number
+// (what MI300-class parts do in their default partition mode), 1 if there is one XCD, 0 if the pattern is anything else.  Asked
+// once per device and process; the kernels' own per-ticket check (run_moves_body) is what a pass relies on.
+int probe_xcc_dealing(int device) {
+  static std::mutex mu; static int known[64]; static bool asked[64] = {};
+  std::lock_guard<std::mutex> lock(mu);
+  if (device < 0 || device >= 64) return 0;
+  if (asked[device]) return known[device];
+  asked[device] = true; known[device] = 0;
+  const int nb = 2048;
+  int32_t* d = nullptr; std::vector<int32_t> x((size_t)nb, -1);
+  if (hipMalloc((void**)&d, nb * sizeof(int32_t)) != hipSuccess) return 0;
+  hipLaunchKernelGGL(k_probe_xcc, dim3(nb), dim3(64), 0, 0, d);
+  const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(x.data(), d, nb * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d);
+  if (!ok) { (void)hipGetLastError(); return 0; }
+  int nx = 0; for (int v : x) nx = std::max(nx, v + 1);
+  if (nx <= 0 || nx > 16) return 0;
+  for (int b = 0; b < nb; ++b) if (x[(size_t)b] != (x[0] + b) % nx) nx = -1;
+  if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] device %d: workgroups are dealt to %s\n", device, nx > 0 ? (std::to_string(nx) + " XCD(s) round robin").c_str() : "the XCDs in no pattern the tickets can rely on: full releases");
+  known[device] = nx > 0 ? nx : 0;
+  return known[device];
+}
+
 emat_status launch_recalc(emat_backend* h) {
   if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   auto set_error = [&](const std::string& s) { h->set_error(s); };
@@ -1488,7 +1528,9 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
       // but does not rely on -- what a ticket hands over goes out through agent-scope write-through stores and the next ticket
       // acquires at agent scope.  EMAT_TICKET_RELEASE=full takes the plain agent-scope release for every ticket.
       if (h->cfg_ticket_spread) b.class_stride = cnt | 1;
-      b.full_release = h->cfg_ticket_full_release ? 1 : 0;
+      // the cheap hand-over only where a part's tickets share an XCD: workgroups are dealt to the XCDs round robin (verified on this
+      // device by probe_xcc_dealing, and re-checked by every ticket), so the stride must be a multiple of their number
+      b.full_release = (h->cfg_ticket_full_release || h->xcc_count <= 0 || b.class_stride % h->xcc_count != 0) ? 1 : 0;
       const unsigned grid = b.chunks > 1 ? (unsigned)(b.chunks * b.class_stride) : (unsigned)cnt;
       const bool side = c != main_class;
       hipStream_t sm = side ? h->class_stream[c + 1] : h->stream;
@@ -1544,6 +1586,7 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   if (const char* e = getenv("EMAT_PARTS_PER_CU")) h->cfg_parts_per_cu = std::max(0, std::min(4 * EMAT_WAVES_PER_EU, atoi(e)));
   if (const char* e = getenv("EMAT_ORDER_BY_TIME")) h->cfg_order_by_time = atoi(e) != 0;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return EMAT_ERR_HIP; h->num_cus = prop.multiProcessorCount; }
+  h->xcc_count = probe_xcc_dealing(cfg->device);
   if (hipStreamCreate(&h->stream) != hipSuccess) return EMAT_ERR_HIP;
   for (hipEvent_t* e : {&h->ev_start, &h->ev_stop}) if (hipEventCreate(e) != hipSuccess) return EMAT_ERR_HIP;
   if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return EMAT_ERR_HIP;
