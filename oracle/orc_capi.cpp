@@ -7,6 +7,7 @@
 
 #include "../include/emat_backend.h"
 #include "orc_build.hpp"
+#include "orc_utree.hpp"
 #include "orc_run.hpp"
 #include "orc_subrun.hpp"
 
@@ -477,10 +478,41 @@ int orc_build_usher_like(orc_build* r, const emat_tip_descs* td, uint64_t seed, 
   tree_sizes(r->tree, num_nodes, num_muts, num_intervals, num_from_states);
   BUILD_CATCH
 }
+// the reference's DEFAULT builder (orc_utree.hpp: guide tree -> refinement rounds -> SPR refinement -> OLS rooting -> phylo tree);
+// report[0..3] = deltas of the guide tree, after the refinement rounds, after SPR refinement, the rooting method (0 regression, 1 midpoint)
+int orc_build_default(orc_build* r, const emat_tip_descs* td, uint64_t seed, int* num_nodes, int* num_muts, int* num_intervals, int* num_from_states, int* report) {
+  BUILD_TRY
+  r->descs = descs_from_c(*td, r->ref);
+  Rng rng; rng.key = seed;
+  Initial_tree_report rep;
+  r->tree = build_initial_phylo_tree(r->ref, r->descs, rng, &rep);
+  if (report) { report[0] = rep.guide_deltas; report[1] = rep.refined_deltas; report[2] = rep.spr_deltas; report[3] = rep.rooting.method == Rooting_method::regression ? 0 : 1; }
+  tree_sizes(r->tree, num_nodes, num_muts, num_intervals, num_from_states);
+  BUILD_CATCH
+}
 int orc_build_tree_get(orc_build* r, emat_flat_tree* out) {
   BUILD_TRY
   tree_to_flat(r->tree, out);
   BUILD_CATCH
+}
+// the reference sequence the last built tree is written against: the default builder re-references its tree to the root sequence
+// (phylo_tree.cpp:309-322), the UShER-like one leaves the sequence it was given
+int orc_build_tree_ref(orc_build* r, uint8_t* out) {
+  BUILD_TRY
+  ORC_CHECK(r->tree.ref_sequence.size() == r->ref.size());
+  std::copy(r->tree.ref_sequence.begin(), r->tree.ref_sequence.end(), out);
+  BUILD_CATCH
+}
+// orc_build_check for a tree written against `tree_ref` rather than the sequence the descriptors are deltas to
+int orc_build_check_with_ref(orc_build* r, const emat_flat_tree* tree, const uint8_t* tree_ref, const emat_tip_descs* td, char* msg, int msg_cap) {
+  std::string m;
+  try {
+    auto t = tree_from_flat(*tree, std::vector<State>(tree_ref, tree_ref + r->ref.size()));
+    m = check_phylo_tree_integrity(t);
+    if (m.empty()) m = check_phylo_tree_matches_tip_descs(t, r->ref, descs_from_c(*td, r->ref));
+  } catch (const std::exception& ex) { m = ex.what(); }
+  std::snprintf(msg, msg_cap, "%s", m.c_str());
+  return m.empty() ? 0 : 1;
 }
 // the reference's closing checks of the builder on ANY tree (e.g. the device's): integrity rules + every tip reproduces its descriptor
 int orc_build_check(orc_build* r, const emat_flat_tree* tree, const emat_tip_descs* td, char* msg, int msg_cap) {

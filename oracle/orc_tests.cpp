@@ -5,7 +5,7 @@
 //   /root/reference/tests/interval_set_tests.cpp, missation_map_tests.cpp, site_deltas_tests.cpp,
 //   phylo_tree_calc_tests.cpp:14-470, spr_study_tests.cpp:14-205, spr_move_tests.cpp:73-1793,
 //   tree_editing_tests.cpp, very_scalable_coalescent_tests.cpp:11-182, scalable_coalescent_tests.cpp,
-//   pop_model_tests.cpp:45-234,281-780, distributions_tests.cpp.
+//   pop_model_tests.cpp:45-234,281-780, distributions_tests.cpp, utree_tests.cpp (in orc_utree_tests.hpp).
 // Only fixture DATA and expected VALUES are restated (with the line they come from); no reference
 // source is copied.  Invoked by tests/test_oracle_pinning.py; exit code = number of failed checks.
 #include <cstdio>
@@ -1532,6 +1532,8 @@ TEST(build_usher_like_tree_reproduces_its_tip_descriptors) {
     EXPECT(same);
   }
 }
+
+#include "orc_utree_tests.hpp"
 
 int main(int argc, char** argv) {
   const char* only = argc > 1 ? argv[1] : nullptr;

@@ -284,12 +284,15 @@ class OracleBuild:
             for n, a in {"orc_build_create": [P(C.c_uint8), i, P(E)], "orc_build_destroy": [E],
                          "orc_build_descs_from_tree": [E, P(_FlatTreeC), P(i), P(i), P(i)],
                          "orc_build_descs_get": [E, P(C.c_float), P(C.c_float), P(i), P(i), P(C.c_uint8), P(i), P(i), P(i)],
-                         "orc_build_usher_like": [E, P(_TipDescsC), C.c_uint64, P(i), P(i), P(i), P(i)], "orc_build_tree_get": [E, P(_FlatTreeC)],
-                         "orc_build_check": [E, P(_FlatTreeC), P(_TipDescsC), C.c_char_p, i]}.items():
+                         "orc_build_usher_like": [E, P(_TipDescsC), C.c_uint64, P(i), P(i), P(i), P(i)],
+                         "orc_build_default": [E, P(_TipDescsC), C.c_uint64, P(i), P(i), P(i), P(i), P(i)], "orc_build_tree_get": [E, P(_FlatTreeC)],
+                         "orc_build_check": [E, P(_FlatTreeC), P(_TipDescsC), C.c_char_p, i], "orc_build_tree_ref": [E, P(C.c_uint8)],
+                         "orc_build_check_with_ref": [E, P(_FlatTreeC), P(C.c_uint8), P(_TipDescsC), C.c_char_p, i]}.items():
                 f = getattr(self.L, n); f.argtypes = a; f.restype = C.c_int
             self.L.orc_build_last_error.argtypes = [E]; self.L.orc_build_last_error.restype = C.c_char_p
             self.L._build_sigs = True
         ref = np.ascontiguousarray(ref, np.uint8)
+        self.num_sites = int(ref.shape[0])
         self.h = E()
         assert self.L.orc_build_create(_ptr(ref, C.c_uint8), ref.shape[0], C.byref(self.h)) == 0
 
@@ -321,7 +324,27 @@ class OracleBuild:
         t.root = v.root
         return t.trimmed()
 
-    def check(self, tree: FlatTree, tips):
+    def build_default(self, tips, seed):
+        """oracle/orc_utree.hpp: the reference's default builder (build_initial_phylo_tree).  Returns (tree, ref, report): the tree is
+        written against `ref`, the ROOT's sequence (the reference re-references there); report = dict(guide_deltas, refined_deltas,
+        spr_deltas, rooting)."""
+        td = tips.c_struct(); n, nm, ni, nf = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        rep = (C.c_int * 4)()
+        self._ck(self.L.orc_build_default(self.h, C.byref(td), int(seed), C.byref(n), C.byref(nm), C.byref(ni), C.byref(nf), rep), "build_default")
+        t = FlatTree.empty(n.value, nm.value, ni.value, nf.value)
+        v = t.c_view()
+        self._ck(self.L.orc_build_tree_get(self.h, C.byref(v)), "build_tree_get")
+        t.root = v.root
+        ref = np.zeros(self.num_sites, np.uint8)
+        self._ck(self.L.orc_build_tree_ref(self.h, _ptr(ref, C.c_uint8)), "build_tree_ref")
+        return t.trimmed(), ref, dict(guide_deltas=rep[0], refined_deltas=rep[1], spr_deltas=rep[2], rooting="regression" if rep[3] == 0 else "midpoint")
+
+    def check(self, tree: FlatTree, tips, ref=None):
+        """`ref`: the sequence the tree is written against when that is not the one the descriptors are deltas to."""
         v = tree.c_view(); td = tips.c_struct(); buf = C.create_string_buffer(512)
+        if ref is not None:
+            ref = np.ascontiguousarray(ref, np.uint8); assert ref.shape[0] == self.num_sites
+            rc = self.L.orc_build_check_with_ref(self.h, C.byref(v), _ptr(ref, C.c_uint8), C.byref(td), buf, 512)
+            return rc, buf.value.decode()
         rc = self.L.orc_build_check(self.h, C.byref(v), C.byref(td), buf, 512)
         return rc, buf.value.decode()

@@ -2,6 +2,8 @@
 of the reference's build_usher_like_tree (oracle/orc_build.hpp, pinned to the reference's fix_up_missations cases): same
 descriptors + same seed => the same tree, bit for bit -- topology, node times, every mutation with its time, every missation and
 from-state; and the reference's own closing checks of the builder (tree integrity, every tip reproduces its descriptor)."""
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -76,6 +78,44 @@ def test_descriptors_the_reference_rejects():
         with pytest.raises(d.EmatError, match=what):
             b.build_usher_like(bad, 1)
     b.close()
+
+
+def _default_built(name, seed, **kw):
+    """A scenario whose tree is the reference's default initial tree for the scenario's tips (written against the root's sequence)."""
+    sc = make_scenario(name, **kw)
+    ob = OracleBuild(sc.ref)
+    try:
+        tips = ob.tip_descs_of(sc.tree)
+        tree, ref, rep = ob.build_default(tips, seed)
+        rc, msg = ob.check(tree, tips, ref=ref)
+        assert rc == 0, msg
+        return dataclasses.replace(sc, tree=tree, ref=ref), tips, tree, rep
+    finally:
+        ob.close()
+
+
+def test_the_references_default_builder_restated():
+    """oracle/orc_utree.hpp (guide tree -> refinement rounds -> SPR refinement -> OLS rooting -> phylo tree; pinned to the reference's
+    tests/utree_tests.cpp by oracle/orc_tests) on the tip descriptors of scenario trees: the reference's closing checks of a built
+    tree pass, every stage is at least as parsimonious as the one before, the same stream gives the same tree."""
+    for name, kw, seed in (("C1", dict(num_tips=12, num_sites=300), 3), ("C1", dict(num_tips=150, num_sites=30000, uncertain_tips=0.3), 4), ("C2", dict(num_tips=400, num_sites=18959), 5)):
+        sc, tips, tree, rep = _default_built(name, seed, **kw)
+        assert tree.num_nodes == 2 * tips.num_tips - 1 and np.all(tree.child0[: tips.num_tips] == -1)
+        assert rep["spr_deltas"] <= rep["refined_deltas"] <= rep["guide_deltas"], rep
+        # mutations above the root re-reference the root sequence away; all others are the unrooted tree's deltas
+        assert tree.mut_site.shape[0] == rep["spr_deltas"], (tree.mut_site.shape[0], rep)
+        _, _, again, _ = _default_built(name, seed, **kw)
+        for f in FIELDS:
+            assert np.array_equal(getattr(tree, f), getattr(again, f)), f
+
+
+@pytest.mark.gpu
+def test_chains_started_from_the_default_builders_tree():
+    """The reference starts a run from build_initial_phylo_tree's tree (cmdline.cpp:437); the local-move path on that starting state:
+    derived quantities and the chains of every part, device against oracle, like test_parity_gpu's cases on simulated trees."""
+    from helpers import run_parity
+    sc, tips, tree, rep = _default_built("C2", 9, num_tips=700, num_sites=18959)
+    run_parity(sc, num_parts=12, moves_per_part=3000, seed=5, trace=300)
 
 
 def test_builder_has_no_host_fallback():
