@@ -156,6 +156,11 @@ EMAT_D void fail_at(Ctx& c, int status, int line) {
 #ifdef EMAT_PROFILE_PHASES
 #define EMAT_SITE(line, hbm, v) atomicAdd(&::emat::g_arena_site_bytes[(line) & 2047][(hbm) ? 1 : 0], (unsigned long long)(v))
 #define EMAT_COUNT(c, k, v) (((int64_t*)hdr_of(c)->reserved)[k] += (int64_t)(v))
+#ifdef EMAT_X_UNLIMITED_SCANS   // probe variant: reserved[11], [12] count the scans without a limit and their ticks instead
+#define EMAT_COUNT_TRIMS(c, k, v) do {} while (0)
+#else
+#define EMAT_COUNT_TRIMS(c, k, v) EMAT_COUNT(c, k, v)
+#endif
 #define EMAT_PHASE_BEGIN() long long _ph_t0 = clock64()
 #define EMAT_PHASE(c, k) do { long long _t = clock64(); hdr_of(c)->phase_ticks[k] += _t - _ph_t0; _ph_t0 = _t; } while (0)
 #define EMAT_TIMED(file_id) ::emat::FnTimer _fn_timer((file_id) * 2048 + (__LINE__ & 2047))
@@ -163,6 +168,7 @@ EMAT_D void fail_at(Ctx& c, int status, int line) {
 #define EMAT_TIMED(file_id) do {} while (0)
 #define EMAT_SITE(line, hbm, v) do {} while (0)
 #define EMAT_COUNT(c, k, v) do {} while (0)
+#define EMAT_COUNT_TRIMS(c, k, v) do {} while (0)
 #define EMAT_PHASE_BEGIN() do {} while (0)
 #define EMAT_PHASE(c, k) do {} while (0)
 #endif
@@ -285,7 +291,7 @@ template <class T> EMAT_D bool sc_open_migrate(Ctx& c, SVec<T>& v, int max_elems
 template <class T> EMAT_D void sc_trim(Ctx& c, SVec<T>& v, int line = __builtin_LINE()) {
   uint32_t used = ((uint32_t)v.n * (uint32_t)sizeof(T) + 15u) & ~15u;
   if (sc_in_lds(c, v.p)) { c.a_top = (uint32_t)((uint8_t*)v.p - c.A) + used; EMAT_COUNT(c, 9, used); EMAT_SITE(line, 0, used); }
-  else { c.sc_top = (uint32_t)((uint8_t*)v.p - c.G) + used; EMAT_COUNT(c, 8, used); EMAT_COUNT(c, 11, 1); EMAT_SITE(line, 1, used); }
+  else { c.sc_top = (uint32_t)((uint8_t*)v.p - c.G) + used; EMAT_COUNT(c, 8, used); EMAT_COUNT_TRIMS(c, 11, 1); EMAT_SITE(line, 1, used); }
   v.cap = v.n;
 }
 // Two containers growing towards each other inside one arena (results upwards from `lo`, a work stack downwards
@@ -321,7 +327,7 @@ EMAT_D ScSpan sc_span_hbm(Ctx& c) {
 EMAT_D void sc_span_commit(Ctx& c, const ScSpan& s, uint32_t used_bytes, int line = __builtin_LINE()) {
   uint32_t u = (used_bytes + 15u) & ~15u;
   if (s.reserved) return;   // the block stays reserved
-  if (s.lds) { c.a_top = (uint32_t)(s.lo - c.A) + u; EMAT_COUNT(c, 9, u); EMAT_SITE(line, 0, u); } else { c.sc_top = (uint32_t)(s.lo - c.G) + u; EMAT_COUNT(c, 8, u); EMAT_COUNT(c, 12, 1); EMAT_SITE(line, 1, u); }
+  if (s.lds) { c.a_top = (uint32_t)(s.lo - c.A) + u; EMAT_COUNT(c, 9, u); EMAT_SITE(line, 0, u); } else { c.sc_top = (uint32_t)(s.lo - c.G) + u; EMAT_COUNT(c, 8, u); EMAT_COUNT_TRIMS(c, 12, 1); EMAT_SITE(line, 1, u); }
 }
 
 // ---- persistent per-node lists in the slab heap ---------------------------------------------------------

@@ -381,7 +381,11 @@ EMAT_NOTAIL EMAT_DN void spr1_move_begin(Ctx& c) { EMAT_TIMED(2);
   c.phase = 0;
   if (hdr_of(c)->n_nodes < 2) return;
   const double chooser = uniform_co(c, 0.0, 1.0);
+#ifdef EMAT_X_NO_UNLIMITED_SCANS   // timing experiment only (a different chain): what the 1 % of scans without a limit cost the slowest chains
+  const int limit = 1; (void)chooser;
+#else
   const int limit = chooser < 0.01 ? 0x7fffffff : 1;
+#endif
   const int root0 = hdr_of(c)->root;
   c.mu_prop = nodes_of(c)[root0].lambda / (c.L - nodes_of(c)[root0].n_missing);
   int X;

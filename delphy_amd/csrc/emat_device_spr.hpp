@@ -1509,8 +1509,14 @@ EMAT_DN void wave_scan_and_study(Ctx& c) {
   if (fr.limit == 1) scanned = wave_local_scan(c, fr);
 #endif
   if (!scanned) {   // the 1 % of scans without a limit on the mutations crossed (and local ones that found no room): serial, on lane 0
+#if defined(EMAT_PROFILE_PHASES) && defined(EMAT_X_UNLIMITED_SCANS)
+    const long long un0 = clock64();
+#endif
     if (lane == 0) *shared = study_seed_fill(c, fr.X, fr.t_X, fr.missing_at_X, fr.limit, fr.init_branch, 0, fr.deltas, fr.can_change_root, fr.hot);
     __syncthreads();
+#if defined(EMAT_PROFILE_PHASES) && defined(EMAT_X_UNLIMITED_SCANS)
+    if (lane == 0) { EMAT_COUNT(c, 11, 1); EMAT_COUNT(c, 12, clock64() - un0); }
+#endif
   }
 #ifdef EMAT_PROFILE_PHASES
   if (lane == 0) { hdr_of(c)->phase_ticks[6] += clock64() - ph0; hdr_of(c)->phase_ticks[13] += shared->n; }
