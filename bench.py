@@ -415,6 +415,20 @@ def main():
                                 "ess_per_million_moves": {k: v["ess_per_million_moves"] for k, v in c["stats"].items()}} for c in pc["configs"]]}
         except Exception as e:
             mixing = {"error": "unreadable profiles/posterior_latest.json: %s" % e}
+    # ... and at a size nearer the benchmark's (tests/posterior_scale.py: C3-like tree, 4 seeds; the coarse arm is the oracle with the
+    # reference's policy of 8 parts on 8 host threads, the fine arms run on the GPU): pooled z of the arms' means and ESS per second
+    scale_path = os.path.join(ROOT, "profiles", "posterior_scale_latest.json")
+    if rank == 0 and os.path.exists(scale_path):
+        try:
+            ps = json.load(open(scale_path))
+            mixing = mixing or {}
+            mixing["at_scale"] = {"source": "profiles/posterior_scale_latest.json (tests/posterior_scale.py: %d tips, %d seeds, burn-in %d cycles)" % (ps["tips"], ps["seeds"], ps["burn_in"]),
+                                  "measured_on_emat_build_id": ps.get("emat_build_id"), "stale": ps.get("emat_build_id") != build_id,
+                                  "worst_abs_pooled_z": ps.get("worst_abs_pooled_z"),
+                                  "pooled_z": {arm: {k: v["pooled_z"] for k, v in q.items()} for arm, q in ps.get("pooled", {}).items()},
+                                  "ess_per_s": {"gpu_at_benchmark_density": ps.get("ess_per_s_at_benchmark_density"), "oracle_8_parts_8_threads": ps.get("ess_per_s_reference_policy_oracle")}}
+        except Exception as e:
+            mixing = dict(mixing or {}, at_scale={"error": "unreadable profiles/posterior_scale_latest.json: %s" % e})
 
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

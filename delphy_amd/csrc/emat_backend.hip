@@ -24,6 +24,9 @@
 #include <stdexcept>
 
 #include "../../include/emat_backend.h"
+#ifdef EMAT_X_DIVERGENT
+__device__ __forceinline__ uint32_t emat_opaque_zero() { uint32_t z; asm("v_mov_b32 %0, 0" : "=v"(z)); return z; }
+#endif
 // 1: every lane of the wave runs the chain, all with the same values (the chain's code does not depend on the lane);
 // 0: lane 0 alone.  With one lane active every non-leaf device function saves and restores the INACTIVE lanes of the
 // VGPR it parks its return address in (s_xor_saveexec + scratch_store / scratch_load + s_waitcnt vmcnt(0)); with all
@@ -34,10 +37,12 @@
 #if defined(EMAT_PROFILE_PHASES) || defined(EMAT_COUNT_CALLS)
 namespace emat {
 __device__ unsigned long long g_fn_ticks[3 * 2048][2];   // EMAT_TIMED scopes: [header * 2048 + line][ticks, calls], all parts
+__device__ unsigned g_fn_min_list_bytes = 0;              // ... or only the parts whose lists take at least this much (EMAT_FN_MIN_LISTS: the heavy parts near the root)
+__shared__ int s_fn_count_me;
 struct FnTimer {   // inclusive ticks and calls of the enclosing scope, keyed by (header, source line); lane 0 only
   int key; long long t0;
   __device__ FnTimer(int k) : key(k), t0(clock64()) {}
-  __device__ ~FnTimer() { if (threadIdx.x == 0) { atomicAdd(&g_fn_ticks[key][0], (unsigned long long)(clock64() - t0)); atomicAdd(&g_fn_ticks[key][1], 1ull); } }
+  __device__ ~FnTimer() { if (threadIdx.x == 0 && s_fn_count_me) { atomicAdd(&g_fn_ticks[key][0], (unsigned long long)(clock64() - t0)); atomicAdd(&g_fn_ticks[key][1], 1ull); } }
 };
 }
 #endif
@@ -226,6 +231,9 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
     done_at_start = gh->moves_done - (int64_t)(uint32_t)((uint32_t)gh->moves_done - gh->pad0);
   } else done_at_start = gh->moves_done;
   const uint32_t area = a.lds_slab_bytes;
+#if defined(EMAT_PROFILE_PHASES) || defined(EMAT_COUNT_CALLS)
+  if (lane == 0) s_fn_count_me = (gh->heap_top - gh->heap_begin) >= g_fn_min_list_bytes ? 1 : 0;
+#endif
   const bool can_stage = tables_staged && area != 0 && gh->off_nodes == (uint32_t)sizeof(SlabHeader);
   if (lane == 0 && chunk == 0) { st_ticks(0); a.part_ticks[a.num_parts + part] = (int64_t)wall_clock64(); }   // duration, start (emat_debug_part_ticks)
   // Up to two legs: a part whose USED state fits the staging area but whose heap capacity does not is staged whole with
@@ -295,9 +303,9 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
     // scan and study of an SPR move), all 64 lanes do that work and lane 0 picks the move up again.
     for (;;) {
       if (EMAT_CHAIN_ON_ALL_LANES || lane == 0) {
-        if (staged) dev_lds::run_chain_loop(*(dev_lds::Ctx*)(emat_lds_ctx));
-        else if (prefix) dev_mix::run_chain_loop(*(dev_mix::Ctx*)(emat_lds_ctx));
-        else dev::run_chain_loop(*(dev::Ctx*)(emat_lds_ctx));
+        if (staged) dev_lds::run_chain_loop(*(dev_lds::Ctx*)(emat_lds_ctx + EMAT_OPQ));
+        else if (prefix) dev_mix::run_chain_loop(*(dev_mix::Ctx*)(emat_lds_ctx + EMAT_OPQ));
+        else dev::run_chain_loop(*(dev::Ctx*)(emat_lds_ctx + EMAT_OPQ));
       }
       __syncthreads();
       if (((const dev::Ctx*)(emat_lds_ctx))->svc == 0) break;
@@ -2243,6 +2251,8 @@ emat_status emat_debug_fn_ticks(emat_backend* h, uint64_t* out_12288) {
   HIP_TRY(hipMemcpyFromSymbol(out_12288, HIP_SYMBOL(::emat::g_fn_ticks), sizeof(unsigned long long) * 12288));
   std::vector<unsigned long long> z(12288, 0);
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(::emat::g_fn_ticks), z.data(), sizeof(unsigned long long) * 12288));
+  const unsigned min_lists = getenv("EMAT_FN_MIN_LISTS") ? (unsigned)atoi(getenv("EMAT_FN_MIN_LISTS")) : 0u;   // from the next pass on: only parts whose lists take at least this many bytes
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(::emat::g_fn_min_list_bytes), &min_lists, sizeof(min_lists)));
   return EMAT_OK;
 #else
   return fail(h, EMAT_ERR_STATE, "built without -DEMAT_PROFILE_PHASES");

@@ -125,10 +125,18 @@ struct Ctx {
 
 static_assert(sizeof(Ctx) + 16 <= k_lds_ctx_bytes, "context outgrew its LDS slot (the last 16 bytes are the kernel's flag word)");
 // Base pointers of the part's persistent state.
+// -DEMAT_X_DIVERGENT (an experiment): what the chain would cost if its addresses were NOT wave-uniform,
+// as they would be with several chains side by side in one wavefront -- every base address gets a zero the compiler cannot see
+// through (a VGPR), so address arithmetic, loaded values and branches all leave the scalar unit.  Still one chain per wave.
+#ifdef EMAT_X_DIVERGENT
+#define EMAT_OPQ ::emat_opaque_zero()   // (defined before the first inclusion, in emat_backend.hip)
+#else
+#define EMAT_OPQ 0u
+#endif
 #if EMAT_VARIANT_LDS
-EMAT_DF uint8_t* slab_at(const Ctx&, uint32_t off) { return emat_lds + (off - (uint32_t)sizeof(SlabHeader)); }   // slab byte `off` (beyond the header)
-EMAT_DF SlabHeader* hdr_of(const Ctx&) { return (SlabHeader*)emat_lds_hdr; }
-EMAT_DF NodeRec* nodes_of(const Ctx&) { return (NodeRec*)emat_lds; }   // off_nodes == sizeof(SlabHeader), checked at launch
+EMAT_DF uint8_t* slab_at(const Ctx&, uint32_t off) { return emat_lds + (off - (uint32_t)sizeof(SlabHeader)) + EMAT_OPQ; }   // slab byte `off` (beyond the header)
+EMAT_DF SlabHeader* hdr_of(const Ctx&) { return (SlabHeader*)(emat_lds_hdr + EMAT_OPQ); }
+EMAT_DF NodeRec* nodes_of(const Ctx&) { return (NodeRec*)(emat_lds + EMAT_OPQ); }   // off_nodes == sizeof(SlabHeader), checked at launch
 EMAT_DF const double* mu_of(const Ctx&) { return (const double*)emat_lds_tables; }
 EMAT_DF const double* pi_of(const Ctx&) { return (const double*)emat_lds_tables + k_max_lds_partitions; }
 EMAT_DF const double* q_of(const Ctx&) { return (const double*)emat_lds_tables + k_max_lds_partitions * 5; }

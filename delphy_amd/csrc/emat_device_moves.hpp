@@ -99,7 +99,7 @@ EMAT_NOTAIL EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new
 #define EMAT_SIMPLE_MOVE EMAT_NOTAIL EMAT_DN
 #endif
 #endif
-template <bool kRoot> EMAT_SIMPLE_MOVE void inner_node_displace_move(Ctx& c) {   // subrun.cpp:148-232
+template <bool kRoot> EMAT_SIMPLE_MOVE void inner_node_displace_move(Ctx& c) { EMAT_TIMED(2);   // subrun.cpp:148-232
   begin_move(c, k_inner_node_displace);
   int node;
   { int guard = 0; do { node = pick_random_node(c); } while (is_tip(c, node) && guard++ < (1 << 26)); }
@@ -162,7 +162,7 @@ template <bool kRoot> EMAT_SIMPLE_MOVE void inner_node_displace_move(Ctx& c) {  
   }
 }
 
-template <bool kRoot> EMAT_SIMPLE_MOVE void tip_displace_move(Ctx& c) {   // subrun.cpp:234-285
+template <bool kRoot> EMAT_SIMPLE_MOVE void tip_displace_move(Ctx& c) { EMAT_TIMED(2);   // subrun.cpp:234-285
   begin_move(c, k_tip_displace);
   int node;
   { int guard = 0; do { node = pick_random_node(c); } while (!is_tip(c, node) && guard++ < (1 << 26)); }
@@ -195,7 +195,7 @@ template <bool kRoot> EMAT_SIMPLE_MOVE void tip_displace_move(Ctx& c) {   // sub
 }
 
 // phylo_tree.cpp:579-644; result in scratch
-EMAT_D SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) {
+EMAT_D SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) { EMAT_TIMED(2);
   const int n = nmuts(c, X);
   SVec<MutRec> out = sc_vec<MutRec>(c, n);
   if (c.failed) return out;
@@ -231,7 +231,7 @@ EMAT_D SVec<MutRec> randomize_branch_mutation_times(Ctx& c, int X) {
 // and one logarithm per mutation and list, in sequence), and each sum then runs in its own order over the same operands -- bit
 // for bit the reference's two numbers.  A re-timed mutation carries the index of the one it came from in its `pad` field.
 struct ReformFactors { double* A; double* B; };
-EMAT_D ReformFactors reform_factors(Ctx& c, const MutRec* m, int n) {
+EMAT_D ReformFactors reform_factors(Ctx& c, const MutRec* m, int n) { EMAT_TIMED(2);
   ReformFactors f; f.A = (double*)sc_alloc(c, (uint32_t)n * 16u); f.B = f.A + n;
   if (c.failed) return f;
   for (int j0 = 0; j0 < n; j0 += 4) {
@@ -252,7 +252,7 @@ EMAT_D ReformFactors reform_factors(Ctx& c, const MutRec* m, int n) {
   for (int j = 0; j < n; ++j) f.B[j] = m_log(f.B[j]);
   return f;
 }
-template <bool kRoot> EMAT_SIMPLE_MOVE void branch_reform_move(Ctx& c) {   // subrun.cpp:287-320
+template <bool kRoot> EMAT_SIMPLE_MOVE void branch_reform_move(Ctx& c) { EMAT_TIMED(2);   // subrun.cpp:287-320
   begin_move(c, k_branch_reform);
   if (hdr_of(c)->n_nodes < 3) return;
   const int X = pick_random_node(c);

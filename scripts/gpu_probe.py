@@ -328,7 +328,10 @@ def fn_probe(nparts=8192, moves=1000):
     ph1 = np.zeros((eng.num_local_parts, 16))
     for p in range(eng.num_local_parts):
         lib.emat_debug_phase_ticks(eng.backend.handle, p, pb); ph1[p] = list(pb)
-    dph = (ph1 - ph0).sum(axis=0)
+    min_lists = int(os.environ.get("EMAT_FN_MIN_LISTS", "0"))    # only the parts whose lists take at least this many bytes (the library filters its function timers alike)
+    sel = np.array([eng.backend.debug_slab_layout(p)["heap_used"] >= min_lists for p in range(eng.num_local_parts)])
+    print("parts counted: %d of %d (lists >= %d bytes)" % (sel.sum(), len(sel), min_lists))
+    dph = (ph1 - ph0)[sel].sum(axis=0)
     simple, topo = dph[14], dph[15]
     a = np.array(list(buf), dtype=np.float64).reshape(3 * 2048, 2)
     files = ["emat_device_core.hpp", "emat_device_spr.hpp", "emat_device_moves.hpp"]
@@ -344,7 +347,7 @@ def fn_probe(nparts=8192, moves=1000):
     dticks = sum(eng.backend.part_stats(p)["device_ticks"] for p in range(eng.num_local_parts))
     print("pass %.2f ms; chains %.3g ticks of 10 ns over both passes" % (eng.backend.last_run_ms(), dticks))
     print("parts %d, moves %d: simple moves %.3g ticks, topology moves %.3g ticks (%.1f%% of chain time)" % (eng.num_local_parts, moves, simple, topo, 100 * topo / (simple + topo)))
-    ntopo = sum(sum(eng.backend.part_stats(p)["proposed"][3:5]) for p in range(eng.num_local_parts)) / 2.0
+    ntopo = sum(sum(eng.backend.part_stats(p)["proposed"][3:5]) for p in range(eng.num_local_parts) if sel[p]) / 2.0
     os.environ["EMAT_PHASE_EXTRA"] = "1"
     ex = np.zeros(16)
     for p in range(eng.num_local_parts):
