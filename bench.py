@@ -161,7 +161,7 @@ def cpu_baseline(sc, num_parts, seed, target_seconds, t_step):
     return out
 
 
-def inclusive_cycles(sc, args, cycles=3):
+def inclusive_cycles(sc, args, cycles=10):
     """Whole cycles through the host run driver (emat_run_do_mcmc_steps), the reference's default 50 x nodes local moves per
     cycle (run.cpp:669-672), wall clock.  Two ways: with the whole tree resident in HBM (the host draws the
     partition on the topology, kernels cut the part slabs and gather them back) and with the tree on the host (subtree
@@ -179,14 +179,17 @@ def inclusive_cycles(sc, args, cycles=3):
         if device_tree:
             run.set_device_tree(True)
         run.do_mcmc_steps(per_cycle, per_cycle)          # warm-up cycle: allocations, first launch, tree upload
+        each = []
         t0 = time.perf_counter()
-        run.do_mcmc_steps(cycles * per_cycle, per_cycle)
+        for _ in range(cycles):                          # (one call per cycle only to time the cycles apart; the driver repartitions at every cycle boundary either way)
+            t1 = time.perf_counter(); run.do_mcmc_steps(per_cycle, per_cycle); each.append((time.perf_counter() - t1) * 1e3)
         dt = time.perf_counter() - t0
         run.close(); b.close()
-        return {"value": cycles * per_cycle / dt, "unit": "moves/s", "ms_per_cycle": dt / cycles * 1e3}
+        return {"value": cycles * per_cycle / dt, "unit": "moves/s", "ms_per_cycle": dt / cycles * 1e3, "ms_per_cycle_min": min(each), "ms_per_cycle_max": max(each)}
 
     dev, host = one(True), one(False)
     return {"value": dev["value"], "unit": "moves/s", "cycles": cycles, "moves_per_cycle": per_cycle, "ms_per_cycle": dev["ms_per_cycle"],
+            "ms_per_cycle_min": dev["ms_per_cycle_min"], "ms_per_cycle_max": dev["ms_per_cycle_max"],
             "what": "emat_run_do_mcmc_steps with the tree resident in HBM: stencil + partition on the host's copy of the topology, part slabs cut and "
                     "gathered back by kernels, %d local moves per cycle (no global moves), wall clock" % per_cycle,
             "host_tree": dict(host, what="the same cycles with the tree on the host: subtree build + slab encode + H2D + moves + D2H + decode + reassemble")}

@@ -1412,7 +1412,10 @@ emat_status materialize(emat_backend* h) {
 // How this device deals the workgroups of a launch to its XCDs: the number of XCDs if workgroup b runs on XCD b mod that number
 // (what MI300-class parts do in their default partition mode), 1 if there is one XCD, 0 if the pattern is anything else.  Asked
 // once per device and process; the kernels' own per-ticket check (run_moves_body) is what a pass relies on.
-int probe_xcc_dealing(int device) {
+// (On the caller's stream, never the null stream: once a process has used the null stream it holds one of the runtime's four hardware
+// queues for good, and with two handles alive -- bench.py's engine and its run driver -- a main stream then shares a queue with a
+// side stream and waits 15-19 ms per pass for that stream's kernel: whole cycles of 48 ms instead of 29.)
+int probe_xcc_dealing(int device, hipStream_t stream) {
   static std::mutex mu; static int known[64]; static bool asked[64] = {};
   std::lock_guard<std::mutex> lock(mu);
   if (device < 0 || device >= 64) return 0;
@@ -1421,8 +1424,8 @@ int probe_xcc_dealing(int device) {
   const int nb = 2048;
   int32_t* d = nullptr; std::vector<int32_t> x((size_t)nb, -1);
   if (hipMalloc((void**)&d, nb * sizeof(int32_t)) != hipSuccess) return 0;
-  hipLaunchKernelGGL(k_probe_xcc, dim3(nb), dim3(64), 0, 0, d);
-  const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(x.data(), d, nb * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess;
+  hipLaunchKernelGGL(k_probe_xcc, dim3(nb), dim3(64), 0, stream, d);
+  const bool ok = hipMemcpyAsync(x.data(), d, nb * sizeof(int32_t), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
   (void)hipFree(d);
   if (!ok) { (void)hipGetLastError(); return 0; }
   int nx = 0; for (int v : x) nx = std::max(nx, v + 1);
@@ -1594,8 +1597,8 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   if (const char* e = getenv("EMAT_PARTS_PER_CU")) h->cfg_parts_per_cu = std::max(0, std::min(4 * EMAT_WAVES_PER_EU, atoi(e)));
   if (const char* e = getenv("EMAT_ORDER_BY_TIME")) h->cfg_order_by_time = atoi(e) != 0;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return EMAT_ERR_HIP; h->num_cus = prop.multiProcessorCount; }
-  h->xcc_count = probe_xcc_dealing(cfg->device);
   if (hipStreamCreate(&h->stream) != hipSuccess) return EMAT_ERR_HIP;
+  h->xcc_count = probe_xcc_dealing(cfg->device, h->stream);
   for (hipEvent_t* e : {&h->ev_start, &h->ev_stop}) if (hipEventCreate(e) != hipSuccess) return EMAT_ERR_HIP;
   if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return EMAT_ERR_HIP;
   for (int c = 1; c < emat_backend::k_max_classes; ++c) {

@@ -11,7 +11,8 @@ from delphy_amd.sharding import ShardedEngine
 
 area = int(sys.argv[1]) if len(sys.argv) > 1 else 9648
 sc = make_scenario("C4")
-eng = ShardedEngine(sc, num_parts=8192, seed=20261001)
+world, rank = int(os.environ.get("EMAT_PROBE_WORLD", "1")), int(os.environ.get("EMAT_PROBE_RANK", "0"))   # one GPU of N, emulated (scripts/scale_probe.py)
+eng = ShardedEngine(sc, num_parts=8192, seed=20261001, rank=rank, world=world, device_tree=world > 1, allreduce=lambda a, op: a, allgather_bytes=lambda b: [b])
 eng.setup()
 b = eng.backend
 b.run_moves_per_part(1000); b.synchronize()
