@@ -98,6 +98,7 @@ struct KernelArgs {
   // ticket c of a part starts when ticket c - 1 has written the slab back (chunk_done[part] == c).  Shorter tickets pack the
   // slots better at the end of a pass; the chain -- one RNG stream per part, state in the slab -- is the same chain.
   int32_t chunks, class_count, class_stride, taper;
+  int32_t single_below;           // the first `single_below` slots of the launch order (the parts expected to run longest) do their whole pass in ONE ticket, from the start of the pass: longest jobs first and unsplit, the many short chains -- in tickets -- fill in around them
   int32_t full_release;           // EMAT_TICKET_RELEASE=full: every ticket hands its part over with an agent-scope RELEASE (the path that needs no assumption about where workgroups run)
   int32_t cum_w[8];               // cumulative ticket weights (EMAT_TICKET_WEIGHTS) or zeros
   int32_t* chunk_done;            // [num_parts], zeroed before the launch
@@ -188,6 +189,8 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
   int* lds_flag = (int*)(emat_lds_ctx + k_lds_ctx_bytes - 16);   // spare tail of the context slot: lane 0 -> all lanes
   const int chunk = a.chunks > 1 ? (int)blockIdx.x / a.class_stride : 0, slot = a.chunks > 1 ? (int)blockIdx.x % a.class_stride : (int)blockIdx.x;
   if (a.chunks > 1 && slot >= a.class_count) return;   // padding: the stride is a multiple of 8 so that a part's tickets land on one XCD
+  const bool single = a.chunks > 1 && slot < a.single_below;   // this part's pass is one ticket: its later tickets have nothing to do
+  if (single && chunk > 0) return;
   const int part = a.order[slot];
   // Per-part words that one ticket of a part writes and the next reads (status, chain ticks): agent-scope atomics, which every
   // XCD sees without a cache write-back.
@@ -225,7 +228,8 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
     __syncthreads();
     // cumulative over the tickets so far.  The tickets of a part shrink in the ratio n : n-1 : ... : 1, so that the jobs that start
     // last -- the ones a pass ends with -- are the shortest (equal tickets: EMAT_TICKET_TAPER=0)
-    if (a.cum_w[0] > 0) target = chunk + 1 == a.chunks ? pass_target : pass_target * a.cum_w[chunk] / a.cum_w[a.chunks - 1];   // a table of weights (the default for four tickets, or EMAT_TICKET_WEIGHTS="w1,w2,...")
+    if (single) target = pass_target;
+    else if (a.cum_w[0] > 0) target = chunk + 1 == a.chunks ? pass_target : pass_target * a.cum_w[chunk] / a.cum_w[a.chunks - 1];   // a table of weights (the default for four tickets, or EMAT_TICKET_WEIGHTS="w1,w2,...")
     else if (a.taper) { const int64_t nn = a.chunks, done_w = (int64_t)(chunk + 1) * (2 * nn - chunk), all_w = nn * (nn + 1); target = chunk + 1 == a.chunks ? pass_target : pass_target * done_w / all_w; }
     else target = pass_target * (chunk + 1) / a.chunks;
     done_at_start = gh->moves_done - (int64_t)(uint32_t)((uint32_t)gh->moves_done - gh->pad0);
@@ -349,7 +353,7 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
     const int again_all = *lds_flag;
     if (again_all < 2) {
       const uint32_t out_bytes = staged ? ((const SlabHeader*)emat_lds_hdr)->heap_top : (prefix ? staged_bytes : 0u);
-      if (out_bytes && a.chunks > 1) { wave_copy8_through(gslab, emat_lds_hdr, (uint32_t)sizeof(SlabHeader), lane); wave_copy8_through(gslab + sizeof(SlabHeader), lds_slab, out_bytes - (uint32_t)sizeof(SlabHeader), lane); }
+      if (out_bytes && a.chunks > 1 && !single) { wave_copy8_through(gslab, emat_lds_hdr, (uint32_t)sizeof(SlabHeader), lane); wave_copy8_through(gslab + sizeof(SlabHeader), lds_slab, out_bytes - (uint32_t)sizeof(SlabHeader), lane); }
       else if (out_bytes) { wave_copy16(gslab, emat_lds_hdr, (uint32_t)sizeof(SlabHeader), lane); wave_copy16(gslab + sizeof(SlabHeader), lds_slab, out_bytes - (uint32_t)sizeof(SlabHeader), lane); }
     }
     if (again_all == 4) { wave_copy16(gslab, snap, (((const SlabHeader*)snap)->heap_top + 15u) & ~15u, lane); break; }
@@ -357,7 +361,7 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
     allow_whole = false;
   }
   if (lane == 0 && chunk < k_ticket_log) a.part_ticks[(size_t)(3 + 2 * chunk) * a.num_parts + part] = (int64_t)wall_clock64();   // ... to here
-  if (a.chunks > 1) {   // hand the part to its next ticket: the slab is in HBM again
+  if (a.chunks > 1 && !single) {   // hand the part to its next ticket: the slab is in HBM again
     __syncthreads();
     // An agent-scope release writes back every dirty line of this XCD's L2 -- among them the private-memory lines of the 500
     // other chains resident there -- once per ticket: half of a pass's HBM write traffic.  A ticket whose
@@ -895,6 +899,7 @@ struct emat_backend {
   bool cfg_taper = true;            // EMAT_TICKET_TAPER: tickets of a part shrink (10 : 6 : 3 : 1 for four tickets, else n : ... : 1) instead of being equal
   int cfg_chunks = 4;               // EMAT_CHUNKS (tuning knob): tickets per part and pass (main class; measured at C4 once a ticket's release no longer wrote the L2 back, equal tickets: 2 -> 378, 3 -> 384, 6 -> 382, 10 -> 379, 16 -> 365, 32 -> 322 M moves/s; tapered: 3 -> 390, 4 -> 392, 5 -> 388; before: 1 -> 311, 2 -> 338, 3 -> 340, 4 -> 331, 8 -> 301)
   bool cfg_ticket_spread = false;   // EMAT_TICKET_XCD_SPREAD=1 (tests): odd ticket stride, a part's tickets on different XCDs
+  int cfg_single_ticket_parts = 0;        // EMAT_SINGLE_TICKET_PARTS (tuning knob): how many of the largest main-class parts run their pass as one ticket
   bool cfg_ticket_full_release = false;   // EMAT_TICKET_RELEASE=full: agent-scope release at every hand-over
   bool cfg_chunks_forced = false;   // EMAT_CHUNKS was given: tickets also when the parts are fewer than the wave slots (tests)
   DevBuf<int32_t> d_chunk_done;
@@ -1541,6 +1546,7 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
       if (h->cfg_ticket_spread) b.class_stride = cnt | 1;
       // the cheap hand-over only where a part's tickets share an XCD: workgroups are dealt to the XCDs round robin (verified on this
       // device by probe_xcc_dealing, and re-checked by every ticket), so the stride must be a multiple of their number
+      b.single_below = (c == main_class && chunks > 1) ? std::min(h->cfg_single_ticket_parts, cnt) : 0;
       b.full_release = (h->cfg_ticket_full_release || h->xcc_count <= 0 || b.class_stride % h->xcc_count != 0) ? 1 : 0;
       const unsigned grid = b.chunks > 1 ? (unsigned)(b.chunks * b.class_stride) : (unsigned)cnt;
       const bool side = c != main_class;
@@ -1573,6 +1579,13 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
     *out = h.release();
     return EMAT_OK;
   }
+  // A pass runs on three streams at once (the main class and up to two side classes), beside whatever the host program uses -- the
+  // null stream of its blocking copies, a framework's own.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues,
+  // four by default, and two streams on one queue run one after the other: with five users, the main class ended up behind the root
+  // part's side launch in about one process in three (8 ms per synchronised pass, the 400-against-418 M moves/s "coin flip" of
+  // rounds 3 and 4; 12 of 12 runs at 417-418 M with eight queues).  The variable is read when the runtime starts, so this only helps a
+  // process whose first HIP call is ours; delphy_amd/__init__.py and bench.py set it before anything else can.
+  if (!getenv("GPU_MAX_HW_QUEUES")) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return EMAT_ERR_NO_DEVICE;
   if (cfg->device < 0 || cfg->device >= ndev) return EMAT_ERR_INVALID_ARGUMENT;
@@ -1594,6 +1607,7 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   if (const char* e = getenv("EMAT_CHUNKS")) { h->cfg_chunks = std::max(1, std::min(64, atoi(e))); h->cfg_chunks_forced = true; }
   if (const char* e = getenv("EMAT_TICKET_XCD_SPREAD")) h->cfg_ticket_spread = atoi(e) != 0;
   if (const char* e = getenv("EMAT_TICKET_RELEASE")) h->cfg_ticket_full_release = strcmp(e, "full") == 0;
+  if (const char* e = getenv("EMAT_SINGLE_TICKET_PARTS")) h->cfg_single_ticket_parts = std::max(0, atoi(e));
   if (const char* e = getenv("EMAT_PARTS_PER_CU")) h->cfg_parts_per_cu = std::max(0, std::min(4 * EMAT_WAVES_PER_EU, atoi(e)));
   if (const char* e = getenv("EMAT_ORDER_BY_TIME")) h->cfg_order_by_time = atoi(e) != 0;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return EMAT_ERR_HIP; h->num_cus = prop.multiProcessorCount; }
