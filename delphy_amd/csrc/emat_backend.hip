@@ -1581,9 +1581,9 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   }
   // A pass runs on three streams at once (the main class and up to two side classes), beside whatever the host program uses -- the
   // null stream of its blocking copies, a framework's own.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues,
-  // four by default, and two streams on one queue run one after the other: with five users, the main class ended up behind the root
-  // part's side launch in about one process in three (8 ms per synchronised pass, the 400-against-418 M moves/s "coin flip" of
-  // rounds 3 and 4; 12 of 12 runs at 417-418 M with eight queues).  The variable is read when the runtime starts, so this only helps a
+  // four by default, and two streams on one queue run one after the other: with five users, about one process in three ran every
+  // pass 0.8 ms longer than its main kernel (the 400-against-418 M moves/s "coin flip" of rounds 3 and 4); with eight queues 24 of
+  // 24 runs were at 417-418 M.  The variable is read when the runtime starts, so this only helps a
   // process whose first HIP call is ours; delphy_amd/__init__.py and bench.py set it before anything else can.
   if (!getenv("GPU_MAX_HW_QUEUES")) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
   int ndev = 0;
