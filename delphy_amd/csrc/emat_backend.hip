@@ -2354,3 +2354,4 @@ emat_status emat_last_run_ms(emat_backend* h, double* ms) {
 
 #include "emat_gtree_host.hpp"
 #include "emat_build_host.hpp"
+#include "emat_utree_host.hpp"

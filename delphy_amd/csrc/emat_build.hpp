@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
-struct BuiltTree { FlatTree tree; bool valid = false; };
+struct BuiltTree { FlatTree tree; std::vector<uint8_t> ref; bool valid = false; };   // `ref`: the sequence the tree is written against (the default builder moves it to the root's)
 
 struct BHostMut { double t; int32_t site; uint8_t from, to; };
 struct BHostNode {

@@ -170,6 +170,7 @@ emat_status build_usher_like(emat_backend* h, const emat_tip_descs& td, uint64_t
       for (auto& fs : nd.mfs) { f.mfs_site.push_back(fs.first); f.mfs_state.push_back(fs.second); }
       f.mut_offset[v + 1] = (int32_t)f.mut_site.size(); f.miss_offset[v + 1] = (int32_t)f.miss_start.size(); f.mfs_offset[v + 1] = (int32_t)f.mfs_site.size();
     }
+    h->built.ref = h->ref;
     h->built.valid = true;
     return EMAT_OK;
   }

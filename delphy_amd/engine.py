@@ -278,7 +278,7 @@ def load_library():
         "emat_part_get_sizes": [B, i32, P(i32), P(i32), P(i32), P(i32)], "emat_part_download": [B, i32, P(_FlatTreeC)],
         "emat_part_get_derived": [B, i32, P(dbl), P(i32), P(dbl), P(dbl)],
         "emat_part_get_coalescent": [B, i32, P(i32), P(dbl), P(dbl), P(dbl), P(dbl), P(i32), P(dbl), P(dbl)],
-        "emat_tree_build_usher_like": [B, P(_TipDescsC), u64], "emat_tree_built_sizes": [B, P(i32), P(i32), P(i32), P(i32)], "emat_tree_built_get": [B, P(_FlatTreeC)],
+        "emat_tree_build_usher_like": [B, P(_TipDescsC), u64], "emat_tree_build_default": [B, P(_TipDescsC), u64, P(i32)], "emat_tree_built_ref": [B, P(C.c_uint8)], "emat_tree_built_sizes": [B, P(i32), P(i32), P(i32), P(i32)], "emat_tree_built_get": [B, P(_FlatTreeC)],
         "emat_part_get_rng": [B, i32, P(u64), P(u64), P(u64), P(i32)], "emat_check_derived": [B, dbl, P(i32), P(dbl)], "emat_debug_slab_layout": [B, i32, P(C.c_uint32)],
         "emat_part_get_stats": [B, i32, P(_PartStatsC)], "emat_part_get_trace": [B, i32, P(i32), P(dbl)],
         "emat_last_run_ms": [B, P(dbl)], "emat_last_kernel_ms": [B, P(dbl), P(i32)],
@@ -740,6 +740,23 @@ class EmatBackend:
         self._ck(self._lib.emat_tree_built_get(self._h, C.byref(v)), "emat_tree_built_get")
         t.root = v.root
         return t.trimmed()
+
+    def build_default(self, tips: "TipDescs", seed: int):
+        """the reference's DEFAULT initial tree (build_initial_phylo_tree: maximum-parsimony guide tree, nearest-first
+        rebuilds, SPR refinement, regression rooting, dating) from tip descriptors (set_ref_sequence first).  Host code, as in the
+        reference: works on a device = -1 handle.  Returns (tree, ref, report): the tree is written against `ref`, the ROOT's sequence."""
+        td = tips.c_struct()
+        rep = (C.c_int32 * 4)()
+        self._ck(self._lib.emat_tree_build_default(self._h, C.byref(td), seed, rep), "emat_tree_build_default")
+        n, nm, ni, nf = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._lib.emat_tree_built_sizes(self._h, C.byref(n), C.byref(nm), C.byref(ni), C.byref(nf)), "emat_tree_built_sizes")
+        t = FlatTree.empty(n.value, nm.value, ni.value, nf.value)
+        v = t.c_view()
+        self._ck(self._lib.emat_tree_built_get(self._h, C.byref(v)), "emat_tree_built_get")
+        t.root = v.root
+        ref = np.zeros(self.num_sites, np.uint8)
+        self._ck(self._lib.emat_tree_built_ref(self._h, ref.ctypes.data_as(C.POINTER(C.c_uint8))), "emat_tree_built_ref")
+        return t.trimmed(), ref, dict(guide_deltas=rep[0], refined_deltas=rep[1], spr_deltas=rep[2], rooting="regression" if rep[3] == 0 else "midpoint")
 
     def main_class_mask(self, num_parts: int) -> np.ndarray:
         """Debugging aid: which resident parts run in the main launch (k_run_moves) rather than in a side class (k_run_moves_side)."""

@@ -420,6 +420,17 @@ emat_status emat_tree_build_usher_like(emat_backend* h, const emat_tip_descs* ti
 /* The tree it made, as a flat tree (for emat_run_create / emat_tree_upload): sizes, then the arrays. */
 emat_status emat_tree_built_sizes(emat_backend* h, int32_t* num_nodes, int32_t* num_muts, int32_t* num_intervals, int32_t* num_from_states);
 emat_status emat_tree_built_get(emat_backend* h, emat_flat_tree* out);
+/* replaces: build_initial_phylo_tree (reference core/utree.cpp:1892-1925), the reference's DEFAULT initial tree (--v0-init-method
+ * mp_plus_timing, cmdline.cpp:113-115, 437): maximum-parsimony guide tree by branch-and-bound insertion (utree.cpp:190-755), up to five
+ * rebuilds in nearest-first order (:761-914), SPR refinement of tips and subtrees (:920-1081), rooting by the least-squares regression
+ * of divergence on sampling date with the midpoint fall-back (:1085-1464), dating from the fitted rate (:1750-1890), then
+ * fix_up_missations and randomize_mutation_times.  Host code, as in the reference (no device needed: works on a device = -1 handle);
+ * same descriptors + same seed => the same tree.  The tree is written against the ROOT's sequence, as the reference's is after
+ * rereference_to_root_sequence (phylo_tree.cpp:309-322): fetch that sequence with emat_tree_built_ref and hand it on wherever the tree
+ * goes (emat_run_create, emat_set_ref_sequence + emat_tree_upload).  report (may be NULL): [0..2] site deltas in the guide tree, after
+ * the rebuilds, after SPR refinement; [3] 0 = rooted by regression, 1 = by the midpoint fall-back. */
+emat_status emat_tree_build_default(emat_backend* h, const emat_tip_descs* tips, uint64_t seed, int32_t* report /*[4]*/);
+emat_status emat_tree_built_ref(emat_backend* h, uint8_t* ref_sequence /*[num_sites]*/);
 
 /* Byte breakdown of one part's slab as the backend lays it out (works on host-only handles too): header, node records, coalescent
  * cell table, trace ring, list-heap content, list-heap capacity, scratch, and the number of cells kept. */
