@@ -187,6 +187,7 @@ struct Builder {                                                    // utree.cpp
   Sdv m_to_x; std::vector<std::pair<int32_t, uint8_t>> m_state;     // the new joint M: its deltas to the piece, and where it differs from the focus
   std::vector<std::pair<int, int>> heap; std::vector<int> ties;
   int give_up_after = 0; std::vector<int> dfs, component;
+  long long n_pops = 0, n_crossed = 0, n_searches = 0;               // (EMAT_VERBOSE: arcs the searches expanded, arcs the focus crossed)
 
   Builder(const Tips& t, HostRng& g) : tips(t), rng(g) { T.init(t.n()); T.ref = *t.ref; setup(); }
   Builder(Tree&& tree, const Tips& t, HostRng& g) : tips(t), rng(g), T(std::move(tree)) { placed = T.n_tips; setup(); }
@@ -253,11 +254,12 @@ struct Builder {                                                    // utree.cpp
   }
   void walk(int v) {                                                // the focus moves, the Fitch sets follow (:648-657)
     T.walk_focus_to(v, [&](int a) {
+      ++n_crossed;
       for (const Sd& d : T.dl[(size_t)a]) { cost_here += (int)fx.allows(d.site, d.from, d.from) - (int)fx.allows(d.site, d.to, d.from); fx.focus_changed(d.site, d.from, d.to); }
     });
   }
   std::pair<int, int> best_arc() {                                  // best-first over the arcs around the focus (:421-482)
-    int best = cost_here; ties.clear();
+    int best = cost_here; ties.clear(); ++n_searches;
     auto note = [&](int c, int a) { if (c < best) { best = c; ties.clear(); } if (c == best) ties.push_back(a); };
     heap.clear();
     const auto later = std::greater<>{};
@@ -265,7 +267,7 @@ struct Builder {                                                    // utree.cpp
     std::make_heap(heap.begin(), heap.end(), later);
     while (!heap.empty()) {
       std::pop_heap(heap.begin(), heap.end(), later);
-      const auto [c_in, a_in] = heap.back(); heap.pop_back();
+      const auto [c_in, a_in] = heap.back(); heap.pop_back(); ++n_pops;
       if (c_in > best + slack(best)) break;
       walk(T.to(a_in));
       for (int a : T.adj[(size_t)T.focus]) if (a != k_none && a != Tree::mate(a_in)) { const int c = cost_on(a); note(c, a); heap.push_back({c, a}); std::push_heap(heap.begin(), heap.end(), later); }
@@ -418,8 +420,9 @@ inline void spr_refine(Tree& tree, const Tips& tips, HostRng& rng) {   // utree.
       b.hang_subtree(X, best, M, de);
     }
     idle = best_cost - before < 0 ? 0 : idle + 1;
-    if (idle >= N) break;
+    if (idle >= N) { if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] spr_refine: stopped after %d attempts (%d without improvement)\n", attempt + 1, idle); break; }
   }
+  if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] spr_refine: %lld searches expanded %lld arcs, the focus crossed %lld arcs\n", b.n_searches, b.n_pops, b.n_crossed);
   tree = std::move(T);
 }
 

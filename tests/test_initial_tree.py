@@ -94,6 +94,66 @@ def _default_built(name, seed, **kw):
         ob.close()
 
 
+def _default_built_by_the_product(sc, seed):
+    """emat_tree_build_default (host C++ in the product) next to the oracle's restatement: same descriptors + same seed => the same tree,
+    the same root sequence, the same parsimony report.  Returns the product's scenario."""
+    ob = OracleBuild(sc.ref)
+    b = d.EmatBackend(sc.num_sites, device=-1)          # host code: no device needed
+    try:
+        tips = ob.tip_descs_of(sc.tree)
+        b.set_ref_sequence(sc.ref)
+        got, gref, grep_ = b.build_default(tips, seed)
+        want, wref, wrep = ob.build_default(tips, seed)
+        assert got.root == want.root and np.array_equal(gref, wref) and grep_ == wrep, (grep_, wrep)
+        for f in FIELDS:
+            x, y = getattr(got, f), getattr(want, f)
+            assert x.shape == y.shape and np.array_equal(x, y), "%s differs (seed %d)" % (f, seed)
+        rc, msg = ob.check(got, tips, ref=gref)
+        assert rc == 0, msg
+        return dataclasses.replace(sc, tree=got, ref=gref), tips, grep_
+    finally:
+        b.close(); ob.close()
+
+
+@pytest.mark.parametrize("name,kw,seed", [("C1", dict(num_tips=12, num_sites=300), 3), ("C1", dict(num_tips=2, num_sites=300), 1), ("C1", dict(num_tips=3, num_sites=300), 2),
+                                          ("C1", dict(num_tips=150, num_sites=30000, uncertain_tips=0.3), 4), ("C2", dict(num_tips=1610, num_sites=18959), 5),
+                                          ("C3", dict(num_tips=3000, num_sites=29903, uncertain_tips=0.1), 6), ("C4", dict(num_tips=4000), 8)])
+def test_product_default_builder_equals_the_restated_reference(name, kw, seed):
+    """SURVEY 8(f).4, the reference's default initial tree (utree.cpp) in the product: bit for bit the oracle's tree -- topology, every
+    time, every mutation, missation and from-state, the root sequence -- and the reference's closing checks of a built tree."""
+    sc2, tips, rep = _default_built_by_the_product(make_scenario(name, **kw), seed)
+    assert sc2.tree.num_nodes == 2 * tips.num_tips - 1 and np.all(sc2.tree.child0[: tips.num_tips] == -1)
+    assert rep["spr_deltas"] <= rep["refined_deltas"] <= rep["guide_deltas"]
+
+
+def test_product_default_builder_on_randomised_descriptors():
+    """Seeded random scenarios (tree size, genome length, mutation and gap density, tip-date uncertainty all vary)."""
+    import os
+    from delphy_amd.scenarios import random_scenario
+    rng = np.random.default_rng(int(os.environ.get("EMAT_FUZZ_SEED", "20261010")))
+    for case in range(int(os.environ.get("EMAT_FUZZ_CASES", "12"))):
+        sc, _, _, what = random_scenario(rng, case, max_tips=600)
+        try:
+            _default_built_by_the_product(sc, 1000 + case)
+        except AssertionError as e:
+            raise AssertionError("%s: %s" % (what, e))
+
+
+def test_product_default_builder_rejects_what_the_reference_rejects():
+    sc = make_scenario("C1", num_tips=12, num_sites=300)
+    ob = OracleBuild(sc.ref); tips = ob.tip_descs_of(sc.tree); ob.close()
+    b = d.EmatBackend(sc.num_sites, device=-1)
+    with pytest.raises(d.EmatError, match="emat_set_ref_sequence"):
+        b.build_default(tips, 1)
+    b.set_ref_sequence(sc.ref)
+    k = int(np.flatnonzero(np.diff(tips.delta_offset) > 0)[0]); j = int(tips.delta_offset[k])
+    bad = d.TipDescs(tips.t_min.copy(), tips.t_max.copy(), tips.delta_offset.copy(), tips.delta_site.copy(), tips.delta_to.copy(), tips.miss_offset.copy(), tips.miss_start.copy(), tips.miss_end.copy())
+    bad.delta_to[j] = sc.ref[tips.delta_site[j]]
+    with pytest.raises(d.EmatError, match="equal 'from' and 'to'"):
+        b.build_default(bad, 1)
+    b.close()
+
+
 def test_the_references_default_builder_restated():
     """oracle/orc_utree.hpp (guide tree -> refinement rounds -> SPR refinement -> OLS rooting -> phylo tree; pinned to the reference's
     tests/utree_tests.cpp by oracle/orc_tests) on the tip descriptors of scenario trees: the reference's closing checks of a built
@@ -111,10 +171,11 @@ def test_the_references_default_builder_restated():
 
 @pytest.mark.gpu
 def test_chains_started_from_the_default_builders_tree():
-    """The reference starts a run from build_initial_phylo_tree's tree (cmdline.cpp:437); the local-move path on that starting state:
+    """The reference starts a run from build_initial_phylo_tree's tree (cmdline.cpp:437) -- here emat_tree_build_default's, equal to the
+    oracle's; the local-move path on that starting state:
     derived quantities and the chains of every part, device against oracle, like test_parity_gpu's cases on simulated trees."""
     from helpers import run_parity
-    sc, tips, tree, rep = _default_built("C2", 9, num_tips=700, num_sites=18959)
+    sc, tips, rep = _default_built_by_the_product(make_scenario("C2", num_tips=700, num_sites=18959), 9)
     run_parity(sc, num_parts=12, moves_per_part=3000, seed=5, trace=300)
 
 
