@@ -178,6 +178,20 @@ struct Fitch {
     return state == focus_state;
   }
   void focus_changed(int site, uint8_t was, uint8_t is) { if (b_iv_contains(any, site) || mask_at(site)) return; sd_first(fixed, site, is, was); }   // (pop_front of was -> is)
+  // The same sets in ABSOLUTE terms, frozen when they are set up: where the piece's state is known (`fixed` as it was then: its `to`
+  // states), else the state of the node that was the focus then (`then_focus`: that node's deltas against the reference sequence), else
+  // the reference sequence.  With these a search can price every arc it expands from where the focus stands, instead of walking the
+  // focus to each arc in best-first order as the reference does (at 30 000 tips the focus crossed 3.8 arcs per arc expanded): the
+  // costs, the order of expansion and the list of ties are the same numbers in the same order.
+  Sdv then_fixed, then_focus;
+  void freeze(const Sdv& ref_to_focus) { then_fixed = fixed; then_focus = ref_to_focus; }
+  bool allows_abs(int site, uint8_t state, const std::vector<uint8_t>& ref) const {
+    if (b_iv_contains(any, site)) return true;
+    if (const uint8_t* m = mask_at(site)) return (*m >> state) & 1;
+    if (const Sd* d = sd_find(then_fixed, site)) return state == d->to;
+    if (const Sd* d = sd_find(then_focus, site)) return state == d->to;
+    return state == ref[(size_t)site];
+  }
 };
 
 struct Builder {                                                    // utree.cpp:190-739
@@ -185,7 +199,7 @@ struct Builder {                                                    // utree.cpp
   int placed = 0, L = 0; double sqrt_6L = 0.0;
   Fitch fx; int cost_here = 0;                                       // ... and what attaching AT the focus would cost
   Sdv m_to_x; std::vector<std::pair<int32_t, uint8_t>> m_state;     // the new joint M: its deltas to the piece, and where it differs from the focus
-  std::vector<std::pair<int, int>> heap; std::vector<int> ties;
+  std::vector<std::pair<int, int>> heap; std::vector<int> ties, cost_at;
   int give_up_after = 0; std::vector<int> dfs, component;
   long long n_pops = 0, n_crossed = 0, n_searches = 0;               // (EMAT_VERBOSE: arcs the searches expanded, arcs the focus crossed)
 
@@ -225,6 +239,7 @@ struct Builder {                                                    // utree.cpp
     for (int k = 0; k < tips.n_deltas(X); ++k) fx.fixed.push_back(tips.delta(X, k));
     for (const Sd& d : T.ref_to_focus) if (!b_iv_contains(fx.any, d.site)) sd_first(fx.fixed, d.site, d.to, d.from);
     cost_here = (int)fx.fixed.size();
+    fx.freeze(T.ref_to_focus);
   }
   void fitch_of_subtree(int X) {                                    // :351-415: the focus is X's neighbour M; X's other neighbours D, E
     fx.clear(); cost_here = 0;
@@ -246,6 +261,7 @@ struct Builder {                                                    // utree.cpp
       if (no_d || no_e || t.d == t.e) { const uint8_t f = no_d ? t.e : t.d; if (t.m != f) { fx.fixed.push_back(Sd{t.site, t.m, f}); ++cost_here; } }
       else { fx.open.push_back({t.site, (uint8_t)((1u << t.d) | (1u << t.e))}); if (t.m != t.d && t.m != t.e) ++cost_here; }
     }
+    fx.freeze(T.ref_to_focus);
   }
   int cost_on(int a) const {                                        // attaching in the middle of focal arc a (:708-718)
     int saved = 0;
@@ -258,19 +274,25 @@ struct Builder {                                                    // utree.cpp
       for (const Sd& d : T.dl[(size_t)a]) { cost_here += (int)fx.allows(d.site, d.from, d.from) - (int)fx.allows(d.site, d.to, d.from); fx.focus_changed(d.site, d.from, d.to); }
     });
   }
-  std::pair<int, int> best_arc() {                                  // best-first over the arcs around the focus (:421-482)
+  std::pair<int, int> best_arc() {                                  // best-first over the arcs around the focus (:421-482); the focus stays where it is
     int best = cost_here; ties.clear(); ++n_searches;
     auto note = [&](int c, int a) { if (c < best) { best = c; ties.clear(); } if (c == best) ties.push_back(a); };
+    auto saved_on = [&](int a) { int k = 0; for (const Sd& d : T.dl[(size_t)a]) if (!fx.allows_abs(d.site, d.from, T.ref) && fx.allows_abs(d.site, d.to, T.ref)) ++k; return k; };
+    if (cost_at.size() < T.adj.size()) cost_at.resize(T.adj.size());   // what attaching AT a node would cost, for the nodes the search has reached (a tree: each once)
     heap.clear();
     const auto later = std::greater<>{};
-    for (int a : T.adj[(size_t)T.focus]) if (a != k_none) { const int c = cost_on(a); note(c, a); heap.push_back({c, a}); }
+    cost_at[(size_t)T.focus] = cost_here;
+    for (int a : T.adj[(size_t)T.focus]) if (a != k_none) { const int c = cost_here - saved_on(a); note(c, a); heap.push_back({c, a}); }
     std::make_heap(heap.begin(), heap.end(), later);
     while (!heap.empty()) {
       std::pop_heap(heap.begin(), heap.end(), later);
       const auto [c_in, a_in] = heap.back(); heap.pop_back(); ++n_pops;
       if (c_in > best + slack(best)) break;
-      walk(T.to(a_in));
-      for (int a : T.adj[(size_t)T.focus]) if (a != k_none && a != Tree::mate(a_in)) { const int c = cost_on(a); note(c, a); heap.push_back({c, a}); std::push_heap(heap.begin(), heap.end(), later); }
+      int c_v = cost_at[(size_t)T.from(a_in)];
+      for (const Sd& d : T.dl[(size_t)a_in]) c_v += (int)fx.allows_abs(d.site, d.from, T.ref) - (int)fx.allows_abs(d.site, d.to, T.ref);
+      const int v = T.to(a_in);
+      cost_at[(size_t)v] = c_v;
+      for (int a : T.adj[(size_t)v]) if (a != k_none && a != Tree::mate(a_in)) { const int c = c_v - saved_on(a); note(c, a); heap.push_back({c, a}); std::push_heap(heap.begin(), heap.end(), later); }
     }
     if (ties.empty()) return {k_none, best};
     return {ties[(size_t)(((unsigned __int128)rng.next64() * (uint64_t)ties.size()) >> 64)], best};
