@@ -40,10 +40,10 @@ for san in "address,undefined" "thread"; do
   LD_PRELOAD=$PRE ASAN_OPTIONS=detect_leaks=0 TSAN_OPTIONS="report_signal_unsafe=0" EMAT_HOST_THREADS=8 EMAT_LIB_PATH=$W/libemat_san.so python3 $W/drive.py 2>&1 | grep -E "ERROR|WARNING: ThreadSanitizer|runtime error|host driver" | sort | uniq -c
 done
 # the whole library (C-ABI, slab encode / decode, coalescent-part builder) with HOST-side ASan, through the CPU tests that
-# use host-only handles; the device code is compiled without instrumentation
+# use host-only handles (the default initial-tree builder among them: host code throughout); the device code is compiled without instrumentation
 echo "== hipcc -fsanitize=address -fno-gpu-sanitize (host code of libemat_hip.so), CPU tests"
 hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -ffp-contract=off -fPIC -fsanitize=address -fno-gpu-sanitize -shared-libsan -Wno-unused-function -Wno-unused-result \
-      -shared -o $W/libemat_hip_asan.so $ROOT/delphy_amd/csrc/emat_backend.hip $ROOT/delphy_amd/csrc/emat_run.cpp $ROOT/delphy_amd/csrc/emat_dphy.cpp
+      -shared -o $W/libemat_hip_asan.so $ROOT/delphy_amd/csrc/emat_backend.hip $ROOT/delphy_amd/csrc/emat_run.cpp $ROOT/delphy_amd/csrc/emat_dphy.cpp $ROOT/delphy_amd/csrc/emat_multi.cpp -ldl
 RT=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.asan-x86_64.so)
-(cd $ROOT && LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0 EMAT_LIB_PATH=$W/libemat_hip_asan.so python3 -m pytest tests/test_host_driver.py tests/test_abi.py tests/test_dphy_writer.py -x -q -m "not gpu" 2>&1 | grep -E "AddressSanitizer|passed|failed")
+(cd $ROOT && LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0 EMAT_LIB_PATH=$W/libemat_hip_asan.so python3 -m pytest tests/test_host_driver.py tests/test_abi.py tests/test_dphy_writer.py tests/test_list_limits.py tests/test_initial_tree.py -x -q -m "not gpu" 2>&1 | grep -E "AddressSanitizer|passed|failed")
 rm -rf $W
