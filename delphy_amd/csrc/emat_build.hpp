@@ -511,8 +511,13 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
           } else if (grafter) { for (int j = 0; j < T && !full; ++j) { if (!b_push_front(s_sd, nsd, (uint32_t)k_g_sd, s_pm[j].site, s_pm[j].to, s_pm[j].from, bad)) full = true; } }
         } else if (grafter) {
           for (int k = 0; k < dxn; ++k) { b.sd[k].site = b.d_site[dx0 + k]; b.sd[k].from = b.ref[b.d_site[dx0 + k]]; b.sd[k].to = b.d_to[dx0 + k]; b.sd[k].pad = 0; }
+          // root first.  (The path, graft point first, is in s_path when it was FOUND -- np <= k_g_path -- and in b.path when it had to be
+          // walked: until round 4's fuzz hunt this loop read b.path either way, i.e. stale nodes whenever a path that fitted the staging
+          // area met a tip whose deltas + path mutations did not: a tip with 537 deltas, seed 777001 case 4.)
+          const bool path_in_lds = np <= k_g_path;
           for (int i = np - 1; i >= 0 && !full; --i) {
-            const MutRec* m = b.pool + b.ml_off[b.path[i]]; const int nm = b.ml_cnt[b.path[i]];
+            const int pv = path_in_lds ? s_path[i] : b.path[i];
+            const MutRec* m = b.pool + b.ml_off[pv]; const int nm = b.ml_cnt[pv];
             for (int k = 0; k < nm; ++k) if (t_root <= m[k].t && m[k].t <= t_P) { if (!b_push_front(b.sd, nsd, b.sd_cap, m[k].site, m[k].to, m[k].from, bad)) { full = true; break; } }
           }
         }
