@@ -100,8 +100,17 @@ __device__ inline bool b_push_front(BDelta* sd, int& n, uint32_t cap, int site, 
 }
 
 constexpr int k_build_threads = 1024;
-constexpr int k_x_deltas = 2048, k_x_miss = 256;                  // the new tip's descriptor held in LDS by every workgroup
-constexpr int k_g_sd = 1024, k_g_pm = 1536, k_g_path = 1024;   // LDS staging of the graft step: site deltas, path mutations / X's new mutations, path nodes
+// LDS staging: the new tip's descriptor (every workgroup), and for the graft step site deltas, path mutations / X's new mutations, path
+// nodes.  Inputs that outgrow an area take the same steps on buffers in HBM.  -DEMAT_BUILD_TINY_STAGING shrinks the areas so that
+// ordinary test inputs take every one of those fall-backs (scripts/build_variant.sh tiny_staging -DEMAT_BUILD_TINY_STAGING; the
+// builder's parity tests must pass on it unchanged).
+#ifdef EMAT_BUILD_TINY_STAGING
+constexpr int k_x_deltas = 4, k_x_miss = 1;
+constexpr int k_g_sd = 24, k_g_pm = 40, k_g_path = 8;
+#else
+constexpr int k_x_deltas = 2048, k_x_miss = 256;
+constexpr int k_g_sd = 1024, k_g_pm = 1536, k_g_path = 1024;
+#endif
 
 
 // Inclusive sum over the 1 024 threads of a workgroup: a shuffle scan inside every wavefront, the sixteen wave totals scanned by
@@ -446,7 +455,7 @@ __global__ void __launch_bounds__(k_build_threads) k_build_usher_graft(BuildDev 
           __syncthreads();
           sd = s_sd;
           const int T = s_gi[6];
-          if (T > 0 && T <= 1024 && dxn < 1024 && b.L < (1 << 22)) {
+          if (T > 0 && T <= 1024 && dxn < 1024 && T < k_g_path && dxn < k_g_path && b.L < (1 << 22)) {   // (keys and ranks live in s_len, s_path and s_pcnt)
             // What a run of push_front calls leaves at a site depends on that site's entry and on its own mutations, in path order,
             // alone: the sites are independent.  So: sort the path's mutations by (site, place on the path) -- a bitonic sort
             // in LDS --, let one thread per site run that site's calls (the same operations in the same order as the one-by-one
