@@ -199,7 +199,7 @@ struct Builder {                                                    // utree.cpp
   int placed = 0, L = 0; double sqrt_6L = 0.0;
   Fitch fx; int cost_here = 0;                                       // ... and what attaching AT the focus would cost
   Sdv m_to_x; std::vector<std::pair<int32_t, uint8_t>> m_state;     // the new joint M: its deltas to the piece, and where it differs from the focus
-  std::vector<std::pair<int, int>> heap; std::vector<int> ties, cost_at;
+  std::vector<uint64_t> heap64; std::vector<int> ties, cost_at, across;
   int give_up_after = 0; std::vector<int> dfs, component;
   long long n_pops = 0, n_crossed = 0, n_searches = 0;               // (EMAT_VERBOSE: arcs the searches expanded, arcs the focus crossed)
 
@@ -277,22 +277,34 @@ struct Builder {                                                    // utree.cpp
   std::pair<int, int> best_arc() {                                  // best-first over the arcs around the focus (:421-482); the focus stays where it is
     int best = cost_here; ties.clear(); ++n_searches;
     auto note = [&](int c, int a) { if (c < best) { best = c; ties.clear(); } if (c == best) ties.push_back(a); };
-    auto saved_on = [&](int a) { int k = 0; for (const Sd& d : T.dl[(size_t)a]) if (!fx.allows_abs(d.site, d.from, T.ref) && fx.allows_abs(d.site, d.to, T.ref)) ++k; return k; };
+    // one look at an arc's deltas gives both what attaching on it would save and how the cost changes across it (kept for when the arc
+    // is expanded); most arcs of a large tree carry no delta at all
+    auto price = [&](int a, int c_origin) {
+      int saved = 0, shift = 0;
+      for (const Sd& d : T.dl[(size_t)a]) { const bool f = fx.allows_abs(d.site, d.from, T.ref), t = fx.allows_abs(d.site, d.to, T.ref); saved += (!f && t); shift += (int)f - (int)t; }
+      across[(size_t)a] = shift;
+      return c_origin - saved;
+    };
     if (cost_at.size() < T.adj.size()) cost_at.resize(T.adj.size());   // what attaching AT a node would cost, for the nodes the search has reached (a tree: each once)
-    heap.clear();
-    const auto later = std::greater<>{};
+    if (across.size() < T.tgt.size()) across.resize(T.tgt.size());
+    // the queue: (cost, arc) pairs in ascending order, as the reference's heap of pairs pops them -- every arc enters once, so the order of
+    // popping is the order of the keys whatever the container: one 64-bit key per entry
+    constexpr int64_t k_bias = 1 << 20;
+    auto key = [&](int c, int a) { return (uint64_t)((int64_t)c + k_bias) << 32 | (uint32_t)a; };
+    heap64.clear();
+    const auto later = std::greater<uint64_t>{};
     cost_at[(size_t)T.focus] = cost_here;
-    for (int a : T.adj[(size_t)T.focus]) if (a != k_none) { const int c = cost_here - saved_on(a); note(c, a); heap.push_back({c, a}); }
-    std::make_heap(heap.begin(), heap.end(), later);
-    while (!heap.empty()) {
-      std::pop_heap(heap.begin(), heap.end(), later);
-      const auto [c_in, a_in] = heap.back(); heap.pop_back(); ++n_pops;
+    for (int a : T.adj[(size_t)T.focus]) if (a != k_none) { const int c = price(a, cost_here); note(c, a); heap64.push_back(key(c, a)); }
+    std::make_heap(heap64.begin(), heap64.end(), later);
+    while (!heap64.empty()) {
+      std::pop_heap(heap64.begin(), heap64.end(), later);
+      const uint64_t top = heap64.back(); heap64.pop_back(); ++n_pops;
+      const int c_in = (int)((int64_t)(top >> 32) - k_bias), a_in = (int)(uint32_t)top;
       if (c_in > best + slack(best)) break;
-      int c_v = cost_at[(size_t)T.from(a_in)];
-      for (const Sd& d : T.dl[(size_t)a_in]) c_v += (int)fx.allows_abs(d.site, d.from, T.ref) - (int)fx.allows_abs(d.site, d.to, T.ref);
+      const int c_v = cost_at[(size_t)T.from(a_in)] + across[(size_t)a_in];
       const int v = T.to(a_in);
       cost_at[(size_t)v] = c_v;
-      for (int a : T.adj[(size_t)v]) if (a != k_none && a != Tree::mate(a_in)) { const int c = c_v - saved_on(a); note(c, a); heap.push_back({c, a}); std::push_heap(heap.begin(), heap.end(), later); }
+      for (int a : T.adj[(size_t)v]) if (a != k_none && a != Tree::mate(a_in)) { const int c = price(a, c_v); note(c, a); heap64.push_back(key(c, a)); std::push_heap(heap64.begin(), heap64.end(), later); }
     }
     if (ties.empty()) return {k_none, best};
     return {ties[(size_t)(((unsigned __int128)rng.next64() * (uint64_t)ties.size()) >> 64)], best};
