@@ -110,4 +110,6 @@ if __name__ == "__main__":
         worst = max(worst, max(abs(v) for v in z.values()))
         print("    parts %5d: " % cfg["parts"] + "  ".join("%s %+.2f" % (k, v) for k, v in z.items()))
     out["worst_abs_z"] = worst
+    import delphy_amd as d
+    out["emat_build_id"] = d.library_build_id()       # which device code sampled these chains (bench.py marks the block stale when it differs)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "posterior_check.json"), "w"), indent=1)
