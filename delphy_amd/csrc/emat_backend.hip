@@ -1585,7 +1585,7 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   // pass 0.8 ms longer than its main kernel (the 400-against-418 M moves/s "coin flip" of rounds 3 and 4); with eight queues 24 of
   // 24 runs were at 417-418 M.  The variable is read when the runtime starts, so this only helps a
   // process whose first HIP call is ours; delphy_amd/__init__.py and bench.py set it before anything else can.
-  if (!getenv("GPU_MAX_HW_QUEUES")) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  { static std::once_flag once; std::call_once(once, [] { if (!getenv("GPU_MAX_HW_QUEUES")) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }); }   // (once per process: setenv is not for concurrent use)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return EMAT_ERR_NO_DEVICE;
   if (cfg->device < 0 || cfg->device >= ndev) return EMAT_ERR_INVALID_ARGUMENT;

@@ -21,7 +21,41 @@ namespace {
 namespace ut {
 
 struct Sd { int32_t site; uint8_t from, to; };                       // one site's change
-using Sdv = std::vector<Sd>;                                          // ascending site, one entry per site
+// A list of them, ascending site, one entry per site.  Up to two entries live in the object itself: nine arcs in ten of a large tree
+// carry at most two deltas, and a search that expands thousands of arcs per placement is bound by the cache misses of reaching them
+// (24 bytes per arc, mates side by side, instead of a vector header that points somewhere else).
+class Sdv {
+  static constexpr uint32_t k_in = 2;
+  union { Sd in_[k_in]; Sd* out_; };
+  uint32_t n_ = 0, cap_ = k_in;
+  Sd* data_() { return cap_ > k_in ? out_ : in_; }
+  const Sd* data_() const { return cap_ > k_in ? out_ : in_; }
+  void grow_(uint32_t want) {
+    if (want <= cap_) return;
+    uint32_t nc = cap_ * 2 > want ? cap_ * 2 : want;
+    Sd* np = (Sd*)std::malloc(sizeof(Sd) * nc);
+    if (!np) throw std::bad_alloc();
+    std::memcpy(np, data_(), sizeof(Sd) * n_);
+    if (cap_ > k_in) std::free(out_);
+    out_ = np; cap_ = nc;
+  }
+ public:
+  using iterator = Sd*; using const_iterator = const Sd*;
+  Sdv() {}
+  Sdv(const Sdv& o) { grow_(o.n_); std::memcpy(data_(), o.data_(), sizeof(Sd) * o.n_); n_ = o.n_; }
+  Sdv(Sdv&& o) noexcept { std::memcpy((void*)this, (const void*)&o, sizeof(Sdv)); o.n_ = 0; o.cap_ = k_in; }
+  Sdv& operator=(const Sdv& o) { if (this != &o) { n_ = 0; grow_(o.n_); std::memcpy(data_(), o.data_(), sizeof(Sd) * o.n_); n_ = o.n_; } return *this; }
+  Sdv& operator=(Sdv&& o) noexcept { if (this != &o) { if (cap_ > k_in) std::free(out_); std::memcpy((void*)this, (const void*)&o, sizeof(Sdv)); o.n_ = 0; o.cap_ = k_in; } return *this; }
+  ~Sdv() { if (cap_ > k_in) std::free(out_); }
+  iterator begin() { return data_(); } iterator end() { return data_() + n_; }
+  const_iterator begin() const { return data_(); } const_iterator end() const { return data_() + n_; }
+  size_t size() const { return n_; } bool empty() const { return n_ == 0; }
+  void clear() { n_ = 0; }
+  void push_back(const Sd& d) { grow_(n_ + 1); data_()[n_++] = d; }
+  iterator insert(iterator pos, const Sd& d) { const size_t k = (size_t)(pos - data_()); grow_(n_ + 1); Sd* p = data_(); std::memmove(p + k + 1, p + k, sizeof(Sd) * (n_ - k)); p[k] = d; ++n_; return p + k; }
+  iterator erase(iterator pos) { Sd* p = data_(); const size_t k = (size_t)(pos - p); std::memmove(p + k, p + k + 1, sizeof(Sd) * (n_ - k - 1)); --n_; return p + k; }
+};
+static_assert(sizeof(Sdv) == 24, "an arc's deltas: 24 bytes");
 inline Sdv::iterator sd_at(Sdv& v, int site) { return std::lower_bound(v.begin(), v.end(), site, [](const Sd& d, int s) { return d.site < s; }); }
 inline Sdv::const_iterator sd_at(const Sdv& v, int site) { return std::lower_bound(v.begin(), v.end(), site, [](const Sd& d, int s) { return d.site < s; }); }
 inline const Sd* sd_find(const Sdv& v, int site) { auto it = sd_at(v, site); return it != v.end() && it->site == site ? &*it : nullptr; }
