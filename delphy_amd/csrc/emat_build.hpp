@@ -6,14 +6,18 @@
 // loop O(tips x nodes): that loop runs on the device.  What the scan computes for a region (branch b, segment between its
 // mutations) is the number of sites at which the sequence there differs from the new tip's, over the sites the tip has; that
 // number changes by -1 / 0 / +1 per mutation crossed, so for a whole tree it is a per-branch sum (all nodes side by side)
-// followed by a prefix sum down the tree -- pointer jumping, log2(depth) rounds -- instead of the reference's depth-first walk
-// with a hash map.  The walk's ORDER matters as well (among the regions that tie for the minimum the reference picks by
-// cumulative length in visiting order, a floating-point sum): the visiting order is the pre-order with the second child first
-// and a branch's segments in time order, so a node's position is again a prefix sum down the tree (1 + the size of the sibling
-// subtree that is visited before it), computed by the same pointer jumping; the tying regions are then laid out in that order
-// by a block-wide scan, and ONE thread adds their lengths in order, draws, and makes the graft (three nodes change).
-// One launch runs the whole loop without returning to the host: up to one workgroup of 1 024 threads per CU, all resident,
-// meeting at a barrier of their own between the phases of a tip (a counter in HBM that only grows; about twenty meetings per tip).
+// followed by a prefix sum down the tree, instead of the reference's depth-first walk with a hash map.  The walk's ORDER matters as
+// well (among the regions that tie for the minimum the reference picks by cumulative length in visiting order, a floating-point
+// sum): the visiting order is the pre-order with the second child first and a branch's segments in time order.  Every node's place in
+// that order and the size of its subtree are KEPT from tip to tip (a graft inserts two places and enlarges its ancestors, which every
+// node applies to itself from a five-word record of the graft); a subtree is then a stretch of places, so the per-branch changes go
+// into a difference array over the places (+d where the subtree starts, -d where it ends) and ONE prefix scan gives every node its
+// distance.  (Until round 4: two prefix sums down the tree by pointer jumping, log2(depth) rounds with a meeting each, per tip.)
+// The tying regions are laid out in visiting order by a second scan, and the first workgroup -- one deciding thread, the others
+// staging its inputs in LDS and doing what is parallel: the path to the root found by interval containment, the composition of
+// the deltas site by site -- adds their lengths in order, draws, and makes the graft (three nodes change).
+// One cooperative launch runs the whole loop without returning to the host: up to one workgroup of 1 024 threads per four CUs, all
+// resident, meeting seven times per tip at a barrier of their own (BGrid::sync: one release and one acquire per workgroup).
 //
 // The O(nodes) passes after the loop -- fix_up_missations (phylo_tree.cpp:414-507), pseudo_date (dates.cpp:63-82),
 // randomize_mutation_times (phylo_tree.cpp:567-644) -- are host C++ below: they run once, like the partitioning the reference
