@@ -273,9 +273,6 @@ def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
-    # three streams of the engine + torch's + the null stream: more than the HIP runtime's default of four hardware queues (DESIGN.md
-    # section 8, round 4); read when the runtime starts, i.e. before torch's first GPU call below
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -5,13 +5,7 @@ include/emat_host.h); this package is the Python host-side mirror of that interf
 bench.py, __graft_entry__.py and the tests.  There is no CPU fallback: constructing an `EmatBackend`
 without the built library or without a HIP device raises.
 """
-import os as _os
-
-# A pass uses three HIP streams at once beside the host program's own; the runtime's default of four hardware queues makes two of
-# them share one in about one process in three (DESIGN.md section 8, round 4).  Read when the HIP runtime starts: set it before then.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-from .engine import (  # noqa: F401,E402
+from .engine import (  # noqa: F401
     EmatBackend,
     EmatError,
     EmatMultiRun,

@@ -98,6 +98,7 @@ struct KernelArgs {
   // ticket c of a part starts when ticket c - 1 has written the slab back (chunk_done[part] == c).  Shorter tickets pack the
   // slots better at the end of a pass; the chain -- one RNG stream per part, state in the slab -- is the same chain.
   int32_t chunks, class_count, class_stride, taper;
+  int32_t* side_started;          // side classes of a synchronised pass: every workgroup counts itself in as it starts (k_wait_side_start), else nullptr
   int32_t single_below;           // the first `single_below` slots of the launch order (the parts expected to run longest) do their whole pass in ONE ticket, from the start of the pass: longest jobs first and unsplit, the many short chains -- in tickets -- fill in around them
   int32_t full_release;           // EMAT_TICKET_RELEASE=full: every ticket hands its part over with an agent-scope RELEASE (the path that needs no assumption about where workgroups run)
   int32_t cum_w[8];               // cumulative ticket weights (EMAT_TICKET_WEIGHTS) or zeros
@@ -183,6 +184,7 @@ __global__ void k_probe_xcc(int32_t* out) { if (threadIdx.x == 0) out[blockIdx.x
 
 template <bool kSide> __device__ __forceinline__ void run_moves_body(const KernelArgs& a) {
   const int lane = threadIdx.x;
+  if (kSide && a.side_started != nullptr && lane == 0) __hip_atomic_fetch_add(a.side_started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident: the main class may come
   double* lds_tables = (double*)emat_lds_tables;
   const bool tables_staged = stage_tables(a, lds_tables, lane) != nullptr;
   uint8_t* lds_slab = emat_lds;
@@ -377,6 +379,19 @@ __global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY EMAT_NOTAIL k_run_moves
 // Same body under another name for the side launches of the size classes (the "giants", §4 of DESIGN.md), so that
 // profiles keep the statistics of the main launch -- the one bench.py's roofline is about -- apart.
 __global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY EMAT_NOTAIL k_run_moves_side(KernelArgs a) { run_moves_body<true>(a); }
+// A side class holds a few workgroups of tens of KB of LDS each -- the root part's wants most of a CU -- and the main class 30 000 of
+// ten KB: once the main class is on the device a large workgroup only fits when a CU happens to drain, which is at the tail of the
+// pass.  Launch order alone does not settle who is placed first (two streams, two queues: a race the side classes lost in one process
+// in three, rocprofv3 --kernel-trace: root part's kernel 27 ms instead of 9 in the first pass); and a side class that starts at the
+// tail of a pass ends in the next one, starts again at ITS tail, and so on: every later pass of that process carries the lag, which the
+// final synchronisation then waits for (0.9 ms per pass over ten passes -- the 400-against-418 M moves/s coin flip of rounds 3 and 4).
+// So on a synchronised pass the engine's stream holds the main class back until every side workgroup has reported itself resident:
+// microseconds on an idle device, and bounded (2 ms of the 100 MHz counter) in case something else holds the CUs.
+__global__ void k_wait_side_start(const int32_t* started, int32_t expected) {
+  if (threadIdx.x != 0) return;
+  const uint64_t w0 = wall_clock64();
+  while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected && wall_clock64() - w0 < 200000ull) __builtin_amdgcn_s_sleep(8);
+}
 
 // ---- sufficient statistics of the global moves (calc_Ttwiddle_beta_a phylo_tree_calc.cpp:288-369, calc_num_muts_beta_ab
 //      :599-610, calc_num_muts :577-585), one part per workgroup ---------------------------------------------------------
@@ -902,7 +917,7 @@ struct emat_backend {
   int cfg_single_ticket_parts = 0;        // EMAT_SINGLE_TICKET_PARTS (tuning knob): how many of the largest main-class parts run their pass as one ticket
   bool cfg_ticket_full_release = false;   // EMAT_TICKET_RELEASE=full: agent-scope release at every hand-over
   bool cfg_chunks_forced = false;   // EMAT_CHUNKS was given: tickets also when the parts are fewer than the wave slots (tests)
-  DevBuf<int32_t> d_chunk_done;
+  DevBuf<int32_t> d_chunk_done, d_side_started;
   int cfg_parts_per_cu = 0;         // EMAT_PARTS_PER_CU (tuning knob): workgroups of the main class per CU, instead of the percentile rule
   bool cfg_gt_host_coal = false;    // EMAT_TREE_HOST_COALESCENT=1: emat_tree_repartition builds the coalescent tables on the host (bit-identical to the host cycle; tests)
 
@@ -1526,6 +1541,10 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
     const int main_count = h->class_begin[h->num_classes] - h->class_begin[h->num_classes - 1];
     const int chunks = (counts == nullptr && per_part >= 4 * h->cfg_chunks && (h->cfg_chunks_forced || main_count > 4 * EMAT_WAVES_PER_EU * h->num_cus)) ? h->cfg_chunks : 1;
     if (chunks > 1) { HIP_TRY(h->d_chunk_done.alloc(h->parts.size() + 130)); HIP_TRY(hipMemsetAsync(h->d_chunk_done.p, 0, (h->parts.size() + 130) * sizeof(int32_t), h->stream)); }   // + 64 eight-byte counters of waiting time
+    // (the counter the side workgroups of a synchronised pass report to, zeroed before the event the side streams wait for)
+    int side_wgs = 0; for (int c = 0; c + 1 < h->num_classes; ++c) side_wgs += h->class_begin[c + 1] - h->class_begin[c];
+    const bool hold_main = h->sides_must_fork && side_wgs > 0;
+    if (hold_main) { HIP_TRY(h->d_side_started.alloc(1)); HIP_TRY(hipMemsetAsync(h->d_side_started.p, 0, sizeof(int32_t), h->stream)); }
     HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
     for (int c = 0; c < h->num_classes; ++c) {
       const int lo = h->class_begin[c], cnt = h->class_begin[c + 1] - lo;
@@ -1552,6 +1571,8 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
       const bool side = c != main_class;
       hipStream_t sm = side ? h->class_stream[c + 1] : h->stream;
       if (side && h->sides_must_fork) HIP_TRY(hipStreamWaitEvent(sm, h->ev_fork, 0));
+      b.side_started = (side && hold_main) ? h->d_side_started.p : nullptr;
+      if (c == main_class && hold_main) { hipLaunchKernelGGL(k_wait_side_start, dim3(1), dim3(64), 0, sm, h->d_side_started.p, side_wgs); HIP_TRY(hipGetLastError()); }
       if (c == main_class) hipLaunchKernelGGL(k_run_moves, dim3(grid), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
       else hipLaunchKernelGGL(k_run_moves_side, dim3(grid), dim3(k_wave), shmem_for(h->class_lds[c]), sm, b);
       HIP_TRY(hipGetLastError());
@@ -1579,13 +1600,6 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
     *out = h.release();
     return EMAT_OK;
   }
-  // A pass runs on three streams at once (the main class and up to two side classes), beside whatever the host program uses -- the
-  // null stream of its blocking copies, a framework's own.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues,
-  // four by default, and two streams on one queue run one after the other: with five users, about one process in three ran every
-  // pass 0.8 ms longer than its main kernel (the 400-against-418 M moves/s "coin flip" of rounds 3 and 4); with eight queues 24 of
-  // 24 runs were at 417-418 M.  The variable is read when the runtime starts, so this only helps a
-  // process whose first HIP call is ours; delphy_amd/__init__.py and bench.py set it before anything else can.
-  { static std::once_flag once; std::call_once(once, [] { if (!getenv("GPU_MAX_HW_QUEUES")) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }); }   // (once per process: setenv is not for concurrent use)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return EMAT_ERR_NO_DEVICE;
   if (cfg->device < 0 || cfg->device >= ndev) return EMAT_ERR_INVALID_ARGUMENT;
