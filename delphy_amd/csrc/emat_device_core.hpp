@@ -37,9 +37,22 @@ namespace emat {
 extern __shared__ __attribute__((aligned(16))) uint8_t emat_lds[];
 constexpr uint32_t k_lds_tables_bytes = k_max_lds_partitions * (1 + 4 + 16) * 8;   // mu, pi, q per site partition
 constexpr uint32_t k_lds_ctx_bytes = 288;
-constexpr uint32_t k_lds_static_bytes = k_lds_tables_bytes + k_lds_ctx_bytes;      // what every k_run_moves workgroup holds besides the slab image and the arena
+// The chain's random numbers come from a counter-based generator, so its NEXT blocks can be computed before they are wanted -- and by
+// lanes the chain does not use: whenever the chain is about to run out, the wave's other lanes compute the Philox blocks of the next
+// k_rng_blocks counters side by side (one block, two 64-bit draws, per lane) into this array, and the chain's draws become a 16-byte LDS
+// read instead of ten rounds of 32 x 32 -> 64 multiplies on the scalar unit (a third of a simple move's scalar instructions; inlined
+// at every draw, also a good part of the code the instruction cache has to hold).  Same counters, same numbers, same order.
+// 0 switches it off (every draw computes its block).
+#ifndef EMAT_RNG_BLOCKS
+#define EMAT_RNG_BLOCKS 32
+#endif
+constexpr uint32_t k_rng_blocks = EMAT_RNG_BLOCKS;
+static_assert(k_rng_blocks == 0 || (k_rng_blocks <= 64 && (k_rng_blocks & (k_rng_blocks - 1)) == 0), "one block per lane, a power of two");
+constexpr uint32_t k_lds_rng_bytes = k_rng_blocks * 16;
+constexpr uint32_t k_lds_static_bytes = k_lds_tables_bytes + k_lds_ctx_bytes + k_lds_rng_bytes;      // what every k_run_moves workgroup holds besides the slab image and the arena
 __shared__ __attribute__((aligned(16))) uint8_t emat_lds_tables[k_lds_tables_bytes];
 __shared__ __attribute__((aligned(16))) uint8_t emat_lds_ctx[k_lds_ctx_bytes];
+__shared__ __attribute__((aligned(16))) uint32_t emat_lds_rng[k_rng_blocks ? k_rng_blocks * 4 : 4];
 // The staged slab's HEADER is a third static object, for the same reason: its fields (root, node count, the coalescent
 // window, heap marks, counters) are read all the time and must not look clobbered by every store into nodes or lists.
 // The dynamic block then starts with slab byte sizeof(SlabHeader): slab offset `off` lives at emat_lds + off - sizeof(SlabHeader).
@@ -104,6 +117,7 @@ struct Ctx {
   uint8_t phase, svc;
   // RNG (Philox4x32-10; one 128-bit block per draw)
   uint64_t rng_key, rng_ctr;
+  uint64_t rng_base;          // emat_lds_rng holds the blocks of counters rng_base .. rng_base + k_rng_blocks - 1 (rng_fill)
   uint64_t rng_spare;
   uint8_t* frame;
   double mu_prop;             // effective JC69 rate of the current SPR move (subrun.cpp:502,710)
@@ -205,13 +219,35 @@ EMAT_D void philox4x32_10(uint64_t ctr, uint64_t key, uint32_t out[4]) {
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-EMAT_D uint64_t rng_next64(Ctx& c) {
-  if (c.rng_has_spare) { c.rng_has_spare = false; return c.rng_spare; }
+// (out of line: the rare draw beyond what the wave has computed ahead -- a long mutational history -- and builds without the buffer)
+EMAT_DN uint64_t rng_next64_computed(Ctx& c) {
   uint32_t w[4];
   philox4x32_10(c.rng_ctr++, c.rng_key, w);
   c.rng_spare = (uint64_t)w[2] | ((uint64_t)w[3] << 32); c.rng_has_spare = true;
   return (uint64_t)w[0] | ((uint64_t)w[1] << 32);
 }
+EMAT_D uint64_t rng_next64(Ctx& c) {
+  if (c.rng_has_spare) { c.rng_has_spare = false; return c.rng_spare; }
+  if (k_rng_blocks != 0) {
+    const uint64_t k = c.rng_ctr - c.rng_base;
+    if (k < (uint64_t)k_rng_blocks) {
+      const uint4 w = *(const uint4*)&emat_lds_rng[(uint32_t)k * 4u];
+      c.rng_ctr += 1;
+      c.rng_spare = (uint64_t)w.z | ((uint64_t)w.w << 32); c.rng_has_spare = true;
+      return (uint64_t)w.x | ((uint64_t)w.y << 32);
+    }
+  }
+  return rng_next64_computed(c);
+}
+// All lanes: the blocks of the next k_rng_blocks counters (the caller synchronises the wave before and after).
+EMAT_D void rng_fill(Ctx& c, int lane) {
+  if (k_rng_blocks == 0) return;
+  const uint64_t base = c.rng_ctr;
+  if (lane < (int)k_rng_blocks) { uint32_t w[4]; philox4x32_10(base + (uint64_t)lane, c.rng_key, w); *(uint4*)&emat_lds_rng[(uint32_t)lane * 4u] = make_uint4(w[0], w[1], w[2], w[3]); }
+  if (lane == 0) c.rng_base = base;
+}
+// the chain, between two moves: few enough blocks left that the next move might run out
+EMAT_D bool rng_wants_fill(const Ctx& c) { return k_rng_blocks != 0 && c.rng_ctr - c.rng_base + 8u > (uint64_t)k_rng_blocks; }
 // Rewind the stream to where the current move drew its first number (the spare half-block is recomputed, not stored).
 EMAT_DN void rng_rewind_to_move_start(Ctx& c) {
   c.rng_ctr = c.mv_rng_ctr; c.rng_has_spare = c.mv_rng_had_spare;

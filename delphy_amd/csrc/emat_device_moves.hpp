@@ -587,7 +587,11 @@ EMAT_NOTAIL EMAT_D bool mcmc_sub_iteration(Ctx& c) {
 EMAT_NOTAIL EMAT_DN void run_chain_loop(Ctx& c) {
   c.svc = 0;
   for (;;) {
-    if (c.phase == 0) { if (c.moves_left <= 0) return; c.moves_left -= 1; }
+    if (c.phase == 0) {
+      if (c.moves_left <= 0) return;
+      if (rng_wants_fill(c)) { c.svc = 2; return; }                 // the wave computes the next stretch of the stream (rng_fill), then calls again
+      c.moves_left -= 1;
+    }
     if (!mcmc_sub_iteration(c)) { c.moves_left = 0; c.phase = 0; c.svc = 0; return; }
     if (c.svc != 0) return;
   }
