@@ -247,7 +247,10 @@ EMAT_D void rng_fill(Ctx& c, int lane) {
   if (lane == 0) c.rng_base = base;
 }
 // the chain, between two moves: few enough blocks left that the next move might run out
-EMAT_D bool rng_wants_fill(const Ctx& c) { return k_rng_blocks != 0 && c.rng_ctr - c.rng_base + 8u > (uint64_t)k_rng_blocks; }
+#ifndef EMAT_RNG_MARGIN
+#define EMAT_RNG_MARGIN 8     // blocks (two draws each) a move may use before it has to compute its own
+#endif
+EMAT_D bool rng_wants_fill(const Ctx& c) { return k_rng_blocks != 0 && c.rng_ctr - c.rng_base + (uint64_t)EMAT_RNG_MARGIN > (uint64_t)k_rng_blocks; }
 // Rewind the stream to where the current move drew its first number (the spare half-block is recomputed, not stored).
 EMAT_DN void rng_rewind_to_move_start(Ctx& c) {
   c.rng_ctr = c.mv_rng_ctr; c.rng_has_spare = c.mv_rng_had_spare;
