@@ -135,6 +135,7 @@ template <class CtxT> __device__ inline void init_ctx(CtxT& c, uint8_t* slab, ui
   c.L = a.evo.num_sites;
   c.ref = (const __attribute__((address_space(1))) uint8_t*)a.evo.ref_sequence; c.part = (const __attribute__((address_space(1))) uint8_t*)a.evo.partition_for_site;
   c.nu = (const __attribute__((address_space(1))) double*)a.evo.nu_l; c.cumQ = (const __attribute__((address_space(1))) double*)a.evo.cum_Q_l;
+  c.have_logq = lds_tables != nullptr;
   if (lds_tables) { c.mu = lds_tables; c.pi = lds_tables + k_max_lds_partitions; c.q = lds_tables + k_max_lds_partitions * 5; }
   else { c.mu = a.evo.mu; c.pi = a.evo.pi; c.q = a.evo.q; }
   c.pop = a.pop;
@@ -154,6 +155,7 @@ __device__ inline const double* stage_tables(const KernelArgs& a, double* lds_ta
   for (int i = lane; i < P; i += k_wave) lds_tables[i] = a.evo.mu[i];
   for (int i = lane; i < P * 4; i += k_wave) lds_tables[k_max_lds_partitions + i] = a.evo.pi[i];
   for (int i = lane; i < P * 16; i += k_wave) lds_tables[k_max_lds_partitions * 5 + i] = a.evo.q[i];
+  for (int i = lane; i < P * 16; i += k_wave) { const double arg = a.evo.mu[i / 16] * 1.0 * a.evo.q[i]; emat_lds_logq[i] = arg > 0.0 ? dev::m_log(arg) : 0.0; }   // (the diagonal is never asked for)
   return lds_tables;
 }
 

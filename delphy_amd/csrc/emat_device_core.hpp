@@ -49,10 +49,15 @@ constexpr uint32_t k_lds_ctx_bytes = 288;
 constexpr uint32_t k_rng_blocks = EMAT_RNG_BLOCKS;
 static_assert(k_rng_blocks == 0 || (k_rng_blocks <= 64 && (k_rng_blocks & (k_rng_blocks - 1)) == 0), "one block per lane, a power of two");
 constexpr uint32_t k_lds_rng_bytes = k_rng_blocks * 16;
-constexpr uint32_t k_lds_static_bytes = k_lds_tables_bytes + k_lds_ctx_bytes + k_lds_rng_bytes;      // what every k_run_moves workgroup holds besides the slab image and the arena
+constexpr uint32_t k_lds_static_bytes = k_lds_tables_bytes + k_lds_ctx_bytes + k_lds_rng_bytes + k_max_lds_partitions * 16 * 8;      // what every k_run_moves workgroup holds besides the slab image and the arena
 __shared__ __attribute__((aligned(16))) uint8_t emat_lds_tables[k_lds_tables_bytes];
 __shared__ __attribute__((aligned(16))) uint8_t emat_lds_ctx[k_lds_ctx_bytes];
 __shared__ __attribute__((aligned(16))) uint32_t emat_lds_rng[k_rng_blocks ? k_rng_blocks * 4 : 4];
+// log(mu q_ab) per site partition: what a mutation a -> b at a site of relative rate 1 contributes to its branch's log G besides its
+// time (phylo_tree_calc.h:185-206 takes the logarithm per mutation and evaluation): sixteen numbers per partition, taken by the device's
+// own log from the very product the moves would form (mu * 1.0 * q), when the tables are staged.
+constexpr uint32_t k_lds_logq_bytes = k_max_lds_partitions * 16 * 8;
+__shared__ __attribute__((aligned(16))) double emat_lds_logq[k_max_lds_partitions * 16];
 // The staged slab's HEADER is a third static object, for the same reason: its fields (root, node count, the coalescent
 // window, heap marks, counters) are read all the time and must not look clobbered by every store into nodes or lists.
 // The dynamic block then starts with slab byte sizeof(SlabHeader): slab offset `off` lives at emat_lds + off - sizeof(SlabHeader).
@@ -111,6 +116,7 @@ struct Ctx {
   bool only_displacing_inner_nodes;
   bool topology_moves_enabled;
   bool includes_run_root;
+  bool have_logq;             // emat_lds_logq is filled (the HKY tables are staged): sites of relative rate 1 take their log(mu q_ab) from it
   bool rng_has_spare;         // rng_spare holds the second 64-bit half of the last Philox block, not yet consumed
   // A move that wants work done by the whole wave (candidate scan and study of an SPR move) parks itself: `phase` says
   // where it resumes, `svc` what the wave is to do meanwhile, `frame` points at the move's state in the scratch arena.
@@ -603,12 +609,18 @@ EMAT_DN double calc_lambda_at_node(Ctx& c, int node) {   // cpp:406-418
   for (int cur = node; cur != k_no_node; cur = nodes_of(c)[cur].parent) r += delta_lambda_across_branch(c, cur);
   return r;
 }
+// log(mu_l nu_l q_ab): from the table where the site's relative rate is exactly 1 (mu * 1.0 * q is mu * q bit for bit), else taken
+EMAT_D double log_mu_nu_q(const Ctx& c, int l, int a, int b) {
+  const int pa = (int)c.part[l]; const double nu = c.nu[l];
+  if (c.have_logq && nu == 1.0) return emat_lds_logq[pa * 16 + a * 4 + b];
+  return m_log(mu_of(c)[pa] * nu * q_of(c)[pa * 16 + a * 4 + b]);
+}
 EMAT_D double branch_log_G(const Ctx& c, double t_P, double t_X, double lambda_X, const MutRec* m, int nm) {   // h:185-206
   double r = -lambda_X * (t_X - t_P);
   for (int i = nm - 1; i >= 0; --i) {
     int l = m[i].site;
     r -= mu_of(c)[c.part[l]] * c.nu[l] * (q_a(c, l, m[i].from) - q_a(c, l, m[i].to)) * (m[i].t - t_P);
-    r += m_log(mu_of(c)[c.part[l]] * c.nu[l] * q_ab(c, l, m[i].from, m[i].to));
+    r += log_mu_nu_q(c, l, m[i].from, m[i].to);
   }
   return r;
 }

@@ -234,6 +234,7 @@ struct ReformFactors { double* A; double* B; };
 EMAT_D ReformFactors reform_factors(Ctx& c, const MutRec* m, int n) { EMAT_TIMED(2);
   ReformFactors f; f.A = (double*)sc_alloc(c, (uint32_t)n * 16u); f.B = f.A + n;
   if (c.failed) return f;
+  uint32_t need_log = 0u; bool all_logs = false;   // which entries still hold the logarithm's argument (bit j for j < 32; beyond: decided again per entry)
   for (int j0 = 0; j0 < n; j0 += 4) {
     int l[4]; int pa[4]; double nu[4];
 #pragma unroll
@@ -246,10 +247,11 @@ EMAT_D ReformFactors reform_factors(Ctx& c, const MutRec* m, int n) { EMAT_TIMED
       const double mn = mu_of(c)[pa[k]] * nu[k];
       const double* q = q_of(c) + pa[k] * 16;
       f.A[j0 + k] = mn * (-q[(int)mm.from * 5] - -q[(int)mm.to * 5]);      // mu nu (q_a(from) - q_a(to)), q_a = -q_aa
-      f.B[j0 + k] = mn * q[(int)mm.from * 4 + (int)mm.to];                 // the logarithm's argument; taken below
+      if (c.have_logq && nu[k] == 1.0) f.B[j0 + k] = emat_lds_logq[pa[k] * 16 + (int)mm.from * 4 + (int)mm.to];
+      else { f.B[j0 + k] = mn * q[(int)mm.from * 4 + (int)mm.to]; need_log |= 1u << ((j0 + k) & 31); if (j0 + k >= 32) all_logs = true; }   // the logarithm's argument; taken below
     }
   }
-  for (int j = 0; j < n; ++j) f.B[j] = m_log(f.B[j]);
+  if (need_log != 0u || all_logs) for (int j = 0; j < n; ++j) if (all_logs ? !(c.have_logq && c.nu[m[j].site] == 1.0) : ((need_log >> j) & 1u)) f.B[j] = m_log(f.B[j]);
   return f;
 }
 template <bool kRoot> EMAT_SIMPLE_MOVE void branch_reform_move(Ctx& c) { EMAT_TIMED(2);   // subrun.cpp:287-320
