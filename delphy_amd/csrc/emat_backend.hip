@@ -585,6 +585,94 @@ __global__ void __launch_bounds__(k_wave) k_debug_tree_query(KernelArgs a, int p
   for (int i = 0; i < n; ++i) out[i] = op == 0 ? dev::find_MRCA_of(c, qa[i], qb[i]) : (dev::descends_from(c, qa[i], qb[i]) ? 1 : 0);
 }
 
+// test hook (emat_debug_graft): the moves' own graft analysis, peel, re-attachment, proposal and apply on one part's slab, on
+// lane 0 as inside a chain, with everything the analysis found written out as numbers (layout: emat_backend.h).
+struct GraftOut { double* p; int cap; int n; };
+__device__ inline void go_put(GraftOut& o, double v) { if (o.n < o.cap) o.p[o.n] = v; ++o.n; }
+__device__ inline void go_graft(GraftOut& o, const dev::Graft& g) {
+  go_put(o, (double)g.nbi); go_put(o, g.delta_log_G); go_put(o, g.log_alpha_mut); go_put(o, (double)g.X); go_put(o, (double)g.S); go_put(o, g.t_P);
+  for (int i = 0; i < g.nbi; ++i) {
+    const dev::BranchInfo& b = g.bi[i];
+    go_put(o, (double)b.A); go_put(o, (double)b.B); go_put(o, b.is_open ? 1.0 : 0.0); go_put(o, b.T_to_X); go_put(o, b.pl_A); go_put(o, b.pl_X);
+    go_put(o, (double)b.warm.n); for (int k = 0; k < b.warm.n; ++k) { go_put(o, (double)b.warm.p[k].start); go_put(o, (double)b.warm.p[k].end); }
+    go_put(o, (double)b.hot.n); for (int k = 0; k < b.hot.n; ++k) { go_put(o, (double)b.hot.p[k].start); go_put(o, (double)b.hot.p[k].end); }
+    go_put(o, (double)b.hot_muts.n); for (int k = 0; k < b.hot_muts.n; ++k) { const MutRec& m = b.hot_muts.p[k]; go_put(o, (double)m.site); go_put(o, (double)m.from); go_put(o, (double)m.to); go_put(o, m.t); }
+    go_put(o, (double)b.hot_deltas.n); for (int k = 0; k < b.hot_deltas.n; ++k) { const dev::SdRec& d = b.hot_deltas.p[k]; go_put(o, (double)d.site); go_put(o, (double)d.from); go_put(o, (double)d.to); }
+  }
+}
+__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY k_debug_graft(KernelArgs a, int part, int X, double mu_proposal, int mode, int new_S, double new_t_P, double* out, int out_cap, int32_t* out_len) {
+  __shared__ __attribute__((aligned(16))) double lds_tables[k_lds_tables_bytes / 8];
+  const int lane = threadIdx.x;
+  uint8_t* slab = a.slabs + a.slab_off[part];
+  const double* tables = stage_tables(a, lds_tables, lane);
+  __syncthreads();
+  if (lane != 0) return;
+  dev::Ctx c;
+  init_ctx(c, slab, slab, a, tables);
+  dev::sc_reset(c);
+  c.mu_prop = mu_proposal;
+  GraftOut o; o.p = out; o.cap = out_cap; o.n = 0;
+  go_put(o, 0.0);                                   // [0]: the part's status afterwards
+  go_put(o, mode == 3 ? 2.0 : 1.0);                 // [1]: grafts written out
+  dev::Graft* g = (dev::Graft*)dev::sc_alloc(c, (uint32_t)(2 * sizeof(dev::Graft)));
+  if (!c.failed) {
+    dev::analyze_graft(c, X, g[0]);                 // Spr_move::analyze_graft (spr_move.cpp:9-36)
+    if (!c.failed) go_graft(o, g[0]);
+    if (mode >= 1 && !c.failed) {
+      dev::peel_graft(c, g[0]);                     // Spr_move::peel_graft (:38-62)
+      if (!c.failed) {
+        go_put(o, (double)dev::count_min_mutations(c, g[0]));                      // count_min_mutations (spr_move.cpp:64-71)
+        { int closed = 0; if (g[0].rooty) closed = g[0].bi[dev::k_SPX].hot_muts.n; else for (int i = 0; i < g[0].nbi; ++i) if (!g[0].bi[i].is_open) closed += g[0].bi[i].hot_muts.n;
+          go_put(o, (double)closed); }                                             // count_closed_mutations (:73-89; not needed by a move)
+        const dev::SVec<dev::SdRec> d = dev::summarize_closed_mutations(c, g[0], 0);      // summarize_closed_mutations (:1126-1156)
+        go_put(o, (double)d.n); for (int k = 0; k < d.n; ++k) { go_put(o, (double)d.p[k].site); go_put(o, (double)d.p[k].from); go_put(o, (double)d.p[k].to); }
+      }
+    }
+    if (mode == 2 && !c.failed) dev::apply_graft(c, g[0]);                         // Spr_move::apply_graft (:64-89)
+    if (mode == 3 && !c.failed) {
+      // the middle of an SPR move without its candidate study (subrun.cpp:580-640): re-attach at (new_S, new_t_P), propose the new
+      // graft's mutations from the part's random stream, apply them, and account for the change of log G as an accepted move does
+      dev::spr_move_topology(c, X, new_S, new_t_P);                                // Spr_move::move (spr_move.cpp:1071-1099)
+      if (!c.failed) dev::propose_new_graft(c, X, g[1]);
+      if (!c.failed) { go_graft(o, g[1]); dev::apply_graft(c, g[1]); }
+      if (!c.failed) { c.H->log_G -= g[0].delta_log_G; c.H->log_G += g[1].delta_log_G; }
+    }
+  }
+  c.H->rng_counter = c.rng_ctr; c.H->rng_spare = c.rng_spare; c.H->rng_has_spare = c.rng_has_spare ? 1u : 0u;
+  out[0] = (double)(c.failed ? (c.H->status != 0 ? c.H->status : k_part_internal) : 0);
+  *out_len = o.n;
+}
+
+// test hook (emat_debug_sample_history): the proposal's JC69 history sampler, history by history, as the reference's own statistical
+// test drives it (tests/spr_move_tests.cpp:1795-1961): for history i the path ends at (branch[i], t_end[i]); the deltas are where
+// `start_seq` differs from the tree's sequence there; sample_mutational_history + adjust_mutational_history; every mutation written out.
+__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY k_debug_sample_history(KernelArgs a, int part, int n, const int32_t* branch, const double* t_end, const uint8_t* start_seq,
+                                                                                double T, double mu, int32_t* counts, double* muts, int muts_cap, int32_t* status) {
+  __shared__ __attribute__((aligned(16))) double lds_tables[k_lds_tables_bytes / 8];
+  const int lane = threadIdx.x;
+  uint8_t* slab = a.slabs + a.slab_off[part];
+  const double* tables = stage_tables(a, lds_tables, lane);
+  __syncthreads();
+  if (lane != 0) return;
+  dev::Ctx c;
+  init_ctx(c, slab, slab, a, tables);
+  int written = 0;
+  for (int i = 0; i < n && !c.failed; ++i) {
+    dev::sc_reset(c);
+    dev::SVec<dev::SdRec> deltas = dev::sc_vec<dev::SdRec>(c, c.L + 1);
+    for (int l = 0; l < c.L && !c.failed; ++l) { const int e = dev::calc_site_state_at(c, branch[i], t_end[i], l); if (e != (int)start_seq[l]) dev::sd_push_back(c, deltas, l, (int)start_seq[l], e); }
+    if (c.failed) break;
+    dev::SVec<MutRec> h = dev::sample_mutational_history(c, c.L, T, mu, deltas);
+    if (c.failed) break;
+    dev::adjust_mutational_history(c, h, deltas, branch[i], t_end[i]);
+    counts[i] = h.n;
+    for (int k = 0; k < h.n; ++k, ++written) if (written < muts_cap) { double* o = muts + 4 * (size_t)written; o[0] = (double)h.p[k].site; o[1] = (double)h.p[k].from; o[2] = (double)h.p[k].to; o[3] = h.p[k].t; }
+  }
+  c.H->rng_counter = c.rng_ctr; c.H->rng_spare = c.rng_spare; c.H->rng_has_spare = c.rng_has_spare ? 1u : 0u;
+  status[0] = c.failed ? (c.H->status != 0 ? c.H->status : k_part_internal) : 0;
+  status[1] = written;
+}
+
 // ---- compact copies of what the host reads most often, so that it does not have to download the slabs for them ----------
 // Every part's 256-byte header (status, counters, log_G, log prior, RNG position) into one dense array.
 __global__ void __launch_bounds__(k_wave) k_gather_headers(KernelArgs a, uint8_t* out) {
@@ -2248,6 +2336,60 @@ emat_status emat_debug_tree_query(emat_backend* h, int32_t part_id, int32_t op, 
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
   return EMAT_OK;
+}
+/* test hook (header: emat_debug_graft) */
+emat_status emat_debug_graft(emat_backend* h, int32_t part_id, int32_t X, double mu_proposal, int32_t mode, int32_t new_sibling, double new_t_P,
+                             double* out, int32_t out_cap, int32_t* out_len) {
+  if (!h || !out || !out_len || out_cap < 2 || mode < 0 || mode > 3) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
+  if (part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  const int nn = h->parts[part_id].n_nodes;
+  if (X < 0 || X >= nn || (mode == 3 && (new_sibling < 0 || new_sibling >= nn))) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_debug_graft: node index out of range");
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  emat_status st = emat_synchronize(h); if (st) return st;
+  st = sync_model_to_device(h); if (st) return st;
+  st = materialize(h); if (st) return st;
+  DevBuf<double> dout; DevBuf<int32_t> dlen;
+  HIP_TRY(dout.alloc((size_t)out_cap)); HIP_TRY(dlen.alloc(1));
+  KernelArgs ka = make_args(h);
+  hipLaunchKernelGGL(k_debug_graft, dim3(1), dim3(k_wave), 0, h->stream, ka, (int)part_id, (int)X, mu_proposal, (int)mode, (int)new_sibling, new_t_P, dout.p, (int)out_cap, dlen.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out_len, dlen.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, dout.p, (size_t)std::min(*out_len, out_cap) * sizeof(double), hipMemcpyDeviceToHost));
+  if (mode >= 1) { h->host_slabs_current = false; h->headers_current = false; }   // the part's slab was edited on the device
+  if (out[0] != 0.0) return fail(h, EMAT_ERR_INTERNAL, "emat_debug_graft: the device code stopped with part status " + std::to_string((int)out[0]));
+  return *out_len > out_cap ? fail(h, EMAT_ERR_CAPACITY, "emat_debug_graft: out_cap too small") : EMAT_OK;
+}
+/* test hook (header: emat_debug_sample_history) */
+emat_status emat_debug_sample_history(emat_backend* h, int32_t part_id, int32_t n, const int32_t* branch, const double* t_end, const uint8_t* start_seq, double T, double mu,
+                                      int32_t* counts, double* muts, int32_t muts_cap, int32_t* num_muts) {
+  if (!h || n < 0 || !branch || !t_end || !start_seq || !counts || !muts || muts_cap < 0 || !num_muts) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
+  if (part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  const int nn = h->parts[part_id].n_nodes;
+  for (int i = 0; i < n; ++i) if (branch[i] < 0 || branch[i] >= nn) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_debug_sample_history: node index out of range");
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  emat_status st = emat_synchronize(h); if (st) return st;
+  st = sync_model_to_device(h); if (st) return st;
+  st = materialize(h); if (st) return st;
+  DevBuf<int32_t> db, dc, ds; DevBuf<double> dt, dm; DevBuf<uint8_t> dseq;
+  HIP_TRY(db.upload(branch, (size_t)std::max(n, 1))); HIP_TRY(dt.upload(t_end, (size_t)std::max(n, 1))); HIP_TRY(dseq.upload(start_seq, (size_t)h->cfg.num_sites));
+  HIP_TRY(dc.alloc((size_t)std::max(n, 1))); HIP_TRY(dm.alloc((size_t)std::max(muts_cap, 1) * 4)); HIP_TRY(ds.alloc(2));
+  KernelArgs ka = make_args(h);
+  hipLaunchKernelGGL(k_debug_sample_history, dim3(1), dim3(k_wave), 0, h->stream, ka, (int)part_id, (int)n, db.p, dt.p, dseq.p, T, mu, dc.p, dm.p, (int)muts_cap, ds.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  int32_t status[2];
+  HIP_TRY(hipMemcpy(status, ds.p, sizeof status, hipMemcpyDeviceToHost));
+  h->host_slabs_current = false; h->headers_current = false;   // the part's random stream moved on
+  if (status[0] != 0) return fail(h, EMAT_ERR_INTERNAL, "emat_debug_sample_history: the device code stopped with part status " + std::to_string(status[0]));
+  *num_muts = status[1];
+  if (n > 0) HIP_TRY(hipMemcpy(counts, dc.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (status[1] > 0) HIP_TRY(hipMemcpy(muts, dm.p, (size_t)std::min(status[1], muts_cap) * 4 * sizeof(double), hipMemcpyDeviceToHost));
+  return status[1] > muts_cap ? fail(h, EMAT_ERR_CAPACITY, "emat_debug_sample_history: muts_cap too small") : EMAT_OK;
 }
 /* debugging aid (not part of the boundary): how many parts the next launch runs with each code variant
  * (out3 = {whole slab staged in LDS, prefix staged, HBM only}); mirrors the kernel's per-part decision (single class). */

@@ -251,7 +251,8 @@ EMAT_D ReformFactors reform_factors(Ctx& c, const MutRec* m, int n) { EMAT_TIMED
       else { f.B[j0 + k] = mn * q[(int)mm.from * 4 + (int)mm.to]; need_log |= 1u << ((j0 + k) & 31); if (j0 + k >= 32) all_logs = true; }   // the logarithm's argument; taken below
     }
   }
-  if (need_log != 0u || all_logs) for (int j = 0; j < n; ++j) if (all_logs ? !(c.have_logq && c.nu[m[j].site] == 1.0) : ((need_log >> j) & 1u)) f.B[j] = m_log(f.B[j]);
+  if (all_logs) { for (int j = 0; j < n; ++j) if (!(c.have_logq && c.nu[m[j].site] == 1.0)) f.B[j] = m_log(f.B[j]); }
+  else if (need_log != 0u) { const int n32 = n < 32 ? n : 32; for (int j = 0; j < n32; ++j) if ((need_log >> j) & 1u) f.B[j] = m_log(f.B[j]); }   // entries from 32 on need none (all_logs would be set): never shift by >= 32
   return f;
 }
 template <bool kRoot> EMAT_SIMPLE_MOVE void branch_reform_move(Ctx& c) { EMAT_TIMED(2);   // subrun.cpp:287-320

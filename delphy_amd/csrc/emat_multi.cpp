@@ -45,7 +45,7 @@ struct Rccl {
   bool load(std::string& err) {
     const char* names[] = {getenv("EMAT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) { if (!n || !*n) continue; lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
-    if (!lib) { err = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "?"); return false; }
+    if (!lib) { const char* e = dlerror(); err = std::string("librccl.so could not be loaded: ") + (e ? e : "?"); return false; }   // dlerror() clears what it returns: once
     auto sym = [&](const char* s) -> void* { void* p = dlsym(lib, s); if (!p) err = std::string("librccl.so lacks ") + s; return p; };
     CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
     GroupStart = (decltype(GroupStart))sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
@@ -248,6 +248,7 @@ emat_status emat_multi_reassemble(emat_multi* m) {
     for (auto& s : m->shards) { st = grow(m, s, s.send, s.send_cap, most); if (st) return st; st = grow(m, s, s.recv, s.recv_cap, most * (uint64_t)n); if (st) return st; }
     st = m->on_every_shard([&](int i) { Shard& s = m->shards[(size_t)i]; uint64_t need = 0; return (int)emat_tree_export_nodes(s.backend, s.send, s.send_cap, &need); });   // kernels write into the buffer RCCL sends; returns with them finished
     if (st) return st;
+    for (auto& s : m->shards) if (s.export_bytes < most) { M_HIP(hipSetDevice(s.device)); M_HIP(hipMemsetAsync(s.send + s.export_bytes, 0, most - s.export_bytes, s.stream)); }   // the padding up to the common stride is sent too: defined bytes
     M_NCCL(m->rccl.GroupStart());
     for (auto& s : m->shards) { M_HIP(hipSetDevice(s.device)); M_NCCL(m->rccl.AllGather(s.send, s.recv, most, ncclUint8, s.comm, s.stream)); }
     M_NCCL(m->rccl.GroupEnd());

@@ -285,6 +285,8 @@ def load_library():
         "emat_debug_gamma": [B, i32, i32, P(dbl), P(dbl), P(dbl)],
         "emat_debug_pop": [B, P(_PopModelC), i32, i32, P(dbl), P(dbl), P(dbl)], "emat_debug_interval_op": [B, i32, P(i32), i32, P(i32), i32, P(i32), P(i32)],
         "emat_debug_tree_query": [B, i32, i32, i32, P(i32), P(i32), P(i32)],
+        "emat_debug_graft": [B, i32, i32, dbl, i32, i32, dbl, P(dbl), i32, P(i32)],
+        "emat_debug_sample_history": [B, i32, i32, P(i32), P(dbl), P(C.c_uint8), dbl, dbl, P(i32), P(dbl), i32, P(i32)],
         "emat_get_num_muts_l": [B, P(i32)], "emat_get_scalable_coalescent_log_prior": [B, dbl, dbl, P(dbl)],
         "emat_scalable_coalescent_partial": [B, dbl, dbl, i32, i32, P(dbl), P(dbl), P(i32)],
         "emat_scalable_coalescent_log_prior": [B, dbl, dbl, i32, i32, P(dbl), dbl, P(dbl)],
@@ -383,6 +385,39 @@ def make_synthetic_emat(p: SynthParams):
         return tree, refseq, float(tmax.value)
     finally:
         lib.emat_synth_destroy(h)
+
+
+def decode_graft_output(v, mode: int) -> dict:
+    """The doubles of emat_debug_graft (include/emat_backend.h) as {"status", "grafts": [graft...], "count_min_mutations",
+    "count_closed_mutations", "closed_deltas"}; a graft is {"delta_log_G", "log_alpha_mut", "X", "S", "t_P", "branch_infos": [...]}
+    with mutations as [from, site, to, t] and deltas as [site, from, to]."""
+    pos = [0]
+    def take():
+        x = float(v[pos[0]]); pos[0] += 1; return x
+    def graft():
+        nbi = int(take()); g = {"delta_log_G": take(), "log_alpha_mut": take(), "X": int(take()), "S": int(take()), "t_P": take(), "branch_infos": []}
+        for _ in range(nbi):
+            b = {"A": int(take()), "B": int(take()), "is_open": take() != 0.0, "T_to_X": take(), "partial_lambda_at_A": take(), "partial_lambda_at_X": take()}
+            b["warm_sites"] = [[int(take()), int(take())] for _ in range(int(take()))]
+            b["hot_sites"] = [[int(take()), int(take())] for _ in range(int(take()))]
+            muts = []
+            for _ in range(int(take())):
+                site, fr, to, t = int(take()), int(take()), int(take()), take()
+                muts.append([fr, site, to, t])
+            b["hot_muts_to_X"] = muts
+            b["hot_deltas_to_X"] = [[int(take()), int(take()), int(take())] for _ in range(int(take()))]
+            g["branch_infos"].append(b)
+        return g
+    out = {"status": int(take())}
+    num = int(take())
+    out["grafts"] = [graft()]
+    if mode >= 1:
+        out["count_min_mutations"] = int(take()); out["count_closed_mutations"] = int(take())
+        out["closed_deltas"] = [[int(take()), int(take()), int(take())] for _ in range(int(take()))]
+    if num == 2:
+        out["grafts"].append(graft())
+    assert pos[0] == len(v), "emat_debug_graft output not consumed exactly: %d of %d" % (pos[0], len(v))
+    return out
 
 
 class EmatBackend:
@@ -688,6 +723,26 @@ class EmatBackend:
         """Test hook: the moves' find_MRCA_of (op 0) / descends_from (op 1) on a resident part; -1 = no node."""
         a = np.ascontiguousarray(a, np.int32); b = np.ascontiguousarray(b, np.int32); out = np.zeros_like(a); ip = C.POINTER(C.c_int32)
         self._ck(self._lib.emat_debug_tree_query(self._h, part, op, a.shape[0], a.ctypes.data_as(ip), b.ctypes.data_as(ip), out.ctypes.data_as(ip)), "emat_debug_tree_query")
+        return out
+
+    def debug_graft(self, part: int, X: int, mu_proposal: float, mode: int = 0, new_sibling: int = 0, new_t_P: float = 0.0) -> dict:
+        """Test hook: the moves' own graft analysis (mode 0), + peel (1), + apply (2), or a whole re-attachment with a proposed
+        new graft (3) on a resident part; returns what emat_debug_graft writes out, decoded (decode_graft_output)."""
+        out = np.zeros(4096); n = C.c_int32()
+        self._ck(self._lib.emat_debug_graft(self._h, part, X, mu_proposal, mode, new_sibling, new_t_P, out.ctypes.data_as(C.POINTER(C.c_double)), out.shape[0], C.byref(n)), "emat_debug_graft")
+        return decode_graft_output(out[: n.value], mode)
+
+    def debug_sample_history(self, part: int, branch, t_end, start_seq, T: float, mu: float):
+        """Test hook: one sampled mutational history per (branch[i], t_end[i]) on a resident part; returns a list of histories, each a
+        list of [from, site, to, t]."""
+        branch = np.ascontiguousarray(branch, np.int32); t_end = np.ascontiguousarray(t_end, np.float64); seq = np.ascontiguousarray(start_seq, np.uint8)
+        n = branch.shape[0]; cap = 64 * n + 1024
+        counts = np.zeros(max(n, 1), np.int32); muts = np.zeros((cap, 4)); tot = C.c_int32()
+        self._ck(self._lib.emat_debug_sample_history(self._h, part, n, _ptr(branch, C.c_int32), _ptr(t_end, C.c_double), _ptr(seq, C.c_uint8), T, mu,
+                                                     _ptr(counts, C.c_int32), _ptr(muts, C.c_double), cap, C.byref(tot)), "emat_debug_sample_history")
+        out, k = [], 0
+        for i in range(n):
+            out.append([[int(m[1]), int(m[0]), int(m[2]), float(m[3])] for m in muts[k: k + counts[i]]]); k += int(counts[i])
         return out
 
     def debug_gamma(self, mode: int, a, x_or_q) -> np.ndarray:

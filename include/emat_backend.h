@@ -386,6 +386,29 @@ emat_status emat_debug_pop(emat_backend* h, const emat_pop_model* pop_model, int
  * find_MRCA_of(a[i], b[i]); op 1: out[i] = descends_from(a[i], b[i]) (0 / 1); -1 stands for k_no_node.  tests/ runs them over the
  * reference's own table of cases (phylo_tree_tests.cpp:365-525). */
 emat_status emat_debug_tree_query(emat_backend* h, int32_t part_id, int32_t op, int32_t n, const int32_t* a, const int32_t* b, int32_t* out);
+/* The moves' own SPR graft machinery on one resident part, with what it found written out as numbers (reference Spr_move,
+ * spr_move.h:86-150, spr_move.cpp:9-1156).  `mu_proposal` is the JC69 rate of the proposal (the reference's mu_JC); whether the root
+ * sequence may change is the part's includes_run_root flag (the reference's can_change_root).
+ *   mode 0: analyze_graft(X);  1: ... + peel_graft;  2: ... + apply_graft of the same graft (a round trip);
+ *   mode 3: analyze_graft(X), peel_graft, Spr_move::move(X, new_sibling, new_t_P), propose_new_graft(X) from the part's random
+ *           stream, apply_graft, and the part's log G updated by the two delta_log_G as an accepted move does (what the reference's
+ *           run_full_spr_move_test steps through, tests/spr_move_tests.cpp:1518-1641).
+ * out (doubles): [0] part status afterwards (0 = fine), [1] number of grafts that follow (1; 2 in mode 3: old, then new), each graft as
+ *   nbi, delta_log_G, log_alpha_mut, X, S, t_P, then per branch info: A, B, is_open, T_to_X, partial_lambda_at_A, partial_lambda_at_X,
+ *   n_warm, (start, end) x n_warm, n_hot, (start, end) x n_hot, n_hot_muts, (site, from, to, t) x n, n_hot_deltas, (site, from, to) x n;
+ *   after the first graft, for mode >= 1: count_min_mutations, count_closed_mutations, n, (site, from, to) x n of summarize_closed_mutations.
+ * *out_len = doubles needed (EMAT_ERR_CAPACITY when more than out_cap).  tests/ runs it over the reference's own fixtures and expected
+ * values (tests/spr_move_tests.cpp:142-1516, as data in tests/golden/reference_expectations.json). */
+emat_status emat_debug_graft(emat_backend* h, int32_t part_id, int32_t X, double mu_proposal, int32_t mode, int32_t new_sibling, double new_t_P,
+                             double* out, int32_t out_cap, int32_t* out_len);
+/* The proposal's JC69 mutational-history sampler on one resident part, history by history (reference sample_mutational_history +
+ * adjust_mutational_history, spr_move.cpp:1164-1370, 1409-1439), driven as the reference's own statistical test drives it
+ * (tests/spr_move_tests.cpp:1795-1961): history i ends at the point (branch[i], t_end[i]) of the tree and starts T earlier from `start_seq`
+ * (num_sites states); its site deltas are where start_seq differs from the tree's sequence at that point.  counts[i] = its number of
+ * mutations; muts = (site, from, to, t) per mutation, histories back to back; *num_muts = their total (EMAT_ERR_CAPACITY above muts_cap).
+ * Random numbers come from the part's stream. */
+emat_status emat_debug_sample_history(emat_backend* h, int32_t part_id, int32_t n, const int32_t* branch, const double* t_end, const uint8_t* start_seq, double T, double mu,
+                                      int32_t* counts, double* muts, int32_t muts_cap, int32_t* num_muts);
 /* The device's interval-set algebra on two valid sets given as (start, end) pairs (reference interval_set.h:130-138, 238-500):
  * op 1 merge, 2 intersect, 3 subtract -> pairs in `out` (room for na + nb + 1 pairs), *n_out = their number; op 5 contains
  * (site b[0]), 6 sets intersect -> *n_out = 0 / 1. */

@@ -245,6 +245,84 @@ int orc_tree_query(orc_engine* e, int part_id, int op, int n, const int* a, cons
   ORC_CATCH
 }
 
+/* The oracle's Spr_move on one part, with what it found written out in the layout of emat_debug_graft (include/emat_backend.h):
+ * mode 0 analyze_graft(X); 1 + peel_graft; 2 + apply_graft; 3 analyze, peel, move(X, new_sibling, new_t_P), propose_new_graft, apply. */
+int orc_debug_graft(orc_engine* e, int part_id, int X, double mu_proposal, int mode, int new_sibling, double new_t_P, double* out, int out_cap, int* out_len) {
+  ORC_TRY
+  Part& pt = *e->parts.at(part_id);
+  Subrun& sr = *pt.subrun;
+  sr.ref_freqs = calc_state_frequencies_per_partition_of(sr.tree.ref_sequence, sr.evo);
+  sr.ref_cum_Q_l = calc_cum_Q_l_for_sequence(sr.tree.ref_sequence, sr.evo);
+  sr.lambda_i = calc_lambda_i(sr.tree, sr.evo, sr.ref_cum_Q_l);
+  sr.num_sites_missing = calc_num_sites_missing_at_every_node(sr.tree);
+  if (mode == 3) sr.log_G = sr.calc_cur_log_G();
+  Spr_move spr{sr.tree, mu_proposal, sr.includes_run_root, sr.evo, sr.lambda_i, sr.ref_cum_Q_l, sr.num_sites_missing};
+  int n = 0;
+  auto put = [&](double v) { if (n < out_cap) out[n] = v; ++n; };
+  auto put_graft = [&](const Spr_graft& g) {
+    put((double)g.branch_infos.size()); put(g.delta_log_G); put(g.log_alpha_mut); put((double)g.X); put((double)g.S); put(g.t_P);
+    for (auto& b : g.branch_infos) {
+      put((double)b.A); put((double)b.B); put(b.is_open ? 1.0 : 0.0); put(b.T_to_X); put(b.partial_lambda_at_A); put(b.partial_lambda_at_X);
+      put((double)b.warm_sites.v.size()); for (auto& [s0, s1] : b.warm_sites.v) { put((double)s0); put((double)s1); }
+      put((double)b.hot_sites.v.size()); for (auto& [s0, s1] : b.hot_sites.v) { put((double)s0); put((double)s1); }
+      put((double)b.hot_muts_to_X.size()); for (auto& m : b.hot_muts_to_X) { put((double)m.site); put((double)m.from); put((double)m.to); put(m.t); }
+      put((double)b.hot_deltas_to_X.size()); for (auto& [l, d] : b.hot_deltas_to_X) { put((double)l); put((double)d.from); put((double)d.to); }
+    }
+  };
+  put(0.0); put(mode == 3 ? 2.0 : 1.0);
+  Spr_graft g0 = spr.analyze_graft(X);
+  put_graft(g0);
+  if (mode >= 1) {
+    spr.peel_graft(g0);
+    put((double)spr.count_min_mutations(g0)); put((double)spr.count_closed_mutations(g0));
+    auto d = spr.summarize_closed_mutations(g0);
+    put((double)d.size()); for (auto& [l, sd] : d) { put((double)l); put((double)sd.from); put((double)sd.to); }
+  }
+  if (mode == 2) spr.apply_graft(g0);
+  if (mode == 3) {
+    spr.move(X, new_sibling, new_t_P);
+    Spr_graft g1 = spr.propose_new_graft(X, pt.rng);
+    put_graft(g1);
+    spr.apply_graft(g1);
+    sr.log_G -= g0.delta_log_G; sr.log_G += g1.delta_log_G;
+  }
+  *out_len = n;
+  ORC_CATCH
+}
+/* sample_mutational_history + adjust_mutational_history per (branch[i], t_end[i]), in the layout of emat_debug_sample_history */
+int orc_debug_sample_history(orc_engine* e, int part_id, int n, const int* branch, const double* t_end, const uint8_t* start_seq, double T, double mu,
+                             int* counts, double* muts, int muts_cap, int* num_muts) {
+  ORC_TRY
+  Part& pt = *e->parts.at(part_id);
+  const Phylo_tree& tree = pt.subrun->tree;
+  const int L = tree.num_sites();
+  int written = 0;
+  for (int i = 0; i < n; ++i) {
+    Phylo_tree_loc end_loc{branch[i], t_end[i]};
+    Site_deltas deltas;
+    for (int l = 0; l < L; ++l) { State es = calc_site_state_at(tree, end_loc, l); if (es != (State)start_seq[l]) deltas.insert({l, Site_delta{(State)start_seq[l], es}}); }
+    auto h = sample_mutational_history(L, T, mu, deltas, pt.rng);
+    adjust_mutational_history(h, deltas, tree, end_loc);
+    counts[i] = (int)h.size();
+    for (auto& m : h) { if (written < muts_cap) { double* o = muts + 4 * (size_t)written; o[0] = m.site; o[1] = m.from; o[2] = m.to; o[3] = m.t; } ++written; }
+  }
+  *num_muts = written;
+  ORC_CATCH
+}
+/* log G of one part as it stands (incrementally maintained) and recomputed from scratch, without touching the coalescent prior */
+int orc_part_log_G(orc_engine* e, int part_id, double* incremental, double* from_scratch) {
+  ORC_TRY
+  Subrun& sr = *e->parts.at(part_id)->subrun;
+  *incremental = sr.log_G;
+  auto li = sr.lambda_i;
+  sr.ref_freqs = calc_state_frequencies_per_partition_of(sr.tree.ref_sequence, sr.evo);
+  sr.ref_cum_Q_l = calc_cum_Q_l_for_sequence(sr.tree.ref_sequence, sr.evo);
+  sr.lambda_i = calc_lambda_i(sr.tree, sr.evo, sr.ref_cum_Q_l);
+  *from_scratch = sr.calc_cur_log_G();
+  sr.lambda_i = li;
+  ORC_CATCH
+}
+
 int orc_get_totals(orc_engine* e, double* log_G, double* log_aug) {
   ORC_TRY
   double g = 0.0, a = 0.0;

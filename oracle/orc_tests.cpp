@@ -574,7 +574,31 @@ TEST(spr_move_analyze_graft_simple) {
     EXPECT_NEAR(SPX.partial_lambda_at_A, mu(0) * nu(0) * qa(0, sT), 1e-9); EXPECT_NEAR(SPX.partial_lambda_at_X, mu(0) * nu(0) * qa(0, sG), 1e-9);
     EXPECT(SPX.hot_sites.v == (std::vector<Site_interval>{{0, 1}}));
     EXPECT(SPX.hot_muts_to_X == (Mutation_list{Mutation{sT, 0, sA, -1.5}, Mutation{sA, 0, sT, 0.0}, Mutation{sT, 0, sG, 1.0}}));
-    EXPECT(SPX.hot_deltas_to_X.size() == 1 && SPX.hot_deltas_to_X.at(0) == (Site_delta{sT, sG})); }
+    EXPECT(SPX.hot_deltas_to_X.size() == 1 && SPX.hot_deltas_to_X.at(0) == (Site_delta{sT, sG}));
+    EXPECT_NEAR(g.log_alpha_mut, -mu_JC * 0.5 + std::log(mu_JC / 3) + -mu_JC * 0.5 + -mu_JC * 1.0 + std::log(mu_JC / 3) + -mu_JC * 1.0 + std::log(mu_JC / 3) + -mu_JC * 2.0 + -std::log(P_JC(sT, sG, 5.0))
+                + -mu_JC * 1.0 + -mu_JC * 4.0, 1e-9);
+    EXPECT_NEAR(g.delta_log_G, -mu(0) * nu(0) * qa(0, sA) * 0.5 + std::log(mu(0) * nu(0) * qab(0, sA, sT)) + -mu(0) * nu(0) * qa(0, sT) * 0.5
+                + -mu(0) * nu(0) * qa(0, sA) * 1.0 + std::log(mu(0) * nu(0) * qab(0, sA, sT)) + -mu(0) * nu(0) * qa(0, sT) * 1.0 + std::log(mu(0) * nu(0) * qab(0, sT, sG)) + -mu(0) * nu(0) * qa(0, sG) * 2.0
+                + std::log(evo.pi_l_a(0, sA) / evo.pi_l_a(0, sT)) + -mu(1) * nu(1) * qa(1, sA) * 1.0 + -mu(2) * nu(2) * qa(2, sA) * 4.0, 1e-9); }
+  { auto g = spr.analyze_graft(x_);   // :366-470 (rooty, the inner node x pruned from under the root)
+    EXPECT(g.branch_infos.size() == 3);
+    auto& PX = g.branch_infos[Spr_graft::k_branch_info_P_X]; auto& PS = g.branch_infos[Spr_graft::k_branch_info_P_S]; auto& SPX = g.branch_infos[Spr_graft::k_branch_info_S_P_X];
+    EXPECT(PX.A == r_ && PX.B == x_ && PX.is_open && PX.T_to_X == 1.0);   // site 1 is only present in P->X
+    EXPECT_NEAR(PX.partial_lambda_at_A, mu(1) * nu(1) * qa(1, sA), 1e-9); EXPECT_NEAR(PX.partial_lambda_at_X, mu(1) * nu(1) * qa(1, sA), 1e-9);
+    EXPECT(PX.warm_sites.v == (std::vector<Site_interval>{{1, 2}}) && PX.hot_sites.v == PX.warm_sites.v && PX.hot_muts_to_X.empty() && PX.hot_deltas_to_X.empty());
+    EXPECT(PS.A == r_ && PS.B == c_ && PS.is_open && PS.T_to_X == 4.0);   // site 2 is only present in P->S
+    EXPECT_NEAR(PS.partial_lambda_at_A, mu(2) * nu(2) * qa(2, sA), 1e-9); EXPECT_NEAR(PS.partial_lambda_at_X, mu(2) * nu(2) * qa(2, sA), 1e-9);
+    EXPECT(PS.warm_sites.v == (std::vector<Site_interval>{{2, 3}}) && PS.hot_sites.v == PS.warm_sites.v && PS.hot_muts_to_X.empty() && PS.hot_deltas_to_X.empty());
+    EXPECT(SPX.A == c_ && SPX.B == r_ && !SPX.is_open && SPX.T_to_X == 5.0);   // site 0 all the way along S->P->X
+    EXPECT_NEAR(SPX.partial_lambda_at_A, mu(0) * nu(0) * qa(0, sG), 1e-9); EXPECT_NEAR(SPX.partial_lambda_at_X, mu(0) * nu(0) * qa(0, sT), 1e-9);
+    EXPECT(SPX.warm_sites.v == (std::vector<Site_interval>{{0, 1}}) && SPX.hot_sites.v == SPX.warm_sites.v);
+    EXPECT(SPX.hot_muts_to_X == (Mutation_list{Mutation{sG, 0, sT, -3.0}, Mutation{sT, 0, sA, -2.0}, Mutation{sA, 0, sT, -0.5}}));
+    EXPECT(SPX.hot_deltas_to_X.size() == 1 && SPX.hot_deltas_to_X.at(0) == (Site_delta{sG, sT}));
+    EXPECT_NEAR(g.log_alpha_mut, -mu_JC * 2.0 + std::log(mu_JC / 3) + -mu_JC * 1.0 + std::log(mu_JC / 3) + -mu_JC * 1.0 + -mu_JC * 0.5 + std::log(mu_JC / 3) + -mu_JC * 0.5 + -std::log(P_JC(sG, sT, 5.0))
+                + -mu_JC * 1.0 + -mu_JC * 4.0, 1e-9);
+    EXPECT_NEAR(g.delta_log_G, -mu(0) * nu(0) * qa(0, sA) * 1.0 + std::log(mu(0) * nu(0) * qab(0, sA, sT)) + -mu(0) * nu(0) * qa(0, sT) * 1.0 + std::log(mu(0) * nu(0) * qab(0, sT, sG)) + -mu(0) * nu(0) * qa(0, sG) * 2.0
+                + -mu(0) * nu(0) * qa(0, sA) * 0.5 + std::log(mu(0) * nu(0) * qab(0, sA, sT)) + -mu(0) * nu(0) * qa(0, sT) * 0.5
+                + std::log(evo.pi_l_a(0, sA) / evo.pi_l_a(0, sG)) + -mu(1) * nu(1) * qa(1, sA) * 1.0 + -mu(2) * nu(2) * qa(2, sA) * 4.0, 1e-9); }
 }
 enum { tP = 0, tX = 1, tS = 2 };
 static SprCtx tricky_rooty() {   // spr_move_tests.cpp:1205-1259
@@ -597,6 +621,50 @@ static bool same_muts_unordered(Mutation_list a, Mutation_list b) {
   auto key = [](const Mutation& m) { return std::make_tuple(m.site, m.from, m.to, m.t); };
   std::sort(a.begin(), a.end(), [&](auto& x, auto& y) { return key(x) < key(y); }); std::sort(b.begin(), b.end(), [&](auto& x, auto& y) { return key(x) < key(y); });
   return a == b;
+}
+TEST(spr_move_tricky_rooty_analyze_graft_X) {   // spr_move_tests.cpp:1261-1433
+  auto C = tricky_rooty(); auto& evo = C.evo;
+  auto mu = [&](int l) { return evo.mu_l(l); }; auto nu = [&](int l) { return evo.nu_l[l]; };
+  auto qa = [&](int l, State a) { return evo.q_l_a(l, a); }; auto qab = [&](int l, State a, State b) { return evo.q_l_ab(l, a, b); };
+  auto pi = [&](int l, State a) { return evo.pi_l_a(l, a); };
+  auto spr = C.spr(true);
+  auto g = spr.analyze_graft(tX);
+  EXPECT(g.branch_infos.size() == 3);
+  auto& PX = g.branch_infos[Spr_graft::k_branch_info_P_X]; auto& PS = g.branch_infos[Spr_graft::k_branch_info_P_S]; auto& SPX = g.branch_infos[Spr_graft::k_branch_info_S_P_X];
+  EXPECT(PX.A == tP && PX.B == tX && PX.is_open && PX.T_to_X == 3.0);   // P->X: sites 1, 2
+  EXPECT_NEAR(PX.partial_lambda_at_A, mu(1) * nu(1) * qa(1, sA) + mu(2) * nu(2) * qa(2, sA), 1e-9);
+  EXPECT_NEAR(PX.partial_lambda_at_X, mu(1) * nu(1) * qa(1, sC) + mu(2) * nu(2) * qa(2, sA), 1e-9);
+  EXPECT(PX.warm_sites.v == (std::vector<Site_interval>{{1, 3}}) && PX.hot_sites.v == PX.warm_sites.v);
+  EXPECT(PX.hot_muts_to_X == (Mutation_list{Mutation{sA, 1, sC, 1.0}}) && PX.hot_deltas_to_X.empty());
+  EXPECT(PS.A == tP && PS.B == tS && PS.is_open && PS.T_to_X == 4.0);   // P->S: sites 3, 4
+  EXPECT_NEAR(PS.partial_lambda_at_A, mu(3) * nu(3) * qa(3, sC) + mu(4) * nu(4) * qa(4, sC), 1e-9);
+  EXPECT_NEAR(PS.partial_lambda_at_X, mu(3) * nu(3) * qa(3, sG) + mu(4) * nu(4) * qa(4, sC), 1e-9);
+  EXPECT(PS.warm_sites.v == (std::vector<Site_interval>{{3, 5}}) && PS.hot_sites.v == PS.warm_sites.v);
+  EXPECT(PS.hot_muts_to_X == (Mutation_list{Mutation{sC, 3, sG, 1.0}}) && PS.hot_deltas_to_X.empty());
+  EXPECT(SPX.A == tS && SPX.B == tP && !SPX.is_open && SPX.T_to_X == 7.0);   // S->P->X: sites 0, 5, 6, 8
+  EXPECT_NEAR(SPX.partial_lambda_at_A, mu(0) * nu(0) * qa(0, sA) + mu(5) * nu(5) * qa(5, sA) + mu(6) * nu(6) * qa(6, sG) + mu(8) * nu(8) * qa(8, sA), 1e-9);
+  EXPECT_NEAR(SPX.partial_lambda_at_X, mu(0) * nu(0) * qa(0, sA) + mu(5) * nu(5) * qa(5, sC) + mu(6) * nu(6) * qa(6, sC) + mu(8) * nu(8) * qa(8, sA), 1e-9);
+  EXPECT(SPX.warm_sites.v == (std::vector<Site_interval>{{0, 1}, {5, 7}, {8, 9}}) && SPX.hot_sites.v == SPX.warm_sites.v);
+  EXPECT(SPX.hot_muts_to_X == (Mutation_list{Mutation{sG, 6, sC, -2.0}, Mutation{sA, 5, sC, 2.0}}));
+  EXPECT(SPX.hot_deltas_to_X.size() == 2 && SPX.hot_deltas_to_X.at(5) == (Site_delta{sA, sC}) && SPX.hot_deltas_to_X.at(6) == (Site_delta{sG, sC}));
+  EXPECT_NEAR(g.log_alpha_mut,
+              -mu_JC * 7.0 + -std::log(P_JC(sA, sA, 7.0))                                                   // site 0 (S->P->X)
+              + -mu_JC * 1.0 + std::log(mu_JC / 3) + -mu_JC * 2.0                                            // site 1 (P->X)
+              + -mu_JC * 3.0                                                                                 // site 2 (P->X)
+              + -mu_JC * 1.0 + std::log(mu_JC / 3) + -mu_JC * 3.0                                            // site 3 (P->S)
+              + -mu_JC * 4.0                                                                                 // site 4 (P->S)
+              + -mu_JC * 4.0 + -mu_JC * 2.0 + std::log(mu_JC / 3) + -mu_JC * 1.0 + -std::log(P_JC(sA, sC, 7.0))   // site 5 (S->P->X)
+              + -mu_JC * 2.0 + std::log(mu_JC / 3) + -mu_JC * 2.0 + -mu_JC * 3.0 + -std::log(P_JC(sG, sC, 7.0))   // site 6 (S->P->X)
+              + -mu_JC * 4.0 + -mu_JC * 3.0 + -std::log(P_JC(sA, sA, 7.0)), 1e-9);                           // site 7 missing; site 8 (S->P->X)
+  EXPECT_NEAR(g.delta_log_G,
+              -mu(0) * nu(0) * qa(0, sA) * 4.0 + -mu(0) * nu(0) * qa(0, sA) * 3.0
+              + -mu(1) * nu(1) * qa(1, sA) * 1.0 + std::log(mu(1) * nu(1) * qab(1, sA, sC)) + -mu(1) * nu(1) * qa(1, sC) * 2.0 + std::log(pi(1, sA) / pi(1, sC))
+              + -mu(2) * nu(2) * qa(2, sA) * 3.0
+              + -mu(3) * nu(3) * qa(3, sC) * 1.0 + std::log(mu(3) * nu(3) * qab(3, sC, sG)) + -mu(3) * nu(3) * qa(3, sG) * 3.0 + std::log(pi(3, sC) / pi(3, sG))
+              + -mu(4) * nu(4) * qa(4, sC) * 4.0
+              + -mu(5) * nu(5) * qa(5, sA) * 4.0 + -mu(5) * nu(5) * qa(5, sA) * 2.0 + std::log(mu(5) * nu(5) * qab(5, sA, sC)) + -mu(5) * nu(5) * qa(5, sC) * 1.0
+              + -mu(6) * nu(6) * qa(6, sC) * 2.0 + std::log(mu(6) * nu(6) * qab(6, sC, sG)) + -mu(6) * nu(6) * qa(6, sG) * 2.0 + -mu(6) * nu(6) * qa(6, sC) * 3.0 + std::log(pi(6, sC) / pi(6, sG))
+              + -mu(8) * nu(8) * qa(8, sA) * 4.0 + -mu(8) * nu(8) * qa(8, sA) * 3.0, 1e-9);
 }
 TEST(spr_move_tricky_rooty_peel_and_reapply) {
   { auto C = tricky_rooty(); auto spr = C.spr();
@@ -762,6 +830,128 @@ TEST(spr_move_precarious_with_root_properties) {
   run_propose_new_graft_test(C, 1000, true);
   for (auto& k : std::vector<Case>{{a_, b_, 0.6}, {a_, x_, -0.4}, {a_, c_, 0.0}, {a_, r_, -1.5}, {b_, a_, 0.6}, {b_, x_, -0.4}, {b_, c_, 0.0}, {b_, r_, -1.5},
                                    {c_, x_, -0.6}, {c_, r_, -1.4}, {c_, a_, 0.5}, {c_, b_, 0.5}, {x_, c_, -0.6}, {x_, r_, -1.2}})   // :1765-1793
+    for (int seed = 0; seed < 200; ++seed) { Rng rng; rng.key = seed + 12345; run_full_spr_move_test(C, k.X, k.SS, k.t, rng); }
+}
+// ---- closed-form analyze_graft_a of the two precarious-path fixtures (spr_move_tests.cpp:931-1035, 1107-1199)
+TEST(spr_move_precarious_without_root_analyze_graft_a) {
+  enum { r = 0, x = 1, y = 2, a = 3, b = 4, c = 5, d = 6 };
+  auto C = precarious_without_root(); auto& evo = C.evo;
+  auto mu = [&](int l) { return evo.mu_l(l); }; auto nu = [&](int l) { return evo.nu_l[l]; };
+  auto qa = [&](int l, State s) { return evo.q_l_a(l, s); }; auto qab = [&](int l, State s, State t) { return evo.q_l_ab(l, s, t); };
+  auto spr = C.spr(false);   // can_change_root = false (:932)
+  auto g = spr.analyze_graft(a);
+  EXPECT(g.branch_infos.size() == 3);
+  auto& b0 = g.branch_infos[0]; auto& b1 = g.branch_infos[1]; auto& b2 = g.branch_infos[2];
+  EXPECT(b0.A == y && b0.B == a && !b0.is_open && b0.T_to_X == 2.0);   // y->a: sites 0 and 1 warm, site 0 hot
+  EXPECT_NEAR(b0.partial_lambda_at_A, mu(0) * nu(0) * qa(0, sA), 1e-9); EXPECT_NEAR(b0.partial_lambda_at_X, mu(0) * nu(0) * qa(0, sA), 1e-9);
+  EXPECT(b0.warm_sites.contains(0) && b0.warm_sites.contains(1) && b0.hot_sites.contains(0) && !b0.hot_sites.contains(1));
+  EXPECT(b0.hot_muts_to_X.empty() && b0.hot_deltas_to_X.empty());
+  EXPECT(b1.A == x && b1.B == y && !b1.is_open && b1.T_to_X == 3.0);   // x->y: site 1 warm, not hot
+  EXPECT_NEAR(b1.partial_lambda_at_A, 0.0, 1e-9); EXPECT_NEAR(b1.partial_lambda_at_X, 0.0, 1e-9);
+  EXPECT(b1.warm_sites.v == (std::vector<Site_interval>{{1, 2}}) && b1.hot_sites.empty() && b1.hot_muts_to_X.empty() && b1.hot_deltas_to_X.empty());
+  EXPECT(b2.A == r && b2.B == x && !b2.is_open && b2.T_to_X == 4.0);   // r->x: site 1 warm and hot
+  EXPECT_NEAR(b2.partial_lambda_at_A, mu(1) * nu(1) * qa(1, sA), 1e-9); EXPECT_NEAR(b2.partial_lambda_at_X, mu(1) * nu(1) * qa(1, sT), 1e-9);
+  EXPECT(b2.warm_sites.v == (std::vector<Site_interval>{{1, 2}}) && b2.hot_sites.v == b2.warm_sites.v);
+  EXPECT(b2.hot_muts_to_X == (Mutation_list{Mutation{sA, 1, sC, -0.5}, Mutation{sC, 1, sT, 2.0}}));
+  EXPECT(b2.hot_deltas_to_X.size() == 1 && b2.hot_deltas_to_X.at(1) == (Site_delta{sA, sT}));
+  EXPECT_NEAR(g.log_alpha_mut, -mu_JC * 2.0 + -std::log(P_JC(sA, sA, 2.0))
+              + -mu_JC * 0.5 + std::log(mu_JC / 3) + -mu_JC * 0.5 + -mu_JC * 1.0 + -mu_JC * 1.0 + std::log(mu_JC / 3) + -mu_JC * 1.0 + -std::log(P_JC(sA, sT, 4.0)), 1e-9);
+  EXPECT_NEAR(g.delta_log_G, -mu(0) * nu(0) * qa(0, sA) * 2.0
+              + -mu(1) * nu(1) * qa(1, sA) * 0.5 + std::log(mu(1) * nu(1) * qab(1, sA, sC)) + -mu(1) * nu(1) * qa(1, sC) * 0.5 + -mu(1) * nu(1) * qa(1, sC) * 1.0
+              + -mu(1) * nu(1) * qa(1, sC) * 1.0 + std::log(mu(1) * nu(1) * qab(1, sC, sT)) + -mu(1) * nu(1) * qa(1, sT) * 1.0, 1e-9);
+}
+TEST(spr_move_precarious_with_root_analyze_graft_a) {
+  auto C = precarious_with_root(); auto& evo = C.evo;
+  auto mu = [&](int l) { return evo.mu_l(l); }; auto nu = [&](int l) { return evo.nu_l[l]; };
+  auto qa = [&](int l, State s) { return evo.q_l_a(l, s); }; auto qab = [&](int l, State s, State t) { return evo.q_l_ab(l, s, t); };
+  auto spr = C.spr(true);
+  auto g = spr.analyze_graft(a_);
+  EXPECT(g.branch_infos.size() == 3);
+  auto& b0 = g.branch_infos[0]; auto& b1 = g.branch_infos[1]; auto& b2 = g.branch_infos[2];
+  EXPECT(b0.A == x_ && b0.B == a_ && !b0.is_open && b0.T_to_X == 1.0);   // x->a: sites 0 and 1 warm, site 0 hot
+  EXPECT_NEAR(b0.partial_lambda_at_A, mu(0) * nu(0) * qa(0, sA), 1e-9); EXPECT_NEAR(b0.partial_lambda_at_X, mu(0) * nu(0) * qa(0, sA), 1e-9);
+  EXPECT(b0.warm_sites.contains(0) && b0.warm_sites.contains(1) && b0.hot_sites.contains(0) && !b0.hot_sites.contains(1));
+  EXPECT(b0.hot_muts_to_X.empty() && b0.hot_deltas_to_X.empty());
+  EXPECT(b1.A == r_ && b1.B == x_ && !b1.is_open && b1.T_to_X == 2.0);   // r->x: site 1 warm, not hot
+  EXPECT(b1.partial_lambda_at_A == 0.0 && b1.partial_lambda_at_X == 0.0);
+  EXPECT(b1.warm_sites.v == (std::vector<Site_interval>{{1, 2}}) && b1.hot_sites.empty() && b1.hot_muts_to_X.empty() && b1.hot_deltas_to_X.empty());
+  EXPECT(b2.A == k_no_node && b2.B == r_ && b2.is_open && b2.T_to_X == 2.0);   // *->r: site 1 warm and hot, an open path
+  EXPECT_NEAR(b2.partial_lambda_at_A, mu(1) * nu(1) * qa(1, sA), 1e-9); EXPECT_NEAR(b2.partial_lambda_at_X, mu(1) * nu(1) * qa(1, sC), 1e-9);
+  EXPECT(b2.warm_sites.v == (std::vector<Site_interval>{{1, 2}}) && b2.hot_sites.v == b2.warm_sites.v);
+  EXPECT(b2.hot_muts_to_X == (Mutation_list{Mutation{sA, 1, sC, -0.5}}) && b2.hot_deltas_to_X.empty());   // open path: no hot deltas
+  EXPECT_NEAR(g.log_alpha_mut, -mu_JC * 1.0 + -std::log(P_JC(sA, sA, 1.0)) + -mu_JC * 0.5 + std::log(mu_JC / 3) + -mu_JC * 0.5 + -mu_JC * 1.0, 1e-9);
+  EXPECT_NEAR(g.delta_log_G, -mu(0) * nu(0) * qa(0, sA) * 1.0
+              + -mu(1) * nu(1) * qa(1, sA) * 0.5 + std::log(mu(1) * nu(1) * qab(1, sA, sC)) + -mu(1) * nu(1) * qa(1, sC) * 0.5 + -mu(1) * nu(1) * qa(1, sC) * 1.0
+              + std::log(evo.pi_l_a(1, sA) / evo.pi_l_a(1, sC)), 1e-9);
+}
+// ---- the two superfluous-mutation fixtures (spr_move_tests.cpp:568-615, 719-783): a mutation and its reversal on the path of the graft
+static SprCtx superfluous_at_root() {   // :568-615: r (AANN) with tips x (T at site 0 from -0.5) and s (T at site 0 from 1.0)
+  enum { r = 0, x = 1, s = 2 };
+  Phylo_tree t(3); t.root = r; t.ref_sequence = {sA, sC, sA, sA};
+  set_inner(t, r, k_no_node, x, s, -1.0); miss(t, r, {{2, sA}, {3, sA}}); t.at(r).mutations = {Mutation{sC, 1, sA, NEG}};
+  set_tip(t, x, r, 0.0); t.at(x).mutations = {Mutation{sA, 0, sT, -0.5}};
+  set_tip(t, s, r, 3.0); t.at(s).mutations = {Mutation{sA, 0, sT, 1.0}};
+  return SprCtx(std::move(t), fixture_evo());
+}
+static SprCtx superfluous_not_at_root() {   // :719-783: x carries A0T, both its tips a and b carry T0A back; c is plain
+  Phylo_tree t(5); t.root = r_; t.ref_sequence = {sA, sC, sA, sA};
+  set_inner(t, r_, k_no_node, x_, c_, -1.0); miss(t, r_, {{2, sA}, {3, sA}}); t.at(r_).mutations = {Mutation{sC, 1, sA, NEG}};
+  set_inner(t, x_, r_, a_, b_, 0.0); t.at(x_).mutations = {Mutation{sA, 0, sT, -0.5}};
+  set_tip(t, a_, x_, 1.0); t.at(a_).mutations = {Mutation{sT, 0, sA, 0.5}};
+  set_tip(t, b_, x_, 2.0); t.at(b_).mutations = {Mutation{sT, 0, sA, 1.0}};
+  set_tip(t, c_, r_, 3.0);
+  return SprCtx(std::move(t), fixture_evo());
+}
+TEST(spr_move_superfluous_mutation_at_root) {
+  enum { r = 0, x = 1, s = 2 };
+  auto C = superfluous_at_root(); auto& evo = C.evo;
+  EXPECT(check_phylo_tree_integrity(C.tree).empty());
+  auto mu = [&](int l) { return evo.mu_l(l); }; auto nu = [&](int l) { return evo.nu_l[l]; };
+  auto qa = [&](int l, State a) { return evo.q_l_a(l, a); }; auto qab = [&](int l, State a, State b) { return evo.q_l_ab(l, a, b); };
+  { auto spr = C.spr(true);
+    auto g = spr.analyze_graft(x);   // :617-713
+    EXPECT(g.branch_infos.size() == 3);
+    auto& PX = g.branch_infos[Spr_graft::k_branch_info_P_X]; auto& PS = g.branch_infos[Spr_graft::k_branch_info_P_S]; auto& SPX = g.branch_infos[Spr_graft::k_branch_info_S_P_X];
+    EXPECT(PX.A == r && PX.B == x && PX.is_open && PX.T_to_X == 1.0 && PX.partial_lambda_at_A == 0.0 && PX.partial_lambda_at_X == 0.0);   // no site is present only in P->X
+    EXPECT(PX.warm_sites.empty() && PX.hot_sites.empty() && PX.hot_muts_to_X.empty() && PX.hot_deltas_to_X.empty());
+    EXPECT(PS.A == r && PS.B == s && PS.is_open && PS.T_to_X == 4.0 && PS.partial_lambda_at_A == 0.0 && PS.partial_lambda_at_X == 0.0);   // nor only in P->S
+    EXPECT(PS.warm_sites.empty() && PS.hot_sites.empty() && PS.hot_muts_to_X.empty() && PS.hot_deltas_to_X.empty());
+    EXPECT(SPX.A == s && SPX.B == r && !SPX.is_open && SPX.T_to_X == 5.0);   // sites 0 and 1 all the way along S->P->X
+    EXPECT_NEAR(SPX.partial_lambda_at_A, mu(0) * nu(0) * qa(0, sT) + mu(1) * nu(1) * qa(1, sA), 1e-9);
+    EXPECT_NEAR(SPX.partial_lambda_at_X, mu(0) * nu(0) * qa(0, sT) + mu(1) * nu(1) * qa(1, sA), 1e-9);
+    EXPECT(SPX.warm_sites.v == (std::vector<Site_interval>{{0, 2}}) && SPX.hot_sites.v == SPX.warm_sites.v);
+    EXPECT(SPX.hot_muts_to_X == (Mutation_list{Mutation{sT, 0, sA, -3.0}, Mutation{sA, 0, sT, -0.5}}));   // T->A then A->T: superfluous, so ...
+    EXPECT(SPX.hot_deltas_to_X.empty());                                                                       // ... no net delta
+    EXPECT_NEAR(g.log_alpha_mut, -mu_JC * 2.0 + std::log(mu_JC / 3) + -mu_JC * 2.0 + -mu_JC * 0.5 + std::log(mu_JC / 3) + -mu_JC * 0.5 + -std::log(P_JC(sT, sT, 5.0))
+                + -mu_JC * 5.0 + -std::log(P_JC(sA, sA, 5.0)), 1e-9);
+    EXPECT_NEAR(g.delta_log_G, -mu(0) * nu(0) * qa(0, sA) * 2.0 + std::log(mu(0) * nu(0) * qab(0, sA, sT)) + -mu(0) * nu(0) * qa(0, sT) * 2.0
+                + -mu(0) * nu(0) * qa(0, sA) * 0.5 + std::log(mu(0) * nu(0) * qab(0, sA, sT)) + -mu(0) * nu(0) * qa(0, sT) * 0.5
+                + std::log(evo.pi_l_a(0, sA) / evo.pi_l_a(0, sT))
+                + -mu(1) * nu(1) * qa(1, sA) * 4.0 + -mu(1) * nu(1) * qa(1, sA) * 1.0, 1e-9); }
+  run_propose_new_graft_test(C, 1000, true);   // :715-717
+  for (auto& k : std::vector<Case>{{x, s, -0.5}, {x, r, -1.5}, {s, x, -0.5}, {s, r, -1.5}})   // :1673-1690
+    for (int seed = 0; seed < 200; ++seed) { Rng rng; rng.key = seed + 12345; run_full_spr_move_test(C, k.X, k.SS, k.t, rng); }
+}
+TEST(spr_move_superfluous_mutation_not_at_root) {
+  auto C = superfluous_not_at_root(); auto& evo = C.evo;
+  EXPECT(check_phylo_tree_integrity(C.tree).empty());
+  auto mu = [&](int l) { return evo.mu_l(l); }; auto nu = [&](int l) { return evo.nu_l[l]; };
+  auto qa = [&](int l, State a) { return evo.q_l_a(l, a); }; auto qab = [&](int l, State a, State b) { return evo.q_l_ab(l, a, b); };
+  { auto spr = C.spr(true);
+    auto g = spr.analyze_graft(a_);   // :785-842
+    EXPECT(g.branch_infos.size() == 1);
+    auto& b0 = g.branch_infos[0];
+    EXPECT(b0.A == x_ && b0.B == a_ && !b0.is_open && b0.T_to_X == 1.0);
+    EXPECT_NEAR(b0.partial_lambda_at_A, mu(0) * nu(0) * qa(0, sT) + mu(1) * nu(1) * qa(1, sA), 1e-9);
+    EXPECT_NEAR(b0.partial_lambda_at_X, mu(0) * nu(0) * qa(0, sA) + mu(1) * nu(1) * qa(1, sA), 1e-9);
+    EXPECT(b0.warm_sites.contains(0) && b0.warm_sites.contains(1) && b0.hot_sites.contains(0) && b0.hot_sites.contains(1));
+    EXPECT(b0.hot_muts_to_X == (Mutation_list{Mutation{sT, 0, sA, 0.5}}));
+    EXPECT(b0.hot_deltas_to_X.size() == 1 && b0.hot_deltas_to_X.at(0) == (Site_delta{sT, sA}));
+    EXPECT_NEAR(g.log_alpha_mut, -mu_JC * 0.5 + std::log(mu_JC / 3) + -mu_JC * 0.5 + -std::log(P_JC(sT, sA, 1.0)) + -mu_JC * 1.0 + -std::log(P_JC(sA, sA, 1.0)), 1e-9);
+    EXPECT_NEAR(g.delta_log_G, -mu(0) * nu(0) * qa(0, sT) * 0.5 + std::log(mu(0) * nu(0) * qab(0, sT, sA)) + -mu(0) * nu(0) * qa(0, sA) * 0.5 + -mu(1) * nu(1) * qa(1, sA) * 1.0, 1e-9); }
+  run_propose_new_graft_test(C, 1000, true);   // :844-846
+  for (auto& k : std::vector<Case>{{a_, b_, 0.6}, {a_, x_, -0.4}, {a_, c_, 0.5}, {a_, r_, -1.5}, {b_, a_, 0.6}, {b_, x_, -0.4}, {b_, c_, 0.5}, {b_, r_, -1.5},
+                                   {c_, x_, -0.4}, {c_, r_, -1.3}, {c_, a_, 0.5}, {c_, b_, 1.0}, {x_, c_, -0.4}, {x_, r_, -1.6}})   // :1692-1720
     for (int seed = 0; seed < 200; ++seed) { Rng rng; rng.key = seed + 12345; run_full_spr_move_test(C, k.X, k.SS, k.t, rng); }
 }
 TEST(spr_move_tricky_rooty_properties) { auto C = tricky_rooty(); run_propose_new_graft_test(C, 1000, true); }
@@ -1306,6 +1496,50 @@ TEST(sample_mutational_history_constraints) {
     for (auto& m : hh) { if (cur.count(m.site)) EXPECT(cur[m.site] == m.from); cur[m.site] = m.to; }
     for (auto& [l, s] : cur) EXPECT(s == sA);
   }
+}
+
+// spr_move_tests.cpp:1795-1961: on the simple fixture, 25 000 histories of length T = 1 / mu_JC ending at a random point of the tree,
+// from the target start sequence TGCA: site 3 is A at both ends everywhere, so every mutation there is part of an A ~> A excursion --
+// "unusual" (any mutation at site 3) with probability (p* - p_0) / p*, "super-unusual" (more than two) with (p* - p_0 - p_1 - p_2) / p*,
+// where p_m = (mu T)^m e^(-mu T) (P^m)_AA / m!: 0.17828634147519676 and 0.04133406505439621 at mu T = 1 (the reference's numbers,
+// :1947-1952), within three binomial standard errors as there (the generator differs, so the counts do, the frequencies must not).
+TEST(sample_mutational_history_unusual_trajectory_frequencies) {
+  SprCtx C(complex_tree(true), fixture_evo());
+  const int L = C.tree.num_sites(), num_histories = 25000;
+  const std::vector<State> target_start_seq{sT, sG, sC, sA};
+  int num_unusual = 0, num_super_unusual = 0;
+  // the theory, recomputed: (P^m)_AA for the jump chain of JC69 is 1/4 + 3/4 (-1/3)^m
+  { double pstar = 0, p[3] = {0, 0, 0}, f = 1;
+    for (int m = 0; m < 40; ++m) { if (m > 0) f *= m; double pm = std::exp(-1.0) / f * (0.25 + 0.75 * std::pow(-1.0 / 3.0, m)); pstar += pm; if (m < 3) p[m] = pm; }
+    EXPECT_NEAR((pstar - p[0]) / pstar, 0.17828634147519676, 1e-9); EXPECT_NEAR((pstar - p[0] - p[1] - p[2]) / pstar, 0.04133406505439621, 1e-9); }
+  for (int seed = 0; seed < num_histories; ++seed) {
+    Rng rng; rng.key = seed + 12345;
+    int branch = r_; while (branch == r_) branch = rng.uniform_int(C.tree.size());
+    const double t_end = rng.uniform_co(C.tree.branch_begin_t(branch), C.tree.at(branch).t);
+    Phylo_tree_loc end_loc{branch, t_end};
+    const double T = 1.0 / mu_JC;
+    auto end_seq = target_start_seq;
+    for (int l = 0; l < L; ++l) end_seq[l] = calc_site_state_at(C.tree, end_loc, l);
+    EXPECT(end_seq[3] == sA);
+    Site_deltas deltas;
+    for (int l = 0; l < L; ++l) if (target_start_seq[l] != end_seq[l]) deltas.insert({l, Site_delta{target_start_seq[l], end_seq[l]}});
+    auto h = sample_mutational_history(L, T, mu_JC, deltas, rng);
+    adjust_mutational_history(h, deltas, C.tree, end_loc);
+    auto seq = target_start_seq; double prev_t = -1e300; int at3 = 0;
+    for (auto& m : h) {
+      EXPECT(m.t >= prev_t && m.t >= t_end - T && m.t <= t_end); prev_t = m.t;
+      EXPECT(seq[m.site] == m.from); seq[m.site] = m.to;
+      if (m.site == 3) ++at3;
+    }
+    EXPECT(seq == end_seq);
+    if (at3 > 0) ++num_unusual;
+    if (at3 > 2) ++num_super_unusual;
+  }
+  const double pu = num_unusual / (double)num_histories, eu = std::sqrt(pu * (1 - pu) / num_histories);
+  const double ps = num_super_unusual / (double)num_histories, es = std::sqrt(ps * (1 - ps) / num_histories);
+  std::printf("  unusual %.5f +- %.5f (expected 0.17829), super-unusual %.5f +- %.5f (expected 0.04133)\n", pu, eu, ps, es);
+  EXPECT_NEAR(pu, 0.17828634147519676, 3 * eu);
+  EXPECT_NEAR(ps, 0.04133406505439621, 3 * es);
 }
 
 // =================================================================================================

@@ -11,10 +11,16 @@ the numbers.  Covered:
                                        constructor arguments the reference rejects (std::invalid_argument);
   * tests/interval_set_tests.cpp       inserts, contains, merge, intersect, subtract, is_subset_of, slow_elements;
   * tests/scalable_coalescent_tests.cpp  the `log_prior` case: node times, tip flags and the three expected priors;
-  * tests/phylo_tree_tests.cpp         the fixture tree's topology and times, and the find_MRCA_of / descends_from tables over its nodes.
+  * tests/phylo_tree_tests.cpp         the fixture tree's topology and times, and the find_MRCA_of / descends_from tables over its nodes;
+  * tests/spr_move_tests.cpp           all six fixture trees with their evolution model, and every expectation of the nine
+                                       analyze_graft_* tests (branch infos, partial lambdas, warm / hot sites, hot mutations and
+                                       deltas, log_alpha_mut, delta_log_G -- the closed-form right-hand sides evaluated), of the
+                                       tricky rooty graft's peel / closed-mutations / peel-and-reapply tests, the (X, SS, t) cases of
+                                       the full_spr_move tests, and the parameters and expected frequencies of the
+                                       sample_mutational_history test.
 
-Not covered here (kept as C++ in oracle/orc_tests.cpp, which restates the fixtures): tests that build trees
-(tree_editing, spr_study, spr_move, phylo_tree_calc, missation_map, site_deltas), printing and derivative tests (off the path).
+Not covered here (kept as C++ in oracle/orc_tests.cpp, which restates the fixtures): the other tests that build trees
+(tree_editing, spr_study, phylo_tree_calc, missation_map, site_deltas), printing and derivative tests (off the path).
 Usage: python tests/golden/make_reference_expectations.py [/root/reference]"""
 import json
 import math
@@ -251,14 +257,198 @@ def phylo_tree_query_cases():
             "find_MRCA_of": mrca, "find_MRCA_of_all_times_equal": mrca_eq, "descends_from": desc}
 
 
+# ---- tests/spr_move_tests.cpp ---------------------------------------------------------------------------------------------
+STATE = {"rA": 0, "rC": 1, "rG": 2, "rT": 3}
+NEG_DBL_MAX = -1.7976931348623157e308
+FLT_MAX = 3.4028234663852886e38
+
+
+def _block_after(src, start):
+    """Text of the {...} block whose opening brace is the first '{' at or after `start`; returns (text, end index)."""
+    i = src.index("{", start)
+    depth, j = 1, i + 1
+    while depth:
+        depth += {"{": 1, "}": -1}.get(src[j], 0)
+        j += 1
+    return src[i + 1: j - 1], j
+
+
+def _num(tok):
+    tok = tok.strip()
+    if tok in ("-std::numeric_limits<double>::max()",): return NEG_DBL_MAX
+    if tok in ("-std::numeric_limits<float>::max()",): return -FLT_MAX
+    if tok in ("+std::numeric_limits<float>::max()", "std::numeric_limits<float>::max()"): return FLT_MAX
+    return float(tok)
+
+
+def _mutations(text):
+    """[[from, site, to, t]] of every Mutation{rX, site, rY, t} in `text`, in order."""
+    return [[STATE[a], int(l), STATE[b], _num(t)] for a, l, b, t in re.findall(r"Mutation\{(r[ACGT]),\s*(\d+),\s*(r[ACGT]),\s*([^}]*)\}", text)]
+
+
+def _missations(text):
+    return [[int(l), STATE[a]] for l, a in re.findall(r"Missation\{(\d+),\s*(r[ACGT])\}", text)]
+
+
+def _states(text):
+    return [STATE[x] for x in re.findall(r"r[ACGT]", text)]
+
+
+def spr_move_cases():
+    path = os.path.join(REF, "tests", "spr_move_tests.cpp")
+    raw = open(path).read()
+    src = strip_comments(raw)
+    # -- the base fixture: reference sequence, the two-partition model, mu_JC
+    base_txt, _ = _block_after(src, src.index("class Spr_move_test_base"))
+    base_ref = _states(re.search(r"Real_sequence ref_sequence\{([^}]*)\}", base_txt).group(1))
+    base_pfs = [int(x) for x in re.search(r"make_global_evo_model\(\{([^}]*)\}\)", base_txt).group(1).split(",")]
+    mu_JC = float(re.search(r"double mu_JC = ([0-9.]+);", base_txt).group(1))
+    q = [[[0.0] * 4 for _ in range(4)] for _ in range(2)]
+    for p_, a, b, e in re.findall(r"q_(\d)_ab\[(r[ACGT])\]\[(r[ACGT])\] = ([^;]*);", base_txt):
+        q[int(p_)][STATE[a]][STATE[b]] = cxx_eval(e, {})
+    base_nu = [float(x) for x in re.search(r"evo\.nu_l = \{([^}]*)\};", base_txt).group(1).split(",")]
+    mu, pi = [0.0, 0.0], [None, None]
+    for p_, body in re.findall(r"evo\.partition_evo_model\[(\d)\] = \{(.*?)\};", base_txt, flags=re.S):
+        mu[int(p_)] = float(re.search(r"\.mu = ([0-9.]+)", body).group(1))
+        pi[int(p_)] = [float(x) for x in re.search(r"\.pi_a = \{([^}]*)\}", body).group(1).split(",")]
+    for p_ in range(2):
+        for a in range(4):
+            assert abs(sum(q[p_][a])) < 1e-12, "rows of a rate matrix sum to zero"
+    # -- the fixture classes
+    fixtures = {}
+    for m in re.finditer(r"class (Spr_move_\w+_test) : public Spr_move_test_base \{", src):
+        name = m.group(1)
+        txt, _ = _block_after(src, m.start())
+        idx = {n: int(i) for n, i in re.findall(r"static constexpr Node_index (\w+) = (\d+);", txt)}
+        idx["k_no_node"] = -1
+        n = int(re.search(r"Phylo_tree tree\{(\d+)\};", txt).group(1))
+        ref, pfs, nu = list(base_ref), list(base_pfs), list(base_nu)
+        mm = re.search(r"tree\.ref_sequence = ref_sequence = \{([^}]*)\};", txt)
+        if mm: ref = _states(mm.group(1))
+        mm = re.search(r"evo\.partition_for_site = \{([^}]*)\};", txt)
+        if mm: pfs = [int(x) for x in mm.group(1).split(",")]
+        mm = re.search(r"evo\.nu_l = \{([^}]*)\};", txt)
+        if mm: nu = [float(x) for x in mm.group(1).split(",")]
+        nodes = [{"parent": -1, "children": [], "t": 0.0, "t_min": 0.0, "t_max": 0.0, "mutations": [], "missations": [], "name": ""} for _ in range(n)]
+        for st in statements(_block_after(txt, txt.index(name + "()"))[0]):
+            mm = re.search(r"tree\.at\((\w+)\)\.(\w+) = (.*)$", st)
+            if not mm: continue
+            nd, field, val = nodes[idx[mm.group(1)]], mm.group(2), mm.group(3)
+            if field == "parent": nd["parent"] = idx[val.strip()]
+            elif field == "children": nd["children"] = [idx[x.strip()] for x in val.strip()[1:-1].split(",") if x.strip()]
+            elif field == "name": nd["name"] = val.strip().strip('"')
+            elif field == "mutations": nd["mutations"] = _mutations(val)
+            elif field == "missations": nd["missations"] = _missations(val)
+            elif field in ("t", "t_min", "t_max"):
+                v = _num(val.split("=")[-1])
+                for f in re.findall(r"\.(t_min|t_max)\b", val) + [field]: nd[f] = v
+        root = idx[re.search(r"tree\.root = (\w+);", txt).group(1)]
+        fixtures[name] = {"names": {k: v for k, v in idx.items() if k != "k_no_node"}, "root": root, "ref_sequence": ref, "nodes": nodes,
+                          "evo": {"partition_for_site": pfs, "nu_l": nu, "mu": mu, "pi": pi, "q": q}}
+    # -- the tests
+    BI_INDEX = {"Spr_graft::k_branch_info_P_X": 0, "Spr_graft::k_branch_info_P_S": 1, "Spr_graft::k_branch_info_S_P_X": 2}
+    graft_tests, peel_tests, move_cases, history = [], [], [], None
+    for m in re.finditer(r"^TEST_F\((\w+),\s*(\w+)\)\s*\{", src, flags=re.M):
+        fixture, test = m.group(1), m.group(2)
+        body, _ = _block_after(src, m.end() - 1)
+        line = src[: m.start()].count("\n") + 1
+        fx = fixtures[fixture]; idx = dict(fx["names"]); idx["k_no_node"] = -1
+        evo = fx["evo"]
+        env = {"mu_JC": mu_JC, "rA": 0, "rC": 1, "rG": 2, "rT": 3,
+               "mu_l": lambda l: evo["mu"][evo["partition_for_site"][l]], "nu_l": lambda l: evo["nu_l"][l],
+               "pi_l_a": lambda l, a: evo["pi"][evo["partition_for_site"][l]][a],
+               "q_l_ab": lambda l, a, b: evo["q"][evo["partition_for_site"][l]][a][b],
+               "q_l_a": lambda l, a: -evo["q"][evo["partition_for_site"][l]][a][a],
+               "P_JC": lambda a, b, t: (1.0 + 3. / 4 * math.expm1(-4. / 3. * mu_JC * t)) if a == b else (-1. / 4. * math.expm1(-4. / 3. * mu_JC * t))}
+        sts = statements(body)
+        if test.startswith("analyze_graft") or test in ("peel_graft_X", "closed_mutations_graft_X", "peel_reapply_graft_X"):
+            ccr = True
+            for st in sts:
+                mm = re.match(r"auto can_change_root = (true|false)$", st)
+                if mm: ccr = mm.group(1) == "true"
+            ctor = [st for st in sts if st.startswith("auto spr = Spr_move{")][0]
+            third = split_args(ctor[ctor.index("{") + 1: ctor.rindex("}")])[2]
+            can_change_root = ccr if third == "can_change_root" else (third == "true")
+            X = idx[re.search(r"spr\.analyze_graft\((\w+)\)", body).group(1)]
+        if test.startswith("analyze_graft"):
+            alias, bis, out = {}, {}, {"fixture": fixture, "test": test, "line": line, "can_change_root": can_change_root, "X": X}
+            skipped = 0
+            for st in sts:
+                mm = re.match(r"const auto& (\w+) = analysis\.branch_infos\[(.*)\]$", st)
+                if mm:
+                    k = BI_INDEX.get(mm.group(2)); k = int(mm.group(2)) if k is None else k
+                    alias[mm.group(1)] = k; bis[k] = {"index": k}
+                    continue
+                mm = re.match(r"EXPECT_THAT\(analysis\.branch_infos, testing::SizeIs\((\d+)\)\)$", st)
+                if mm: out["num_branch_infos"] = int(mm.group(1)); continue
+                mm = re.match(r"EXPECT_THAT\(analysis\.(log_alpha_mut|delta_log_G), testing::DoubleNear\((.*), ([0-9.e+-]+)\)\)$", st)
+                if mm: out[mm.group(1)] = cxx_eval(mm.group(2), env); out["tol"] = float(mm.group(3)); continue
+                mm = re.match(r"EXPECT_THAT\((?:estd::ranges::to_vec\()?(\w+)\.(\w+?)(?:\.slow_elements\(\)\))?, testing::(.*)\)$", st)
+                if mm and mm.group(1) in alias:
+                    b, field, matcher = bis[alias[mm.group(1)]], mm.group(2), mm.group(3)
+                    if field in ("A", "B"): b[field] = idx[re.match(r"Eq\((\w+)\)", matcher).group(1)]
+                    elif field == "is_open": b[field] = matcher.startswith("IsTrue")
+                    elif field == "T_to_X": b[field] = float(re.match(r"Eq\(([0-9.]+)\)", matcher).group(1))
+                    elif field in ("partial_lambda_at_A", "partial_lambda_at_X"):
+                        mm2 = re.match(r"DoubleNear\((.*), ([0-9.e+-]+)\)$", matcher)
+                        b[field] = cxx_eval(mm2.group(1), env) if mm2 else float(re.match(r"Eq\(([0-9.]+)\)", matcher).group(1))
+                    elif field in ("warm_sites", "hot_sites"):
+                        c = b.setdefault(field, {})
+                        if matcher.startswith("ElementsAre("): c["intervals"] = parse_intervals(matcher)
+                        elif matcher.startswith("IsEmpty"): c["intervals"] = []
+                        elif matcher.startswith("IsSupersetOf("): c.setdefault("contains", []).extend(int(x) for x in re.findall(r"\d+", matcher))
+                        elif matcher.startswith("Contains("): c.setdefault("contains", []).extend(int(x) for x in re.findall(r"\d+", matcher))
+                        elif matcher.startswith("Not(testing::Contains("): c.setdefault("not_contains", []).extend(int(x) for x in re.findall(r"\d+", matcher))
+                        else: raise ValueError(st)
+                    elif field == "hot_muts_to_X": b[field] = _mutations(matcher)
+                    elif field == "hot_deltas_to_X": b[field] = [[int(l), STATE[a], STATE[c_]] for l, a, c_ in re.findall(r"site_deltas_entry\((\d+),\s*(r[ACGT]),\s*(r[ACGT])\)", matcher)]
+                    else: raise ValueError(st)
+                    continue
+                if st.startswith("EXPECT"): raise ValueError("unconverted expectation in %s.%s: %s" % (fixture, test, st))
+            out["branch_infos"] = [bis[k] for k in sorted(bis)]
+            assert len(out["branch_infos"]) == out["num_branch_infos"] and "log_alpha_mut" in out and "delta_log_G" in out, (fixture, test)
+            graft_tests.append(out)
+        elif test in ("peel_graft_X", "closed_mutations_graft_X", "peel_reapply_graft_X"):
+            out = {"fixture": fixture, "test": test, "line": line, "can_change_root": can_change_root, "X": X,
+                   "mode": 2 if "spr.apply_graft(analysis)" in body else 1, "nodes": {}}
+            for st in sts:
+                mm = re.match(r"EXPECT_THAT\(tree\.at\((\w+)\)\.mutations, testing::(.*)\)$", st)
+                if mm: out["nodes"].setdefault(str(idx[mm.group(1)]), {})["mutations_unordered"] = _mutations(mm.group(2)); continue
+                mm = re.match(r"EXPECT_THAT\(estd::ranges::to_vec\(tree\.at\((\w+)\)\.missations\.slow_elements\(ref_sequence\)\), testing::(.*)\)$", st)
+                if mm: out["nodes"].setdefault(str(idx[mm.group(1)]), {})["missations"] = _missations(mm.group(2)); continue
+                mm = re.match(r"EXPECT_THAT\(tree\.ref_sequence, testing::Eq\(Real_sequence\{(.*)\}\)\)$", st)
+                if mm: out["ref_sequence"] = _states(mm.group(1)); continue
+                if re.match(r"EXPECT_THAT\(tree\.ref_sequence, testing::Eq\(ref_sequence\)\)$", st): continue
+                mm = re.match(r"EXPECT_THAT\(spr\.count_closed_mutations\(analysis\), testing::Eq\((\d+)\)\)$", st)
+                if mm: out["count_closed_mutations"] = int(mm.group(1)); continue
+                mm = re.match(r"EXPECT_THAT\(spr\.summarize_closed_mutations\(analysis\), testing::UnorderedElementsAre\((.*)\)\)$", st)
+                if mm: out["closed_deltas"] = [[int(l), STATE[a], STATE[c_]] for l, a, c_ in re.findall(r"site_deltas_entry\((\d+),\s*(r[ACGT]),\s*(r[ACGT])\)", mm.group(1))]; continue
+                if st.startswith("EXPECT"): raise ValueError("unconverted expectation in %s.%s: %s" % (fixture, test, st))
+            peel_tests.append(out)
+        elif test == "full_spr_move":
+            cases = [[idx[a], idx[b], float(t)] for a, b, t in re.findall(r"Case\{(\w+),\s*(\w+),\s*(-?[0-9.]+)\}", body)]
+            seeds = int(re.search(r"seed != (\d+)", body).group(1))
+            move_cases.append({"fixture": fixture, "line": line, "cases": cases, "seeds": seeds})
+        elif test == "sample_mutational_history":
+            history = {"fixture": fixture, "line": line, "num_histories": int(re.search(r"is_debug_enabled \? [0-9']+ : ([0-9']+)", body).group(1).replace("'", "")),
+                       "target_start_seq": _states(re.search(r"target_start_seq = Real_sequence\{([^}]*)\}", body).group(1)),
+                       "mu_T": 1.0, "watched_site": int(re.search(r"m\.site == (\d+)", body).group(1)),
+                       "expected_p_unusual": float(re.search(r"expected_p_unusual = ([0-9.]+);", body).group(1)),
+                       "expected_p_super_unusual": float(re.search(r"expected_p_super_unusual = ([0-9.]+);", body).group(1)), "sigmas": 3}
+    assert len(graft_tests) == 9 and len(peel_tests) == 3 and len(move_cases) == 5 and history is not None, (len(graft_tests), len(peel_tests), len(move_cases))
+    return {"mu_JC": mu_JC, "states": "A C G T = 0 1 2 3; a mutation is [from, site, to, t], a missation [site, from], a delta [site, from, to]; node times of -1.797e308 / t_min, t_max of -+3.4e38 are the reference's -DBL_MAX / -+FLT_MAX",
+            "fixtures": fixtures, "analyze_graft": graft_tests, "peel_apply": peel_tests, "full_spr_move": move_cases, "sample_mutational_history": history}
+
+
 if __name__ == "__main__":
     pop, sk1 = pop_model_cases()
     iv, sk2 = interval_set_cases()
     sc = scalable_coalescent_case()
-    out = {"source": "expectations of the reference's tests/pop_model_tests.cpp, interval_set_tests.cpp, scalable_coalescent_tests.cpp, evaluated by tests/golden/make_reference_expectations.py",
-           "pop_model": pop, "interval_set": iv, "scalable_coalescent": sc, "phylo_tree_queries": phylo_tree_query_cases(),
+    out = {"source": "expectations of the reference's tests/pop_model_tests.cpp, interval_set_tests.cpp, scalable_coalescent_tests.cpp, phylo_tree_tests.cpp, spr_move_tests.cpp, evaluated by tests/golden/make_reference_expectations.py",
+           "pop_model": pop, "interval_set": iv, "scalable_coalescent": sc, "phylo_tree_queries": phylo_tree_query_cases(), "spr_move": spr_move_cases(),
            "not_converted": {"pop_model_tests.cpp": sk1, "interval_set_tests.cpp": sk2, "why": "accessors, printing, iterator-identity and derivative expectations (off the hot path)"}}
     json.dump(out, open(OUT, "w"), indent=0)
     print("pop_model cases %d (skipped %d) | interval_set cases %d (skipped %d) | scalable_coalescent stages %d" % (len(pop), sk1, len(iv), sk2, len(sc["stages"])))
+    print("spr_move: %d fixtures, %d analyze_graft tests, %d peel / apply tests, %d full_spr_move case lists" % (len(out["spr_move"]["fixtures"]), len(out["spr_move"]["analyze_graft"]), len(out["spr_move"]["peel_apply"]), len(out["spr_move"]["full_spr_move"])))
     from collections import Counter
     print(Counter(c["test"] for c in pop)); print(Counter(c["test"] for c in iv))

@@ -36,6 +36,8 @@ def lib():
             "orc_part_check": [E, C.c_int, C.c_char_p, C.c_int],
             "orc_Ttwiddle_l": [E, C.c_int, P(dbl)], "orc_num_muts_l": [E, P(C.c_int)], "orc_scalable_log_prior": [E, C.c_int, dbl, dbl, P(dbl)],
             "orc_tree_query": [E, C.c_int, C.c_int, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int)],
+            "orc_debug_graft": [E, C.c_int, C.c_int, dbl, C.c_int, C.c_int, dbl, P(dbl), C.c_int, P(C.c_int)], "orc_part_log_G": [E, C.c_int, P(dbl), P(dbl)],
+            "orc_debug_sample_history": [E, C.c_int, C.c_int, P(C.c_int), P(dbl), P(C.c_uint8), dbl, dbl, P(C.c_int), P(dbl), C.c_int, P(C.c_int)],
         }
         for n, a in sigs.items():
             f = getattr(L, n); f.argtypes = a; f.restype = C.c_int
@@ -104,6 +106,30 @@ class OracleEngine:
         na = np.ascontiguousarray(tables["num_active_parts"], np.int32)
         self._ck(self.L.orc_set_coalescent_part(self.h, C.byref(m), part, int(includes_tree_root), kb.shape[0], _ptr(kb, C.c_double), _ptr(kt, C.c_double), _ptr(k, C.c_double),
                                                 _ptr(ps, C.c_double), _ptr(na, C.c_int), tables["t_ref"], tables["t_step"], rng["counter"], rng["spare"], int(rng["has_spare"])), "set_coalescent_part")
+
+    def debug_graft(self, part, X, mu_proposal, mode=0, new_sibling=0, new_t_P=0.0):
+        """The oracle's Spr_move on one part, in the layout and with the modes of EmatBackend.debug_graft."""
+        from delphy_amd.engine import decode_graft_output
+        out = np.zeros(4096); n = C.c_int()
+        self._ck(self.L.orc_debug_graft(self.h, part, X, mu_proposal, mode, new_sibling, new_t_P, _ptr(out, C.c_double), out.shape[0], C.byref(n)), "debug_graft")
+        return decode_graft_output(out[: n.value], mode)
+
+    def debug_sample_history(self, part, branch, t_end, start_seq, T, mu):
+        branch = np.ascontiguousarray(branch, np.int32); t_end = np.ascontiguousarray(t_end, np.float64); seq = np.ascontiguousarray(start_seq, np.uint8)
+        n = branch.shape[0]; cap = 64 * n + 1024
+        counts = np.zeros(max(n, 1), np.int32); muts = np.zeros((cap, 4)); tot = C.c_int()
+        self._ck(self.L.orc_debug_sample_history(self.h, part, n, _ptr(branch, C.c_int), _ptr(t_end, C.c_double), _ptr(seq, C.c_uint8), T, mu,
+                                                 _ptr(counts, C.c_int), _ptr(muts, C.c_double), cap, C.byref(tot)), "debug_sample_history")
+        out, k = [], 0
+        for i in range(n):
+            out.append([[int(m[1]), int(m[0]), int(m[2]), float(m[3])] for m in muts[k: k + counts[i]]]); k += int(counts[i])
+        return out
+
+    def part_log_G(self, part):
+        """(log G as maintained incrementally, log G recomputed from scratch) of one part."""
+        a, b = C.c_double(), C.c_double()
+        self._ck(self.L.orc_part_log_G(self.h, part, C.byref(a), C.byref(b)), "part_log_G")
+        return a.value, b.value
 
     def recalc_derived(self):
         self._ck(self.L.orc_recalc_derived(self.h), "recalc_derived")

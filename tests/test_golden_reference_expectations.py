@@ -223,3 +223,156 @@ def test_tree_query_expectations_of_the_reference():
 def test_device_tree_queries_against_the_reference_expectations():
     """The same tables against the moves' own find_MRCA_of / descends_from on the device (emat_debug_tree_query)."""
     _tree_queries_through(d.EmatBackend)
+
+
+# ---- tests/spr_move_tests.cpp as data: graft analysis, peel / apply, whole re-attachments, the history sampler ----------------------
+import graft_golden as gg  # noqa: E402
+
+SM = G["spr_move"]
+
+
+def _with_fixture(engine_cls, fx, can_change_root, seed, fn):
+    e = engine_cls(len(fx["ref_sequence"]))
+    try:
+        gg.configure_fixture(e, fx, can_change_root, seed)
+        return fn(e)
+    finally:
+        e.close()
+
+
+def _analyze_graft_expectations_through(engine_cls):
+    """All nine analyze_graft_* tests of the reference (spr_move_tests.cpp:142-1433) and the tricky rooty graft's peel / closed-mutations /
+    peel-and-reapply tests (:1435-1516): the fixture as the engine's only part, the engine's own analysis, the reference's numbers."""
+    assert len(SM["analyze_graft"]) == 9 and len(SM["peel_apply"]) == 3
+    for t in SM["analyze_graft"]:
+        fx = SM["fixtures"][t["fixture"]]
+        r = _with_fixture(engine_cls, fx, t["can_change_root"], 1, lambda e: e.debug_graft(0, t["X"], SM["mu_JC"], 0))
+        gg.check_analysis(r["grafts"][0], t, "%s.%s (spr_move_tests.cpp:%d)" % (t["fixture"], t["test"], t["line"]))
+    for t in SM["peel_apply"]:
+        fx = SM["fixtures"][t["fixture"]]
+        r, tree = _with_fixture(engine_cls, fx, t["can_change_root"], 1, lambda e: (e.debug_graft(0, t["X"], SM["mu_JC"], t["mode"]), e.part_download(0)))
+        gg.check_peel_apply(r, tree, fx, t, "%s.%s (spr_move_tests.cpp:%d)" % (t["fixture"], t["test"], t["line"]))
+
+
+def test_analyze_graft_expectations_of_the_reference():
+    _analyze_graft_expectations_through(oracle_ffi.OracleEngine)
+
+
+@pytest.mark.gpu
+def test_device_graft_analysis_against_the_reference_expectations():
+    """The same numbers against the moves' own device code (emat_debug_graft): analyze_graft, peel_graft, apply_graft run on lane 0 of a
+    wavefront on the fixture's slab, as inside a chain -- not through the oracle."""
+    _analyze_graft_expectations_through(d.EmatBackend)
+
+
+def _full_spr_moves_through(engine_cls, seeds):
+    """run_full_spr_move_test (spr_move_tests.cpp:1518-1641) over the reference's (X, SS, t) cases of all five fixtures: analyze the old graft,
+    peel it, re-attach X above SS at t, propose a new graft from the random stream, apply it.  Then, as there: the tree is sound, log G moved
+    by exactly new.delta_log_G - old.delta_log_G, the incrementally kept lambda_i / missing-site counts equal a recomputation, every tip
+    still carries its sequence, and a fresh analysis of X finds the graft that was proposed."""
+    device = engine_cls is d.EmatBackend
+    done = 0
+    for lst in SM["full_spr_move"]:
+        fx = SM["fixtures"][lst["fixture"]]
+        ref = fx["ref_sequence"]
+        before = gg.tip_sequences(gg.fixture_tree(fx), ref)
+        assert lst["seeds"] == 200
+        for X, SS, t in lst["cases"]:
+            for seed in range(seeds):
+                def run(e):
+                    if device:
+                        e.recalc_derived()
+                    r = e.debug_graft(0, X, SM["mu_JC"], 3, SS, t)
+                    if device:
+                        e.check_derived(1.0)        # Subrun::check_derived_quantities on the device: lambda_i, log G (1e-6), missing-site counts
+                    else:
+                        inc, scratch = e.part_log_G(0)
+                        assert abs(inc - scratch) <= 1e-6, (lst["fixture"], X, SS, t, seed, inc, scratch)
+                    return r, e.part_download(0), e.debug_graft(0, X, SM["mu_JC"], 0)
+                r, tree, redux = _with_fixture(engine_cls, fx, True, seed + 12345, run)
+                what = "%s X=%d SS=%d t=%g seed %d" % (lst["fixture"], X, SS, t, seed)
+                assert len(r["grafts"]) == 2, what
+                gg.same_grafts(redux["grafts"][0], r["grafts"][1])
+                after = gg.tip_sequences(tree, ref)           # (also checks that every mutation starts from the state the sequence holds)
+                for tip, seq in before.items():
+                    assert np.array_equal(seq, after[tip]), (what, tip, seq, after[tip])
+                chk = oracle_ffi.OracleEngine(len(ref))
+                try:
+                    chk.set_ref_sequence(np.asarray(ref, np.uint8)); chk.set_hky(1e-3, 2.0, (0.25, 0.25, 0.25, 0.25)); chk.set_flags(10.0)
+                    chk.upload_parts([tree], [True], [1])
+                    rc, msg = chk.part_check(0)               # assert_phylo_tree_integrity
+                    assert rc == 0, (what, msg)
+                finally:
+                    chk.close()
+                P = int(tree.parent[X])
+                kids = {int(tree.child0[P]), int(tree.child1[P])}
+                assert tree.t[P] == t and X in kids and (SS in kids or SS == P), what      # (SS == P: P slid along its own branch)
+                done += 1
+    return done
+
+
+def test_full_spr_moves_of_the_reference_cases():
+    assert _full_spr_moves_through(oracle_ffi.OracleEngine, 20) == 73 * 20
+
+
+@pytest.mark.gpu
+def test_device_full_spr_moves_of_the_reference_cases():
+    """Spr_move::move + propose_new_graft + apply_graft as the device runs them inside an SPR move, on the reference's 73 cases."""
+    assert _full_spr_moves_through(d.EmatBackend, 6) == 73 * 6
+
+
+def _history_frequencies_through(engine_cls, num_histories):
+    """sample_mutational_history's statistical test (spr_move_tests.cpp:1795-1961): histories of length T = 1 / mu_JC ending at random points
+    of the simple fixture, from the start sequence TGCA; every history must be sorted, inside (t_end - T, t_end], and lead from the start
+    sequence to the tree's sequence at its end point; mutations at the watched site (A at both ends everywhere) make a history `unusual`
+    (any) or `super-unusual` (more than two), with the probabilities the reference derives, within its three binomial standard errors."""
+    h = SM["sample_mutational_history"]
+    fx = SM["fixtures"][h["fixture"]]
+    L = len(fx["ref_sequence"])
+    tree = gg.fixture_tree(fx)
+    rng = np.random.default_rng(20261003)
+    branch = rng.integers(0, tree.num_nodes - 1, num_histories).astype(np.int32)
+    branch = np.where(branch >= fx["root"], branch + 1, branch).astype(np.int32)        # any node but the root
+    lo, hi = tree.t[tree.parent[branch]], tree.t[branch]
+    t_end = lo + (hi - lo) * rng.random(num_histories)
+    T = h["mu_T"] / SM["mu_JC"]
+    start = np.asarray(h["target_start_seq"], np.uint8)
+    hist = _with_fixture(engine_cls, fx, True, 12345, lambda e: e.debug_sample_history(0, branch, t_end, start, T, SM["mu_JC"]))
+    # the tree's sequence at (branch, t): the tip sequences machinery on a tree cut there
+    def seq_at(b, t):
+        path, n = [], int(b)
+        while n >= 0:
+            path.append(n); n = int(tree.parent[n])
+        seq = np.array(fx["ref_sequence"], np.int64)
+        for n in reversed(path):
+            for k in range(int(tree.mut_offset[n]), int(tree.mut_offset[n + 1])):
+                if n != b or tree.mut_t[k] <= t:
+                    seq[int(tree.mut_site[k])] = tree.mut_to[k]
+        return seq
+    unusual = super_unusual = 0
+    for i in range(num_histories):
+        seq = start.astype(np.int64).copy()
+        prev = -np.inf
+        for fr, site, to, tm in hist[i]:
+            assert prev <= tm and t_end[i] - T <= tm <= t_end[i], (i, hist[i])
+            assert seq[site] == fr and fr != to, (i, hist[i]); seq[site] = to; prev = tm
+        end = seq_at(branch[i], t_end[i])
+        # sites missing at the end point have no defined state there; calc_site_state_at still answers for them from the lists above
+        assert np.array_equal(seq, end), (i, seq, end, hist[i])
+        at = sum(1 for m in hist[i] if m[1] == h["watched_site"])
+        unusual += at > 0; super_unusual += at > 2
+    pu, ps = unusual / num_histories, super_unusual / num_histories
+    eu, es = math.sqrt(pu * (1 - pu) / num_histories), math.sqrt(ps * (1 - ps) / num_histories)
+    assert abs(pu - h["expected_p_unusual"]) <= h["sigmas"] * eu, (pu, eu, h["expected_p_unusual"])
+    assert abs(ps - h["expected_p_super_unusual"]) <= h["sigmas"] * es, (ps, es, h["expected_p_super_unusual"])
+    return pu, ps
+
+
+def test_history_sampler_frequencies_of_the_reference():
+    _history_frequencies_through(oracle_ffi.OracleEngine, SM["sample_mutational_history"]["num_histories"])
+
+
+@pytest.mark.gpu
+def test_device_history_sampler_frequencies_of_the_reference():
+    """The device's own sample_mutational_history + adjust_mutational_history (emat_debug_sample_history), 25 000 histories."""
+    _history_frequencies_through(d.EmatBackend, SM["sample_mutational_history"]["num_histories"])

@@ -69,6 +69,28 @@ def test_site_rate_heterogeneity():
     run_parity(sc, 4, 2000, trace=2000, nu_l=nu)
 
 
+def test_site_rates_mostly_one_on_branches_of_more_than_32_mutations():
+    """A branch reform gathers log(mu nu q) from the LDS table for sites of rate 1 and takes a logarithm for the others, keeping
+    the 'needs a logarithm' flags of the first 32 mutations in a bit mask (reform_factors): a branch of more than 32 mutations
+    whose first 32 hold a site with nu != 1 and whose later ones hold none used to shift the mask by >= 32."""
+    import delphy_amd.engine as e
+    par = e.SynthParams(num_tips=14, num_sites=6000, tip_span=200.0, pop_n0=2000.0, mu=6e-6, gaps_per_tip=1, mean_gap_len=40, seed=4242)
+    par.pi, par.kappa = (0.31, 0.19, 0.21, 0.29), 5.0
+    tree, ref, tmax = e.make_synthetic_emat(par)
+    sc = make_scenario("C1", num_tips=14, num_sites=6000)
+    sc.tree, sc.ref, sc.t_max_tip, sc.mu = tree, ref, tmax, par.mu
+    sc.pop = d.PopModel.exp(tmax, 2000.0, 0.0, 0.0)
+    nu = np.ones(6000)
+    shaped = 0
+    for n in range(tree.num_nodes):
+        sites = tree.mut_site[tree.mut_offset[n]:tree.mut_offset[n + 1]]
+        if sites.shape[0] > 32 and n != tree.root and sites[0] not in sites[32:] and np.all(nu[sites[32:]] == 1.0):
+            nu[sites[0]] = 1.7; shaped += 1
+    assert shaped >= 2, "the scenario must hold branches of more than 32 mutations (has %d)" % shaped
+    run_parity(sc, 1, 3000, trace=3000, nu_l=nu, topology=False)
+    run_parity(sc, 2, 1500, trace=1500, nu_l=nu)
+
+
 def _variant_counts(sc, lds_max, monkeypatch):
     import ctypes as C
     if lds_max is None:
