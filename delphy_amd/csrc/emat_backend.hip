@@ -2350,6 +2350,7 @@ emat_status emat_debug_graft(emat_backend* h, int32_t part_id, int32_t X, double
   emat_status st = emat_synchronize(h); if (st) return st;
   st = sync_model_to_device(h); if (st) return st;
   st = materialize(h); if (st) return st;
+  if (!h->derived_valid) { st = launch_recalc(h); if (st) return st; }   // the analysis starts from the nodes' lambda_i and missing-site counts, as a move does
   DevBuf<double> dout; DevBuf<int32_t> dlen;
   HIP_TRY(dout.alloc((size_t)out_cap)); HIP_TRY(dlen.alloc(1));
   KernelArgs ka = make_args(h);
@@ -2375,6 +2376,7 @@ emat_status emat_debug_sample_history(emat_backend* h, int32_t part_id, int32_t 
   emat_status st = emat_synchronize(h); if (st) return st;
   st = sync_model_to_device(h); if (st) return st;
   st = materialize(h); if (st) return st;
+  if (!h->derived_valid) { st = launch_recalc(h); if (st) return st; }
   DevBuf<int32_t> db, dc, ds; DevBuf<double> dt, dm; DevBuf<uint8_t> dseq;
   HIP_TRY(db.upload(branch, (size_t)std::max(n, 1))); HIP_TRY(dt.upload(t_end, (size_t)std::max(n, 1))); HIP_TRY(dseq.upload(start_seq, (size_t)h->cfg.num_sites));
   HIP_TRY(dc.alloc((size_t)std::max(n, 1))); HIP_TRY(dm.alloc((size_t)std::max(muts_cap, 1) * 4)); HIP_TRY(ds.alloc(2));
