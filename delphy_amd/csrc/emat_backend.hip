@@ -673,6 +673,32 @@ __global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY k_debug_sample_history(
   status[1] = written;
 }
 
+// test hook (emat_debug_edit): one tree-editing session on node X of one part's slab, step by step as the caller lists them
+// (Tree_editing_session, reference tree_editing.cpp:7-302): 0 slide_P_along_branch(t), 1 hop_up, 2 flip, 3 hop_down(node); then end().
+__global__ void __launch_bounds__(k_wave) EMAT_OCCUPANCY k_debug_edit(KernelArgs a, int part, int X, int n_ops, const int32_t* op_kind, const int32_t* op_node, const double* op_t, int32_t* status) {
+  __shared__ __attribute__((aligned(16))) double lds_tables[k_lds_tables_bytes / 8];
+  const int lane = threadIdx.x;
+  uint8_t* slab = a.slabs + a.slab_off[part];
+  const double* tables = stage_tables(a, lds_tables, lane);
+  __syncthreads();
+  if (lane != 0) return;
+  dev::Ctx c;
+  init_ctx(c, slab, slab, a, tables);
+  dev::sc_reset(c);
+  dev::Edit e;
+  int cap = 8;
+  for (int i = 0; i < c.H->n_nodes; ++i) cap += dev::nmuts(c, i);
+  dev::edit_begin(c, e, X, cap);
+  for (int i = 0; i < n_ops && !c.failed; ++i) {
+    if (op_kind[i] == 0) dev::edit_slide_P_along_branch(c, e, op_t[i]);
+    else if (op_kind[i] == 1) dev::edit_do_hop_up(c, X);
+    else if (op_kind[i] == 2) dev::edit_flip(c, e);
+    else dev::edit_hop_down(c, e, op_node[i]);
+  }
+  dev::edit_end(c, e);
+  status[0] = c.failed ? (c.H->status != 0 ? c.H->status : k_part_internal) : 0;
+}
+
 // ---- compact copies of what the host reads most often, so that it does not have to download the slabs for them ----------
 // Every part's 256-byte header (status, counters, log_G, log prior, RNG position) into one dense array.
 __global__ void __launch_bounds__(k_wave) k_gather_headers(KernelArgs a, uint8_t* out) {
@@ -2392,6 +2418,32 @@ emat_status emat_debug_sample_history(emat_backend* h, int32_t part_id, int32_t 
   if (n > 0) HIP_TRY(hipMemcpy(counts, dc.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (status[1] > 0) HIP_TRY(hipMemcpy(muts, dm.p, (size_t)std::min(status[1], muts_cap) * 4 * sizeof(double), hipMemcpyDeviceToHost));
   return status[1] > muts_cap ? fail(h, EMAT_ERR_CAPACITY, "emat_debug_sample_history: muts_cap too small") : EMAT_OK;
+}
+/* test hook (header: emat_debug_edit) */
+emat_status emat_debug_edit(emat_backend* h, int32_t part_id, int32_t X, int32_t n_ops, const int32_t* op_kind, const int32_t* op_node, const double* op_t) {
+  if (!h || n_ops < 0 || (n_ops > 0 && (!op_kind || !op_node || !op_t))) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
+  if (part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  const int nn = h->parts[part_id].n_nodes;
+  if (X < 0 || X >= nn) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_debug_edit: node index out of range");
+  for (int i = 0; i < n_ops; ++i) if (op_kind[i] < 0 || op_kind[i] > 3 || (op_kind[i] == 3 && (op_node[i] < 0 || op_node[i] >= nn))) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_debug_edit: bad step");
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  emat_status st = emat_synchronize(h); if (st) return st;
+  st = sync_model_to_device(h); if (st) return st;
+  st = materialize(h); if (st) return st;
+  if (!h->derived_valid) { st = launch_recalc(h); if (st) return st; }   // the session keeps lambda_i and the missing-site counts up to date from where they stand
+  DevBuf<int32_t> dk, dn, ds; DevBuf<double> dt;
+  HIP_TRY(dk.upload(op_kind, (size_t)std::max(n_ops, 1))); HIP_TRY(dn.upload(op_node, (size_t)std::max(n_ops, 1))); HIP_TRY(dt.upload(op_t, (size_t)std::max(n_ops, 1))); HIP_TRY(ds.alloc(1));
+  KernelArgs ka = make_args(h);
+  hipLaunchKernelGGL(k_debug_edit, dim3(1), dim3(k_wave), 0, h->stream, ka, (int)part_id, (int)X, (int)n_ops, dk.p, dn.p, dt.p, ds.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  int32_t status = 0;
+  HIP_TRY(hipMemcpy(&status, ds.p, sizeof status, hipMemcpyDeviceToHost));
+  h->host_slabs_current = false; h->headers_current = false;
+  if (status != 0) return fail(h, EMAT_ERR_INTERNAL, "emat_debug_edit: the device code stopped with part status " + std::to_string(status));
+  return EMAT_OK;
 }
 /* debugging aid (not part of the boundary): how many parts the next launch runs with each code variant
  * (out3 = {whole slab staged in LDS, prefix staged, HBM only}); mirrors the kernel's per-part decision (single class). */

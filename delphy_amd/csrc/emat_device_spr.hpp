@@ -244,6 +244,29 @@ EMAT_D void edit_hop_down(Ctx& c, Edit& e, int SS) {   // tree_editing.cpp:280-2
   if (c.failed) return;
   edit_do_hop_up(c, sibling_of(c, U, SS));
 }
+// Tree_editing_session's constructor (tree_editing.cpp:7-29): the mutations on P-X become the session's deltas (room for `cap`)
+EMAT_D void edit_begin(Ctx& c, Edit& e, int X, int cap) {
+  e.X = X;
+  e.deltas = sc_vec<SdRec>(c, cap);
+  const MutRec* m = muts_of(c, X);
+  for (int i = 0; i < nmuts(c, X); ++i) sd_push_back(c, e.deltas, m[i].site, m[i].from, m[i].to);
+  nodes_of(c)[X].muts.cnt = 0;
+}
+// Tree_editing_session::end (tree_editing.cpp:294-302): the deltas go back on P-X as mutations at its midpoint
+EMAT_D void edit_end(Ctx& c, Edit& e) {
+  if (c.failed) return;
+  const int X = e.X;
+  EMAT_CHECK(c, nmuts(c, X) == 0);
+  if (e.deltas.n != 0) {
+    double mut_t = 0.5 * (nodes_of(c)[X].t + nodes_of(c)[nodes_of(c)[X].parent].t);
+    list_reserve<MutRec>(c, nodes_of(c)[X].muts, e.deltas.n);
+    if (!c.failed) {
+      MutRec* m = muts_of(c, X);
+      for (int i = 0; i < e.deltas.n; ++i) m[i] = make_mut(e.deltas.p[i].from, e.deltas.p[i].site, e.deltas.p[i].to, mut_t);
+      set_list_cnt(c, nodes_of(c)[X].muts, e.deltas.n);
+    }
+  }
+}
 // spr_move.cpp:1101-1156
 EMAT_DN void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) { EMAT_TIMED(1);
   if (c.failed) return;
@@ -254,14 +277,8 @@ EMAT_DN void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) { EMAT_TIM
   if (GG == P) GG = G;
   const int A = find_MRCA_of(c, G, GG);
   ScMark mark = sc_mark(c);
-  Edit e; e.X = X;
-  int cap = nmuts(c, X) + path_mut_count(c, P) + path_mut_count(c, SS) + 8;
-  e.deltas = sc_vec<SdRec>(c, cap);
-  {   // Tree_editing_session ctor (tree_editing.cpp:7-29)
-    const MutRec* m = muts_of(c, X);
-    for (int i = 0; i < nmuts(c, X); ++i) sd_push_back(c, e.deltas, m[i].site, m[i].from, m[i].to);
-    nodes_of(c)[X].muts.cnt = 0;
-  }
+  Edit e;
+  edit_begin(c, e, X, nmuts(c, X) + path_mut_count(c, P) + path_mut_count(c, SS) + 8);
   int guard = 0;
   while (!c.failed && nodes_of(c)[P].parent != A && guard++ < (1 << 24)) {
     edit_slide_P_along_branch(c, e, nodes_of(c)[nodes_of(c)[P].parent].t);
@@ -288,18 +305,7 @@ EMAT_DN void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) { EMAT_TIM
     EMAT_CHECK(c, sibling_of(c, P, X) == SS);
     edit_slide_P_along_branch(c, e, new_t_P);
   }
-  if (!c.failed) {   // Tree_editing_session::end (tree_editing.cpp:294-302)
-    EMAT_CHECK(c, nmuts(c, X) == 0);
-    if (e.deltas.n != 0) {
-      double mut_t = 0.5 * (nodes_of(c)[X].t + nodes_of(c)[nodes_of(c)[X].parent].t);
-      list_reserve<MutRec>(c, nodes_of(c)[X].muts, e.deltas.n);
-      if (!c.failed) {
-        MutRec* m = muts_of(c, X);
-        for (int i = 0; i < e.deltas.n; ++i) m[i] = make_mut(e.deltas.p[i].from, e.deltas.p[i].site, e.deltas.p[i].to, mut_t);
-        set_list_cnt(c, nodes_of(c)[X].muts, e.deltas.n);
-      }
-    }
-  }
+  edit_end(c, e);
   sc_release(c, mark);
 }
 

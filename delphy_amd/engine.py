@@ -285,7 +285,7 @@ def load_library():
         "emat_debug_gamma": [B, i32, i32, P(dbl), P(dbl), P(dbl)],
         "emat_debug_pop": [B, P(_PopModelC), i32, i32, P(dbl), P(dbl), P(dbl)], "emat_debug_interval_op": [B, i32, P(i32), i32, P(i32), i32, P(i32), P(i32)],
         "emat_debug_tree_query": [B, i32, i32, i32, P(i32), P(i32), P(i32)],
-        "emat_debug_graft": [B, i32, i32, dbl, i32, i32, dbl, P(dbl), i32, P(i32)],
+        "emat_debug_graft": [B, i32, i32, dbl, i32, i32, dbl, P(dbl), i32, P(i32)], "emat_debug_edit": [B, i32, i32, i32, P(i32), P(i32), P(dbl)],
         "emat_debug_sample_history": [B, i32, i32, P(i32), P(dbl), P(C.c_uint8), dbl, dbl, P(i32), P(dbl), i32, P(i32)],
         "emat_get_num_muts_l": [B, P(i32)], "emat_get_scalable_coalescent_log_prior": [B, dbl, dbl, P(dbl)],
         "emat_scalable_coalescent_partial": [B, dbl, dbl, i32, i32, P(dbl), P(dbl), P(i32)],
@@ -731,6 +731,13 @@ class EmatBackend:
         out = np.zeros(4096); n = C.c_int32()
         self._ck(self._lib.emat_debug_graft(self._h, part, X, mu_proposal, mode, new_sibling, new_t_P, out.ctypes.data_as(C.POINTER(C.c_double)), out.shape[0], C.byref(n)), "emat_debug_graft")
         return decode_graft_output(out[: n.value], mode)
+
+    def debug_edit(self, part: int, X: int, ops):
+        """Test hook: one tree-editing session on node X; ops = [["slide", t] | ["hop_up"] | ["flip"] | ["hop_down", node], ...]."""
+        kind = np.array([{"slide": 0, "hop_up": 1, "flip": 2, "hop_down": 3}[o[0]] for o in ops], np.int32)
+        node = np.array([int(o[1]) if o[0] == "hop_down" else -1 for o in ops], np.int32)
+        t = np.array([float(o[1]) if o[0] == "slide" else 0.0 for o in ops], np.float64)
+        self._ck(self._lib.emat_debug_edit(self._h, part, X, kind.shape[0], _ptr(kind, C.c_int32), _ptr(node, C.c_int32), _ptr(t, C.c_double)), "emat_debug_edit")
 
     def debug_sample_history(self, part: int, branch, t_end, start_seq, T: float, mu: float):
         """Test hook: one sampled mutational history per (branch[i], t_end[i]) on a resident part; returns a list of histories, each a

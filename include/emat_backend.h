@@ -409,6 +409,12 @@ emat_status emat_debug_graft(emat_backend* h, int32_t part_id, int32_t X, double
  * Random numbers come from the part's stream. */
 emat_status emat_debug_sample_history(emat_backend* h, int32_t part_id, int32_t n, const int32_t* branch, const double* t_end, const uint8_t* start_seq, double T, double mu,
                                       int32_t* counts, double* muts, int32_t muts_cap, int32_t* num_muts);
+/* One tree-editing session of the moves' own device code on node X of a resident part (reference Tree_editing_session,
+ * tree_editing.cpp:7-302; what Spr_move::move is built from): the constructor, then step i of n_ops: op_kind[i] = 0
+ * slide_P_along_branch(op_t[i]), 1 hop_up(), 2 flip(), 3 hop_down(op_node[i]); then end().  lambda_i and the missing-site counts of
+ * the nodes are kept up to date by the steps, as in a move (emat_check_derived verifies them afterwards).  tests/ runs the ten
+ * cases of the reference's tests/tree_editing_tests.cpp through it. */
+emat_status emat_debug_edit(emat_backend* h, int32_t part_id, int32_t X, int32_t n_ops, const int32_t* op_kind, const int32_t* op_node, const double* op_t);
 /* The device's interval-set algebra on two valid sets given as (start, end) pairs (reference interval_set.h:130-138, 238-500):
  * op 1 merge, 2 intersect, 3 subtract -> pairs in `out` (room for na + nb + 1 pairs), *n_out = their number; op 5 contains
  * (site b[0]), 6 sets intersect -> *n_out = 0 / 1. */

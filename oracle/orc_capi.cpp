@@ -309,6 +309,31 @@ int orc_debug_sample_history(orc_engine* e, int part_id, int n, const int* branc
   *num_muts = written;
   ORC_CATCH
 }
+/* One Tree_editing_session on node X of one part, steps as in emat_debug_edit (0 slide(t), 1 hop_up, 2 flip, 3 hop_down(node)), then end();
+ * *lambda_dev = largest |lambda_i kept by the session - lambda_i recomputed|, *missing_bad = nodes whose missing-site count is off. */
+int orc_debug_edit(orc_engine* e, int part_id, int X, int n_ops, const int* op_kind, const int* op_node, const double* op_t, double* lambda_dev, int* missing_bad) {
+  ORC_TRY
+  Subrun& sr = *e->parts.at(part_id)->subrun;
+  sr.ref_cum_Q_l = calc_cum_Q_l_for_sequence(sr.tree.ref_sequence, sr.evo);
+  sr.lambda_i = calc_lambda_i(sr.tree, sr.evo, sr.ref_cum_Q_l);
+  sr.num_sites_missing = calc_num_sites_missing_at_every_node(sr.tree);
+  {
+    Tree_editing_session edit{sr.tree, X, sr.evo, sr.lambda_i, sr.ref_cum_Q_l, sr.num_sites_missing};
+    for (int i = 0; i < n_ops; ++i) {
+      if (op_kind[i] == 0) edit.slide_P_along_branch(op_t[i]);
+      else if (op_kind[i] == 1) edit.hop_up();
+      else if (op_kind[i] == 2) edit.flip();
+      else edit.hop_down(op_node[i]);
+    }
+    edit.end();
+  }
+  auto li = calc_lambda_i(sr.tree, sr.evo, sr.ref_cum_Q_l);
+  auto nm = calc_num_sites_missing_at_every_node(sr.tree);
+  double dev = 0.0; int bad = 0;
+  for (int n = 0; n < sr.tree.size(); ++n) { dev = std::max(dev, std::fabs(li[n] - sr.lambda_i[n])); if (nm[n] != sr.num_sites_missing[n]) ++bad; }
+  *lambda_dev = dev; *missing_bad = bad;
+  ORC_CATCH
+}
 /* log G of one part as it stands (incrementally maintained) and recomputed from scratch, without touching the coalescent prior */
 int orc_part_log_G(orc_engine* e, int part_id, double* incremental, double* from_scratch) {
   ORC_TRY

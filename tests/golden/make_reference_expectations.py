@@ -17,10 +17,14 @@ the numbers.  Covered:
                                        deltas, log_alpha_mut, delta_log_G -- the closed-form right-hand sides evaluated), of the
                                        tricky rooty graft's peel / closed-mutations / peel-and-reapply tests, the (X, SS, t) cases of
                                        the full_spr_move tests, and the parameters and expected frequencies of the
-                                       sample_mutational_history test.
+                                       sample_mutational_history test;
+  * tests/phylo_tree_calc_tests.cpp    the fixture with its model, lambda_i and missing-site counts per node, log G below the root, the two
+                                       root-prior cases with zero-probability states, calc_num_muts / _beta_ab / _l, calc_Ttwiddle_beta_a, calc_T;
+  * tests/tree_editing_tests.cpp       all ten tests: the tree each test starts its editing session from, the session's steps, and the
+                                       expected times, mutation lists, missations, parents and root afterwards.
 
 Not covered here (kept as C++ in oracle/orc_tests.cpp, which restates the fixtures): the other tests that build trees
-(tree_editing, spr_study, phylo_tree_calc, missation_map, site_deltas), printing and derivative tests (off the path).
+(spr_study, the rest of phylo_tree_calc, missation_map, site_deltas), printing and derivative tests (off the path).
 Usage: python tests/golden/make_reference_expectations.py [/root/reference]"""
 import json
 import math
@@ -273,8 +277,12 @@ def _block_after(src, start):
     return src[i + 1: j - 1], j
 
 
+_NUM_ENV = {}      # "tree.at(r).t" -> value, while a test body of tree_editing_tests.cpp is being read
+
+
 def _num(tok):
     tok = tok.strip()
+    if tok in _NUM_ENV: return _NUM_ENV[tok]
     if tok in ("-std::numeric_limits<double>::max()",): return NEG_DBL_MAX
     if tok in ("-std::numeric_limits<float>::max()",): return -FLT_MAX
     if tok in ("+std::numeric_limits<float>::max()", "std::numeric_limits<float>::max()"): return FLT_MAX
@@ -294,26 +302,230 @@ def _states(text):
     return [STATE[x] for x in re.findall(r"r[ACGT]", text)]
 
 
+def _fixture_model(txt):
+    """(reference sequence, partition_for_site, nu_l, mu[2], pi[2][4], q[2][4][4]) as a fixture class of the reference's tests sets them up."""
+    ref = _states(re.search(r"Real_sequence ref_sequence\{([^}]*)\}", txt).group(1))
+    pfs = [int(x) for x in re.search(r"make_global_evo_model\(\{([^}]*)\}\)", txt).group(1).split(",")]
+    q = [[[0.0] * 4 for _ in range(4)] for _ in range(2)]
+    for p_, a, b, e in re.findall(r"q_(\d)_ab\[(r[ACGT])\]\[(r[ACGT])\] = ([^;]*);", txt):
+        q[int(p_)][STATE[a]][STATE[b]] = cxx_eval(e, {})
+    nu = [float(x) for x in re.search(r"evo\.nu_l = \{([^}]*)\};", txt).group(1).split(",")]
+    mu, pi = [0.0, 0.0], [None, None]
+    for p_, body in re.findall(r"evo\.partition_evo_model\[(\d)\] = \{(.*?)\};", txt, flags=re.S):
+        mu[int(p_)] = float(re.search(r"\.mu = ([0-9.]+)", body).group(1))
+        pi[int(p_)] = [float(x) for x in re.search(r"\.pi_a = \{([^}]*)\}", body).group(1).split(",")]
+    for p_ in range(2):
+        for a in range(4):
+            assert abs(sum(q[p_][a])) < 1e-12, "rows of a rate matrix sum to zero"
+    return ref, pfs, nu, mu, pi, q
+
+
+def _fixture_nodes(ctor_body, idx, n):
+    nodes = [{"parent": -1, "children": [], "t": 0.0, "t_min": 0.0, "t_max": 0.0, "mutations": [], "missations": [], "name": ""} for _ in range(n)]
+    for st in statements(ctor_body):
+        mm = re.search(r"tree\.at\((\w+)\)\.(\w+) = (.*)$", st)
+        if not mm: continue
+        nd, field, val = nodes[idx[mm.group(1)]], mm.group(2), mm.group(3)
+        if field == "parent": nd["parent"] = idx[val.strip()]
+        elif field == "children": nd["children"] = [idx[x.strip()] for x in val.strip()[1:-1].split(",") if x.strip()]
+        elif field == "name": nd["name"] = val.strip().strip('"')
+        elif field == "mutations": nd["mutations"] = _mutations(val)
+        elif field == "missations": nd["missations"] = _missations(val)
+        elif field in ("t", "t_min", "t_max"):
+            v = _num(val.split("=")[-1])
+            for f in re.findall(r"\.(t_min|t_max)\b", val) + [field]: nd[f] = v
+    return nodes
+
+
+def _model_env(evo, extra=None):
+    env = {"rA": 0, "rC": 1, "rG": 2, "rT": 3,
+           "mu_l": lambda l: evo["mu"][evo["partition_for_site"][l]], "nu_l": lambda l: evo["nu_l"][l],
+           "pi_l_a": lambda l, a: evo["pi"][evo["partition_for_site"][l]][a],
+           "q_l_ab": lambda l, a, b: evo["q"][evo["partition_for_site"][l]][a][b],
+           "q_l_a": lambda l, a: -evo["q"][evo["partition_for_site"][l]][a][a]}
+    env.update(extra or {})
+    return env
+
+
+def phylo_tree_calc_cases():
+    """tests/phylo_tree_calc_tests.cpp: the fixture (tree + model) and what the tests on the hot path expect of it -- lambda_i per node
+    (calc_lambda_i), missing-site counts, log G below the root, the root prior with zero-probability states, and the global moves'
+    sufficient statistics (calc_num_muts, _beta_ab, _l, calc_Ttwiddle_beta_a, calc_T)."""
+    path = os.path.join(REF, "tests", "phylo_tree_calc_tests.cpp")
+    src = strip_comments(open(path).read())
+    name = "Phylo_tree_calc_complex_test"
+    txt, _ = _block_after(src, src.index("class " + name))
+    ref, pfs, nu, mu, pi, q = _fixture_model(txt)
+    idx = {n: int(i) for n, i in re.findall(r"static constexpr Node_index (\w+) = (\d+);", txt)}; idx["k_no_node"] = -1
+    n = int(re.search(r"Phylo_tree tree\{(\d+)\};", txt).group(1))
+    ctor, _ = _block_after(txt, txt.index(name + "()"))
+    evo = {"partition_for_site": pfs, "nu_l": nu, "mu": mu, "pi": pi, "q": q}
+    fx = {"names": {k: v for k, v in idx.items() if k != "k_no_node"}, "root": idx[re.search(r"tree\.root = (\w+);", ctor).group(1)], "ref_sequence": ref,
+          "nodes": _fixture_nodes(ctor, idx, n), "evo": evo}
+    blocks = {b[0]: b for b in test_blocks(path)}
+    out = {"fixture": fx}
+    # calc_lambda_i: one DoubleNear per node
+    lam = [None] * n
+    for st in statements(blocks["calc_lambda_i"][2]):
+        mm = re.match(r"EXPECT_THAT\(lambda_i\[(\w+)\], testing::DoubleNear\((.*), ([0-9.e+-]+)\)\)$", st)
+        if mm and mm.group(1) in idx: lam[idx[mm.group(1)]] = cxx_eval(mm.group(2), _model_env(evo))
+    assert all(v is not None for v in lam)
+    out["lambda_i"] = {"line": blocks["calc_lambda_i"][1], "expected": lam, "tol": 1e-6}
+    miss = [None] * n
+    for st in statements(blocks["calc_num_sites_missing_at_every_node"][2]):
+        mm = re.match(r"EXPECT_THAT\(result\[(\w+)\], testing::Eq\((\d+)\)\)$", st)
+        if mm: miss[idx[mm.group(1)]] = int(mm.group(2))
+    assert all(v is not None for v in miss)
+    out["num_sites_missing"] = {"line": blocks["calc_num_sites_missing_at_every_node"][1], "expected": miss}
+    # calc_log_G_below_root: `expected += <sum>` statements
+    g = 0.0
+    for st in statements(blocks["calc_log_G_below_root"][2]):
+        mm = re.match(r"expected \+= (.*)$", st)
+        if mm: g += cxx_eval(mm.group(1), _model_env(evo))
+    out["log_G_below_root"] = {"line": blocks["calc_log_G_below_root"][1], "expected": g, "tol": 1e-6}
+    # the two root-prior tests: the model's pi replaced, then a closed form or -inf
+    rp = []
+    for t in ("calc_log_root_prior_zero_p_is_ok", "calc_log_root_prior_zero_p_is_impossible"):
+        pi2 = [list(pi[0]), list(pi[1])]
+        exp = None
+        for st in statements(blocks[t][2]):
+            mm = re.match(r"evo\.partition_evo_model\[(\d)\]\.pi_a = Seq_vector\{([^}]*)\}$", st)
+            if mm: pi2[int(mm.group(1))] = [float(x) for x in mm.group(2).split(",")]; continue
+            mm = re.match(r"auto expected = (.*)$", st)
+            if mm: exp = cxx_eval(mm.group(1), _model_env({**evo, "pi": pi2}))
+            if re.match(r"EXPECT_THAT\(result, testing::Eq\(-std::numeric_limits<double>::infinity\(\)\)\)$", st): exp = "-inf"
+        assert exp is not None
+        rp.append({"test": t, "line": blocks[t][1], "pi": pi2, "expected": exp, "tol": 1e-6})
+    out["log_root_prior"] = rp
+    # sufficient statistics of the global moves
+    out["num_muts"] = int(re.search(r"calc_num_muts\(tree\), testing::Eq\((\d+)\)", blocks["calc_num_muts"][2]).group(1))
+    M = [[[0] * 4 for _ in range(4)] for _ in range(2)]
+    for p_, a, b in re.findall(r"\+\+expected\[(\d)\]\[(r[ACGT])\]\[(r[ACGT])\]", blocks["calc_num_muts_beta_ab"][2]): M[int(p_)][STATE[a]][STATE[b]] += 1
+    out["num_muts_beta_ab"] = M
+    out["num_muts_l"] = [int(x) for x in re.search(r"Node_vector<int>\{(.*?)\}", blocks["calc_num_muts_l"][2], flags=re.S).group(1).split(",")]
+    T = [[0.0] * 4 for _ in range(2)]
+    for p_, a, e in re.findall(r"expected\[(\d)\]\[(r[ACGT])\] \+= ([^;]*);", blocks["calc_Ttwiddle_beta_a"][2]): T[int(p_)][STATE[a]] += cxx_eval(e, _model_env(evo))
+    out["Ttwiddle_beta_a"] = {"expected": T, "tol": 1e-6}
+    tt = 0.0
+    for e in re.findall(r"expected \+= ([^;]*);", blocks["calc_T"][2]): tt += cxx_eval(e, {})
+    out["T"] = tt
+    assert out["num_muts"] == sum(out["num_muts_l"]) == sum(sum(sum(r) for r in m) for m in M)
+    return out
+
+
+def _apply_node_statement(st, nodes, idx):
+    mm = re.search(r"^tree\.at\((\w+)\)\.(\w+) = (.*)$", st)
+    if not mm: return False
+    nd, field, val = nodes[idx[mm.group(1)]], mm.group(2), mm.group(3)
+    if field == "parent": nd["parent"] = idx[val.strip()]
+    elif field == "children": nd["children"] = [idx[x.strip()] for x in val.strip()[1:-1].split(",") if x.strip()]
+    elif field == "name": nd["name"] = val.strip().strip('"')
+    elif field == "mutations": nd["mutations"] = _mutations(val)
+    elif field == "missations": nd["missations"] = _missations(val)
+    elif field in ("t", "t_min", "t_max"):
+        v = _num(val.split("=")[-1])
+        for f in re.findall(r"\.(t_min|t_max)\b", val) + [field]: nd[f] = v
+    else: return False
+    return True
+
+
+def tree_editing_cases():
+    """tests/tree_editing_tests.cpp: all ten tests -- the fixture as the test leaves it before the editing session opens, the session's steps
+    (slide_P_along_branch, hop_up, flip, hop_down), and every expectation on times, mutation lists, missations, parents and the root,
+    with `old_tree` references resolved to values."""
+    path = os.path.join(REF, "tests", "tree_editing_tests.cpp")
+    src = strip_comments(open(path).read())
+    base_txt, _ = _block_after(src, src.index("class Tree_editing_test_base"))
+    ref, pfs, nu, mu, pi, q = _fixture_model(base_txt)
+    evo = {"partition_for_site": pfs, "nu_l": nu, "mu": mu, "pi": pi, "q": q}
+    fixtures = {}
+    for m in re.finditer(r"class (Tree_editing_\w+_test) : public Tree_editing_test_base \{", src):
+        name = m.group(1)
+        txt, _ = _block_after(src, m.start())
+        idx = {n: int(i) for n, i in re.findall(r"static constexpr Node_index (\w+) = (\d+);", txt)}; idx["k_no_node"] = -1
+        n = int(re.search(r"Phylo_tree tree\{(\d+)\};", txt).group(1))
+        r2 = re.search(r"Real_sequence ref_sequence\{([^}]*)\}", txt)
+        ctor, _ = _block_after(txt, txt.index(name + "()"))
+        fixtures[name] = {"idx": idx, "root": idx[re.search(r"tree\.root = (\w+);", ctor).group(1)], "ref_sequence": _states(r2.group(1)) if r2 else list(ref),
+                          "nodes": _fixture_nodes(ctor, idx, n)}
+    tests = []
+    for m in re.finditer(r"^TEST_F\((\w+),\s*(\w+)\)\s*\{", src, flags=re.M):
+        fixture, test = m.group(1), m.group(2)
+        body, _ = _block_after(src, m.end() - 1)
+        fx = fixtures[fixture]; idx = fx["idx"]
+        nodes = json.loads(json.dumps(fx["nodes"]))
+        old = json.loads(json.dumps(nodes))
+        root = fx["root"]
+        names = {v: k for k, v in idx.items()}
+        def refresh_env():
+            _NUM_ENV.clear()
+            for k, v in idx.items():
+                if v >= 0: _NUM_ENV["tree.at(%s).t" % k] = nodes[v]["t"]
+        X, ops, expect = None, [], {"t": {}, "mutations": {}, "missations": {}, "parent": {}}
+        session_open = False
+        for st in statements(body):
+            refresh_env()
+            if not session_open and _apply_node_statement(st, nodes, idx): continue
+            if st == "old_tree = tree": old = json.loads(json.dumps(nodes)); continue
+            mm = re.match(r"auto edit = Tree_editing_session\{tree, (\w+),", st)
+            if mm: X = idx[mm.group(1)]; session_open = True; start = json.loads(json.dumps(nodes)); continue
+            mm = re.match(r"edit\.slide_P_along_branch\((.*)\)$", st)
+            if mm:
+                t = _num(mm.group(1)); ops.append(["slide", t])
+                continue
+            if st == "edit.hop_up()": ops.append(["hop_up"]); continue
+            if st == "edit.flip()": ops.append(["flip"]); continue
+            mm = re.match(r"edit\.hop_down\((\w+)\)$", st)
+            if mm: ops.append(["hop_down", idx[mm.group(1)]]); continue
+            if st == "edit.end()": continue
+            mm = re.match(r"EXPECT_THAT\(tree\.at\((\w+)\)\.t, testing::(Eq|DoubleNear)\((.*)\)\)$", st)
+            if mm:
+                arg = split_args(mm.group(3))[0]
+                mo = re.match(r"old_tree\.at\((\w+)\)\.t$", arg)
+                expect["t"][str(idx[mm.group(1)])] = old[idx[mo.group(1)]]["t"] if mo else float(arg)
+                continue
+            mm = re.match(r"EXPECT_THAT\(tree\.at\((\w+)\)\.mutations, testing::(.*)\)$", st)
+            if mm:
+                node, matcher = str(idx[mm.group(1)]), mm.group(2)
+                mo = re.match(r"Eq\(old_tree\.at\((\w+)\)\.mutations\)$", matcher)
+                if mo: expect["mutations"][node] = {"ordered": old[idx[mo.group(1)]]["mutations"]}
+                elif matcher.startswith("UnorderedElementsAre("): expect["mutations"][node] = {"unordered": _mutations(matcher)}
+                elif matcher.startswith("ElementsAre("): expect["mutations"][node] = {"ordered": _mutations(matcher)}
+                elif matcher.startswith("IsEmpty"): expect["mutations"][node] = {"ordered": []}
+                else: raise ValueError(st)
+                continue
+            mm = re.match(r"EXPECT_THAT\((?:estd::ranges::to_vec\()?tree\.at\((\w+)\)\.missations(?:\.slow_elements\(ref_sequence\)\))?, testing::(.*)\)$", st)
+            if mm:
+                node, matcher = str(idx[mm.group(1)]), mm.group(2)
+                mo = re.match(r"Eq\(old_tree\.at\((\w+)\)\.missations\)$", matcher)
+                if mo: expect["missations"][node] = old[idx[mo.group(1)]]["missations"]
+                elif matcher.startswith("ElementsAre("): expect["missations"][node] = _missations(matcher)
+                elif matcher.startswith("IsEmpty"): expect["missations"][node] = []
+                else: raise ValueError(st)
+                continue
+            mm = re.match(r"EXPECT_THAT\(tree\.at\((\w+)\)\.parent, testing::Eq\((\w+)\)\)$", st)
+            if mm: expect["parent"][str(idx[mm.group(1)])] = idx[mm.group(2)]; continue
+            mm = re.match(r"EXPECT_THAT\(tree\.root, testing::Eq\((\w+)\)\)$", st)
+            if mm: expect["root"] = idx[mm.group(1)]; continue
+            if st.startswith("EXPECT_THAT(num_sites_missing_at_every_node"): expect["derived_quantities_kept"] = True; continue
+            if st.startswith("EXPECT") : raise ValueError("unconverted expectation in %s.%s: %s" % (fixture, test, st))
+        _NUM_ENV.clear()
+        assert X is not None and ops
+        tests.append({"fixture": fixture, "test": test, "line": src[: m.start()].count("\n") + 1, "X": X, "ops": ops,
+                      "tree": {"names": {k: v for k, v in idx.items() if v >= 0}, "root": root, "ref_sequence": fx["ref_sequence"], "nodes": start, "evo": evo},
+                      "expect": expect})
+    assert len(tests) == 10, len(tests)
+    return tests
+
+
 def spr_move_cases():
     path = os.path.join(REF, "tests", "spr_move_tests.cpp")
     raw = open(path).read()
     src = strip_comments(raw)
     # -- the base fixture: reference sequence, the two-partition model, mu_JC
     base_txt, _ = _block_after(src, src.index("class Spr_move_test_base"))
-    base_ref = _states(re.search(r"Real_sequence ref_sequence\{([^}]*)\}", base_txt).group(1))
-    base_pfs = [int(x) for x in re.search(r"make_global_evo_model\(\{([^}]*)\}\)", base_txt).group(1).split(",")]
+    base_ref, base_pfs, base_nu, mu, pi, q = _fixture_model(base_txt)
     mu_JC = float(re.search(r"double mu_JC = ([0-9.]+);", base_txt).group(1))
-    q = [[[0.0] * 4 for _ in range(4)] for _ in range(2)]
-    for p_, a, b, e in re.findall(r"q_(\d)_ab\[(r[ACGT])\]\[(r[ACGT])\] = ([^;]*);", base_txt):
-        q[int(p_)][STATE[a]][STATE[b]] = cxx_eval(e, {})
-    base_nu = [float(x) for x in re.search(r"evo\.nu_l = \{([^}]*)\};", base_txt).group(1).split(",")]
-    mu, pi = [0.0, 0.0], [None, None]
-    for p_, body in re.findall(r"evo\.partition_evo_model\[(\d)\] = \{(.*?)\};", base_txt, flags=re.S):
-        mu[int(p_)] = float(re.search(r"\.mu = ([0-9.]+)", body).group(1))
-        pi[int(p_)] = [float(x) for x in re.search(r"\.pi_a = \{([^}]*)\}", body).group(1).split(",")]
-    for p_ in range(2):
-        for a in range(4):
-            assert abs(sum(q[p_][a])) < 1e-12, "rows of a rate matrix sum to zero"
     # -- the fixture classes
     fixtures = {}
     for m in re.finditer(r"class (Spr_move_\w+_test) : public Spr_move_test_base \{", src):
@@ -329,19 +541,7 @@ def spr_move_cases():
         if mm: pfs = [int(x) for x in mm.group(1).split(",")]
         mm = re.search(r"evo\.nu_l = \{([^}]*)\};", txt)
         if mm: nu = [float(x) for x in mm.group(1).split(",")]
-        nodes = [{"parent": -1, "children": [], "t": 0.0, "t_min": 0.0, "t_max": 0.0, "mutations": [], "missations": [], "name": ""} for _ in range(n)]
-        for st in statements(_block_after(txt, txt.index(name + "()"))[0]):
-            mm = re.search(r"tree\.at\((\w+)\)\.(\w+) = (.*)$", st)
-            if not mm: continue
-            nd, field, val = nodes[idx[mm.group(1)]], mm.group(2), mm.group(3)
-            if field == "parent": nd["parent"] = idx[val.strip()]
-            elif field == "children": nd["children"] = [idx[x.strip()] for x in val.strip()[1:-1].split(",") if x.strip()]
-            elif field == "name": nd["name"] = val.strip().strip('"')
-            elif field == "mutations": nd["mutations"] = _mutations(val)
-            elif field == "missations": nd["missations"] = _missations(val)
-            elif field in ("t", "t_min", "t_max"):
-                v = _num(val.split("=")[-1])
-                for f in re.findall(r"\.(t_min|t_max)\b", val) + [field]: nd[f] = v
+        nodes = _fixture_nodes(_block_after(txt, txt.index(name + "()"))[0], idx, n)
         root = idx[re.search(r"tree\.root = (\w+);", txt).group(1)]
         fixtures[name] = {"names": {k: v for k, v in idx.items() if k != "k_no_node"}, "root": root, "ref_sequence": ref, "nodes": nodes,
                           "evo": {"partition_for_site": pfs, "nu_l": nu, "mu": mu, "pi": pi, "q": q}}
@@ -354,12 +554,7 @@ def spr_move_cases():
         line = src[: m.start()].count("\n") + 1
         fx = fixtures[fixture]; idx = dict(fx["names"]); idx["k_no_node"] = -1
         evo = fx["evo"]
-        env = {"mu_JC": mu_JC, "rA": 0, "rC": 1, "rG": 2, "rT": 3,
-               "mu_l": lambda l: evo["mu"][evo["partition_for_site"][l]], "nu_l": lambda l: evo["nu_l"][l],
-               "pi_l_a": lambda l, a: evo["pi"][evo["partition_for_site"][l]][a],
-               "q_l_ab": lambda l, a, b: evo["q"][evo["partition_for_site"][l]][a][b],
-               "q_l_a": lambda l, a: -evo["q"][evo["partition_for_site"][l]][a][a],
-               "P_JC": lambda a, b, t: (1.0 + 3. / 4 * math.expm1(-4. / 3. * mu_JC * t)) if a == b else (-1. / 4. * math.expm1(-4. / 3. * mu_JC * t))}
+        env = _model_env(evo, {"mu_JC": mu_JC, "P_JC": lambda a, b, t: (1.0 + 3. / 4 * math.expm1(-4. / 3. * mu_JC * t)) if a == b else (-1. / 4. * math.expm1(-4. / 3. * mu_JC * t))})
         sts = statements(body)
         if test.startswith("analyze_graft") or test in ("peel_graft_X", "closed_mutations_graft_X", "peel_reapply_graft_X"):
             ccr = True
@@ -444,8 +639,8 @@ if __name__ == "__main__":
     pop, sk1 = pop_model_cases()
     iv, sk2 = interval_set_cases()
     sc = scalable_coalescent_case()
-    out = {"source": "expectations of the reference's tests/pop_model_tests.cpp, interval_set_tests.cpp, scalable_coalescent_tests.cpp, phylo_tree_tests.cpp, spr_move_tests.cpp, evaluated by tests/golden/make_reference_expectations.py",
-           "pop_model": pop, "interval_set": iv, "scalable_coalescent": sc, "phylo_tree_queries": phylo_tree_query_cases(), "spr_move": spr_move_cases(),
+    out = {"source": "expectations of the reference's tests/pop_model_tests.cpp, interval_set_tests.cpp, scalable_coalescent_tests.cpp, phylo_tree_tests.cpp, spr_move_tests.cpp, phylo_tree_calc_tests.cpp, tree_editing_tests.cpp, evaluated by tests/golden/make_reference_expectations.py",
+           "pop_model": pop, "interval_set": iv, "scalable_coalescent": sc, "phylo_tree_queries": phylo_tree_query_cases(), "spr_move": spr_move_cases(), "phylo_tree_calc": phylo_tree_calc_cases(), "tree_editing": tree_editing_cases(),
            "not_converted": {"pop_model_tests.cpp": sk1, "interval_set_tests.cpp": sk2, "why": "accessors, printing, iterator-identity and derivative expectations (off the hot path)"}}
     json.dump(out, open(OUT, "w"), indent=0)
     print("pop_model cases %d (skipped %d) | interval_set cases %d (skipped %d) | scalable_coalescent stages %d" % (len(pop), sk1, len(iv), sk2, len(sc["stages"])))

@@ -36,7 +36,7 @@ def lib():
             "orc_part_check": [E, C.c_int, C.c_char_p, C.c_int],
             "orc_Ttwiddle_l": [E, C.c_int, P(dbl)], "orc_num_muts_l": [E, P(C.c_int)], "orc_scalable_log_prior": [E, C.c_int, dbl, dbl, P(dbl)],
             "orc_tree_query": [E, C.c_int, C.c_int, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int)],
-            "orc_debug_graft": [E, C.c_int, C.c_int, dbl, C.c_int, C.c_int, dbl, P(dbl), C.c_int, P(C.c_int)], "orc_part_log_G": [E, C.c_int, P(dbl), P(dbl)],
+            "orc_debug_graft": [E, C.c_int, C.c_int, dbl, C.c_int, C.c_int, dbl, P(dbl), C.c_int, P(C.c_int)], "orc_part_log_G": [E, C.c_int, P(dbl), P(dbl)], "orc_debug_edit": [E, C.c_int, C.c_int, C.c_int, P(C.c_int), P(C.c_int), P(dbl), P(dbl), P(C.c_int)],
             "orc_debug_sample_history": [E, C.c_int, C.c_int, P(C.c_int), P(dbl), P(C.c_uint8), dbl, dbl, P(C.c_int), P(dbl), C.c_int, P(C.c_int)],
         }
         for n, a in sigs.items():
@@ -124,6 +124,15 @@ class OracleEngine:
         for i in range(n):
             out.append([[int(m[1]), int(m[0]), int(m[2]), float(m[3])] for m in muts[k: k + counts[i]]]); k += int(counts[i])
         return out
+
+    def debug_edit(self, part, X, ops):
+        """One editing session as EmatBackend.debug_edit; returns (largest deviation of the kept lambda_i, nodes with a wrong missing-site count)."""
+        kind = np.array([{"slide": 0, "hop_up": 1, "flip": 2, "hop_down": 3}[o[0]] for o in ops], np.int32)
+        node = np.array([int(o[1]) if o[0] == "hop_down" else -1 for o in ops], np.int32)
+        t = np.array([float(o[1]) if o[0] == "slide" else 0.0 for o in ops], np.float64)
+        dev, bad = C.c_double(), C.c_int()
+        self._ck(self.L.orc_debug_edit(self.h, part, X, kind.shape[0], _ptr(kind, C.c_int), _ptr(node, C.c_int), _ptr(t, C.c_double), C.byref(dev), C.byref(bad)), "debug_edit")
+        return dev.value, bad.value
 
     def part_log_G(self, part):
         """(log G as maintained incrementally, log G recomputed from scratch) of one part."""

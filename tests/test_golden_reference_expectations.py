@@ -376,3 +376,103 @@ def test_history_sampler_frequencies_of_the_reference():
 def test_device_history_sampler_frequencies_of_the_reference():
     """The device's own sample_mutational_history + adjust_mutational_history (emat_debug_sample_history), 25 000 histories."""
     _history_frequencies_through(d.EmatBackend, SM["sample_mutational_history"]["num_histories"])
+
+
+# ---- tests/phylo_tree_calc_tests.cpp as data: derived quantities and the global moves' sufficient statistics of its fixture -----------
+PC = G["phylo_tree_calc"]
+
+
+def _phylo_tree_calc_expectations_through(engine_cls):
+    """calc_lambda_i, calc_num_sites_missing_at_every_node, calc_log_G_below_root, calc_log_root_prior (with states of probability zero),
+    calc_num_muts / _beta_ab / _l and calc_Ttwiddle_beta_a on the reference's fixture (phylo_tree_calc_tests.cpp:14-116), each against the
+    number the reference's test states (:248-284, 355-380, 381-439, 441-482, 497-505, 557-607)."""
+    fx = PC["fixture"]
+    n = len(fx["nodes"])
+    def derived(includes_root, pi=None):
+        f = dict(fx); f["evo"] = dict(fx["evo"])
+        if pi is not None:
+            f["evo"]["pi"] = pi
+        def go(e):
+            e.recalc_derived()
+            lam, miss, log_G, _ = e.part_derived(0, n)
+            stats = e.global_stats(2) if includes_root else None
+            return lam, miss, log_G, stats, (e.num_muts_l() if includes_root else None)
+        return _with_fixture(engine_cls, f, includes_root, 1, go)
+    lam, miss, below, _, _ = derived(False)                                   # a part without the run's root: log G is the sum below its root
+    assert np.all(np.abs(lam - np.array(PC["lambda_i"]["expected"])) <= PC["lambda_i"]["tol"]), (lam, PC["lambda_i"])
+    assert miss.tolist() == PC["num_sites_missing"]["expected"]
+    assert abs(below - PC["log_G_below_root"]["expected"]) <= PC["log_G_below_root"]["tol"], (below, PC["log_G_below_root"])
+    lam2, miss2, with_root, (T, M, num), per_site = derived(True)
+    assert np.array_equal(lam, lam2) and np.array_equal(miss, miss2)
+    assert num == PC["num_muts"] and M.tolist() == PC["num_muts_beta_ab"] and per_site.tolist() == PC["num_muts_l"]
+    assert np.all(np.abs(T - np.array(PC["Ttwiddle_beta_a"]["expected"])) <= PC["Ttwiddle_beta_a"]["tol"]), (T, PC["Ttwiddle_beta_a"])
+    for case in PC["log_root_prior"]:
+        _, _, g, _, _ = derived(True, case["pi"])
+        prior = g - below if np.isfinite(g) else g                                # Subrun::calc_cur_log_G = root prior + sum below the root
+        if case["expected"] == "-inf":
+            assert prior == -np.inf, (case, prior)
+        else:
+            assert abs(prior - case["expected"]) <= case["tol"], (case, prior)
+
+
+def test_phylo_tree_calc_expectations_of_the_reference():
+    _phylo_tree_calc_expectations_through(oracle_ffi.OracleEngine)
+
+
+@pytest.mark.gpu
+def test_device_derived_quantities_against_the_reference_expectations():
+    """The same numbers from the kernels: k_recalc_derived (lambda_i, missing-site counts, branch log-G sums, root prior),
+    k_global_stats and k_num_muts_l on the fixture's slab."""
+    _phylo_tree_calc_expectations_through(d.EmatBackend)
+
+
+# ---- tests/tree_editing_tests.cpp as data: ten editing sessions, step by step -----------------------------------------------------------
+def _tree_editing_expectations_through(engine_cls):
+    """Every test of the reference's tree_editing_tests.cpp (:127-1115): slide up / down (a missation swallowing a mutation, mutations
+    exactly on a branch end, the root sliding down), hop up, flip, hop down and the eight-step SPR -- the tree each test starts from, the
+    session's steps through the engine's own editing primitives, then the reference's expected times, mutation lists (in its order where
+    it states one), missations, parents and root; and lambda_i / missing-site counts kept up to date by the steps."""
+    device = engine_cls is d.EmatBackend
+    assert len(G["tree_editing"]) == 10
+    for t in G["tree_editing"]:
+        fx = t["tree"]
+        what = "%s.%s (tree_editing_tests.cpp:%d)" % (t["fixture"], t["test"], t["line"])
+        def run(e):
+            if device:
+                e.recalc_derived()
+                e.debug_edit(0, t["X"], t["ops"])
+                e.check_derived(1.0)          # lambda_i within 1e-8 x sites, missing-site counts exact (subrun.cpp:28-56)
+            else:
+                dev, bad = e.debug_edit(0, t["X"], t["ops"])
+                assert dev <= 1e-6 and bad == 0, (what, dev, bad)
+            return e.part_download(0)
+        tree = _with_fixture(engine_cls, fx, True, 1, run)
+        ex = t["expect"]
+        for node, want in ex["t"].items():
+            assert abs(tree.t[int(node)] - want) <= 1e-6, (what, node, tree.t[int(node)], want)
+        for node, want in ex["parent"].items():
+            assert int(tree.parent[int(node)]) == want, (what, node, int(tree.parent[int(node)]), want)
+        if "root" in ex:
+            assert tree.root == ex["root"], what
+        for node, want in ex["mutations"].items():
+            n = int(node)
+            a, b = int(tree.mut_offset[n]), int(tree.mut_offset[n + 1])
+            got = [[int(tree.mut_from[k]), int(tree.mut_site[k]), int(tree.mut_to[k]), float(tree.mut_t[k])] for k in range(a, b)]
+            if "ordered" in want:
+                assert got == want["ordered"], (what, node, got, want)
+            else:
+                assert sorted(got) == sorted(want["unordered"]), (what, node, got, want)
+        for node, want in ex["missations"].items():
+            _, miss = gg.node_lists(tree, fx["ref_sequence"], int(node))
+            assert miss == want, (what, node, miss, want)
+
+
+def test_tree_editing_expectations_of_the_reference():
+    _tree_editing_expectations_through(oracle_ffi.OracleEngine)
+
+
+@pytest.mark.gpu
+def test_device_tree_editing_against_the_reference_expectations():
+    """The same ten sessions through the device's own edit_slide_P_along_branch / edit_do_hop_up / edit_flip / edit_hop_down
+    (emat_debug_edit), the code Spr_move::move is made of on the GPU."""
+    _tree_editing_expectations_through(d.EmatBackend)
