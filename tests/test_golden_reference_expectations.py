@@ -441,7 +441,11 @@ def _tree_editing_expectations_through(engine_cls):
             if device:
                 e.recalc_derived()
                 e.debug_edit(0, t["X"], t["ops"])
-                e.check_derived(1.0)          # lambda_i within 1e-8 x sites, missing-site counts exact (subrun.cpp:28-56)
+                n = len(fx["nodes"])
+                lam, miss, _, _ = e.part_derived(0, n)          # as the session's steps left them
+                e.recalc_derived()
+                lam2, miss2, _, _ = e.part_derived(0, n)        # from scratch (k_recalc_derived) on the edited tree
+                assert np.all(np.abs(lam - lam2) <= 1e-6) and np.array_equal(miss, miss2), (what, lam, lam2, miss, miss2)
             else:
                 dev, bad = e.debug_edit(0, t["X"], t["ops"])
                 assert dev <= 1e-6 and bad == 0, (what, dev, bad)
