@@ -47,7 +47,9 @@ def parse():
     ap.add_argument("--parts", type=int, default=None, help="number of partition parts requested from the partitioner (the same at every N: strong scaling of one decomposition); "
                     "default 8192 at C4, 81920 at C5 (about 25 nodes per part)")
     ap.add_argument("--moves-per-part", type=int, default=1000)
-    ap.add_argument("--max-part-nodes", type=int, default=0, help="not in the reference: cut parts larger than this further (0 = the reference's partitioning rule)")
+    ap.add_argument("--max-part-nodes", type=int, default=-1, help="not in the reference: parts larger than this get further, randomly drawn cut nodes at every repartition "
+                                                                    "(-1 = the run driver's default, three times the mean part size; 0 = the reference's partitioning rule exactly)")
+    ap.add_argument("--inclusive-cycles", type=int, default=210, help="whole cycles of the `inclusive` figure (the reference redraws its partition stencils every 200 cycles)")
     ap.add_argument("--no-lds", action="store_true")
     ap.add_argument("--no-topology", action="store_true", help="diagnostic: disable subtree-slide and SPR moves")
     ap.add_argument("--only-displace", action="store_true", help="diagnostic: only inner-node displacement moves")
@@ -161,38 +163,55 @@ def cpu_baseline(sc, num_parts, seed, target_seconds, t_step):
     return out
 
 
-def inclusive_cycles(sc, args, cycles=10):
+def inclusive_cycles(sc, args, cycles=210):
     """Whole cycles through the host run driver (emat_run_do_mcmc_steps), the reference's default 50 x nodes local moves per
-    cycle (run.cpp:669-672), wall clock.  Two ways: with the whole tree resident in HBM (the host draws the
-    partition on the topology, kernels cut the part slabs and gather them back) and with the tree on the host (subtree
-    build -> slab encode -> H2D -> moves -> D2H -> decode -> reassemble).  Reported beside `value`, never as it."""
+    cycle (run.cpp:669-672), wall clock, cycle by cycle over more than one stencil period of the reference (its partition stencils
+    are redrawn every 200 cycles, run.cpp:87-108, and the parts they delimit drift apart in size while they are in use).  Three ways:
+    with the whole tree resident in HBM (the host draws the partition on the topology, kernels cut the part slabs
+    and gather them back) under the run driver's default part-size limit; the same under the reference's partitioning rule exactly
+    (emat_run_set_max_part_nodes(0), fewer cycles: a cycle then lasts as long as the chain of its largest part); and with the tree on
+    the host (subtree build -> slab encode -> H2D -> moves -> D2H -> decode -> reassemble).  Reported beside `value`, never as it."""
+    import numpy as np
     import delphy_amd as d
     per_cycle = 50 * sc.tree.num_nodes
 
-    def one(device_tree):
+    def one(device_tree, limit, n):
         b = d.EmatBackend(sc.num_sites)
         run = d.EmatRun(b, sc.tree, sc.ref, 20261001)
         run.set_num_parts(args.parts)
-        run.set_max_part_nodes(args.max_part_nodes)
+        run.set_max_part_nodes(limit)
         run.set_hky(sc.mu, sc.kappa, sc.pi)
         run.set_pop_model(sc.pop)
         if device_tree:
             run.set_device_tree(True)
-        run.do_mcmc_steps(per_cycle, per_cycle)          # warm-up cycle: allocations, first launch, tree upload
-        each = []
+        run.do_mcmc_steps(per_cycle, per_cycle)          # warm-up cycle: allocations, first launch, tree upload, the first ten stencils
+        rows = []
         t0 = time.perf_counter()
-        for _ in range(cycles):                          # (one call per cycle only to time the cycles apart; the driver repartitions at every cycle boundary either way)
-            t1 = time.perf_counter(); run.do_mcmc_steps(per_cycle, per_cycle); each.append((time.perf_counter() - t1) * 1e3)
+        for _ in range(n):                               # (one call per cycle only to time the cycles apart; the driver repartitions at every cycle boundary either way)
+            t1 = time.perf_counter(); run.do_mcmc_steps(per_cycle, per_cycle); ms = (time.perf_counter() - t1) * 1e3
+            st = run.partition_stats()
+            rows.append((ms, st["num_parts"], st["largest_part_nodes"], st["extra_cuts"]))
         dt = time.perf_counter() - t0
+        lim = run.partition_stats()["max_part_nodes"]
         run.close(); b.close()
-        return {"value": cycles * per_cycle / dt, "unit": "moves/s", "ms_per_cycle": dt / cycles * 1e3, "ms_per_cycle_min": min(each), "ms_per_cycle_max": max(each)}
+        a = np.array(rows); k = max(1, n // 10)
+        p10, p50, p90 = (float(np.percentile(a[:, 0], q)) for q in (10, 50, 90))
+        return {"value": n * per_cycle / dt, "unit": "moves/s", "cycles": n, "ms_per_cycle": dt / n * 1e3, "ms_per_cycle_min": float(a[:, 0].min()), "ms_per_cycle_max": float(a[:, 0].max()),
+                "ms_per_cycle_p10": p10, "ms_per_cycle_p50": p50, "ms_per_cycle_p90": p90, "p90_over_p10": p90 / p10, "max_part_nodes": lim,
+                "by_tenth_of_the_run": [{"ms_per_cycle": float(a[i: i + k, 0].mean()), "parts": float(a[i: i + k, 1].mean()), "largest_part_nodes": int(a[i: i + k, 2].max()),
+                                         "cut_nodes_added_by_the_limit": float(a[i: i + k, 3].mean())} for i in range(0, n, k)]}
 
-    dev, host = one(True), one(False)
-    return {"value": dev["value"], "unit": "moves/s", "cycles": cycles, "moves_per_cycle": per_cycle, "ms_per_cycle": dev["ms_per_cycle"],
-            "ms_per_cycle_min": dev["ms_per_cycle_min"], "ms_per_cycle_max": dev["ms_per_cycle_max"],
-            "what": "emat_run_do_mcmc_steps with the tree resident in HBM: stencil + partition on the host's copy of the topology, part slabs cut and "
-                    "gathered back by kernels, %d local moves per cycle (no global moves), wall clock" % per_cycle,
-            "host_tree": dict(host, what="the same cycles with the tree on the host: subtree build + slab encode + H2D + moves + D2H + decode + reassemble")}
+    dev = one(True, args.max_part_nodes, cycles)
+    ref_rule = one(True, 0, max(10, cycles // 5)) if args.max_part_nodes != 0 else None
+    host = one(False, args.max_part_nodes, max(5, cycles // 20))
+    out = dict(dev, moves_per_cycle=per_cycle,
+               what="emat_run_do_mcmc_steps with the tree resident in HBM: stencil + partition on the host's copy of the topology, part slabs cut and "
+                    "gathered back by kernels, %d local moves per cycle (no global moves), wall clock, %d successive cycles (the reference redraws its stencils every 200)" % (per_cycle, cycles),
+               host_tree=dict(host, what="the same cycles with the tree on the host: subtree build + slab encode + H2D + moves + D2H + decode + reassemble"))
+    if ref_rule is not None:
+        out["reference_partition_rule"] = dict(ref_rule, what="the same cycles with emat_run_set_max_part_nodes(0): the reference's partitioning rule exactly, whose parts drift apart in size between "
+                                                                "two redraws of the stencils; every part makes the same number of moves, so a cycle lasts as long as the chain of its largest part")
+    return out
 
 
 def _part_digest(backend, p):
@@ -384,7 +403,7 @@ def main():
     # PMC counters cannot be read from inside this process: the figure comes from the committed rocprofv3 --pmc passes
     # of this same command (scripts/profile.sh) and is stamped with the kernel build it was measured on; it is quoted
     # only for the default single-GPU workload and only while the device code is the one that was profiled
-    if world == 1 and args.workload == "C4" and args.tips is None and args.parts == 8192 and args.moves_per_part == 1000 and args.max_part_nodes == 0 and not (args.no_topology or args.only_displace or args.no_lds):
+    if world == 1 and args.workload == "C4" and args.tips is None and args.parts == 8192 and args.moves_per_part == 1000 and args.max_part_nodes == -1 and not (args.no_topology or args.only_displace or args.no_lds):
         try:
             pm = json.load(open(pmc_path))
             stamp = pm.get("device_code_sha16")
@@ -438,7 +457,7 @@ def main():
         cpu_base = cpu_baseline(sc, args.parts, 20261001, args.cpu_seconds, eng.t_step)
     inclusive = None
     if rank == 0 and world == 1 and not args.no_inclusive:
-        inclusive = inclusive_cycles(sc, args)
+        inclusive = inclusive_cycles(sc, args, args.inclusive_cycles)
 
     if rank == 0:
         out = {

@@ -104,7 +104,8 @@ struct RunDriver {
   uint64_t seed = 0;
   SplitMix64 bitgen{0};
   int num_parts = 1;
-  int max_part_nodes = 0;   // > 0: parts larger than this are cut further at every repartition (not in the reference; see refine_stencil)
+  int max_part_nodes = -1;  // parts larger than this are cut further at every repartition (not in the reference; see refine_stencil): -1 = three times the mean part size, 0 = off
+  int last_num_parts = 0, last_largest_part = 0, last_extra_cuts = 0;   // of the last repartition (emat_run_partition_stats)
   // model
   bool have_hky = false; double hky_mu = 0, hky_kappa = 1, hky_pi[4] = {0.25, 0.25, 0.25, 0.25};
   std::vector<double> nu_l;
@@ -188,55 +189,71 @@ struct RunDriver {
     return cuts;
   }
 
-  // NOT in the reference: cut oversized parts further.  The reference sizes its parts for a handful of CPU threads and
-  // lets them vary freely (a stencil drawn for 8 000 parts routinely contains a few parts of 300+ nodes next to a
-  // median of 25); every part performs the same number of moves per pass and the GPU runs all parts at once, so the pass
-  // lasts as long as the largest part.  Any set of cut nodes is a valid partition for the sampler (it only decides
-  // which nodes are frozen during a pass), so parts above `max_part_nodes` are split at the node that halves them
-  // best, with the reference's floor of 10 nodes per part.  Applied to the stencil in use at every repartition, since
-  // part sizes drift as the tree is re-hung.
-  std::vector<int32_t> refine_stencil(std::vector<int32_t> cuts) const {   // needs sync_topology()
-    if (max_part_nodes <= 0) return cuts;
+  // NOT in the reference: cut oversized parts further.  The reference sizes its parts for a handful of CPU threads; its stencils are
+  // lists of cut NODES drawn every 200 cycles, and as the moves re-hang subtrees the parts those nodes delimit drift apart in
+  // size -- by a few per cent at 8 parts of 25 000 nodes, but at 8 000 parts of 25 nodes a stencil that started balanced holds parts
+  // of 700-2 000 nodes after a few cycles.  Every part performs the same number of moves per pass and the GPU runs all parts at
+  // once, so the pass lasts as long as the chain of the largest part.  Parts above `limit` nodes therefore get further cut nodes,
+  // drawn UNIFORMLY AT RANDOM among their inner nodes, round after round until no piece exceeds the limit.
+  // Why that does not bias the sampler (the reference's own concern, run.cpp:88-93): a pass only moves nodes WITHIN a part of the
+  // refined partition R, so which nodes a part owns, and which of them are inner nodes, is the same before and after the pass --
+  // for the parts of R and for every coarser level they were cut from.  The rule reads nothing else (no subtree sizes, no times),
+  // so the probability of drawing R from the tree before the pass and from the tree after it is the same: the pass is a mixture of
+  // within-part kernels whose weights are constant on every set of trees it connects, which keeps each kernel's detailed balance.
+  // (Cutting at the node that halves a part best -- what this function did until round 4 -- reads subtree sizes, which a pass
+  // changes: a state-dependent choice of the kind the reference avoids by redrawing its stencils slowly.)
+  // The draws come from a stream of their own (seed, epoch): the reference-rule stream `bitgen` sees the same sequence with the
+  // limit on or off.
+  int effective_max_part_nodes(size_t num_nodes) const {
+    if (max_part_nodes >= 0) return max_part_nodes;
+    const long mean = (long)num_nodes / std::max(1, num_parts);
+    return (int)std::max(64L, 3 * mean);
+  }
+  std::vector<int32_t> refine_stencil(std::vector<int32_t> cuts) {   // needs sync_topology()
     const int N = (int)tp_parent.size();
-    const int limit = std::max(max_part_nodes, 21);
+    const int eff = effective_max_part_nodes((size_t)N);
+    last_extra_cuts = 0;
+    if (eff <= 0) return cuts;
+    const int limit = std::max(eff, 21);
     std::vector<char> is_cut(N, 0);
     for (int32_t c : cuts) is_cut[c] = 1;
     is_cut[tp_root] = 1;
-    // size[v]: nodes of v's part that lie in v's subtree (a cut child counts as one: it is a tip of this part)
-    std::vector<int32_t> size(N, 1), order; order.reserve(N);
-    { std::vector<int32_t> st; st.push_back(tp_root);
-      while (!st.empty()) { int32_t v = st.back(); st.pop_back(); order.push_back(v); if (tp_c0[v] != EMAT_NO_NODE) { st.push_back(tp_c0[v]); st.push_back(tp_c1[v]); } } }
-    for (auto it = order.rbegin(); it != order.rend(); ++it) {
-      const int32_t k0 = tp_c0[*it], k1 = tp_c1[*it];
-      if (k0 != EMAT_NO_NODE) size[*it] = 1 + (is_cut[k0] ? 1 : size[k0]) + (is_cut[k1] ? 1 : size[k1]);
-    }
-    std::vector<int32_t> work;
-    for (int v = 0; v < N; ++v) if (is_cut[v] && size[v] > limit) work.push_back(v);
-    while (!work.empty()) {
-      const int32_t c = work.back(); work.pop_back();
-      if (size[c] <= limit) continue;
-      // walk down the heavier side until the subtree holds at most half of the part
-      int32_t v = c, best = -1; int best_score = -1;
-      while (tp_c0[v] != EMAT_NO_NODE) {
-        const int32_t a = tp_c0[v], b = tp_c1[v];
-        const int sa = is_cut[a] ? 1 : size[a], sb = is_cut[b] ? 1 : size[b];
-        const int32_t h = sa >= sb ? a : b; const int sh = std::max(sa, sb);
-        if (is_cut[h] || sh < 10) break;
-        const int rest = size[c] - sh + 1;   // the part keeps a frozen tip where the subtree was
-        const int score = std::min(sh, rest);
-        if (rest >= 10 && score > best_score) { best_score = score; best = h; }
-        if (sh * 2 <= size[c]) break;
-        v = h;
+    std::vector<int32_t> roots(cuts);
+    if (std::find(roots.begin(), roots.end(), tp_root) == roots.end()) roots.push_back(tp_root);
+    // Every part of the stencil on its own (host threads): walk it from its cut node, and if it is oversized cut it, then its
+    // oversized pieces, and so on.  A walk stops at cut nodes, so a task only ever writes is_cut of nodes its own part owns.
+    std::vector<std::vector<int32_t>> extra(roots.size());
+    const uint64_t round_seed = seed ^ (0x9E3779B97F4A7C15ull * (epoch + 1)) ^ 0x5A17C0DEull;
+    parallel_for((int)roots.size(), [&](int ri) {
+      std::vector<int32_t> work, inner, stack;
+      work.push_back(roots[(size_t)ri]);
+      SplitMix64 rng(round_seed ^ (0xD6E8FEB86659FD93ull * (uint64_t)(roots[(size_t)ri] + 1)));   // a stream per part: the result does not depend on the threads
+      bool first = true;
+      while (!work.empty()) {
+        const int32_t c = work.back(); work.pop_back();
+        // the piece below c: its size (a cut child counts as one node: it is a tip here) and its inner nodes other than c
+        int size = 0; inner.clear(); stack.clear(); stack.push_back(c);
+        while (!stack.empty()) {
+          const int32_t v = stack.back(); stack.pop_back(); ++size;
+          if (tp_c0[v] == EMAT_NO_NODE || (is_cut[v] && v != c)) continue;
+          if (v != c) inner.push_back(v);
+          stack.push_back(tp_c0[v]); stack.push_back(tp_c1[v]);
+        }
+        if (first && size <= limit) return;   // the common case: one walk, nothing to do
+        first = false;
+        if (size <= limit || inner.empty()) continue;
+        // as many new cut nodes as would make the pieces `limit` nodes on average, a uniformly drawn subset of the inner nodes
+        const int want = std::min((int)inner.size(), std::max(1, (size + limit - 1) / limit - 1));
+        for (int k = 0; k < want; ++k) { const int j = k + rng.below((int)inner.size() - k); std::swap(inner[(size_t)k], inner[(size_t)j]); }
+        for (int k = 0; k < want; ++k) { is_cut[inner[(size_t)k]] = 1; extra[(size_t)ri].push_back(inner[(size_t)k]); work.push_back(inner[(size_t)k]); }
+        work.push_back(c);   // what is left above the new cut nodes may still be too large
       }
-      if (best < 0) continue;   // cannot be split within the size floor
-      is_cut[best] = 1; cuts.push_back(best);
-      for (int32_t u = tp_parent[best]; ; u = tp_parent[u]) { size[u] -= size[best] - 1; if (u == c) break; }
-      if (size[best] > limit) work.push_back(best);
-      if (size[c] > limit) work.push_back(c);
-    }
+    }, 16);
+    for (auto& e : extra) { cuts.insert(cuts.end(), e.begin(), e.end()); last_extra_cuts += (int)e.size(); }
     return cuts;
   }
 
+  void note_partition_stats() { last_num_parts = (int)parts.size(); last_largest_part = 0; for (auto& pm : parts) last_largest_part = std::max(last_largest_part, (int)pm.orig.size()); }
   // tree_partitioning.h:88-135 and :196-239
   void partition_tree(const std::vector<int32_t>& stencil) {
     int root_idx = (int)stencil.size(); bool root_in = false;
@@ -594,11 +611,13 @@ struct RunDriver {
       const size_t N = tp_parent.size();
       if (stencil.size() + 1 >= 64 && N / (stencil.size() + 1) <= 2048) {
         int32_t P = 0, rp = -1;
-        emat_status st1 = bk(emat_tree_partition(backend, (int32_t)stencil.size(), stencil.data(), &P, &rp, nullptr)); if (st1) return st1;
+        std::vector<int32_t> psz(stencil.size() + 1, 0);
+        emat_status st1 = bk(emat_tree_partition(backend, (int32_t)stencil.size(), stencil.data(), &P, &rp, psz.data())); if (st1) return st1;
+        last_num_parts = P; last_largest_part = 0; for (int p = 0; p < P; ++p) last_largest_part = std::max(last_largest_part, (int)psz[(size_t)p]);
         parts.assign((size_t)P, PartMap{});
         for (int p = 0; p < P; ++p) parts[p].cut_point = p < (int)stencil.size() ? stencil[p] : tp_root;
         root_part = rp; partition_on_device = true;
-      } else { partition_tree(stencil); partition_on_device = false; }
+      } else { partition_tree(stencil); partition_on_device = false; note_partition_stats(); }
       ++epoch;
     } catch (const std::exception& ex) { return fail(EMAT_ERR_INTERNAL, ex.what()); }
     auto t2 = now();
@@ -680,6 +699,7 @@ struct RunDriver {
       part_kids.clear();
       t1 = now();
       partition_tree(stencil);
+      note_partition_stats();
       if (!tree.nodes[tree.root].mfs.empty()) return fail(EMAT_ERR_INTERNAL, "root missations carry from_states");
       normalize_root();
       ++epoch;
@@ -787,7 +807,15 @@ emat_status emat_run_create(emat_backend* backend, const emat_flat_tree* tree, c
 emat_status emat_run_destroy(emat_run* r) { delete r; return EMAT_OK; }
 const char* emat_run_last_error(const emat_run* r) { return r ? r->d.last_error.c_str() : "null run"; }
 
-emat_status emat_run_set_max_part_nodes(emat_run* r, int32_t n) { if (!r || n < 0) return EMAT_ERR_INVALID_ARGUMENT; r->d.max_part_nodes = n; return EMAT_OK; }
+emat_status emat_run_set_max_part_nodes(emat_run* r, int32_t n) { if (!r || n < -1) return EMAT_ERR_INVALID_ARGUMENT; r->d.max_part_nodes = n; return EMAT_OK; }
+emat_status emat_run_partition_stats(emat_run* r, int32_t* num_parts, int32_t* largest_part_nodes, int32_t* extra_cuts, int32_t* max_part_nodes_in_effect) {
+  if (!r) return EMAT_ERR_INVALID_ARGUMENT;
+  if (num_parts) *num_parts = r->d.last_num_parts;
+  if (largest_part_nodes) *largest_part_nodes = r->d.last_largest_part;
+  if (extra_cuts) *extra_cuts = r->d.last_extra_cuts;
+  if (max_part_nodes_in_effect) *max_part_nodes_in_effect = r->d.effective_max_part_nodes(r->d.device_tree ? r->d.tp_parent.size() : r->d.tree.nodes.size());
+  return EMAT_OK;
+}
 emat_status emat_run_set_num_parts(emat_run* r, int32_t n) { if (!r || n < 1) return EMAT_ERR_INVALID_ARGUMENT; r->d.num_parts = n; r->d.stencils.clear(); return EMAT_OK; }
 emat_status emat_run_set_hky(emat_run* r, double mu, double kappa, const double pi[4], const double* nu_l) {
   if (!r || !pi || !(mu >= 0) || !(kappa > 0)) return EMAT_ERR_INVALID_ARGUMENT;

@@ -292,7 +292,7 @@ def load_library():
         "emat_scalable_coalescent_log_prior": [B, dbl, dbl, i32, i32, P(dbl), dbl, P(dbl)],
         "emat_synth_create": [P(_SynthParamsC), P(S)], "emat_synth_get": [S, P(_FlatTreeC), P(P(C.c_uint8)), P(dbl)],
         "emat_run_create": [B, P(_FlatTreeC), P(C.c_uint8), i32, u64, P(R)], "emat_run_destroy": [R],
-        "emat_run_set_num_parts": [R, i32], "emat_run_set_max_part_nodes": [R, i32], "emat_run_set_hky": [R, dbl, dbl, P(dbl), P(dbl)], "emat_run_set_pop_model": [R, P(_PopModelC)],
+        "emat_run_set_num_parts": [R, i32], "emat_run_set_max_part_nodes": [R, i32], "emat_run_partition_stats": [R, P(i32), P(i32), P(i32), P(i32)], "emat_run_set_hky": [R, dbl, dbl, P(dbl), P(dbl)], "emat_run_set_pop_model": [R, P(_PopModelC)],
         "emat_run_set_coalescent_t_step": [R, dbl], "emat_run_set_flags": [R, i32, i32],
         "emat_run_repartition": [R], "emat_run_num_parts": [R, P(i32), P(i32)],
         "emat_run_part_sizes": [R, i32, P(i32), P(i32), P(i32), P(i32)], "emat_run_part_get": [R, i32, P(_FlatTreeC), P(i32), P(u64)],
@@ -882,8 +882,15 @@ class EmatRun:
         self._ck(self._lib.emat_run_set_num_parts(self._h, n), "emat_run_set_num_parts")
 
     def set_max_part_nodes(self, n: int):
-        """Not in the reference: cut parts larger than n nodes further at every repartition (0 = off)."""
+        """Not in the reference: parts larger than n nodes get further, randomly drawn cut nodes at every repartition
+        (-1 = three times the mean part size, the default; 0 = off, the reference's rule exactly)."""
         self._ck(self._lib.emat_run_set_max_part_nodes(self._h, n), "emat_run_set_max_part_nodes")
+
+    def partition_stats(self) -> dict:
+        """The last repartition: number of parts, nodes of the largest, cut nodes added by the size limit, the limit in effect."""
+        a, b, c, e = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._lib.emat_run_partition_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(e)), "emat_run_partition_stats")
+        return {"num_parts": a.value, "largest_part_nodes": b.value, "extra_cuts": c.value, "max_part_nodes": e.value}
 
     def set_hky(self, mu: float, kappa: float, pi, nu_l=None):
         pi = np.ascontiguousarray(pi, np.float64)

@@ -60,9 +60,14 @@ const char* emat_run_last_error(const emat_run* r);
 
 /* reference Run::set_num_parts (run.h:46-47) */
 emat_status emat_run_set_num_parts(emat_run* r, int32_t num_parts);
-/* NOT in the reference (0 = off, the reference's rule): at every repartition, parts of more than `max_nodes` nodes are cut
- * further, because on the GPU a pass lasts as long as its largest part.  Any set of cut nodes is a valid partition. */
+/* NOT in the reference: at every repartition, parts of more than `max_nodes` nodes get further cut nodes, because on the GPU a pass
+ * lasts as long as the chain of its largest part, and the parts of a stencil drift apart in size while it is in use (run.cpp:87-108
+ * redraws stencils every 200 cycles only).  The extra cut nodes are drawn uniformly at random among the part's inner nodes -- a rule
+ * that reads nothing a pass can change, so that it leaves the sampler's stationary distribution alone (emat_run.cpp, refine_stencil).
+ * -1 (the default) = three times the mean part size, at least 64; 0 = off: the reference's rule exactly; > 0 = that many nodes. */
 emat_status emat_run_set_max_part_nodes(emat_run* r, int32_t max_nodes);
+/* The last repartition: how many parts, the node count of the largest, how many cut nodes the rule above added, the limit in effect. */
+emat_status emat_run_partition_stats(emat_run* r, int32_t* num_parts, int32_t* largest_part_nodes, int32_t* extra_cuts, int32_t* max_part_nodes_in_effect);
 /* HKY substitution model with per-site relative rates nu_l (NULL = all 1): reference Hky_model +
  * Run::derive_evo (evo_hky.cpp:7-50).  One site partition. */
 emat_status emat_run_set_hky(emat_run* r, double mu, double kappa, const double pi[4], const double* nu_l);

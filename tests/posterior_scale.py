@@ -47,10 +47,11 @@ def chain_gpu(tips, num_parts, cycles, seed, out_path):
     t_step = sc.default_t_step(); run.set_coalescent_t_step(t_step)
     nodes = sc.tree.num_nodes; per_cycle = 50 * nodes
     t_ref = float(np.max(sc.tree.t[sc.tree.child0 == -1]))
-    rows, frozen, t0 = [], [], time.perf_counter()
+    rows, frozen, extra, largest, t0 = [], [], [], [], time.perf_counter()
     for c in range(cycles):
         run.repartition()
         n, _ = run.num_parts(); frozen.append((n - 1) / nodes)
+        ps = run.partition_stats(); extra.append(ps["extra_cuts"]); largest.append(ps["largest_part_nodes"])     # the part-size limit of the run driver at work (emat_run_set_max_part_nodes)
         run.run_moves(per_cycle)
         G, _ = b.totals()
         prior = b.scalable_coalescent_log_prior(t_ref, t_step)
@@ -60,7 +61,8 @@ def chain_gpu(tips, num_parts, cycles, seed, out_path):
         rows.append([G, prior, float(t[root]), float(np.sum(t[par >= 0] - t[par[par >= 0]])), nm])
         if (c + 1) % 200 == 0 or c + 1 == cycles:             # what there is so far survives a cut-off run
             json.dump({"rows": rows, "parts": n, "parts_requested": num_parts, "frozen_fraction": float(np.mean(frozen)), "seconds": time.perf_counter() - t0, "moves_per_cycle": per_cycle,
-                       "nodes": nodes, "engine": "gpu", "emat_build_id": d.library_build_id()}, open(out_path + ".tmp", "w"))
+                       "nodes": nodes, "engine": "gpu", "emat_build_id": d.library_build_id(), "max_part_nodes": ps["max_part_nodes"], "extra_cuts_per_cycle": float(np.mean(extra)),
+                       "largest_part_nodes_max": int(np.max(largest))}, open(out_path + ".tmp", "w"))
             os.replace(out_path + ".tmp", out_path)
     run.close(); b.close()
 
@@ -129,6 +131,8 @@ def summarise(path, burn, cycles):
     a = json.load(open(path)); rows = np.array(a["rows"])[burn:]
     cfg = {k: a[k] for k in ("parts", "parts_requested", "frozen_fraction", "seconds", "moves_per_cycle", "engine")}
     cfg["emat_build_id"] = a.get("emat_build_id")
+    for k in ("max_part_nodes", "extra_cuts_per_cycle", "largest_part_nodes_max"):
+        if k in a: cfg[k] = a[k]
     cfg["retained"] = int(rows.shape[0]); cfg["moves_per_s"] = len(a["rows"]) * a["moves_per_cycle"] / a["seconds"]
     cfg["stats"] = {}
     for j, nm in enumerate(NAMES):
@@ -169,7 +173,8 @@ if __name__ == "__main__":
         assert p is None or p.wait() == 0, (s, arm)
         res[(s, arm)] = summarise(path, burn, cycles)
         c = res[(s, arm)]
-        print("seed %d %-7s parts %5d (frozen %.2f%%) %s | %d retained | %.0f s, %.2f M moves/s" % (s, arm, c["parts"], 100 * c["frozen_fraction"], c["engine"], c["retained"], c["seconds"], c["moves_per_s"] / 1e6), flush=True)
+        print("seed %d %-7s parts %5d (frozen %.2f%%) %s | %d retained | %.0f s, %.2f M moves/s%s" % (s, arm, c["parts"], 100 * c["frozen_fraction"], c["engine"], c["retained"], c["seconds"], c["moves_per_s"] / 1e6,
+              " | part-size limit %d nodes: %.1f cut nodes added per cycle, largest part %d" % (c["max_part_nodes"], c["extra_cuts_per_cycle"], c["largest_part_nodes_max"]) if "max_part_nodes" in c else ""), flush=True)
         for nm in NAMES:
             st = c["stats"][nm]
             print("      %-22s mean %14.4f sd %10.4f ESS %8.1f se %9.4f ESS/s %8.3f ESS per 1e6 moves %8.4f" % (nm, st["mean"], st["sd"], st["ess"], st["se"], st["ess_per_s"], st["ess_per_million_moves"]), flush=True)

@@ -32,8 +32,7 @@ def _run(sc, seed, parts, device_tree, max_part_nodes=0, host_coalescent=True):
             os.environ["EMAT_TREE_HOST_COALESCENT"] = old
     run = d.EmatRun(b, sc.tree, sc.ref, seed)
     run.set_num_parts(parts)
-    if max_part_nodes:
-        run.set_max_part_nodes(max_part_nodes)
+    run.set_max_part_nodes(max_part_nodes)      # 0: the reference's partition rule exactly
     run.set_hky(sc.mu, sc.kappa, sc.pi)
     run.set_pop_model(sc.pop)
     if device_tree:

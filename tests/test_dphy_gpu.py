@@ -33,6 +33,7 @@ def test_a_device_resident_run_written_to_a_dphy_file_is_the_oracles_run(tmp_pat
     b = d.EmatBackend(sc.num_sites, trace_moves=300)
     run = d.EmatRun(b, sc.tree, sc.ref, 7)
     run.set_num_parts(parts); run.set_hky(sc.mu, sc.kappa, sc.pi); run.set_pop_model(sc.pop)
+    run.set_max_part_nodes(0)        # the reference's partition rule exactly, as the restated Run applies it
     run.set_device_tree(True)
     orun = OracleRun(sc.tree, sc.ref, 7 ^ 0xD1B54A32D192ED03, parts)
     q = DphyParams(); L.emat_dphy_params_defaults(C.byref(q))

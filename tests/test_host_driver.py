@@ -150,8 +150,8 @@ def test_global_statistics_decompose_over_parts():
 
 
 def test_oversized_parts_can_be_cut_further(sc):
-    """emat_run_set_max_part_nodes (not in the reference): with a limit, no part exceeds it (parts cannot shrink below the
-    reference's floor of 10), the partition still covers the tree, the parts still pass the reference's tree invariants,
+    """emat_run_set_max_part_nodes (not in the reference): with a limit, no part exceeds it (a part has at least a root and two
+    tips), the partition still covers the tree, the parts still pass the reference's tree invariants,
     and reassembling reproduces the tree exactly."""
     from oracle_ffi import OracleEngine
     from helpers import configure
@@ -166,7 +166,7 @@ def test_oversized_parts_can_be_cut_further(sc):
         sizes[limit] = [t.num_nodes for t, _, _ in parts]
         assert sum(sizes[limit]) == sc.tree.num_nodes + (n - 1)
         if limit:
-            assert max(sizes[limit]) <= limit and min(sizes[limit]) >= 3
+            assert max(sizes[limit]) <= limit and min(sizes[limit]) >= 3 and run.partition_stats()["extra_cuts"] == n - len(sizes[0])
             _, ref = run.tree()
             chk = OracleEngine(sc.num_sites)
             configure(chk, sc, ref, [t for t, _, _ in parts], [r for _, r, _ in parts], [s for _, _, s in parts], root_part)

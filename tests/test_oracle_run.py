@@ -25,6 +25,7 @@ def same_tree(a, b, what):
 def cycles(sc, seed, num_parts, n_cycles, moves_per_part):
     run = d.EmatRun(None, sc.tree, sc.ref, seed)
     run.set_num_parts(num_parts)
+    run.set_max_part_nodes(0)        # the reference's partition rule exactly (the run driver's default also caps the part size)
     orun = OracleRun(sc.tree, sc.ref, seed ^ 0xD1B54A32D192ED03, num_parts)     # emat_run_create: the partition stream is SplitMix64(seed ^ this constant)
     root_changes = 0
     try:
