@@ -984,7 +984,12 @@ struct emat_backend {
   bool order_valid = false;         // d_order holds the current parts, largest first
   std::vector<int32_t> h_order;     // host copy of d_order
   bool last_launch_uniform = false; // the last launch ran the same number of moves on every part (its durations are comparable)
-  bool cfg_order_by_time = false;   // EMAT_ORDER_BY_TIME (tuning knob): re-sort the launch order by measured durations at every synchronisation
+  bool cfg_order_by_time = false;   // option "order_by_time" (tuning knob): re-sort the launch order by measured durations at every synchronisation
+  std::string cfg_ticket_weights;   // option "ticket_weights": "w1,w2,..." the tickets' ratio, as many numbers as tickets
+  int cfg_build_blocks = 0;         // option "build_blocks": workgroups of the initial-tree builder's launch (0 = by tree size)
+  bool cfg_tree_tight = false;      // option "tree_tight" (testing aid): the device-resident tree gets no spare room, so that the growth paths run
+  unsigned cfg_fn_min_lists = 0;    // option "fn_min_lists" (profiling builds): function timers count only parts whose lists take at least this many bytes
+  bool cfg_phase_extra = false;     // option "phase_extra" (profiling builds): emat_debug_phase_ticks returns the scan and arena counters
                                     // (measured at C4: 292 vs 296 M moves/s -- with two parts per slot the slot that ran the longest part
                                     // still takes one more; off by default)
   bool pass_pending = false;        // a launch has not been checked for stopped parts yet (finish_pass)
@@ -1035,7 +1040,7 @@ struct emat_backend {
   bool cfg_ticket_spread = false;   // EMAT_TICKET_XCD_SPREAD=1 (tests): odd ticket stride, a part's tickets on different XCDs
   int cfg_single_ticket_parts = 0;        // EMAT_SINGLE_TICKET_PARTS (tuning knob): how many of the largest main-class parts run their pass as one ticket
   bool cfg_ticket_full_release = false;   // EMAT_TICKET_RELEASE=full: agent-scope release at every hand-over
-  bool cfg_chunks_forced = false;   // EMAT_CHUNKS was given: tickets also when the parts are fewer than the wave slots (tests)
+  bool cfg_chunks_forced = false;   // option "chunks" was given: tickets also when the parts are fewer than the wave slots (tests)
   DevBuf<int32_t> d_chunk_done, d_side_started;
   int cfg_parts_per_cu = 0;         // EMAT_PARTS_PER_CU (tuning knob): workgroups of the main class per CU, instead of the percentile rule
   bool cfg_gt_host_coal = false;    // EMAT_TREE_HOST_COALESCENT=1: emat_tree_repartition builds the coalescent tables on the host (bit-identical to the host cycle; tests)
@@ -1675,7 +1680,7 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
       b.taper = h->cfg_taper ? 1 : 0;
       for (int k = 0; k < 8; ++k) b.cum_w[k] = 0;
       if (h->cfg_taper && chunks == 4) { b.cum_w[0] = 10; b.cum_w[1] = 16; b.cum_w[2] = 19; b.cum_w[3] = 20; }   // 10 : 6 : 3 : 1 (measured best of the ratios tried)
-      if (const char* e = getenv("EMAT_TICKET_WEIGHTS")) { int acc = 0, k = 0; for (const char* q = e; *q && k < 8;) { acc += std::max(1, atoi(q)); b.cum_w[k++] = acc; while (*q && *q != ',') ++q; if (*q == ',') ++q; } if (k != chunks) for (int j = 0; j < 8; ++j) b.cum_w[j] = 0; }
+      if (const char* e = h->cfg_ticket_weights.empty() ? nullptr : h->cfg_ticket_weights.c_str()) { int acc = 0, k = 0; for (const char* q = e; *q && k < 8;) { acc += std::max(1, atoi(q)); b.cum_w[k++] = acc; while (*q && *q != ',') ++q; if (*q == ',') ++q; } if (k != chunks) for (int j = 0; j < 8; ++j) b.cum_w[j] = 0; }
       b.chunks = c == main_class ? chunks : 1; b.class_count = cnt; b.class_stride = (cnt + 7) & ~7; b.chunk_done = h->d_chunk_done.p;
       // Testing knobs.  EMAT_TICKET_XCD_SPREAD=1 makes the stride odd, so that consecutive tickets of a part land on DIFFERENT XCDs
       // (workgroups go round the eight XCDs by index): the hand-over then has to cross L2s, which the default placement avoids
@@ -1725,24 +1730,6 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
   if (hipSetDevice(cfg->device) != hipSuccess) return EMAT_ERR_HIP;
   auto h = std::make_unique<emat_backend>();
   h->cfg = *cfg; h->L = cfg->num_sites;
-  if (const char* e = getenv("EMAT_SLACK")) h->cfg.slab_slack = atof(e);
-  if (const char* e = getenv("EMAT_HEAP_PER_NODE")) h->cfg_heap_per_node = atof(e);
-  if (const char* e = getenv("EMAT_LDS_SCRATCH")) h->cfg_lds_scratch = (uint32_t)atoi(e) & ~15u;
-  if (const char* e = getenv("EMAT_LDS_CLASSES")) {   // e.g. "60,90,99,100"
-    h->cfg_class_pct.clear();
-    for (const char* q = e; *q;) { h->cfg_class_pct.push_back(std::max(1, std::min(100, atoi(q)))); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
-  }
-  if (const char* e = getenv("EMAT_LDS_MAX")) h->cfg_lds_max = (uint32_t)atoi(e) & ~511u;
-  if (const char* e = getenv("EMAT_GIANTS")) h->cfg_giants = atoi(e) != 0;
-  if (const char* e = getenv("EMAT_SIDE_ARENA")) h->cfg_side_arena = (uint32_t)atoi(e);
-  if (const char* e = getenv("EMAT_TREE_HOST_COALESCENT")) h->cfg_gt_host_coal = atoi(e) != 0;
-  if (const char* e = getenv("EMAT_TICKET_TAPER")) h->cfg_taper = atoi(e) != 0;
-  if (const char* e = getenv("EMAT_CHUNKS")) { h->cfg_chunks = std::max(1, std::min(64, atoi(e))); h->cfg_chunks_forced = true; }
-  if (const char* e = getenv("EMAT_TICKET_XCD_SPREAD")) h->cfg_ticket_spread = atoi(e) != 0;
-  if (const char* e = getenv("EMAT_TICKET_RELEASE")) h->cfg_ticket_full_release = strcmp(e, "full") == 0;
-  if (const char* e = getenv("EMAT_SINGLE_TICKET_PARTS")) h->cfg_single_ticket_parts = std::max(0, atoi(e));
-  if (const char* e = getenv("EMAT_PARTS_PER_CU")) h->cfg_parts_per_cu = std::max(0, std::min(4 * EMAT_WAVES_PER_EU, atoi(e)));
-  if (const char* e = getenv("EMAT_ORDER_BY_TIME")) h->cfg_order_by_time = atoi(e) != 0;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return EMAT_ERR_HIP; h->num_cus = prop.multiProcessorCount; }
   if (hipStreamCreate(&h->stream) != hipSuccess) return EMAT_ERR_HIP;
   h->xcc_count = probe_xcc_dealing(cfg->device, h->stream);
@@ -1768,6 +1755,41 @@ emat_status emat_backend_destroy(emat_backend* h) {
   delete h;
   return EMAT_OK;
 }
+/* Tuning and test options of one handle (header: emat_set_option).  Until round 4 these were environment variables read at
+ * emat_backend_create; a process that embeds the library sets them per handle instead, and nothing in its environment reaches them. */
+emat_status emat_set_option(emat_backend* h, const char* key, const char* value) {
+  if (!h || !key || !value) return EMAT_ERR_INVALID_ARGUMENT;
+  if (h->slabs_on_device) return fail(h, EMAT_ERR_STATE, "emat_set_option: options are set before the first launch");
+  const std::string k(key);
+  const char* e = value;
+  if (k == "slack") h->cfg.slab_slack = atof(e);
+  else if (k == "heap_per_node") h->cfg_heap_per_node = atof(e);
+  else if (k == "lds_scratch") h->cfg_lds_scratch = (uint32_t)atoi(e) & ~15u;
+  else if (k == "lds_classes") {   // e.g. "60,90,99,100"
+    h->cfg_class_pct.clear();
+    for (const char* q = e; *q;) { h->cfg_class_pct.push_back(std::max(1, std::min(100, atoi(q)))); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+  }
+  else if (k == "lds_max") h->cfg_lds_max = (uint32_t)atoi(e) & ~511u;
+  else if (k == "giants") h->cfg_giants = atoi(e) != 0;
+  else if (k == "side_arena") h->cfg_side_arena = (uint32_t)atoi(e);
+  else if (k == "tree_host_coalescent") h->cfg_gt_host_coal = atoi(e) != 0;
+  else if (k == "ticket_taper") h->cfg_taper = atoi(e) != 0;
+  else if (k == "chunks") { h->cfg_chunks = std::max(1, std::min(64, atoi(e))); h->cfg_chunks_forced = true; }
+  else if (k == "ticket_xcd_spread") h->cfg_ticket_spread = atoi(e) != 0;
+  else if (k == "ticket_release") h->cfg_ticket_full_release = strcmp(e, "full") == 0;
+  else if (k == "ticket_weights") h->cfg_ticket_weights = e;
+  else if (k == "single_ticket_parts") h->cfg_single_ticket_parts = std::max(0, atoi(e));
+  else if (k == "parts_per_cu") h->cfg_parts_per_cu = std::max(0, std::min(4 * EMAT_WAVES_PER_EU, atoi(e)));
+  else if (k == "order_by_time") h->cfg_order_by_time = atoi(e) != 0;
+  else if (k == "build_blocks") h->cfg_build_blocks = std::max(0, atoi(e));
+  else if (k == "tree_tight") h->cfg_tree_tight = atoi(e) != 0;
+  else if (k == "fn_min_lists") h->cfg_fn_min_lists = (unsigned)std::max(0, atoi(e));
+  else if (k == "phase_extra") h->cfg_phase_extra = atoi(e) != 0;
+  else return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_set_option: unknown option '" + k + "'");
+  return EMAT_OK;
+}
+/* Size of the host thread pool of this library (per process; takes effect if called before the first parallel loop; 0 = default). */
+emat_status emat_set_host_threads(int32_t n) { if (n < 0) return EMAT_ERR_INVALID_ARGUMENT; host_threads_override() = n; return EMAT_OK; }
 const char* emat_last_error(const emat_backend* h) { return h ? h->last_error.c_str() : "null backend"; }
 #ifndef EMAT_BUILD_ID
 #define EMAT_BUILD_ID "unstamped"
@@ -2483,7 +2505,7 @@ emat_status emat_debug_fn_ticks(emat_backend* h, uint64_t* out_12288) {
   HIP_TRY(hipMemcpyFromSymbol(out_12288, HIP_SYMBOL(::emat::g_fn_ticks), sizeof(unsigned long long) * 12288));
   std::vector<unsigned long long> z(12288, 0);
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(::emat::g_fn_ticks), z.data(), sizeof(unsigned long long) * 12288));
-  const unsigned min_lists = getenv("EMAT_FN_MIN_LISTS") ? (unsigned)atoi(getenv("EMAT_FN_MIN_LISTS")) : 0u;   // from the next pass on: only parts whose lists take at least this many bytes
+  const unsigned min_lists = h->cfg_fn_min_lists;   // from the next pass on: only parts whose lists take at least this many bytes
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(::emat::g_fn_min_list_bytes), &min_lists, sizeof(min_lists)));
   return EMAT_OK;
 #else
@@ -2534,7 +2556,7 @@ emat_status emat_debug_phase_ticks(emat_backend* h, int32_t part_id, int64_t* ou
   const SlabHeader* H = (const SlabHeader*)(h->h_slabs.data() + h->parts[part_id].slab_off);
 #ifdef EMAT_PROFILE_PHASES
   for (int i = 0; i < 16; ++i) out16[i] = H->phase_ticks[i];
-  if (getenv("EMAT_PHASE_EXTRA")) for (int i = 0; i < 16; ++i) out16[i] = ((const int64_t*)H->reserved)[i];   // scan and arena counters instead
+  if (h->cfg_phase_extra) for (int i = 0; i < 16; ++i) out16[i] = ((const int64_t*)H->reserved)[i];   // scan and arena counters instead
 #else
   (void)H; for (int i = 0; i < 16; ++i) out16[i] = 0;   // phase counters exist only in -DEMAT_PROFILE_PHASES builds
 #endif

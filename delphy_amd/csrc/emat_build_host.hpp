@@ -94,7 +94,7 @@ emat_status build_usher_like(emat_backend* h, const emat_tip_descs& td, uint64_t
     // barriers, and a meeting costs more the more workgroups attend: measured at 30 000 tips, 0.73 / 0.56 / 0.51 / 0.59 ms per tip
     // on 8 / 16 / 32 / 59 workgroups)
     int blocks = std::max(1, std::min(std::max(1, h->num_cus / 4), (N + 2 * k_build_threads - 1) / (2 * k_build_threads)));
-    if (const char* e = getenv("EMAT_BUILD_BLOCKS")) blocks = std::max(1, std::min(atoi(e), h->num_cus > 0 ? h->num_cus : 1));
+    if (h->cfg_build_blocks > 0) blocks = std::max(1, std::min(h->cfg_build_blocks, h->num_cus > 0 ? h->num_cus : 1));
     DevBuf<int32_t> d_shared; HIP_TRY(d_shared.alloc(8 + 64 + 2 * (size_t)blocks));
     HIP_TRY(hipMemsetAsync(d_shared.p, 0, (8 + 64 + 2 * (size_t)blocks) * sizeof(int32_t), h->stream));
     // the difference arrays start out zero; the first three nodes' places in the visiting order (the root, then its second child, then its first)

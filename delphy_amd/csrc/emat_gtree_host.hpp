@@ -74,7 +74,7 @@ emat_status emat_tree_upload(emat_backend* h, const emat_flat_tree* tree) {
   HIP_TRY(G.root.upload(&tree->root, 1));
   HIP_TRY(G.muts.upload(lm.data(), n)); HIP_TRY(G.miss.upload(li.data(), n)); HIP_TRY(G.mfs.upload(lf.data(), n));
   // the moves create and destroy list records: room for twice the present content plus a record per node
-  const bool tight = getenv("EMAT_TREE_TIGHT") != nullptr;   // testing aid: no room at all, so that the growth paths run
+  const bool tight = h->cfg_tree_tight;   // testing aid: no room at all, so that the growth paths run
   HIP_TRY(G.mut_heap.alloc(tight ? nm + 1 : 2 * nm + (size_t)n + 1024)); HIP_TRY(G.iv_heap.alloc(tight ? ni + 1 : 2 * ni + (size_t)n + 1024)); HIP_TRY(G.fs_heap.alloc(tight ? nf + 1 : 2 * nf + (size_t)n + 1024));
   if (nm) HIP_TRY(hipMemcpy(G.mut_heap.p, rm.data(), nm * sizeof(MutRec), hipMemcpyHostToDevice));
   if (ni) HIP_TRY(hipMemcpy(G.iv_heap.p, ri.data(), ni * sizeof(IvRec), hipMemcpyHostToDevice));
@@ -282,7 +282,7 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
     HIP_TRY(G.lpar.upload(lpar.data(), total));
   }
   HIP_TRY(G.measure.alloc(P));
-  { const size_t room = getenv("EMAT_TREE_TIGHT") ? 1 : (size_t)64 * P + 4096;
+  { const size_t room = h->cfg_tree_tight ? 1 : (size_t)64 * P + 4096;
     HIP_TRY(G.pool_muts.alloc(std::max<size_t>(G.pool_muts.n, room))); HIP_TRY(G.pool_ivs.alloc(std::max<size_t>(G.pool_ivs.n, room))); }
   HIP_TRY(G.pool_tops.alloc(2));
   const auto t1 = now();

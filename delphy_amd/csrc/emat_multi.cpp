@@ -33,6 +33,8 @@
 
 namespace {
 
+std::string& rccl_library_name() { static std::string s; return s; }
+
 struct Rccl {
   void* lib = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
@@ -43,8 +45,11 @@ struct Rccl {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool load(std::string& err) {
-    const char* names[] = {getenv("EMAT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) { if (!n || !*n) continue; lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+    // emat_multi_set_rccl_library names the ONE library to try; otherwise the usual names
+    const std::string& only = rccl_library_name();
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    if (!only.empty()) lib = dlopen(only.c_str(), RTLD_NOW | RTLD_LOCAL);
+    else for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
     if (!lib) { const char* e = dlerror(); err = std::string("librccl.so could not be loaded: ") + (e ? e : "?"); return false; }   // dlerror() clears what it returns: once
     auto sym = [&](const char* s) -> void* { void* p = dlsym(lib, s); if (!p) err = std::string("librccl.so lacks ") + s; return p; };
     CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
@@ -186,6 +191,18 @@ emat_run* emat_multi_shard(emat_multi* m, int32_t i) { return (m && i >= 0 && i 
 #define M_EVERY(expr) do { if (!m) return EMAT_ERR_INVALID_ARGUMENT; for (auto& s : m->shards) { emat_status st = (expr); if (st) return m->fail(st, emat_run_last_error(s.run)); } return EMAT_OK; } while (0)
 emat_status emat_multi_set_num_parts(emat_multi* m, int32_t num_parts) { M_EVERY(emat_run_set_num_parts(s.run, num_parts)); }
 emat_status emat_multi_set_max_part_nodes(emat_multi* m, int32_t max_nodes) { M_EVERY(emat_run_set_max_part_nodes(s.run, max_nodes)); }
+/* emat_set_option on every shard's backend (before the first repartition) */
+emat_status emat_multi_set_option(emat_multi* m, const char* key, const char* value) { M_EVERY(emat_set_option(s.backend, key, value)); }
+/* Which RCCL to load (dlopen name or path) instead of trying the usual names; process-wide, before emat_run_create_multi.  NULL or "" = the usual names. */
+emat_status emat_multi_set_rccl_library(const char* name) { rccl_library_name() = name ? name : ""; return EMAT_OK; }
+/* test hook: can RCCL be loaded with the present setting?  EMAT_OK, or EMAT_ERR_HIP with the reason in `err` (NUL-terminated, cut to err_cap). */
+emat_status emat_multi_debug_rccl_load(char* err, int32_t err_cap) {
+  Rccl r; std::string e;
+  const bool ok = r.load(e);
+  if (r.lib) dlclose(r.lib);
+  if (err && err_cap > 0) { const size_t n = std::min(e.size(), (size_t)err_cap - 1); memcpy(err, e.data(), n); err[n] = 0; }
+  return ok ? EMAT_OK : EMAT_ERR_HIP;
+}
 emat_status emat_multi_set_hky(emat_multi* m, double mu, double kappa, const double pi[4], const double* nu_l) { M_EVERY(emat_run_set_hky(s.run, mu, kappa, pi, nu_l)); }
 emat_status emat_multi_set_pop_model(emat_multi* m, const emat_pop_model* pm) { M_EVERY(emat_run_set_pop_model(s.run, pm)); }
 emat_status emat_multi_set_coalescent_t_step(emat_multi* m, double t_step) { M_EVERY(emat_run_set_coalescent_t_step(s.run, t_step)); }

@@ -13,10 +13,11 @@
 
 namespace emat {
 
+inline int& host_threads_override() { static int n = 0; return n; }   // emat_set_host_threads: before the first parallel loop of the process
 inline int host_threads() {
   unsigned hw = std::thread::hardware_concurrency();
   if (hw == 0) hw = 1;
-  if (const char* e = getenv("EMAT_HOST_THREADS")) return std::max(1, atoi(e));   // tuning knob
+  if (host_threads_override() > 0) return host_threads_override();   // tuning knob
   return (int)std::min(hw, 16u);   // the per-part work is allocation-bound: measured flat beyond ~16 threads
 }
 

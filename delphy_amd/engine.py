@@ -285,6 +285,7 @@ def load_library():
         "emat_debug_gamma": [B, i32, i32, P(dbl), P(dbl), P(dbl)],
         "emat_debug_pop": [B, P(_PopModelC), i32, i32, P(dbl), P(dbl), P(dbl)], "emat_debug_interval_op": [B, i32, P(i32), i32, P(i32), i32, P(i32), P(i32)],
         "emat_debug_tree_query": [B, i32, i32, i32, P(i32), P(i32), P(i32)],
+        "emat_set_option": [B, C.c_char_p, C.c_char_p], "emat_set_host_threads": [i32],
         "emat_debug_graft": [B, i32, i32, dbl, i32, i32, dbl, P(dbl), i32, P(i32)], "emat_debug_edit": [B, i32, i32, i32, P(i32), P(i32), P(dbl)],
         "emat_debug_sample_history": [B, i32, i32, P(i32), P(dbl), P(C.c_uint8), dbl, dbl, P(i32), P(dbl), i32, P(i32)],
         "emat_get_num_muts_l": [B, P(i32)], "emat_get_scalable_coalescent_log_prior": [B, dbl, dbl, P(dbl)],
@@ -318,7 +319,7 @@ def load_library():
     M = C.c_void_p
     sigs.update({
         "emat_run_create_multi": [P(i32), i32, P(_ConfigC), P(_FlatTreeC), P(C.c_uint8), i32, u64, i32, P(M)], "emat_multi_destroy": [M],
-        "emat_multi_set_num_parts": [M, i32], "emat_multi_set_max_part_nodes": [M, i32], "emat_multi_set_hky": [M, dbl, dbl, P(dbl), P(dbl)], "emat_multi_set_pop_model": [M, P(_PopModelC)],
+        "emat_multi_set_num_parts": [M, i32], "emat_multi_set_max_part_nodes": [M, i32], "emat_multi_set_option": [M, C.c_char_p, C.c_char_p], "emat_multi_set_rccl_library": [C.c_char_p], "emat_multi_debug_rccl_load": [C.c_char_p, i32], "emat_multi_set_hky": [M, dbl, dbl, P(dbl), P(dbl)], "emat_multi_set_pop_model": [M, P(_PopModelC)],
         "emat_multi_set_coalescent_t_step": [M, dbl], "emat_multi_set_flags": [M, i32, i32], "emat_multi_set_paranoid": [M, i32],
         "emat_multi_repartition": [M], "emat_multi_run_moves": [M, i64], "emat_multi_check_derived": [M, dbl], "emat_multi_reassemble": [M],
         "emat_multi_get_totals": [M, P(dbl), P(dbl)], "emat_multi_do_mcmc_steps": [M, i64, i64],
@@ -330,6 +331,8 @@ def load_library():
         fn.restype = C.c_int
     lib.emat_last_error.argtypes = [B]
     lib.emat_last_error.restype = C.c_char_p
+    if os.environ.get("EMAT_HOST_THREADS"):     # (the library reads no tuning from the environment: this mirror forwards it)
+        lib.emat_set_host_threads(int(os.environ["EMAT_HOST_THREADS"]))
     lib.emat_build_id.argtypes = []
     lib.emat_build_id.restype = C.c_char_p
     lib.emat_run_last_error.argtypes = [R]
@@ -420,6 +423,19 @@ def decode_graft_output(v, mode: int) -> dict:
     return out
 
 
+# The library itself reads no tuning from the environment (emat_set_option per handle).  For A/B scripts and tests this mirror forwards
+# EMAT_<NAME> variables of the process to every handle it creates -- the behaviour the library had built in until round 4.
+OPTION_KEYS = ("slack", "heap_per_node", "lds_scratch", "lds_classes", "lds_max", "giants", "side_arena", "tree_host_coalescent", "ticket_taper", "chunks", "ticket_xcd_spread",
+               "ticket_release", "ticket_weights", "single_ticket_parts", "parts_per_cu", "order_by_time", "build_blocks", "tree_tight", "fn_min_lists", "phase_extra")
+
+
+def _forward_env_options(setter):
+    for k in OPTION_KEYS:
+        v = os.environ.get("EMAT_" + k.upper())
+        if v is not None:
+            setter(k, v)
+
+
 class EmatBackend:
     """The engine behind include/emat_backend.h: one resident `Subrun` per partition part, on the GPU."""
 
@@ -432,6 +448,11 @@ class EmatBackend:
             raise EmatError("emat_backend_create failed: %s (the engine needs a HIP device; there is no CPU fallback)" % STATUS_NAMES.get(st, st))
         self.num_sites = num_sites
         self._keep = []
+        _forward_env_options(lambda k, v: self.set_option(k, v))
+
+    def set_option(self, key: str, value):
+        """A tuning / test option of this handle (include/emat_backend.h, emat_set_option), before the first launch."""
+        self._ck(self._lib.emat_set_option(self._h, key.encode(), str(value).encode()), "emat_set_option(%s)" % key)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -1028,11 +1049,14 @@ class EmatMultiRun:
         cfg = _ConfigC(0, self.num_sites, 0, 0.0, trace_moves, 1 if use_lds else 0)
         self._h = C.c_void_p()
         v = tree.c_view()
+        if os.environ.get("EMAT_RCCL_LIB"):
+            self._lib.emat_multi_set_rccl_library(os.environ["EMAT_RCCL_LIB"].encode())
         st = self._lib.emat_run_create_multi(_ptr(dev, C.c_int32), int(dev.shape[0]), C.byref(cfg), C.byref(v), _ptr(self._ref, C.c_uint8), self.num_sites, int(seed),
                                              self.EXCHANGE[exchange], C.byref(self._h))
         if st != 0:
             raise EmatError("emat_run_create_multi failed: %s (the engine needs HIP devices; exchange \"rccl\" needs librccl.so and one device per shard)" % STATUS_NAMES.get(st, st))
         self.num_shards = int(self._lib.emat_multi_num_shards(self._h))
+        _forward_env_options(lambda k, v: self._ck(self._lib.emat_multi_set_option(self._h, k.encode(), str(v).encode()), "emat_multi_set_option(%s)" % k))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -101,6 +101,24 @@ typedef struct emat_backend emat_backend;
 /* replaces: Subrun construction/destruction as a set (reference run.cpp:131,182-183) */
 emat_status emat_backend_create(const emat_config* cfg, emat_backend** out);
 emat_status emat_backend_destroy(emat_backend* h);
+/* Tuning and test options of one handle, by name, set after emat_backend_create and before the first launch (defaults are what
+ * bench.py measures; an unknown name is refused).  The library reads NO tuning from the environment (only EMAT_VERBOSE, which
+ * makes it narrate on stderr): an embedding process decides per handle.  The Python mirror forwards EMAT_<NAME> variables for
+ * A/B scripts.
+ *   "lds_classes"   percentile of part sizes the staging area must hold whole, default "60"; a comma list makes size classes
+ *   "lds_max"       largest staging area in bytes (default 98304);  "lds_scratch"  extra LDS scratch arena per part (default 0)
+ *   "giants"        0 disables the side launches;  "side_arena"  bytes of arena a part must be left with in the main area
+ *   "chunks"        tickets per part and pass in the main class (default 4);  "ticket_taper"  0 = equal tickets
+ *   "ticket_weights" "w1,w2,...";  "single_ticket_parts"  how many of the largest parts run a pass unsplit;  "parts_per_cu"
+ *   "slack", "heap_per_node"   list-heap capacity = content x slack + bytes per node (3.0 / 64)
+ *   "order_by_time" 1 = re-sort the launch order by measured chain times at every synchronisation
+ *   "tree_host_coalescent"  1 = emat_tree_repartition builds the coalescent tables with the host's code (bit-identical to the host cycle)
+ *   testing aids: "ticket_xcd_spread" (a part's tickets on different XCDs), "ticket_release" ("full": plain agent-scope releases),
+ *   "tree_tight" (no spare room in the device tree), "build_blocks" (workgroups of the initial-tree builder);
+ *   profiling builds: "fn_min_lists", "phase_extra". */
+emat_status emat_set_option(emat_backend* h, const char* key, const char* value);
+/* Size of the library's host thread pool (per process, before its first parallel loop; 0 = default: min(cores, 16)). */
+emat_status emat_set_host_threads(int32_t n);
 const char* emat_last_error(const emat_backend* h);   /* human-readable text for the last failure */
 /* First 16 hex digits of the SHA-256 of the sources the kernels of THIS library were compiled from (csrc/Makefile: DEVSRC, in
  * that order); "unstamped" for a build that bypassed the Makefile.  bench.py refuses a library whose id differs from the

@@ -157,6 +157,10 @@ emat_backend* emat_multi_backend(emat_multi* m, int32_t shard);
 emat_run* emat_multi_shard(emat_multi* m, int32_t shard);
 emat_status emat_multi_set_num_parts(emat_multi* m, int32_t num_parts);
 emat_status emat_multi_set_max_part_nodes(emat_multi* m, int32_t max_nodes);
+emat_status emat_multi_set_option(emat_multi* m, const char* key, const char* value);   /* emat_set_option on every shard's backend */
+/* Which RCCL to dlopen (name or path) instead of the usual names; process-wide, before emat_run_create_multi; NULL = the usual names. */
+emat_status emat_multi_set_rccl_library(const char* name);
+emat_status emat_multi_debug_rccl_load(char* err, int32_t err_cap);   /* test hook: EMAT_OK if RCCL loads with the present setting, else EMAT_ERR_HIP and why */
 emat_status emat_multi_set_hky(emat_multi* m, double mu, double kappa, const double pi[4], const double* nu_l);
 emat_status emat_multi_set_pop_model(emat_multi* m, const emat_pop_model* pm);
 emat_status emat_multi_set_coalescent_t_step(emat_multi* m, double t_step);

@@ -72,3 +72,33 @@ def test_the_hbm_resident_tree_has_no_host_fallback():
     with pytest.raises(d.EmatError, match="EMAT_ERR_NO_DEVICE"):
         run.repartition()
     run.close(); b.close()
+
+
+def test_options_are_set_per_handle_and_the_library_reads_no_tuning_from_the_environment():
+    """emat_set_option replaces the EMAT_* environment switches the library used to read at emat_backend_create:
+    known names are taken, unknown ones refused, and the only getenv left in the product's C++ is EMAT_VERBOSE."""
+    b = d.EmatBackend(100, device=-1)
+    for k, v in (("lds_classes", "60,90"), ("chunks", 3), ("ticket_release", "full"), ("tree_host_coalescent", 1), ("slack", 1.5)):
+        b.set_option(k, v)
+    with pytest.raises(d.EmatError, match="unknown option"):
+        b.set_option("no_such_option", 1)
+    b.close()
+    left = set()
+    for f in os.listdir(os.path.join(ROOT, "delphy_amd", "csrc")):
+        if f.endswith((".hpp", ".hip", ".cpp")):
+            left |= set(re.findall(r'getenv\("(\w+)"\)', open(os.path.join(ROOT, "delphy_amd", "csrc", f)).read()))
+    assert left == {"EMAT_VERBOSE"}, left
+
+
+def test_a_missing_rccl_is_reported_not_crashed_on():
+    """Rccl::load with a library that cannot be opened (ADVICE round 4: the message was built from two dlerror() calls, the second
+    of which returns NULL): a status and a text, and the usual names work again afterwards."""
+    lib = d.load_library()
+    buf = C.create_string_buffer(512)
+    assert lib.emat_multi_set_rccl_library(b"/nonexistent/librccl_not_here.so") == 0
+    try:
+        assert lib.emat_multi_debug_rccl_load(buf, 512) != 0
+        assert b"could not be loaded" in buf.value and b"librccl_not_here" in buf.value, buf.value
+    finally:
+        lib.emat_multi_set_rccl_library(None)
+    assert lib.emat_multi_debug_rccl_load(buf, 512) == 0, buf.value      # the image ships RCCL: the default names load

@@ -192,18 +192,24 @@ def test_coalescent_posterior_of_n_tips_through_partitioned_cycles_on_the_gpu():
     rng = np.random.default_rng(5)
     ref = rng.choice(4, size=L, p=PI).astype(np.uint8)
     tree = _ladder(N_TIPS)
-    for device_tree in (False, True):
+    # the third arm: two parts requested and a part-size limit of 21 nodes (emat_run_set_max_part_nodes: parts above it get further cut
+    # nodes, drawn uniformly among their inner nodes -- the rule the run driver applies by default at three times the mean part
+    # size, which this 47-node tree never reaches): the same closed-form posterior must come out
+    for device_tree, parts, limit in ((False, 3, -1), (True, 3, -1), (True, 2, 21)):
         b = d.EmatBackend(L)
         run = d.EmatRun(b, tree, ref, 23)
-        run.set_num_parts(3); run.set_hky(MU, KAPPA, PI); run.set_pop_model(d.PopModel.const(N_POP)); run.set_coalescent_t_step(T_STEP_N)
+        run.set_num_parts(parts); run.set_max_part_nodes(limit); run.set_hky(MU, KAPPA, PI); run.set_pop_model(d.PopModel.const(N_POP)); run.set_coalescent_t_step(T_STEP_N)
         if device_tree:
             run.set_device_tree(True)
-        hs, Ts = [], []
+        hs, Ts, cut = [], [], 0
         for cycle in range(2500):
             run.do_mcmc_steps(450, 450)
+            st = run.partition_stats(); cut += st["extra_cuts"]
+            assert limit < 0 or st["largest_part_nodes"] <= limit
             whole, _ = run.tree()
             h, T = _tree_stats(whole)
             hs.append(h); Ts.append(T)
+        assert (cut > 2500) == (limit > 0), (limit, cut)
         # lambda: the rate of leaving the reference sequence (no mutations anywhere, so every node has it)
         chk = OracleEngine(L)
         sc = Scenario("n tips", whole, ref, 0.0, MU, KAPPA, PI, d.PopModel.const(N_POP), L)
