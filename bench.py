@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--moves-per-part", type=int, default=1000)
     ap.add_argument("--max-part-nodes", type=int, default=-1, help="not in the reference: parts larger than this get further, randomly drawn cut nodes at every repartition "
                                                                     "(-1 = the run driver's default, three times the mean part size; 0 = the reference's partitioning rule exactly)")
+    ap.add_argument("--secondary", default="C5", help="a second workload measured the same way and reported as `secondary` (default C5, the one with enough parts for eight GPUs; '' = none)")
+    ap.add_argument("--secondary-steps", type=int, default=3)
     ap.add_argument("--inclusive-cycles", type=int, default=210, help="whole cycles of the `inclusive` figure (the reference redraws its partition stencils every 200 cycles)")
     ap.add_argument("--no-lds", action="store_true")
     ap.add_argument("--no-topology", action="store_true", help="diagnostic: disable subtree-slide and SPR moves")
@@ -214,6 +216,49 @@ def inclusive_cycles(sc, args, cycles=210):
     return out
 
 
+def measure_secondary(args, world, rank, local_rank, shared_gpu, allreduce, dist, torch):
+    """`args.secondary` (C5) through the same timed region as the headline: W warm-up passes, K passes between barriers, the MAX over
+    ranks of the time, all parts of the run / that time."""
+    import numpy as np
+    from delphy_amd.scenarios import make_scenario
+    from delphy_amd.sharding import ShardedEngine
+    t0 = time.perf_counter()
+    sc2 = make_scenario(args.secondary)
+    parts = {"C5": 81920, "C4": 8192, "C3": 1024}.get(args.secondary, 8192)
+    eng = ShardedEngine(sc2, num_parts=parts, seed=20261001, rank=rank, world=world, device=local_rank, use_lds=not args.no_lds, allreduce=allreduce, max_part_nodes=args.max_part_nodes)
+    eng.setup()
+    setup_s = time.perf_counter() - t0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.backend.synchronize()
+
+    eng.backend.run_moves_per_part(args.moves_per_part)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.secondary_steps):
+        eng.backend.run_moves_per_part(args.moves_per_part)
+    barrier()
+    dt = time.perf_counter() - t1
+    rank_ms, rank_parts, rank_setup = [dt / args.secondary_steps * 1e3], [eng.num_local_parts], [setup_s]
+    if world > 1:
+        mine = torch.tensor([rank_ms[0], float(eng.num_local_parts), setup_s], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms, rank_parts, rank_setup = [float(e[0].item()) for e in every], [int(e[1].item()) for e in every], [float(e[2].item()) for e in every]
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    bad = eng.local_stats()["bad_parts"]
+    total = eng.total_parts
+    eng.close()
+    return {"workload": "%s: synthetic %d-tip EMAT, %d sites, %d partition parts (%d nodes), %d moves/part/step" % (sc2.name, sc2.num_tips, sc2.num_sites, total, sc2.tree.num_nodes, args.moves_per_part),
+            "value": total * args.moves_per_part * args.secondary_steps / dt, "unit": "moves/s", "steps": args.secondary_steps, "warmup": 1, "ms_per_step": dt / args.secondary_steps * 1e3,
+            "scaling": "strong", "per_rank": {"ms_per_step": rank_ms, "parts": rank_parts, "setup_s": rank_setup}, "parts_stopped_on_rank_0": bad}
+
+
 def _part_digest(backend, p):
     """What a part's chain left behind, as numbers that survive a float64 tensor: 48 bits of a hash of everything discrete (topology,
     sites, states, interval endpoints), the sum of its node times, its log G and augmented prior, its move and random-draw counts."""
@@ -326,6 +371,7 @@ def main():
         raise SystemExit("bench.py: %s was built from device code %s, the sources are %s: rebuild (python -c 'import __graft_entry__ as g; g.build()')"
                          % (d.library_path(), build_id, d.source_build_id()))
 
+    t_setup0 = time.perf_counter()
     sc = make_scenario(args.workload, num_tips=args.tips)
     # The reference cuts the tree into as many parts as it has workers (tools/delphy.cpp:130-132); here a worker is a
     # wavefront slot, ~4 000 per GPU, so the request grows with the number of GPUs.  The tree is the same at every N
@@ -340,6 +386,7 @@ def main():
     eng.topology = not args.no_topology
     eng.only_displace = args.only_displace
     eng.setup()   # partition, upload this rank's parts, exchange the coalescent grid, recalc derived quantities
+    setup_s = time.perf_counter() - t_setup0     # every rank generates the tree and draws the partition itself (same seed: no communication)
 
     def barrier():
         if world > 1:
@@ -369,13 +416,15 @@ def main():
     rank_ms = [dt / args.steps * 1e3]
     rank_kernel_ms = [float(np.mean(ev_ms)) if ev_ms else float("nan")]
     rank_parts = [eng.num_local_parts]
+    rank_setup_s = [setup_s]
     if world > 1:
-        mine = torch.tensor([dt / args.steps * 1e3, rank_kernel_ms[0], float(eng.num_local_parts)], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
+        mine = torch.tensor([dt / args.steps * 1e3, rank_kernel_ms[0], float(eng.num_local_parts), setup_s], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         rank_ms = [float(e[0].item()) for e in every]
         rank_kernel_ms = [float(e[1].item()) for e in every]
         rank_parts = [int(e[2].item()) for e in every]
+        rank_setup_s = [float(e[3].item()) for e in every]
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -452,6 +501,12 @@ def main():
         except Exception as e:
             mixing = dict(mixing or {}, at_scale={"error": "unreadable profiles/posterior_scale_latest.json: %s" % e})
 
+    # The same measurement on the workload that HAS the parts to fill eight GPUs (C5: 1 000 000 tips, about 80 000 parts -- the 100 000-tip
+    # tree of the metric yields about 8 000, fewer than one GPU has wave slots from N = 2 on), so that a scaling run shows both curves.
+    secondary = None
+    if args.secondary and args.secondary != args.workload and args.tips is None:
+        secondary = measure_secondary(args, world, rank, local_rank, shared_gpu, allreduce, dist, torch)
+
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_base = cpu_baseline(sc, args.parts, 20261001, args.cpu_seconds, eng.t_step)
@@ -484,7 +539,8 @@ def main():
                 "collectives": ("gloo on one shared GPU (plumbing check)" if shared_gpu else "RCCL, world size %d" % dist.get_world_size()) if world > 1 else "none (one rank)",
                 "emat_build_id": build_id,
             },
-            "per_rank": {"ms_per_step": rank_ms, "kernel_ms": rank_kernel_ms, "parts": rank_parts},
+            "per_rank": {"ms_per_step": rank_ms, "kernel_ms": rank_kernel_ms, "parts": rank_parts, "setup_s": rank_setup_s},
+            "secondary": secondary,
             # "bound" names the yardstick the contract asks for; "limiter" says what actually limits the kernel
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_read": traffic_read, "traffic_write": traffic_write, "traffic_source": traffic_source,

@@ -51,3 +51,19 @@ def test_two_ranks_on_the_one_gpu_of_the_test_box():
     sc = out["scale_check"]
     assert sc["ok"] and sc["ranks_seen"] == 2 and sc["parts_reported"] == sc["parts_of_the_run"] == sum(out["per_rank"]["parts"])
     assert sc["parts_with_other_move_or_draw_counts"] == 0 and sc["parts_whose_trees_differ"] == 0 and sc["parts_verified"] >= 8 and sc["max_rel_err"] < 1e-9
+
+
+@pytest.mark.gpu
+def test_eight_ranks_on_the_one_gpu_of_the_test_box():
+    """`python bench.py --gpus 8`, the command of the driver's scaling run, with all eight ranks on the one GPU of the test box (gloo):
+    it must finish within ten minutes, check itself (scale_check: what the eight ranks computed is what one rank computes), time every
+    rank's setup, and carry the C5 series as `secondary`."""
+    import json
+    r = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-inclusive", "--secondary-steps", "1"], {"EMAT_BENCH_SHARED_GPU": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and len(out["per_rank"]["ms_per_step"]) == 8 and len(out["per_rank"]["setup_s"]) == 8 and max(out["per_rank"]["setup_s"]) < 120
+    sc = out["scale_check"]
+    assert sc["ok"] and sc["ranks_seen"] == 8 and sc["parts_reported"] == sc["parts_of_the_run"] == sum(out["per_rank"]["parts"])
+    sec = out["secondary"]
+    assert sec["workload"].startswith("C5") and len(sec["per_rank"]["parts"]) == 8 and sum(sec["per_rank"]["parts"]) > 70000 and sec["value"] > 0 and sec["parts_stopped_on_rank_0"] == 0
