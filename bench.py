@@ -44,9 +44,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C4", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--tips", type=int, default=None, help="override the number of tips (debug)")
-    ap.add_argument("--parts", type=int, default=None, help="number of partition parts requested from the partitioner (the same at every N: strong scaling of one decomposition); "
-                    "default 8192 at C4, 81920 at C5 (about 25 nodes per part)")
-    ap.add_argument("--moves-per-part", type=int, default=1000)
+    ap.add_argument("--parts", type=int, default=None, help="number of partition parts requested from the partitioner; default: 8192 at C4, 81920 at C5 (about 25 nodes per part), "
+                    "and at least 8192 per GPU -- the reference cuts as many parts as it has workers (tools/delphy.cpp:130-132), here two per wavefront slot; "
+                    "the partitioner's floor of 10 nodes per part caps what a tree yields (13 140 parts at C4)")
+    ap.add_argument("--moves-per-part", type=int, default=None, help="moves per part and step; default 1000 on one GPU, and on N > 1 what keeps the moves of a step the same as on one GPU")
     ap.add_argument("--max-part-nodes", type=int, default=-1, help="not in the reference: parts larger than this get further, randomly drawn cut nodes at every repartition "
                                                                     "(-1 = the run driver's default, three times the mean part size; 0 = the reference's partitioning rule exactly)")
     ap.add_argument("--secondary", default="C5", help="a second workload measured the same way and reported as `secondary` (default C5, the one with enough parts for eight GPUs; '' = none)")
@@ -61,8 +62,12 @@ def parse():
                     "(outside the timed region; the counters of ALL parts are compared whatever this says; 0 = no check)")
     ap.add_argument("--no-inclusive", action="store_true", help="skip the host-cycle-inclusive figure (repartition + moves + reassemble through the run driver)")
     args = ap.parse_args()
+    args.parts_auto = args.parts is None
     if args.parts is None:
         args.parts = DEFAULT_PARTS[args.workload]
+    args.moves_auto = args.moves_per_part is None
+    if args.moves_per_part is None:
+        args.moves_per_part = 1000
     return args
 
 
@@ -222,9 +227,10 @@ def measure_secondary(args, world, rank, local_rank, shared_gpu, allreduce, dist
     import numpy as np
     from delphy_amd.scenarios import make_scenario
     from delphy_amd.sharding import ShardedEngine
+    moves = 1000
     t0 = time.perf_counter()
     sc2 = make_scenario(args.secondary)
-    parts = {"C5": 81920, "C4": 8192, "C3": 1024}.get(args.secondary, 8192)
+    parts = max(DEFAULT_PARTS.get(args.secondary, 8192), 8192 * world)
     eng = ShardedEngine(sc2, num_parts=parts, seed=20261001, rank=rank, world=world, device=local_rank, use_lds=not args.no_lds, allreduce=allreduce, max_part_nodes=args.max_part_nodes)
     eng.setup()
     setup_s = time.perf_counter() - t0
@@ -235,11 +241,11 @@ def measure_secondary(args, world, rank, local_rank, shared_gpu, allreduce, dist
         torch.cuda.synchronize()
         eng.backend.synchronize()
 
-    eng.backend.run_moves_per_part(args.moves_per_part)
+    eng.backend.run_moves_per_part(moves)
     barrier()
     t1 = time.perf_counter()
     for _ in range(args.secondary_steps):
-        eng.backend.run_moves_per_part(args.moves_per_part)
+        eng.backend.run_moves_per_part(moves)
     barrier()
     dt = time.perf_counter() - t1
     rank_ms, rank_parts, rank_setup = [dt / args.secondary_steps * 1e3], [eng.num_local_parts], [setup_s]
@@ -254,8 +260,8 @@ def measure_secondary(args, world, rank, local_rank, shared_gpu, allreduce, dist
     bad = eng.local_stats()["bad_parts"]
     total = eng.total_parts
     eng.close()
-    return {"workload": "%s: synthetic %d-tip EMAT, %d sites, %d partition parts (%d nodes), %d moves/part/step" % (sc2.name, sc2.num_tips, sc2.num_sites, total, sc2.tree.num_nodes, args.moves_per_part),
-            "value": total * args.moves_per_part * args.secondary_steps / dt, "unit": "moves/s", "steps": args.secondary_steps, "warmup": 1, "ms_per_step": dt / args.secondary_steps * 1e3,
+    return {"workload": "%s: synthetic %d-tip EMAT, %d sites, %d partition parts (%d nodes), %d moves/part/step" % (sc2.name, sc2.num_tips, sc2.num_sites, total, sc2.tree.num_nodes, moves),
+            "value": total * moves * args.secondary_steps / dt, "unit": "moves/s", "steps": args.secondary_steps, "warmup": 1, "ms_per_step": dt / args.secondary_steps * 1e3,
             "scaling": "strong", "per_rank": {"ms_per_step": rank_ms, "parts": rank_parts, "setup_s": rank_setup}, "parts_stopped_on_rank_0": bad}
 
 
@@ -371,6 +377,12 @@ def main():
         raise SystemExit("bench.py: %s was built from device code %s, the sources are %s: rebuild (python -c 'import __graft_entry__ as g; g.build()')"
                          % (d.library_path(), build_id, d.source_build_id()))
 
+    # The reference cuts the tree into as many parts as it has workers (tools/delphy.cpp:130-132).  Here a worker is a wavefront slot, 4 096
+    # per GPU, and a pass wants about two parts per slot (with one, a rank's pass is as long as its slowest chain): the request grows with
+    # the number of GPUs, the moves of a step stay what they are on one GPU.  Same tree, same total work at every N: "strong" scaling.
+    base_parts = args.parts
+    if args.parts_auto:
+        args.parts = max(args.parts, 8192 * world)
     t_setup0 = time.perf_counter()
     sc = make_scenario(args.workload, num_tips=args.tips)
     # The reference cuts the tree into as many parts as it has workers (tools/delphy.cpp:130-132); here a worker is a
@@ -387,6 +399,8 @@ def main():
     eng.only_displace = args.only_displace
     eng.setup()   # partition, upload this rank's parts, exchange the coalescent grid, recalc derived quantities
     setup_s = time.perf_counter() - t_setup0     # every rank generates the tree and draws the partition itself (same seed: no communication)
+    if args.moves_auto and args.parts != base_parts:
+        args.moves_per_part = max(1, int(round(1000.0 * base_parts / eng.total_parts)))   # about the moves a step has on one GPU, over the finer partition
 
     def barrier():
         if world > 1:
@@ -443,6 +457,8 @@ def main():
     # (of the parts that ran in that kernel: the few parts of the side classes run beside it in k_run_moves_side)
     in_main = eng.backend.main_class_mask(eng.num_local_parts)
     per_part = np.array(stats1["algorithmic_bytes_of_part"], np.float64) - np.array(stats0["algorithmic_bytes_of_part"], np.float64)
+    per_part_w = np.array(stats1["algorithmic_write_bytes_of_part"], np.float64) - np.array(stats0["algorithmic_write_bytes_of_part"], np.float64)
+    write_bytes_per_launch = float(per_part_w[in_main].sum()) / max(1, launches)
     bytes_per_launch = float(per_part[in_main].sum()) / max(1, launches)
     bytes_per_launch_all = float(per_part.sum()) / max(1, launches)
     avg_ms = float(np.mean(ev_ms)) if ev_ms else float("nan")
@@ -532,7 +548,7 @@ def main():
                 "workload": "%s: synthetic %d-tip EMAT, %d sites, HKY(kappa=5) + %s, %d partition parts (%d nodes), %d moves/part/step, move mix 7.5/7.5/15/1/1"
                             % (sc.name, sc.num_tips, sc.num_sites, {0: "constant pop", 1: "exponential-growth coalescent", 2: "skygrid"}[sc.pop.kind],
                                total_parts, sc.tree.num_nodes, args.moves_per_part),
-                "parts_per_gpu": local_parts, "max_part_nodes": args.max_part_nodes,
+                "parts_per_gpu": local_parts, "parts_requested": args.parts, "max_part_nodes": args.max_part_nodes,
                 "lds_staging": not args.no_lds,
                 "tickets_per_part_and_pass": int(os.environ.get("EMAT_CHUNKS", "4")),
                 "parallelism": "parts sharded over %d GPU(s), one wavefront per part" % world,
@@ -547,6 +563,10 @@ def main():
                          "limiter": "instruction issue and LDS / L2 latency: a part's chain is serial and runs on one lane of its wavefront (the wave's other lanes "
                                     "take part in slab staging and in the candidate scan + study of SPR moves); residency is capped by LDS at 16 parts per CU",
                          "kernel": "k_run_moves", "kernel_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         # reads and writes apart, each with its own denominator: what the moves must read / must store, counted by the kernel
+                         "algorithmic_read_bytes": bytes_per_launch - write_bytes_per_launch, "algorithmic_write_bytes": write_bytes_per_launch,
+                         "traffic_read_over_algorithmic": (traffic_read / (bytes_per_launch - write_bytes_per_launch)) if traffic_read else None,
+                         "traffic_write_over_algorithmic": (traffic_write / write_bytes_per_launch) if (traffic_write and write_bytes_per_launch > 0) else None,
                          "parts_in_kernel": int(in_main.sum()), "algorithmic_bytes_per_pass_all_parts": bytes_per_launch_all},
             "cpu_baseline": cpu_base,
             "inclusive": inclusive,

@@ -146,7 +146,7 @@ template <class CtxT> __device__ inline void init_ctx(CtxT& c, uint8_t* slab, ui
   c.includes_run_root = (c.H->flags & k_flag_includes_run_root) != 0;
   c.rng_key = c.H->rng_key; c.rng_ctr = c.H->rng_counter; c.rng_spare = c.H->rng_spare; c.rng_has_spare = c.H->rng_has_spare != 0; c.phase = 0; c.svc = 0; c.frame = nullptr;
   c.rng_base = c.rng_ctr - (uint64_t)k_rng_blocks;   // nothing computed ahead yet: the chain's first step asks the wave for it
-  c.mu_prop = 0.0; c.sc_top = c.H->scratch_begin; c.A = nullptr; c.a_top = 0; c.a_end = 0; c.failed = false; c.bytes = 0;
+  c.mu_prop = 0.0; c.sc_top = c.H->scratch_begin; c.A = nullptr; c.a_top = 0; c.a_end = 0; c.failed = false; c.bytes = 0; c.bytes_w = 0;
   c.tr_kind = -1.0; c.tr_node = -1.0; c.tr_acc = 0.0; c.tr_log_mh = 0.0;
 }
 __device__ inline const double* stage_tables(const KernelArgs& a, double* lds_tables, int lane) {
@@ -329,7 +329,7 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
       if (raise_prio) __builtin_amdgcn_s_setprio(0);
       const dev::Ctx& c = *(const dev::Ctx*)(emat_lds_ctx);
       H->rng_counter = c.rng_ctr; H->rng_spare = c.rng_spare; H->rng_has_spare = c.rng_has_spare ? 1u : 0u;
-      H->alg_bytes += c.bytes;
+      H->alg_bytes += c.bytes; H->alg_write16 += (uint32_t)((c.bytes_w + 8) >> 4);
       const int64_t dt = (int64_t)(wall_clock64() - tick0);
       H->device_ticks += dt;
       st_ticks(ld_ticks() + dt);
@@ -1352,7 +1352,7 @@ emat_status pull_from_device_impl(emat_backend* h) {
     decode_slab(ph, slab, h->sh_ktw.empty() ? nullptr : h->sh_ktw.data(), h->sh_popsize.data(), h->sh_nact.data());
     ph.stats.status = H->status; ph.stats.num_nodes = H->n_nodes; ph.stats.moves_done = H->moves_done;
     for (int k = 0; k < 5; ++k) { ph.stats.proposed[k] = H->proposed[k]; ph.stats.accepted[k] = H->accepted[k]; }
-    ph.stats.algorithmic_bytes = H->alg_bytes; ph.stats.rng_draws = (int64_t)H->rng_counter; ph.stats.device_ticks = H->device_ticks;
+    ph.stats.algorithmic_bytes = H->alg_bytes; ph.stats.algorithmic_write_bytes = 16 * (int64_t)H->alg_write16; ph.stats.rng_draws = (int64_t)H->rng_counter; ph.stats.device_ticks = H->device_ticks;
   });
   h->host_slabs_current = true;
   return EMAT_OK;
@@ -1540,7 +1540,7 @@ emat_status materialize(emat_backend* h) {
     // carry the statistics over re-materialisations
     SlabHeader* H = (SlabHeader*)(h->h_slabs.data() + ph.slab_off);
     H->moves_done = ph.stats.moves_done; for (int k = 0; k < 5; ++k) { H->proposed[k] = ph.stats.proposed[k]; H->accepted[k] = ph.stats.accepted[k]; }
-    H->alg_bytes = ph.stats.algorithmic_bytes; H->device_ticks = ph.stats.device_ticks;
+    H->alg_bytes = ph.stats.algorithmic_bytes; H->alg_write16 = (uint32_t)(ph.stats.algorithmic_write_bytes / 16); H->device_ticks = ph.stats.device_ticks;
   });
   assign_size_classes(h);
   h->order_valid = false;
@@ -2100,7 +2100,7 @@ emat_status emat_part_get_stats(emat_backend* h, int32_t part_id, emat_part_stat
     const SlabHeader* H = header_of(h, (size_t)part_id);
     out->status = H->status; out->num_nodes = H->n_nodes; out->moves_done = H->moves_done;
     for (int k = 0; k < 5; ++k) { out->proposed[k] = H->proposed[k]; out->accepted[k] = H->accepted[k]; }
-    out->algorithmic_bytes = H->alg_bytes; out->rng_draws = (int64_t)H->rng_counter; out->device_ticks = H->device_ticks;
+    out->algorithmic_bytes = H->alg_bytes; out->algorithmic_write_bytes = 16 * (int64_t)H->alg_write16; out->rng_draws = (int64_t)H->rng_counter; out->device_ticks = H->device_ticks;
     if (H->status != 0) h->set_error("part " + std::to_string(part_id) + " stopped with status " + std::to_string(H->status) + " at device line " + std::to_string(H->fail_line));
   }
   return EMAT_OK;

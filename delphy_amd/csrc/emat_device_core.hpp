@@ -135,8 +135,9 @@ struct Ctx {
   bool mv_rng_had_spare;      // RNG position at the first draw of the current move: (mv_rng_ctr, mv_rng_had_spare), see stop_for_cells
   // statistics
   int64_t bytes;
+  int64_t bytes_w;            // the part of `bytes` that is written (cells, re-timed lists, region records, re-hung nodes): roofline.algorithmic_write_bytes
   // trace of the current move
-  double tr_kind, tr_node, tr_acc, tr_log_mh;
+  double tr_log_mh; float tr_kind, tr_node, tr_acc;   // (kind, node and accept flag are small integers: floats hold them exactly)
   int64_t moves_left;         // moves of the current launch still to do (run_chain_loop keeps nothing in registers across a move)
   uint64_t mv_rng_ctr;
   // the run-wide cell arrays (SharedCells, emat_slab.hpp): absolute cell index; the root part has its own copies in its slab
@@ -871,7 +872,7 @@ EMAT_DF void coal_add_interval(Ctx& c, double t_start, double t_end, double delt
     k.kbar_p[cell_end - first] += delta_k * (cell_ubound(c, cell_end) - t_end) / ts;
     for (int i = cell_start + 1; i < cell_end; ++i) k.kbar_p[i - first] += delta_k;
   }
-  c.bytes += 8 * (int64_t)(cell_end - cell_start + 1);
+  c.bytes += 8 * (int64_t)(cell_end - cell_start + 1); c.bytes_w += 8 * (int64_t)(cell_end - cell_start + 1);
 }
 EMAT_DF double coal_cell_term(const Ctx& c, const Cells& k, int w, double new_k, double old_k) {
   double na, tsop, ktw;   // num_active_parts, t_step / popsize_bar (the same double, divided when the cell was made), k_twiddle_bar

@@ -297,7 +297,7 @@ template <bool kRoot> EMAT_SIMPLE_MOVE void branch_reform_move(Ctx& c) { EMAT_TI
   note_move(c, X, log_mh, acc, k_branch_reform);
   if (acc) {
     for (int i = 0; i < nm.n; ++i) nm.p[i].pad = 0;
-    list_assign<MutRec>(c, nodes_of(c)[X].muts, nm.p, nm.n); hdr_of(c)->log_G += delta_log_G; c.bytes += 16 * nm.n;
+    list_assign<MutRec>(c, nodes_of(c)[X].muts, nm.p, nm.n); hdr_of(c)->log_G += delta_log_G; c.bytes += 16 * nm.n; c.bytes_w += 16 * nm.n;
   }
 }
 
@@ -531,7 +531,6 @@ EMAT_DN bool compact_heap(Ctx& c) {
     }
   }
   hdr_of(c)->heap_top = top;
-  hdr_of(c)->compactions++;
   return true;
 }
 

@@ -212,7 +212,7 @@ EMAT_DN void edit_do_hop_up(Ctx& c, int X) {   // tree_editing.cpp:164-231
   nodes_of(c)[P].n_missing = nodes_of(c)[G].n_missing;
   nodes_of(c)[G].lambda = nodes_of(c)[P].lambda + delta_lambda_across_node_missations(c, G);
   nodes_of(c)[G].n_missing = nodes_of(c)[P].n_missing + iv_num_sites(miss_of(c, G), (int)nodes_of(c)[G].miss.cnt);
-  c.bytes += 5 * 64;
+  c.bytes += 5 * 64; c.bytes_w += 160;   // (five node records re-linked: counted once, half of it as written)
 }
 EMAT_DN void edit_flip(Ctx& c, Edit& e) {   // tree_editing.cpp:233-278
   const int X = e.X, P = nodes_of(c)[X].parent;
@@ -234,7 +234,7 @@ EMAT_DN void edit_flip(Ctx& c, Edit& e) {   // tree_editing.cpp:233-278
   nodes_of(c)[U].parent = P;
   nodes_of(c)[P].lambda = nodes_of(c)[G].lambda + delta_lambda_across_node_missations(c, P);
   nodes_of(c)[P].n_missing = nodes_of(c)[G].n_missing + iv_num_sites(miss_of(c, P), (int)nodes_of(c)[P].miss.cnt);
-  c.bytes += 5 * 64;
+  c.bytes += 5 * 64; c.bytes_w += 160;   // (five node records re-linked: counted once, half of it as written)
 }
 EMAT_D void edit_hop_down(Ctx& c, Edit& e, int SS) {   // tree_editing.cpp:280-292
   const int P = nodes_of(c)[e.X].parent;
@@ -1167,7 +1167,7 @@ EMAT_DN Study make_study(Ctx& c, SVec<Region> regions, int num_missing_at_X, dou
       st.sum_W += W;
     }
   }
-  c.bytes += 2 * 48 * (int64_t)regions.n;
+  c.bytes += 2 * 48 * (int64_t)regions.n; c.bytes_w += 48 * (int64_t)regions.n;   // every region record written once and read once
   return st;
 }
 EMAT_D int study_pick_nexus_region(Ctx& c, const Study& st) {   // spr_study.cpp:404-422
@@ -1282,7 +1282,7 @@ EMAT_D void wave_make_study(Ctx& c, Spr1Frame& fr, SVec<Region> regions) {
     double sum_W = 0.0;
     for (int i = 0; i < regions.n; ++i) sum_W += regions.p[i].W;
     st.log_Wmax = log_Wmax; st.sum_W = sum_W;
-    c.bytes += 2 * 48 * (int64_t)regions.n;
+    c.bytes += 2 * 48 * (int64_t)regions.n; c.bytes_w += 48 * (int64_t)regions.n;
   }
   __syncthreads();
 }

@@ -113,7 +113,7 @@ struct SlabHeader {
   int64_t accepted[5];
   int64_t alg_bytes;
   int32_t fail_line;           // source line of the first failed device check (debugging aid)
-  int32_t compactions;
+  uint32_t alg_write16;        // the written part of alg_bytes, in units of 16 bytes (the header has no room for another 64-bit counter; heap compactions used to be counted here)
   int64_t device_ticks;        // wall_clock64() ticks (100 MHz) spent in the serial section of k_run_moves, cumulative
   uint64_t rng_spare;          // unconsumed second half of the last Philox block
   uint32_t rng_has_spare;

@@ -109,7 +109,7 @@ class _ConfigC(C.Structure):
 
 class _PartStatsC(C.Structure):
     _fields_ = [("status", C.c_int32), ("num_nodes", C.c_int32), ("moves_done", C.c_int64), ("proposed", C.c_int64 * 5),
-                ("accepted", C.c_int64 * 5), ("algorithmic_bytes", C.c_int64), ("rng_draws", C.c_int64), ("device_ticks", C.c_int64)]
+                ("accepted", C.c_int64 * 5), ("algorithmic_bytes", C.c_int64), ("rng_draws", C.c_int64), ("device_ticks", C.c_int64), ("algorithmic_write_bytes", C.c_int64)]
 
 
 class _SynthParamsC(C.Structure):
@@ -810,7 +810,7 @@ class EmatBackend:
         s = _PartStatsC()
         self._ck(self._lib.emat_part_get_stats(self._h, part, C.byref(s)), "emat_part_get_stats")
         return dict(status=s.status, num_nodes=s.num_nodes, moves_done=s.moves_done, proposed=list(s.proposed), accepted=list(s.accepted),
-                    algorithmic_bytes=s.algorithmic_bytes, rng_draws=s.rng_draws, device_ticks=s.device_ticks)
+                    algorithmic_bytes=s.algorithmic_bytes, rng_draws=s.rng_draws, device_ticks=s.device_ticks, algorithmic_write_bytes=s.algorithmic_write_bytes)
 
     def build_usher_like(self, tips: "TipDescs", seed: int) -> "FlatTree":
         """the reference's UShER-like initial tree from tip descriptors (set_ref_sequence first); the graft loop runs on the device."""

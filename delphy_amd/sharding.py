@@ -201,11 +201,11 @@ class ShardedEngine:
         return self.run.tree()
 
     def local_stats(self):
-        tot = dict(algorithmic_bytes=0, moves_done=0, bad_parts=0, proposed=[0] * 5, accepted=[0] * 5, algorithmic_bytes_of_part=[])
+        tot = dict(algorithmic_bytes=0, moves_done=0, bad_parts=0, proposed=[0] * 5, accepted=[0] * 5, algorithmic_bytes_of_part=[], algorithmic_write_bytes_of_part=[])
         for p in range(self.num_local_parts):
             s = self.backend.part_stats(p)
             tot["algorithmic_bytes"] += s["algorithmic_bytes"]
-            tot["algorithmic_bytes_of_part"].append(s["algorithmic_bytes"])
+            tot["algorithmic_bytes_of_part"].append(s["algorithmic_bytes"]); tot["algorithmic_write_bytes_of_part"].append(s["algorithmic_write_bytes"])
             tot["moves_done"] += s["moves_done"]
             tot["bad_parts"] += 1 if s["status"] != 0 else 0
             for k in range(5):

@@ -375,6 +375,7 @@ typedef struct emat_part_stats {
   int64_t algorithmic_bytes;     /* bytes the moves touched, counted with SURVEY section 8(d)'s per-record sizes */
   int64_t rng_draws;
   int64_t device_ticks;          /* 100 MHz wall-clock ticks this part's wavefront spent running moves (cumulative) */
+  int64_t algorithmic_write_bytes; /* the part of algorithmic_bytes that is written: coalescent cells, re-timed mutation lists, region records, re-linked nodes */
 } emat_part_stats;
 emat_status emat_part_get_stats(emat_backend* h, int32_t part_id, emat_part_stats* out);
 
