@@ -206,6 +206,13 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
   auto ld_ticks = [&]() -> int64_t { return __hip_atomic_load(&a.part_ticks[part], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   uint8_t* gslab = a.slabs + a.slab_off[part];
   SlabHeader* gh = (SlabHeader*)gslab;
+#ifndef EMAT_X_DYN_LDS_BY_TABLE
+  // the staged variants address the dynamic LDS block at a constant (k_lds_dyn_base, emat_device_core.hpp): is it where they think it is?
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)emat_lds != k_lds_dyn_base) {
+    if (lane == 0) { gh->fail_line = -3; st_status(k_part_internal); if (a.chunks > 1) __hip_atomic_store(&a.chunk_done[part], a.chunks, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+    return;
+  }
+#endif
   const int64_t pass_target = a.moves_for_part ? a.moves_for_part[part] : a.moves_per_part + (part == 0 ? a.extra_moves_part0 : 0) + (part < a.one_more_below ? 1 : 0);
   int64_t target = pass_target, done_at_start;
   if (a.chunks > 1) {
@@ -225,7 +232,8 @@ template <bool kSide> __device__ __forceinline__ void run_moves_body(const Kerne
         // the predecessor handed the part over without writing its L2 back: it must have run behind this very L2
         if (!gave_up && (seen & 0x100) != 0 && ((seen >> 12) & 15) != xcc_id()) { gave_up = true; gh->fail_line = -(int32_t)__LINE__; }
         if (waited) atomicAdd((unsigned long long*)&a.chunk_done[((a.num_parts + 1) & ~1) + 2 * (blockIdx.x & 63)], (unsigned long long)(wall_clock64() - w0));   // (EMAT_VERBOSE: slot time spent waiting)
-        if (gave_up) { st_status(k_part_internal); *lds_flag = -1; } else *lds_flag = 0;
+        // (a ticket that gives up says so to its successors as well: they would each wait out their own two minutes -- ADVICE round 4)
+        if (gave_up) { st_status(k_part_internal); __hip_atomic_store(&a.chunk_done[part], a.chunks, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); *lds_flag = -1; } else *lds_flag = 0;
       }
       __syncthreads();
       if (*lds_flag == -1) return;
@@ -1310,7 +1318,10 @@ emat_status finish_pass(emat_backend* h) {
       h->fatal_status = (status[fatal] == k_part_cell_overflow || status[fatal] == k_part_list_limit) ? EMAT_ERR_CAPACITY : EMAT_ERR_INTERNAL;
       h->fatal_message = "part " + std::to_string(fatal) + " stopped inside a move with status " + std::to_string(status[fatal]) + " (device source line " + std::to_string(H->fail_line) +
                          "); " + std::to_string(stopped) + " part(s) stopped in all";
-      if (H->fail_line < 0)
+      if (H->fail_line == -3)
+        h->fatal_message += ": the dynamic LDS block of k_run_moves does not start where the device code was compiled to find it (k_lds_dyn_base): the library was not built with "
+                            "-mllvm -amdgpu-lower-module-lds-strategy=module (csrc/Makefile)";
+      else if (H->fail_line < 0)
         h->fatal_message += ": a ticket found that its predecessor had handed the part over on another XCD (the cheap hand-over is only valid behind one L2; the device did not "
                             "deal this launch's workgroups to its XCDs as probed): run with EMAT_TICKET_RELEASE=full";
       if (status[fatal] == k_part_list_limit)

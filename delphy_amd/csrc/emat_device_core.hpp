@@ -62,7 +62,18 @@ __shared__ __attribute__((aligned(16))) double emat_lds_logq[k_max_lds_partition
 // window, heap marks, counters) are read all the time and must not look clobbered by every store into nodes or lists.
 // The dynamic block then starts with slab byte sizeof(SlabHeader): slab offset `off` lives at emat_lds + off - sizeof(SlabHeader).
 __shared__ __attribute__((aligned(16))) uint8_t emat_lds_hdr[sizeof(SlabHeader)];
+// Where the dynamic block starts in a k_run_moves workgroup: right after the five static objects above (the library is compiled with
+// -amdgpu-lower-module-lds-strategy=module, which gives them fixed addresses; every one is a multiple of 16 bytes).  The out-of-line
+// device functions of the staged variants use this CONSTANT instead of the symbol `emat_lds`, whose address LLVM makes them look up in a
+// per-kernel table in constant memory (an s_load and its wait at the entry of every function that touches the slab); run_moves_body
+// checks at its start that the dynamic block really is there and stops every part loudly if it is not.
+constexpr uint32_t k_lds_dyn_base = k_lds_tables_bytes + k_lds_ctx_bytes + (k_rng_blocks ? k_rng_blocks * 16 : 16) + k_lds_logq_bytes + (uint32_t)sizeof(SlabHeader);
 }  // namespace emat
+#ifdef EMAT_X_DYN_LDS_BY_TABLE   // (A/B: the symbol, as until round 5)
+#define EMAT_DYN_LDS ::emat::emat_lds
+#else
+#define EMAT_DYN_LDS ((uint8_t*)(__attribute__((address_space(3))) uint8_t*)(uintptr_t)::emat::k_lds_dyn_base)
+#endif
 #define EMAT_D static __device__ inline
 #define EMAT_DN static __device__ __noinline__
 #define EMAT_DF static __device__ __forceinline__
@@ -155,9 +166,9 @@ static_assert(sizeof(Ctx) + 16 <= k_lds_ctx_bytes, "context outgrew its LDS slot
 #define EMAT_OPQ 0u
 #endif
 #if EMAT_VARIANT_LDS
-EMAT_DF uint8_t* slab_at(const Ctx&, uint32_t off) { return emat_lds + (off - (uint32_t)sizeof(SlabHeader)) + EMAT_OPQ; }   // slab byte `off` (beyond the header)
+EMAT_DF uint8_t* slab_at(const Ctx&, uint32_t off) { return EMAT_DYN_LDS + (off - (uint32_t)sizeof(SlabHeader)) + EMAT_OPQ; }   // slab byte `off` (beyond the header)
 EMAT_DF SlabHeader* hdr_of(const Ctx&) { return (SlabHeader*)(emat_lds_hdr + EMAT_OPQ); }
-EMAT_DF NodeRec* nodes_of(const Ctx&) { return (NodeRec*)(emat_lds + EMAT_OPQ); }   // off_nodes == sizeof(SlabHeader), checked at launch
+EMAT_DF NodeRec* nodes_of(const Ctx&) { return (NodeRec*)(EMAT_DYN_LDS + EMAT_OPQ); }   // off_nodes == sizeof(SlabHeader), checked at launch
 EMAT_DF const double* mu_of(const Ctx&) { return (const double*)emat_lds_tables; }
 EMAT_DF const double* pi_of(const Ctx&) { return (const double*)emat_lds_tables + k_max_lds_partitions; }
 EMAT_DF const double* q_of(const Ctx&) { return (const double*)emat_lds_tables + k_max_lds_partitions * 5; }

@@ -33,7 +33,7 @@ def library_path() -> str:
     return os.environ.get("EMAT_LIB_PATH") or os.path.join(_HERE, _LIB_NAME)
 
 
-_DEVSRC = ("emat_backend.hip", "emat_device_core.hpp", "emat_device_moves.hpp", "emat_device_spr.hpp", "emat_slab.hpp", "emat_gtree_kernels.hpp", "emat_build.hpp")
+_DEVSRC = ("emat_backend.hip", "emat_device_core.hpp", "emat_device_moves.hpp", "emat_device_spr.hpp", "emat_slab.hpp", "emat_gtree_kernels.hpp", "emat_build.hpp", "Makefile")
 
 
 def source_build_id() -> str:
