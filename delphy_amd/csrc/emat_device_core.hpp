@@ -218,10 +218,29 @@ EMAT_D void fail_at(Ctx& c, int status, int line) {
 // site, and the instruction cache of a CU pair is 64 KB for 32 resident chains that are all somewhere else in the code
 // (measured: simple moves 15 % smaller, +1.5 % moves/s; taking the ten Philox rounds out of line as well costs more in
 // calls than it saves in fetches).
+#ifndef EMAT_INLINE_TRANSC   // bit mask: 1 log, 2 exp, 4 log1p, 8 expm1 inlined at their call sites instead of behind a call
+#define EMAT_INLINE_TRANSC 0
+#endif
+#if EMAT_INLINE_TRANSC & 1
+EMAT_DF double m_log(double x) { return ::log(x); }
+#else
 EMAT_DN double m_log(double x) { return ::log(x); }
+#endif
+#if EMAT_INLINE_TRANSC & 2
+EMAT_DF double m_exp(double x) { return ::exp(x); }
+#else
 EMAT_DN double m_exp(double x) { return ::exp(x); }
+#endif
+#if EMAT_INLINE_TRANSC & 4
+EMAT_DF double m_log1p(double x) { return ::log1p(x); }
+#else
 EMAT_DN double m_log1p(double x) { return ::log1p(x); }
+#endif
+#if EMAT_INLINE_TRANSC & 8
+EMAT_DF double m_expm1(double x) { return ::expm1(x); }
+#else
 EMAT_DN double m_expm1(double x) { return ::expm1(x); }
+#endif
 // ---- RNG: identical stream to the parity oracle (oracle/orc_core.hpp `Rng`) -------------------------
 EMAT_D void philox4x32_10(uint64_t ctr, uint64_t key, uint32_t out[4]) {
   uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;
