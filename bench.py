@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--no-topology", action="store_true", help="diagnostic: disable subtree-slide and SPR moves")
     ap.add_argument("--only-displace", action="store_true", help="diagnostic: only inner-node displacement moves")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-time budget of each CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of each CPU baseline sample")
     ap.add_argument("--verify-parts", type=int, default=4, help="N > 1: parts per rank whose final trees are compared with a one-GPU run of the same partition on rank 0 "
                     "(outside the timed region; the counters of ALL parts are compared whatever this says; 0 = no check)")
     ap.add_argument("--no-inclusive", action="store_true", help="skip the host-cycle-inclusive figure (repartition + moves + reassemble through the run driver)")
@@ -154,9 +154,11 @@ def cpu_baseline(sc, num_parts, seed, target_seconds, t_step):
     policy of as many parts as cores (tools/delphy.cpp:130-132) on the same tree, and config C1 on a single thread."""
     from delphy_amd.scenarios import make_scenario
     cores = max(1, min(os.cpu_count() or 1, 64))
-    n, moves, dt = _time_oracle(sc, num_parts, seed, target_seconds, t_step, cores, 2000)
-    out = {"value": n * moves / dt, "unit": "moves/s", "cores": cores, "kind": "port",
-           "sample": "GPU partition replayed on the CPU: same %d parts, %d moves per part = %.3g moves (%.1f s wall on %d host threads, after a 2000-move pilot); "
+    # three samples, the median quoted and the spread beside it: one 5-second sample varied by 25 % from box to box and run to run (VERDICT round 4)
+    samples = sorted((_time_oracle(sc, num_parts, seed, target_seconds / 2.0, t_step, cores, 2000) for _ in range(3)), key=lambda x: x[0] * x[1] / x[2])
+    n, moves, dt = samples[1]
+    out = {"value": n * moves / dt, "unit": "moves/s", "cores": cores, "kind": "port", "value_min": samples[0][0] * samples[0][1] / samples[0][2], "value_max": samples[2][0] * samples[2][1] / samples[2][2],
+           "sample": "GPU partition replayed on the CPU, three times (median quoted, min and max beside it): same %d parts, %d moves per part = %.3g moves (%.1f s wall on %d host threads, after a 2000-move pilot); "
                      "CPU restatement of Delphy's algorithm (oracle/), not Delphy itself" % (n, moves, n * moves, dt, cores)}
     n2, moves2, dt2 = _time_oracle(sc, cores, seed, target_seconds, t_step, cores, 20000)
     c1 = make_scenario("C1")
@@ -493,29 +495,32 @@ def main():
     if rank == 0 and os.path.exists(mix_path):
         try:
             pc = json.load(open(mix_path))
+            if pc.get("emat_build_id") != build_id:
+                raise KeyError("measured on device code %s, the loaded library is %s: not quoted (re-run scripts/posterior_check.py)" % (pc.get("emat_build_id"), build_id))
             mixing = {"measured_on_emat_build_id": pc.get("emat_build_id"),
-                      "stale": pc.get("emat_build_id") != build_id,   # a sampler property, not a kernel timing: quoted either way, but marked when the device code has changed since
                       "source": "profiles/posterior_latest.json (scripts/posterior_check.py: %d tips, %d retained samples per arm, one per cycle of 50 x nodes moves)" % (pc["tips"], pc["configs"][0]["retained"]),
                       "worst_abs_z_between_arms": pc.get("worst_abs_z"),
                       "arms": [{"parts": c["parts"], "frozen_fraction": c["frozen_fraction"], "moves_per_s": c["moves_per_s"],
                                 "ess_per_s": {k: v["ess_per_s"] for k, v in c["stats"].items()},
                                 "ess_per_million_moves": {k: v["ess_per_million_moves"] for k, v in c["stats"].items()}} for c in pc["configs"]]}
         except Exception as e:
-            mixing = {"error": "unreadable profiles/posterior_latest.json: %s" % e}
+            mixing = {"omitted": "profiles/posterior_latest.json: %s" % e}
     # ... and at a size nearer the benchmark's (tests/posterior_scale.py: C3-like tree, 4 seeds; the coarse arm is the oracle with the
     # reference's policy of 8 parts on 8 host threads, the fine arms run on the GPU): pooled z of the arms' means and ESS per second
     scale_path = os.path.join(ROOT, "profiles", "posterior_scale_latest.json")
     if rank == 0 and os.path.exists(scale_path):
         try:
             ps = json.load(open(scale_path))
+            if ps.get("emat_build_id") != build_id:
+                raise KeyError("measured on device code %s, the loaded library is %s: not quoted (re-run tests/posterior_scale.py)" % (ps.get("emat_build_id"), build_id))
             mixing = mixing or {}
             mixing["at_scale"] = {"source": "profiles/posterior_scale_latest.json (tests/posterior_scale.py: %d tips, %d seeds, burn-in %d cycles)" % (ps["tips"], ps["seeds"], ps["burn_in"]),
-                                  "measured_on_emat_build_id": ps.get("emat_build_id"), "stale": ps.get("emat_build_id") != build_id,
+                                  "measured_on_emat_build_id": ps.get("emat_build_id"), "part_size_limit": ps.get("part_size_limit"),
                                   "worst_abs_pooled_z": ps.get("worst_abs_pooled_z"),
                                   "pooled_z": {arm: {k: v["pooled_z"] for k, v in q.items()} for arm, q in ps.get("pooled", {}).items()},
                                   "ess_per_s": {"gpu_at_benchmark_density": ps.get("ess_per_s_at_benchmark_density"), "oracle_8_parts_8_threads": ps.get("ess_per_s_reference_policy_oracle")}}
         except Exception as e:
-            mixing = dict(mixing or {}, at_scale={"error": "unreadable profiles/posterior_scale_latest.json: %s" % e})
+            mixing = dict(mixing or {}, at_scale={"omitted": "profiles/posterior_scale_latest.json: %s" % e})
 
     # The same measurement on the workload that HAS the parts to fill eight GPUs (C5: 1 000 000 tips, about 80 000 parts -- the 100 000-tip
     # tree of the metric yields about 8 000, fewer than one GPU has wave slots from N = 2 on), so that a scaling run shows both curves.

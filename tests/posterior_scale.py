@@ -201,5 +201,8 @@ if __name__ == "__main__":
     out["ess_per_s_at_benchmark_density"] = {nm: float(np.mean([res[(s, dens)]["stats"][nm]["ess_per_s"] for s in range(seeds)])) for nm in NAMES}
     out["ess_per_s_reference_policy_oracle"] = {nm: float(np.mean([res[(s, "coarse")]["stats"][nm]["ess_per_s"] for s in range(seeds)])) for nm in NAMES}
     out["emat_build_id"] = res[(0, "fine0")]["emat_build_id"]
+    # the run driver's part-size limit at work in the device arms (the oracle arm partitions by the reference's rule alone): the posterior-equivalence arm of that limit
+    out["part_size_limit"] = {arm: {"max_part_nodes": res[(0, arm)].get("max_part_nodes"), "cut_nodes_added_per_cycle": float(np.mean([res[(s, arm)].get("extra_cuts_per_cycle", 0.0) for s in range(seeds)])),
+                                    "largest_part_nodes": int(max(res[(s, arm)].get("largest_part_nodes_max", 0) for s in range(seeds)))} for arm in ("fine0", "fine1")}
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "posterior_scale.json"), "w"), indent=1)
     print("worst |pooled z| = %.2f" % worst)
