@@ -36,13 +36,13 @@ def _tree_summaries(tree):
     return float(tree.t[tree.root]), T, nm
 
 
-def chain_gpu(tips, num_parts, cycles, seed, out_path):
-    """The engine: tree resident in HBM, parts cut / moved / gathered by kernels."""
+def chain_gpu(tips, num_parts, cycles, seed, out_path, limit=-1):
+    """The engine: tree resident in HBM, parts cut / moved / gathered by kernels.  `limit`: emat_run_set_max_part_nodes (-1 = the driver's default)."""
     import delphy_amd as d
     sc = _scenario(tips)
     b = d.EmatBackend(sc.num_sites)
     run = d.EmatRun(b, sc.tree, sc.ref, seed)
-    run.set_num_parts(num_parts); run.set_hky(sc.mu, sc.kappa, sc.pi); run.set_pop_model(sc.pop)
+    run.set_num_parts(num_parts); run.set_max_part_nodes(limit); run.set_hky(sc.mu, sc.kappa, sc.pi); run.set_pop_model(sc.pop)
     run.set_device_tree(True)
     t_step = sc.default_t_step(); run.set_coalescent_t_step(t_step)
     nodes = sc.tree.num_nodes; per_cycle = 50 * nodes
@@ -144,7 +144,7 @@ def summarise(path, burn, cycles):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--gpu":
-        chain_gpu(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]); sys.exit(0)
+        chain_gpu(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], int(sys.argv[7]) if len(sys.argv) > 7 else -1); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--oracle":
         chain_oracle(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], int(sys.argv[7])); sys.exit(0)
     only_summarise = len(sys.argv) > 1 and sys.argv[1] == "--summarise"      # (what the arms of a cut-off run left in gpurun_out/posterior_scale)
