@@ -522,6 +522,22 @@ def main():
         except Exception as e:
             mixing = dict(mixing or {}, at_scale={"omitted": "profiles/posterior_scale_latest.json: %s" % e})
 
+    # ... and the run driver's part-size limit against the reference's partition rule, device arms only (tests/posterior_limit.py)
+    lim_path = os.path.join(ROOT, "profiles", "posterior_limit_latest.json")
+    if rank == 0 and os.path.exists(lim_path):
+        try:
+            pl = json.load(open(lim_path))
+            if pl.get("emat_build_id") != build_id:
+                raise KeyError("measured on device code %s, the loaded library is %s: not quoted (re-run tests/posterior_limit.py)" % (pl.get("emat_build_id"), build_id))
+            mixing = mixing or {}
+            mixing["part_size_limit"] = {"source": "profiles/posterior_limit_latest.json (tests/posterior_limit.py: %d tips, %d parts requested, %d seeds, %d cycles, burn-in %d; every arm on the GPU, "
+                                                   "the arm under the reference's rule against the arms with the limit)" % (pl["tips"], pl["parts_requested"], pl["seeds"], pl["cycles"], pl["burn_in"]),
+                                         "measured_on_emat_build_id": pl.get("emat_build_id"), "worst_abs_pooled_z": pl.get("worst_abs_pooled_z"),
+                                         "arms": {arm: {"limit_in_effect": q.get("limit_in_effect"), "cut_nodes_added_per_cycle": q.get("cut_nodes_added_per_cycle"),
+                                                        "pooled_z": {k: v["pooled_z"] for k, v in q.items() if isinstance(v, dict)}} for arm, q in pl.get("pooled", {}).items()}}
+        except Exception as e:
+            mixing = dict(mixing or {}, part_size_limit={"omitted": "profiles/posterior_limit_latest.json: %s" % e})
+
     # The same measurement on the workload that HAS the parts to fill eight GPUs (C5: 1 000 000 tips, about 80 000 parts -- the 100 000-tip
     # tree of the metric yields about 8 000, fewer than one GPU has wave slots from N = 2 on), so that a scaling run shows both curves.
     secondary = None
