@@ -343,7 +343,7 @@ template <class T> EMAT_D SVec<T> sc_vec(Ctx& c, int cap, int line = __builtin_L
   v.p = (T*)(c.G + c.sc_top); v.cap = cap; c.sc_top += b;
   return v;
 }
-template <class T> EMAT_D void push(Ctx& c, SVec<T>& v, const T& x, int line = __builtin_LINE()) { if (v.n < v.cap) v.p[v.n++] = x; else fail_at(c, k_part_overflow, line); }   // reports the caller's line
+template <class T> EMAT_DF void push(Ctx& c, SVec<T>& v, const T& x, int line = __builtin_LINE()) { if (v.n < v.cap) v.p[v.n++] = x; else fail_at(c, k_part_overflow, line); }   // reports the caller's line
 // An open-ended vector: takes (up to `max_elems` of) the free space of one arena -- the LDS arena when it still
 // has at least `min_lds_elems` elements of room, else the HBM arena -- and must be trimmed with sc_trim.
 template <class T> EMAT_D SVec<T> sc_open(Ctx& c, int max_elems, int min_lds_elems) {
@@ -359,7 +359,7 @@ template <class T> EMAT_D SVec<T> sc_open(Ctx& c, int max_elems, int min_lds_ele
 }
 // An open vector in the LDS arena ran out of room: move it to the part's HBM scratch region (the rest of which it takes,
 // up to `max_elems`) and give the LDS arena back.  False when it already was in HBM or HBM has no more room than it had.
-template <class T> EMAT_D bool sc_open_migrate(Ctx& c, SVec<T>& v, int max_elems) {
+template <class T> EMAT_DF bool sc_open_migrate(Ctx& c, SVec<T>& v, int max_elems) {
   if (!sc_in_lds(c, v.p)) return false;
   uint32_t g0 = (c.sc_top + 15u) & ~15u;
   int room_g = hdr_of(c)->scratch_end > g0 ? (int)((hdr_of(c)->scratch_end - g0) / sizeof(T)) : 0;
@@ -372,7 +372,7 @@ template <class T> EMAT_D bool sc_open_migrate(Ctx& c, SVec<T>& v, int max_elems
   return true;
 }
 // give back the unused tail of the most recent allocation in its arena
-template <class T> EMAT_D void sc_trim(Ctx& c, SVec<T>& v, int line = __builtin_LINE()) {
+template <class T> EMAT_DF void sc_trim(Ctx& c, SVec<T>& v, int line = __builtin_LINE()) {
   uint32_t used = ((uint32_t)v.n * (uint32_t)sizeof(T) + 15u) & ~15u;
   if (sc_in_lds(c, v.p)) { c.a_top = (uint32_t)((uint8_t*)v.p - c.A) + used; EMAT_COUNT(c, 9, used); EMAT_SITE(line, 0, used); }
   else { c.sc_top = (uint32_t)((uint8_t*)v.p - c.G) + used; EMAT_COUNT(c, 8, used); EMAT_COUNT_TRIMS(c, 11, 1); EMAT_SITE(line, 1, used); }
@@ -592,29 +592,36 @@ EMAT_DN void miss_set_from_state(Ctx& c, int node, int l, int from) {
 struct SdRec { int32_t site; uint8_t from, to; uint16_t pad; };
 EMAT_D int sd_lower_bound(const SdRec* v, int n, int l) { int lo = 0, hi = n; while (lo < hi) { int mid = (lo + hi) >> 1; if (v[mid].site < l) lo = mid + 1; else hi = mid; } return lo; }
 EMAT_D bool sd_contains(const SVec<SdRec>& v, int l) { int k = sd_lower_bound(v.p, v.n, l); return k < v.n && v.p[k].site == l; }
-EMAT_D void sd_insert_at(Ctx& c, SVec<SdRec>& v, int k, int site, int from, int to) {
+EMAT_DF void sd_insert_at(Ctx& c, SVec<SdRec>& v, int k, int site, int from, int to) {
   if (v.n >= v.cap) { EMAT_FAIL(c, k_part_overflow); return; }
   for (int i = v.n; i > k; --i) v.p[i] = v.p[i - 1];
   v.p[k].site = site; v.p[k].from = (uint8_t)from; v.p[k].to = (uint8_t)to; v.p[k].pad = 0; v.n++;
 }
-EMAT_D void sd_erase_at(SVec<SdRec>& v, int k) { for (int i = k; i + 1 < v.n; ++i) v.p[i] = v.p[i + 1]; v.n--; }
-EMAT_DN void sd_push_front(Ctx& c, SVec<SdRec>& v, int site, int from, int to) {   // site_deltas.h:43-65
+EMAT_DF void sd_erase_at(SVec<SdRec>& v, int k) { for (int i = k; i + 1 < v.n; ++i) v.p[i] = v.p[i + 1]; v.n--; }
+// (The out-of-line helpers that edit a scratch vector take its header BY VALUE and return it: a header whose address is handed to a
+// function the compiler does not inline has to live in private memory -- scratch, one 64-byte line per dword with one lane active, and an
+// L1 / L2 round trip per access where a register costs nothing.  The wrappers with the old signatures are inlined into their callers.)
+EMAT_DN SVec<SdRec> sd_push_front_v(Ctx& c, SVec<SdRec> v, int site, int from, int to) {   // site_deltas.h:43-65
   int k = sd_lower_bound(v.p, v.n, site);
   if (k < v.n && v.p[k].site == site) {
     EMAT_CHECK(c, to == (int)v.p[k].from);
     v.p[k].from = (uint8_t)from;
     if (v.p[k].from == v.p[k].to) sd_erase_at(v, k);
   } else sd_insert_at(c, v, k, site, from, to);
+  return v;
 }
-EMAT_D void sd_pop_front(Ctx& c, SVec<SdRec>& v, int site, int from, int to) { sd_push_front(c, v, site, to, from); }
-EMAT_DN void sd_push_back(Ctx& c, SVec<SdRec>& v, int site, int from, int to) {    // site_deltas.h:88-110
+EMAT_DF void sd_push_front(Ctx& c, SVec<SdRec>& v, int site, int from, int to) { v = sd_push_front_v(c, v, site, from, to); }
+EMAT_DF void sd_pop_front(Ctx& c, SVec<SdRec>& v, int site, int from, int to) { sd_push_front(c, v, site, to, from); }
+EMAT_DN SVec<SdRec> sd_push_back_v(Ctx& c, SVec<SdRec> v, int site, int from, int to) {    // site_deltas.h:88-110
   int k = sd_lower_bound(v.p, v.n, site);
   if (k < v.n && v.p[k].site == site) {
     EMAT_CHECK(c, from == (int)v.p[k].to);
     v.p[k].to = (uint8_t)to;
     if (v.p[k].from == v.p[k].to) sd_erase_at(v, k);
   } else sd_insert_at(c, v, k, site, from, to);
+  return v;
 }
+EMAT_DF void sd_push_back(Ctx& c, SVec<SdRec>& v, int site, int from, int to) { v = sd_push_back_v(c, v, site, from, to); }
 
 // ---- genetic-likelihood calculus (phylo_tree_calc.h:121-206, phylo_tree_calc.cpp:41-118,406-456) ----------------
 // (Issuing the gathers four intervals at a time, padded with repeats, was measured in round 4: 1.3 % slower on inner-node

@@ -15,19 +15,21 @@ namespace emat {
 namespace EMAT_DEV_NS {
 
 // ---- scratch missation map ("sliding_missations", spr_move.cpp:615-698) ------------------------------------
-EMAT_DN void fsv_set(Ctx& c, SVec<FsRec>& v, int l, int from) {   // Missation_map::set_from_state on a scratch list
+EMAT_DN SVec<FsRec> fsv_set_v(Ctx& c, SVec<FsRec> v, int l, int from) {   // Missation_map::set_from_state on a scratch list (header by value: see sd_push_front_v)
   int k = fs_lower_bound(v.p, v.n, l);
   bool present = (k < v.n && v.p[k].site == l);
   if (from != (int)c.ref[l]) {
-    if (present) { v.p[k].state = (uint8_t)from; return; }
-    if (v.n >= v.cap) { EMAT_FAIL(c, k_part_overflow); return; }
+    if (present) { v.p[k].state = (uint8_t)from; return v; }
+    if (v.n >= v.cap) { EMAT_FAIL(c, k_part_overflow); return v; }
     for (int i = v.n; i > k; --i) v.p[i] = v.p[i - 1];
     v.p[k].site = l; v.p[k].state = (uint8_t)from; v.p[k].pad[0] = v.p[k].pad[1] = v.p[k].pad[2] = 0; v.n++;
   } else if (present) { for (int i = k; i + 1 < v.n; ++i) v.p[i] = v.p[i + 1]; v.n--; }
+  return v;
 }
+EMAT_DF void fsv_set(Ctx& c, SVec<FsRec>& v, int l, int from) { v = fsv_set_v(c, v, l, from); }
 
 // Rebuild the root's "mutations" (ref -> root deltas, t = -DBL_MAX) from a delta list, in site order.
-EMAT_DN void set_root_muts_from_deltas(Ctx& c, int root, const SVec<SdRec>& d) { EMAT_TIMED(1);
+EMAT_DN void set_root_muts_from_deltas(Ctx& c, int root, const SVec<SdRec> d) { EMAT_TIMED(1);
   ListRef& r = nodes_of(c)[root].muts;
   list_reserve<MutRec>(c, r, d.n);
   if (c.failed) return;
@@ -103,7 +105,7 @@ EMAT_DN void node_factor_out_common(Ctx& c, int a, int b, int common) {
   sc_release(c, mark);
 }
 
-EMAT_DN void edit_slide_root(Ctx& c, Edit& e, double new_t_P) {   // tree_editing.cpp:114-158
+EMAT_DN Edit edit_slide_root_v(Ctx& c, Edit e, double new_t_P) {   // tree_editing.cpp:114-158 (the session by value: see sd_push_front_v)
   const int X = e.X, P = nodes_of(c)[X].parent;
   EMAT_CHECK(c, P == hdr_of(c)->root);
   double old_t_P = nodes_of(c)[P].t;
@@ -127,11 +129,13 @@ EMAT_DN void edit_slide_root(Ctx& c, Edit& e, double new_t_P) {   // tree_editin
     }
   }
   nodes_of(c)[P].t = new_t_P;
+  return e;
 }
-EMAT_DN void edit_slide_P_along_branch(Ctx& c, Edit& e, double new_t_P) {   // tree_editing.cpp:31-112
+EMAT_DF void edit_slide_root(Ctx& c, Edit& e, double new_t_P) { e = edit_slide_root_v(c, e, new_t_P); }
+EMAT_DN Edit edit_slide_P_along_branch_v(Ctx& c, Edit e, double new_t_P) {   // tree_editing.cpp:31-112
   const int X = e.X, P = nodes_of(c)[X].parent;
   EMAT_CHECK(c, !is_tip(c, P));
-  if (P == hdr_of(c)->root) { edit_slide_root(c, e, new_t_P); return; }
+  if (P == hdr_of(c)->root) return edit_slide_root_v(c, e, new_t_P);
   double old_t_P = nodes_of(c)[P].t;
   int S = sibling_of(c, P, X);
   if (new_t_P < old_t_P) {
@@ -144,7 +148,7 @@ EMAT_DN void edit_slide_P_along_branch(Ctx& c, Edit& e, double new_t_P) {   // t
       for (int i = first; i < nP; ++i) if (!miss_contains(c, S, mP[i].site)) ++kept;
       int nS = nmuts(c, S);
       list_reserve<MutRec>(c, nodes_of(c)[S].muts, nS + kept);
-      if (c.failed) return;
+      if (c.failed) return e;
       MutRec* mS = muts_of(c, S); mP = muts_of(c, P);
       for (int i = nS - 1; i >= 0; --i) mS[i + kept] = mS[i];
       int w = kept;
@@ -165,7 +169,7 @@ EMAT_DN void edit_slide_P_along_branch(Ctx& c, Edit& e, double new_t_P) {   // t
     int last = 0; while (last < nS && !(mS[last].t > new_t_P)) ++last;
     if (last != 0) {
       list_reserve<MutRec>(c, nodes_of(c)[P].muts, nmuts(c, P) + last);
-      if (c.failed) return;
+      if (c.failed) return e;
       mS = muts_of(c, S);
       for (int i = 0; i < last && !c.failed; ++i) {
         MutRec m = mS[i];
@@ -178,7 +182,9 @@ EMAT_DN void edit_slide_P_along_branch(Ctx& c, Edit& e, double new_t_P) {   // t
     }
   }
   nodes_of(c)[P].t = new_t_P;
+  return e;
 }
+EMAT_DF void edit_slide_P_along_branch(Ctx& c, Edit& e, double new_t_P) { e = edit_slide_P_along_branch_v(c, e, new_t_P); }
 EMAT_DN void edit_do_hop_up(Ctx& c, int X) {   // tree_editing.cpp:164-231
   EMAT_CHECK(c, X != hdr_of(c)->root);
   const int P = nodes_of(c)[X].parent;
@@ -214,7 +220,7 @@ EMAT_DN void edit_do_hop_up(Ctx& c, int X) {   // tree_editing.cpp:164-231
   nodes_of(c)[G].n_missing = nodes_of(c)[P].n_missing + iv_num_sites(miss_of(c, G), (int)nodes_of(c)[G].miss.cnt);
   c.bytes += 5 * 64; c.bytes_w += 160;   // (five node records re-linked: counted once, half of it as written)
 }
-EMAT_DN void edit_flip(Ctx& c, Edit& e) {   // tree_editing.cpp:233-278
+EMAT_DN void edit_flip(Ctx& c, const Edit e) {   // tree_editing.cpp:233-278 (reads e.X only)
   const int X = e.X, P = nodes_of(c)[X].parent;
   EMAT_CHECK(c, !is_tip(c, P) && P != hdr_of(c)->root && nmuts(c, P) == 0);
   const int G = nodes_of(c)[P].parent;
@@ -236,7 +242,7 @@ EMAT_DN void edit_flip(Ctx& c, Edit& e) {   // tree_editing.cpp:233-278
   nodes_of(c)[P].n_missing = nodes_of(c)[G].n_missing + iv_num_sites(miss_of(c, P), (int)nodes_of(c)[P].miss.cnt);
   c.bytes += 5 * 64; c.bytes_w += 160;   // (five node records re-linked: counted once, half of it as written)
 }
-EMAT_D void edit_hop_down(Ctx& c, Edit& e, int SS) {   // tree_editing.cpp:280-292
+EMAT_DF void edit_hop_down(Ctx& c, const Edit& e, int SS) {   // tree_editing.cpp:280-292
   const int P = nodes_of(c)[e.X].parent;
   EMAT_CHECK(c, SS != hdr_of(c)->root);
   const int U = nodes_of(c)[SS].parent;
@@ -245,7 +251,7 @@ EMAT_D void edit_hop_down(Ctx& c, Edit& e, int SS) {   // tree_editing.cpp:280-2
   edit_do_hop_up(c, sibling_of(c, U, SS));
 }
 // Tree_editing_session's constructor (tree_editing.cpp:7-29): the mutations on P-X become the session's deltas (room for `cap`)
-EMAT_D void edit_begin(Ctx& c, Edit& e, int X, int cap) {
+EMAT_DF void edit_begin(Ctx& c, Edit& e, int X, int cap) {
   e.X = X;
   e.deltas = sc_vec<SdRec>(c, cap);
   const MutRec* m = muts_of(c, X);
@@ -253,7 +259,7 @@ EMAT_D void edit_begin(Ctx& c, Edit& e, int X, int cap) {
   nodes_of(c)[X].muts.cnt = 0;
 }
 // Tree_editing_session::end (tree_editing.cpp:294-302): the deltas go back on P-X as mutations at its midpoint
-EMAT_D void edit_end(Ctx& c, Edit& e) {
+EMAT_DF void edit_end(Ctx& c, Edit& e) {
   if (c.failed) return;
   const int X = e.X;
   EMAT_CHECK(c, nmuts(c, X) == 0);
@@ -315,7 +321,7 @@ EMAT_DN void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) { EMAT_TIM
 EMAT_D int choose_different_state(Ctx& c, int s) { int delta = 1 + uniform_int(c, 3); return (s + delta) % 4; }
 
 struct KTruncPoisson { double lambda; int min_k; double normalization, term_before_min_k, max_k; };   // distributions.h:77-175
-EMAT_DN KTruncPoisson ktp_make(double lambda, int min_k) {
+EMAT_DF KTruncPoisson ktp_make(double lambda, int min_k) {   // (inlined into its two callers: a 40-byte struct returned by an out-of-line function travels through private memory)
   KTruncPoisson d; d.lambda = lambda; d.min_k = min_k; d.normalization = 0.0; d.term_before_min_k = 0.0; d.max_k = 0.0;
   if ((double)min_k <= lambda) return d;
   d.max_k = (10.0 * min_k > 10.0 * lambda) ? 10.0 * min_k : 10.0 * lambda;
@@ -330,34 +336,40 @@ EMAT_DN KTruncPoisson ktp_make(double lambda, int min_k) {
   }
   return d;
 }
-EMAT_DN int ktp_sample(Ctx& c, const KTruncPoisson& d) {
+// (the distribution's five numbers as scalar arguments: a struct of 40 bytes passed by value goes through the caller's private frame all the same)
+EMAT_DN int ktp_sample_s(Ctx& c, double lambda, int min_k, double normalization, double term_before_min_k, double max_k) {
+  KTruncPoisson d; d.lambda = lambda; d.min_k = min_k; d.normalization = normalization; d.term_before_min_k = term_before_min_k; d.max_k = max_k;
   if (d.normalization == 0.0) { int guard = 0; while (guard++ < (1 << 26)) { int k = poisson(c, d.lambda); if (k >= d.min_k) return k; } return d.min_k; }
   double u = uniform_co(c, 0.0, d.normalization);
   double cum = 0.0; int k = d.min_k; double term = d.term_before_min_k;
   while (k < d.max_k) { term *= d.lambda / k; cum += term; if (cum > u) break; ++k; }
   return k;
 }
+EMAT_DF int ktp_sample(Ctx& c, const KTruncPoisson& d) { return ktp_sample_s(c, d.lambda, d.min_k, d.normalization, d.term_before_min_k, d.max_k); }
 
 // Appends to `out` (open-ended scratch vector).  States of a trajectory are drawn first (rejection on the end state), then
 // its times, exactly as spr_move.cpp:1181-1227.  Both are staged IN PLACE, in the records they end up in (`to` and `t` of
 // out.p[out.n ..]); a vector that started in the LDS arena and runs out of room moves to the part's HBM scratch.
 constexpr int k_open_max = 1 << 20;   // most elements an open vector of a sampler takes of an arena (the arena's free space bounds it first)
-EMAT_D bool open_room(Ctx& c, SVec<MutRec>& out, int extra) {
+EMAT_DF bool open_room(Ctx& c, SVec<MutRec>& out, int extra) {
   if (out.cap - out.n >= extra) return true;
   if (sc_open_migrate(c, out, k_open_max) && out.cap - out.n >= extra) return true;
   EMAT_FAIL(c, k_part_overflow); return false;
 }
-EMAT_DN void sample_site_trajectory(Ctx& c, SVec<MutRec>& out, int l, int from, int to, const KTruncPoisson& dist, double T, bool accept_only_if_match, bool& accepted) {
+// (The vector's header by value, in and out, and the distribution as scalars: see sd_push_front_v.  The trajectory was accepted exactly when the
+// vector came back longer: a trajectory has at least min_k >= 1 mutations.)
+EMAT_DN SVec<MutRec> sample_site_trajectory_v(Ctx& c, SVec<MutRec> out, int l, int from, int to, double d_lambda, int d_min_k, double d_normalization, double d_term_before_min_k, double d_max_k,
+                                              double T, bool accept_only_if_match) {
   int n = 0; int s = from;
   int guard = 0;
   while (guard++ < (1 << 26)) {
-    n = ktp_sample(c, dist);
-    if (!open_room(c, out, n)) { accepted = false; return; }
+    n = ktp_sample_s(c, d_lambda, d_min_k, d_normalization, d_term_before_min_k, d_max_k);
+    if (!open_room(c, out, n)) return out;
     MutRec* rec = out.p + out.n;
     s = from;
     for (int i = 0; i < n; ++i) { s = choose_different_state(c, s); rec[i].to = (uint8_t)s; }
-    if (s == to) { accepted = true; break; }
-    if (!accept_only_if_match) { accepted = false; return; }   // caller restarts from scratch on its own terms
+    if (s == to) break;
+    if (!accept_only_if_match) return out;   // caller restarts from scratch on its own terms
   }
   MutRec* rec = out.p + out.n;
   for (int i = 0; i < n; ++i) rec[i].t = uniform_co(c, -T, 0.0);
@@ -365,6 +377,12 @@ EMAT_DN void sample_site_trajectory(Ctx& c, SVec<MutRec>& out, int l, int from, 
   int prev = from;
   for (int i = 0; i < n; ++i) { const int st = rec[i].to; rec[i] = make_mut((uint8_t)prev, l, (uint8_t)st, rec[i].t); prev = st; }
   out.n += n;
+  return out;
+}
+EMAT_DF void sample_site_trajectory(Ctx& c, SVec<MutRec>& out, int l, int from, int to, const KTruncPoisson& dist, double T, bool accept_only_if_match, bool& accepted) {
+  const SVec<MutRec> r = sample_site_trajectory_v(c, out, l, from, to, dist.lambda, dist.min_k, dist.normalization, dist.term_before_min_k, dist.max_k, T, accept_only_if_match);
+  accepted = r.n > out.n;
+  out = r;
 }
 // spr_move.cpp:1164-1370; result appended into a fresh open-ended scratch vector (caller trims)
 EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double mu, const SVec<SdRec>& deltas) { EMAT_TIMED(1);
@@ -424,7 +442,7 @@ EMAT_DN SVec<MutRec> sample_unconstrained_mutational_history(Ctx& c, int L, doub
   return out;
 }
 // spr_move.cpp:1409-1439
-EMAT_DN void adjust_mutational_history(Ctx& c, SVec<MutRec>& h, const SVec<SdRec>& deltas, int end_branch, double end_t) { EMAT_TIMED(1);
+EMAT_DN void adjust_mutational_history(Ctx& c, const SVec<MutRec> h, const SVec<SdRec> deltas, int end_branch, double end_t) { EMAT_TIMED(1);   // (headers by value: only the records change)
   for (int i = h.n - 1; i >= 0; --i) {
     MutRec& m = h.p[i];
     m.t += end_t;
