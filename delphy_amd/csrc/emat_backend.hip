@@ -887,6 +887,7 @@ template <class T> struct DevBuf {
     if (count > n) { if (p) (void)hipFree(p); p = nullptr; n = 0; hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); if (e != hipSuccess) return e; n = count; }
     return hipSuccess;
   }
+  hipError_t alloc_roomy(size_t count) { return count > n ? alloc(count + count / 4) : hipSuccess; }   // for buffers whose need creeps up from cycle to cycle: a quarter more than asked, so that most new maxima fit
   hipError_t upload(const T* src, size_t count) {
     if (count > n) { if (p) (void)hipFree(p); p = nullptr; n = 0; hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); if (e != hipSuccess) return e; n = count; }
     if (count) return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
@@ -948,6 +949,11 @@ struct GTreeHost {
   std::vector<int32_t> h_part_off, h_orig, h_kid0, h_kid1;   // host copies (h_orig / h_kid* only when the partition came from the host or was asked for)
   bool partition_on_device = false;   // made by emat_tree_partition
   DevBuf<int32_t> lidx;
+  DevBuf<uint8_t> d_is_cut; DevBuf<int32_t> d_cut, d_sizes, d_part_status;   // emat_tree_partition's inputs and counts (kept: three allocations less per cycle)
+  PinnedBytes pin_sizes, pin_measure;                                         // where its sizes + offsets, and the measures queued behind it, land
+  hipEvent_t ev_sizes = nullptr, ev_measure = nullptr;
+  bool measure_queued = false;      // k_gt_measure of the current partition was launched by emat_tree_partition, its results are on their way to pin_measure
+  ~GTreeHost() { if (ev_sizes) (void)hipEventDestroy(ev_sizes); if (ev_measure) (void)hipEventDestroy(ev_measure); }
   DevBuf<GRootDelta> root_deltas_in;
   DevBuf<int32_t> part_off, orig, kid0, kid1, lpar;
   DevBuf<double> co_kbar, co_ktw, co_k_bar, co_k_tw, co_popsize, co_tsop; DevBuf<int32_t> co_num_active;   // the coalescent grid, when it is built on the device
@@ -957,6 +963,10 @@ struct GTreeHost {
   DevBuf<GRootDelta> root_deltas; DevBuf<int32_t> n_root_deltas;
   // host mirrors
   std::vector<int32_t> h_parent, h_c0, h_c1; std::vector<double> h_t; std::vector<float> h_t_min, h_t_max; int32_t h_root = EMAT_NO_NODE;
+  // Kept current by every reassemble: the children of every node, packed (pin_kids: n pairs), the root and its time -- what a cycle's
+  // partitioner needs.  The arrays above follow only when somebody asks for them (gt_full_mirrors).
+  DevBuf<int2> d_kids; PinnedBytes pin_kids; double h_root_t = 0.0; bool full_mirrors_stale = false;
+  const int32_t* kids() const { return (const int32_t*)pin_kids.data(); }   // [2 v] = child0, [2 v + 1] = child1
   GTreeDev dev() {
     GTreeDev g{};
     g.n_nodes = n; g.root = root.p; g.parent = parent.p; g.c0 = c0.p; g.c1 = c1.p; g.t = t.p; g.t_min = t_min.p; g.t_max = t_max.p;
@@ -1021,6 +1031,7 @@ struct emat_backend {
   int uploads_expected = 0;
   int root_part = -1;
   PinnedBytes h_slabs;
+  size_t slab_bytes_total = 0;      // bytes of all slabs on the device (h_slabs is brought to this size when somebody pulls)
   DevBuf<uint8_t> d_slabs, d_snaps; DevBuf<uint64_t> d_slab_off; DevBuf<int32_t> d_order, d_part_status; DevBuf<int64_t> d_part_ticks, d_moves_for_part;
   bool slabs_on_device = false;     // device slabs are materialised
   bool host_slabs_current = false;  // h_slabs mirrors the device
@@ -1031,6 +1042,7 @@ struct emat_backend {
   std::vector<uint32_t> used_bytes;         // per part: prefix + list content (what a part staged whole brings into LDS)
   // SharedCells: host mirror (absolute cell index) and the device copy the kernels read
   std::vector<double> sh_ktw, sh_popsize, sh_tsop; std::vector<int32_t> sh_nact;
+  bool grid_mirrors_on_device = false;   // the grid was built on the device (emat_tree_repartition) and the four vectors above have not been fetched yet
   DevBuf<double> d_sh_ktw, d_sh_tsop; DevBuf<int32_t> d_sh_nact;
   SharedCells shared_dev{nullptr, nullptr, nullptr, 0};   // what make_args hands the kernels (the HBM-resident tree points it at its own grid arrays)
   uint32_t cfg_side_arena = 1;              // EMAT_SIDE_ARENA (tuning knob; 0 = off): a part that would be left with less arena than this in the main area joins the giants' 8-per-CU class.  The default, 1 byte, moves exactly the parts that cannot be staged WHOLE there (0.5 % at C4): with their lists in HBM they were the last chains of every pass (19.6 ms where the rest was done by 19.9: pass 21.5 -> 20.1 ms); 1-4 KB moves hundreds and loses
@@ -1283,14 +1295,17 @@ emat_status finish_pass(emat_backend* h) {
   const size_t n = h->parts.size();
   std::vector<int32_t> status(n);
   for (int round = 0; round < 5; ++round) {
+    HostLaps laps;
     { emat_status js = join_side_classes(h); if (js) return js; }
     h->sides_must_fork = true;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    laps.mark("finish_pass: 1 wait for the moves");
     HIP_TRY(hipMemcpy(status.data(), h->d_part_status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    laps.mark("finish_pass: 2 status D2H");
     h->pass_pending = false;
     size_t stopped = 0, fatal = n;
     for (size_t p = 0; p < n; ++p) if (status[p] != 0) { ++stopped; if (status[p] != k_part_need_space && status[p] != k_part_need_cells && fatal == n) fatal = p; }
-    if (stopped == 0 && getenv("EMAT_VERBOSE")) {   // what bounded the pass: the slowest chains next to the mean
+    if (stopped == 0 && verbose_reports()) {   // what bounded the pass: the slowest chains next to the mean
       std::vector<int64_t> ticks(2 * n);
       HIP_TRY(hipMemcpy(ticks.data(), h->d_part_ticks.p, 2 * n * sizeof(int64_t), hipMemcpyDeviceToHost));
       std::vector<int> idx(n); std::iota(idx.begin(), idx.end(), 0);
@@ -1310,7 +1325,7 @@ emat_status finish_pass(emat_backend* h) {
       for (size_t k = 0; k < std::min<size_t>(3, n); ++k) fprintf(stderr, " part %d (%d nodes, %u B) %.1f ms from %.1f", idx[k], h->parts[idx[k]].n_nodes, h->persistent_bytes[idx[k]], ticks[idx[k]] / 1e5, (ticks[n + idx[k]] - first) / 1e5);
       fprintf(stderr, "\n");
     }
-    if (stopped == 0) { if (round == 0 && h->last_launch_uniform) (void)refresh_order_from_ticks(h); return EMAT_OK; }
+    if (stopped == 0) { if (round == 0 && h->last_launch_uniform) (void)refresh_order_from_ticks(h); laps.mark("finish_pass: 3 status scan + refresh_order_from_ticks"); return EMAT_OK; }
     h->host_slabs_current = false; h->headers_current = false;
     emat_status st = pull_from_device(h); if (st) return st;
     if (fatal != n) {
@@ -1336,7 +1351,7 @@ emat_status finish_pass(emat_backend* h) {
       counts[p] = ph.expected_moves - ph.stats.moves_done;
       ph.stats.status = 0;
     }
-    if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] %zu part(s) ran out of slab space or grid cells: re-materialising with more room and running the rest of their moves\n", stopped);
+    if (verbose_reports()) fprintf(stderr, "[emat] %zu part(s) ran out of slab space or grid cells: re-materialising with more room and running the rest of their moves\n", stopped);
     h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false;   // every part is re-encoded from its decoded state (tree, RNG, cells, statistics)
     st = launch_moves(h, 0, 0, &counts, 0); if (st) return st;
   }
@@ -1355,6 +1370,14 @@ emat_status pull_from_device_impl(emat_backend* h) {
   if (h->host_only || !h->slabs_on_device || h->host_slabs_current) return EMAT_OK;
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->grid_mirrors_on_device) {   // the run-wide cell arrays of a grid built on the device: decode_slab reads them
+    const size_t nc = (size_t)h->shared_dev.num_cells;
+    h->sh_ktw.resize(nc); h->sh_popsize.resize(nc); h->sh_tsop.resize(nc); h->sh_nact.resize(nc);
+    HIP_TRY(hipMemcpy(h->sh_ktw.data(), h->shared_dev.k_twiddle_bar, nc * 8, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(h->sh_popsize.data(), h->gt.co_popsize.p, nc * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h->sh_tsop.data(), h->shared_dev.ts_over_pop, nc * 8, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(h->sh_nact.data(), h->shared_dev.num_active_parts, nc * 4, hipMemcpyDeviceToHost));
+    h->grid_mirrors_on_device = false;
+  }
+  HIP_TRY(h->h_slabs.resize(h->slab_bytes_total));   // (grow-only; a repartition on the device does not touch the host mirror)
   HIP_TRY(hipMemcpy(h->h_slabs.data(), h->d_slabs.p, h->h_slabs.size(), hipMemcpyDeviceToHost));
   parallel_for((int)h->parts.size(), [&](int p) {
     PartHost& ph = h->parts[p];
@@ -1423,8 +1446,10 @@ void place_slab(emat_backend* h, size_t p, const SlabGeo& g, uint64_t& off, uint
 // order out class by class.
 void assign_size_classes(emat_backend* h) {
   const size_t n = h->parts.size();
+  const bool verbose = verbose_reports();
   std::vector<uint32_t> v = h->persistent_bytes;
-  std::sort(v.begin(), v.end());
+  const bool by_percentiles = h->cfg.use_lds && n != 0 && h->cfg_class_pct.size() > 1;
+  if (by_percentiles || verbose) std::sort(v.begin(), v.end());   // (the default rule needs one order statistic: nth_element below)
   h->class_of.assign(n, 0);
   std::vector<uint32_t> areas;   // per class, descending
   const uint32_t lds_cu = 160u * 1024u, overhead = k_lds_static_bytes + (h->cfg.use_lds ? h->cfg_lds_scratch : 0u);
@@ -1461,6 +1486,7 @@ void assign_size_classes(emat_backend* h) {
     // occupancy, the rest stage their prefix.
     const int pct = h->cfg_class_pct.empty() ? 60 : h->cfg_class_pct[0];
     const size_t hi = pct >= 100 ? n : std::max<size_t>(1, std::min(n, (n * (size_t)pct + 99) / 100));
+    if (!verbose) std::nth_element(v.begin(), v.begin() + (hi - 1), v.end());
     const uint32_t need = std::min<uint32_t>((v[hi - 1] + 511u) & ~511u, h->cfg_lds_max & ~511u);
     uint32_t main_area = 0;
     for (uint32_t k = 4u * EMAT_WAVES_PER_EU; k >= 1; --k) {   // 4 SIMDs x waves per SIMD allowed by the VGPR budget (one wave per workgroup)
@@ -1495,7 +1521,7 @@ void assign_size_classes(emat_backend* h) {
   for (size_t p = 0; p < n; ++p) ++count[h->class_of[p]];
   h->class_begin[0] = 0;
   for (int c = 0; c < h->num_classes; ++c) { h->class_lds[c] = areas[c]; h->class_begin[c + 1] = h->class_begin[c] + count[c]; }
-  if (getenv("EMAT_VERBOSE") && n > 0) {
+  if (verbose && n > 0) {
     fprintf(stderr, "[emat] parts %zu persistent bytes p50 %u p90 %u p99 %u max %u | classes:", n, v[n / 2], v[n * 9 / 10], v[n * 99 / 100], v.back());
     for (int c = 0; c < h->num_classes; ++c) fprintf(stderr, " [%d parts, LDS %u]", h->class_begin[c + 1] - h->class_begin[c], h->class_lds[c]);
     fprintf(stderr, "\n");
@@ -1520,6 +1546,7 @@ emat_status upload_shared_cells(emat_backend* h) {
   }
   HIP_TRY(h->d_sh_ktw.upload(h->sh_ktw.data(), h->sh_ktw.size())); HIP_TRY(h->d_sh_tsop.upload(h->sh_tsop.data(), h->sh_tsop.size())); HIP_TRY(h->d_sh_nact.upload(h->sh_nact.data(), h->sh_nact.size()));
   h->shared_dev = SharedCells{h->d_sh_ktw.p, h->d_sh_tsop.p, h->d_sh_nact.p, total};
+  h->grid_mirrors_on_device = false;
   return EMAT_OK;
 }
 
@@ -1542,7 +1569,7 @@ emat_status materialize(emat_backend* h) {
     geo[p] = slab_geometry(h, ph.tree.num_nodes(), ph.tree.num_muts(), heap_content_bytes(ph.tree), (int)ph.coal.k_bar_p.size(), ph.includes_run_root, ph.space_boost, ph.cell_boost);
     place_slab(h, p, geo[p], off, heap_content_bytes(ph.tree));
   }
-  HIP_TRY(h->h_slabs.resize(off));
+  HIP_TRY(h->h_slabs.resize(off)); h->slab_bytes_total = off;
   std::vector<uint64_t> offs(h->parts.size());
   parallel_for((int)h->parts.size(), [&](int p) {
     PartHost& ph = h->parts[p];
@@ -1586,7 +1613,7 @@ int probe_xcc_dealing(int device, hipStream_t stream) {
   int nx = 0; for (int v : x) nx = std::max(nx, v + 1);
   if (nx <= 0 || nx > 16) return 0;
   for (int b = 0; b < nb; ++b) if (x[(size_t)b] != (x[0] + b) % nx) nx = -1;
-  if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] device %d: workgroups are dealt to %s\n", device, nx > 0 ? (std::to_string(nx) + " XCD(s) round robin").c_str() : "the XCDs in no pattern the tickets can rely on: full releases");
+  if (verbose_reports()) fprintf(stderr, "[emat] device %d: workgroups are dealt to %s\n", device, nx > 0 ? (std::to_string(nx) + " XCD(s) round robin").c_str() : "the XCDs in no pattern the tickets can rely on: full releases");
   known[device] = nx > 0 ? nx : 0;
   return known[device];
 }
@@ -1612,15 +1639,29 @@ emat_status launch_recalc(emat_backend* h) {
 // free slots in index order, which makes it a longest-processing-time-first list scheduler (size and duration of a
 // part correlate at 0.85); packing lists of parts per workgroup on the host was measured slower twice.  The order only
 // decides WHEN a part's chain runs; every chain is independent (own RNG stream, own slab).
-emat_status build_order(emat_backend* h) {
+// (`queued`: the copy goes onto the engine's stream behind whatever is running there -- for a caller that knows nothing in flight
+// reads the order -- instead of waiting for the stream first.)
+emat_status build_order(emat_backend* h, bool queued = false) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   const int n = (int)h->parts.size();
-  std::vector<int32_t> order(n);
+  // by class, then by persistent size, largest first, ties in index order: a stable radix sort (three passes of 12 bits) on
+  // (class, ~size); the comparison sort this replaces took half a millisecond of every cycle at 13 000 parts
+  std::vector<uint64_t> key((size_t)n), key2((size_t)n);
+  std::vector<int32_t> order((size_t)n), order2((size_t)n);
   std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->class_of[a] != h->class_of[b] ? h->class_of[a] < h->class_of[b] : h->persistent_bytes[a] > h->persistent_bytes[b]; });
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(h->d_order.upload(order.data(), order.size()));
+  auto sort_key = [&](int i) { return ((uint64_t)h->class_of[(size_t)i] << 32) | (uint64_t)(0xFFFFFFFFu - h->persistent_bytes[(size_t)i]); };   // 36 bits (k_max_classes <= 16)
+  for (int i = 0; i < n; ++i) key[(size_t)i] = sort_key(i);
+  for (int pass = 0; pass < 3; ++pass) {
+    const int shift = 12 * pass;
+    uint32_t count[4097] = {};
+    for (int i = 0; i < n; ++i) ++count[((key[(size_t)i] >> shift) & 0xFFFu) + 1];
+    for (int d = 0; d < 4096; ++d) count[d + 1] += count[d];
+    for (int i = 0; i < n; ++i) { const uint32_t at = count[(key[(size_t)i] >> shift) & 0xFFFu]++; key2[at] = key[(size_t)i]; order2[at] = order[(size_t)i]; }
+    key.swap(key2); order.swap(order2);
+  }
   h->h_order = order;
+  if (queued) { HIP_TRY(h->d_order.alloc(order.size())); HIP_TRY(hipMemcpyAsync(h->d_order.p, h->h_order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream)); }
+  else { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(h->d_order.upload(order.data(), order.size())); }
   h->order_valid = true;
   return EMAT_OK;
 }
@@ -1629,16 +1670,21 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   if (h->parts.empty()) return fail(h, EMAT_ERR_STATE, "no parts uploaded");
   if (h->fatal_status != EMAT_OK) return fail(h, h->fatal_status, h->fatal_message);
+  HostLaps laps;
   emat_status st = sync_model_to_device(h); if (st) return st;
   st = materialize(h); if (st) return st;
+  laps.mark("launch_moves: 1 model + materialize");
   if (!h->derived_valid) { st = join_side_classes(h); if (st) return st; h->sides_must_fork = true; st = launch_recalc(h); if (st) return st; }
+  laps.mark("launch_moves: 2 launch_recalc");
   const uint32_t lds_scratch = h->cfg.use_lds ? h->cfg_lds_scratch : 0u;
   // the dynamic block: the slab image beyond its header + the arena; tables, context and the header image are static LDS
   auto shmem_for = [&](uint32_t slab_area) { return (size_t)(slab_area > (uint32_t)sizeof(SlabHeader) ? slab_area - (uint32_t)sizeof(SlabHeader) : 0u) + lds_scratch; };
   for (int c = 0; c < h->num_classes; ++c)
     if (shmem_for(h->class_lds[c]) + k_lds_static_bytes + sizeof(SlabHeader) > 160 * 1024) return fail(h, EMAT_ERR_CAPACITY, "LDS request exceeds 160 KiB: lower EMAT_LDS_MAX or disable use_lds");
   if (!h->order_valid) { st = build_order(h); if (st) return st; }
-  HIP_TRY(h->d_snaps.alloc(h->d_slabs.n));
+  laps.mark("launch_moves: 3 build_order (sort, wait for the stream, H2D)");
+  HIP_TRY(h->d_snaps.alloc(h->d_slabs.n));   // (as roomy as the slabs: grows when they do)
+  laps.mark("launch_moves: 4 snapshot allocation");
   KernelArgs a = make_args(h);
   a.moves_per_part = per_part; a.extra_moves_part0 = extra0; a.one_more_below = one_more_below;
   a.lds_scratch_bytes = lds_scratch; a.snaps = h->d_snaps.p;
@@ -1716,6 +1762,7 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
     h->sides_must_fork = false;
   }
   HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+  laps.mark("launch_moves: 5 expected moves, events, memsets, launches");
   h->host_slabs_current = false; h->headers_current = false;
   return EMAT_OK;
 }
@@ -1763,6 +1810,7 @@ emat_status emat_backend_destroy(emat_backend* h) {
     if (h->ev_join[c]) (void)hipEventDestroy(h->ev_join[c]);
   }
   for (hipEvent_t e : {h->ev_start, h->ev_stop, h->ev_fork}) if (e) (void)hipEventDestroy(e);
+  HostSpans::instance().report();
   delete h;
   return EMAT_OK;
 }

@@ -118,7 +118,7 @@ emat_status build_usher_like(emat_backend* h, const emat_tip_descs& td, uint64_t
     }
     int32_t status[2];
     HIP_TRY(hipMemcpy(status, d_status.p, sizeof status, hipMemcpyDeviceToHost));
-    if (getenv("EMAT_VERBOSE") && n > 2) {
+    if (verbose_reports() && n > 2) {
       long long pr[8]; HIP_TRY(hipMemcpy(pr, d_prof.p, sizeof pr, hipMemcpyDeviceToHost));
       const double k = 1e-5 / (double)(n - 2);   // ticks of 10 ns -> ms per tip
       fprintf(stderr, "[emat] build_usher_like: %d tips on %d workgroups, per tip: %.3f ms = parallel phases + barriers %.3f | tie sums %.3f (%.1f tying regions) | path + deltas %.3f (finding the path %.3f) | links + sizes %.3f | mutations %.3f\n",

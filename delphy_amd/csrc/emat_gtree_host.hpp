@@ -28,16 +28,34 @@ emat_status gt_require(emat_backend* h, bool need_resident) {
   return EMAT_OK;
 }
 
+// After a reassemble: the packed children, the root and its time come over at once (1.6 MB at 200 000 nodes, into page-locked
+// memory); parent, children and times as separate arrays -- 4 MB more, which a cycle of the run driver never looks at -- on demand.
 emat_status gt_fetch_mirrors(emat_backend* h) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   GTreeHost& G = h->gt;
   const size_t n = (size_t)G.n;
-  G.h_parent.resize(n); G.h_c0.resize(n); G.h_c1.resize(n); G.h_t.resize(n);
-  HIP_TRY(hipMemcpy(G.h_parent.data(), G.parent.p, n * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(G.h_c0.data(), G.c0.p, n * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(G.h_c1.data(), G.c1.p, n * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(G.h_t.data(), G.t.p, n * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(G.d_kids.alloc(n)); HIP_TRY(G.pin_kids.resize(n * sizeof(int2)));
+  hipLaunchKernelGGL(k_gt_pack_kids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, G.dev(), G.d_kids.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(G.pin_kids.data(), G.d_kids.p, n * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(&G.h_root, G.root.p, 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&G.h_root_t, G.t.p + G.h_root, 8, hipMemcpyDeviceToHost));
+  G.full_mirrors_stale = true;
+  return EMAT_OK;
+}
+emat_status gt_full_mirrors(emat_backend* h) {
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  GTreeHost& G = h->gt;
+  if (!G.full_mirrors_stale) return EMAT_OK;
+  const size_t n = (size_t)G.n;
+  G.h_parent.resize(n); G.h_c0.resize(n); G.h_c1.resize(n); G.h_t.resize(n);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(G.h_parent.data(), G.parent.p, n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(G.h_t.data(), G.t.p, n * 8, hipMemcpyDeviceToHost));
+  const int32_t* k = G.kids();
+  for (size_t v = 0; v < n; ++v) { G.h_c0[v] = k[2 * v]; G.h_c1[v] = k[2 * v + 1]; }
+  G.full_mirrors_stale = false;
   return EMAT_OK;
 }
 
@@ -84,7 +102,9 @@ emat_status emat_tree_upload(emat_backend* h, const emat_flat_tree* tree) {
   { int32_t z = 0; HIP_TRY(G.status.upload(&z, 1)); }
   G.h_parent.assign(tree->parent, tree->parent + n); G.h_c0.assign(tree->child0, tree->child0 + n); G.h_c1.assign(tree->child1, tree->child1 + n);
   G.h_t.assign(tree->t, tree->t + n); G.h_t_min.assign(tree->t_min, tree->t_min + n); G.h_t_max.assign(tree->t_max, tree->t_max + n);
-  G.h_root = tree->root;
+  G.h_root = tree->root; G.h_root_t = tree->t[tree->root]; G.full_mirrors_stale = false;
+  HIP_TRY(G.pin_kids.resize((size_t)n * sizeof(int2)));
+  { int32_t* k = (int32_t*)G.pin_kids.data(); for (int v = 0; v < n; ++v) { k[2 * v] = tree->child0[v]; k[2 * v + 1] = tree->child1[v]; } }
   G.resident = true; G.parts_live = false;
   return EMAT_OK;
 }
@@ -106,6 +126,7 @@ emat_status emat_tree_download(emat_backend* h, emat_flat_tree* out, uint8_t* re
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   GTreeHost& G = h->gt;
   if (G.parts_live) return fail(h, EMAT_ERR_STATE, "the parts are out on their slabs: emat_tree_reassemble first");
+  st = gt_full_mirrors(h); if (st) return st;
   const int n = G.n;
   if (out->num_nodes < n || out->cap_muts < (int32_t)G.used[0] || out->cap_intervals < (int32_t)G.used[1] || out->cap_from_states < (int32_t)G.used[2]) return EMAT_ERR_BUFFER_TOO_SMALL;
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -138,11 +159,28 @@ emat_status emat_tree_get_topology(emat_backend* h, int32_t* parent, int32_t* ch
   emat_status st = gt_require(h, true); if (st) return st;
   const GTreeHost& G = h->gt;
   if (G.parts_live) return fail(h, EMAT_ERR_STATE, "the parts are out on their slabs: emat_tree_reassemble first");
-  if (parent) std::copy(G.h_parent.begin(), G.h_parent.end(), parent);
-  if (child0) std::copy(G.h_c0.begin(), G.h_c0.end(), child0);
-  if (child1) std::copy(G.h_c1.begin(), G.h_c1.end(), child1);
-  if (t) std::copy(G.h_t.begin(), G.h_t.end(), t);
+  st = gt_full_mirrors(h); if (st) return st;
+  const int n = G.n, chunk = 32768;   // (4 MB at 200 000 nodes, once per cycle: on the host threads)
+  parallel_for((n + chunk - 1) / chunk, [&](int c) {
+    const size_t b = (size_t)c * chunk, e = std::min<size_t>((size_t)n, b + chunk);
+    if (parent) std::copy(G.h_parent.begin() + b, G.h_parent.begin() + e, parent + b);
+    if (child0) std::copy(G.h_c0.begin() + b, G.h_c0.begin() + e, child0 + b);
+    if (child1) std::copy(G.h_c1.begin() + b, G.h_c1.begin() + e, child1 + b);
+    if (t) std::copy(G.h_t.begin() + b, G.h_t.begin() + e, t + b);
+  }, 1);
   if (root) *root = G.h_root;
+  return EMAT_OK;
+}
+
+emat_status emat_tree_get_kids(emat_backend* h, const int32_t** kids, int32_t* num_nodes, int32_t* root, double* t_root) {
+  if (!h || !kids) return EMAT_ERR_INVALID_ARGUMENT;
+  emat_status st = gt_require(h, true); if (st) return st;
+  const GTreeHost& G = h->gt;
+  if (G.parts_live) return fail(h, EMAT_ERR_STATE, "the parts are out on their slabs: emat_tree_reassemble first");
+  *kids = G.kids();
+  if (num_nodes) *num_nodes = G.n;
+  if (root) *root = G.h_root;
+  if (t_root) *t_root = G.h_root_t;
   return EMAT_OK;
 }
 
@@ -153,42 +191,75 @@ emat_status emat_tree_partition(emat_backend* h, int32_t num_cuts, const int32_t
   GTreeHost& G = h->gt;
   if (G.parts_live) return fail(h, EMAT_ERR_STATE, "the parts are out on their slabs: emat_tree_reassemble first");
   const int n = G.n;
+  EMAT_SPAN("tree_partition (all)");
   // partition_tree's rule for the run's root (tree_partitioning.h:196-239): a part of its own at the end unless the stencil names it
   std::vector<uint8_t> is_cut((size_t)n, 0);
   std::vector<int32_t> cut_of_part(cut_nodes, cut_nodes + num_cuts);
+  const int32_t* const kids = G.kids();
   int rp = -1;
   for (int i = 0; i < num_cuts; ++i) {
     const int32_t c = cut_nodes[i];
-    if (c < 0 || c >= n || is_cut[c] || G.h_c0[c] == EMAT_NO_NODE) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_partition: cut nodes must be distinct inner nodes");
+    if (c < 0 || c >= n || is_cut[c] || kids[2 * (size_t)c] == EMAT_NO_NODE) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_partition: cut nodes must be distinct inner nodes");
     is_cut[c] = 1;
     if (c == G.h_root && rp < 0) rp = i;
   }
   if (rp < 0) { is_cut[G.h_root] = 1; rp = num_cuts; cut_of_part.push_back(G.h_root); }
   const int P = (int)cut_of_part.size();
   if (h->cfg.max_parts > 0 && P > h->cfg.max_parts) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "more parts than cfg.max_parts");
-  if (h->stream) HIP_TRY(hipStreamSynchronize(h->stream));
-  DevBuf<uint8_t> d_is_cut; DevBuf<int32_t> d_cut, d_sizes;
-  HIP_TRY(d_is_cut.upload(is_cut.data(), (size_t)n)); HIP_TRY(d_cut.upload(cut_of_part.data(), (size_t)P)); HIP_TRY(d_sizes.alloc((size_t)P));
+  HostLaps laps;
+  // Everything below is queued on the engine's stream without the host in between: the counts, the offsets from the counts
+  // (k_gt_part_offsets), the arrays, and -- when the model on the device is current -- the measuring pass of the repartition that
+  // is bound to follow (k_gt_measure needs nothing the host computes from this partition).  The host only waits for the sizes.
+  if (!G.ev_sizes) { HIP_TRY(hipEventCreateWithFlags(&G.ev_sizes, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&G.ev_measure, hipEventDisableTiming)); }
+  HIP_TRY(G.d_is_cut.alloc((size_t)n)); HIP_TRY(G.d_cut.alloc((size_t)P)); HIP_TRY(G.d_sizes.alloc((size_t)P)); HIP_TRY(G.d_part_status.alloc(1));
   const size_t total = (size_t)n + (size_t)P - 1;
   HIP_TRY(G.part_off.alloc((size_t)P + 1)); HIP_TRY(G.orig.alloc(total)); HIP_TRY(G.kid0.alloc(total)); HIP_TRY(G.kid1.alloc(total)); HIP_TRY(G.lpar.alloc(total)); HIP_TRY(G.lidx.alloc((size_t)n));
+  HIP_TRY(G.pin_sizes.resize(((size_t)2 * P + 2) * sizeof(int32_t)));
+  HIP_TRY(hipMemcpyAsync(G.d_is_cut.p, is_cut.data(), (size_t)n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(G.d_cut.p, cut_of_part.data(), (size_t)P * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemsetAsync(G.d_part_status.p, 0, sizeof(int32_t), h->stream));
   const unsigned blocks = (unsigned)((P + 63) / 64);
-  hipLaunchKernelGGL(k_gt_partition, dim3(blocks), dim3(64), 0, h->stream, G.dev(), (const uint8_t*)d_is_cut.p, (const int32_t*)d_cut.p, P, 0, d_sizes.p,
-                     (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+  hipLaunchKernelGGL(k_gt_partition, dim3(blocks), dim3(64), 0, h->stream, G.dev(), (const uint8_t*)G.d_is_cut.p, (const int32_t*)G.d_cut.p, P, 0, G.d_sizes.p,
+                     (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr);
+  hipLaunchKernelGGL(k_gt_part_offsets, dim3(1), dim3(1024), 0, h->stream, (const int32_t*)G.d_sizes.p, P, (long long)total, G.part_off.p, G.d_part_status.p);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  std::vector<int32_t> sizes((size_t)P);
-  HIP_TRY(hipMemcpy(sizes.data(), d_sizes.p, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToHost));
-  G.h_part_off.assign((size_t)P + 1, 0);
-  for (int p = 0; p < P; ++p) { if (sizes[p] < 1) return fail(h, EMAT_ERR_INTERNAL, "emat_tree_partition: empty part"); G.h_part_off[p + 1] = G.h_part_off[p] + sizes[p]; }
-  if ((size_t)G.h_part_off[P] != total) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_partition: the cut nodes do not partition the tree (a cut below another part's tip?)");
-  HIP_TRY(hipMemcpy(G.part_off.p, G.h_part_off.data(), ((size_t)P + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_gt_partition, dim3(blocks), dim3(64), 0, h->stream, G.dev(), (const uint8_t*)d_is_cut.p, (const int32_t*)d_cut.p, P, 1, (int32_t*)nullptr,
-                     (const int32_t*)G.part_off.p, G.orig.p, G.kid0.p, G.kid1.p, G.lpar.p, G.lidx.p);
+  int32_t* pin = (int32_t*)G.pin_sizes.data();   // [P] sizes, [P + 1] offsets, status
+  HIP_TRY(hipMemcpyAsync(pin, G.d_sizes.p, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(pin + P, G.part_off.p, ((size_t)P + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(pin + 2 * P + 1, G.d_part_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipEventRecord(G.ev_sizes, h->stream));
+  hipLaunchKernelGGL(k_gt_partition, dim3(blocks), dim3(64), 0, h->stream, G.dev(), (const uint8_t*)G.d_is_cut.p, (const int32_t*)G.d_cut.p, P, 1, (int32_t*)nullptr,
+                     (const int32_t*)G.part_off.p, G.orig.p, G.kid0.p, G.kid1.p, G.lpar.p, G.lidx.p, (const int32_t*)G.d_part_status.p);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));   // (the temporaries above go out of scope)
   G.P = P; G.root_part = rp; G.partition_on_device = true; G.h_orig.clear(); G.h_kid0.clear();
+  G.measure_queued = false;
+  if (h->have_ref && h->have_evo && !h->model_dirty && h->d_ref.n >= (size_t)h->L) {
+    HIP_TRY(G.measure.alloc((size_t)P));
+    { const size_t room = h->cfg_tree_tight ? 1 : (size_t)64 * P + 4096;
+      HIP_TRY(G.pool_muts.alloc(std::max<size_t>(G.pool_muts.n, room))); HIP_TRY(G.pool_ivs.alloc(std::max<size_t>(G.pool_ivs.n, room))); }
+    HIP_TRY(G.pool_tops.alloc(2));
+    HIP_TRY(G.pin_measure.resize((size_t)P * sizeof(GMeasure)));
+    HIP_TRY(hipMemsetAsync(G.pool_tops.p, 0, 2 * sizeof(uint32_t), h->stream));
+    hipLaunchKernelGGL((k_gt_measure<k_gt_small_cut_intervals, k_gt_small_cut_deltas>), dim3((unsigned)P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const uint8_t*)h->d_ref.p, G.measure.p,
+                       (const int32_t*)nullptr, (const int32_t*)G.d_part_status.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(G.pin_measure.data(), G.measure.p, (size_t)P * sizeof(GMeasure), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(G.ev_measure, h->stream));
+    G.measure_queued = true;
+  }
+  laps.mark("tree_partition: 1 validation, uploads, launches");
+  HIP_TRY(hipEventSynchronize(G.ev_sizes));
+  laps.mark("tree_partition: 2 wait for sizes + offsets");
+  const int32_t pst = pin[2 * P + 1];
+  if (pst != 0) {
+    G.P = 0; G.partition_on_device = false; G.measure_queued = false;
+    HIP_TRY(hipStreamSynchronize(h->stream));   // (what was queued behind the counts saw the status too and did nothing)
+    if (pst == 3) return fail(h, EMAT_ERR_INTERNAL, "emat_tree_partition: empty part");
+    return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_partition: the cut nodes do not partition the tree (a cut below another part's tip?)");
+  }
+  G.h_part_off.assign(pin + P, pin + 2 * P + 1);
   *num_parts = P; *root_part = rp;
-  if (part_sizes) std::copy(sizes.begin(), sizes.end(), part_sizes);
+  if (part_sizes) std::copy(pin, pin + P, part_sizes);
   return EMAT_OK;
 }
 
@@ -233,7 +304,7 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
   if (!h->have_ref || !h->have_evo) return fail(h, EMAT_ERR_STATE, "set_ref_sequence and set_evo must precede emat_tree_repartition");
   GTreeHost& G = h->gt;
   const int P = num_parts, n = G.n, lo = part_lo, hi = part_hi, nloc = hi - lo;   // this process runs the parts [lo, hi): local part q is part lo + q
-  const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
+  const bool verbose = verbose_reports();
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t0 = now();
@@ -244,6 +315,7 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
   // every node is a non-root node of exactly one part; the run's root is the root of the root part
   if (part_offset[0] != 0 || (int64_t)part_offset[P] != (int64_t)n + P - 1) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_repartition: the parts do not cover the tree");
   const size_t total = (size_t)part_offset[P];
+  if (!made_here || h->cfg_gt_host_coal) { st = gt_full_mirrors(h); if (st) return st; }
   if (!made_here) {
     std::atomic<int> bad{0};
     parallel_for(P, [&](int p) {
@@ -262,10 +334,20 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
       for (int s = (p == root_part ? 0 : 1), b = part_offset[p], np = part_offset[p + 1] - b; s < np; ++s) { if (owned[orig[b + s]]++) { bad.store(1); break; } }
     if (bad.load()) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_repartition: a node belongs to two parts");
   }
-  if (h->stream) HIP_TRY(hipStreamSynchronize(h->stream));
-  try { h->pop = HostPopModel::from_c(*pm); } catch (const std::exception& ex) { return fail(h, EMAT_ERR_INVALID_ARGUMENT, ex.what()); }
-  h->have_pop = true; h->model_dirty = true;
-  st = sync_model_to_device(h); if (st) return st;
+  EMAT_SPAN("tree_repartition (all)");
+  {   // the population model is handed over with every repartition and is the same from cycle to cycle: only a changed one travels
+    HostPopModel np;
+    try { np = HostPopModel::from_c(*pm); } catch (const std::exception& ex) { return fail(h, EMAT_ERR_INVALID_ARGUMENT, ex.what()); }
+    const bool same = h->have_pop && np.kind == h->pop.kind && np.skygrid_type == h->pop.skygrid_type && std::memcmp(np.p, h->pop.p, sizeof(np.p)) == 0 &&
+                      std::memcmp(&np.t_c, &h->pop.t_c, sizeof(double)) == 0 && np.x == h->pop.x && np.gamma == h->pop.gamma;
+    if (!same) { h->pop = std::move(np); h->model_dirty = true; }
+    h->have_pop = true;
+  }
+  const bool measure_queued = made_here && G.measure_queued && !h->model_dirty;   // (queued by emat_tree_partition: the stream is busy with it, and nothing below needs it idle)
+  G.measure_queued = false;
+  if (!measure_queued && h->stream) HIP_TRY(hipStreamSynchronize(h->stream));
+  { EMAT_SPAN("tree_repartition: sync_model_to_device"); st = sync_model_to_device(h); if (st) return st; }
+  HostLaps laps;
   G.P = P; G.root_part = root_part; G.parts_live = false;
   const bool device_coal = !h->cfg_gt_host_coal;
   if (nloc != P && !device_coal) return fail(h, EMAT_ERR_STATE, "a block of the parts needs the coalescent tables built on the device (EMAT_TREE_HOST_COALESCENT builds them from all parts on the host)");
@@ -281,35 +363,41 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
     }, 64);
     HIP_TRY(G.lpar.upload(lpar.data(), total));
   }
-  HIP_TRY(G.measure.alloc(P));
-  { const size_t room = h->cfg_tree_tight ? 1 : (size_t)64 * P + 4096;
-    HIP_TRY(G.pool_muts.alloc(std::max<size_t>(G.pool_muts.n, room))); HIP_TRY(G.pool_ivs.alloc(std::max<size_t>(G.pool_ivs.n, room))); }
-  HIP_TRY(G.pool_tops.alloc(2));
-  const auto t1 = now();
+  if (!measure_queued) {
+    HIP_TRY(G.measure.alloc(P));
+    { const size_t room = h->cfg_tree_tight ? 1 : (size_t)64 * P + 4096;
+      HIP_TRY(G.pool_muts.alloc(std::max<size_t>(G.pool_muts.n, room))); HIP_TRY(G.pool_ivs.alloc(std::max<size_t>(G.pool_ivs.n, room))); }
+    HIP_TRY(G.pool_tops.alloc(2));
+  }
+  const auto t1 = now(); laps.mark("tree_repartition: 01 allocations");
   auto launch_measure = [&]() -> emat_status {
     HIP_TRY(hipMemsetAsync(G.pool_tops.p, 0, 2 * sizeof(uint32_t), h->stream));
-    hipLaunchKernelGGL((k_gt_measure<k_gt_small_cut_intervals, k_gt_small_cut_deltas>), dim3((unsigned)P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const uint8_t*)h->d_ref.p, G.measure.p, (const int32_t*)nullptr);
+    hipLaunchKernelGGL((k_gt_measure<k_gt_small_cut_intervals, k_gt_small_cut_deltas>), dim3((unsigned)P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const uint8_t*)h->d_ref.p, G.measure.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     return EMAT_OK;
   };
   // the parts whose cut-point state did not fit the small kernel's LDS: once more, with the full capacities
   auto remeasure_large = [&](const std::vector<int32_t>& list) -> emat_status {
     HIP_TRY(G.measure_list.upload(list.data(), list.size()));
-    hipLaunchKernelGGL((k_gt_measure<k_gt_max_cut_intervals, k_gt_max_cut_deltas>), dim3((unsigned)list.size()), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const uint8_t*)h->d_ref.p, G.measure.p, (const int32_t*)G.measure_list.p);
+    hipLaunchKernelGGL((k_gt_measure<k_gt_max_cut_intervals, k_gt_max_cut_deltas>), dim3((unsigned)list.size()), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const uint8_t*)h->d_ref.p, G.measure.p, (const int32_t*)G.measure_list.p, (const int32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     return EMAT_OK;
   };
   st = join_side_classes(h); if (st) return st;   // (side launches of a pass nobody gathered: the slabs are about to be rebuilt)
   h->sides_must_fork = true;
-  st = launch_measure(); if (st) return st;
-  // while the device measures: skeletons of the parts (topology + times), and from them the coalescent cell tables
+  if (!measure_queued) { st = launch_measure(); if (st) return st; }
+  laps.mark("tree_repartition: 02 join sides + launch k_gt_measure");
+  // The records of the parts.  With the coalescent tables built on the host they come first (the builder reads the parts' skeletons:
+  // topology + times) and fill the time the device spends measuring; with the tables built on the device nothing on the host needs
+  // them before the slabs are placed, and they are written in ONE pass over the records at the end, together with everything the
+  // measures decide (a record is 600 bytes, thirteen thousand of them are 8 MB: three passes cost three times the cache misses).
   h->coal_builder.reset();
   h->fatal_status = EMAT_OK; h->fatal_message.clear(); h->pass_pending = false;
   if (!device_coal) h->parts.clear();   // (with the tables built on the device the records hold no vectors worth freeing and re-allocating 8 000 times per cycle)
   h->parts.resize(nloc);
   h->uploads_expected = 0; h->root_part = (root_part >= lo && root_part < hi) ? root_part - lo : -1;
   h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false; h->have_coal = false; h->derived_valid = false;
-  parallel_for(nloc, [&](int q) {
+  auto init_record = [&](int q) {
     const int p = lo + q;
     PartHost& ph = h->parts[q];
     const int b = part_offset[p], np = part_offset[p + 1] - b;
@@ -328,8 +416,9 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
     ph.includes_run_root = p == root_part; ph.n_nodes = np;
     ph.rng.key = seeds[p]; ph.rng.counter = 0; ph.rng.spare = 0; ph.rng.has_spare = false;
     ph.uploaded = true; ph.stats = emat_part_stats{}; ph.expected_moves = 0; ph.space_boost = 1.0; ph.cell_boost = 1; ph.trace.clear();
-  }, 64);
-  const auto t2 = now();
+  };
+  if (!device_coal) parallel_for(nloc, init_record, 64);
+  const auto t2 = now(); laps.mark("tree_repartition: 03 part records (host coalescent only)");
   if (!device_coal) try {
     std::vector<const FlatTree*> trees; std::vector<HostRng*> rngs;
     for (auto& ph : h->parts) { trees.push_back(&ph.tree); rngs.push_back(&ph.rng); }
@@ -341,8 +430,16 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
   std::vector<GMeasure> me(P);
   bool large_done = false;
   for (int attempt = 0;; ++attempt) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(me.data(), G.measure.p, (size_t)P * sizeof(GMeasure), hipMemcpyDeviceToHost));
+    if (attempt == 0 && measure_queued) {
+      HIP_TRY(hipEventSynchronize(G.ev_measure));
+      laps.mark("tree_repartition: 04 wait for k_gt_measure");
+      std::memcpy(me.data(), G.pin_measure.data(), (size_t)P * sizeof(GMeasure));
+    } else {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      laps.mark("tree_repartition: 04 wait for k_gt_measure");
+      HIP_TRY(hipMemcpy(me.data(), G.measure.p, (size_t)P * sizeof(GMeasure), hipMemcpyDeviceToHost));
+    }
+    laps.mark("tree_repartition: 05 measures D2H");
     {
       std::vector<int32_t> large;
       for (int p = 0; p < P; ++p) if (me[p].status == k_gt_cut_state_overflow) large.push_back(p);
@@ -364,7 +461,7 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
     ++G.pool_regrows; large_done = false;
     st = launch_measure(); if (st) return st;
   }
-  const auto t4 = now();
+  const auto t4 = now(); laps.mark("tree_repartition: 06 status scan of the measures");
   // geometry, placement, size classes: as for host-encoded parts
   const int trace_cap = h->cfg.trace_moves > 0 ? h->cfg.trace_moves : 0;
   uint64_t off = 0; h->max_slab_bytes = 0; h->persistent_bytes.assign(nloc, 0); h->prefix_bytes.assign(nloc, 0);
@@ -389,37 +486,54 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
       GPartDesc& d = desc[p];
       d.cell_first = wf; d.n_cells = lc - wf + 1; d.n_cells_total = lc + 1; d.t_ref = co.t_ref; d.t_step = t_step; d.coal_first_active = fc;
       d.rng_key = seeds[p]; d.cells_off = pool; pool += (uint64_t)(lc - wf + 1);
-      if (p >= lo && p < hi) {
-        HostCoalPart& c = h->parts[p - lo].coal;
-        if (!c.k_bar_p.empty()) c = HostCoalPart{};   // (tables decoded by a pull of the previous partition)
-        c.cell_first = wf; c.n_cells_total = lc + 1; c.t_ref = co.t_ref; c.t_step = t_step;
-        h->parts[p - lo].rng.counter = (uint64_t)(lc - fc + 1);   // one Philox block per Gaussian draw
-      }
     }
     HIP_TRY(G.co_kbar.alloc(pool)); HIP_TRY(G.co_ktw.alloc(pool));
     HIP_TRY(G.co_k_bar.alloc(co.num_cells)); HIP_TRY(G.co_k_tw.alloc(co.num_cells)); HIP_TRY(G.co_popsize.alloc(co.num_cells)); HIP_TRY(G.co_num_active.alloc(co.num_cells)); HIP_TRY(G.co_tsop.alloc(co.num_cells));
     co.kbar_pool = G.co_kbar.p; co.ktw_pool = G.co_ktw.p; co.k_bar = G.co_k_bar.p; co.k_tw = G.co_k_tw.p; co.popsize = G.co_popsize.p; co.num_active = G.co_num_active.p; co.ts_over_pop = G.co_tsop.p;
     co.status = G.status.p;
   }
-  for (int p = lo; p < hi; ++p) {
-    PartHost& ph = h->parts[p - lo];
-    const int nc = device_coal ? num_cells_of[p] : (int)ph.coal.k_bar_p.size();
-    const SlabGeo g = slab_geometry(h, me[p].n_nodes, me[p].num_muts, me[p].content_bytes, nc, ph.includes_run_root, ph.space_boost);
-    place_slab(h, (size_t)(p - lo), g, off, me[p].content_bytes);
-    offs[p - lo] = ph.slab_off;
+  laps.mark("tree_repartition: 07 cell ranges + pool allocations");
+  // where every slab goes: from the measures alone (a fresh record is the root part or not, and has no boosts)
+  std::vector<SlabGeo> geo((size_t)nloc);
+  if (h->used_bytes.size() < (size_t)nloc) h->used_bytes.resize((size_t)nloc, 0u);
+  for (int q = 0; q < nloc; ++q) {
+    const int p = lo + q;
+    const int nc = device_coal ? num_cells_of[p] : (int)h->parts[q].coal.k_bar_p.size();
+    const SlabGeo g = slab_geometry(h, me[p].n_nodes, me[p].num_muts, me[p].content_bytes, nc, p == root_part, 1.0);
+    geo[(size_t)q] = g; offs[(size_t)q] = off; off += g.bytes;
+    h->used_bytes[(size_t)q] = g.bytes - g.scratch - g.heap + me[p].content_bytes;
+    h->persistent_bytes[(size_t)q] = g.bytes - g.scratch;
+    h->prefix_bytes[(size_t)q] = g.bytes - g.scratch - g.heap;
+    h->max_slab_bytes = std::max(h->max_slab_bytes, g.bytes);
+    if (!device_coal) { desc[p].cells_off = cells_bytes; cells_bytes += (uint64_t)nc * 32u + (((uint64_t)nc * 4u + 7u) & ~(uint64_t)7u); }
+  }
+  laps.mark("tree_repartition: 08a slab geometry + placement");
+  // the one pass over the records, and the descriptors the build kernel reads
+  parallel_for(nloc, [&](int q) {
+    const int p = lo + q;
+    if (device_coal) init_record(q);
+    PartHost& ph = h->parts[q];
+    const SlabGeo& g = geo[(size_t)q];
+    ph.slab_off = offs[(size_t)q]; ph.slab_bytes = g.bytes; ph.scratch_bytes = g.scratch;
     GPartDesc d = desc[p];
+    if (device_coal) {
+      HostCoalPart& c = ph.coal;
+      if (!c.k_bar_p.empty()) c = HostCoalPart{};   // (tables decoded by a pull of the previous partition)
+      c.cell_first = d.cell_first; c.n_cells_total = d.n_cells_total; c.t_ref = d.t_ref; c.t_step = d.t_step;
+      ph.rng.counter = (uint64_t)(d.n_cells_total - first_active[p]);   // one Philox block per Gaussian draw: cells first_active .. last
+    }
+    const int nc = device_coal ? num_cells_of[p] : (int)ph.coal.k_bar_p.size();
     d.slab_bytes = g.bytes; d.heap_bytes = g.heap; d.scratch_bytes = g.scratch; d.cell_cap = g.cell_cap; d.trace_cap = trace_cap;
     d.flags = ph.includes_run_root ? k_flag_includes_run_root : 0u;
     d.rng_key = ph.rng.key; d.rng_counter = ph.rng.counter; d.rng_spare = ph.rng.spare; d.rng_has_spare = ph.rng.has_spare ? 1u : 0u;
     d.cell_first = ph.coal.cell_first; d.n_cells = nc; d.n_cells_total = ph.coal.n_cells_total; d.t_ref = ph.coal.t_ref; d.t_step = ph.coal.t_step;
-    if (device_coal) { d.coal_first_active = first_active[p]; }
-    else { d.cells_off = cells_bytes; cells_bytes += (uint64_t)nc * 32u + (((uint64_t)nc * 4u + 7u) & ~(uint64_t)7u); d.coal_first_active = ph.coal.cell_first; }
+    d.coal_first_active = device_coal ? first_active[p] : ph.coal.cell_first;
     desc[p] = d;
-  }
-  const auto t5 = now();
+  }, 256);
+  const auto t5 = now(); laps.mark("tree_repartition: 08b records + descriptors (one pass)");
   assign_size_classes(h);
   h->order_valid = false;
-  const auto t6 = now();
+  const auto t6 = now(); laps.mark("tree_repartition: 09 size classes");
   std::vector<uint8_t> cells(cells_bytes);
   if (!device_coal) parallel_for(P, [&](int p) {
     const HostCoalPart& c = h->parts[p].coal; const size_t nc = c.k_bar_p.size();
@@ -431,9 +545,11 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
   const auto t7 = now();
   HIP_TRY(G.desc.upload(desc.data(), (size_t)P)); HIP_TRY(G.cells.upload(cells.data(), cells.size()));
   HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
-  HIP_TRY(h->d_slabs.alloc(off)); HIP_TRY(h->h_slabs.resize(off));
+  laps.mark("tree_repartition: 10 descriptors + offsets H2D");
+  HIP_TRY(h->d_slabs.alloc_roomy(off)); h->slab_bytes_total = off;
   HIP_TRY(h->d_part_ticks.alloc((2 + 2 * k_ticket_log) * (size_t)nloc)); HIP_TRY(hipMemsetAsync(h->d_part_ticks.p, 0, (2 + 2 * k_ticket_log) * (size_t)nloc * sizeof(int64_t), h->stream));
   HIP_TRY(h->d_part_status.alloc((size_t)nloc)); HIP_TRY(hipMemsetAsync(h->d_part_status.p, 0, (size_t)nloc * sizeof(int32_t), h->stream));
+  laps.mark("tree_repartition: 11 slab allocation + memsets");
   if (device_coal) {
     HIP_TRY(hipMemsetAsync(G.status.p, 0, sizeof(int32_t), h->stream));
     const unsigned cell_blocks = (unsigned)co.num_cells;
@@ -446,18 +562,24 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
   hipLaunchKernelGGL(k_gt_build, dim3((unsigned)nloc), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const GMeasure*)G.measure.p, (const GPartDesc*)G.desc.p,
                      (const uint8_t*)G.cells.p, co, h->d_slabs.p, (const uint64_t*)h->d_slab_off.p, lo);
   HIP_TRY(hipGetLastError());
+  laps.mark("tree_repartition: 12 launches (coalescent x4, k_gt_build)");
+  // the launch order of the pass to come, while the device builds the slabs (nothing in flight reads it: the side launches of the
+  // last pass were joined above, and the copy is queued behind the kernels)
+  st = build_order(h, true); if (st) return st;
+  laps.mark("tree_repartition: 12b launch order (sort + queued H2D)");
   if (device_coal) {   // a lineage outside its part's window, or a grid whose last cell no part is active in: the host builder throws on both
     int32_t cst = 0;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    laps.mark("tree_repartition: 13 wait for the kernels");
     HIP_TRY(hipMemcpy(&cst, G.status.p, sizeof(cst), hipMemcpyDeviceToHost));
     if (cst != k_gt_ok) { h->slabs_on_device = false; h->parts.clear(); return fail(h, EMAT_ERR_INVALID_ARGUMENT, "coalescent grid: a lineage outside its part's cells, or an inactive final cell"); }
-    // the run-wide cell arrays ARE the grid the kernels just built: the moves read them in place; a few KB of host mirror for the getters
-    const size_t nc = (size_t)co.num_cells;
-    h->sh_ktw.resize(nc); h->sh_popsize.resize(nc); h->sh_tsop.resize(nc); h->sh_nact.resize(nc);
-    HIP_TRY(hipMemcpy(h->sh_ktw.data(), G.co_k_tw.p, nc * 8, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(h->sh_popsize.data(), G.co_popsize.p, nc * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h->sh_tsop.data(), G.co_tsop.p, nc * 8, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(h->sh_nact.data(), G.co_num_active.p, nc * 4, hipMemcpyDeviceToHost));
+    // the run-wide cell arrays ARE the grid the kernels just built: the moves read them in place; the host's mirror of them (a few KB,
+    // read when slabs are decoded) follows when a pull asks for it (pull_grid_mirrors)
     h->shared_dev = SharedCells{G.co_k_tw.p, G.co_tsop.p, G.co_num_active.p, co.num_cells};
-  } else { emat_status st2 = upload_shared_cells(h); if (st2) return st2; }
+    h->grid_mirrors_on_device = true;
+    h->sh_ktw.clear(); h->sh_popsize.clear(); h->sh_tsop.clear(); h->sh_nact.clear();
+  } else { emat_status st2 = upload_shared_cells(h); if (st2) return st2; h->grid_mirrors_on_device = false; }
+  laps.mark("tree_repartition: 14 status of the grid");
   h->slabs_on_device = true; h->host_slabs_current = false; h->headers_current = false; h->derived_valid = false;
   G.parts_live = true;
   if (verbose) {
@@ -560,18 +682,21 @@ emat_status emat_tree_reassemble(emat_backend* h, int32_t* num_root_deltas, int3
   if (!h || (capacity > 0 && (!site || !from || !to))) return EMAT_ERR_INVALID_ARGUMENT;
   emat_status st = gt_require(h, true); if (st) return st;
   GTreeHost& G = h->gt;
-  const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
+  const bool verbose = verbose_reports();
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t0 = now();
   if (G.parts_live && (G.lo != 0 || G.hi != G.P)) return fail(h, EMAT_ERR_STATE, "this process holds a block of the parts: the other processes' nodes must be exchanged (emat_tree_gather_local, _export_nodes, _apply_nodes, _reassemble_end)");
+  HostLaps laps;
   st = gt_reassemble_begin(h); if (st) return st;
-  const auto t1 = now();
+  const auto t1 = now(); laps.mark("tree_reassemble: 1 finish_pass (waits for the moves)");
   std::vector<GRootDelta> rd; bool owner = false;
   st = gt_root_deltas(h, rd, owner); if (st) return st;
+  laps.mark("tree_reassemble: 2 root deltas");
   st = gt_gather_local(h, rd); if (st) return st;
-  const auto t2 = now();
+  const auto t2 = now(); laps.mark("tree_reassemble: 3 k_gt_gather");
   st = gt_reassemble_end(h); if (st) return st;
+  laps.mark("tree_reassemble: 4 topology mirrors D2H");
   const int nd = (int)rd.size();
   if (verbose) fprintf(stderr, "[emat] tree_reassemble: wait for the moves + status check %.1f ms | root changes (%d) + k_gt_gather + reference tables %.1f ms | topology + times D2H %.1f ms\n",
                        ms(t0, t1), nd, ms(t1, t2), ms(t2, now()));

@@ -92,9 +92,10 @@ __device__ inline uint32_t wave_sum_u32(uint32_t x) {
 //      indices exactly as it does (two consecutive ones to the children of every node it expands).  No stack: in a binary
 //      tree with parent links the way back up is known.  mode 0 counts the part's nodes, mode 1 writes the arrays.
 __global__ void k_gt_partition(GTreeDev g, const uint8_t* is_cut, const int32_t* cut_of_part, int num_parts, int mode, int32_t* sizes,
-                               const int32_t* part_off, int32_t* orig, int32_t* kid0, int32_t* kid1, int32_t* lpar, int32_t* lidx) {
+                               const int32_t* part_off, int32_t* orig, int32_t* kid0, int32_t* kid1, int32_t* lpar, int32_t* lidx, const int32_t* gate) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= num_parts) return;
+  if (gate && *gate != 0) return;   // (k_gt_part_offsets found the counts wrong: the offsets are not to be written through)
   const int32_t cut = cut_of_part[p];
   const int b = mode ? part_off[p] : 0;
   int cnt = 1;
@@ -121,6 +122,31 @@ __global__ void k_gt_partition(GTreeDev g, const uint8_t* is_cut, const int32_t*
   if (!mode) sizes[p] = cnt;
 }
 
+// What the host's partitioner reads of the tree every cycle: each node's two children side by side (one cache line per visit of
+// its walks), 8 bytes a node instead of the 24 of parent, children and time.
+__global__ void k_gt_pack_kids(GTreeDev g, int2* kids) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < g.n_nodes) kids[v] = make_int2(g.c0[v], g.c1[v]);
+}
+
+// The parts' offsets from their sizes, between the two passes of k_gt_partition: one workgroup, so that the host need not take
+// the sizes, add them up and send the sums back while the device waits.  status: 3 = an empty part, 2 = the sizes do not add up to
+// `expect_total` (the cut nodes do not partition the tree); mode 1 and whatever else is queued behind it look at it first.
+__global__ void __launch_bounds__(1024) k_gt_part_offsets(const int32_t* sizes, int num_parts, long long expect_total, int32_t* part_off, int32_t* status) {
+  __shared__ long long part[1024];
+  const int t = threadIdx.x, per = (num_parts + 1023) / 1024, b = t * per, e = min(num_parts, b + per);
+  long long s = 0; bool bad = false;
+  for (int i = b; i < e; ++i) { const int v = sizes[i]; if (v < 1) bad = true; s += v; }
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) { const long long v = t >= d ? part[t - d] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
+  const long long total = part[1023];
+  long long run = part[t] - s;
+  if (total == expect_total) for (int i = b; i < e; ++i) { part_off[i] = (int32_t)run; run += sizes[i]; }
+  if (t == 1023) { part_off[num_parts] = (int32_t)(total == expect_total ? total : 0); if (total != expect_total) atomicMax(status, 2); }
+  if (bad) atomicMax(status, 3);
+}
+
 // ---- pass 1 of a repartition: the state at every cut point + how much list content every part holds ------------
 // State at a cut point c = the sites missing at c (union of the missations from c up to the root) and the net changes
 // reference sequence -> sequence at c, sorted by site, over the sites present at c.  The walk goes UP from c, so later
@@ -132,11 +158,12 @@ struct GCutDelta { int32_t site; uint8_t from, to; uint16_t pad; };
 // is how many pointer chases are in flight) for all parts, and with the full capacities for the parts that overflowed it
 // (`part_list`, or null for all parts).
 template <int kMaxIv, int kMaxDl>
-__global__ void __launch_bounds__(k_wave) k_gt_measure(GTreeDev g, GPartition pt, GPools pools, const uint8_t* ref, GMeasure* out, const int32_t* part_list) {
+__global__ void __launch_bounds__(k_wave) k_gt_measure(GTreeDev g, GPartition pt, GPools pools, const uint8_t* ref, GMeasure* out, const int32_t* part_list, const int32_t* gate) {
   __shared__ IvRec acc[2][kMaxIv];
   __shared__ GCutDelta dl[kMaxDl];
   __shared__ int sh[4];
   __shared__ uint32_t sh_off[2];
+  if (gate && *gate != 0) return;   // queued behind a partition that turned out wrong (emat_tree_partition)
   const int p = part_list ? part_list[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
   const int base = pt.part_off[p], n = pt.part_off[p + 1] - base;
   if (lane == 0) {

@@ -30,6 +30,7 @@
 
 #include "../../include/emat_backend.h"
 #include "../../include/emat_host.h"
+#include "host_parallel.hpp"   // verbose_reports
 
 namespace {
 
@@ -162,7 +163,7 @@ emat_status emat_run_create_multi(const int32_t* devices, int32_t n, const emat_
   for (auto& s : m->shards) {
     if (hipSetDevice(s.device) != hipSuccess || hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&s.totals, 4 * sizeof(double)) != hipSuccess) return cleanup(EMAT_ERR_HIP);
   }
-  if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat_multi] %d shard(s), exchange: %s\n", n, m->exchange_note.c_str());
+  if (emat::verbose_reports()) fprintf(stderr, "[emat_multi] %d shard(s), exchange: %s\n", n, m->exchange_note.c_str());
   *out = m.release();
   return EMAT_OK;
 }

@@ -149,7 +149,7 @@ struct RunDriver {
   // tree_partitioning.h:139-194
   std::vector<int32_t> generate_random_partition_stencil() {
     std::vector<int32_t> cuts;
-    const int N = (int)tp_parent.size();   // needs sync_topology()
+    const int N = tp_n;   // needs sync_topology() / fetch_device_topology()
     std::vector<int> descendants(N, 0);
     long num_branches_left = N; int num_parts_left = num_parts;
     struct Item { int32_t node; int csf; };
@@ -157,7 +157,7 @@ struct RunDriver {
     bool done = false;
     while (!stack.empty() && !done) {
       Item it = stack.back(); stack.pop_back();
-      const int32_t nd_c0 = tp_c0[it.node], nd_c1 = tp_c1[it.node];
+      const int32_t nd_c0 = tp_kids[it.node].c0, nd_c1 = tp_kids[it.node].c1;
       const int nch = nd_c0 == EMAT_NO_NODE ? 0 : 2;
       if (it.csf == -1) {
         stack.push_back({it.node, nch});
@@ -209,8 +209,8 @@ struct RunDriver {
     const long mean = (long)num_nodes / std::max(1, num_parts);
     return (int)std::max(64L, 3 * mean);
   }
-  std::vector<int32_t> refine_stencil(std::vector<int32_t> cuts) {   // needs sync_topology()
-    const int N = (int)tp_parent.size();
+  std::vector<int32_t> refine_stencil(std::vector<int32_t> cuts) {   // needs sync_topology() / fetch_device_topology()
+    const int N = tp_n;
     const int eff = effective_max_part_nodes((size_t)N);
     last_extra_cuts = 0;
     if (eff <= 0) return cuts;
@@ -224,9 +224,10 @@ struct RunDriver {
     // oversized pieces, and so on.  A walk stops at cut nodes, so a task only ever writes is_cut of nodes its own part owns.
     std::vector<std::vector<int32_t>> extra(roots.size());
     const uint64_t round_seed = seed ^ (0x9E3779B97F4A7C15ull * (epoch + 1)) ^ 0x5A17C0DEull;
+    const Kids* const kids = tp_kids;
     parallel_for((int)roots.size(), [&](int ri) {
-      std::vector<int32_t> work, inner, stack;
-      work.push_back(roots[(size_t)ri]);
+      static thread_local std::vector<int32_t> work, inner, stack;   // (8 000 tasks per cycle: no allocation in any of them)
+      work.clear(); work.push_back(roots[(size_t)ri]);
       SplitMix64 rng(round_seed ^ (0xD6E8FEB86659FD93ull * (uint64_t)(roots[(size_t)ri] + 1)));   // a stream per part: the result does not depend on the threads
       bool first = true;
       while (!work.empty()) {
@@ -235,9 +236,12 @@ struct RunDriver {
         int size = 0; inner.clear(); stack.clear(); stack.push_back(c);
         while (!stack.empty()) {
           const int32_t v = stack.back(); stack.pop_back(); ++size;
-          if (tp_c0[v] == EMAT_NO_NODE || (is_cut[v] && v != c)) continue;
+          const Kids k = kids[v];   // (both children in one cache line: the walk is bound by misses on a 200 000-node tree)
+          if (k.c0 == EMAT_NO_NODE || (is_cut[v] && v != c)) continue;
           if (v != c) inner.push_back(v);
-          stack.push_back(tp_c0[v]); stack.push_back(tp_c1[v]);
+          stack.push_back(k.c0); stack.push_back(k.c1);
+          __builtin_prefetch(&kids[k.c0]); __builtin_prefetch(&is_cut[(size_t)k.c0]);   // (c1 is visited next, c0 after c1's whole subtree: its lines are on their way by then)
+          __builtin_prefetch(&kids[k.c1]); __builtin_prefetch(&is_cut[(size_t)k.c1]);
         }
         if (first && size <= limit) return;   // the common case: one walk, nothing to do
         first = false;
@@ -259,7 +263,7 @@ struct RunDriver {
     int root_idx = (int)stencil.size(); bool root_in = false;
     for (size_t i = 0; i < stencil.size(); ++i) if (stencil[i] == tp_root) { root_in = true; root_idx = (int)i; break; }
     const int P = (int)stencil.size() + (root_in ? 0 : 1);
-    std::vector<char> is_cut(tp_parent.size(), 0);
+    std::vector<char> is_cut((size_t)tp_n, 0);
     for (int32_t c : stencil) is_cut[c] = 1;
     if (!root_in) { is_cut[tp_root] = 1; root_idx = P - 1; }
     root_part = root_idx;
@@ -275,7 +279,7 @@ struct RunDriver {
       std::vector<std::pair<int32_t, int32_t>> kids(1, {EMAT_NO_NODE, EMAT_NO_NODE});
       while (!work.empty()) {
         W w = work.back(); work.pop_back();
-        const int32_t k0 = tp_c0[w.src], k1 = tp_c1[w.src];
+        const int32_t k0 = tp_kids[w.src].c0, k1 = tp_kids[w.src].c1;
         if (k0 == EMAT_NO_NODE || (is_cut[w.src] && w.src != pm.cut_point)) continue;
         int32_t dl = (int32_t)pm.orig.size(); pm.orig.push_back(k0);
         int32_t dr = (int32_t)pm.orig.size(); pm.orig.push_back(k1);
@@ -289,16 +293,24 @@ struct RunDriver {
   std::vector<std::vector<std::pair<int32_t, int32_t>>> part_kids;
   // Compact copy of the whole tree's topology (the node records carry three vectors each and are 100+ bytes apart:
   // walking them misses the cache at every step).  Rebuilt at the start of every repartition.
-  std::vector<int32_t> tp_parent, tp_c0, tp_c1; std::vector<double> tp_t; int32_t tp_root = EMAT_NO_NODE;
+  // The partitioner's walks read a node's two children and nothing else: side by side, one cache line per visit (they are bound
+  // by misses on a 200 000-node tree).  `tp_kids` points at this object's own copy (host-resident tree) or straight into the
+  // backend's page-locked mirror of the device-resident tree, which every reassemble refreshes.
+  struct Kids { int32_t c0, c1; };
+  std::vector<int32_t> tp_parent; std::vector<Kids> tp_kids_own; const Kids* tp_kids = nullptr;
+  int tp_n = 0; int32_t tp_root = EMAT_NO_NODE; double tp_root_t = 0.0;
   void sync_topology() {
     const int N = (int)tree.nodes.size();
-    tp_parent.resize(N); tp_c0.resize(N); tp_c1.resize(N); tp_t.resize(N); tp_root = tree.root;
-    parallel_for(N, [&](int v) { const HNode& nd = tree.nodes[v]; tp_parent[v] = nd.parent; tp_c0[v] = nd.c0; tp_c1[v] = nd.c1; tp_t[v] = nd.t; }, 4096);
+    tp_parent.resize(N); tp_kids_own.resize(N); tp_root = tree.root; tp_root_t = tree.nodes[tree.root].t;
+    parallel_for(N, [&](int v) { const HNode& nd = tree.nodes[v]; tp_parent[v] = nd.parent; tp_kids_own[v] = Kids{nd.c0, nd.c1}; }, 4096);
+    tp_kids = tp_kids_own.data(); tp_n = N;
   }
   emat_status fetch_device_topology() {   // device-resident tree: what the backend mirrored at its last upload / reassemble
-    const size_t N = tree.nodes.size();
-    tp_parent.resize(N); tp_c0.resize(N); tp_c1.resize(N); tp_t.resize(N);
-    return bk(emat_tree_get_topology(backend, tp_parent.data(), tp_c0.data(), tp_c1.data(), tp_t.data(), &tp_root));
+    static_assert(sizeof(Kids) == 2 * sizeof(int32_t), "Kids is a pair of int32");
+    const int32_t* k = nullptr; int32_t n = 0;
+    emat_status st = bk(emat_tree_get_kids(backend, &k, &n, &tp_root, &tp_root_t)); if (st) return st;
+    tp_kids = (const Kids*)k; tp_n = n;
+    return EMAT_OK;
   }
   // `tree` (and `ref`) as of the last reassemble, when the authoritative copy lives on the device
   emat_status ensure_host_tree() {
@@ -404,7 +416,7 @@ struct RunDriver {
     std::vector<CutState> states;
     auto tc0 = std::chrono::steady_clock::now();
     cut_point_states(states);
-    if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat_run] cut_point_states %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
+    if (verbose_reports()) fprintf(stderr, "[emat_run] cut_point_states %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
     auto build_one = [&](int p) {
       const PartMap& pm = parts[p];
       const int n = (int)pm.orig.size();
@@ -473,7 +485,7 @@ struct RunDriver {
     return EMAT_OK;
   }
   double default_t_step() const {   // Run keeps ~400 cells over the tree span (run.cpp:20, :734-747)
-    double lo = device_tree && !tp_t.empty() ? tp_t[tp_root] : tree.nodes[tree.root].t, hi = t_max_tip();
+    double lo = device_tree && tp_n > 0 ? tp_root_t : tree.nodes[tree.root].t, hi = t_max_tip();
     double span = hi - lo; if (!(span > 0)) span = 1.0;
     return std::max(span / 400.0, 1.0 / 400.0);
   }
@@ -578,7 +590,7 @@ struct RunDriver {
   // The same cycle with the whole tree resident in HBM: the host draws and applies the stencil on the topology alone
   // and hands the parts over as three int arrays; nodes, mutations and missations never leave the device.
   emat_status repartition_device() {
-    const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
+    const bool verbose = verbose_reports();
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     auto t0 = now();
@@ -594,8 +606,9 @@ struct RunDriver {
       device_tree_uploaded = true; host_tree_stale = false;
     }
     if (!model_pushed) { st = push_model(); if (st) return st; }
-    st = fetch_device_topology(); if (st) return st;
+    { EMAT_SPAN("run.repartition: fetch_device_topology"); st = fetch_device_topology(); if (st) return st; }
     auto t1 = now();
+    HostLaps laps;
     std::vector<int32_t> part_off, orig, kid0, kid1;
     try {
       if (stencils.empty() || stencil_refresh_countdown <= 0) {
@@ -605,18 +618,21 @@ struct RunDriver {
       }
       --stencil_refresh_countdown;
       const std::vector<int32_t> stencil = refine_stencil(stencils[bitgen.below((int)stencils.size())]);
+      laps.mark("run.repartition: stencil pick + refine_stencil");
       part_kids.clear();
       // partition_tree itself: on the device (one thread per part) unless the parts are few and large, where one host thread
       // per part is the better fit
-      const size_t N = tp_parent.size();
+      const size_t N = (size_t)tp_n;
       if (stencil.size() + 1 >= 64 && N / (stencil.size() + 1) <= 2048) {
         int32_t P = 0, rp = -1;
         std::vector<int32_t> psz(stencil.size() + 1, 0);
         emat_status st1 = bk(emat_tree_partition(backend, (int32_t)stencil.size(), stencil.data(), &P, &rp, psz.data())); if (st1) return st1;
         last_num_parts = P; last_largest_part = 0; for (int p = 0; p < P; ++p) last_largest_part = std::max(last_largest_part, (int)psz[(size_t)p]);
+        laps.mark("run.repartition: emat_tree_partition + largest part");
         parts.assign((size_t)P, PartMap{});
         for (int p = 0; p < P; ++p) parts[p].cut_point = p < (int)stencil.size() ? stencil[p] : tp_root;
         root_part = rp; partition_on_device = true;
+        laps.mark("run.repartition: part maps");
       } else { partition_tree(stencil); partition_on_device = false; note_partition_stats(); }
       ++epoch;
     } catch (const std::exception& ex) { return fail(EMAT_ERR_INTERNAL, ex.what()); }
@@ -631,6 +647,7 @@ struct RunDriver {
       part_epoch.assign(P, 0);
       emat_pop_model pm = pop; pm.skygrid_x = sky_x.data(); pm.skygrid_gamma = sky_g.data();
       auto t3 = now();
+      laps.mark("run.repartition: seeds, shard block");
       st = bk(emat_tree_repartition_range(backend, P, nullptr, nullptr, nullptr, nullptr, root_part, part_seeds.data(), &pm, t_step_set ? t_step : default_t_step(), part_lo, part_hi));
       if (st) return st;
       parts_uploaded = true; coal_built = true; host_tree_stale = true;
@@ -681,7 +698,7 @@ struct RunDriver {
   }
 
   emat_status repartition() {   // run.cpp:110-193 (+ refresh_partition_stencils :87-108)
-    const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
+    const bool verbose = verbose_reports();
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     auto t0 = now(), t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0;
@@ -725,7 +742,7 @@ struct RunDriver {
   }
 
   emat_status reassemble() {   // run.cpp:195-256
-    const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
+    const bool verbose = verbose_reports();
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     auto t0 = now(), t1 = t0, t2 = t0;
@@ -813,7 +830,7 @@ emat_status emat_run_partition_stats(emat_run* r, int32_t* num_parts, int32_t* l
   if (num_parts) *num_parts = r->d.last_num_parts;
   if (largest_part_nodes) *largest_part_nodes = r->d.last_largest_part;
   if (extra_cuts) *extra_cuts = r->d.last_extra_cuts;
-  if (max_part_nodes_in_effect) *max_part_nodes_in_effect = r->d.effective_max_part_nodes(r->d.device_tree ? r->d.tp_parent.size() : r->d.tree.nodes.size());
+  if (max_part_nodes_in_effect) *max_part_nodes_in_effect = r->d.effective_max_part_nodes(r->d.device_tree ? (size_t)r->d.tp_n : r->d.tree.nodes.size());
   return EMAT_OK;
 }
 emat_status emat_run_set_num_parts(emat_run* r, int32_t n) { if (!r || n < 1) return EMAT_ERR_INVALID_ARGUMENT; r->d.num_parts = n; r->d.stencils.clear(); return EMAT_OK; }
@@ -1006,18 +1023,20 @@ emat_status emat_run_do_mcmc_steps(emat_run* r, int64_t steps, int64_t per_cycle
   if (r->d.shard_world > 1) return r->d.fail(EMAT_ERR_STATE, "a sharded run is cycled by its caller, who owns the collectives (see emat_host.h)");
   if (per_cycle <= 0) per_cycle = 50 * (int64_t)r->d.tree.nodes.size();
   int64_t done = 0;
-  const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
+  const bool verbose = verbose_reports();
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   while (done < steps) {
     const auto t0 = now();
+    HostLaps laps;
     emat_status st = r->d.repartition(); if (st) return st;
-    const auto t1 = now();
+    const auto t1 = now(); laps.mark("cycle: 1 repartition");
     int64_t k = std::min(per_cycle, steps - done);
     st = r->d.run_moves(k); if (st) return st;
     if (r->d.paranoid) { st = r->d.bk(emat_check_derived(r->d.backend, 1.0, nullptr, nullptr)); if (st) return st; }
-    const auto t2 = now();
+    const auto t2 = now(); laps.mark("cycle: 2 run_moves (launch)");
     st = r->d.reassemble(); if (st) return st;
+    laps.mark("cycle: 3 reassemble (waits for the moves)");
     done += k;
     if (verbose) fprintf(stderr, "[emat_run] cycle: repartition %.1f ms | launch of the moves %.1f ms | reassemble (waits for the moves) %.1f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, now()));
   }

@@ -488,9 +488,9 @@ inline void spr_refine(Tree& tree, const Tips& tips, HostRng& rng) {   // utree.
       b.hang_subtree(X, best, M, de);
     }
     idle = best_cost - before < 0 ? 0 : idle + 1;
-    if (idle >= N) { if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] spr_refine: stopped after %d attempts (%d without improvement)\n", attempt + 1, idle); break; }
+    if (idle >= N) { if (verbose_reports()) fprintf(stderr, "[emat] spr_refine: stopped after %d attempts (%d without improvement)\n", attempt + 1, idle); break; }
   }
-  if (getenv("EMAT_VERBOSE")) fprintf(stderr, "[emat] spr_refine: %lld searches expanded %lld arcs, the focus crossed %lld arcs\n", b.n_searches, b.n_pops, b.n_crossed);
+  if (verbose_reports()) fprintf(stderr, "[emat] spr_refine: %lld searches expanded %lld arcs, the focus crossed %lld arcs\n", b.n_searches, b.n_pops, b.n_crossed);
   tree = std::move(T);
 }
 
@@ -594,7 +594,7 @@ emat_status build_default_tree(emat_backend* h, const emat_tip_descs& td, uint64
   HostRng rng; rng.key = seed;
   const ut::Tips tips{&td, &h->ref};
   const int N = td.num_tips;
-  const bool verbose = getenv("EMAT_VERBOSE") != nullptr;
+  const bool verbose = verbose_reports();
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(now() - a).count(); };
   try {

@@ -8,6 +8,11 @@
 #include <exception>
 #include <functional>
 #include <mutex>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -92,6 +97,48 @@ template <class F> void parallel_for(int n, F&& f, int grain = 32) {
   const std::function<void(int)> fn = [&f](int i) { f(i); };
   HostPool::instance().run(n, grain, fn);
 }
+
+// The one environment variable the library reads.  EMAT_VERBOSE=<anything> turns the progress reports on stderr on; the value
+// "spans" turns on the host-span accounting below INSTEAD (the reports do extra device reads and sorts, which the spans would book).
+inline bool verbose_reports() { const char* e = getenv("EMAT_VERBOSE"); return e != nullptr && std::strcmp(e, "spans") != 0; }
+inline bool verbose_spans() { const char* e = getenv("EMAT_VERBOSE"); return e != nullptr && std::strcmp(e, "spans") == 0; }
+
+// Where the host's share of a cycle goes (EMAT_VERBOSE=spans): named spans, nested freely, summed per name over the life of the
+// process and printed when a backend handle is destroyed.  Off, a span costs one load and a branch.
+class HostSpans {
+ public:
+  static HostSpans& instance() { static HostSpans s; return s; }
+  const bool on;
+  void add(const char* name, double ms) { std::lock_guard<std::mutex> g(mu_); auto& e = acc_[name]; e.first += ms; e.second += 1; auto& v = all_[name]; v.push_back((float)ms); }
+  void report() {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!on || acc_.empty()) return;
+    fprintf(stderr, "[emat] host spans (EMAT_VERBOSE=spans): total ms | calls | mean us | median us\n");
+    for (const auto& kv : acc_) {
+      std::vector<float>& v = all_[kv.first]; std::sort(v.begin(), v.end());
+      fprintf(stderr, "[emat]   %-58s %10.1f %8lld %10.1f %10.1f\n", kv.first.c_str(), kv.second.first, (long long)kv.second.second, 1e3 * kv.second.first / (double)kv.second.second, 1e3 * v[v.size() / 2]);
+    }
+    acc_.clear(); all_.clear();
+  }
+ private:
+  HostSpans() : on(verbose_spans()) {}
+  std::mutex mu_;
+  std::map<std::string, std::pair<double, long long>> acc_;
+  std::map<std::string, std::vector<float>> all_;
+};
+struct HostSpan {
+  const char* name; std::chrono::steady_clock::time_point t0;
+  explicit HostSpan(const char* n) : name(HostSpans::instance().on ? n : nullptr) { if (name) t0 = std::chrono::steady_clock::now(); }
+  ~HostSpan() { if (name) HostSpans::instance().add(name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+};
+struct HostLaps {   // consecutive stretches of one function: mark("name") books the time since the previous mark
+  std::chrono::steady_clock::time_point last; const bool on;
+  HostLaps() : on(HostSpans::instance().on) { if (on) last = std::chrono::steady_clock::now(); }
+  void mark(const char* name) { if (!on) return; const auto t = std::chrono::steady_clock::now(); HostSpans::instance().add(name, std::chrono::duration<double, std::milli>(t - last).count()); last = t; }
+};
+#define EMAT_SPAN_CAT2(a, b) a##b
+#define EMAT_SPAN_CAT(a, b) EMAT_SPAN_CAT2(a, b)
+#define EMAT_SPAN(name) ::emat::HostSpan EMAT_SPAN_CAT(emat_span_, __LINE__)(name)
 
 }  // namespace emat
 #endif  // EMAT_HOST_PARALLEL_HPP_

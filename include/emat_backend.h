@@ -232,6 +232,11 @@ emat_status emat_tree_upload(emat_backend* h, const emat_flat_tree* tree);
 emat_status emat_tree_get_sizes(emat_backend* h, int32_t* num_nodes, int32_t* num_muts, int32_t* num_intervals, int32_t* num_from_states);
 emat_status emat_tree_download(emat_backend* h, emat_flat_tree* out, uint8_t* ref_sequence /* [num_sites] or NULL */);
 emat_status emat_tree_get_topology(emat_backend* h, int32_t* parent, int32_t* child0, int32_t* child1, double* t, int32_t* root);
+/* What generate_random_partition_stencil and partition_tree (tree_partitioning.h:88-239) read of the tree and nothing more: every
+ * node's two children side by side ((*kids)[2 v], (*kids)[2 v + 1]; EMAT_NO_NODE at the tips), the root and the root's time.
+ * `*kids` points into the backend's own page-locked mirror, which every reassemble refreshes (1.6 MB at 200 000 nodes instead of
+ * the 4 MB of emat_tree_get_topology, and no copy): valid until the next emat_tree_reassemble(_end) or emat_tree_upload. */
+emat_status emat_tree_get_kids(emat_backend* h, const int32_t** kids, int32_t* num_nodes, int32_t* root, double* t_root);
 /* partition_tree (tree_partitioning.h:88-135, 196-239) on the device, for callers that only have the cut nodes of a stencil:
  * one thread per part walks the part down from its cut point and numbers its nodes exactly as the reference's work list does.
  * Part i has cut node cut_nodes[i]; unless the stencil names the run's root, the root part comes last.  The arrays stay on
