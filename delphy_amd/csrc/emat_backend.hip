@@ -929,7 +929,6 @@ struct PartHost {
   int32_t n_nodes = 0;             // (the tree itself may live only on the device: emat_tree_repartition)
   emat_part_stats stats{};
   std::vector<double> trace;       // the part's move trace so far (4 doubles per move), carried over re-materialisations
-  int64_t expected_moves = 0;      // moves requested of this part since its upload
   double space_boost = 1.0;        // multiplier of the heap and scratch capacities; doubled when the part ran out of space
   int cell_boost = 1;              // multiplier of the room the root part's grid gets to grow into; quadrupled when it ran out
 };
@@ -966,6 +965,11 @@ struct GTreeHost {
   // Kept current by every reassemble: the children of every node, packed (pin_kids: n pairs), the root and its time -- what a cycle's
   // partitioner needs.  The arrays above follow only when somebody asks for them (gt_full_mirrors).
   DevBuf<int2> d_kids; PinnedBytes pin_kids; double h_root_t = 0.0; bool full_mirrors_stale = false;
+  bool d_kids_current = false;      // d_kids holds every node's children (k_gt_gather_links only rewrites the inner nodes of the parts it sees)
+  DevBuf<double> d_root_t; PinnedBytes pin_small;   // the root's time; { int32 root, int32 n_root_deltas, double t_root } on their way to the host
+  // emat_tree_reassemble of a single process returns once topology and root are on the host: k_gt_gather may still be running.
+  // Whoever touches the device-resident tree next (gt_require) waits for it and checks how it went (gt_finish_gather).
+  bool gather_pending = false; std::vector<GRootDelta> gather_rd;
   const int32_t* kids() const { return (const int32_t*)pin_kids.data(); }   // [2 v] = child0, [2 v + 1] = child1
   GTreeDev dev() {
     GTreeDev g{};
@@ -996,6 +1000,7 @@ struct emat_backend {
   hipEvent_t ev_fork = nullptr, ev_join[k_max_classes] = {};
   int num_classes = 1; int class_begin[k_max_classes + 1] = {}; uint32_t class_lds[k_max_classes] = {};
   std::vector<int> class_of;        // per part
+  std::vector<int64_t> expected_moves;   // per part: moves requested of it since its upload (apart from the part records: every launch adds to all of them)
   std::vector<int> cfg_class_pct{60};                // EMAT_LDS_CLASSES (tuning knob): percentiles of persistent size that close each class; the last
                                                      // class always extends to the largest part (its staging area is still that percentile's size)
   uint32_t cfg_lds_max = 96 * 1024;                  // EMAT_LDS_MAX (tuning knob): largest staging area; larger parts run out of HBM
@@ -1348,7 +1353,7 @@ emat_status finish_pass(emat_backend* h) {
     for (size_t p = 0; p < n; ++p) if (status[p] != 0) {
       PartHost& ph = h->parts[p];
       if (status[p] == k_part_need_cells) ph.cell_boost *= 4; else ph.space_boost *= 2.0;
-      counts[p] = ph.expected_moves - ph.stats.moves_done;
+      counts[p] = h->expected_moves[p] - ph.stats.moves_done;
       ph.stats.status = 0;
     }
     if (verbose_reports()) fprintf(stderr, "[emat] %zu part(s) ran out of slab space or grid cells: re-materialising with more room and running the rest of their moves\n", stopped);
@@ -1689,7 +1694,7 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
   a.moves_per_part = per_part; a.extra_moves_part0 = extra0; a.one_more_below = one_more_below;
   a.lds_scratch_bytes = lds_scratch; a.snaps = h->d_snaps.p;
   if (counts) { st = join_side_classes(h); if (st) return st; h->sides_must_fork = true; HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(h->d_moves_for_part.upload(counts->data(), counts->size())); a.moves_for_part = h->d_moves_for_part.p; }
-  else for (size_t p = 0; p < h->parts.size(); ++p) h->parts[p].expected_moves += per_part + (p == 0 ? extra0 : 0) + ((int64_t)p < one_more_below ? 1 : 0);
+  else { h->expected_moves.resize(h->parts.size(), 0); for (size_t p = 0; p < h->parts.size(); ++p) h->expected_moves[p] += per_part + (p == 0 ? extra0 : 0) + ((int64_t)p < one_more_below ? 1 : 0); }
   h->pass_pending = true;
   h->last_launch_uniform = counts == nullptr;
   HIP_TRY(hipEventRecord(h->ev_start, h->stream));
@@ -1888,6 +1893,7 @@ emat_status emat_begin_upload(emat_backend* h, int32_t num_parts) {
   h->coal_builder.reset();
   h->fatal_status = EMAT_OK; h->fatal_message.clear(); h->pass_pending = false;
   h->parts.clear(); h->parts.resize(num_parts);
+  h->expected_moves.assign((size_t)num_parts, 0);
   h->uploads_expected = num_parts; h->root_part = -1; h->gt.parts_live = false;
   h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false; h->have_coal = false; h->derived_valid = false;
   return EMAT_OK;
@@ -1904,7 +1910,7 @@ emat_status emat_part_upload(emat_backend* h, int32_t part_id, const emat_flat_t
   ph.tree = FlatTree::from_view(*subtree); ph.n_nodes = subtree->num_nodes;
   ph.includes_run_root = includes_run_root != 0;
   ph.rng.key = seed; ph.rng.counter = 0; ph.rng.spare = 0; ph.rng.has_spare = false;
-  ph.uploaded = true; ph.stats = emat_part_stats{}; ph.expected_moves = 0; ph.space_boost = 1.0; ph.cell_boost = 1; ph.trace.clear();
+  ph.uploaded = true; ph.stats = emat_part_stats{}; ph.space_boost = 1.0; ph.cell_boost = 1; ph.trace.clear();
   if (ph.includes_run_root) h->root_part = part_id;
   return EMAT_OK;
 }

@@ -21,10 +21,12 @@ const char* gt_status_text(int32_t s) {
   }
 }
 
-emat_status gt_require(emat_backend* h, bool need_resident) {
+emat_status gt_finish_gather(emat_backend* h);
+emat_status gt_require(emat_backend* h, bool need_resident, bool gather_may_run = false) {
   if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
   if (need_resident && !h->gt.resident) return fail(h, EMAT_ERR_STATE, "emat_tree_upload first");
+  if (h->gt.gather_pending && !gather_may_run) return gt_finish_gather(h);
   return EMAT_OK;
 }
 
@@ -41,7 +43,7 @@ emat_status gt_fetch_mirrors(emat_backend* h) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(&G.h_root, G.root.p, 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(&G.h_root_t, G.t.p + G.h_root, 8, hipMemcpyDeviceToHost));
-  G.full_mirrors_stale = true;
+  G.full_mirrors_stale = true; G.d_kids_current = true;
   return EMAT_OK;
 }
 emat_status gt_full_mirrors(emat_backend* h) {
@@ -102,7 +104,7 @@ emat_status emat_tree_upload(emat_backend* h, const emat_flat_tree* tree) {
   { int32_t z = 0; HIP_TRY(G.status.upload(&z, 1)); }
   G.h_parent.assign(tree->parent, tree->parent + n); G.h_c0.assign(tree->child0, tree->child0 + n); G.h_c1.assign(tree->child1, tree->child1 + n);
   G.h_t.assign(tree->t, tree->t + n); G.h_t_min.assign(tree->t_min, tree->t_min + n); G.h_t_max.assign(tree->t_max, tree->t_max + n);
-  G.h_root = tree->root; G.h_root_t = tree->t[tree->root]; G.full_mirrors_stale = false;
+  G.h_root = tree->root; G.h_root_t = tree->t[tree->root]; G.full_mirrors_stale = false; G.d_kids_current = false; G.gather_pending = false;
   HIP_TRY(G.pin_kids.resize((size_t)n * sizeof(int2)));
   { int32_t* k = (int32_t*)G.pin_kids.data(); for (int v = 0; v < n; ++v) { k[2 * v] = tree->child0[v]; k[2 * v + 1] = tree->child1[v]; } }
   G.resident = true; G.parts_live = false;
@@ -174,7 +176,7 @@ emat_status emat_tree_get_topology(emat_backend* h, int32_t* parent, int32_t* ch
 
 emat_status emat_tree_get_kids(emat_backend* h, const int32_t** kids, int32_t* num_nodes, int32_t* root, double* t_root) {
   if (!h || !kids) return EMAT_ERR_INVALID_ARGUMENT;
-  emat_status st = gt_require(h, true); if (st) return st;
+  emat_status st = gt_require(h, true, true); if (st) return st;   // (the mirror is current as soon as emat_tree_reassemble returns; the lists may still be on their way)
   const GTreeHost& G = h->gt;
   if (G.parts_live) return fail(h, EMAT_ERR_STATE, "the parts are out on their slabs: emat_tree_reassemble first");
   *kids = G.kids();
@@ -395,6 +397,7 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
   h->fatal_status = EMAT_OK; h->fatal_message.clear(); h->pass_pending = false;
   if (!device_coal) h->parts.clear();   // (with the tables built on the device the records hold no vectors worth freeing and re-allocating 8 000 times per cycle)
   h->parts.resize(nloc);
+  h->expected_moves.assign((size_t)nloc, 0);
   h->uploads_expected = 0; h->root_part = (root_part >= lo && root_part < hi) ? root_part - lo : -1;
   h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false; h->have_coal = false; h->derived_valid = false;
   auto init_record = [&](int q) {
@@ -415,7 +418,7 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
     }
     ph.includes_run_root = p == root_part; ph.n_nodes = np;
     ph.rng.key = seeds[p]; ph.rng.counter = 0; ph.rng.spare = 0; ph.rng.has_spare = false;
-    ph.uploaded = true; ph.stats = emat_part_stats{}; ph.expected_moves = 0; ph.space_boost = 1.0; ph.cell_boost = 1; ph.trace.clear();
+    ph.uploaded = true; ph.stats = emat_part_stats{}; ph.space_boost = 1.0; ph.cell_boost = 1; ph.trace.clear();
   };
   if (!device_coal) parallel_for(nloc, init_record, 64);
   const auto t2 = now(); laps.mark("tree_repartition: 03 part records (host coalescent only)");
@@ -491,8 +494,18 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
     HIP_TRY(G.co_k_bar.alloc(co.num_cells)); HIP_TRY(G.co_k_tw.alloc(co.num_cells)); HIP_TRY(G.co_popsize.alloc(co.num_cells)); HIP_TRY(G.co_num_active.alloc(co.num_cells)); HIP_TRY(G.co_tsop.alloc(co.num_cells));
     co.kbar_pool = G.co_kbar.p; co.ktw_pool = G.co_ktw.p; co.k_bar = G.co_k_bar.p; co.k_tw = G.co_k_tw.p; co.popsize = G.co_popsize.p; co.num_active = G.co_num_active.p; co.ts_over_pop = G.co_tsop.p;
     co.status = G.status.p;
+    // the grid's four kernels need nothing but the cell ranges: they run while the host places the slabs (the descriptors travel
+    // twice -- with the cell ranges now, complete before k_gt_build)
+    HIP_TRY(G.desc.upload(desc.data(), (size_t)P));
+    HIP_TRY(hipMemsetAsync(G.status.p, 0, sizeof(int32_t), h->stream));
+    const unsigned cell_blocks = (unsigned)co.num_cells;
+    hipLaunchKernelGGL(k_gt_coal_kbar, dim3((unsigned)P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), (const GPartDesc*)G.desc.p, co);
+    hipLaunchKernelGGL(k_gt_coal_grid, dim3(cell_blocks), dim3(k_wave), 0, h->stream, P, (const GPartDesc*)G.desc.p, co, (const PopTable*)h->d_pop.p);
+    hipLaunchKernelGGL(k_gt_coal_draw, dim3((unsigned)P), dim3(k_wave), 0, h->stream, (const GPartDesc*)G.desc.p, co);
+    hipLaunchKernelGGL(k_gt_coal_ktw, dim3(cell_blocks), dim3(k_wave), 0, h->stream, P, (const GPartDesc*)G.desc.p, co);
+    HIP_TRY(hipGetLastError());
   }
-  laps.mark("tree_repartition: 07 cell ranges + pool allocations");
+  laps.mark("tree_repartition: 07 cell ranges + pool allocations + coalescent launches");
   // where every slab goes: from the measures alone (a fresh record is the root part or not, and has no boosts)
   std::vector<SlabGeo> geo((size_t)nloc);
   if (h->used_bytes.size() < (size_t)nloc) h->used_bytes.resize((size_t)nloc, 0u);
@@ -550,19 +563,10 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
   HIP_TRY(h->d_part_ticks.alloc((2 + 2 * k_ticket_log) * (size_t)nloc)); HIP_TRY(hipMemsetAsync(h->d_part_ticks.p, 0, (2 + 2 * k_ticket_log) * (size_t)nloc * sizeof(int64_t), h->stream));
   HIP_TRY(h->d_part_status.alloc((size_t)nloc)); HIP_TRY(hipMemsetAsync(h->d_part_status.p, 0, (size_t)nloc * sizeof(int32_t), h->stream));
   laps.mark("tree_repartition: 11 slab allocation + memsets");
-  if (device_coal) {
-    HIP_TRY(hipMemsetAsync(G.status.p, 0, sizeof(int32_t), h->stream));
-    const unsigned cell_blocks = (unsigned)co.num_cells;
-    hipLaunchKernelGGL(k_gt_coal_kbar, dim3((unsigned)P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), (const GPartDesc*)G.desc.p, co);
-    hipLaunchKernelGGL(k_gt_coal_grid, dim3(cell_blocks), dim3(k_wave), 0, h->stream, P, (const GPartDesc*)G.desc.p, co, (const PopTable*)h->d_pop.p);
-    hipLaunchKernelGGL(k_gt_coal_draw, dim3((unsigned)P), dim3(k_wave), 0, h->stream, (const GPartDesc*)G.desc.p, co);
-    hipLaunchKernelGGL(k_gt_coal_ktw, dim3(cell_blocks), dim3(k_wave), 0, h->stream, P, (const GPartDesc*)G.desc.p, co);
-    HIP_TRY(hipGetLastError());
-  }
   hipLaunchKernelGGL(k_gt_build, dim3((unsigned)nloc), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const GMeasure*)G.measure.p, (const GPartDesc*)G.desc.p,
                      (const uint8_t*)G.cells.p, co, h->d_slabs.p, (const uint64_t*)h->d_slab_off.p, lo);
   HIP_TRY(hipGetLastError());
-  laps.mark("tree_repartition: 12 launches (coalescent x4, k_gt_build)");
+  laps.mark("tree_repartition: 12 launch of k_gt_build");
   // the launch order of the pass to come, while the device builds the slabs (nothing in flight reads it: the side launches of the
   // last pass were joined above, and the copy is queued behind the kernels)
   st = build_order(h, true); if (st) return st;
@@ -629,21 +633,25 @@ emat_status gt_root_deltas(emat_backend* h, std::vector<GRootDelta>& rd, bool& o
 }
 
 // every local part writes the nodes it owns into this process's copy of the tree; the heaps are rebuilt from zero
-emat_status gt_gather_local(emat_backend* h, const std::vector<GRootDelta>& rd) {
+// (in two halves: the launch, and the wait + check, which a single process postpones until somebody needs the tree: gt_finish_gather)
+emat_status gt_launch_gather(emat_backend* h) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   GTreeHost& G = h->gt;
-  const int nloc = G.hi - G.lo;
-  const size_t room = std::max<size_t>(rd.size(), (size_t)k_gt_max_root_deltas);
-  HIP_TRY(G.root_deltas.alloc(room)); HIP_TRY(G.n_root_deltas.alloc(1)); HIP_TRY(G.root_deltas_in.alloc(room));
-  if (!rd.empty()) HIP_TRY(hipMemcpy(G.root_deltas_in.p, rd.data(), rd.size() * sizeof(GRootDelta), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemsetAsync(G.tops.p, 0, 3 * sizeof(uint32_t), h->stream));
+  HIP_TRY(hipMemsetAsync(G.status.p, 0, sizeof(int32_t), h->stream));
+  HIP_TRY(hipMemsetAsync(G.n_root_deltas.p, 0, sizeof(int32_t), h->stream));
+  hipLaunchKernelGGL(k_gt_gather, dim3((unsigned)(G.hi - G.lo)), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), (const uint8_t*)h->d_slabs.p, (const uint64_t*)h->d_slab_off.p,
+                     h->d_ref.p, G.root_deltas.p, G.n_root_deltas.p, G.status.p, G.lo, (const GRootDelta*)G.root_deltas_in.p, (int)G.gather_rd.size());
+  HIP_TRY(hipGetLastError());
+  return EMAT_OK;
+}
+emat_status gt_finish_gather(emat_backend* h) {
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  GTreeHost& G = h->gt;
+  if (!G.gather_pending) return EMAT_OK;
+  G.gather_pending = false;
   int32_t status = 0;
   for (int attempt = 0;; ++attempt) {
-    HIP_TRY(hipMemsetAsync(G.tops.p, 0, 3 * sizeof(uint32_t), h->stream));
-    HIP_TRY(hipMemsetAsync(G.status.p, 0, sizeof(int32_t), h->stream));
-    HIP_TRY(hipMemsetAsync(G.n_root_deltas.p, 0, sizeof(int32_t), h->stream));
-    hipLaunchKernelGGL(k_gt_gather, dim3((unsigned)nloc), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), (const uint8_t*)h->d_slabs.p, (const uint64_t*)h->d_slab_off.p,
-                       h->d_ref.p, G.root_deltas.p, G.n_root_deltas.p, G.status.p, G.lo, (const GRootDelta*)G.root_deltas_in.p, (int)rd.size());
-    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(&status, G.status.p, sizeof(status), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(G.used, G.tops.p, sizeof(G.used), hipMemcpyDeviceToHost));
@@ -652,13 +660,25 @@ emat_status gt_gather_local(emat_backend* h, const std::vector<GRootDelta>& rd) 
     // the atomics kept counting: G.used is what the heaps need (nothing of the old content is read by the gather)
     HIP_TRY(G.mut_heap.alloc((size_t)G.used[0] * 2 + 1024)); HIP_TRY(G.iv_heap.alloc((size_t)G.used[1] * 2 + 1024)); HIP_TRY(G.fs_heap.alloc((size_t)G.used[2] * 2 + 1024));
     ++G.heap_regrows;
+    emat_status st = gt_launch_gather(h); if (st) return st;
   }
-  if (!rd.empty()) {   // the reference sequence moved with the root sequence: its derived tables follow
-    for (const GRootDelta& d : rd) h->ref[d.site] = d.to;
+  if (!G.gather_rd.empty()) {   // the reference sequence moved with the root sequence: its derived tables follow
+    for (const GRootDelta& d : G.gather_rd) h->ref[d.site] = d.to;
     HIP_TRY(hipMemcpy(h->d_ref.p, h->ref.data(), h->ref.size(), hipMemcpyHostToDevice));
     refresh_ref_derived(h);
   }
   return EMAT_OK;
+}
+emat_status gt_gather_local(emat_backend* h, const std::vector<GRootDelta>& rd, bool wait = true) {
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  GTreeHost& G = h->gt;
+  const size_t room = std::max<size_t>(rd.size(), (size_t)k_gt_max_root_deltas);
+  HIP_TRY(G.root_deltas.alloc(room)); HIP_TRY(G.n_root_deltas.alloc(1)); HIP_TRY(G.root_deltas_in.alloc(room));
+  if (!rd.empty()) HIP_TRY(hipMemcpy(G.root_deltas_in.p, rd.data(), rd.size() * sizeof(GRootDelta), hipMemcpyHostToDevice));
+  G.gather_rd = rd;
+  emat_status st = gt_launch_gather(h); if (st) return st;
+  G.gather_pending = true;
+  return wait || !rd.empty() ? gt_finish_gather(h) : EMAT_OK;   // (a changed root sequence changes the host's tables too: not worth postponing)
 }
 
 emat_status gt_reassemble_end(emat_backend* h) {
@@ -690,13 +710,36 @@ emat_status emat_tree_reassemble(emat_backend* h, int32_t* num_root_deltas, int3
   HostLaps laps;
   st = gt_reassemble_begin(h); if (st) return st;
   const auto t1 = now(); laps.mark("tree_reassemble: 1 finish_pass (waits for the moves)");
-  std::vector<GRootDelta> rd; bool owner = false;
-  st = gt_root_deltas(h, rd, owner); if (st) return st;
-  laps.mark("tree_reassemble: 2 root deltas");
-  st = gt_gather_local(h, rd); if (st) return st;
-  const auto t2 = now(); laps.mark("tree_reassemble: 3 k_gt_gather");
-  st = gt_reassemble_end(h); if (st) return st;
-  laps.mark("tree_reassemble: 4 topology mirrors D2H");
+  // One process holds every part.  What the host needs to draw the next partition -- the links, the root, the changes of the root
+  // sequence -- is written and fetched first (three small kernels, one wait); the gather of every list follows and is NOT waited
+  // for: it runs while the caller picks and refines its next stencil, and whoever touches the tree next finishes it (gt_require).
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  std::vector<GRootDelta> rd;
+  {
+    const size_t n = (size_t)G.n;
+    HIP_TRY(G.root_deltas.alloc(k_gt_max_root_deltas)); HIP_TRY(G.n_root_deltas.alloc(1));
+    HIP_TRY(G.d_kids.alloc(n)); HIP_TRY(G.pin_kids.resize(n * sizeof(int2))); HIP_TRY(G.d_root_t.alloc(1)); HIP_TRY(G.pin_small.resize(16));
+    HIP_TRY(hipMemsetAsync(G.n_root_deltas.p, 0, sizeof(int32_t), h->stream));
+    hipLaunchKernelGGL(k_gt_root_deltas, dim3(1), dim3(k_wave), 0, h->stream, (const uint8_t*)h->d_slabs.p, (const uint64_t*)h->d_slab_off.p, G.root_part - G.lo, G.root_deltas.p, (int)G.root_deltas.n, G.n_root_deltas.p);
+    hipLaunchKernelGGL(k_gt_gather_links, dim3((unsigned)(G.hi - G.lo)), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), (const uint8_t*)h->d_slabs.p, (const uint64_t*)h->d_slab_off.p, G.lo, G.d_kids.p, G.d_root_t.p);
+    if (!G.d_kids_current) hipLaunchKernelGGL(k_gt_pack_kids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, G.dev(), G.d_kids.p);   // (the first time: the tips' entries)
+    HIP_TRY(hipGetLastError());
+    uint8_t* small = G.pin_small.data();
+    HIP_TRY(hipMemcpyAsync(G.pin_kids.data(), G.d_kids.p, n * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(small, G.root.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(small + 4, G.n_root_deltas.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(small + 8, G.d_root_t.p, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int32_t nd = 0;
+    std::memcpy(&G.h_root, small, 4); std::memcpy(&nd, small + 4, 4); std::memcpy(&G.h_root_t, small + 8, 8);
+    G.d_kids_current = true; G.full_mirrors_stale = true;
+    if ((size_t)nd > G.root_deltas.n) { bool owner = false; st = gt_root_deltas(h, rd, owner); if (st) return st; }   // (more changes than there was room for: read again, with the room)
+    else { rd.resize((size_t)nd); if (nd > 0) HIP_TRY(hipMemcpy(rd.data(), G.root_deltas.p, (size_t)nd * sizeof(GRootDelta), hipMemcpyDeviceToHost)); }
+  }
+  laps.mark("tree_reassemble: 2 root deltas, links, children mirror");
+  st = gt_gather_local(h, rd, false); if (st) return st;
+  const auto t2 = now(); laps.mark("tree_reassemble: 3 launch of k_gt_gather");
+  G.parts_live = false;
   const int nd = (int)rd.size();
   if (verbose) fprintf(stderr, "[emat] tree_reassemble: wait for the moves + status check %.1f ms | root changes (%d) + k_gt_gather + reference tables %.1f ms | topology + times D2H %.1f ms\n",
                        ms(t0, t1), nd, ms(t1, t2), ms(t2, now()));

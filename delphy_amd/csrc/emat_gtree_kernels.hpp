@@ -558,6 +558,30 @@ __global__ void __launch_bounds__(k_wave) k_gt_gather(GTreeDev g, GPartition pt,
   }
 }
 
+// The links alone -- children, parents, the root, and the packed children the host's partitioner reads -- ahead of k_gt_gather,
+// which rewrites every list of the tree and takes ten times as long: the host draws the next partition from these while the
+// lists are still on their way.  (k_gt_gather writes the same links again.)
+__global__ void __launch_bounds__(k_wave) k_gt_gather_links(GTreeDev g, GPartition pt, const uint8_t* slabs, const uint64_t* slab_off, int part_base, int2* kids, double* root_t_out) {
+  const int q = blockIdx.x, p = part_base + q, lane = threadIdx.x;
+  const int base = pt.part_off[p], n = pt.part_off[p + 1] - base;
+  const uint8_t* slab = slabs + slab_off[q];
+  const SlabHeader* H = (const SlabHeader*)slab;
+  if (H->n_nodes != n) return;   // (k_gt_gather reports it)
+  const NodeRec* N = (const NodeRec*)(slab + H->off_nodes);
+  for (int s = lane; s < n; s += k_wave) {
+    const NodeRec& r = N[s];
+    if (r.child0 == EMAT_NO_NODE) continue;
+    const int32_t o = pt.orig[base + s], l = pt.orig[base + r.child0], rr = pt.orig[base + r.child1];
+    g.c0[o] = l; g.c1[o] = rr; g.parent[l] = o; g.parent[rr] = o;
+    kids[o] = make_int2(l, rr);
+  }
+  if (p == pt.root_part && lane == 0) {
+    const int32_t nr = pt.orig[base + H->root];
+    g.root[0] = nr; g.parent[nr] = EMAT_NO_NODE;
+    root_t_out[0] = N[H->root].t;
+  }
+}
+
 // ---- one run over several processes, every one with the whole tree in its HBM: after gathering its own parts a process
 //      hands the nodes it owns to the others (compact per-node arrays + its three heap segments) and takes theirs -------------
 // Writes as many of the changes as `out` holds (`cap`) and reports how many there are: the caller comes again with more room.

@@ -215,9 +215,14 @@ struct RunDriver {
     last_extra_cuts = 0;
     if (eff <= 0) return cuts;
     const int limit = std::max(eff, 21);
-    std::vector<char> is_cut(N, 0);
-    for (int32_t c : cuts) is_cut[c] = 1;
-    is_cut[tp_root] = 1;
+    // cut marks as a bit set (25 KB at 200 000 nodes: resident in every core's cache, where a byte per node costs a second miss per
+    // visited node); tasks set bits of their own parts only, but share words: atomic OR, relaxed loads
+    std::vector<std::atomic<uint32_t>> cut_bits(((size_t)N + 31) / 32);
+    for (auto& w : cut_bits) w.store(0, std::memory_order_relaxed);
+    auto mark_cut = [&](int32_t v) { cut_bits[(size_t)v >> 5].fetch_or(1u << (v & 31), std::memory_order_relaxed); };
+    auto is_cut = [&](int32_t v) { return (cut_bits[(size_t)v >> 5].load(std::memory_order_relaxed) >> (v & 31)) & 1u; };
+    for (int32_t c : cuts) mark_cut(c);
+    mark_cut(tp_root);
     std::vector<int32_t> roots(cuts);
     if (std::find(roots.begin(), roots.end(), tp_root) == roots.end()) roots.push_back(tp_root);
     // Every part of the stencil on its own (host threads): walk it from its cut node, and if it is oversized cut it, then its
@@ -237,11 +242,10 @@ struct RunDriver {
         while (!stack.empty()) {
           const int32_t v = stack.back(); stack.pop_back(); ++size;
           const Kids k = kids[v];   // (both children in one cache line: the walk is bound by misses on a 200 000-node tree)
-          if (k.c0 == EMAT_NO_NODE || (is_cut[v] && v != c)) continue;
+          if (k.c0 == EMAT_NO_NODE || (v != c && is_cut(v))) continue;
           if (v != c) inner.push_back(v);
           stack.push_back(k.c0); stack.push_back(k.c1);
-          __builtin_prefetch(&kids[k.c0]); __builtin_prefetch(&is_cut[(size_t)k.c0]);   // (c1 is visited next, c0 after c1's whole subtree: its lines are on their way by then)
-          __builtin_prefetch(&kids[k.c1]); __builtin_prefetch(&is_cut[(size_t)k.c1]);
+          __builtin_prefetch(&kids[k.c0]); __builtin_prefetch(&kids[k.c1]);   // (c1 is visited next, c0 after c1's whole subtree: its line is on its way by then)
         }
         if (first && size <= limit) return;   // the common case: one walk, nothing to do
         first = false;
@@ -249,10 +253,10 @@ struct RunDriver {
         // as many new cut nodes as would make the pieces `limit` nodes on average, a uniformly drawn subset of the inner nodes
         const int want = std::min((int)inner.size(), std::max(1, (size + limit - 1) / limit - 1));
         for (int k = 0; k < want; ++k) { const int j = k + rng.below((int)inner.size() - k); std::swap(inner[(size_t)k], inner[(size_t)j]); }
-        for (int k = 0; k < want; ++k) { is_cut[inner[(size_t)k]] = 1; extra[(size_t)ri].push_back(inner[(size_t)k]); work.push_back(inner[(size_t)k]); }
+        for (int k = 0; k < want; ++k) { mark_cut(inner[(size_t)k]); extra[(size_t)ri].push_back(inner[(size_t)k]); work.push_back(inner[(size_t)k]); }
         work.push_back(c);   // what is left above the new cut nodes may still be too large
       }
-    }, 16);
+    }, 16, 32);
     for (auto& e : extra) { cuts.insert(cuts.end(), e.begin(), e.end()); last_extra_cuts += (int)e.size(); }
     return cuts;
   }

@@ -33,8 +33,11 @@ class HostPool {
  public:
   static HostPool& instance() { static HostPool p; return p; }
   // Calls f(i) for i in [0, n) in chunks of `grain` dealt dynamically to the threads; rethrows the first exception.
-  void run(int n, int grain, const std::function<void(int)>& f) {
-    const int want = std::min(host_threads(), std::max(1, n / std::max(1, grain)));
+  // (`more_threads` > 0: a loop bound by cache misses rather than by allocation may use up to that many threads, if the machine has them)
+  void run(int n, int grain, const std::function<void(int)>& f, int more_threads = 0) {
+    int cap = host_threads();
+    if (more_threads > cap && host_threads_override() <= 0) cap = std::min(more_threads, (int)std::max(1u, std::thread::hardware_concurrency()));
+    const int want = std::min(cap, std::max(1, n / std::max(1, grain)));
     if (want <= 1 || in_worker()) { for (int i = 0; i < n; ++i) f(i); return; }
     std::lock_guard<std::mutex> submit(submit_mu_);
     ensure_workers(want - 1);
@@ -92,10 +95,10 @@ class HostPool {
   std::exception_ptr err_;
 };
 
-template <class F> void parallel_for(int n, F&& f, int grain = 32) {
+template <class F> void parallel_for(int n, F&& f, int grain = 32, int more_threads = 0) {
   if (n <= 0) return;
   const std::function<void(int)> fn = [&f](int i) { f(i); };
-  HostPool::instance().run(n, grain, fn);
+  HostPool::instance().run(n, grain, fn, more_threads);
 }
 
 // The one environment variable the library reads.  EMAT_VERBOSE=<anything> turns the progress reports on stderr on; the value
