@@ -221,22 +221,33 @@ EMAT_D void fail_at(Ctx& c, int status, int line) {
 #ifndef EMAT_INLINE_TRANSC   // bit mask: 1 log, 2 exp, 4 log1p, 8 expm1 inlined at their call sites instead of behind a call
 #define EMAT_INLINE_TRANSC 0
 #endif
-#if EMAT_INLINE_TRANSC & 1
+#ifdef EMAT_X_FLOAT_TRANSC   // (experiment: what the chain would gain if the four cost a third -- single precision; parity is gone)
+EMAT_DN double m_log(double x) { return (double)::logf((float)x); }
+EMAT_DN double m_exp(double x) { return (double)::expf((float)x); }
+EMAT_DN double m_log1p(double x) { return (double)::log1pf((float)x); }
+EMAT_DN double m_expm1(double x) { return (double)::expm1f((float)x); }
+#define EMAT_TRANSC_DEFINED
+#endif
+#ifdef EMAT_TRANSC_DEFINED
+#elif EMAT_INLINE_TRANSC & 1
 EMAT_DF double m_log(double x) { return ::log(x); }
 #else
 EMAT_DN double m_log(double x) { return ::log(x); }
 #endif
-#if EMAT_INLINE_TRANSC & 2
+#ifdef EMAT_TRANSC_DEFINED
+#elif EMAT_INLINE_TRANSC & 2
 EMAT_DF double m_exp(double x) { return ::exp(x); }
 #else
 EMAT_DN double m_exp(double x) { return ::exp(x); }
 #endif
-#if EMAT_INLINE_TRANSC & 4
+#ifdef EMAT_TRANSC_DEFINED
+#elif EMAT_INLINE_TRANSC & 4
 EMAT_DF double m_log1p(double x) { return ::log1p(x); }
 #else
 EMAT_DN double m_log1p(double x) { return ::log1p(x); }
 #endif
-#if EMAT_INLINE_TRANSC & 8
+#ifdef EMAT_TRANSC_DEFINED
+#elif EMAT_INLINE_TRANSC & 8
 EMAT_DF double m_expm1(double x) { return ::expm1(x); }
 #else
 EMAT_DN double m_expm1(double x) { return ::expm1(x); }
@@ -849,6 +860,8 @@ EMAT_D Cells cells_of(Ctx& c) {
 }
 // (A fast path through the reciprocal of t_step, falling back to the division near cell boundaries, was measured in round 4: 6 %
 // SLOWER on inner-node displacements -- the division is a dozen straight-line instructions, the shortcut a branch.)
+// (A product with 1 / t_step here and in the two functions below -- guarded so that it floors like the quotient -- takes 60 vector
+// instructions out of a displacement move and was measured at 464.0 against 464.5 M moves/s: the division stays, as the reference has it.)
 EMAT_D int cell_for(const Ctx& c, double t) { return (int)floor((hdr_of(c)->t_ref - t) / hdr_of(c)->t_step); }
 EMAT_D double cell_ubound(const Ctx& c, int cell) { return hdr_of(c)->t_ref - hdr_of(c)->t_step * cell; }
 EMAT_D double cell_lbound(const Ctx& c, int cell) { return cell_ubound(c, cell) - hdr_of(c)->t_step; }
