@@ -308,6 +308,7 @@ def load_library():
         "emat_run_set_device_tree": [R, i32], "emat_run_moves_even": [B, i64, i32], "emat_debug_tree_counters": [B, P(i32)],
         "emat_tree_upload": [B, P(_FlatTreeC)], "emat_tree_get_sizes": [B, P(i32), P(i32), P(i32), P(i32)], "emat_tree_download": [B, P(_FlatTreeC), P(C.c_uint8)],
         "emat_tree_get_topology": [B, P(i32), P(i32), P(i32), P(dbl), P(i32)],
+        "emat_tree_get_kids": [B, P(P(i32)), P(i32), P(i32), P(dbl)],
         "emat_tree_repartition": [B, i32, P(i32), P(i32), P(i32), P(i32), i32, P(u64), P(_PopModelC), dbl],
         "emat_tree_reassemble": [B, P(i32), P(i32), P(C.c_uint8), P(C.c_uint8), i32],
         "emat_tree_partition": [B, i32, P(i32), P(i32), P(i32), P(i32)], "emat_tree_get_partition": [B, P(i32), P(i32), P(i32), P(i32)],
@@ -559,6 +560,15 @@ class EmatBackend:
         t = np.zeros(n.value); root = C.c_int32()
         self._ck(self._lib.emat_tree_get_topology(self._h, _ptr(parent, C.c_int32), _ptr(c0, C.c_int32), _ptr(c1, C.c_int32), _ptr(t, C.c_double), C.byref(root)), "emat_tree_get_topology")
         return parent, c0, c1, t, int(root.value)
+
+    def tree_kids(self):
+        """(child0, child1) of every node, the root and the root's time, from the backend's own mirror (emat_tree_get_kids): current as
+        soon as emat_tree_reassemble has returned, while the lists of the tree may still be on their way.  A copy: the mirror itself
+        is only valid until the next reassemble."""
+        kp = C.POINTER(C.c_int32)(); n = C.c_int32(); root = C.c_int32(); t_root = C.c_double()
+        self._ck(self._lib.emat_tree_get_kids(self._h, C.byref(kp), C.byref(n), C.byref(root), C.byref(t_root)), "emat_tree_get_kids")
+        kids = np.ctypeslib.as_array(kp, shape=(n.value, 2)).copy()
+        return kids, int(root.value), float(t_root.value)
 
     def tree_repartition(self, part_offset, orig, kid0, kid1, root_part: int, seeds, pop: PopModel, t_step: float):
         po, og, k0, k1 = (np.ascontiguousarray(a, np.int32) for a in (part_offset, orig, kid0, kid1))

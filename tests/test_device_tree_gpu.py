@@ -599,3 +599,30 @@ def test_gather_rereferences_missing_data_for_any_number_of_root_changes(num_cha
     b.close()
 
 
+
+
+def test_children_mirror_is_current_when_reassemble_returns():
+    """emat_tree_get_kids: the children of every node, the root and its time as the backend mirrors them -- after the upload, and
+    after whole cycles of the run driver, where emat_tree_reassemble hands the links over before the gather of the lists has
+    finished (k_gt_gather_links; gt_finish_gather): they must equal what emat_tree_get_topology and emat_tree_download report
+    once the gather is through, and asking for them must not disturb the tree that is still being written."""
+    sc = make_scenario("C3", num_tips=3000, num_sites=29903, uncertain_tips=0.1)
+    b = d.EmatBackend(sc.num_sites)
+    run = d.EmatRun(b, sc.tree, sc.ref, 23)
+    run.set_num_parts(128); run.set_hky(sc.mu, sc.kappa, sc.pi); run.set_pop_model(sc.pop); run.set_device_tree(True)
+    run.repartition(); run.reassemble()
+    kids, root, t_root = b.tree_kids()
+    assert np.array_equal(kids[:, 0], sc.tree.child0) and np.array_equal(kids[:, 1], sc.tree.child1) and root == sc.tree.root and t_root == sc.tree.t[root]
+    changed = False
+    for cycle in range(4):
+        run.repartition(); run.run_moves(128 * 500 + 3); run.reassemble()
+        kids, root, t_root = b.tree_kids()                     # (the lists may still be on their way)
+        parent, c0, c1, t, root2 = b.tree_topology()           # (waits for them)
+        assert root == root2 and t_root == t[root] and np.array_equal(kids[:, 0], c0) and np.array_equal(kids[:, 1], c1), cycle
+        inner = np.flatnonzero(c0 >= 0)
+        assert np.array_equal(parent[c0[inner]], inner) and np.array_equal(parent[c1[inner]], inner) and parent[root] == -1
+        tree, _ = b.tree_download()
+        assert np.array_equal(tree.child0, c0) and np.array_equal(tree.child1, c1) and np.array_equal(tree.t, t)
+        changed = changed or not np.array_equal(c0, sc.tree.child0)
+    assert changed                                                 # the cycles did re-hang subtrees
+    run.close(); b.close()
