@@ -103,7 +103,8 @@ emat_status emat_backend_create(const emat_config* cfg, emat_backend** out);
 emat_status emat_backend_destroy(emat_backend* h);
 /* Tuning and test options of one handle, by name, set after emat_backend_create and before the first launch (defaults are what
  * bench.py measures; an unknown name is refused).  The library reads NO tuning from the environment (only EMAT_VERBOSE, which
- * makes it narrate on stderr): an embedding process decides per handle.  The Python mirror forwards EMAT_<NAME> variables for
+ * makes it narrate on stderr -- or, with the value "spans", account for the host's time per named stretch of a cycle and print the
+ * table when a handle is destroyed): an embedding process decides per handle.  The Python mirror forwards EMAT_<NAME> variables for
  * A/B scripts.
  *   "lds_classes"   percentile of part sizes the staging area must hold whole, default "60"; a comma list makes size classes
  *   "lds_max"       largest staging area in bytes (default 98304);  "lds_scratch"  extra LDS scratch arena per part (default 0)
@@ -223,7 +224,10 @@ emat_status emat_synchronize(emat_backend* h);
  *                               from topology + times.
  *   emat_tree_reassemble        run.cpp:195-256 + normalize_root: every part writes the nodes it owns back, the record
  *                               heaps are rebuilt, the changes of the root sequence are folded into the reference
- *                               sequence on the device (and reported, so that the caller's copy can follow)
+ *                               sequence on the device (and reported, so that the caller's copy can follow).  It returns
+ *                               when links, root and root changes are on the host (emat_tree_get_kids); the gather of the
+ *                               lists may still be running, and the next emat_tree_* call that needs them waits for it
+ *                               (that is also where a failure of the gather is reported)
  *   emat_tree_download          the whole tree (and its reference sequence) back as a flat tree
  *
  * Between emat_tree_repartition and emat_tree_reassemble the backend holds ordinary parts: every run / getter /
