@@ -3,7 +3,7 @@ posterior alone?  Device arms only, so that the runs can be long: the same tree,
 under the reference's partition rule exactly (limit 0) and one arm per limit given (the driver's default, and a much tighter one that adds several times
 as many cut nodes -- whatever the rule did to the posterior, that arm would show it first).  Summaries, effective sample sizes and pooled z as in
 tests/posterior_scale.py.  Usage (GPU box):
-    python tests/posterior_limit.py [tips=5000] [parts=200] [cycles=8400] [burn_in=400] [seeds=4] [limits=-1,48]   -> gpurun_out/posterior_limit.json + a table"""
+    python tests/posterior_limit.py [tips=5000] [parts=200] [cycles=8400] [burn_in=400] [seeds=4] [limits=-1,48] [seed_base=9001]   -> gpurun_out/posterior_limit.json + a table"""
 import json
 import os
 import subprocess
@@ -18,13 +18,14 @@ if __name__ == "__main__":
     a = sys.argv[1:]
     tips, parts, cycles, burn, seeds = (int(a[i]) if len(a) > i else v for i, v in enumerate((5000, 200, 8400, 400, 4)))
     limits = [int(x) for x in (a[5] if len(a) > 5 else "-1,48").split(",")]
+    seed_base = int(a[6]) if len(a) > 6 else 9001      # (another base = an independent replication)
     out_dir = os.path.join(ROOT, "gpurun_out", "posterior_limit"); os.makedirs(out_dir, exist_ok=True)
     me = os.path.join(ROOT, "tests", "posterior_scale.py")
     procs = []
     for s in range(seeds):
         for k, lim in enumerate([0] + limits):
             p = os.path.join(out_dir, "seed%d_limit%d.json" % (s, lim))
-            procs.append((s, lim, p, subprocess.Popen([sys.executable, me, "--gpu", str(tips), str(parts), str(cycles), str(9001 + 17 * s + k), p, str(lim)])))
+            procs.append((s, lim, p, subprocess.Popen([sys.executable, me, "--gpu", str(tips), str(parts), str(cycles), str(seed_base + 17 * s + k), p, str(lim)])))
     res = {}
     for s, lim, path, p in procs:
         assert p.wait() == 0, (s, lim)
@@ -34,7 +35,7 @@ if __name__ == "__main__":
         for nm in NAMES:
             st = c["stats"][nm]
             print("      %-22s mean %14.4f sd %10.4f ESS %8.1f se %9.4f" % (nm, st["mean"], st["sd"], st["ess"], st["se"]), flush=True)
-    out = {"tips": tips, "parts_requested": parts, "cycles": cycles, "burn_in": burn, "seeds": seeds, "limits": limits, "emat_build_id": res[(0, 0)]["emat_build_id"], "pooled": {}, "arms": {}}
+    out = {"tips": tips, "parts_requested": parts, "cycles": cycles, "burn_in": burn, "seeds": seeds, "seed_base": seed_base, "limits": limits, "emat_build_id": res[(0, 0)]["emat_build_id"], "pooled": {}, "arms": {}}
     for (s, lim), c in res.items():
         out["arms"]["seed%d_limit%d" % (s, lim)] = c
     worst = 0.0

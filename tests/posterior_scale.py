@@ -9,7 +9,7 @@ reference's 50 x nodes local moves with a fresh partition.  Five summaries: log 
 length, mutation count.  Standard errors from the effective sample size (Geyer's initial positive sequence); every seed gives one
 z-score per summary and fine arm against its own coarse arm; the seeds are independent, so the pooled z is the mean difference over
 the root-sum-square of the standard errors.  Usage:
-    python tests/posterior_scale.py [tips] [cycles] [burn_in] [seeds]      -> gpurun_out/posterior_scale.json + a table
+    python tests/posterior_scale.py [tips] [cycles] [burn_in] [seeds] [seed_base=7001]      -> gpurun_out/posterior_scale.json + a table
 """
 import json
 import os
@@ -154,6 +154,7 @@ if __name__ == "__main__":
     cycles = int(sys.argv[2]) if len(sys.argv) > 2 else 10400
     burn = int(sys.argv[3]) if len(sys.argv) > 3 else 400
     seeds = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+    seed_base = int(sys.argv[5]) if len(sys.argv) > 5 else 7001      # (another base = an independent replication of the whole comparison)
     coarse_cycles = int(os.environ.get("EMAT_POSTERIOR_COARSE_CYCLES", cycles))
     nodes = 2 * tips - 1
     fine = [200, max(8, nodes // 25)]
@@ -161,13 +162,13 @@ if __name__ == "__main__":
     procs = []
     me = os.path.abspath(__file__)
     for s in range(seeds):
-        seed = 7001 + 13 * s
+        seed = seed_base + 13 * s
         p = os.path.join(out_dir, "seed%d_coarse.json" % s)
         procs.append((s, "coarse", p, None if only_summarise else subprocess.Popen([sys.executable, me, "--oracle", str(tips), "8", str(coarse_cycles), str(seed), p, "8"])))
         for k, nparts in enumerate(fine):
             p = os.path.join(out_dir, "seed%d_fine%d.json" % (s, k))
             procs.append((s, "fine%d" % k, p, None if only_summarise else subprocess.Popen([sys.executable, me, "--gpu", str(tips), str(nparts), str(cycles), str(seed + 1 + k), p])))
-    out = {"tips": tips, "nodes": nodes, "cycles": cycles, "coarse_cycles": coarse_cycles, "burn_in": burn, "seeds": seeds, "arms": {}, "z_per_seed": [], "pooled": {}}
+    out = {"tips": tips, "nodes": nodes, "cycles": cycles, "coarse_cycles": coarse_cycles, "burn_in": burn, "seeds": seeds, "seed_base": seed_base, "arms": {}, "z_per_seed": [], "pooled": {}}
     res = {}
     for s, arm, path, p in procs:
         assert p is None or p.wait() == 0, (s, arm)
