@@ -221,7 +221,13 @@ emat_status emat_tree_partition(emat_backend* h, int32_t num_cuts, const int32_t
   HIP_TRY(hipMemcpyAsync(G.d_cut.p, cut_of_part.data(), (size_t)P * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemsetAsync(G.d_part_status.p, 0, sizeof(int32_t), h->stream));
   const unsigned blocks = (unsigned)((P + 63) / 64);
-  hipLaunchKernelGGL(k_gt_partition, dim3(blocks), dim3(64), 0, h->stream, G.dev(), (const uint8_t*)G.d_is_cut.p, (const int32_t*)G.d_cut.p, P, 0, G.d_sizes.p,
+  if (!G.d_kids_current) {   // (the first partition after an upload: the packed children every reassemble keeps current from then on)
+    HIP_TRY(G.d_kids.alloc((size_t)n));
+    hipLaunchKernelGGL(k_gt_pack_kids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, G.dev(), G.d_kids.p);
+    HIP_TRY(hipGetLastError());
+    G.d_kids_current = true;
+  }
+  hipLaunchKernelGGL(k_gt_partition, dim3(blocks), dim3(64), 0, h->stream, G.dev(), (const int2*)G.d_kids.p, (const uint8_t*)G.d_is_cut.p, (const int32_t*)G.d_cut.p, P, 0, G.d_sizes.p,
                      (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr);
   hipLaunchKernelGGL(k_gt_part_offsets, dim3(1), dim3(1024), 0, h->stream, (const int32_t*)G.d_sizes.p, P, (long long)total, G.part_off.p, G.d_part_status.p);
   HIP_TRY(hipGetLastError());
@@ -230,7 +236,7 @@ emat_status emat_tree_partition(emat_backend* h, int32_t num_cuts, const int32_t
   HIP_TRY(hipMemcpyAsync(pin + P, G.part_off.p, ((size_t)P + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(pin + 2 * P + 1, G.d_part_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipEventRecord(G.ev_sizes, h->stream));
-  hipLaunchKernelGGL(k_gt_partition, dim3(blocks), dim3(64), 0, h->stream, G.dev(), (const uint8_t*)G.d_is_cut.p, (const int32_t*)G.d_cut.p, P, 1, (int32_t*)nullptr,
+  hipLaunchKernelGGL(k_gt_partition, dim3(blocks), dim3(64), 0, h->stream, G.dev(), (const int2*)G.d_kids.p, (const uint8_t*)G.d_is_cut.p, (const int32_t*)G.d_cut.p, P, 1, (int32_t*)nullptr,
                      (const int32_t*)G.part_off.p, G.orig.p, G.kid0.p, G.kid1.p, G.lpar.p, G.lidx.p, (const int32_t*)G.d_part_status.p);
   HIP_TRY(hipGetLastError());
   G.P = P; G.root_part = rp; G.partition_on_device = true; G.h_orig.clear(); G.h_kid0.clear();

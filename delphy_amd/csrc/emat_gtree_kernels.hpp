@@ -91,30 +91,45 @@ __device__ inline uint32_t wave_sum_u32(uint32_t x) {
 //      depth first, right child first -- the order in which the host's LIFO work list expands nodes -- handing out part-local
 //      indices exactly as it does (two consecutive ones to the children of every node it expands).  No stack: in a binary
 //      tree with parent links the way back up is known.  mode 0 counts the part's nodes, mode 1 writes the arrays.
-__global__ void k_gt_partition(GTreeDev g, const uint8_t* is_cut, const int32_t* cut_of_part, int num_parts, int mode, int32_t* sizes,
-                               const int32_t* part_off, int32_t* orig, int32_t* kid0, int32_t* kid1, int32_t* lpar, int32_t* lidx, const int32_t* gate) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+// (Round 5: a thread keeps the left siblings it still has to visit on a stack of its own in LDS, with the local index each was given,
+// and reads a node's two children as one pair (`kids`, kept current by every reassemble): one round trip to memory per node instead of
+// the four of finding the way back up through parent links -- the kernel is as long as the walk of the largest part is deep in
+// dependent loads.  A part deeper than the stack falls back to the parent links for the rest of its walk: what was on the stack is
+// exactly what walking up finds again.)
+constexpr int k_gt_part_stack = 48;
+__global__ void __launch_bounds__(64) k_gt_partition(GTreeDev g, const int2* kids, const uint8_t* is_cut, const int32_t* cut_of_part, int num_parts, int mode, int32_t* sizes,
+                                                     const int32_t* part_off, int32_t* orig, int32_t* kid0, int32_t* kid1, int32_t* lpar, int32_t* lidx, const int32_t* gate) {
+  __shared__ int2 pending[k_gt_part_stack][64];   // [depth][thread]
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, me = threadIdx.x;
   if (p >= num_parts) return;
   if (gate && *gate != 0) return;   // (k_gt_part_offsets found the counts wrong: the offsets are not to be written through)
   const int32_t cut = cut_of_part[p];
   const int b = mode ? part_off[p] : 0;
-  int cnt = 1;
+  int cnt = 1, sp = 0;
+  bool stacked = true;
   if (mode) { orig[b] = cut; lpar[b] = EMAT_NO_NODE; }
   int32_t cur = cut; int dst = 0;
   for (;;) {
-    const int32_t k0 = g.c0[cur], k1 = g.c1[cur];
-    if (k0 != EMAT_NO_NODE && (!is_cut[cur] || cur == cut)) {   // expanded: its children join the part
+    const int2 k = kids[cur];
+    if (k.x != EMAT_NO_NODE && (cur == cut || !is_cut[cur])) {   // expanded: its children join the part
       const int dl = cnt, dr = cnt + 1; cnt += 2;
-      if (mode) { orig[b + dl] = k0; orig[b + dr] = k1; kid0[b + dst] = dl; kid1[b + dst] = dr; lpar[b + dl] = dst; lpar[b + dr] = dst; lidx[k0] = dl; lidx[k1] = dr; }
-      cur = k1; dst = dr;
+      if (mode) { orig[b + dl] = k.x; orig[b + dr] = k.y; kid0[b + dst] = dl; kid1[b + dst] = dr; lpar[b + dl] = dst; lpar[b + dr] = dst; lidx[k.x] = dl; lidx[k.y] = dr; }
+      if (stacked) { if (sp < k_gt_part_stack) { pending[sp][me] = make_int2(k.x, dl); ++sp; } else stacked = false; }
+      cur = k.y; dst = dr;
       continue;
     }
     if (mode) { kid0[b + dst] = EMAT_NO_NODE; kid1[b + dst] = EMAT_NO_NODE; }   // a tip of the part
+    if (stacked) {
+      if (sp == 0) break;
+      --sp; cur = pending[sp][me].x; dst = pending[sp][me].y;
+      continue;
+    }
     bool done = false;
     for (;;) {   // back up to the nearest ancestor whose left subtree is still to do
       if (cur == cut) { done = true; break; }
       const int32_t par = g.parent[cur];
-      if (cur == g.c1[par]) { cur = g.c0[par]; dst = mode ? lidx[cur] : 0; break; }
+      const int2 pk = kids[par];
+      if (cur == pk.y) { cur = pk.x; dst = mode ? lidx[cur] : 0; break; }
       cur = par;
     }
     if (done) break;
@@ -169,6 +184,9 @@ __global__ void __launch_bounds__(k_wave) k_gt_measure(GTreeDev g, GPartition pt
   if (lane == 0) {
     int status = k_gt_ok, cur_buf = 0, n_acc = 0, n_dl = 0;
     const int32_t tree_root = g.root[0];
+    // (Asking for the next ancestor's headers and the first entries of this one's lists ahead of time -- one round trip per ancestor instead
+    // of three -- made the kernel TWICE as slow, 0.97 against 0.48 ms: with 6 600 walks in flight it is bound by the number of requests, and
+    // most ancestors have no missations and at most one mutation to fetch.)
     for (int32_t cur = pt.orig[base]; cur != EMAT_NO_NODE && status == k_gt_ok; cur = g.parent[cur]) {
       const GList mi = g.miss[cur], mu = g.muts[cur];
       if (mi.cnt != 0) {   // union with merging of touching intervals (interval_set.h:238-288)
