@@ -965,6 +965,7 @@ struct GTreeHost {
   // Kept current by every reassemble: the children of every node, packed (pin_kids: n pairs), the root and its time -- what a cycle's
   // partitioner needs.  The arrays above follow only when somebody asks for them (gt_full_mirrors).
   DevBuf<int2> d_kids; PinnedBytes pin_kids; double h_root_t = 0.0; bool full_mirrors_stale = false;
+  DevBuf<GClimb> climb; bool climb_current = false;   // GClimb records of every node (k_gt_pack_climb), remade before a measuring pass if lists or links were written since
   bool d_kids_current = false;      // d_kids holds every node's children (k_gt_gather_links only rewrites the inner nodes of the parts it sees)
   DevBuf<double> d_root_t; PinnedBytes pin_small;   // the root's time; { int32 root, int32 n_root_deltas, double t_root } on their way to the host
   // emat_tree_reassemble of a single process returns once topology and root are on the host: k_gt_gather may still be running.
@@ -973,7 +974,7 @@ struct GTreeHost {
   const int32_t* kids() const { return (const int32_t*)pin_kids.data(); }   // [2 v] = child0, [2 v + 1] = child1
   GTreeDev dev() {
     GTreeDev g{};
-    g.n_nodes = n; g.root = root.p; g.parent = parent.p; g.c0 = c0.p; g.c1 = c1.p; g.t = t.p; g.t_min = t_min.p; g.t_max = t_max.p;
+    g.n_nodes = n; g.climb = climb.p; g.root = root.p; g.parent = parent.p; g.c0 = c0.p; g.c1 = c1.p; g.t = t.p; g.t_min = t_min.p; g.t_max = t_max.p;
     g.muts = muts.p; g.miss = miss.p; g.mfs = mfs.p; g.mut_heap = mut_heap.p; g.iv_heap = iv_heap.p; g.fs_heap = fs_heap.p;
     g.mut_cap = (uint32_t)mut_heap.n; g.iv_cap = (uint32_t)iv_heap.n; g.fs_cap = (uint32_t)fs_heap.n; g.tops = tops.p;
     return g;

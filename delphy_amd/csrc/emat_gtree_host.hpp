@@ -46,6 +46,17 @@ emat_status gt_fetch_mirrors(emat_backend* h) {
   G.full_mirrors_stale = true; G.d_kids_current = true;
   return EMAT_OK;
 }
+// the walk records of k_gt_measure, when lists or links were written since they were last made (queued on the engine's stream)
+emat_status gt_ensure_climb(emat_backend* h) {
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  GTreeHost& G = h->gt;
+  if (G.climb_current && G.climb.n >= (size_t)G.n) return EMAT_OK;
+  HIP_TRY(G.climb.alloc((size_t)G.n));
+  hipLaunchKernelGGL(k_gt_pack_climb, dim3((unsigned)((G.n + 255) / 256)), dim3(256), 0, h->stream, G.dev());
+  HIP_TRY(hipGetLastError());
+  G.climb_current = true;
+  return EMAT_OK;
+}
 emat_status gt_full_mirrors(emat_backend* h) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   GTreeHost& G = h->gt;
@@ -104,7 +115,7 @@ emat_status emat_tree_upload(emat_backend* h, const emat_flat_tree* tree) {
   { int32_t z = 0; HIP_TRY(G.status.upload(&z, 1)); }
   G.h_parent.assign(tree->parent, tree->parent + n); G.h_c0.assign(tree->child0, tree->child0 + n); G.h_c1.assign(tree->child1, tree->child1 + n);
   G.h_t.assign(tree->t, tree->t + n); G.h_t_min.assign(tree->t_min, tree->t_min + n); G.h_t_max.assign(tree->t_max, tree->t_max + n);
-  G.h_root = tree->root; G.h_root_t = tree->t[tree->root]; G.full_mirrors_stale = false; G.d_kids_current = false; G.gather_pending = false;
+  G.h_root = tree->root; G.h_root_t = tree->t[tree->root]; G.full_mirrors_stale = false; G.d_kids_current = false; G.gather_pending = false; G.climb_current = false;
   HIP_TRY(G.pin_kids.resize((size_t)n * sizeof(int2)));
   { int32_t* k = (int32_t*)G.pin_kids.data(); for (int v = 0; v < n; ++v) { k[2 * v] = tree->child0[v]; k[2 * v + 1] = tree->child1[v]; } }
   G.resident = true; G.parts_live = false;
@@ -245,9 +256,10 @@ emat_status emat_tree_partition(emat_backend* h, int32_t num_cuts, const int32_t
     HIP_TRY(G.measure.alloc((size_t)P));
     { const size_t room = h->cfg_tree_tight ? 1 : (size_t)64 * P + 4096;
       HIP_TRY(G.pool_muts.alloc(std::max<size_t>(G.pool_muts.n, room))); HIP_TRY(G.pool_ivs.alloc(std::max<size_t>(G.pool_ivs.n, room))); }
-    HIP_TRY(G.pool_tops.alloc(2));
+    HIP_TRY(G.pool_tops.alloc(2 * k_gt_pool_lanes * k_gt_pool_stride));
     HIP_TRY(G.pin_measure.resize((size_t)P * sizeof(GMeasure)));
-    HIP_TRY(hipMemsetAsync(G.pool_tops.p, 0, 2 * sizeof(uint32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(G.pool_tops.p, 0, 2 * k_gt_pool_lanes * k_gt_pool_stride * sizeof(uint32_t), h->stream));
+    { emat_status cs = gt_ensure_climb(h); if (cs) return cs; }
     hipLaunchKernelGGL((k_gt_measure<k_gt_small_cut_intervals, k_gt_small_cut_deltas>), dim3((unsigned)P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const uint8_t*)h->d_ref.p, G.measure.p,
                        (const int32_t*)nullptr, (const int32_t*)G.d_part_status.p);
     HIP_TRY(hipGetLastError());
@@ -375,11 +387,12 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
     HIP_TRY(G.measure.alloc(P));
     { const size_t room = h->cfg_tree_tight ? 1 : (size_t)64 * P + 4096;
       HIP_TRY(G.pool_muts.alloc(std::max<size_t>(G.pool_muts.n, room))); HIP_TRY(G.pool_ivs.alloc(std::max<size_t>(G.pool_ivs.n, room))); }
-    HIP_TRY(G.pool_tops.alloc(2));
+    HIP_TRY(G.pool_tops.alloc(2 * k_gt_pool_lanes * k_gt_pool_stride));
   }
   const auto t1 = now(); laps.mark("tree_repartition: 01 allocations");
   auto launch_measure = [&]() -> emat_status {
-    HIP_TRY(hipMemsetAsync(G.pool_tops.p, 0, 2 * sizeof(uint32_t), h->stream));
+    { emat_status cs = gt_ensure_climb(h); if (cs) return cs; }
+    HIP_TRY(hipMemsetAsync(G.pool_tops.p, 0, 2 * k_gt_pool_lanes * k_gt_pool_stride * sizeof(uint32_t), h->stream));
     hipLaunchKernelGGL((k_gt_measure<k_gt_small_cut_intervals, k_gt_small_cut_deltas>), dim3((unsigned)P), dim3(k_wave), 0, h->stream, G.dev(), G.partition(), G.pools(), (const uint8_t*)h->d_ref.p, G.measure.p, (const int32_t*)nullptr, (const int32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     return EMAT_OK;
@@ -464,8 +477,12 @@ emat_status emat_tree_repartition_range(emat_backend* h, int32_t num_parts, cons
     if (worst == k_gt_ok) break;
     if (worst != k_gt_pool_overflow || attempt == 4) return fail(h, worst == k_gt_cut_state_overflow || worst == k_gt_list_too_long ? EMAT_ERR_CAPACITY : EMAT_ERR_INTERNAL,
                                                                   "emat_tree_repartition: part " + std::to_string(who) + ": " + gt_status_text(worst));
-    uint32_t tops[2];
-    HIP_TRY(hipMemcpy(tops, G.pool_tops.p, sizeof(tops), hipMemcpyDeviceToHost));   // the atomics kept counting: what the pools need
+    uint32_t tops[2] = {0u, 0u};
+    {   // the atomics kept counting: the fullest region of either pool says what every region needs
+      std::vector<uint32_t> all(2 * k_gt_pool_lanes * k_gt_pool_stride);
+      HIP_TRY(hipMemcpy(all.data(), G.pool_tops.p, all.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      for (uint32_t r = 0; r < k_gt_pool_lanes; ++r) { tops[0] = std::max(tops[0], all[r * k_gt_pool_stride] * k_gt_pool_lanes); tops[1] = std::max(tops[1], all[(k_gt_pool_lanes + r) * k_gt_pool_stride] * k_gt_pool_lanes); }
+    }
     HIP_TRY(G.pool_muts.alloc((size_t)tops[0] * 2 + 4096)); HIP_TRY(G.pool_ivs.alloc((size_t)tops[1] * 2 + 4096));
     ++G.pool_regrows; large_done = false;
     st = launch_measure(); if (st) return st;
@@ -643,6 +660,7 @@ emat_status gt_root_deltas(emat_backend* h, std::vector<GRootDelta>& rd, bool& o
 emat_status gt_launch_gather(emat_backend* h) {
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   GTreeHost& G = h->gt;
+  G.climb_current = false;   // (lists and links are about to be rewritten)
   HIP_TRY(hipMemsetAsync(G.tops.p, 0, 3 * sizeof(uint32_t), h->stream));
   HIP_TRY(hipMemsetAsync(G.status.p, 0, sizeof(int32_t), h->stream));
   HIP_TRY(hipMemsetAsync(G.n_root_deltas.p, 0, sizeof(int32_t), h->stream));
@@ -861,6 +879,7 @@ emat_status emat_tree_apply_nodes(emat_backend* h, const uint8_t* buf, uint64_t 
   DevBuf<GNodeExport> d_in;
   HIP_TRY(d_in.alloc(n));
   if (n) HIP_TRY(hipMemcpy(d_in.p, buf + 32, n * sizeof(GNodeExport), hipMemcpyDefault));
+  G.climb_current = false;
   hipLaunchKernelGGL(k_gt_apply, dim3((unsigned)((n + 255) / 256 + 1)), dim3(256), 0, h->stream, G.dev(), (const GNodeExport*)d_in.p, (int)n, G.used[0], G.used[1], G.used[2], new_root);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));

@@ -15,8 +15,16 @@ namespace emat {
 
 struct GList { uint32_t off, cnt; };   // records [off, off + cnt) of the heap of its kind
 
+// What a walk from a cut point to the root reads of every node on its way, in ONE 16-byte request instead of three (parent, and the
+// headers of the node's missations and mutations): k_gt_measure makes 13 000 such walks side by side and is bound by the number of
+// requests it issues.  A copy (k_gt_pack_climb), made after the tree's lists and links were last written.  Counts fit 16 bits: no
+// list of the tree is longer than k_gt_max_list.
+struct GClimb { int32_t parent; uint32_t miss_off, muts_off; uint16_t miss_cnt, muts_cnt; };
+static_assert(sizeof(GClimb) == 16, "GClimb is one 16-byte load");
+
 struct GTreeDev {
   int32_t n_nodes;
+  GClimb* climb;                     // [n_nodes], see above
   int32_t* root;                     // [1]
   int32_t* parent; int32_t* c0; int32_t* c1;
   double* t; const float* t_min; const float* t_max;
@@ -44,7 +52,12 @@ struct GMeasure {                    // per part, written by k_gt_measure
   double t_min, t_max, t_max_exact;  // CoalBuilder::local_range: tips count with their float bounds, t_max_exact is the latest node time in full precision
 };
 
-struct GPools { MutRec* muts; IvRec* ivs; uint32_t mut_cap, iv_cap; uint32_t* tops; /* [2] */ };
+// The cut-point states of all parts, bump-allocated by k_gt_measure.  One counter per pool would take 13 000 atomic additions to the same
+// word, one behind the other (0.3 ms of a 0.45-ms kernel): each pool is k_gt_pool_lanes regions with a counter each (64 bytes apart), part p
+// takes from region p mod k_gt_pool_lanes.  `tops` [2 x k_gt_pool_lanes x 16]: the counters keep counting past a full region, so the fullest
+// one tells the host how much room to give.
+constexpr uint32_t k_gt_pool_lanes = 64, k_gt_pool_stride = 16;
+struct GPools { MutRec* muts; IvRec* ivs; uint32_t mut_cap, iv_cap; uint32_t* tops; };
 
 struct GPartDesc {                   // per part, from the host: geometry of the slab + what its header starts with
   uint32_t slab_bytes, heap_bytes, scratch_bytes;
@@ -139,6 +152,13 @@ __global__ void __launch_bounds__(64) k_gt_partition(GTreeDev g, const int2* kid
 
 // What the host's partitioner reads of the tree every cycle: each node's two children side by side (one cache line per visit of
 // its walks), 8 bytes a node instead of the 24 of parent, children and time.
+__global__ void k_gt_pack_climb(GTreeDev g) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= g.n_nodes) return;
+  const GList mi = g.miss[v], mu = g.muts[v];
+  GClimb c; c.parent = g.parent[v]; c.miss_off = mi.off; c.muts_off = mu.off; c.miss_cnt = (uint16_t)mi.cnt; c.muts_cnt = (uint16_t)mu.cnt;
+  g.climb[v] = c;
+}
 __global__ void k_gt_pack_kids(GTreeDev g, int2* kids) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v < g.n_nodes) kids[v] = make_int2(g.c0[v], g.c1[v]);
@@ -187,8 +207,10 @@ __global__ void __launch_bounds__(k_wave) k_gt_measure(GTreeDev g, GPartition pt
     // (Asking for the next ancestor's headers and the first entries of this one's lists ahead of time -- one round trip per ancestor instead
     // of three -- made the kernel TWICE as slow, 0.97 against 0.48 ms: with 6 600 walks in flight it is bound by the number of requests, and
     // most ancestors have no missations and at most one mutation to fetch.)
-    for (int32_t cur = pt.orig[base]; cur != EMAT_NO_NODE && status == k_gt_ok; cur = g.parent[cur]) {
-      const GList mi = g.miss[cur], mu = g.muts[cur];
+    GClimb here{EMAT_NO_NODE, 0u, 0u, 0, 0};
+    for (int32_t cur = pt.orig[base]; cur != EMAT_NO_NODE && status == k_gt_ok; cur = here.parent) {
+      here = g.climb[cur];
+      const GList mi{here.miss_off, here.miss_cnt}, mu{here.muts_off, here.muts_cnt};
       if (mi.cnt != 0) {   // union with merging of touching intervals (interval_set.h:238-288)
         const IvRec* B = g.iv_heap + mi.off; const IvRec* A = acc[cur_buf]; IvRec* O = acc[cur_buf ^ 1];
         uint32_t ia = 0, ib = 0; int no = 0; bool inside = false; int cs = 0, ce = 0;
@@ -227,8 +249,10 @@ __global__ void __launch_bounds__(k_wave) k_gt_measure(GTreeDev g, GPartition pt
     }
     uint32_t om = 0, oi = 0;
     if (status == k_gt_ok) {
-      om = atomicAdd(&pools.tops[0], (uint32_t)n_keep); oi = atomicAdd(&pools.tops[1], (uint32_t)n_acc);
-      if (om + (uint32_t)n_keep > pools.mut_cap || oi + (uint32_t)n_acc > pools.iv_cap) status = k_gt_pool_overflow;
+      const uint32_t region = (uint32_t)p % k_gt_pool_lanes, m_room = pools.mut_cap / k_gt_pool_lanes, i_room = pools.iv_cap / k_gt_pool_lanes;
+      om = atomicAdd(&pools.tops[region * k_gt_pool_stride], (uint32_t)n_keep); oi = atomicAdd(&pools.tops[(k_gt_pool_lanes + region) * k_gt_pool_stride], (uint32_t)n_acc);
+      if (om + (uint32_t)n_keep > m_room || oi + (uint32_t)n_acc > i_room) status = k_gt_pool_overflow;
+      om += region * m_room; oi += region * i_room;
       if ((uint32_t)n_keep > k_gt_max_list || (uint32_t)n_acc > k_gt_max_list) status = k_gt_list_too_long;
     }
     sh[0] = status; sh[1] = n_keep; sh[2] = n_acc; sh[3] = cur_buf; sh_off[0] = om; sh_off[1] = oi;
