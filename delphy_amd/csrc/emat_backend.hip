@@ -948,6 +948,7 @@ struct GTreeHost {
   std::vector<int32_t> h_part_off, h_orig, h_kid0, h_kid1;   // host copies (h_orig / h_kid* only when the partition came from the host or was asked for)
   bool partition_on_device = false;   // made by emat_tree_partition
   DevBuf<int32_t> lidx;
+  PinnedBytes pin_cut;   // emat_tree_partition's cut marks and cut nodes on their way to the device
   DevBuf<uint8_t> d_is_cut; DevBuf<int32_t> d_cut, d_sizes, d_part_status;   // emat_tree_partition's inputs and counts (kept: three allocations less per cycle)
   PinnedBytes pin_sizes, pin_measure;                                         // where its sizes + offsets, and the measures queued behind it, land
   hipEvent_t ev_sizes = nullptr, ev_measure = nullptr;
@@ -971,6 +972,7 @@ struct GTreeHost {
   // emat_tree_reassemble of a single process returns once topology and root are on the host: k_gt_gather may still be running.
   // Whoever touches the device-resident tree next (gt_require) waits for it and checks how it went (gt_finish_gather).
   bool gather_pending = false; std::vector<GRootDelta> gather_rd;
+  emat_status gather_failed = EMAT_OK; std::string gather_failed_text;   // a deferred gather that failed: sticky until emat_tree_upload (gt_require)
   const int32_t* kids() const { return (const int32_t*)pin_kids.data(); }   // [2 v] = child0, [2 v + 1] = child1
   GTreeDev dev() {
     GTreeDev g{};
@@ -1007,10 +1009,12 @@ struct emat_backend {
   uint32_t cfg_lds_max = 96 * 1024;                  // EMAT_LDS_MAX (tuning knob): largest staging area; larger parts run out of HBM
   bool order_valid = false;         // d_order holds the current parts, largest first
   std::vector<int32_t> h_order;     // host copy of d_order
+  PinnedBytes pin_order;            // ... and what a queued upload of it is copied from (build_order)
   bool last_launch_uniform = false; // the last launch ran the same number of moves on every part (its durations are comparable)
   bool cfg_order_by_time = false;   // option "order_by_time" (tuning knob): re-sort the launch order by measured durations at every synchronisation
   std::string cfg_ticket_weights;   // option "ticket_weights": "w1,w2,..." the tickets' ratio, as many numbers as tickets
   int cfg_build_blocks = 0;         // option "build_blocks": workgroups of the initial-tree builder's launch (0 = by tree size)
+  bool cfg_debug_fail_gather = false;   // option "debug_fail_gather" (testing aid): the next deferred gather of the device-resident tree reports k_gt_inconsistent
   bool cfg_tree_tight = false;      // option "tree_tight" (testing aid): the device-resident tree gets no spare room, so that the growth paths run
   unsigned cfg_fn_min_lists = 0;    // option "fn_min_lists" (profiling builds): function timers count only parts whose lists take at least this many bytes
   bool cfg_phase_extra = false;     // option "phase_extra" (profiling builds): emat_debug_phase_ticks returns the scan and arena counters
@@ -1666,7 +1670,11 @@ emat_status build_order(emat_backend* h, bool queued = false) {
     key.swap(key2); order.swap(order2);
   }
   h->h_order = order;
-  if (queued) { HIP_TRY(h->d_order.alloc(order.size())); HIP_TRY(hipMemcpyAsync(h->d_order.p, h->h_order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream)); }
+  if (queued) {   // (from page-locked memory: a copy from a pageable vector would wait for the stream -- k_gt_build and the grid kernels -- to reach it)
+    HIP_TRY(h->d_order.alloc(order.size())); HIP_TRY(h->pin_order.resize(order.size() * sizeof(int32_t)));
+    std::memcpy(h->pin_order.data(), order.data(), order.size() * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(h->d_order.p, h->pin_order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  }
   else { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(h->d_order.upload(order.data(), order.size())); }
   h->order_valid = true;
   return EMAT_OK;
@@ -1778,6 +1786,7 @@ emat_status launch_moves(emat_backend* h, int64_t per_part, int64_t extra0, cons
 // =================================================================================================
 // C-ABI
 // =================================================================================================
+namespace { emat_status gt_finish_gather(emat_backend* h); }   // (emat_gtree_host.hpp, included at the end of this file)
 extern "C" {
 
 emat_status emat_backend_create(const emat_config* cfg, emat_backend** out) {
@@ -1848,6 +1857,7 @@ emat_status emat_set_option(emat_backend* h, const char* key, const char* value)
   else if (k == "order_by_time") h->cfg_order_by_time = atoi(e) != 0;
   else if (k == "build_blocks") h->cfg_build_blocks = std::max(0, atoi(e));
   else if (k == "tree_tight") h->cfg_tree_tight = atoi(e) != 0;
+  else if (k == "debug_fail_gather") h->cfg_debug_fail_gather = atoi(e) != 0;
   else if (k == "fn_min_lists") h->cfg_fn_min_lists = (unsigned)std::max(0, atoi(e));
   else if (k == "phase_extra") h->cfg_phase_extra = atoi(e) != 0;
   else return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_set_option: unknown option '" + k + "'");
@@ -2111,6 +2121,16 @@ emat_status emat_part_get_derived(emat_backend* h, int32_t part_id, double* lamb
   for (int i = 0; i < H->n_nodes; ++i) { if (lambda_i) lambda_i[i] = N[i].lambda; if (num_missing) num_missing[i] = N[i].n_missing; }
   if (log_G) *log_G = H->log_G;
   if (log_aug) *log_aug = H->log_aug_prior;
+  return EMAT_OK;
+}
+emat_status emat_part_get_state_frequencies(emat_backend* h, int32_t part_id, int32_t* num_partitions, int32_t* counts) {
+  if (!h || !num_partitions || part_id < 0 || part_id >= (int)h->parts.size()) return EMAT_ERR_INVALID_ARGUMENT;
+  if (!h->have_ref || !h->have_evo) return fail(h, EMAT_ERR_STATE, "set_ref_sequence and set_evo first");
+  if (h->gt.gather_pending) { emat_status st = gt_finish_gather(h); if (st) return st; }   // (a gather on its way may still move the reference sequence with the root's)
+  const int P = h->num_partitions;
+  if (*num_partitions < P || !counts) { *num_partitions = P; return fail(h, EMAT_ERR_BUFFER_TOO_SMALL, "emat_part_get_state_frequencies: room for fewer site partitions than the model has"); }
+  *num_partitions = P;
+  std::copy(h->ref_freqs.begin(), h->ref_freqs.begin() + (size_t)P * 4, counts);   // the host's copy of the table the kernels read (d_ref_freqs)
   return EMAT_OK;
 }
 emat_status emat_part_get_coalescent(emat_backend* h, int32_t part_id, int32_t* num_cells, double* k_bar_p, double* k_tw_p, double* k_tw,

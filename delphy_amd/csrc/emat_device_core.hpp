@@ -69,6 +69,11 @@ __shared__ __attribute__((aligned(16))) uint8_t emat_lds_hdr[sizeof(SlabHeader)]
 // checks at its start that the dynamic block really is there and stops every part loudly if it is not.
 constexpr uint32_t k_lds_dyn_base = k_lds_tables_bytes + k_lds_ctx_bytes + (k_rng_blocks ? k_rng_blocks * 16 : 16) + k_lds_logq_bytes + (uint32_t)sizeof(SlabHeader);
 }  // namespace emat
+// Profiling and call-counting builds declare one more static LDS object (s_fn_count_me, emat_backend.hip): the dynamic block then does not
+// start at the constant, and run_moves_body's check would stop every part (fail_line -3).  Those builds take the symbol instead.
+#if (defined(EMAT_PROFILE_PHASES) || defined(EMAT_COUNT_CALLS)) && !defined(EMAT_X_DYN_LDS_BY_TABLE)
+#define EMAT_X_DYN_LDS_BY_TABLE
+#endif
 #ifdef EMAT_X_DYN_LDS_BY_TABLE   // (A/B: the symbol, as until round 5)
 #define EMAT_DYN_LDS ::emat::emat_lds
 #else

@@ -22,10 +22,15 @@ const char* gt_status_text(int32_t s) {
 }
 
 emat_status gt_finish_gather(emat_backend* h);
-emat_status gt_require(emat_backend* h, bool need_resident, bool gather_may_run = false) {
+// `uploading`: emat_tree_upload, the one call that may follow a failed gather (it replaces the tree the gather left half written).
+emat_status gt_require(emat_backend* h, bool need_resident, bool gather_may_run = false, bool uploading = false) {
   if (!bind_device(h)) return fail(h, EMAT_ERR_HIP, "hipSetDevice failed");
   if (h->host_only) return fail(h, EMAT_ERR_NO_DEVICE, "host-only handle (device = -1): the engine has no CPU fallback");
+  if (uploading) return EMAT_OK;   // (whatever gather was pending or failed concerns the tree that is being replaced)
   if (need_resident && !h->gt.resident) return fail(h, EMAT_ERR_STATE, "emat_tree_upload first");
+  // A deferred gather that failed (emat_tree_reassemble had already returned EMAT_OK with the new links) leaves the device-resident tree
+  // with new links but half-written lists: every later emat_tree_* call reports that, with the first failure's text, until a tree is uploaded.
+  if (h->gt.gather_failed != EMAT_OK) return fail(h, h->gt.gather_failed, "the device-resident tree is incomplete since a deferred gather failed (" + h->gt.gather_failed_text + "): emat_tree_upload a tree to go on");
   if (h->gt.gather_pending && !gather_may_run) return gt_finish_gather(h);
   return EMAT_OK;
 }
@@ -78,7 +83,7 @@ extern "C" {
 
 emat_status emat_tree_upload(emat_backend* h, const emat_flat_tree* tree) {
   if (!h || !tree) return EMAT_ERR_INVALID_ARGUMENT;
-  emat_status st = gt_require(h, false); if (st) return st;
+  emat_status st = gt_require(h, false, false, true); if (st) return st;
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   const std::string msg = validate_flat_tree(*tree, h->L);
   if (!msg.empty()) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "emat_tree_upload: " + msg);
@@ -116,6 +121,8 @@ emat_status emat_tree_upload(emat_backend* h, const emat_flat_tree* tree) {
   G.h_parent.assign(tree->parent, tree->parent + n); G.h_c0.assign(tree->child0, tree->child0 + n); G.h_c1.assign(tree->child1, tree->child1 + n);
   G.h_t.assign(tree->t, tree->t + n); G.h_t_min.assign(tree->t_min, tree->t_min + n); G.h_t_max.assign(tree->t_max, tree->t_max + n);
   G.h_root = tree->root; G.h_root_t = tree->t[tree->root]; G.full_mirrors_stale = false; G.d_kids_current = false; G.gather_pending = false; G.climb_current = false;
+  G.gather_failed = EMAT_OK; G.gather_failed_text.clear();
+  G.measure_queued = false; G.partition_on_device = false; G.P = 0;   // (a partition made of the tree that was here says nothing about this one: emat_tree_partition first)
   HIP_TRY(G.pin_kids.resize((size_t)n * sizeof(int2)));
   { int32_t* k = (int32_t*)G.pin_kids.data(); for (int v = 0; v < n; ++v) { k[2 * v] = tree->child0[v]; k[2 * v + 1] = tree->child1[v]; } }
   G.resident = true; G.parts_live = false;
@@ -206,8 +213,13 @@ emat_status emat_tree_partition(emat_backend* h, int32_t num_cuts, const int32_t
   const int n = G.n;
   EMAT_SPAN("tree_partition (all)");
   // partition_tree's rule for the run's root (tree_partitioning.h:196-239): a part of its own at the end unless the stencil names it
-  std::vector<uint8_t> is_cut((size_t)n, 0);
-  std::vector<int32_t> cut_of_part(cut_nodes, cut_nodes + num_cuts);
+  // (both arrays in page-locked memory: a hipMemcpyAsync from pageable memory waits for the stream to reach it, and the stream is busy
+  // with the gather this call is meant to overlap -- ADVICE round 5)
+  HIP_TRY(G.pin_cut.resize((((size_t)n + 15) & ~(size_t)15) + ((size_t)num_cuts + 1) * sizeof(int32_t)));
+  uint8_t* const is_cut = G.pin_cut.data(); std::memset(is_cut, 0, (size_t)n);
+  int32_t* const cut_of_part = (int32_t*)(G.pin_cut.data() + (((size_t)n + 15) & ~(size_t)15));
+  std::copy(cut_nodes, cut_nodes + num_cuts, cut_of_part);
+  int n_cut_parts = num_cuts;
   const int32_t* const kids = G.kids();
   int rp = -1;
   for (int i = 0; i < num_cuts; ++i) {
@@ -216,8 +228,8 @@ emat_status emat_tree_partition(emat_backend* h, int32_t num_cuts, const int32_t
     is_cut[c] = 1;
     if (c == G.h_root && rp < 0) rp = i;
   }
-  if (rp < 0) { is_cut[G.h_root] = 1; rp = num_cuts; cut_of_part.push_back(G.h_root); }
-  const int P = (int)cut_of_part.size();
+  if (rp < 0) { is_cut[G.h_root] = 1; rp = num_cuts; cut_of_part[n_cut_parts++] = G.h_root; }
+  const int P = n_cut_parts;
   if (h->cfg.max_parts > 0 && P > h->cfg.max_parts) return fail(h, EMAT_ERR_INVALID_ARGUMENT, "more parts than cfg.max_parts");
   HostLaps laps;
   // Everything below is queued on the engine's stream without the host in between: the counts, the offsets from the counts
@@ -228,8 +240,8 @@ emat_status emat_tree_partition(emat_backend* h, int32_t num_cuts, const int32_t
   const size_t total = (size_t)n + (size_t)P - 1;
   HIP_TRY(G.part_off.alloc((size_t)P + 1)); HIP_TRY(G.orig.alloc(total)); HIP_TRY(G.kid0.alloc(total)); HIP_TRY(G.kid1.alloc(total)); HIP_TRY(G.lpar.alloc(total)); HIP_TRY(G.lidx.alloc((size_t)n));
   HIP_TRY(G.pin_sizes.resize(((size_t)2 * P + 2) * sizeof(int32_t)));
-  HIP_TRY(hipMemcpyAsync(G.d_is_cut.p, is_cut.data(), (size_t)n, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(G.d_cut.p, cut_of_part.data(), (size_t)P * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(G.d_is_cut.p, is_cut, (size_t)n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(G.d_cut.p, cut_of_part, (size_t)P * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemsetAsync(G.d_part_status.p, 0, sizeof(int32_t), h->stream));
   const unsigned blocks = (unsigned)((P + 63) / 64);
   if (!G.d_kids_current) {   // (the first partition after an upload: the packed children every reassemble keeps current from then on)
@@ -669,16 +681,25 @@ emat_status gt_launch_gather(emat_backend* h) {
   HIP_TRY(hipGetLastError());
   return EMAT_OK;
 }
+emat_status gt_finish_gather_once(emat_backend* h);
+// The gather stays pending until it has SUCCEEDED; a failure is kept (gt_require) instead of being reported once from whichever call came next.
 emat_status gt_finish_gather(emat_backend* h) {
-  auto set_error = [&](const std::string& s) { h->set_error(s); };
   GTreeHost& G = h->gt;
   if (!G.gather_pending) return EMAT_OK;
-  G.gather_pending = false;
+  const emat_status st = gt_finish_gather_once(h);
+  if (st == EMAT_OK) { G.gather_pending = false; return EMAT_OK; }
+  G.gather_failed = st; G.gather_failed_text = h->last_error;
+  return st;
+}
+emat_status gt_finish_gather_once(emat_backend* h) {
+  auto set_error = [&](const std::string& s) { h->set_error(s); };
+  GTreeHost& G = h->gt;
   int32_t status = 0;
   for (int attempt = 0;; ++attempt) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(&status, G.status.p, sizeof(status), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(G.used, G.tops.p, sizeof(G.used), hipMemcpyDeviceToHost));
+    if (h->cfg_debug_fail_gather && status == k_gt_ok) { h->cfg_debug_fail_gather = false; status = k_gt_inconsistent; }   // option "debug_fail_gather" (testing aid): the next gather reports an inconsistency
     if (status == k_gt_ok) break;
     if (status != k_gt_heap_overflow || attempt == 2) return fail(h, EMAT_ERR_INTERNAL, std::string("emat_tree_reassemble: ") + gt_status_text(status));
     // the atomics kept counting: G.used is what the heaps need (nothing of the old content is read by the gather)

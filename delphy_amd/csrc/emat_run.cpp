@@ -104,8 +104,9 @@ struct RunDriver {
   uint64_t seed = 0;
   SplitMix64 bitgen{0};
   int num_parts = 1;
-  int max_part_nodes = -1;  // parts larger than this are cut further at every repartition (not in the reference; see refine_stencil): -1 = three times the mean part size, 0 = off
+  int max_part_nodes = 0;   // 0 = the reference's partition rule exactly (the default, so that a drop-in Run reproduces the reference / oracle partition); opt-in, not in the reference (see refine_stencil): > 0 = parts larger than this are cut further at every repartition, -1 = three times the mean part size
   int last_num_parts = 0, last_largest_part = 0, last_extra_cuts = 0;   // of the last repartition (emat_run_partition_stats)
+  int last_pick = -1; uint64_t last_refine_epoch = 0;                  // ... which stencil it picked, and the epoch its refinement's random stream was keyed with (emat_run_debug_redraw_partition)
   // model
   bool have_hky = false; double hky_mu = 0, hky_kappa = 1, hky_pi[4] = {0.25, 0.25, 0.25, 0.25};
   std::vector<double> nu_l;
@@ -250,7 +251,12 @@ struct RunDriver {
         if (first && size <= limit) return;   // the common case: one walk, nothing to do
         first = false;
         if (size <= limit || inner.empty()) continue;
-        // as many new cut nodes as would make the pieces `limit` nodes on average, a uniformly drawn subset of the inner nodes
+        // as many new cut nodes as would make the pieces `limit` nodes on average, a uniformly drawn subset of the inner nodes.
+        // The subset is drawn from the inner nodes IN NODE ORDER, not in the order the walk met them: the walk's order is the piece's
+        // topology, which the pass changes, while the set is not -- so the draw is a function of (what a pass leaves alone, the stream)
+        // alone, and repeating it on the tree after the pass gives the very same cut nodes (round 6: emat_run_debug_redraw_partition,
+        // tests/test_host_driver.py; until then the invariance held in distribution only).
+        std::sort(inner.begin(), inner.end());
         const int want = std::min((int)inner.size(), std::max(1, (size + limit - 1) / limit - 1));
         for (int k = 0; k < want; ++k) { const int j = k + rng.below((int)inner.size() - k); std::swap(inner[(size_t)k], inner[(size_t)j]); }
         for (int k = 0; k < want; ++k) { mark_cut(inner[(size_t)k]); extra[(size_t)ri].push_back(inner[(size_t)k]); work.push_back(inner[(size_t)k]); }
@@ -621,7 +627,8 @@ struct RunDriver {
         stencil_refresh_countdown = 200;
       }
       --stencil_refresh_countdown;
-      const std::vector<int32_t> stencil = refine_stencil(stencils[bitgen.below((int)stencils.size())]);
+      last_pick = bitgen.below((int)stencils.size()); last_refine_epoch = epoch;
+      const std::vector<int32_t> stencil = refine_stencil(stencils[(size_t)last_pick]);
       laps.mark("run.repartition: stencil pick + refine_stencil");
       part_kids.clear();
       // partition_tree itself: on the device (one thread per part) unless the parts are few and large, where one host thread
@@ -716,7 +723,8 @@ struct RunDriver {
         stencil_refresh_countdown = 200;
       }
       --stencil_refresh_countdown;
-      const std::vector<int32_t> stencil = refine_stencil(stencils[bitgen.below((int)stencils.size())]);
+      last_pick = bitgen.below((int)stencils.size()); last_refine_epoch = epoch;
+      const std::vector<int32_t> stencil = refine_stencil(stencils[(size_t)last_pick]);
       part_kids.clear();
       t1 = now();
       partition_tree(stencil);
@@ -829,6 +837,26 @@ emat_status emat_run_destroy(emat_run* r) { delete r; return EMAT_OK; }
 const char* emat_run_last_error(const emat_run* r) { return r ? r->d.last_error.c_str() : "null run"; }
 
 emat_status emat_run_set_max_part_nodes(emat_run* r, int32_t n) { if (!r || n < -1) return EMAT_ERR_INVALID_ARGUMENT; r->d.max_part_nodes = n; return EMAT_OK; }
+/* Test hook: the cut nodes the LAST repartition's draw (same stencil, same random stream of the refinement) gives on the tree AS IT IS NOW.
+ * Between a repartition and the reassemble that follows a pass, the moves only re-hang and re-time nodes within parts; refine_stencil
+ * reads nothing such a pass can change, so the draw on the tree after the pass must be the draw on the tree before it -- the premise of
+ * the argument that the part-size limit leaves the sampler's stationary distribution alone (refine_stencil).  Changes no state. */
+emat_status emat_run_debug_redraw_partition(emat_run* r, int32_t* cut_nodes, int32_t* num_cut_nodes) {
+  if (!r || !num_cut_nodes) return EMAT_ERR_INVALID_ARGUMENT;
+  RunDriver& d = r->d;
+  if (d.last_pick < 0 || d.last_pick >= (int)d.stencils.size()) return d.fail(EMAT_ERR_STATE, "emat_run_repartition first");
+  if (d.device_tree) { emat_status st = d.fetch_device_topology(); if (st) return st; } else d.sync_topology();
+  const uint64_t epoch_now = d.epoch; const int extra_now = d.last_extra_cuts;
+  d.epoch = d.last_refine_epoch;
+  std::vector<int32_t> cuts;
+  try { cuts = d.refine_stencil(d.stencils[(size_t)d.last_pick]); } catch (const std::exception& ex) { d.epoch = epoch_now; d.last_extra_cuts = extra_now; return d.fail(EMAT_ERR_INTERNAL, ex.what()); }
+  d.epoch = epoch_now; d.last_extra_cuts = extra_now;
+  std::sort(cuts.begin(), cuts.end());
+  const int32_t cap = *num_cut_nodes; *num_cut_nodes = (int32_t)cuts.size();
+  if (cap < (int32_t)cuts.size() || !cut_nodes) return d.fail(EMAT_ERR_BUFFER_TOO_SMALL, "emat_run_debug_redraw_partition: array too small");
+  std::copy(cuts.begin(), cuts.end(), cut_nodes);
+  return EMAT_OK;
+}
 emat_status emat_run_partition_stats(emat_run* r, int32_t* num_parts, int32_t* largest_part_nodes, int32_t* extra_cuts, int32_t* max_part_nodes_in_effect) {
   if (!r) return EMAT_ERR_INVALID_ARGUMENT;
   if (num_parts) *num_parts = r->d.last_num_parts;

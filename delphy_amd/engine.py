@@ -276,7 +276,7 @@ def load_library():
         "emat_run_local_moves": [B, i64], "emat_run_moves_per_part": [B, i64], "emat_synchronize": [B], "emat_recalc_derived": [B],
         "emat_get_totals": [B, P(dbl), P(dbl)], "emat_get_global_stats": [B, i32, P(dbl), P(i64), P(i64)],
         "emat_part_get_sizes": [B, i32, P(i32), P(i32), P(i32), P(i32)], "emat_part_download": [B, i32, P(_FlatTreeC)],
-        "emat_part_get_derived": [B, i32, P(dbl), P(i32), P(dbl), P(dbl)],
+        "emat_part_get_derived": [B, i32, P(dbl), P(i32), P(dbl), P(dbl)], "emat_part_get_state_frequencies": [B, i32, P(i32), P(i32)],
         "emat_part_get_coalescent": [B, i32, P(i32), P(dbl), P(dbl), P(dbl), P(dbl), P(i32), P(dbl), P(dbl)],
         "emat_tree_build_usher_like": [B, P(_TipDescsC), u64], "emat_tree_build_default": [B, P(_TipDescsC), u64, P(i32)], "emat_tree_built_ref": [B, P(C.c_uint8)], "emat_tree_built_sizes": [B, P(i32), P(i32), P(i32), P(i32)], "emat_tree_built_get": [B, P(_FlatTreeC)],
         "emat_part_get_rng": [B, i32, P(u64), P(u64), P(u64), P(i32)], "emat_check_derived": [B, dbl, P(i32), P(dbl)], "emat_debug_slab_layout": [B, i32, P(C.c_uint32)],
@@ -293,7 +293,7 @@ def load_library():
         "emat_scalable_coalescent_log_prior": [B, dbl, dbl, i32, i32, P(dbl), dbl, P(dbl)],
         "emat_synth_create": [P(_SynthParamsC), P(S)], "emat_synth_get": [S, P(_FlatTreeC), P(P(C.c_uint8)), P(dbl)],
         "emat_run_create": [B, P(_FlatTreeC), P(C.c_uint8), i32, u64, P(R)], "emat_run_destroy": [R],
-        "emat_run_set_num_parts": [R, i32], "emat_run_set_max_part_nodes": [R, i32], "emat_run_partition_stats": [R, P(i32), P(i32), P(i32), P(i32)], "emat_run_set_hky": [R, dbl, dbl, P(dbl), P(dbl)], "emat_run_set_pop_model": [R, P(_PopModelC)],
+        "emat_run_set_num_parts": [R, i32], "emat_run_set_max_part_nodes": [R, i32], "emat_run_partition_stats": [R, P(i32), P(i32), P(i32), P(i32)], "emat_run_debug_redraw_partition": [R, P(i32), P(i32)], "emat_run_set_hky": [R, dbl, dbl, P(dbl), P(dbl)], "emat_run_set_pop_model": [R, P(_PopModelC)],
         "emat_run_set_coalescent_t_step": [R, dbl], "emat_run_set_flags": [R, i32, i32],
         "emat_run_repartition": [R], "emat_run_num_parts": [R, P(i32), P(i32)],
         "emat_run_part_sizes": [R, i32, P(i32), P(i32), P(i32), P(i32)], "emat_run_part_get": [R, i32, P(_FlatTreeC), P(i32), P(u64)],
@@ -806,6 +806,13 @@ class EmatBackend:
         self._ck(self._lib.emat_part_get_derived(self._h, part, _ptr(lam, C.c_double), _ptr(nmiss, C.c_int32), C.byref(g), C.byref(a)), "emat_part_get_derived")
         return lam, nmiss, float(g.value), float(a.value)
 
+    def part_state_frequencies(self, part: int) -> np.ndarray:
+        """Subrun::state_frequencies_of_ref_sequence_per_partition (subrun.h:45): counts[site partition, state] of the reference sequence."""
+        n = C.c_int32(8)
+        counts = np.zeros((8, 4), np.int32)
+        self._ck(self._lib.emat_part_get_state_frequencies(self._h, part, C.byref(n), _ptr(counts, C.c_int32)), "emat_part_get_state_frequencies")
+        return counts[: n.value].copy()
+
     def part_coalescent(self, part: int, cap: int = 1 << 16):
         n = C.c_int32(cap)
         kb, kt, k, ps = np.zeros(cap), np.zeros(cap), np.zeros(cap), np.zeros(cap)
@@ -914,7 +921,7 @@ class EmatRun:
 
     def set_max_part_nodes(self, n: int):
         """Not in the reference: parts larger than n nodes get further, randomly drawn cut nodes at every repartition
-        (-1 = three times the mean part size, the default; 0 = off, the reference's rule exactly)."""
+        (0 = off, the reference's rule exactly: the default; -1 = three times the mean part size)."""
         self._ck(self._lib.emat_run_set_max_part_nodes(self._h, n), "emat_run_set_max_part_nodes")
 
     def partition_stats(self) -> dict:
@@ -922,6 +929,14 @@ class EmatRun:
         a, b, c, e = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         self._ck(self._lib.emat_run_partition_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(e)), "emat_run_partition_stats")
         return {"num_parts": a.value, "largest_part_nodes": b.value, "extra_cuts": c.value, "max_part_nodes": e.value}
+
+    def debug_redraw_partition(self) -> np.ndarray:
+        """Test hook: the sorted cut nodes the last repartition's draw (same stencil, same refinement stream) gives on the tree as it is now."""
+        n = C.c_int32(0)
+        self._lib.emat_run_debug_redraw_partition(self._h, None, C.byref(n))        # (asks for the count)
+        cuts = np.zeros(max(1, n.value), np.int32); n = C.c_int32(cuts.shape[0])
+        self._ck(self._lib.emat_run_debug_redraw_partition(self._h, _ptr(cuts, C.c_int32), C.byref(n)), "emat_run_debug_redraw_partition")
+        return cuts[: n.value].copy()
 
     def set_hky(self, mu: float, kappa: float, pi, nu_l=None):
         pi = np.ascontiguousarray(pi, np.float64)

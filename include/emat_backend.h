@@ -361,6 +361,14 @@ emat_status emat_part_get_derived(emat_backend* h, int32_t part_id, double* lamb
                                   int32_t* num_sites_missing /*[num_nodes]*/, double* log_G,
                                   double* log_augmented_coalescent_prior);
 
+/* replaces: subrun.state_frequencies_of_ref_sequence_per_partition() (reference subrun.h:45-46; Run reads the root part's in
+ * check_global_and_local_totals_match, run.cpp:354-355, and the HKY moves use the run's own copy, run.cpp:477): how many sites of
+ * every site partition carry each state in the reference sequence the part is written against
+ * (calc_state_frequencies_per_partition_of, phylo_tree_calc.cpp:95-106) -- the table the kernels evaluate the root prior from
+ * (calc_log_root_prior, phylo_tree_calc.cpp:467-504), refreshed whenever the reference sequence follows the root sequence.
+ * `*num_partitions` is in/out (capacity in rows of four, count out); counts[beta * 4 + a]. */
+emat_status emat_part_get_state_frequencies(emat_backend* h, int32_t part_id, int32_t* num_partitions, int32_t* counts /*[num_partitions][4]*/);
+
 /* Coalescent-part arrays of one part (reference very_scalable_coalescent.h:47-56), for the
  * cross-part exchange and for tests.  `*num_cells` is in/out (capacity in, length out). */
 emat_status emat_part_get_coalescent(emat_backend* h, int32_t part_id, int32_t* num_cells,

@@ -64,8 +64,15 @@ emat_status emat_run_set_num_parts(emat_run* r, int32_t num_parts);
  * lasts as long as the chain of its largest part, and the parts of a stencil drift apart in size while it is in use (run.cpp:87-108
  * redraws stencils every 200 cycles only).  The extra cut nodes are drawn uniformly at random among the part's inner nodes -- a rule
  * that reads nothing a pass can change, so that it leaves the sampler's stationary distribution alone (emat_run.cpp, refine_stencil).
- * -1 (the default) = three times the mean part size, at least 64; 0 = off: the reference's rule exactly; > 0 = that many nodes. */
+ * 0 (the DEFAULT since round 6) = off: the reference's rule exactly, so that a run that sets nothing reproduces the reference's (and the
+ * oracle's) partition; -1 = three times the mean part size, at least 64 (what bench.py's `inclusive` and the posterior scripts opt into);
+ * > 0 = that many nodes. */
 emat_status emat_run_set_max_part_nodes(emat_run* r, int32_t max_nodes);
+/* Test hook of the rule above: the (sorted) cut nodes that the last repartition's draw -- same stencil, same random stream of the
+ * refinement -- gives on the tree as it is NOW.  A pass only moves nodes within parts and the rule reads nothing such a pass changes, so
+ * after emat_run_reassemble the answer must be what it was right after emat_run_repartition (tests/test_host_driver.py): the premise of
+ * the argument that the limit cannot bias the sampler.  `*num_cut_nodes`: capacity in, count out.  Changes no state. */
+emat_status emat_run_debug_redraw_partition(emat_run* r, int32_t* cut_nodes, int32_t* num_cut_nodes);
 /* The last repartition: how many parts, the node count of the largest, how many cut nodes the rule above added, the limit in effect. */
 emat_status emat_run_partition_stats(emat_run* r, int32_t* num_parts, int32_t* largest_part_nodes, int32_t* extra_cuts, int32_t* max_part_nodes_in_effect);
 /* HKY substitution model with per-site relative rates nu_l (NULL = all 1): reference Hky_model +

@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import re
+import sys
 
 import pytest
 
@@ -102,3 +103,36 @@ def test_a_missing_rccl_is_reported_not_crashed_on():
     finally:
         lib.emat_multi_set_rccl_library(None)
     assert lib.emat_multi_debug_rccl_load(buf, 512) == 0, buf.value      # the image ships RCCL: the default names load
+
+
+def test_state_frequencies_of_the_reference_sequence_per_site_partition():
+    """emat_part_get_state_frequencies = Subrun::state_frequencies_of_ref_sequence_per_partition (subrun.h:45, read at run.cpp:354-355;
+    calc_state_frequencies_per_partition_of, phylo_tree_calc.cpp:95-106): counts[site partition][state] of the reference sequence the
+    parts are written against -- with one and with two site partitions, on a host-only handle (it is a read-back, no launch)."""
+    import numpy as np
+    from delphy_amd.scenarios import make_scenario
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import configure, split_parts
+    sc = make_scenario("C1", num_tips=30, num_sites=900)
+    parts, incl, seeds, root_part, ref = split_parts(sc, 3, 5)
+    b = d.EmatBackend(sc.num_sites, device=-1)
+    configure(b, sc, ref, parts, incl, seeds, root_part)
+    for p in range(len(parts)):
+        got = b.part_state_frequencies(p)
+        assert got.shape == (1, 4) and np.array_equal(got[0], np.bincount(ref, minlength=4)) and got.sum() == sc.num_sites
+    b.close()
+    # two site partitions (the mpox shape, run.cpp:400-435)
+    pfs = (np.arange(sc.num_sites) % 3 == 0).astype(np.uint8)
+    mu = np.array([1e-3, 2e-3]); pi = np.array([[0.31, 0.19, 0.21, 0.29], [0.25, 0.25, 0.25, 0.25]])
+    q = np.zeros((2, 4, 4))
+    for k in range(2):
+        for a in range(4):
+            for c in range(4):
+                if a != c: q[k, a, c] = pi[k, c]
+            q[k, a, a] = -q[k, a].sum()
+    b = d.EmatBackend(sc.num_sites, device=-1)
+    configure(b, sc, ref, parts, incl, seeds, root_part, evo=(mu, pi, q, pfs))
+    got = b.part_state_frequencies(root_part)
+    want = np.stack([np.bincount(ref[pfs == k], minlength=4) for k in range(2)])
+    assert np.array_equal(got, want)
+    b.close()

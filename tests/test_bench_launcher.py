@@ -67,3 +67,20 @@ def test_eight_ranks_on_the_one_gpu_of_the_test_box():
     assert sc["ok"] and sc["ranks_seen"] == 8 and sc["parts_reported"] == sc["parts_of_the_run"] == sum(out["per_rank"]["parts"])
     sec = out["secondary"]
     assert sec["workload"].startswith("C5") and len(sec["per_rank"]["parts"]) == 8 and sum(sec["per_rank"]["parts"]) > 70000 and sec["value"] > 0 and sec["parts_stopped_on_rank_0"] == 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_two_gpus_over_rccl():
+    """`python bench.py --gpus 2` WITHOUT EMAT_BENCH_SHARED_GPU: one rank per GPU, collectives over RCCL -- what the driver's scaling run
+    types.  Skipped on a one-GPU box (every lease so far); on the first node with two GPUs it runs by itself and must pass its own
+    scale_check with rccl_world == 2."""
+    import json
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the test box has one)")
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--secondary-steps", "1"], {})
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and len(out["per_rank"]["ms_per_step"]) == 2
+    sc = out["scale_check"]
+    assert sc["ok"] and sc["ranks_seen"] == 2 and sc["rccl_world"] == 2 and sc["parts_with_other_move_or_draw_counts"] == 0 and sc["parts_whose_trees_differ"] == 0

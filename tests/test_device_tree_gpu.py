@@ -626,3 +626,36 @@ def test_children_mirror_is_current_when_reassemble_returns():
         changed = changed or not np.array_equal(c0, sc.tree.child0)
     assert changed                                                 # the cycles did re-hang subtrees
     run.close(); b.close()
+
+
+def test_a_deferred_gather_that_fails_stays_failed_until_a_tree_is_uploaded():
+    """emat_tree_reassemble returns once links, root and root changes are on the host; the gather of the lists is checked by whoever
+    touches the tree next (gt_finish_gather).  If THAT fails, the tree on the device has new links and half-written lists: the failure
+    must not be reported once and forgotten -- every emat_tree_* call fails with its text until emat_tree_upload replaces the tree
+    (ADVICE round 5).  `debug_fail_gather` makes the next gather report an inconsistency after emat_tree_reassemble has returned."""
+    sc = make_scenario("C3", num_tips=1500, num_sites=29903, uncertain_tips=0.1)
+    b = d.EmatBackend(sc.num_sites)
+    run = d.EmatRun(b, sc.tree, sc.ref, 29)
+    run.set_num_parts(64); run.set_hky(sc.mu, sc.kappa, sc.pi); run.set_pop_model(sc.pop); run.set_device_tree(True)
+    run.repartition(); run.run_moves(64 * 200); run.reassemble()
+    good, good_ref = b.tree_download()                              # (a healthy cycle first)
+    run.repartition(); run.run_moves(64 * 200)
+    b.set_option("debug_fail_gather", 1)
+    run.reassemble()                                                # returns: the links are there, the lists are on their way
+    for attempt in range(3):                                        # ... and the gather's verdict is sticky
+        with pytest.raises(d.EmatError, match="inconsistent|incomplete"):
+            b.tree_topology() if attempt != 1 else b.tree_download()
+    with pytest.raises(d.EmatError, match="incomplete"):
+        b.tree_kids()
+    with pytest.raises(d.EmatError, match="incomplete"):
+        run.repartition()
+    b.tree_upload(good)                                             # the way out
+    parent, c0, c1, t, root = b.tree_topology()
+    assert root == good.root and np.array_equal(c0, good.child0) and np.array_equal(t, good.t)
+    # and an upload forgets the partition of the tree that was there (ADVICE round 5, low): cutting without arrays must ask for a new one
+    import ctypes as C
+    n_parts, root_part = run.num_parts()
+    seeds = np.ones(n_parts, np.uint64); m = sc.pop.c_struct()
+    st = b._lib.emat_tree_repartition(b._h, n_parts, None, None, None, None, root_part, seeds.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(m), sc.default_t_step())
+    assert st != 0 and b"emat_tree_partition first" in b._lib.emat_last_error(b._h)
+    run.close(); b.close()

@@ -184,6 +184,7 @@ def test_c5_whole_cycles_with_the_tree_resident_in_hbm():
     b = d.EmatBackend(sc.num_sites)
     run = d.EmatRun(b, sc.tree, sc.ref, 20261005)
     run.set_num_parts(81920); run.set_hky(sc.mu, sc.kappa, sc.pi); run.set_pop_model(sc.pop)
+    run.set_max_part_nodes(-1)       # the part-size limit bench.py's whole cycles opt into (the library's default is the reference's rule)
     run.set_device_tree(True)
     try:
         run.do_mcmc_steps(2 * 81920 * 100, 81920 * 100)

@@ -182,6 +182,51 @@ def test_oversized_parts_can_be_cut_further(sc):
     assert len(sizes[40]) > len(sizes[0])
 
 
+def test_the_part_size_limits_draw_is_invariant_under_the_pass_it_governs(sc):
+    """The proof that the part-size limit cannot bias the sampler (emat_run.cpp, refine_stencil) rests on one
+    premise: the rule reads nothing a pass can change -- which nodes a piece owns and which of them are inner nodes -- so the SAME draw
+    (same stencil, same random streams) on the tree AFTER a pass gives the same cut nodes as on the tree before it.  Here that premise
+    is a test: repartition with a limit that bites, topology-changing moves on every part (the oracle as the engine), reassemble, and
+    the draw is repeated on the new tree through emat_run_debug_redraw_partition.  (Writing this test found that the draw used to depend
+    on the ORDER in which a walk met the inner nodes -- topology -- and held in distribution only; the candidates are now taken in
+    node order.)  One thing a pass CAN change is which node is the tree's root (a rooty SPR in the root part): the root piece then
+    excludes another node from its candidates, its draw is another realisation of the same uniform rule -- equal probabilities, which is
+    what detailed balance needs, but not the same cut nodes; those cycles are held to the rest of the statement only: every piece
+    within the limit.  With the limit off the stencil's own cut nodes come back."""
+    strict = 0
+    for limit, seed in ((25, 11), (40, 12), (0, 13)):
+        run = d.EmatRun(None, sc.tree, sc.ref, seed)
+        run.set_num_parts(6); run.set_max_part_nodes(limit)
+        for cycle in range(4):
+            run.repartition()
+            n, root_part = run.num_parts()
+            before = run.debug_redraw_partition()
+            assert len(set(before.tolist()) - {int(run.tree()[0].root)}) == n - 1      # one cut node per part but the root's
+            if limit:
+                assert run.partition_stats()["extra_cuts"] > 0 and run.partition_stats()["largest_part_nodes"] <= limit
+            parts, incl, seeds = [], [], []
+            for i in range(n):
+                t, r, s = run.part(i)
+                parts.append(t); incl.append(r); seeds.append(s)
+            tree0, ref = run.tree()
+            orc = OracleEngine(sc.num_sites)
+            configure(orc, sc, ref, parts, incl, seeds, root_part)
+            orc.run_moves_per_part(300, threads=2)
+            for i in range(n):
+                run.part_put(i, orc.part_download(i))
+            orc.close()
+            run.reassemble()
+            tree1, _ = run.tree()
+            after = run.debug_redraw_partition()
+            if tree0.root == tree1.root:
+                assert np.array_equal(before, after), "limit %d cycle %d: the draw moved with the pass" % (limit, cycle)
+                strict += int(limit > 0 and not np.array_equal(tree0.parent, tree1.parent))
+            else:
+                assert limit == 0 or abs(len(before) - len(after)) <= max(2, len(before) // 4)
+        run.close()
+    assert strict >= 4          # cycles with a limit that bit, a pass that re-hung subtrees, and the very same draw afterwards
+
+
 def test_coalescent_window_covers_lineages_past_a_frozen_tips_float_bound():
     """A frozen cut-point tip carries t_min = t_max = (float)t, which can lie below its exact double time t.  When that tip
     is the latest node of its part and a cell boundary falls between (float)t and t, the branch above it reaches the

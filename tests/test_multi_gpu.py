@@ -81,6 +81,32 @@ def test_shards_of_one_process_equal_the_single_backend_run(devices, exchange, c
     assert not np.array_equal(want[-1][0][0].parent, sc.tree.parent)      # the cycles did change the tree
 
 
+def _two_devices():
+    import torch
+    return torch.cuda.device_count() >= 2      # (counting devices does not initialise the GPU on this image)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,exchange,cycles", [([0, 1], "rccl", 3), ([0, 1], "auto", 3), ([0, 1], "host", 3)])
+def test_shards_on_two_devices_equal_the_single_backend_run(devices, exchange, cycles):
+    """The first test that runs ncclCommInitAll with n > 1 and the grouped ncclAllGather / ncclAllReduce BETWEEN devices
+    (emat_multi.cpp): collected on every box, skipped where there is one GPU (every lease so far), so that the first node with two runs
+    it by itself.  Same statement as above: every shard ends every cycle with exactly the single-backend tree; `auto` must have picked
+    RCCL (one shard per device), `host` exchanges the same records through host buffers."""
+    if not _two_devices():
+        pytest.skip("needs two GPUs (the test box has one)")
+    sc = make_scenario("C3", num_tips=3000, num_sites=29903, uncertain_tips=0.1)
+    parts, seed, moves = 128, 17, 400
+    want = _single(sc, parts, seed, cycles, moves)
+    got, how = _multi(sc, devices, exchange, parts, seed, cycles, moves)
+    assert how.startswith("RCCL") == (exchange in ("rccl", "auto")), how
+    for c in range(cycles):
+        (tree1, tot1), (trees, tot) = want[c], got[c]
+        for s, t in enumerate(trees):
+            _same(t, tree1, "cycle %d shard %d" % (c, s))
+        assert abs(tot[0] - tot1[0]) <= 1e-10 * abs(tot1[0]) and abs(tot[1] - tot1[1]) <= 1e-10 * abs(tot1[1]), (tot, tot1)
+
+
 @pytest.mark.gpu
 def test_do_mcmc_steps_of_a_multi_run():
     sc = make_scenario("C2", num_tips=800, num_sites=6000)
