@@ -184,10 +184,10 @@ def inclusive_cycles(sc, args, cycles=210):
     import delphy_amd as d
     per_cycle = 50 * sc.tree.num_nodes
 
-    def one(device_tree, limit, n):
+    def one(device_tree, limit, n, parts=None):
         b = d.EmatBackend(sc.num_sites)
         run = d.EmatRun(b, sc.tree, sc.ref, 20261001)
-        run.set_num_parts(args.parts)
+        run.set_num_parts(args.parts if parts is None else parts)
         run.set_max_part_nodes(limit)
         run.set_hky(sc.mu, sc.kappa, sc.pi)
         run.set_pop_model(sc.pop)
@@ -217,25 +217,105 @@ def inclusive_cycles(sc, args, cycles=210):
                what="emat_run_do_mcmc_steps with the tree resident in HBM: stencil + partition on the host's copy of the topology, part slabs cut and "
                     "gathered back by kernels, %d local moves per cycle (no global moves), wall clock, %d successive cycles (the reference redraws its stencils every 200)" % (per_cycle, cycles),
                host_tree=dict(host, what="the same cycles with the tree on the host: subtree build + slab encode + H2D + moves + D2H + decode + reassemble"))
+    if args.parts_auto and args.workload == "C4":
+        # what N >= 2 cut (bench.py requests 8192 parts per GPU; the partitioner's floor of ten nodes per part caps C4 at about 13 000): whole cycles of ONE GPU on that
+        # partition, so that a scaling curve of `inclusive` has its x 1 on the same decomposition as its other points
+        out["grown_partition"] = dict(one(True, args.max_part_nodes, max(10, cycles // 5), parts=8 * args.parts),
+                                      what="the same cycles with %d parts requested, the partition bench.py --gpus N >= 2 runs" % (8 * args.parts))
     if ref_rule is not None:
         out["reference_partition_rule"] = dict(ref_rule, what="the same cycles with emat_run_set_max_part_nodes(0): the reference's partitioning rule exactly, whose parts drift apart in size between "
                                                                 "two redraws of the stencils; every part makes the same number of moves, so a cycle lasts as long as the chain of its largest part")
     return out
 
 
+def inclusive_sharded(sc, args, parts, cycles, world, rank, local_rank, shared_gpu, dist, torch):
+    """Whole SHARDED cycles (N > 1), the counterpart of `inclusive_cycles`: every rank keeps the whole tree in its HBM and a contiguous
+    block of the parts; one cycle = repartition (every rank draws the same partition, cuts its own block) -> the reference's 50 x nodes
+    local moves -> gather of the local parts, all-gather of what they own (the tree's lists, once per cycle), apply, totals
+    (delphy_amd.sharding.ShardedEngine.cycle = reference Run::do_mcmc_steps without global moves, run.cpp:622-657).  Wall clock per
+    cycle, MAX over ranks; rank 0's time by phase.  Over RCCL the node exchange stays in device buffers; with EMAT_BENCH_SHARED_GPU
+    (all ranks on one GPU, gloo) it goes through host buffers and the times mean nothing -- only that the path runs."""
+    import numpy as np
+    from delphy_amd.sharding import ShardedEngine
+    dev = "cpu" if shared_gpu else "cuda"
+    allreduce = allgather = None
+    if shared_gpu:
+        def allreduce(arr, op):
+            t = torch.from_numpy(np.ascontiguousarray(arr))
+            dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op])
+            return t.numpy()
+
+        def allgather(buf):
+            sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(sizes, torch.tensor([buf.shape[0]], dtype=torch.int64))
+            n = [int(x.item()) for x in sizes]
+            padded = torch.zeros(max(max(n), 1), dtype=torch.uint8); padded[: buf.shape[0]] = torch.from_numpy(np.ascontiguousarray(buf))
+            out = [torch.zeros_like(padded) for _ in range(world)]
+            dist.all_gather(out, padded)
+            return [o[: n[r]].numpy() for r, o in enumerate(out)]
+    eng = ShardedEngine(sc, num_parts=parts, seed=20261001, rank=rank, world=world, device=local_rank, use_lds=not args.no_lds, allreduce=allreduce, allgather_bytes=allgather,
+                        max_part_nodes=args.max_part_nodes, device_tree=True)
+    eng.topology = not args.no_topology
+    eng.only_displace = args.only_displace
+    per_cycle = 50 * sc.tree.num_nodes
+    eng.cycle(per_cycle)                      # warm-up cycle: tree upload, allocations, the first ten stencils, communicator warm-up
+    dist.barrier(); torch.cuda.synchronize()
+    eng.spans = {}
+    rows, nbytes = [], []
+    t0 = time.perf_counter()
+    for _ in range(cycles):
+        t1 = time.perf_counter()
+        eng.cycle(per_cycle)
+        rows.append((time.perf_counter() - t1) * 1e3)
+        nbytes.append(getattr(eng, "last_exchange_bytes", 0))
+    dist.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    total_parts, local_parts = eng.total_parts, eng.num_local_parts
+    spans = {k: v / cycles * 1e3 for k, v in sorted(eng.spans.items())}
+    mine = torch.tensor([spans.get(k, 0.0) for k in sorted(spans)] + [float(local_parts)], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    eng.close()
+    a = np.array(rows)
+    return {"value": cycles * per_cycle / dt, "unit": "moves/s", "cycles": cycles, "moves_per_cycle": per_cycle, "ms_per_cycle": dt / cycles * 1e3,
+            "ms_per_cycle_p10": float(np.percentile(a, 10)), "ms_per_cycle_p50": float(np.percentile(a, 50)), "ms_per_cycle_p90": float(np.percentile(a, 90)),
+            "parts_requested": parts, "parts_of_the_last_cycle": total_parts, "max_part_nodes": args.max_part_nodes,
+            "exchange_bytes_per_cycle_all_ranks": float(np.mean(nbytes)),
+            "ms_per_cycle_by_phase_rank_0": spans,
+            "ms_per_cycle_by_phase_max_over_ranks": {k: max(float(e[i].item()) for e in every) for i, k in enumerate(sorted(spans))},
+            "parts_per_rank_last_cycle": [int(e[-1].item()) for e in every],
+            "what": "ShardedEngine.cycle with the tree resident in every rank's HBM: every rank draws the same partition and cuts its own block of parts, %d local moves per cycle over "
+                    "all ranks (no global moves), gather of the local parts, one all-gather of the nodes they own (%s), apply, all-reduce of the totals; wall clock, %d successive cycles, "
+                    "MAX over ranks" % (per_cycle, "host buffers over gloo, all ranks on ONE GPU: a plumbing check, the times mean nothing" if shared_gpu else "device buffers over RCCL", cycles)}
+
+
 def measure_secondary(args, world, rank, local_rank, shared_gpu, allreduce, dist, torch):
     """`args.secondary` (C5) through the same timed region as the headline: W warm-up passes, K passes between barriers, the MAX over
     ranks of the time, all parts of the run / that time."""
-    import numpy as np
     from delphy_amd.scenarios import make_scenario
-    from delphy_amd.sharding import ShardedEngine
-    moves = 1000
     t0 = time.perf_counter()
     sc2 = make_scenario(args.secondary)
     parts = max(DEFAULT_PARTS.get(args.secondary, 8192), 8192 * world)
+    return measure_resident(args, sc2, parts, 1000, args.secondary_steps, world, rank, local_rank, shared_gpu, allreduce, dist, torch, t0)
+
+
+def measure_resident(args, sc2, parts, moves, steps, world, rank, local_rank, shared_gpu, allreduce, dist, torch, t0=None, moves_of_a_step=None):
+    """A workload / decomposition through the same timed region as the headline: one warm-up pass, `steps` passes between barriers, the
+    MAX over ranks of the time, all parts of the run / that time.  `moves_of_a_step`: scale the moves per part so that a step has that
+    many moves whatever the partition yields (the headline's rule at N > 1)."""
+    import numpy as np
+    from delphy_amd.sharding import ShardedEngine
+    t0 = time.perf_counter() if t0 is None else t0
     eng = ShardedEngine(sc2, num_parts=parts, seed=20261001, rank=rank, world=world, device=local_rank, use_lds=not args.no_lds, allreduce=allreduce, max_part_nodes=args.max_part_nodes)
+    eng.topology = not args.no_topology
+    eng.only_displace = args.only_displace
     eng.setup()
     setup_s = time.perf_counter() - t0
+    if moves_of_a_step is not None:
+        moves = max(1, int(round(moves_of_a_step / eng.total_parts)))
 
     def barrier():
         if world > 1:
@@ -246,11 +326,11 @@ def measure_secondary(args, world, rank, local_rank, shared_gpu, allreduce, dist
     eng.backend.run_moves_per_part(moves)
     barrier()
     t1 = time.perf_counter()
-    for _ in range(args.secondary_steps):
+    for _ in range(steps):
         eng.backend.run_moves_per_part(moves)
     barrier()
     dt = time.perf_counter() - t1
-    rank_ms, rank_parts, rank_setup = [dt / args.secondary_steps * 1e3], [eng.num_local_parts], [setup_s]
+    rank_ms, rank_parts, rank_setup = [dt / steps * 1e3], [eng.num_local_parts], [setup_s]
     if world > 1:
         mine = torch.tensor([rank_ms[0], float(eng.num_local_parts), setup_s], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
         every = [torch.zeros_like(mine) for _ in range(world)]
@@ -263,7 +343,7 @@ def measure_secondary(args, world, rank, local_rank, shared_gpu, allreduce, dist
     total = eng.total_parts
     eng.close()
     return {"workload": "%s: synthetic %d-tip EMAT, %d sites, %d partition parts (%d nodes), %d moves/part/step" % (sc2.name, sc2.num_tips, sc2.num_sites, total, sc2.tree.num_nodes, moves),
-            "value": total * moves * args.secondary_steps / dt, "unit": "moves/s", "steps": args.secondary_steps, "warmup": 1, "ms_per_step": dt / args.secondary_steps * 1e3,
+            "value": total * moves * steps / dt, "unit": "moves/s", "steps": steps, "warmup": 1, "ms_per_step": dt / steps * 1e3, "parts_requested": parts, "parts": total, "moves_per_part": moves,
             "scaling": "strong", "per_rank": {"ms_per_step": rank_ms, "parts": rank_parts, "setup_s": rank_setup}, "parts_stopped_on_rank_0": bad}
 
 
@@ -544,12 +624,35 @@ def main():
     if args.secondary and args.secondary != args.workload and args.tips is None:
         secondary = measure_secondary(args, world, rank, local_rank, shared_gpu, allreduce, dist, torch)
 
+    # Both decompositions side by side: `value` at N = 1 runs the 8192-part request, at N >= 2 the request grows with the GPUs and the moves per part
+    # shrink so that a step keeps its moves.  A scaling curve read off `value` alone would mix the two: N = 1 therefore also times the grown partition, and N >= 2 the
+    # fixed one, through the same timed region.
+    decompositions = None
+    if args.parts_auto and args.moves_auto and args.workload == "C4" and args.tips is None:
+        step_moves = 1000.0 * base_parts
+        if world == 1:
+            decompositions = {"grown_partition": dict(measure_resident(args, sc, 8 * base_parts, 1000, args.steps, world, rank, local_rank, shared_gpu, allreduce, dist, torch, moves_of_a_step=step_moves),
+                                                      what="the partition bench.py --gpus N >= 2 runs (8192 parts requested per GPU; the partitioner's floor of ten nodes per part caps C4 at about 13 000), on this one GPU, "
+                                                           "with the moves of a step kept: the x 1 of a scaling curve read on that decomposition")}
+        else:
+            decompositions = {"fixed_partition": dict(measure_resident(args, sc, base_parts, 1000, args.steps, world, rank, local_rank, shared_gpu, allreduce, dist, torch),
+                                                      what="N = 1's partition (8192 parts requested, 1000 moves per part) sharded over these ranks: the other decomposition, on which a rank of N >= 2 holds "
+                                                           "fewer parts than wave slots and its pass is its slowest chain"),
+                              "grown_partition": {"value": value, "ms_per_step": dt / args.steps * 1e3, "parts": total_parts, "parts_requested": args.parts, "moves_per_part": args.moves_per_part,
+                                                  "what": "the headline `value` of this line"}}
+
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_base = cpu_baseline(sc, args.parts, 20261001, args.cpu_seconds, eng.t_step)
     inclusive = None
     if rank == 0 and world == 1 and not args.no_inclusive:
         inclusive = inclusive_cycles(sc, args, args.inclusive_cycles)
+    if world > 1 and not args.no_inclusive:
+        # whole sharded cycles: the reference's steps/s is inclusive of everything (tools/delphy.cpp:44-51; run.cpp:622-657), and so is this -- on both decompositions
+        cyc = max(4, min(args.inclusive_cycles, 60))
+        inclusive = inclusive_sharded(sc, args, args.parts, cyc, world, rank, local_rank, shared_gpu, dist, torch)
+        if args.parts != base_parts:
+            inclusive["fixed_partition"] = inclusive_sharded(sc, args, base_parts, max(4, cyc // 3), world, rank, local_rank, shared_gpu, dist, torch)
 
     if rank == 0:
         out = {
@@ -578,6 +681,7 @@ def main():
             },
             "per_rank": {"ms_per_step": rank_ms, "kernel_ms": rank_kernel_ms, "parts": rank_parts, "setup_s": rank_setup_s},
             "secondary": secondary,
+            "decompositions": decompositions,
             # "bound" names the yardstick the contract asks for; "limiter" says what actually limits the kernel
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_read": traffic_read, "traffic_write": traffic_write, "traffic_source": traffic_source,

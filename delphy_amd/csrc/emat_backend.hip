@@ -1833,6 +1833,7 @@ emat_status emat_backend_destroy(emat_backend* h) {
  * emat_backend_create; a process that embeds the library sets them per handle instead, and nothing in its environment reaches them. */
 emat_status emat_set_option(emat_backend* h, const char* key, const char* value) {
   if (!h || !key || !value) return EMAT_ERR_INVALID_ARGUMENT;
+  if (strcmp(key, "debug_fail_gather") == 0) { h->cfg_debug_fail_gather = atoi(value) != 0; return EMAT_OK; }   // (a test hook that is armed in the middle of a run)
   if (h->slabs_on_device) return fail(h, EMAT_ERR_STATE, "emat_set_option: options are set before the first launch");
   const std::string k(key);
   const char* e = value;

@@ -106,6 +106,15 @@ class ShardedEngine:
         self.max_part_nodes = max_part_nodes   # not in the reference: cut larger parts further (0 = the reference's rule)
         self.device_tree = device_tree         # every rank keeps the whole tree in its HBM; ranks exchange node updates, not part trees
         self._configured = False
+        self.spans = None                      # {phase: seconds} when a caller wants a cycle's time booked by phase (bench.py `inclusive` at N > 1)
+
+    def _lap(self, name, t0):
+        """Books the time since t0 under `name` (only when self.spans is a dict) and returns now."""
+        import time
+        t1 = time.perf_counter()
+        if self.spans is not None:
+            self.spans[name] = self.spans.get(name, 0.0) + (t1 - t0)
+        return t1
 
     def close(self):
         self.run.close()
@@ -126,14 +135,18 @@ class ShardedEngine:
 
     def repartition(self):
         """Cut the tree (identically on every rank), upload this rank's parts, build their coalescent parts across ranks."""
+        import time
         if not self._configured:
             self._configure()
+        t = time.perf_counter()
         self.run.repartition()
         self.total_parts, self.root_part = self.run.num_parts()
         self.part_lo, self.part_hi, self.local_root = self.run.shard_range()
         self.num_local_parts = self.part_hi - self.part_lo
+        t = self._lap("1 repartition (stencil, partition_tree, cut-point states, slabs of the local block)", t)
         if not self.device_tree:      # (with the tree on the devices every rank builds the whole grid itself, identically: no exchange)
             self.build_coalescent()
+            self._lap("1b coalescent grid (three all-reduces)", t)
 
     def setup(self):
         """First cut + upload (what bench.py and the probes call before timing resident passes)."""
@@ -158,44 +171,74 @@ class ShardedEngine:
 
     def reassemble(self):
         """Every rank receives every other rank's parts and gathers the same whole tree (reference run.cpp:195-256)."""
+        import time
+        t0 = time.perf_counter()
         if self.device_tree and self.world > 1:
             # the trees stay on the devices: the rank with the root part publishes how the root sequence changed, every rank gathers
             # its own parts into its own copy of the tree, and the ranks exchange what their parts own (include/emat_backend.h)
             b = self.backend
             rd = b.tree_root_deltas()
+            t0 = self._lap("3 wait for the pass + root-sequence changes", t0)
             mine = np.zeros(0, np.uint8) if rd is None else np.concatenate([np.array([len(rd[0])], np.int32).view(np.uint8), rd[0].view(np.uint8), rd[1], rd[2]])
             owner = [g for g in self.allgather_bytes(mine) if g.shape[0] > 0]
             assert len(owner) == 1, "exactly one rank holds the root part"
             k = int(owner[0][:4].view(np.int32)[0])
             site = owner[0][4:4 + 4 * k].view(np.int32).copy(); frm = owner[0][4 + 4 * k:4 + 5 * k].copy(); to = owner[0][4 + 5 * k:4 + 6 * k].copy()
+            t0 = self._lap("4 all-gather of the root-sequence changes (small)", t0)
             b.tree_gather_local(site, frm, to)
+            t0 = self._lap("5 gather of the local parts into the local copy of the tree", t0)
+            nbytes = 0
             if self.allgather_device is not None:
                 # device buffers end to end: the export kernels write into the tensor RCCL sends, the apply kernels read what it delivered
                 need = b.tree_export_size()
-                for r, t in enumerate(self.allgather_device(need, lambda mine: b.tree_export_nodes_into(mine.data_ptr(), int(mine.numel())))):
+                got = self.allgather_device(need, lambda mine: b.tree_export_nodes_into(mine.data_ptr(), int(mine.numel())))
+                t0 = self._lap("6 export of the local nodes + all-gather (device buffers)", t0)
+                for r, t in enumerate(got):
+                    nbytes += int(t.numel())
                     if r != self.rank:
                         b.tree_apply_nodes_at(t.data_ptr(), int(t.numel()))
             else:
                 exported = b.tree_export_nodes()
-                for r, buf in enumerate(self.allgather_bytes(exported)):
+                got = self.allgather_bytes(exported)
+                t0 = self._lap("6 export of the local nodes + all-gather (host buffers)", t0)
+                for r, buf in enumerate(got):
+                    nbytes += int(buf.shape[0])
                     if r != self.rank:
                         b.tree_apply_nodes(buf)
+            self.last_exchange_bytes = nbytes
+            t0 = self._lap("7 apply of the other ranks' nodes", t0)
             b.tree_reassemble_end()
             self.run.note_device_reassembled(site, to)
+            self._lap("8 children mirror to the host, driver state", t0)
             return
         if self.world > 1:
             mine = self.run.pack_local_parts()
-            for r, buf in enumerate(self.allgather_bytes(mine)):
+            t0 = self._lap("3 wait for the pass + pack of the local parts", t0)
+            got = self.allgather_bytes(mine)
+            self.last_exchange_bytes = int(sum(g.shape[0] for g in got))
+            t0 = self._lap("6 all-gather of the serialised parts (host buffers)", t0)
+            for r, buf in enumerate(got):
                 if r != self.rank:
                     self.run.unpack_parts(buf)
+            t0 = self._lap("7 unpack of the other ranks' parts", t0)
         self.run.reassemble()
+        self._lap("8 reassemble", t0)
 
     def cycle(self, local_moves: int):
         """One cycle of reference Run::do_mcmc_steps without its global moves (run.cpp:622-657)."""
+        import time
         self.repartition()
+        t = time.perf_counter()
         self.run.run_moves_sharded(local_moves)
+        if self.spans is not None:           # (booked apart from the reassemble, which would wait for the kernels anyway: same critical path)
+            t = self._lap("2a launch of the pass", t)
+            self.backend.synchronize()
+            self._lap("2b the pass (kernels of the local block)", t)
         self.reassemble()
-        return self.global_totals()
+        t = time.perf_counter()
+        tot = self.global_totals()
+        self._lap("9 totals (all-reduce of two doubles)", t)
+        return tot
 
     def tree(self):
         return self.run.tree()
