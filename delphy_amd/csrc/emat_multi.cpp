@@ -20,10 +20,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -82,26 +85,57 @@ struct emat_multi {
   int64_t nodes = 0;
   bool use_rccl = false;
   bool parts_out = false;
+  bool following = false;   // shards 1.. take shard 0's partition draws (emat_run_follow_draws)
   Rccl rccl;
   std::string last_error;
   std::string exchange_note;
 
   emat_status fail(emat_status st, const std::string& m) { last_error = m; return st; }
-  // the same call on every shard, each on a thread of its own (the host work of a repartition is per shard; kernels are launched
-  // asynchronously, so the GPUs run side by side whatever the host does next)
+  // One persistent worker thread per shard (round 6; until then every phase of a cycle started and joined n threads: six fan-outs per
+  // cycle).  A phase hands every worker the same job with its shard's index and waits for all of them; the host work of a phase is per
+  // shard, kernels are launched asynchronously, so the GPUs run side by side whatever the host does next.  Shard 0's job runs on the
+  // calling thread.
+  struct Workers {
+    std::vector<std::thread> threads;
+    std::mutex mu; std::condition_variable go, done;
+    const std::function<int(int)>* job = nullptr;
+    uint64_t generation = 0; int pending = 0; bool quit = false;
+    std::vector<int> rc;
+    void start(int n) {
+      rc.assign((size_t)n, EMAT_OK);
+      for (int i = 1; i < n; ++i) threads.emplace_back([this, i] {
+        uint64_t seen = 0;
+        for (;;) {
+          const std::function<int(int)>* j;
+          { std::unique_lock<std::mutex> lk(mu); go.wait(lk, [&] { return quit || generation != seen; }); if (quit) return; seen = generation; j = job; }
+          const int r = (*j)(i);
+          { std::lock_guard<std::mutex> lk(mu); rc[(size_t)i] = r; if (--pending == 0) done.notify_one(); }
+        }
+      });
+    }
+    void run(const std::function<int(int)>& f) {
+      const int n = (int)rc.size();
+      if (n > 1) { std::lock_guard<std::mutex> lk(mu); job = &f; pending = n - 1; ++generation; }
+      if (n > 1) go.notify_all();
+      rc[0] = f(0);
+      if (n > 1) { std::unique_lock<std::mutex> lk(mu); done.wait(lk, [&] { return pending == 0; }); }
+    }
+    void stop() {
+      { std::lock_guard<std::mutex> lk(mu); quit = true; }
+      go.notify_all();
+      for (auto& t : threads) t.join();
+      threads.clear();
+    }
+  } workers;
   template <class F> emat_status on_every_shard(F&& f) {
     const int n = (int)shards.size();
-    std::vector<int> rc(n, EMAT_OK);
-    if (n == 1) rc[0] = f(0);
-    else {
-      std::vector<std::thread> th;
-      for (int i = 0; i < n; ++i) th.emplace_back([&, i] { rc[i] = f(i); });
-      for (auto& t : th) t.join();
-    }
-    for (int i = 0; i < n; ++i) if (rc[i] != EMAT_OK) {
+    const std::function<int(int)> job = [&](int i) { return (int)f(i); };
+    workers.run(job);
+    const std::vector<int>& rc = workers.rc;
+    for (int i = 0; i < n; ++i) if (rc[(size_t)i] != EMAT_OK) {
       const char* e = emat_run_last_error(shards[i].run);
       const char* b = emat_last_error(shards[i].backend);
-      return fail((emat_status)rc[i], "shard " + std::to_string(i) + " (device " + std::to_string(shards[i].device) + "): " + (e && *e ? e : (b ? b : "")));
+      return fail((emat_status)rc[(size_t)i], "shard " + std::to_string(i) + " (device " + std::to_string(shards[i].device) + "): " + (e && *e ? e : (b ? b : "")));
     }
     return EMAT_OK;
   }
@@ -147,6 +181,7 @@ emat_status emat_run_create_multi(const int32_t* devices, int32_t n, const emat_
     st = emat_run_set_shard(s.run, i, n); if (st) return cleanup(st);
     st = emat_run_set_device_tree(s.run, 1); if (st) return cleanup(st);
   }
+  m->workers.start(n);
   // the exchange: RCCL when asked for (1) or possible (2: every shard on a device of its own and librccl.so loads), else host memory
   if (exchange == 1 && !distinct) return cleanup(EMAT_ERR_INVALID_ARGUMENT);   // RCCL refuses two ranks on one device
   if (exchange != 0 && distinct) {
@@ -170,6 +205,7 @@ emat_status emat_run_create_multi(const int32_t* devices, int32_t n, const emat_
 
 emat_status emat_multi_destroy(emat_multi* m) {
   if (!m) return EMAT_OK;
+  m->workers.stop();
   for (auto& s : m->shards) {
     (void)hipSetDevice(s.device);
     if (s.comm) m->rccl.CommDestroy(s.comm);
@@ -213,7 +249,18 @@ emat_status emat_multi_set_paranoid(emat_multi* m, int32_t on) { M_EVERY(emat_ru
 /* Run::repartition on every shard: the same stencil pick, the same cut, every shard builds the slabs of its own block of parts. */
 emat_status emat_multi_repartition(emat_multi* m) {
   if (!m) return EMAT_ERR_INVALID_ARGUMENT;
-  emat_status st = m->on_every_shard([&](int i) { return (int)emat_run_repartition(m->shards[(size_t)i].run); });
+  emat_status st;
+  // ONE draw per process (round 6): shard 0 picks and refines the cycle's stencil -- on the host pool, with the whole machine to itself -- and
+  // the others take its cut nodes (emat_run_follow_draws); every shard then cuts its own copy of the tree and builds its own block's slabs,
+  // side by side.  (Until then every shard drew and refined the same stencil on a pool of its own.)
+  if (m->shards.size() > 1) {
+    if (!m->following) {   // (set up here rather than at creation: the partition settings are the caller's until the first cut)
+      for (size_t i = 1; i < m->shards.size(); ++i) { st = emat_run_follow_draws(m->shards[i].run, m->shards[0].run); if (st) return m->fail(st, emat_run_last_error(m->shards[i].run)); }
+      m->following = true;
+    }
+    st = emat_run_draw_partition(m->shards[0].run); if (st) return m->fail(st, emat_run_last_error(m->shards[0].run));
+  }
+  st = m->on_every_shard([&](int i) { return (int)emat_run_repartition(m->shards[(size_t)i].run); });
   if (st == EMAT_OK) m->parts_out = true;
   return st;
 }
@@ -243,15 +290,23 @@ emat_status emat_multi_reassemble(emat_multi* m) {
   }
   // (1) how the root sequence changed: known to the shard that holds the root part
   std::vector<int32_t> site((size_t)m->L); std::vector<uint8_t> from((size_t)m->L), to((size_t)m->L);
-  int32_t nd = -1; int owners = 0;
-  for (int i = 0; i < n; ++i) {
-    std::vector<int32_t> s1((size_t)m->L); std::vector<uint8_t> f1((size_t)m->L), t1((size_t)m->L);
+  int32_t nd = -1; std::atomic<int> owners{0};
+  // (every shard is asked -- the call also waits for the shard's pass -- side by side; only the owner of the root part has room for an answer)
+  int owner_shard = -1;
+  for (int i = 0; i < n; ++i) { int32_t lo = 0, hi = 0, lr = -1; if (emat_run_shard_range(m->shards[(size_t)i].run, &lo, &hi, &lr) == EMAT_OK && lr >= 0) owner_shard = i; }
+  std::vector<int32_t> counts((size_t)n, -1);
+  st = m->on_every_shard([&](int i) {
     int32_t k = -1;
-    st = emat_tree_get_root_deltas(m->shards[(size_t)i].backend, &k, s1.data(), f1.data(), t1.data(), m->L);
-    if (st) return m->fail(st, std::string("shard ") + std::to_string(i) + ": " + emat_last_error(m->shards[(size_t)i].backend));
-    if (k >= 0) { ++owners; nd = k; site.swap(s1); from.swap(f1); to.swap(t1); }
-  }
-  if (owners != 1) return m->fail(EMAT_ERR_INTERNAL, "exactly one shard must hold the root part");
+    const bool mine = (i == owner_shard);
+    emat_status s1 = emat_tree_get_root_deltas(m->shards[(size_t)i].backend, &k, mine ? site.data() : nullptr, mine ? from.data() : nullptr, mine ? to.data() : nullptr, mine ? m->L : 0);
+    if (s1 == EMAT_ERR_BUFFER_TOO_SMALL && !mine) s1 = EMAT_ERR_INTERNAL;   // (a shard the drivers do not know as the owner reports root changes)
+    counts[(size_t)i] = k;
+    if (k >= 0) ++owners;
+    return (int)s1;
+  });
+  if (st) return st;
+  if (owners.load() != 1 || owner_shard < 0 || counts[(size_t)owner_shard] < 0) return m->fail(EMAT_ERR_INTERNAL, "exactly one shard must hold the root part");
+  nd = counts[(size_t)owner_shard];
   // (2) every shard: its own parts into its own copy of the tree; (3) what its parts own, as one buffer
   st = m->on_every_shard([&](int i) {
     Shard& s = m->shards[(size_t)i];

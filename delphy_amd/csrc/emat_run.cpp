@@ -267,6 +267,36 @@ struct RunDriver {
     return cuts;
   }
 
+  // ---- the draw of a cycle's partition: refresh_partition_stencils (run.cpp:87-108), the pick, and the part-size limit's refinement.
+  // Apart from the cut itself so that the run drivers of ONE process (emat_multi: a driver per GPU, all with the same seed, all bound to
+  // draw the very same thing) draw once: the leader draws (emat_run_draw_partition, or implicitly at its repartition), a follower
+  // (emat_run_follow_draws) takes the leader's cut nodes -- 8 000-14 000 integers behind a shared pointer -- instead of walking the tree
+  // again on the same host cores (eight shards refined the same stencil eight times).  Needs tp_* (sync_topology /
+  // fetch_device_topology).
+  std::shared_ptr<const std::vector<int32_t>> drawn; uint64_t drawn_for_epoch = ~0ull;
+  RunDriver* follow = nullptr;   // the driver whose draws this one takes (same process, same seed, same tree)
+  void draw_partition() {
+    if (stencils.empty() || stencil_refresh_countdown <= 0) {
+      stencils.clear();
+      for (int i = 0; i < 10; ++i) stencils.push_back(generate_random_partition_stencil());
+      stencil_refresh_countdown = 200;
+    }
+    --stencil_refresh_countdown;
+    last_pick = bitgen.below((int)stencils.size()); last_refine_epoch = epoch;
+    drawn = std::make_shared<const std::vector<int32_t>>(refine_stencil(stencils[(size_t)last_pick]));
+    drawn_for_epoch = epoch;
+  }
+  emat_status ensure_draw() {   // the cut nodes of the partition of this epoch in `drawn`
+    if (follow) {
+      if (follow->drawn_for_epoch != epoch || !follow->drawn) return fail(EMAT_ERR_STATE, "this run takes its partition draws from another one (emat_run_follow_draws), which has not drawn this cycle's yet (emat_run_draw_partition on the leader first)");
+      drawn = follow->drawn; drawn_for_epoch = epoch;
+      last_pick = follow->last_pick; last_refine_epoch = follow->last_refine_epoch; last_extra_cuts = follow->last_extra_cuts;
+      return EMAT_OK;
+    }
+    if (drawn_for_epoch != epoch || !drawn) draw_partition();
+    return EMAT_OK;
+  }
+
   void note_partition_stats() { last_num_parts = (int)parts.size(); last_largest_part = 0; for (auto& pm : parts) last_largest_part = std::max(last_largest_part, (int)pm.orig.size()); }
   // tree_partitioning.h:88-135 and :196-239
   void partition_tree(const std::vector<int32_t>& stencil) {
@@ -621,14 +651,8 @@ struct RunDriver {
     HostLaps laps;
     std::vector<int32_t> part_off, orig, kid0, kid1;
     try {
-      if (stencils.empty() || stencil_refresh_countdown <= 0) {
-        stencils.clear();
-        for (int i = 0; i < 10; ++i) stencils.push_back(generate_random_partition_stencil());
-        stencil_refresh_countdown = 200;
-      }
-      --stencil_refresh_countdown;
-      last_pick = bitgen.below((int)stencils.size()); last_refine_epoch = epoch;
-      const std::vector<int32_t> stencil = refine_stencil(stencils[(size_t)last_pick]);
+      { emat_status ds = ensure_draw(); if (ds) return ds; }
+      const std::vector<int32_t>& stencil = *drawn;
       laps.mark("run.repartition: stencil pick + refine_stencil");
       part_kids.clear();
       // partition_tree itself: on the device (one thread per part) unless the parts are few and large, where one host thread
@@ -717,14 +741,8 @@ struct RunDriver {
     partition_on_device = false;
     try {
       sync_topology();
-      if (stencils.empty() || stencil_refresh_countdown <= 0) {
-        stencils.clear();
-        for (int i = 0; i < 10; ++i) stencils.push_back(generate_random_partition_stencil());
-        stencil_refresh_countdown = 200;
-      }
-      --stencil_refresh_countdown;
-      last_pick = bitgen.below((int)stencils.size()); last_refine_epoch = epoch;
-      const std::vector<int32_t> stencil = refine_stencil(stencils[(size_t)last_pick]);
+      { emat_status ds = ensure_draw(); if (ds) return ds; }
+      const std::vector<int32_t>& stencil = *drawn;
       part_kids.clear();
       t1 = now();
       partition_tree(stencil);
@@ -844,6 +862,7 @@ emat_status emat_run_set_max_part_nodes(emat_run* r, int32_t n) { if (!r || n < 
 emat_status emat_run_debug_redraw_partition(emat_run* r, int32_t* cut_nodes, int32_t* num_cut_nodes) {
   if (!r || !num_cut_nodes) return EMAT_ERR_INVALID_ARGUMENT;
   RunDriver& d = r->d;
+  if (d.follow) return d.fail(EMAT_ERR_STATE, "this run takes its draws from another one (emat_run_follow_draws): ask that one");
   if (d.last_pick < 0 || d.last_pick >= (int)d.stencils.size()) return d.fail(EMAT_ERR_STATE, "emat_run_repartition first");
   if (d.device_tree) { emat_status st = d.fetch_device_topology(); if (st) return st; } else d.sync_topology();
   const uint64_t epoch_now = d.epoch; const int extra_now = d.last_extra_cuts;
@@ -955,6 +974,33 @@ emat_status emat_run_moves(emat_run* r, int64_t count) {
 }
 emat_status emat_run_reassemble(emat_run* r) { if (!r) return EMAT_ERR_INVALID_ARGUMENT; return r->d.reassemble(); }
 
+/* Drivers of one process that are bound to draw the same partitions (same seed, same tree: emat_multi's shards) draw once: `follower` takes
+ * the cut nodes `leader` drew for the same cycle instead of drawing them again.  The leader draws at its own emat_run_repartition, or ahead of
+ * it with emat_run_draw_partition (so that leader and followers can then cut side by side).  NULL leader = draw for itself again. */
+emat_status emat_run_follow_draws(emat_run* follower, emat_run* leader) {
+  if (!follower || follower == leader) return EMAT_ERR_INVALID_ARGUMENT;
+  RunDriver& f = follower->d;
+  if (leader) {
+    const RunDriver& l = leader->d;
+    if (l.seed != f.seed || l.tree.nodes.size() != f.tree.nodes.size() || l.epoch != f.epoch || l.num_parts != f.num_parts || l.max_part_nodes != f.max_part_nodes)
+      return f.fail(EMAT_ERR_INVALID_ARGUMENT, "emat_run_follow_draws: leader and follower must be runs of the same seed, tree, cycle and partition settings");
+    if (l.follow) return f.fail(EMAT_ERR_INVALID_ARGUMENT, "emat_run_follow_draws: the leader itself follows another run");
+  }
+  f.follow = leader ? &leader->d : nullptr;
+  return EMAT_OK;
+}
+emat_status emat_run_draw_partition(emat_run* r) {
+  if (!r) return EMAT_ERR_INVALID_ARGUMENT;
+  RunDriver& d = r->d;
+  if (d.follow) return d.fail(EMAT_ERR_STATE, "emat_run_draw_partition: this run takes its draws from another one");
+  if (d.drawn && d.drawn_for_epoch == d.epoch) return EMAT_OK;   // already drawn for the cycle to come
+  try {
+    if (d.device_tree && d.device_tree_uploaded) { emat_status st = d.fetch_device_topology(); if (st) return st; }
+    else { if (d.device_tree) d.normalize_root(); d.sync_topology(); }   // (before the first upload: the host's copy is the tree)
+    d.draw_partition();
+  } catch (const std::exception& ex) { return d.fail(EMAT_ERR_INTERNAL, ex.what()); }
+  return EMAT_OK;
+}
 emat_status emat_run_set_shard(emat_run* r, int32_t rank, int32_t world) {
   if (!r || world < 1 || rank < 0 || rank >= world) return EMAT_ERR_INVALID_ARGUMENT;
   r->d.shard_rank = rank; r->d.shard_world = world; r->d.parts_uploaded = false;

@@ -293,7 +293,7 @@ def load_library():
         "emat_scalable_coalescent_log_prior": [B, dbl, dbl, i32, i32, P(dbl), dbl, P(dbl)],
         "emat_synth_create": [P(_SynthParamsC), P(S)], "emat_synth_get": [S, P(_FlatTreeC), P(P(C.c_uint8)), P(dbl)],
         "emat_run_create": [B, P(_FlatTreeC), P(C.c_uint8), i32, u64, P(R)], "emat_run_destroy": [R],
-        "emat_run_set_num_parts": [R, i32], "emat_run_set_max_part_nodes": [R, i32], "emat_run_partition_stats": [R, P(i32), P(i32), P(i32), P(i32)], "emat_run_debug_redraw_partition": [R, P(i32), P(i32)], "emat_run_set_hky": [R, dbl, dbl, P(dbl), P(dbl)], "emat_run_set_pop_model": [R, P(_PopModelC)],
+        "emat_run_set_num_parts": [R, i32], "emat_run_set_max_part_nodes": [R, i32], "emat_run_partition_stats": [R, P(i32), P(i32), P(i32), P(i32)], "emat_run_debug_redraw_partition": [R, P(i32), P(i32)], "emat_run_follow_draws": [R, R], "emat_run_draw_partition": [R], "emat_run_set_hky": [R, dbl, dbl, P(dbl), P(dbl)], "emat_run_set_pop_model": [R, P(_PopModelC)],
         "emat_run_set_coalescent_t_step": [R, dbl], "emat_run_set_flags": [R, i32, i32],
         "emat_run_repartition": [R], "emat_run_num_parts": [R, P(i32), P(i32)],
         "emat_run_part_sizes": [R, i32, P(i32), P(i32), P(i32), P(i32)], "emat_run_part_get": [R, i32, P(_FlatTreeC), P(i32), P(u64)],
@@ -929,6 +929,14 @@ class EmatRun:
         a, b, c, e = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         self._ck(self._lib.emat_run_partition_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(e)), "emat_run_partition_stats")
         return {"num_parts": a.value, "largest_part_nodes": b.value, "extra_cuts": c.value, "max_part_nodes": e.value}
+
+    def follow_draws(self, leader: "Optional[EmatRun]"):
+        """This run takes the partition draws of `leader` (same process, seed, tree, settings) instead of drawing them again (emat_multi's shards)."""
+        self._ck(self._lib.emat_run_follow_draws(self._h, leader._h if leader is not None else None), "emat_run_follow_draws")
+
+    def draw_partition(self):
+        """The draw of the coming cycle's partition (stencil refresh, pick, part-size limit) ahead of emat_run_repartition."""
+        self._ck(self._lib.emat_run_draw_partition(self._h), "emat_run_draw_partition")
 
     def debug_redraw_partition(self) -> np.ndarray:
         """Test hook: the sorted cut nodes the last repartition's draw (same stencil, same refinement stream) gives on the tree as it is now."""

@@ -116,6 +116,13 @@ emat_status emat_run_push_params(emat_run* r);
 emat_status emat_run_moves(emat_run* r, int64_t count);
 /* Gather the parts back into the whole tree; with a backend attached the parts are downloaded first. */
 emat_status emat_run_reassemble(emat_run* r);
+/* Several drivers in ONE process that are bound to draw the same partitions (same seed, same tree, same settings: the shards of
+ * emat_run_create_multi) draw once: a follower takes the cut nodes its leader drew for the cycle instead of picking and refining the
+ * stencil again on the same host cores.  The leader draws at its own emat_run_repartition, or ahead of it with emat_run_draw_partition,
+ * after which leader and followers can cut side by side.  (Not in the reference, whose Run is one object; its refresh_partition_stencils
+ * + pick, run.cpp:87-108, 127-129, is what is being shared.) */
+emat_status emat_run_follow_draws(emat_run* follower, emat_run* leader /* NULL: draw for itself again */);
+emat_status emat_run_draw_partition(emat_run* leader);
 /* ---- one run over several processes, one GPU each ---------------------------------------------------
  * Every process creates the same run (same tree, same seed) with its own backend and calls emat_run_set_shard once.
  * The partition is then computed identically everywhere, but a process uploads only its contiguous block of parts

@@ -227,6 +227,36 @@ def test_the_part_size_limits_draw_is_invariant_under_the_pass_it_governs(sc):
     assert strict >= 4          # cycles with a limit that bit, a pass that re-hung subtrees, and the very same draw afterwards
 
 
+def test_runs_of_one_process_share_their_partition_draws(sc):
+    """emat_run_follow_draws / emat_run_draw_partition (what emat_multi's shards do since round 6): a follower takes the cut nodes its leader
+    drew for the cycle -- and ends up with exactly the partition it would have drawn itself, cycle after cycle, with the part-size limit
+    on; a follower asked to cut before its leader drew refuses."""
+    def make(seed):
+        r = d.EmatRun(None, sc.tree, sc.ref, seed); r.set_num_parts(12); r.set_max_part_nodes(40); return r
+    alone, leader, follower = make(21), make(21), make(21)
+    follower.follow_draws(leader)
+    with pytest.raises(d.EmatError, match="has not drawn"):
+        follower.repartition()
+    for cycle in range(3):
+        alone.repartition()
+        leader.draw_partition()
+        follower.repartition(); leader.repartition()          # (in either order once the draw is there)
+        assert alone.num_parts() == leader.num_parts() == follower.num_parts()
+        assert alone.partition_stats() == leader.partition_stats() == follower.partition_stats()
+        n, _ = alone.num_parts()
+        for i in range(n):
+            ta, tl, tf = alone.part(i), leader.part(i), follower.part(i)
+            assert ta[1:] == tl[1:] == tf[1:]
+            assert_trees_match(tl[0], ta[0], 0.0, "leader part %d" % i); assert_trees_match(tf[0], ta[0], 0.0, "follower part %d" % i)
+        for r in (alone, leader, follower):
+            r.reassemble()
+    other = make(22)
+    with pytest.raises(d.EmatError, match="same seed"):
+        other.follow_draws(leader)
+    for r in (alone, leader, follower, other):
+        r.close()
+
+
 def test_coalescent_window_covers_lineages_past_a_frozen_tips_float_bound():
     """A frozen cut-point tip carries t_min = t_max = (float)t, which can lie below its exact double time t.  When that tip
     is the latest node of its part and a cell boundary falls between (float)t and t, the branch above it reaches the
