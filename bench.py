@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of each CPU baseline sample")
     ap.add_argument("--verify-parts", type=int, default=4, help="N > 1: parts per rank whose final trees are compared with a one-GPU run of the same partition on rank 0 "
                     "(outside the timed region; the counters of ALL parts are compared whatever this says; 0 = no check)")
+    ap.add_argument("--no-decompositions", action="store_true", help="skip the second decomposition (N = 1: the partition N >= 2 run; N >= 2: N = 1's partition)")
     ap.add_argument("--no-inclusive", action="store_true", help="skip the host-cycle-inclusive figure (repartition + moves + reassemble through the run driver)")
     args = ap.parse_args()
     args.parts_auto = args.parts is None
@@ -628,7 +629,7 @@ def main():
     # shrink so that a step keeps its moves.  A scaling curve read off `value` alone would mix the two: N = 1 therefore also times the grown partition, and N >= 2 the
     # fixed one, through the same timed region.
     decompositions = None
-    if args.parts_auto and args.moves_auto and args.workload == "C4" and args.tips is None:
+    if args.parts_auto and args.moves_auto and args.workload == "C4" and args.tips is None and not args.no_decompositions:
         step_moves = 1000.0 * base_parts
         if world == 1:
             decompositions = {"grown_partition": dict(measure_resident(args, sc, 8 * base_parts, 1000, args.steps, world, rank, local_rank, shared_gpu, allreduce, dist, torch, moves_of_a_step=step_moves),

@@ -136,6 +136,7 @@ template <class CtxT> __device__ inline void init_ctx(CtxT& c, uint8_t* slab, ui
   c.ref = (const __attribute__((address_space(1))) uint8_t*)a.evo.ref_sequence; c.part = (const __attribute__((address_space(1))) uint8_t*)a.evo.partition_for_site;
   c.nu = (const __attribute__((address_space(1))) double*)a.evo.nu_l; c.cumQ = (const __attribute__((address_space(1))) double*)a.evo.cum_Q_l;
   c.have_logq = lds_tables != nullptr;
+  c.uniform_sites = a.evo.uniform_sites != 0;
   if (lds_tables) { c.mu = lds_tables; c.pi = lds_tables + k_max_lds_partitions; c.q = lds_tables + k_max_lds_partitions * 5; }
   else { c.mu = a.evo.mu; c.pi = a.evo.pi; c.q = a.evo.q; }
   c.pop = a.pop;
@@ -1030,6 +1031,8 @@ struct emat_backend {
   std::vector<uint8_t> ref, partition_for_site;
   std::vector<double> nu_l, cumQ, cum_nu, mu, pi, q;
   std::vector<int32_t> ref_freqs;
+  bool uniform_sites = false;       // one site partition, every nu_l == 1.0: EvoTable::uniform_sites
+  bool cfg_no_uniform_sites = false;   // option "no_uniform_sites" (A/B and tests): the moves read the per-site arrays even then
   int num_partitions = 0;
   RunFlags flags{0.0, 0, 1};
   bool have_ref = false, have_evo = false, have_pop = false, have_coal = false;
@@ -1243,6 +1246,7 @@ void refresh_ref_derived(emat_backend* h) {
       next[4 * h->partition_for_site[l] + h->ref[l]] += h->nu_l[l];
     }
   }
+  h->uniform_sites = h->num_partitions == 1 && !h->cfg_no_uniform_sites && std::all_of(h->nu_l.begin(), h->nu_l.end(), [](double x) { return x == 1.0; });
   h->ref_freqs.assign((size_t)h->num_partitions * 4, 0);
   for (int l = 0; l < L; ++l) ++h->ref_freqs[h->partition_for_site[l] * 4 + h->ref[l]];
   h->model_dirty = true;
@@ -1251,7 +1255,7 @@ void refresh_ref_derived(emat_backend* h) {
 KernelArgs make_args(emat_backend* h) {
   KernelArgs a{};
   a.slabs = h->d_slabs.p; a.slab_off = h->d_slab_off.p; a.order = h->d_order.p; a.part_status = h->d_part_status.p; a.moves_for_part = nullptr; a.part_ticks = h->d_part_ticks.p; a.ref_freqs = h->d_ref_freqs.p; a.cum_nu = h->d_cum_nu.p; a.stats_out = h->d_stats.p;
-  a.evo.num_sites = h->L; a.evo.num_partitions = h->num_partitions;
+  a.evo.num_sites = h->L; a.evo.num_partitions = h->num_partitions; a.evo.uniform_sites = h->uniform_sites ? 1 : 0; a.evo.pad_ = 0;
   a.evo.ref_sequence = h->d_ref.p; a.evo.partition_for_site = h->d_part.p; a.evo.nu_l = h->d_nu.p; a.evo.cum_Q_l = h->d_cumQ.p;
   a.evo.mu = h->d_mu.p; a.evo.pi = h->d_pi.p; a.evo.q = h->d_q.p;
   a.pop = h->d_pop.p; a.shared = h->shared_dev; a.flags = h->flags; a.num_parts = (int)h->parts.size();
@@ -1858,6 +1862,7 @@ emat_status emat_set_option(emat_backend* h, const char* key, const char* value)
   else if (k == "order_by_time") h->cfg_order_by_time = atoi(e) != 0;
   else if (k == "build_blocks") h->cfg_build_blocks = std::max(0, atoi(e));
   else if (k == "tree_tight") h->cfg_tree_tight = atoi(e) != 0;
+  else if (k == "no_uniform_sites") { h->cfg_no_uniform_sites = atoi(e) != 0; if (h->have_evo && h->have_ref) refresh_ref_derived(h); }
   else if (k == "debug_fail_gather") h->cfg_debug_fail_gather = atoi(e) != 0;
   else if (k == "fn_min_lists") h->cfg_fn_min_lists = (unsigned)std::max(0, atoi(e));
   else if (k == "phase_extra") h->cfg_phase_extra = atoi(e) != 0;

@@ -132,6 +132,7 @@ struct Ctx {
   bool only_displacing_inner_nodes;
   bool topology_moves_enabled;
   bool includes_run_root;
+  bool uniform_sites;         // one site partition and nu_l == 1 everywhere (EvoTable::uniform_sites): site_part / site_nu answer without a load
   bool have_logq;             // emat_lds_logq is filled (the HKY tables are staged): sites of relative rate 1 take their log(mu q_ab) from it
   bool rng_has_spare;         // rng_spare holds the second 64-bit half of the last Philox block, not yet consumed
   // A move that wants work done by the whole wave (candidate scan and study of an SPR move) parks itself: `phase` says
@@ -491,12 +492,18 @@ EMAT_D void clamp_mut_times(MutRec* p, int n, double lo, double hi) {   // mutat
 }
 
 // ---- evolution model accessors (evo_model.h:35-47) ----------------------------------------------------------
-EMAT_D double mu_nu(const Ctx& c, int l) { return mu_of(c)[c.part[l]] * c.nu[l]; }
-EMAT_D double q_a(const Ctx& c, int l, int a) { return -q_of(c)[c.part[l] * 16 + a * 5]; }
-EMAT_D double q_ab(const Ctx& c, int l, int a, int b) { return q_of(c)[c.part[l] * 16 + a * 4 + b]; }
-EMAT_D double pi_a(const Ctx& c, int l, int a) { return pi_of(c)[c.part[l] * 4 + a]; }
+// Site partition and relative rate of a site.  Both arrays live in HBM (L entries each); a chain asks for them once per mutation or
+// from-state it touches, each time a dependent global load of several hundred cycles.  In the reference's default model -- one site
+// partition, nu_l == 1 everywhere (run.h:256: alpha moves off) -- the answers are 0 and 1.0 and `mu * 1.0 * x` IS `mu * x` bit for bit,
+// so the loads are skipped (round 6; option "no_uniform_sites" keeps them for A/B runs and for the parity tests of that path).
+EMAT_DF int site_part(const Ctx& c, int l) { return c.uniform_sites ? 0 : (int)c.part[l]; }
+EMAT_DF double site_nu(const Ctx& c, int l) { return c.uniform_sites ? 1.0 : c.nu[l]; }
+EMAT_D double mu_nu(const Ctx& c, int l) { return mu_of(c)[site_part(c, l)] * site_nu(c, l); }
+EMAT_D double q_a(const Ctx& c, int l, int a) { return -q_of(c)[site_part(c, l) * 16 + a * 5]; }
+EMAT_D double q_ab(const Ctx& c, int l, int a, int b) { return q_of(c)[site_part(c, l) * 16 + a * 4 + b]; }
+EMAT_D double pi_a(const Ctx& c, int l, int a) { return pi_of(c)[site_part(c, l) * 4 + a]; }
 // mu nu (-q_minus + q_plus)
-EMAT_D double dq(const Ctx& c, int l, int minus, int plus) { return mu_of(c)[c.part[l]] * c.nu[l] * (-q_a(c, l, minus) + q_a(c, l, plus)); }
+EMAT_D double dq(const Ctx& c, int l, int minus, int plus) { return mu_of(c)[site_part(c, l)] * site_nu(c, l) * (-q_a(c, l, minus) + q_a(c, l, plus)); }
 
 // ---- interval-set algebra on raw sorted arrays (interval_set.h:130-138, 238-500) ---------------------------
 EMAT_D bool iv_contains(const IvRec* v, int n, int l) {
@@ -645,7 +652,7 @@ EMAT_DF void sd_push_back(Ctx& c, SVec<SdRec>& v, int site, int from, int to) { 
 EMAT_D double delta_lambda_across_missations(Ctx& c, const IvRec* iv, int niv, const FsRec* fs, int nfs) {   // h:121-138
   double r = 0.0;
   for (int i = 0; i < niv; ++i) r -= c.cumQ[iv[i].end] - c.cumQ[iv[i].start];
-  for (int i = 0; i < nfs; ++i) { int l = fs[i].site; r -= mu_of(c)[c.part[l]] * c.nu[l] * (q_a(c, l, fs[i].state) - q_a(c, l, c.ref[l])); }
+  for (int i = 0; i < nfs; ++i) { int l = fs[i].site; r -= mu_of(c)[site_part(c, l)] * site_nu(c, l) * (q_a(c, l, fs[i].state) - q_a(c, l, c.ref[l])); }
   return r;
 }
 EMAT_D double delta_lambda_across_node_missations(Ctx& c, int node) {
@@ -654,7 +661,7 @@ EMAT_D double delta_lambda_across_node_missations(Ctx& c, int node) {
 EMAT_D double delta_lambda_across_branch(Ctx& c, int node) {   // h:140-155
   double r = 0.0;
   const MutRec* m = muts_of(c, node); int nm = nmuts(c, node);
-  for (int i = 0; i < nm; ++i) { int l = m[i].site; r += mu_of(c)[c.part[l]] * c.nu[l] * (q_a(c, l, m[i].to) - q_a(c, l, m[i].from)); }
+  for (int i = 0; i < nm; ++i) { int l = m[i].site; r += mu_of(c)[site_part(c, l)] * site_nu(c, l) * (q_a(c, l, m[i].to) - q_a(c, l, m[i].from)); }
   r += delta_lambda_across_node_missations(c, node);
   return r;
 }
@@ -665,7 +672,7 @@ EMAT_DN double calc_lambda_at_node(Ctx& c, int node) {   // cpp:406-418
 }
 // log(mu_l nu_l q_ab): from the table where the site's relative rate is exactly 1 (mu * 1.0 * q is mu * q bit for bit), else taken
 EMAT_D double log_mu_nu_q(const Ctx& c, int l, int a, int b) {
-  const int pa = (int)c.part[l]; const double nu = c.nu[l];
+  const int pa = site_part(c, l); const double nu = site_nu(c, l);
   if (c.have_logq && nu == 1.0) return emat_lds_logq[pa * 16 + a * 4 + b];
   return m_log(mu_of(c)[pa] * nu * q_of(c)[pa * 16 + a * 4 + b]);
 }
@@ -673,7 +680,7 @@ EMAT_D double branch_log_G(const Ctx& c, double t_P, double t_X, double lambda_X
   double r = -lambda_X * (t_X - t_P);
   for (int i = nm - 1; i >= 0; --i) {
     int l = m[i].site;
-    r -= mu_of(c)[c.part[l]] * c.nu[l] * (q_a(c, l, m[i].from) - q_a(c, l, m[i].to)) * (m[i].t - t_P);
+    r -= mu_of(c)[site_part(c, l)] * site_nu(c, l) * (q_a(c, l, m[i].from) - q_a(c, l, m[i].to)) * (m[i].t - t_P);
     r += log_mu_nu_q(c, l, m[i].from, m[i].to);
   }
   return r;

@@ -240,7 +240,7 @@ EMAT_D ReformFactors reform_factors(Ctx& c, const MutRec* m, int n) { EMAT_TIMED
 #pragma unroll
     for (int k = 0; k < 4; ++k) l[k] = m[j0 + k < n ? j0 + k : n - 1].site;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { pa[k] = (int)c.part[l[k]]; nu[k] = c.nu[l[k]]; }     // eight independent loads in flight
+    for (int k = 0; k < 4; ++k) { pa[k] = site_part(c, l[k]); nu[k] = site_nu(c, l[k]); }     // eight independent loads in flight
 #pragma unroll
     for (int k = 0; k < 4; ++k) if (j0 + k < n) {
       const MutRec& mm = m[j0 + k];
@@ -251,7 +251,7 @@ EMAT_D ReformFactors reform_factors(Ctx& c, const MutRec* m, int n) { EMAT_TIMED
       else { f.B[j0 + k] = mn * q[(int)mm.from * 4 + (int)mm.to]; need_log |= 1u << ((j0 + k) & 31); if (j0 + k >= 32) all_logs = true; }   // the logarithm's argument; taken below
     }
   }
-  if (all_logs) { for (int j = 0; j < n; ++j) if (!(c.have_logq && c.nu[m[j].site] == 1.0)) f.B[j] = m_log(f.B[j]); }
+  if (all_logs) { for (int j = 0; j < n; ++j) if (!(c.have_logq && site_nu(c, m[j].site) == 1.0)) f.B[j] = m_log(f.B[j]); }
   else if (need_log != 0u) { const int n32 = n < 32 ? n : 32; for (int j = 0; j < n32; ++j) if ((need_log >> j) & 1u) f.B[j] = m_log(f.B[j]); }   // entries from 32 on need none (all_logs would be set): never shift by >= 32
   return f;
 }
@@ -613,11 +613,11 @@ EMAT_DN double calc_log_root_prior(Ctx& c, const int32_t* ref_freqs, int P) {
     for (int a = 0; a < 4; ++a) {
       int f = ref_freqs[p * 4 + a];
       const MutRec* m = muts_of(c, root);
-      for (int i = 0; i < nmuts(c, root); ++i) if ((int)c.part[m[i].site] == p) { if (m[i].from == a) --f; if (m[i].to == a) ++f; }
+      for (int i = 0; i < nmuts(c, root); ++i) if (site_part(c, m[i].site) == p) { if (m[i].from == a) --f; if (m[i].to == a) ++f; }
       const IvRec* iv = miss_of(c, root);
-      for (int i = 0; i < (int)nodes_of(c)[root].miss.cnt; ++i) for (int l = iv[i].start; l < iv[i].end; ++l) if ((int)c.part[l] == p && (int)c.ref[l] == a) --f;
+      for (int i = 0; i < (int)nodes_of(c)[root].miss.cnt; ++i) for (int l = iv[i].start; l < iv[i].end; ++l) if (site_part(c, l) == p && (int)c.ref[l] == a) --f;
       const FsRec* fs = mfs_of(c, root);
-      for (int i = 0; i < (int)nodes_of(c)[root].mfs.cnt; ++i) if ((int)c.part[fs[i].site] == p) { if ((int)c.ref[fs[i].site] == a) ++f; if ((int)fs[i].state == a) --f; }
+      for (int i = 0; i < (int)nodes_of(c)[root].mfs.cnt; ++i) if (site_part(c, fs[i].site) == p) { if ((int)c.ref[fs[i].site] == a) ++f; if ((int)fs[i].state == a) --f; }
       double pa = pi_of(c)[p * 4 + a];
       if (pa != 0.0) result += f * m_log(pa);
       else if (f != 0) return -k_inf;

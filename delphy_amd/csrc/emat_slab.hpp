@@ -133,6 +133,8 @@ static_assert(sizeof(SlabHeader) == 256, "SlabHeader must be 256 bytes");
 struct EvoTable {               // reference Global_evo_model (core/evo_model.h:20-48)
   int32_t num_sites;
   int32_t num_partitions;
+  int32_t uniform_sites;              // one site partition and nu_l == 1 at every site (the reference's default: run.h:256): the moves then read neither per-site array
+  int32_t pad_;
   const uint8_t* ref_sequence;        // [L]
   const uint8_t* partition_for_site;  // [L]
   const double* nu_l;                 // [L]

@@ -427,7 +427,7 @@ def decode_graft_output(v, mode: int) -> dict:
 # The library itself reads no tuning from the environment (emat_set_option per handle).  For A/B scripts and tests this mirror forwards
 # EMAT_<NAME> variables of the process to every handle it creates -- the behaviour the library had built in until round 4.
 OPTION_KEYS = ("slack", "heap_per_node", "lds_scratch", "lds_classes", "lds_max", "giants", "side_arena", "tree_host_coalescent", "ticket_taper", "chunks", "ticket_xcd_spread",
-               "ticket_release", "ticket_weights", "single_ticket_parts", "parts_per_cu", "order_by_time", "build_blocks", "tree_tight", "fn_min_lists", "phase_extra")
+               "ticket_release", "ticket_weights", "single_ticket_parts", "parts_per_cu", "order_by_time", "build_blocks", "tree_tight", "fn_min_lists", "phase_extra", "no_uniform_sites")
 
 
 def _forward_env_options(setter):

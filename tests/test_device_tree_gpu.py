@@ -641,7 +641,10 @@ def test_a_deferred_gather_that_fails_stays_failed_until_a_tree_is_uploaded():
     good, good_ref = b.tree_download()                              # (a healthy cycle first)
     run.repartition(); run.run_moves(64 * 200)
     b.set_option("debug_fail_gather", 1)
-    run.reassemble()                                                # returns: the links are there, the lists are on their way
+    try:
+        run.reassemble()                                            # returns: the links are there, the lists are on their way ...
+    except d.EmatError as e:                                        # ... unless the root sequence changed in this cycle: then the gather is not postponed
+        assert "inconsistent" in str(e)
     for attempt in range(3):                                        # ... and the gather's verdict is sticky
         with pytest.raises(d.EmatError, match="inconsistent|incomplete"):
             b.tree_topology() if attempt != 1 else b.tree_download()
