@@ -185,7 +185,7 @@ def inclusive_cycles(sc, args, cycles=210):
     import delphy_amd as d
     per_cycle = 50 * sc.tree.num_nodes
 
-    def one(device_tree, limit, n, parts=None):
+    def one(device_tree, limit, n, parts=None, download=False):
         b = d.EmatBackend(sc.num_sites)
         run = d.EmatRun(b, sc.tree, sc.ref, 20261001)
         run.set_num_parts(args.parts if parts is None else parts)
@@ -198,7 +198,10 @@ def inclusive_cycles(sc, args, cycles=210):
         rows = []
         t0 = time.perf_counter()
         for _ in range(n):                               # (one call per cycle only to time the cycles apart; the driver repartitions at every cycle boundary either way)
-            t1 = time.perf_counter(); run.do_mcmc_steps(per_cycle, per_cycle); ms = (time.perf_counter() - t1) * 1e3
+            t1 = time.perf_counter(); run.do_mcmc_steps(per_cycle, per_cycle)
+            if download:
+                b.tree_download()                          # the whole tree and the reference sequence into host arrays (emat_tree_download), every cycle
+            ms = (time.perf_counter() - t1) * 1e3
             st = run.partition_stats()
             rows.append((ms, st["num_parts"], st["largest_part_nodes"], st["extra_cuts"]))
         dt = time.perf_counter() - t0
@@ -214,10 +217,13 @@ def inclusive_cycles(sc, args, cycles=210):
     dev = one(True, args.max_part_nodes, cycles)
     ref_rule = one(True, 0, max(10, cycles // 5)) if args.max_part_nodes != 0 else None
     host = one(False, args.max_part_nodes, max(5, cycles // 20))
+    dev_dl = one(True, args.max_part_nodes, max(10, cycles // 5), download=True)
     out = dict(dev, moves_per_cycle=per_cycle,
                what="emat_run_do_mcmc_steps with the tree resident in HBM: stencil + partition on the host's copy of the topology, part slabs cut and "
                     "gathered back by kernels, %d local moves per cycle (no global moves), wall clock, %d successive cycles (the reference redraws its stencils every 200)" % (per_cycle, cycles),
-               host_tree=dict(host, what="the same cycles with the tree on the host: subtree build + slab encode + H2D + moves + D2H + decode + reassemble"))
+               host_tree=dict(host, what="the same cycles with the tree on the host: subtree build + slab encode + H2D + moves + D2H + decode + reassemble"),
+               resident_tree_downloaded_every_cycle=dict(dev_dl, what="the resident-tree cycles with emat_tree_download after every cycle: what a Run that wants its Phylo_tree on the host after every "
+                                                                       "cycle (logging, global moves that read the tree) pays on top -- the tree stays authoritative on the device, the host gets a copy"))
     if args.parts_auto and args.workload == "C4":
         # what N >= 2 cut (bench.py requests 8192 parts per GPU; the partitioner's floor of ten nodes per part caps C4 at about 13 000): whole cycles of ONE GPU on that
         # partition, so that a scaling curve of `inclusive` has its x 1 on the same decomposition as its other points

@@ -36,13 +36,14 @@ __device__ __forceinline__ uint32_t emat_opaque_zero() { uint32_t z; asm("v_mov_
 #endif
 #if defined(EMAT_PROFILE_PHASES) || defined(EMAT_COUNT_CALLS)
 namespace emat {
-__device__ unsigned long long g_fn_ticks[3 * 2048][2];   // EMAT_TIMED scopes: [header * 2048 + line][ticks, calls], all parts
+constexpr int k_fn_replicas = 64;                          // (one table per workgroup index mod 64: eight thousand waves adding to ONE word per scope made the profiling build 5.6 x slower than the real one)
+__device__ unsigned long long g_fn_ticks[k_fn_replicas * 3 * 2048][2];   // EMAT_TIMED scopes: [replica][header * 2048 + line][ticks, calls], all parts
 __device__ unsigned g_fn_min_list_bytes = 0;              // ... or only the parts whose lists take at least this much (EMAT_FN_MIN_LISTS: the heavy parts near the root)
 __shared__ int s_fn_count_me;
 struct FnTimer {   // inclusive ticks and calls of the enclosing scope, keyed by (header, source line); lane 0 only
   int key; long long t0;
   __device__ FnTimer(int k) : key(k), t0(clock64()) {}
-  __device__ ~FnTimer() { if (threadIdx.x == 0 && s_fn_count_me) { atomicAdd(&g_fn_ticks[key][0], (unsigned long long)(clock64() - t0)); atomicAdd(&g_fn_ticks[key][1], 1ull); } }
+  __device__ ~FnTimer() { if (threadIdx.x == 0 && s_fn_count_me) { const long long dt = clock64() - t0; unsigned long long* e = g_fn_ticks[(blockIdx.x & (k_fn_replicas - 1)) * (3 * 2048) + key]; atomicAdd(&e[0], (unsigned long long)dt); atomicAdd(&e[1], 1ull); } }
 };
 }
 #endif
@@ -2594,9 +2595,11 @@ emat_status emat_debug_fn_ticks(emat_backend* h, uint64_t* out_12288) {
 #if defined(EMAT_PROFILE_PHASES) || defined(EMAT_COUNT_CALLS)
   auto set_error = [&](const std::string& s) { h->set_error(s); };
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpyFromSymbol(out_12288, HIP_SYMBOL(::emat::g_fn_ticks), sizeof(unsigned long long) * 12288));
-  std::vector<unsigned long long> z(12288, 0);
-  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(::emat::g_fn_ticks), z.data(), sizeof(unsigned long long) * 12288));
+  std::vector<unsigned long long> z((size_t)12288 * ::emat::k_fn_replicas, 0);
+  HIP_TRY(hipMemcpyFromSymbol(z.data(), HIP_SYMBOL(::emat::g_fn_ticks), sizeof(unsigned long long) * z.size()));
+  for (int k = 0; k < 12288; ++k) { unsigned long long sum = 0; for (int r = 0; r < ::emat::k_fn_replicas; ++r) sum += z[(size_t)r * 12288 + k]; out_12288[k] = sum; }
+  std::fill(z.begin(), z.end(), 0ull);
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(::emat::g_fn_ticks), z.data(), sizeof(unsigned long long) * z.size()));
   const unsigned min_lists = h->cfg_fn_min_lists;   // from the next pass on: only parts whose lists take at least this many bytes
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(::emat::g_fn_min_list_bytes), &min_lists, sizeof(min_lists)));
   return EMAT_OK;

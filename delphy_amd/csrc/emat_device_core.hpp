@@ -88,7 +88,7 @@ constexpr uint32_t k_lds_dyn_base = k_lds_tables_bytes + k_lds_ctx_bytes + (k_rn
 // -DEMAT_COUNT_CALLS: scripts/count_calls.py puts EMAT_CALLED(header) at the top of every device function of a copy of these
 // headers; calls are counted per (header, line) in g_fn_ticks[..][1] and read with emat_debug_fn_ticks.
 #ifdef EMAT_COUNT_CALLS
-#define EMAT_CALLED(file_id) do { if (threadIdx.x == 0) atomicAdd(&::emat::g_fn_ticks[(file_id) * 2048 + (__LINE__ & 2047)][1], 1ull); } while (0)
+#define EMAT_CALLED(file_id) do { if (threadIdx.x == 0) atomicAdd(&::emat::g_fn_ticks[(blockIdx.x & 63) * (3 * 2048) + (file_id) * 2048 + (__LINE__ & 2047)][1], 1ull); } while (0)
 #endif
 #endif  // EMAT_DEVICE_COMMON_ONCE_
 

@@ -102,7 +102,8 @@ EMAT_NOTAIL EMAT_DN void spr_move_core(Ctx& c, int X, int new_branch, double new
 template <bool kRoot> EMAT_SIMPLE_MOVE void inner_node_displace_move(Ctx& c) { EMAT_TIMED(2);   // subrun.cpp:148-232
   begin_move(c, k_inner_node_displace);
   int node;
-  { int guard = 0; do { node = pick_random_node(c); } while (is_tip(c, node) && guard++ < (1 << 26)); }
+  { EMAT_TIMED(2);   /* inner_displace: pick an inner node */
+    int guard = 0; do { node = pick_random_node(c); } while (is_tip(c, node) && guard++ < (1 << 26)); }
   c.tr_node = (double)node;
   const int root = hdr_of(c)->root;
   if (!kRoot && node == root) return;   // node == root && !includes_run_root
@@ -126,10 +127,11 @@ template <bool kRoot> EMAT_SIMPLE_MOVE void inner_node_displace_move(Ctx& c) { E
     for (int i = 0; i < nm; ++i) t_max = t_max < m[i].t ? t_max : m[i].t;
     c.bytes += 64 + 16 * nm + 24 * (int)nodes_of(c)[cc].miss.cnt;
   }
+  { EMAT_TIMED(2);   /* inner_displace: delta_lambda_across_node_missations of both children */
   for (int k = 0; k < 2; ++k) {
     double lambda_just_below = lambda_at_node + delta_lambda_across_node_missations(c, ch[k]);
     d_logG_dt -= -lambda_just_below;
-  }
+  } }
   c.bytes += 2 * 64 + 16 * (int)nd.muts.cnt;
   const double old_t = nd.t;
   double log_alpha_ratio = 0.0, new_t = old_t;
@@ -143,6 +145,7 @@ template <bool kRoot> EMAT_SIMPLE_MOVE void inner_node_displace_move(Ctx& c) { E
     if (new_t < t_min || new_t > t_max) return;
     log_alpha_ratio = 0.0;
   } else {
+    EMAT_TIMED(2);   /* inner_displace: bounded_exponential */
     new_t = bounded_exponential(c, d_logG_dt, t_min, t_max);
     log_alpha_ratio = d_logG_dt * (new_t - old_t);
   }
@@ -152,9 +155,12 @@ template <bool kRoot> EMAT_SIMPLE_MOVE void inner_node_displace_move(Ctx& c) { E
   double delta_log_prior = coal_delta_displace_coalescence<kRoot>(c, old_t, new_t);
   if (c.failed) return;
   double log_mh = delta_log_G + delta_log_prior - log_alpha_ratio;
-  bool acc = mh_accept(c, log_mh);
-  note_move(c, node, log_mh, acc, k_inner_node_displace);
+  bool acc;
+  { EMAT_TIMED(2);   /* inner_displace: mh_accept + note_move */
+  acc = mh_accept(c, log_mh);
+  note_move(c, node, log_mh, acc, k_inner_node_displace); }
   if (acc) {
+    EMAT_TIMED(2);   /* inner_displace: accepted: coal_coalescence_displaced + updates */
     coal_coalescence_displaced<kRoot>(c, old_t, new_t);
     nodes_of(c)[node].t = new_t;
     hdr_of(c)->log_G += d_logG_dt * (new_t - old_t);
@@ -436,11 +442,13 @@ EMAT_NOTAIL EMAT_DN void spr1_move_propose(Ctx& c) { EMAT_TIMED(2);
   EMAT_PHASE_BEGIN();
   const Study& pre = fr.study;
   const int X = fr.X, P = fr.P;
-  const int new_region = study_pick_nexus_region(c, pre);
+  int new_region; double new_t_P;
+  { EMAT_TIMED(2);   /* spr1_propose: pick region, pick time, log_alpha_in_region */
+  new_region = study_pick_nexus_region(c, pre);
+  new_t_P = study_pick_time_in_region(c, pre, new_region);
+  fr.log_alpha_o2n = study_log_alpha_in_region(c, pre, new_region, new_t_P); }
   const int new_S = pre.regions.p[new_region].branch;
   EMAT_CHECK(c, new_S != P);
-  const double new_t_P = study_pick_time_in_region(c, pre, new_region);
-  fr.log_alpha_o2n = study_log_alpha_in_region(c, pre, new_region, new_t_P);
   fr.pre_new_region_min_muts = pre.regions.p[new_region].min_muts;   // the second scan reuses the regions' storage
   fr.new_S = new_S; fr.new_t_P = new_t_P;
   const double t_new_S = nodes_of(c)[new_S].t;
@@ -489,6 +497,7 @@ EMAT_NOTAIL EMAT_DN void spr1_move_finish(Ctx& c) { EMAT_TIMED(2);
     hdr_of(c)->log_aug_prior += d_prior;
     coal_coalescence_displaced(c, fr.old_t_P, fr.new_t_P);
   } else {
+    EMAT_TIMED(2);   /* spr1_finish: rejected: move back + apply the old graft */
     spr_move_topology(c, X, fr.old_S, fr.old_t_P);
     apply_graft(c, fr.old_graft);
   }

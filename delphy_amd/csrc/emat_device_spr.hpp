@@ -469,10 +469,13 @@ enum { k_PX = 0, k_PS = 1, k_SPX = 2 };
 
 EMAT_D void bi_init(BranchInfo& b) { b.A = b.B = k_no_node; b.is_open = false; b.T_to_X = b.pl_A = b.pl_X = 0.0; b.warm.p = nullptr; b.warm.n = b.warm.cap = 0; b.hot = b.warm; b.hot_muts.p = nullptr; b.hot_muts.n = b.hot_muts.cap = 0; b.hot_deltas.p = nullptr; b.hot_deltas.n = b.hot_deltas.cap = 0; }
 EMAT_D double log_alpha_mut_term(double mu_p, int L, double T, int M, bool is_open, int d) {   // spr_move.cpp:296-315, 809-835
-  double r = -mu_p * L * T + M * m_log(mu_p / 3);
+  // (Two of the logarithms are multiplied by a count that is usually zero -- no hot mutation, no hot delta -- and a finite logarithm times
+  // zero is a zero of the logarithm's sign, which is what is added instead.  The calls are skipped exactly then; an argument whose logarithm is not finite takes the reference's path.)
+  const double a3 = mu_p / 3;
+  double r = -mu_p * L * T + ((M != 0 || !(a3 > 0.0 && a3 < k_inf)) ? M * m_log(a3) : (a3 < 1.0 ? -0.0 : 0.0));   // (0 x a negative logarithm is -0.0)
   if (!is_open) {
     double P_AC = -0.25 * m_expm1(-4. / 3. * mu_p * T);
-    r -= (L - d) * m_log1p(-3 * P_AC) + d * m_log(P_AC);
+    r -= (L - d) * m_log1p(-3 * P_AC) + ((d != 0 || !(P_AC > 0.0 && P_AC < 1.0)) ? d * m_log(P_AC) : -0.0);
   }
   return r;
 }
@@ -644,7 +647,8 @@ EMAT_DN void start_inner_graft_analysis(Ctx& c, int X, Graft& g) { EMAT_TIMED(1)
   const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t;
   g.S = S; g.t_P = t_P;
   int depth = 0, path_muts = 0;
-  for (int cur = X; cur != k_no_node; cur = nodes_of(c)[cur].parent) { ++depth; if (c.includes_run_root || nodes_of(c)[cur].parent != k_no_node) path_muts += nmuts(c, cur); }
+  { EMAT_TIMED(1);   /* start_inner: walk to the part's root (depth, path_muts) */
+  for (int cur = X; cur != k_no_node; cur = nodes_of(c)[cur].parent) { ++depth; if (c.includes_run_root || nodes_of(c)[cur].parent != k_no_node) path_muts += nmuts(c, cur); } }
   // The hot path rarely climbs more than two or three branches (it ends where the sibling's missing sites are used up), while
   // the path to the part's root is 5-15 long: room for four entries to start with, doubled when they run out (the
   // abandoned array stays in the arena until the move ends) -- 104 bytes per entry of an arena of a few KB.
@@ -676,10 +680,13 @@ EMAT_DN void start_inner_graft_analysis(Ctx& c, int X, Graft& g) { EMAT_TIMED(1)
     const MutRec* m = muts_of(c, X);
     for (int i = nmuts(c, X) - 1; i >= 0; --i) PX.pl_A += dq(c, m[i].site, m[i].to, m[i].from);
   }
-  double next_pl_B = -1 * delta_lambda_across_missations(c, sl_iv.p, sl_iv.n, sl_fs.p, sl_fs.n);
+  double next_pl_B;
+  { EMAT_TIMED(1);   /* start_inner: first delta_lambda_across_missations */
+  next_pl_B = -1 * delta_lambda_across_missations(c, sl_iv.p, sl_iv.n, sl_fs.p, sl_fs.n); }
   g.bi[0].pl_A -= next_pl_B;
   int cur = P, parent = nodes_of(c)[cur].parent, sibling = sibling_of(c, parent, cur);
   double partial_lambda = next_pl_B;
+  { EMAT_TIMED(1);   /* start_inner: sliding-missations loop up the hot path */
   while (sl_iv.n != 0 && !c.failed) {
     bi_room(); if (c.failed) break;
     BranchInfo& bi = g.bi[g.nbi++]; bi_init(bi);
@@ -709,8 +716,9 @@ EMAT_DN void start_inner_graft_analysis(Ctx& c, int X, Graft& g) { EMAT_TIMED(1)
       }
       sl_iv.n = 0; sl_fs.n = 0;
     }
-  }
+  } }
   if (c.failed) return;
+  { EMAT_TIMED(1);   /* start_inner: distribute hot mutations along the hot path */
   // distribute hot mutations along the hot path (spr_move.cpp:700-735): gather (mutation, owner), then split by owner
   struct Owned { MutRec m; int owner; int pad; };
   SVec<Owned> tmp = sc_vec<Owned>(c, path_muts + 1);
@@ -720,12 +728,17 @@ EMAT_DN void start_inner_graft_analysis(Ctx& c, int X, Graft& g) { EMAT_TIMED(1)
     const MutRec* mb = muts_of(c, bi_i.B);
     for (int k = nmuts(c, bi_i.B) - 1; k >= 0; --k) {
       if (iv_contains(bi_i.warm.p, bi_i.warm.n, mb[k].site)) {
+        // (the hot sets of the branch infos are pairwise disjoint -- hot_j is cut out of warm_j, warm_j+1 is what is left of it -- so the first
+        // owner found is the only one: the reference's loop over all j >= i pushes the mutation exactly once too)
         bool found = false;
-        for (int j = i; j < g.nbi; ++j) if (iv_contains(g.bi[j].hot.p, g.bi[j].hot.n, mb[k].site)) { Owned o; o.m = mb[k]; o.owner = j; o.pad = 0; push(c, tmp, o); found = true; }
+        for (int j = i; j < g.nbi; ++j) if (iv_contains(g.bi[j].hot.p, g.bi[j].hot.n, mb[k].site)) { Owned o; o.m = mb[k]; o.owner = j; o.pad = 0; push(c, tmp, o); found = true; break; }
         EMAT_CHECK(c, found);
       }
     }
   }
+  if (tmp.n == 0) {   // no hot mutation anywhere on the path (most grafts of a sparsely mutated tree): every list is empty, nothing to allocate or scan
+    for (int j = 0; j < g.nbi; ++j) { BranchInfo& bi = g.bi[j]; bi.hot_muts.p = nullptr; bi.hot_muts.n = bi.hot_muts.cap = 0; bi.hot_deltas.p = nullptr; bi.hot_deltas.n = bi.hot_deltas.cap = 0; bi.pl_X = bi.pl_A; }
+  } else
   for (int j = 0; j < g.nbi && !c.failed; ++j) {
     BranchInfo& bi = g.bi[j];
     int cnt = 0; for (int k = 0; k < tmp.n; ++k) if (tmp.p[k].owner == j) ++cnt;
@@ -738,7 +751,7 @@ EMAT_DN void start_inner_graft_analysis(Ctx& c, int X, Graft& g) { EMAT_TIMED(1)
       if (!bi.is_open) sd_push_back(c, bi.hot_deltas, m.site, m.from, m.to);
       bi.pl_X += dq(c, m.site, m.from, m.to);
     }
-  }
+  } }
   return;
 }
 EMAT_DN void propose_new_inner_graft_mutations(Ctx& c, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:740-785
