@@ -43,7 +43,8 @@ __shared__ int s_fn_count_me;
 struct FnTimer {   // inclusive ticks and calls of the enclosing scope, keyed by (header, source line); lane 0 only
   int key; long long t0;
   __device__ FnTimer(int k) : key(k), t0(clock64()) {}
-  __device__ ~FnTimer() { if (threadIdx.x == 0 && s_fn_count_me) { const long long dt = clock64() - t0; unsigned long long* e = g_fn_ticks[(blockIdx.x & (k_fn_replicas - 1)) * (3 * 2048) + key]; atomicAdd(&e[0], (unsigned long long)dt); atomicAdd(&e[1], 1ull); } }
+  __device__ void stop() { if (key >= 0) { this->~FnTimer(); key = -1; } }
+  __device__ ~FnTimer() { if (key >= 0 && threadIdx.x == 0 && s_fn_count_me) { const long long dt = clock64() - t0; unsigned long long* e = g_fn_ticks[(blockIdx.x & (k_fn_replicas - 1)) * (3 * 2048) + key]; atomicAdd(&e[0], (unsigned long long)dt); atomicAdd(&e[1], 1ull); } }
 };
 }
 #endif

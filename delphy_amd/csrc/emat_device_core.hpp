@@ -210,8 +210,13 @@ EMAT_D void fail_at(Ctx& c, int status, int line) {
 #define EMAT_PHASE_BEGIN() long long _ph_t0 = clock64()
 #define EMAT_PHASE(c, k) do { long long _t = clock64(); hdr_of(c)->phase_ticks[k] += _t - _ph_t0; _ph_t0 = _t; } while (0)
 #define EMAT_TIMED(file_id) ::emat::FnTimer _fn_timer((file_id) * 2048 + (__LINE__ & 2047))
+// a stretch that cannot be a block of its own (it declares what the rest of the function uses): EMAT_TIMED_BLOCK(file, name) ... EMAT_TIMED_END(name)
+#define EMAT_TIMED_BLOCK(file_id, name) ::emat::FnTimer name((file_id) * 2048 + (__LINE__ & 2047))
+#define EMAT_TIMED_END(name) name.stop()
 #else
 #define EMAT_TIMED(file_id) do {} while (0)
+#define EMAT_TIMED_BLOCK(file_id, name) do {} while (0)
+#define EMAT_TIMED_END(name) do {} while (0)
 #define EMAT_SITE(line, hbm, v) do {} while (0)
 #define EMAT_COUNT(c, k, v) do {} while (0)
 #define EMAT_COUNT_TRIMS(c, k, v) do {} while (0)
@@ -704,7 +709,9 @@ EMAT_DN SVec<IvRec> reconstruct_missing_sites_at(Ctx& c, int node) { EMAT_TIMED(
   if (c.failed) return a;
   IvRec* so_far = a.p; IvRec* other = b.p; int n = 0;
   for (int cur = node; cur != k_no_node; cur = nodes_of(c)[cur].parent) {
-    int k = iv_merge(other, so_far, n, miss_of(c, cur), (int)nodes_of(c)[cur].miss.cnt);
+    const int cnt = (int)nodes_of(c)[cur].miss.cnt;
+    if (cnt == 0) continue;   // (most inner nodes miss nothing of their own: the union with nothing is the set as it stands, not a copy of it)
+    int k = iv_merge(other, so_far, n, miss_of(c, cur), cnt);
     IvRec* t = so_far; so_far = other; other = t; n = k;
   }
   SVec<IvRec> r; r.p = so_far; r.n = n; r.cap = total + 1;

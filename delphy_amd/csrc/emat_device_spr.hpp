@@ -397,10 +397,11 @@ EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double m
     for (int i = 0; i < deltas.n && !c.failed; ++i) { bool acc; sample_site_trajectory(c, out, deltas.p[i].site, deltas.p[i].from, deltas.p[i].to, ge1, T, true, acc); }
   }
   double muT = mu * T;
-  double p_0 = m_exp(-muT), p_1 = muT * p_0;
-  double log_one_minus_p_tricky = (muT < 1e-4) ? -0.5 * muT * muT : -muT - m_log1p(-p_1);
   int l = 0;
   if ((double)L * muT * muT < 2e-6) l = L;
+  // (the skip rate is only worked out when some site will be looked at: an exponential and a log1p that most calls never use)
+  double log_one_minus_p_tricky = 0.0;
+  if (l < L) { const double p_0 = m_exp(-muT), p_1 = muT * p_0; log_one_minus_p_tricky = (muT < 1e-4) ? -0.5 * muT * muT : -muT - m_log1p(-p_1); }
   int guard = 0;
   while (l < L && !c.failed && guard++ < (1 << 26)) {
     double u = exponential(c, -log_one_minus_p_tricky);
@@ -653,6 +654,7 @@ EMAT_DN void start_inner_graft_analysis(Ctx& c, int X, Graft& g) { EMAT_TIMED(1)
   // the path to the part's root is 5-15 long: room for four entries to start with, doubled when they run out (the
   // abandoned array stays in the arena until the move ends) -- 104 bytes per entry of an arena of a few KB.
   int bi_cap = depth + 2 < 4 ? depth + 2 : 4;
+  EMAT_TIMED_BLOCK(1, setup_timer);   /* start_inner: setup (branch infos, PX, sliding missations, pl_A of PX) */
   g.bi = (BranchInfo*)sc_alloc(c, (uint32_t)bi_cap * (uint32_t)sizeof(BranchInfo));
   if (c.failed) return;
   auto bi_room = [&]() {
@@ -680,6 +682,7 @@ EMAT_DN void start_inner_graft_analysis(Ctx& c, int X, Graft& g) { EMAT_TIMED(1)
     const MutRec* m = muts_of(c, X);
     for (int i = nmuts(c, X) - 1; i >= 0; --i) PX.pl_A += dq(c, m[i].site, m[i].to, m[i].from);
   }
+  EMAT_TIMED_END(setup_timer);
   double next_pl_B;
   { EMAT_TIMED(1);   /* start_inner: first delta_lambda_across_missations */
   next_pl_B = -1 * delta_lambda_across_missations(c, sl_iv.p, sl_iv.n, sl_fs.p, sl_fs.n); }
