@@ -951,7 +951,6 @@ struct GTreeHost {
   std::vector<int32_t> h_part_off, h_orig, h_kid0, h_kid1;   // host copies (h_orig / h_kid* only when the partition came from the host or was asked for)
   bool partition_on_device = false;   // made by emat_tree_partition
   DevBuf<int32_t> lidx;
-  PinnedBytes pin_cut;   // emat_tree_partition's cut marks and cut nodes on their way to the device
   DevBuf<uint8_t> d_is_cut; DevBuf<int32_t> d_cut, d_sizes, d_part_status;   // emat_tree_partition's inputs and counts (kept: three allocations less per cycle)
   PinnedBytes pin_sizes, pin_measure;                                         // where its sizes + offsets, and the measures queued behind it, land
   hipEvent_t ev_sizes = nullptr, ev_measure = nullptr;
@@ -1012,7 +1011,6 @@ struct emat_backend {
   uint32_t cfg_lds_max = 96 * 1024;                  // EMAT_LDS_MAX (tuning knob): largest staging area; larger parts run out of HBM
   bool order_valid = false;         // d_order holds the current parts, largest first
   std::vector<int32_t> h_order;     // host copy of d_order
-  PinnedBytes pin_order;            // ... and what a queued upload of it is copied from (build_order)
   bool last_launch_uniform = false; // the last launch ran the same number of moves on every part (its durations are comparable)
   bool cfg_order_by_time = false;   // option "order_by_time" (tuning knob): re-sort the launch order by measured durations at every synchronisation
   std::string cfg_ticket_weights;   // option "ticket_weights": "w1,w2,..." the tickets' ratio, as many numbers as tickets
@@ -1676,11 +1674,9 @@ emat_status build_order(emat_backend* h, bool queued = false) {
     key.swap(key2); order.swap(order2);
   }
   h->h_order = order;
-  if (queued) {   // (from page-locked memory: a copy from a pageable vector would wait for the stream -- k_gt_build and the grid kernels -- to reach it)
-    HIP_TRY(h->d_order.alloc(order.size())); HIP_TRY(h->pin_order.resize(order.size() * sizeof(int32_t)));
-    std::memcpy(h->pin_order.data(), order.data(), order.size() * sizeof(int32_t));
-    HIP_TRY(hipMemcpyAsync(h->d_order.p, h->pin_order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-  }
+  // (from the pageable member: measured in round 6 against a page-locked staging copy, which gained nothing here and made the
+  // like copies of emat_tree_partition WAIT for the stream; h_order lives as long as the handle)
+  if (queued) { HIP_TRY(h->d_order.alloc(order.size())); HIP_TRY(hipMemcpyAsync(h->d_order.p, h->h_order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream)); }
   else { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(h->d_order.upload(order.data(), order.size())); }
   h->order_valid = true;
   return EMAT_OK;

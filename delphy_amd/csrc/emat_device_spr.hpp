@@ -392,7 +392,7 @@ EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double m
   const int want = 2 * deltas.n + 8 + (twice < 1e6 ? (int)(3.0 * twice + 6.0 * sqrt(3.0 * twice)) : (1 << 20));
   SVec<MutRec> out = sc_open<MutRec>(c, k_open_max, want);
   if (c.failed) return out;
-  if (deltas.n != 0) {
+  if (deltas.n != 0) { EMAT_TIMED(1);   /* sample_history: constrained sites (ktp_make + one trajectory per delta) */
     KTruncPoisson ge1 = ktp_make(mu * T, 1);
     for (int i = 0; i < deltas.n && !c.failed; ++i) { bool acc; sample_site_trajectory(c, out, deltas.p[i].site, deltas.p[i].from, deltas.p[i].to, ge1, T, true, acc); }
   }
@@ -403,6 +403,7 @@ EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double m
   double log_one_minus_p_tricky = 0.0;
   if (l < L) { const double p_0 = m_exp(-muT), p_1 = muT * p_0; log_one_minus_p_tricky = (muT < 1e-4) ? -0.5 * muT * muT : -muT - m_log1p(-p_1); }
   int guard = 0;
+  EMAT_TIMED_BLOCK(1, skip_timer);   /* sample_history: geometric skipping over the other sites */
   while (l < L && !c.failed && guard++ < (1 << 26)) {
     double u = exponential(c, -log_one_minus_p_tricky);
     if (!(u >= 0 && u < (double)L)) break;
@@ -414,6 +415,7 @@ EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double m
     sample_site_trajectory(c, out, l, 0, 0, ge2, T, false, acc);
     if (acc) ++l;
   }
+  EMAT_TIMED_END(skip_timer);
   sort_muts(out.p, out.n);
   sc_trim(c, out);
   return out;
@@ -763,7 +765,7 @@ EMAT_DN void propose_new_inner_graft_mutations(Ctx& c, Graft& g) { EMAT_TIMED(1)
     BranchInfo& bi = g.bi[idx];
     if (bi.hot.n == 0) { EMAT_CHECK(c, bi.hot_muts.n == 0); continue; }
     SVec<MutRec> nm = sample_history_for(c, bi);
-    if (nm.n != 0) {
+    if (nm.n != 0) { EMAT_TIMED(1);   /* propose_inner: filter + adjust the sampled history */
       filter_not_hot(nm, bi.hot);
       if (bi.B == X) {
         int w = 0;

@@ -213,12 +213,13 @@ emat_status emat_tree_partition(emat_backend* h, int32_t num_cuts, const int32_t
   const int n = G.n;
   EMAT_SPAN("tree_partition (all)");
   // partition_tree's rule for the run's root (tree_partitioning.h:196-239): a part of its own at the end unless the stencil names it
-  // (both arrays in page-locked memory: a hipMemcpyAsync from pageable memory waits for the stream to reach it, and the stream is busy
-  // with the gather this call is meant to overlap -- ADVICE round 5)
-  HIP_TRY(G.pin_cut.resize((((size_t)n + 15) & ~(size_t)15) + ((size_t)num_cuts + 1) * sizeof(int32_t)));
-  uint8_t* const is_cut = G.pin_cut.data(); std::memset(is_cut, 0, (size_t)n);
-  int32_t* const cut_of_part = (int32_t*)(G.pin_cut.data() + (((size_t)n + 15) & ~(size_t)15));
-  std::copy(cut_nodes, cut_nodes + num_cuts, cut_of_part);
+  // (Both arrays in ordinary memory.  Staging them in page-locked memory was tried in round 6 (a copy from pageable memory might
+  // wait for the stream) and measured: page-locked host memory is read uncached by the CPU, and the validation loop below reads is_cut once per
+  // cut node -- 45 -> 680 us for this stretch; the pageable copy never waited for the stream (the runtime stages it).  The copies below are
+  // complete before this function returns: it waits for ev_sizes, which is recorded behind them.)
+  std::vector<uint8_t> is_cut_v((size_t)n, 0);
+  std::vector<int32_t> cut_v(cut_nodes, cut_nodes + num_cuts); cut_v.push_back(EMAT_NO_NODE);   // (room for the root's own part)
+  uint8_t* const is_cut = is_cut_v.data(); int32_t* const cut_of_part = cut_v.data();
   int n_cut_parts = num_cuts;
   const int32_t* const kids = G.kids();
   int rp = -1;

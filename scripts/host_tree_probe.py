@@ -7,6 +7,9 @@ import delphy_amd as d
 from delphy_amd.scenarios import make_scenario
 cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 limit = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+threads = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if threads:
+    d.load_library().emat_set_host_threads(threads)
 sc = make_scenario("C4")
 b = d.EmatBackend(sc.num_sites)
 run = d.EmatRun(b, sc.tree, sc.ref, 20261001)
