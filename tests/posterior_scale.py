@@ -10,7 +10,9 @@ length, mutation count.  Standard errors from the effective sample size (Geyer's
 z-score per summary and fine arm against its own coarse arm; the seeds are independent, so the pooled z is the mean difference over
 the root-sum-square of the standard errors.  Usage:
     python tests/posterior_scale.py [tips] [cycles] [burn_in] [seeds] [seed_base=7001]      -> gpurun_out/posterior_scale.json + a table
-"""
+EMAT_POSTERIOR_COARSE_DIR=<dir>: the oracle arms are not run but read from <dir>/seed<k>_coarse.json(.gz) -- arms made earlier with
+`--oracle <tips> 8 <cycles> <seed_base + 13 k> <path> <threads>` (they do not depend on the engine's build: round 6 ran the four
+8 400-cycle arms in the build container, CPU only, and the device arms of the same length on the GPU box)."""
 import json
 import os
 import subprocess
@@ -127,8 +129,15 @@ def ess(x):
     return float(n / max(1.0, 1.0 + 2.0 * s))
 
 
+def _load(path):
+    if not os.path.exists(path) and os.path.exists(path + ".gz"):
+        import gzip
+        return json.load(gzip.open(path + ".gz", "rt"))
+    return json.load(open(path))
+
+
 def summarise(path, burn, cycles):
-    a = json.load(open(path)); rows = np.array(a["rows"])[burn:]
+    a = _load(path); rows = np.array(a["rows"])[burn:]
     cfg = {k: a[k] for k in ("parts", "parts_requested", "frozen_fraction", "seconds", "moves_per_cycle", "engine")}
     cfg["emat_build_id"] = a.get("emat_build_id")
     for k in ("max_part_nodes", "extra_cuts_per_cycle", "largest_part_nodes_max"):
@@ -161,14 +170,16 @@ if __name__ == "__main__":
     out_dir = os.path.join(ROOT, "gpurun_out", "posterior_scale"); os.makedirs(out_dir, exist_ok=True)
     procs = []
     me = os.path.abspath(__file__)
+    coarse_dir = os.environ.get("EMAT_POSTERIOR_COARSE_DIR")
     for s in range(seeds):
         seed = seed_base + 13 * s
-        p = os.path.join(out_dir, "seed%d_coarse.json" % s)
-        procs.append((s, "coarse", p, None if only_summarise else subprocess.Popen([sys.executable, me, "--oracle", str(tips), "8", str(coarse_cycles), str(seed), p, "8"])))
+        p = os.path.join(coarse_dir or out_dir, "seed%d_coarse.json" % s)
+        procs.append((s, "coarse", p, None if (only_summarise or coarse_dir) else subprocess.Popen([sys.executable, me, "--oracle", str(tips), "8", str(coarse_cycles), str(seed), p, "8"])))
         for k, nparts in enumerate(fine):
             p = os.path.join(out_dir, "seed%d_fine%d.json" % (s, k))
             procs.append((s, "fine%d" % k, p, None if only_summarise else subprocess.Popen([sys.executable, me, "--gpu", str(tips), str(nparts), str(cycles), str(seed + 1 + k), p])))
-    out = {"tips": tips, "nodes": nodes, "cycles": cycles, "coarse_cycles": coarse_cycles, "burn_in": burn, "seeds": seeds, "seed_base": seed_base, "arms": {}, "z_per_seed": [], "pooled": {}}
+    out = {"tips": tips, "nodes": nodes, "cycles": cycles, "coarse_cycles": coarse_cycles, "burn_in": burn, "seeds": seeds, "seed_base": seed_base, "arms": {}, "z_per_seed": [], "pooled": {},
+           "coarse_arms_from": coarse_dir}
     res = {}
     for s, arm, path, p in procs:
         assert p is None or p.wait() == 0, (s, arm)
