@@ -28,6 +28,7 @@ def chain(tips, num_parts, cycles, seed, out_path):
     b = d.EmatBackend(sc.num_sites)
     run = d.EmatRun(b, sc.tree, sc.ref, seed)
     run.set_num_parts(num_parts); run.set_hky(sc.mu, sc.kappa, sc.pi); run.set_pop_model(sc.pop)
+    run.set_max_part_nodes(-1)       # the part-size limit on, as in bench.py's whole cycles (opt-in since round 6)
     run.set_device_tree(True)
     t_step = sc.default_t_step(); run.set_coalescent_t_step(t_step)
     nodes = sc.tree.num_nodes

@@ -9,11 +9,19 @@ W=$(mktemp -d)
 python3 - "$ROOT" "$W" <<'PY'
 import re, sys
 root, w = sys.argv[1], sys.argv[2]
-hdr = open(root + "/include/emat_backend.h").read()
-decls = re.findall(r'^(emat_status\s+emat_\w+\s*\([^;]*\))\s*;', hdr, flags=re.M | re.S)
-out = ['#include "%s/include/emat_backend.h"' % root, 'extern "C" {']
-out += [re.sub(r'/\*.*?\*/', '', d, flags=re.S).strip() + ' { return EMAT_ERR_NO_DEVICE; }' for d in decls]
-out += ['const char* emat_last_error(const emat_backend*) { return "stub"; }', '}']
+# every entry point the three headers declare gets a WEAK stub: what emat_run.cpp defines wins, the rest (engine, emat_multi, .dphy writer)
+# answers "no device" -- the Python mirror resolves every symbol when it loads a library
+out = ['#include "%s/include/emat_backend.h"' % root, '#include "%s/include/emat_host.h"' % root, '#include "%s/include/emat_dphy.h"' % root, 'extern "C" {']
+seen = set()
+for h in ("emat_backend.h", "emat_host.h", "emat_dphy.h"):
+    hdr = re.sub(r'/\*.*?\*/', '', open(root + "/include/" + h).read(), flags=re.S)
+    for ret, name, args in re.findall(r'^((?:const\s+)?[A-Za-z_][\w]*\s*\*?)\s+(emat_\w+)\s*\(([^;{]*)\)\s*;', hdr, flags=re.M | re.S):
+        if name in seen: continue
+        seen.add(name)
+        r = ret.strip()
+        body = "return EMAT_ERR_NO_DEVICE;" if r == "emat_status" else ('return "stub";' if r.replace(" ", "") == "constchar*" else ("" if r == "void" else ("return nullptr;" if r.endswith("*") else "return 0;")))
+        out.append('__attribute__((weak)) %s %s(%s) { %s }' % (r, name, args.strip(), body))
+out += ['}']
 open(w + "/stubs.cpp", "w").write("\n".join(out))
 open(w + "/drive.py", "w").write('''
 import sys; sys.path.insert(0, "%s"); sys.path.insert(0, "%s/tests")
