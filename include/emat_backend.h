@@ -115,7 +115,10 @@ emat_status emat_backend_destroy(emat_backend* h);
  *   "order_by_time" 1 = re-sort the launch order by measured chain times at every synchronisation
  *   "tree_host_coalescent"  1 = emat_tree_repartition builds the coalescent tables with the host's code (bit-identical to the host cycle)
  *   testing aids: "ticket_xcd_spread" (a part's tickets on different XCDs), "ticket_release" ("full": plain agent-scope releases),
- *   "tree_tight" (no spare room in the device tree), "build_blocks" (workgroups of the initial-tree builder);
+ *   "tree_tight" (no spare room in the device tree), "build_blocks" (workgroups of the initial-tree builder),
+ *   "no_uniform_sites" (1: the moves read the per-site partition and rate arrays even when the model is the reference's default of one
+ *   site partition and nu_l == 1 everywhere, where the answers are known without a load: the A/B of that short cut, round 6),
+ *   "debug_fail_gather" (1: the next deferred gather of the device-resident tree reports an inconsistency; may be set at any time);
  *   profiling builds: "fn_min_lists", "phase_extra". */
 emat_status emat_set_option(emat_backend* h, const char* key, const char* value);
 /* Size of the library's host thread pool (per process, before its first parallel loop; 0 = default: min(cores, 16)). */
