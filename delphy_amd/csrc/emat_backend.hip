@@ -886,13 +886,17 @@ namespace emat {
 template <class T> struct DevBuf {
   T* p = nullptr; size_t n = 0;
   ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t count) {   // room for `count` elements, contents undefined
-    if (count > n) { if (p) (void)hipFree(p); p = nullptr; n = 0; hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); if (e != hipSuccess) return e; n = count; }
+  // Room for `count` elements, contents undefined.  A buffer that must grow grows by a quarter more than asked: two dozen buffers are sized by the
+  // number of parts, which creeps up from cycle to cycle within a stencil period (8 000 -> 14 000 at C4 with the part-size limit), and growing to the
+  // exact need re-allocated a dozen of them EVERY cycle -- hipFree is 54 us a call (rocprofv3 --hip-trace of 40 whole cycles, round 6: 496 hipFree).
+  hipError_t alloc(size_t count) {
+    if (count > n) { if (p) (void)hipFree(p); p = nullptr; n = 0; const size_t want = count + (n_grown ? count / 4 : 0); hipError_t e = hipMalloc((void**)&p, std::max<size_t>(want, 1) * sizeof(T)); if (e != hipSuccess) return e; n = want; n_grown = true; }
     return hipSuccess;
   }
+  bool n_grown = false;   // the first allocation is exact (most buffers are allocated once); every later one has room to spare
   hipError_t alloc_roomy(size_t count) { return count > n ? alloc(count + count / 4) : hipSuccess; }   // for buffers whose need creeps up from cycle to cycle: a quarter more than asked, so that most new maxima fit
   hipError_t upload(const T* src, size_t count) {
-    if (count > n) { if (p) (void)hipFree(p); p = nullptr; n = 0; hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)); if (e != hipSuccess) return e; n = count; }
+    hipError_t e = alloc(count); if (e != hipSuccess) return e;
     if (count) return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
     return hipSuccess;
   }

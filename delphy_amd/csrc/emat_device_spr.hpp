@@ -392,10 +392,16 @@ EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double m
   const int want = 2 * deltas.n + 8 + (twice < 1e6 ? (int)(3.0 * twice + 6.0 * sqrt(3.0 * twice)) : (1 << 20));
   SVec<MutRec> out = sc_open<MutRec>(c, k_open_max, want);
   if (c.failed) return out;
+#ifdef EMAT_X_TRIVIAL_CONSTRAINED   // timing experiment only (a different chain, parity gone): every constrained site gets ONE mutation at the branch's midpoint without a draw --
+  // what the pass would take if the per-site rejection sampling cost nothing: the bound on what per-site streams spread over the wavefront could buy
+  if (deltas.n != 0 && open_room(c, out, deltas.n)) { for (int i = 0; i < deltas.n; ++i) out.p[out.n++] = make_mut(deltas.p[i].from, deltas.p[i].site, deltas.p[i].to, -0.5 * T); }
+#else
   if (deltas.n != 0) { EMAT_TIMED(1);   /* sample_history: constrained sites (ktp_make + one trajectory per delta) */
     KTruncPoisson ge1 = ktp_make(mu * T, 1);
-    for (int i = 0; i < deltas.n && !c.failed; ++i) { bool acc; sample_site_trajectory(c, out, deltas.p[i].site, deltas.p[i].from, deltas.p[i].to, ge1, T, true, acc); }
+    for (int i = 0; i < deltas.n && !c.failed; ++i) { EMAT_TIMED(1);   /* sample_history: ONE constrained site */
+      bool acc; sample_site_trajectory(c, out, deltas.p[i].site, deltas.p[i].from, deltas.p[i].to, ge1, T, true, acc); }
   }
+#endif
   double muT = mu * T;
   int l = 0;
   if ((double)L * muT * muT < 2e-6) l = L;
