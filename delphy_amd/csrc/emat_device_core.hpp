@@ -85,6 +85,32 @@ constexpr uint32_t k_lds_dyn_base = k_lds_tables_bytes + k_lds_ctx_bytes + (k_rn
 // A function whose calls must not be marked as tail calls: its callees then qualify for LLVM's no-callee-saved-registers
 // optimisation.  The top of the call tree carries it; below, calls keep the standard convention.
 #define EMAT_NOTAIL __attribute__((disable_tail_calls))
+// Four small functions of the topology moves are INLINED at their call sites since round 6 (-DEMAT_OUTL_<TAG> puts one back out of line for an A/B): a non-leaf
+// call costs a chain a whole-wave save of the VGPR that holds the return address and its reload from L2 before the return, and these are called in loops --
+// KTP / SST: the K-truncated Poisson draw and the trajectory of one site, three rejection rounds per constrained site (+ 1.2 % of a pass together);
+// HOP / SLIDE: tree_editing's hop and slide, once per level an SPR climbs (+ 0.5 % and + 0.3 %).  Seven others measured at +- 0.2 % or worse stay out of line
+// (summarize_closed_mutations, finish_inner_graft_analysis, adjust_mutational_history, propose_new_inner_graft_mutations, sample_mutational_history,
+// peel_inner_graft, study_pick_time_in_region; study_log_alpha_in_region - 0.5 %).
+#ifdef EMAT_OUTL_KTP
+#define EMAT_FN_KTP EMAT_DN
+#else
+#define EMAT_FN_KTP EMAT_DF
+#endif
+#ifdef EMAT_OUTL_SST
+#define EMAT_FN_SST EMAT_DN
+#else
+#define EMAT_FN_SST EMAT_DF
+#endif
+#ifdef EMAT_OUTL_HOP
+#define EMAT_FN_HOP EMAT_DN
+#else
+#define EMAT_FN_HOP EMAT_DF
+#endif
+#ifdef EMAT_OUTL_SLIDE
+#define EMAT_FN_SLIDE EMAT_DN
+#else
+#define EMAT_FN_SLIDE EMAT_DF
+#endif
 // -DEMAT_COUNT_CALLS: scripts/count_calls.py puts EMAT_CALLED(header) at the top of every device function of a copy of these
 // headers; calls are counted per (header, line) in g_fn_ticks[..][1] and read with emat_debug_fn_ticks.
 #ifdef EMAT_COUNT_CALLS

@@ -132,7 +132,7 @@ EMAT_DN Edit edit_slide_root_v(Ctx& c, Edit e, double new_t_P) {   // tree_editi
   return e;
 }
 EMAT_DF void edit_slide_root(Ctx& c, Edit& e, double new_t_P) { e = edit_slide_root_v(c, e, new_t_P); }
-EMAT_DN Edit edit_slide_P_along_branch_v(Ctx& c, Edit e, double new_t_P) {   // tree_editing.cpp:31-112
+EMAT_FN_SLIDE Edit edit_slide_P_along_branch_v(Ctx& c, Edit e, double new_t_P) {   // tree_editing.cpp:31-112
   const int X = e.X, P = nodes_of(c)[X].parent;
   EMAT_CHECK(c, !is_tip(c, P));
   if (P == hdr_of(c)->root) return edit_slide_root_v(c, e, new_t_P);
@@ -185,7 +185,7 @@ EMAT_DN Edit edit_slide_P_along_branch_v(Ctx& c, Edit e, double new_t_P) {   // 
   return e;
 }
 EMAT_DF void edit_slide_P_along_branch(Ctx& c, Edit& e, double new_t_P) { e = edit_slide_P_along_branch_v(c, e, new_t_P); }
-EMAT_DN void edit_do_hop_up(Ctx& c, int X) {   // tree_editing.cpp:164-231
+EMAT_FN_HOP void edit_do_hop_up(Ctx& c, int X) {   // tree_editing.cpp:164-231
   EMAT_CHECK(c, X != hdr_of(c)->root);
   const int P = nodes_of(c)[X].parent;
   EMAT_CHECK(c, !is_tip(c, P) && P != hdr_of(c)->root && nmuts(c, P) == 0);
@@ -337,7 +337,9 @@ EMAT_DF KTruncPoisson ktp_make(double lambda, int min_k) {   // (inlined into it
   return d;
 }
 // (the distribution's five numbers as scalar arguments: a struct of 40 bytes passed by value goes through the caller's private frame all the same)
-EMAT_DN int ktp_sample_s(Ctx& c, double lambda, int min_k, double normalization, double term_before_min_k, double max_k) {
+// (Inlined into the trajectory sampler, and that into the history sampler, since round 6: three rejection rounds per constrained site, each a call of this and
+// each call a whole-wave save and its reload -- out of line they cost 1.2 % of a pass)
+EMAT_FN_KTP int ktp_sample_s(Ctx& c, double lambda, int min_k, double normalization, double term_before_min_k, double max_k) {
   KTruncPoisson d; d.lambda = lambda; d.min_k = min_k; d.normalization = normalization; d.term_before_min_k = term_before_min_k; d.max_k = max_k;
   if (d.normalization == 0.0) { int guard = 0; while (guard++ < (1 << 26)) { int k = poisson(c, d.lambda); if (k >= d.min_k) return k; } return d.min_k; }
   double u = uniform_co(c, 0.0, d.normalization);
@@ -358,12 +360,13 @@ EMAT_DF bool open_room(Ctx& c, SVec<MutRec>& out, int extra) {
 }
 // (The vector's header by value, in and out, and the distribution as scalars: see sd_push_front_v.  The trajectory was accepted exactly when the
 // vector came back longer: a trajectory has at least min_k >= 1 mutations.)
-EMAT_DN SVec<MutRec> sample_site_trajectory_v(Ctx& c, SVec<MutRec> out, int l, int from, int to, double d_lambda, int d_min_k, double d_normalization, double d_term_before_min_k, double d_max_k,
+EMAT_FN_SST SVec<MutRec> sample_site_trajectory_v(Ctx& c, SVec<MutRec> out, int l, int from, int to, double d_lambda, int d_min_k, double d_normalization, double d_term_before_min_k, double d_max_k,
                                               double T, bool accept_only_if_match) {
   int n = 0; int s = from;
   int guard = 0;
-  while (guard++ < (1 << 26)) {
-    n = ktp_sample_s(c, d_lambda, d_min_k, d_normalization, d_term_before_min_k, d_max_k);
+  while (guard++ < (1 << 26)) { EMAT_TIMED(1);   /* site_trajectory: one rejection round (ktp_sample + states) */
+    { EMAT_TIMED(1);   /* site_trajectory: ktp_sample_s */
+    n = ktp_sample_s(c, d_lambda, d_min_k, d_normalization, d_term_before_min_k, d_max_k); }
     if (!open_room(c, out, n)) return out;
     MutRec* rec = out.p + out.n;
     s = from;
@@ -372,6 +375,7 @@ EMAT_DN SVec<MutRec> sample_site_trajectory_v(Ctx& c, SVec<MutRec> out, int l, i
     if (!accept_only_if_match) return out;   // caller restarts from scratch on its own terms
   }
   MutRec* rec = out.p + out.n;
+  EMAT_TIMED(1);   /* site_trajectory: times, sort, records */
   for (int i = 0; i < n; ++i) rec[i].t = uniform_co(c, -T, 0.0);
   for (int i = 1; i < n; ++i) { double x = rec[i].t; int j = i - 1; while (j >= 0 && rec[j].t > x) { rec[j + 1].t = rec[j].t; --j; } rec[j + 1].t = x; }   // the times alone: the states keep their order
   int prev = from;
