@@ -147,7 +147,7 @@ template <class CtxT> __device__ inline void init_ctx(CtxT& c, uint8_t* slab, ui
   c.only_displacing_inner_nodes = a.flags.only_displacing_inner_nodes != 0;
   c.topology_moves_enabled = a.flags.topology_moves_enabled != 0;
   c.includes_run_root = (c.H->flags & k_flag_includes_run_root) != 0;
-  c.rng_key = c.H->rng_key; c.rng_ctr = c.H->rng_counter; c.rng_spare = c.H->rng_spare; c.rng_has_spare = c.H->rng_has_spare != 0; c.phase = 0; c.svc = 0; c.frame = nullptr;
+  c.rng_key = c.H->rng_key; c.rng_ctr = c.H->rng_counter; c.rng_spare = c.H->rng_spare; c.rng_has_spare = c.H->rng_has_spare != 0; c.rng_short = false; c.phase = 0; c.svc = 0; c.frame = nullptr;
   c.rng_base = c.rng_ctr - (uint64_t)k_rng_blocks;   // nothing computed ahead yet: the chain's first step asks the wave for it
   c.mu_prop = 0.0; c.sc_top = c.H->scratch_begin; c.A = nullptr; c.a_top = 0; c.a_end = 0; c.failed = false; c.bytes = 0; c.bytes_w = 0;
   c.tr_kind = -1.0; c.tr_node = -1.0; c.tr_acc = 0.0; c.tr_log_mh = 0.0;

@@ -85,12 +85,13 @@ constexpr uint32_t k_lds_dyn_base = k_lds_tables_bytes + k_lds_ctx_bytes + (k_rn
 // A function whose calls must not be marked as tail calls: its callees then qualify for LLVM's no-callee-saved-registers
 // optimisation.  The top of the call tree carries it; below, calls keep the standard convention.
 #define EMAT_NOTAIL __attribute__((disable_tail_calls))
-// Four small functions of the topology moves are INLINED at their call sites since round 6 (-DEMAT_OUTL_<TAG> puts one back out of line for an A/B): a non-leaf
-// call costs a chain a whole-wave save of the VGPR that holds the return address and its reload from L2 before the return, and these are called in loops --
-// KTP / SST: the K-truncated Poisson draw and the trajectory of one site, three rejection rounds per constrained site (+ 1.2 % of a pass together);
-// HOP / SLIDE: tree_editing's hop and slide, once per level an SPR climbs (+ 0.5 % and + 0.3 %).  Seven others measured at +- 0.2 % or worse stay out of line
-// (summarize_closed_mutations, finish_inner_graft_analysis, adjust_mutational_history, propose_new_inner_graft_mutations, sample_mutational_history,
-// peel_inner_graft, study_pick_time_in_region; study_log_alpha_in_region - 0.5 %).
+// Thirteen functions of the topology moves are INLINED at their call sites since round 6 (-DEMAT_OUTL_<TAG> puts one back out of line for an A/B); two large
+// ones stay out of line (-DEMAT_INL_<TAG> inlines one).  Measured one at a time and in combination at C4: KTP / SST -- the
+// K-truncated Poisson draw and the trajectory of one site, three rejection rounds per constrained site -- + 1.2 % of a pass together; HOP / SLIDE -- tree_editing's
+// hop and slide, once per level an SPR climbs -- + 0.5 % and + 0.3 %; FINI, PNIG, PEEL, PICKT, ADJ (finish_inner_graft_analysis, propose_new_inner_graft_mutations,
+// peel_inner_graft, study_pick_time_in_region, adjust_mutational_history) +- 0.1 % each and together; with SMH, SUMM, APPLY, LALPHA (sample_mutational_history,
+// summarize_closed_mutations, apply_inner_graft, study_log_alpha_in_region: - 0.2 ... - 0.5 % each ALONE) + 1.2 % all nine together -- what a call costs depends on what
+// else is out of line around it.  START (start_inner_graft_analysis, four call sites) - 0.8 %, TOPO (spr_move_topology) - 0.4 %: they stay calls.
 #ifdef EMAT_OUTL_KTP
 #define EMAT_FN_KTP EMAT_DN
 #else
@@ -110,6 +111,61 @@ constexpr uint32_t k_lds_dyn_base = k_lds_tables_bytes + k_lds_ctx_bytes + (k_rn
 #define EMAT_FN_SLIDE EMAT_DN
 #else
 #define EMAT_FN_SLIDE EMAT_DF
+#endif
+#ifdef EMAT_OUTL_FINI
+#define EMAT_FN_FINI EMAT_DN
+#else
+#define EMAT_FN_FINI EMAT_DF
+#endif
+#ifdef EMAT_OUTL_PNIG
+#define EMAT_FN_PNIG EMAT_DN
+#else
+#define EMAT_FN_PNIG EMAT_DF
+#endif
+#ifdef EMAT_OUTL_PEEL
+#define EMAT_FN_PEEL EMAT_DN
+#else
+#define EMAT_FN_PEEL EMAT_DF
+#endif
+#ifdef EMAT_OUTL_PICKT
+#define EMAT_FN_PICKT EMAT_DN
+#else
+#define EMAT_FN_PICKT EMAT_DF
+#endif
+#ifdef EMAT_OUTL_ADJ
+#define EMAT_FN_ADJ EMAT_DN
+#else
+#define EMAT_FN_ADJ EMAT_DF
+#endif
+#ifdef EMAT_OUTL_SMH
+#define EMAT_FN_SMH EMAT_DN
+#else
+#define EMAT_FN_SMH EMAT_DF
+#endif
+#ifdef EMAT_OUTL_SUMM
+#define EMAT_FN_SUMM EMAT_DN
+#else
+#define EMAT_FN_SUMM EMAT_DF
+#endif
+#ifdef EMAT_OUTL_APPLY
+#define EMAT_FN_APPLY EMAT_DN
+#else
+#define EMAT_FN_APPLY EMAT_DF
+#endif
+#ifdef EMAT_OUTL_LALPHA
+#define EMAT_FN_LALPHA EMAT_DN
+#else
+#define EMAT_FN_LALPHA EMAT_DF
+#endif
+#ifdef EMAT_INL_START
+#define EMAT_FN_START EMAT_DF
+#else
+#define EMAT_FN_START EMAT_DN
+#endif
+#ifdef EMAT_INL_TOPO
+#define EMAT_FN_TOPO EMAT_DF
+#else
+#define EMAT_FN_TOPO EMAT_DN
 #endif
 // -DEMAT_COUNT_CALLS: scripts/count_calls.py puts EMAT_CALLED(header) at the top of every device function of a copy of these
 // headers; calls are counted per (header, line) in g_fn_ticks[..][1] and read with emat_debug_fn_ticks.
@@ -176,6 +232,7 @@ struct Ctx {
   uint32_t sc_top;            // HBM arena bump pointer (byte offset from G)
   bool failed;
   bool mv_rng_had_spare;      // RNG position at the first draw of the current move: (mv_rng_ctr, mv_rng_had_spare), see stop_for_cells
+  bool rng_short;             // a LEAF move asked for a number beyond what the wave has computed ahead (rng_next64_t<true>): it commits nothing and is run again out of line
   // statistics
   int64_t bytes;
   int64_t bytes_w;            // the part of `bytes` that is written (cells, re-timed lists, region records, re-hung nodes): roofline.algorithmic_write_bytes
@@ -311,7 +368,11 @@ EMAT_DN uint64_t rng_next64_computed(Ctx& c) {
   c.rng_spare = (uint64_t)w[2] | ((uint64_t)w[3] << 32); c.rng_has_spare = true;
   return (uint64_t)w[0] | ((uint64_t)w[1] << 32);
 }
-EMAT_D uint64_t rng_next64(Ctx& c) {
+// kLeaf: for a move compiled as a LEAF function (no call anywhere in it: no return address to park, hence no whole-wave save and reload around every
+// move -- DESIGN.md section 8, round 6).  Its draws come from what the wave computed ahead; should that run out in the middle of the move (a long run
+// of rejected node picks: about one move in 10^4) the draw says so and returns a harmless number, the move commits nothing, and the caller rewinds the
+// stream and runs the same move out of line.
+template <bool kLeaf> EMAT_DF uint64_t rng_next64_t(Ctx& c) {
   if (c.rng_has_spare) { c.rng_has_spare = false; return c.rng_spare; }
   if (k_rng_blocks != 0) {
     const uint64_t k = c.rng_ctr - c.rng_base;
@@ -322,8 +383,10 @@ EMAT_D uint64_t rng_next64(Ctx& c) {
       return (uint64_t)w.x | ((uint64_t)w.y << 32);
     }
   }
+  if (kLeaf) { c.rng_short = true; return 0x8000000000000000ull; }
   return rng_next64_computed(c);
 }
+EMAT_D uint64_t rng_next64(Ctx& c) { return rng_next64_t<false>(c); }
 // All lanes: the blocks of the next k_rng_blocks counters (the caller synchronises the wave before and after).
 EMAT_D void rng_fill(Ctx& c, int lane) {
   if (k_rng_blocks == 0) return;
@@ -350,6 +413,15 @@ EMAT_D double u01_oc(Ctx& c) { return to_oc(rng_next64(c)); }
 EMAT_D double uniform_co(Ctx& c, double lo, double hi) { return lo + (hi - lo) * u01_co(c); }
 EMAT_D double uniform_oc(Ctx& c, double lo, double hi) { return lo + (hi - lo) * u01_oc(c); }
 EMAT_D int uniform_int(Ctx& c, int n) { return (int)__umul64hi(rng_next64(c), (uint64_t)n); }
+template <bool kLeaf> EMAT_DF double t_u01_co(Ctx& c) { return to_co(rng_next64_t<kLeaf>(c)); }
+template <bool kLeaf> EMAT_DF double t_u01_oo(Ctx& c) { return to_oo(rng_next64_t<kLeaf>(c)); }
+template <bool kLeaf> EMAT_DF double t_uniform_co(Ctx& c, double lo, double hi) { return lo + (hi - lo) * t_u01_co<kLeaf>(c); }
+template <bool kLeaf> EMAT_DF double t_uniform_oc(Ctx& c, double lo, double hi) { return lo + (hi - lo) * to_oc(rng_next64_t<kLeaf>(c)); }
+template <bool kLeaf> EMAT_DF int t_uniform_int(Ctx& c, int n) { return (int)__umul64hi(rng_next64_t<kLeaf>(c), (uint64_t)n); }
+// the four transcendentals: the shared out-of-line copy, or -- in a leaf move -- the same OCML routine inlined (the same numbers)
+template <bool kLeaf> EMAT_DF double t_log(double x) { if constexpr (kLeaf) return ::log(x); else return m_log(x); }
+template <bool kLeaf> EMAT_DF double t_exp(double x) { if constexpr (kLeaf) return ::exp(x); else return m_exp(x); }
+template <bool kLeaf> EMAT_DF double t_log1p(double x) { if constexpr (kLeaf) return ::log1p(x); else return m_log1p(x); }
 EMAT_D double gaussian(Ctx& c, double mean, double sigma) {
   uint64_t a = rng_next64(c), b = rng_next64(c);
   double u1 = to_oc(a), u2 = to_co(b);
@@ -829,16 +901,16 @@ EMAT_DF double skygrid_log_N_uniform(const EMAT_CONST_AS PopTable* p, double t) 
   const double cc = (t - x[k - 1]) / (x[k] - x[k - 1]);
   return (1 - cc) * ga[k - 1] + cc * ga[k];
 }
-EMAT_DF double log_pop_ratio_uniform(const PopTable* pp, double t_new, double t_old) {
+template <bool kLeaf = false> EMAT_DF double log_pop_ratio_uniform(const PopTable* pp, double t_new, double t_old) {
   const EMAT_CONST_AS PopTable* p = uniform_const_ptr(pp);
   const int kind = p->kind;
   if (kind == 0) return 0.0;
   t_new = uniform_f64(t_new); t_old = uniform_f64(t_old);
   if (kind == 2) return skygrid_log_N_uniform(p, t_new) - skygrid_log_N_uniform(p, t_old);
   const double t0 = p->p[0], n0 = p->p[1], gr = p->p[2], floor_n = p->p[3];
-  double a = n0 * m_exp((t_new - t0) * gr); a = floor_n > a ? floor_n : a;
-  double b = n0 * m_exp((t_old - t0) * gr); b = floor_n > b ? floor_n : b;
-  return m_log(a / b);
+  double a = n0 * t_exp<kLeaf>((t_new - t0) * gr); a = floor_n > a ? floor_n : a;
+  double b = n0 * t_exp<kLeaf>((t_old - t0) * gr); b = floor_n > b ? floor_n : b;
+  return t_log<kLeaf>(a / b);
 }
 EMAT_D double exp_unclamped_int(const PopTable& p, double a, double b) { double n0 = p.p[1], g = p.p[2], t0 = p.p[0]; return n0 / g * m_exp(g * (a - t0)) * m_expm1(g * (b - a)); }
 EMAT_DN double skygrid_log_int_N(const PopTable& p, double a, double b) {   // pop_model.cpp:247-330 with gamma_eff = gamma
@@ -1005,9 +1077,9 @@ template <bool kGrow = true> EMAT_DF double coal_delta_on_add_interval(Ctx& c, d
   EMAT_COUNT(c, 13, cell_end - cell_start + 1); EMAT_COUNT(c, 14, 1);
   return d;
 }
-template <bool kGrow = true> EMAT_DF double coal_delta_displace_coalescence(Ctx& c, double old_t, double new_t) { EMAT_TIMED(0);   // cpp:310-326
+template <bool kGrow = true, bool kLeaf = false> EMAT_DF double coal_delta_displace_coalescence(Ctx& c, double old_t, double new_t) { EMAT_TIMED(0);   // cpp:310-326
   double d = (old_t <= new_t) ? coal_delta_on_add_interval<kGrow>(c, old_t, new_t, -1.0) : coal_delta_on_add_interval<kGrow>(c, new_t, old_t, +1.0);
-  { EMAT_TIMED(0); d -= log_pop_ratio_uniform(c.pop, new_t, old_t); }
+  { EMAT_TIMED(0); d -= log_pop_ratio_uniform<kLeaf>(c.pop, new_t, old_t); }
   return d;
 }
 template <bool kGrow = true> EMAT_DF double coal_delta_displace_tip(Ctx& c, double old_t, double new_t) {           // cpp:337-353

@@ -274,7 +274,7 @@ EMAT_DF void edit_end(Ctx& c, Edit& e) {
   }
 }
 // spr_move.cpp:1101-1156
-EMAT_DN void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) { EMAT_TIMED(1);
+EMAT_FN_TOPO void spr_move_topology(Ctx& c, int X, int SS, double new_t_P) { EMAT_TIMED(1);
   if (c.failed) return;
   EMAT_CHECK(c, X != hdr_of(c)->root);
   const int P = nodes_of(c)[X].parent, G = nodes_of(c)[P].parent, S = sibling_of(c, P, X);
@@ -389,7 +389,7 @@ EMAT_DF void sample_site_trajectory(Ctx& c, SVec<MutRec>& out, int l, int from, 
   out = r;
 }
 // spr_move.cpp:1164-1370; result appended into a fresh open-ended scratch vector (caller trims)
-EMAT_DN SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double mu, const SVec<SdRec>& deltas) { EMAT_TIMED(1);
+EMAT_FN_SMH SVec<MutRec> sample_mutational_history(Ctx& c, int L, double T, double mu, const SVec<SdRec>& deltas) { EMAT_TIMED(1);
   // the LDS arena if it has room for the constrained sites (one mutation each, rarely three) and the L (mu T)^2 / 2 other sites
   // expected to be hit twice or more on a long branch; should more turn up, the vector moves to HBM (open_room)
   const double twice = 0.5 * (double)L * (mu * T) * (mu * T);
@@ -455,7 +455,7 @@ EMAT_DN SVec<MutRec> sample_unconstrained_mutational_history(Ctx& c, int L, doub
   return out;
 }
 // spr_move.cpp:1409-1439
-EMAT_DN void adjust_mutational_history(Ctx& c, const SVec<MutRec> h, const SVec<SdRec> deltas, int end_branch, double end_t) { EMAT_TIMED(1);   // (headers by value: only the records change)
+EMAT_FN_ADJ void adjust_mutational_history(Ctx& c, const SVec<MutRec> h, const SVec<SdRec> deltas, int end_branch, double end_t) { EMAT_TIMED(1);   // (headers by value: only the records change)
   for (int i = h.n - 1; i >= 0; --i) {
     MutRec& m = h.p[i];
     m.t += end_t;
@@ -651,7 +651,7 @@ EMAT_DN void apply_rooty_graft(Ctx& c, const Graft& g) { EMAT_TIMED(1);   // spr
 }
 
 // ---- inner grafts -----------------------------------------------------------------------------------------
-EMAT_DN void start_inner_graft_analysis(Ctx& c, int X, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:582-738
+EMAT_FN_START void start_inner_graft_analysis(Ctx& c, int X, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:582-738
   g.X = X; g.rooty = false; g.delta_log_G = g.log_alpha_mut = 0.0; g.nbi = 0; g.bi = nullptr;
   const int P = nodes_of(c)[X].parent;
   EMAT_CHECK(c, X != hdr_of(c)->root && P != hdr_of(c)->root);
@@ -769,7 +769,7 @@ EMAT_DN void start_inner_graft_analysis(Ctx& c, int X, Graft& g) { EMAT_TIMED(1)
   } }
   return;
 }
-EMAT_DN void propose_new_inner_graft_mutations(Ctx& c, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:740-785
+EMAT_FN_PNIG void propose_new_inner_graft_mutations(Ctx& c, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:740-785
   const int X = g.X;
   for (int idx = 0; idx < g.nbi && !c.failed; ++idx) {
     BranchInfo& bi = g.bi[idx];
@@ -791,7 +791,7 @@ EMAT_DN void propose_new_inner_graft_mutations(Ctx& c, Graft& g) { EMAT_TIMED(1)
     recompute_open_pl_A(c, bi);
   }
 }
-EMAT_DN void finish_inner_graft_analysis(Ctx& c, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:787-836
+EMAT_FN_FINI void finish_inner_graft_analysis(Ctx& c, Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:787-836
   if (c.failed || g.nbi == 0) return;
   const int X = g.X; const double t_X = nodes_of(c)[X].t;
   g.delta_log_G = 0.0;
@@ -810,7 +810,7 @@ EMAT_D void recalc_lambda_along_hot_path(Ctx& c, const Graft& g) {   // spr_move
   for (int i = 0; i + 1 < g.nbi; ++i) { int A = g.bi[i].A, B = g.bi[i].B; nodes_of(c)[A].lambda = nodes_of(c)[B].lambda - delta_lambda_across_branch(c, B); }
 }
 EMAT_D void erase_marked_muts(Ctx& c, int node) { MutRec* m = muts_of(c, node); int n = nmuts(c, node), w = 0; for (int i = 0; i < n; ++i) if (m[i].site != -1) m[w++] = m[i]; set_list_cnt(c, nodes_of(c)[node].muts, w); }
-EMAT_DN void peel_inner_graft(Ctx& c, const Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:838-953
+EMAT_FN_PEEL void peel_inner_graft(Ctx& c, const Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:838-953
   if (c.failed || g.nbi == 0) return;
   const int X = g.X, P = nodes_of(c)[X].parent, root = hdr_of(c)->root;
   const double t_X = nodes_of(c)[X].t, t_P = nodes_of(c)[P].t;
@@ -859,7 +859,7 @@ EMAT_DN void peel_inner_graft(Ctx& c, const Graft& g) { EMAT_TIMED(1);   // spr_
   recalc_lambda_along_hot_path(c, g);
   sc_release(c, mark);
 }
-EMAT_DN void apply_inner_graft(Ctx& c, const Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:955-1069
+EMAT_FN_APPLY void apply_inner_graft(Ctx& c, const Graft& g) { EMAT_TIMED(1);   // spr_move.cpp:955-1069
   if (c.failed || g.nbi == 0) return;
   const int X = g.X, root = hdr_of(c)->root;
   const BranchInfo& fin = g.bi[g.nbi - 1];
@@ -918,7 +918,7 @@ EMAT_D int count_min_mutations(const Ctx& c, const Graft& g) {
   int r = 0; for (int i = 0; i < g.nbi; ++i) if (!g.bi[i].is_open) r += g.bi[i].hot_deltas.n; return r;
 }
 // summarize_closed_mutations: fresh scratch delta list with room for `extra` more entries
-EMAT_DN SVec<SdRec> summarize_closed_mutations(Ctx& c, const Graft& g, int extra) { EMAT_TIMED(1);
+EMAT_FN_SUMM SVec<SdRec> summarize_closed_mutations(Ctx& c, const Graft& g, int extra) { EMAT_TIMED(1);
   int tot = 0;
   if (g.rooty) tot = g.bi[k_SPX].hot_deltas.n; else for (int i = 0; i < g.nbi; ++i) if (!g.bi[i].is_open) tot += g.bi[i].hot_deltas.n;
   SVec<SdRec> r = sc_vec<SdRec>(c, tot + extra + 1);
@@ -1221,7 +1221,7 @@ EMAT_D int study_pick_nexus_region(Ctx& c, const Study& st) {   // spr_study.cpp
   for (int i = 0; i < st.regions.n; ++i) { if (st.regions.p[i].W >= r) return i; r -= st.regions.p[i].W; }
   return 0;
 }
-EMAT_DN double study_pick_time_in_region(Ctx& c, const Study& st, int idx) {   // spr_study.cpp:424-471
+EMAT_FN_PICKT double study_pick_time_in_region(Ctx& c, const Study& st, int idx) {   // spr_study.cpp:424-471
   const Region& r = st.regions.p[idx];
   if (r.t_min != k_neg_dbl_max) return uniform_oc(c, r.t_min, r.t_max);
   RootRegionParams p = root_region_params(c, st, r);
@@ -1249,7 +1249,7 @@ EMAT_D int study_find_region(const Study& st, int branch, double t) {   // spr_s
   for (int i = 0; i < st.regions.n; ++i) { const Region& r = st.regions.p[i]; if (r.branch == branch && r.t_min < t && t <= r.t_max) return i; }
   return -1;
 }
-EMAT_DN double study_log_alpha_in_region(Ctx& c, const Study& st, int idx, double t) {   // spr_study.cpp:486-549
+EMAT_FN_LALPHA double study_log_alpha_in_region(Ctx& c, const Study& st, int idx, double t) {   // spr_study.cpp:486-549
   const Region& r = st.regions.p[idx];
   double log_p_region = r.logW - m_log(st.sum_W);
   if (r.t_min != k_neg_dbl_max) return log_p_region - m_log(r.t_max - r.t_min);

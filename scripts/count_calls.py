@@ -42,7 +42,7 @@ def build():
         t, n = instrument(open(p).read(), fid); open(p, "w").write(t); print(f, n, "functions instrumented")
     out = ROOT + "/delphy_amd/libemat_calls.so"
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-function", "-Wno-unused-result", "-mllvm", "-amdgpu-lower-module-lds-strategy=module", "-DEMAT_COUNT_CALLS",
-           '-DEMAT_BUILD_ID="calls"', "-shared", "-o", out, "emat_backend.hip", "emat_run.cpp", "emat_dphy.cpp"]
+           '-DEMAT_BUILD_ID="calls"', "-shared", "-o", out, "emat_backend.hip", "emat_run.cpp", "emat_dphy.cpp", "emat_multi.cpp", "-ldl"]
     subprocess.run(cmd, cwd=tmp + "/delphy_amd/csrc", check=True, stderr=subprocess.DEVNULL)
     print("built", out)
 
