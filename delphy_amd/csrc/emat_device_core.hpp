@@ -91,7 +91,8 @@ constexpr uint32_t k_lds_dyn_base = k_lds_tables_bytes + k_lds_ctx_bytes + (k_rn
 // hop and slide, once per level an SPR climbs -- + 0.5 % and + 0.3 %; FINI, PNIG, PEEL, PICKT, ADJ (finish_inner_graft_analysis, propose_new_inner_graft_mutations,
 // peel_inner_graft, study_pick_time_in_region, adjust_mutational_history) +- 0.1 % each and together; with SMH, SUMM, APPLY, LALPHA (sample_mutational_history,
 // summarize_closed_mutations, apply_inner_graft, study_log_alpha_in_region: - 0.2 ... - 0.5 % each ALONE) + 1.2 % all nine together -- what a call costs depends on what
-// else is out of line around it.  START (start_inner_graft_analysis, four call sites) - 0.8 %, TOPO (spr_move_topology) - 0.4 %: they stay calls.
+// else is out of line around it.  START (start_inner_graft_analysis, four call sites) - 0.8 %, TOPO (spr_move_topology) - 0.4 %: they stay calls; so do the leaf helpers sd_push_back_v,
+// find_MRCA_of, reconstruct_missing_sites_at, calc_site_state_at and edit_flip (- 0.1 ... - 0.5 % each inlined).
 #ifdef EMAT_OUTL_KTP
 #define EMAT_FN_KTP EMAT_DN
 #else
