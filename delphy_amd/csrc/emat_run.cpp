@@ -233,6 +233,7 @@ struct RunDriver {
     const Kids* const kids = tp_kids;
     parallel_for((int)roots.size(), [&](int ri) {
       static thread_local std::vector<int32_t> work, inner, stack;   // (8 000 tasks per cycle: no allocation in any of them)
+      static thread_local std::vector<std::pair<uint64_t, int32_t>> keyed;
       work.clear(); work.push_back(roots[(size_t)ri]);
       SplitMix64 rng(round_seed ^ (0xD6E8FEB86659FD93ull * (uint64_t)(roots[(size_t)ri] + 1)));   // a stream per part: the result does not depend on the threads
       bool first = true;
@@ -252,14 +253,19 @@ struct RunDriver {
         first = false;
         if (size <= limit || inner.empty()) continue;
         // as many new cut nodes as would make the pieces `limit` nodes on average, a uniformly drawn subset of the inner nodes.
-        // The subset is drawn from the inner nodes IN NODE ORDER, not in the order the walk met them: the walk's order is the piece's
-        // topology, which the pass changes, while the set is not -- so the draw is a function of (what a pass leaves alone, the stream)
-        // alone, and repeating it on the tree after the pass gives the very same cut nodes (round 6: emat_run_debug_redraw_partition,
-        // tests/test_host_driver.py; until then the invariance held in distribution only).
-        std::sort(inner.begin(), inner.end());
+        // The subset must not depend on the ORDER in which the walk met the nodes -- that order is the piece's topology, which the pass changes, while
+        // the set is not -- so that the draw is a function of (what a pass leaves alone, the stream) alone and repeating it on the tree after the pass
+        // gives the very same cut nodes (round 6: emat_run_debug_redraw_partition, tests/test_host_driver.py; until then the invariance held in
+        // distribution only).  Every inner node gets a pseudo-random 64-bit key from (a salt drawn from the part's stream, its own index) and the `want`
+        // smallest keys are taken: a uniform subset whatever the order of `inner`, found by selection in O(n) -- sorting the nodes and shuffling, the
+        // first version of this, cost the refinement 0.45 ms per cycle at C4.
         const int want = std::min((int)inner.size(), std::max(1, (size + limit - 1) / limit - 1));
-        for (int k = 0; k < want; ++k) { const int j = k + rng.below((int)inner.size() - k); std::swap(inner[(size_t)k], inner[(size_t)j]); }
-        for (int k = 0; k < want; ++k) { mark_cut(inner[(size_t)k]); extra[(size_t)ri].push_back(inner[(size_t)k]); work.push_back(inner[(size_t)k]); }
+        const uint64_t salt = rng.next();
+        keyed.clear();
+        for (int32_t v : inner) { uint64_t z = salt ^ ((uint64_t)(uint32_t)v * 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; keyed.push_back({z ^ (z >> 31), v}); }
+        std::nth_element(keyed.begin(), keyed.begin() + (want - 1), keyed.end());
+        std::sort(keyed.begin(), keyed.begin() + want);   // (the few that were drawn, by key: the order in which their pieces are looked at next)
+        for (int k = 0; k < want; ++k) { const int32_t v = keyed[(size_t)k].second; mark_cut(v); extra[(size_t)ri].push_back(v); work.push_back(v); }
         work.push_back(c);   // what is left above the new cut nodes may still be too large
       }
     }, 16, 32);
