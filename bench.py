@@ -604,6 +604,8 @@ def main():
             mixing["at_scale"] = {"source": "profiles/posterior_scale_latest.json (tests/posterior_scale.py: %d tips, %d seeds, burn-in %d cycles)" % (ps["tips"], ps["seeds"], ps["burn_in"]),
                                   "measured_on_emat_build_id": ps.get("emat_build_id"), "part_size_limit": ps.get("part_size_limit"),
                                   "worst_abs_pooled_z": ps.get("worst_abs_pooled_z"),
+                                  # (every run of the comparison made on this round's code, not only the last one, and what they say together)
+                                  "replicates": ps.get("replicates"),
                                   "pooled_z": {arm: {k: v["pooled_z"] for k, v in q.items()} for arm, q in ps.get("pooled", {}).items()},
                                   "ess_per_s": {"gpu_at_benchmark_density": ps.get("ess_per_s_at_benchmark_density"), "oracle_8_parts_8_threads": ps.get("ess_per_s_reference_policy_oracle")}}
         except Exception as e:
