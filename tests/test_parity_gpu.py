@@ -213,13 +213,22 @@ def test_randomised_global_move_statistics():
         try:
             configure(gpu, sc, ref, parts, incl, seeds, root_part, None, nu_l=nu_l, evo=evo)
             configure(orc, sc, ref, parts, incl, seeds, root_part, None, nu_l=nu_l, evo=evo)
+            scale = np.ones(2)
             for rounds in range(2):
                 Tg, Mg, ng = gpu.global_stats(P)
                 To, Mo, no = orc.global_stats(P)
                 assert ng == no and np.array_equal(Mg, Mo), (what, Mg.tolist(), Mo.tolist())
                 assert rel_close(Tg, To, 1e-9), (what, Tg.tolist(), To.tolist())
-                assert rel_close(np.array(gpu.totals()), np.array(orc.totals()), 1e-9), what
+                # The totals are maintained INCREMENTALLY by both sides (as by the reference): a total that starts at -2.3e16 -- an exponential-growth
+                # model whose population is 1e-12 in the grid's oldest cells -- and shrinks to -1e9 as the root moves keeps the ABSOLUTE rounding error of
+                # its start, one unit in the last place of 2.3e16 = 4.0 (EMAT_FUZZ_SEED=6102, case 29, found in round 6; round 5's code gives the same
+                # numbers; a recomputation agrees to the last digit).  So the tolerance is relative to the largest magnitude the total has had.
+                tg, to = np.array(gpu.totals()), np.array(orc.totals())
+                scale = np.maximum(scale, np.abs(to))
+                assert np.all(np.abs(tg - to) <= 1e-9 * scale), (what, tg.tolist(), to.tolist())
                 gpu.run_moves_per_part(800); gpu.synchronize(); orc.run_moves_per_part(800, threads=4)
+            gpu.recalc_derived(); orc.recalc_derived()           # ... and recomputed from scratch the totals agree relative to what they ARE
+            assert rel_close(np.array(gpu.totals()), np.array(orc.totals()), 1e-9), what
         except d.EmatError as ex:
             raise AssertionError("%s: %s" % (what, ex)) from ex
         finally:
