@@ -938,6 +938,13 @@ struct PartHost {
   std::vector<double> trace;       // the part's move trace so far (4 doubles per move), carried over re-materialisations
   double space_boost = 1.0;        // multiplier of the heap and scratch capacities; doubled when the part ran out of space
   int cell_boost = 1;              // multiplier of the room the root part's grid gets to grow into; quadrupled when it ran out
+  // What the moves maintain INCREMENTALLY (lambda_i and the missing-site count of every node, log_G, the partial coalescent prior), kept across a
+  // re-materialisation in the middle of a pass (finish_pass: some part ran out of slab space or grid cells).  The reference recomputes these when a Subrun
+  // is made and never again (subrun.cpp:17-26); recomputing them half way gives the same numbers up to rounding -- and a chain that can tell: a node whose
+  // d log G / dt cancels exactly (every site missing below one child or the other) takes the uniform branch of the bounded exponential with the maintained
+  // lambda_i and the other branch with a recomputed one that is two units in the last place off (EMAT_FUZZ_SEED=6202, case 53, found in round 6).
+  std::vector<double> kept_lambda; std::vector<int32_t> kept_n_missing; double kept_log_G = 0.0, kept_log_aug_prior = 0.0;
+  bool derived_kept = false;       // set by finish_pass just before it re-materialises, consumed (and cleared) by materialize
 };
 
 // The whole tree in HBM (emat_gtree_kernels.hpp) with the host mirrors the partitioner and the coalescent builder need:
@@ -1370,7 +1377,17 @@ emat_status finish_pass(emat_backend* h) {
       ph.stats.status = 0;
     }
     if (verbose_reports()) fprintf(stderr, "[emat] %zu part(s) ran out of slab space or grid cells: re-materialising with more room and running the rest of their moves\n", stopped);
-    h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false;   // every part is re-encoded from its decoded state (tree, RNG, cells, statistics)
+    if (h->derived_valid) {   // (h_slabs is what pull_from_device just decoded: the slabs as the pass left them)
+      parallel_for((int)n, [&](int p) {
+        PartHost& ph = h->parts[(size_t)p];
+        const uint8_t* slab = h->h_slabs.data() + ph.slab_off;
+        const SlabHeader* H = (const SlabHeader*)slab; const NodeRec* N = (const NodeRec*)(slab + H->off_nodes);
+        ph.kept_lambda.resize((size_t)H->n_nodes); ph.kept_n_missing.resize((size_t)H->n_nodes);
+        for (int i = 0; i < H->n_nodes; ++i) { ph.kept_lambda[(size_t)i] = N[i].lambda; ph.kept_n_missing[(size_t)i] = N[i].n_missing; }
+        ph.kept_log_G = H->log_G; ph.kept_log_aug_prior = H->log_aug_prior; ph.derived_kept = true;
+      });
+    }
+    h->slabs_on_device = false; h->host_slabs_current = false; h->headers_current = false;   // every part is re-encoded from its decoded state (tree, RNG, cells, statistics, derived quantities)
     st = launch_moves(h, 0, 0, &counts, 0); if (st) return st;
   }
   return EMAT_OK;
@@ -1577,6 +1594,7 @@ emat_status materialize(emat_backend* h) {
   if (!h->have_ref || !h->have_evo) return fail(h, EMAT_ERR_STATE, "set_ref_sequence and set_evo must precede running");
   if (!h->have_coal) return fail(h, EMAT_ERR_STATE, "emat_build_coalescent_parts must precede running");
   const int trace_cap = h->cfg.trace_moves > 0 ? h->cfg.trace_moves : 0;
+  const bool may_keep = h->derived_valid;   // (a model or reference sequence set since then invalidates what finish_pass kept)
   uint64_t off = 0; h->max_slab_bytes = 0; h->persistent_bytes.assign(h->parts.size(), 0); h->prefix_bytes.assign(h->parts.size(), 0);
   std::vector<SlabGeo> geo(h->parts.size());
   for (size_t p = 0; p < h->parts.size(); ++p) {
@@ -1597,7 +1615,14 @@ emat_status materialize(emat_backend* h) {
     SlabHeader* H = (SlabHeader*)(h->h_slabs.data() + ph.slab_off);
     H->moves_done = ph.stats.moves_done; for (int k = 0; k < 5; ++k) { H->proposed[k] = ph.stats.proposed[k]; H->accepted[k] = ph.stats.accepted[k]; }
     H->alg_bytes = ph.stats.algorithmic_bytes; H->alg_write16 = (uint32_t)(ph.stats.algorithmic_write_bytes / 16); H->device_ticks = ph.stats.device_ticks;
+    if (may_keep && ph.derived_kept && (int)ph.kept_lambda.size() == H->n_nodes) {   // a re-materialisation in the middle of a pass: the maintained values go on as they are (PartHost)
+      NodeRec* N = (NodeRec*)(h->h_slabs.data() + ph.slab_off + H->off_nodes);
+      for (int i = 0; i < H->n_nodes; ++i) { N[i].lambda = ph.kept_lambda[(size_t)i]; N[i].n_missing = ph.kept_n_missing[(size_t)i]; }
+      H->log_G = ph.kept_log_G; H->log_aug_prior = ph.kept_log_aug_prior;
+    } else ph.derived_kept = false;
   });
+  bool all_kept = !h->parts.empty();
+  for (PartHost& ph : h->parts) { all_kept = all_kept && ph.derived_kept; ph.derived_kept = false; }
   assign_size_classes(h);
   h->order_valid = false;
   { emat_status st = upload_shared_cells(h); if (st) return st; }
@@ -1605,7 +1630,7 @@ emat_status materialize(emat_backend* h) {
   HIP_TRY(h->d_slab_off.upload(offs.data(), offs.size()));
   { std::vector<int64_t> z((2 + 2 * k_ticket_log) * h->parts.size(), 0); HIP_TRY(h->d_part_ticks.upload(z.data(), z.size())); }   // + entry / exit ticks of the first k_ticket_log tickets of every part
   { std::vector<int32_t> z(h->parts.size(), 0); HIP_TRY(h->d_part_status.upload(z.data(), z.size())); }
-  h->slabs_on_device = true; h->host_slabs_current = true; h->derived_valid = false;
+  h->slabs_on_device = true; h->host_slabs_current = true; h->derived_valid = all_kept;
   return EMAT_OK;
 }
 

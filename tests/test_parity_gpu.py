@@ -235,6 +235,44 @@ def test_randomised_global_move_statistics():
             gpu.close(); orc.close()
 
 
+def test_a_re_materialisation_in_mid_pass_keeps_what_the_moves_maintain():
+    """What the moves maintain incrementally -- lambda_i, missing-site counts, log_G, the partial prior -- is recomputed when a Subrun is made
+    and never again (subrun.cpp:17-26).  Until round 6 the engine recomputed it whenever a pass was interrupted to give a part more room: the
+    same numbers up to rounding, and a chain that can tell.  The case that showed it (EMAT_FUZZ_SEED=6202, case 53 of the global-statistics
+    sweep): the root part outgrows its coalescent grid in the second pass (401 -> 2 027 cells), every part is re-encoded, and in another
+    part a node under which every site is missing below one child or the other -- d log G / dt = lambda - lambda exactly -- took the uniform
+    branch of the bounded exponential in the reference's arithmetic and the other branch with a recomputed lambda_i two units in the last
+    place off: one move skipped its acceptance draw and the chains parted.  Now the maintained values are carried over (PartHost, emat_backend.hip):
+    two passes, every part's trace equal move for move, lambda_i equal BIT for bit."""
+    from helpers import random_scenario
+    rng = np.random.default_rng(6202)
+    for case in range(54):
+        sc, nu_l, evo, what = random_scenario(rng, case)
+        nparts = int(min(max(1, sc.tree.num_nodes // 24), rng.integers(1, 14)))
+        split_seed = int(rng.integers(1, 10**6))
+    parts, incl, seeds, root_part, ref = split_parts(sc, nparts, split_seed)
+    T = 1600
+    gpu = d.EmatBackend(sc.num_sites, trace_moves=T); orc = OracleEngine(sc.num_sites, trace_moves=T)
+    try:
+        configure(gpu, sc, ref, parts, incl, seeds, root_part, None, nu_l=nu_l, evo=evo)
+        configure(orc, sc, ref, parts, incl, seeds, root_part, None, nu_l=nu_l, evo=evo)
+        cells_before = len(gpu.part_coalescent(root_part)["k_bar_p"])
+        for _ in range(2):
+            gpu.run_moves_per_part(800); gpu.synchronize(); orc.run_moves_per_part(800, threads=4)
+        assert len(gpu.part_coalescent(root_part)["k_bar_p"]) > cells_before + max(512, cells_before), "the root part's grid did not outgrow its slab: the case no longer interrupts a pass"
+        for p in range(len(parts)):
+            tg, to = gpu.part_trace(p, T), orc.part_trace(p, T)
+            assert tg.shape == to.shape
+            same = (tg[:, :3] == to[:, :3]).all(axis=1)
+            assert same.all(), "part %d: first differing move %d: gpu %s oracle %s" % (p, int(np.argmin(same)), tg[int(np.argmin(same))], to[int(np.argmin(same))])
+            n = parts[p].num_nodes
+            lg, ng, _, _ = gpu.part_derived(p, n); lo, no, _, _ = orc.part_derived(p, n)
+            assert np.array_equal(np.asarray(lg).view(np.uint64), np.asarray(lo).view(np.uint64)), "part %d: lambda_i differs in the last place" % p
+            assert np.array_equal(ng, no)
+    finally:
+        gpu.close(); orc.close()
+
+
 def test_parts_that_run_out_of_slab_space_are_regrown_and_finish(monkeypatch):
     """A part whose list heap is too small stops BEFORE a move (status 101, state intact); the engine must notice at the
     next synchronisation, give it more room and run the rest of its moves -- the caller sees a complete pass whose
