@@ -52,7 +52,11 @@ def assert_trees_match(tg: d.FlatTree, to: d.FlatTree, tol=1e-9, what=""):
     assert rel_close(tg.mut_t[finite], to.mut_t[finite], tol), "%s: mutation times differ" % what
 
 
-def assert_traces_match(trg, tro, tol=1e-9, what=""):
+def assert_traces_match(trg, tro, tol=1e-9, what="", abs_floor=0.0):
+    """`abs_floor`: what rounding alone may put between two evaluations of a log MH ratio whose TERMS are large: the cells a root part appends to its
+    coalescent grid get their population integral from the device's exp / expm1 on one side and glibc's on the other (one unit in the last place apart), and
+    under an exponential-growth model whose partial prior is -9e7 a tip displacement's ratio of -0.02 came out 6e-9 apart (scripts/fuzz_big_parts.py 6800,
+    case 445).  compare_part passes 16 units in the last place of the largest partial prior the part has held."""
     assert trg.shape == tro.shape, "%s: trace length %s vs %s" % (what, trg.shape, tro.shape)
     for i in range(trg.shape[0]):
         kg, ko = trg[i], tro[i]
@@ -62,7 +66,7 @@ def assert_traces_match(trg, tro, tol=1e-9, what=""):
         elif np.isinf(ko[3]):
             assert kg[3] == ko[3], "%s: move %d" % (what, i)
         else:
-            assert abs(kg[3] - ko[3]) <= tol * max(1.0, abs(ko[3])), "%s: move %d log_mh %r vs %r" % (what, i, kg[3], ko[3])
+            assert abs(kg[3] - ko[3]) <= tol * max(1.0, abs(ko[3])) + abs_floor, "%s: move %d log_mh %r vs %r" % (what, i, kg[3], ko[3])
 
 
 def compare_part(gpu, orc, p, num_nodes, trace, tol, expected_moves, totals_scale=(1.0, 1.0)):
@@ -73,7 +77,8 @@ def compare_part(gpu, orc, p, num_nodes, trace, tol, expected_moves, totals_scal
     1.7e21 = 262144 apart on the two sides, and the oracle's own recomputation is 104112 away from its own running value)."""
     sg, so = gpu.part_stats(p), orc.part_stats(p)
     assert sg["status"] == 0, "part %d device status %d: %s" % (p, sg["status"], gpu.last_error())
-    assert_traces_match(gpu.part_trace(p, trace), orc.part_trace(p, trace), tol, "part %d" % p)
+    assert_traces_match(gpu.part_trace(p, trace), orc.part_trace(p, trace), tol, "part %d" % p,
+                        abs_floor=16 * np.finfo(np.float64).eps * max(totals_scale[1], abs(float(orc.part_derived(p, num_nodes)[3]))))
     assert sg["moves_done"] == so["moves_done"] == expected_moves
     assert sg["proposed"] == so["proposed"] and sg["accepted"] == so["accepted"], "part %d counters %s vs %s" % (p, sg, so)
     assert sg["rng_draws"] == so["rng_draws"], "part %d rng draws %d vs %d" % (p, sg["rng_draws"], so["rng_draws"])
