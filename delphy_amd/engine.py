@@ -814,12 +814,17 @@ class EmatBackend:
         return counts[: n.value].copy()
 
     def part_coalescent(self, part: int, cap: int = 1 << 16):
-        n = C.c_int32(cap)
-        kb, kt, k, ps = np.zeros(cap), np.zeros(cap), np.zeros(cap), np.zeros(cap)
-        na = np.zeros(cap, np.int32)
-        tr, ts = C.c_double(), C.c_double()
-        self._ck(self._lib.emat_part_get_coalescent(self._h, part, C.byref(n), _ptr(kb, C.c_double), _ptr(kt, C.c_double), _ptr(k, C.c_double),
-                                                    _ptr(ps, C.c_double), _ptr(na, C.c_int32), C.byref(tr), C.byref(ts)), "emat_part_get_coalescent")
+        for _ in range(2):      # (a grid that outgrew `cap` -- a root that wandered for 100 000 moves over a fine grid -- reports its length: once more with that)
+            n = C.c_int32(cap)
+            kb, kt, k, ps = np.zeros(cap), np.zeros(cap), np.zeros(cap), np.zeros(cap)
+            na = np.zeros(cap, np.int32)
+            tr, ts = C.c_double(), C.c_double()
+            st = self._lib.emat_part_get_coalescent(self._h, part, C.byref(n), _ptr(kb, C.c_double), _ptr(kt, C.c_double), _ptr(k, C.c_double),
+                                                    _ptr(ps, C.c_double), _ptr(na, C.c_int32), C.byref(tr), C.byref(ts))
+            if st == 0 or n.value <= cap:
+                break
+            cap = n.value
+        self._ck(st, "emat_part_get_coalescent")
         m = n.value
         return dict(k_bar_p=kb[:m], k_twiddle_bar_p=kt[:m], k_twiddle_bar=k[:m], popsize_bar=ps[:m], num_active_parts=na[:m], t_ref=tr.value, t_step=ts.value)
 

@@ -203,8 +203,12 @@ class OracleEngine:
         return lam, nm, g.value, a.value
 
     def part_coalescent(self, part, cap=1 << 16):
-        n = C.c_int(cap); kb, kt, k, ps = np.zeros(cap), np.zeros(cap), np.zeros(cap), np.zeros(cap); na = np.zeros(cap, np.int32); tr, ts = C.c_double(), C.c_double()
-        self._ck(self.L.orc_part_get_coalescent(self.h, part, C.byref(n), _ptr(kb, C.c_double), _ptr(kt, C.c_double), _ptr(k, C.c_double), _ptr(ps, C.c_double), _ptr(na, C.c_int), C.byref(tr), C.byref(ts)), "part_get_coalescent")
+        for cap in (cap, cap << 5):     # (a grid longer than that: a root that wandered for 100 000 moves over a fine grid)
+            n = C.c_int(cap); kb, kt, k, ps = np.zeros(cap), np.zeros(cap), np.zeros(cap), np.zeros(cap); na = np.zeros(cap, np.int32); tr, ts = C.c_double(), C.c_double()
+            rc = self.L.orc_part_get_coalescent(self.h, part, C.byref(n), _ptr(kb, C.c_double), _ptr(kt, C.c_double), _ptr(k, C.c_double), _ptr(ps, C.c_double), _ptr(na, C.c_int), C.byref(tr), C.byref(ts))
+            if rc == 0:
+                break
+        self._ck(rc, "part_get_coalescent")
         m = n.value
         return dict(k_bar_p=kb[:m], k_twiddle_bar_p=kt[:m], k_twiddle_bar=k[:m], popsize_bar=ps[:m], num_active_parts=na[:m], t_ref=tr.value, t_step=ts.value)
 
