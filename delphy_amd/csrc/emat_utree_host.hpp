@@ -234,12 +234,13 @@ struct Builder {                                                    // utree.cpp
   Fitch fx; int cost_here = 0;                                       // ... and what attaching AT the focus would cost
   Sdv m_to_x; std::vector<std::pair<int32_t, uint8_t>> m_state;     // the new joint M: its deltas to the piece, and where it differs from the focus
   std::vector<uint64_t> heap64; std::vector<int> ties, cost_at, across;
+  std::vector<uint8_t> ref_mask, abs_mask;                           // per site: 1 << the reference's state; and the states the piece allows there, laid out once per search (best_arc)
   int give_up_after = 0; std::vector<int> dfs, component;
   long long n_pops = 0, n_crossed = 0, n_searches = 0;               // (EMAT_VERBOSE: arcs the searches expanded, arcs the focus crossed)
 
   Builder(const Tips& t, HostRng& g) : tips(t), rng(g) { T.init(t.n()); T.ref = *t.ref; setup(); }
   Builder(Tree&& tree, const Tips& t, HostRng& g) : tips(t), rng(g), T(std::move(tree)) { placed = T.n_tips; setup(); }
-  void setup() { L = (int)T.ref.size(); sqrt_6L = std::sqrt(6.0 * L); }
+  void setup() { L = (int)T.ref.size(); sqrt_6L = std::sqrt(6.0 * L); if (L >= (1 << 22)) throw std::runtime_error("the default builder's search keys hold costs below 2^22: genome too long"); ref_mask.resize((size_t)L); for (int l = 0; l < L; ++l) ref_mask[(size_t)l] = (uint8_t)(1u << T.ref[(size_t)l]); abs_mask.resize((size_t)L); }
   int new_inner() { return T.n_tips + T.n_inner++; }
   int slack(int cost) const { const double s = cost / sqrt_6L; return std::clamp((int)std::ceil(10.0 * s * (s + 5)), 2, L); }   // :267-271
   uint8_t focus_state(int site) const { const Sd* d = sd_find(T.ref_to_focus, site); return d ? d->to : T.ref[(size_t)site]; }
@@ -311,34 +312,77 @@ struct Builder {                                                    // utree.cpp
   std::pair<int, int> best_arc() {                                  // best-first over the arcs around the focus (:421-482); the focus stays where it is
     int best = cost_here; ties.clear(); ++n_searches;
     auto note = [&](int c, int a) { if (c < best) { best = c; ties.clear(); } if (c == best) ties.push_back(a); };
-    // one look at an arc's deltas gives both what attaching on it would save and how the cost changes across it (kept for when the arc
-    // is expanded); most arcs of a large tree carry no delta at all
-    auto price = [&](int a, int c_origin) {
-      int saved = 0, shift = 0;
-      for (const Sd& d : T.dl[(size_t)a]) { const bool f = fx.allows_abs(d.site, d.from, T.ref), t = fx.allows_abs(d.site, d.to, T.ref); saved += (!f && t); shift += (int)f - (int)t; }
-      across[(size_t)a] = shift;
-      return c_origin - saved;
-    };
+    // Fitch::allows_abs for every site at once: the mask of states the piece allows, in that function's order of precedence (anything where the piece
+    // has no data, else its two or three states, else its known state, else the state of the node that was the focus when the sets were made, else the
+    // reference's).  30 KB laid out once per search (a microsecond) instead of four binary searches per delta priced: the guide tree and the rebuilds,
+    // whose searches price many deltas, take half the time (20 000 tips of C4: 1.7 -> 0.9 s); the refinement's searches mostly cross arcs without deltas (- 10 %).
+    std::memcpy(abs_mask.data(), ref_mask.data(), (size_t)L);
+    for (const Sd& d : fx.then_focus) abs_mask[(size_t)d.site] = (uint8_t)(1u << d.to);
+    for (const Sd& d : fx.then_fixed) abs_mask[(size_t)d.site] = (uint8_t)(1u << d.to);
+    for (const auto& o : fx.open) abs_mask[(size_t)o.first] = o.second;
+    for (const auto& iv : fx.any) std::memset(abs_mask.data() + iv.first, 0xF, (size_t)(iv.second - iv.first));
+    const uint8_t* const am = abs_mask.data();
     if (cost_at.size() < T.adj.size()) cost_at.resize(T.adj.size());   // what attaching AT a node would cost, for the nodes the search has reached (a tree: each once)
     if (across.size() < T.tgt.size()) across.resize(T.tgt.size());
-    // the queue: (cost, arc) pairs in ascending order, as the reference's heap of pairs pops them -- every arc enters once, so the order of
-    // popping is the order of the keys whatever the container: one 64-bit key per entry
-    constexpr int64_t k_bias = 1 << 20;
-    auto key = [&](int c, int a) { return (uint64_t)((int64_t)c + k_bias) << 32 | (uint32_t)a; };
+    // The queue: (cost, arc) pairs in ascending order, as the reference's heap of pairs pops them -- every arc enters once, so the order of popping is
+    // the order of the keys whatever the container: one 64-bit key per entry, kept COMPLEMENTED so that the entry to pop is the largest.  While the
+    // frontier is small (it is ~ 100 entries on average at 20 000 tips) the entries are simply kept sorted, the next one at the back: a pop is a
+    // pop_back and a push a branch-free binary search + a short memmove, where a binary heap's pop is seven levels of unpredictable branches (measured:
+    // 3/4 of the refinement's time was this loop, ~ 160 cycles per pop).  A frontier that outgrows k_sorted_max turns into a heap for the rest of the
+    // search: an ascending array, reversed, is a max-heap.  And the loop is bound by the cache misses of reaching the arcs it expands, so a pop reads
+    // as little as it can and asks for it ahead of time: the low bits of a key carry what the pop needs to know about where its arc came from (below
+    // the bits that decide the order), the far end's three slots are asked for when an arc is queued, the deltas of the arcs beyond when it is next in
+    // line.  Together: 60 000 tips of C4 in 151-161 s instead of 212-216 (same tree, digest for digest: scripts/default_builder_probe.py).
+    constexpr int64_t k_bias = 1 << 21;
+#ifndef EMAT_UT_SORTED_MAX           // (-DEMAT_UT_SORTED_MAX=3 -DEMAT_UT_CARRY_BIAS=1 -DEMAT_UT_CARRY_NONE=3: a test build in which small inputs take the heap and the fall-back too)
+#define EMAT_UT_SORTED_MAX 384
+#define EMAT_UT_CARRY_BIAS 128
+#define EMAT_UT_CARRY_NONE 511
+#endif
+    constexpr size_t k_sorted_max = EMAT_UT_SORTED_MAX;
+    constexpr int k_carry_bias = EMAT_UT_CARRY_BIAS, k_carry_none = EMAT_UT_CARRY_NONE;   // low 9 bits of a key: (cost AT the arc's far end) - (cost ON the arc) + 128, so that a pop reads nothing about where its arc came from; 511: does not fit, cost_at / across hold it
+    auto key = [&](int c, int a, int carry) { return ~((uint64_t)((int64_t)c + k_bias) << 41 | (uint64_t)(uint32_t)a << 9 | (uint64_t)carry); };
+    // one look at an arc's deltas gives both what attaching on it would save and how the cost changes across it; most arcs of a large tree carry no delta at all
+    auto reach = [&](int a, int origin, int c_origin) {
+      int saved = 0, shift = 0;
+      for (const Sd& d : T.dl[(size_t)a]) { const unsigned m = am[(size_t)d.site]; const bool f = (m >> d.from) & 1u, t = (m >> d.to) & 1u; saved += (!f && t); shift += (int)f - (int)t; }
+      const int c = c_origin - saved;
+      note(c, a);
+      int carry = saved + shift + k_carry_bias;
+      if (carry < 0 || carry >= k_carry_none) { carry = k_carry_none; cost_at[(size_t)origin] = c_origin; across[(size_t)a] = shift; }
+      __builtin_prefetch(&T.adj[(size_t)T.tgt[(size_t)a]]);
+      return key(c, a, carry);
+    };
     heap64.clear();
-    const auto later = std::greater<uint64_t>{};
-    cost_at[(size_t)T.focus] = cost_here;
-    for (int a : T.adj[(size_t)T.focus]) if (a != k_none) { const int c = price(a, cost_here); note(c, a); heap64.push_back(key(c, a)); }
-    std::make_heap(heap64.begin(), heap64.end(), later);
+    bool sorted_mode = true;
+    int thr_of = std::numeric_limits<int>::min(), thr = 0;
+    auto push = [&](uint64_t k) {
+      if (sorted_mode) {
+        if (heap64.size() < k_sorted_max) {
+          const size_t n = heap64.size(); heap64.push_back(k);
+          uint64_t* const p = heap64.data(); size_t lo = 0, len = n;           // first position whose entry is > k (none is equal)
+          while (len > 0) { const size_t half = len >> 1; const bool go = p[lo + half] < k; lo = go ? lo + half + 1 : lo; len = go ? len - half - 1 : half; }
+          std::memmove(p + lo + 1, p + lo, (n - lo) * sizeof(uint64_t)); p[lo] = k;
+          return;
+        }
+        std::reverse(heap64.begin(), heap64.end()); sorted_mode = false;
+      }
+      heap64.push_back(k); std::push_heap(heap64.begin(), heap64.end());
+    };
+    auto pop = [&]() { if (!sorted_mode) std::pop_heap(heap64.begin(), heap64.end()); const uint64_t k = ~heap64.back(); heap64.pop_back(); return k; };
+    for (int a : T.adj[(size_t)T.focus]) if (a != k_none) push(reach(a, T.focus, cost_here));
     while (!heap64.empty()) {
-      std::pop_heap(heap64.begin(), heap64.end(), later);
-      const uint64_t top = heap64.back(); heap64.pop_back(); ++n_pops;
-      const int c_in = (int)((int64_t)(top >> 32) - k_bias), a_in = (int)(uint32_t)top;
-      if (c_in > best + slack(best)) break;
-      const int c_v = cost_at[(size_t)T.from(a_in)] + across[(size_t)a_in];
+      const uint64_t top = pop(); ++n_pops;
+      if (!heap64.empty()) {   // (what is next in line now is most likely the next one popped: its far end's slots were asked for when it was queued; now the deltas beyond)
+        const int v2 = T.tgt[(size_t)(uint32_t)(~(sorted_mode ? heap64.back() : heap64.front()) >> 9)];
+        for (int a : T.adj[(size_t)v2]) if (a != k_none) __builtin_prefetch(&T.dl[(size_t)a]);
+      }
+      const int c_in = (int)((int64_t)(top >> 41) - k_bias), a_in = (int)(uint32_t)(top >> 9), carry = (int)(top & 511u);
+      if (best != thr_of) { thr_of = best; thr = best + slack(best); }   // (a division and a ceil(): once per improvement, not once per pop)
+      if (c_in > thr) break;
+      const int c_v = carry != k_carry_none ? c_in + carry - k_carry_bias : cost_at[(size_t)T.from(a_in)] + across[(size_t)a_in];
       const int v = T.to(a_in);
-      cost_at[(size_t)v] = c_v;
-      for (int a : T.adj[(size_t)v]) if (a != k_none && a != Tree::mate(a_in)) { const int c = price(a, c_v); note(c, a); heap64.push_back(key(c, a)); std::push_heap(heap64.begin(), heap64.end(), later); }
+      for (int a : T.adj[(size_t)v]) if (a != k_none && a != Tree::mate(a_in)) push(reach(a, v, c_v));
     }
     if (ties.empty()) return {k_none, best};
     return {ties[(size_t)(((unsigned __int128)rng.next64() * (uint64_t)ties.size()) >> 64)], best};
